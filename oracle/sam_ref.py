@@ -1,0 +1,426 @@
+"""CPU oracle for the SAM arithmetic on micro_sam's hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product (``micro_sam_amd``) never does.
+
+What it restates
+----------------
+micro_sam has no model arithmetic of its own: ``micro_sam/util.py:435-441`` builds the model through
+``segment_anything.sam_model_registry`` (un-vendored third party, ``setup.cfg:58`` — *unpinned*, i.e.
+PyPI ``segment-anything`` 1.0) with the hyper-parameters of ``micro_sam/models/build_sam.py:87-142``.
+This file restates the published v1.0 algorithm of that package, functionally over an upstream-named
+``state_dict`` (names: SURVEY.md Appendix C; evidence inside the reference at
+``micro_sam/models/build_sam.py:26`` and ``micro_sam/util.py:578-598``):
+
+* ``image_encoder``      ViT with 14x14 windowed + global attention and decomposed relative position
+                         bias, LayerNorm eps 1e-6, exact GELU; neck conv1x1 -> LN2d -> conv3x3 -> LN2d.
+* ``prompt_encoder``     random-Fourier positional encoding of points / boxes, mask down-scaling.
+* ``mask_decoder``       two-way transformer (depth 2, 8 heads, down-sample 2, LN eps 1e-5), transposed-conv
+                         up-scaling, hyper-network mask product, IoU head.
+* ``preprocess`` / ``postprocess_masks`` (``Sam``) and ``ResizeLongestSide``.
+
+Parity pinning: the reference ships no golden tensors for this arithmetic.  The
+restatement is pinned against ``transformers.models.sam`` (same network, present in the build
+container) by ``tests/test_oracle_vs_hf.py`` (weights copied through the Appendix-C key map; the HF
+two-way-block LayerNorm eps is forced to upstream's 1e-5) and, for the integer post-processing, against
+the reference's own known-answer tests (``tests/test_oracle_amg.py``).
+
+Precision modes
+---------------
+``precision="fp32"``  strict fp32 (the reference CPU path).
+``precision="bf16"``  emulates the rounding points of the HIP pipeline (config 2 of BASELINE.json,
+                      "vit_b bf16"): every matrix-product operand is rounded to bfloat16, products are
+                      accumulated in fp32, everything else (LayerNorm, softmax, GELU, bias, residuals)
+                      stays fp32.  Tensors the HIP path *stores* in bf16 are rounded at the same place.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# Hyper-parameters, micro_sam/models/build_sam.py:40-84
+VIT_CONFIGS = {
+    "vit_b": dict(embed_dim=768, depth=12, num_heads=12, global_attn_indexes=(2, 5, 8, 11)),
+    "vit_l": dict(embed_dim=1024, depth=24, num_heads=16, global_attn_indexes=(5, 11, 17, 23)),
+    "vit_h": dict(embed_dim=1280, depth=32, num_heads=16, global_attn_indexes=(7, 15, 23, 31)),
+}
+IMG_SIZE = 1024          # build_sam.py:94
+PATCH = 16               # build_sam.py:97
+GRID = IMG_SIZE // PATCH  # 64
+WINDOW = 14              # build_sam.py:111
+PROMPT_DIM = 256         # build_sam.py:96
+PIXEL_MEAN = (123.675, 116.28, 103.53)   # build_sam.py:132
+PIXEL_STD = (58.395, 57.12, 57.375)      # build_sam.py:133
+
+
+class Prec:
+    """Rounding policy (see module docstring)."""
+
+    def __init__(self, precision: str = "fp32"):
+        assert precision in ("fp32", "bf16"), precision
+        self.bf16 = precision == "bf16"
+
+    def r(self, x: Tensor) -> Tensor:
+        """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode."""
+        return x.to(torch.bfloat16).to(torch.float32) if self.bf16 else x
+
+    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+        y = F.linear(self.r(x), self.r(w))
+        return y if b is None else y + b
+
+    def matmul(self, a: Tensor, b: Tensor) -> Tensor:
+        return torch.matmul(self.r(a), self.r(b))
+
+
+# ----------------------------------------------------------------------------------------------
+# Pre / post processing (upstream Sam.preprocess / postprocess_masks, ResizeLongestSide)
+# ----------------------------------------------------------------------------------------------
+
+def get_preprocess_shape(oldh: int, oldw: int, long_side: int = IMG_SIZE) -> Tuple[int, int]:
+    """ResizeLongestSide.get_preprocess_shape."""
+    scale = long_side * 1.0 / max(oldh, oldw)
+    newh, neww = oldh * scale, oldw * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def apply_image(image: np.ndarray) -> np.ndarray:
+    """ResizeLongestSide.apply_image: uint8 HWC -> PIL bilinear resize so that the long side is 1024.
+
+    Called by the reference at micro_sam/util.py:663 and through set_image (util.py:916)."""
+    from PIL import Image
+    h, w = image.shape[:2]
+    newh, neww = get_preprocess_shape(h, w)
+    if (newh, neww) == (h, w):
+        return np.array(image)
+    # torchvision's to_pil_image + resize((h, w)) == PIL BILINEAR with size=(w, h)
+    return np.array(Image.fromarray(image).resize((neww, newh), Image.BILINEAR))
+
+
+def apply_coords(coords: np.ndarray, original_size: Tuple[int, int]) -> np.ndarray:
+    """ResizeLongestSide.apply_coords (used at instance_segmentation.py:358)."""
+    old_h, old_w = original_size
+    new_h, new_w = get_preprocess_shape(old_h, old_w)
+    coords = np.array(coords, dtype=float, copy=True)
+    coords[..., 0] = coords[..., 0] * (new_w / old_w)
+    coords[..., 1] = coords[..., 1] * (new_h / old_h)
+    return coords
+
+
+def apply_boxes(boxes: np.ndarray, original_size: Tuple[int, int]) -> np.ndarray:
+    return apply_coords(np.asarray(boxes).reshape(-1, 2, 2), original_size).reshape(-1, 4)
+
+
+def preprocess(x: Tensor) -> Tensor:
+    """Sam.preprocess: normalise with pixel mean/std and zero-pad bottom/right to 1024 (util.py:670)."""
+    mean = torch.tensor(PIXEL_MEAN, dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    std = torch.tensor(PIXEL_STD, dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    x = (x.to(torch.float32) - mean) / std
+    h, w = x.shape[-2:]
+    return F.pad(x, (0, IMG_SIZE - w, 0, IMG_SIZE - h))
+
+
+def postprocess_masks(masks: Tensor, input_size: Tuple[int, int], original_size: Tuple[int, int]) -> Tensor:
+    """Sam.postprocess_masks: x4 bilinear to 1024^2, crop the padding, bilinear to the original size."""
+    masks = F.interpolate(masks, (IMG_SIZE, IMG_SIZE), mode="bilinear", align_corners=False)
+    masks = masks[..., : input_size[0], : input_size[1]]
+    masks = F.interpolate(masks, tuple(original_size), mode="bilinear", align_corners=False)
+    return masks
+
+
+# ----------------------------------------------------------------------------------------------
+# Image encoder (upstream modeling/image_encoder.py)
+# ----------------------------------------------------------------------------------------------
+
+def _get_rel_pos(q_size: int, k_size: int, rel_pos: Tensor) -> Tensor:
+    max_rel_dist = int(2 * max(q_size, k_size) - 1)
+    if rel_pos.shape[0] != max_rel_dist:
+        rel_pos_resized = F.interpolate(
+            rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=max_rel_dist, mode="linear",
+        )
+        rel_pos_resized = rel_pos_resized.reshape(-1, max_rel_dist).permute(1, 0)
+    else:
+        rel_pos_resized = rel_pos
+    q_coords = torch.arange(q_size)[:, None] * max(k_size / q_size, 1.0)
+    k_coords = torch.arange(k_size)[None, :] * max(q_size / k_size, 1.0)
+    relative_coords = (q_coords - k_coords) + (k_size - 1) * max(q_size / k_size, 1.0)
+    return rel_pos_resized[relative_coords.long()]
+
+
+def _attention_relpos(sd: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int, p: Prec) -> Tensor:
+    """Attention with decomposed rel-pos on a [B', S, S, D] window/global grid."""
+    Bp, H, W, D = x.shape
+    hd = D // num_heads
+    scale = hd ** -0.5
+    qkv = p.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = p.r(qkv)  # HIP path stores q, k, v in bf16
+    qkv = qkv.reshape(Bp, H * W, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.reshape(3, Bp * num_heads, H * W, hd).unbind(0)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    Rh = _get_rel_pos(H, H, p.r(sd[pre + "rel_pos_h"]))
+    Rw = _get_rel_pos(W, W, p.r(sd[pre + "rel_pos_w"]))
+    r_q = q.reshape(Bp * num_heads, H, W, hd)      # NB: unscaled q (upstream behaviour)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", r_q, Rh)
+    rel_w = torch.einsum("bhwc,wkc->bhwk", r_q, Rw)
+    attn = (attn.view(-1, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(-1, H * W, H * W)
+    if p.bf16:
+        # flash-style: unnormalised probabilities rounded to bf16, fp32 row sum of the unrounded values
+        m = attn.max(dim=-1, keepdim=True).values
+        e = torch.exp(attn - m)
+        o = (p.r(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        o = attn.softmax(dim=-1) @ v
+    o = o.view(Bp, num_heads, H, W, hd).permute(0, 2, 3, 1, 4).reshape(Bp, H, W, D)
+    return p.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+
+
+def _window_partition(x: Tensor, ws: int):
+    B, H, W, C = x.shape
+    pad_h = (ws - H % ws) % ws
+    pad_w = (ws - W % ws) % ws
+    if pad_h or pad_w:
+        x = F.pad(x, (0, 0, 0, pad_w, 0, pad_h))
+    Hp, Wp = H + pad_h, W + pad_w
+    x = x.view(B, Hp // ws, ws, Wp // ws, ws, C)
+    windows = x.permute(0, 1, 3, 2, 4, 5).contiguous().view(-1, ws, ws, C)
+    return windows, (Hp, Wp)
+
+
+def _window_unpartition(windows: Tensor, ws: int, pad_hw, hw):
+    Hp, Wp = pad_hw
+    H, W = hw
+    B = windows.shape[0] // (Hp * Wp // ws // ws)
+    x = windows.view(B, Hp // ws, Wp // ws, ws, ws, -1)
+    x = x.permute(0, 1, 3, 2, 4, 5).contiguous().view(B, Hp, Wp, -1)
+    return x[:, :H, :W, :].contiguous()
+
+
+def layer_norm_2d(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
+    """LayerNorm2d (upstream modeling/common.py): normalise over the channel dim of NCHW."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return w[:, None, None] * x + b[:, None, None]
+
+
+def image_encoder(sd: Dict[str, Tensor], x: Tensor, model_type: str = "vit_b", precision: str = "fp32",
+                  return_blocks: bool = False):
+    """ImageEncoderViT.forward: [B,3,1024,1024] normalised -> [B,256,64,64].  Keys prefixed 'image_encoder.'."""
+    cfg = VIT_CONFIGS[model_type[:5]]
+    p = Prec(precision)
+    pre = "image_encoder."
+    D, heads = cfg["embed_dim"], cfg["num_heads"]
+    w = sd[pre + "patch_embed.proj.weight"]
+    x = F.conv2d(p.r(x), p.r(w), None, stride=PATCH) + sd[pre + "patch_embed.proj.bias"].view(1, -1, 1, 1)
+    x = x.permute(0, 2, 3, 1)                                  # NHWC [B,64,64,D]
+    x = x + sd[pre + "pos_embed"]
+    taps = []
+    for i in range(cfg["depth"]):
+        bp = f"{pre}blocks.{i}."
+        shortcut = x
+        y = F.layer_norm(x, (D,), sd[bp + "norm1.weight"], sd[bp + "norm1.bias"], eps=1e-6)
+        if i in cfg["global_attn_indexes"]:
+            y = _attention_relpos(sd, bp + "attn.", y, heads, p)
+        else:
+            H, W = y.shape[1:3]
+            y, pad_hw = _window_partition(y, WINDOW)
+            y = _attention_relpos(sd, bp + "attn.", y, heads, p)
+            y = _window_unpartition(y, WINDOW, pad_hw, (H, W))
+        x = shortcut + y
+        y = F.layer_norm(x, (D,), sd[bp + "norm2.weight"], sd[bp + "norm2.bias"], eps=1e-6)
+        y = p.linear(y, sd[bp + "mlp.lin1.weight"], sd[bp + "mlp.lin1.bias"])
+        y = F.gelu(y)                                          # exact erf GELU
+        y = p.linear(y, sd[bp + "mlp.lin2.weight"], sd[bp + "mlp.lin2.bias"])
+        x = x + y
+        if return_blocks:
+            taps.append(x.clone())
+    x = x.permute(0, 3, 1, 2)                                  # NCHW
+    x = F.conv2d(p.r(x), p.r(sd[pre + "neck.0.weight"]))
+    x = layer_norm_2d(x, sd[pre + "neck.1.weight"], sd[pre + "neck.1.bias"])
+    x = F.conv2d(p.r(x), p.r(sd[pre + "neck.2.weight"]), padding=1)
+    x = layer_norm_2d(x, sd[pre + "neck.3.weight"], sd[pre + "neck.3.bias"])
+    return (x, taps) if return_blocks else x
+
+
+# ----------------------------------------------------------------------------------------------
+# Prompt encoder (upstream modeling/prompt_encoder.py)
+# ----------------------------------------------------------------------------------------------
+
+def _pe_encoding(G: Tensor, coords: Tensor) -> Tensor:
+    """PositionEmbeddingRandom._pe_encoding: coords in [0,1]^2 -> 256-d."""
+    coords = 2 * coords - 1
+    coords = coords @ G
+    coords = 2 * np.pi * coords
+    return torch.cat([torch.sin(coords), torch.cos(coords)], dim=-1)
+
+
+def get_dense_pe(sd: Dict[str, Tensor]) -> Tensor:
+    """PromptEncoder.get_dense_pe: [1,256,64,64]."""
+    G = sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"]
+    grid = torch.ones((GRID, GRID), dtype=torch.float32, device=G.device)
+    y_embed = (grid.cumsum(dim=0) - 0.5) / GRID
+    x_embed = (grid.cumsum(dim=1) - 0.5) / GRID
+    pe = _pe_encoding(G, torch.stack([x_embed, y_embed], dim=-1))
+    return pe.permute(2, 0, 1).unsqueeze(0)
+
+
+def prompt_encoder(sd: Dict[str, Tensor], points: Optional[Tuple[Tensor, Tensor]], boxes: Optional[Tensor],
+                   masks: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+    """PromptEncoder.forward -> (sparse [B,N,256], dense [B,256,64,64])."""
+    pre = "prompt_encoder."
+    G = sd[pre + "pe_layer.positional_encoding_gaussian_matrix"]
+    dev = G.device
+    if points is not None:
+        bs = points[0].shape[0]
+    elif boxes is not None:
+        bs = boxes.shape[0]
+    elif masks is not None:
+        bs = masks.shape[0]
+    else:
+        bs = 1
+    sparse = torch.empty((bs, 0, PROMPT_DIM), device=dev)
+    if points is not None:
+        coords, labels = points
+        coords = coords.to(torch.float32) + 0.5
+        if boxes is None:
+            coords = torch.cat([coords, torch.zeros((bs, 1, 2), device=dev)], dim=1)
+            labels = torch.cat([labels, -torch.ones((bs, 1), device=dev, dtype=labels.dtype)], dim=1)
+        norm = coords.clone()
+        norm[:, :, 0] = norm[:, :, 0] / IMG_SIZE
+        norm[:, :, 1] = norm[:, :, 1] / IMG_SIZE
+        e = _pe_encoding(G, norm)
+        e[labels == -1] = 0.0
+        e[labels == -1] += sd[pre + "not_a_point_embed.weight"]
+        e[labels == 0] += sd[pre + "point_embeddings.0.weight"]
+        e[labels == 1] += sd[pre + "point_embeddings.1.weight"]
+        sparse = torch.cat([sparse, e], dim=1)
+    if boxes is not None:
+        b = boxes.to(torch.float32) + 0.5
+        c = b.reshape(-1, 2, 2).clone()
+        c[:, :, 0] = c[:, :, 0] / IMG_SIZE
+        c[:, :, 1] = c[:, :, 1] / IMG_SIZE
+        e = _pe_encoding(G, c)
+        e[:, 0, :] += sd[pre + "point_embeddings.2.weight"][0]
+        e[:, 1, :] += sd[pre + "point_embeddings.3.weight"][0]
+        sparse = torch.cat([sparse, e], dim=1)
+    if masks is not None:
+        m = F.conv2d(masks, sd[pre + "mask_downscaling.0.weight"], sd[pre + "mask_downscaling.0.bias"], stride=2)
+        m = F.gelu(layer_norm_2d(m, sd[pre + "mask_downscaling.1.weight"], sd[pre + "mask_downscaling.1.bias"]))
+        m = F.conv2d(m, sd[pre + "mask_downscaling.3.weight"], sd[pre + "mask_downscaling.3.bias"], stride=2)
+        m = F.gelu(layer_norm_2d(m, sd[pre + "mask_downscaling.4.weight"], sd[pre + "mask_downscaling.4.bias"]))
+        dense = F.conv2d(m, sd[pre + "mask_downscaling.6.weight"], sd[pre + "mask_downscaling.6.bias"])
+    else:
+        dense = sd[pre + "no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(bs, -1, GRID, GRID)
+    return sparse, dense
+
+
+# ----------------------------------------------------------------------------------------------
+# Mask decoder (upstream modeling/mask_decoder.py + transformer.py)
+# ----------------------------------------------------------------------------------------------
+
+def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads: int = 8) -> Tensor:
+    q = p.linear(q, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"])
+    k = p.linear(k, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"])
+    v = p.linear(v, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"])
+    q, k, v = p.r(q), p.r(k), p.r(v)   # HIP path stores the projected q/k/v in bf16
+    b, nq, c = q.shape
+    def sep(t):
+        return t.reshape(b, t.shape[1], heads, c // heads).transpose(1, 2)
+    q, k, v = sep(q), sep(k), sep(v)
+    attn = (q @ k.transpose(-2, -1)) / math.sqrt(c // heads)
+    attn = torch.softmax(attn, dim=-1)
+    out = attn @ v
+    out = out.transpose(1, 2).reshape(b, nq, c)
+    return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+
+
+def _ln(sd, pre: str, x: Tensor, eps: float = 1e-5) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[pre + "weight"], sd[pre + "bias"], eps=eps)
+
+
+def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_embedding: Tensor, p: Prec):
+    pre = "mask_decoder.transformer."
+    bs, c, h, w = image_embedding.shape
+    keys = image_embedding.flatten(2).permute(0, 2, 1)
+    key_pe = image_pe.flatten(2).permute(0, 2, 1)
+    queries = point_embedding
+    query_pe = point_embedding
+    keys = p.r(keys)  # HIP path keeps the image-token stream in bf16
+    for i in range(2):
+        lp = f"{pre}layers.{i}."
+        if i == 0:
+            queries = _dec_attention(sd, lp + "self_attn.", queries, queries, queries, p)
+        else:
+            q = queries + query_pe
+            queries = queries + _dec_attention(sd, lp + "self_attn.", q, q, queries, p)
+        queries = _ln(sd, lp + "norm1.", queries)
+        q = queries + query_pe
+        k = keys + key_pe
+        queries = queries + _dec_attention(sd, lp + "cross_attn_token_to_image.", q, k, keys, p)
+        queries = _ln(sd, lp + "norm2.", queries)
+        m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"])
+        m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"])
+        queries = _ln(sd, lp + "norm3.", queries + m)
+        q = queries + query_pe
+        k = keys + key_pe
+        keys = keys + _dec_attention(sd, lp + "cross_attn_image_to_token.", k, q, queries, p)
+        keys = p.r(_ln(sd, lp + "norm4.", keys))
+    q = queries + query_pe
+    k = keys + key_pe
+    queries = queries + _dec_attention(sd, pre + "final_attn_token_to_image.", q, k, keys, p)
+    queries = _ln(sd, pre + "norm_final_attn.", queries)
+    return queries, keys
+
+
+def _mlp3(sd, pre: str, x: Tensor, p: Prec) -> Tensor:
+    x = F.relu(p.linear(x, sd[pre + "layers.0.weight"], sd[pre + "layers.0.bias"]))
+    x = F.relu(p.linear(x, sd[pre + "layers.1.weight"], sd[pre + "layers.1.bias"]))
+    return p.linear(x, sd[pre + "layers.2.weight"], sd[pre + "layers.2.bias"])
+
+
+def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor, dense: Tensor,
+                 multimask_output: bool, precision: str = "fp32") -> Tuple[Tensor, Tensor]:
+    """MaskDecoder.forward -> (low-res masks [B,C,256,256], iou [B,C])."""
+    p = Prec(precision)
+    pre = "mask_decoder."
+    output_tokens = torch.cat([sd[pre + "iou_token.weight"], sd[pre + "mask_tokens.weight"]], dim=0)
+    output_tokens = output_tokens.unsqueeze(0).expand(sparse.size(0), -1, -1)
+    tokens = torch.cat((output_tokens, sparse), dim=1)
+    src = torch.repeat_interleave(image_embeddings, tokens.shape[0], dim=0)
+    src = src + dense
+    pos_src = torch.repeat_interleave(image_pe, tokens.shape[0], dim=0)
+    b, c, h, w = src.shape
+    hs, src = two_way_transformer(sd, src, pos_src, tokens, p)
+    iou_token_out = hs[:, 0, :]
+    mask_tokens_out = hs[:, 1:5, :]
+    src = src.transpose(1, 2).view(b, c, h, w)
+    up = F.conv_transpose2d(p.r(src), p.r(sd[pre + "output_upscaling.0.weight"]), None, stride=2)
+    up = up + sd[pre + "output_upscaling.0.bias"].view(1, -1, 1, 1)
+    up = F.gelu(layer_norm_2d(up, sd[pre + "output_upscaling.1.weight"], sd[pre + "output_upscaling.1.bias"]))
+    up = F.conv_transpose2d(p.r(up), p.r(sd[pre + "output_upscaling.3.weight"]), None, stride=2)
+    up = F.gelu(up + sd[pre + "output_upscaling.3.bias"].view(1, -1, 1, 1))
+    hyper = torch.stack(
+        [_mlp3(sd, f"{pre}output_hypernetworks_mlps.{i}.", mask_tokens_out[:, i, :], p) for i in range(4)], dim=1)
+    b, c, h, w = up.shape
+    masks = (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)   # fp32 product in both modes
+    iou = _mlp3(sd, pre + "iou_prediction_head.", iou_token_out, p)
+    sl = slice(1, None) if multimask_output else slice(0, 1)
+    return masks[:, sl, :, :], iou[:, sl]
+
+
+def predict_torch(sd, features: Tensor, input_size, original_size, point_coords: Optional[Tensor],
+                  point_labels: Optional[Tensor], boxes: Optional[Tensor] = None, mask_input: Optional[Tensor] = None,
+                  multimask_output: bool = True, return_logits: bool = False, precision: str = "fp32"):
+    """SamPredictor.predict_torch -> (masks, iou, low_res)."""
+    points = (point_coords, point_labels) if point_coords is not None else None
+    sparse, dense = prompt_encoder(sd, points, boxes, mask_input)
+    low_res, iou = mask_decoder(sd, features, get_dense_pe(sd), sparse, dense, multimask_output, precision)
+    masks = postprocess_masks(low_res, input_size, original_size)
+    if not return_logits:
+        masks = masks > 0.0
+    return masks, iou, low_res

@@ -1,0 +1,99 @@
+"""Pin the integer post-processing oracle against the reference's known-answer tests."""
+import numpy as np
+import torch
+
+from oracle import amg_ref as A
+
+
+def test_batched_mask_to_box_known_answer():
+    # reference: test/test_vendored.py:12-25
+    mask = np.zeros((10, 10), dtype=bool)
+    mask[7:9, 3:5] = True
+    box = A.batched_mask_to_box(torch.as_tensor(mask))
+    assert box.tolist() == [3, 7, 4, 8]
+    assert A.batched_mask_to_box(torch.zeros(2, 5, 5, dtype=torch.bool)).tolist() == [[0, 0, 0, 0]] * 2
+
+
+def _rle_python(mask_1d):
+    counts, val, cnt = ([] if mask_1d[0] == 0 else [0]), mask_1d[0], 0
+    for m in mask_1d:
+        if m == val:
+            cnt += 1
+        else:
+            counts.append(cnt); val = m; cnt = 1
+    counts.append(cnt)
+    return counts
+
+
+def _random_shapes(rng, shape, n):
+    h, w = shape
+    out = np.zeros((n,) + shape, dtype=bool)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(n):
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(4, 40)
+        if i % 2 == 0:
+            out[i] = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        else:
+            out[i, max(cy - r, 0):cy + r, max(cx - r, 0):cx + r] = True
+    return out
+
+
+def test_rle_matches_independent_restatement_and_sums():
+    # reference: test/test_vendored.py:63-78 (shape 128x256, 6 random shapes; sum(counts) == H*W; == upstream)
+    rng = np.random.default_rng(0)
+    masks = _random_shapes(rng, (128, 256), 6)
+    masks[0, 0, 0] = True   # a mask that starts with 1 -> counts start with 0
+    rles = A.mask_to_rle(torch.from_numpy(masks))
+    for m, rle in zip(masks, rles):
+        assert rle["size"] == [128, 256]
+        assert sum(rle["counts"]) == 128 * 256
+        assert rle["counts"] == _rle_python(m.T.reshape(-1))
+        assert np.array_equal(A.rle_to_mask(rle), m)
+        assert A.area_from_rle(rle) == int(m.sum())
+
+
+def test_nms_known_cases():
+    boxes = torch.tensor([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10]], dtype=torch.float)
+    scores = torch.tensor([0.9, 0.95, 0.5, 0.9])
+    keep = A.nms(boxes, scores, 0.5)
+    assert keep.tolist() == [1, 2]          # box 0 and 3 overlap box 1 with IoU 0.68
+    keep = A.nms(boxes, scores, 0.7)
+    assert keep.tolist() == [1, 0, 2]       # equal boxes 0/3: the first (stable order) wins
+
+
+def test_point_grid_and_crop_boxes():
+    g = A.build_all_layer_point_grids(32, 0, 1)[0]
+    assert g.shape == (1024, 2)
+    assert np.allclose(g[0], [1 / 64, 1 / 64]) and np.allclose(g[33], [3 / 64, 3 / 64])
+    boxes, layers = A.generate_crop_boxes((480, 640), 0, 512 / 1500)
+    assert boxes == [[0, 0, 640, 480]] and layers == [0]
+
+
+def test_label_components_and_segmentation_merge():
+    seg = np.zeros((8, 8), dtype="uint32")
+    seg[0:2, 0:2] = 5
+    seg[0:2, 2:4] = 7          # touches the first region but has another value -> separate component
+    seg[5:8, 5:8] = 5          # same value, disconnected -> separate component
+    lab = A.label_components(seg)
+    assert lab[0, 0] == 1 and lab[0, 2] == 2 and lab[6, 6] == 3 and lab[4, 4] == 0
+    m1 = np.zeros((8, 8), bool); m1[0:4, 0:4] = True
+    m2 = np.zeros((8, 8), bool); m2[1:3, 1:3] = True
+    masks = [{"segmentation": m1, "area": 16}, {"segmentation": m2, "area": 4}]
+    out = A.mask_data_to_segmentation(masks, shape=(8, 8), with_background=True, merge_exclusively=False)
+    # background (0, 48 px) is the largest -> removed (stays 0); ring of m1 -> 1, m2 -> 2
+    assert out.dtype == np.uint32 and out.max() == 2 and out[0, 0] == 1 and out[1, 1] == 2 and out[7, 7] == 0
+
+
+def test_to_image_matches_reference_formula():
+    rng = np.random.default_rng(0)
+    x = rng.random((64, 48)).astype("float64") * 1000
+    y = A.to_image(x)
+    assert y.shape == (64, 48, 3) and y.dtype == np.uint8
+    xf = x.astype("float32"); xf = xf - xf.min(); xf = xf / (xf.max() + 1e-7)
+    assert np.array_equal(y[..., 0], (xf * 255).astype("uint8"))
+    assert y.max() == 254 or y.max() == 255
+
+
+def test_stability_score():
+    m = torch.tensor([[[2.0, 0.5], [-0.5, -2.0]]])
+    assert abs(A.calculate_stability_score(m, 0.0, 1.0).item() - 1 / 3) < 1e-7
