@@ -1,0 +1,190 @@
+/*
+ * msam_hip.h - C ABI of libmsam_hip.so, the MI355X (gfx950) SAM inference core behind micro_sam's
+ * SamPredictor boundary.
+ *
+ * The reference has no FFI: its seam is the duck-typed `SamPredictor` returned by
+ * `micro_sam.util.get_sam_model` (micro_sam/util.py:318-476).  Every entry point below names the reference
+ * call it stands behind.  Conventions:
+ *   - plain C: pointers + sizes, no torch / C++ types.  All `void*` / `float*` buffers are DEVICE pointers
+ *     owned by the caller; the library never allocates user-visible memory (workspace is caller-provided,
+ *     sized by the *_workspace_bytes queries).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous.
+ *   - return 0 on success, non-zero on error; msam_last_error() returns a static message.
+ *     The Python shim (micro_sam_amd/_lib.py) raises ValueError / RuntimeError from it.
+ *   - not re-entrant per model object (the reference's predictor is a stateful singleton,
+ *     micro_sam/sam_annotator/_state.py:41-47); safe from any single host thread.
+ */
+#ifndef MSAM_HIP_H
+#define MSAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSAM_MAX_BLOCKS 32
+#define MSAM_F32 1
+#define MSAM_BF16 2
+#define MSAM_ACT_NONE 0
+#define MSAM_ACT_GELU 1
+#define MSAM_ACT_RELU 2
+
+const char* msam_last_error(void);
+int msam_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Building-block operators (each is what a torch op does inside segment_anything's modules; exported so
+ * that tests can pin every kernel against the oracle separately).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* out = act(A[M,K] * W[N,K]^T + bias + table + resid); bf16 operands, fp32 accumulate (MFMA).
+ * Replaces torch.nn.Linear / 1x1 conv / patch-embed conv / transposed-conv GEMMs of the reference model. */
+typedef struct {
+    const void* A; int64_t lda;          /* bf16 [M,K], row stride lda (elements) */
+    const void* W; int64_t ldw;          /* bf16 [N,K] (torch Linear weight layout) */
+    int32_t M, N, K;                     /* N % 128 == 0, K % 64 == 0 */
+    const float* bias;                   /* [N] or NULL */
+    const float* table;                  /* optional additive table, indexed [(row % table_rows)*table_ld + n] */
+    int32_t table_rows, table_cols;      /* applied to columns n < table_cols */
+    int64_t table_ld;
+    const void* resid;                   /* optional residual, resid_dtype MSAM_F32 / MSAM_BF16, 0 = none */
+    int32_t resid_dtype; int32_t resid_rows;  /* resid row = row % resid_rows (resid_rows 0 -> row) */
+    int64_t ldr;
+    int32_t act;                         /* MSAM_ACT_* applied last */
+    void* out; int32_t out_dtype; int64_t ldc;   /* plain output (out_mode 0) */
+    int32_t out_mode;                    /* 0 plain, 1 qkv-split (ViT attention layout), 2 kv-split (decoder) */
+    void* q; void* k; void* v;           /* out_mode 1: q,k,v -> [B,heads,tokens,hd] bf16
+                                            out_mode 2 (N == 256): k <- cols 0..127 as [M,128] bf16,
+                                            v <- cols 128..255 transposed [M/tokens,128,tokens] bf16 */
+    int32_t heads, head_dim, tokens;
+    int32_t use_glds;                    /* 1: global_load_lds staging variant, 0: register staging */
+} msam_gemm_t;
+int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
+
+/* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
+ * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.
+ * out_nchw_hw > 0: write fp32 output transposed to [rows/hw, dim, hw] (the encoder's NCHW result). */
+int msam_layernorm(const float* x, const float* weight, const float* bias, float eps, int64_t rows, int32_t dim,
+                   void* out, int32_t out_dtype, int32_t gelu, int32_t out_nchw_hw, void* stream);
+
+/* fp32 [B,3,1024,1024] (output of Sam.preprocess) -> bf16 patch matrix [B*4096, 768] (c,ky,kx order). */
+int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream);
+/* uint8 HWC [B,h,w,3] (h,w <= 1024; output of ResizeLongestSide.apply_image) -> normalised, zero padded bf16 patch
+ * matrix [B*4096,768]: fuses Sam.preprocess (micro_sam/util.py:670) into the patch gather. */
+int msam_patchify_u8(const uint8_t* img, int32_t B, int32_t h, int32_t w, void* out_bf16, void* stream);
+/* bf16 [B,64,64,C] -> bf16 [B*4096, 9*C] rows for the 3x3 / pad 1 neck convolution ((ky,kx,c) column order). */
+int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, void* stream);
+int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
+
+/* ViT attention with decomposed relative position bias (segment_anything ImageEncoderViT Attention).
+ * q,k,v: bf16 [B,heads,4096,64];
+ * rel_h/rel_w: bf16 [2S-1,64]; qkv_bias: fp32 [3*D] (padding tokens of windowed blocks carry bias-only q/k/v);
+ * out: bf16 [B*4096, heads*64] token-major. */
+int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                          const float* qkv_bias, int32_t B, int32_t heads, void* out, void* stream);
+int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                          int32_t B, int32_t heads, void* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Image encoder:  predictor.model.image_encoder(x)   (micro_sam/util.py:674)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t embed_dim, depth, heads;               /* micro_sam/models/build_sam.py:40-84 */
+    int32_t is_global[MSAM_MAX_BLOCKS];
+    const void* patch_w; const float* patch_b;     /* bf16 [D,768]; fp32 [D] */
+    const float* pos_embed;                        /* fp32 [4096, D] */
+    const float* ln1_w[MSAM_MAX_BLOCKS]; const float* ln1_b[MSAM_MAX_BLOCKS];
+    const void* qkv_w[MSAM_MAX_BLOCKS]; const float* qkv_b[MSAM_MAX_BLOCKS];
+    const void* rel_h[MSAM_MAX_BLOCKS]; const void* rel_w[MSAM_MAX_BLOCKS];      /* bf16 */
+    const void* proj_w[MSAM_MAX_BLOCKS]; const float* proj_b[MSAM_MAX_BLOCKS];
+    const float* ln2_w[MSAM_MAX_BLOCKS]; const float* ln2_b[MSAM_MAX_BLOCKS];
+    const void* lin1_w[MSAM_MAX_BLOCKS]; const float* lin1_b[MSAM_MAX_BLOCKS];
+    const void* lin2_w[MSAM_MAX_BLOCKS]; const float* lin2_b[MSAM_MAX_BLOCKS];
+    const void* neck0_w;                           /* bf16 [256, D] */
+    const float* neck1_w; const float* neck1_b;
+    const void* neck2_w;                           /* bf16 [256, 9*256], (ky,kx,c) column order */
+    const float* neck3_w; const float* neck3_b;
+    int32_t use_glds;
+} msam_encoder_t;
+
+int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B);
+/* img: fp32 [B,3,1024,1024] (img_u8 == NULL) or uint8 HWC [B,h,w,3] (img_f32 == NULL);
+ * out: fp32 [B,256,64,64].  tap (optional, may be NULL): fp32 [B*4096, D] copy of the residual stream after
+ * block `tap_block` (test hook). */
+int msam_encoder_forward(const msam_encoder_t* enc, const float* img_f32, const uint8_t* img_u8, int32_t h, int32_t w,
+                         int32_t B, float* out, void* workspace, int64_t workspace_bytes,
+                         float* tap, int32_t tap_block, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Prompt encoder + mask decoder:  predictor.predict_torch(...)  up to the low-res logits
+ * (micro_sam/instance_segmentation.py:361-366, micro_sam/inference.py:248-255)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* q_w; const float* q_b; const void* k_w; const float* k_b;
+    const void* v_w; const float* v_b; const void* o_w; const float* o_b;   /* weights bf16, biases fp32 */
+} msam_attn_w_t;
+typedef struct {
+    msam_attn_w_t self_attn, t2i, i2t;
+    const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b, *n4_w, *n4_b;
+    const void* mlp1_w; const float* mlp1_b; const void* mlp2_w; const float* mlp2_b;
+} msam_twoway_layer_t;
+typedef struct {
+    /* prompt encoder */
+    const float* pe_gauss;           /* fp32 [2,128] */
+    const float* point_embed;        /* fp32 [4,256]: point_embeddings.{0..3} */
+    const float* not_a_point;        /* fp32 [256] */
+    const float* no_mask;            /* fp32 [256] */
+    /* mask decoder */
+    const float* out_tokens;         /* fp32 [5,256]: iou_token, mask_tokens[0..3] */
+    msam_twoway_layer_t layer[2];
+    msam_attn_w_t final_attn; const float *nf_w, *nf_b;
+    const void* up1_w; const float* up1_b;     /* bf16 [256 (sub*64+co), 256 (ci)]; fp32 [256] (bias[co] tiled x4) */
+    const float* up_ln_w; const float* up_ln_b;
+    const void* up2_w; const float* up2_b;     /* bf16 [128 (sub*32+co), 64 (ci)]; fp32 [32] */
+    const void* hyp_w[4][3]; const float* hyp_b[4][3];   /* 4 hyper-network MLPs, bf16 / fp32; the last layer
+                                                             is zero-padded to 128 output rows */
+    const void* iou_w[3]; const float* iou_b[3];           /* IoU head, last layer zero-padded to 128 rows */
+    int32_t use_glds;
+} msam_decoder_t;
+
+/* Per-image constants of the decoder (dense positional encoding etc.): computed once per model. */
+int64_t msam_decoder_const_bytes(void);
+int msam_decoder_prepare_const(const msam_decoder_t* dec, void* consts, void* stream);
+/* Per-tile image-side precompute: src tokens, layer-0 image projections (prompt independent). */
+int64_t msam_decoder_image_bytes(void);
+int msam_decoder_prepare_image(const msam_decoder_t* dec, const void* consts, const float* embedding /*[256,64,64]*/,
+                               void* image_state, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t msam_decoder_workspace_bytes(int32_t P);
+/* points: fp32 [P,Np,2] in the 1024-frame (after transform.apply_coords), labels: int32 [P,Np] (1/0/-1);
+ * boxes: fp32 [P,4] or NULL.  (Mask prompts use the dense path of the Python shim.)
+ * low_res: fp32 [P,C,256,256], iou: fp32 [P,C] with C = 3 (multimask) or 1. */
+int msam_decoder_forward(const msam_decoder_t* dec, const void* consts, const void* image_state,
+                         const float* points, const int32_t* labels, int32_t Np, const float* boxes, int32_t P,
+                         int32_t multimask, float* low_res, float* iou,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Mask post-processing:  Sam.postprocess_masks + AMGBase._to_mask_data
+ * (micro_sam/instance_segmentation.py:229-255, micro_sam/_vendored.py:33-152)
+ * ------------------------------------------------------------------------------------------------- */
+/* low_res fp32 [N,256,256] -> for every mask n (fused, logits are never materialised at full resolution):
+ *   bilinear x4 to 1024^2 (align_corners=False), crop to (in_h,in_w), bilinear to (out_h,out_w),
+ *   counts[n] = {#(v > thr+off), #(v > thr-off), #(v > thr)}   (stability numerator / denominator, area)
+ *   boxes[n]  = xyxy inclusive box of (v > thr), {0,0,0,0} if empty        (batched_mask_to_box)
+ *   bits      = bit mask [N, ceil(out_h/32), out_w] uint32: bit b of word [n][yw][x] is pixel (y = yw*32 + b, x)
+ * logits (optional, may be NULL): fp32 [N,out_h,out_w] full-resolution values (return_logits path). */
+int msam_postprocess_masks(const float* low_res, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
+                           float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits, float* logits,
+                           void* stream);
+/* Column-major run-length encoding of the bit masks (mask_to_rle_pytorch, _vendored.py:114-152).
+ * Pass 1 (run_counts): number of runs per mask incl. the leading zero-run convention.
+ * Pass 2 (rle_encode): counts written at offsets[n] (exclusive prefix sum of run counts, int64). */
+int msam_rle_run_counts(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_w, int32_t* n_runs, void* stream);
+int msam_rle_encode(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_w, const int64_t* offsets,
+                    int32_t* counts_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSAM_HIP_H */

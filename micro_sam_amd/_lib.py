@@ -1,0 +1,158 @@
+"""ctypes binding of libmsam_hip.so (C ABI declared in include/msam_hip.h).
+
+Torch is used only as the owner of device memory and streams: every call passes raw ``tensor.data_ptr()``
+values and the current HIP stream handle.  There is NO fallback: if the shared library is missing the import
+of any compute entry point raises, and calling a kernel without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from . import build as _build
+
+MSAM_MAX_BLOCKS = 32
+F32, BF16 = 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("lda", _i64), ("W", _vp), ("ldw", _i64), ("M", _i32), ("N", _i32), ("K", _i32),
+        ("bias", _vp), ("table", _vp), ("table_rows", _i32), ("table_cols", _i32), ("table_ld", _i64),
+        ("resid", _vp), ("resid_dtype", _i32), ("resid_rows", _i32), ("ldr", _i64), ("act", _i32),
+        ("out", _vp), ("out_dtype", _i32), ("ldc", _i64), ("out_mode", _i32),
+        ("q", _vp), ("k", _vp), ("v", _vp), ("heads", _i32), ("head_dim", _i32), ("tokens", _i32),
+        ("use_glds", _i32),
+    ]
+
+
+_blk = _vp * MSAM_MAX_BLOCKS
+
+
+class EncoderParams(C.Structure):
+    _fields_ = [
+        ("embed_dim", _i32), ("depth", _i32), ("heads", _i32), ("is_global", _i32 * MSAM_MAX_BLOCKS),
+        ("patch_w", _vp), ("patch_b", _vp), ("pos_embed", _vp),
+        ("ln1_w", _blk), ("ln1_b", _blk), ("qkv_w", _blk), ("qkv_b", _blk), ("rel_h", _blk), ("rel_w", _blk),
+        ("proj_w", _blk), ("proj_b", _blk), ("ln2_w", _blk), ("ln2_b", _blk),
+        ("lin1_w", _blk), ("lin1_b", _blk), ("lin2_w", _blk), ("lin2_b", _blk),
+        ("neck0_w", _vp), ("neck1_w", _vp), ("neck1_b", _vp), ("neck2_w", _vp), ("neck3_w", _vp), ("neck3_b", _vp),
+        ("use_glds", _i32),
+    ]
+
+
+class AttnW(C.Structure):
+    _fields_ = [("q_w", _vp), ("q_b", _vp), ("k_w", _vp), ("k_b", _vp), ("v_w", _vp), ("v_b", _vp),
+                ("o_w", _vp), ("o_b", _vp)]
+
+
+class TwoWayLayer(C.Structure):
+    _fields_ = [("self_attn", AttnW), ("t2i", AttnW), ("i2t", AttnW),
+                ("n1_w", _vp), ("n1_b", _vp), ("n2_w", _vp), ("n2_b", _vp), ("n3_w", _vp), ("n3_b", _vp),
+                ("n4_w", _vp), ("n4_b", _vp),
+                ("mlp1_w", _vp), ("mlp1_b", _vp), ("mlp2_w", _vp), ("mlp2_b", _vp)]
+
+
+class DecoderParams(C.Structure):
+    _fields_ = [
+        ("pe_gauss", _vp), ("point_embed", _vp), ("not_a_point", _vp), ("no_mask", _vp), ("out_tokens", _vp),
+        ("layer", TwoWayLayer * 2), ("final_attn", AttnW), ("nf_w", _vp), ("nf_b", _vp),
+        ("up1_w", _vp), ("up1_b", _vp), ("up_ln_w", _vp), ("up_ln_b", _vp), ("up2_w", _vp), ("up2_b", _vp),
+        ("hyp_w", (_vp * 3) * 4), ("hyp_b", (_vp * 3) * 4), ("iou_w", _vp * 3), ("iou_b", _vp * 3),
+        ("use_glds", _i32),
+    ]
+
+
+_PROTOS = {
+    "msam_last_error": (C.c_char_p, []),
+    "msam_abi_version": (_i32, []),
+    "msam_gemm_bf16": (_i32, [C.POINTER(GemmParams), _vp]),
+    "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
+    "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "msam_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "msam_window_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),
+    "msam_encoder_forward": (_i32, [C.POINTER(EncoderParams), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "msam_decoder_const_bytes": (_i64, []),
+    "msam_decoder_prepare_const": (_i32, [C.POINTER(DecoderParams), _vp, _vp]),
+    "msam_decoder_image_bytes": (_i64, []),
+    "msam_decoder_prepare_image": (_i32, [C.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _i64, _vp]),
+    "msam_decoder_workspace_bytes": (_i64, [_i32]),
+    "msam_decoder_forward": (_i32, [C.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp,
+                                    _i64, _vp]),
+    "msam_postprocess_masks": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "msam_rle_run_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_rle_encode": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+}
+OPTIONAL = {"msam_paint_label_image", "msam_label_components"}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load (once) libmsam_hip.so; raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"micro_sam_amd: {path} is missing. Build it with `python -m micro_sam_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback."
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in _PROTOS.items():
+        if not hasattr(lib, name):
+            if name in OPTIONAL:
+                continue
+            raise RuntimeError(f"micro_sam_amd: {path} does not export {name}")
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return [n for n in _PROTOS if n not in OPTIONAL]
+
+
+def check(status: int, what: str = "") -> None:
+    if status == 0:
+        return
+    msg = load().msam_last_error().decode("utf-8", "replace")
+    if status == 1:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("micro_sam_amd needs an AMD GPU (gfx950); torch.cuda.is_available() is False. "
+                           "There is no CPU fallback.")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor expected"
+    return t.data_ptr()

@@ -1,0 +1,179 @@
+"""Host-side helpers of automatic mask generation: the subset of ``segment_anything.utils.amg`` that micro_sam
+calls (``micro_sam/instance_segmentation.py:99-255,356-530``; semantics in SURVEY.md Appendix B) plus greedy box NMS
+(``torchvision.ops.batched_nms`` with one category).  These are host code in the reference as well."""
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+from itertools import product
+from typing import Any, Dict, Iterator, List, Tuple
+
+import numpy as np
+import torch
+
+
+class MaskData:
+    """Columnar store (lists / ndarrays / tensors of equal length) with ``filter`` / ``cat`` / ``to_numpy``."""
+
+    _TYPES = (list, np.ndarray, torch.Tensor)
+
+    def __init__(self, **kwargs) -> None:
+        for v in kwargs.values():
+            assert isinstance(v, self._TYPES), "MaskData only supports list, numpy arrays, and torch tensors."
+        self._stats = dict(**kwargs)
+
+    def __setitem__(self, key: str, item: Any) -> None:
+        assert isinstance(item, self._TYPES), "MaskData only supports list, numpy arrays, and torch tensors."
+        self._stats[key] = item
+
+    def __delitem__(self, key: str) -> None:
+        del self._stats[key]
+
+    def __getitem__(self, key: str) -> Any:
+        return self._stats[key]
+
+    def __contains__(self, key: str) -> bool:
+        return key in self._stats
+
+    def items(self):
+        return self._stats.items()
+
+    def filter(self, keep: torch.Tensor) -> None:
+        keep = torch.as_tensor(keep)
+        for k, v in self._stats.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                self._stats[k] = v[keep.to(v.device)]
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = v[keep.detach().cpu().numpy()]
+            elif keep.dtype == torch.bool:
+                flags = keep.tolist()
+                self._stats[k] = [a for a, f in zip(v, flags) if f]
+            else:
+                self._stats[k] = [v[i] for i in keep.tolist()]
+
+    def cat(self, new_stats: "MaskData") -> None:
+        for k, v in new_stats.items():
+            cur = self._stats.get(k)
+            if cur is None:
+                self._stats[k] = deepcopy(v)
+            elif isinstance(v, torch.Tensor):
+                self._stats[k] = torch.cat([cur, v], dim=0)
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = np.concatenate([cur, v], axis=0)
+            elif isinstance(v, list):
+                self._stats[k] = cur + deepcopy(v)
+            else:
+                raise TypeError(f"MaskData key {k} has an unsupported type {type(v)}.")
+
+    def to_numpy(self) -> None:
+        for k, v in self._stats.items():
+            if isinstance(v, torch.Tensor):
+                self._stats[k] = v.float().cpu().numpy() if v.dtype == torch.bfloat16 else v.detach().cpu().numpy()
+
+
+def build_point_grid(n_per_side: int) -> np.ndarray:
+    """Cell-centre grid in (0,1)^2, row-major over y, every row an (x, y) pair."""
+    centres = (np.arange(n_per_side, dtype=np.float64) + 0.5) / n_per_side
+    centres = np.linspace(centres[0], centres[-1], n_per_side) if n_per_side > 1 else centres
+    xs, ys = np.meshgrid(centres, centres)
+    return np.stack([xs, ys], axis=-1).reshape(-1, 2)
+
+
+def build_all_layer_point_grids(n_per_side: int, n_layers: int, scale_per_layer: int) -> List[np.ndarray]:
+    return [build_point_grid(int(n_per_side / (scale_per_layer ** i))) for i in range(n_layers + 1)]
+
+
+def generate_crop_boxes(im_size: Tuple[int, ...], n_layers: int, overlap_ratio: float):
+    im_h, im_w = im_size
+    boxes, layers = [[0, 0, im_w, im_h]], [0]
+    short = min(im_h, im_w)
+    for layer in range(1, n_layers + 1):
+        n = 2 ** layer
+        overlap = int(overlap_ratio * short * (2 / n))
+        cw = int(math.ceil((overlap * (n - 1) + im_w) / n))
+        ch = int(math.ceil((overlap * (n - 1) + im_h) / n))
+        x0s = [int((cw - overlap) * i) for i in range(n)]
+        y0s = [int((ch - overlap) * i) for i in range(n)]
+        for x0, y0 in product(x0s, y0s):
+            boxes.append([x0, y0, min(x0 + cw, im_w), min(y0 + ch, im_h)])
+            layers.append(layer)
+    return boxes, layers
+
+
+def batch_iterator(batch_size: int, *args) -> Iterator[List[Any]]:
+    n = len(args[0])
+    assert all(len(a) == n for a in args), "Batched iteration must have inputs of all the same size."
+    for start in range(0, n, batch_size):
+        yield [a[start:start + batch_size] for a in args]
+
+
+def uncrop_boxes_xyxy(boxes: torch.Tensor, crop_box: List[int]) -> torch.Tensor:
+    x0, y0 = crop_box[0], crop_box[1]
+    offset = torch.tensor([[x0, y0, x0, y0]], device=boxes.device)
+    return boxes + (offset.unsqueeze(1) if boxes.dim() == 3 else offset)
+
+
+def uncrop_points(points: torch.Tensor, crop_box: List[int]) -> torch.Tensor:
+    offset = torch.tensor([[crop_box[0], crop_box[1]]], device=points.device)
+    return points + (offset.unsqueeze(1) if points.dim() == 3 else offset)
+
+
+def is_box_near_crop_edge(boxes: torch.Tensor, crop_box: List[int], orig_box: List[int], atol: float = 20.0):
+    crop_t = torch.as_tensor(crop_box, dtype=torch.float, device=boxes.device)[None]
+    orig_t = torch.as_tensor(orig_box, dtype=torch.float, device=boxes.device)[None]
+    b = uncrop_boxes_xyxy(boxes, crop_box).float()
+    near_crop = torch.isclose(b, crop_t, atol=atol, rtol=0)
+    near_img = torch.isclose(b, orig_t, atol=atol, rtol=0)
+    return torch.any(near_crop & ~near_img, dim=1)
+
+
+def rle_to_mask(rle: Dict[str, Any]) -> np.ndarray:
+    """Uncompressed column-major RLE -> bool [h, w]."""
+    h, w = rle["size"]
+    counts = np.asarray(rle["counts"], dtype=np.int64)
+    vals = (np.arange(len(counts)) & 1).astype(bool)
+    return np.repeat(vals, counts).reshape(w, h).T
+
+
+def area_from_rle(rle: Dict[str, Any]) -> int:
+    return int(sum(rle["counts"][1::2]))
+
+
+def box_xyxy_to_xywh(box_xyxy):
+    b = deepcopy(box_xyxy)
+    b[2] = b[2] - b[0]
+    b[3] = b[3] - b[1]
+    return b
+
+
+def box_area(boxes: torch.Tensor) -> torch.Tensor:
+    return (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+
+
+def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Greedy NMS, torchvision semantics: stable descending score order, suppress IoU > threshold (areas without +1),
+    boxes of different categories never suppress each other.  Returns kept indices in score order (int64)."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    b = boxes.detach().float().cpu().numpy()
+    s = scores.detach().float().cpu().numpy()
+    cat = idxs.detach().cpu().numpy()
+    order = np.argsort(-s, kind="stable")
+    b, cat = b[order], cat[order]
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    alive = np.ones(n, dtype=bool)
+    keep = []
+    for i in range(n):
+        if not alive[i]:
+            continue
+        keep.append(order[i])
+        j = slice(i + 1, n)
+        w = np.minimum(b[i, 2], b[j, 2]) - np.maximum(b[i, 0], b[j, 0])
+        h = np.minimum(b[i, 3], b[j, 3]) - np.maximum(b[i, 1], b[j, 1])
+        inter = np.maximum(w, np.float32(0)) * np.maximum(h, np.float32(0))
+        iou = inter / (area[i] + area[j] - inter)
+        alive[j] &= ~((iou > iou_threshold) & (cat[j] == cat[i]))
+    return torch.as_tensor(np.asarray(keep, dtype=np.int64), device=boxes.device)

@@ -1,0 +1,347 @@
+// ViT attention with decomposed relative-position bias for the SAM image encoder (head_dim 64).
+//
+// Both kernels compute the TRANSPOSED score tile S^T = K * Q^T with v_mfma_f32_16x16x32_bf16, so that in the
+// C layout (row = key = (l>>4)*4 + r, col = query = l & 15) every softmax statistic is a per-lane-column
+// quantity (reduce over registers + 2 cross-lane steps), and the un-normalised probabilities P^T can be fed
+// straight back as the B operand of O^T = V^T * P^T without touching LDS: for the k-slot (g = l>>4, i) of a
+// K=32 MFMA built from two 16-key tiles t0,t1 the key is t*16 + g*4 + (i & 3); the V^T fragment is read
+// with the same key map (two 8-byte LDS reads).
+//
+//   window kernel : one workgroup per (image, 14x14 window, head); all 196 keys (+ bias-only padding tokens
+//                   of the 70x70 padded grid) resident in LDS; rel-pos terms T[q][j] = q . R[j] by MFMA.
+//   global kernel : one workgroup per (image, head, image row of 64 queries); flash-style online softmax over
+//                   128 tiles of 32 keys (half an image row: kh is constant per tile), K / V^T tiles double
+//                   buffered in LDS with register prefetch; rel_h[q][kh] and rel_w[q][kw] precomputed by MFMA
+//                   into LDS in the prologue.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int TOK = 4096;
+constexpr float NEG_BIG = -1.0e30f;
+
+MSAM_DEVINL uint4 bias_chunk_bf16(const float* b) {   // 8 fp32 -> 8 bf16
+    uint4 r;
+    r.x = pack2bf(b[0], b[1]); r.y = pack2bf(b[2], b[3]); r.z = pack2bf(b[4], b[5]); r.w = pack2bf(b[6], b[7]);
+    return r;
+}
+
+// --------------------------------------------------------------------------------------------- window
+constexpr int WS = 14, WN = 196, WKT = 13 /* key tiles */, WKP = 224 /* padded keys for PV pairs */;
+constexpr int VT_RS = 232;    // V^T row stride in bf16 (464 B = 116 dwords = 4 * odd -> conflict-free b64 reads)
+constexpr int T_RS = 65;      // rel-pos table row stride (floats)
+
+__global__ __launch_bounds__(256) void window_attention_kernel(
+    const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
+    const u16* __restrict__ relw, const float* __restrict__ qkv_bias, int heads, u16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint4 k_lds[WKT * 16 * 8];            // 26 KB
+    __shared__ __attribute__((aligned(16))) u16 vt_lds[HD * VT_RS];               // 29 KB
+    __shared__ __attribute__((aligned(16))) float t_lds[4][16 * T_RS];            // 16.3 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    int bid = blockIdx.x;
+    const int head = bid % heads; bid /= heads;
+    const int win = bid % 25, b = bid / 25;
+    const int wy = win / 5, wx = win % 5;
+    const int D = heads * HD;
+    const long bh = ((long)b * heads + head) * TOK * HD;
+    const u16* Qb = Q + bh; const u16* Kb = K + bh; const u16* Vb = V + bh;
+    const float* bq = qkv_bias + head * HD;
+    const float* bk = qkv_bias + D + head * HD;
+    const float* bv = qkv_bias + 2 * D + head * HD;
+
+    // ---- stage K (row-major, swizzled chunks) and V^T
+    for (int c = tid; c < WKT * 16 * 8; c += 256) {
+        const int row = c >> 3, ch = c & 7;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (row < WN) {
+            const int y = wy * WS + row / WS, x = wx * WS + row % WS;
+            if (y < 64 && x < 64) val = *(const uint4*)(Kb + (long)(y * 64 + x) * HD + ch * 8);
+            else val = bias_chunk_bf16(bk + ch * 8);
+        }
+        k_lds[row * 8 + (ch ^ swz(row))] = val;
+    }
+    for (int c = tid; c < WKP * 8; c += 256) {
+        const int key = c % WKP, ch = c / WKP;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (key < WN) {
+            const int y = wy * WS + key / WS, x = wx * WS + key % WS;
+            if (y < 64 && x < 64) val = *(const uint4*)(Vb + (long)(y * 64 + x) * HD + ch * 8);
+            else val = bias_chunk_bf16(bv + ch * 8);
+        }
+        const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vt_lds[(ch * 8 + 2 * i) * VT_RS + key] = (u16)(wv[i] & 0xffff);
+            vt_lds[(ch * 8 + 2 * i + 1) * VT_RS + key] = (u16)(wv[i] >> 16);
+        }
+    }
+
+    // ---- rel-pos rows as MFMA A operand: tile jt rows j = jt*16 + fr; j < 27 -> rel_h[j], 32 <= j < 59 -> rel_w[j-32]
+    uint4 ra[4][2];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const int j = jt * 16 + fr;
+        const u16* src = nullptr;
+        if (j < 27) src = relh + j * HD;
+        else if (j >= 32 && j < 59) src = relw + (j - 32) * HD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            ra[jt][ks] = src ? *(const uint4*)(src + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    float* tl = t_lds[wave];
+    for (int qt = wave; qt < WKT; qt += 4) {
+        // Q fragments (B operand): query qi = qt*16 + fr
+        const int qi = qt * 16 + fr;
+        const int qh = (qi < WN ? qi : WN - 1) / WS, qw = (qi < WN ? qi : WN - 1) % WS;
+        const int qy = wy * WS + qh, qx = wx * WS + qw;
+        const bool q_real = qi < WN && qy < 64 && qx < 64;
+        uint4 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (q_real) qf[ks] = *(const uint4*)(Qb + (long)(qy * 64 + qx) * HD + ks * 32 + fg * 8);
+            else if (qi < WN) qf[ks] = bias_chunk_bf16(bq + ks * 32 + fg * 8);
+            else qf[ks] = make_uint4(0, 0, 0, 0);
+        }
+        // T^T[j][q] = R[j] . q  -> t_lds[q][j]
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4_t t = {0.f, 0.f, 0.f, 0.f};
+            t = mfma16(ra[jt][0], qf[0], t);
+            t = mfma16(ra[jt][1], qf[1], t);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tl[fr * T_RS + jt * 16 + fg * 4 + r] = t[r];
+        }
+        // S^T = K Q^T
+        f32x4_t s[WKT];
+#pragma unroll
+        for (int kt = 0; kt < WKT; ++kt) {
+            const int row = kt * 16 + fr;
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(k_lds[row * 8 + ((0 + fg) ^ swz(row))], qf[0], a);
+            a = mfma16(k_lds[row * 8 + ((4 + fg) ^ swz(row))], qf[1], a);
+            s[kt] = a;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // scale, rel-pos bias, mask padding keys; column-wise (per query) softmax
+        float m = NEG_BIG;
+#pragma unroll
+        for (int kt = 0; kt < WKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fg * 4 + r;
+                float v = NEG_BIG;
+                if (key < WN) {
+                    const int kh = key / WS, kw = key - kh * WS;
+                    v = s[kt][r] * 0.125f + tl[fr * T_RS + (qh - kh + 13)] + tl[fr * T_RS + 32 + (qw - kw + 13)];
+                }
+                s[kt][r] = v;
+                m = fmaxf(m, v);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < WKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float p = __expf(s[kt][r] - m); s[kt][r] = p; l += p; }
+        l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+        // O^T = V^T P^T
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int t0 = 2 * u, t1 = 2 * u + 1;
+            uint4 pb;
+            pb.x = pack2bf(s[t0][0], s[t0][1]); pb.y = pack2bf(s[t0][2], s[t0][3]);
+            if (t1 < WKT) { pb.z = pack2bf(s[t1][0], s[t1][1]); pb.w = pack2bf(s[t1][2], s[t1][3]); }
+            else { pb.z = 0; pb.w = 0; }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u16* vr = vt_lds + (dt * 16 + fr) * VT_RS + fg * 4;
+                uint2 lo = *(const uint2*)(vr + t0 * 16), hi = *(const uint2*)(vr + t1 * 16);
+                o[dt] = mfma16(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[dt]);
+            }
+        }
+        if (q_real) {
+            const float inv = 1.0f / l;
+            u16* dst = out + ((long)b * TOK + qy * 64 + qx) * D + head * HD + fg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk; pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv); pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+                *(uint2*)(dst + dt * 16) = pk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// --------------------------------------------------------------------------------------------- global
+constexpr int GQ = 64;            // queries per workgroup (one image row)
+constexpr int GKT = 32;           // keys per tile
+constexpr int GVT_RS = 40;        // V^T tile row stride in bf16 (80 B = 20 dwords = 4 * odd)
+constexpr int GB_RS = 68;         // bias table row stride in floats (272 B, multiple of 16 B)
+
+__global__ __launch_bounds__(256) void global_attention_kernel(
+    const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
+    const u16* __restrict__ relw, int heads, u16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint4 k_lds[2][GKT * 8];              // 8 KB
+    __shared__ __attribute__((aligned(16))) u16 vt_lds[2][HD * GVT_RS];           // 10 KB
+    __shared__ __attribute__((aligned(16))) float rh_lds[GQ * GB_RS];             // 17 KB  rel_h[q][kh]
+    __shared__ __attribute__((aligned(16))) float bw_lds[GQ * GB_RS];             // 17 KB  rel_w[q][kw]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    int bid = blockIdx.x;
+    const int qrow = bid & 63; bid >>= 6;
+    const int head = bid % heads, b = bid / heads;
+    const int D = heads * HD;
+    const long bh = ((long)b * heads + head) * TOK * HD;
+    const u16* Qb = Q + bh; const u16* Kb = K + bh; const u16* Vb = V + bh;
+
+    const int ql = wave * 16 + fr;            // query column inside the image row = qw
+    const int qh = qrow, qw = ql;
+    uint4 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const uint4*)(Qb + (long)(qh * 64 + qw) * HD + ks * 32 + fg * 8);
+
+    // ---- prologue: rel_h[q][kh] = q . rel_pos_h[qh - kh + 63]  (A rows indexed by kh)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int kh = t * 16 + fr;
+        const u16* src = relh + (qh - kh + 63) * HD;
+        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+        c = mfma16(*(const uint4*)(src + fg * 8), qf[0], c);
+        c = mfma16(*(const uint4*)(src + 32 + fg * 8), qf[1], c);
+        *(float4*)(rh_lds + ql * GB_RS + t * 16 + fg * 4) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+    // rel_w[q][kw] = q . rel_pos_w[qw - kw + 63]: compute T[j][q] for all 127 rows j, scatter to kw = qw - j + 63
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+        const int j = jt * 16 + fr;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (j < 127) { a0 = *(const uint4*)(relw + j * HD + fg * 8); a1 = *(const uint4*)(relw + j * HD + 32 + fg * 8); }
+        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+        c = mfma16(a0, qf[0], c);
+        c = mfma16(a1, qf[1], c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kw = qw - (jt * 16 + fg * 4 + r) + 63;
+            if (kw >= 0 && kw < 64) bw_lds[ql * GB_RS + kw] = c[r];
+        }
+    }
+
+    // ---- K / V^T tile staging (register prefetch, double-buffered LDS)
+    const int k_row = tid >> 3, k_ch = tid & 7;          // K tile: 32 rows x 8 chunks
+    const int v_key = tid & 31, v_ch = tid >> 5;         // V tile: key fastest (LDS-friendly transposed writes)
+    uint4 rk, rv;
+    rk = *(const uint4*)(Kb + (long)k_row * HD + k_ch * 8);
+    rv = *(const uint4*)(Vb + (long)v_key * HD + v_ch * 8);
+#define G_COMMIT(buf_)                                                                   \
+    do {                                                                                 \
+        k_lds[buf_][k_row * 8 + (k_ch ^ swz(k_row))] = rk;                               \
+        u16* vd_ = vt_lds[buf_] + (v_ch * 8) * GVT_RS + v_key;                           \
+        vd_[0 * GVT_RS] = (u16)(rv.x & 0xffff); vd_[1 * GVT_RS] = (u16)(rv.x >> 16);     \
+        vd_[2 * GVT_RS] = (u16)(rv.y & 0xffff); vd_[3 * GVT_RS] = (u16)(rv.y >> 16);     \
+        vd_[4 * GVT_RS] = (u16)(rv.z & 0xffff); vd_[5 * GVT_RS] = (u16)(rv.z >> 16);     \
+        vd_[6 * GVT_RS] = (u16)(rv.w & 0xffff); vd_[7 * GVT_RS] = (u16)(rv.w >> 16);     \
+    } while (0)
+    G_COMMIT(0);
+    __syncthreads();
+
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, l = 0.f;
+    const int NT = TOK / GKT;   // 128
+    for (int kt = 0; kt < NT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < NT) {
+            rk = *(const uint4*)(Kb + (long)((kt + 1) * GKT + k_row) * HD + k_ch * 8);
+            rv = *(const uint4*)(Vb + (long)((kt + 1) * GKT + v_key) * HD + v_ch * 8);
+        }
+        const int kh = kt >> 1, kw0 = (kt & 1) * 32;
+        f32x4_t s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = t * 16 + fr;
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(k_lds[buf][row * 8 + ((0 + fg) ^ swz(row))], qf[0], a);
+            a = mfma16(k_lds[buf][row * 8 + ((4 + fg) ^ swz(row))], qf[1], a);
+            s[t] = a;
+        }
+        const float rh = rh_lds[ql * GB_RS + kh];
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 bw = *(const float4*)(bw_lds + ql * GB_RS + kw0 + t * 16 + fg * 4);
+            s[t][0] = s[t][0] * 0.125f + rh + bw.x; s[t][1] = s[t][1] * 0.125f + rh + bw.y;
+            s[t][2] = s[t][2] * 0.125f + rh + bw.z; s[t][3] = s[t][3] * 0.125f + rh + bw.w;
+            mt = fmaxf(mt, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt);
+        const float alpha = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { float p = __expf(s[t][r] - mn); s[t][r] = p; ps += p; }
+        l = l * alpha + ps;      // per-lane partial row sum; the 4 lane groups are combined after the loop
+        uint4 pb;
+        pb.x = pack2bf(s[0][0], s[0][1]); pb.y = pack2bf(s[0][2], s[0][3]);
+        pb.z = pack2bf(s[1][0], s[1][1]); pb.w = pack2bf(s[1][2], s[1][3]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
+            const u16* vr = vt_lds[buf] + (dt * 16 + fr) * GVT_RS + fg * 4;
+            uint2 lo = *(const uint2*)(vr), hi = *(const uint2*)(vr + 16);
+            o[dt] = mfma16(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[dt]);
+        }
+        if (kt + 1 < NT) G_COMMIT(buf ^ 1);
+        __syncthreads();
+    }
+#undef G_COMMIT
+    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    u16* dst = out + ((long)b * TOK + qh * 64 + qw) * D + head * HD + fg * 4;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        uint2 pk; pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv); pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+        *(uint2*)(dst + dt * 16) = pk;
+    }
+}
+
+}  // namespace
+
+extern "C" int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                                     const float* qkv_bias, int32_t B, int32_t heads, void* out, void* stream) {
+    if (!q || !k || !v || !rel_h || !rel_w || !qkv_bias || !out || B <= 0 || heads <= 0) {
+        msam_set_error("msam_window_attention: bad arguments");
+        return 1;
+    }
+    hipLaunchKernelGGL(window_attention_kernel, dim3(B * 25 * heads), dim3(256), 0, (hipStream_t)stream, (const u16*)q,
+                       (const u16*)k, (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, (u16*)out);
+    return msam_check_launch("msam_window_attention");
+}
+
+extern "C" int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                                     int32_t B, int32_t heads, void* out, void* stream) {
+    if (!q || !k || !v || !rel_h || !rel_w || !out || B <= 0 || heads <= 0) {
+        msam_set_error("msam_global_attention: bad arguments");
+        return 1;
+    }
+    hipLaunchKernelGGL(global_attention_kernel, dim3(B * heads * 64), dim3(256), 0, (hipStream_t)stream, (const u16*)q,
+                       (const u16*)k, (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, heads, (u16*)out);
+    return msam_check_launch("msam_global_attention");
+}

@@ -1,0 +1,53 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of micro_sam_amd.
+// Wave = 64 lanes.  MFMA fragment maps used everywhere (v_mfma_f32_16x16x32_bf16):
+//   A operand: lane l holds A[row = l & 15][k = (l >> 4) * 8 + i], i = 0..7   (8 bf16 = 16 B)
+//   B operand: lane l holds B[k = (l >> 4) * 8 + i][col = l & 15]
+//   C/D      : lane l, reg r holds C[row = (l >> 4) * 4 + r][col = l & 15]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define MSAM_DEVINL __device__ __forceinline__
+
+// round-to-nearest-even fp32 -> bf16 (bit pattern), NaN preserved as quiet NaN
+MSAM_DEVINL u16 f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+}
+MSAM_DEVINL float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
+MSAM_DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+MSAM_DEVINL f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
+    bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
+    bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+}
+
+// exact (erf) GELU, as torch.nn.functional.gelu default
+MSAM_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// LDS swizzle for a [rows][64] bf16 tile (128-B rows, 8 chunks of 16 B): chunk' = chunk ^ swz(row).
+// Chosen so that the 16-lane service groups of ds_read_b128 (MI355X_MICROARCH, LDS table) hit 16 distinct
+// 16-B slots when lanes read rows (l & 15) at chunk c0 + (l >> 4).
+MSAM_DEVINL int swz(int row) { return ((row >> 1) & 7) ^ (((row + 4) >> 3) & 1); }
+
+MSAM_DEVINL float wave_sum_xor16(float v) {   // sum over the 16 lanes sharing (l >> 4)
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    return v;
+}
+MSAM_DEVINL float wave_sum64(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+}
+MSAM_DEVINL float wave_max64(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}

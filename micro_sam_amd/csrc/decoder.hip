@@ -1,0 +1,631 @@
+// SAM prompt encoder + two-way-transformer mask decoder for P prompts on one image embedding.
+//
+// Dataflow (bf16 MFMA operands, fp32 accumulation / LayerNorm / softmax; see DESIGN.md "decoder"):
+//   per model   : dense positional encoding pos[4096,256] and its projections pos*Wk^T, pos*Wq^T for every
+//                 image-side attention (added as GEMM "table" epilogues: (x+pos)W = xW + posW).
+//   per image   : src = embedding^T + no_mask_embed;  layer-0 K|V^T and image-to-token Q (prompt independent).
+//   per prompt  : token-side chain on [P*Nt,256] rows through the shared GEMM kernel; image-side stream
+//                 keys[P*4096,256] (bf16) updated by image->token attention + out_proj + LN4; token->image
+//                 attention is a flash-style MFMA kernel over the 4096 image tokens; up-scaling =
+//                 ConvT(2x2)->LN2d->GELU as GEMM + row-LN(64), ConvT(2x2)->GELU->hyper-network product fused.
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+
+constexpr int T = 4096;        // image tokens
+constexpr int C = 256;         // transformer dim
+constexpr int CI = 128;        // internal dim of the cross attentions
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float TWO_PI = 6.283185307179586f;
+
+// ------------------------------------------------------------------------------------------ small kernels
+
+// PositionEmbeddingRandom: pe(c) = [sin(2pi * ((2c-1) @ G)), cos(...)], c in [0,1]^2
+MSAM_DEVINL void pe_encode(const float* __restrict__ G, float cx, float cy, int j, float& s, float& c) {
+    const float x = 2.f * cx - 1.f, y = 2.f * cy - 1.f;
+    const float v = TWO_PI * (x * G[j] + y * G[128 + j]);
+    s = sinf(v); c = cosf(v);
+}
+
+__global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__ G, float* __restrict__ pos_f32,
+                                                       u16* __restrict__ pos_bf16) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;      // over 4096 * 128
+    if (idx >= T * 128) return;
+    const int t = idx >> 7, j = idx & 127;
+    const int ty = t >> 6, tx = t & 63;
+    float s, c;
+    pe_encode(G, (tx + 0.5f) / 64.f, (ty + 0.5f) / 64.f, j, s, c);
+    pos_f32[t * C + j] = s; pos_f32[t * C + 128 + j] = c;
+    pos_bf16[t * C + j] = f2bf(s); pos_bf16[t * C + 128 + j] = f2bf(c);
+}
+
+// tokens[p][0..4] = output tokens; then points (+0.5, label embeddings), padding point when no box, box corners.
+__global__ __launch_bounds__(256) void prompt_tokens_kernel(
+    const float* __restrict__ G, const float* __restrict__ point_embed, const float* __restrict__ not_a_point,
+    const float* __restrict__ out_tokens, const float* __restrict__ points, const int* __restrict__ labels, int Np,
+    const float* __restrict__ boxes, int P, int Nt, float* __restrict__ tokens) {
+    const int p = blockIdx.x, c = threadIdx.x;           // 256 threads = 256 channels
+    if (p >= P) return;
+    float* tp = tokens + (long)p * Nt * C;
+    for (int i = 0; i < 5; ++i) tp[i * C + c] = out_tokens[i * C + c];
+    const int j = c & 127;
+    int row = 5;
+    for (int i = 0; i < Np; ++i, ++row) {
+        const float px = points[((long)p * Np + i) * 2] + 0.5f, py = points[((long)p * Np + i) * 2 + 1] + 0.5f;
+        const int lab = labels[(long)p * Np + i];
+        float s, co;
+        pe_encode(G, px / 1024.f, py / 1024.f, j, s, co);
+        float v = c < 128 ? s : co;
+        if (lab == -1) v = not_a_point[c];
+        else if (lab == 0) v += point_embed[0 * C + c];
+        else if (lab == 1) v += point_embed[1 * C + c];
+        tp[row * C + c] = v;
+    }
+    if (Np > 0 && !boxes) { tp[row * C + c] = not_a_point[c]; ++row; }     // padding point (0,0), label -1
+    if (boxes) {
+        for (int k = 0; k < 2; ++k, ++row) {
+            const float bx = boxes[(long)p * 4 + 2 * k] + 0.5f, by = boxes[(long)p * 4 + 2 * k + 1] + 0.5f;
+            float s, co;
+            pe_encode(G, bx / 1024.f, by / 1024.f, j, s, co);
+            tp[row * C + c] = (c < 128 ? s : co) + point_embed[(2 + k) * C + c];
+        }
+    }
+}
+
+// src[t][c] = emb[c][t] + no_mask[c]  (NCHW -> token-major); bf16 copy
+__global__ __launch_bounds__(256) void src_prepare_kernel(const float* __restrict__ emb, const float* __restrict__ no_mask,
+                                                          float* __restrict__ src_f32, u16* __restrict__ src_bf16) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = emb[(long)(c0 + i) * T + t0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const float v = tile[tx][i] + no_mask[c0 + tx];
+        src_f32[(long)(t0 + i) * C + c0 + tx] = v;
+        src_bf16[(long)(t0 + i) * C + c0 + tx] = f2bf(v);
+    }
+}
+
+// out_bf16 = bf16(a + b) over n elements (b may be NULL)
+__global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       u16* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 x = *(const float4*)(a + i * 4);
+        if (b) { float4 y = *(const float4*)(b + i * 4); x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
+        uint2 pk; pk.x = pack2bf(x.x, x.y); pk.y = pack2bf(x.z, x.w);
+        *(uint2*)(out + i * 4) = pk;
+    }
+}
+
+// Token self-attention: q,k,v bf16 [P*Nt,256], 8 heads x 32; thread = (head, query i); Nt <= 16.
+__global__ __launch_bounds__(128) void token_self_attn_kernel(const u16* __restrict__ q, const u16* __restrict__ k,
+                                                              const u16* __restrict__ v, int Nt, u16* __restrict__ out) {
+    const int p = blockIdx.x, head = threadIdx.x >> 4, i = threadIdx.x & 15;
+    if (i >= Nt) return;
+    const long base = (long)p * Nt * C + head * 32;
+    float qv[32];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        uint4 w = *(const uint4*)(q + base + (long)i * C + c4 * 8);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { qv[c4 * 8 + 2 * x] = bf2f((u16)(ww[x] & 0xffff)); qv[c4 * 8 + 2 * x + 1] = bf2f((u16)(ww[x] >> 16)); }
+    }
+    float s[16];
+    float m = NEG_BIG;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float acc = 0.f;
+        if (j < Nt) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                uint4 w = *(const uint4*)(k + base + (long)j * C + c4 * 8);
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    acc += qv[c4 * 8 + 2 * x] * bf2f((u16)(ww[x] & 0xffff));
+                    acc += qv[c4 * 8 + 2 * x + 1] * bf2f((u16)(ww[x] >> 16));
+                }
+            }
+            acc *= 0.17677669529663687f;     // 1/sqrt(32)
+        } else acc = NEG_BIG;
+        s[j] = acc; m = fmaxf(m, acc);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s[j] = __expf(s[j] - m); l += s[j]; }
+    float o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (j < Nt) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                uint4 w = *(const uint4*)(v + base + (long)j * C + c4 * 8);
+                const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    o[c4 * 8 + 2 * x] += s[j] * bf2f((u16)(ww[x] & 0xffff));
+                    o[c4 * 8 + 2 * x + 1] += s[j] * bf2f((u16)(ww[x] >> 16));
+                }
+            }
+        }
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        uint4 pk;
+        pk.x = pack2bf(o[c4 * 8 + 0] * inv, o[c4 * 8 + 1] * inv); pk.y = pack2bf(o[c4 * 8 + 2] * inv, o[c4 * 8 + 3] * inv);
+        pk.z = pack2bf(o[c4 * 8 + 4] * inv, o[c4 * 8 + 5] * inv); pk.w = pack2bf(o[c4 * 8 + 6] * inv, o[c4 * 8 + 7] * inv);
+        *(uint4*)(out + base + (long)i * C + c4 * 8) = pk;
+    }
+}
+
+// Token -> image cross attention (8 heads x 16, 4096 keys), transposed-score MFMA form (see attention.hip):
+//   S^T[t][j] = k_img[t] . q_tok[j],  online softmax over t per column j,  O^T[d][j] += V^T[d][t] P^T[t][j].
+// One workgroup per (prompt, head); the 4 waves split the 4096 keys and merge their (m, l, O) at the end.
+// k_img: bf16 [rows,128] (row = pk*4096 + t), vT: bf16 [Pk,128,4096]; kv_shared: all prompts use prompt 0's K/V.
+__global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ qtok, const u16* __restrict__ kimg,
+                                                       const u16* __restrict__ vT, int kv_shared, int Nt,
+                                                       u16* __restrict__ out) {
+    __shared__ float red[4][16][20];      // per wave: [j][m, l, o[16]] (+pad)
+    const int p = blockIdx.x >> 3, head = blockIdx.x & 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int pk = kv_shared ? 0 : p;
+    const u16* kb = kimg + (long)pk * T * CI + head * 16;
+    const u16* vb = vT + ((long)pk * CI + head * 16 + fr) * T;
+    // B operand: q_tok[j = fr][d = fg*8 ..] for fg < 2 (K = 16 zero-padded to 32)
+    uint4 qf = make_uint4(0, 0, 0, 0);
+    if (fg < 2 && fr < Nt) qf = *(const uint4*)(qtok + ((long)p * Nt + fr) * CI + head * 16 + fg * 8);
+    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+    float m = NEG_BIG, l = 0.f;
+    const int t_begin = wave * (T / 4), t_end = t_begin + T / 4;
+    for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+        uint4 ka0 = make_uint4(0, 0, 0, 0), ka1 = ka0;
+        if (fg < 2) {
+            ka0 = *(const uint4*)(kb + (long)(t0 + fr) * CI + fg * 8);
+            ka1 = *(const uint4*)(kb + (long)(t0 + 16 + fr) * CI + fg * 8);
+        }
+        const uint2 v0 = *(const uint2*)(vb + t0 + fg * 4), v1 = *(const uint2*)(vb + t0 + 16 + fg * 4);
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        s0 = mfma16(ka0, qf, s0);
+        s1 = mfma16(ka1, qf, s1);
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] *= 0.25f; s1[r] *= 0.25f; mt = fmaxf(mt, fmaxf(s0[r], s1[r])); }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt), alpha = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mn); s1[r] = __expf(s1[r] - mn); ps += s0[r] + s1[r]; }
+        l = l * alpha + ps;
+        uint4 pb;
+        pb.x = pack2bf(s0[0], s0[1]); pb.y = pack2bf(s0[2], s0[3]); pb.z = pack2bf(s1[0], s1[1]); pb.w = pack2bf(s1[2], s1[3]);
+        o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+        o = mfma16(make_uint4(v0.x, v0.y, v1.x, v1.y), pb, o);
+    }
+    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+    // merge the 4 waves: lane (j = fr, fg) holds o[d = fg*4 + r]
+    if (fg == 0) { red[wave][fr][0] = m; red[wave][fr][1] = l; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][fr][2 + fg * 4 + r] = o[r];
+    __syncthreads();
+    if (wave == 0 && fr < Nt) {
+        float mm = fmaxf(fmaxf(red[0][fr][0], red[1][fr][0]), fmaxf(red[2][fr][0], red[3][fr][0]));
+        float ll = 0.f, oo[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __expf(red[w][fr][0] - mm);
+            ll += a * red[w][fr][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oo[r] += a * red[w][fr][2 + fg * 4 + r];
+        }
+        const float inv = 1.f / ll;
+        uint2 pkd; pkd.x = pack2bf(oo[0] * inv, oo[1] * inv); pkd.y = pack2bf(oo[2] * inv, oo[3] * inv);
+        *(uint2*)(out + ((long)p * Nt + fr) * CI + head * 16 + fg * 4) = pkd;
+    }
+}
+
+// Image -> token cross attention: every image token attends over the Nt (<= 16) prompt tokens.
+//   S^T[j][t] = k_tok[j] . q_img[t]  (A = k_tok rows, B = q_img),  softmax over j = over the lane's registers and
+//   lane groups,  O^T[d][t] = V_tok^T[d][j] P^T[j][t].
+// grid = (16 chunks of 256 tokens, P); wave handles 4 tiles of 16 tokens x 8 heads.
+__global__ __launch_bounds__(256) void i2t_attn_kernel(const u16* __restrict__ qimg, int q_shared,
+                                                       const u16* __restrict__ ktok, const u16* __restrict__ vtok,
+                                                       int Nt, u16* __restrict__ out) {
+    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const u16* qb = qimg + (q_shared ? 0 : (long)p * T * CI);
+    u16* ob = out + (long)p * T * CI;
+    for (int head = 0; head < 8; ++head) {
+        // A operand for the scores: k_tok[j = fr][head*16 + fg*8 ..], fg < 2
+        uint4 ka = make_uint4(0, 0, 0, 0);
+        if (fg < 2 && fr < Nt) ka = *(const uint4*)(ktok + ((long)p * Nt + fr) * CI + head * 16 + fg * 8);
+        // A operand for PV: V^T[d = fr][j slot (fg, i)] = v_tok[j = fg*4 + i][head*16 + fr] for i < 4, else 0
+        uint4 va = make_uint4(0, 0, 0, 0);
+        {
+            u16 e[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = fg * 4 + i;
+                e[i] = j < Nt ? vtok[((long)p * Nt + j) * CI + head * 16 + fr] : (u16)0;
+            }
+            va.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16); va.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = blockIdx.x * 256 + (wave * 4 + tt) * 16 + fr;
+            uint4 qf = make_uint4(0, 0, 0, 0);
+            if (fg < 2) qf = *(const uint4*)(qb + (long)t * CI + head * 16 + fg * 8);
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+            s = mfma16(ka, qf, s);                       // rows j = fg*4 + r, col t = fr
+            float mt = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] = (fg * 4 + r < Nt) ? s[r] * 0.25f : NEG_BIG; mt = fmaxf(mt, s[r]); }
+            mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mt); ps += s[r]; }
+            ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+            uint4 pb; pb.x = pack2bf(s[0], s[1]); pb.y = pack2bf(s[2], s[3]); pb.z = 0; pb.w = 0;
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+            o = mfma16(va, pb, o);                       // rows d = fg*4 + r, col t = fr
+            const float inv = 1.f / ps;
+            uint2 pkd; pkd.x = pack2bf(o[0] * inv, o[1] * inv); pkd.y = pack2bf(o[2] * inv, o[3] * inv);
+            *(uint2*)(ob + (long)t * CI + head * 16 + fg * 4) = pkd;
+        }
+    }
+}
+
+// Fused second up-scaling stage: up1 bf16 [rows,64] (row = ((p*4096 + token)*4 + sub)) x W2 [128,64] ->
+// GELU(. + b2[c2]) . hyper[p][mask][c2]  -> low_res[p][mask'][y][x].
+// MFMA column (n-tile ni, lane column j) is mapped to weight row sub2*32 + c2 with sub2 = j >> 2,
+// c2 = (j & 3)*8 + ni, so the 32-channel reduction is 8 in-lane FMAs + 2 xor-shuffles.
+// One wave = 32 rows x 128 columns; persistent workgroups stride over 128-row tiles.
+__global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restrict__ up1, const u16* __restrict__ w2,
+                                                             const float* __restrict__ b2, const float* __restrict__ hyper,
+                                                             int hyper_ld, int mask0, int nmask, long rows,
+                                                             float* __restrict__ low_res) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int sub2 = fr >> 2, cq = (fr & 3) * 8;
+    uint4 wb[8][2];
+    float bias[8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni) {
+        const int wrow = sub2 * 32 + cq + ni;
+        wb[ni][0] = *(const uint4*)(w2 + wrow * 64 + fg * 8);
+        wb[ni][1] = *(const uint4*)(w2 + wrow * 64 + 32 + fg * 8);
+        bias[ni] = b2[cq + ni];
+    }
+    const long ntiles = rows / 128;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * 128 + wave * 32;
+        const int p = (int)(row0 / (T * 4));
+        float h[3][8];
+#pragma unroll
+        for (int mk = 0; mk < 3; ++mk)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+                h[mk][ni] = mk < nmask ? hyper[((long)p * 4 + mask0 + mk) * hyper_ld + cq + ni] : 0.f;
+        f32x4_t acc[2][8];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const u16* ar = up1 + (row0 + mi * 16 + fr) * 64;
+            const uint4 a0 = *(const uint4*)(ar + fg * 8), a1 = *(const uint4*)(ar + 32 + fg * 8);
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                c = mfma16(a0, wb[ni][0], c);
+                c = mfma16(a1, wb[ni][1], c);
+                acc[mi][ni] = c;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float part[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni) {
+                    const float g = gelu_erf(acc[mi][ni][r] + bias[ni]);
+#pragma unroll
+                    for (int mk = 0; mk < 3; ++mk) part[mk] += g * h[mk][ni];
+                }
+#pragma unroll
+                for (int mk = 0; mk < 3; ++mk) {
+                    part[mk] += __shfl_xor(part[mk], 1);
+                    part[mk] += __shfl_xor(part[mk], 2);
+                }
+                if ((fr & 3) == 0) {
+                    const long row = row0 + mi * 16 + fg * 4 + r;
+                    const int sub = (int)(row & 3), token = (int)((row >> 2) & (T - 1));
+                    const int y = (token >> 6) * 4 + (sub >> 1) * 2 + (sub2 >> 1);
+                    const int x = (token & 63) * 4 + (sub & 1) * 2 + (sub2 & 1);
+#pragma unroll
+                    for (int mk = 0; mk < 3; ++mk)
+                        if (mk < nmask) low_res[(((long)p * nmask + mk) * 256 + y) * 256 + x] = part[mk];
+                }
+            }
+        }
+    }
+}
+
+inline int grid_for(long items) { long g = (items + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
+
+// ------------------------------------------------------------------------------------------ host helpers
+
+struct Ctx { hipStream_t s; int use_glds; };
+
+int gemm(const Ctx& cx, const void* A, long lda, const void* W, int M, int N, int K, const float* bias, void* out,
+         int out_dtype, long ldc, int act = 0, const void* resid = nullptr, int resid_dtype = 0, long ldr = 0,
+         int resid_rows = 0, const float* table = nullptr, int table_cols = 0) {
+    msam_gemm_t g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    g.table = table; g.table_rows = T; g.table_cols = table_cols; g.table_ld = CI;
+    g.resid = resid; g.resid_dtype = resid_dtype; g.resid_rows = resid_rows; g.ldr = ldr;
+    g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc; g.out_mode = 0; g.use_glds = cx.use_glds;
+    return msam_gemm_bf16(&g, cx.s);
+}
+
+// K | V^T projection of an image-token stream x[rows,256] with the concatenated weight [Wk; Wv] (bf16 [256,256])
+int gemm_kv(const Ctx& cx, const void* x, int rows, const void* wkv, const float* bkv, const float* pek, void* k_out,
+            void* vT_out) {
+    msam_gemm_t g{};
+    g.A = x; g.lda = C; g.W = wkv; g.ldw = C; g.M = rows; g.N = 256; g.K = C; g.bias = bkv;
+    g.table = pek; g.table_rows = T; g.table_cols = CI; g.table_ld = CI;
+    g.out_mode = 2; g.k = k_out; g.v = vT_out; g.tokens = T; g.use_glds = cx.use_glds;
+    return msam_gemm_bf16(&g, cx.s);
+}
+
+struct Consts {     // layout of the `consts` buffer
+    float* pos_f32; u16* pos_bf16; float* pe_k[3]; float* pe_q[2]; u16* wkv[3]; float* bkv[3];
+};
+constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4;
+
+Consts carve_consts(void* base) {
+    Consts c; char* p = (char*)base;
+    c.pos_f32 = (float*)p; p += (long)T * C * 4;
+    c.pos_bf16 = (u16*)p; p += (long)T * C * 2;
+    for (int i = 0; i < 3; ++i) { c.pe_k[i] = (float*)p; p += (long)T * CI * 4; }
+    for (int i = 0; i < 2; ++i) { c.pe_q[i] = (float*)p; p += (long)T * CI * 4; }
+    for (int i = 0; i < 3; ++i) { c.wkv[i] = (u16*)p; p += (long)C * C * 2; }
+    for (int i = 0; i < 3; ++i) { c.bkv[i] = (float*)p; p += (long)C * 4; }
+    return c;
+}
+
+struct ImageState { float* src_f32; u16* src_bf16; u16* k0; u16* vT0; u16* q0; };
+constexpr long IMAGE_BYTES = (long)T * C * 4 + (long)T * C * 2 + 3L * T * CI * 2;
+
+ImageState carve_image(void* base) {
+    ImageState s; char* p = (char*)base;
+    s.src_f32 = (float*)p; p += (long)T * C * 4;
+    s.src_bf16 = (u16*)p; p += (long)T * C * 2;
+    s.k0 = (u16*)p; p += (long)T * CI * 2;
+    s.vT0 = (u16*)p; p += (long)T * CI * 2;
+    s.q0 = (u16*)p; p += (long)T * CI * 2;
+    return s;
+}
+
+inline long align256(long x) { return (x + 255) & ~255L; }
+
+}  // namespace
+
+extern "C" int64_t msam_decoder_const_bytes(void) { return CONST_BYTES; }
+extern "C" int64_t msam_decoder_image_bytes(void) { return IMAGE_BYTES; }
+
+extern "C" int msam_decoder_prepare_const(const msam_decoder_t* dec, void* consts, void* stream) {
+    if (!dec || !consts) { msam_set_error("msam_decoder_prepare_const: null argument"); return 1; }
+    Ctx cx{(hipStream_t)stream, dec->use_glds};
+    Consts c = carve_consts(consts);
+    hipLaunchKernelGGL(dense_pe_kernel, dim3(T * 128 / 256), dim3(256), 0, cx.s, dec->pe_gauss, c.pos_f32, c.pos_bf16);
+    if (int e = msam_check_launch("dense_pe")) return e;
+    // concatenated [Wk; Wv] weights / biases of the three token->image attentions (device-to-device copies)
+    const msam_attn_w_t* t2i[3] = {&dec->layer[0].t2i, &dec->layer[1].t2i, &dec->final_attn};
+    for (int i = 0; i < 3; ++i) {
+        hipMemcpyAsync(c.wkv[i], t2i[i]->k_w, (size_t)CI * C * 2, hipMemcpyDeviceToDevice, cx.s);
+        hipMemcpyAsync(c.wkv[i] + (long)CI * C, t2i[i]->v_w, (size_t)CI * C * 2, hipMemcpyDeviceToDevice, cx.s);
+        hipMemcpyAsync(c.bkv[i], t2i[i]->k_b, CI * 4, hipMemcpyDeviceToDevice, cx.s);
+        hipMemcpyAsync(c.bkv[i] + CI, t2i[i]->v_b, CI * 4, hipMemcpyDeviceToDevice, cx.s);
+        // pos . Wk^T (no bias): added to the k half through the GEMM table epilogue
+        if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, nullptr, c.pe_k[i], MSAM_F32, CI)) return e;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, nullptr, c.pe_q[i], MSAM_F32, CI)) return e;
+    return 0;
+}
+
+extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void* consts, const float* embedding,
+                                          void* image_state, void* workspace, int64_t workspace_bytes, void* stream) {
+    (void)workspace; (void)workspace_bytes;
+    if (!dec || !consts || !embedding || !image_state) { msam_set_error("msam_decoder_prepare_image: null argument"); return 1; }
+    Ctx cx{(hipStream_t)stream, dec->use_glds};
+    Consts c = carve_consts((void*)consts);
+    ImageState im = carve_image(image_state);
+    hipLaunchKernelGGL(src_prepare_kernel, dim3(T / 32, C / 32), dim3(256), 0, cx.s, embedding, dec->no_mask, im.src_f32,
+                       im.src_bf16);
+    if (int e = msam_check_launch("src_prepare")) return e;
+    if (int e = gemm_kv(cx, im.src_bf16, T, c.wkv[0], c.bkv[0], c.pe_k[0], im.k0, im.vT0)) return e;
+    return gemm(cx, im.src_bf16, C, dec->layer[0].i2t.q_w, T, CI, C, dec->layer[0].i2t.q_b, im.q0, MSAM_BF16, CI, 0,
+                nullptr, 0, 0, 0, c.pe_q[0], CI);
+}
+
+namespace {
+struct Work {
+    float *qpe, *queries, *tmp; u16 *a, *b, *qs, *ks, *vs, *attn_tok, *mlp_h;
+    u16 *keys, *kimg, *vT, *qimg, *attn_img, *up1; float* pre;
+    u16 *hh0, *hh1; float *hyper, *iou_full;
+};
+long work_bytes(int P, int Nt) {
+    const long M = (long)P * Nt, R = (long)P * T;
+    long b = 0;
+    b += 3 * align256(M * C * 4);                 // qpe, queries, tmp
+    b += 6 * align256(M * C * 2);                 // a, b, qs, ks, vs, attn_tok
+    b += align256(M * 2048 * 2);                  // mlp_h
+    b += align256(R * C * 2);                     // keys
+    b += 4 * align256(R * CI * 2);                // kimg, vT, qimg, attn_img
+    b += align256(R * C * 2);                     // up1
+    b += align256(R * C * 4);                     // pre
+    b += 2 * align256((long)P * C * 2);           // hh0, hh1
+    b += align256((long)P * 4 * 128 * 4) + align256((long)P * 128 * 4);
+    return b;
+}
+Work carve_work(void* base, int P, int Nt) {
+    const long M = (long)P * Nt, R = (long)P * T;
+    Work w; char* p = (char*)base;
+    auto take = [&](long bytes) { char* r = p; p += align256(bytes); return r; };
+    w.qpe = (float*)take(M * C * 4); w.queries = (float*)take(M * C * 4); w.tmp = (float*)take(M * C * 4);
+    w.a = (u16*)take(M * C * 2); w.b = (u16*)take(M * C * 2); w.qs = (u16*)take(M * C * 2); w.ks = (u16*)take(M * C * 2);
+    w.vs = (u16*)take(M * C * 2); w.attn_tok = (u16*)take(M * C * 2);
+    w.mlp_h = (u16*)take(M * 2048 * 2);
+    w.keys = (u16*)take(R * C * 2);
+    w.kimg = (u16*)take(R * CI * 2); w.vT = (u16*)take(R * CI * 2); w.qimg = (u16*)take(R * CI * 2);
+    w.attn_img = (u16*)take(R * CI * 2);
+    w.up1 = (u16*)take(R * C * 2);
+    w.pre = (float*)take(R * C * 4);
+    w.hh0 = (u16*)take((long)P * C * 2); w.hh1 = (u16*)take((long)P * C * 2);
+    w.hyper = (float*)take((long)P * 4 * 128 * 4); w.iou_full = (float*)take((long)P * 128 * 4);
+    return w;
+}
+
+__global__ void gather_iou_kernel(const float* __restrict__ iou_full, int P, int c0, int nc, float* __restrict__ iou) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < P * nc) iou[i] = iou_full[(long)(i / nc) * 128 + c0 + (i % nc)];
+}
+}  // namespace
+
+extern "C" int64_t msam_decoder_workspace_bytes(int32_t P) { return work_bytes(P, 16); }
+
+extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* consts, const void* image_state,
+                                    const float* points, const int32_t* labels, int32_t Np, const float* boxes, int32_t P,
+                                    int32_t multimask, float* low_res, float* iou, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+    if (!dec || !consts || !image_state || !low_res || !iou || !workspace || P <= 0) {
+        msam_set_error("msam_decoder_forward: null argument");
+        return 1;
+    }
+    if ((!points || Np <= 0) && !boxes) { msam_set_error("msam_decoder_forward: need points and/or boxes"); return 1; }
+    if (!points) Np = 0;
+    const int Nt = 5 + Np + (boxes ? 2 : (Np > 0 ? 1 : 0));
+    if (Nt > 16) { msam_set_error("msam_decoder_forward: at most 16 tokens per prompt (<= 10 points)"); return 1; }
+    if (workspace_bytes < work_bytes(P, Nt)) { msam_set_error("msam_decoder_forward: workspace too small"); return 1; }
+    Ctx cx{(hipStream_t)stream, dec->use_glds};
+    Consts c = carve_consts((void*)consts);
+    ImageState im = carve_image((void*)image_state);
+    Work w = carve_work(workspace, P, Nt);
+    const int M = P * Nt;
+    const long R = (long)P * T;
+    const long n4 = (long)M * C / 4;
+    int e;
+#define CHECK(x) do { if ((e = (x))) return e; } while (0)
+#define ADD_CAST(a_, b_, out_) do { hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n4)), dim3(256), 0, cx.s, a_, b_, out_, n4); \
+                                     CHECK(msam_check_launch("add_cast")); } while (0)
+#define LN(x_, w_, b_, rows_, out_, dt_) CHECK(msam_layernorm(x_, w_, b_, 1e-5f, rows_, C, out_, dt_, 0, 0, cx.s))
+
+    hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, cx.s, dec->pe_gauss, dec->point_embed, dec->not_a_point,
+                       dec->out_tokens, points, labels, Np, boxes, P, Nt, w.qpe);
+    CHECK(msam_check_launch("prompt_tokens"));
+    hipMemcpyAsync(w.queries, w.qpe, (size_t)M * C * 4, hipMemcpyDeviceToDevice, cx.s);
+
+    // test hook: MSAM_DEBUG_DEC_LAYERS=0/1 stops the two-way transformer early so that intermediate workspace buffers
+    // can be compared with the oracle's per-layer taps (outputs are then NOT the model's outputs)
+    const char* dbg = getenv("MSAM_DEBUG_DEC_LAYERS");
+    const int nlayers = dbg ? atoi(dbg) : 2;
+    for (int li = 0; li < nlayers && li < 2; ++li) {
+        const msam_twoway_layer_t& L = dec->layer[li];
+        // (1) token self attention
+        ADD_CAST(w.queries, li == 0 ? nullptr : w.qpe, w.a);          // q = k input
+        ADD_CAST(w.queries, nullptr, w.b);                            // v input
+        CHECK(gemm(cx, w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_BF16, C));
+        CHECK(gemm(cx, w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_BF16, C));
+        CHECK(gemm(cx, w.b, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_BF16, C));
+        hipLaunchKernelGGL(token_self_attn_kernel, dim3(P), dim3(128), 0, cx.s, w.qs, w.ks, w.vs, Nt, w.attn_tok);
+        CHECK(msam_check_launch("token_self_attn"));
+        CHECK(gemm(cx, w.attn_tok, C, L.self_attn.o_w, M, C, C, L.self_attn.o_b, w.tmp, MSAM_F32, C, 0,
+                   li == 0 ? nullptr : w.queries, li == 0 ? 0 : MSAM_F32, C));
+        LN(w.tmp, L.n1_w, L.n1_b, M, w.queries, MSAM_F32);
+        // (2) token -> image attention
+        ADD_CAST(w.queries, w.qpe, w.a);
+        CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_BF16, CI));
+        if (li == 0) {
+            hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
+        } else {
+            CHECK(gemm_kv(cx, w.keys, (int)R, c.wkv[1], c.bkv[1], c.pe_k[1], w.kimg, w.vT));
+            hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
+        }
+        CHECK(msam_check_launch("t2i_attn"));
+        CHECK(gemm(cx, w.attn_tok, CI, L.t2i.o_w, M, C, CI, L.t2i.o_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
+        LN(w.tmp, L.n2_w, L.n2_b, M, w.queries, MSAM_F32);
+        // (3) token MLP
+        ADD_CAST(w.queries, nullptr, w.a);
+        CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_BF16, 2048, MSAM_ACT_RELU));
+        CHECK(gemm(cx, w.mlp_h, 2048, L.mlp2_w, M, C, 2048, L.mlp2_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
+        LN(w.tmp, L.n3_w, L.n3_b, M, w.queries, MSAM_F32);
+        // (4) image -> token attention, updates the image-token stream
+        ADD_CAST(w.queries, w.qpe, w.a);
+        ADD_CAST(w.queries, nullptr, w.b);
+        CHECK(gemm(cx, w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI));
+        CHECK(gemm(cx, w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI));
+        if (li == 0) {
+            hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, im.q0, 1, w.ks, w.vs, Nt, w.attn_img);
+        } else {
+            CHECK(gemm(cx, w.keys, C, L.i2t.q_w, (int)R, CI, C, L.i2t.q_b, w.qimg, MSAM_BF16, CI, 0, nullptr, 0, 0, 0,
+                       c.pe_q[1], CI));
+            hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, w.qimg, 0, w.ks, w.vs, Nt, w.attn_img);
+        }
+        CHECK(msam_check_launch("i2t_attn"));
+        if (li == 0)
+            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.pre, MSAM_F32, C, 0, im.src_bf16,
+                       MSAM_BF16, C, T));
+        else
+            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.pre, MSAM_F32, C, 0, w.keys, MSAM_BF16, C));
+        LN(w.pre, L.n4_w, L.n4_b, R, w.keys, MSAM_BF16);
+    }
+    if (dbg) return 0;   // test hook: leave queries / keys of the last executed layer in the workspace
+    // final token -> image attention
+    ADD_CAST(w.queries, w.qpe, w.a);
+    CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_BF16, CI));
+    CHECK(gemm_kv(cx, w.keys, (int)R, c.wkv[2], c.bkv[2], c.pe_k[2], w.kimg, w.vT));
+    hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
+    CHECK(msam_check_launch("t2i_attn_final"));
+    CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
+               MSAM_F32, C));
+    LN(w.tmp, dec->nf_w, dec->nf_b, M, w.queries, MSAM_F32);
+
+    // heads: hyper-network MLPs on mask tokens 1..4, IoU head on token 0 (bf16 copy of queries, strided rows)
+    ADD_CAST(w.queries, nullptr, w.a);
+    for (int i = 0; i < 4; ++i) {
+        const u16* tok = w.a + (long)(1 + i) * C;
+        CHECK(gemm(cx, tok, (long)Nt * C, dec->hyp_w[i][0], P, C, C, dec->hyp_b[i][0], w.hh0, MSAM_BF16, C, MSAM_ACT_RELU));
+        CHECK(gemm(cx, w.hh0, C, dec->hyp_w[i][1], P, C, C, dec->hyp_b[i][1], w.hh1, MSAM_BF16, C, MSAM_ACT_RELU));
+        CHECK(gemm(cx, w.hh1, C, dec->hyp_w[i][2], P, 128, C, dec->hyp_b[i][2], w.hyper + (long)i * 128, MSAM_F32, 4 * 128));
+    }
+    CHECK(gemm(cx, w.a, (long)Nt * C, dec->iou_w[0], P, C, C, dec->iou_b[0], w.hh0, MSAM_BF16, C, MSAM_ACT_RELU));
+    CHECK(gemm(cx, w.hh0, C, dec->iou_w[1], P, C, C, dec->iou_b[1], w.hh1, MSAM_BF16, C, MSAM_ACT_RELU));
+    CHECK(gemm(cx, w.hh1, C, dec->iou_w[2], P, 128, C, dec->iou_b[2], w.iou_full, MSAM_F32, 128));
+    const int mask0 = multimask ? 1 : 0, nmask = multimask ? 3 : 1;
+    hipLaunchKernelGGL(gather_iou_kernel, dim3((P * nmask + 255) / 256), dim3(256), 0, cx.s, w.iou_full, P, mask0, nmask, iou);
+    CHECK(msam_check_launch("gather_iou"));
+
+    // up-scaling: ConvT1 as GEMM (+bias per output channel, expanded to 256 columns) -> LN2d(64)+GELU -> fused ConvT2
+    CHECK(gemm(cx, w.keys, C, dec->up1_w, (int)R, C, C, dec->up1_b, w.pre, MSAM_F32, C));
+    CHECK(msam_layernorm(w.pre, dec->up_ln_w, dec->up_ln_b, 1e-6f, R * 4, 64, w.up1, MSAM_BF16, 1, 0, cx.s));
+    {
+        const long rows = R * 4;
+        long tiles = rows / 128;
+        int grid = (int)(tiles < 2048 ? tiles : 2048);
+        hipLaunchKernelGGL(upscale2_hyper_kernel, dim3(grid), dim3(256), 0, cx.s, w.up1, (const u16*)dec->up2_w, dec->up2_b,
+                           w.hyper, 128, mask0, nmask, rows, low_res);
+        CHECK(msam_check_launch("upscale2_hyper"));
+    }
+#undef CHECK
+#undef ADD_CAST
+#undef LN
+    return 0;
+}

@@ -1,0 +1,102 @@
+// Host-side sequencing of the SAM ViT image encoder on the HIP kernels (no device code in this file).
+// Stands behind `predictor.model.image_encoder(x)` (micro_sam/util.py:674) and, with uint8 input, also fuses
+// `predictor.model.preprocess` (util.py:670).  Hyper-parameters: micro_sam/models/build_sam.py:40-113.
+//
+// Residual stream x: fp32 [B*4096, D].  Every GEMM operand is bf16 (LN output, attention output, GELU output).
+// Windowed blocks run on the 4096 real tokens only: the reference pads LN output with zeros to 70x70, so padding
+// tokens are exactly q/k/v = bias, which the window attention kernel synthesises (no partition / un-partition copies).
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+constexpr long TOK = 4096;
+inline long al(long x) { return (x + 255) & ~255L; }
+struct EncWork { float* x; u16 *xn, *patches, *q, *k, *v, *attn, *hid, *n1, *col; float *n0, *n2; };
+long enc_bytes(int D, int B) {
+    const long R = (long)B * TOK;
+    return al(R * D * 4) + al(R * D * 2) + al(R * 768 * 2) + 3 * al(R * D * 2) + al(R * D * 2) + al(R * 4 * D * 2) +
+           al(R * 256 * 2) + al(R * 2304 * 2) + 2 * al(R * 256 * 4);
+}
+EncWork carve(void* base, int D, int B) {
+    const long R = (long)B * TOK;
+    char* p = (char*)base; EncWork w;
+    auto take = [&](long b) { char* r = p; p += al(b); return r; };
+    w.x = (float*)take(R * D * 4); w.xn = (u16*)take(R * D * 2); w.patches = (u16*)take(R * 768 * 2);
+    w.q = (u16*)take(R * D * 2); w.k = (u16*)take(R * D * 2); w.v = (u16*)take(R * D * 2);
+    w.attn = (u16*)take(R * D * 2); w.hid = (u16*)take(R * 4 * D * 2);
+    w.n1 = (u16*)take(R * 256 * 2); w.col = (u16*)take(R * 2304 * 2);
+    w.n0 = (float*)take(R * 256 * 4); w.n2 = (float*)take(R * 256 * 4);
+    return w;
+}
+}  // namespace
+
+extern "C" int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B) {
+    if (!enc || B <= 0) return 0;
+    return enc_bytes(enc->embed_dim, B);
+}
+
+extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_f32, const uint8_t* img_u8, int32_t h,
+                                    int32_t w_, int32_t B, float* out, void* workspace, int64_t workspace_bytes, float* tap,
+                                    int32_t tap_block, void* stream) {
+    if (!enc || !out || !workspace || B <= 0 || (!img_f32 && !img_u8)) { msam_set_error("msam_encoder_forward: null argument"); return 1; }
+    const int D = enc->embed_dim, H = enc->heads;
+    if (D % 128 || H <= 0 || D / H != 64 || enc->depth > MSAM_MAX_BLOCKS) {
+        msam_set_error("msam_encoder_forward: unsupported geometry (need embed_dim % 128 == 0 and head_dim == 64: vit_b / vit_l)");
+        return 1;
+    }
+    if (workspace_bytes < enc_bytes(D, B)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    EncWork w = carve(workspace, D, B);
+    const int R = (int)(B * TOK);
+    int e;
+#define CHECK(x) do { if ((e = (x))) return e; } while (0)
+    auto gemm = [&](const void* A, long lda, const void* W, int N, int K, const float* bias, void* o, int odt, long ldc,
+                    int act, const void* resid, int rdt, long ldr, const float* table, int trows, int tcols, long tld) {
+        msam_gemm_t g{};
+        g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = R; g.N = N; g.K = K; g.bias = bias;
+        g.table = table; g.table_rows = trows; g.table_cols = tcols; g.table_ld = tld;
+        g.resid = resid; g.resid_dtype = rdt; g.ldr = ldr; g.act = act; g.out = o; g.out_dtype = odt; g.ldc = ldc;
+        g.use_glds = enc->use_glds;
+        return msam_gemm_bf16(&g, s);
+    };
+    // patch embedding (+ bias + absolute position embedding)
+    if (img_u8) CHECK(msam_patchify_u8(img_u8, B, h, w_, w.patches, s));
+    else CHECK(msam_patchify(img_f32, B, w.patches, s));
+    CHECK(gemm(w.patches, 768, enc->patch_w, D, 768, enc->patch_b, w.x, MSAM_F32, D, 0, nullptr, 0, 0, enc->pos_embed,
+               (int)TOK, D, D));
+    for (int i = 0; i < enc->depth; ++i) {
+        CHECK(msam_layernorm(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
+        {
+            msam_gemm_t g{};
+            g.A = w.xn; g.lda = D; g.W = enc->qkv_w[i]; g.ldw = D; g.M = R; g.N = 3 * D; g.K = D; g.bias = enc->qkv_b[i];
+            g.out_mode = 1; g.q = w.q; g.k = w.k; g.v = w.v; g.heads = H; g.head_dim = 64; g.tokens = (int)TOK;
+            g.use_glds = enc->use_glds;
+            CHECK(msam_gemm_bf16(&g, s));
+        }
+        if (enc->is_global[i]) CHECK(msam_global_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], B, H, w.attn, s));
+        else CHECK(msam_window_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], enc->qkv_b[i], B, H, w.attn, s));
+        CHECK(gemm(w.attn, D, enc->proj_w[i], D, D, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0, 0, 0));
+        CHECK(msam_layernorm(w.x, enc->ln2_w[i], enc->ln2_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
+        CHECK(gemm(w.xn, D, enc->lin1_w[i], 4 * D, D, enc->lin1_b[i], w.hid, MSAM_BF16, 4 * D, MSAM_ACT_GELU, nullptr, 0, 0,
+                   nullptr, 0, 0, 0));
+        CHECK(gemm(w.hid, 4 * D, enc->lin2_w[i], D, 4 * D, enc->lin2_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0,
+                   0, 0));
+        if (tap && tap_block == i)
+            if (hipMemcpyAsync(tap, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                msam_set_error("msam_encoder_forward: tap copy failed");
+                return 2;
+            }
+    }
+    // neck: conv1x1 -> LayerNorm2d -> conv3x3 (pad 1) -> LayerNorm2d, output NCHW fp32
+    CHECK(msam_cast_f32_to_bf16(w.x, w.xn, (long)R * D, s));
+    CHECK(gemm(w.xn, D, enc->neck0_w, 256, D, nullptr, w.n0, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
+    CHECK(msam_layernorm(w.n0, enc->neck1_w, enc->neck1_b, 1e-6f, R, 256, w.n1, MSAM_BF16, 0, 0, s));
+    CHECK(msam_im2col3x3(w.n1, B, 256, w.col, s));
+    CHECK(gemm(w.col, 2304, enc->neck2_w, 256, 2304, nullptr, w.n2, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
+    CHECK(msam_layernorm(w.n2, enc->neck3_w, enc->neck3_b, 1e-6f, R, 256, out, MSAM_F32, 0, (int)TOK, s));
+#undef CHECK
+    return 0;
+}

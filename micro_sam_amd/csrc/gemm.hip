@@ -1,0 +1,282 @@
+// bf16 x bf16 -> fp32 MFMA GEMM with fused epilogues, C = act(A[M,K] * W[N,K]^T + bias + table + resid).
+// Both operands are K-contiguous ("NT"), so A and B fragments are single 16-byte reads.
+// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16 tiles.
+// LDS: 2 buffers x (A 16 KB + B 16 KB), rows of 128 B XOR-swizzled per 16-B chunk (common.h swz()).
+// Two staging variants (msam_gemm_t.use_glds):
+//   0: global_load_dwordx4 -> VGPR -> ds_write_b128, next tile's loads in flight during the MFMA phase
+//   1: global_load_lds_dwordx4 (LDS-DMA), swizzle applied on the per-lane SOURCE address (LDS image linear)
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_CHUNKS = BM * 8;   // 16-B chunks per operand tile
+
+struct Epi {
+    const float* bias; const float* table; int table_rows, table_cols; long table_ld;
+    const void* resid; int resid_dtype, resid_rows; long ldr;
+    int act;
+    void* out; int out_dtype; long ldc;
+    int out_mode; u16* q; u16* k; u16* v; int heads, head_dim, tokens;
+};
+
+template <bool GLDS>
+__global__ __launch_bounds__(256) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
+                                                   long ldw, int M, int N, int K, Epi e) {
+    __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TILE_CHUNKS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
+    // XCD-aware remap (bijective): consecutive tiles (sharing the A panel) run on one XCD / one L2
+    int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    {
+        int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging map: thread t covers LDS chunk position (row = pass*32 + t/8, c' = t%8), which holds global
+    // chunk c' ^ swz(row)
+    const int srow = tid >> 3, scp = tid & 7;
+    const u16* a_src[4]; const u16* w_src[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int row = p * 32 + srow;
+        int gc = scp ^ swz(row);
+        int ar = m0 + row; if (ar > M - 1) ar = M - 1;
+        a_src[p] = A + (long)ar * lda + gc * 8;
+        w_src[p] = W + (long)(n0 + row) * ldw + gc * 8;
+    }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+    (void)ra0; (void)rw0;
+
+#define MSAM_ISSUE(kt_, buf_)                                                                          \
+    do {                                                                                               \
+        if constexpr (GLDS) {                                                                          \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                            \
+                /* wave-uniform LDS base for this wave & pass; lane l lands at base + l*16 */          \
+                uint4* la = &lds[buf_][0][(p * 32 + wave * 8) * 8];                                    \
+                uint4* lw = &lds[buf_][1][(p * 32 + wave * 8) * 8];                                    \
+                __builtin_amdgcn_global_load_lds(                                                      \
+                    (const __attribute__((address_space(1))) void*)(a_src[p] + (long)(kt_) * BK),      \
+                    (__attribute__((address_space(3))) void*)la, 16, 0, 0);                            \
+                __builtin_amdgcn_global_load_lds(                                                      \
+                    (const __attribute__((address_space(1))) void*)(w_src[p] + (long)(kt_) * BK),      \
+                    (__attribute__((address_space(3))) void*)lw, 16, 0, 0);                            \
+            }                                                                                          \
+        } else {                                                                                       \
+            ra0 = *(const uint4*)(a_src[0] + (long)(kt_) * BK);                                        \
+            ra1 = *(const uint4*)(a_src[1] + (long)(kt_) * BK);                                        \
+            ra2 = *(const uint4*)(a_src[2] + (long)(kt_) * BK);                                        \
+            ra3 = *(const uint4*)(a_src[3] + (long)(kt_) * BK);                                        \
+            rw0 = *(const uint4*)(w_src[0] + (long)(kt_) * BK);                                        \
+            rw1 = *(const uint4*)(w_src[1] + (long)(kt_) * BK);                                        \
+            rw2 = *(const uint4*)(w_src[2] + (long)(kt_) * BK);                                        \
+            rw3 = *(const uint4*)(w_src[3] + (long)(kt_) * BK);                                        \
+        }                                                                                              \
+    } while (0)
+#define MSAM_COMMIT(buf_)                                                                              \
+    do {                                                                                               \
+        if constexpr (!GLDS) {                                                                         \
+            lds[buf_][0][(0 * 32 + srow) * 8 + scp] = ra0;                                             \
+            lds[buf_][0][(1 * 32 + srow) * 8 + scp] = ra1;                                             \
+            lds[buf_][0][(2 * 32 + srow) * 8 + scp] = ra2;                                             \
+            lds[buf_][0][(3 * 32 + srow) * 8 + scp] = ra3;                                             \
+            lds[buf_][1][(0 * 32 + srow) * 8 + scp] = rw0;                                             \
+            lds[buf_][1][(1 * 32 + srow) * 8 + scp] = rw1;                                             \
+            lds[buf_][1][(2 * 32 + srow) * 8 + scp] = rw2;                                             \
+            lds[buf_][1][(3 * 32 + srow) * 8 + scp] = rw3;                                             \
+        }                                                                                              \
+    } while (0)
+
+    MSAM_ISSUE(0, 0);
+    MSAM_COMMIT(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) MSAM_ISSUE(kt + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int row = wm * 64 + i * 16 + fr;
+                a[i] = lds[buf][0][row * 8 + ((ks * 4 + fg) ^ swz(row))];
+                int col = wn * 64 + i * 16 + fr;
+                b[i] = lds[buf][1][col * 8 + ((ks * 4 + fg) ^ swz(col))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) MSAM_COMMIT(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: stage the fp32 C tile through LDS (reusing the operand buffers), then every thread
+    // handles 4 consecutive columns of one row per pass -> 16-byte loads of bias/table/resid, 8/16-byte stores
+    float* ldsC = (float*)&lds[0][0][0];          // [128][128] fp32 = 64 KB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ldsC[(wm * 64 + i * 16 + fg * 4 + r) * BN + wn * 64 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+
+    const int c4 = (tid & 31) * 4;                // column offset inside the tile
+    const int col = n0 + c4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.bias) { float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+    const bool use_table = e.table && col < e.table_cols;   // table_cols % 4 == 0
+    // qkv-split constants (4 consecutive columns stay inside one head: head_dim % 4 == 0)
+    int which = 0, head = 0, d = 0;
+    if (e.out_mode == 1) {
+        const int D = e.heads * e.head_dim;
+        which = col / D; int rem = col - which * D; head = rem / e.head_dim; d = rem - head * e.head_dim;
+    }
+    for (int pass = 0; pass < 16; ++pass) {
+        const int lr = pass * 8 + (tid >> 5);
+        const int row = m0 + lr;
+        if (row >= M) break;      // rows only grow with pass: uniform tail, no barrier inside the loop
+        float4 c = *(const float4*)(ldsC + lr * BN + c4);
+        float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+        if (use_table) {
+            float4 t = *(const float4*)(e.table + (long)(row % e.table_rows) * e.table_ld + col);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (e.resid_dtype) {
+            const int rr = e.resid_rows ? (row % e.resid_rows) : row;
+            if (e.resid_dtype == MSAM_F32) {
+                float4 t = *(const float4*)((const float*)e.resid + (long)rr * e.ldr + col);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            } else {
+                uint2 t = *(const uint2*)((const u16*)e.resid + (long)rr * e.ldr + col);
+                v[0] += bf2f((u16)(t.x & 0xffff)); v[1] += bf2f((u16)(t.x >> 16));
+                v[2] += bf2f((u16)(t.y & 0xffff)); v[3] += bf2f((u16)(t.y >> 16));
+            }
+        }
+        if (e.act == MSAM_ACT_GELU) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
+        } else if (e.act == MSAM_ACT_RELU) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
+        }
+        if (e.out_mode == 0) {
+            if (e.out_dtype == MSAM_F32) {
+                *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
+            }
+        } else if (e.out_mode == 1) {
+            u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
+            const int b = row / e.tokens, t = row - b * e.tokens;
+            uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+            *(uint2*)(dst + ((long)(b * e.heads + head) * e.tokens + t) * e.head_dim + d) = pk;
+        } else {
+            // out_mode 2 (decoder K|V projection, N == 256): k half stored row-major [M,128]; the v half is
+            // written back to LDS (activated, bf16-rounded values) and stored transposed below
+            if (col < 128) {
+                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                *(uint2*)(e.k + (long)row * 128 + col) = pk;
+            } else {
+                *(float4*)(ldsC + lr * BN + c4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    if (e.out_mode == 2 && n0 == 128) {
+        // vT[b][d][t]: thread -> (d = tid & 127, token half = tid >> 7): 64 consecutive tokens = 128 B contiguous
+        __syncthreads();
+        const int dd = tid & 127, th = tid >> 7;
+        const int b = m0 / e.tokens, t0 = m0 - b * e.tokens + th * 64;     // tokens % 128 == 0: tile inside one b
+        u16* dst = e.v + ((long)b * 128 + dd) * e.tokens + t0;
+        for (int i = 0; i < 64; i += 8) {
+            if (m0 + th * 64 + i >= M) break;                               // M % 8 == 0 enforced by the launcher
+            uint4 pk;
+            const float* src = ldsC + (th * 64 + i) * BN + dd;
+            pk.x = pack2bf(src[0], src[BN]); pk.y = pack2bf(src[2 * BN], src[3 * BN]);
+            pk.z = pack2bf(src[4 * BN], src[5 * BN]); pk.w = pack2bf(src[6 * BN], src[7 * BN]);
+            *(uint4*)(dst + i) = pk;
+        }
+    }
+}
+
+thread_local char g_err[512] = "";
+
+}  // namespace
+
+extern "C" const char* msam_last_error(void) { return g_err; }
+extern "C" int msam_abi_version(void) { return 1; }
+
+void msam_set_error(const char* msg) {
+    int i = 0;
+    for (; msg[i] && i < 510; ++i) g_err[i] = msg[i];
+    g_err[i] = 0;
+}
+
+int msam_check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        char buf[400];
+        snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(err));
+        msam_set_error(buf);
+        return 2;
+    }
+    return 0;
+}
+
+extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
+    if (!p || !p->A || !p->W) { msam_set_error("msam_gemm_bf16: null operand"); return 1; }
+    if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->N % BN != 0 || p->K % BK != 0) {
+        msam_set_error("msam_gemm_bf16: need M > 0, N % 128 == 0, K % 64 == 0");
+        return 1;
+    }
+    if ((p->lda % 8) || (p->ldw % 8)) { msam_set_error("msam_gemm_bf16: lda/ldw must be multiples of 8"); return 1; }
+    if (p->out_mode == 0 && (p->ldc % 4)) { msam_set_error("msam_gemm_bf16: ldc must be a multiple of 4"); return 1; }
+    if ((p->table && ((p->table_cols % 4) || (p->table_ld % 4))) || (p->resid && (p->ldr % 4))) {
+        msam_set_error("msam_gemm_bf16: table_cols/table_ld/ldr must be multiples of 4");
+        return 1;
+    }
+    if (p->out_mode == 0 && !p->out) { msam_set_error("msam_gemm_bf16: null output"); return 1; }
+    if (p->out_mode == 1 && (!p->q || !p->k || !p->v || p->heads * p->head_dim * 3 != p->N || p->head_dim % 4)) {
+        msam_set_error("msam_gemm_bf16: bad qkv-split arguments");
+        return 1;
+    }
+    if (p->out_mode == 2 && (!p->k || !p->v || p->N != 256 || p->tokens % 128 || p->M % p->tokens)) {
+        msam_set_error("msam_gemm_bf16: bad kv-split arguments (N == 256, tokens % 128 == 0, M % tokens == 0)");
+        return 1;
+    }
+    Epi e;
+    e.bias = p->bias; e.table = p->table; e.table_rows = p->table_rows > 0 ? p->table_rows : 1;
+    e.table_cols = p->table_cols; e.table_ld = p->table_ld;
+    e.resid = p->resid; e.resid_dtype = p->resid ? p->resid_dtype : 0; e.resid_rows = p->resid_rows; e.ldr = p->ldr;
+    e.act = p->act; e.out = p->out; e.out_dtype = p->out_dtype; e.ldc = p->ldc;
+    e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
+    e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
+    int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
+    hipStream_t s = (hipStream_t)stream;
+    if (p->use_glds)
+        hipLaunchKernelGGL(gemm_kernel<true>, dim3(tiles), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
+                           (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+    else
+        hipLaunchKernelGGL(gemm_kernel<false>, dim3(tiles), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
+                           (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+    return msam_check_launch("msam_gemm_bf16");
+}

@@ -1,0 +1,238 @@
+// HBM-bound helper kernels of the encoder / decoder: LayerNorm (row-wise, fp32 statistics), patch gather
+// (+ fused Sam.preprocess for uint8 input), 3x3 im2col for the neck, casts.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+
+// One wave per row.  VEC = float4 loads per lane (dim == 256 * VEC) or 0 for the scalar path (dim <= 64*20).
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, long rows, int dim,
+                                                        void* out, int out_dtype, int gelu, int nchw_hw) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * dim;
+    constexpr int NV = VEC > 0 ? VEC * 4 : 20;
+    float v[NV];
+    float s = 0.f;
+    if constexpr (VEC > 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            float4 t = *(const float4*)(xr + (i * 64 + lane) * 4);
+            v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
+            s += (t.x + t.y) + (t.z + t.w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int c = i * 64 + lane;
+            v[i] = c < dim ? xr[c] : 0.f;
+            s += v[i];
+        }
+    }
+    const float mean = wave_sum64(s) / (float)dim;
+    float q = 0.f;
+    if constexpr (VEC > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { float d = v[i] - mean; q += d * d; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { int c = i * 64 + lane; float d = c < dim ? v[i] - mean : 0.f; q += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)dim + eps);
+
+    auto emit = [&](int c, float val) {
+        float y = (val - mean) * rstd * w[c] + b[c];
+        if (gelu) y = gelu_erf(y);
+        return y;
+    };
+    if constexpr (VEC > 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            float y0 = emit(c, v[i * 4]), y1 = emit(c + 1, v[i * 4 + 1]), y2 = emit(c + 2, v[i * 4 + 2]),
+                  y3 = emit(c + 3, v[i * 4 + 3]);
+            if (nchw_hw > 0) {
+                const long bimg = row / nchw_hw, t = row - bimg * nchw_hw;
+                float* o = (float*)out + (bimg * dim + c) * (long)nchw_hw + t;
+                o[0] = y0; o[nchw_hw] = y1; o[2L * nchw_hw] = y2; o[3L * nchw_hw] = y3;
+            } else if (out_dtype == MSAM_F32) {
+                *(float4*)((float*)out + row * dim + c) = make_float4(y0, y1, y2, y3);
+            } else {
+                uint2 pk; pk.x = pack2bf(y0, y1); pk.y = pack2bf(y2, y3);
+                *(uint2*)((u16*)out + row * dim + c) = pk;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 64 + lane;
+            if (c < dim) {
+                float y = emit(c, v[i]);
+                if (nchw_hw > 0) {
+                    const long bimg = row / nchw_hw, t = row - bimg * nchw_hw;
+                    ((float*)out)[(bimg * dim + c) * (long)nchw_hw + t] = y;
+                } else if (out_dtype == MSAM_F32) ((float*)out)[row * dim + c] = y;
+                else ((u16*)out)[row * dim + c] = f2bf(y);
+            }
+        }
+    }
+}
+
+// dim == 64 fast path: one 16-lane group per row (4 rows per wave), float4 per lane.
+__global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float eps, long rows,
+                                                          void* out, int out_dtype, int gelu) {
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = (threadIdx.x & 15) * 4;
+    if (row >= rows) return;   // rows % 16 == 0 is not required: whole 16-lane groups exit together
+    float4 t = *(const float4*)(x + row * 64 + c);
+    float mean = wave_sum_xor16((t.x + t.y) + (t.z + t.w)) * (1.0f / 64.0f);
+    float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+    float var = wave_sum_xor16((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 64.0f);
+    float rstd = 1.0f / sqrtf(var + eps);
+    float4 ww = *(const float4*)(w + c), bb = *(const float4*)(b + c);
+    float y0 = d0 * rstd * ww.x + bb.x, y1 = d1 * rstd * ww.y + bb.y, y2 = d2 * rstd * ww.z + bb.z,
+          y3 = d3 * rstd * ww.w + bb.w;
+    if (gelu) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
+    if (out_dtype == MSAM_F32) *(float4*)((float*)out + row * 64 + c) = make_float4(y0, y1, y2, y3);
+    else { uint2 pk; pk.x = pack2bf(y0, y1); pk.y = pack2bf(y2, y3); *(uint2*)((u16*)out + row * 64 + c) = pk; }
+}
+
+// thread -> 8 consecutive kx of one (patch, c, ky): out col = c*256 + ky*16 + kx
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, u16* __restrict__ out) {
+    const long total = (long)B * 4096 * 96;   // 768 / 8 chunks per patch row
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % 96);
+        const long prow = i / 96;
+        const int b = (int)(prow / 4096), pidx = (int)(prow % 4096);
+        const int py = pidx >> 6, px = pidx & 63;
+        const int c = chunk >> 5, ky = (chunk >> 1) & 15, kx0 = (chunk & 1) * 8;
+        const float* src = img + (((long)b * 3 + c) * 1024 + (py * 16 + ky)) * 1024 + px * 16 + kx0;
+        float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+        uint4 pk; pk.x = pack2bf(a.x, a.y); pk.y = pack2bf(a.z, a.w); pk.z = pack2bf(d.x, d.y); pk.w = pack2bf(d.z, d.w);
+        *(uint4*)(out + prow * 768 + chunk * 8) = pk;
+    }
+}
+
+// Sam.preprocess fused: (u8 - mean) / std, zero pad to 1024 (micro_sam/models/build_sam.py:132-133)
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, int B, int h, int w,
+                                                          u16* __restrict__ out) {
+    const float mean[3] = {123.675f, 116.28f, 103.53f};
+    const float stdv[3] = {58.395f, 57.12f, 57.375f};
+    const long total = (long)B * 4096 * 96;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % 96);
+        const long prow = i / 96;
+        const int b = (int)(prow / 4096), pidx = (int)(prow % 4096);
+        const int py = pidx >> 6, px = pidx & 63;
+        const int c = chunk >> 5, ky = (chunk >> 1) & 15, kx0 = (chunk & 1) * 8;
+        const int y = py * 16 + ky, x0 = px * 16 + kx0;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int x = x0 + j;
+            v[j] = (y < h && x < w)
+                       ? __fdiv_rn((float)img[(((long)b * h + y) * w + x) * 3 + c] - mean[c], stdv[c]) : 0.f;
+        }
+        uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+        *(uint4*)(out + prow * 768 + chunk * 8) = pk;
+    }
+}
+
+// x bf16 [B,64,64,C] -> [B*4096, 9*C], column (ky*3+kx)*C + c, zero padding 1
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const u16* __restrict__ x, int B, int C, u16* __restrict__ out) {
+    const int cpr = 9 * C / 8;   // chunks per row
+    const long total = (long)B * 4096 * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % cpr);
+        const long row = i / cpr;
+        const int b = (int)(row / 4096), t = (int)(row % 4096);
+        const int ty = t >> 6, tx = t & 63;
+        const int tap = (chunk * 8) / C, c0 = chunk * 8 - tap * C;
+        const int yy = ty + tap / 3 - 1, xx = tx + tap % 3 - 1;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) val = *(const uint4*)(x + (((long)b * 64 + yy) * 64 + xx) * C + c0);
+        *(uint4*)(out + row * (9L * C) + chunk * 8) = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, u16* __restrict__ out, long n) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 t = *(const float4*)(x + i * 4);
+        uint2 pk; pk.x = pack2bf(t.x, t.y); pk.y = pack2bf(t.z, t.w);
+        *(uint2*)(out + i * 4) = pk;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
+}
+
+inline int grid_for(long work_items) {
+    long g = (work_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int msam_layernorm(const float* x, const float* weight, const float* bias, float eps, int64_t rows,
+                              int32_t dim, void* out, int32_t out_dtype, int32_t gelu, int32_t out_nchw_hw,
+                              void* stream) {
+    if (!x || !weight || !bias || !out || rows <= 0 || dim <= 0) { msam_set_error("msam_layernorm: bad arguments"); return 1; }
+    if (out_nchw_hw > 0 && (out_dtype != MSAM_F32 || rows % out_nchw_hw)) {
+        msam_set_error("msam_layernorm: NCHW output needs fp32 and rows % hw == 0");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (dim == 64 && out_nchw_hw == 0) {
+        hipLaunchKernelGGL(layernorm64_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, weight, bias, eps,
+                           (long)rows, out, out_dtype, gelu);
+        return msam_check_launch("msam_layernorm");
+    }
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define LN_LAUNCH(V) hipLaunchKernelGGL(layernorm_kernel<V>, grid, block, 0, s, x, weight, bias, eps, (long)rows, dim, \
+                                        out, out_dtype, gelu, out_nchw_hw)
+    if (dim == 256) LN_LAUNCH(1);
+    else if (dim == 768) LN_LAUNCH(3);
+    else if (dim == 1024) LN_LAUNCH(4);
+    else if (dim == 1280) LN_LAUNCH(5);
+    else if (dim <= 1280) LN_LAUNCH(0);
+    else { msam_set_error("msam_layernorm: dim > 1280 unsupported"); return 1; }
+#undef LN_LAUNCH
+    return msam_check_launch("msam_layernorm");
+}
+
+extern "C" int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream) {
+    if (!img || !out_bf16 || B <= 0) { msam_set_error("msam_patchify: bad arguments"); return 1; }
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img, B,
+                       (u16*)out_bf16);
+    return msam_check_launch("msam_patchify");
+}
+
+extern "C" int msam_patchify_u8(const uint8_t* img, int32_t B, int32_t h, int32_t w, void* out_bf16, void* stream) {
+    if (!img || !out_bf16 || B <= 0 || h <= 0 || w <= 0 || h > 1024 || w > 1024) {
+        msam_set_error("msam_patchify_u8: bad arguments (need 0 < h,w <= 1024)");
+        return 1;
+    }
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img,
+                       B, h, w, (u16*)out_bf16);
+    return msam_check_launch("msam_patchify_u8");
+}
+
+extern "C" int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, void* stream) {
+    if (!x_bf16 || !out_bf16 || B <= 0 || C <= 0 || C % 8) { msam_set_error("msam_im2col3x3: bad arguments"); return 1; }
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((long)B * 4096 * 9 * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)x_bf16, B, C, (u16*)out_bf16);
+    return msam_check_launch("msam_im2col3x3");
+}
+
+extern "C" int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream) {
+    if (!x || !out_bf16 || n <= 0) { msam_set_error("msam_cast_f32_to_bf16: bad arguments"); return 1; }
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out_bf16,
+                       (long)n);
+    return msam_check_launch("msam_cast_f32_to_bf16");
+}

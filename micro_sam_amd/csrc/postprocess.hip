@@ -1,0 +1,251 @@
+// Mask post-processing on the device (HBM-bound integer / byte work):
+//   Sam.postprocess_masks (two bilinear resamplings) + calculate_stability_score + threshold +
+//   batched_mask_to_box + column-major RLE  (micro_sam/instance_segmentation.py:229-255,
+//   micro_sam/_vendored.py:33-152).  Full-resolution fp32 logits are never written unless asked for.
+//
+// The bilinear arithmetic reproduces torch's CPU kernel bit for bit (verified in tests/): for each axis
+//   scale = in / out (fp32), src = max(scale * (dst + 0.5) - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, in - 1),
+//   w1 = src - i0, w0 = 1 - w1,   value = fma(w0, p0, w1 * p1)   (inner axis x first, then y).
+// so all integer outputs (counts, boxes, bit masks, RLE) are exact given the same low-res logits.
+//
+// Bit-mask layout: bits[n][yw][x], one uint32 = 32 consecutive rows y = yw*32 + b of column x -> coalesced stores
+// here and coalesced column-major walks in the RLE kernels.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+
+struct Axis { int i0, i1; float w0, w1; };
+
+MSAM_DEVINL Axis axis_weights(int dst, float scale, int in_size) {
+    // torch: scale * (dst + 0.5) - 0.5 with separately rounded mul / sub
+    float src = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+    if (src < 0.f) src = 0.f;
+    Axis a;
+    a.i0 = (int)src;                                            // floor for src >= 0
+    a.i1 = a.i0 + (a.i0 < in_size - 1 ? 1 : 0);
+    a.w1 = __fsub_rn(src, (float)a.i0);
+    a.w0 = __fsub_rn(1.0f, a.w1);
+    return a;
+}
+
+MSAM_DEVINL float lerp_torch(float w0, float p0, float w1, float p1) { return __fmaf_rn(w0, p0, __fmul_rn(w1, p1)); }
+
+// value of the 1024x1024 intermediate (x4 up-sampling of the 256x256 low-res mask) at (Y, X)
+MSAM_DEVINL float stage1(const float* __restrict__ low, int Y, int X) {
+    const Axis ay = axis_weights(Y, 0.25f, 256), ax = axis_weights(X, 0.25f, 256);
+    const float* r0 = low + ay.i0 * 256; const float* r1 = low + ay.i1 * 256;
+    const float t0 = lerp_torch(ax.w0, r0[ax.i0], ax.w1, r0[ax.i1]);
+    const float t1 = lerp_torch(ax.w0, r1[ax.i0], ax.w1, r1[ax.i1]);
+    return lerp_torch(ay.w0, t0, ay.w1, t1);
+}
+
+__global__ void init_stats_kernel(int* __restrict__ counts, int* __restrict__ boxes, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    counts[n * 3] = 0; counts[n * 3 + 1] = 0; counts[n * 3 + 2] = 0;
+    boxes[n * 4] = 0x7fffffff; boxes[n * 4 + 1] = 0x7fffffff; boxes[n * 4 + 2] = -1; boxes[n * 4 + 3] = -1;
+}
+
+__global__ void finalize_boxes_kernel(int* __restrict__ boxes, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    if (boxes[n * 4 + 2] < boxes[n * 4] || boxes[n * 4 + 3] < boxes[n * 4 + 1]) {
+        boxes[n * 4] = 0; boxes[n * 4 + 1] = 0; boxes[n * 4 + 2] = 0; boxes[n * 4 + 3] = 0;
+    }
+}
+
+// grid (ceil(out_w/256), words_per_col, N); thread = column x, 32 rows of word yw
+template <bool TWO_STAGE>
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ low_res, int in_h, int in_w, int out_h,
+                                                          int out_w, float thr, float off, int* __restrict__ counts,
+                                                          int* __restrict__ boxes, uint32_t* __restrict__ bits,
+                                                          float* __restrict__ logits) {
+    const int x = blockIdx.x * 256 + threadIdx.x, yw = blockIdx.y, n = blockIdx.z;
+    const int wpc = (out_h + 31) >> 5;
+    const float* low = low_res + (long)n * 65536;
+    const float hi_t = thr + off, lo_t = thr - off;
+    uint32_t word = 0;
+    int c_hi = 0, c_lo = 0, c_m = 0, ymin = 0x7fffffff, ymax = -1;
+    if (x < out_w) {
+        Axis ax2; float sx = 0.f, sy = 0.f;
+        if (TWO_STAGE) { sx = (float)in_w / (float)out_w; sy = (float)in_h / (float)out_h; ax2 = axis_weights(x, sx, in_w); }
+        for (int b = 0; b < 32; ++b) {
+            const int y = yw * 32 + b;
+            if (y >= out_h) break;
+            float v;
+            if (TWO_STAGE) {
+                const Axis ay2 = axis_weights(y, sy, in_h);
+                const float t0 = lerp_torch(ax2.w0, stage1(low, ay2.i0, ax2.i0), ax2.w1, stage1(low, ay2.i0, ax2.i1));
+                const float t1 = lerp_torch(ax2.w0, stage1(low, ay2.i1, ax2.i0), ax2.w1, stage1(low, ay2.i1, ax2.i1));
+                v = lerp_torch(ay2.w0, t0, ay2.w1, t1);
+            } else {
+                v = stage1(low, y, x);
+            }
+            if (logits) logits[((long)n * out_h + y) * out_w + x] = v;
+            c_hi += v > hi_t; c_lo += v > lo_t;
+            if (v > thr) { word |= 1u << b; ++c_m; ymin = min(ymin, y); ymax = y; }
+        }
+        bits[((long)n * wpc + yw) * out_w + x] = word;
+    }
+    // block reduction -> one atomic per statistic per workgroup
+    int xmin = word ? x : 0x7fffffff, xmax = word ? x : -1;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        c_hi += __shfl_xor(c_hi, s); c_lo += __shfl_xor(c_lo, s); c_m += __shfl_xor(c_m, s);
+        ymin = min(ymin, __shfl_xor(ymin, s)); ymax = max(ymax, __shfl_xor(ymax, s));
+        xmin = min(xmin, __shfl_xor(xmin, s)); xmax = max(xmax, __shfl_xor(xmax, s));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (c_hi) atomicAdd(&counts[n * 3], c_hi);
+        if (c_lo) atomicAdd(&counts[n * 3 + 1], c_lo);
+        if (c_m) {
+            atomicAdd(&counts[n * 3 + 2], c_m);
+            atomicMin(&boxes[n * 4], xmin); atomicMin(&boxes[n * 4 + 1], ymin);
+            atomicMax(&boxes[n * 4 + 2], xmax); atomicMax(&boxes[n * 4 + 3], ymax);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- RLE
+// Flattened column-major sequence s = x*H + y.  A "transition" at s means bit[s] != bit[s-1] (bit[-1] := 0, so a
+// mask starting with 1 yields a transition at s = 0, i.e. the leading 0-length run of the reference format).
+// counts = differences of consecutive transition positions, plus the final run L - last.
+// One workgroup (256 threads) per mask; thread handles columns x = tid, tid+256, ...
+
+MSAM_DEVINL uint32_t col_prev_bit(const uint32_t* __restrict__ bm, int wpc, int out_w, int out_h, int x) {
+    if (x == 0) return 0u;
+    const int y = out_h - 1;
+    return (bm[(long)(y >> 5) * out_w + (x - 1)] >> (y & 31)) & 1u;
+}
+
+MSAM_DEVINL int col_transitions(const uint32_t* __restrict__ bm, int wpc, int out_w, int out_h, int x, uint32_t prev) {
+    int cnt = 0;
+    for (int yw = 0; yw < wpc; ++yw) {
+        uint32_t w = bm[(long)yw * out_w + x];
+        const int nb = min(32, out_h - yw * 32);
+        uint32_t shifted = (w << 1) | prev;
+        uint32_t diff = w ^ shifted;
+        if (nb < 32) diff &= (1u << nb) - 1u;
+        cnt += __popc(diff);
+        prev = (w >> (nb - 1)) & 1u;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void rle_count_kernel(const uint32_t* __restrict__ bits, int out_h, int out_w,
+                                                        int* __restrict__ n_runs) {
+    __shared__ int red[4];
+    const int n = blockIdx.x, wpc = (out_h + 31) >> 5;
+    const uint32_t* bm = bits + (long)n * wpc * out_w;
+    int cnt = 0;
+    for (int x = threadIdx.x; x < out_w; x += 256) cnt += col_transitions(bm, wpc, out_w, out_h, x, col_prev_bit(bm, wpc, out_w, out_h, x));
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) cnt += __shfl_xor(cnt, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) n_runs[n] = red[0] + red[1] + red[2] + red[3] + 1;   // + the final run
+}
+
+__global__ __launch_bounds__(256) void rle_encode_kernel(const uint32_t* __restrict__ bits, int out_h, int out_w,
+                                                         const long* __restrict__ offsets, int* __restrict__ out) {
+    __shared__ int scan[256];
+    __shared__ int carry;
+    const int n = blockIdx.x, wpc = (out_h + 31) >> 5, tid = threadIdx.x;
+    const uint32_t* bm = bits + (long)n * wpc * out_w;
+    int* dst = out + offsets[n];
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    // pass A: transition positions, written to dst[k] (k-th transition of the mask)
+    for (int x0 = 0; x0 < out_w; x0 += 256) {
+        const int x = x0 + tid;
+        uint32_t prev = 0; int cnt = 0;
+        if (x < out_w) { prev = col_prev_bit(bm, wpc, out_w, out_h, x); cnt = col_transitions(bm, wpc, out_w, out_h, x, prev); }
+        // exclusive scan of cnt over the 256 threads
+        scan[tid] = cnt;
+        __syncthreads();
+        for (int s = 1; s < 256; s <<= 1) {
+            int v = tid >= s ? scan[tid - s] : 0;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        int k = carry + scan[tid] - cnt;
+        if (x < out_w) {
+            for (int yw = 0; yw < wpc; ++yw) {
+                uint32_t w = bm[(long)yw * out_w + x];
+                const int nb = min(32, out_h - yw * 32);
+                uint32_t diff = w ^ ((w << 1) | prev);
+                if (nb < 32) diff &= (1u << nb) - 1u;
+                while (diff) {
+                    const int b = __ffs(diff) - 1;
+                    diff &= diff - 1;
+                    dst[k++] = x * out_h + yw * 32 + b;
+                }
+                prev = (w >> (nb - 1)) & 1u;
+            }
+        }
+        __syncthreads();
+        if (tid == 255) carry += scan[255];
+        __syncthreads();
+    }
+    const int ntrans = carry;
+    // pass B: in-place differences; element k needs pos[k] and pos[k-1] -> process chunks from the END so that a
+    // chunk's predecessors are still untouched
+    const int L = out_w * out_h;
+    const int nchunks = (ntrans + 1 + 255) / 256;      // ntrans transitions + 1 final run
+    for (int ch = nchunks - 1; ch >= 0; --ch) {
+        const int k = ch * 256 + tid;
+        int val = 0; bool ok = k <= ntrans;
+        if (ok) {
+            const int cur = k < ntrans ? dst[k] : L;
+            const int prv = k > 0 ? dst[k - 1] : 0;
+            val = cur - prv;
+        }
+        __syncthreads();
+        if (ok) dst[k] = val;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h,
+                                      int32_t out_w, float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits,
+                                      float* logits, void* stream) {
+    if (!low_res || !counts || !boxes || !bits || N <= 0) { msam_set_error("msam_postprocess_masks: null argument"); return 1; }
+    if (in_h <= 0 || in_w <= 0 || in_h > 1024 || in_w > 1024 || out_h <= 0 || out_w <= 0) {
+        msam_set_error("msam_postprocess_masks: bad sizes");
+        return 1;
+    }
+    if (N > 65535) { msam_set_error("msam_postprocess_masks: at most 65535 masks per call"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(init_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, s, counts, boxes, N);
+    dim3 grid((out_w + 255) / 256, (out_h + 31) / 32, N);
+    if (in_h == out_h && in_w == out_w)
+        hipLaunchKernelGGL(postprocess_kernel<false>, grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, out_w, thr, off,
+                           counts, boxes, bits, logits);
+    else
+        hipLaunchKernelGGL(postprocess_kernel<true>, grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, out_w, thr, off,
+                           counts, boxes, bits, logits);
+    hipLaunchKernelGGL(finalize_boxes_kernel, dim3((N + 255) / 256), dim3(256), 0, s, boxes, N);
+    return msam_check_launch("msam_postprocess_masks");
+}
+
+extern "C" int msam_rle_run_counts(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_w, int32_t* n_runs,
+                                   void* stream) {
+    if (!bits || !n_runs || N <= 0 || out_h <= 0 || out_w <= 0) { msam_set_error("msam_rle_run_counts: bad arguments"); return 1; }
+    hipLaunchKernelGGL(rle_count_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, bits, out_h, out_w, n_runs);
+    return msam_check_launch("msam_rle_run_counts");
+}
+
+extern "C" int msam_rle_encode(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_w, const int64_t* offsets,
+                               int32_t* counts_out, void* stream) {
+    if (!bits || !offsets || !counts_out || N <= 0) { msam_set_error("msam_rle_encode: bad arguments"); return 1; }
+    hipLaunchKernelGGL(rle_encode_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, bits, out_h, out_w,
+                       (const long*)offsets, counts_out);
+    return msam_check_launch("msam_rle_encode");
+}

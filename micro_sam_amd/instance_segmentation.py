@@ -1,0 +1,246 @@
+"""Automatic mask generation behind the reference's API: ``AMGBase`` / ``AutomaticMaskGenerator``
+(``micro_sam/instance_segmentation.py:65-530``) with the expensive ``initialize`` running on libmsam_hip.so.
+
+Differences to the reference are internal only:
+* all grid prompts of a crop are decoded in chunks of ``points_per_batch`` exactly as in the reference, but each chunk
+  goes low-res logits -> (stability counts, boxes, bit masks, RLE) on the device; the [64,3,H,W] fp32 logits and bool
+  masks the reference materialises never exist;
+* ``crop_n_layers > 0`` and the tiled generator are not provided this round (SURVEY.md 8(f) / DESIGN.md).
+"""
+from __future__ import annotations
+
+from abc import ABC
+from copy import deepcopy
+from typing import Any, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import amg_utils, ops, util
+from .predictor import SamPredictor
+
+
+class AMGBase(ABC):
+    def __init__(self):
+        self._is_initialized = False
+        self._crop_list = None
+        self._crop_boxes = None
+        self._original_size = None
+
+    @property
+    def is_initialized(self):
+        return self._is_initialized
+
+    @property
+    def crop_list(self):
+        return self._crop_list
+
+    @property
+    def crop_boxes(self):
+        return self._crop_boxes
+
+    @property
+    def original_size(self):
+        return self._original_size
+
+    def _postprocess_batch(self, data, crop_box, original_size, pred_iou_thresh, stability_score_thresh, box_nms_thresh):
+        orig_h, orig_w = original_size
+        if pred_iou_thresh > 0.0:
+            data.filter(data["iou_preds"] > pred_iou_thresh)
+        if stability_score_thresh > 0.0:
+            data.filter(data["stability_score"] >= stability_score_thresh)
+        keep_mask = ~amg_utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h])
+        if not torch.all(keep_mask):
+            data.filter(keep_mask)
+        keep_by_nms = amg_utils.batched_nms(data["boxes"].float(), data["iou_preds"],
+                                            torch.zeros_like(data["boxes"][:, 0]), iou_threshold=box_nms_thresh)
+        data.filter(keep_by_nms)
+        data["boxes"] = amg_utils.uncrop_boxes_xyxy(data["boxes"], crop_box)
+        data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["rles"]))])
+        try:
+            data["points"] = amg_utils.uncrop_points(data["points"], crop_box)
+        except KeyError:
+            pass
+        return data
+
+    def _postprocess_masks(self, mask_data, min_mask_region_area, box_nms_thresh, crop_nms_thresh, output_mode):
+        if min_mask_region_area > 0:
+            raise NotImplementedError("micro_sam_amd: min_mask_region_area > 0 (cv2 small-region removal) is not provided")
+        if output_mode == "coco_rle":
+            raise NotImplementedError("micro_sam_amd: output_mode='coco_rle' needs pycocotools, not provided")
+        elif output_mode in ("binary_mask", "instance_segmentation"):
+            mask_data["segmentations"] = [amg_utils.rle_to_mask(rle) for rle in mask_data["rles"]]
+        elif output_mode == "rle":
+            mask_data["segmentations"] = mask_data["rles"]
+        else:
+            raise ValueError(f"Invalid output mode {output_mode}.")
+        curr_anns = []
+        for idx in range(len(mask_data["segmentations"])):
+            ann = {
+                "segmentation": mask_data["segmentations"][idx],
+                "area": amg_utils.area_from_rle(mask_data["rles"][idx]),
+                "bbox": amg_utils.box_xyxy_to_xywh(mask_data["boxes"][idx]).tolist(),
+                "predicted_iou": mask_data["iou_preds"][idx].item(),
+                "stability_score": mask_data["stability_score"][idx].item(),
+                "crop_box": amg_utils.box_xyxy_to_xywh(mask_data["crop_boxes"][idx]).tolist(),
+            }
+            try:
+                ann["point_coords"] = [mask_data["points"][idx].tolist()]
+            except KeyError:
+                pass
+            curr_anns.append(ann)
+        return curr_anns
+
+    def _to_mask_data_device(self, iou_preds, post, crop_box, original_size, points=None):
+        """``AMGBase._to_mask_data`` (reference :229-255) from the fused device post-processing results."""
+        orig_h, orig_w = original_size
+        x0, y0, x1, y1 = crop_box
+        if not (x0 == 0 and y0 == 0 and x1 == orig_w and y1 == orig_h):
+            raise NotImplementedError("micro_sam_amd: crops that differ from the full image are not provided this round")
+        n_masks_per_prompt = iou_preds.shape[1]
+        data = amg_utils.MaskData(iou_preds=iou_preds.flatten(0, 1))
+        if points is not None:
+            data["points"] = torch.as_tensor(points.repeat(n_masks_per_prompt, axis=0), dtype=torch.float)
+        counts = post["counts"]
+        # calculate_stability_score: #(logit > thr + off) / #(logit > thr - off); int32 / int32 -> float32 (0/0 -> nan)
+        data["stability_score"] = counts[:, 0] / counts[:, 1]
+        data["boxes"] = post["boxes"]
+        rle_counts, rle_offsets = ops.rle_encode(post["bits"], orig_h, orig_w)
+        data["rles"] = ops.rles_to_list(rle_counts, rle_offsets, orig_h, orig_w)
+        return data
+
+    def get_state(self) -> Dict[str, Any]:
+        if not self.is_initialized:
+            raise RuntimeError("The state has not been computed yet. Call initialize first.")
+        return {"crop_list": self.crop_list, "crop_boxes": self.crop_boxes, "original_size": self.original_size}
+
+    def set_state(self, state: Dict[str, Any]) -> None:
+        self._crop_list = state["crop_list"]
+        self._crop_boxes = state["crop_boxes"]
+        self._original_size = state["original_size"]
+        self._is_initialized = True
+
+    def clear_state(self):
+        self._crop_list = None
+        self._crop_boxes = None
+        self._original_size = None
+        self._is_initialized = False
+
+
+class AutomaticMaskGenerator(AMGBase):
+    """Grid-prompt instance segmentation; same constructor / ``initialize`` / ``generate`` as the reference (:288-530)."""
+
+    def __init__(self, predictor: SamPredictor, points_per_side: Optional[int] = 32, points_per_batch: Optional[int] = None,
+                 crop_n_layers: int = 0, crop_overlap_ratio: float = 512 / 1500, crop_n_points_downscale_factor: int = 1,
+                 point_grids: Optional[List[np.ndarray]] = None, stability_score_offset: float = 1.0):
+        super().__init__()
+        if points_per_side is not None:
+            self.point_grids = amg_utils.build_all_layer_point_grids(points_per_side, crop_n_layers,
+                                                                     crop_n_points_downscale_factor)
+        elif point_grids is not None:
+            self.point_grids = point_grids
+        else:
+            raise ValueError("Can't have both points_per_side and point_grid be None or not None.")
+        if crop_n_layers != 0:
+            raise NotImplementedError("micro_sam_amd: crop_n_layers > 0 is not provided this round")
+        self._predictor = predictor
+        self._points_per_side = points_per_side
+        self._points_per_batch = 64 if points_per_batch is None else points_per_batch
+        self._crop_n_layers = crop_n_layers
+        self._crop_overlap_ratio = crop_overlap_ratio
+        self._crop_n_points_downscale_factor = crop_n_points_downscale_factor
+        self._stability_score_offset = stability_score_offset
+
+    def _process_batch(self, points, im_size, crop_box, original_size):
+        transformed_points = self._predictor.transform.apply_coords(points, im_size)
+        in_points = torch.as_tensor(transformed_points, device=self._predictor.device, dtype=torch.float)
+        in_labels = torch.ones(in_points.shape[0], dtype=torch.int, device=in_points.device)
+        iou_preds, post = self._predictor.predict_masks_device(
+            in_points[:, None, :], in_labels[:, None], multimask_output=True,
+            stability_score_offset=self._stability_score_offset)
+        return self._to_mask_data_device(iou_preds, post, crop_box, original_size, points=points)
+
+    def _process_crop(self, image, crop_box, crop_layer_idx, precomputed_embeddings, pbar_init=None, pbar_update=None):
+        x0, y0, x1, y1 = crop_box
+        cropped_im = image[y0:y1, x0:x1, :]
+        cropped_im_size = cropped_im.shape[:2]
+        if not precomputed_embeddings:
+            self._predictor.set_image(cropped_im)
+        points_scale = np.array(cropped_im_size)[None, ::-1]
+        points_for_image = self.point_grids[crop_layer_idx] * points_scale
+        data = amg_utils.MaskData()
+        n_batches = len(points_for_image) // self._points_per_batch + \
+            int(len(points_for_image) % self._points_per_batch != 0)
+        if pbar_init is not None:
+            pbar_init(n_batches, "Predict masks for point grid prompts")
+        for (points,) in amg_utils.batch_iterator(self._points_per_batch, points_for_image):
+            batch_data = self._process_batch(points, cropped_im_size, crop_box, self.original_size)
+            data.cat(batch_data)
+            del batch_data
+            if pbar_update is not None:
+                pbar_update(1)
+        if not precomputed_embeddings:
+            self._predictor.reset_image()
+        return data
+
+    @torch.no_grad()
+    def initialize(self, image: np.ndarray, image_embeddings=None, i: Optional[int] = None, verbose: bool = False,
+                   pbar_init: Optional[callable] = None, pbar_update: Optional[callable] = None) -> None:
+        original_size = image.shape[:2]
+        self._original_size = original_size
+        crop_boxes, layer_idxs = amg_utils.generate_crop_boxes(original_size, self._crop_n_layers,
+                                                               self._crop_overlap_ratio)
+        if len(crop_boxes) == 1:
+            if image_embeddings is None:
+                image_embeddings = util.precompute_image_embeddings(self._predictor, image, verbose=verbose)
+            util.set_precomputed(self._predictor, image_embeddings, i=i)
+            precomputed_embeddings = True
+        else:
+            precomputed_embeddings = False
+        image = util._to_image(image)
+        _, pbar_init, pbar_update, pbar_close = util.handle_pbar(verbose, pbar_init, pbar_update)
+        crop_list = []
+        for crop_box, layer_idx in zip(crop_boxes, layer_idxs):
+            crop_list.append(self._process_crop(image, crop_box, layer_idx, precomputed_embeddings=precomputed_embeddings,
+                                                pbar_init=pbar_init, pbar_update=pbar_update))
+        pbar_close()
+        self._is_initialized = True
+        self._crop_list = crop_list
+        self._crop_boxes = crop_boxes
+
+    @torch.no_grad()
+    def generate(self, pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95, box_nms_thresh: float = 0.7,
+                 crop_nms_thresh: float = 0.7, min_mask_region_area: int = 0, output_mode: str = "instance_segmentation",
+                 with_background: bool = True) -> Union[List[Dict[str, Any]], np.ndarray]:
+        if not self.is_initialized:
+            raise RuntimeError("AutomaticMaskGenerator has not been initialized. Call initialize first.")
+        data = amg_utils.MaskData()
+        for data_, crop_box in zip(self.crop_list, self.crop_boxes):
+            crop_data = self._postprocess_batch(
+                data=deepcopy(data_), crop_box=crop_box, original_size=self.original_size,
+                pred_iou_thresh=pred_iou_thresh, stability_score_thresh=stability_score_thresh,
+                box_nms_thresh=box_nms_thresh)
+            data.cat(crop_data)
+        if len(self.crop_boxes) > 1 and len(data["crop_boxes"]) > 0:
+            scores = 1 / amg_utils.box_area(data["crop_boxes"])
+            scores = scores.to(data["boxes"].device)
+            keep_by_nms = amg_utils.batched_nms(data["boxes"].float(), scores, torch.zeros_like(data["boxes"][:, 0]),
+                                                iou_threshold=crop_nms_thresh)
+            data.filter(keep_by_nms)
+        data.to_numpy()
+        masks = self._postprocess_masks(data, min_mask_region_area, box_nms_thresh, crop_nms_thresh, output_mode)
+        if output_mode == "instance_segmentation":
+            shape = next(iter(masks))["segmentation"].shape if len(masks) > 0 else self.original_size
+            masks = util.mask_data_to_segmentation(masks, shape=shape, with_background=with_background,
+                                                   merge_exclusively=False)
+        return masks
+
+
+def get_instance_segmentation_generator(predictor: SamPredictor, is_tiled: bool = False, decoder=None,
+                                        segmentation_mode: Optional[str] = None, **kwargs) -> AMGBase:
+    """Factory with the reference's signature (:1631-1670); only the AMG mode exists in this build."""
+    if is_tiled:
+        raise NotImplementedError("micro_sam_amd: tiled automatic mask generation is not provided this round")
+    if decoder is not None or (segmentation_mode not in (None, "amg")):
+        raise NotImplementedError("micro_sam_amd: only segmentation_mode='amg' is provided (AIS/APG: SURVEY.md 8(f))")
+    return AutomaticMaskGenerator(predictor, **kwargs)

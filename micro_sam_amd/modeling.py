@@ -1,0 +1,487 @@
+"""SAM model objects behind micro_sam's ``SamPredictor`` boundary, computed by libmsam_hip.so.
+
+The module tree and parameter names are those of upstream ``segment_anything`` (the names micro_sam depends
+on: ``micro_sam/models/build_sam.py:26``, ``micro_sam/util.py:457,578-598``, ``micro_sam/models/peft_sam.py:41-44``,
+``micro_sam/instance_segmentation.py:774-783``), so real checkpoints ``load_state_dict``
+unchanged and ``blocks[i].attn.qkv`` etc. stay ordinary ``nn.Module``s.  The ``forward`` passes do not run torch
+ops: they hand device pointers of cached bf16/fp32 weight copies to the C ABI (``include/msam_hip.h``).
+
+Hyper-parameters: ``micro_sam/models/build_sam.py:40-142``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+VIT_CONFIGS = {
+    # micro_sam/models/build_sam.py:40-84
+    "vit_b": dict(embed_dim=768, depth=12, num_heads=12, global_attn_indexes=(2, 5, 8, 11)),
+    "vit_l": dict(embed_dim=1024, depth=24, num_heads=16, global_attn_indexes=(5, 11, 17, 23)),
+    "vit_h": dict(embed_dim=1280, depth=32, num_heads=16, global_attn_indexes=(7, 15, 23, 31)),
+}
+IMG_SIZE, PATCH, GRID, WINDOW, PROMPT_DIM = 1024, 16, 64, 14, 256
+
+
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.bfloat16).contiguous()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class LayerNorm2d(nn.Module):
+    def __init__(self, num_channels: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.eps = eps
+
+
+class MLPBlock(nn.Module):
+    def __init__(self, dim: int, mlp_dim: int, act=nn.GELU) -> None:
+        super().__init__()
+        self.lin1 = nn.Linear(dim, mlp_dim)
+        self.lin2 = nn.Linear(mlp_dim, dim)
+        self.act = act()
+
+
+class _ViTAttention(nn.Module):
+    def __init__(self, dim: int, num_heads: int, input_size: int) -> None:
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+        self.use_rel_pos = True
+        self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size - 1, head_dim))
+        self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size - 1, head_dim))
+
+
+class _ViTBlock(nn.Module):
+    def __init__(self, dim: int, num_heads: int, window_size: int) -> None:
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _ViTAttention(dim, num_heads, GRID if window_size == 0 else window_size)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = MLPBlock(dim, dim * 4)
+        self.window_size = window_size
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, embed_dim: int) -> None:
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=PATCH, stride=PATCH)
+
+
+def _resize_rel_pos(rel_pos: torch.Tensor, size: int) -> torch.Tensor:
+    """get_rel_pos' table interpolation for checkpoints whose table length differs from 2S-1."""
+    want = 2 * size - 1
+    if rel_pos.shape[0] == want:
+        return rel_pos
+    r = F.interpolate(rel_pos.float().reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=want, mode="linear")
+    return r.reshape(-1, want).permute(1, 0)
+
+
+class ImageEncoderViT(nn.Module):
+    """``predictor.model.image_encoder``: [B,3,1024,1024] fp32 (normalised, padded) -> [B,256,64,64] fp32."""
+
+    def __init__(self, embed_dim: int, depth: int, num_heads: int, global_attn_indexes: Tuple[int, ...]) -> None:
+        super().__init__()
+        self.img_size = IMG_SIZE
+        self.embed_dim, self.depth, self.num_heads = embed_dim, depth, num_heads
+        self.global_attn_indexes = tuple(global_attn_indexes)
+        self.patch_embed = _PatchEmbed(embed_dim)
+        self.pos_embed = nn.Parameter(torch.zeros(1, GRID, GRID, embed_dim))
+        self.blocks = nn.ModuleList(
+            [_ViTBlock(embed_dim, num_heads, 0 if i in self.global_attn_indexes else WINDOW) for i in range(depth)])
+        self.neck = nn.Sequential(
+            nn.Conv2d(embed_dim, PROMPT_DIM, kernel_size=1, bias=False), LayerNorm2d(PROMPT_DIM),
+            nn.Conv2d(PROMPT_DIM, PROMPT_DIM, kernel_size=3, padding=1, bias=False), LayerNorm2d(PROMPT_DIM))
+        self.use_glds = 0
+        self._prep = None
+        self._workspace = None
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    def invalidate(self) -> None:
+        self._prep = None
+
+    def _prepare(self):
+        if self._prep is not None:
+            return self._prep
+        dev = self.pos_embed.device
+        _lib.require_gpu(dev)
+        D = self.embed_dim
+        keep: List[torch.Tensor] = []
+
+        def k(t):
+            keep.append(t)
+            return t.data_ptr()
+
+        p = _lib.EncoderParams()
+        p.embed_dim, p.depth, p.heads = D, self.depth, self.num_heads
+        p.patch_w = k(_bf16(self.patch_embed.proj.weight.reshape(D, 3 * PATCH * PATCH)))
+        p.patch_b = k(_f32(self.patch_embed.proj.bias))
+        p.pos_embed = k(_f32(self.pos_embed.reshape(GRID * GRID, D)))
+        for i, blk in enumerate(self.blocks):
+            size = GRID if blk.window_size == 0 else blk.window_size
+            p.is_global[i] = 1 if blk.window_size == 0 else 0
+            p.ln1_w[i], p.ln1_b[i] = k(_f32(blk.norm1.weight)), k(_f32(blk.norm1.bias))
+            p.qkv_w[i], p.qkv_b[i] = k(_bf16(blk.attn.qkv.weight)), k(_f32(blk.attn.qkv.bias))
+            p.rel_h[i] = k(_bf16(_resize_rel_pos(blk.attn.rel_pos_h, size)))
+            p.rel_w[i] = k(_bf16(_resize_rel_pos(blk.attn.rel_pos_w, size)))
+            p.proj_w[i], p.proj_b[i] = k(_bf16(blk.attn.proj.weight)), k(_f32(blk.attn.proj.bias))
+            p.ln2_w[i], p.ln2_b[i] = k(_f32(blk.norm2.weight)), k(_f32(blk.norm2.bias))
+            p.lin1_w[i], p.lin1_b[i] = k(_bf16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
+            p.lin2_w[i], p.lin2_b[i] = k(_bf16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
+        p.neck0_w = k(_bf16(self.neck[0].weight.reshape(PROMPT_DIM, D)))
+        p.neck1_w, p.neck1_b = k(_f32(self.neck[1].weight)), k(_f32(self.neck[1].bias))
+        p.neck2_w = k(_bf16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(PROMPT_DIM, 9 * PROMPT_DIM)))
+        p.neck3_w, p.neck3_b = k(_f32(self.neck[3].weight)), k(_f32(self.neck[3].bias))
+        p.use_glds = int(self.use_glds)
+        self._prep = (p, keep)
+        return self._prep
+
+    def _get_workspace(self, params, B: int) -> torch.Tensor:
+        need = _lib.load().msam_encoder_workspace_bytes(C.byref(params), B)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != self.pos_embed.device:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.pos_embed.device)
+        return self._workspace
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, tap_block: Optional[int] = None):
+        if self.embed_dim // self.num_heads != 64:
+            raise NotImplementedError("micro_sam_amd: the HIP encoder supports head_dim 64 (vit_b, vit_l) this round")
+        assert x.dim() == 4 and x.shape[1:] == (3, IMG_SIZE, IMG_SIZE), x.shape
+        params, _ = self._prepare()
+        x = x.to(device=self.pos_embed.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        ws = self._get_workspace(params, B)
+        out = torch.empty((B, PROMPT_DIM, GRID, GRID), dtype=torch.float32, device=x.device)
+        tap = None
+        if tap_block is not None:
+            tap = torch.empty((B * GRID * GRID, self.embed_dim), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().msam_encoder_forward(
+            C.byref(params), x.data_ptr(), None, IMG_SIZE, IMG_SIZE, B, out.data_ptr(), ws.data_ptr(), ws.numel(),
+            _lib.ptr(tap), -1 if tap_block is None else int(tap_block), _lib.stream_ptr()), "msam_encoder_forward")
+        return (out, tap) if tap_block is not None else out
+
+    @torch.no_grad()
+    def forward_u8(self, images: torch.Tensor) -> torch.Tensor:
+        """uint8 HWC batch [B,h,w,3] (after ``ResizeLongestSide.apply_image``): ``Sam.preprocess`` fused on device."""
+        assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] == 3, images.shape
+        params, _ = self._prepare()
+        images = images.to(self.pos_embed.device).contiguous()
+        B, h, w = images.shape[:3]
+        ws = self._get_workspace(params, B)
+        out = torch.empty((B, PROMPT_DIM, GRID, GRID), dtype=torch.float32, device=images.device)
+        _lib.check(_lib.load().msam_encoder_forward(
+            C.byref(params), None, images.data_ptr(), h, w, B, out.data_ptr(), ws.data_ptr(), ws.numel(), None, -1,
+            _lib.stream_ptr()), "msam_encoder_forward")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ prompt encoder
+
+class PositionEmbeddingRandom(nn.Module):
+    def __init__(self, num_pos_feats: int = 128) -> None:
+        super().__init__()
+        self.register_buffer("positional_encoding_gaussian_matrix", torch.randn((2, num_pos_feats)))
+
+
+class PromptEncoder(nn.Module):
+    """Parameter holder with upstream names; evaluated inside the fused decoder call."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.embed_dim = PROMPT_DIM
+        self.input_image_size = (IMG_SIZE, IMG_SIZE)
+        self.image_embedding_size = (GRID, GRID)
+        self.pe_layer = PositionEmbeddingRandom(PROMPT_DIM // 2)
+        self.point_embeddings = nn.ModuleList([nn.Embedding(1, PROMPT_DIM) for _ in range(4)])
+        self.not_a_point_embed = nn.Embedding(1, PROMPT_DIM)
+        self.mask_input_size = (4 * GRID, 4 * GRID)
+        self.mask_downscaling = nn.Sequential(
+            nn.Conv2d(1, 4, kernel_size=2, stride=2), LayerNorm2d(4), nn.GELU(),
+            nn.Conv2d(4, 16, kernel_size=2, stride=2), LayerNorm2d(16), nn.GELU(),
+            nn.Conv2d(16, PROMPT_DIM, kernel_size=1))
+        self.no_mask_embed = nn.Embedding(1, PROMPT_DIM)
+        self._dense_pe_fn = None
+
+    def get_dense_pe(self) -> torch.Tensor:
+        """[1,256,64,64] dense positional encoding (computed by the decoder's constant pass)."""
+        if self._dense_pe_fn is None:
+            raise RuntimeError("get_dense_pe: the prompt encoder is not attached to a Sam model")
+        return self._dense_pe_fn()
+
+    def forward(self, points, boxes, masks):
+        raise NotImplementedError(
+            "micro_sam_amd: prompt_encoder is evaluated inside Sam.decode / SamPredictor.predict_torch "
+            "(fused HIP decoder); the stand-alone module call is not provided this round")
+
+
+# ------------------------------------------------------------------------------------------------ mask decoder
+
+class _DecAttention(nn.Module):
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1) -> None:
+        super().__init__()
+        self.embedding_dim, self.num_heads = embedding_dim, num_heads
+        self.internal_dim = embedding_dim // downsample_rate
+        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.k_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
+
+
+class _TwoWayBlock(nn.Module):
+    def __init__(self, skip_first_layer_pe: bool) -> None:
+        super().__init__()
+        self.self_attn = _DecAttention(PROMPT_DIM, 8)
+        self.norm1 = nn.LayerNorm(PROMPT_DIM)
+        self.cross_attn_token_to_image = _DecAttention(PROMPT_DIM, 8, downsample_rate=2)
+        self.norm2 = nn.LayerNorm(PROMPT_DIM)
+        self.mlp = MLPBlock(PROMPT_DIM, 2048, nn.ReLU)
+        self.norm3 = nn.LayerNorm(PROMPT_DIM)
+        self.norm4 = nn.LayerNorm(PROMPT_DIM)
+        self.cross_attn_image_to_token = _DecAttention(PROMPT_DIM, 8, downsample_rate=2)
+        self.skip_first_layer_pe = skip_first_layer_pe
+
+
+class TwoWayTransformer(nn.Module):
+    def __init__(self) -> None:
+        super().__init__()
+        self.layers = nn.ModuleList([_TwoWayBlock(i == 0) for i in range(2)])
+        self.final_attn_token_to_image = _DecAttention(PROMPT_DIM, 8, downsample_rate=2)
+        self.norm_final_attn = nn.LayerNorm(PROMPT_DIM)
+
+
+class _MLP(nn.Module):
+    def __init__(self, input_dim: int, hidden_dim: int, output_dim: int, num_layers: int) -> None:
+        super().__init__()
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+
+class MaskDecoder(nn.Module):
+    def __init__(self, num_multimask_outputs: int = 3) -> None:
+        super().__init__()
+        if num_multimask_outputs != 3:
+            raise NotImplementedError("micro_sam_amd: only num_multimask_outputs == 3 is supported")
+        self.transformer_dim = PROMPT_DIM
+        self.transformer = TwoWayTransformer()
+        self.num_multimask_outputs = num_multimask_outputs
+        self.iou_token = nn.Embedding(1, PROMPT_DIM)
+        self.num_mask_tokens = num_multimask_outputs + 1
+        self.mask_tokens = nn.Embedding(self.num_mask_tokens, PROMPT_DIM)
+        self.output_upscaling = nn.Sequential(
+            nn.ConvTranspose2d(PROMPT_DIM, PROMPT_DIM // 4, kernel_size=2, stride=2), LayerNorm2d(PROMPT_DIM // 4),
+            nn.GELU(), nn.ConvTranspose2d(PROMPT_DIM // 4, PROMPT_DIM // 8, kernel_size=2, stride=2), nn.GELU())
+        self.output_hypernetworks_mlps = nn.ModuleList([_MLP(PROMPT_DIM, PROMPT_DIM, PROMPT_DIM // 8, 3)
+                                                        for _ in range(self.num_mask_tokens)])
+        self.iou_prediction_head = _MLP(PROMPT_DIM, 256, self.num_mask_tokens, 3)
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(
+            "micro_sam_amd: mask_decoder is evaluated inside Sam.decode / SamPredictor.predict_torch "
+            "(fused HIP decoder); the stand-alone module call is not provided this round")
+
+
+# ------------------------------------------------------------------------------------------------ Sam
+
+class Sam(nn.Module):
+    mask_threshold: float = 0.0
+    image_format: str = "RGB"
+
+    def __init__(self, image_encoder: ImageEncoderViT, prompt_encoder: PromptEncoder, mask_decoder: MaskDecoder,
+                 pixel_mean=(123.675, 116.28, 103.53), pixel_std=(58.395, 57.12, 57.375)) -> None:
+        super().__init__()
+        self.image_encoder = image_encoder
+        self.prompt_encoder = prompt_encoder
+        self.mask_decoder = mask_decoder
+        self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
+        self.use_glds = 0
+        self._dec = None            # (params, keep-alive tensors, consts buffer)
+        self._img_state = None      # (key, buffer)
+        self._dec_ws = None
+        self.prompt_encoder._dense_pe_fn = self._dense_pe
+        self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    @property
+    def device(self) -> torch.device:
+        return self.pixel_mean.device
+
+    def invalidate(self) -> None:
+        self._dec = None
+        self._img_state = None
+        self.image_encoder.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):   # .to(device) / .cuda() move parameters: drop cached device copies
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
+
+    # -- reference: Sam.preprocess / Sam.postprocess_masks (micro_sam/util.py:670, trainable_sam.py:108)
+    def preprocess(self, x: torch.Tensor) -> torch.Tensor:
+        x = (x - self.pixel_mean) / self.pixel_std
+        h, w = x.shape[-2:]
+        return F.pad(x, (0, IMG_SIZE - w, 0, IMG_SIZE - h))
+
+    def postprocess_masks(self, masks: torch.Tensor, input_size, original_size) -> torch.Tensor:
+        """Returns fp32 logits at the original size, computed by the fused HIP resampling kernel."""
+        from .ops import postprocess_masks as _pp
+        b, c = masks.shape[:2]
+        res = _pp(masks.reshape(b * c, 256, 256), tuple(input_size), tuple(original_size), self.mask_threshold, 1.0,
+                  want_logits=True)
+        return res["logits"].reshape(b, c, *original_size)
+
+    # -- decoder plumbing
+    def _prepare_decoder(self):
+        if self._dec is not None:
+            return self._dec
+        dev = self.device
+        _lib.require_gpu(dev)
+        pe, md = self.prompt_encoder, self.mask_decoder
+        keep: List[torch.Tensor] = []
+
+        def k(t):
+            t = t.to(dev)
+            keep.append(t)
+            return t.data_ptr()
+
+        def attn(dst, mod):
+            dst.q_w, dst.q_b = k(_bf16(mod.q_proj.weight)), k(_f32(mod.q_proj.bias))
+            dst.k_w, dst.k_b = k(_bf16(mod.k_proj.weight)), k(_f32(mod.k_proj.bias))
+            dst.v_w, dst.v_b = k(_bf16(mod.v_proj.weight)), k(_f32(mod.v_proj.bias))
+            dst.o_w, dst.o_b = k(_bf16(mod.out_proj.weight)), k(_f32(mod.out_proj.bias))
+
+        p = _lib.DecoderParams()
+        p.pe_gauss = k(_f32(pe.pe_layer.positional_encoding_gaussian_matrix))
+        p.point_embed = k(_f32(torch.cat([e.weight for e in pe.point_embeddings], dim=0)))
+        p.not_a_point = k(_f32(pe.not_a_point_embed.weight.reshape(-1)))
+        p.no_mask = k(_f32(pe.no_mask_embed.weight.reshape(-1)))
+        p.out_tokens = k(_f32(torch.cat([md.iou_token.weight, md.mask_tokens.weight], dim=0)))
+        for i, blk in enumerate(md.transformer.layers):
+            L = p.layer[i]
+            attn(L.self_attn, blk.self_attn)
+            attn(L.t2i, blk.cross_attn_token_to_image)
+            attn(L.i2t, blk.cross_attn_image_to_token)
+            for j, nm in enumerate((blk.norm1, blk.norm2, blk.norm3, blk.norm4), start=1):
+                setattr(L, f"n{j}_w", k(_f32(nm.weight)))
+                setattr(L, f"n{j}_b", k(_f32(nm.bias)))
+            L.mlp1_w, L.mlp1_b = k(_bf16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
+            L.mlp2_w, L.mlp2_b = k(_bf16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
+        attn(p.final_attn, md.transformer.final_attn_token_to_image)
+        p.nf_w, p.nf_b = k(_f32(md.transformer.norm_final_attn.weight)), k(_f32(md.transformer.norm_final_attn.bias))
+        up = md.output_upscaling
+        # ConvTranspose2d weight [ci, co, ky, kx] -> GEMM weight rows n = (ky*2+kx)*co_n + co, cols ci
+        p.up1_w = k(_bf16(up[0].weight.permute(2, 3, 1, 0).reshape(4 * 64, PROMPT_DIM)))
+        p.up1_b = k(_f32(up[0].bias.repeat(4)))
+        p.up_ln_w, p.up_ln_b = k(_f32(up[1].weight)), k(_f32(up[1].bias))
+        p.up2_w = k(_bf16(up[3].weight.permute(2, 3, 1, 0).reshape(4 * 32, 64)))
+        p.up2_b = k(_f32(up[3].bias))
+
+        def pad_rows(wt, bs, rows=128):
+            wp = torch.zeros((rows, wt.shape[1]), dtype=wt.dtype, device=wt.device)
+            wp[: wt.shape[0]] = wt
+            bp = torch.zeros((rows,), dtype=bs.dtype, device=bs.device)
+            bp[: bs.shape[0]] = bs
+            return wp, bp
+
+        for i, mlp in enumerate(md.output_hypernetworks_mlps):
+            for j, lin in enumerate(mlp.layers):
+                wt, bs = lin.weight.detach(), lin.bias.detach()
+                if j == 2:
+                    wt, bs = pad_rows(wt, bs)
+                p.hyp_w[i][j], p.hyp_b[i][j] = k(_bf16(wt)), k(_f32(bs))
+        for j, lin in enumerate(md.iou_prediction_head.layers):
+            wt, bs = lin.weight.detach(), lin.bias.detach()
+            if j == 2:
+                wt, bs = pad_rows(wt, bs)
+            p.iou_w[j], p.iou_b[j] = k(_bf16(wt)), k(_f32(bs))
+        p.use_glds = int(self.use_glds)
+        lib = _lib.load()
+        consts = torch.empty(lib.msam_decoder_const_bytes(), dtype=torch.uint8, device=dev)
+        _lib.check(lib.msam_decoder_prepare_const(C.byref(p), consts.data_ptr(), _lib.stream_ptr()),
+                   "msam_decoder_prepare_const")
+        self._dec = (p, keep, consts)
+        return self._dec
+
+    def _dense_pe(self) -> torch.Tensor:
+        _, _, consts = self._prepare_decoder()
+        pos = consts[: GRID * GRID * PROMPT_DIM * 4].view(torch.float32).reshape(GRID * GRID, PROMPT_DIM)
+        return pos.t().reshape(1, PROMPT_DIM, GRID, GRID).contiguous()
+
+    def _image_state(self, features: torch.Tensor) -> torch.Tensor:
+        key = (features.data_ptr(), features._version, tuple(features.shape))
+        if self._img_state is not None and self._img_state[0] == key:
+            return self._img_state[1]
+        p, _, consts = self._prepare_decoder()
+        lib = _lib.load()
+        feats = features.to(device=self.device, dtype=torch.float32).reshape(PROMPT_DIM, GRID * GRID).contiguous()
+        state = torch.empty(lib.msam_decoder_image_bytes(), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.msam_decoder_prepare_image(C.byref(p), consts.data_ptr(), feats.data_ptr(), state.data_ptr(),
+                                                  None, 0, _lib.stream_ptr()), "msam_decoder_prepare_image")
+        self._img_state = (key, state, feats)
+        return state
+
+    @torch.no_grad()
+    def decode(self, features: torch.Tensor, point_coords: Optional[torch.Tensor], point_labels: Optional[torch.Tensor],
+               boxes: Optional[torch.Tensor] = None, mask_input: Optional[torch.Tensor] = None,
+               multimask_output: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """prompt_encoder + mask_decoder of ``SamPredictor.predict_torch`` for one image embedding [1,256,64,64].
+
+        point_coords [P,Np,2] / boxes [P,4] are in the 1024 input frame.  Returns (low_res [P,C,256,256], iou [P,C])."""
+        if mask_input is not None:
+            raise NotImplementedError("micro_sam_amd: mask prompts are not supported by the HIP decoder this round")
+        if features.numel() != PROMPT_DIM * GRID * GRID:
+            raise ValueError(f"expected one image embedding [1,256,64,64], got {tuple(features.shape)}")
+        p, _, consts = self._prepare_decoder()
+        state = self._image_state(features)
+        lib = _lib.load()
+        dev = self.device
+        if point_coords is not None:
+            pts = point_coords.to(device=dev, dtype=torch.float32).contiguous()
+            lbl = point_labels.to(device=dev, dtype=torch.int32).contiguous()
+            P, Np = pts.shape[0], pts.shape[1]
+        else:
+            pts = lbl = None
+            P, Np = boxes.shape[0], 0
+        bx = None if boxes is None else boxes.to(device=dev, dtype=torch.float32).reshape(-1, 4).contiguous()
+        nc = 3 if multimask_output else 1
+        low = torch.empty((P, nc, 256, 256), dtype=torch.float32, device=dev)
+        iou = torch.empty((P, nc), dtype=torch.float32, device=dev)
+        need = lib.msam_decoder_workspace_bytes(P)
+        if self._dec_ws is None or self._dec_ws.numel() < need or self._dec_ws.device != dev:
+            self._dec_ws = None
+            self._dec_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _lib.check(lib.msam_decoder_forward(
+            C.byref(p), consts.data_ptr(), state.data_ptr(), _lib.ptr(pts), _lib.ptr(lbl), Np, _lib.ptr(bx), P,
+            1 if multimask_output else 0, low.data_ptr(), iou.data_ptr(), self._dec_ws.data_ptr(), self._dec_ws.numel(),
+            _lib.stream_ptr()), "msam_decoder_forward")
+        return low, iou
+
+
+def build_sam(model_type: str = "vit_b", num_multimask_outputs: int = 3) -> Sam:
+    """micro_sam/models/build_sam.py:87-142 (image_size fixed at 1024)."""
+    key = model_type[:5]
+    if key not in VIT_CONFIGS:
+        raise ValueError(f"Invalid model_type: {model_type}. Expect one of {tuple(VIT_CONFIGS)} (vit_t: not supported)")
+    cfg = VIT_CONFIGS[key]
+    sam = Sam(ImageEncoderViT(cfg["embed_dim"], cfg["depth"], cfg["num_heads"], cfg["global_attn_indexes"]),
+              PromptEncoder(), MaskDecoder(num_multimask_outputs))
+    sam.eval()
+    return sam
+
+
+sam_model_registry = {
+    "vit_b": lambda **kw: build_sam("vit_b", **kw),
+    "vit_l": lambda **kw: build_sam("vit_l", **kw),
+    "vit_h": lambda **kw: build_sam("vit_h", **kw),
+}

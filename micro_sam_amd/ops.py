@@ -1,0 +1,179 @@
+"""Thin Python wrappers over the operator-level C ABI (tensors in, tensors out; torch only allocates)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32  # noqa: F401
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
+         out_dtype: torch.dtype = torch.float32, resid: Optional[torch.Tensor] = None, resid_rows: int = 0,
+         table: Optional[torch.Tensor] = None, table_cols: int = 0, use_glds: int = 0,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(a[M,K] @ w[N,K]^T + bias + table[row % rows, :table_cols] + resid); a, w bf16."""
+    _lib.require_gpu()
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    p = _lib.GemmParams()
+    p.A, p.lda, p.W, p.ldw, p.M, p.N, p.K = a.data_ptr(), K, w.data_ptr(), K, M, N, K
+    p.bias = _lib.ptr(bias)
+    if table is not None:
+        p.table, p.table_rows, p.table_cols, p.table_ld = table.data_ptr(), table.shape[0], table_cols, table.shape[1]
+    if resid is not None:
+        p.resid = resid.data_ptr()
+        p.resid_dtype = F32 if resid.dtype == torch.float32 else BF16
+        p.resid_rows, p.ldr = resid_rows, resid.shape[1]
+    p.act = act
+    p.out, p.out_dtype, p.ldc = out.data_ptr(), (F32 if out.dtype == torch.float32 else BF16), N
+    p.use_glds = use_glds
+    _lib.check(_lib.load().msam_gemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_gemm_bf16")
+    return out
+
+
+def gemm_qkv(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, heads: int, use_glds: int = 0):
+    """QKV projection with the ViT attention layout epilogue: returns q, k, v as bf16 [B,heads,tokens,hd]."""
+    M, K = a.shape
+    N = w.shape[0]
+    tokens, hd = M // B, N // 3 // heads
+    q, k, v = (torch.empty((B, heads, tokens, hd), dtype=torch.bfloat16, device=a.device) for _ in range(3))
+    p = _lib.GemmParams()
+    p.A, p.lda, p.W, p.ldw, p.M, p.N, p.K = a.data_ptr(), K, w.data_ptr(), K, M, N, K
+    p.bias = bias.data_ptr()
+    p.out_mode, p.q, p.k, p.v = 1, q.data_ptr(), k.data_ptr(), v.data_ptr()
+    p.heads, p.head_dim, p.tokens, p.use_glds = heads, hd, tokens, use_glds
+    _lib.check(_lib.load().msam_gemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_gemm_bf16(qkv)")
+    return q, k, v
+
+
+def gemm_kv(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, table: torch.Tensor, tokens: int, use_glds: int = 0):
+    """Decoder K|V projection (N == 256): k bf16 [M,128], vT bf16 [M/tokens,128,tokens]."""
+    M, K = a.shape
+    k = torch.empty((M, 128), dtype=torch.bfloat16, device=a.device)
+    vT = torch.empty((M // tokens, 128, tokens), dtype=torch.bfloat16, device=a.device)
+    p = _lib.GemmParams()
+    p.A, p.lda, p.W, p.ldw, p.M, p.N, p.K = a.data_ptr(), K, w.data_ptr(), K, M, 256, K
+    p.bias = bias.data_ptr()
+    p.table, p.table_rows, p.table_cols, p.table_ld = table.data_ptr(), table.shape[0], 128, table.shape[1]
+    p.out_mode, p.k, p.v, p.tokens, p.use_glds = 2, k.data_ptr(), vT.data_ptr(), tokens, use_glds
+    _lib.check(_lib.load().msam_gemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_gemm_bf16(kv)")
+    return k, vT
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out_dtype=torch.float32,
+              gelu: bool = False, nchw_hw: int = 0) -> torch.Tensor:
+    rows, dim = x.shape
+    if nchw_hw:
+        out = torch.empty((rows // nchw_hw, dim, nchw_hw), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((rows, dim), dtype=out_dtype, device=x.device)
+    _lib.check(_lib.load().msam_layernorm(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), eps, rows, dim, out.data_ptr(),
+                                          F32 if out.dtype == torch.float32 else BF16, int(gelu), nchw_hw,
+                                          _lib.stream_ptr()), "msam_layernorm")
+    return out
+
+
+def patchify(img: torch.Tensor) -> torch.Tensor:
+    B = img.shape[0]
+    out = torch.empty((B * 4096, 768), dtype=torch.bfloat16, device=img.device)
+    _lib.check(_lib.load().msam_patchify(img.data_ptr(), B, out.data_ptr(), _lib.stream_ptr()), "msam_patchify")
+    return out
+
+
+def patchify_u8(img: torch.Tensor) -> torch.Tensor:
+    B, h, w = img.shape[:3]
+    out = torch.empty((B * 4096, 768), dtype=torch.bfloat16, device=img.device)
+    _lib.check(_lib.load().msam_patchify_u8(img.data_ptr(), B, h, w, out.data_ptr(), _lib.stream_ptr()), "msam_patchify_u8")
+    return out
+
+
+def im2col3x3(x: torch.Tensor) -> torch.Tensor:
+    B, _, _, Cc = x.shape
+    out = torch.empty((B * 4096, 9 * Cc), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().msam_im2col3x3(x.data_ptr(), B, Cc, out.data_ptr(), _lib.stream_ptr()), "msam_im2col3x3")
+    return out
+
+
+def window_attention(q, k, v, rel_h, rel_w, qkv_bias) -> torch.Tensor:
+    B, heads = q.shape[:2]
+    out = torch.empty((B * 4096, heads * 64), dtype=torch.bfloat16, device=q.device)
+    _lib.check(_lib.load().msam_window_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
+                                                 qkv_bias.data_ptr(), B, heads, out.data_ptr(), _lib.stream_ptr()),
+               "msam_window_attention")
+    return out
+
+
+def global_attention(q, k, v, rel_h, rel_w) -> torch.Tensor:
+    B, heads = q.shape[:2]
+    out = torch.empty((B * 4096, heads * 64), dtype=torch.bfloat16, device=q.device)
+    _lib.check(_lib.load().msam_global_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
+                                                 B, heads, out.data_ptr(), _lib.stream_ptr()), "msam_global_attention")
+    return out
+
+
+def postprocess_masks(low_res: torch.Tensor, input_size: Tuple[int, int], original_size: Tuple[int, int],
+                      mask_threshold: float = 0.0, stability_offset: float = 1.0,
+                      want_logits: bool = False) -> Dict[str, torch.Tensor]:
+    """Fused Sam.postprocess_masks + stability counts + threshold + boxes + bit packing for masks [N,256,256].
+
+    Returns dict(counts int32 [N,3] = (#>thr+off, #>thr-off, #>thr), boxes int32 [N,4] xyxy, bits uint32
+    [N, ceil(H/32), W] as int32 storage, logits fp32 [N,H,W] when requested)."""
+    _lib.require_gpu()
+    low_res = low_res.to(torch.float32).contiguous()
+    N = low_res.shape[0]
+    H, W = int(original_size[0]), int(original_size[1])
+    dev = low_res.device
+    counts = torch.empty((N, 3), dtype=torch.int32, device=dev)
+    boxes = torch.empty((N, 4), dtype=torch.int32, device=dev)
+    bits = torch.empty((N, (H + 31) // 32, W), dtype=torch.int32, device=dev)
+    logits = torch.empty((N, H, W), dtype=torch.float32, device=dev) if want_logits else None
+    lib = _lib.load()
+    step = 65535
+    for s in range(0, N, step):
+        n = min(step, N - s)
+        _lib.check(lib.msam_postprocess_masks(
+            low_res[s:].data_ptr(), n, int(input_size[0]), int(input_size[1]), H, W, float(mask_threshold),
+            float(stability_offset), counts[s:].data_ptr(), boxes[s:].data_ptr(), bits[s:].data_ptr(),
+            None if logits is None else logits[s:].data_ptr(), _lib.stream_ptr()), "msam_postprocess_masks")
+    out = {"counts": counts, "boxes": boxes, "bits": bits}
+    if want_logits:
+        out["logits"] = logits
+    return out
+
+
+def rle_encode(bits: torch.Tensor, height: int, width: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Column-major uncompressed RLE of bit masks [N, ceil(H/32), W].  Returns (counts int32 [total], offsets int64 [N+1])."""
+    N = bits.shape[0]
+    lib = _lib.load()
+    n_runs = torch.empty((N,), dtype=torch.int32, device=bits.device)
+    _lib.check(lib.msam_rle_run_counts(bits.data_ptr(), N, height, width, n_runs.data_ptr(), _lib.stream_ptr()),
+               "msam_rle_run_counts")
+    offsets = torch.zeros((N + 1,), dtype=torch.int64, device=bits.device)
+    torch.cumsum(n_runs, 0, out=offsets[1:])
+    total = int(offsets[-1].item())
+    counts = torch.empty((total,), dtype=torch.int32, device=bits.device)
+    _lib.check(lib.msam_rle_encode(bits.data_ptr(), N, height, width, offsets.data_ptr(), counts.data_ptr(),
+                                   _lib.stream_ptr()), "msam_rle_encode")
+    return counts, offsets
+
+
+def rles_to_list(counts: torch.Tensor, offsets: torch.Tensor, height: int, width: int) -> List[Dict[str, Any]]:
+    """Device RLE buffers -> the reference's list-of-dicts format ({"size": [h, w], "counts": [...]})."""
+    c = counts.cpu().numpy()
+    o = offsets.cpu().numpy()
+    return [{"size": [height, width], "counts": c[o[i]:o[i + 1]].tolist()} for i in range(len(o) - 1)]
+
+
+def unpack_bits(bits: torch.Tensor, height: int) -> torch.Tensor:
+    """bit masks [N, ceil(H/32), W] -> bool [N,H,W] (test / binary_mask output helper; torch ops only)."""
+    N, wpc, W = bits.shape
+    sh = torch.arange(32, device=bits.device, dtype=torch.int32).view(1, 1, 32, 1)
+    m = ((bits.unsqueeze(2) >> sh) & 1).to(torch.bool).reshape(N, wpc * 32, W)
+    return m[:, :height]

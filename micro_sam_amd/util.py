@@ -1,0 +1,333 @@
+"""micro_sam.util's hot-path surface on the MI355X core: ``get_sam_model``, ``precompute_image_embeddings``,
+``set_precomputed``, ``_to_image``, ``mask_data_to_segmentation`` (reference: micro_sam/util.py:318-476,618-681,
+902-1018,1133-1258,1773-1848).  Same names, argument meaning and error behaviour; what is not provided this round
+raises ``NotImplementedError`` naming the missing piece (zarr cache on disk, tiling) instead of silently differing.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import warnings
+from collections import OrderedDict
+from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import modeling
+from .predictor import SamPredictor
+
+ImageEmbeddings = Dict[str, Any]
+_DEFAULT_MODEL = "vit_b"
+
+
+def get_device(device: Optional[Union[str, torch.device]] = None) -> Union[str, torch.device]:
+    """Reference util.py:204-231, restricted to what this build can run on: an AMD GPU."""
+    if device is None or device == "auto":
+        if not torch.cuda.is_available():
+            raise RuntimeError("micro_sam_amd requires a GPU (PyTorch-ROCm 'cuda' device); none is available.")
+        return "cuda"
+    dev_type = torch.device(device).type if not isinstance(device, str) else device.lower().split(":")[0]
+    if dev_type != "cuda":
+        raise RuntimeError(f"Unsupported device: {device}. micro_sam_amd only runs on 'cuda' (ROCm) devices.")
+    if not torch.cuda.is_available():
+        raise RuntimeError("PyTorch CUDA (ROCm) backend is not available.")
+    return device
+
+
+def _compute_hash(path: str) -> str:
+    import xxhash
+    h = xxhash.xxh128()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return f"xxh128:{h.hexdigest()}"
+
+
+def _load_checkpoint(checkpoint_path: str):
+    """torch_em style ({'model_state', 'decoder_state'}, 'sam.' prefix) or plain SAM state dict (util.py:273-290)."""
+    state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    if "model_state" in state:
+        model_state = OrderedDict((k[len("sam."):] if k.startswith("sam.") else k, v)
+                                  for k, v in state["model_state"].items())
+    else:
+        model_state = state
+    return state, model_state
+
+
+def _validate_model_type(state) -> str:
+    """micro_sam/models/build_sam.py:24-37."""
+    if "image_encoder.patch_embed.proj.weight" in state:
+        return {768: "vit_b", 1024: "vit_l", 1280: "vit_h"}[state["image_encoder.patch_embed.proj.weight"].shape[0]]
+    return "vit_t"
+
+
+def get_sam_model(model_type: str = _DEFAULT_MODEL, device: Optional[Union[str, torch.device]] = None,
+                  checkpoint_path: Optional[Union[str, os.PathLike]] = None, return_sam: bool = False,
+                  return_state: bool = False, peft_kwargs: Optional[Dict] = None, flexible_load_checkpoint: bool = False,
+                  progress_bar_factory: Optional[Callable] = None, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+                  **model_kwargs):
+    """Build the HIP-backed SAM and wrap it in a ``SamPredictor`` (reference util.py:318-476).
+
+    ``state_dict`` (extension): an upstream-named state dict used instead of a checkpoint file - the build / GPU
+    environments have no network, so the reference's pooch download of named models is not available; without
+    ``checkpoint_path`` or ``state_dict`` this raises."""
+    device = get_device(device)
+    if peft_kwargs:
+        raise NotImplementedError("micro_sam_amd: PEFT surgery is not provided (SURVEY.md 8(f) rank 4)")
+    abbreviated = model_type[:5]
+    if abbreviated not in ("vit_b", "vit_l", "vit_h", "vit_t"):
+        raise ValueError(f"Invalid model_type: {abbreviated}. Expect one of ('vit_h', 'vit_b', 'vit_l', 'vit_t')")
+    state, model_hash = None, "xxh128:synthetic"
+    if checkpoint_path is not None:
+        checkpoint_path = str(checkpoint_path)
+        model_hash = _compute_hash(checkpoint_path)
+        state, model_state = _load_checkpoint(checkpoint_path)
+        provided = _validate_model_type(model_state)
+        if abbreviated != provided:
+            warnings.warn(f"'model_type' {model_type!r} does not match the checkpoint ({provided!r}); using {provided!r}.")
+            model_type = abbreviated = provided
+    elif state_dict is not None:
+        model_state = state_dict
+    else:
+        raise RuntimeError("micro_sam_amd.get_sam_model: no network access for model downloads - pass checkpoint_path "
+                           "(a SAM / micro_sam checkpoint file) or state_dict.")
+    if abbreviated == "vit_t":
+        raise RuntimeError("vit_t (MobileSAM / TinyViT) is not provided by micro_sam_amd; use vit_b / vit_l.")
+    sam = modeling.sam_model_registry[abbreviated](**model_kwargs)
+    if flexible_load_checkpoint:
+        own = sam.state_dict()
+        model_state = {k: v for k, v in model_state.items() if k in own and own[k].shape == v.shape}
+        sam.load_state_dict(model_state, strict=False)
+    else:
+        sam.load_state_dict(model_state)
+    sam.to(device=device)
+    predictor = SamPredictor(sam)
+    predictor.model_type = abbreviated
+    predictor._hash = model_hash
+    predictor.model_name = model_type
+    predictor.checkpoint_path = checkpoint_path
+    if return_sam and return_state:
+        return predictor, sam, state
+    if return_sam:
+        return predictor, sam
+    if return_state:
+        return predictor, state
+    return predictor
+
+
+# ------------------------------------------------------------------------------------------------ embeddings
+
+def _to_image(image):
+    """Any 2-d / HWC array -> uint8 RGB with per-channel min-max normalisation (reference util.py:618-651)."""
+    input_ = image
+    ndim = input_.ndim
+    n_channels = 1 if ndim == 2 else input_.shape[-1]
+    if ndim == 2:
+        input_ = np.concatenate([input_[..., None]] * 3, axis=-1)
+    elif ndim == 3 and n_channels == 1:
+        input_ = np.concatenate([input_] * 3, axis=-1)
+    elif ndim == 3 and n_channels == 2:
+        input_ = np.concatenate([input_, np.zeros(input_.shape[:2] + (1,), dtype=input_.dtype)], axis=-1)
+    elif ndim == 3 and n_channels == 3:
+        pass
+    elif ndim == 3 and n_channels > 3:
+        warnings.warn(f"You provided an input with {n_channels} channels. Only the first three will be used.")
+        input_ = input_[..., :3]
+    else:
+        raise ValueError(f"Invalid input dimensionality {ndim}. Expect either a 2D input (=grayscale image) "
+                         "or a 3D input (= image with channels).")
+    assert input_.ndim == 3 and input_.shape[-1] == 3
+    input_ = input_.astype("float32")
+    input_ -= input_.min(axis=(0, 1))[None, None]
+    input_ /= (input_.max(axis=(0, 1))[None, None] + 1e-7)
+    return np.array((input_ * 255).astype("uint8"))
+
+
+@torch.no_grad()
+def _compute_embeddings_batched(predictor, batched_images):
+    """Reference util.py:654-681; normalisation + padding are fused into the encoder's uint8 patch gather."""
+    predictor.reset_image()
+    tensors, original_sizes, input_sizes = [], [], []
+    for image in batched_images:
+        resized = predictor.transform.apply_image(image)
+        original_sizes.append(image.shape[:2])
+        input_sizes.append(tuple(resized.shape[:2]))
+        tensors.append(torch.as_tensor(np.ascontiguousarray(resized)))
+    if len({t.shape for t in tensors}) != 1:
+        raise ValueError("All images of a batch must have the same shape.")
+    batch = torch.stack(tensors).to(predictor.device, non_blocking=True)
+    features = predictor.model.image_encoder.forward_u8(batch)
+    predictor.original_size = original_sizes[-1]
+    predictor.input_size = input_sizes[-1]
+    predictor.features = features[-1:]
+    predictor.is_image_set = True
+    return features, original_sizes, input_sizes
+
+
+def handle_pbar(verbose, pbar_init, pbar_update):
+    """Reference util.py:1098-1130."""
+    if verbose and pbar_init is None:
+        assert pbar_update is None
+        from tqdm import tqdm
+        pbar = tqdm()
+
+        def pbar_init(total, description):
+            pbar.total = total
+            pbar.set_description(description)
+
+        def pbar_update(update):
+            pbar.update(update)
+
+        def pbar_close():
+            pbar.close()
+    elif verbose and pbar_init is not None:
+        assert pbar_update is not None
+        pbar = None
+
+        def pbar_close():
+            pass
+    else:
+        pbar = None
+
+        def noop(*args):
+            pass
+
+        pbar_init, pbar_update, pbar_close = noop, noop, noop
+    return pbar, pbar_init, pbar_update, pbar_close
+
+
+def _compute_2d(input_, predictor, pbar_init, pbar_update, keep_on_device):
+    pbar_init(1, "Compute Image Embeddings 2D")
+    predictor.reset_image()
+    predictor.set_image(_to_image(input_))
+    features = predictor.get_image_embedding()
+    features = features if keep_on_device else features.cpu().numpy()
+    pbar_update(1)
+    return {"features": features, "input_size": predictor.input_size, "original_size": predictor.original_size}
+
+
+def _compute_3d(input_, predictor, pbar_init, pbar_update, batch_size, keep_on_device):
+    n_slices = input_.shape[0]
+    pbar_init(n_slices, "Compute Image Embeddings 3D")
+    features = []
+    input_sizes = original_sizes = None
+    for z_start in range(0, n_slices, batch_size):
+        z_stop = min(z_start + batch_size, n_slices)
+        images = [_to_image(input_[z]) for z in range(z_start, z_stop)]
+        emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, images)
+        features.append(emb.unsqueeze(1))          # [b,1,256,64,64]
+        pbar_update(z_stop - z_start)
+    features = torch.cat(features)
+    if not keep_on_device:
+        features = features.cpu().numpy()
+    return {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}
+
+
+def precompute_image_embeddings(predictor: SamPredictor, input_: np.ndarray, save_path=None, lazy_loading: bool = False,
+                                ndim: Optional[int] = None, tile_shape: Optional[Tuple[int, int]] = None,
+                                halo: Optional[Tuple[int, int]] = None, verbose: bool = True, batch_size: int = 1,
+                                mask=None, pbar_init: Optional[callable] = None, pbar_update: Optional[callable] = None,
+                                keep_on_device: bool = False) -> ImageEmbeddings:
+    """Reference util.py:1133-1212.  ``keep_on_device`` (extension): return the features as a device tensor instead of
+    a host numpy array (``set_precomputed`` accepts both, as in the reference util.py:1248-1252)."""
+    ndim = input_.ndim if ndim is None else ndim
+    if save_path is not None:
+        raise NotImplementedError("micro_sam_amd: the zarr embedding cache (save_path) is not provided this round")
+    if tile_shape is not None:
+        raise NotImplementedError("micro_sam_amd: tiled embeddings (tile_shape / halo) are not provided this round")
+    _, pbar_init, pbar_update, pbar_close = handle_pbar(verbose, pbar_init, pbar_update)
+    if ndim == 2:
+        embeddings = _compute_2d(input_, predictor, pbar_init, pbar_update, keep_on_device)
+    elif ndim == 3:
+        embeddings = _compute_3d(input_, predictor, pbar_init, pbar_update, batch_size, keep_on_device)
+    else:
+        raise ValueError(f"Invalid dimesionality {input_.ndim}, expect 2 or 3 dim data.")
+    pbar_close()
+    return embeddings
+
+
+def set_precomputed(predictor: SamPredictor, image_embeddings: ImageEmbeddings, i: Optional[int] = None,
+                    tile_id: Optional[int] = None) -> SamPredictor:
+    """Reference util.py:1215-1258."""
+    if tile_id is not None:
+        raise NotImplementedError("micro_sam_amd: tiled embeddings are not provided this round")
+    device = predictor.device
+    features = image_embeddings["features"]
+    assert features.ndim in (4, 5), f"{features.ndim}"
+    if features.ndim == 5 and i is None:
+        raise ValueError("The data is 3D so an index i is needed.")
+    elif features.ndim == 4 and i is not None:
+        raise ValueError("The data is 2D so an index is not needed.")
+    sel = features if i is None else features[i]
+    predictor.features = sel.to(device) if torch.is_tensor(sel) else torch.from_numpy(np.asarray(sel[:])).to(device)
+    predictor.original_size = image_embeddings["original_size"]
+    predictor.input_size = image_embeddings["input_size"]
+    predictor.is_image_set = True
+    return predictor
+
+
+# ------------------------------------------------------------------------------------------------ label image
+
+def _label_equal_value_components(seg: np.ndarray) -> np.ndarray:
+    """4-connected components of equal non-zero value, numbered in raster order of their first pixel
+    (``elf.parallel.label`` in the reference util.py:1834; numbering rule documented in DESIGN.md).
+
+    Components are found on the (2H-1)x(2W-1) pixel/link lattice with scipy's binary labelling."""
+    from scipy import ndimage
+    h, w = seg.shape
+    lat = np.zeros((2 * h - 1, 2 * w - 1), dtype=bool)
+    fg = seg != 0
+    lat[::2, ::2] = fg
+    lat[::2, 1::2] = fg[:, 1:] & (seg[:, 1:] == seg[:, :-1])
+    lat[1::2, ::2] = fg[1:, :] & (seg[1:, :] == seg[:-1, :])
+    lab, _ = ndimage.label(lat)           # default structure: 4-connectivity; labels in raster order
+    return lab[::2, ::2].astype(seg.dtype)
+
+
+def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape: Optional[Tuple[int, int]] = None,
+                              min_object_size: int = 0, max_object_size: Optional[int] = None, label_masks: bool = True,
+                              with_background: bool = False, merge_exclusively: bool = True) -> np.ndarray:
+    """Reference util.py:1773-1848."""
+    masks = sorted(masks, key=(lambda x: x["area"]), reverse=True)
+    if shape is None:
+        shape = next(iter(masks))["segmentation"].shape
+    segmentation = np.zeros(shape, dtype="uint32")
+
+    def require_numpy(mask):
+        return mask.cpu().numpy() if torch.is_tensor(mask) else mask
+
+    seg_id = 1
+    for mask_data in masks:
+        area = mask_data["area"]
+        if (area < min_object_size) or (max_object_size is not None and area > max_object_size):
+            continue
+        this_mask = require_numpy(mask_data["segmentation"])
+        this_seg_id = mask_data.get("seg_id", seg_id)
+        if "global_bbox" in mask_data:
+            bb = mask_data["bbox"]
+            bb = np.s_[bb[1]:bb[1] + bb[3], bb[0]:bb[0] + bb[2]]
+            gbb = mask_data["global_bbox"]
+            gbb = np.s_[gbb[1]:gbb[1] + gbb[3], gbb[0]:gbb[0] + gbb[2]]
+            this_mask = np.logical_and(this_mask[bb], segmentation[gbb] == 0) if merge_exclusively else this_mask[bb]
+            segmentation[gbb][this_mask] = this_seg_id
+        else:
+            if merge_exclusively:
+                this_mask = np.logical_and(this_mask, segmentation == 0)
+            segmentation[this_mask] = this_seg_id
+        seg_id = this_seg_id + 1
+    if label_masks:
+        segmentation = _label_equal_value_components(segmentation)
+    sizes = np.bincount(segmentation.ravel())
+    seg_ids = np.nonzero(sizes)[0]
+    sizes = sizes[seg_ids]
+    filter_ids = seg_ids[sizes < min_object_size]
+    if with_background:
+        filter_ids = np.concatenate([filter_ids, [seg_ids[np.argmax(sizes)]]])
+    lut = np.ones(int(segmentation.max()) + 1, dtype=bool)
+    lut[filter_ids] = False
+    lut[0] = False
+    # zero the filtered ids, then relabel the survivors consecutively (order preserving, 0 stays 0)
+    new_ids = np.zeros(lut.shape[0], dtype=segmentation.dtype)
+    new_ids[lut] = np.arange(1, int(lut.sum()) + 1, dtype=segmentation.dtype)
+    return new_ids[segmentation]

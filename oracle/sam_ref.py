@@ -323,9 +323,19 @@ def prompt_encoder(sd: Dict[str, Tensor], points: Optional[Tuple[Tensor, Tensor]
 # Mask decoder (upstream modeling/mask_decoder.py + transformer.py)
 # ----------------------------------------------------------------------------------------------
 
-def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads: int = 8) -> Tensor:
-    q = p.linear(q, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"])
-    k = p.linear(k, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"])
+def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads: int = 8,
+                   q_pe: Optional[Tensor] = None, k_pe: Optional[Tensor] = None, mfma_pv: bool = False) -> Tensor:
+    """q_pe / k_pe: positional encodings of the IMAGE-side operand.  fp32 mode adds them before the projection
+    (upstream); bf16 mode follows the HIP dataflow (x + pe) W = x W + pe W with separately rounded operands."""
+    def proj(x, pe, name):
+        w, b = sd[pre + name + ".weight"], sd[pre + name + ".bias"]
+        if pe is None:
+            return p.linear(x, w, b)
+        if not p.bf16:
+            return p.linear(x + pe, w, b)
+        return p.linear(x, w, b) + p.linear(pe, w)
+    q = proj(q, q_pe, "q_proj")
+    k = proj(k, k_pe, "k_proj")
     v = p.linear(v, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"])
     q, k, v = p.r(q), p.r(k), p.r(v)   # HIP path stores the projected q/k/v in bf16
     b, nq, c = q.shape
@@ -333,8 +343,12 @@ def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads
         return t.reshape(b, t.shape[1], heads, c // heads).transpose(1, 2)
     q, k, v = sep(q), sep(k), sep(v)
     attn = (q @ k.transpose(-2, -1)) / math.sqrt(c // heads)
-    attn = torch.softmax(attn, dim=-1)
-    out = attn @ v
+    if p.bf16 and mfma_pv:
+        # HIP cross attentions: un-normalised probabilities rounded to bf16 for the P.V MFMA, fp32 row sum
+        e = torch.exp(attn - attn.max(dim=-1, keepdim=True).values)
+        out = (p.r(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        out = torch.softmax(attn, dim=-1) @ v
     out = out.transpose(1, 2).reshape(b, nq, c)
     return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
 
@@ -343,7 +357,8 @@ def _ln(sd, pre: str, x: Tensor, eps: float = 1e-5) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[pre + "weight"], sd[pre + "bias"], eps=eps)
 
 
-def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_embedding: Tensor, p: Prec):
+def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_embedding: Tensor, p: Prec,
+                        debug: Optional[dict] = None):
     pre = "mask_decoder.transformer."
     bs, c, h, w = image_embedding.shape
     keys = image_embedding.flatten(2).permute(0, 2, 1)
@@ -360,20 +375,25 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
             queries = queries + _dec_attention(sd, lp + "self_attn.", q, q, queries, p)
         queries = _ln(sd, lp + "norm1.", queries)
         q = queries + query_pe
-        k = keys + key_pe
-        queries = queries + _dec_attention(sd, lp + "cross_attn_token_to_image.", q, k, keys, p)
+        queries = queries + _dec_attention(sd, lp + "cross_attn_token_to_image.", q, keys, keys, p, k_pe=key_pe,
+                                           mfma_pv=True)
         queries = _ln(sd, lp + "norm2.", queries)
         m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"])
         m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"])
         queries = _ln(sd, lp + "norm3.", queries + m)
         q = queries + query_pe
-        k = keys + key_pe
-        keys = keys + _dec_attention(sd, lp + "cross_attn_image_to_token.", k, q, queries, p)
+        keys = keys + _dec_attention(sd, lp + "cross_attn_image_to_token.", keys, q, queries, p, q_pe=key_pe,
+                                     mfma_pv=True)
         keys = p.r(_ln(sd, lp + "norm4.", keys))
+        if debug is not None:
+            debug[f"queries{i}"] = queries.clone()
+            debug[f"keys{i}"] = keys.clone()
     q = queries + query_pe
-    k = keys + key_pe
-    queries = queries + _dec_attention(sd, pre + "final_attn_token_to_image.", q, k, keys, p)
+    queries = queries + _dec_attention(sd, pre + "final_attn_token_to_image.", q, keys, keys, p, k_pe=key_pe,
+                                       mfma_pv=True)
     queries = _ln(sd, pre + "norm_final_attn.", queries)
+    if debug is not None:
+        debug["queries_final"] = queries.clone()
     return queries, keys
 
 
@@ -384,7 +404,7 @@ def _mlp3(sd, pre: str, x: Tensor, p: Prec) -> Tensor:
 
 
 def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor, dense: Tensor,
-                 multimask_output: bool, precision: str = "fp32") -> Tuple[Tensor, Tensor]:
+                 multimask_output: bool, precision: str = "fp32", debug: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
     """MaskDecoder.forward -> (low-res masks [B,C,256,256], iou [B,C])."""
     p = Prec(precision)
     pre = "mask_decoder."
@@ -395,17 +415,24 @@ def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor,
     src = src + dense
     pos_src = torch.repeat_interleave(image_pe, tokens.shape[0], dim=0)
     b, c, h, w = src.shape
-    hs, src = two_way_transformer(sd, src, pos_src, tokens, p)
+    if debug is not None:
+        debug["tokens"] = tokens.clone()
+    hs, src = two_way_transformer(sd, src, pos_src, tokens, p, debug)
     iou_token_out = hs[:, 0, :]
     mask_tokens_out = hs[:, 1:5, :]
     src = src.transpose(1, 2).view(b, c, h, w)
     up = F.conv_transpose2d(p.r(src), p.r(sd[pre + "output_upscaling.0.weight"]), None, stride=2)
     up = up + sd[pre + "output_upscaling.0.bias"].view(1, -1, 1, 1)
     up = F.gelu(layer_norm_2d(up, sd[pre + "output_upscaling.1.weight"], sd[pre + "output_upscaling.1.bias"]))
+    if debug is not None:
+        debug["up1"] = up.clone()
     up = F.conv_transpose2d(p.r(up), p.r(sd[pre + "output_upscaling.3.weight"]), None, stride=2)
     up = F.gelu(up + sd[pre + "output_upscaling.3.bias"].view(1, -1, 1, 1))
     hyper = torch.stack(
         [_mlp3(sd, f"{pre}output_hypernetworks_mlps.{i}.", mask_tokens_out[:, i, :], p) for i in range(4)], dim=1)
+    if debug is not None:
+        debug["hyper"] = hyper.clone()
+        debug["up"] = up.clone()
     b, c, h, w = up.shape
     masks = (hyper @ up.view(b, c, h * w)).view(b, -1, h, w)   # fp32 product in both modes
     iou = _mlp3(sd, pre + "iou_prediction_head.", iou_token_out, p)
@@ -415,11 +442,12 @@ def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor,
 
 def predict_torch(sd, features: Tensor, input_size, original_size, point_coords: Optional[Tensor],
                   point_labels: Optional[Tensor], boxes: Optional[Tensor] = None, mask_input: Optional[Tensor] = None,
-                  multimask_output: bool = True, return_logits: bool = False, precision: str = "fp32"):
+                  multimask_output: bool = True, return_logits: bool = False, precision: str = "fp32",
+                  debug: Optional[dict] = None):
     """SamPredictor.predict_torch -> (masks, iou, low_res)."""
     points = (point_coords, point_labels) if point_coords is not None else None
     sparse, dense = prompt_encoder(sd, points, boxes, mask_input)
-    low_res, iou = mask_decoder(sd, features, get_dense_pe(sd), sparse, dense, multimask_output, precision)
+    low_res, iou = mask_decoder(sd, features, get_dense_pe(sd), sparse, dense, multimask_output, precision, debug)
     masks = postprocess_masks(low_res, input_size, original_size)
     if not return_logits:
         masks = masks > 0.0
