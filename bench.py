@@ -1,0 +1,189 @@
+"""Benchmark of the hot path: 1024^2 tiles/s, embed + AMG (vit_b, bf16 MFMA operands), BASELINE.json config 2.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = TILES_PER_STEP synthetic tiles per rank through: batched image encoder -> per tile AutomaticMaskGenerator
+initialize (32x32 grid prompts, 64 per decoder batch, fused mask post-processing + RLE on the device) -> generate
+(default thresholds, box NMS, merge to a uint32 label image); with N > 1 the label tiles of all ranks are all-gathered
+(RCCL) inside the timed region.  Inputs (uint8 RGB tiles, output of util._to_image) are resident in HBM before the timed
+region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TILES_PER_STEP = 8
+ENC_BATCH = 8
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+TILE_TFLOP_ALGORITHMIC = 4.64      # encoder 0.938 + AMG decode 3.70
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(sd, tile_u8):
+    """The CPU oracle (restated reference hot path, fp32) on a bounded sample of the same workload:
+    one tile's encoder + 2 of its 16 decoder batches (+ their mask post-processing) + generate; the per-batch cost is
+    extrapolated to 16 batches.  Reported only, never used as a target."""
+    from oracle import amg_ref as A
+    from oracle import pipeline_ref as PR
+    torch.set_num_threads(os.cpu_count() or 1)
+    img = A.to_image(tile_u8)
+    t0 = time.perf_counter()
+    feats, osz, isz = PR.compute_embeddings(sd, [img], "vit_b", "fp32")
+    t_enc = time.perf_counter() - t0
+    tm = {}
+    t0 = time.perf_counter()
+    state = PR.amg_initialize(sd, img, feats, isz[0], osz[0], precision="fp32", timings=tm, max_batches=2)
+    t_init2 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    PR.amg_generate(state)
+    t_gen = time.perf_counter() - t0
+    per_tile = t_enc + 8.0 * t_init2 + t_gen
+    return {"value": 1.0 / per_tile, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 tile: encoder {t_enc:.1f}s + 2/16 decoder batches {t_init2:.1f}s (x8 extrapolated) + "
+                      f"generate {t_gen:.1f}s, fp32 torch on host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--glds", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from micro_sam_amd import _lib, parallel, util
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+
+    sd = synthetic_state_dict("vit_b", 0, variant="blobs")
+    predictor = util.get_sam_model("vit_b", device=dev, state_dict=sd)
+    predictor.model.use_glds = args.glds
+    predictor.model.image_encoder.use_glds = args.glds
+    amg = AutomaticMaskGenerator(predictor)          # reference defaults: 32x32 grid, 64 points per batch
+
+    n_steps = args.warmup + args.steps
+    # distinct synthetic tiles per rank and step (seed = global tile index), staged in HBM before timing
+    n_tiles = TILES_PER_STEP
+    tiles_np = [synthetic_tile(1000 + rank * n_tiles + i) for i in range(n_tiles)]
+    tiles_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in tiles_np]).to(dev)
+    torch.cuda.synchronize()
+    lib = _lib.load()
+    stage = {"encode": 0.0, "initialize": 0.0, "generate": 0.0, "gather": 0.0}
+    n_instances = 0
+
+    prof = {"launches": 0, "ms": 0.0, "flops": 0.0}
+
+    def collect():
+        n_, ms_, fl_ = C.c_int32(), C.c_double(), C.c_double()
+        lib.msam_profile_collect(C.byref(n_), C.byref(ms_), C.byref(fl_))
+        prof["launches"] += n_.value; prof["ms"] += ms_.value; prof["flops"] += fl_.value
+
+    def step(timed: bool):
+        nonlocal n_instances
+        labels = torch.empty((n_tiles, 1024, 1024), dtype=torch.int32, device=dev)
+        t0 = time.perf_counter()
+        feats = []
+        for s in range(0, n_tiles, ENC_BATCH):
+            feats.append(predictor.model.image_encoder.forward_u8(tiles_u8[s:s + ENC_BATCH]))
+        feats = torch.cat(feats).unsqueeze(1)                       # [n,1,256,64,64] on device
+        emb = {"features": feats, "input_size": (1024, 1024), "original_size": (1024, 1024)}
+        if timed:
+            torch.cuda.synchronize(); stage["encode"] += time.perf_counter() - t0
+            collect()
+        for i in range(n_tiles):
+            t1 = time.perf_counter()
+            amg.initialize(tiles_np[i], emb, i=i)
+            if timed:
+                torch.cuda.synchronize(); stage["initialize"] += time.perf_counter() - t1
+                collect()
+            t2 = time.perf_counter()
+            seg = amg.generate()
+            labels[i] = torch.as_tensor(seg.astype(np.int32), device=dev)
+            n_instances = int(seg.max())
+            if timed:
+                stage["generate"] += time.perf_counter() - t2
+        t3 = time.perf_counter()
+        full = parallel.gather_label_tiles(labels, n_tiles * world) if world > 1 else labels
+        if timed:
+            torch.cuda.synchronize(); stage["gather"] += time.perf_counter() - t3
+        return full
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lib.msam_profile_enable(1)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    lib.msam_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_tiles = n_tiles * args.steps * world
+        value = total_tiles / elapsed
+        achieved = prof["flops"] / (prof["ms"] * 1e-3) / 1e12 if prof["ms"] > 0 else 0.0
+        out = {
+            "metric": "1024^2 tiles/s embed+AMG (vit_b bf16)", "value": round(value, 4), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
+                                   "AutomaticMaskGenerator (32x32 grid, 64 prompts/batch, multimask, default thresholds)",
+                       "tiles_per_step_per_gpu": n_tiles, "encoder_batch": ENC_BATCH, "weights": "seeded random init "
+                       "(synthetic.py variant 'blobs')", "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
+                       "instances_last_tile": n_instances,
+                       "stage_seconds_per_tile": {k: round(v / (n_tiles * args.steps), 5) for k, v in stage.items()},
+                       "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC,
+                       "whole_path_tflops_algorithmic": round(TILE_TFLOP_ALGORITHMIC * value / world, 2)},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<GLDS=%d> (bf16 MFMA GEMM, all projection / MLP / conv GEMMs)" % args.glds,
+                         "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": prof["launches"],
+                         "avg_launch_us": round(prof["ms"] * 1e3 / max(prof["launches"], 1), 2),
+                         "avg_launch_gflop": round(prof["flops"] / max(prof["launches"], 1) / 1e9, 3),
+                         "gemm_seconds_per_tile": round(prof["ms"] * 1e-3 / (n_tiles * args.steps), 5)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            log("timing the CPU oracle on a bounded sample ...")
+            out["cpu_baseline"] = cpu_baseline(sd, tiles_np[0])
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,6 +62,13 @@ typedef struct {
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 
+/* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
+ * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
+ * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and
+ * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
+int msam_profile_enable(int on);
+int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops);
+
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
  * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.
  * out_nchw_hw > 0: write fp32 output transposed to [rows/hw, dim, hw] (the encoder's NCHW result). */

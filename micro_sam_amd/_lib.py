@@ -73,6 +73,8 @@ _PROTOS = {
     "msam_last_error": (C.c_char_p, []),
     "msam_abi_version": (_i32, []),
     "msam_gemm_bf16": (_i32, [C.POINTER(GemmParams), _vp]),
+    "msam_profile_enable": (_i32, [_i32]),
+    "msam_profile_collect": (_i32, [C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

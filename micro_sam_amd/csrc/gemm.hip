@@ -242,6 +242,44 @@ int msam_check_launch(const char* what) {
     return 0;
 }
 
+// ---- optional live profiling of the GEMM kernel with HIP events on the launch stream (bench.py roofline leg)
+namespace {
+struct ProfSlot { hipEvent_t a, b; double flops; };
+constexpr int PROF_MAX = 4096;
+ProfSlot g_prof[PROF_MAX];
+int g_prof_n = 0, g_prof_on = 0, g_prof_init = 0;
+}  // namespace
+
+extern "C" int msam_profile_enable(int on) {
+    if (on && !g_prof_init) {
+        for (int i = 0; i < PROF_MAX; ++i) {
+            if (hipEventCreate(&g_prof[i].a) != hipSuccess || hipEventCreate(&g_prof[i].b) != hipSuccess) {
+                msam_set_error("msam_profile_enable: hipEventCreate failed");
+                return 2;
+            }
+        }
+        g_prof_init = 1;
+    }
+    g_prof_on = on; g_prof_n = 0;
+    return 0;
+}
+
+// Synchronises the recorded events; returns launches, total milliseconds and total flops (2*M*N*K) since enable.
+extern "C" int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops) {
+    double ms = 0, fl = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (hipEventSynchronize(g_prof[i].b) != hipSuccess) { msam_set_error("msam_profile_collect: sync failed"); return 2; }
+        float t = 0.f;
+        hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+        ms += t; fl += g_prof[i].flops;
+    }
+    if (launches) *launches = g_prof_n;
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    g_prof_n = 0;
+    return 0;
+}
+
 extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     if (!p || !p->A || !p->W) { msam_set_error("msam_gemm_bf16: null operand"); return 1; }
     if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->N % BN != 0 || p->K % BK != 0) {
@@ -272,11 +310,17 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
     int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     hipStream_t s = (hipStream_t)stream;
+    const bool prof = g_prof_on && g_prof_n < PROF_MAX;
+    if (prof) {
+        g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K;
+        (void)hipEventRecord(g_prof[g_prof_n].a, s);
+    }
     if (p->use_glds)
         hipLaunchKernelGGL(gemm_kernel<true>, dim3(tiles), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
                            (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
     else
         hipLaunchKernelGGL(gemm_kernel<false>, dim3(tiles), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
                            (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+    if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
     return msam_check_launch("msam_gemm_bf16");
 }

@@ -71,7 +71,8 @@ class AMGBase(ABC):
         elif output_mode in ("binary_mask", "instance_segmentation"):
             mask_data["segmentations"] = [amg_utils.rle_to_mask(rle) for rle in mask_data["rles"]]
         elif output_mode == "rle":
-            mask_data["segmentations"] = mask_data["rles"]
+            mask_data["segmentations"] = [{"size": r["size"], "counts": np.asarray(r["counts"]).tolist()}
+                                          for r in mask_data["rles"]]
         else:
             raise ValueError(f"Invalid output mode {output_mode}.")
         curr_anns = []
@@ -106,7 +107,8 @@ class AMGBase(ABC):
         data["stability_score"] = counts[:, 0] / counts[:, 1]
         data["boxes"] = post["boxes"]
         rle_counts, rle_offsets = ops.rle_encode(post["bits"], orig_h, orig_w)
-        data["rles"] = ops.rles_to_list(rle_counts, rle_offsets, orig_h, orig_w)
+        # counts stay int32 numpy views (not Python lists): same content as the reference's RLE dicts
+        data["rles"] = ops.rles_to_list(rle_counts, rle_offsets, orig_h, orig_w, as_list=False)
         return data
 
     def get_state(self) -> Dict[str, Any]:

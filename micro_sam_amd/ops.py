@@ -164,11 +164,17 @@ def rle_encode(bits: torch.Tensor, height: int, width: int) -> Tuple[torch.Tenso
     return counts, offsets
 
 
-def rles_to_list(counts: torch.Tensor, offsets: torch.Tensor, height: int, width: int) -> List[Dict[str, Any]]:
-    """Device RLE buffers -> the reference's list-of-dicts format ({"size": [h, w], "counts": [...]})."""
+def rles_to_list(counts: torch.Tensor, offsets: torch.Tensor, height: int, width: int,
+                 as_list: bool = True) -> List[Dict[str, Any]]:
+    """Device RLE buffers -> the reference's list-of-dicts format ({"size": [h, w], "counts": [...]}).
+
+    ``as_list=False`` keeps every ``counts`` as an int32 numpy view into one host buffer (no per-element Python
+    objects); ``rle_to_mask`` / ``area_from_rle`` / pickling work on both."""
     c = counts.cpu().numpy()
     o = offsets.cpu().numpy()
-    return [{"size": [height, width], "counts": c[o[i]:o[i + 1]].tolist()} for i in range(len(o) - 1)]
+    if as_list:
+        return [{"size": [height, width], "counts": c[o[i]:o[i + 1]].tolist()} for i in range(len(o) - 1)]
+    return [{"size": [height, width], "counts": c[o[i]:o[i + 1]]} for i in range(len(o) - 1)]
 
 
 def unpack_bits(bits: torch.Tensor, height: int) -> torch.Tensor:

@@ -36,24 +36,31 @@ def _load_calibration() -> Dict[str, dict]:
         return json.load(f)
 
 
-def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0,
-                         calibrated: bool = True) -> "OrderedDict[str, torch.Tensor]":
+def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0, calibrated: bool = True,
+                         variant: str = "field") -> "OrderedDict[str, torch.Tensor]":
     """fp32 CPU state_dict with upstream SAM key names for ``model_type`` in {vit_b, vit_l, vit_h}.
 
-    ``calibrated``: apply the 32-float hyper-network calibration stored in ``data/synthetic_calib.json``
-    (written by ``tools/calibrate_synthetic.py``) when one exists for (model_type, seed)."""
+    ``variant``:
+      "field"  mask logits are zero-mean fields that follow the image content (masks span the image; numerically
+               benign: used by the parity tests);
+      "blobs"  additionally gives the image->token attention a prompt-locality kernel and the hyper-network a
+               negative far-field offset, so every grid prompt yields a compact blob near its point: realistic AMG
+               workload (distinct boxes, non-trivial NMS, hundreds of instances, short RLEs) - used by bench.py.
+    ``calibrated``: apply the hyper-network calibration stored in ``data/synthetic_calib.json`` (written by
+    ``tools/calibrate_synthetic.py``) when one exists for (model_type, seed, variant)."""
+    assert variant in ("field", "blobs"), variant
     cfg = VIT_CONFIGS[model_type[:5]]
     D, depth, heads = cfg["embed_dim"], cfg["depth"], cfg["num_heads"]
     hd = D // heads
     g = torch.Generator().manual_seed(seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    calib = _load_calibration().get(f"{model_type[:5]}/{seed}") if calibrated else None
+    calib = _load_calibration().get(f"{model_type[:5]}/{seed}/{variant}") if calibrated else None
 
     def n(*shape, std=0.02, mean=0.0):
         return torch.randn(*shape, generator=g) * std + mean
 
     e = "image_encoder."
-    sd[e + "pos_embed"] = n(1, 64, 64, D, std=0.1)
+    sd[e + "pos_embed"] = n(1, 64, 64, D, std=0.02)
     sd[e + "patch_embed.proj.weight"] = n(D, 3, 16, 16, std=0.03)
     sd[e + "patch_embed.proj.bias"] = n(D, std=0.02)
     for i in range(depth):
@@ -117,18 +124,29 @@ def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0,
         sd[lp + "norm3.weight"] = n(256, std=0.05, mean=1.0); sd[lp + "norm3.bias"] = n(256, std=0.02)
         sd[lp + "norm4.weight"] = n(256, std=0.05, mean=1.0); sd[lp + "norm4.bias"] = n(256, std=0.02)
         attn(lp + "cross_attn_image_to_token.", 128)
+        # prompt locality: aligned q / k projections (same orthonormal 128x256 map U, no bias) make the image->token
+        # attention logit contain pos(x)^T U^T U pe(point) - the random-Fourier kernel, peaked within ~80 px of
+        # the prompt - so image tokens near the prompt pick up the point token's value (a local "marker")
+        u_mat = torch.linalg.qr(n(256, 128, std=1.0))[0].t().contiguous()          # [128,256], orthonormal rows
+        if variant == "blobs":
+            ip = lp + "cross_attn_image_to_token."
+            sd[ip + "q_proj.weight"] = 1.7 * u_mat
+            sd[ip + "k_proj.weight"] = 1.7 * u_mat.clone()
+            sd[ip + "q_proj.bias"] = torch.zeros(128)
+            sd[ip + "k_proj.bias"] = torch.zeros(128)
+            sd[ip + "out_proj.weight"] = sd[ip + "out_proj.weight"] * 12.0
     attn(m + "transformer.final_attn_token_to_image.", 128)
     sd[m + "transformer.norm_final_attn.weight"] = n(256, std=0.05, mean=1.0)
     sd[m + "transformer.norm_final_attn.bias"] = n(256, std=0.02)
     sd[m + "iou_token.weight"] = n(1, 256, std=0.5)
     sd[m + "mask_tokens.weight"] = n(4, 256, std=0.5)
-    # sub-pixel-consistent transposed convs (+-10 %): masks are smooth at the 4x4 sub-pixel level instead of
-    # pixel noise, so run-length encodings have microscopy-like run counts
-    sd[m + "output_upscaling.0.weight"] = n(256, 64, 1, 1, std=1.0 / 16) * n(256, 64, 2, 2, std=0.1, mean=1.0)
+    # nearly sub-pixel-consistent transposed convs (+-3 %: still distinct per sub-pixel, so indexing bugs show):
+    # masks are smooth at the 4x4 sub-pixel level instead of pixel noise -> saner run-length counts
+    sd[m + "output_upscaling.0.weight"] = n(256, 64, 1, 1, std=1.0 / 16) * n(256, 64, 2, 2, std=0.03, mean=1.0)
     sd[m + "output_upscaling.0.bias"] = n(64, std=0.02)
     sd[m + "output_upscaling.1.weight"] = n(64, std=0.05, mean=1.0)
     sd[m + "output_upscaling.1.bias"] = n(64, std=0.02)
-    sd[m + "output_upscaling.3.weight"] = n(64, 32, 1, 1, std=1.0 / 8) * n(64, 32, 2, 2, std=0.1, mean=1.0)
+    sd[m + "output_upscaling.3.weight"] = n(64, 32, 1, 1, std=1.0 / 8) * n(64, 32, 2, 2, std=0.03, mean=1.0)
     sd[m + "output_upscaling.3.bias"] = n(32, std=0.02)
     for i in range(4):
         hp = f"{m}output_hypernetworks_mlps.{i}."
@@ -143,6 +161,9 @@ def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0,
             u = u / u.norm()
             proj = torch.eye(32) - torch.outer(u, u)
             w2, b2 = float(calib["gain"]) * proj @ w2, float(calib["gain"]) * proj @ b2
+            if "du" in calib:
+                # negative far-field offset (along ubar) + positive response to the prompt marker (along du)
+                b2 = b2 - float(calib["beta"]) * u + float(calib["gamma"]) * torch.tensor(calib["du"], dtype=torch.float32)
         sd[hp + "layers.2.weight"] = w2; sd[hp + "layers.2.bias"] = b2
     ip = m + "iou_prediction_head."
     sd[ip + "layers.0.weight"] = n(256, 256, std=1.0 / 16); sd[ip + "layers.0.bias"] = n(256, std=0.02)

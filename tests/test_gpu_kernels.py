@@ -1,0 +1,162 @@
+"""Kernel-level parity (through the C ABI) against plain torch fp32 on the same bf16-rounded operands.
+Tolerances: fp32 outputs differ from torch only by accumulation order (abs 1e-3 on O(10) values); bf16 outputs by one
+bf16 rounding (rel 1e-2)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import ops
+    return ops, torch.device("cuda")
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def _close(got, ref, atol, rtol):
+    got, ref = got.float(), ref.float()
+    return bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= atol + rtol * ref.abs()).all())
+
+
+@pytest.mark.parametrize("glds", [0, 1])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (300, 128, 128), (4100, 256, 2304), (448, 2048, 256)])
+def test_gemm_plain(env, shape, glds):
+    ops, dev = env
+    M, N, K = shape
+    g = torch.Generator().manual_seed(0)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = a.float() @ w.float().t() + bias
+    assert _close(ops.gemm(a, w, bias, use_glds=glds), ref, 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize("glds", [0, 1])
+def test_gemm_epilogues(env, glds):
+    ops, dev = env
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 8192, 256, 128
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    table = torch.randn(4096, 128, generator=g).to(dev)
+    resid_f = torch.randn(M, N, generator=g).to(dev)
+    resid_b = _bf(torch.randn(4096, N, generator=g)).to(dev)
+    base = a.float() @ w.float().t() + bias
+    ref = base.clone(); ref[:, :128] += table.repeat(2, 1)
+    assert _close(ops.gemm(a, w, bias, table=table, table_cols=128, use_glds=glds), ref, 1e-3, 1e-4)
+    assert _close(ops.gemm(a, w, bias, resid=resid_f, use_glds=glds), base + resid_f, 1e-3, 1e-4)
+    assert _close(ops.gemm(a, w, bias, resid=resid_b, resid_rows=4096, use_glds=glds),
+                  base + resid_b.float().repeat(2, 1), 1e-3, 1e-4)
+    assert _close(ops.gemm(a, w, bias, act=ops.ACT_GELU, out_dtype=torch.bfloat16, use_glds=glds), F.gelu(base), 2e-2, 1e-2)
+    assert _close(ops.gemm(a, w, bias, act=ops.ACT_RELU, out_dtype=torch.bfloat16, use_glds=glds), F.relu(base), 2e-2, 1e-2)
+    x = resid_f.clone()
+    ops.gemm(a, w, bias, resid=x, out=x, use_glds=glds)          # in-place residual stream update
+    assert _close(x, base + resid_f, 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize("glds", [0, 1])
+def test_gemm_layout_epilogues(env, glds):
+    ops, dev = env
+    g = torch.Generator().manual_seed(2)
+    B, heads, D = 2, 12, 768
+    a = _bf(torch.randn(B * 4096, D, generator=g)).to(dev)
+    w = _bf(torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(dev)
+    bias = torch.randn(3 * D, generator=g).to(dev)
+    ref = (a.float() @ w.float().t() + bias).reshape(B, 4096, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    for t, r in zip(ops.gemm_qkv(a, w, bias, B, heads, use_glds=glds), ref):
+        assert _close(t, r, 3e-2, 1e-2)
+    a = _bf(torch.randn(2 * 4096, 256, generator=g)).to(dev)
+    w = _bf(torch.randn(256, 256, generator=g) / 16).to(dev)
+    bias = torch.randn(256, generator=g).to(dev)
+    table = torch.randn(4096, 128, generator=g).to(dev)
+    ref = a.float() @ w.float().t() + bias
+    ref[:, :128] += table.repeat(2, 1)
+    k, vT = ops.gemm_kv(a, w, bias, table, 4096, use_glds=glds)
+    assert _close(k, ref[:, :128], 3e-2, 1e-2)
+    assert _close(vT, ref[:, 128:].reshape(2, 4096, 128).permute(0, 2, 1), 3e-2, 1e-2)
+
+
+def test_gemm_argument_errors(env):
+    ops, dev = env
+    a = torch.zeros(128, 64, dtype=torch.bfloat16, device=dev)
+    w = torch.zeros(100, 64, dtype=torch.bfloat16, device=dev)      # N % 128 != 0
+    with pytest.raises(ValueError):
+        ops.gemm(a, w)
+
+
+@pytest.mark.parametrize("dim", [64, 96, 256, 768, 1024, 1280])
+def test_layernorm(env, dim):
+    ops, dev = env
+    g = torch.Generator().manual_seed(3)
+    rows = 4096 if dim == 64 else 1001
+    x = (torch.randn(rows, dim, generator=g) * 3 + 1).to(dev)
+    w = torch.randn(dim, generator=g).to(dev); b = torch.randn(dim, generator=g).to(dev)
+    ref = F.layer_norm(x, (dim,), w, b, eps=1e-6)
+    assert _close(ops.layernorm(x, w, b, 1e-6), ref, 2e-5, 1e-5)
+    assert _close(ops.layernorm(x, w, b, 1e-6, out_dtype=torch.bfloat16, gelu=True), F.gelu(ref), 2e-2, 1e-2)
+
+
+def test_layernorm_nchw(env):
+    ops, dev = env
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2 * 4096, 256, generator=g).to(dev)
+    w = torch.randn(256, generator=g).to(dev); b = torch.randn(256, generator=g).to(dev)
+    ref = F.layer_norm(x, (256,), w, b, eps=1e-6).reshape(2, 4096, 256).permute(0, 2, 1)
+    assert _close(ops.layernorm(x, w, b, 1e-6, nchw_hw=4096), ref, 2e-5, 1e-5)
+
+
+def test_patch_gather_and_im2col_are_exact(env):
+    ops, dev = env
+    from oracle import sam_ref as S
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(2, 3, 1024, 1024, generator=g).to(dev)
+    ref = F.unfold(img, kernel_size=16, stride=16).permute(0, 2, 1).reshape(2 * 4096, 768)
+    assert bool((ops.patchify(img).float() == _bf(ref).float()).all())
+    u8 = torch.randint(0, 256, (2, 700, 1024, 3), generator=g, dtype=torch.uint8).to(dev)
+    pre = S.preprocess(u8.permute(0, 3, 1, 2))                                    # Sam.preprocess restatement
+    ref = F.unfold(pre, kernel_size=16, stride=16).permute(0, 2, 1).reshape(2 * 4096, 768)
+    assert bool((ops.patchify_u8(u8).float() == _bf(ref).float()).all())
+    x = _bf(torch.randn(2, 64, 64, 256, generator=g)).to(dev)
+    ref = F.unfold(x.float().permute(0, 3, 1, 2), kernel_size=3, padding=1)
+    ref = ref.reshape(2, 256, 9, 4096).permute(0, 3, 2, 1).reshape(2 * 4096, 9 * 256)
+    assert bool((ops.im2col3x3(x).float() == ref).all())
+
+
+@pytest.mark.parametrize("window", [True, False])
+def test_vit_attention_vs_oracle(env, window):
+    """QKV GEMM + attention kernel vs the oracle's attention (bf16 rounding points) with an identity out-projection."""
+    ops, dev = env
+    from oracle import sam_ref as S
+    g = torch.Generator().manual_seed(6)
+    B, heads, D = 1, 12, 768
+    Sz = 14 if window else 64
+    x = _bf(torch.randn(B, 64, 64, D, generator=g)).to(dev)
+    qkv_w = (torch.randn(3 * D, D, generator=g) * 1.3 / math.sqrt(D)).to(dev)
+    qkv_b = (torch.randn(3 * D, generator=g) * 0.3).to(dev)
+    rel_h = (torch.randn(2 * Sz - 1, 64, generator=g) * 0.08).to(dev)
+    rel_w = (torch.randn(2 * Sz - 1, 64, generator=g) * 0.08).to(dev)
+    q, k, v = ops.gemm_qkv(x.reshape(-1, D), _bf(qkv_w), qkv_b, B, heads)
+    if window:
+        out = ops.window_attention(q, k, v, _bf(rel_h), _bf(rel_w), qkv_b)
+    else:
+        out = ops.global_attention(q, k, v, _bf(rel_h), _bf(rel_w))
+    sd = {"a.qkv.weight": qkv_w, "a.qkv.bias": qkv_b, "a.rel_pos_h": rel_h, "a.rel_pos_w": rel_w,
+          "a.proj.weight": torch.eye(D, device=dev), "a.proj.bias": torch.zeros(D, device=dev)}
+    p = S.Prec("bf16")
+    y = x.float()
+    if window:
+        yw, pad_hw = S._window_partition(y, 14)
+        ref = S._window_unpartition(S._attention_relpos(sd, "a.", yw, heads, p), 14, pad_hw, (64, 64))
+    else:
+        ref = S._attention_relpos(sd, "a.", y, heads, p)
+    assert _close(out, ref.reshape(-1, D), 2e-2, 2e-2)

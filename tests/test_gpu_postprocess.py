@@ -1,0 +1,73 @@
+"""Integer / byte post-processing parity: bit-exact against the CPU oracle (torch bilinear + reference formulas)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [((1024, 1024), (1024, 1024)), ((1024, 768), (1024, 768)), ((1024, 1024), (512, 512)), ((683, 1024), (400, 600))]
+
+
+@pytest.fixture(scope="module")
+def low_res():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    g = torch.Generator().manual_seed(6)
+    low = torch.randn(6, 256, 256, generator=g) * 3
+    low = F.avg_pool2d(low[None], 5, stride=1, padding=2)[0] * 4
+    low[4] = -5.0       # empty mask
+    low[5] = 5.0        # full mask (RLE starts with a zero-length run)
+    return low
+
+
+@pytest.mark.parametrize("in_hw,out_hw", SIZES)
+def test_postprocess_and_rle_bit_exact(low_res, in_hw, out_hw):
+    from micro_sam_amd import ops
+    from oracle import amg_ref as A
+    from oracle import sam_ref as S
+    ref_logits = S.postprocess_masks(low_res[None], in_hw, out_hw)[0]            # Sam.postprocess_masks on the CPU
+    res = ops.postprocess_masks(low_res.cuda(), in_hw, out_hw, 0.0, 1.0, want_logits=True)
+    assert bool((res["logits"].cpu() == ref_logits).all()), "bilinear resampling must be bit-exact"
+    m = ref_logits > 0.0
+    counts_ref = torch.stack([(ref_logits > 1.0).sum((1, 2)), (ref_logits > -1.0).sum((1, 2)), m.sum((1, 2))], 1).int()
+    assert res["counts"].cpu().tolist() == counts_ref.tolist()                   # stability numerator / denominator, area
+    assert res["boxes"].cpu().tolist() == A.batched_mask_to_box(m).tolist()
+    assert bool((ops.unpack_bits(res["bits"], out_hw[0]).cpu() == m).all())
+    counts, offsets = ops.rle_encode(res["bits"], out_hw[0], out_hw[1])
+    assert ops.rles_to_list(counts, offsets, out_hw[0], out_hw[1]) == A.mask_to_rle(m)
+    # stability score as the reference computes it
+    stab = (res["counts"][:, 0] / res["counts"][:, 1]).cpu()
+    ref_stab = A.calculate_stability_score(ref_logits, 0.0, 1.0)
+    assert torch.equal(torch.nan_to_num(stab, nan=-1.0), torch.nan_to_num(ref_stab, nan=-1.0))
+
+
+def test_vendored_api_on_noisy_masks():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import _vendored
+    from oracle import amg_ref as A
+    g = torch.Generator().manual_seed(7)
+    m = torch.rand(3, 300, 200, generator=g) > 0.5
+    m[0, 0, 0] = True
+    assert _vendored.mask_to_rle_pytorch(m.cuda()) == A.mask_to_rle(m)
+    assert _vendored.batched_mask_to_box(m.cuda()).cpu().tolist() == A.batched_mask_to_box(m).tolist()
+    # reference known answer: test/test_vendored.py:12-25
+    k = torch.zeros(10, 10, dtype=torch.bool); k[7:9, 3:5] = True
+    assert _vendored.batched_mask_to_box(k.cuda()).cpu().tolist() == [3, 7, 4, 8]
+
+
+def test_rle_round_trip_at_full_size():
+    """Size-independent property at BASELINE size: decode(encode(mask)) == mask, sum(counts) == H*W."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import amg_utils, ops
+    g = torch.Generator().manual_seed(8)
+    low = F.avg_pool2d(torch.randn(1, 64, 256, 256, generator=g), 7, 1, 3)[0] * 20
+    res = ops.postprocess_masks(low.cuda(), (1024, 1024), (1024, 1024))
+    counts, offsets = ops.rle_encode(res["bits"], 1024, 1024)
+    rles = ops.rles_to_list(counts, offsets, 1024, 1024, as_list=False)
+    masks = ops.unpack_bits(res["bits"], 1024).cpu().numpy()
+    for i, r in enumerate(rles):
+        assert int(r["counts"].sum()) == 1024 * 1024
+        assert (amg_utils.rle_to_mask(r) == masks[i]).all()
+        assert amg_utils.area_from_rle(r) == int(res["counts"][i, 2])
