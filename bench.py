@@ -38,7 +38,7 @@ def cpu_baseline(sd, tile_u8):
     extrapolated to 16 batches.  Reported only, never used as a target."""
     from oracle import amg_ref as A
     from oracle import pipeline_ref as PR
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only slow the fp32 torch ops down
     img = A.to_image(tile_u8)
     t0 = time.perf_counter()
     feats, osz, isz = PR.compute_embeddings(sd, [img], "vit_b", "fp32")

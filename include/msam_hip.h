@@ -191,6 +191,26 @@ int msam_rle_run_counts(const uint32_t* bits, int32_t N, int32_t out_h, int32_t 
 int msam_rle_encode(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_w, const int64_t* offsets,
                     int32_t* counts_out, void* stream);
 
+/* Greedy box NMS = torchvision.ops.batched_nms with one category (instance_segmentation.py:126): boxes_sorted fp32
+ * [K,4] xyxy in descending score order (stable); keep_flags[i] = 1 if box i survives (IoU > threshold suppresses,
+ * areas without +1).  mask_scratch: K * ceil(K/64) uint64. */
+int msam_box_nms(const float* boxes_sorted, int32_t K, float iou_threshold, uint64_t* mask_scratch, int32_t* keep_flags,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Merge masks to a label image:  util.mask_data_to_segmentation  (micro_sam/util.py:1773-1848)
+ * ------------------------------------------------------------------------------------------------- */
+/* label[y][x] = r + 1 for the LAST r in `order` (int32 [K], indices into bits[*]) whose mask covers the pixel, else 0:
+ * the reference's area-descending painting where later masks overwrite (merge_exclusively=False).
+ * bits: [*, ceil(H/32), W] as produced by msam_postprocess_masks; label: int32 [H,W]. */
+int msam_paint_label_image(const uint32_t* bits, const int32_t* order, int32_t K, int32_t H, int32_t W, int32_t* label,
+                           void* stream);
+/* Connected components (4-connectivity) of equal non-zero value (elf.parallel.label at util.py:1834):
+ * roots[i] = smallest linear index of pixel i's component, -1 for background.  changed_flag: int32 device scratch.
+ * Synchronises the stream once per union pass (at most max_iters, default 8); iters_done (host, optional). */
+int msam_label_components(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
+                          int32_t max_iters, int32_t* iters_done, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,10 +94,11 @@ _PROTOS = {
     "msam_postprocess_masks": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "msam_rle_run_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_rle_encode": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "msam_box_nms": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
-    "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, C.POINTER(_i32), _vp]),
 }
-OPTIONAL = {"msam_paint_label_image", "msam_label_components"}
+OPTIONAL = set()
 
 _lib: Optional[C.CDLL] = None
 

@@ -1,0 +1,173 @@
+// Device side of util.mask_data_to_segmentation (micro_sam/util.py:1773-1848): paint the kept masks into a label image
+// straight from their bit masks, then connected-component labelling (4-connectivity, components = regions of equal
+// non-zero value, i.e. elf.parallel.label on the painted image).  HBM-bound integer work; no GEMM shape anywhere.
+//
+//   paint : the reference paints masks in area-descending order, later (smaller) masks overwrite earlier ones, so
+//           label(y,x) = rank+1 of the LAST mask in paint order that covers the pixel.  One thread per (32-row word,
+//           column): walks the masks from last to first, assigns the still-unassigned bits, stops when all 32 are done.
+//   label : label-equivalence union-find: L[i] = i; hook(L[L[i]] <- min over equal-valued neighbours) + pointer-jumping
+//           compression, iterated until no hook fires.  The root of a component is its smallest linear index, so
+//           sorting roots == raster order of each component's first pixel (numbering rule in DESIGN.md).
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+
+__global__ __launch_bounds__(256) void paint_kernel(const uint32_t* __restrict__ bits, const int* __restrict__ order, int K,
+                                                    int H, int W, int* __restrict__ label) {
+    const int x = blockIdx.x * 256 + threadIdx.x, yw = blockIdx.y;
+    if (x >= W) return;
+    const int wpc = (H + 31) >> 5;
+    const int nb = min(32, H - yw * 32);
+    uint32_t un = nb < 32 ? ((1u << nb) - 1u) : 0xffffffffu;
+    for (int r = K - 1; r >= 0 && un; --r) {
+        const uint32_t w = bits[((long)order[r] * wpc + yw) * W + x];
+        uint32_t hit = w & un;
+        un &= ~w;
+        while (hit) {
+            const int b = __ffs(hit) - 1;
+            hit &= hit - 1;
+            label[(long)(yw * 32 + b) * W + x] = r + 1;
+        }
+    }
+    while (un) {
+        const int b = __ffs(un) - 1;
+        un &= un - 1;
+        label[(long)(yw * 32 + b) * W + x] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void cc_init_kernel(const int* __restrict__ seg, int n, int* __restrict__ L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) L[i] = seg[i] != 0 ? i : -1;
+}
+
+__device__ __forceinline__ int cc_find(const int* L, int i) {
+    int r = L[i];
+    while (true) { const int p = L[r]; if (p == r) break; r = p; }
+    return r;
+}
+
+// hook: for every foreground pixel join with the right and the lower neighbour of equal value (covers every 4-edge once)
+__global__ __launch_bounds__(256) void cc_hook_kernel(const int* __restrict__ seg, int H, int W, int* L, int* __restrict__ changed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const int v = seg[i];
+    if (v == 0) return;
+    const int y = i / W, x = i - y * W;
+    int any = 0;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int j = d == 0 ? (x + 1 < W ? i + 1 : -1) : (y + 1 < H ? i + W : -1);
+        if (j < 0 || seg[j] != v) continue;
+        int a = cc_find(L, i), b = cc_find(L, j);
+        while (a != b) {                       // union by smaller index (lock-free)
+            if (a < b) { const int t = a; a = b; b = t; }      // a > b
+            const int old = atomicMin(&L[a], b);
+            if (old == a) { any = 1; break; }
+            a = old;                            // someone hooked a elsewhere: continue from there
+            any = 1;
+        }
+    }
+    if (any) *changed = 1;
+}
+
+__global__ __launch_bounds__(256) void cc_compress_kernel(int n, int* L) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && L[i] >= 0) L[i] = cc_find(L, i);
+}
+
+// ---- greedy box NMS (torchvision.ops.nms semantics) on score-sorted boxes: suppression bit matrix + serial sweep
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int K, float thr,
+                                                      unsigned long long* __restrict__ mask) {
+    const int rb = blockIdx.y, cb = blockIdx.x, t = threadIdx.x;
+    const int nblk = (K + 63) >> 6;
+    __shared__ float cbx[64][4];
+    const int cj = cb * 64 + t;
+    if (cj < K) { cbx[t][0] = boxes[cj * 4]; cbx[t][1] = boxes[cj * 4 + 1]; cbx[t][2] = boxes[cj * 4 + 2]; cbx[t][3] = boxes[cj * 4 + 3]; }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i >= K) return;
+    unsigned long long bitsv = 0ull;
+    if (cb >= rb) {                                         // only j > i can be suppressed by i
+        const float x1 = boxes[i * 4], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
+        const float ai = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+        const int ncol = min(64, K - cb * 64);
+        for (int c = (cb == rb ? t + 1 : 0); c < ncol; ++c) {
+            const float w = fmaxf(0.f, __fsub_rn(fminf(x2, cbx[c][2]), fmaxf(x1, cbx[c][0])));
+            const float h = fmaxf(0.f, __fsub_rn(fminf(y2, cbx[c][3]), fmaxf(y1, cbx[c][1])));
+            const float inter = __fmul_rn(w, h);
+            const float aj = __fmul_rn(__fsub_rn(cbx[c][2], cbx[c][0]), __fsub_rn(cbx[c][3], cbx[c][1]));
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, aj), inter));
+            if (iou > thr) bitsv |= 1ull << c;
+        }
+    }
+    mask[(long)i * nblk + cb] = bitsv;
+}
+
+// one wave: lane l owns words l, l+64, ... of the running "removed" set (K <= 64*64*4 words handled by the stride loop)
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int K,
+                                                       int* __restrict__ keep) {
+    const int nblk = (K + 63) >> 6, lane = threadIdx.x;
+    extern __shared__ unsigned long long remv[];
+    for (int w = lane; w < nblk; w += 64) remv[w] = 0ull;
+    __syncthreads();
+    for (int i = 0; i < K; ++i) {
+        const bool removed = (remv[i >> 6] >> (i & 63)) & 1ull;          // uniform across the wave
+        if (lane == 0) keep[i] = removed ? 0 : 1;
+        if (!removed)
+            for (int w = lane; w < nblk; w += 64) remv[w] |= mask[(long)i * nblk + w];
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int msam_box_nms(const float* boxes_sorted, int32_t K, float iou_threshold, uint64_t* mask_scratch,
+                            int32_t* keep_flags, void* stream) {
+    if (K < 0 || (K > 0 && (!boxes_sorted || !mask_scratch || !keep_flags))) { msam_set_error("msam_box_nms: bad arguments"); return 1; }
+    if (K == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (K + 63) / 64;
+    if (nblk * 8 > 60000) { msam_set_error("msam_box_nms: too many boxes"); return 1; }
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, s, boxes_sorted, K, iou_threshold,
+                       (unsigned long long*)mask_scratch);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K, keep_flags);
+    return msam_check_launch("msam_box_nms");
+}
+
+extern "C" int msam_paint_label_image(const uint32_t* bits, const int32_t* order, int32_t K, int32_t H, int32_t W,
+                                      int32_t* label, void* stream) {
+    if (!label || H <= 0 || W <= 0 || K < 0 || (K > 0 && (!bits || !order))) {
+        msam_set_error("msam_paint_label_image: bad arguments");
+        return 1;
+    }
+    hipLaunchKernelGGL(paint_kernel, dim3((W + 255) / 256, (H + 31) / 32), dim3(256), 0, (hipStream_t)stream, bits, order, K,
+                       H, W, label);
+    return msam_check_launch("msam_paint_label_image");
+}
+
+extern "C" int msam_label_components(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
+                                     int32_t max_iters, int32_t* iters_done, void* stream) {
+    if (!seg || !roots || !changed_flag || H <= 0 || W <= 0) { msam_set_error("msam_label_components: bad arguments"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int n = H * W, grid = (n + 255) / 256;
+    hipLaunchKernelGGL(cc_init_kernel, dim3(grid), dim3(256), 0, s, seg, n, roots);
+    int it = 0;
+    // the union loop inside cc_hook_kernel already merges whole trees, so one hook pass + compression is complete;
+    // further passes only confirm convergence (changed == 0) - bounded by max_iters
+    for (; it < (max_iters > 0 ? max_iters : 8); ++it) {
+        if (hipMemsetAsync(changed_flag, 0, sizeof(int), s) != hipSuccess) { msam_set_error("msam_label_components: memset"); return 2; }
+        hipLaunchKernelGGL(cc_hook_kernel, dim3(grid), dim3(256), 0, s, seg, H, W, roots, changed_flag);
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid), dim3(256), 0, s, n, roots);
+        int h = 0;
+        if (hipMemcpyAsync(&h, changed_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) { msam_set_error("msam_label_components: readback"); return 2; }
+        if (!h) { ++it; break; }
+    }
+    if (iters_done) *iters_done = it;
+    return msam_check_launch("msam_label_components");
+}

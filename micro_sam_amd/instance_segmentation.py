@@ -2,9 +2,13 @@
 (``micro_sam/instance_segmentation.py:65-530``) with the expensive ``initialize`` running on libmsam_hip.so.
 
 Differences to the reference are internal only:
-* all grid prompts of a crop are decoded in chunks of ``points_per_batch`` exactly as in the reference, but each chunk
-  goes low-res logits -> (stability counts, boxes, bit masks, RLE) on the device; the [64,3,H,W] fp32 logits and bool
-  masks the reference materialises never exist;
+* the grid prompts of a crop are decoded in device chunks (``device_chunk`` prompts, default all 1024 at once; prompts
+  are independent, so the result per prompt does not depend on the chunking - ``points_per_batch`` only sets the
+  progress-bar granularity); each chunk goes low-res logits -> (stability counts, boxes, areas, bit masks) on the
+  device; the [64,3,H,W] fp32 logits and bool masks the reference materialises never exist;
+* the initialised state stays in HBM (``DeviceMaskData``: bit masks [N, H/32, W] instead of RLE lists); the reference's
+  ``"rles"`` column is produced lazily by the HIP RLE kernels the first time it is read (state pickling, ``rle`` /
+  ``binary_mask`` output); ``generate(output_mode="instance_segmentation")`` paints + labels on the device;
 * ``crop_n_layers > 0`` and the tiled generator are not provided this round (SURVEY.md 8(f) / DESIGN.md).
 """
 from __future__ import annotations
@@ -18,6 +22,69 @@ import torch
 
 from . import amg_utils, ops, util
 from .predictor import SamPredictor
+
+
+class DeviceMaskData(amg_utils.MaskData):
+    """``MaskData`` whose masks live on the device as bit masks (column ``"bits"`` + ``"mask_size"``).
+
+    ``data["rles"]`` (the reference's column) is materialised on first access by the HIP RLE kernels and cached;
+    ``filter`` / ``cat`` keep both representations consistent."""
+
+    def __init__(self, mask_size=None, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.mask_size = mask_size
+
+    def __getitem__(self, key: str):
+        if key == "rles" and "rles" not in self._stats and "bits" in self._stats:
+            self._stats["rles"] = self._encode_rles()
+        return self._stats[key]
+
+    def _encode_rles(self):
+        bits = self._stats["bits"]
+        h, w = self.mask_size
+        if bits.shape[0] == 0:
+            return []
+        counts, offsets = ops.rle_encode(bits.contiguous(), h, w)
+        return ops.rles_to_list(counts, offsets, h, w, as_list=False)
+
+    def shallow_copy(self) -> "DeviceMaskData":
+        out = DeviceMaskData(mask_size=self.mask_size)
+        out._stats = dict(self._stats)
+        return out
+
+    def cat(self, new_stats) -> None:
+        if getattr(new_stats, "mask_size", None) is not None:
+            self.mask_size = new_stats.mask_size
+        if "rles" in self._stats and "rles" not in new_stats._stats and "bits" in new_stats._stats:
+            new_stats["rles"]                      # materialise so that both sides carry the column
+        for k, v in new_stats.items():
+            cur = self._stats.get(k)
+            if cur is None:
+                self._stats[k] = v                 # columns are never mutated in place: no deep copy needed
+            elif isinstance(v, torch.Tensor):
+                self._stats[k] = torch.cat([cur, v.to(cur.device)], dim=0)
+            elif isinstance(v, np.ndarray):
+                self._stats[k] = np.concatenate([cur, v], axis=0)
+            else:
+                self._stats[k] = cur + list(v)
+
+    def __len__(self) -> int:
+        return int(self._stats["iou_preds"].shape[0]) if "iou_preds" in self._stats else 0
+
+    def __getstate__(self):
+        """Pickle in the reference's format: RLE dicts on the host instead of device bit masks."""
+        stats = {}
+        for k, v in self._stats.items():
+            if k == "bits":
+                continue
+            stats[k] = v.cpu() if torch.is_tensor(v) else v
+        if "bits" in self._stats:
+            stats["rles"] = self["rles"]
+        return {"_stats": stats, "mask_size": self.mask_size}
+
+    def __setstate__(self, state):
+        self._stats = state["_stats"]
+        self.mask_size = state["mask_size"]
 
 
 class AMGBase(ABC):
@@ -52,11 +119,14 @@ class AMGBase(ABC):
         keep_mask = ~amg_utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h])
         if not torch.all(keep_mask):
             data.filter(keep_mask)
-        keep_by_nms = amg_utils.batched_nms(data["boxes"].float(), data["iou_preds"],
-                                            torch.zeros_like(data["boxes"][:, 0]), iou_threshold=box_nms_thresh)
+        if data["boxes"].is_cuda:
+            keep_by_nms = ops.box_nms(data["boxes"], data["iou_preds"], box_nms_thresh)      # one category
+        else:
+            keep_by_nms = amg_utils.batched_nms(data["boxes"].float(), data["iou_preds"],
+                                                torch.zeros_like(data["boxes"][:, 0]), iou_threshold=box_nms_thresh)
         data.filter(keep_by_nms)
         data["boxes"] = amg_utils.uncrop_boxes_xyxy(data["boxes"], crop_box)
-        data["crop_boxes"] = torch.tensor([crop_box for _ in range(len(data["rles"]))])
+        data["crop_boxes"] = torch.tensor([crop_box for _ in range(int(data["iou_preds"].shape[0]))])
         try:
             data["points"] = amg_utils.uncrop_points(data["points"], crop_box)
         except KeyError:
@@ -69,7 +139,12 @@ class AMGBase(ABC):
         if output_mode == "coco_rle":
             raise NotImplementedError("micro_sam_amd: output_mode='coco_rle' needs pycocotools, not provided")
         elif output_mode in ("binary_mask", "instance_segmentation"):
-            mask_data["segmentations"] = [amg_utils.rle_to_mask(rle) for rle in mask_data["rles"]]
+            if "bits" in mask_data:
+                h, w = mask_data.mask_size
+                dense = ops.unpack_bits(torch.as_tensor(mask_data["bits"]), h).cpu().numpy()
+                mask_data["segmentations"] = [m for m in dense]
+            else:
+                mask_data["segmentations"] = [amg_utils.rle_to_mask(rle) for rle in mask_data["rles"]]
         elif output_mode == "rle":
             mask_data["segmentations"] = [{"size": r["size"], "counts": np.asarray(r["counts"]).tolist()}
                                           for r in mask_data["rles"]]
@@ -79,7 +154,7 @@ class AMGBase(ABC):
         for idx in range(len(mask_data["segmentations"])):
             ann = {
                 "segmentation": mask_data["segmentations"][idx],
-                "area": amg_utils.area_from_rle(mask_data["rles"][idx]),
+                "area": int(mask_data["area"][idx]) if "area" in mask_data else amg_utils.area_from_rle(mask_data["rles"][idx]),
                 "bbox": amg_utils.box_xyxy_to_xywh(mask_data["boxes"][idx]).tolist(),
                 "predicted_iou": mask_data["iou_preds"][idx].item(),
                 "stability_score": mask_data["stability_score"][idx].item(),
@@ -99,16 +174,15 @@ class AMGBase(ABC):
         if not (x0 == 0 and y0 == 0 and x1 == orig_w and y1 == orig_h):
             raise NotImplementedError("micro_sam_amd: crops that differ from the full image are not provided this round")
         n_masks_per_prompt = iou_preds.shape[1]
-        data = amg_utils.MaskData(iou_preds=iou_preds.flatten(0, 1))
+        data = DeviceMaskData(mask_size=(orig_h, orig_w), iou_preds=iou_preds.flatten(0, 1))
         if points is not None:
             data["points"] = torch.as_tensor(points.repeat(n_masks_per_prompt, axis=0), dtype=torch.float)
         counts = post["counts"]
         # calculate_stability_score: #(logit > thr + off) / #(logit > thr - off); int32 / int32 -> float32 (0/0 -> nan)
         data["stability_score"] = counts[:, 0] / counts[:, 1]
         data["boxes"] = post["boxes"]
-        rle_counts, rle_offsets = ops.rle_encode(post["bits"], orig_h, orig_w)
-        # counts stay int32 numpy views (not Python lists): same content as the reference's RLE dicts
-        data["rles"] = ops.rles_to_list(rle_counts, rle_offsets, orig_h, orig_w, as_list=False)
+        data["area"] = counts[:, 2]                 # == area_from_rle of the mask
+        data["bits"] = post["bits"]                 # uncrop_masks is the identity for the full-image crop
         return data
 
     def get_state(self) -> Dict[str, Any]:
@@ -134,8 +208,10 @@ class AutomaticMaskGenerator(AMGBase):
 
     def __init__(self, predictor: SamPredictor, points_per_side: Optional[int] = 32, points_per_batch: Optional[int] = None,
                  crop_n_layers: int = 0, crop_overlap_ratio: float = 512 / 1500, crop_n_points_downscale_factor: int = 1,
-                 point_grids: Optional[List[np.ndarray]] = None, stability_score_offset: float = 1.0):
+                 point_grids: Optional[List[np.ndarray]] = None, stability_score_offset: float = 1.0,
+                 device_chunk: int = 1024):
         super().__init__()
+        self._device_chunk = int(device_chunk)
         if points_per_side is not None:
             self.point_grids = amg_utils.build_all_layer_point_grids(points_per_side, crop_n_layers,
                                                                      crop_n_points_downscale_factor)
@@ -170,17 +246,19 @@ class AutomaticMaskGenerator(AMGBase):
             self._predictor.set_image(cropped_im)
         points_scale = np.array(cropped_im_size)[None, ::-1]
         points_for_image = self.point_grids[crop_layer_idx] * points_scale
-        data = amg_utils.MaskData()
+        data = DeviceMaskData(mask_size=tuple(self.original_size))
         n_batches = len(points_for_image) // self._points_per_batch + \
             int(len(points_for_image) % self._points_per_batch != 0)
         if pbar_init is not None:
             pbar_init(n_batches, "Predict masks for point grid prompts")
-        for (points,) in amg_utils.batch_iterator(self._points_per_batch, points_for_image):
+        # prompts are independent: decode them in large device chunks (same per-prompt results as 64 at a time)
+        chunk = max(self._device_chunk, self._points_per_batch)
+        for (points,) in amg_utils.batch_iterator(chunk, points_for_image):
             batch_data = self._process_batch(points, cropped_im_size, crop_box, self.original_size)
             data.cat(batch_data)
             del batch_data
             if pbar_update is not None:
-                pbar_update(1)
+                pbar_update(int(np.ceil(len(points) / self._points_per_batch)))
         if not precomputed_embeddings:
             self._predictor.reset_image()
         return data
@@ -216,10 +294,12 @@ class AutomaticMaskGenerator(AMGBase):
                  with_background: bool = True) -> Union[List[Dict[str, Any]], np.ndarray]:
         if not self.is_initialized:
             raise RuntimeError("AutomaticMaskGenerator has not been initialized. Call initialize first.")
-        data = amg_utils.MaskData()
+        data = DeviceMaskData()
         for data_, crop_box in zip(self.crop_list, self.crop_boxes):
+            # filter() re-binds columns and never mutates them in place: a shallow copy protects the state
             crop_data = self._postprocess_batch(
-                data=deepcopy(data_), crop_box=crop_box, original_size=self.original_size,
+                data=data_.shallow_copy() if isinstance(data_, DeviceMaskData) else deepcopy(data_),
+                crop_box=crop_box, original_size=self.original_size,
                 pred_iou_thresh=pred_iou_thresh, stability_score_thresh=stability_score_thresh,
                 box_nms_thresh=box_nms_thresh)
             data.cat(crop_data)
@@ -229,7 +309,16 @@ class AutomaticMaskGenerator(AMGBase):
             keep_by_nms = amg_utils.batched_nms(data["boxes"].float(), scores, torch.zeros_like(data["boxes"][:, 0]),
                                                 iou_threshold=crop_nms_thresh)
             data.filter(keep_by_nms)
+        if output_mode == "instance_segmentation" and min_mask_region_area == 0 and "bits" in data:
+            # device path of util.mask_data_to_segmentation (paint by area + connected components + relabel)
+            return util.mask_data_to_segmentation_device(data["bits"], data["area"], self.original_size,
+                                                         with_background=with_background)
+        bits = data["bits"] if "bits" in data else None
+        if bits is not None:
+            del data["bits"]
         data.to_numpy()
+        if bits is not None:
+            data["bits"] = bits                   # keep the masks on the device for unpacking
         masks = self._postprocess_masks(data, min_mask_region_area, box_nms_thresh, crop_nms_thresh, output_mode)
         if output_mode == "instance_segmentation":
             shape = next(iter(masks))["segmentation"].shape if len(masks) > 0 else self.original_size

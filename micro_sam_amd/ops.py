@@ -183,3 +183,41 @@ def unpack_bits(bits: torch.Tensor, height: int) -> torch.Tensor:
     sh = torch.arange(32, device=bits.device, dtype=torch.int32).view(1, 1, 32, 1)
     m = ((bits.unsqueeze(2) >> sh) & 1).to(torch.bool).reshape(N, wpc * 32, W)
     return m[:, :height]
+
+
+def paint_label_image(bits: torch.Tensor, order: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """label[y,x] = r+1 of the last mask bits[order[r]] covering the pixel (0 if none): int32 [H,W]."""
+    label = torch.empty((height, width), dtype=torch.int32, device=bits.device)
+    order = order.to(device=bits.device, dtype=torch.int32).contiguous()
+    _lib.check(_lib.load().msam_paint_label_image(bits.data_ptr() if order.numel() else None,
+                                                  order.data_ptr() if order.numel() else None, order.numel(), height, width,
+                                                  label.data_ptr(), _lib.stream_ptr()), "msam_paint_label_image")
+    return label
+
+
+def label_components(seg: torch.Tensor) -> torch.Tensor:
+    """4-connected components of equal non-zero value of an int32 [H,W] image: root (smallest linear index) per pixel,
+    -1 for background, int32 [H*W]."""
+    h, w = seg.shape
+    seg = seg.contiguous()
+    roots = torch.empty((h * w,), dtype=torch.int32, device=seg.device)
+    flag = torch.zeros((1,), dtype=torch.int32, device=seg.device)
+    iters = C.c_int32(0)
+    _lib.check(_lib.load().msam_label_components(seg.data_ptr(), h, w, roots.data_ptr(), flag.data_ptr(), 16, C.byref(iters),
+                                                 _lib.stream_ptr()), "msam_label_components")
+    return roots
+
+
+def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Greedy NMS on the device (torchvision.ops.nms semantics): kept indices in descending score order (int64)."""
+    k = int(boxes.shape[0])
+    if k == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores.float(), descending=True, stable=True).indices
+    b = boxes.float()[order].contiguous()
+    nblk = (k + 63) // 64
+    scratch = torch.empty((k * nblk,), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty((k,), dtype=torch.int32, device=boxes.device)
+    _lib.check(_lib.load().msam_box_nms(b.data_ptr(), k, float(iou_threshold), scratch.data_ptr(), keep.data_ptr(),
+                                        _lib.stream_ptr()), "msam_box_nms")
+    return order[keep.bool()]

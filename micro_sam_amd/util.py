@@ -331,3 +331,41 @@ def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape: Optional[Tuple
     new_ids = np.zeros(lut.shape[0], dtype=segmentation.dtype)
     new_ids[lut] = np.arange(1, int(lut.sum()) + 1, dtype=segmentation.dtype)
     return new_ids[segmentation]
+
+
+@torch.no_grad()
+def mask_data_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, shape: Tuple[int, int],
+                                     min_object_size: int = 0, with_background: bool = False) -> np.ndarray:
+    """``mask_data_to_segmentation(..., label_masks=True, merge_exclusively=False)`` (reference util.py:1773-1848) computed
+    on the device from bit masks [K, ceil(H/32), W] and their areas [K]; returns the uint32 label image on the host.
+
+    Same semantics as the host function above: stable area-descending paint order, later masks overwrite, 4-connected
+    components of equal value numbered in raster order of their first pixel, drop components smaller than
+    ``min_object_size`` and (``with_background``) the largest one counting label 0, relabel consecutively."""
+    from . import ops
+    h, w = int(shape[0]), int(shape[1])
+    dev = bits.device
+    k = int(bits.shape[0])
+    if k == 0:
+        return np.zeros((h, w), dtype="uint32")
+    order = torch.sort(areas.to(dev), descending=True, stable=True).indices
+    if min_object_size > 0:
+        order = order[areas.to(dev)[order] >= min_object_size]
+    painted = ops.paint_label_image(bits, order, h, w)
+    roots = ops.label_components(painted).to(torch.int64)
+    fg = roots >= 0
+    idx = torch.arange(h * w, device=dev)
+    is_root = fg & (roots == idx)
+    comp_of_root = torch.cumsum(is_root.to(torch.int64), 0)                  # 1..C at root positions (raster order)
+    cid = torch.where(fg, comp_of_root[roots.clamp(min=0)], torch.zeros_like(roots))
+    n_comp = int(comp_of_root[-1].item())
+    sizes = torch.bincount(cid, minlength=n_comp + 1)
+    keep = torch.ones(n_comp + 1, dtype=torch.bool, device=dev)
+    keep[0] = False
+    keep &= sizes >= min_object_size
+    if with_background:
+        present = sizes > 0                                                  # np.unique only reports ids that occur
+        masked = torch.where(present, sizes, torch.full_like(sizes, -1))
+        keep[int(torch.argmax(masked).item())] = False                       # first maximum = smallest id on ties
+    new_id = torch.cumsum(keep.to(torch.int64), 0) * keep
+    return new_id[cid].reshape(h, w).to(torch.int32).cpu().numpy().astype("uint32")

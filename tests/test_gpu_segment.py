@@ -1,0 +1,80 @@
+"""Device generate() stages (box NMS, paint, connected components, relabel): identical ids to the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _random_masks(rng, n, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = np.zeros((n, h, w), dtype=bool)
+    for i in range(n):
+        for _ in range(rng.integers(1, 4)):               # several blobs per mask -> several components per id
+            cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(3, max(4, min(h, w) // 4))
+            out[i] |= (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+    return out
+
+
+@pytest.mark.parametrize("shape,n", [((64, 96), 5), ((300, 200), 40), ((1024, 1024), 200), ((1024, 1024), 0)])
+@pytest.mark.parametrize("with_background", [True, False])
+def test_mask_data_to_segmentation_device(shape, n, with_background):
+    _gpu()
+    from micro_sam_amd import _vendored, util
+    from oracle import amg_ref as A
+    rng = np.random.default_rng(n + shape[0])
+    masks = _random_masks(rng, n, *shape) if n else np.zeros((0,) + shape, dtype=bool)
+    if n:
+        masks[1] = masks[0]                                # equal areas: stable order matters
+    areas = masks.reshape(n, -1).sum(1)
+    recs = [{"segmentation": m, "area": int(a)} for m, a in zip(masks, areas)]
+    ref = A.mask_data_to_segmentation(recs, shape=shape, with_background=with_background, merge_exclusively=False)
+    bits = _vendored.pack_bits(torch.as_tensor(masks).cuda()) if n else torch.zeros((0, (shape[0] + 31) // 32, shape[1]), dtype=torch.int32, device="cuda")
+    got = util.mask_data_to_segmentation_device(bits, torch.as_tensor(areas, dtype=torch.int32).cuda(), shape,
+                                                with_background=with_background)
+    assert got.dtype == np.uint32 and got.shape == tuple(shape)
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} pixels differ, max ids {got.max()} vs {ref.max()}"
+    # the host implementation of the product agrees as well
+    host = util.mask_data_to_segmentation(recs, shape=shape, with_background=with_background, merge_exclusively=False)
+    assert np.array_equal(host, ref)
+
+
+def test_label_components_worst_cases():
+    _gpu()
+    from micro_sam_amd import ops
+    from oracle import amg_ref as A
+    rng = np.random.default_rng(0)
+    cases = [rng.integers(0, 3, size=(257, 130)), np.ones((64, 64), dtype=int), np.zeros((33, 17), dtype=int)]
+    spiral = np.zeros((101, 101), dtype=int)                # one long snake: deep union-find chains
+    spiral[::2, :] = 1; spiral[1::4, -1] = 1; spiral[3::4, 0] = 1
+    cases.append(spiral)
+    for seg in cases:
+        roots = ops.label_components(torch.as_tensor(seg, dtype=torch.int32).cuda()).cpu().numpy()
+        ref = A.label_components(seg.astype("uint32"))
+        fg = seg.reshape(-1) != 0
+        assert (roots[~fg] == -1).all()
+        # same partition, and every root is the smallest linear index of its component
+        _, inv = np.unique(roots[fg], return_inverse=True)
+        assert np.array_equal(inv + 1, ref.reshape(-1)[fg])
+        idx = np.arange(seg.size)[fg]
+        assert (roots[fg] <= idx).all() and (roots[roots[fg]] == roots[fg]).all()
+
+
+@pytest.mark.parametrize("k", [1, 63, 64, 65, 700, 3072])
+def test_box_nms_matches_oracle(k):
+    _gpu()
+    from micro_sam_amd import ops
+    from oracle import amg_ref as A
+    rng = np.random.default_rng(k)
+    xy = rng.integers(0, 900, size=(k, 2)).astype(np.float32)
+    wh = rng.integers(0, 200, size=(k, 2)).astype(np.float32)           # includes zero-area boxes
+    boxes = torch.as_tensor(np.concatenate([xy, xy + wh], axis=1))
+    scores = torch.as_tensor(rng.integers(0, 50, size=k).astype(np.float32) / 50)   # many ties: stable order matters
+    for thr in (0.7, 0.3):
+        got = ops.box_nms(boxes.cuda(), scores.cuda(), thr).cpu()
+        assert got.tolist() == A.nms(boxes, scores, thr).tolist()
