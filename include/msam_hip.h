@@ -59,6 +59,10 @@ typedef struct {
                                             v <- cols 128..255 transposed [M/tokens,128,tokens] bf16 */
     int32_t heads, head_dim, tokens;
     int32_t use_glds;                    /* 1: global_load_lds staging variant, 0: register staging */
+    int32_t ln_mode;                     /* fused LayerNorm epilogue (N == 256 only, row-complete 64x256 tile kernel):
+                                            0 none, 1 LayerNorm over the 256-wide row, 2 LayerNorm over each 64-column
+                                            group followed by exact GELU; applied after bias/table/resid */
+    const float* ln_w; const float* ln_b; float ln_eps;    /* [256] (mode 1) or [64] (mode 2) */
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 

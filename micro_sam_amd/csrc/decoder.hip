@@ -365,8 +365,10 @@ struct Ctx { hipStream_t s; int use_glds; };
 
 int gemm(const Ctx& cx, const void* A, long lda, const void* W, int M, int N, int K, const float* bias, void* out,
          int out_dtype, long ldc, int act = 0, const void* resid = nullptr, int resid_dtype = 0, long ldr = 0,
-         int resid_rows = 0, const float* table = nullptr, int table_cols = 0) {
+         int resid_rows = 0, const float* table = nullptr, int table_cols = 0, int ln_mode = 0,
+         const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f) {
     msam_gemm_t g{};
+    g.ln_mode = ln_mode; g.ln_w = ln_w; g.ln_b = ln_b; g.ln_eps = ln_eps;
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
     g.table = table; g.table_rows = T; g.table_cols = table_cols; g.table_ld = CI;
     g.resid = resid; g.resid_dtype = resid_dtype; g.resid_rows = resid_rows; g.ldr = ldr;
@@ -580,12 +582,13 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
             hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, w.qimg, 0, w.ks, w.vs, Nt, w.attn_img);
         }
         CHECK(msam_check_launch("i2t_attn"));
+        // out_proj + residual + norm4 fused (row-complete GEMM epilogue); layer 1 updates the stream in place
         if (li == 0)
-            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.pre, MSAM_F32, C, 0, im.src_bf16,
-                       MSAM_BF16, C, T));
+            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, MSAM_BF16, C, 0, im.src_bf16,
+                       MSAM_BF16, C, T, nullptr, 0, 1, L.n4_w, L.n4_b, 1e-5f));
         else
-            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.pre, MSAM_F32, C, 0, w.keys, MSAM_BF16, C));
-        LN(w.pre, L.n4_w, L.n4_b, R, w.keys, MSAM_BF16);
+            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, MSAM_BF16, C, 0, w.keys, MSAM_BF16,
+                       C, 0, nullptr, 0, 1, L.n4_w, L.n4_b, 1e-5f));
     }
     if (dbg) return 0;   // test hook: leave queries / keys of the last executed layer in the workspace
     // final token -> image attention
@@ -613,9 +616,9 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     hipLaunchKernelGGL(gather_iou_kernel, dim3((P * nmask + 255) / 256), dim3(256), 0, cx.s, w.iou_full, P, mask0, nmask, iou);
     CHECK(msam_check_launch("gather_iou"));
 
-    // up-scaling: ConvT1 as GEMM (+bias per output channel, expanded to 256 columns) -> LN2d(64)+GELU -> fused ConvT2
-    CHECK(gemm(cx, w.keys, C, dec->up1_w, (int)R, C, C, dec->up1_b, w.pre, MSAM_F32, C));
-    CHECK(msam_layernorm(w.pre, dec->up_ln_w, dec->up_ln_b, 1e-6f, R * 4, 64, w.up1, MSAM_BF16, 1, 0, cx.s));
+    // up-scaling: ConvT1 as GEMM with fused (bias, LayerNorm2d over 64 channels, GELU) epilogue -> fused ConvT2
+    CHECK(gemm(cx, w.keys, C, dec->up1_w, (int)R, C, C, dec->up1_b, w.up1, MSAM_BF16, C, 0, nullptr, 0, 0, 0, nullptr, 0,
+               2, dec->up_ln_w, dec->up_ln_b, 1e-6f));
     {
         const long rows = R * 4;
         long tiles = rows / 128;

@@ -218,6 +218,151 @@ __global__ __launch_bounds__(256) void gemm_kernel(const u16* __restrict__ A, lo
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Row-complete variant for N == 256 with a fused LayerNorm epilogue (decoder image-token stream):
+// tile 64 x 256 x 64, 4 waves side by side along N (each 64 x 64), so one workgroup owns whole output rows and the
+// epilogue can normalise them in place:   ln_mode 1: LayerNorm over the 256-wide row (norm4 of the two-way block)
+//                                          ln_mode 2: LayerNorm over each 64-column group + GELU (LayerNorm2d + GELU of
+//                                                     the first up-scaling stage; columns = (sub-pixel, channel))
+// This removes the fp32 pre-norm round trip through HBM (write 4 B + read 4 B per element) of the unfused form.
+struct EpiLN { const float* ln_w; const float* ln_b; float eps; int mode; };
+
+__global__ __launch_bounds__(256) void gemm_ln_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
+                                                      long ldw, int M, int K, Epi e, EpiLN ln) {
+    extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
+    constexpr int LM = 64, LN_ = 256;
+    uint4* ldsA = dyn_lds;                       // [2][64*8]
+    uint4* ldsB = dyn_lds + 2 * LM * 8;          // [2][256*8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * LM;
+    const int srow = tid >> 3, scp = tid & 7;
+
+    const u16 *a_s0, *a_s1, *w_s0, *w_s1, *w_s2, *w_s3, *w_s4, *w_s5, *w_s6, *w_s7;
+    {
+        int r0 = srow, r1 = 32 + srow;
+        int ar0 = min(m0 + r0, M - 1), ar1 = min(m0 + r1, M - 1);
+        a_s0 = A + (long)ar0 * lda + (scp ^ swz(r0)) * 8;
+        a_s1 = A + (long)ar1 * lda + (scp ^ swz(r1)) * 8;
+#define WSRC(p_) (W + (long)((p_) * 32 + srow) * ldw + (scp ^ swz((p_) * 32 + srow)) * 8)
+        w_s0 = WSRC(0); w_s1 = WSRC(1); w_s2 = WSRC(2); w_s3 = WSRC(3); w_s4 = WSRC(4); w_s5 = WSRC(5); w_s6 = WSRC(6); w_s7 = WSRC(7);
+#undef WSRC
+    }
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int nk = K / BK;
+    uint4 ra0, ra1, rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7;
+#define LN_ISSUE(kt_)                                                                               \
+    do {                                                                                            \
+        const long ko_ = (long)(kt_) * BK;                                                          \
+        ra0 = *(const uint4*)(a_s0 + ko_); ra1 = *(const uint4*)(a_s1 + ko_);                       \
+        rw0 = *(const uint4*)(w_s0 + ko_); rw1 = *(const uint4*)(w_s1 + ko_);                       \
+        rw2 = *(const uint4*)(w_s2 + ko_); rw3 = *(const uint4*)(w_s3 + ko_);                       \
+        rw4 = *(const uint4*)(w_s4 + ko_); rw5 = *(const uint4*)(w_s5 + ko_);                       \
+        rw6 = *(const uint4*)(w_s6 + ko_); rw7 = *(const uint4*)(w_s7 + ko_);                       \
+    } while (0)
+#define LN_COMMIT(buf_)                                                                             \
+    do {                                                                                            \
+        uint4* la_ = ldsA + (buf_) * LM * 8; uint4* lb_ = ldsB + (buf_) * LN_ * 8;                  \
+        la_[(0 * 32 + srow) * 8 + scp] = ra0; la_[(1 * 32 + srow) * 8 + scp] = ra1;                 \
+        lb_[(0 * 32 + srow) * 8 + scp] = rw0; lb_[(1 * 32 + srow) * 8 + scp] = rw1;                 \
+        lb_[(2 * 32 + srow) * 8 + scp] = rw2; lb_[(3 * 32 + srow) * 8 + scp] = rw3;                 \
+        lb_[(4 * 32 + srow) * 8 + scp] = rw4; lb_[(5 * 32 + srow) * 8 + scp] = rw5;                 \
+        lb_[(6 * 32 + srow) * 8 + scp] = rw6; lb_[(7 * 32 + srow) * 8 + scp] = rw7;                 \
+    } while (0)
+    LN_ISSUE(0);
+    LN_COMMIT(0);
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) LN_ISSUE(kt + 1);
+        const uint4* la = ldsA + buf * LM * 8; const uint4* lb = ldsB + buf * LN_ * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 16 + fr;
+                a[i] = la[row * 8 + ((ks * 4 + fg) ^ swz(row))];
+                const int col = wave * 64 + i * 16 + fr;
+                b[i] = lb[col * 8 + ((ks * 4 + fg) ^ swz(col))];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) LN_COMMIT(buf ^ 1);
+        __syncthreads();
+    }
+#undef LN_ISSUE
+#undef LN_COMMIT
+    float* ldsC = (float*)dyn_lds;                // [64][256] fp32 = 64 KB (<= 80 KB staging area)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ldsC[(i * 16 + fg * 4 + r) * LN_ + wave * 64 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+
+    const int col = lane * 4;                      // one wave = one full 256-wide row per pass
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.bias) { float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+    const bool use_table = e.table && col < e.table_cols;
+    float lw[4] = {1.f, 1.f, 1.f, 1.f}, lb4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ln.mode) {
+        const int lc = ln.mode == 2 ? (col & 63) : col;
+        float4 w4 = *(const float4*)(ln.ln_w + lc), b4 = *(const float4*)(ln.ln_b + lc);
+        lw[0] = w4.x; lw[1] = w4.y; lw[2] = w4.z; lw[3] = w4.w; lb4[0] = b4.x; lb4[1] = b4.y; lb4[2] = b4.z; lb4[3] = b4.w;
+    }
+    for (int pass = 0; pass < 16; ++pass) {
+        const int lr = pass * 4 + wave;
+        const int row = m0 + lr;
+        if (row >= M) break;                       // uniform per wave
+        float4 c = *(const float4*)(ldsC + lr * LN_ + col);
+        float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+        if (use_table) {
+            float4 t = *(const float4*)(e.table + (long)(row % e.table_rows) * e.table_ld + col);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        if (e.resid_dtype) {
+            const int rr = e.resid_rows ? (row % e.resid_rows) : row;
+            if (e.resid_dtype == MSAM_F32) {
+                float4 t = *(const float4*)((const float*)e.resid + (long)rr * e.ldr + col);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            } else {
+                uint2 t = *(const uint2*)((const u16*)e.resid + (long)rr * e.ldr + col);
+                v[0] += bf2f((u16)(t.x & 0xffff)); v[1] += bf2f((u16)(t.x >> 16));
+                v[2] += bf2f((u16)(t.y & 0xffff)); v[3] += bf2f((u16)(t.y >> 16));
+            }
+        }
+        if (ln.mode) {
+            const float s = (v[0] + v[1]) + (v[2] + v[3]);
+            const float inv_n = ln.mode == 1 ? (1.0f / 256.0f) : (1.0f / 64.0f);
+            const float mean = (ln.mode == 1 ? wave_sum64(s) : wave_sum_xor16(s)) * inv_n;
+            const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            const float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            const float var = (ln.mode == 1 ? wave_sum64(q) : wave_sum_xor16(q)) * inv_n;
+            const float rstd = 1.0f / sqrtf(var + ln.eps);
+            v[0] = d0 * rstd * lw[0] + lb4[0]; v[1] = d1 * rstd * lw[1] + lb4[1];
+            v[2] = d2 * rstd * lw[2] + lb4[2]; v[3] = d3 * rstd * lw[3] + lb4[3];
+            if (ln.mode == 2) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+        }
+        if (e.act == MSAM_ACT_GELU) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+        else if (e.act == MSAM_ACT_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        if (e.out_dtype == MSAM_F32) {
+            *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+            *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
+        }
+    }
+}
+
 thread_local char g_err[512] = "";
 
 }  // namespace
@@ -308,8 +453,30 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.act = p->act; e.out = p->out; e.out_dtype = p->out_dtype; e.ldc = p->ldc;
     e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
-    int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     hipStream_t s = (hipStream_t)stream;
+    if (p->ln_mode) {
+        if (p->N != 256 || p->out_mode != 0 || !p->ln_w || !p->ln_b || p->ln_mode < 0 || p->ln_mode > 2) {
+            msam_set_error("msam_gemm_bf16: fused LayerNorm needs N == 256, plain output and ln_w / ln_b");
+            return 1;
+        }
+        static bool attr_set = false;
+        constexpr int LN_LDS = 2 * (64 * 8 + 256 * 8) * 16;     // 80 KB dynamic LDS
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)gemm_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS) != hipSuccess) {
+                msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
+                return 2;
+            }
+            attr_set = true;
+        }
+        EpiLN ln{p->ln_w, p->ln_b, p->ln_eps, p->ln_mode};
+        const bool prof_ln = g_prof_on && g_prof_n < PROF_MAX;
+        if (prof_ln) { g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; (void)hipEventRecord(g_prof[g_prof_n].a, s); }
+        hipLaunchKernelGGL(gemm_ln_kernel, dim3((p->M + 63) / 64), dim3(256), LN_LDS, s, (const u16*)p->A, (long)p->lda,
+                           (const u16*)p->W, (long)p->ldw, p->M, p->K, e, ln);
+        if (prof_ln) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
+        return msam_check_launch("msam_gemm_bf16(ln)");
+    }
+    int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
     if (prof) {
         g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K;

@@ -70,7 +70,32 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
     const float hi_t = thr + off, lo_t = thr - off;
     uint32_t word = 0;
     int c_hi = 0, c_lo = 0, c_m = 0, ymin = 0x7fffffff, ymax = -1;
-    if (x < out_w) {
+    if (!TWO_STAGE) {
+        if (x < out_w) {
+            // x4 fast path: the horizontal lerp of the 10 low-res rows under this 32-row word is shared by its 32
+            // pixels (same arithmetic as stage1(), so still bit-exact): pixel b uses rows c, c+1 with c = (b + 2) / 4
+            const Axis ax = axis_weights(x, 0.25f, 256);
+            const int rlo = yw * 8 - 1;
+            float t[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                const int r = min(max(rlo + k, 0), 255);
+                t[k] = lerp_torch(ax.w0, low[r * 256 + ax.i0], ax.w1, low[r * 256 + ax.i1]);
+            }
+#pragma unroll
+            for (int b = 0; b < 32; ++b) {
+                const int y = yw * 32 + b;
+                if (y < out_h) {
+                    const Axis ay = axis_weights(y, 0.25f, 256);
+                    const float v = lerp_torch(ay.w0, t[(b + 2) / 4], ay.w1, t[(b + 2) / 4 + 1]);
+                    if (logits) logits[((long)n * out_h + y) * out_w + x] = v;
+                    c_hi += v > hi_t; c_lo += v > lo_t;
+                    if (v > thr) { word |= 1u << b; ++c_m; ymin = min(ymin, y); ymax = y; }
+                }
+            }
+            bits[((long)n * wpc + yw) * out_w + x] = word;
+        }
+    } else if (x < out_w) {
         Axis ax2; float sx = 0.f, sy = 0.f;
         if (TWO_STAGE) { sx = (float)in_w / (float)out_w; sy = (float)in_h / (float)out_h; ax2 = axis_weights(x, sx, in_w); }
         for (int b = 0; b < 32; ++b) {

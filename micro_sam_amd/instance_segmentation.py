@@ -277,7 +277,12 @@ class AutomaticMaskGenerator(AMGBase):
             precomputed_embeddings = True
         else:
             precomputed_embeddings = False
-        image = util._to_image(image)
+        if precomputed_embeddings:
+            # with precomputed embeddings only the image SHAPE is used below (the reference converts the image with
+            # util._to_image regardless); skip the host-side conversion of the pixel data
+            image = np.broadcast_to(np.zeros((1, 1, 1), dtype=np.uint8), tuple(original_size) + (3,))
+        else:
+            image = util._to_image(image)
         _, pbar_init, pbar_update, pbar_close = util.handle_pbar(verbose, pbar_init, pbar_update)
         crop_list = []
         for crop_box, layer_idx in zip(crop_boxes, layer_idxs):

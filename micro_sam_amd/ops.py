@@ -14,8 +14,10 @@ from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32  # noqa: F401
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
          out_dtype: torch.dtype = torch.float32, resid: Optional[torch.Tensor] = None, resid_rows: int = 0,
          table: Optional[torch.Tensor] = None, table_cols: int = 0, use_glds: int = 0,
-         out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(a[M,K] @ w[N,K]^T + bias + table[row % rows, :table_cols] + resid); a, w bf16."""
+         out: Optional[torch.Tensor] = None, ln_mode: int = 0, ln_w: Optional[torch.Tensor] = None,
+         ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
+    """act(LN(a[M,K] @ w[N,K]^T + bias + table[row % rows, :table_cols] + resid)); a, w bf16.
+    ln_mode 1: LayerNorm over the row (N == 256); 2: LayerNorm over 64-column groups + GELU."""
     _lib.require_gpu()
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
     M, K = a.shape
@@ -34,6 +36,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.act = act
     p.out, p.out_dtype, p.ldc = out.data_ptr(), (F32 if out.dtype == torch.float32 else BF16), N
     p.use_glds = use_glds
+    if ln_mode:
+        p.ln_mode, p.ln_w, p.ln_b, p.ln_eps = ln_mode, ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
     _lib.check(_lib.load().msam_gemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_gemm_bf16")
     return out
 

@@ -160,3 +160,30 @@ def test_vit_attention_vs_oracle(env, window):
     else:
         ref = S._attention_relpos(sd, "a.", y, heads, p)
     assert _close(out, ref.reshape(-1, D), 2e-2, 2e-2)
+
+
+@pytest.mark.parametrize("K", [128, 256])
+def test_gemm_fused_layernorm(env, K):
+    """Row-complete 64x256 GEMM with LayerNorm(256) and LayerNorm(64 groups)+GELU epilogues (decoder norm4 / up-scaling)."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(9)
+    M = 4096 + 40                                   # M tail (not a multiple of 64)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(256, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(256, generator=g).to(dev)
+    resid = _bf(torch.randn(M, 256, generator=g)).to(dev)
+    lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
+    pre = a.float() @ w.float().t() + bias + resid.float()
+    ref = F.layer_norm(pre, (256,), lw, lb, eps=1e-5)
+    out = ops.gemm(a, w, bias, resid=resid, out_dtype=torch.bfloat16, ln_mode=1, ln_w=lw, ln_b=lb, ln_eps=1e-5)
+    assert _close(out, ref, 2e-2, 1e-2)
+    out32 = ops.gemm(a, w, bias, resid=resid, out_dtype=torch.float32, ln_mode=1, ln_w=lw, ln_b=lb, ln_eps=1e-5)
+    assert _close(out32, ref, 2e-4, 1e-4)
+    x = resid.clone()                               # in-place stream update (layer 1 of the two-way transformer)
+    ops.gemm(a, w, bias, resid=x, out=x, ln_mode=1, ln_w=lw, ln_b=lb, ln_eps=1e-5)
+    assert _close(x, ref, 2e-2, 1e-2)
+    pre2 = a.float() @ w.float().t() + bias
+    ref2 = F.gelu(F.layer_norm(pre2.reshape(M, 4, 64), (64,), lw[:64], lb[:64], eps=1e-6)).reshape(M, 256)
+    out2 = ops.gemm(a, w, bias, out_dtype=torch.bfloat16, ln_mode=2, ln_w=lw[:64].contiguous(), ln_b=lb[:64].contiguous(),
+                    ln_eps=1e-6)
+    assert _close(out2, ref2, 2e-2, 1e-2)

@@ -31,7 +31,7 @@ def test_mask_data_to_segmentation_device(shape, n, with_background):
     masks = _random_masks(rng, n, *shape) if n else np.zeros((0,) + shape, dtype=bool)
     if n:
         masks[1] = masks[0]                                # equal areas: stable order matters
-    areas = masks.reshape(n, -1).sum(1)
+    areas = masks.reshape(n, shape[0] * shape[1]).sum(1)
     recs = [{"segmentation": m, "area": int(a)} for m, a in zip(masks, areas)]
     ref = A.mask_data_to_segmentation(recs, shape=shape, with_background=with_background, merge_exclusively=False)
     bits = _vendored.pack_bits(torch.as_tensor(masks).cuda()) if n else torch.zeros((0, (shape[0] + 31) // 32, shape[1]), dtype=torch.int32, device="cuda")
