@@ -66,6 +66,21 @@ typedef struct {
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 
+/* Weights-stationary streaming GEMM for the decoder's image-token stream (M = P*4096 rows, N,K in {128,256}):
+ * out = epi(A[M,K] * W[N,K]^T), A / W / out bf16, contiguous rows (lda = K, ldw = K).  Same epilogue vocabulary as
+ * msam_gemm_bf16 (bias, row-indexed table on the first table_cols columns, bf16 residual, ln_mode 1/2 for N == 256),
+ * or kv_split (N == 256): k_out <- columns 0..127 as [M,128], vT_out <- columns 128..255 as [M/tokens,128,tokens]. */
+typedef struct {
+    const void* A; const void* W; int32_t M, N, K;
+    const float* bias;
+    const float* table; int32_t table_rows, table_cols; int64_t table_ld;
+    const void* resid; int32_t resid_rows; int64_t ldr;        /* bf16 residual, row = row % resid_rows (0 -> row) */
+    int32_t ln_mode; const float* ln_w; const float* ln_b; float ln_eps;
+    void* out; int64_t ldc;
+    int32_t kv_split; void* k_out; void* vT_out; int32_t tokens;
+} msam_wsgemm_t;
+int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream);
+
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and
@@ -201,6 +216,11 @@ int msam_rle_encode(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_
 int msam_box_nms(const float* boxes_sorted, int32_t K, float iou_threshold, uint64_t* mask_scratch, int32_t* keep_flags,
                  void* stream);
 
+/* Same, with boxes that an earlier filter already rejected: valid_sorted int32 [K] (0 = rejected; such boxes neither
+ * survive nor suppress).  Lets generate() run threshold filters + NMS without compacting on the host. */
+int msam_box_nms_valid(const float* boxes_sorted, const int32_t* valid_sorted, int32_t K, float iou_threshold,
+                       uint64_t* mask_scratch, int32_t* keep_flags, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Merge masks to a label image:  util.mask_data_to_segmentation  (micro_sam/util.py:1773-1848)
  * ------------------------------------------------------------------------------------------------- */
@@ -209,11 +229,19 @@ int msam_box_nms(const float* boxes_sorted, int32_t K, float iou_threshold, uint
  * bits: [*, ceil(H/32), W] as produced by msam_postprocess_masks; label: int32 [H,W]. */
 int msam_paint_label_image(const uint32_t* bits, const int32_t* order, int32_t K, int32_t H, int32_t W, int32_t* label,
                            void* stream);
+/* As msam_paint_label_image with the number of masks read from device memory (k_dev: int32[1]). */
+int msam_paint_label_image_dev(const uint32_t* bits, const int32_t* order, const int32_t* k_dev, int32_t H, int32_t W,
+                               int32_t* label, void* stream);
 /* Connected components (4-connectivity) of equal non-zero value (elf.parallel.label at util.py:1834):
  * roots[i] = smallest linear index of pixel i's component, -1 for background.  changed_flag: int32 device scratch.
  * Synchronises the stream once per union pass (at most max_iters, default 8); iters_done (host, optional). */
 int msam_label_components(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
                           int32_t max_iters, int32_t* iters_done, void* stream);
+
+/* Fully asynchronous variant: `passes` union passes (one is complete for the lock-free union, a second one verifies),
+ * changed_flag = flag of the last pass to be checked by the caller whenever convenient. */
+int msam_label_components_async(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
+                                int32_t passes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,16 @@ class GemmParams(C.Structure):
     ]
 
 
+class WsGemmParams(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("W", _vp), ("M", _i32), ("N", _i32), ("K", _i32), ("bias", _vp),
+        ("table", _vp), ("table_rows", _i32), ("table_cols", _i32), ("table_ld", _i64),
+        ("resid", _vp), ("resid_rows", _i32), ("ldr", _i64),
+        ("ln_mode", _i32), ("ln_w", _vp), ("ln_b", _vp), ("ln_eps", _f32),
+        ("out", _vp), ("ldc", _i64), ("kv_split", _i32), ("k_out", _vp), ("vT_out", _vp), ("tokens", _i32),
+    ]
+
+
 _blk = _vp * MSAM_MAX_BLOCKS
 
 
@@ -73,6 +83,7 @@ _PROTOS = {
     "msam_last_error": (C.c_char_p, []),
     "msam_abi_version": (_i32, []),
     "msam_gemm_bf16": (_i32, [C.POINTER(GemmParams), _vp]),
+    "msam_wsgemm_bf16": (_i32, [C.POINTER(WsGemmParams), _vp]),
     "msam_profile_enable": (_i32, [_i32]),
     "msam_profile_collect": (_i32, [C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
@@ -95,6 +106,9 @@ _PROTOS = {
     "msam_rle_run_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_rle_encode": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "msam_box_nms": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp]),
+    "msam_box_nms_valid": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "msam_paint_label_image_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "msam_label_components_async": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, C.POINTER(_i32), _vp]),
 }

@@ -314,27 +314,26 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni)
                 h[mk][ni] = mk < nmask ? hyper[((long)p * 4 + mask0 + mk) * hyper_ld + cq + ni] : 0.f;
-        f32x4_t acc[2][8];
-#pragma unroll
+#pragma unroll 1
         for (int mi = 0; mi < 2; ++mi) {
-            const u16* ar = up1 + (row0 + mi * 16 + fr) * 64;
-            const uint4 a0 = *(const uint4*)(ar + fg * 8), a1 = *(const uint4*)(ar + 32 + fg * 8);
+            f32x4_t acc[8];
+            {
+                const u16* ar = up1 + (row0 + mi * 16 + fr) * 64;
+                const uint4 a0 = *(const uint4*)(ar + fg * 8), a1 = *(const uint4*)(ar + 32 + fg * 8);
 #pragma unroll
-            for (int ni = 0; ni < 8; ++ni) {
-                f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-                c = mfma16(a0, wb[ni][0], c);
-                c = mfma16(a1, wb[ni][1], c);
-                acc[mi][ni] = c;
+                for (int ni = 0; ni < 8; ++ni) {
+                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma16(a0, wb[ni][0], c);
+                    c = mfma16(a1, wb[ni][1], c);
+                    acc[ni] = c;
+                }
             }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float part[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ni = 0; ni < 8; ++ni) {
-                    const float g = gelu_erf(acc[mi][ni][r] + bias[ni]);
+                    const float g = gelu_erf(acc[ni][r] + bias[ni]);
 #pragma unroll
                     for (int mk = 0; mk < 3; ++mk) part[mk] += g * h[mk][ni];
                 }
@@ -384,6 +383,21 @@ int gemm_kv(const Ctx& cx, const void* x, int rows, const void* wkv, const float
     g.table = pek; g.table_rows = T; g.table_cols = CI; g.table_ld = CI;
     g.out_mode = 2; g.k = k_out; g.v = vT_out; g.tokens = T; g.use_glds = cx.use_glds;
     return msam_gemm_bf16(&g, cx.s);
+}
+
+// weights-stationary streaming GEMM on the per-prompt image-token stream (rows = P*4096)
+int wsgemm(const Ctx& cx, const void* A, const void* W, int M, int N, int K, const float* bias, void* out,
+           const float* table = nullptr, int table_cols = 0, const void* resid = nullptr, int resid_rows = 0, int ln_mode = 0,
+           const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f, void* k_out = nullptr,
+           void* vT_out = nullptr) {
+    msam_wsgemm_t g{};
+    g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    g.table = table; g.table_rows = T; g.table_cols = table_cols; g.table_ld = CI;
+    g.resid = resid; g.resid_rows = resid_rows; g.ldr = C;
+    g.ln_mode = ln_mode; g.ln_w = ln_w; g.ln_b = ln_b; g.ln_eps = ln_eps;
+    g.out = out; g.ldc = N;
+    if (k_out) { g.kv_split = 1; g.k_out = k_out; g.vT_out = vT_out; g.tokens = T; }
+    return msam_wsgemm_bf16(&g, cx.s);
 }
 
 struct Consts {     // layout of the `consts` buffer
@@ -558,7 +572,8 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         if (li == 0) {
             hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
         } else {
-            CHECK(gemm_kv(cx, w.keys, (int)R, c.wkv[1], c.bkv[1], c.pe_k[1], w.kimg, w.vT));
+            CHECK(wsgemm(cx, w.keys, c.wkv[1], (int)R, 256, C, c.bkv[1], nullptr, c.pe_k[1], CI, nullptr, 0, 0, nullptr, nullptr,
+                         0.f, w.kimg, w.vT));
             hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
         }
         CHECK(msam_check_launch("t2i_attn"));
@@ -577,24 +592,24 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         if (li == 0) {
             hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, im.q0, 1, w.ks, w.vs, Nt, w.attn_img);
         } else {
-            CHECK(gemm(cx, w.keys, C, L.i2t.q_w, (int)R, CI, C, L.i2t.q_b, w.qimg, MSAM_BF16, CI, 0, nullptr, 0, 0, 0,
-                       c.pe_q[1], CI));
+            CHECK(wsgemm(cx, w.keys, L.i2t.q_w, (int)R, CI, C, L.i2t.q_b, w.qimg, c.pe_q[1], CI));
             hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, w.qimg, 0, w.ks, w.vs, Nt, w.attn_img);
         }
         CHECK(msam_check_launch("i2t_attn"));
         // out_proj + residual + norm4 fused (row-complete GEMM epilogue); layer 1 updates the stream in place
         if (li == 0)
-            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, MSAM_BF16, C, 0, im.src_bf16,
-                       MSAM_BF16, C, T, nullptr, 0, 1, L.n4_w, L.n4_b, 1e-5f));
+            CHECK(wsgemm(cx, w.attn_img, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, nullptr, 0, im.src_bf16, T, 1, L.n4_w,
+                         L.n4_b, 1e-5f));
         else
-            CHECK(gemm(cx, w.attn_img, CI, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, MSAM_BF16, C, 0, w.keys, MSAM_BF16,
-                       C, 0, nullptr, 0, 1, L.n4_w, L.n4_b, 1e-5f));
+            CHECK(wsgemm(cx, w.attn_img, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, nullptr, 0, w.keys, 0, 1, L.n4_w, L.n4_b,
+                         1e-5f));
     }
     if (dbg) return 0;   // test hook: leave queries / keys of the last executed layer in the workspace
     // final token -> image attention
     ADD_CAST(w.queries, w.qpe, w.a);
     CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_BF16, CI));
-    CHECK(gemm_kv(cx, w.keys, (int)R, c.wkv[2], c.bkv[2], c.pe_k[2], w.kimg, w.vT));
+    CHECK(wsgemm(cx, w.keys, c.wkv[2], (int)R, 256, C, c.bkv[2], nullptr, c.pe_k[2], CI, nullptr, 0, 0, nullptr, nullptr, 0.f,
+                 w.kimg, w.vT));
     hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
     CHECK(msam_check_launch("t2i_attn_final"));
     CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
@@ -617,8 +632,8 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     CHECK(msam_check_launch("gather_iou"));
 
     // up-scaling: ConvT1 as GEMM with fused (bias, LayerNorm2d over 64 channels, GELU) epilogue -> fused ConvT2
-    CHECK(gemm(cx, w.keys, C, dec->up1_w, (int)R, C, C, dec->up1_b, w.up1, MSAM_BF16, C, 0, nullptr, 0, 0, 0, nullptr, 0,
-               2, dec->up_ln_w, dec->up_ln_b, 1e-6f));
+    CHECK(wsgemm(cx, w.keys, dec->up1_w, (int)R, C, C, dec->up1_b, w.up1, nullptr, 0, nullptr, 0, 2, dec->up_ln_w, dec->up_ln_b,
+                 1e-6f));
     {
         const long rows = R * 4;
         long tiles = rows / 128;

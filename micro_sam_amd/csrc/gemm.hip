@@ -425,6 +425,13 @@ extern "C" int msam_profile_collect(int32_t* launches, double* total_ms, double*
     return 0;
 }
 
+// used by the other GEMM-family kernels (wsgemm.hip) so that they are part of the same live measurement
+void msam_profile_mark(void* stream, int begin, double flops) {
+    if (!g_prof_on || g_prof_n >= PROF_MAX) return;
+    if (begin) { g_prof[g_prof_n].flops = flops; (void)hipEventRecord(g_prof[g_prof_n].a, (hipStream_t)stream); }
+    else { (void)hipEventRecord(g_prof[g_prof_n].b, (hipStream_t)stream); ++g_prof_n; }
+}
+
 extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     if (!p || !p->A || !p->W) { msam_set_error("msam_gemm_bf16: null operand"); return 1; }
     if (p->M <= 0 || p->N <= 0 || p->K <= 0 || p->N % BN != 0 || p->K % BK != 0) {

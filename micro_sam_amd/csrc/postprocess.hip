@@ -82,17 +82,23 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                 const int r = min(max(rlo + k, 0), 255);
                 t[k] = lerp_torch(ax.w0, low[r * 256 + ax.i0], ax.w1, low[r * 256 + ax.i1]);
             }
+            // vertical weights of the x4 grid are compile-time constants: frac(src) in {.625,.875,.125,.375} by b % 4
+            // (exactly what axis_weights computes in fp32), except the two clamped rows at the top of the image
+            const float W1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+            const int nb = min(32, out_h - yw * 32);
 #pragma unroll
             for (int b = 0; b < 32; ++b) {
-                const int y = yw * 32 + b;
-                if (y < out_h) {
-                    const Axis ay = axis_weights(y, 0.25f, 256);
-                    const float v = lerp_torch(ay.w0, t[(b + 2) / 4], ay.w1, t[(b + 2) / 4 + 1]);
-                    if (logits) logits[((long)n * out_h + y) * out_w + x] = v;
+                float w1 = W1[b & 3];
+                if (b < 2 && yw == 0) w1 = 0.0f;
+                const float w0 = 1.0f - w1;
+                const float v = lerp_torch(w0, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
+                if (b < nb) {
+                    if (logits) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
                     c_hi += v > hi_t; c_lo += v > lo_t;
-                    if (v > thr) { word |= 1u << b; ++c_m; ymin = min(ymin, y); ymax = y; }
+                    word |= (uint32_t)(v > thr) << b;
                 }
             }
+            if (word) { c_m = __popc(word); ymin = yw * 32 + __ffs(word) - 1; ymax = yw * 32 + 31 - __clz(word); }
             bits[((long)n * wpc + yw) * out_w + x] = word;
         }
     } else if (x < out_w) {

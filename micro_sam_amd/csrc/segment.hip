@@ -17,9 +17,10 @@ int msam_check_launch(const char* what);
 namespace {
 
 __global__ __launch_bounds__(256) void paint_kernel(const uint32_t* __restrict__ bits, const int* __restrict__ order, int K,
-                                                    int H, int W, int* __restrict__ label) {
+                                                    const int* __restrict__ k_dev, int H, int W, int* __restrict__ label) {
     const int x = blockIdx.x * 256 + threadIdx.x, yw = blockIdx.y;
     if (x >= W) return;
+    if (k_dev) K = *k_dev;                     // number of masks decided on the device (no host round trip)
     const int wpc = (H + 31) >> 5;
     const int nb = min(32, H - yw * 32);
     uint32_t un = nb < 32 ? ((1u << nb) - 1u) : 0xffffffffu;
@@ -110,10 +111,15 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
 
 // one wave: lane l owns words l, l+64, ... of the running "removed" set (K <= 64*64*4 words handled by the stride loop)
 __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int K,
-                                                       int* __restrict__ keep) {
+                                                       const int* __restrict__ valid, int* __restrict__ keep) {
     const int nblk = (K + 63) >> 6, lane = threadIdx.x;
     extern __shared__ unsigned long long remv[];
-    for (int w = lane; w < nblk; w += 64) remv[w] = 0ull;
+    for (int w = lane; w < nblk; w += 64) {
+        unsigned long long r = 0ull;
+        if (valid)                                   // boxes filtered out beforehand start as "removed"
+            for (int b = 0; b < 64 && w * 64 + b < K; ++b) r |= (unsigned long long)(valid[w * 64 + b] == 0) << b;
+        remv[w] = r;
+    }
     __syncthreads();
     for (int i = 0; i < K; ++i) {
         const bool removed = (remv[i >> 6] >> (i & 63)) & 1ull;          // uniform across the wave
@@ -126,8 +132,16 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
 
 }  // namespace
 
+extern "C" int msam_box_nms_valid(const float* boxes_sorted, const int32_t* valid_sorted, int32_t K, float iou_threshold,
+                                  uint64_t* mask_scratch, int32_t* keep_flags, void* stream);
+
 extern "C" int msam_box_nms(const float* boxes_sorted, int32_t K, float iou_threshold, uint64_t* mask_scratch,
                             int32_t* keep_flags, void* stream) {
+    return msam_box_nms_valid(boxes_sorted, nullptr, K, iou_threshold, mask_scratch, keep_flags, stream);
+}
+
+extern "C" int msam_box_nms_valid(const float* boxes_sorted, const int32_t* valid_sorted, int32_t K, float iou_threshold,
+                                  uint64_t* mask_scratch, int32_t* keep_flags, void* stream) {
     if (K < 0 || (K > 0 && (!boxes_sorted || !mask_scratch || !keep_flags))) { msam_set_error("msam_box_nms: bad arguments"); return 1; }
     if (K == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
@@ -135,7 +149,8 @@ extern "C" int msam_box_nms(const float* boxes_sorted, int32_t K, float iou_thre
     if (nblk * 8 > 60000) { msam_set_error("msam_box_nms: too many boxes"); return 1; }
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, s, boxes_sorted, K, iou_threshold,
                        (unsigned long long*)mask_scratch);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K, keep_flags);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K,
+                       valid_sorted, keep_flags);
     return msam_check_launch("msam_box_nms");
 }
 
@@ -146,8 +161,31 @@ extern "C" int msam_paint_label_image(const uint32_t* bits, const int32_t* order
         return 1;
     }
     hipLaunchKernelGGL(paint_kernel, dim3((W + 255) / 256, (H + 31) / 32), dim3(256), 0, (hipStream_t)stream, bits, order, K,
-                       H, W, label);
+                       (const int*)nullptr, H, W, label);
     return msam_check_launch("msam_paint_label_image");
+}
+
+extern "C" int msam_paint_label_image_dev(const uint32_t* bits, const int32_t* order, const int32_t* k_dev, int32_t H,
+                                          int32_t W, int32_t* label, void* stream) {
+    if (!label || !bits || !order || !k_dev || H <= 0 || W <= 0) { msam_set_error("msam_paint_label_image_dev: bad arguments"); return 1; }
+    hipLaunchKernelGGL(paint_kernel, dim3((W + 255) / 256, (H + 31) / 32), dim3(256), 0, (hipStream_t)stream, bits, order, 0,
+                       k_dev, H, W, label);
+    return msam_check_launch("msam_paint_label_image_dev");
+}
+
+// Fixed number of union passes without host synchronisation; changed_flag holds the flag of the LAST pass (0 = converged).
+extern "C" int msam_label_components_async(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
+                                           int32_t passes, void* stream) {
+    if (!seg || !roots || !changed_flag || H <= 0 || W <= 0 || passes <= 0) { msam_set_error("msam_label_components_async: bad arguments"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int n = H * W, grid = (n + 255) / 256;
+    hipLaunchKernelGGL(cc_init_kernel, dim3(grid), dim3(256), 0, s, seg, n, roots);
+    for (int it = 0; it < passes; ++it) {
+        if (hipMemsetAsync(changed_flag, 0, sizeof(int), s) != hipSuccess) { msam_set_error("msam_label_components_async: memset"); return 2; }
+        hipLaunchKernelGGL(cc_hook_kernel, dim3(grid), dim3(256), 0, s, seg, H, W, roots, changed_flag);
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid), dim3(256), 0, s, n, roots);
+    }
+    return msam_check_launch("msam_label_components_async");
 }
 
 extern "C" int msam_label_components(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,

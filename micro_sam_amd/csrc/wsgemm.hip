@@ -1,0 +1,217 @@
+// Weights-stationary streaming GEMM for the decoder's image-token stream:  C[M,N] = epi(A[M,K] * W[N,K]^T)
+// with M = P*4096 (millions of rows), N in {128,256}, K in {128,256}: the whole weight matrix (32-128 KB bf16) is
+// tiny, the activations are the traffic.  So the weights never touch LDS: each of the 8 waves of a persistent
+// workgroup keeps ITS N/8 output columns of W as MFMA B fragments in registers for the whole launch (<= 64 VGPRs),
+// and only the activation row blocks (64 rows x K) stream HBM -> VGPR -> LDS (double buffered, 16-lane-group
+// conflict-free XOR swizzle) -> A fragments.  Per 64-row tile and wave: K/32 x 4 ds_read_b128 feed K/32 x 4 x N/128
+// MFMAs; nothing but the A tile is ever written to LDS in the main loop.
+// Epilogue: the fp32 tile goes through LDS once so that every wave then owns whole rows: bias, positional table,
+// residual, LayerNorm(256) / LayerNorm(64 groups)+GELU, coalesced bf16 stores; or the K | V^T split store.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+void msam_profile_mark(void* stream, int begin, double flops);
+
+namespace {
+
+constexpr int WM = 64;          // rows per tile
+constexpr int NWAVES = 8;
+
+struct WsEpi {
+    const float* bias; const float* table; int table_rows, table_cols; long table_ld;
+    const u16* resid; int resid_rows; long ldr;
+    const float* ln_w; const float* ln_b; float ln_eps; int ln_mode;
+    u16* out; long ldc;              // plain bf16 output [M, N]
+    int kv_split; u16* k_out; u16* vT_out; int tokens;
+};
+
+// 4-bit chunk swizzle: the 16 rows of a ds_read_b128 service group hit 16 distinct 16-byte slots
+MSAM_DEVINL int swz16(int row) { return (row & 15) ^ (((row + 4) >> 3) & 1); }
+
+template <int N, int K>
+__global__ __launch_bounds__(512) void wsgemm_kernel(const u16* __restrict__ A, const u16* __restrict__ W, int M, WsEpi e) {
+    constexpr int NT = N / NWAVES / 16;          // n-tiles per wave (1 or 2)
+    constexpr int KC = K / 32;                   // 32-deep k chunks
+    constexpr int CPR = K / 8;                   // 16-byte chunks per A row
+    constexpr int APT = WM * CPR / 512;          // A chunks staged per thread (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
+    uint4* ldsA = dyn_lds;                                        // [2][WM * CPR]
+    float* ldsC = (float*)(dyn_lds + 2 * WM * CPR);               // [WM][N] fp32
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    // ---- stationary weights: B fragments of this wave's columns
+    uint4 bfr[NT][KC];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            bfr[ni][kc] = *(const uint4*)(W + (long)(wave * (NT * 16) + ni * 16 + fr) * K + kc * 32 + fg * 8);
+
+    const int ntiles = M / WM;
+    // staging map: chunk id q = p*512 + tid -> (row = q / CPR, c = q % CPR)
+    uint4 ra0, ra1, ra2, ra3;
+    (void)ra2; (void)ra3;
+#define WS_SRC(p_, tile_) (A + ((long)(tile_) * WM + ((p_) * 512 + tid) / CPR) * K + (((p_) * 512 + tid) % CPR) * 8)
+#define WS_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * 512 + tid) / CPR) * CPR + \
+                              ((((p_) * 512 + tid) % CPR) ^ swz16(((p_) * 512 + tid) / CPR))]
+#define WS_LOAD(tile_)                                                                    \
+    do {                                                                                  \
+        ra0 = *(const uint4*)WS_SRC(0, tile_); ra1 = *(const uint4*)WS_SRC(1, tile_);     \
+        if constexpr (APT == 4) { ra2 = *(const uint4*)WS_SRC(2, tile_); ra3 = *(const uint4*)WS_SRC(3, tile_); } \
+    } while (0)
+#define WS_STORE(buf_)                                                                    \
+    do {                                                                                  \
+        WS_DST(0, buf_) = ra0; WS_DST(1, buf_) = ra1;                                     \
+        if constexpr (APT == 4) { WS_DST(2, buf_) = ra2; WS_DST(3, buf_) = ra3; }         \
+    } while (0)
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    WS_LOAD(tile);
+    WS_STORE(0);
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) WS_LOAD(next);                         // in flight during the MFMA phase
+        f32x4_t acc[4][NT];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const uint4* la = ldsA + buf * WM * CPR;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            uint4 a[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int row = mi * 16 + fr;
+                a[mi] = la[row * CPR + ((kc * 4 + fg) ^ swz16(row))];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma16(a[mi], bfr[ni][kc], acc[mi][ni]);
+        }
+        // ---- fp32 tile -> LDS (row-complete epilogue); ldsC is private to the epilogue, ldsA[buf^1] gets the next tile
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ldsC[(mi * 16 + fg * 4 + r) * N + wave * (NT * 16) + ni * 16 + fr] = acc[mi][ni][r];
+        if (next < ntiles) WS_STORE(buf ^ 1);
+        __syncthreads();
+
+        const long row0 = (long)tile * WM;
+        constexpr int LPR = N / 4;                 // lanes per row (64 for N = 256, 32 for N = 128)
+        constexpr int RPP = 64 / LPR;              // rows per wave pass (1 or 2)
+        const int col = (lane % LPR) * 4;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e.bias) { const float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+        const bool use_table = e.table && col < e.table_cols;
+#pragma unroll
+        for (int pass = 0; pass < WM / (NWAVES * RPP); ++pass) {
+            const int lr = (pass * NWAVES + wave) * RPP + lane / LPR;
+            const long row = row0 + lr;
+            const float4 c = *(const float4*)(ldsC + lr * N + col);
+            float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+            if (use_table) {
+                const float4 t = *(const float4*)(e.table + (row % e.table_rows) * e.table_ld + col);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (e.resid) {
+                const long rr = e.resid_rows ? (row % e.resid_rows) : row;
+                const uint2 t = *(const uint2*)(e.resid + rr * e.ldr + col);
+                v[0] += bf2f((u16)(t.x & 0xffff)); v[1] += bf2f((u16)(t.x >> 16));
+                v[2] += bf2f((u16)(t.y & 0xffff)); v[3] += bf2f((u16)(t.y >> 16));
+            }
+            if (N == 256 && e.ln_mode) {
+                const float s = (v[0] + v[1]) + (v[2] + v[3]);
+                const float inv_n = e.ln_mode == 1 ? (1.0f / 256.0f) : (1.0f / 64.0f);
+                const float mean = (e.ln_mode == 1 ? wave_sum64(s) : wave_sum_xor16(s)) * inv_n;
+                const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                const float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                const float var = (e.ln_mode == 1 ? wave_sum64(q) : wave_sum_xor16(q)) * inv_n;
+                const float rstd = 1.0f / sqrtf(var + e.ln_eps);
+                const int lc = e.ln_mode == 2 ? (col & 63) : col;
+                const float4 w4 = *(const float4*)(e.ln_w + lc), b4 = *(const float4*)(e.ln_b + lc);
+                v[0] = d0 * rstd * w4.x + b4.x; v[1] = d1 * rstd * w4.y + b4.y;
+                v[2] = d2 * rstd * w4.z + b4.z; v[3] = d3 * rstd * w4.w + b4.w;
+                if (e.ln_mode == 2) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+            }
+            if (!e.kv_split) {
+                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                *(uint2*)(e.out + row * e.ldc + col) = pk;
+            } else if (col < 128) {
+                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                *(uint2*)(e.k_out + row * 128 + col) = pk;
+            } else {
+                *(float4*)(ldsC + lr * N + col) = make_float4(v[0], v[1], v[2], v[3]);     // finished v values back
+            }
+        }
+        if (N == 256 && e.kv_split) {
+            __syncthreads();
+            // V^T[b][d][t]: thread -> (d = tid & 127, 16-row group g = tid >> 7): 16 tokens = 32 contiguous bytes
+            const int d = tid & 127, g = tid >> 7;
+            const long b = row0 / e.tokens, t0 = row0 - b * e.tokens + g * 16;
+            const float* src = ldsC + (g * 16) * N + 128 + d;
+            uint4 p0, p1;
+            p0.x = pack2bf(src[0 * N], src[1 * N]); p0.y = pack2bf(src[2 * N], src[3 * N]);
+            p0.z = pack2bf(src[4 * N], src[5 * N]); p0.w = pack2bf(src[6 * N], src[7 * N]);
+            p1.x = pack2bf(src[8 * N], src[9 * N]); p1.y = pack2bf(src[10 * N], src[11 * N]);
+            p1.z = pack2bf(src[12 * N], src[13 * N]); p1.w = pack2bf(src[14 * N], src[15 * N]);
+            u16* dst = e.vT_out + (b * 128 + d) * e.tokens + t0;
+            *(uint4*)dst = p0; *(uint4*)(dst + 8) = p1;
+        }
+        __syncthreads();        // ldsC free again; next tile's A (stored above) visible
+        buf ^= 1;
+    }
+}
+
+template <int N, int K>
+int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
+    constexpr int LDS_BYTES = 2 * WM * (K / 8) * 16 + WM * N * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wsgemm_kernel<N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess) { msam_set_error("msam_wsgemm_bf16: cannot raise the dynamic LDS limit"); return 2; }
+        attr_set = true;
+    }
+    const int ntiles = M / WM;
+    const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
+    msam_profile_mark(s, 1, 2.0 * M * (double)N * K);
+    hipLaunchKernelGGL((wsgemm_kernel<N, K>), dim3(grid), dim3(512), LDS_BYTES, s, A, W, M, e);
+    msam_profile_mark(s, 0, 0.0);
+    return msam_check_launch("msam_wsgemm_bf16");
+}
+
+}  // namespace
+
+extern "C" int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream) {
+    if (!p || !p->A || !p->W) { msam_set_error("msam_wsgemm_bf16: null operand"); return 1; }
+    if (p->M <= 0 || p->M % WM) { msam_set_error("msam_wsgemm_bf16: M must be a positive multiple of 64"); return 1; }
+    if (p->kv_split && (p->N != 256 || !p->k_out || !p->vT_out || p->tokens % WM || p->M % p->tokens || p->ln_mode)) {
+        msam_set_error("msam_wsgemm_bf16: bad kv-split arguments");
+        return 1;
+    }
+    if (!p->kv_split && !p->out) { msam_set_error("msam_wsgemm_bf16: null output"); return 1; }
+    if (p->ln_mode && (p->N != 256 || !p->ln_w || !p->ln_b)) { msam_set_error("msam_wsgemm_bf16: LayerNorm needs N == 256"); return 1; }
+    WsEpi e;
+    e.bias = p->bias; e.table = p->table; e.table_rows = p->table_rows > 0 ? p->table_rows : 1; e.table_cols = p->table_cols;
+    e.table_ld = p->table_ld; e.resid = (const u16*)p->resid; e.resid_rows = p->resid_rows; e.ldr = p->ldr;
+    e.ln_w = p->ln_w; e.ln_b = p->ln_b; e.ln_eps = p->ln_eps; e.ln_mode = p->ln_mode;
+    e.out = (u16*)p->out; e.ldc = p->ldc; e.kv_split = p->kv_split; e.k_out = (u16*)p->k_out; e.vT_out = (u16*)p->vT_out;
+    e.tokens = p->tokens > 0 ? p->tokens : WM;
+    hipStream_t s = (hipStream_t)stream;
+    const u16* A = (const u16*)p->A; const u16* W = (const u16*)p->W;
+    if (p->N == 256 && p->K == 256) return launch<256, 256>(A, W, p->M, e, s);
+    if (p->N == 256 && p->K == 128) return launch<256, 128>(A, W, p->M, e, s);
+    if (p->N == 128 && p->K == 256) return launch<128, 256>(A, W, p->M, e, s);
+    if (p->N == 128 && p->K == 128) return launch<128, 128>(A, W, p->M, e, s);
+    msam_set_error("msam_wsgemm_bf16: N and K must be 128 or 256");
+    return 1;
+}

@@ -294,6 +294,30 @@ class AutomaticMaskGenerator(AMGBase):
         self._crop_boxes = crop_boxes
 
     @torch.no_grad()
+    def generate_device(self, pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95,
+                        box_nms_thresh: float = 0.7, with_background: bool = True, min_object_size: int = 0):
+        """``generate(output_mode="instance_segmentation")`` without a single host synchronisation: threshold filters as one
+        boolean vector, device NMS on the valid subset, paint + connected components + relabel on the device.
+
+        Returns (labels int32 [H,W] device tensor, flag int32[1] that reads 0 when the labelling converged).
+        Identical labels to ``generate()`` (same filters in the same order, same stable sorts)."""
+        if not self.is_initialized:
+            raise RuntimeError("AutomaticMaskGenerator has not been initialized. Call initialize first.")
+        if len(self.crop_list) != 1 or "bits" not in self.crop_list[0]:
+            raise RuntimeError("generate_device needs the single-crop device state produced by initialize()")
+        data, crop_box = self.crop_list[0], self.crop_boxes[0]
+        orig_h, orig_w = self.original_size
+        valid = torch.ones_like(data["iou_preds"], dtype=torch.bool)
+        if pred_iou_thresh > 0.0:
+            valid &= data["iou_preds"] > pred_iou_thresh
+        if stability_score_thresh > 0.0:
+            valid &= data["stability_score"] >= stability_score_thresh
+        valid &= ~amg_utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h])
+        keep = ops.box_nms_flags(data["boxes"], data["iou_preds"], valid, box_nms_thresh)
+        return util.masks_to_segmentation_device(data["bits"], data["area"], keep, self.original_size,
+                                                 min_object_size=min_object_size, with_background=with_background)
+
+    @torch.no_grad()
     def generate(self, pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95, box_nms_thresh: float = 0.7,
                  crop_nms_thresh: float = 0.7, min_mask_region_area: int = 0, output_mode: str = "instance_segmentation",
                  with_background: bool = True) -> Union[List[Dict[str, Any]], np.ndarray]:

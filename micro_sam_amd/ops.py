@@ -225,3 +225,75 @@ def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> 
     _lib.check(_lib.load().msam_box_nms(b.data_ptr(), k, float(iou_threshold), scratch.data_ptr(), keep.data_ptr(),
                                         _lib.stream_ptr()), "msam_box_nms")
     return order[keep.bool()]
+
+
+def wsgemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, table: Optional[torch.Tensor] = None,
+           table_cols: int = 0, resid: Optional[torch.Tensor] = None, resid_rows: int = 0, ln_mode: int = 0,
+           ln_w: Optional[torch.Tensor] = None, ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+           kv_split_tokens: int = 0, out: Optional[torch.Tensor] = None):
+    """Weights-stationary decoder GEMM (see include/msam_hip.h).  Returns out bf16 [M,N], or (k, vT) with kv_split_tokens."""
+    _lib.require_gpu()
+    M, K = a.shape
+    N = w.shape[0]
+    p = _lib.WsGemmParams()
+    p.A, p.W, p.M, p.N, p.K = a.data_ptr(), w.data_ptr(), M, N, K
+    p.bias = _lib.ptr(bias)
+    if table is not None:
+        p.table, p.table_rows, p.table_cols, p.table_ld = table.data_ptr(), table.shape[0], table_cols, table.shape[1]
+    if resid is not None:
+        assert resid.dtype == torch.bfloat16
+        p.resid, p.resid_rows, p.ldr = resid.data_ptr(), resid_rows, resid.shape[1]
+    if ln_mode:
+        p.ln_mode, p.ln_w, p.ln_b, p.ln_eps = ln_mode, ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
+    ret = None
+    if kv_split_tokens:
+        k = torch.empty((M, 128), dtype=torch.bfloat16, device=a.device)
+        vT = torch.empty((M // kv_split_tokens, 128, kv_split_tokens), dtype=torch.bfloat16, device=a.device)
+        p.kv_split, p.k_out, p.vT_out, p.tokens = 1, k.data_ptr(), vT.data_ptr(), kv_split_tokens
+        ret = (k, vT)
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+        p.out, p.ldc = out.data_ptr(), N
+        ret = out
+    _lib.check(_lib.load().msam_wsgemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_wsgemm_bf16")
+    return ret
+
+
+def box_nms_flags(boxes: torch.Tensor, scores: torch.Tensor, valid: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """Greedy NMS restricted to ``valid`` boxes, without any host synchronisation: returns bool keep flags [N] in the
+    ORIGINAL order (boxes with valid == False are never kept and never suppress)."""
+    k = int(boxes.shape[0])
+    if k == 0:
+        return torch.zeros((0,), dtype=torch.bool, device=boxes.device)
+    s = torch.where(valid, scores.float(), torch.full_like(scores, float("-inf"), dtype=torch.float32))
+    order = torch.sort(s, descending=True, stable=True).indices
+    b = boxes.float()[order].contiguous()
+    v = valid[order].to(torch.int32).contiguous()
+    nblk = (k + 63) // 64
+    scratch = torch.empty((k * nblk,), dtype=torch.int64, device=boxes.device)
+    keep_sorted = torch.empty((k,), dtype=torch.int32, device=boxes.device)
+    _lib.check(_lib.load().msam_box_nms_valid(b.data_ptr(), v.data_ptr(), k, float(iou_threshold), scratch.data_ptr(),
+                                              keep_sorted.data_ptr(), _lib.stream_ptr()), "msam_box_nms_valid")
+    keep = torch.zeros((k,), dtype=torch.bool, device=boxes.device)
+    keep[order] = keep_sorted.bool()
+    return keep
+
+
+def paint_label_image_dev(bits: torch.Tensor, order: torch.Tensor, k_dev: torch.Tensor, height: int, width: int) -> torch.Tensor:
+    """paint_label_image with the mask count taken from device memory (k_dev int32[1]); order int32 [N]."""
+    label = torch.empty((height, width), dtype=torch.int32, device=bits.device)
+    _lib.check(_lib.load().msam_paint_label_image_dev(bits.data_ptr(), order.data_ptr(), k_dev.data_ptr(), height, width,
+                                                      label.data_ptr(), _lib.stream_ptr()), "msam_paint_label_image_dev")
+    return label
+
+
+def label_components_async(seg: torch.Tensor, passes: int = 2):
+    """label_components without host synchronisation: (roots int32 [H*W], changed_flag int32[1] of the last pass)."""
+    h, w = seg.shape
+    seg = seg.contiguous()
+    roots = torch.empty((h * w,), dtype=torch.int32, device=seg.device)
+    flag = torch.zeros((1,), dtype=torch.int32, device=seg.device)
+    _lib.check(_lib.load().msam_label_components_async(seg.data_ptr(), h, w, roots.data_ptr(), flag.data_ptr(), passes,
+                                                       _lib.stream_ptr()), "msam_label_components_async")
+    return roots, flag

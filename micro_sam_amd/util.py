@@ -369,3 +369,43 @@ def mask_data_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, sh
         keep[int(torch.argmax(masked).item())] = False                       # first maximum = smallest id on ties
     new_id = torch.cumsum(keep.to(torch.int64), 0) * keep
     return new_id[cid].reshape(h, w).to(torch.int32).cpu().numpy().astype("uint32")
+
+
+@torch.no_grad()
+def masks_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, keep: torch.Tensor, shape: Tuple[int, int],
+                                 min_object_size: int = 0, with_background: bool = False):
+    """Sync-free variant of ``mask_data_to_segmentation_device`` over ALL candidate masks with a boolean ``keep`` vector
+    (the survivors of the threshold filters and NMS): no compaction, no host round trip.
+
+    Returns (labels int32 [H,W] on the device, converged flag tensor int32[1] - must read 0)."""
+    from . import ops
+    h, w = int(shape[0]), int(shape[1])
+    dev = bits.device
+    n = int(bits.shape[0])
+    if n == 0:
+        return torch.zeros((h, w), dtype=torch.int32, device=dev), torch.zeros((1,), dtype=torch.int32, device=dev)
+    areas = areas.to(dev)
+    sel = keep & (areas >= min_object_size) if min_object_size > 0 else keep
+    # stable area-descending order of the selected masks; unselected ones sink to the end and are cut off by k_dev
+    key = torch.where(sel, areas.to(torch.int64), torch.full((n,), -1, dtype=torch.int64, device=dev))
+    order = torch.sort(key, descending=True, stable=True).indices.to(torch.int32).contiguous()
+    k_dev = sel.sum().to(torch.int32).reshape(1)
+    painted = ops.paint_label_image_dev(bits, order, k_dev, h, w)
+    roots32, flag = ops.label_components_async(painted, passes=2)
+    roots = roots32.to(torch.int64)
+    fg = roots >= 0
+    safe_roots = roots.clamp(min=0)
+    # component sizes keyed by root pixel index (no compaction): sizes[r] for roots, 0 elsewhere
+    sizes = torch.zeros(h * w, dtype=torch.int64, device=dev)
+    sizes.scatter_add_(0, safe_roots, fg.to(torch.int64))
+    idx = torch.arange(h * w, device=dev)
+    is_root = fg & (roots == idx)
+    keep_root = is_root & (sizes >= min_object_size)
+    if with_background:
+        bg_size = (~fg).sum()
+        best = torch.argmax(sizes)                          # first maximum = smallest root index = smallest component id
+        drop_component = sizes[best] > bg_size              # label 0 wins ties (it is the smallest id)
+        keep_root = keep_root & ~((idx == best) & drop_component)
+    new_id = torch.cumsum(keep_root.to(torch.int64), 0) * keep_root      # consecutive ids in raster order of the roots
+    labels = torch.where(fg, new_id[safe_roots], torch.zeros_like(roots))
+    return labels.reshape(h, w).to(torch.int32), flag

@@ -187,3 +187,34 @@ def test_gemm_fused_layernorm(env, K):
     out2 = ops.gemm(a, w, bias, out_dtype=torch.bfloat16, ln_mode=2, ln_w=lw[:64].contiguous(), ln_b=lb[:64].contiguous(),
                     ln_eps=1e-6)
     assert _close(out2, ref2, 2e-2, 1e-2)
+
+
+@pytest.mark.parametrize("N,K", [(256, 256), (256, 128), (128, 256), (128, 128)])
+def test_wsgemm_epilogues(env, N, K):
+    """Weights-stationary decoder GEMM: plain + table, residual + LayerNorm(256), LayerNorm(64)+GELU, K|V^T split."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(10 + N + K)
+    P, T = 3, 4096
+    M = P * T
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    table = torch.randn(T, 128, generator=g).to(dev)
+    base = a.float() @ w.float().t() + bias
+    ref = base.clone(); ref[:, :128] += table.repeat(P, 1)
+    assert _close(ops.wsgemm(a, w, bias, table=table, table_cols=128), ref, 3e-2, 1e-2)
+    if N == 256:
+        lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
+        resid = _bf(torch.randn(T, 256, generator=g)).to(dev)
+        ref1 = F.layer_norm(base + resid.float().repeat(P, 1), (256,), lw, lb, eps=1e-5)
+        assert _close(ops.wsgemm(a, w, bias, resid=resid, resid_rows=T, ln_mode=1, ln_w=lw, ln_b=lb), ref1, 2e-2, 1e-2)
+        x = _bf(torch.randn(M, 256, generator=g)).to(dev)
+        ref1b = F.layer_norm(base + x.float(), (256,), lw, lb, eps=1e-5)
+        ops.wsgemm(a, w, bias, resid=x, ln_mode=1, ln_w=lw, ln_b=lb, out=x)                 # in-place stream update
+        assert _close(x, ref1b, 2e-2, 1e-2)
+        ref2 = F.gelu(F.layer_norm(base.reshape(M, 4, 64), (64,), lw[:64], lb[:64], eps=1e-6)).reshape(M, 256)
+        out2 = ops.wsgemm(a, w, bias, ln_mode=2, ln_w=lw[:64].contiguous(), ln_b=lb[:64].contiguous(), ln_eps=1e-6)
+        assert _close(out2, ref2, 2e-2, 1e-2)
+        k, vT = ops.wsgemm(a, w, bias, table=table, table_cols=128, kv_split_tokens=T)
+        assert _close(k, ref[:, :128], 3e-2, 1e-2)
+        assert _close(vT, ref[:, 128:].reshape(P, T, 128).permute(0, 2, 1), 3e-2, 1e-2)

@@ -143,6 +143,14 @@ def test_amg_initialize_generate_vs_oracle(ctx):
     cl = A.MaskData(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in state["crop_list"][0].items()})
     seg_ref = PR.amg_generate({"crop_list": [cl], "crop_boxes": state["crop_boxes"], "original_size": state["original_size"]})
     assert np.array_equal(seg, seg_ref)
+    # sync-free device generate == generate == oracle
+    lab, flag = amg.generate_device()
+    assert int(flag.item()) == 0 and np.array_equal(lab.cpu().numpy().astype("uint32"), seg)
+    seg_lo = amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5, box_nms_thresh=0.9)
+    cl2 = A.MaskData(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in state["crop_list"][0].items()})
+    seg_lo_ref = PR.amg_generate({"crop_list": [cl2], "crop_boxes": state["crop_boxes"], "original_size": state["original_size"]},
+                                 pred_iou_thresh=0.5, stability_score_thresh=0.5, box_nms_thresh=0.9)
+    assert seg_lo.max() > 0 and np.array_equal(seg_lo, seg_lo_ref)
     for mode in ("binary_mask", "rle"):
         recs = amg.generate(output_mode=mode, pred_iou_thresh=0.5, stability_score_thresh=0.5)
         assert isinstance(recs, list) and all("bbox" in r and "predicted_iou" in r for r in recs)
