@@ -238,6 +238,9 @@ int msam_paint_label_image_dev(const uint32_t* bits, const int32_t* order, const
 int msam_label_components(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
                           int32_t max_iters, int32_t* iters_done, void* stream);
 
+/* sizes[r] = number of pixels whose root is r (int32 [n], zeroed here), bg_count[0] = number of background pixels
+ * (roots[i] < 0): the `unique(..., return_counts=True)` of util.py:1837 keyed by root index. */
+int msam_component_sizes(const int32_t* roots, int32_t n, int32_t* sizes, int32_t* bg_count, void* stream);
 /* Fully asynchronous variant: `passes` union passes (one is complete for the lock-free union, a second one verifies),
  * changed_flag = flag of the last pass to be checked by the caller whenever convenient. */
 int msam_label_components_async(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,

@@ -58,85 +58,100 @@ __global__ void finalize_boxes_kernel(int* __restrict__ boxes, int N) {
     }
 }
 
-// grid (ceil(out_w/256), words_per_col, N); thread = column x, 32 rows of word yw
+// grid (ceil(out_w/256), N); thread = column x, loops over all 32-row words of its column (so a mask contributes
+// only ceil(W/256) x 7 atomics instead of one set per 32x256 patch - the atomics were the bottleneck)
 template <bool TWO_STAGE>
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ low_res, int in_h, int in_w, int out_h,
                                                           int out_w, float thr, float off, int* __restrict__ counts,
                                                           int* __restrict__ boxes, uint32_t* __restrict__ bits,
                                                           float* __restrict__ logits) {
-    const int x = blockIdx.x * 256 + threadIdx.x, yw = blockIdx.y, n = blockIdx.z;
+    __shared__ int red[4][7];
+    const int x = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     const int wpc = (out_h + 31) >> 5;
     const float* low = low_res + (long)n * 65536;
     const float hi_t = thr + off, lo_t = thr - off;
-    uint32_t word = 0;
     int c_hi = 0, c_lo = 0, c_m = 0, ymin = 0x7fffffff, ymax = -1;
-    if (!TWO_STAGE) {
-        if (x < out_w) {
-            // x4 fast path: the horizontal lerp of the 10 low-res rows under this 32-row word is shared by its 32
-            // pixels (same arithmetic as stage1(), so still bit-exact): pixel b uses rows c, c+1 with c = (b + 2) / 4
+    bool any = false;
+    if (x < out_w) {
+        if (!TWO_STAGE) {
+            // x4 fast path: the horizontal lerp of the 10 low-res rows under a 32-row word is shared by its 32 pixels
+            // (same arithmetic as stage1(), so still bit-exact): pixel b uses rows c, c+1 with c = (b + 2) / 4;
+            // vertical weights are compile-time constants: frac(src) in {.625,.875,.125,.375} by b % 4 (exactly what
+            // axis_weights computes in fp32), except the two clamped rows at the top of the image
             const Axis ax = axis_weights(x, 0.25f, 256);
-            const int rlo = yw * 8 - 1;
-            float t[10];
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                const int r = min(max(rlo + k, 0), 255);
-                t[k] = lerp_torch(ax.w0, low[r * 256 + ax.i0], ax.w1, low[r * 256 + ax.i1]);
-            }
-            // vertical weights of the x4 grid are compile-time constants: frac(src) in {.625,.875,.125,.375} by b % 4
-            // (exactly what axis_weights computes in fp32), except the two clamped rows at the top of the image
             const float W1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
-            const int nb = min(32, out_h - yw * 32);
+            for (int yw = 0; yw < wpc; ++yw) {
+                const int rlo = yw * 8 - 1;
+                float t[10];
 #pragma unroll
-            for (int b = 0; b < 32; ++b) {
-                float w1 = W1[b & 3];
-                if (b < 2 && yw == 0) w1 = 0.0f;
-                const float w0 = 1.0f - w1;
-                const float v = lerp_torch(w0, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
-                if (b < nb) {
-                    if (logits) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
-                    c_hi += v > hi_t; c_lo += v > lo_t;
-                    word |= (uint32_t)(v > thr) << b;
+                for (int k = 0; k < 10; ++k) {
+                    const int r = min(max(rlo + k, 0), 255);
+                    t[k] = lerp_torch(ax.w0, low[r * 256 + ax.i0], ax.w1, low[r * 256 + ax.i1]);
                 }
+                const int nb = min(32, out_h - yw * 32);
+                uint32_t word = 0;
+#pragma unroll
+                for (int b = 0; b < 32; ++b) {
+                    float w1 = W1[b & 3];
+                    if (b < 2 && yw == 0) w1 = 0.0f;
+                    const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
+                    if (b < nb) {
+                        if (logits) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
+                        c_hi += v > hi_t; c_lo += v > lo_t;
+                        word |= (uint32_t)(v > thr) << b;
+                    }
+                }
+                if (word) {
+                    c_m += __popc(word); any = true;
+                    ymin = min(ymin, yw * 32 + __ffs(word) - 1); ymax = yw * 32 + 31 - __clz(word);
+                }
+                bits[((long)n * wpc + yw) * out_w + x] = word;
             }
-            if (word) { c_m = __popc(word); ymin = yw * 32 + __ffs(word) - 1; ymax = yw * 32 + 31 - __clz(word); }
-            bits[((long)n * wpc + yw) * out_w + x] = word;
-        }
-    } else if (x < out_w) {
-        Axis ax2; float sx = 0.f, sy = 0.f;
-        if (TWO_STAGE) { sx = (float)in_w / (float)out_w; sy = (float)in_h / (float)out_h; ax2 = axis_weights(x, sx, in_w); }
-        for (int b = 0; b < 32; ++b) {
-            const int y = yw * 32 + b;
-            if (y >= out_h) break;
-            float v;
-            if (TWO_STAGE) {
-                const Axis ay2 = axis_weights(y, sy, in_h);
-                const float t0 = lerp_torch(ax2.w0, stage1(low, ay2.i0, ax2.i0), ax2.w1, stage1(low, ay2.i0, ax2.i1));
-                const float t1 = lerp_torch(ax2.w0, stage1(low, ay2.i1, ax2.i0), ax2.w1, stage1(low, ay2.i1, ax2.i1));
-                v = lerp_torch(ay2.w0, t0, ay2.w1, t1);
-            } else {
-                v = stage1(low, y, x);
+        } else {
+            const float sx = (float)in_w / (float)out_w, sy = (float)in_h / (float)out_h;
+            const Axis ax2 = axis_weights(x, sx, in_w);
+            for (int yw = 0; yw < wpc; ++yw) {
+                uint32_t word = 0;
+                for (int b = 0; b < 32; ++b) {
+                    const int y = yw * 32 + b;
+                    if (y >= out_h) break;
+                    const Axis ay2 = axis_weights(y, sy, in_h);
+                    const float t0 = lerp_torch(ax2.w0, stage1(low, ay2.i0, ax2.i0), ax2.w1, stage1(low, ay2.i0, ax2.i1));
+                    const float t1 = lerp_torch(ax2.w0, stage1(low, ay2.i1, ax2.i0), ax2.w1, stage1(low, ay2.i1, ax2.i1));
+                    const float v = lerp_torch(ay2.w0, t0, ay2.w1, t1);
+                    if (logits) logits[((long)n * out_h + y) * out_w + x] = v;
+                    c_hi += v > hi_t; c_lo += v > lo_t;
+                    if (v > thr) { word |= 1u << b; ++c_m; any = true; ymin = min(ymin, y); ymax = y; }
+                }
+                bits[((long)n * wpc + yw) * out_w + x] = word;
             }
-            if (logits) logits[((long)n * out_h + y) * out_w + x] = v;
-            c_hi += v > hi_t; c_lo += v > lo_t;
-            if (v > thr) { word |= 1u << b; ++c_m; ymin = min(ymin, y); ymax = y; }
         }
-        bits[((long)n * wpc + yw) * out_w + x] = word;
     }
-    // block reduction -> one atomic per statistic per workgroup
-    int xmin = word ? x : 0x7fffffff, xmax = word ? x : -1;
+    int xmin = any ? x : 0x7fffffff, xmax = any ? x : -1;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
         c_hi += __shfl_xor(c_hi, s); c_lo += __shfl_xor(c_lo, s); c_m += __shfl_xor(c_m, s);
         ymin = min(ymin, __shfl_xor(ymin, s)); ymax = max(ymax, __shfl_xor(ymax, s));
         xmin = min(xmin, __shfl_xor(xmin, s)); xmax = max(xmax, __shfl_xor(xmax, s));
     }
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        if (c_hi) atomicAdd(&counts[n * 3], c_hi);
-        if (c_lo) atomicAdd(&counts[n * 3 + 1], c_lo);
-        if (c_m) {
-            atomicAdd(&counts[n * 3 + 2], c_m);
-            atomicMin(&boxes[n * 4], xmin); atomicMin(&boxes[n * 4 + 1], ymin);
-            atomicMax(&boxes[n * 4 + 2], xmax); atomicMax(&boxes[n * 4 + 3], ymax);
+        red[wave][0] = c_hi; red[wave][1] = c_lo; red[wave][2] = c_m; red[wave][3] = xmin; red[wave][4] = ymin;
+        red[wave][5] = xmax; red[wave][6] = ymax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int hi = 0, lo = 0, m = 0, x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+        for (int w = 0; w < 4; ++w) {
+            hi += red[w][0]; lo += red[w][1]; m += red[w][2];
+            x0 = min(x0, red[w][3]); y0 = min(y0, red[w][4]); x1 = max(x1, red[w][5]); y1 = max(y1, red[w][6]);
+        }
+        if (hi) atomicAdd(&counts[n * 3], hi);
+        if (lo) atomicAdd(&counts[n * 3 + 1], lo);
+        if (m) {
+            atomicAdd(&counts[n * 3 + 2], m);
+            atomicMin(&boxes[n * 4], x0); atomicMin(&boxes[n * 4 + 1], y0);
+            atomicMax(&boxes[n * 4 + 2], x1); atomicMax(&boxes[n * 4 + 3], y1);
         }
     }
 }
@@ -255,7 +270,7 @@ extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t i
     if (N > 65535) { msam_set_error("msam_postprocess_masks: at most 65535 masks per call"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, s, counts, boxes, N);
-    dim3 grid((out_w + 255) / 256, (out_h + 31) / 32, N);
+    dim3 grid((out_w + 255) / 256, N);
     if (in_h == out_h && in_w == out_w)
         hipLaunchKernelGGL(postprocess_kernel<false>, grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, out_w, thr, off,
                            counts, boxes, bits, logits);

@@ -81,6 +81,45 @@ __global__ __launch_bounds__(256) void cc_compress_kernel(int n, int* L) {
     if (i < n && L[i] >= 0) L[i] = cc_find(L, i);
 }
 
+// Component sizes keyed by root index: sizes[root] += 1 for every foreground pixel.  A plain scatter-add puts hundreds
+// of thousands of atomics on the few addresses of the big components; here every workgroup first aggregates its 4096
+// pixels in an LDS open-addressing table (runs of equal roots are pre-summed per thread), then flushes one global
+// atomic per distinct root.
+__global__ __launch_bounds__(256) void cc_sizes_kernel(const int* __restrict__ roots, int n, int* __restrict__ sizes,
+                                                       int* __restrict__ bg_count) {
+    constexpr int TAB = 512, PER = 16;
+    __shared__ int keys[TAB], vals[TAB];
+    __shared__ int bg;
+    for (int i = threadIdx.x; i < TAB; i += 256) { keys[i] = -1; vals[i] = 0; }
+    if (threadIdx.x == 0) bg = 0;
+    __syncthreads();
+    const int base = (blockIdx.x * 256 + threadIdx.x) * PER;
+    int cur = -2, cnt = 0, nbg = 0;
+    auto flush = [&](int key, int c) {
+        if (key < 0 || c == 0) return;
+        unsigned h = ((unsigned)key * 2654435761u) >> 23;          // 9 bits
+        for (int probe = 0; probe < 16; ++probe, h = (h + 1) & (TAB - 1)) {
+            const int prev = atomicCAS(&keys[h], -1, key);
+            if (prev == -1 || prev == key) { atomicAdd(&vals[h], c); return; }
+        }
+        atomicAdd(&sizes[key], c);                                 // table crowded: straight to global memory
+    };
+    for (int k = 0; k < PER; ++k) {
+        const int i = base + k;
+        if (i >= n) break;
+        const int r = roots[i];
+        if (r < 0) { ++nbg; continue; }
+        if (r == cur) ++cnt;
+        else { flush(cur, cnt); cur = r; cnt = 1; }
+    }
+    flush(cur, cnt);
+    if (nbg) atomicAdd(&bg, nbg);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TAB; i += 256)
+        if (keys[i] >= 0) atomicAdd(&sizes[keys[i]], vals[i]);
+    if (threadIdx.x == 0 && bg) atomicAdd(bg_count, bg);
+}
+
 // ---- greedy box NMS (torchvision.ops.nms semantics) on score-sorted boxes: suppression bit matrix + serial sweep
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, int K, float thr,
                                                       unsigned long long* __restrict__ mask) {
@@ -171,6 +210,17 @@ extern "C" int msam_paint_label_image_dev(const uint32_t* bits, const int32_t* o
     hipLaunchKernelGGL(paint_kernel, dim3((W + 255) / 256, (H + 31) / 32), dim3(256), 0, (hipStream_t)stream, bits, order, 0,
                        k_dev, H, W, label);
     return msam_check_launch("msam_paint_label_image_dev");
+}
+
+extern "C" int msam_component_sizes(const int32_t* roots, int32_t n, int32_t* sizes, int32_t* bg_count, void* stream) {
+    if (!roots || !sizes || !bg_count || n <= 0) { msam_set_error("msam_component_sizes: bad arguments"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sizes, 0, (size_t)n * sizeof(int), s) != hipSuccess || hipMemsetAsync(bg_count, 0, sizeof(int), s) != hipSuccess) {
+        msam_set_error("msam_component_sizes: memset failed");
+        return 2;
+    }
+    hipLaunchKernelGGL(cc_sizes_kernel, dim3((n + 4095) / 4096), dim3(256), 0, s, roots, n, sizes, bg_count);
+    return msam_check_launch("msam_component_sizes");
 }
 
 // Fixed number of union passes without host synchronisation; changed_flag holds the flag of the LAST pass (0 = converged).

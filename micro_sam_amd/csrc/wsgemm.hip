@@ -16,7 +16,7 @@ void msam_profile_mark(void* stream, int begin, double flops);
 
 namespace {
 
-constexpr int WM = 64;          // rows per tile
+constexpr int WM = 32;          // rows per tile (small tiles + 2-3 workgroups per CU: the kernel is HBM / latency bound)
 constexpr int NWAVES = 8;
 
 struct WsEpi {
@@ -31,11 +31,12 @@ struct WsEpi {
 MSAM_DEVINL int swz16(int row) { return (row & 15) ^ (((row + 4) >> 3) & 1); }
 
 template <int N, int K>
-__global__ __launch_bounds__(512) void wsgemm_kernel(const u16* __restrict__ A, const u16* __restrict__ W, int M, WsEpi e) {
+__global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_kernel(const u16* __restrict__ A, const u16* __restrict__ W, int M, WsEpi e) {
     constexpr int NT = N / NWAVES / 16;          // n-tiles per wave (1 or 2)
     constexpr int KC = K / 32;                   // 32-deep k chunks
     constexpr int CPR = K / 8;                   // 16-byte chunks per A row
-    constexpr int APT = WM * CPR / 512;          // A chunks staged per thread (2 or 4)
+    constexpr int APT = WM * CPR / 512;          // A chunks staged per thread (1 or 2)
+    constexpr int MT = WM / 16;                  // m-tiles per wave
     extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
     uint4* ldsA = dyn_lds;                                        // [2][WM * CPR]
     float* ldsC = (float*)(dyn_lds + 2 * WM * CPR);               // [WM][N] fp32
@@ -51,20 +52,20 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(const u16* __restrict__ A, 
 
     const int ntiles = M / WM;
     // staging map: chunk id q = p*512 + tid -> (row = q / CPR, c = q % CPR)
-    uint4 ra0, ra1, ra2, ra3;
-    (void)ra2; (void)ra3;
+    uint4 ra0, ra1;
+    (void)ra1;
 #define WS_SRC(p_, tile_) (A + ((long)(tile_) * WM + ((p_) * 512 + tid) / CPR) * K + (((p_) * 512 + tid) % CPR) * 8)
 #define WS_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * 512 + tid) / CPR) * CPR + \
                               ((((p_) * 512 + tid) % CPR) ^ swz16(((p_) * 512 + tid) / CPR))]
 #define WS_LOAD(tile_)                                                                    \
     do {                                                                                  \
-        ra0 = *(const uint4*)WS_SRC(0, tile_); ra1 = *(const uint4*)WS_SRC(1, tile_);     \
-        if constexpr (APT == 4) { ra2 = *(const uint4*)WS_SRC(2, tile_); ra3 = *(const uint4*)WS_SRC(3, tile_); } \
+        ra0 = *(const uint4*)WS_SRC(0, tile_);                                            \
+        if constexpr (APT == 2) { ra1 = *(const uint4*)WS_SRC(1, tile_); }                \
     } while (0)
 #define WS_STORE(buf_)                                                                    \
     do {                                                                                  \
-        WS_DST(0, buf_) = ra0; WS_DST(1, buf_) = ra1;                                     \
-        if constexpr (APT == 4) { WS_DST(2, buf_) = ra2; WS_DST(3, buf_) = ra3; }         \
+        WS_DST(0, buf_) = ra0;                                                            \
+        if constexpr (APT == 2) { WS_DST(1, buf_) = ra1; }                                \
     } while (0)
 
     int tile = blockIdx.x;
@@ -76,28 +77,43 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(const u16* __restrict__ A, 
     for (; tile < ntiles; tile += gridDim.x) {
         const int next = tile + gridDim.x;
         if (next < ntiles) WS_LOAD(next);                         // in flight during the MFMA phase
-        f32x4_t acc[4][NT];
+        f32x4_t acc[MT][NT];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const uint4* la = ldsA + buf * WM * CPR;
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
-            uint4 a[4];
+            uint4 a[MT];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = 0; mi < MT; ++mi) {
                 const int row = mi * 16 + fr;
                 a[mi] = la[row * CPR + ((kc * 4 + fg) ^ swz16(row))];
             }
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma16(a[mi], bfr[ni][kc], acc[mi][ni]);
         }
         // ---- fp32 tile -> LDS (row-complete epilogue); ldsC is private to the epilogue, ldsA[buf^1] gets the next tile
+        // epilogue operands (positional table, residual rows) are requested BEFORE the barrier so that their HBM
+        // latency overlaps the LDS round trip of the accumulators
+        const long row0 = (long)tile * WM;
+        constexpr int LPR = N / 4;                 // lanes per row (64 for N = 256, 32 for N = 128)
+        constexpr int RPP = 64 / LPR;              // rows per wave pass (1 or 2)
+        constexpr int NPASS = WM / (NWAVES * RPP); // 4 (N = 256) or 2 (N = 128)
+        const int col = (lane % LPR) * 4;
+        const bool use_table = e.table && col < e.table_cols;
+        uint2 res[NPASS];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const long row = row0 + (pass * NWAVES + wave) * RPP + lane / LPR;
+            res[pass] = e.resid ? *(const uint2*)(e.resid + (e.resid_rows ? (row % e.resid_rows) : row) * e.ldr + col)
+                                : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -106,29 +122,20 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(const u16* __restrict__ A, 
         if (next < ntiles) WS_STORE(buf ^ 1);
         __syncthreads();
 
-        const long row0 = (long)tile * WM;
-        constexpr int LPR = N / 4;                 // lanes per row (64 for N = 256, 32 for N = 128)
-        constexpr int RPP = 64 / LPR;              // rows per wave pass (1 or 2)
-        const int col = (lane % LPR) * 4;
         float bias4[4] = {0.f, 0.f, 0.f, 0.f};
         if (e.bias) { const float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
-        const bool use_table = e.table && col < e.table_cols;
 #pragma unroll
-        for (int pass = 0; pass < WM / (NWAVES * RPP); ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int lr = (pass * NWAVES + wave) * RPP + lane / LPR;
             const long row = row0 + lr;
             const float4 c = *(const float4*)(ldsC + lr * N + col);
             float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
-            if (use_table) {
+            if (use_table) {       // 2 MB table, L2 resident
                 const float4 t = *(const float4*)(e.table + (row % e.table_rows) * e.table_ld + col);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
-            if (e.resid) {
-                const long rr = e.resid_rows ? (row % e.resid_rows) : row;
-                const uint2 t = *(const uint2*)(e.resid + rr * e.ldr + col);
-                v[0] += bf2f((u16)(t.x & 0xffff)); v[1] += bf2f((u16)(t.x >> 16));
-                v[2] += bf2f((u16)(t.y & 0xffff)); v[3] += bf2f((u16)(t.y >> 16));
-            }
+            v[0] += bf2f((u16)(res[pass].x & 0xffff)); v[1] += bf2f((u16)(res[pass].x >> 16));
+            v[2] += bf2f((u16)(res[pass].y & 0xffff)); v[3] += bf2f((u16)(res[pass].y >> 16));
             if (N == 256 && e.ln_mode) {
                 const float s = (v[0] + v[1]) + (v[2] + v[3]);
                 const float inv_n = e.ln_mode == 1 ? (1.0f / 256.0f) : (1.0f / 64.0f);
@@ -155,17 +162,14 @@ __global__ __launch_bounds__(512) void wsgemm_kernel(const u16* __restrict__ A, 
         }
         if (N == 256 && e.kv_split) {
             __syncthreads();
-            // V^T[b][d][t]: thread -> (d = tid & 127, 16-row group g = tid >> 7): 16 tokens = 32 contiguous bytes
+            // V^T[b][d][t]: thread -> (d = tid & 127, 8-row group g = tid >> 7): 8 tokens = 16 contiguous bytes
             const int d = tid & 127, g = tid >> 7;
-            const long b = row0 / e.tokens, t0 = row0 - b * e.tokens + g * 16;
-            const float* src = ldsC + (g * 16) * N + 128 + d;
-            uint4 p0, p1;
+            const long b = row0 / e.tokens, t0 = row0 - b * e.tokens + g * 8;
+            const float* src = ldsC + (g * 8) * N + 128 + d;
+            uint4 p0;
             p0.x = pack2bf(src[0 * N], src[1 * N]); p0.y = pack2bf(src[2 * N], src[3 * N]);
             p0.z = pack2bf(src[4 * N], src[5 * N]); p0.w = pack2bf(src[6 * N], src[7 * N]);
-            p1.x = pack2bf(src[8 * N], src[9 * N]); p1.y = pack2bf(src[10 * N], src[11 * N]);
-            p1.z = pack2bf(src[12 * N], src[13 * N]); p1.w = pack2bf(src[14 * N], src[15 * N]);
-            u16* dst = e.vT_out + (b * 128 + d) * e.tokens + t0;
-            *(uint4*)dst = p0; *(uint4*)(dst + 8) = p1;
+            *(uint4*)(e.vT_out + (b * 128 + d) * e.tokens + t0) = p0;
         }
         __syncthreads();        // ldsC free again; next tile's A (stored above) visible
         buf ^= 1;
@@ -182,7 +186,8 @@ int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
         attr_set = true;
     }
     const int ntiles = M / WM;
-    const int grid = ntiles < 256 ? ntiles : 256;          // one persistent workgroup per CU
+    const int per_cu = (K == 256 && N == 256) ? 2 : 3;      // resident workgroups per CU (LDS / VGPR budget)
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
     msam_profile_mark(s, 1, 2.0 * M * (double)N * K);
     hipLaunchKernelGGL((wsgemm_kernel<N, K>), dim3(grid), dim3(512), LDS_BYTES, s, A, W, M, e);
     msam_profile_mark(s, 0, 0.0);
@@ -193,8 +198,8 @@ int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
 
 extern "C" int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream) {
     if (!p || !p->A || !p->W) { msam_set_error("msam_wsgemm_bf16: null operand"); return 1; }
-    if (p->M <= 0 || p->M % WM) { msam_set_error("msam_wsgemm_bf16: M must be a positive multiple of 64"); return 1; }
-    if (p->kv_split && (p->N != 256 || !p->k_out || !p->vT_out || p->tokens % WM || p->M % p->tokens || p->ln_mode)) {
+    if (p->M <= 0 || p->M % 64) { msam_set_error("msam_wsgemm_bf16: M must be a positive multiple of 64"); return 1; }
+    if (p->kv_split && (p->N != 256 || !p->k_out || !p->vT_out || p->tokens % 64 || p->M % p->tokens || p->ln_mode)) {
         msam_set_error("msam_wsgemm_bf16: bad kv-split arguments");
         return 1;
     }
@@ -205,7 +210,7 @@ extern "C" int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream) {
     e.table_ld = p->table_ld; e.resid = (const u16*)p->resid; e.resid_rows = p->resid_rows; e.ldr = p->ldr;
     e.ln_w = p->ln_w; e.ln_b = p->ln_b; e.ln_eps = p->ln_eps; e.ln_mode = p->ln_mode;
     e.out = (u16*)p->out; e.ldc = p->ldc; e.kv_split = p->kv_split; e.k_out = (u16*)p->k_out; e.vT_out = (u16*)p->vT_out;
-    e.tokens = p->tokens > 0 ? p->tokens : WM;
+    e.tokens = p->tokens > 0 ? p->tokens : 64;
     hipStream_t s = (hipStream_t)stream;
     const u16* A = (const u16*)p->A; const u16* W = (const u16*)p->W;
     if (p->N == 256 && p->K == 256) return launch<256, 256>(A, W, p->M, e, s);

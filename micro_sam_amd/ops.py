@@ -297,3 +297,13 @@ def label_components_async(seg: torch.Tensor, passes: int = 2):
     _lib.check(_lib.load().msam_label_components_async(seg.data_ptr(), h, w, roots.data_ptr(), flag.data_ptr(), passes,
                                                        _lib.stream_ptr()), "msam_label_components_async")
     return roots, flag
+
+
+def component_sizes(roots: torch.Tensor):
+    """(sizes int32 [n] keyed by root index, bg_count int32[1]) for roots int32 [n] (-1 = background)."""
+    n = roots.numel()
+    sizes = torch.empty((n,), dtype=torch.int32, device=roots.device)
+    bg = torch.empty((1,), dtype=torch.int32, device=roots.device)
+    _lib.check(_lib.load().msam_component_sizes(roots.data_ptr(), n, sizes.data_ptr(), bg.data_ptr(), _lib.stream_ptr()),
+               "msam_component_sizes")
+    return sizes, bg

@@ -396,13 +396,13 @@ def masks_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, keep: 
     fg = roots >= 0
     safe_roots = roots.clamp(min=0)
     # component sizes keyed by root pixel index (no compaction): sizes[r] for roots, 0 elsewhere
-    sizes = torch.zeros(h * w, dtype=torch.int64, device=dev)
-    sizes.scatter_add_(0, safe_roots, fg.to(torch.int64))
+    sizes32, bg32 = ops.component_sizes(roots32)
+    sizes = sizes32.to(torch.int64)
     idx = torch.arange(h * w, device=dev)
     is_root = fg & (roots == idx)
     keep_root = is_root & (sizes >= min_object_size)
     if with_background:
-        bg_size = (~fg).sum()
+        bg_size = bg32[0].to(torch.int64)
         best = torch.argmax(sizes)                          # first maximum = smallest root index = smallest component id
         drop_component = sizes[best] > bg_size              # label 0 wins ties (it is the smallest id)
         keep_root = keep_root & ~((idx == best) & drop_component)
