@@ -52,31 +52,34 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
 
     const int ntiles = M / WM;
     // staging map: chunk id q = p*512 + tid -> (row = q / CPR, c = q % CPR)
-    uint4 ra0, ra1;
-    (void)ra1;
+    uint4 ra0, ra1, rb0, rb1;       // two register sets: tiles are requested TWO iterations ahead (HBM latency under load
+    (void)ra1; (void)rb1;           // is several microseconds; one workgroup per CU has nothing else to hide it with)
 #define WS_SRC(p_, tile_) (A + ((long)(tile_) * WM + ((p_) * 512 + tid) / CPR) * K + (((p_) * 512 + tid) % CPR) * 8)
 #define WS_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * 512 + tid) / CPR) * CPR + \
                               ((((p_) * 512 + tid) % CPR) ^ swz16(((p_) * 512 + tid) / CPR))]
-#define WS_LOAD(tile_)                                                                    \
+#define WS_LOAD(r0_, r1_, tile_)                                                          \
     do {                                                                                  \
-        ra0 = *(const uint4*)WS_SRC(0, tile_);                                            \
-        if constexpr (APT == 2) { ra1 = *(const uint4*)WS_SRC(1, tile_); }                \
+        r0_ = *(const uint4*)WS_SRC(0, tile_);                                            \
+        if constexpr (APT == 2) { r1_ = *(const uint4*)WS_SRC(1, tile_); }                \
     } while (0)
-#define WS_STORE(buf_)                                                                    \
+#define WS_STORE(r0_, r1_, buf_)                                                          \
     do {                                                                                  \
-        WS_DST(0, buf_) = ra0;                                                            \
-        if constexpr (APT == 2) { WS_DST(1, buf_) = ra1; }                                \
+        WS_DST(0, buf_) = r0_;                                                            \
+        if constexpr (APT == 2) { WS_DST(1, buf_) = r1_; }                                \
     } while (0)
 
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
-    WS_LOAD(tile);
-    WS_STORE(0);
+    WS_LOAD(ra0, ra1, tile);
+    WS_STORE(ra0, ra1, 0);
+    if (tile + (int)gridDim.x < ntiles) WS_LOAD(ra0, ra1, tile + gridDim.x);     // pending set of the first iteration
     __syncthreads();
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) WS_LOAD(next);                         // in flight during the MFMA phase
+    // one iteration: `pend` holds tile+stride (requested one iteration ago, stored to LDS at the end of this one),
+    // `fresh` receives tile+2*stride now
+    auto iteration = [&](uint4& pend0, uint4& pend1, uint4& fresh0, uint4& fresh1) {
+        const int next = tile + gridDim.x, next2 = tile + 2 * gridDim.x;
+        if (next2 < ntiles) WS_LOAD(fresh0, fresh1, next2);
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     ldsC[(mi * 16 + fg * 4 + r) * N + wave * (NT * 16) + ni * 16 + fr] = acc[mi][ni][r];
-        if (next < ntiles) WS_STORE(buf ^ 1);
+        if (next < ntiles) WS_STORE(pend0, pend1, buf ^ 1);
         __syncthreads();
 
         float bias4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -173,6 +176,13 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
         }
         __syncthreads();        // ldsC free again; next tile's A (stored above) visible
         buf ^= 1;
+    };
+    while (tile < ntiles) {
+        iteration(ra0, ra1, rb0, rb1);
+        tile += gridDim.x;
+        if (tile >= ntiles) break;
+        iteration(rb0, rb1, ra0, ra1);
+        tile += gridDim.x;
     }
 }
 
