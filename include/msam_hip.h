@@ -69,7 +69,8 @@ int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 /* Weights-stationary streaming GEMM for the decoder's image-token stream (M = P*4096 rows, N,K in {128,256}):
  * out = epi(A[M,K] * W[N,K]^T), A / W / out bf16, contiguous rows (lda = K, ldw = K).  Same epilogue vocabulary as
  * msam_gemm_bf16 (bias, row-indexed table on the first table_cols columns, bf16 residual, ln_mode 1/2 for N == 256),
- * or kv_split (N == 256): k_out <- columns 0..127 as [M,128], vT_out <- columns 128..255 as [M/tokens,128,tokens]. */
+ * or kv_split: N == 256: k_out <- columns 0..127 as [M,128], vT_out <- columns 128..255 as [M/tokens,128,tokens];
+ * N == 128: all columns to vT_out transposed (k_out unused).  ln_mode 2 is also available for N == 128. */
 typedef struct {
     const void* A; const void* W; int32_t M, N, K;
     const float* bias;

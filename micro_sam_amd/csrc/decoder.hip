@@ -400,6 +400,16 @@ int wsgemm(const Ctx& cx, const void* A, const void* W, int M, int N, int K, con
     return msam_wsgemm_bf16(&g, cx.s);
 }
 
+// K | V^T projection of the per-prompt stream as two N = 128 launches (k with the positional table, v transposed)
+int wsgemm_kv(const Ctx& cx, const void* x, const u16* wkv, const float* bkv, const float* pek, int rows, void* k_out,
+              void* vT_out) {
+    if (int e = wsgemm(cx, x, wkv, rows, CI, C, bkv, k_out, pek, CI)) return e;
+    msam_wsgemm_t g{};
+    g.A = x; g.W = wkv + (long)CI * C; g.M = rows; g.N = CI; g.K = C; g.bias = bkv + CI;
+    g.kv_split = 1; g.vT_out = vT_out; g.tokens = T;
+    return msam_wsgemm_bf16(&g, cx.s);
+}
+
 struct Consts {     // layout of the `consts` buffer
     float* pos_f32; u16* pos_bf16; float* pe_k[3]; float* pe_q[2]; u16* wkv[3]; float* bkv[3];
 };
@@ -572,8 +582,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         if (li == 0) {
             hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
         } else {
-            CHECK(wsgemm(cx, w.keys, c.wkv[1], (int)R, 256, C, c.bkv[1], nullptr, c.pe_k[1], CI, nullptr, 0, 0, nullptr, nullptr,
-                         0.f, w.kimg, w.vT));
+            CHECK(wsgemm_kv(cx, w.keys, c.wkv[1], c.bkv[1], c.pe_k[1], (int)R, w.kimg, w.vT));
             hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
         }
         CHECK(msam_check_launch("t2i_attn"));
@@ -608,8 +617,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     // final token -> image attention
     ADD_CAST(w.queries, w.qpe, w.a);
     CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_BF16, CI));
-    CHECK(wsgemm(cx, w.keys, c.wkv[2], (int)R, 256, C, c.bkv[2], nullptr, c.pe_k[2], CI, nullptr, 0, 0, nullptr, nullptr, 0.f,
-                 w.kimg, w.vT));
+    CHECK(wsgemm_kv(cx, w.keys, c.wkv[2], c.bkv[2], c.pe_k[2], (int)R, w.kimg, w.vT));
     hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
     CHECK(msam_check_launch("t2i_attn_final"));
     CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
@@ -632,8 +640,13 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     CHECK(msam_check_launch("gather_iou"));
 
     // up-scaling: ConvT1 as GEMM with fused (bias, LayerNorm2d over 64 channels, GELU) epilogue -> fused ConvT2
-    CHECK(wsgemm(cx, w.keys, dec->up1_w, (int)R, C, C, dec->up1_b, w.up1, nullptr, 0, nullptr, 0, 2, dec->up_ln_w, dec->up_ln_b,
-                 1e-6f));
+    for (int half = 0; half < 2; ++half) {      // two N = 128 launches (two 64-channel LayerNorm groups each)
+        msam_wsgemm_t g{};
+        g.A = w.keys; g.W = (const u16*)dec->up1_w + (long)half * 128 * C; g.M = (int)R; g.N = 128; g.K = C;
+        g.bias = dec->up1_b + half * 128; g.ln_mode = 2; g.ln_w = dec->up_ln_w; g.ln_b = dec->up_ln_b; g.ln_eps = 1e-6f;
+        g.out = w.up1 + half * 128; g.ldc = C;
+        CHECK(msam_wsgemm_bf16(&g, cx.s));
+    }
     {
         const long rows = R * 4;
         long tiles = rows / 128;

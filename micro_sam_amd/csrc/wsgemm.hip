@@ -17,7 +17,6 @@ void msam_profile_mark(void* stream, int begin, double flops);
 namespace {
 
 constexpr int WM = 32;          // rows per tile (small tiles + 2-3 workgroups per CU: the kernel is HBM / latency bound)
-constexpr int NWAVES = 8;
 
 struct WsEpi {
     const float* bias; const float* table; int table_rows, table_cols; long table_ld;
@@ -30,12 +29,16 @@ struct WsEpi {
 // 4-bit chunk swizzle: the 16 rows of a ds_read_b128 service group hit 16 distinct 16-byte slots
 MSAM_DEVINL int swz16(int row) { return (row & 15) ^ (((row + 4) >> 3) & 1); }
 
+// 8 waves; N = 128 variants keep <= 128 VGPRs so that two workgroups share a CU and overlap their MFMA / epilogue
+// phases (the decoder therefore issues its N = 256, K = 256 products as two N = 128 launches)
 template <int N, int K>
-__global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_kernel(const u16* __restrict__ A, const u16* __restrict__ W, int M, WsEpi e) {
+__global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_kernel(const u16* __restrict__ A, const u16* __restrict__ W, int M, WsEpi e) {
+    constexpr int NWAVES = 8;
+    constexpr int NTHR = NWAVES * 64;
     constexpr int NT = N / NWAVES / 16;          // n-tiles per wave (1 or 2)
     constexpr int KC = K / 32;                   // 32-deep k chunks
     constexpr int CPR = K / 8;                   // 16-byte chunks per A row
-    constexpr int APT = WM * CPR / 512;          // A chunks staged per thread (1 or 2)
+    constexpr int APT = WM * CPR / NTHR;         // A chunks staged per thread (1 or 2)
     constexpr int MT = WM / 16;                  // m-tiles per wave
     extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
     uint4* ldsA = dyn_lds;                                        // [2][WM * CPR]
@@ -54,9 +57,9 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
     // staging map: chunk id q = p*512 + tid -> (row = q / CPR, c = q % CPR)
     uint4 ra0, ra1, rb0, rb1;       // two register sets: tiles are requested TWO iterations ahead (HBM latency under load
     (void)ra1; (void)rb1;           // is several microseconds; one workgroup per CU has nothing else to hide it with)
-#define WS_SRC(p_, tile_) (A + ((long)(tile_) * WM + ((p_) * 512 + tid) / CPR) * K + (((p_) * 512 + tid) % CPR) * 8)
-#define WS_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * 512 + tid) / CPR) * CPR + \
-                              ((((p_) * 512 + tid) % CPR) ^ swz16(((p_) * 512 + tid) / CPR))]
+#define WS_SRC(p_, tile_) (A + ((long)(tile_) * WM + ((p_) * NTHR + tid) / CPR) * K + (((p_) * NTHR + tid) % CPR) * 8)
+#define WS_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * NTHR + tid) / CPR) * CPR + \
+                              ((((p_) * NTHR + tid) % CPR) ^ swz16(((p_) * NTHR + tid) / CPR))]
 #define WS_LOAD(r0_, r1_, tile_)                                                          \
     do {                                                                                  \
         r0_ = *(const uint4*)WS_SRC(0, tile_);                                            \
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
             }
             v[0] += bf2f((u16)(res[pass].x & 0xffff)); v[1] += bf2f((u16)(res[pass].x >> 16));
             v[2] += bf2f((u16)(res[pass].y & 0xffff)); v[3] += bf2f((u16)(res[pass].y >> 16));
-            if (N == 256 && e.ln_mode) {
+            if ((N == 256 && e.ln_mode) || (N == 128 && e.ln_mode == 2)) {
                 const float s = (v[0] + v[1]) + (v[2] + v[3]);
                 const float inv_n = e.ln_mode == 1 ? (1.0f / 256.0f) : (1.0f / 64.0f);
                 const float mean = (e.ln_mode == 1 ? wave_sum64(s) : wave_sum_xor16(s)) * inv_n;
@@ -153,7 +156,9 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
                 v[2] = d2 * rstd * w4.z + b4.z; v[3] = d3 * rstd * w4.w + b4.w;
                 if (e.ln_mode == 2) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
             }
-            if (!e.kv_split) {
+            if (N == 128 && e.kv_split) {
+                *(float4*)(ldsC + lr * N + col) = make_float4(v[0], v[1], v[2], v[3]);     // all columns go out transposed
+            } else if (!e.kv_split) {
                 uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
                 *(uint2*)(e.out + row * e.ldc + col) = pk;
             } else if (col < 128) {
@@ -163,16 +168,18 @@ __global__ __launch_bounds__(512, (K == 256 && N == 256) ? 2 : 4) void wsgemm_ke
                 *(float4*)(ldsC + lr * N + col) = make_float4(v[0], v[1], v[2], v[3]);     // finished v values back
             }
         }
-        if (N == 256 && e.kv_split) {
+        if (e.kv_split) {
             __syncthreads();
-            // V^T[b][d][t]: thread -> (d = tid & 127, 8-row group g = tid >> 7): 8 tokens = 16 contiguous bytes
+            // V^T[b][d][t]: thread -> (d = tid & 127, 8-row group g = tid >> 7 < 4): 8 tokens = 16 contiguous bytes
             const int d = tid & 127, g = tid >> 7;
-            const long b = row0 / e.tokens, t0 = row0 - b * e.tokens + g * 8;
-            const float* src = ldsC + (g * 8) * N + 128 + d;
-            uint4 p0;
-            p0.x = pack2bf(src[0 * N], src[1 * N]); p0.y = pack2bf(src[2 * N], src[3 * N]);
-            p0.z = pack2bf(src[4 * N], src[5 * N]); p0.w = pack2bf(src[6 * N], src[7 * N]);
-            *(uint4*)(e.vT_out + (b * 128 + d) * e.tokens + t0) = p0;
+            if (g < WM / 8) {
+                const long b = row0 / e.tokens, t0 = row0 - b * e.tokens + g * 8;
+                const float* src = ldsC + (g * 8) * N + (N == 256 ? 128 : 0) + d;
+                uint4 p0;
+                p0.x = pack2bf(src[0 * N], src[1 * N]); p0.y = pack2bf(src[2 * N], src[3 * N]);
+                p0.z = pack2bf(src[4 * N], src[5 * N]); p0.w = pack2bf(src[6 * N], src[7 * N]);
+                *(uint4*)(e.vT_out + (b * 128 + d) * e.tokens + t0) = p0;
+            }
         }
         __syncthreads();        // ldsC free again; next tile's A (stored above) visible
         buf ^= 1;
@@ -196,10 +203,11 @@ int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
         attr_set = true;
     }
     const int ntiles = M / WM;
-    const int per_cu = (K == 256 && N == 256) ? 2 : 3;      // resident workgroups per CU (LDS / VGPR budget)
+    constexpr int NTHR = 512;
+    const int per_cu = 2;                                   // resident workgroups per CU (LDS / VGPR budget)
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
     msam_profile_mark(s, 1, 2.0 * M * (double)N * K);
-    hipLaunchKernelGGL((wsgemm_kernel<N, K>), dim3(grid), dim3(512), LDS_BYTES, s, A, W, M, e);
+    hipLaunchKernelGGL((wsgemm_kernel<N, K>), dim3(grid), dim3(NTHR), LDS_BYTES, s, A, W, M, e);
     msam_profile_mark(s, 0, 0.0);
     return msam_check_launch("msam_wsgemm_bf16");
 }
@@ -209,12 +217,15 @@ int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
 extern "C" int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream) {
     if (!p || !p->A || !p->W) { msam_set_error("msam_wsgemm_bf16: null operand"); return 1; }
     if (p->M <= 0 || p->M % 64) { msam_set_error("msam_wsgemm_bf16: M must be a positive multiple of 64"); return 1; }
-    if (p->kv_split && (p->N != 256 || !p->k_out || !p->vT_out || p->tokens % 64 || p->M % p->tokens || p->ln_mode)) {
-        msam_set_error("msam_wsgemm_bf16: bad kv-split arguments");
+    if (p->kv_split && (!p->vT_out || (p->N == 256 && !p->k_out) || p->tokens % 64 || p->M % p->tokens || p->ln_mode)) {
+        msam_set_error("msam_wsgemm_bf16: bad kv-split / transposed-output arguments");
         return 1;
     }
     if (!p->kv_split && !p->out) { msam_set_error("msam_wsgemm_bf16: null output"); return 1; }
-    if (p->ln_mode && (p->N != 256 || !p->ln_w || !p->ln_b)) { msam_set_error("msam_wsgemm_bf16: LayerNorm needs N == 256"); return 1; }
+    if (p->ln_mode && (!p->ln_w || !p->ln_b || (p->ln_mode == 1 && p->N != 256) || p->ln_mode < 0 || p->ln_mode > 2)) {
+        msam_set_error("msam_wsgemm_bf16: LayerNorm(256) needs N == 256; LayerNorm(64 groups) needs ln_w / ln_b");
+        return 1;
+    }
     WsEpi e;
     e.bias = p->bias; e.table = p->table; e.table_rows = p->table_rows > 0 ? p->table_rows : 1; e.table_cols = p->table_cols;
     e.table_ld = p->table_ld; e.resid = (const u16*)p->resid; e.resid_rows = p->resid_rows; e.ldr = p->ldr;

@@ -218,3 +218,9 @@ def test_wsgemm_epilogues(env, N, K):
         k, vT = ops.wsgemm(a, w, bias, table=table, table_cols=128, kv_split_tokens=T)
         assert _close(k, ref[:, :128], 3e-2, 1e-2)
         assert _close(vT, ref[:, 128:].reshape(P, T, 128).permute(0, 2, 1), 3e-2, 1e-2)
+    else:
+        lw = (torch.randn(64, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(64, generator=g).to(dev)
+        ref2 = F.gelu(F.layer_norm(base.reshape(M, 2, 64), (64,), lw, lb, eps=1e-6)).reshape(M, 128)
+        assert _close(ops.wsgemm(a, w, bias, ln_mode=2, ln_w=lw, ln_b=lb, ln_eps=1e-6), ref2, 2e-2, 1e-2)
+        _, vT = ops.wsgemm(a, w, bias, kv_split_tokens=T)                      # N = 128: all columns transposed
+        assert _close(vT, base.reshape(P, T, 128).permute(0, 2, 1), 3e-2, 1e-2)
