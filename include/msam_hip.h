@@ -82,6 +82,21 @@ typedef struct {
 } msam_wsgemm_t;
 int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream);
 
+/* Fused image-side half of a two-way block on the per-prompt stream (upstream TwoWayAttentionBlock step 4):
+ *   q = (x + pos) Wq^T + bq  [layer 1]  or the precomputed prompt-independent q_shared [layer 0];
+ *   attn = softmax_j(q . k_tok[j] / 4) v_tok  (8 heads x 16, Nt <= 16 prompt tokens);
+ *   out = LayerNorm(x + attn Wo^T + bo).
+ * xin: bf16 [rows,256] (layer 1, may alias out) or the shared src [4096,256] (layer 0: q_shared != NULL);
+ * peq: fp32 [4096,128] = pos Wq^T; ktok / vtok: bf16 [rows/4096 * Nt, 128]; rows % 4096 == 0. */
+typedef struct {
+    const void* xin; const void* q_shared;
+    const void* wq; const float* bq; const float* peq;
+    const void* wo; const float* bo; const float* ln_w; const float* ln_b; float ln_eps;
+    const void* ktok; const void* vtok; int32_t Nt;
+    void* out; int32_t rows;
+} msam_image_layer_t;
+int msam_decoder_image_layer(const msam_image_layer_t* p, void* stream);
+
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and

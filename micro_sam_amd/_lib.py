@@ -42,6 +42,14 @@ class WsGemmParams(C.Structure):
     ]
 
 
+class ImageLayerParams(C.Structure):
+    _fields_ = [
+        ("xin", _vp), ("q_shared", _vp), ("wq", _vp), ("bq", _vp), ("peq", _vp),
+        ("wo", _vp), ("bo", _vp), ("ln_w", _vp), ("ln_b", _vp), ("ln_eps", _f32),
+        ("ktok", _vp), ("vtok", _vp), ("Nt", _i32), ("out", _vp), ("rows", _i32),
+    ]
+
+
 _blk = _vp * MSAM_MAX_BLOCKS
 
 
@@ -84,6 +92,7 @@ _PROTOS = {
     "msam_abi_version": (_i32, []),
     "msam_gemm_bf16": (_i32, [C.POINTER(GemmParams), _vp]),
     "msam_wsgemm_bf16": (_i32, [C.POINTER(WsGemmParams), _vp]),
+    "msam_decoder_image_layer": (_i32, [C.POINTER(ImageLayerParams), _vp]),
     "msam_profile_enable": (_i32, [_i32]),
     "msam_profile_collect": (_i32, [C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),

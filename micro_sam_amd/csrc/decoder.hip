@@ -288,11 +288,14 @@ __global__ __launch_bounds__(256) void i2t_attn_kernel(const u16* __restrict__ q
 // GELU(. + b2[c2]) . hyper[p][mask][c2]  -> low_res[p][mask'][y][x].
 // MFMA column (n-tile ni, lane column j) is mapped to weight row sub2*32 + c2 with sub2 = j >> 2,
 // c2 = (j & 3)*8 + ni, so the 32-channel reduction is 8 in-lane FMAs + 2 xor-shuffles.
-// One wave = 32 rows x 128 columns; persistent workgroups stride over 128-row tiles.
+// One wave = 32 rows (8 tokens x 4 sub-pixels) x 128 columns per step; the next step's A fragments are requested
+// before the current epilogue; the wave's 3 x 4 x 32 output patch goes through a wave-private LDS slab so that the
+// stores are 128-byte row segments instead of scattered dwords.
 __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restrict__ up1, const u16* __restrict__ w2,
                                                              const float* __restrict__ b2, const float* __restrict__ hyper,
                                                              int hyper_ld, int mask0, int nmask, long rows,
                                                              float* __restrict__ low_res) {
+    __shared__ float slab[4][3 * 4 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int sub2 = fr >> 2, cq = (fr & 3) * 8;
     uint4 wb[8][2];
@@ -304,36 +307,46 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
         wb[ni][1] = *(const uint4*)(w2 + wrow * 64 + 32 + fg * 8);
         bias[ni] = b2[cq + ni];
     }
-    const long ntiles = rows / 128;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row0 = tile * 128 + wave * 32;
+    float* my = slab[wave];
+    const long nsteps = rows / 32;                     // 32-row steps, strided over all waves of the grid
+    const long stride = (long)gridDim.x * 4;
+    long step = (long)blockIdx.x * 4 + wave;
+    if (step >= nsteps) return;
+    uint4 a00, a01, a10, a11;                          // A fragments of the two 16-row halves (mi = 0, 1)
+#define UP_LOAD(step_)                                                                           \
+    do {                                                                                         \
+        const u16* ar_ = up1 + ((step_) * 32 + fr) * 64 + fg * 8;                                \
+        a00 = *(const uint4*)ar_; a01 = *(const uint4*)(ar_ + 32);                               \
+        a10 = *(const uint4*)(ar_ + 16 * 64); a11 = *(const uint4*)(ar_ + 16 * 64 + 32);         \
+    } while (0)
+    UP_LOAD(step);
+    for (; step < nsteps; step += stride) {
+        const long row0 = step * 32;
         const int p = (int)(row0 / (T * 4));
+        const int token0 = (int)((row0 >> 2) & (T - 1));
         float h[3][8];
 #pragma unroll
         for (int mk = 0; mk < 3; ++mk)
 #pragma unroll
             for (int ni = 0; ni < 8; ++ni)
                 h[mk][ni] = mk < nmask ? hyper[((long)p * 4 + mask0 + mk) * hyper_ld + cq + ni] : 0.f;
-#pragma unroll 1
-        for (int mi = 0; mi < 2; ++mi) {
-            f32x4_t acc[8];
-            {
-                const u16* ar = up1 + (row0 + mi * 16 + fr) * 64;
-                const uint4 a0 = *(const uint4*)(ar + fg * 8), a1 = *(const uint4*)(ar + 32 + fg * 8);
+        f32x4_t acc0[8], acc1[8];
 #pragma unroll
-                for (int ni = 0; ni < 8; ++ni) {
-                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-                    c = mfma16(a0, wb[ni][0], c);
-                    c = mfma16(a1, wb[ni][1], c);
-                    acc[ni] = c;
-                }
-            }
+        for (int ni = 0; ni < 8; ++ni) {
+            f32x4_t c = {0.f, 0.f, 0.f, 0.f}, d = c;
+            c = mfma16(a00, wb[ni][0], c); c = mfma16(a01, wb[ni][1], c);
+            d = mfma16(a10, wb[ni][0], d); d = mfma16(a11, wb[ni][1], d);
+            acc0[ni] = c; acc1[ni] = d;
+        }
+        if (step + stride < nsteps) UP_LOAD(step + stride);        // in flight during the GELU / reduction epilogue
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float part[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ni = 0; ni < 8; ++ni) {
-                    const float g = gelu_erf(acc[ni][r] + bias[ni]);
+                    const float g = gelu_erf((mi == 0 ? acc0[ni][r] : acc1[ni][r]) + bias[ni]);
 #pragma unroll
                     for (int mk = 0; mk < 3; ++mk) part[mk] += g * h[mk][ni];
                 }
@@ -343,17 +356,23 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
                     part[mk] += __shfl_xor(part[mk], 2);
                 }
                 if ((fr & 3) == 0) {
-                    const long row = row0 + mi * 16 + fg * 4 + r;
-                    const int sub = (int)(row & 3), token = (int)((row >> 2) & (T - 1));
-                    const int y = (token >> 6) * 4 + (sub >> 1) * 2 + (sub2 >> 1);
-                    const int x = (token & 63) * 4 + (sub & 1) * 2 + (sub2 & 1);
+                    // row = row0 + mi*16 + fg*4 + r  ->  sub = r, local token = mi*4 + fg
+                    const int yl = (r >> 1) * 2 + (sub2 >> 1), xl = (mi * 4 + fg) * 4 + (r & 1) * 2 + (sub2 & 1);
 #pragma unroll
-                    for (int mk = 0; mk < 3; ++mk)
-                        if (mk < nmask) low_res[(((long)p * nmask + mk) * 256 + y) * 256 + x] = part[mk];
+                    for (int mk = 0; mk < 3; ++mk) my[(mk * 4 + yl) * 32 + xl] = part[mk];
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
+        const int ty = token0 >> 6, tx0 = token0 & 63;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int idx = k * 64 + lane, mk = idx >> 7, yl = (idx >> 5) & 3, xl = idx & 31;
+            if (mk < nmask) low_res[(((long)p * nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + xl] = my[idx];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
+#undef UP_LOAD
 }
 
 inline int grid_for(long items) { long g = (items + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
@@ -598,20 +617,15 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         ADD_CAST(w.queries, nullptr, w.b);
         CHECK(gemm(cx, w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI));
         CHECK(gemm(cx, w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI));
-        if (li == 0) {
-            hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, im.q0, 1, w.ks, w.vs, Nt, w.attn_img);
-        } else {
-            CHECK(wsgemm(cx, w.keys, L.i2t.q_w, (int)R, CI, C, L.i2t.q_b, w.qimg, c.pe_q[1], CI));
-            hipLaunchKernelGGL(i2t_attn_kernel, dim3(16, P), dim3(256), 0, cx.s, w.qimg, 0, w.ks, w.vs, Nt, w.attn_img);
+        // q-projection (layer 1) + image->token attention + out_proj + residual + norm4 in ONE launch (declayer.hip)
+        {
+            msam_image_layer_t g{};
+            g.wo = L.i2t.o_w; g.bo = L.i2t.o_b; g.ln_w = L.n4_w; g.ln_b = L.n4_b; g.ln_eps = 1e-5f;
+            g.ktok = w.ks; g.vtok = w.vs; g.Nt = Nt; g.out = w.keys; g.rows = (int)R;
+            if (li == 0) { g.xin = im.src_bf16; g.q_shared = im.q0; }
+            else { g.xin = w.keys; g.wq = L.i2t.q_w; g.bq = L.i2t.q_b; g.peq = c.pe_q[1]; }
+            CHECK(msam_decoder_image_layer(&g, cx.s));
         }
-        CHECK(msam_check_launch("i2t_attn"));
-        // out_proj + residual + norm4 fused (row-complete GEMM epilogue); layer 1 updates the stream in place
-        if (li == 0)
-            CHECK(wsgemm(cx, w.attn_img, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, nullptr, 0, im.src_bf16, T, 1, L.n4_w,
-                         L.n4_b, 1e-5f));
-        else
-            CHECK(wsgemm(cx, w.attn_img, L.i2t.o_w, (int)R, C, CI, L.i2t.o_b, w.keys, nullptr, 0, w.keys, 0, 1, L.n4_w, L.n4_b,
-                         1e-5f));
     }
     if (dbg) return 0;   // test hook: leave queries / keys of the last executed layer in the workspace
     // final token -> image attention
@@ -650,7 +664,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     {
         const long rows = R * 4;
         long tiles = rows / 128;
-        int grid = (int)(tiles < 2048 ? tiles : 2048);
+        int grid = (int)(tiles < 1024 ? tiles : 1024);
         hipLaunchKernelGGL(upscale2_hyper_kernel, dim3(grid), dim3(256), 0, cx.s, w.up1, (const u16*)dec->up2_w, dec->up2_b,
                            w.hyper, 128, mask0, nmask, rows, low_res);
         CHECK(msam_check_launch("upscale2_hyper"));

@@ -307,3 +307,19 @@ def component_sizes(roots: torch.Tensor):
     _lib.check(_lib.load().msam_component_sizes(roots.data_ptr(), n, sizes.data_ptr(), bg.data_ptr(), _lib.stream_ptr()),
                "msam_component_sizes")
     return sizes, bg
+
+
+def decoder_image_layer(xin, ktok, vtok, wo, bo, ln_w, ln_b, Nt, *, q_shared=None, wq=None, bq=None, peq=None,
+                        rows=None, ln_eps: float = 1e-5, out=None):
+    """Fused image-side half of a two-way block (include/msam_hip.h msam_decoder_image_layer)."""
+    _lib.require_gpu()
+    rows = xin.shape[0] if rows is None else rows
+    if out is None:
+        out = torch.empty((rows, 256), dtype=torch.bfloat16, device=xin.device)
+    p = _lib.ImageLayerParams()
+    p.xin, p.q_shared = xin.data_ptr(), _lib.ptr(q_shared)
+    p.wq, p.bq, p.peq = _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(peq)
+    p.wo, p.bo, p.ln_w, p.ln_b, p.ln_eps = wo.data_ptr(), bo.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
+    p.ktok, p.vtok, p.Nt, p.out, p.rows = ktok.data_ptr(), vtok.data_ptr(), Nt, out.data_ptr(), rows
+    _lib.check(_lib.load().msam_decoder_image_layer(C.byref(p), _lib.stream_ptr()), "msam_decoder_image_layer")
+    return out

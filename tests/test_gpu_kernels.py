@@ -224,3 +224,44 @@ def test_wsgemm_epilogues(env, N, K):
         assert _close(ops.wsgemm(a, w, bias, ln_mode=2, ln_w=lw, ln_b=lb, ln_eps=1e-6), ref2, 2e-2, 1e-2)
         _, vT = ops.wsgemm(a, w, bias, kv_split_tokens=T)                      # N = 128: all columns transposed
         assert _close(vT, base.reshape(P, T, 128).permute(0, 2, 1), 3e-2, 1e-2)
+
+
+@pytest.mark.parametrize("layer0", [True, False])
+@pytest.mark.parametrize("Nt", [7, 12])
+def test_decoder_image_layer_fused(env, layer0, Nt):
+    """Fused q-proj + image->token attention + out-proj + LayerNorm vs plain torch on the same bf16-rounded operands."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(20 + Nt + int(layer0))
+    P, T = 2, 4096
+    R = P * T
+    x = _bf(torch.randn(T if layer0 else R, 256, generator=g)).to(dev)
+    ktok = _bf(torch.randn(P * Nt, 128, generator=g)).to(dev)
+    vtok = _bf(torch.randn(P * Nt, 128, generator=g)).to(dev)
+    wo = _bf(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev)
+    bo = torch.randn(256, generator=g).to(dev)
+    lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
+    wq = _bf(torch.randn(128, 256, generator=g) / 16).to(dev)
+    bq = torch.randn(128, generator=g).to(dev)
+    peq = torch.randn(T, 128, generator=g).to(dev)
+    if layer0:
+        q_sh = _bf(torch.randn(T, 128, generator=g)).to(dev)
+        q = q_sh.float().repeat(P, 1)
+        xres = x.float().repeat(P, 1)
+        out = ops.decoder_image_layer(x, ktok, vtok, wo, bo, lw, lb, Nt, q_shared=q_sh, rows=R)
+    else:
+        q = _bf(x.float() @ wq.float().t() + bq + peq.repeat(P, 1)).float()      # the kernel keeps q in bf16
+        xres = x.float()
+        out = ops.decoder_image_layer(x, ktok, vtok, wo, bo, lw, lb, Nt, wq=wq, bq=bq, peq=peq)
+    qh = q.reshape(P, T, 8, 16).permute(0, 2, 1, 3)
+    kh = ktok.float().reshape(P, Nt, 8, 16).permute(0, 2, 1, 3)
+    vh = vtok.float().reshape(P, Nt, 8, 16).permute(0, 2, 1, 3)
+    s = (qh @ kh.transpose(-1, -2)) / 4.0
+    e = torch.exp(s - s.amax(-1, keepdim=True))
+    attn = (_bf(e).float() @ vh) / e.sum(-1, keepdim=True)                      # un-normalised P in bf16, fp32 row sum
+    attn = _bf(attn.permute(0, 2, 1, 3).reshape(R, 128)).float()
+    ref = F.layer_norm(xres + attn @ wo.float().t() + bo, (256,), lw, lb, eps=1e-5)
+    assert _close(out, ref, 3e-2, 2e-2)
+    if not layer0:                                                               # in-place update of the stream
+        x2 = x.clone()
+        ops.decoder_image_layer(x2, ktok, vtok, wo, bo, lw, lb, Nt, wq=wq, bq=bq, peq=peq, out=x2)
+        assert _close(x2, ref, 3e-2, 2e-2)
