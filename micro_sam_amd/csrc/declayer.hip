@@ -5,12 +5,19 @@
 //     keys = LayerNorm(keys + attn Wo^T + bo)        (norm4)
 //
 // One launch replaces q-projection GEMM + image->token attention kernel + out-projection/LayerNorm GEMM and their
-// HBM round trips (q 1 MiB + attn 2 MiB + residual re-read 2 MiB per prompt): the stream is read once (16 KB per
-// 32-token tile) and written once.  Both weight matrices stay in registers for the whole launch (weights-stationary,
-// see wsgemm.hip): Wq 16 columns x 256 per wave, Wo 32 columns x 128 per wave = 64 VGPRs.
-// Per tile: keys tile -> LDS (double buffered, requested two tiles ahead) -> MFMA q-proj -> q tile (bf16, LDS) ->
-// per (16 tokens, head) transposed-score MFMA attention (attention.hip form) -> attn tile (bf16, LDS) -> MFMA
-// out-proj -> fp32 tile (LDS) -> row-complete epilogue (bias + residual from the LDS keys tile + LayerNorm) -> store.
+// HBM round trips: the stream is read once (16 KB per 32-token tile) and written once.
+//
+// Wave-specialised software pipeline, one 16-wave workgroup per CU (a CU's register file cannot hold both weight
+// matrices twice, so two independent 8-wave workgroups do not fit; two cooperating groups do):
+//   group A (waves 0-7, wave = head): keeps its 16 rows of Wq as MFMA A fragments (32 VGPRs); per tile computes
+//       q^T = Wq . keys^T straight into the C layout (row = d, col = token), which after bf16 packing IS the B operand
+//       of S^T = k_tok . q^T (k-slot map (lane group g, i<4) <-> d = 4g+i, k_tok fragments loaded with the same map), then
+//       softmax over the <= 16 prompt tokens in registers and O^T = V_tok^T . P^T; writes the attention tile to LDS.
+//   group B (waves 8-15): keeps its 32 columns of Wo as B fragments (32 VGPRs); per tile out-projection from the
+//       attention tile of the PREVIOUS iteration, fp32 tile through LDS, then row-complete epilogue (bias + residual
+//       from the LDS keys tile + LayerNorm) and coalesced bf16 stores.
+// While A works on tile i, B finishes tile i-1 and the loads of tile i+1 are in flight: three keys buffers, two
+// attention buffers, two block barriers per tile.
 #include "common.h"
 #include "../../include/msam_hip.h"
 
@@ -20,7 +27,7 @@ void msam_profile_mark(void* stream, int begin, double flops);
 
 namespace {
 
-constexpr int T = 4096, C = 256, CI = 128, WM = 32, NTHR = 512;
+constexpr int T = 4096, C = 256, CI = 128, WM = 32, NTHR = 1024, CPR = C / 8;
 constexpr float NEG_BIG = -1.0e30f;
 
 struct LayerArgs {
@@ -35,182 +42,199 @@ struct LayerArgs {
 MSAM_DEVINL int swzr(int row) { return row & 15; }
 
 template <bool L0>
-__global__ __launch_bounds__(NTHR, L0 ? 4 : 3) void dec_image_layer_kernel(LayerArgs a) {
+__global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
-    constexpr int CPR = C / 8;                                   // 32 chunks per keys row
-    uint4* ldsA = dyn_lds;                                       // [2][WM*CPR]            32 KB (unused for L0)
-    uint4* ldsQ = dyn_lds + (L0 ? 0 : 2 * WM * CPR);             // [WM][16]  bf16 q tile   8 KB
-    uint4* ldsP = ldsQ + WM * 16;                                // [WM][16]  bf16 attn     8 KB
-    float* ldsC = (float*)(ldsP + WM * 16);                      // [WM][256] fp32         32 KB
+    uint4* ldsK = dyn_lds;                                        // [3][WM*CPR] keys tiles (layer 1)   48 KB
+    uint4* ldsP = dyn_lds + (L0 ? 0 : 3 * WM * CPR);              // [2][WM*16]  bf16 attention tiles   16 KB
+    float* ldsC = (float*)(ldsP + 2 * WM * 16);                   // [WM][256]   fp32                   32 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    // ---- stationary weights
-    uint4 wqf[8];                                                // Wq rows wave*16 + fr, 8 k-chunks (layer 1)
-    if constexpr (!L0) {
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) wqf[kc] = *(const uint4*)(a.wq + (long)(wave * 16 + fr) * C + kc * 32 + fg * 8);
-    }
-    uint4 wof[2][4];                                             // Wo rows wave*32 + ni*16 + fr, 4 k-chunks
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) wof[ni][kc] = *(const uint4*)(a.wo + (long)(wave * 32 + ni * 16 + fr) * CI + kc * 32 + fg * 8);
-
+    const bool grpA = wave < 8;
     const int ntiles = a.rows / WM;
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    uint4 ra0, ra1;                  // next tile's rows (two workgroups per CU overlap the remaining latency)
-    (void)ra0; (void)ra1;
-#define DL_SRC(p_, tile_) (a.xin + ((long)(tile_) * WM + ((p_) * NTHR + tid) / CPR) * C + (((p_) * NTHR + tid) % CPR) * 8)
-#define DL_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * NTHR + tid) / CPR) * CPR + \
-                              ((((p_) * NTHR + tid) % CPR) ^ swzr(((p_) * NTHR + tid) / CPR))]
-#define DL_LOAD(r0_, r1_, tile_) do { r0_ = *(const uint4*)DL_SRC(0, tile_); r1_ = *(const uint4*)DL_SRC(1, tile_); } while (0)
-#define DL_STORE(r0_, r1_, buf_) do { DL_DST(0, buf_) = r0_; DL_DST(1, buf_) = r1_; } while (0)
+    const int stride = gridDim.x;
+    const int first = blockIdx.x;
+    if (first >= ntiles) return;
+    const int my_tiles = (ntiles - first + stride - 1) / stride;   // tiles of this workgroup
+
+    // ---- stationary weights
+    uint4 wst[8];
+    if (grpA) {
+        if constexpr (!L0) {
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) wst[kc] = *(const uint4*)(a.wq + (long)(wave * 16 + fr) * C + kc * 32 + fg * 8);
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) wst[kc] = make_uint4(0, 0, 0, 0);
+        }
+    } else {
+        const int wb = wave - 8;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+                wst[ni * 4 + kc] = *(const uint4*)(a.wo + (long)(wb * 32 + ni * 16 + fr) * CI + kc * 32 + fg * 8);
+    }
+
+    // keys tile staging (group A threads, 2 chunks each)
+    uint4 ra0 = make_uint4(0, 0, 0, 0), ra1 = ra0;
+#define DL_SRC(p_, tile_) (a.xin + ((long)(tile_) * WM + ((p_) * 512 + tid) / CPR) * C + (((p_) * 512 + tid) % CPR) * 8)
+#define DL_DST(p_, buf_) ldsK[(buf_) * WM * CPR + (((p_) * 512 + tid) / CPR) * CPR + \
+                              ((((p_) * 512 + tid) % CPR) ^ swzr(((p_) * 512 + tid) / CPR))]
     if constexpr (!L0) {
-        DL_LOAD(ra0, ra1, tile);
-        DL_STORE(ra0, ra1, 0);
+        if (grpA) {
+            ra0 = *(const uint4*)DL_SRC(0, first); ra1 = *(const uint4*)DL_SRC(1, first);
+            DL_DST(0, 0) = ra0; DL_DST(1, 0) = ra1;
+        }
     }
     __syncthreads();
-    int buf = 0;
 
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        const long row0 = (long)tile * WM;
-        const int p = (int)(row0 / T), t0 = (int)(row0 - (long)p * T);
-        if constexpr (!L0) {
-            if (next < ntiles) DL_LOAD(ra0, ra1, next);
-            // ---- q projection: this wave's 16 columns for the 32 rows
-            const uint4* la = ldsA + buf * WM * CPR;
-            f32x4_t qa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // iteration i: A handles tile i (i < my_tiles), B handles tile i-1 (i >= 1)
+    for (int i = 0; i <= my_tiles; ++i) {
+        if (grpA) {
+            const bool work = i < my_tiles;
+            const int tile = first + i * stride;
+            const long row0 = (long)tile * WM;
+            const int p = (int)(row0 / T), t0 = (int)(row0 - (long)p * T);
+            const int head = wave;
+            const bool have_next = (i + 1 < my_tiles);
+            if constexpr (!L0) {
+                if (have_next) { ra0 = *(const uint4*)DL_SRC(0, tile + stride); ra1 = *(const uint4*)DL_SRC(1, tile + stride); }
+            }
+            uint4 qb0 = make_uint4(0, 0, 0, 0), qb1 = qb0;       // B operands of S^T for the two token tiles
+            uint4 ka = make_uint4(0, 0, 0, 0), va = make_uint4(0, 0, 0, 0);
+            if (work) {
+                if constexpr (!L0) {
+                    // q^T = Wq . keys^T : rows d = fg*4 + r of this head, cols = tokens
+                    const uint4* lk = ldsK + (i % 3) * WM * CPR;
+                    f32x4_t qa0 = {0.f, 0.f, 0.f, 0.f}, qa1 = qa0;
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const int row = mi * 16 + fr;
-                    qa[mi] = mfma16(la[row * CPR + ((kc * 4 + fg) ^ swzr(row))], wqf[kc], qa[mi]);
+                    for (int kc = 0; kc < 8; ++kc) {
+                        const int r0 = fr, r1 = 16 + fr;
+                        qa0 = mfma16(wst[kc], lk[r0 * CPR + ((kc * 4 + fg) ^ swzr(r0))], qa0);
+                        qa1 = mfma16(wst[kc], lk[r1 * CPR + ((kc * 4 + fg) ^ swzr(r1))], qa1);
+                    }
+                    const float4 b4 = *(const float4*)(a.bq + head * 16 + fg * 4);
+                    const float4 pe0 = *(const float4*)(a.peq + (long)(t0 + fr) * CI + head * 16 + fg * 4);
+                    const float4 pe1 = *(const float4*)(a.peq + (long)(t0 + 16 + fr) * CI + head * 16 + fg * 4);
+                    qb0.x = pack2bf(qa0[0] + b4.x + pe0.x, qa0[1] + b4.y + pe0.y);
+                    qb0.y = pack2bf(qa0[2] + b4.z + pe0.z, qa0[3] + b4.w + pe0.w);
+                    qb1.x = pack2bf(qa1[0] + b4.x + pe1.x, qa1[1] + b4.y + pe1.y);
+                    qb1.y = pack2bf(qa1[2] + b4.z + pe1.z, qa1[3] + b4.w + pe1.w);
+                    // k_tok fragment with the SAME k-slot map: slots i < 4 <-> d = fg*4 + i
+                    if (fr < a.Nt) {
+                        const uint2 k2 = *(const uint2*)(a.ktok + ((long)p * a.Nt + fr) * CI + head * 16 + fg * 4);
+                        ka.x = k2.x; ka.y = k2.y;
+                    }
+                } else {
+                    // prompt-independent q rows and k_tok in the natural map: slots (fg < 2, i) <-> d = fg*8 + i
+                    if (fg < 2) {
+                        qb0 = *(const uint4*)(a.q_shared + (long)(t0 + fr) * CI + head * 16 + fg * 8);
+                        qb1 = *(const uint4*)(a.q_shared + (long)(t0 + 16 + fr) * CI + head * 16 + fg * 8);
+                        if (fr < a.Nt) ka = *(const uint4*)(a.ktok + ((long)p * a.Nt + fr) * CI + head * 16 + fg * 8);
+                    }
+                }
+                // V_tok^T fragment: lane (fr = d, fg): slots i < 4 <-> j = fg*4 + i
+                {
+                    u16 e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+                    const u16* vb = a.vtok + (long)p * a.Nt * CI + head * 16 + fr;
+                    if (fg * 4 + 0 < a.Nt) e0 = vb[(fg * 4 + 0) * CI];
+                    if (fg * 4 + 1 < a.Nt) e1 = vb[(fg * 4 + 1) * CI];
+                    if (fg * 4 + 2 < a.Nt) e2 = vb[(fg * 4 + 2) * CI];
+                    if (fg * 4 + 3 < a.Nt) e3 = vb[(fg * 4 + 3) * CI];
+                    va.x = (uint32_t)e0 | ((uint32_t)e1 << 16); va.y = (uint32_t)e2 | ((uint32_t)e3 << 16);
                 }
             }
-            const int qc = wave * 16 + fr;                        // q column of this lane
-            const float qb = a.bq[qc];
-            u16* q16 = (u16*)ldsQ;
+            __syncthreads();                                   // barrier 1 (B: fp32 tile written)
+            if (work) {
+                uint4* lp = ldsP + (i & 1) * WM * 16;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int row = mt * 16 + fr;
+                    f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+                    s = mfma16(ka, mt == 0 ? qb0 : qb1, s);    // rows j = fg*4 + r, col token = fr
+                    float mx = NEG_BIG;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[r] = (fg * 4 + r < a.Nt) ? s[r] * 0.25f : NEG_BIG; mx = fmaxf(mx, s[r]); }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float ps = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mx); ps += s[r]; }
+                    ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+                    uint4 pb; pb.x = pack2bf(s[0], s[1]); pb.y = pack2bf(s[2], s[3]); pb.z = 0; pb.w = 0;
+                    f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+                    o = mfma16(va, pb, o);                     // rows d = fg*4 + r, col token = fr
+                    const float inv = 1.f / ps;
+                    uint2 pk; pk.x = pack2bf(o[0] * inv, o[1] * inv); pk.y = pack2bf(o[2] * inv, o[3] * inv);
+                    uint2* dst = (uint2*)(lp + row * 16 + ((head * 2 + (fg >> 1)) ^ swzr(row)));
+                    dst[fg & 1] = pk;
+                }
+            }
+            if constexpr (!L0) {
+                if (have_next) { DL_DST(0, (i + 1) % 3) = ra0; DL_DST(1, (i + 1) % 3) = ra1; }
+            }
+            __syncthreads();                                   // barrier 2 (end of iteration)
+        } else {
+            const bool work = i >= 1;
+            const int tile = first + (i - 1) * stride;
+            const long row0 = (long)tile * WM;
+            const int t0 = (int)(row0 % T);
+            const int wb = wave - 8;
+            if (work) {
+                const uint4* lp = ldsP + ((i - 1) & 1) * WM * 16;
+                f32x4_t oc00 = {0.f, 0.f, 0.f, 0.f}, oc01 = oc00, oc10 = oc00, oc11 = oc00;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    const int r0 = fr, r1 = 16 + fr;
+                    const uint4 af0 = lp[r0 * 16 + ((kc * 4 + fg) ^ swzr(r0))];
+                    const uint4 af1 = lp[r1 * 16 + ((kc * 4 + fg) ^ swzr(r1))];
+                    oc00 = mfma16(af0, wst[kc], oc00); oc01 = mfma16(af0, wst[4 + kc], oc01);
+                    oc10 = mfma16(af1, wst[kc], oc10); oc11 = mfma16(af1, wst[4 + kc], oc11);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = mi * 16 + fg * 4 + r;
-                    const float v = qa[mi][r] + qb + a.peq[(long)(t0 + row) * CI + qc];
-                    q16[row * 128 + (((qc >> 3) ^ swzr(row)) << 3) + (qc & 7)] = f2bf(v);
+                    ldsC[(fg * 4 + r) * C + wb * 32 + fr] = oc00[r];
+                    ldsC[(fg * 4 + r) * C + wb * 32 + 16 + fr] = oc01[r];
+                    ldsC[(16 + fg * 4 + r) * C + wb * 32 + fr] = oc10[r];
+                    ldsC[(16 + fg * 4 + r) * C + wb * 32 + 16 + fr] = oc11[r];
                 }
-        } else {
-            // layer 0: the prompt-independent q rows of this token range
-            if (tid < WM * 16) {
-                const int row = tid >> 4, c = tid & 15;
-                ldsQ[row * 16 + (c ^ swzr(row))] = *(const uint4*)(a.q_shared + (long)(t0 + row) * CI + c * 8);
             }
-        }
-        __syncthreads();
-        // ---- image -> token attention: wave = head, two 16-token tiles
-        {
-            const int head = wave;
-            uint4 ka = make_uint4(0, 0, 0, 0);
-            if (fg < 2 && fr < a.Nt) ka = *(const uint4*)(a.ktok + ((long)p * a.Nt + fr) * CI + head * 16 + fg * 8);
-            uint4 va = make_uint4(0, 0, 0, 0);
-            {
-                u16 e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-                const u16* vb = a.vtok + (long)p * a.Nt * CI + head * 16 + fr;
-                if (fg * 4 + 0 < a.Nt) e0 = vb[(fg * 4 + 0) * CI];
-                if (fg * 4 + 1 < a.Nt) e1 = vb[(fg * 4 + 1) * CI];
-                if (fg * 4 + 2 < a.Nt) e2 = vb[(fg * 4 + 2) * CI];
-                if (fg * 4 + 3 < a.Nt) e3 = vb[(fg * 4 + 3) * CI];
-                va.x = (uint32_t)e0 | ((uint32_t)e1 << 16); va.y = (uint32_t)e2 | ((uint32_t)e3 << 16);
-            }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int row = mt * 16 + fr;
-                uint4 qf = make_uint4(0, 0, 0, 0);
-                if (fg < 2) qf = ldsQ[row * 16 + ((head * 2 + fg) ^ swzr(row))];
-                f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-                s = mfma16(ka, qf, s);                            // rows j = fg*4 + r, col token = fr
-                float mx = NEG_BIG;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[r] = (fg * 4 + r < a.Nt) ? s[r] * 0.25f : NEG_BIG; mx = fmaxf(mx, s[r]); }
-                mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float ps = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mx); ps += s[r]; }
-                ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
-                uint4 pb; pb.x = pack2bf(s[0], s[1]); pb.y = pack2bf(s[2], s[3]); pb.z = 0; pb.w = 0;
-                f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-                o = mfma16(va, pb, o);                            // rows d = fg*4 + r, col token = fr
-                const float inv = 1.f / ps;
-                uint2 pk; pk.x = pack2bf(o[0] * inv, o[1] * inv); pk.y = pack2bf(o[2] * inv, o[3] * inv);
-                // attn[token = row][head*16 + fg*4 .. +3]: chunk head*2 + (fg >> 1), 8-byte half (fg & 1)
-                uint2* dst = (uint2*)(ldsP + row * 16 + ((head * 2 + (fg >> 1)) ^ swzr(row)));
-                dst[fg & 1] = pk;
-            }
-        }
-        __syncthreads();
-        // ---- out projection: this wave's 32 columns
-        f32x4_t oc[2][2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) oc[mi][ni] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int row = mi * 16 + fr;
-                const uint4 af = ldsP[row * 16 + ((kc * 4 + fg) ^ swzr(row))];
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) oc[mi][ni] = mfma16(af, wof[ni][kc], oc[mi][ni]);
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ldsC[(mi * 16 + fg * 4 + r) * C + wave * 32 + ni * 16 + fr] = oc[mi][ni][r];
-        __syncthreads();
-        // ---- row-complete epilogue: one wave = one 256-wide row per pass
-        const int col = lane * 4;
+            __syncthreads();                                   // barrier 1
+            if (work) {
+                const int col = lane * 4;
 #pragma unroll 1
-        for (int pass = 0; pass < 4; ++pass) {
-            const float4 b4 = *(const float4*)(a.bo + col), w4 = *(const float4*)(a.ln_w + col), g4 = *(const float4*)(a.ln_b + col);
-            const int lr = pass * 8 + wave;
-            const float4 c = *(const float4*)(ldsC + lr * C + col);
-            uint2 rs;
-            if constexpr (!L0) {
-                const uint4* la = ldsA + buf * WM * CPR;
-                rs = ((const uint2*)(la + lr * CPR + ((lane >> 1) ^ swzr(lr))))[lane & 1];
-            } else {
-                rs = *(const uint2*)(a.xin + (long)(t0 + lr) * C + col);
+                for (int pass = 0; pass < 4; ++pass) {
+                    const float4 b4 = *(const float4*)(a.bo + col), w4 = *(const float4*)(a.ln_w + col), g4 = *(const float4*)(a.ln_b + col);
+                    const int lr = pass * 8 + wb;
+                    const float4 c = *(const float4*)(ldsC + lr * C + col);
+                    uint2 rs;
+                    if constexpr (!L0) {
+                        const uint4* lk = ldsK + ((i - 1) % 3) * WM * CPR;
+                        rs = ((const uint2*)(lk + lr * CPR + ((lane >> 1) ^ swzr(lr))))[lane & 1];
+                    } else {
+                        rs = *(const uint2*)(a.xin + (long)(t0 + lr) * C + col);
+                    }
+                    float v0 = c.x + b4.x + bf2f((u16)(rs.x & 0xffff)), v1 = c.y + b4.y + bf2f((u16)(rs.x >> 16));
+                    float v2 = c.z + b4.z + bf2f((u16)(rs.y & 0xffff)), v3 = c.w + b4.w + bf2f((u16)(rs.y >> 16));
+                    const float mean = wave_sum64((v0 + v1) + (v2 + v3)) * (1.0f / 256.0f);
+                    v0 -= mean; v1 -= mean; v2 -= mean; v3 -= mean;
+                    const float var = wave_sum64((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3)) * (1.0f / 256.0f);
+                    const float rstd = 1.0f / sqrtf(var + a.eps);
+                    uint2 pk;
+                    pk.x = pack2bf(v0 * rstd * w4.x + g4.x, v1 * rstd * w4.y + g4.y);
+                    pk.y = pack2bf(v2 * rstd * w4.z + g4.z, v3 * rstd * w4.w + g4.w);
+                    *(uint2*)(a.out + (row0 + lr) * C + col) = pk;
+                }
             }
-            float v0 = c.x + b4.x + bf2f((u16)(rs.x & 0xffff)), v1 = c.y + b4.y + bf2f((u16)(rs.x >> 16));
-            float v2 = c.z + b4.z + bf2f((u16)(rs.y & 0xffff)), v3 = c.w + b4.w + bf2f((u16)(rs.y >> 16));
-            const float mean = wave_sum64((v0 + v1) + (v2 + v3)) * (1.0f / 256.0f);
-            v0 -= mean; v1 -= mean; v2 -= mean; v3 -= mean;
-            const float var = wave_sum64((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3)) * (1.0f / 256.0f);
-            const float rstd = 1.0f / sqrtf(var + a.eps);
-            uint2 pk;
-            pk.x = pack2bf(v0 * rstd * w4.x + g4.x, v1 * rstd * w4.y + g4.y);
-            pk.y = pack2bf(v2 * rstd * w4.z + g4.z, v3 * rstd * w4.w + g4.w);
-            *(uint2*)(a.out + (row0 + lr) * C + col) = pk;
+            __syncthreads();                                   // barrier 2
         }
-        if constexpr (!L0) { if (next < ntiles) DL_STORE(ra0, ra1, buf ^ 1); }
-        __syncthreads();
-        buf ^= 1;
     }
 #undef DL_SRC
 #undef DL_DST
-#undef DL_LOAD
-#undef DL_STORE
 }
 
 template <bool L0>
 int launch(const LayerArgs& a, hipStream_t s) {
-    constexpr int LDS_BYTES = (L0 ? 0 : 2 * WM * 32 * 16) + 2 * WM * 16 * 16 + WM * C * 4;
+    constexpr int LDS_BYTES = (L0 ? 0 : 3 * WM * CPR * 16) + 2 * WM * 16 * 16 + WM * C * 4;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)dec_image_layer_kernel<L0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -218,7 +242,7 @@ int launch(const LayerArgs& a, hipStream_t s) {
         attr_set = true;
     }
     const int ntiles = a.rows / WM;
-    const int grid = ntiles < 512 ? ntiles : 512;                 // two workgroups per CU
+    const int grid = ntiles < 256 ? ntiles : 256;                 // one 16-wave workgroup per CU
     const double flops = 2.0 * a.rows * ((L0 ? 0.0 : (double)CI * C) + (double)C * CI);
     msam_profile_mark(s, 1, flops);
     hipLaunchKernelGGL((dec_image_layer_kernel<L0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
