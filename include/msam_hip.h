@@ -103,6 +103,9 @@ int msam_decoder_image_layer(const msam_image_layer_t* p, void* stream);
  * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
 int msam_profile_enable(int on);
 int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops);
+/* Per kernel family: [0] tiled MFMA GEMM (gemm_kernel / gemm_ln_kernel, MFMA-bound), [1] streaming decoder kernels
+ * (wsgemm_kernel / dec_image_layer_kernel, HBM-bound).  Arrays of 2: launches, summed ms, flops, algorithmic bytes. */
+int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
  * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.

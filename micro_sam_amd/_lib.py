@@ -95,6 +95,7 @@ _PROTOS = {
     "msam_decoder_image_layer": (_i32, [C.POINTER(ImageLayerParams), _vp]),
     "msam_profile_enable": (_i32, [_i32]),
     "msam_profile_collect": (_i32, [C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "msam_profile_collect_family": (_i32, [_i32 * 2, C.c_double * 2, C.c_double * 2, C.c_double * 2]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

@@ -23,7 +23,7 @@
 
 void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
-void msam_profile_mark(void* stream, int begin, double flops);
+void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int family);
 
 namespace {
 
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
             __syncthreads();                                   // barrier 1
             if (work) {
                 const int col = lane * 4;
-#pragma unroll 1
+#pragma unroll 2
                 for (int pass = 0; pass < 4; ++pass) {
                     const float4 b4 = *(const float4*)(a.bo + col), w4 = *(const float4*)(a.ln_w + col), g4 = *(const float4*)(a.ln_b + col);
                     const int lr = pass * 8 + wb;
@@ -244,9 +244,10 @@ int launch(const LayerArgs& a, hipStream_t s) {
     const int ntiles = a.rows / WM;
     const int grid = ntiles < 256 ? ntiles : 256;                 // one 16-wave workgroup per CU
     const double flops = 2.0 * a.rows * ((L0 ? 0.0 : (double)CI * C) + (double)C * CI);
-    msam_profile_mark(s, 1, flops);
+    const double bytes = (double)a.rows * ((L0 ? 0.0 : C * 2.0) + C * 2.0);   // read the stream (layer 1), write it
+    msam_profile_mark2(s, 1, flops, bytes, 1);
     hipLaunchKernelGGL((dec_image_layer_kernel<L0>), dim3(grid), dim3(NTHR), LDS_BYTES, s, a);
-    msam_profile_mark(s, 0, 0.0);
+    msam_profile_mark2(s, 0, 0.0, 0.0, 1);
     return msam_check_launch("msam_decoder_image_layer");
 }
 

@@ -389,11 +389,13 @@ int msam_check_launch(const char* what) {
 
 // ---- optional live profiling of the GEMM kernel with HIP events on the launch stream (bench.py roofline leg)
 namespace {
-struct ProfSlot { hipEvent_t a, b; double flops; };
+struct ProfSlot { hipEvent_t a, b; double flops, bytes; int family; };
 constexpr int PROF_MAX = 4096;
 ProfSlot g_prof[PROF_MAX];
 int g_prof_n = 0, g_prof_on = 0, g_prof_init = 0;
 }  // namespace
+
+extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
 extern "C" int msam_profile_enable(int on) {
     if (on && !g_prof_init) {
@@ -411,26 +413,36 @@ extern "C" int msam_profile_enable(int on) {
 
 // Synchronises the recorded events; returns launches, total milliseconds and total flops (2*M*N*K) since enable.
 extern "C" int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops) {
-    double ms = 0, fl = 0;
+    int32_t n[2]; double ms[2], fl[2], by[2];
+    if (int e = msam_profile_collect_family(n, ms, fl, by)) return e;
+    if (launches) *launches = n[0] + n[1];
+    if (total_ms) *total_ms = ms[0] + ms[1];
+    if (total_flops) *total_flops = fl[0] + fl[1];
+    return 0;
+}
+
+extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes) {
+    for (int f = 0; f < 2; ++f) { launches[f] = 0; ms[f] = 0; flops[f] = 0; bytes[f] = 0; }
     for (int i = 0; i < g_prof_n; ++i) {
         if (hipEventSynchronize(g_prof[i].b) != hipSuccess) { msam_set_error("msam_profile_collect: sync failed"); return 2; }
         float t = 0.f;
         hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
-        ms += t; fl += g_prof[i].flops;
+        const int f = g_prof[i].family & 1;
+        ++launches[f]; ms[f] += t; flops[f] += g_prof[i].flops; bytes[f] += g_prof[i].bytes;
     }
-    if (launches) *launches = g_prof_n;
-    if (total_ms) *total_ms = ms;
-    if (total_flops) *total_flops = fl;
     g_prof_n = 0;
     return 0;
 }
 
 // used by the other GEMM-family kernels (wsgemm.hip) so that they are part of the same live measurement
-void msam_profile_mark(void* stream, int begin, double flops) {
+void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int family) {
     if (!g_prof_on || g_prof_n >= PROF_MAX) return;
-    if (begin) { g_prof[g_prof_n].flops = flops; (void)hipEventRecord(g_prof[g_prof_n].a, (hipStream_t)stream); }
-    else { (void)hipEventRecord(g_prof[g_prof_n].b, (hipStream_t)stream); ++g_prof_n; }
+    if (begin) {
+        g_prof[g_prof_n].flops = flops; g_prof[g_prof_n].bytes = bytes; g_prof[g_prof_n].family = family;
+        (void)hipEventRecord(g_prof[g_prof_n].a, (hipStream_t)stream);
+    } else { (void)hipEventRecord(g_prof[g_prof_n].b, (hipStream_t)stream); ++g_prof_n; }
 }
+void msam_profile_mark(void* stream, int begin, double flops) { msam_profile_mark2(stream, begin, flops, 0.0, 1); }
 
 extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     if (!p || !p->A || !p->W) { msam_set_error("msam_gemm_bf16: null operand"); return 1; }
@@ -477,7 +489,10 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         }
         EpiLN ln{p->ln_w, p->ln_b, p->ln_eps, p->ln_mode};
         const bool prof_ln = g_prof_on && g_prof_n < PROF_MAX;
-        if (prof_ln) { g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; (void)hipEventRecord(g_prof[g_prof_n].a, s); }
+        if (prof_ln) {
+            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
+            (void)hipEventRecord(g_prof[g_prof_n].a, s);
+        }
         hipLaunchKernelGGL(gemm_ln_kernel, dim3((p->M + 63) / 64), dim3(256), LN_LDS, s, (const u16*)p->A, (long)p->lda,
                            (const u16*)p->W, (long)p->ldw, p->M, p->K, e, ln);
         if (prof_ln) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
@@ -486,7 +501,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
     if (prof) {
-        g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K;
+        g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
         (void)hipEventRecord(g_prof[g_prof_n].a, s);
     }
     if (p->use_glds)

@@ -12,7 +12,7 @@
 
 void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
-void msam_profile_mark(void* stream, int begin, double flops);
+void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int family);
 
 namespace {
 
@@ -206,9 +206,11 @@ int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
     constexpr int NTHR = 512;
     const int per_cu = 2;                                   // resident workgroups per CU (LDS / VGPR budget)
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-    msam_profile_mark(s, 1, 2.0 * M * (double)N * K);
+    // algorithmic HBM bytes: read A (bf16) [+ residual], write the bf16 output
+    const double bytes = (double)M * (K * 2.0 + N * 2.0 + (e.resid && !e.resid_rows ? N * 2.0 : 0.0));
+    msam_profile_mark2(s, 1, 2.0 * M * (double)N * K, bytes, 1);
     hipLaunchKernelGGL((wsgemm_kernel<N, K>), dim3(grid), dim3(NTHR), LDS_BYTES, s, A, W, M, e);
-    msam_profile_mark(s, 0, 0.0);
+    msam_profile_mark2(s, 0, 0.0, 0.0, 1);
     return msam_check_launch("msam_wsgemm_bf16");
 }
 
