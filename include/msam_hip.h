@@ -79,6 +79,7 @@ typedef struct {
     int32_t ln_mode; const float* ln_w; const float* ln_b; float ln_eps;
     void* out; int64_t ldc;
     int32_t kv_split; void* k_out; void* vT_out; int32_t tokens;
+    int32_t head_major;      /* plain output stored as [M/tokens][N/16][tokens][16] (heads of 16 columns contiguous) */
 } msam_wsgemm_t;
 int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream);
 

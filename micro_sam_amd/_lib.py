@@ -39,6 +39,7 @@ class WsGemmParams(C.Structure):
         ("resid", _vp), ("resid_rows", _i32), ("ldr", _i64),
         ("ln_mode", _i32), ("ln_w", _vp), ("ln_b", _vp), ("ln_eps", _f32),
         ("out", _vp), ("ldc", _i64), ("kv_split", _i32), ("k_out", _vp), ("vT_out", _vp), ("tokens", _i32),
+        ("head_major", _i32),
     ]
 
 

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(128) void token_self_attn_kernel(const u16* __restr
 // Token -> image cross attention (8 heads x 16, 4096 keys), transposed-score MFMA form (see attention.hip):
 //   S^T[t][j] = k_img[t] . q_tok[j],  online softmax over t per column j,  O^T[d][j] += V^T[d][t] P^T[t][j].
 // One workgroup per (prompt, head); the 4 waves split the 4096 keys and merge their (m, l, O) at the end.
-// k_img: bf16 [rows,128] (row = pk*4096 + t), vT: bf16 [Pk,128,4096]; kv_shared: all prompts use prompt 0's K/V.
+// k_img: bf16 head-major [Pk][8][4096][16] (each (prompt, head) slice is one contiguous 128 KiB stream),
+// vT: bf16 [Pk,128,4096]; kv_shared: all prompts use prompt 0's K/V.
 __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ qtok, const u16* __restrict__ kimg,
                                                        const u16* __restrict__ vT, int kv_shared, int Nt,
                                                        u16* __restrict__ out) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ q
     const int p = blockIdx.x >> 3, head = blockIdx.x & 7;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int pk = kv_shared ? 0 : p;
-    const u16* kb = kimg + (long)pk * T * CI + head * 16;
+    const u16* kb = kimg + ((long)pk * 8 + head) * T * 16;
     const u16* vb = vT + ((long)pk * CI + head * 16 + fr) * T;
     // B operand: q_tok[j = fr][d = fg*8 ..] for fg < 2 (K = 16 zero-padded to 32)
     uint4 qf = make_uint4(0, 0, 0, 0);
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ q
     for (int t0 = t_begin; t0 < t_end; t0 += 32) {
         uint4 ka0 = make_uint4(0, 0, 0, 0), ka1 = ka0;
         if (fg < 2) {
-            ka0 = *(const uint4*)(kb + (long)(t0 + fr) * CI + fg * 8);
-            ka1 = *(const uint4*)(kb + (long)(t0 + 16 + fr) * CI + fg * 8);
+            ka0 = *(const uint4*)(kb + (long)(t0 + fr) * 16 + fg * 8);
+            ka1 = *(const uint4*)(kb + (long)(t0 + 16 + fr) * 16 + fg * 8);
         }
         const uint2 v0 = *(const uint2*)(vb + t0 + fg * 4), v1 = *(const uint2*)(vb + t0 + 16 + fg * 4);
         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -422,7 +423,13 @@ int wsgemm(const Ctx& cx, const void* A, const void* W, int M, int N, int K, con
 // K | V^T projection of the per-prompt stream as two N = 128 launches (k with the positional table, v transposed)
 int wsgemm_kv(const Ctx& cx, const void* x, const u16* wkv, const float* bkv, const float* pek, int rows, void* k_out,
               void* vT_out) {
-    if (int e = wsgemm(cx, x, wkv, rows, CI, C, bkv, k_out, pek, CI)) return e;
+    {
+        msam_wsgemm_t k{};
+        k.A = x; k.W = wkv; k.M = rows; k.N = CI; k.K = C; k.bias = bkv;
+        k.table = pek; k.table_rows = T; k.table_cols = CI; k.table_ld = CI;
+        k.out = k_out; k.ldc = CI; k.head_major = 1; k.tokens = T;
+        if (int e = msam_wsgemm_bf16(&k, cx.s)) return e;
+    }
     msam_wsgemm_t g{};
     g.A = x; g.W = wkv + (long)CI * C; g.M = rows; g.N = CI; g.K = C; g.bias = bkv + CI;
     g.kv_split = 1; g.vT_out = vT_out; g.tokens = T;
@@ -496,7 +503,7 @@ extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void*
     hipLaunchKernelGGL(src_prepare_kernel, dim3(T / 32, C / 32), dim3(256), 0, cx.s, embedding, dec->no_mask, im.src_f32,
                        im.src_bf16);
     if (int e = msam_check_launch("src_prepare")) return e;
-    if (int e = gemm_kv(cx, im.src_bf16, T, c.wkv[0], c.bkv[0], c.pe_k[0], im.k0, im.vT0)) return e;
+    if (int e = wsgemm_kv(cx, im.src_bf16, c.wkv[0], c.bkv[0], c.pe_k[0], T, im.k0, im.vT0)) return e;
     return gemm(cx, im.src_bf16, C, dec->layer[0].i2t.q_w, T, CI, C, dec->layer[0].i2t.q_b, im.q0, MSAM_BF16, CI, 0,
                 nullptr, 0, 0, 0, c.pe_q[0], CI);
 }

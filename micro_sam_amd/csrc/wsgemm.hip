@@ -24,6 +24,7 @@ struct WsEpi {
     const float* ln_w; const float* ln_b; float ln_eps; int ln_mode;
     u16* out; long ldc;              // plain bf16 output [M, N]
     int kv_split; u16* k_out; u16* vT_out; int tokens;
+    int head_major;                  // plain output as [M/tokens][N/16][tokens][16] (per-head contiguous K for t2i attention)
 };
 
 // 4-bit chunk swizzle: the 16 rows of a ds_read_b128 service group hit 16 distinct 16-byte slots
@@ -160,7 +161,12 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
                 *(float4*)(ldsC + lr * N + col) = make_float4(v[0], v[1], v[2], v[3]);     // all columns go out transposed
             } else if (!e.kv_split) {
                 uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-                *(uint2*)(e.out + row * e.ldc + col) = pk;
+                if (e.head_major) {
+                    const long b = row / e.tokens, t = row - b * e.tokens;
+                    *(uint2*)(e.out + ((b * (N / 16) + (col >> 4)) * e.tokens + t) * 16 + (col & 15)) = pk;
+                } else {
+                    *(uint2*)(e.out + row * e.ldc + col) = pk;
+                }
             } else if (col < 128) {
                 uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
                 *(uint2*)(e.k_out + row * 128 + col) = pk;
@@ -224,6 +230,7 @@ extern "C" int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream) {
         return 1;
     }
     if (!p->kv_split && !p->out) { msam_set_error("msam_wsgemm_bf16: null output"); return 1; }
+    if (p->head_major && (p->kv_split || p->tokens <= 0 || p->M % p->tokens)) { msam_set_error("msam_wsgemm_bf16: bad head_major arguments"); return 1; }
     if (p->ln_mode && (!p->ln_w || !p->ln_b || (p->ln_mode == 1 && p->N != 256) || p->ln_mode < 0 || p->ln_mode > 2)) {
         msam_set_error("msam_wsgemm_bf16: LayerNorm(256) needs N == 256; LayerNorm(64 groups) needs ln_w / ln_b");
         return 1;
@@ -234,6 +241,7 @@ extern "C" int msam_wsgemm_bf16(const msam_wsgemm_t* p, void* stream) {
     e.ln_w = p->ln_w; e.ln_b = p->ln_b; e.ln_eps = p->ln_eps; e.ln_mode = p->ln_mode;
     e.out = (u16*)p->out; e.ldc = p->ldc; e.kv_split = p->kv_split; e.k_out = (u16*)p->k_out; e.vT_out = (u16*)p->vT_out;
     e.tokens = p->tokens > 0 ? p->tokens : 64;
+    e.head_major = p->head_major;
     hipStream_t s = (hipStream_t)stream;
     const u16* A = (const u16*)p->A; const u16* W = (const u16*)p->W;
     if (p->N == 256 && p->K == 256) return launch<256, 256>(A, W, p->M, e, s);

@@ -230,7 +230,7 @@ def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> 
 def wsgemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, table: Optional[torch.Tensor] = None,
            table_cols: int = 0, resid: Optional[torch.Tensor] = None, resid_rows: int = 0, ln_mode: int = 0,
            ln_w: Optional[torch.Tensor] = None, ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-           kv_split_tokens: int = 0, out: Optional[torch.Tensor] = None):
+           kv_split_tokens: int = 0, out: Optional[torch.Tensor] = None, head_major_tokens: int = 0):
     """Weights-stationary decoder GEMM (see include/msam_hip.h).  Returns out bf16 [M,N], or (k, vT) with kv_split_tokens."""
     _lib.require_gpu()
     M, K = a.shape
@@ -255,6 +255,8 @@ def wsgemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if out is None:
             out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
         p.out, p.ldc = out.data_ptr(), N
+        if head_major_tokens:
+            p.head_major, p.tokens = 1, head_major_tokens
         ret = out
     _lib.check(_lib.load().msam_wsgemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_wsgemm_bf16")
     return ret

@@ -222,6 +222,8 @@ def test_wsgemm_epilogues(env, N, K):
         lw = (torch.randn(64, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(64, generator=g).to(dev)
         ref2 = F.gelu(F.layer_norm(base.reshape(M, 2, 64), (64,), lw, lb, eps=1e-6)).reshape(M, 128)
         assert _close(ops.wsgemm(a, w, bias, ln_mode=2, ln_w=lw, ln_b=lb, ln_eps=1e-6), ref2, 2e-2, 1e-2)
+        hm = ops.wsgemm(a, w, bias, head_major_tokens=T)                        # [P][8 heads][T][16]
+        assert _close(hm.reshape(P, 8, T, 16), base.reshape(P, T, 8, 16).permute(0, 2, 1, 3), 3e-2, 1e-2)
         _, vT = ops.wsgemm(a, w, bias, kv_split_tokens=T)                      # N = 128: all columns transposed
         assert _close(vT, base.reshape(P, T, 128).permute(0, 2, 1), 3e-2, 1e-2)
 
