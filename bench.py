@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--glds", type=int, default=0)
+    ap.add_argument("--device-chunk", type=int, default=1024,
+                    help="grid prompts decoded per decoder pass (results do not depend on it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,7 +85,7 @@ def main():
     predictor = util.get_sam_model("vit_b", device=dev, state_dict=sd)
     predictor.model.use_glds = args.glds
     predictor.model.image_encoder.use_glds = args.glds
-    amg = AutomaticMaskGenerator(predictor)          # reference defaults: 32x32 grid, 64 points per batch
+    amg = AutomaticMaskGenerator(predictor, device_chunk=args.device_chunk)   # reference defaults: 32x32 grid, 64 points per batch
 
     n_steps = args.warmup + args.steps
     # distinct synthetic tiles per rank and step (seed = global tile index), staged in HBM before timing

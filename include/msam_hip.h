@@ -98,6 +98,19 @@ typedef struct {
 } msam_image_layer_t;
 int msam_decoder_image_layer(const msam_image_layer_t* p, void* stream);
 
+/* Token -> image cross attention with the K / V projections folded into the token side (reference:
+ * segment_anything/modeling/transformer.py Attention as called by TwoWayAttentionBlock.cross_attn_token_to_image and
+ * TwoWayTransformer.final_attn_token_to_image):
+ *   S = (keys + pe) Wk^T q / 4 is evaluated as keys . (Wk^T q) + (pe Wk^T + bk) . q, and softmax(S) (keys Wv^T + bv) as
+ *   (softmax(S) keys) Wv^T + bv, so the per-prompt image-token stream is read once and no K / V stream is written.
+ * keys: bf16 [Pk,4096,256] (kv_shared != 0: every prompt uses prompt 0's stream); qtok: bf16 [P,Nt,128] projected
+ * queries, 1 <= Nt <= 8; wk, wv: bf16 [128,256]; tabk: bf16 [4096,128] = pe Wk^T + bk; bv fp32 [128];
+ * out: bf16 [P,Nt,128] (input of the attention's out_proj).  workspace >= msam_t2i_fold_workspace_bytes(P). */
+int64_t msam_t2i_fold_workspace_bytes(int32_t P);
+int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, const void* qtok, int32_t P, int32_t Nt, const void* wk,
+                            const void* tabk, const void* wv, const float* bv, void* out, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and

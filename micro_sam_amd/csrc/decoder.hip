@@ -438,8 +438,9 @@ int wsgemm_kv(const Ctx& cx, const void* x, const u16* wkv, const float* bkv, co
 
 struct Consts {     // layout of the `consts` buffer
     float* pos_f32; u16* pos_bf16; float* pe_k[3]; float* pe_q[2]; u16* wkv[3]; float* bkv[3];
+    u16* tab_k[3];  // bf16(pos Wk^T + bk): score table of the folded token->image attention (t2ifold.hip)
 };
-constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4;
+constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4 + 3L * T * CI * 2;
 
 Consts carve_consts(void* base) {
     Consts c; char* p = (char*)base;
@@ -449,6 +450,7 @@ Consts carve_consts(void* base) {
     for (int i = 0; i < 2; ++i) { c.pe_q[i] = (float*)p; p += (long)T * CI * 4; }
     for (int i = 0; i < 3; ++i) { c.wkv[i] = (u16*)p; p += (long)C * C * 2; }
     for (int i = 0; i < 3; ++i) { c.bkv[i] = (float*)p; p += (long)C * 4; }
+    for (int i = 0; i < 3; ++i) { c.tab_k[i] = (u16*)p; p += (long)T * CI * 2; }
     return c;
 }
 
@@ -487,6 +489,7 @@ extern "C" int msam_decoder_prepare_const(const msam_decoder_t* dec, void* const
         hipMemcpyAsync(c.bkv[i] + CI, t2i[i]->v_b, CI * 4, hipMemcpyDeviceToDevice, cx.s);
         // pos . Wk^T (no bias): added to the k half through the GEMM table epilogue
         if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, nullptr, c.pe_k[i], MSAM_F32, CI)) return e;
+        if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, t2i[i]->k_b, c.tab_k[i], MSAM_BF16, CI)) return e;
     }
     for (int i = 0; i < 2; ++i)
         if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, nullptr, c.pe_q[i], MSAM_F32, CI)) return e;
@@ -544,6 +547,21 @@ Work carve_work(void* base, int P, int Nt) {
     w.hh0 = (u16*)take((long)P * C * 2); w.hh1 = (u16*)take((long)P * C * 2);
     w.hyper = (float*)take((long)P * 4 * 128 * 4); w.iou_full = (float*)take((long)P * 128 * 4);
     return w;
+}
+
+// token -> image attention over the per-prompt stream w.keys: folded form (one pass over the stream, t2ifold.hip) for
+// up to 8 tokens per prompt, explicit K / V^T projection + attention kernel otherwise
+int t2i_stream(const Ctx& cx, const Work& w, const Consts& c, int idx, const msam_attn_w_t& aw, int P, int Nt) {
+    const long R = (long)P * T;
+    if (Nt <= 8) {
+        // workspace of the folded form = the (then unused) K / V^T / q / attention stream buffers, contiguous in `Work`
+        const int64_t avail = (int64_t)((char*)w.up1 - (char*)w.kimg);
+        return msam_t2i_fold_attention(w.keys, 0, w.qs, P, Nt, aw.k_w, c.tab_k[idx], aw.v_w, aw.v_b, w.attn_tok, w.kimg,
+                                       avail, cx.s);
+    }
+    if (int e = wsgemm_kv(cx, w.keys, c.wkv[idx], c.bkv[idx], c.pe_k[idx], (int)R, w.kimg, w.vT)) return e;
+    hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
+    return msam_check_launch("t2i_attn");
 }
 
 __global__ void gather_iou_kernel(const float* __restrict__ iou_full, int P, int c0, int nc, float* __restrict__ iou) {
@@ -606,12 +624,12 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         ADD_CAST(w.queries, w.qpe, w.a);
         CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_BF16, CI));
         if (li == 0) {
+            // prompt-independent K / V^T of the shared embedding (prepare_image): 1 MiB, L2 resident
             hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
+            CHECK(msam_check_launch("t2i_attn"));
         } else {
-            CHECK(wsgemm_kv(cx, w.keys, c.wkv[1], c.bkv[1], c.pe_k[1], (int)R, w.kimg, w.vT));
-            hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
+            CHECK(t2i_stream(cx, w, c, 1, L.t2i, P, Nt));
         }
-        CHECK(msam_check_launch("t2i_attn"));
         CHECK(gemm(cx, w.attn_tok, CI, L.t2i.o_w, M, C, CI, L.t2i.o_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n2_w, L.n2_b, M, w.queries, MSAM_F32);
         // (3) token MLP
@@ -638,9 +656,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     // final token -> image attention
     ADD_CAST(w.queries, w.qpe, w.a);
     CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_BF16, CI));
-    CHECK(wsgemm_kv(cx, w.keys, c.wkv[2], c.bkv[2], c.pe_k[2], (int)R, w.kimg, w.vT));
-    hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, w.kimg, w.vT, 0, Nt, w.attn_tok);
-    CHECK(msam_check_launch("t2i_attn_final"));
+    CHECK(t2i_stream(cx, w, c, 2, dec->final_attn, P, Nt));
     CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
                MSAM_F32, C));
     LN(w.tmp, dec->nf_w, dec->nf_b, M, w.queries, MSAM_F32);

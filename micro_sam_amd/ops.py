@@ -325,3 +325,19 @@ def decoder_image_layer(xin, ktok, vtok, wo, bo, ln_w, ln_b, Nt, *, q_shared=Non
     p.ktok, p.vtok, p.Nt, p.out, p.rows = ktok.data_ptr(), vtok.data_ptr(), Nt, out.data_ptr(), rows
     _lib.check(_lib.load().msam_decoder_image_layer(C.byref(p), _lib.stream_ptr()), "msam_decoder_image_layer")
     return out
+
+
+def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False):
+    """Token -> image attention with folded K / V projections (include/msam_hip.h msam_t2i_fold_attention).
+    keys bf16 [Pk,4096,256], qtok bf16 [P,Nt,128] (Nt <= 8), wk / wv bf16 [128,256], tabk bf16 [4096,128], bv fp32 [128]
+    -> bf16 [P,Nt,128]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    P, Nt = qtok.shape[0], qtok.shape[1]
+    nbytes = int(lib.msam_t2i_fold_workspace_bytes(P))
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=keys.device)
+    out = torch.empty((P, Nt, 128), dtype=torch.bfloat16, device=keys.device)
+    _lib.check(lib.msam_t2i_fold_attention(keys.data_ptr(), int(kv_shared), qtok.data_ptr(), P, Nt, wk.data_ptr(),
+                                           tabk.data_ptr(), wv.data_ptr(), bv.data_ptr(), out.data_ptr(), work.data_ptr(),
+                                           nbytes, _lib.stream_ptr()), "msam_t2i_fold_attention")
+    return out

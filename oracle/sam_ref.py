@@ -324,9 +324,14 @@ def prompt_encoder(sd: Dict[str, Tensor], points: Optional[Tuple[Tensor, Tensor]
 # ----------------------------------------------------------------------------------------------
 
 def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads: int = 8,
-                   q_pe: Optional[Tensor] = None, k_pe: Optional[Tensor] = None, mfma_pv: bool = False) -> Tensor:
+                   q_pe: Optional[Tensor] = None, k_pe: Optional[Tensor] = None, mfma_pv: bool = False,
+                   fold: bool = False) -> Tensor:
     """q_pe / k_pe: positional encodings of the IMAGE-side operand.  fp32 mode adds them before the projection
-    (upstream); bf16 mode follows the HIP dataflow (x + pe) W = x W + pe W with separately rounded operands."""
+    (upstream); bf16 mode follows the HIP dataflow (x + pe) W = x W + pe W with separately rounded operands.
+    fold (bf16 mode only, token->image attention over the per-prompt stream with <= 8 tokens): the HIP path folds the
+    K / V projections into the token side (csrc/t2ifold.hip) - same mathematics, different bf16 rounding points."""
+    if p.bf16 and fold and q.shape[1] <= 8:
+        return _dec_attention_folded(sd, pre, q, k, p, heads, k_pe)
     def proj(x, pe, name):
         w, b = sd[pre + name + ".weight"], sd[pre + name + ".bias"]
         if pe is None:
@@ -353,6 +358,27 @@ def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads
     return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
 
 
+def _dec_attention_folded(sd, pre: str, q: Tensor, keys: Tensor, p: Prec, heads: int, k_pe: Tensor) -> Tensor:
+    """bf16 emulation of csrc/t2ifold.hip: S = keys . bf16(Wk_h^T q_h) + bf16(pe Wk^T + bk)_h . q_h, un-normalised
+    probabilities rounded to bf16 for the P . keys MFMA, context kept in fp32 for the per-head value projection."""
+    wk, bk = sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]
+    wv, bv = sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]
+    q = p.r(p.linear(q, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]))            # [b, nq, 128]
+    b, nq, ci = q.shape
+    hd = ci // heads
+    qh = q.reshape(b, nq, heads, hd).transpose(1, 2)                                     # [b, h, nq, 16]
+    wkh = p.r(wk).reshape(heads, hd, -1)                                                 # [h, 16, 256]
+    qf = p.r(torch.einsum("bhtd,hdc->bhtc", qh, wkh))                                    # folded queries, bf16
+    tab = p.r(p.linear(k_pe[:1], wk, bk))[0].reshape(-1, heads, hd)                      # [T, h, 16]
+    keys = p.r(keys)
+    s = (torch.einsum("bhtc,bjc->bhtj", qf, keys) + torch.einsum("bhtd,jhd->bhtj", qh, tab)) / math.sqrt(hd)
+    e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
+    ctx = torch.einsum("bhtj,bjc->bhtc", p.r(e), keys) / e.sum(dim=-1, keepdim=True)     # [b, h, nq, 256] fp32
+    out = torch.einsum("bhtc,hdc->bhtd", ctx, p.r(wv).reshape(heads, hd, -1)) + bv.reshape(1, heads, 1, hd)
+    out = out.transpose(1, 2).reshape(b, nq, ci)
+    return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+
+
 def _ln(sd, pre: str, x: Tensor, eps: float = 1e-5) -> Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[pre + "weight"], sd[pre + "bias"], eps=eps)
 
@@ -376,7 +402,7 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
         queries = _ln(sd, lp + "norm1.", queries)
         q = queries + query_pe
         queries = queries + _dec_attention(sd, lp + "cross_attn_token_to_image.", q, keys, keys, p, k_pe=key_pe,
-                                           mfma_pv=True)
+                                           mfma_pv=True, fold=i > 0)
         queries = _ln(sd, lp + "norm2.", queries)
         m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"])
         m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"])
@@ -390,7 +416,7 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
             debug[f"keys{i}"] = keys.clone()
     q = queries + query_pe
     queries = queries + _dec_attention(sd, pre + "final_attn_token_to_image.", q, keys, keys, p, k_pe=key_pe,
-                                       mfma_pv=True)
+                                       mfma_pv=True, fold=True)
     queries = _ln(sd, pre + "norm_final_attn.", queries)
     if debug is not None:
         debug["queries_final"] = queries.clone()

@@ -267,3 +267,32 @@ def test_decoder_image_layer_fused(env, layer0, Nt):
         x2 = x.clone()
         ops.decoder_image_layer(x2, ktok, vtok, wo, bo, lw, lb, Nt, wq=wq, bq=bq, peq=peq, out=x2)
         assert _close(x2, ref, 3e-2, 2e-2)
+
+
+@pytest.mark.parametrize("P,Nt,shared", [(3, 7, False), (2, 8, False), (40, 5, True), (600, 7, True)])
+def test_t2i_fold_attention(env, P, Nt, shared):
+    """Folded token->image attention (one pass over the stream) vs the unfolded fp32 formulation of the reference:
+    softmax((keys + pe) Wk^T + bk) . q / 4) (keys Wv^T + bv), all key-split counts (P = 3 -> 16 splits ... 600 -> 1)."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(77 + P)
+    T = 4096
+    Pk = 1 if shared else P
+    keys = _bf(torch.randn(Pk, T, 256, generator=g)).to(dev)
+    pe = torch.randn(T, 256, generator=g).to(dev)
+    wk = _bf(torch.randn(128, 256, generator=g) / 16).to(dev)
+    wv = _bf(torch.randn(128, 256, generator=g) / 16).to(dev)
+    bk = torch.randn(128, generator=g).to(dev); bv = torch.randn(128, generator=g).to(dev)
+    qtok = _bf(torch.randn(P, Nt, 128, generator=g) * 1.5).to(dev)
+    tab = pe @ wk.float().t() + bk
+    tabk = tab.to(torch.bfloat16)
+    out = ops.t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, kv_shared=shared)
+    kf = keys.float().expand(P, T, 256)
+    K = kf @ wk.float().t() + tabk.float()                                      # [P,T,128]
+    V = kf @ wv.float().t() + bv
+    qh = qtok.float().reshape(P, Nt, 8, 16).permute(0, 2, 1, 3)
+    kh = K.reshape(P, T, 8, 16).permute(0, 2, 1, 3)
+    vh = V.reshape(P, T, 8, 16).permute(0, 2, 1, 3)
+    a = torch.softmax((qh @ kh.transpose(-1, -2)) / 4.0, dim=-1)
+    ref = (a @ vh).permute(0, 2, 1, 3).reshape(P, Nt, 128)
+    # scores reach |s| ~ 30 with these operands: bf16 rounding of the folded query gives ~1e-2 relative score error
+    assert _close(out, ref, 6e-2, 3e-2)
