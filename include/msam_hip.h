@@ -111,6 +111,19 @@ int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, const void* qto
                             const void* tabk, const void* wv, const float* bv, void* out, void* workspace,
                             int64_t workspace_bytes, void* stream);
 
+/* Image -> token cross attention + out_proj + residual + norm4 of a two-way block with the q / out projections folded
+ * into the (<= 8) prompt tokens (same reference code as msam_decoder_image_layer; TwoWayAttentionBlock.
+ * cross_attn_image_to_token + norm4):
+ *   S = keys . (Wq_h^T k_{t,h}) + (pe Wq^T + bq)_h . k_{t,h},  P = softmax_t(S / 4),
+ *   out = LayerNorm(keys + sum_{h,t} P (Wo[:, 16h:16h+16] v_{t,h}) + bo).
+ * xin: bf16 [Px,4096,256] (x_shared != 0: every prompt reads prompt 0, layer 0); ktok / vtok: bf16 [P,Nt,128] projected
+ * prompt tokens; wq bf16 [128,256]; tabq bf16 [4096,128] = pe Wq^T + bq; wo bf16 [256,128]; out bf16 [P,4096,256], may
+ * alias xin.  workspace >= msam_i2t_fold_workspace_bytes(P). */
+int64_t msam_i2t_fold_workspace_bytes(int32_t P);
+int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void* ktok, const void* vtok, int32_t P, int32_t Nt,
+                        const void* wq, const void* tabq, const void* wo, const float* bo, const float* ln_w,
+                        const float* ln_b, float ln_eps, void* out, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and

@@ -96,6 +96,8 @@ _PROTOS = {
     "msam_decoder_image_layer": (_i32, [C.POINTER(ImageLayerParams), _vp]),
     "msam_t2i_fold_workspace_bytes": (_i64, [_i32]),
     "msam_t2i_fold_attention": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "msam_i2t_fold_workspace_bytes": (_i64, [_i32]),
+    "msam_i2t_fold_layer": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _vp]),
     "msam_profile_enable": (_i32, [_i32]),
     "msam_profile_collect": (_i32, [C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "msam_profile_collect_family": (_i32, [_i32 * 2, C.c_double * 2, C.c_double * 2, C.c_double * 2]),

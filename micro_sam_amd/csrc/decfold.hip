@@ -1,0 +1,598 @@
+// Token -> image cross attention of the mask decoder with the K / V projections FOLDED into the token side
+// (SURVEY.md A.4 step (2) and the final attention; reference: segment_anything two-way transformer `Attention`):
+//
+//     S[j][(h,t)] = (keys_j + pe_j) Wk_h^T . q_{h,t} / 4  =  keys_j . Q'_{h,t} / 4 + tabK_{j,h} . q_{h,t} / 4
+//         Q'_{h,t} = Wk_h^T q_{h,t}  (256 channels),  tabK = pe Wk^T + bk  (prompt independent table)
+//     out_{h,t}   = softmax_j(S) (keys_j Wv_h^T + bv_h)  =  (softmax_j(S) keys) Wv_h^T + bv_h
+//
+// The 4096 x 256 per-prompt image-token stream is therefore read ONCE per attention (2 MiB / prompt) instead of being
+// projected to K and V^T (two more streams written and read back): 4x less HBM traffic on this path, and fewer MFMA flops
+// (the 8 x 8 = 64 folded queries per prompt are cheaper than two 256 -> 128 projections of 4096 tokens).
+//
+// Main kernel: 4 waves, wave w owns the 16 score columns of heads 2w, 2w+1 (col = (h & 1) * 8 + t).  Per 32-key tile
+// (staged global -> registers two tiles ahead -> LDS double buffer):
+//     S^T = keys . Q'^T           8 MFMA 16x16x32 per 16-key block, A = keys rows (ds_read_b128), B = Q' (32 VGPRs, resident)
+//         + tabK . q (block diag) 1 MFMA, K = 32 = the two heads' 16 channels
+//     online softmax per lane column (transposed-score form, see attention.hip)
+//     O'^T[c][(h,t)] += keys^T P^T   16 MFMA, A = keys^T through ds_read_b64_tr_b16 (hardware 4x4 transpose, LDS image is
+//                                    [16 channel tiles][32 keys][16 channels] with the 16-B halves of a row swapped on
+//                                    key bit 3 so that the b128 score reads are bank-conflict free as well), B = P^T
+//                                    straight from the score registers
+// (m, l, O') partials go to a fp32 workspace ([P][KS][64][256], KS key splits when there are few prompts); the finish
+// kernel merges the splits, normalises and applies the per-head 256 -> 16 value projection.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int family);
+
+namespace {
+
+constexpr int T = 4096, C = 256, CI = 128, TK = 32, NTHR = 256;
+constexpr int KEYS_BYTES = TK * C * 2, TAB_BYTES = TK * CI * 2, BUF_BYTES = KEYS_BYTES + TAB_BYTES;
+constexpr float NEG_BIG = -1.0e30f;
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+MSAM_DEVINL uint2 lds_tr16(const unsigned char* p) {
+    s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
+// Q'[p][h*8 + t][c] = sum_d q[p][t][h*16 + d] Wk[h*16 + d][c]   (zero rows for t >= Nt)
+__global__ __launch_bounds__(256) void fold_q_kernel(const u16* __restrict__ qtok, const u16* __restrict__ wk, int Nt,
+                                                     u16* __restrict__ qprime) {
+    __shared__ float q[8][16];
+    const int p = blockIdx.x >> 3, h = blockIdx.x & 7, c = threadIdx.x;
+    if (c < 128) {
+        const int t = c >> 4, d = c & 15;
+        q[t][d] = t < Nt ? bf2f(qtok[((long)p * Nt + t) * CI + h * 16 + d]) : 0.f;
+    }
+    __syncthreads();
+    float w[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) w[d] = bf2f(wk[(h * 16 + d) * C + c]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) a = fmaf(q[t][d], w[d], a);
+        qprime[(((long)p * 64) + h * 8 + t) * C + c] = f2bf(a);
+    }
+}
+
+struct FoldArgs {
+    const u16* keys; int kv_shared;      // bf16 [Pk, 4096, 256]
+    const u16* qprime;                   // bf16 [P, 64, 256]
+    const u16* qtok; int Nt;             // bf16 [P, Nt, 128]
+    const u16* tabk;                     // bf16 [4096, 128]
+    int nitems, KS;                      // work items (prompt, key split)
+    float* opart;                        // fp32 [P, KS, 64, 256]
+    float* stats;                        // fp32 [P, KS, 64, 2]  (m, l)
+};
+
+__global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int TPI = (T / TK) / a.KS;                                  // tiles per item
+    const int my_items = (a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nq = my_items * TPI;
+    if (nq <= 0) return;
+
+    // ---- staging: 4 keys chunks + 2 table chunks (16 B) per thread and tile
+    uint4 ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5;
+    int kdst[4], tdst[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
+        kdst[i] = (c >> 1) * 1024 + row * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = i * NTHR + tid, row = id >> 4, c = id & 15;
+        tdst[i] = KEYS_BYTES + row * 256 + ((c ^ (row & 15)) << 4);
+    }
+    auto tile_src = [&](int q, const u16*& kp, const u16*& tp) {
+        const int item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
+        const int p = item / a.KS, ks = item - p * a.KS;
+        const int key0 = ks * (T / a.KS) + (q % TPI) * TK;
+        kp = a.keys + ((long)(a.kv_shared ? 0 : p) * T + key0) * C;
+        tp = a.tabk + (long)key0 * CI;
+    };
+#define FA_LOAD(r0_, r1_, r2_, r3_, r4_, r5_, q_)                                                  \
+    do {                                                                                           \
+        const u16 *kp_, *tp_;                                                                      \
+        tile_src(q_, kp_, tp_);                                                                    \
+        r0_ = *(const uint4*)(kp_ + (0 * NTHR + tid) * 8); r1_ = *(const uint4*)(kp_ + (1 * NTHR + tid) * 8); \
+        r2_ = *(const uint4*)(kp_ + (2 * NTHR + tid) * 8); r3_ = *(const uint4*)(kp_ + (3 * NTHR + tid) * 8); \
+        r4_ = *(const uint4*)(tp_ + (0 * NTHR + tid) * 8); r5_ = *(const uint4*)(tp_ + (1 * NTHR + tid) * 8); \
+    } while (0)
+#define FA_STORE(r0_, r1_, r2_, r3_, r4_, r5_, buf_)                                               \
+    do {                                                                                           \
+        unsigned char* b_ = lds + (buf_) * BUF_BYTES;                                              \
+        *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_; *(uint4*)(b_ + kdst[2]) = r2_; \
+        *(uint4*)(b_ + kdst[3]) = r3_; *(uint4*)(b_ + tdst[0]) = r4_; *(uint4*)(b_ + tdst[1]) = r5_; \
+    } while (0)
+
+    // ---- per-lane LDS read offsets
+    int koff[2], toff[2], troff[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int key = b * 16 + fr;
+        koff[b] = (fg >> 1) * 1024 + key * 32 + (((fg & 1) ^ ((key >> 3) & 1)) << 4);
+        toff[b] = KEYS_BYTES + key * 256 + (((w * 4 + fg) ^ fr) << 4);
+        const int tkey = b * 16 + fg * 4 + (fr >> 2), cc = fr & 3;
+        troff[b] = tkey * 32 + ((((cc >> 1) ^ (fg >> 1)) & 1) << 4) + (cc & 1) * 8;
+    }
+
+    uint4 qb[8], qd;
+    f32x4_t acc[16];
+    float m = NEG_BIG, l = 0.f;
+    int item = 0;
+
+    FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, 0);
+    FA_STORE(ra0, ra1, ra2, ra3, ra4, ra5, 0);
+    if (1 < nq) FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, 1);
+    __syncthreads();
+
+    int q = 0, buf = 0;
+    auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& p4, uint4& p5, uint4& f0, uint4& f1, uint4& f2,
+                         uint4& f3, uint4& f4, uint4& f5) {
+        if (q + 2 < nq) FA_LOAD(f0, f1, f2, f3, f4, f5, q + 2);
+        const int tt = q % TPI;
+        if (tt == 0) {                                   // new work item: folded queries of this wave's two heads
+            item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
+            const int p = item / a.KS;
+            const u16* qp = a.qprime + (((long)p * 64) + w * 16 + fr) * C + fg * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qb[ks] = *(const uint4*)(qp + ks * 32);
+            const int hh = fr >> 3, t = fr & 7;
+            qd = make_uint4(0, 0, 0, 0);
+            if ((fg >> 1) == hh && t < a.Nt)
+                qd = *(const uint4*)(a.qtok + ((long)p * a.Nt + t) * CI + (2 * w + hh) * 16 + (fg & 1) * 8);
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            m = NEG_BIG; l = 0.f;
+        }
+        const unsigned char* B = lds + buf * BUF_BYTES;
+        // ---- scores of the two 16-key blocks
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const uint4 a0 = *(const uint4*)(B + koff[0] + ks * 2048);
+            const uint4 a1 = *(const uint4*)(B + koff[1] + ks * 2048);
+            s0 = mfma16(a0, qb[ks], s0);
+            s1 = mfma16(a1, qb[ks], s1);
+        }
+        s0 = mfma16(*(const uint4*)(B + toff[0]), qd, s0);
+        s1 = mfma16(*(const uint4*)(B + toff[1]), qd, s1);
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] *= 0.25f; s1[r] *= 0.25f; mt = fmaxf(mt, fmaxf(s0[r], s1[r])); }
+        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float mn = fmaxf(m, mt), alpha = __expf(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mn); s1[r] = __expf(s1[r] - mn); ps += s0[r] + s1[r]; }
+        l = l * alpha + ps;
+        uint4 pb;
+        pb.x = pack2bf(s0[0], s0[1]); pb.y = pack2bf(s0[2], s0[3]); pb.z = pack2bf(s1[0], s1[1]); pb.w = pack2bf(s1[2], s1[3]);
+        // ---- O'^T += keys^T P^T over the 16 channel tiles
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) {
+            const uint2 t0 = lds_tr16(B + ct * 1024 + troff[0]);
+            const uint2 t1 = lds_tr16(B + ct * 1024 + troff[1]);
+            f32x4_t o = acc[ct];
+            o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
+            acc[ct] = mfma16(make_uint4(t0.x, t0.y, t1.x, t1.y), pb, o);
+        }
+        if (tt == TPI - 1) {                             // work item complete: (m, l, O') partial of this key split
+            float lt = l;
+            lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
+            const long col = (long)item * 64 + w * 16 + fr;
+            if (fg == 0) { a.stats[col * 2] = m; a.stats[col * 2 + 1] = lt; }
+            float* op = a.opart + col * C + fg * 4;
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct)
+                *(float4*)(op + ct * 16) = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+        }
+        if (q + 1 < nq) FA_STORE(p0, p1, p2, p3, p4, p5, buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    };
+    while (true) {
+        iteration(ra0, ra1, ra2, ra3, ra4, ra5, rb0, rb1, rb2, rb3, rb4, rb5);
+        if (++q >= nq) break;
+        iteration(rb0, rb1, rb2, rb3, rb4, rb5, ra0, ra1, ra2, ra3, ra4, ra5);
+        if (++q >= nq) break;
+    }
+#undef FA_LOAD
+#undef FA_STORE
+}
+
+// merge the key splits, normalise, per-head value projection: out[p][t][h*16 + d] = ctx_{h,t} . Wv[h*16 + d] + bv
+__global__ __launch_bounds__(128) void fold_finish_kernel(const float* __restrict__ opart, const float* __restrict__ stats,
+                                                          int KS, int Nt, const u16* __restrict__ wv,
+                                                          const float* __restrict__ bv, u16* __restrict__ out) {
+    __shared__ float ctx[8][C + 4];
+    __shared__ float scale[8][16];
+    const int p = blockIdx.x >> 3, h = blockIdx.x & 7, tid = threadIdx.x;
+    if (tid < 8) {
+        const int t = tid;
+        float mm = NEG_BIG;
+        for (int k = 0; k < KS; ++k) mm = fmaxf(mm, stats[(((long)p * KS + k) * 64 + h * 8 + t) * 2]);
+        float ll = 0.f;
+        for (int k = 0; k < KS; ++k) {
+            const float* st = stats + (((long)p * KS + k) * 64 + h * 8 + t) * 2;
+            const float e = __expf(st[0] - mm);
+            scale[t][k] = e; ll += e * st[1];
+        }
+        const float inv = 1.f / ll;
+        for (int k = 0; k < KS; ++k) scale[t][k] *= inv;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 8 * C; idx += 128) {
+        const int t = idx >> 8, c = idx & (C - 1);
+        float v = 0.f;
+        for (int k = 0; k < KS; ++k) v += scale[t][k] * opart[(((long)p * KS + k) * 64 + h * 8 + t) * C + c];
+        ctx[t][c] = v;
+    }
+    __syncthreads();
+    const int t = tid >> 4, d = tid & 15;
+    if (t >= Nt) return;
+    const u16* wr = wv + (long)(h * 16 + d) * C;
+    float acc = bv[h * 16 + d];
+#pragma unroll 4
+    for (int c8 = 0; c8 < C / 8; ++c8) {
+        const uint4 wq = *(const uint4*)(wr + c8 * 8);
+        const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            acc = fmaf(ctx[t][c8 * 8 + 2 * x], bf2f((u16)(ww[x] & 0xffff)), acc);
+            acc = fmaf(ctx[t][c8 * 8 + 2 * x + 1], bf2f((u16)(ww[x] >> 16)), acc);
+        }
+    }
+    out[((long)p * Nt + t) * CI + h * 16 + d] = f2bf(acc);
+}
+
+// ============================================================================================================
+// Image -> token cross attention + out-projection + residual + LayerNorm, same folding:
+//     S[j][(h,t)] = ((keys_j + pe_j) Wq_h^T + bq_h) . k_{t,h} / 4 = keys_j . K'_{h,t} / 4 + tabQ_{j,h} . k_{t,h} / 4
+//         K'_{h,t} = Wq_h^T k_{t,h},  tabQ = pe Wq^T + bq
+//     P = softmax over the <= 8 prompt tokens t of each head
+//     keys_j <- LayerNorm(keys_j + sum_{(h,t)} P[j][(h,t)] V'_{h,t} + bo),   V'_{h,t} = Wo[:, 16h : 16h+16] v_{t,h}
+// i.e. per 32-token tile two 32 x 256 x 64 products against per-prompt operands K', V' (32 KB each) instead of the two
+// 256 x 128 weight matrices - half the MFMA work, and the stationary operands of one prompt fit the registers of a
+// 4-wave workgroup (32 + 32 VGPRs per lane), so two workgroups per CU stream independently (the weights-stationary
+// form needed a 16-wave wave-specialised workgroup, declayer.hip, kept for > 8 tokens per prompt).
+//
+// Wave w: scores of heads 2w, 2w+1 (transposed form: rows (h,t), columns image tokens; the softmax over t is 4 registers
+// + one cross-lane exchange), normalised P^T as bf16 to LDS [token][64]; then the 64 output channels 64w .. 64w+63
+// (O^T = V'^T P^T, rows channels, columns tokens), residual from the LDS stream tile, LayerNorm statistics across the
+// four waves through LDS, result written into the stream tile in place and copied out with coalesced 16-byte stores.
+struct I2tArgs {
+    const u16* xin; int x_shared;        // bf16 [Px, 4096, 256] (x_shared: every prompt reads prompt 0)
+    const u16* kfold;                    // bf16 [P, 64, 256]   K'
+    const u16* vfoldT;                   // bf16 [P, 256, 64]   V'^T
+    const u16* ktok; int Nt;             // bf16 [P, Nt, 128]
+    const u16* tabq;                     // bf16 [4096, 128]
+    const float* bo; const float* ln_w; const float* ln_b; float eps;
+    int nitems, KS;
+    u16* out;                            // bf16 [P, 4096, 256] (may alias xin)
+};
+
+constexpr int PT_BYTES = TK * 64 * 2;
+// stream tile in LDS: 8 k-step sub-tiles [32 tokens][64 B] (+64 B pad so that the staging stores of one row spread over
+// the four bank windows), 16-byte slot' = slot ^ ((token >> 2) & 3): conflict-free b128 operand reads with the k-step as
+// an immediate offset
+constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;
+
+__global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + PT_BYTES];
+    __shared__ float red[4][TK][2];
+    __shared__ __attribute__((aligned(16))) float prm[3][C];                  // bo, ln_w, ln_b
+    unsigned char* const PT = lds + 2 * XT_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int TPI = (T / TK) / a.KS;
+    const int my_items = (a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nq = my_items * TPI;
+    if (nq <= 0) return;
+    prm[0][tid] = a.bo[tid]; prm[1][tid] = a.ln_w[tid]; prm[2][tid] = a.ln_b[tid];
+
+    // ---- staging: 4 chunks (16 B) of the stream tile per thread
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    int kdst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
+        kdst[i] = (c >> 2) * SUB_BYTES + row * 64 + (((c & 3) ^ ((row >> 2) & 3)) << 4);
+    }
+    auto tile_pos = [&](int q, int& p, int& key0) {
+        const int item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
+        p = item / a.KS;
+        key0 = (item - p * a.KS) * (T / a.KS) + (q % TPI) * TK;
+    };
+#define FI_LOAD(r0_, r1_, r2_, r3_, q_)                                                            \
+    do {                                                                                           \
+        int p_, k0_;                                                                               \
+        tile_pos(q_, p_, k0_);                                                                     \
+        const u16* kp_ = a.xin + ((long)(a.x_shared ? 0 : p_) * T + k0_) * C;                      \
+        r0_ = *(const uint4*)(kp_ + (0 * NTHR + tid) * 8); r1_ = *(const uint4*)(kp_ + (1 * NTHR + tid) * 8); \
+        r2_ = *(const uint4*)(kp_ + (2 * NTHR + tid) * 8); r3_ = *(const uint4*)(kp_ + (3 * NTHR + tid) * 8); \
+    } while (0)
+#define FI_STORE(r0_, r1_, r2_, r3_, buf_)                                                         \
+    do {                                                                                           \
+        unsigned char* b_ = lds + (buf_) * XT_BYTES;                                               \
+        *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_; *(uint4*)(b_ + kdst[2]) = r2_; \
+        *(uint4*)(b_ + kdst[3]) = r3_;                                                             \
+    } while (0)
+    // table operand of the NEXT tile (B fragment: token fr / 16 + fr, channels 32w + fg*8 ..), straight from L2
+#define FI_TAB(q_)                                                                                 \
+    do {                                                                                           \
+        int p_, k0_;                                                                               \
+        tile_pos(q_, p_, k0_);                                                                     \
+        const u16* tp_ = a.tabq + ((long)k0_ + fr) * CI + w * 32 + fg * 8;                         \
+        tb0 = *(const uint4*)tp_; tb1 = *(const uint4*)(tp_ + 16 * CI);                            \
+    } while (0)
+
+    uint4 kq[8], vq[4][2], kd, tb0, tb1;
+    const int hh_row = fr >> 3, t_row = fr & 7;           // A-operand row fr of this wave's score tile = (head 2w+hh, token t)
+    // per-lane LDS offsets: operand reads (token fr, slot fg), residual / result (token fr, channels (4w+i)*16 + fg*4 ..)
+    const int boff = fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);
+    int xoff[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        xoff[e] = (2 * w) * SUB_BYTES + fr * 64 + ((((e * 2 + (fg >> 1)) ^ ((fr >> 2) & 3)) & 3) << 4) + (fg & 1) * 8;
+
+    FI_LOAD(ra0, ra1, ra2, ra3, 0);
+    FI_TAB(0);
+    FI_STORE(ra0, ra1, ra2, ra3, 0);
+    if (1 < nq) FI_LOAD(ra0, ra1, ra2, ra3, 1);
+    __syncthreads();
+
+    int q = 0, buf = 0;
+    auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& f0, uint4& f1, uint4& f2, uint4& f3) {
+        if (q + 2 < nq) FI_LOAD(f0, f1, f2, f3, q + 2);
+        int p, key0;
+        tile_pos(q, p, key0);
+        if (q % TPI == 0) {                              // new work item: this prompt's folded operands
+            const u16* kp = a.kfold + (((long)p * 64) + w * 16 + fr) * C + fg * 8;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kq[ks] = *(const uint4*)(kp + ks * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u16* vp = a.vfoldT + (((long)p * C) + (w * 4 + i) * 16 + fr) * 64 + fg * 8;
+                vq[i][0] = *(const uint4*)vp; vq[i][1] = *(const uint4*)(vp + 32);
+            }
+            kd = make_uint4(0, 0, 0, 0);
+            if ((fg >> 1) == hh_row && t_row < a.Nt)
+                kd = *(const uint4*)(a.ktok + ((long)p * a.Nt + t_row) * CI + (2 * w + hh_row) * 16 + (fg & 1) * 8);
+        }
+        unsigned char* B = lds + buf * XT_BYTES;
+        // ---- S^T (rows (h,t) of heads 2w, 2w+1; two 16-token column tiles)
+        f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const uint4 b0 = *(const uint4*)(B + boff + ks * SUB_BYTES);
+            const uint4 b1 = *(const uint4*)(B + boff + ks * SUB_BYTES + 16 * 64);
+            s0 = mfma16(kq[ks], b0, s0);
+            s1 = mfma16(kq[ks], b1, s1);
+        }
+        s0 = mfma16(kd, tb0, s0);
+        s1 = mfma16(kd, tb1, s1);
+        if (q + 1 < nq) FI_TAB(q + 1);
+        // softmax over the 8 tokens of a head: rows fg*4 + r, i.e. token (fg & 1) * 4 + r of head 2w + (fg >> 1)
+        {
+            float m0 = NEG_BIG, m1 = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = (fg & 1) * 4 + r < a.Nt;
+                s0[r] = ok ? s0[r] * 0.25f : NEG_BIG; s1[r] = ok ? s1[r] * 0.25f : NEG_BIG;
+                m0 = fmaxf(m0, s0[r]); m1 = fmaxf(m1, s1[r]);
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 16)); m1 = fmaxf(m1, __shfl_xor(m1, 16));
+            float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - m0); s1[r] = __expf(s1[r] - m1); l0 += s0[r]; l1 += s1[r]; }
+            l0 += __shfl_xor(l0, 16); l1 += __shfl_xor(l1, 16);
+            const float i0 = 1.f / l0, i1 = 1.f / l1;
+            uint2 q0, q1;
+            q0.x = pack2bf(s0[0] * i0, s0[1] * i0); q0.y = pack2bf(s0[2] * i0, s0[3] * i0);
+            q1.x = pack2bf(s1[0] * i1, s1[1] * i1); q1.y = pack2bf(s1[2] * i1, s1[3] * i1);
+            // P^T tile [token][64 (h,t)] bf16, 128-byte rows, chunk' = chunk ^ ((token >> 1) & 7)  ((16 + fr) >> 1 & 7 == fr >> 1 & 7)
+            const int po = fr * 128 + (((2 * w + (fg >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fg & 1) * 8;
+            *(uint2*)(PT + po) = q0;
+            *(uint2*)(PT + po + 16 * 128) = q1;
+        }
+        __syncthreads();                                 // (A) P^T complete
+        // ---- O^T for channels 64w .. 64w+63
+        f32x4_t o[4][2];
+        {
+            uint4 pf[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int po = fr * 128 + (((kk * 4 + fg) ^ ((fr >> 1) & 7)) << 4);
+                pf[0][kk] = *(const uint4*)(PT + po);
+                pf[1][kk] = *(const uint4*)(PT + po + 16 * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                    c = mfma16(vq[i][0], pf[n][0], c);
+                    c = mfma16(vq[i][1], pf[n][1], c);
+                    o[i][n] = c;
+                }
+        }
+        // residual + bias; LayerNorm partial sums over this wave's 64 channels.  lane: token n*16 + fr, channels
+        // (4w + i)*16 + fg*4 + r  (sub-tile 2w + (i >> 1), slot (i & 1)*2 + (fg >> 1), byte (fg & 1)*8)
+        float s1a[2] = {0.f, 0.f}, s2a[2] = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 bo4 = *(const float4*)&prm[0][(w * 4 + i) * 16 + fg * 4];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const uint2 xr = *(const uint2*)(B + xoff[i & 1] + (i >> 1) * SUB_BYTES + n * 16 * 64);
+                o[i][n][0] += bo4.x + bf2f((u16)(xr.x & 0xffff)); o[i][n][1] += bo4.y + bf2f((u16)(xr.x >> 16));
+                o[i][n][2] += bo4.z + bf2f((u16)(xr.y & 0xffff)); o[i][n][3] += bo4.w + bf2f((u16)(xr.y >> 16));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s1a[n] += o[i][n][r]; s2a[n] += o[i][n][r] * o[i][n][r]; }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            s1a[n] += __shfl_xor(s1a[n], 16); s1a[n] += __shfl_xor(s1a[n], 32);
+            s2a[n] += __shfl_xor(s2a[n], 16); s2a[n] += __shfl_xor(s2a[n], 32);
+            if (fg == 0) { red[w][n * 16 + fr][0] = s1a[n]; red[w][n * 16 + fr][1] = s2a[n]; }
+        }
+        __syncthreads();                                 // (B) statistics of all four channel quarters
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int tok = n * 16 + fr;
+            const float su = red[0][tok][0] + red[1][tok][0] + red[2][tok][0] + red[3][tok][0];
+            const float sq = red[0][tok][1] + red[1][tok][1] + red[2][tok][1] + red[3][tok][1];
+            const float mean = su * (1.f / C);
+            const float rstd = rsqrtf(fmaxf(sq * (1.f / C) - mean * mean, 0.f) + a.eps);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cbase = (w * 4 + i) * 16 + fg * 4;
+                const float4 g4 = *(const float4*)&prm[1][cbase], b4 = *(const float4*)&prm[2][cbase];
+                uint2 y;
+                y.x = pack2bf((o[i][n][0] - mean) * rstd * g4.x + b4.x, (o[i][n][1] - mean) * rstd * g4.y + b4.y);
+                y.y = pack2bf((o[i][n][2] - mean) * rstd * g4.z + b4.z, (o[i][n][3] - mean) * rstd * g4.w + b4.w);
+                *(uint2*)(B + xoff[i & 1] + (i >> 1) * SUB_BYTES + n * 16 * 64) = y;     // in place
+            }
+        }
+        if (q + 1 < nq) FI_STORE(p0, p1, p2, p3, buf ^ 1);
+        __syncthreads();                                 // (C) updated tile complete, next tile staged
+        {
+            u16* op = a.out + ((long)p * T + key0) * C;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(uint4*)(op + (i * NTHR + tid) * 8) = *(const uint4*)(B + kdst[i]);
+        }
+        buf ^= 1;
+    };
+    while (true) {
+        iteration(ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3);
+        if (++q >= nq) break;
+        iteration(rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3);
+        if (++q >= nq) break;
+    }
+#undef FI_LOAD
+#undef FI_STORE
+#undef FI_TAB
+}
+
+// V'^T[p][c][h*8 + t] = sum_d Wo[c][h*16 + d] v[p][t][h*16 + d]   (zero for t >= Nt)
+__global__ __launch_bounds__(256) void fold_v_kernel(const u16* __restrict__ vtok, const u16* __restrict__ wo, int Nt,
+                                                     u16* __restrict__ vfoldT) {
+    __shared__ float v[8][CI];
+    const int p = blockIdx.x, c = threadIdx.x;
+    for (int i = c; i < 8 * CI; i += 256) {
+        const int t = i >> 7, d = i & (CI - 1);
+        v[t][d] = t < Nt ? bf2f(vtok[((long)p * Nt + t) * CI + d]) : 0.f;
+    }
+    __syncthreads();
+    u16* dst = vfoldT + ((long)p * C + c) * 64;
+    for (int h = 0; h < 8; ++h) {
+        const uint4 w0 = *(const uint4*)(wo + (long)c * CI + h * 16), w1 = *(const uint4*)(wo + (long)c * CI + h * 16 + 8);
+        const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        float wf[16];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { wf[2 * x] = bf2f((u16)(ww[x] & 0xffff)); wf[2 * x + 1] = bf2f((u16)(ww[x] >> 16)); }
+        uint32_t pk[4];
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) { a0 = fmaf(wf[d], v[2 * t2][h * 16 + d], a0); a1 = fmaf(wf[d], v[2 * t2 + 1][h * 16 + d], a1); }
+            pk[t2] = pack2bf(a0, a1);
+        }
+        *(uint4*)(dst + h * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+int key_splits(int P) {
+    int ks = 1;
+    while (P * ks < 512 && ks < 16) ks *= 2;
+    return ks;
+}
+
+}  // namespace
+
+extern "C" int64_t msam_t2i_fold_workspace_bytes(int32_t P) {
+    const long ks = key_splits(P);
+    return (long)P * 64 * C * 2 + (long)P * ks * 64 * C * 4 + (long)P * ks * 64 * 2 * 4;
+}
+
+extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, const void* qtok, int32_t P, int32_t Nt,
+                                       const void* wk, const void* tabk, const void* wv, const float* bv, void* out,
+                                       void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!keys || !qtok || !wk || !tabk || !wv || !bv || !out || !workspace || P <= 0) {
+        msam_set_error("msam_t2i_fold_attention: null argument");
+        return 1;
+    }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_t2i_fold_attention: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    if (workspace_bytes < msam_t2i_fold_workspace_bytes(P)) { msam_set_error("msam_t2i_fold_attention: workspace too small"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int KS = key_splits(P);
+    char* wp = (char*)workspace;
+    u16* qprime = (u16*)wp; wp += (long)P * 64 * C * 2;
+    float* opart = (float*)wp; wp += (long)P * KS * 64 * C * 4;
+    float* stats = (float*)wp;
+    hipLaunchKernelGGL(fold_q_kernel, dim3(P * 8), dim3(256), 0, s, (const u16*)qtok, (const u16*)wk, Nt, qprime);
+    if (int e = msam_check_launch("fold_q")) return e;
+    FoldArgs a{};
+    a.keys = (const u16*)keys; a.kv_shared = kv_shared; a.qprime = qprime; a.qtok = (const u16*)qtok; a.Nt = Nt;
+    a.tabk = (const u16*)tabk; a.nitems = P * KS; a.KS = KS; a.opart = opart; a.stats = stats;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
+    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
+    const double bytes = (double)(kv_shared ? 1 : P) * T * C * 2 + (double)P * KS * 64 * C * 4;
+    msam_profile_mark2(stream, 1, flops, bytes, 1);
+    hipLaunchKernelGGL(fold_attn_kernel, dim3(grid), dim3(NTHR), 0, s, a);
+    msam_profile_mark2(stream, 0, flops, bytes, 1);
+    if (int e = msam_check_launch("fold_attn")) return e;
+    hipLaunchKernelGGL(fold_finish_kernel, dim3(P * 8), dim3(128), 0, s, opart, stats, KS, Nt, (const u16*)wv, bv, (u16*)out);
+    return msam_check_launch("fold_finish");
+}
+
+extern "C" int64_t msam_i2t_fold_workspace_bytes(int32_t P) { return (long)P * 64 * C * 2 * 2; }
+
+extern "C" int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void* ktok, const void* vtok, int32_t P,
+                                   int32_t Nt, const void* wq, const void* tabq, const void* wo, const float* bo,
+                                   const float* ln_w, const float* ln_b, float ln_eps, void* out, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    if (!xin || !ktok || !vtok || !wq || !tabq || !wo || !bo || !ln_w || !ln_b || !out || !workspace || P <= 0) {
+        msam_set_error("msam_i2t_fold_layer: null argument");
+        return 1;
+    }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t_fold_layer: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    if (workspace_bytes < msam_i2t_fold_workspace_bytes(P)) { msam_set_error("msam_i2t_fold_layer: workspace too small"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    u16* kfold = (u16*)workspace;
+    u16* vfoldT = kfold + (long)P * 64 * C;
+    hipLaunchKernelGGL(fold_q_kernel, dim3(P * 8), dim3(256), 0, s, (const u16*)ktok, (const u16*)wq, Nt, kfold);
+    if (int e = msam_check_launch("fold_k")) return e;
+    hipLaunchKernelGGL(fold_v_kernel, dim3(P), dim3(256), 0, s, (const u16*)vtok, (const u16*)wo, Nt, vfoldT);
+    if (int e = msam_check_launch("fold_v")) return e;
+    I2tArgs a{};
+    a.xin = (const u16*)xin; a.x_shared = x_shared; a.kfold = kfold; a.vfoldT = vfoldT; a.ktok = (const u16*)ktok; a.Nt = Nt;
+    a.tabq = (const u16*)tabq; a.bo = bo; a.ln_w = ln_w; a.ln_b = ln_b; a.eps = ln_eps;
+    a.KS = key_splits(P); a.nitems = P * a.KS; a.out = (u16*)out;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
+    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
+    const double bytes = (double)(x_shared ? 1 : P) * T * C * 2 + (double)P * T * C * 2;
+    msam_profile_mark2(stream, 1, flops, bytes, 1);
+    hipLaunchKernelGGL(fold_i2t_kernel, dim3(grid), dim3(NTHR), 0, s, a);
+    msam_profile_mark2(stream, 0, flops, bytes, 1);
+    return msam_check_launch("fold_i2t");
+}

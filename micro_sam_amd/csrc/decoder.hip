@@ -438,9 +438,10 @@ int wsgemm_kv(const Ctx& cx, const void* x, const u16* wkv, const float* bkv, co
 
 struct Consts {     // layout of the `consts` buffer
     float* pos_f32; u16* pos_bf16; float* pe_k[3]; float* pe_q[2]; u16* wkv[3]; float* bkv[3];
-    u16* tab_k[3];  // bf16(pos Wk^T + bk): score table of the folded token->image attention (t2ifold.hip)
+    u16* tab_k[3];  // bf16(pos Wk^T + bk): score table of the folded token->image attention (decfold.hip)
+    u16* tab_q[2];  // bf16(pos Wq^T + bq): score table of the folded image->token attention
 };
-constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4 + 3L * T * CI * 2;
+constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4 + 5L * T * CI * 2;
 
 Consts carve_consts(void* base) {
     Consts c; char* p = (char*)base;
@@ -451,6 +452,7 @@ Consts carve_consts(void* base) {
     for (int i = 0; i < 3; ++i) { c.wkv[i] = (u16*)p; p += (long)C * C * 2; }
     for (int i = 0; i < 3; ++i) { c.bkv[i] = (float*)p; p += (long)C * 4; }
     for (int i = 0; i < 3; ++i) { c.tab_k[i] = (u16*)p; p += (long)T * CI * 2; }
+    for (int i = 0; i < 2; ++i) { c.tab_q[i] = (u16*)p; p += (long)T * CI * 2; }
     return c;
 }
 
@@ -491,8 +493,11 @@ extern "C" int msam_decoder_prepare_const(const msam_decoder_t* dec, void* const
         if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, nullptr, c.pe_k[i], MSAM_F32, CI)) return e;
         if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, t2i[i]->k_b, c.tab_k[i], MSAM_BF16, CI)) return e;
     }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, nullptr, c.pe_q[i], MSAM_F32, CI)) return e;
+        if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, dec->layer[i].i2t.q_b, c.tab_q[i], MSAM_BF16, CI))
+            return e;
+    }
     return 0;
 }
 
@@ -549,7 +554,7 @@ Work carve_work(void* base, int P, int Nt) {
     return w;
 }
 
-// token -> image attention over the per-prompt stream w.keys: folded form (one pass over the stream, t2ifold.hip) for
+// token -> image attention over the per-prompt stream w.keys: folded form (one pass over the stream, decfold.hip) for
 // up to 8 tokens per prompt, explicit K / V^T projection + attention kernel otherwise
 int t2i_stream(const Ctx& cx, const Work& w, const Consts& c, int idx, const msam_attn_w_t& aw, int P, int Nt) {
     const long R = (long)P * T;
@@ -642,8 +647,13 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         ADD_CAST(w.queries, nullptr, w.b);
         CHECK(gemm(cx, w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI));
         CHECK(gemm(cx, w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI));
-        // q-projection (layer 1) + image->token attention + out_proj + residual + norm4 in ONE launch (declayer.hip)
-        {
+        // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
+        // for up to 8 tokens per prompt, weights-stationary fused kernel (declayer.hip) otherwise
+        if (Nt <= 8) {
+            CHECK(msam_i2t_fold_layer(li == 0 ? (const void*)im.src_bf16 : (const void*)w.keys, li == 0, w.ks, w.vs, P, Nt,
+                                      L.i2t.q_w, c.tab_q[li], L.i2t.o_w, L.i2t.o_b, L.n4_w, L.n4_b, 1e-5f, w.keys, w.qimg,
+                                      (int64_t)((char*)w.up1 - (char*)w.qimg), cx.s));
+        } else {
             msam_image_layer_t g{};
             g.wo = L.i2t.o_w; g.bo = L.i2t.o_b; g.ln_w = L.n4_w; g.ln_b = L.n4_b; g.ln_eps = 1e-5f;
             g.ktok = w.ks; g.vtok = w.vs; g.Nt = Nt; g.out = w.keys; g.rows = (int)R;

@@ -341,3 +341,20 @@ def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False)
                                            tabk.data_ptr(), wv.data_ptr(), bv.data_ptr(), out.data_ptr(), work.data_ptr(),
                                            nbytes, _lib.stream_ptr()), "msam_t2i_fold_attention")
     return out
+
+
+def i2t_fold_layer(xin, ktok, vtok, wq, tabq, wo, bo, ln_w, ln_b, *, x_shared: bool = False, ln_eps: float = 1e-5, out=None):
+    """Folded image->token attention + out_proj + residual + LayerNorm (include/msam_hip.h msam_i2t_fold_layer).
+    xin bf16 [Px,4096,256], ktok / vtok bf16 [P,Nt,128] (Nt <= 8) -> bf16 [P,4096,256]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    P, Nt = ktok.shape[0], ktok.shape[1]
+    nbytes = int(lib.msam_i2t_fold_workspace_bytes(P))
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=xin.device)
+    if out is None:
+        out = torch.empty((P, 4096, 256), dtype=torch.bfloat16, device=xin.device)
+    _lib.check(lib.msam_i2t_fold_layer(xin.data_ptr(), int(x_shared), ktok.data_ptr(), vtok.data_ptr(), P, Nt, wq.data_ptr(),
+                                       tabq.data_ptr(), wo.data_ptr(), bo.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                       ln_eps, out.data_ptr(), work.data_ptr(), nbytes, _lib.stream_ptr()),
+               "msam_i2t_fold_layer")
+    return out

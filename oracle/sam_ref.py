@@ -325,13 +325,15 @@ def prompt_encoder(sd: Dict[str, Tensor], points: Optional[Tuple[Tensor, Tensor]
 
 def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads: int = 8,
                    q_pe: Optional[Tensor] = None, k_pe: Optional[Tensor] = None, mfma_pv: bool = False,
-                   fold: bool = False) -> Tensor:
+                   fold: bool = False, fold_i2t: bool = False) -> Tensor:
     """q_pe / k_pe: positional encodings of the IMAGE-side operand.  fp32 mode adds them before the projection
     (upstream); bf16 mode follows the HIP dataflow (x + pe) W = x W + pe W with separately rounded operands.
     fold (bf16 mode only, token->image attention over the per-prompt stream with <= 8 tokens): the HIP path folds the
-    K / V projections into the token side (csrc/t2ifold.hip) - same mathematics, different bf16 rounding points."""
+    K / V projections into the token side (csrc/decfold.hip) - same mathematics, different bf16 rounding points."""
     if p.bf16 and fold and q.shape[1] <= 8:
         return _dec_attention_folded(sd, pre, q, k, p, heads, k_pe)
+    if p.bf16 and fold_i2t and k.shape[1] <= 8:
+        return _dec_attention_i2t_folded(sd, pre, q, k, v, p, heads, q_pe)
     def proj(x, pe, name):
         w, b = sd[pre + name + ".weight"], sd[pre + name + ".bias"]
         if pe is None:
@@ -359,7 +361,7 @@ def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads
 
 
 def _dec_attention_folded(sd, pre: str, q: Tensor, keys: Tensor, p: Prec, heads: int, k_pe: Tensor) -> Tensor:
-    """bf16 emulation of csrc/t2ifold.hip: S = keys . bf16(Wk_h^T q_h) + bf16(pe Wk^T + bk)_h . q_h, un-normalised
+    """bf16 emulation of csrc/decfold.hip: S = keys . bf16(Wk_h^T q_h) + bf16(pe Wk^T + bk)_h . q_h, un-normalised
     probabilities rounded to bf16 for the P . keys MFMA, context kept in fp32 for the per-head value projection."""
     wk, bk = sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]
     wv, bv = sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]
@@ -377,6 +379,27 @@ def _dec_attention_folded(sd, pre: str, q: Tensor, keys: Tensor, p: Prec, heads:
     out = torch.einsum("bhtc,hdc->bhtd", ctx, p.r(wv).reshape(heads, hd, -1)) + bv.reshape(1, heads, 1, hd)
     out = out.transpose(1, 2).reshape(b, nq, ci)
     return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+
+
+def _dec_attention_i2t_folded(sd, pre: str, keys: Tensor, k_in: Tensor, v_in: Tensor, p: Prec, heads: int,
+                              q_pe: Tensor) -> Tensor:
+    """bf16 emulation of csrc/decfold.hip fold_i2t_kernel: S = keys . bf16(Wq_h^T k_h) + bf16(pe Wq^T + bq)_h . k_h,
+    softmax over the prompt tokens, normalised P rounded to bf16, out = P . bf16(Wo_h v_h) + bo (out_proj folded)."""
+    wq, bq = sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]
+    wo, bo = sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"]
+    k = p.r(p.linear(k_in, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]))        # [b, nt, 128]
+    v = p.r(p.linear(v_in, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]))
+    b, nt, ci = k.shape
+    hd = ci // heads
+    kh = k.reshape(b, nt, heads, hd).transpose(1, 2)                                    # [b, h, nt, 16]
+    vh = v.reshape(b, nt, heads, hd).transpose(1, 2)
+    kf = p.r(torch.einsum("bhtd,hdc->bhtc", kh, p.r(wq).reshape(heads, hd, -1)))        # K' [b, h, nt, 256]
+    vf = p.r(torch.einsum("chd,bhtd->bhtc", p.r(wo).reshape(-1, heads, hd), vh))        # V' [b, h, nt, 256]
+    tab = p.r(p.linear(q_pe[:1], wq, bq))[0].reshape(-1, heads, hd)                     # [T, h, 16]
+    keys = p.r(keys)
+    s = (torch.einsum("bjc,bhtc->bjht", keys, kf) + torch.einsum("jhd,bhtd->bjht", tab, kh)) / math.sqrt(hd)
+    a = p.r(torch.softmax(s, dim=-1))
+    return torch.einsum("bjht,bhtc->bjc", a, vf) + bo
 
 
 def _ln(sd, pre: str, x: Tensor, eps: float = 1e-5) -> Tensor:
@@ -409,7 +432,7 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
         queries = _ln(sd, lp + "norm3.", queries + m)
         q = queries + query_pe
         keys = keys + _dec_attention(sd, lp + "cross_attn_image_to_token.", keys, q, queries, p, q_pe=key_pe,
-                                     mfma_pv=True)
+                                     mfma_pv=True, fold_i2t=True)
         keys = p.r(_ln(sd, lp + "norm4.", keys))
         if debug is not None:
             debug[f"queries{i}"] = queries.clone()

@@ -296,3 +296,36 @@ def test_t2i_fold_attention(env, P, Nt, shared):
     ref = (a @ vh).permute(0, 2, 1, 3).reshape(P, Nt, 128)
     # scores reach |s| ~ 30 with these operands: bf16 rounding of the folded query gives ~1e-2 relative score error
     assert _close(out, ref, 6e-2, 3e-2)
+
+
+@pytest.mark.parametrize("P,Nt,shared", [(3, 7, False), (2, 8, True), (70, 5, True), (520, 7, True)])
+def test_i2t_fold_layer(env, P, Nt, shared):
+    """Folded image->token attention + out_proj + residual + LayerNorm vs the unfolded fp32 formulation."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(91 + P)
+    T = 4096
+    Px = 1 if shared else P
+    x = _bf(torch.randn(Px, T, 256, generator=g)).to(dev)
+    pe = torch.randn(T, 256, generator=g).to(dev)
+    wq = _bf(torch.randn(128, 256, generator=g) / 16).to(dev); bq = torch.randn(128, generator=g).to(dev)
+    wo = _bf(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev); bo = torch.randn(256, generator=g).to(dev)
+    lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
+    ktok = _bf(torch.randn(P, Nt, 128, generator=g)).to(dev)
+    vtok = _bf(torch.randn(P, Nt, 128, generator=g)).to(dev)
+    tabq = (pe @ wq.float().t() + bq).to(torch.bfloat16)
+    out = ops.i2t_fold_layer(x, ktok, vtok, wq, tabq, wo, bo, lw, lb, x_shared=shared)
+    n = min(P, 4)                                                               # reference on the first / last prompts
+    for sl in (slice(0, n), slice(P - n, P)):
+        xf = x.float().expand(P, T, 256)[sl]
+        q = xf @ wq.float().t() + tabq.float()
+        qh = q.reshape(-1, T, 8, 16).permute(0, 2, 1, 3)
+        kh = ktok[sl].float().reshape(-1, Nt, 8, 16).permute(0, 2, 1, 3)
+        vh = vtok[sl].float().reshape(-1, Nt, 8, 16).permute(0, 2, 1, 3)
+        a = torch.softmax((qh @ kh.transpose(-1, -2)) / 4.0, dim=-1)
+        attn = (a @ vh).permute(0, 2, 1, 3).reshape(-1, T, 128)
+        ref = F.layer_norm(xf + attn @ wo.float().t() + bo, (256,), lw, lb, eps=1e-5)
+        assert _close(out[sl], ref, 5e-2, 3e-2)
+    if not shared:                                                              # in-place update of the stream
+        x2 = x.clone()
+        ops.i2t_fold_layer(x2, ktok, vtok, wq, tabq, wo, bo, lw, lb, out=x2)
+        assert torch.equal(x2, out)
