@@ -29,20 +29,18 @@ MSAM_DEVINL f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
 }
 
-// erf-GELU (torch.nn.functional.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32
-// rounding level) with one v_rcp and one v_exp instead of ocml's branchy erff: the up-scaling epilogue evaluates
-// 2.1e9 GELUs per tile, which made it VALU-bound.
-MSAM_DEVINL float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float y = 1.0f - p * t * __expf(-ax * ax);
-    return copysignf(y, x);
+// erf-GELU (torch.nn.functional.gelu default) as  gelu(x) = max(x, 0) - |x| * Psi(|x|),  Psi(t) = erfc(t / sqrt 2) / 2.
+// log2 Psi is smooth and nearly quadratic: a minimax cubic (weighted by t * Psi, the resulting gelu error) gives
+// |gelu error| <= 5.5e-5 absolute for every x (all coefficients negative: the approximation decays monotonically, no
+// clamp needed), i.e. ~70x below the bf16 rounding applied to the activations afterwards.  3 FMA + v_exp_f32 + max + FMA:
+// the decoder's up-scaling stages evaluate 3.2e9 GELUs per 1024-prompt batch and were VALU-bound on the erf form.
+MSAM_DEVINL float gelu_erf(float x) {
+    const float t = fabsf(x);
+    float q = fmaf(-0.0248758f, t, -0.49884797f);
+    q = fmaf(q, t, -1.12922424f);
+    q = fmaf(q, t, -1.00353579f);
+    return fmaf(-t, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
 }
-MSAM_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 // LDS swizzle for a [rows][64] bf16 tile (128-B rows, 8 chunks of 16 B): chunk' = chunk ^ swz(row).
 // Chosen so that the 16-lane service groups of ds_read_b128 (MI355X_MICROARCH, LDS table) hit 16 distinct
