@@ -23,6 +23,29 @@ MSAM_DEVINL u16 f2bf(float f) {
 MSAM_DEVINL float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
 MSAM_DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
+// vmcnt is an in-order counter: waiting for ANY global load also waits for every load issued before it.  Registers
+// that are loaded once (stationary operands) and first used inside a persistent loop make the compiler place that wait
+// INSIDE the loop, where it drains the tile prefetch on every iteration.  wait_vmem_all() (s_waitcnt vmcnt(0), which the
+// compiler's wait-count pass takes into account) pins the wait to where the loads are issued; the loop body then only
+// waits for what it really needs.
+MSAM_DEVINL void wait_vmem_all() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+
+// Buffer addressing for tile streams: base in a scalar resource descriptor, per-lane byte offset in ONE loop-invariant
+// VGPR, per-tile byte offset in an SGPR - no 64-bit VGPR address arithmetic per load (the compiler otherwise builds the
+// addresses in the destination registers of the previous prefetch, and that write-after-write on a register with a load
+// in flight costs a vmcnt wait at the top of every iteration).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+MSAM_DEVINL rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000);
+}
+MSAM_DEVINL uint4 buf_load16(rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+MSAM_DEVINL void buf_store16(const uint4& v, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+}
+
 MSAM_DEVINL f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) {
     bf16x8_t av = __builtin_bit_cast(bf16x8_t, a);
     bf16x8_t bv = __builtin_bit_cast(bf16x8_t, b);

@@ -93,20 +93,23 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
         const int id = i * NTHR + tid, row = id >> 4, c = id & 15;
         tdst[i] = KEYS_BYTES + row * 256 + ((c ^ (row & 15)) << 4);
     }
-    auto tile_src = [&](int q, const u16*& kp, const u16*& tp) {
+    // tile q of this workgroup -> (prompt stream base, byte offset of the tile in the stream / table)
+    const int voff = tid * 16;
+    const rsrc_t rtab = make_rsrc(a.tabk, T * CI * 2);
+    auto tile_src = [&](int q, rsrc_t& rk, int& koffs, int& toffs) {
         const int item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
         const int p = item / a.KS, ks = item - p * a.KS;
         const int key0 = ks * (T / a.KS) + (q % TPI) * TK;
-        kp = a.keys + ((long)(a.kv_shared ? 0 : p) * T + key0) * C;
-        tp = a.tabk + (long)key0 * CI;
+        rk = make_rsrc(a.keys + (long)(a.kv_shared ? 0 : p) * T * C, T * C * 2);
+        koffs = key0 * C * 2; toffs = key0 * CI * 2;
     };
 #define FA_LOAD(r0_, r1_, r2_, r3_, r4_, r5_, q_)                                                  \
     do {                                                                                           \
-        const u16 *kp_, *tp_;                                                                      \
-        tile_src(q_, kp_, tp_);                                                                    \
-        r0_ = *(const uint4*)(kp_ + (0 * NTHR + tid) * 8); r1_ = *(const uint4*)(kp_ + (1 * NTHR + tid) * 8); \
-        r2_ = *(const uint4*)(kp_ + (2 * NTHR + tid) * 8); r3_ = *(const uint4*)(kp_ + (3 * NTHR + tid) * 8); \
-        r4_ = *(const uint4*)(tp_ + (0 * NTHR + tid) * 8); r5_ = *(const uint4*)(tp_ + (1 * NTHR + tid) * 8); \
+        rsrc_t rk_; int ko_, to_;                                                                  \
+        tile_src(q_, rk_, ko_, to_);                                                               \
+        r0_ = buf_load16(rk_, voff, ko_); r1_ = buf_load16(rk_, voff, ko_ + NTHR * 16);            \
+        r2_ = buf_load16(rk_, voff, ko_ + 2 * NTHR * 16); r3_ = buf_load16(rk_, voff, ko_ + 3 * NTHR * 16); \
+        r4_ = buf_load16(rtab, voff, to_); r5_ = buf_load16(rtab, voff, to_ + NTHR * 16);          \
     } while (0)
 #define FA_STORE(r0_, r1_, r2_, r3_, r4_, r5_, buf_)                                               \
     do {                                                                                           \
@@ -131,15 +134,17 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
     float m = NEG_BIG, l = 0.f;
     int item = 0;
 
+    // every global load of the steady state is unconditional (tile index clamped to the last tile): the compiler can
+    // then count the younger loads / stores and wait with vmcnt(n > 0) instead of draining the prefetch (common.h)
     FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, 0);
     FA_STORE(ra0, ra1, ra2, ra3, ra4, ra5, 0);
-    if (1 < nq) FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, 1);
+    FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, min(1, nq - 1));
     __syncthreads();
 
     int q = 0, buf = 0;
     auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& p4, uint4& p5, uint4& f0, uint4& f1, uint4& f2,
                          uint4& f3, uint4& f4, uint4& f5) {
-        if (q + 2 < nq) FA_LOAD(f0, f1, f2, f3, f4, f5, q + 2);
+        FA_LOAD(f0, f1, f2, f3, f4, f5, min(q + 2, nq - 1));
         const int tt = q % TPI;
         if (tt == 0) {                                   // new work item: folded queries of this wave's two heads
             item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
             qd = make_uint4(0, 0, 0, 0);
             if ((fg >> 1) == hh && t < a.Nt)
                 qd = *(const uint4*)(a.qtok + ((long)p * a.Nt + t) * CI + (2 * w + hh) * 16 + (fg & 1) * 8);
+            wait_vmem_all();                                 // wait here (once per item), not in the steady state
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             m = NEG_BIG; l = 0.f;
@@ -314,13 +320,17 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         p = item / a.KS;
         key0 = (item - p * a.KS) * (T / a.KS) + (q % TPI) * TK;
     };
+    const int voff = tid * 16;
+    const rsrc_t rtab = make_rsrc(a.tabq, T * CI * 2);
+    const int tvoff = (fr * CI + w * 32 + fg * 8) * 2;     // table B fragment: token fr, channels 32w + fg*8 ..
 #define FI_LOAD(r0_, r1_, r2_, r3_, q_)                                                            \
     do {                                                                                           \
         int p_, k0_;                                                                               \
         tile_pos(q_, p_, k0_);                                                                     \
-        const u16* kp_ = a.xin + ((long)(a.x_shared ? 0 : p_) * T + k0_) * C;                      \
-        r0_ = *(const uint4*)(kp_ + (0 * NTHR + tid) * 8); r1_ = *(const uint4*)(kp_ + (1 * NTHR + tid) * 8); \
-        r2_ = *(const uint4*)(kp_ + (2 * NTHR + tid) * 8); r3_ = *(const uint4*)(kp_ + (3 * NTHR + tid) * 8); \
+        const rsrc_t rx_ = make_rsrc(a.xin + (long)(a.x_shared ? 0 : p_) * T * C, T * C * 2);      \
+        const int so_ = k0_ * C * 2;                                                               \
+        r0_ = buf_load16(rx_, voff, so_); r1_ = buf_load16(rx_, voff, so_ + NTHR * 16);            \
+        r2_ = buf_load16(rx_, voff, so_ + 2 * NTHR * 16); r3_ = buf_load16(rx_, voff, so_ + 3 * NTHR * 16); \
     } while (0)
 #define FI_STORE(r0_, r1_, r2_, r3_, buf_)                                                         \
     do {                                                                                           \
@@ -328,13 +338,12 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_; *(uint4*)(b_ + kdst[2]) = r2_; \
         *(uint4*)(b_ + kdst[3]) = r3_;                                                             \
     } while (0)
-    // table operand of the NEXT tile (B fragment: token fr / 16 + fr, channels 32w + fg*8 ..), straight from L2
+    // table operand of the NEXT tile (B fragments of tokens fr and 16 + fr), straight from L2
 #define FI_TAB(q_)                                                                                 \
     do {                                                                                           \
         int p_, k0_;                                                                               \
         tile_pos(q_, p_, k0_);                                                                     \
-        const u16* tp_ = a.tabq + ((long)k0_ + fr) * CI + w * 32 + fg * 8;                         \
-        tb0 = *(const uint4*)tp_; tb1 = *(const uint4*)(tp_ + 16 * CI);                            \
+        tb0 = buf_load16(rtab, tvoff, k0_ * CI * 2); tb1 = buf_load16(rtab, tvoff, (k0_ + 16) * CI * 2); \
     } while (0)
 
     uint4 kq[8], vq[4][2], kd, tb0, tb1;
@@ -346,15 +355,16 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
     for (int e = 0; e < 2; ++e)
         xoff[e] = (2 * w) * SUB_BYTES + fr * 64 + ((((e * 2 + (fg >> 1)) ^ ((fr >> 2) & 3)) & 3) << 4) + (fg & 1) * 8;
 
+    // unconditional (clamped) loads in the steady state, see fold_attn_kernel
     FI_LOAD(ra0, ra1, ra2, ra3, 0);
     FI_TAB(0);
     FI_STORE(ra0, ra1, ra2, ra3, 0);
-    if (1 < nq) FI_LOAD(ra0, ra1, ra2, ra3, 1);
+    FI_LOAD(ra0, ra1, ra2, ra3, min(1, nq - 1));
     __syncthreads();
 
     int q = 0, buf = 0;
     auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& f0, uint4& f1, uint4& f2, uint4& f3) {
-        if (q + 2 < nq) FI_LOAD(f0, f1, f2, f3, q + 2);
+        FI_LOAD(f0, f1, f2, f3, min(q + 2, nq - 1));
         int p, key0;
         tile_pos(q, p, key0);
         if (q % TPI == 0) {                              // new work item: this prompt's folded operands
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
             kd = make_uint4(0, 0, 0, 0);
             if ((fg >> 1) == hh_row && t_row < a.Nt)
                 kd = *(const uint4*)(a.ktok + ((long)p * a.Nt + t_row) * CI + (2 * w + hh_row) * 16 + (fg & 1) * 8);
+            wait_vmem_all();                                 // wait here (once per item), not in the steady state
         }
         unsigned char* B = lds + buf * XT_BYTES;
         // ---- S^T (rows (h,t) of heads 2w, 2w+1; two 16-token column tiles)
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         }
         s0 = mfma16(kd, tb0, s0);
         s1 = mfma16(kd, tb1, s1);
-        if (q + 1 < nq) FI_TAB(q + 1);
+        FI_TAB(min(q + 1, nq - 1));
         // softmax over the 8 tokens of a head: rows fg*4 + r, i.e. token (fg & 1) * 4 + r of head 2w + (fg >> 1)
         {
             float m0 = NEG_BIG, m1 = NEG_BIG;
@@ -469,9 +480,9 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         if (q + 1 < nq) FI_STORE(p0, p1, p2, p3, buf ^ 1);
         __syncthreads();                                 // (C) updated tile complete, next tile staged
         {
-            u16* op = a.out + ((long)p * T + key0) * C;
+            const rsrc_t ro = make_rsrc(a.out + (long)p * T * C, T * C * 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *(uint4*)(op + (i * NTHR + tid) * 8) = *(const uint4*)(B + kdst[i]);
+            for (int i = 0; i < 4; ++i) buf_store16(*(const uint4*)(B + kdst[i]), ro, voff, key0 * C * 2 + i * NTHR * 16);
         }
         buf ^= 1;
     };

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
                                                              int hyper_ld, int mask0, int nmask, long rows,
                                                              float* __restrict__ low_res) {
     __shared__ float slab[4][3 * 4 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
     const int sub2 = fr >> 2, cq = (fr & 3) * 8;
     uint4 wb[8][2];
     float bias[8];
@@ -314,13 +314,17 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
     long step = (long)blockIdx.x * 4 + wave;
     if (step >= nsteps) return;
     uint4 a00, a01, a10, a11;                          // A fragments of the two 16-row halves (mi = 0, 1)
+    // buffer addressing + unconditional (clamped) prefetch: see common.h wait_vmem_all() / make_rsrc()
+    const int voff = (fr * 64 + fg * 8) * 2;
 #define UP_LOAD(step_)                                                                           \
     do {                                                                                         \
-        const u16* ar_ = up1 + ((step_) * 32 + fr) * 64 + fg * 8;                                \
-        a00 = *(const uint4*)ar_; a01 = *(const uint4*)(ar_ + 32);                               \
-        a10 = *(const uint4*)(ar_ + 16 * 64); a11 = *(const uint4*)(ar_ + 16 * 64 + 32);         \
+        const rsrc_t ru_ = make_rsrc(up1 + (step_) * 32 * 64, 32 * 64 * 2);                      \
+        a00 = buf_load16(ru_, voff, 0); a01 = buf_load16(ru_, voff, 64);                         \
+        a10 = buf_load16(ru_, voff, 16 * 64 * 2); a11 = buf_load16(ru_, voff, 16 * 64 * 2 + 64); \
     } while (0)
+    wait_vmem_all();                                   // stationary weights complete before the loop
     UP_LOAD(step);
+    const int nm1 = nmask - 1;
     for (; step < nsteps; step += stride) {
         const long row0 = step * 32;
         const int p = (int)(row0 / (T * 4));
@@ -329,8 +333,8 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
 #pragma unroll
         for (int mk = 0; mk < 3; ++mk)
 #pragma unroll
-            for (int ni = 0; ni < 8; ++ni)
-                h[mk][ni] = mk < nmask ? hyper[((long)p * 4 + mask0 + mk) * hyper_ld + cq + ni] : 0.f;
+            for (int ni = 0; ni < 8; ++ni)       // masks >= nmask: valid (clamped) loads whose results are never stored
+                h[mk][ni] = hyper[((long)p * 4 + mask0 + min(mk, nm1)) * hyper_ld + cq + ni];
         f32x4_t acc0[8], acc1[8];
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) {
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restri
             d = mfma16(a10, wb[ni][0], d); d = mfma16(a11, wb[ni][1], d);
             acc0[ni] = c; acc1[ni] = d;
         }
-        if (step + stride < nsteps) UP_LOAD(step + stride);        // in flight during the GELU / reduction epilogue
+        UP_LOAD(min(step + stride, nsteps - 1));                   // in flight during the GELU / reduction epilogue
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll

@@ -32,7 +32,9 @@ MSAM_DEVINL int swz16(int row) { return (row & 15) ^ (((row + 4) >> 3) & 1); }
 
 // 8 waves; N = 128 variants keep <= 128 VGPRs so that two workgroups share a CU and overlap their MFMA / epilogue
 // phases (the decoder therefore issues its N = 256, K = 256 products as two N = 128 launches)
-template <int N, int K>
+// EPI: the epilogue reads per-row operands from global memory (positional table and / or residual rows); compiled out
+// otherwise so that the steady state contains no load but the tile prefetch (common.h wait_vmem_all())
+template <int N, int K, bool EPI>
 __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_kernel(const u16* __restrict__ A, const u16* __restrict__ W, int M, WsEpi e) {
     constexpr int NWAVES = 8;
     constexpr int NTHR = NWAVES * 64;
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
     extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
     uint4* ldsA = dyn_lds;                                        // [2][WM * CPR]
     float* ldsC = (float*)(dyn_lds + 2 * WM * CPR);               // [WM][N] fp32
+    float* prm = ldsC + WM * N;                                   // [3][N]: bias, ln_w, ln_b per output column
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
     // ---- stationary weights: B fragments of this wave's columns
@@ -53,18 +56,28 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
             bfr[ni][kc] = *(const uint4*)(W + (long)(wave * (NT * 16) + ni * 16 + fr) * K + kc * 32 + fg * 8);
+    // epilogue parameters live in LDS: a global load inside the loop would have to be waited for with vmcnt(0), which
+    // also waits for the tile prefetch issued before it (see common.h touch())
+    for (int c = threadIdx.x; c < N; c += NTHR) {
+        const int lc = e.ln_mode == 2 ? (c & 63) : c;
+        prm[c] = e.bias ? e.bias[c] : 0.f;
+        prm[N + c] = e.ln_mode ? e.ln_w[lc] : 1.f;
+        prm[2 * N + c] = e.ln_mode ? e.ln_b[lc] : 0.f;
+    }
+    wait_vmem_all();
 
     const int ntiles = M / WM;
     // staging map: chunk id q = p*512 + tid -> (row = q / CPR, c = q % CPR)
     uint4 ra0, ra1, rb0, rb1;       // two register sets: tiles are requested TWO iterations ahead (HBM latency under load
     (void)ra1; (void)rb1;           // is several microseconds; one workgroup per CU has nothing else to hide it with)
-#define WS_SRC(p_, tile_) (A + ((long)(tile_) * WM + ((p_) * NTHR + tid) / CPR) * K + (((p_) * NTHR + tid) % CPR) * 8)
+    const int voff = tid * 16;      // a tile is WM * K * 2 contiguous bytes: chunk p*512 + tid at byte (p*512 + tid) * 16
 #define WS_DST(p_, buf_) ldsA[(buf_) * WM * CPR + (((p_) * NTHR + tid) / CPR) * CPR + \
                               ((((p_) * NTHR + tid) % CPR) ^ swz16(((p_) * NTHR + tid) / CPR))]
 #define WS_LOAD(r0_, r1_, tile_)                                                          \
     do {                                                                                  \
-        r0_ = *(const uint4*)WS_SRC(0, tile_);                                            \
-        if constexpr (APT == 2) { r1_ = *(const uint4*)WS_SRC(1, tile_); }                \
+        const rsrc_t ra_ = make_rsrc(A + (long)(tile_) * WM * K, WM * K * 2);             \
+        r0_ = buf_load16(ra_, voff, 0);                                                   \
+        if constexpr (APT == 2) { r1_ = buf_load16(ra_, voff, NTHR * 16); }               \
     } while (0)
 #define WS_STORE(r0_, r1_, buf_)                                                          \
     do {                                                                                  \
@@ -76,14 +89,30 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
     if (tile >= ntiles) return;
     WS_LOAD(ra0, ra1, tile);
     WS_STORE(ra0, ra1, 0);
-    if (tile + (int)gridDim.x < ntiles) WS_LOAD(ra0, ra1, tile + gridDim.x);     // pending set of the first iteration
+    WS_LOAD(ra0, ra1, min(tile + (int)gridDim.x, ntiles - 1));     // pending set of the first iteration (clamped: loads
+                                                                    // of the steady state are unconditional)
     __syncthreads();
     int buf = 0;
     // one iteration: `pend` holds tile+stride (requested one iteration ago, stored to LDS at the end of this one),
     // `fresh` receives tile+2*stride now
     auto iteration = [&](uint4& pend0, uint4& pend1, uint4& fresh0, uint4& fresh1) {
         const int next = tile + gridDim.x, next2 = tile + 2 * gridDim.x;
-        if (next2 < ntiles) WS_LOAD(fresh0, fresh1, next2);
+        // epilogue operands of THIS tile (residual rows) are requested before the prefetch of tile + 2 strides: vmcnt is
+        // in order, so waiting for them later leaves the (younger) prefetch in flight
+        const long row0 = (long)tile * WM;
+        constexpr int LPR = N / 4;                 // lanes per row (64 for N = 256, 32 for N = 128)
+        constexpr int RPP = 64 / LPR;              // rows per wave pass (1 or 2)
+        constexpr int NPASS = WM / (NWAVES * RPP); // 4 (N = 256) or 2 (N = 128)
+        const int col = (lane % LPR) * 4;
+        const bool use_table = EPI && e.table && col < e.table_cols;
+        uint2 res[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const long row = row0 + (pass * NWAVES + wave) * RPP + lane / LPR;
+            res[pass] = (EPI && e.resid) ? *(const uint2*)(e.resid + (e.resid_rows ? (row % e.resid_rows) : row) * e.ldr + col)
+                                         : make_uint2(0u, 0u);
+        }
+        WS_LOAD(fresh0, fresh1, min(next2, ntiles - 1));
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -104,21 +133,6 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
                 for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma16(a[mi], bfr[ni][kc], acc[mi][ni]);
         }
         // ---- fp32 tile -> LDS (row-complete epilogue); ldsC is private to the epilogue, ldsA[buf^1] gets the next tile
-        // epilogue operands (positional table, residual rows) are requested BEFORE the barrier so that their HBM
-        // latency overlaps the LDS round trip of the accumulators
-        const long row0 = (long)tile * WM;
-        constexpr int LPR = N / 4;                 // lanes per row (64 for N = 256, 32 for N = 128)
-        constexpr int RPP = 64 / LPR;              // rows per wave pass (1 or 2)
-        constexpr int NPASS = WM / (NWAVES * RPP); // 4 (N = 256) or 2 (N = 128)
-        const int col = (lane % LPR) * 4;
-        const bool use_table = e.table && col < e.table_cols;
-        uint2 res[NPASS];
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const long row = row0 + (pass * NWAVES + wave) * RPP + lane / LPR;
-            res[pass] = e.resid ? *(const uint2*)(e.resid + (e.resid_rows ? (row % e.resid_rows) : row) * e.ldr + col)
-                                : make_uint2(0u, 0u);
-        }
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -129,8 +143,8 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
         if (next < ntiles) WS_STORE(pend0, pend1, buf ^ 1);
         __syncthreads();
 
-        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (e.bias) { const float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+        float bias4[4];
+        { const float4 b = *(const float4*)(prm + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int lr = (pass * NWAVES + wave) * RPP + lane / LPR;
@@ -151,8 +165,7 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
                 const float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 const float var = (e.ln_mode == 1 ? wave_sum64(q) : wave_sum_xor16(q)) * inv_n;
                 const float rstd = 1.0f / sqrtf(var + e.ln_eps);
-                const int lc = e.ln_mode == 2 ? (col & 63) : col;
-                const float4 w4 = *(const float4*)(e.ln_w + lc), b4 = *(const float4*)(e.ln_b + lc);
+                const float4 w4 = *(const float4*)(prm + N + col), b4 = *(const float4*)(prm + 2 * N + col);
                 v[0] = d0 * rstd * w4.x + b4.x; v[1] = d1 * rstd * w4.y + b4.y;
                 v[2] = d2 * rstd * w4.z + b4.z; v[3] = d3 * rstd * w4.w + b4.w;
                 if (e.ln_mode == 2) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
@@ -199,12 +212,12 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
     }
 }
 
-template <int N, int K>
-int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
-    constexpr int LDS_BYTES = 2 * WM * (K / 8) * 16 + WM * N * 4;
+template <int N, int K, bool EPI>
+int launch_epi(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
+    constexpr int LDS_BYTES = 2 * WM * (K / 8) * 16 + WM * N * 4 + 3 * N * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wsgemm_kernel<N, K>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        if (hipFuncSetAttribute((const void*)wsgemm_kernel<N, K, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) { msam_set_error("msam_wsgemm_bf16: cannot raise the dynamic LDS limit"); return 2; }
         attr_set = true;
     }
@@ -215,9 +228,14 @@ int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
     // algorithmic HBM bytes: read A (bf16) [+ residual], write the bf16 output
     const double bytes = (double)M * (K * 2.0 + N * 2.0 + (e.resid && !e.resid_rows ? N * 2.0 : 0.0));
     msam_profile_mark2(s, 1, 2.0 * M * (double)N * K, bytes, 1);
-    hipLaunchKernelGGL((wsgemm_kernel<N, K>), dim3(grid), dim3(NTHR), LDS_BYTES, s, A, W, M, e);
+    hipLaunchKernelGGL((wsgemm_kernel<N, K, EPI>), dim3(grid), dim3(NTHR), LDS_BYTES, s, A, W, M, e);
     msam_profile_mark2(s, 0, 0.0, 0.0, 1);
     return msam_check_launch("msam_wsgemm_bf16");
+}
+
+template <int N, int K>
+int launch(const u16* A, const u16* W, int M, const WsEpi& e, hipStream_t s) {
+    return (e.table || e.resid) ? launch_epi<N, K, true>(A, W, M, e, s) : launch_epi<N, K, false>(A, W, M, e, s);
 }
 
 }  // namespace
