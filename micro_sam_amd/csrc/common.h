@@ -13,15 +13,16 @@ typedef unsigned short u16;
 
 #define MSAM_DEVINL __device__ __forceinline__
 
-// round-to-nearest-even fp32 -> bf16 (bit pattern), NaN preserved as quiet NaN
-MSAM_DEVINL u16 f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (u16)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16 through the gfx950 conversion instruction (v_cvt_pk_bf16_f32, NaN stays NaN);
+// the integer emulation (bias add + NaN branch) cost ~10 VALU instructions and an exec-mask branch per value
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+MSAM_DEVINL u16 f2bf(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
 MSAM_DEVINL float bf2f(u16 h) { return __uint_as_float(((uint32_t)h) << 16); }
-MSAM_DEVINL uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+MSAM_DEVINL uint32_t pack2bf(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
 
 // vmcnt is an in-order counter: waiting for ANY global load also waits for every load issued before it.  Registers
 // that are loaded once (stationary operands) and first used inside a persistent loop make the compiler place that wait

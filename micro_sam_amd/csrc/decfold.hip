@@ -30,7 +30,10 @@ void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int
 namespace {
 
 constexpr int T = 4096, C = 256, CI = 128, TK = 32, NTHR = 256;
-constexpr int KEYS_BYTES = TK * C * 2, TAB_BYTES = TK * CI * 2, BUF_BYTES = KEYS_BYTES + TAB_BYTES;
+// stream tile image of fold_attn_kernel: 16 channel sub-tiles [32 keys][16 channels] of 1024 B, padded to 1056 B so that the
+// staging stores of one token row (16 lanes -> 8 sub-tiles) spread over all LDS banks instead of hitting one 32-byte window
+constexpr int SUBT = 1024 + 32;
+constexpr int KEYS_BYTES = 16 * SUBT, TAB_BYTES = TK * CI * 2, BUF_BYTES = KEYS_BYTES + TAB_BYTES;
 constexpr float NEG_BIG = -1.0e30f;
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -75,7 +78,8 @@ struct FoldArgs {
 __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int TPI = (T / TK) / a.KS;                                  // tiles per item
+    const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 7 - ks_sh;
+    const int TPI = 1 << tpi_sh;                                      // tiles per item ((T / TK) / KS)
     const int my_items = (a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nq = my_items * TPI;
     if (nq <= 0) return;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
-        kdst[i] = (c >> 1) * 1024 + row * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4);
+        kdst[i] = (c >> 1) * SUBT + row * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -96,10 +100,10 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
     // tile q of this workgroup -> (prompt stream base, byte offset of the tile in the stream / table)
     const int voff = tid * 16;
     const rsrc_t rtab = make_rsrc(a.tabk, T * CI * 2);
-    auto tile_src = [&](int q, rsrc_t& rk, int& koffs, int& toffs) {
-        const int item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
-        const int p = item / a.KS, ks = item - p * a.KS;
-        const int key0 = ks * (T / a.KS) + (q % TPI) * TK;
+    auto tile_src = [&](int q, rsrc_t& rk, int& koffs, int& toffs) {   // KS, TPI are powers of two
+        const int item = (int)blockIdx.x + (q >> tpi_sh) * (int)gridDim.x;
+        const int p = item >> ks_sh, ks = item & (a.KS - 1);
+        const int key0 = ks * (T >> ks_sh) + (q & (TPI - 1)) * TK;
         rk = make_rsrc(a.keys + (long)(a.kv_shared ? 0 : p) * T * C, T * C * 2);
         koffs = key0 * C * 2; toffs = key0 * CI * 2;
     };
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int key = b * 16 + fr;
-        koff[b] = (fg >> 1) * 1024 + key * 32 + (((fg & 1) ^ ((key >> 3) & 1)) << 4);
+        koff[b] = (fg >> 1) * SUBT + key * 32 + (((fg & 1) ^ ((key >> 3) & 1)) << 4);
         toff[b] = KEYS_BYTES + key * 256 + (((w * 4 + fg) ^ fr) << 4);
         const int tkey = b * 16 + fg * 4 + (fr >> 2), cc = fr & 3;
         troff[b] = tkey * 32 + ((((cc >> 1) ^ (fg >> 1)) & 1) << 4) + (cc & 1) * 8;
@@ -145,10 +149,10 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
     auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& p4, uint4& p5, uint4& f0, uint4& f1, uint4& f2,
                          uint4& f3, uint4& f4, uint4& f5) {
         FA_LOAD(f0, f1, f2, f3, f4, f5, min(q + 2, nq - 1));
-        const int tt = q % TPI;
+        const int tt = q & (TPI - 1);
         if (tt == 0) {                                   // new work item: folded queries of this wave's two heads
-            item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
-            const int p = item / a.KS;
+            item = (int)blockIdx.x + (q >> tpi_sh) * (int)gridDim.x;
+            const int p = item >> ks_sh;
             const u16* qp = a.qprime + (((long)p * 64) + w * 16 + fr) * C + fg * 8;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) qb[ks] = *(const uint4*)(qp + ks * 32);
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const uint4 a0 = *(const uint4*)(B + koff[0] + ks * 2048);
-            const uint4 a1 = *(const uint4*)(B + koff[1] + ks * 2048);
+            const uint4 a0 = *(const uint4*)(B + koff[0] + ks * 2 * SUBT);
+            const uint4 a1 = *(const uint4*)(B + koff[1] + ks * 2 * SUBT);
             s0 = mfma16(a0, qb[ks], s0);
             s1 = mfma16(a1, qb[ks], s1);
         }
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
         // ---- O'^T += keys^T P^T over the 16 channel tiles
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
-            const uint2 t0 = lds_tr16(B + ct * 1024 + troff[0]);
-            const uint2 t1 = lds_tr16(B + ct * 1024 + troff[1]);
+            const uint2 t0 = lds_tr16(B + ct * SUBT + troff[0]);
+            const uint2 t1 = lds_tr16(B + ct * SUBT + troff[1]);
             f32x4_t o = acc[ct];
             o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
             acc[ct] = mfma16(make_uint4(t0.x, t0.y, t1.x, t1.y), pb, o);
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
     __shared__ __attribute__((aligned(16))) float prm[3][C];                  // bo, ln_w, ln_b
     unsigned char* const PT = lds + 2 * XT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const int TPI = (T / TK) / a.KS;
+    const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 7 - ks_sh;
+    const int TPI = 1 << tpi_sh;                                      // tiles per item ((T / TK) / KS)
     const int my_items = (a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nq = my_items * TPI;
     if (nq <= 0) return;
@@ -315,10 +320,10 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
         kdst[i] = (c >> 2) * SUB_BYTES + row * 64 + (((c & 3) ^ ((row >> 2) & 3)) << 4);
     }
-    auto tile_pos = [&](int q, int& p, int& key0) {
-        const int item = (int)blockIdx.x + (q / TPI) * (int)gridDim.x;
-        p = item / a.KS;
-        key0 = (item - p * a.KS) * (T / a.KS) + (q % TPI) * TK;
+    auto tile_pos = [&](int q, int& p, int& key0) {        // KS, TPI are powers of two; results are wave-uniform
+        const int item = (int)blockIdx.x + (q >> tpi_sh) * (int)gridDim.x;
+        p = __builtin_amdgcn_readfirstlane(item >> ks_sh);
+        key0 = __builtin_amdgcn_readfirstlane((item & (a.KS - 1)) * (T >> ks_sh) + (q & (TPI - 1)) * TK);
     };
     const int voff = tid * 16;
     const rsrc_t rtab = make_rsrc(a.tabq, T * CI * 2);
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         FI_LOAD(f0, f1, f2, f3, min(q + 2, nq - 1));
         int p, key0;
         tile_pos(q, p, key0);
-        if (q % TPI == 0) {                              // new work item: this prompt's folded operands
+        if ((q & (TPI - 1)) == 0) {                      // new work item: this prompt's folded operands
             const u16* kp = a.kfold + (((long)p * 64) + w * 16 + fr) * C + fg * 8;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) kq[ks] = *(const uint4*)(kp + ks * 32);
