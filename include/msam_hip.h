@@ -124,6 +124,17 @@ int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void* ktok, con
                         const void* wq, const void* tabq, const void* wo, const float* bo, const float* ln_w,
                         const float* ln_b, float ln_eps, void* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Output up-scaling + hyper-network product of the mask decoder in one pass over the image-token stream (reference:
+ * segment_anything/modeling/mask_decoder.py MaskDecoder.predict_masks: output_upscaling = ConvTranspose2d(256,64,2,2),
+ * LayerNorm2d(64), GELU, ConvTranspose2d(64,32,2,2), GELU; masks = hyper_in @ upscaled).
+ * keys: bf16 [P,4096,256] (token = 64*ty + tx); w1: bf16 [256 = sub*64 + c1, 256] with sub = 2*dy + dx of the first
+ * transposed convolution, b1 fp32 [256]; ln_w / ln_b fp32 [64]; w2: bf16 [128 = sub2*32 + c2, 64], b2 fp32 [32];
+ * hyper: fp32 [P,4,hyper_ld], the first 32 entries of mask (mask0 + m) are the hyper-network weights of output mask m;
+ * low_res: fp32 [P,nmask,256,256], pixel (4*ty + 2*dy + dy2, 4*tx + 2*dx + dx2). */
+int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float* b1, const float* ln_w, const float* ln_b,
+                       float ln_eps, const void* w2, const float* b2, const float* hyper, int32_t hyper_ld, int32_t mask0,
+                       int32_t nmask, float* low_res, void* stream);
+
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and

@@ -285,101 +285,6 @@ __global__ __launch_bounds__(256) void i2t_attn_kernel(const u16* __restrict__ q
     }
 }
 
-// Fused second up-scaling stage: up1 bf16 [rows,64] (row = ((p*4096 + token)*4 + sub)) x W2 [128,64] ->
-// GELU(. + b2[c2]) . hyper[p][mask][c2]  -> low_res[p][mask'][y][x].
-// MFMA column (n-tile ni, lane column j) is mapped to weight row sub2*32 + c2 with sub2 = j >> 2,
-// c2 = (j & 3)*8 + ni, so the 32-channel reduction is 8 in-lane FMAs + 2 xor-shuffles.
-// One wave = 32 rows (8 tokens x 4 sub-pixels) x 128 columns per step; the next step's A fragments are requested
-// before the current epilogue; the wave's 3 x 4 x 32 output patch goes through a wave-private LDS slab so that the
-// stores are 128-byte row segments instead of scattered dwords.
-__global__ __launch_bounds__(256) void upscale2_hyper_kernel(const u16* __restrict__ up1, const u16* __restrict__ w2,
-                                                             const float* __restrict__ b2, const float* __restrict__ hyper,
-                                                             int hyper_ld, int mask0, int nmask, long rows,
-                                                             float* __restrict__ low_res) {
-    __shared__ float slab[4][3 * 4 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
-    const int sub2 = fr >> 2, cq = (fr & 3) * 8;
-    uint4 wb[8][2];
-    float bias[8];
-#pragma unroll
-    for (int ni = 0; ni < 8; ++ni) {
-        const int wrow = sub2 * 32 + cq + ni;
-        wb[ni][0] = *(const uint4*)(w2 + wrow * 64 + fg * 8);
-        wb[ni][1] = *(const uint4*)(w2 + wrow * 64 + 32 + fg * 8);
-        bias[ni] = b2[cq + ni];
-    }
-    float* my = slab[wave];
-    const long nsteps = rows / 32;                     // 32-row steps, strided over all waves of the grid
-    const long stride = (long)gridDim.x * 4;
-    long step = (long)blockIdx.x * 4 + wave;
-    if (step >= nsteps) return;
-    uint4 a00, a01, a10, a11;                          // A fragments of the two 16-row halves (mi = 0, 1)
-    // buffer addressing + unconditional (clamped) prefetch: see common.h wait_vmem_all() / make_rsrc()
-    const int voff = (fr * 64 + fg * 8) * 2;
-#define UP_LOAD(step_)                                                                           \
-    do {                                                                                         \
-        const rsrc_t ru_ = make_rsrc(up1 + (step_) * 32 * 64, 32 * 64 * 2);                      \
-        a00 = buf_load16(ru_, voff, 0); a01 = buf_load16(ru_, voff, 64);                         \
-        a10 = buf_load16(ru_, voff, 16 * 64 * 2); a11 = buf_load16(ru_, voff, 16 * 64 * 2 + 64); \
-    } while (0)
-    wait_vmem_all();                                   // stationary weights complete before the loop
-    UP_LOAD(step);
-    const int nm1 = nmask - 1;
-    for (; step < nsteps; step += stride) {
-        const long row0 = step * 32;
-        const int p = (int)(row0 / (T * 4));
-        const int token0 = (int)((row0 >> 2) & (T - 1));
-        float h[3][8];
-#pragma unroll
-        for (int mk = 0; mk < 3; ++mk)
-#pragma unroll
-            for (int ni = 0; ni < 8; ++ni)       // masks >= nmask: valid (clamped) loads whose results are never stored
-                h[mk][ni] = hyper[((long)p * 4 + mask0 + min(mk, nm1)) * hyper_ld + cq + ni];
-        f32x4_t acc0[8], acc1[8];
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
-            f32x4_t c = {0.f, 0.f, 0.f, 0.f}, d = c;
-            c = mfma16(a00, wb[ni][0], c); c = mfma16(a01, wb[ni][1], c);
-            d = mfma16(a10, wb[ni][0], d); d = mfma16(a11, wb[ni][1], d);
-            acc0[ni] = c; acc1[ni] = d;
-        }
-        UP_LOAD(min(step + stride, nsteps - 1));                   // in flight during the GELU / reduction epilogue
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float part[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ni = 0; ni < 8; ++ni) {
-                    const float g = gelu_erf((mi == 0 ? acc0[ni][r] : acc1[ni][r]) + bias[ni]);
-#pragma unroll
-                    for (int mk = 0; mk < 3; ++mk) part[mk] += g * h[mk][ni];
-                }
-#pragma unroll
-                for (int mk = 0; mk < 3; ++mk) {
-                    part[mk] += __shfl_xor(part[mk], 1);
-                    part[mk] += __shfl_xor(part[mk], 2);
-                }
-                if ((fr & 3) == 0) {
-                    // row = row0 + mi*16 + fg*4 + r  ->  sub = r, local token = mi*4 + fg
-                    const int yl = (r >> 1) * 2 + (sub2 >> 1), xl = (mi * 4 + fg) * 4 + (r & 1) * 2 + (sub2 & 1);
-#pragma unroll
-                    for (int mk = 0; mk < 3; ++mk) my[(mk * 4 + yl) * 32 + xl] = part[mk];
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int ty = token0 >> 6, tx0 = token0 & 63;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int idx = k * 64 + lane, mk = idx >> 7, yl = (idx >> 5) & 3, xl = idx & 31;
-            if (mk < nmask) low_res[(((long)p * nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + xl] = my[idx];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#undef UP_LOAD
-}
-
 inline int grid_for(long items) { long g = (items + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -690,22 +595,9 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     hipLaunchKernelGGL(gather_iou_kernel, dim3((P * nmask + 255) / 256), dim3(256), 0, cx.s, w.iou_full, P, mask0, nmask, iou);
     CHECK(msam_check_launch("gather_iou"));
 
-    // up-scaling: ConvT1 as GEMM with fused (bias, LayerNorm2d over 64 channels, GELU) epilogue -> fused ConvT2
-    for (int half = 0; half < 2; ++half) {      // two N = 128 launches (two 64-channel LayerNorm groups each)
-        msam_wsgemm_t g{};
-        g.A = w.keys; g.W = (const u16*)dec->up1_w + (long)half * 128 * C; g.M = (int)R; g.N = 128; g.K = C;
-        g.bias = dec->up1_b + half * 128; g.ln_mode = 2; g.ln_w = dec->up_ln_w; g.ln_b = dec->up_ln_b; g.ln_eps = 1e-6f;
-        g.out = w.up1 + half * 128; g.ldc = C;
-        CHECK(msam_wsgemm_bf16(&g, cx.s));
-    }
-    {
-        const long rows = R * 4;
-        long tiles = rows / 128;
-        int grid = (int)(tiles < 1024 ? tiles : 1024);
-        hipLaunchKernelGGL(upscale2_hyper_kernel, dim3(grid), dim3(256), 0, cx.s, w.up1, (const u16*)dec->up2_w, dec->up2_b,
-                           w.hyper, 128, mask0, nmask, rows, low_res);
-        CHECK(msam_check_launch("upscale2_hyper"));
-    }
+    // up-scaling (ConvT1 + LayerNorm2d + GELU + ConvT2 + GELU) and hyper-network product in one pass over the stream
+    CHECK(msam_upscale_fused(w.keys, P, dec->up1_w, dec->up1_b, dec->up_ln_w, dec->up_ln_b, 1e-6f, dec->up2_w, dec->up2_b,
+                             w.hyper, 128, mask0, nmask, low_res, cx.s));
 #undef CHECK
 #undef ADD_CAST
 #undef LN

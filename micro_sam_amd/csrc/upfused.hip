@@ -1,0 +1,249 @@
+// Fused output up-scaling of the mask decoder (reference: segment_anything MaskDecoder.predict_masks,
+// output_upscaling = ConvT(256->64, 2x2) . LayerNorm2d . GELU . ConvT(64->32, 2x2) . GELU, followed by the
+// hyper-network product  masks = hyper_in @ upscaled;  SURVEY.md A.4 step (6)) in ONE pass over the per-prompt
+// image-token stream: 2 MiB read and 3 x 256 KiB written per prompt, no intermediate stream.
+//
+// Everything is computed in TRANSPOSED form so that each stage's accumulator registers ARE the next stage's MFMA B
+// operand (k-slot map (lane group g, i < 4) <-> row 4g + i of the first 16-row tile, i >= 4 <-> the second tile):
+//   stage 1   U^T [(sub, c1)][token] = W1 . keys^T     A = W1 rows (stationary, 128 VGPRs), B = keys tile (LDS, b128)
+//             + bias, LayerNorm2d over the 64 c1 of a (token, sub) = registers + 2 cross-lane steps, GELU, pack to bf16
+//   stage 2   Y^T [(sub2, c2)][pixel] = W2 . G1        A = W2 (LDS, k-permuted image), B = G1 (registers)
+//             + bias, GELU, split into bf16 hi + lo
+//   stage 3   out^T [mask][pixel] = H . G2             A = hyper weights of the prompt (hi + lo), B = G2 (registers)
+// One 8-wave workgroup per CU; wave = (sub-pixel of stage 1, 16-token half of the 32-token tile); one barrier per tile
+// (tile staging double buffer + output patch double buffer).
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int family);
+
+namespace {
+
+constexpr int T = 4096, C = 256, TK = 32, NTHR = 512;
+constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;     // k-step sub-tiles [32 tokens][64 B] (+ pad), see decfold.hip
+constexpr int W2_BYTES = 128 * 128;
+constexpr int PATCH = 3 * 4 * 128;                                    // [mask][4 rows][128 pixels] fp32
+
+struct UpArgs {
+    const u16* keys;                     // bf16 [P, 4096, 256]
+    const u16* w1; const float* b1;      // bf16 [256 = sub*64 + c1][256], fp32 [256]
+    const float* lnw; const float* lnb; float eps;     // LayerNorm2d over the 64 channels
+    const u16* w2; const float* b2;      // bf16 [128 = sub2*32 + c2][64], fp32 [32]
+    const float* hyper; int hyper_ld, mask0, nmask;    // fp32 [P, 4, hyper_ld]
+    int nitems, KS;
+    float* out;                          // fp32 [P, nmask, 256, 256]
+};
+
+__global__ __launch_bounds__(NTHR, 1) void up_fused_kernel(UpArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
+    __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
+    __shared__ __attribute__((aligned(16))) float prm[256 + 64 + 64 + 32];       // b1, ln_w, ln_b, b2
+    unsigned char* const W2L = lds + 2 * XT_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    const int sub = w >> 1, ct = w & 1;
+    const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 7 - ks_sh, TPI = 1 << tpi_sh;
+    const int my_items = (a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nq = my_items * TPI;
+    if (nq <= 0) return;
+
+    if (tid < 416) prm[tid] = tid < 256 ? a.b1[tid] : tid < 320 ? a.lnw[tid - 256] : tid < 384 ? a.lnb[tid - 320] : a.b2[tid - 384];
+    // W2 image: row (sub2, c2), 16-byte chunk (kk, g) = { W2[row][32kk + 4g .. +3], W2[row][32kk + 16 + 4g .. +3] }: the k-slot
+    // order in which stage 1 leaves its results; chunk' = chunk ^ ((row >> 1) & 7)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int id = j * NTHR + tid, row = id >> 3, ch = id & 7, kk = ch >> 2, g = ch & 3;
+        const uint2 lo = *(const uint2*)(a.w2 + row * 64 + kk * 32 + g * 4);
+        const uint2 hi = *(const uint2*)(a.w2 + row * 64 + kk * 32 + 16 + g * 4);
+        *(uint4*)(W2L + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    uint4 w1f[4][8];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            w1f[rt][ks] = *(const uint4*)(a.w1 + (long)(sub * 64 + rt * 16 + fr) * C + ks * 32 + fg * 8);
+    wait_vmem_all();
+
+    // ---- staging: 2 chunks of the stream tile per thread
+    uint4 ra0, ra1, rb0, rb1;
+    int kdst[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
+        kdst[i] = (c >> 2) * SUB_BYTES + row * 64 + (((c & 3) ^ ((row >> 2) & 3)) << 4);
+    }
+    auto tile_pos = [&](int q, int& p, int& key0) {
+        const int item = (int)blockIdx.x + (q >> tpi_sh) * (int)gridDim.x;
+        p = __builtin_amdgcn_readfirstlane(item >> ks_sh);
+        key0 = __builtin_amdgcn_readfirstlane((item & (a.KS - 1)) * (T >> ks_sh) + (q & (TPI - 1)) * TK);
+    };
+    const int voff = tid * 16;
+#define UF_LOAD(r0_, r1_, q_)                                                                      \
+    do {                                                                                           \
+        int p_, k0_;                                                                               \
+        tile_pos(q_, p_, k0_);                                                                     \
+        const rsrc_t rx_ = make_rsrc(a.keys + (long)p_ * T * C, T * C * 2);                        \
+        r0_ = buf_load16(rx_, voff, k0_ * C * 2); r1_ = buf_load16(rx_, voff, k0_ * C * 2 + NTHR * 16); \
+    } while (0)
+#define UF_STORE(r0_, r1_, buf_)                                                                   \
+    do {                                                                                           \
+        unsigned char* b_ = lds + (buf_) * XT_BYTES;                                               \
+        *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_;                              \
+    } while (0)
+
+    const int boff = (ct * 16 + fr) * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);         // stage-1 B fragment (token, k-step slot fg)
+    const int w2off = fr * 128;                                                   // + row-tile * 2048, chunk swizzled below
+    const int w2sw = (fr >> 1) & 7;
+    uint4 hh = make_uint4(0, 0, 0, 0), hl = hh;                                   // hyper weights of the prompt (A operand)
+
+    UF_LOAD(ra0, ra1, 0);
+    UF_STORE(ra0, ra1, 0);
+    UF_LOAD(ra0, ra1, min(1, nq - 1));
+    __syncthreads();
+
+    int q = 0, buf = 0;
+    auto iteration = [&](uint4& p0, uint4& p1, uint4& f0, uint4& f1) {
+        UF_LOAD(f0, f1, min(q + 2, nq - 1));
+        int p, key0;
+        tile_pos(q, p, key0);
+        if ((q & (TPI - 1)) == 0) {                      // new work item: hyper weights, rows = masks, k-slots = c2
+            float h8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (fr < a.nmask) {
+                const float* hp = a.hyper + ((long)p * 4 + a.mask0 + fr) * a.hyper_ld;
+                const float4 x0 = *(const float4*)(hp + fg * 4), x1 = *(const float4*)(hp + 16 + fg * 4);
+                h8[0] = x0.x; h8[1] = x0.y; h8[2] = x0.z; h8[3] = x0.w; h8[4] = x1.x; h8[5] = x1.y; h8[6] = x1.z; h8[7] = x1.w;
+            }
+            wait_vmem_all();
+            float l8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) l8[i] = h8[i] - bf2f(f2bf(h8[i]));
+            hh = make_uint4(pack2bf(h8[0], h8[1]), pack2bf(h8[2], h8[3]), pack2bf(h8[4], h8[5]), pack2bf(h8[6], h8[7]));
+            hl = make_uint4(pack2bf(l8[0], l8[1]), pack2bf(l8[2], l8[3]), pack2bf(l8[4], l8[5]), pack2bf(l8[6], l8[7]));
+        }
+        const unsigned char* B = lds + buf * XT_BYTES;
+        // ---- stage 1: U^T rows (sub, c1 = 16 rt + 4 fg + r), column token ct*16 + fr
+        f32x4_t u[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) u[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const uint4 kf = *(const uint4*)(B + boff + ks * SUB_BYTES);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16(w1f[rt][ks], kf, u[rt]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const float4 b4 = *(const float4*)&prm[sub * 64 + rt * 16 + fg * 4];
+            u[rt][0] += b4.x; u[rt][1] += b4.y; u[rt][2] += b4.z; u[rt][3] += b4.w;
+            s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
+        }
+        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+        const float mean = s * (1.f / 64.f);
+        float ss = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { u[rt][r] -= mean; ss += u[rt][r] * u[rt][r]; }
+        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
+        const float rstd = rsqrtf(ss * (1.f / 64.f) + a.eps);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
+            u[rt][0] = gelu_erf(u[rt][0] * rstd * g4.x + b4.x); u[rt][1] = gelu_erf(u[rt][1] * rstd * g4.y + b4.y);
+            u[rt][2] = gelu_erf(u[rt][2] * rstd * g4.z + b4.z); u[rt][3] = gelu_erf(u[rt][3] * rstd * g4.w + b4.w);
+        }
+        uint4 g1[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            g1[kk] = make_uint4(pack2bf(u[2 * kk][0], u[2 * kk][1]), pack2bf(u[2 * kk][2], u[2 * kk][3]),
+                                pack2bf(u[2 * kk + 1][0], u[2 * kk + 1][1]), pack2bf(u[2 * kk + 1][2], u[2 * kk + 1][3]));
+        // ---- stages 2 and 3, one second-level sub-pixel at a time
+        float* pt = patch[q & 1];
+        const float4 ba = *(const float4*)&prm[384 + fg * 4], bb = *(const float4*)&prm[384 + 16 + fg * 4];
+#pragma unroll
+        for (int sub2 = 0; sub2 < 4; ++sub2) {
+            f32x4_t ya = {0.f, 0.f, 0.f, 0.f}, yb = ya;              // c2 = 4 fg + r and 16 + 4 fg + r
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint4 wa = *(const uint4*)(W2L + (sub2 * 2) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
+                const uint4 wb = *(const uint4*)(W2L + (sub2 * 2 + 1) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
+                ya = mfma16(wa, g1[kk], ya);
+                yb = mfma16(wb, g1[kk], yb);
+            }
+            float ga[4], gb[4];
+            ga[0] = gelu_erf(ya[0] + ba.x); ga[1] = gelu_erf(ya[1] + ba.y); ga[2] = gelu_erf(ya[2] + ba.z); ga[3] = gelu_erf(ya[3] + ba.w);
+            gb[0] = gelu_erf(yb[0] + bb.x); gb[1] = gelu_erf(yb[1] + bb.y); gb[2] = gelu_erf(yb[2] + bb.z); gb[3] = gelu_erf(yb[3] + bb.w);
+            const uint4 gh = make_uint4(pack2bf(ga[0], ga[1]), pack2bf(ga[2], ga[3]), pack2bf(gb[0], gb[1]), pack2bf(gb[2], gb[3]));
+            const uint32_t hw[4] = {gh.x, gh.y, gh.z, gh.w};
+            float la[4], lb[4];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                la[2 * x] = ga[2 * x] - bf2f((u16)(hw[x] & 0xffff)); la[2 * x + 1] = ga[2 * x + 1] - bf2f((u16)(hw[x] >> 16));
+                lb[2 * x] = gb[2 * x] - bf2f((u16)(hw[2 + x] & 0xffff)); lb[2 * x + 1] = gb[2 * x + 1] - bf2f((u16)(hw[2 + x] >> 16));
+            }
+            const uint4 gl = make_uint4(pack2bf(la[0], la[1]), pack2bf(la[2], la[3]), pack2bf(lb[0], lb[1]), pack2bf(lb[2], lb[3]));
+            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
+            o = mfma16(hh, gh, o);
+            o = mfma16(hl, gh, o);
+            o = mfma16(hh, gl, o);
+            if (fg == 0) {                               // rows = masks r, column = token fr
+                const int yl = (sub >> 1) * 2 + (sub2 >> 1), xl = (ct * 16 + fr) * 4 + (sub & 1) * 2 + (sub2 & 1);
+                pt[(0 * 4 + yl) * 128 + xl] = o[0];
+                pt[(1 * 4 + yl) * 128 + xl] = o[1];
+                pt[(2 * 4 + yl) * 128 + xl] = o[2];
+            }
+        }
+        UF_STORE(p0, p1, buf ^ 1);
+        __syncthreads();                                 // next tile staged; output patch of this tile complete
+        if (tid < 128 * a.nmask) {
+            const int mk = tid >> 7, rem = tid & 127, yl = rem >> 5, x4 = rem & 31;
+            const int ty = key0 >> 6, tx0 = key0 & 63;
+            *(float4*)(a.out + (((long)p * a.nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + x4 * 4) =
+                *(const float4*)&pt[(mk * 4 + yl) * 128 + x4 * 4];
+        }
+        buf ^= 1;
+    };
+    while (true) {
+        iteration(ra0, ra1, rb0, rb1);
+        if (++q >= nq) break;
+        iteration(rb0, rb1, ra0, ra1);
+        if (++q >= nq) break;
+    }
+#undef UF_LOAD
+#undef UF_STORE
+}
+
+}  // namespace
+
+extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float* b1, const float* ln_w,
+                                  const float* ln_b, float ln_eps, const void* w2, const float* b2, const float* hyper,
+                                  int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res, void* stream) {
+    if (!keys || !w1 || !b1 || !ln_w || !ln_b || !w2 || !b2 || !hyper || !low_res || P <= 0) {
+        msam_set_error("msam_upscale_fused: null argument");
+        return 1;
+    }
+    if (nmask < 1 || nmask > 3 || mask0 < 0 || mask0 + nmask > 4 || hyper_ld < 32 || hyper_ld % 4) {
+        msam_set_error("msam_upscale_fused: 1 <= nmask <= 3 masks out of 4, hyper_ld >= 32 and a multiple of 4");
+        return 1;
+    }
+    UpArgs a{};
+    a.keys = (const u16*)keys; a.w1 = (const u16*)w1; a.b1 = b1; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps;
+    a.w2 = (const u16*)w2; a.b2 = b2; a.hyper = hyper; a.hyper_ld = hyper_ld; a.mask0 = mask0; a.nmask = nmask;
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int ks = 1;
+    while (P * ks < cus && ks < 16) ks *= 2;
+    a.KS = ks; a.nitems = P * ks; a.out = low_res;
+    const int grid = a.nitems < cus ? a.nitems : cus;
+    const double rows = (double)P * T;
+    const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
+    const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
+    msam_profile_mark2(stream, 1, flops, bytes, 1);
+    hipLaunchKernelGGL(up_fused_kernel, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    msam_profile_mark2(stream, 0, flops, bytes, 1);
+    return msam_check_launch("up_fused");
+}

@@ -358,3 +358,15 @@ def i2t_fold_layer(xin, ktok, vtok, wq, tabq, wo, bo, ln_w, ln_b, *, x_shared: b
                                        ln_eps, out.data_ptr(), work.data_ptr(), nbytes, _lib.stream_ptr()),
                "msam_i2t_fold_layer")
     return out
+
+
+def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: int, *, ln_eps: float = 1e-6):
+    """Fused output up-scaling + hyper-network product (include/msam_hip.h msam_upscale_fused).
+    keys bf16 [P,4096,256], hyper fp32 [P,4,ld] -> fp32 [P,nmask,256,256]."""
+    _lib.require_gpu()
+    P = keys.shape[0]
+    out = torch.empty((P, nmask, 256, 256), dtype=torch.float32, device=keys.device)
+    _lib.check(_lib.load().msam_upscale_fused(keys.data_ptr(), P, w1.data_ptr(), b1.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                              ln_eps, w2.data_ptr(), b2.data_ptr(), hyper.data_ptr(), hyper.shape[-1], mask0,
+                                              nmask, out.data_ptr(), _lib.stream_ptr()), "msam_upscale_fused")
+    return out

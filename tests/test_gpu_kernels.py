@@ -329,3 +329,31 @@ def test_i2t_fold_layer(env, P, Nt, shared):
         x2 = x.clone()
         ops.i2t_fold_layer(x2, ktok, vtok, wq, tabq, wo, bo, lw, lb, out=x2)
         assert torch.equal(x2, out)
+
+
+@pytest.mark.parametrize("P,mask0,nmask", [(2, 1, 3), (3, 0, 1), (300, 1, 3)])
+def test_upscale_fused(env, P, mask0, nmask):
+    """Fused ConvT + LayerNorm2d + GELU + ConvT + GELU + hyper product vs torch (conv_transpose2d on the same bf16 operands)."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(5 + P)
+    keys = _bf(torch.randn(P, 4096, 256, generator=g)).to(dev)
+    ct1 = _bf(torch.randn(256, 64, 2, 2, generator=g) / 16).to(dev); cb1 = torch.randn(64, generator=g).to(dev)
+    lw = (torch.randn(64, generator=g) * 0.2 + 1).to(dev); lb = (torch.randn(64, generator=g) * 0.3).to(dev)
+    ct2 = _bf(torch.randn(64, 32, 2, 2, generator=g) / 8).to(dev); cb2 = torch.randn(32, generator=g).to(dev)
+    hyper = torch.randn(P, 4, 128, generator=g).to(dev)
+    w1 = ct1.permute(2, 3, 1, 0).reshape(256, 256).contiguous().to(torch.bfloat16)
+    w2 = ct2.permute(2, 3, 1, 0).reshape(128, 64).contiguous().to(torch.bfloat16)
+    out = ops.upscale_fused(keys, w1, cb1.repeat(4).contiguous(), lw, lb, w2, cb2, hyper, mask0, nmask)
+    sel = list(range(min(P, 2))) + ([P - 1] if P > 2 else [])
+    src = keys[sel].float().transpose(1, 2).reshape(len(sel), 256, 64, 64)
+    up = F.conv_transpose2d(src, ct1.float(), cb1, stride=2)
+    mu = up.mean(1, keepdim=True); var = ((up - mu) ** 2).mean(1, keepdim=True)
+    up = (up - mu) / torch.sqrt(var + 1e-6) * lw.view(1, -1, 1, 1) + lb.view(1, -1, 1, 1)
+    up = _bf(F.gelu(up)).float()
+    up = F.gelu(F.conv_transpose2d(up, ct2.float(), cb2, stride=2))                   # [n,32,256,256]
+    ref = torch.einsum("nmc,nchw->nmhw", hyper[sel][:, mask0:mask0 + nmask, :32], up)
+    # stage 1 is rounded to bf16 in both; a rounding-boundary flip of one of the 64 stage-2 inputs moves an output by a few
+    # 1e-3 of the output scale, so the maximum is bounded loosely and the mean error tightly
+    scale = ref.abs().max().item()
+    err = (out[sel] - ref).abs()
+    assert err.max().item() <= 6e-3 * scale and err.mean().item() <= 3e-4 * scale
