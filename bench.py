@@ -97,13 +97,22 @@ def main():
     stage = {"encode": 0.0, "initialize": 0.0, "generate": 0.0, "gather": 0.0}
     n_instances = 0
 
-    # live HIP-event measurement per kernel family: [0] tiled MFMA GEMM, [1] streaming decoder kernels (HBM-bound)
-    prof = [{"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0} for _ in range(2)]
+    # live HIP-event measurement per kernel family (include/msam_hip.h msam_profile_collect_family)
+    NF = _lib.PROFILE_FAMILIES
+    FAMILY = [
+        ("gemm_kernel (128x128x64 bf16 MFMA GEMM: encoder + token-side projections)", "mfma"),
+        ("wsgemm_kernel / dec_image_layer_kernel (weights-stationary streaming kernels, > 8 tokens per prompt)", "hbm"),
+        ("fold_i2t_kernel (folded image->token attention + out_proj + norm4: stream read (layer 1) + written in place)", "hbm"),
+        ("fold_attn_kernel (folded token->image attention: stream read once)", "hbm"),
+        ("up_fused_kernel (fused up-scaling + hyper product: stream read once, fp32 low-res logits written)", "hbm"),
+        ("reserved", "hbm"),
+    ]
+    prof = [{"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0} for _ in range(NF)]
 
     def collect():
-        n_, ms_, fl_, by_ = (C.c_int32 * 2)(), (C.c_double * 2)(), (C.c_double * 2)(), (C.c_double * 2)()
+        n_, ms_, fl_, by_ = (C.c_int32 * NF)(), (C.c_double * NF)(), (C.c_double * NF)(), (C.c_double * NF)()
         lib.msam_profile_collect_family(n_, ms_, fl_, by_)
-        for f in range(2):
+        for f in range(NF):
             prof[f]["launches"] += n_[f]; prof[f]["ms"] += ms_[f]; prof[f]["flops"] += fl_[f]; prof[f]["bytes"] += by_[f]
 
     def step(timed: bool):
@@ -171,27 +180,38 @@ def main():
         def fam(f):
             d = prof[f]
             sec = d["ms"] * 1e-3
-            return {"launches": d["launches"], "seconds_per_tile": round(sec / tiles_timed, 5),
-                    "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
-                    "tflops": round(d["flops"] / sec / 1e12, 2) if sec > 0 else 0.0,
-                    "gbytes_per_s": round(d["bytes"] / sec / 1e9, 1) if sec > 0 and d["bytes"] > 0 else None,
-                    "avg_launch_gflop": round(d["flops"] / max(d["launches"], 1) / 1e9, 3),
-                    "avg_launch_mbytes": round(d["bytes"] / max(d["launches"], 1) / 1e6, 2)}
+            r = {"kernel": FAMILY[f][0], "bound": FAMILY[f][1], "launches": d["launches"],
+                 "seconds_per_tile": round(sec / tiles_timed, 5),
+                 "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
+                 "tflops": round(d["flops"] / sec / 1e12, 2) if sec > 0 else 0.0,
+                 "gbytes_per_s": round(d["bytes"] / sec / 1e9, 1) if sec > 0 and d["bytes"] > 0 else None,
+                 "avg_launch_gflop": round(d["flops"] / max(d["launches"], 1) / 1e9, 3),
+                 "avg_launch_mbytes": round(d["bytes"] / max(d["launches"], 1) / 1e6, 2)}
+            if FAMILY[f][1] == "mfma":
+                r.update(achieved=r["tflops"], peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(r["tflops"] / PEAK_BF16_TFLOPS, 4))
+            else:
+                g = r["gbytes_per_s"] or 0.0
+                r.update(achieved=g, peak=PEAK_HBM_GBS, unit="GB/s", frac=round(g / PEAK_HBM_GBS, 4))
+            return r
 
-        mfma, stream = fam(0), fam(1)
-        # the dominant kernel family by GPU time decides which roofline is quoted; the other one is kept alongside
-        if prof[1]["ms"] >= prof[0]["ms"]:
-            roof = {"bound": "hbm", "kernel": "wsgemm_kernel / dec_image_layer_kernel (weights-stationary streaming kernels on "
-                    "the decoder's per-prompt image-token stream; algorithmic bytes = stream read + write per launch)",
-                    "achieved": stream["gbytes_per_s"], "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round((stream["gbytes_per_s"] or 0.0) / PEAK_HBM_GBS, 4), "traffic": None, **stream,
-                    "mfma_family": {"kernel": "gemm_kernel (128x128x64 bf16 MFMA GEMM)", "bound": "mfma", "achieved": mfma["tflops"],
-                                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(mfma["tflops"] / PEAK_BF16_TFLOPS, 4), **mfma}}
-        else:
-            roof = {"bound": "mfma", "kernel": "gemm_kernel (128x128x64 bf16 MFMA GEMM)", "achieved": mfma["tflops"],
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(mfma["tflops"] / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, **mfma, "streaming_family": stream}
+        fams = [fam(f) for f in range(NF) if prof[f]["launches"] > 0]
+        fams.sort(key=lambda r: -r["seconds_per_tile"])
+        # roofline of the dominant kernel (largest GPU time in the timed region); the others are kept alongside.
+        # `traffic`: HBM bytes per launch from the PMC passes of profiles/ (FETCH_SIZE / WRITE_SIZE, separate runs), when a
+        # table for this kernel is committed
+        dom = dict(fams[0]) if fams else {"bound": "hbm", "achieved": 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 0.0}
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            for name, rec in pmc.items():
+                if isinstance(rec, dict) and name.split("<")[0] in dom.get("kernel", ""):
+                    traffic = rec.get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
+                "traffic": traffic, **{k: v for k, v in dom.items() if k not in ("bound", "achieved", "peak", "unit", "frac")},
+                "other_kernels": fams[1:]}
         out = {
             "metric": "1024^2 tiles/s embed+AMG (vit_b bf16)", "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -141,8 +141,11 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
  * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
 int msam_profile_enable(int on);
 int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops);
-/* Per kernel family: [0] tiled MFMA GEMM (gemm_kernel / gemm_ln_kernel, MFMA-bound), [1] streaming decoder kernels
- * (wsgemm_kernel / dec_image_layer_kernel, HBM-bound).  Arrays of 2: launches, summed ms, flops, algorithmic bytes. */
+/* Per kernel family (arrays of MSAM_PROFILE_FAMILIES: launches, summed ms, flops, algorithmic HBM bytes):
+ * [0] tiled MFMA GEMM (gemm_kernel, MFMA-bound), [1] weights-stationary streaming kernels (wsgemm_kernel /
+ * dec_image_layer_kernel), [2] fold_i2t_kernel, [3] fold_attn_kernel, [4] up_fused_kernel (the decoder kernels that stream
+ * the per-prompt image-token stream once; HBM-bound), [5] reserved. */
+#define MSAM_PROFILE_FAMILIES 6
 int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).

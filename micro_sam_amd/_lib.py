@@ -19,6 +19,7 @@ F32, BF16 = 1, 2
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+PROFILE_FAMILIES = 6          # include/msam_hip.h MSAM_PROFILE_FAMILIES
 
 
 class GemmParams(C.Structure):
@@ -101,7 +102,8 @@ _PROTOS = {
     "msam_i2t_fold_layer": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _vp]),
     "msam_profile_enable": (_i32, [_i32]),
     "msam_profile_collect": (_i32, [C.POINTER(_i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "msam_profile_collect_family": (_i32, [_i32 * 2, C.c_double * 2, C.c_double * 2, C.c_double * 2]),
+    "msam_profile_collect_family": (_i32, [_i32 * PROFILE_FAMILIES, C.c_double * PROFILE_FAMILIES, C.c_double * PROFILE_FAMILIES,
+                                          C.c_double * PROFILE_FAMILIES]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
     "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

@@ -570,9 +570,9 @@ extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, cons
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
     const double bytes = (double)(kv_shared ? 1 : P) * T * C * 2 + (double)P * KS * 64 * C * 4;
-    msam_profile_mark2(stream, 1, flops, bytes, 1);
+    msam_profile_mark2(stream, 1, flops, bytes, 3);
     hipLaunchKernelGGL(fold_attn_kernel, dim3(grid), dim3(NTHR), 0, s, a);
-    msam_profile_mark2(stream, 0, flops, bytes, 1);
+    msam_profile_mark2(stream, 0, flops, bytes, 3);
     if (int e = msam_check_launch("fold_attn")) return e;
     hipLaunchKernelGGL(fold_finish_kernel, dim3(P * 8), dim3(128), 0, s, opart, stats, KS, Nt, (const u16*)wv, bv, (u16*)out);
     return msam_check_launch("fold_finish");
@@ -607,8 +607,8 @@ extern "C" int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
     const double bytes = (double)(x_shared ? 1 : P) * T * C * 2 + (double)P * T * C * 2;
-    msam_profile_mark2(stream, 1, flops, bytes, 1);
+    msam_profile_mark2(stream, 1, flops, bytes, 2);
     hipLaunchKernelGGL(fold_i2t_kernel, dim3(grid), dim3(NTHR), 0, s, a);
-    msam_profile_mark2(stream, 0, flops, bytes, 1);
+    msam_profile_mark2(stream, 0, flops, bytes, 2);
     return msam_check_launch("fold_i2t");
 }

@@ -413,21 +413,23 @@ extern "C" int msam_profile_enable(int on) {
 
 // Synchronises the recorded events; returns launches, total milliseconds and total flops (2*M*N*K) since enable.
 extern "C" int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops) {
-    int32_t n[2]; double ms[2], fl[2], by[2];
+    int32_t n[MSAM_PROFILE_FAMILIES]; double ms[MSAM_PROFILE_FAMILIES], fl[MSAM_PROFILE_FAMILIES], by[MSAM_PROFILE_FAMILIES];
     if (int e = msam_profile_collect_family(n, ms, fl, by)) return e;
-    if (launches) *launches = n[0] + n[1];
-    if (total_ms) *total_ms = ms[0] + ms[1];
-    if (total_flops) *total_flops = fl[0] + fl[1];
+    int32_t nn = 0; double tm = 0, tf = 0;
+    for (int f = 0; f < MSAM_PROFILE_FAMILIES; ++f) { nn += n[f]; tm += ms[f]; tf += fl[f]; }
+    if (launches) *launches = nn;
+    if (total_ms) *total_ms = tm;
+    if (total_flops) *total_flops = tf;
     return 0;
 }
 
 extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes) {
-    for (int f = 0; f < 2; ++f) { launches[f] = 0; ms[f] = 0; flops[f] = 0; bytes[f] = 0; }
+    for (int f = 0; f < MSAM_PROFILE_FAMILIES; ++f) { launches[f] = 0; ms[f] = 0; flops[f] = 0; bytes[f] = 0; }
     for (int i = 0; i < g_prof_n; ++i) {
         if (hipEventSynchronize(g_prof[i].b) != hipSuccess) { msam_set_error("msam_profile_collect: sync failed"); return 2; }
         float t = 0.f;
         hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
-        const int f = g_prof[i].family & 1;
+        const int f = (unsigned)g_prof[i].family < MSAM_PROFILE_FAMILIES ? g_prof[i].family : 1;
         ++launches[f]; ms[f] += t; flops[f] += g_prof[i].flops; bytes[f] += g_prof[i].bytes;
     }
     g_prof_n = 0;

@@ -242,8 +242,8 @@ extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, c
     const double rows = (double)P * T;
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
     const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
-    msam_profile_mark2(stream, 1, flops, bytes, 1);
+    msam_profile_mark2(stream, 1, flops, bytes, 4);
     hipLaunchKernelGGL(up_fused_kernel, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
-    msam_profile_mark2(stream, 0, flops, bytes, 1);
+    msam_profile_mark2(stream, 0, flops, bytes, 4);
     return msam_check_launch("up_fused");
 }
