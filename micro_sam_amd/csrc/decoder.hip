@@ -235,6 +235,84 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ q
     }
 }
 
+// Token -> image attention on the SHARED layer-0 K / V^T (prompt independent, L2 resident) for up to 8 tokens per prompt:
+// one workgroup per (4 prompts, head), i.e. two 16-column score tiles (column = (prompt & 1) * 8 + token) per K / V^T
+// fragment - a quarter of the L2 traffic of the one-prompt-per-workgroup kernel above, which is L2-bandwidth bound.
+__global__ __launch_bounds__(256) void t2i_shared4_kernel(const u16* __restrict__ qtok, const u16* __restrict__ kimg,
+                                                          const u16* __restrict__ vT, int P, int Nt, u16* __restrict__ out) {
+    __shared__ float red[4][32][20];      // per wave: [column][m, l, o[16]] (+pad)
+    const int pg = blockIdx.x >> 3, head = blockIdx.x & 7;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
+    const u16* kb = kimg + (long)head * T * 16;
+    const u16* vb = vT + ((long)head * 16 + fr) * T;
+    const int tk = fr & 7;
+    uint4 qf[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int p = pg * 4 + n * 2 + (fr >> 3);
+        qf[n] = make_uint4(0, 0, 0, 0);
+        if (fg < 2 && tk < Nt && p < P) qf[n] = *(const uint4*)(qtok + ((long)p * Nt + tk) * CI + head * 16 + fg * 8);
+    }
+    f32x4_t o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
+    const int t_begin = wave * (T / 4), t_end = t_begin + T / 4;
+    for (int t0 = t_begin; t0 < t_end; t0 += 32) {
+        uint4 ka0 = make_uint4(0, 0, 0, 0), ka1 = ka0;
+        if (fg < 2) {
+            ka0 = *(const uint4*)(kb + (long)(t0 + fr) * 16 + fg * 8);
+            ka1 = *(const uint4*)(kb + (long)(t0 + 16 + fr) * 16 + fg * 8);
+        }
+        const uint2 v0 = *(const uint2*)(vb + t0 + fg * 4), v1 = *(const uint2*)(vb + t0 + 16 + fg * 4);
+        const uint4 va = make_uint4(v0.x, v0.y, v1.x, v1.y);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            s0 = mfma16(ka0, qf[n], s0);
+            s1 = mfma16(ka1, qf[n], s1);
+            float mt = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s0[r] *= 0.25f; s1[r] *= 0.25f; mt = fmaxf(mt, fmaxf(s0[r], s1[r])); }
+            mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m[n], mt), alpha = __expf(m[n] - mn);
+            m[n] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mn); s1[r] = __expf(s1[r] - mn); ps += s0[r] + s1[r]; }
+            l[n] = l[n] * alpha + ps;
+            uint4 pb;
+            pb.x = pack2bf(s0[0], s0[1]); pb.y = pack2bf(s0[2], s0[3]); pb.z = pack2bf(s1[0], s1[1]); pb.w = pack2bf(s1[2], s1[3]);
+            o[n][0] *= alpha; o[n][1] *= alpha; o[n][2] *= alpha; o[n][3] *= alpha;
+            o[n] = mfma16(va, pb, o[n]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        float ln = l[n];
+        ln += __shfl_xor(ln, 16); ln += __shfl_xor(ln, 32);
+        if (fg == 0) { red[wave][n * 16 + fr][0] = m[n]; red[wave][n * 16 + fr][1] = ln; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][n * 16 + fr][2 + fg * 4 + r] = o[n][r];
+    }
+    __syncthreads();
+    if (wave < 2) {                                  // wave n merges score tile n: lane (column fr, fg) -> o[d = fg*4 + r]
+        const int n = wave, c = n * 16 + fr, p = pg * 4 + n * 2 + (fr >> 3);
+        if (tk < Nt && p < P) {
+            const float mm = fmaxf(fmaxf(red[0][c][0], red[1][c][0]), fmaxf(red[2][c][0], red[3][c][0]));
+            float ll = 0.f, oo[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float a = __expf(red[w][c][0] - mm);
+                ll += a * red[w][c][1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oo[r] += a * red[w][c][2 + fg * 4 + r];
+            }
+            const float inv = 1.f / ll;
+            uint2 pkd; pkd.x = pack2bf(oo[0] * inv, oo[1] * inv); pkd.y = pack2bf(oo[2] * inv, oo[3] * inv);
+            *(uint2*)(out + ((long)p * Nt + tk) * CI + head * 16 + fg * 4) = pkd;
+        }
+    }
+}
+
 // Image -> token cross attention: every image token attends over the Nt (<= 16) prompt tokens.
 //   S^T[j][t] = k_tok[j] . q_img[t]  (A = k_tok rows, B = q_img),  softmax over j = over the lane's registers and
 //   lane groups,  O^T[d][t] = V_tok^T[d][j] P^T[j][t].
@@ -539,7 +617,11 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_BF16, CI));
         if (li == 0) {
             // prompt-independent K / V^T of the shared embedding (prepare_image): 1 MiB, L2 resident
-            hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
+            if (Nt <= 8)
+                hipLaunchKernelGGL(t2i_shared4_kernel, dim3(((P + 3) / 4) * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, P, Nt,
+                                   w.attn_tok);
+            else
+                hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
             CHECK(msam_check_launch("t2i_attn"));
         } else {
             CHECK(t2i_stream(cx, w, c, 1, L.t2i, P, Nt));

@@ -66,28 +66,48 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                                                           int* __restrict__ boxes, uint32_t* __restrict__ bits,
                                                           float* __restrict__ logits) {
     __shared__ int red[4][7];
+    __shared__ float tile[2][10 * 66];
     const int x = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     const int wpc = (out_h + 31) >> 5;
     const float* low = low_res + (long)n * 65536;
     const float hi_t = thr + off, lo_t = thr - off;
     int c_hi = 0, c_lo = 0, c_m = 0, ymin = 0x7fffffff, ymax = -1;
     bool any = false;
-    if (x < out_w) {
-        if (!TWO_STAGE) {
-            // x4 fast path: the horizontal lerp of the 10 low-res rows under a 32-row word is shared by its 32 pixels
-            // (same arithmetic as stage1(), so still bit-exact): pixel b uses rows c, c+1 with c = (b + 2) / 4;
-            // vertical weights are compile-time constants: frac(src) in {.625,.875,.125,.375} by b % 4 (exactly what
-            // axis_weights computes in fp32), except the two clamped rows at the top of the image
-            const Axis ax = axis_weights(x, 0.25f, 256);
-            const float W1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
-            for (int yw = 0; yw < wpc; ++yw) {
-                const int rlo = yw * 8 - 1;
+    if (!TWO_STAGE) {
+        // x4 fast path: the horizontal lerp of the 10 low-res rows under a 32-row word is shared by its 32 pixels
+        // (same arithmetic as stage1(), so still bit-exact): pixel b uses rows c, c+1 with c = (b + 2) / 4;
+        // vertical weights are compile-time constants: frac(src) in {.625,.875,.125,.375} by b % 4 (exactly what
+        // axis_weights computes in fp32), except the two clamped rows at the top of the image.
+        // The 10 x 66 low-res patch under the block's 256 columns is staged through LDS (one coalesced load of 660
+        // floats per word instead of 20 mostly redundant dword loads per thread), next word's patch in flight during
+        // the 32-row loop.
+        const int cbase = max((int)blockIdx.x * 64 - 1, 0);
+        int sr[3], sc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = threadIdx.x + k * 256;
+            sr[k] = idx / 66; sc[k] = min(cbase + idx % 66, 255);
+        }
+        float nx[3] = {0.f, 0.f, 0.f};
+#define PP_LOAD(yw_)                                                                               \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k)                                              \
+            if (threadIdx.x + k * 256 < 660) nx[k] = low[min(max((yw_) * 8 - 1 + sr[k], 0), 255) * 256 + sc[k]];
+#define PP_STORE(buf_)                                                                             \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k)                                              \
+            if (threadIdx.x + k * 256 < 660) tile[buf_][threadIdx.x + k * 256] = nx[k];
+        PP_LOAD(0);
+        PP_STORE(0);
+        __syncthreads();
+        const Axis ax = axis_weights(min(x, out_w - 1), 0.25f, 256);
+        const int l0 = ax.i0 - cbase, l1 = ax.i1 - cbase;
+        const float W1[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+        for (int yw = 0; yw < wpc; ++yw) {
+            if (yw + 1 < wpc) { PP_LOAD(yw + 1); }
+            const float* tl = tile[yw & 1];
+            if (x < out_w) {
                 float t[10];
 #pragma unroll
-                for (int k = 0; k < 10; ++k) {
-                    const int r = min(max(rlo + k, 0), 255);
-                    t[k] = lerp_torch(ax.w0, low[r * 256 + ax.i0], ax.w1, low[r * 256 + ax.i1]);
-                }
+                for (int k = 0; k < 10; ++k) t[k] = lerp_torch(ax.w0, tl[k * 66 + l0], ax.w1, tl[k * 66 + l1]);
                 const int nb = min(32, out_h - yw * 32);
                 uint32_t word = 0;
 #pragma unroll
@@ -107,7 +127,13 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                 }
                 bits[((long)n * wpc + yw) * out_w + x] = word;
             }
-        } else {
+            if (yw + 1 < wpc) { PP_STORE((yw + 1) & 1); }
+            __syncthreads();
+        }
+#undef PP_LOAD
+#undef PP_STORE
+    } else if (x < out_w) {
+        {
             const float sx = (float)in_w / (float)out_w, sy = (float)in_h / (float)out_h;
             const Axis ax2 = axis_weights(x, sx, in_w);
             for (int yw = 0; yw < wpc; ++yw) {

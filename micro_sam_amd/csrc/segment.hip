@@ -169,6 +169,59 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
     }
 }
 
+// K <= 4096 (nblk <= 64): block-wise sweep.  The 64 x 64 diagonal blocks of the suppression matrix sit in LDS, every wave
+// resolves the 64 boxes of a block redundantly in registers (no barrier for the keep word), and the rows of the block are
+// OR-ed into the running "removed" set by all 256 threads with unconditional loads issued before the resolve.
+__global__ __launch_bounds__(256) void nms_sweep64_kernel(const unsigned long long* __restrict__ mask, int K,
+                                                          const int* __restrict__ valid, int* __restrict__ keep) {
+    typedef unsigned long long u64;
+    const int nblk = (K + 63) >> 6, tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    extern __shared__ u64 sm[];
+    u64* remv = sm;                    // [64]
+    u64* diag = sm + 64;               // [nblk * 64]
+    u64* part = diag + nblk * 64;      // [4][64]
+    if (tid < 64) {
+        u64 r = 0ull;
+        if (tid < nblk) {
+            for (int b = 0; b < 64; ++b) {
+                const int i = tid * 64 + b;
+                if (i >= K || (valid && valid[i] == 0)) r |= 1ull << b;     // filtered / padding boxes start as "removed"
+            }
+        }
+        remv[tid] = r;
+    }
+    for (int i = tid; i < nblk * 64; i += 256) diag[i] = i < K ? mask[(long)i * nblk + (i >> 6)] : 0ull;
+    __syncthreads();
+    for (int b = 0; b < nblk; ++b) {
+        u64 rows[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = b * 64 + grp * 16 + j;
+            rows[j] = (lane < nblk && lane > b && r < K) ? mask[(long)r * nblk + lane] : 0ull;
+        }
+        u64 cur = remv[b];
+        const u64 d = diag[b * 64 + lane];
+        const unsigned dlo = (unsigned)d, dhi = (unsigned)(d >> 32);
+        u64 keepw = 0ull;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            if (!((cur >> i) & 1ull)) {
+                keepw |= 1ull << i;
+                cur |= ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+            }
+        }
+        if (grp == 0 && b * 64 + lane < K) keep[b * 64 + lane] = (int)((keepw >> lane) & 1ull);
+        u64 acc = 0ull;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if ((keepw >> (grp * 16 + j)) & 1ull) acc |= rows[j];
+        part[grp * 64 + lane] = acc;
+        __syncthreads();
+        if (grp == 0) remv[lane] |= part[lane] | part[64 + lane] | part[128 + lane] | part[192 + lane];
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int msam_box_nms_valid(const float* boxes_sorted, const int32_t* valid_sorted, int32_t K, float iou_threshold,
@@ -188,8 +241,12 @@ extern "C" int msam_box_nms_valid(const float* boxes_sorted, const int32_t* vali
     if (nblk * 8 > 60000) { msam_set_error("msam_box_nms: too many boxes"); return 1; }
     hipLaunchKernelGGL(nms_mask_kernel, dim3(nblk, nblk), dim3(64), 0, s, boxes_sorted, K, iou_threshold,
                        (unsigned long long*)mask_scratch);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K,
-                       valid_sorted, keep_flags);
+    if (nblk <= 64)
+        hipLaunchKernelGGL(nms_sweep64_kernel, dim3(1), dim3(256), (64 + nblk * 64 + 256) * 8, s,
+                           (const unsigned long long*)mask_scratch, K, valid_sorted, keep_flags);
+    else
+        hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K,
+                           valid_sorted, keep_flags);
     return msam_check_launch("msam_box_nms");
 }
 
