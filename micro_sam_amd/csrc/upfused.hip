@@ -10,8 +10,10 @@
 //   stage 2   Y^T [(sub2, c2)][pixel] = W2 . G1        A = W2 (LDS, k-permuted image), B = G1 (registers)
 //             + bias, GELU, split into bf16 hi + lo
 //   stage 3   out^T [mask][pixel] = H . G2             A = hyper weights of the prompt (hi + lo), B = G2 (registers)
-// One 8-wave workgroup per CU; wave = (sub-pixel of stage 1, 16-token half of the 32-token tile); one barrier per tile
-// (tile staging double buffer + output patch double buffer).
+// 4-wave workgroups on 16-token tiles, wave = sub-pixel of stage 1, two workgroups per CU: the stages of a wave are a long
+// serial chain (MFMA -> LayerNorm -> GELU -> MFMA -> GELU -> MFMA), so independent workgroups in different phases keep
+// both the MFMA and the VALU pipes busy (one 8-wave workgroup ran all waves in lock step: 2.05 ms vs this form).  One
+// barrier per tile (tile staging double buffer + output patch double buffer).
 #include "common.h"
 #include "../../include/msam_hip.h"
 
@@ -21,10 +23,10 @@ void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int
 
 namespace {
 
-constexpr int T = 4096, C = 256, TK = 32, NTHR = 512;
+constexpr int T = 4096, C = 256, TK = 16, NTHR = 256;
 constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;     // k-step sub-tiles [32 tokens][64 B] (+ pad), see decfold.hip
 constexpr int W2_BYTES = 128 * 128;
-constexpr int PATCH = 3 * 4 * 128;                                    // [mask][4 rows][128 pixels] fp32
+constexpr int PATCH = 3 * 4 * 64;                                     // [mask][4 rows][64 pixels] fp32
 
 struct UpArgs {
     const u16* keys;                     // bf16 [P, 4096, 256]
@@ -36,23 +38,23 @@ struct UpArgs {
     float* out;                          // fp32 [P, nmask, 256, 256]
 };
 
-__global__ __launch_bounds__(NTHR, 1) void up_fused_kernel(UpArgs a) {
+__global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
     __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
     __shared__ __attribute__((aligned(16))) float prm[256 + 64 + 64 + 32];       // b1, ln_w, ln_b, b2
     unsigned char* const W2L = lds + 2 * XT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
-    const int sub = w >> 1, ct = w & 1;
-    const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 7 - ks_sh, TPI = 1 << tpi_sh;
+    const int sub = w;
+    const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 8 - ks_sh, TPI = 1 << tpi_sh;        // 256 tiles per prompt
     const int my_items = (a.nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int nq = my_items * TPI;
     if (nq <= 0) return;
 
-    if (tid < 416) prm[tid] = tid < 256 ? a.b1[tid] : tid < 320 ? a.lnw[tid - 256] : tid < 384 ? a.lnb[tid - 320] : a.b2[tid - 384];
+    for (int i = tid; i < 416; i += NTHR) prm[i] = i < 256 ? a.b1[i] : i < 320 ? a.lnw[i - 256] : i < 384 ? a.lnb[i - 320] : a.b2[i - 384];
     // W2 image: row (sub2, c2), 16-byte chunk (kk, g) = { W2[row][32kk + 4g .. +3], W2[row][32kk + 16 + 4g .. +3] }: the k-slot
     // order in which stage 1 leaves its results; chunk' = chunk ^ ((row >> 1) & 7)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
         const int id = j * NTHR + tid, row = id >> 3, ch = id & 7, kk = ch >> 2, g = ch & 3;
         const uint2 lo = *(const uint2*)(a.w2 + row * 64 + kk * 32 + g * 4);
         const uint2 hi = *(const uint2*)(a.w2 + row * 64 + kk * 32 + 16 + g * 4);
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(NTHR, 1) void up_fused_kernel(UpArgs a) {
         *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_;                              \
     } while (0)
 
-    const int boff = (ct * 16 + fr) * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);         // stage-1 B fragment (token, k-step slot fg)
+    const int boff = fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);                     // stage-1 B fragment (token fr, k-step slot fg)
     const int w2off = fr * 128;                                                   // + row-tile * 2048, chunk swizzled below
     const int w2sw = (fr >> 1) & 7;
     uint4 hh = make_uint4(0, 0, 0, 0), hl = hh;                                   // hyper weights of the prompt (A operand)
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(NTHR, 1) void up_fused_kernel(UpArgs a) {
             hl = make_uint4(pack2bf(l8[0], l8[1]), pack2bf(l8[2], l8[3]), pack2bf(l8[4], l8[5]), pack2bf(l8[6], l8[7]));
         }
         const unsigned char* B = lds + buf * XT_BYTES;
-        // ---- stage 1: U^T rows (sub, c1 = 16 rt + 4 fg + r), column token ct*16 + fr
+        // ---- stage 1: U^T rows (sub, c1 = 16 rt + 4 fg + r), column token fr
         f32x4_t u[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) u[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -190,19 +192,19 @@ __global__ __launch_bounds__(NTHR, 1) void up_fused_kernel(UpArgs a) {
             o = mfma16(hl, gh, o);
             o = mfma16(hh, gl, o);
             if (fg == 0) {                               // rows = masks r, column = token fr
-                const int yl = (sub >> 1) * 2 + (sub2 >> 1), xl = (ct * 16 + fr) * 4 + (sub & 1) * 2 + (sub2 & 1);
-                pt[(0 * 4 + yl) * 128 + xl] = o[0];
-                pt[(1 * 4 + yl) * 128 + xl] = o[1];
-                pt[(2 * 4 + yl) * 128 + xl] = o[2];
+                const int yl = (sub >> 1) * 2 + (sub2 >> 1), xl = fr * 4 + (sub & 1) * 2 + (sub2 & 1);
+                pt[(0 * 4 + yl) * 64 + xl] = o[0];
+                pt[(1 * 4 + yl) * 64 + xl] = o[1];
+                pt[(2 * 4 + yl) * 64 + xl] = o[2];
             }
         }
         UF_STORE(p0, p1, buf ^ 1);
         __syncthreads();                                 // next tile staged; output patch of this tile complete
-        if (tid < 128 * a.nmask) {
-            const int mk = tid >> 7, rem = tid & 127, yl = rem >> 5, x4 = rem & 31;
+        if (tid < 64 * a.nmask) {
+            const int mk = tid >> 6, rem = tid & 63, yl = rem >> 4, x4 = rem & 15;
             const int ty = key0 >> 6, tx0 = key0 & 63;
             *(float4*)(a.out + (((long)p * a.nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + x4 * 4) =
-                *(const float4*)&pt[(mk * 4 + yl) * 128 + x4 * 4];
+                *(const float4*)&pt[(mk * 4 + yl) * 64 + x4 * 4];
         }
         buf ^= 1;
     };
@@ -236,9 +238,9 @@ extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, c
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int ks = 1;
-    while (P * ks < cus && ks < 16) ks *= 2;
+    while (P * ks < 2 * cus && ks < 16) ks *= 2;
     a.KS = ks; a.nitems = P * ks; a.out = low_res;
-    const int grid = a.nitems < cus ? a.nitems : cus;
+    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double rows = (double)P * T;
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
     const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
