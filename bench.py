@@ -94,7 +94,7 @@ def main():
     tiles_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in tiles_np]).to(dev)
     torch.cuda.synchronize()
     lib = _lib.load()
-    stage = {"encode": 0.0, "initialize": 0.0, "generate": 0.0, "gather": 0.0}
+    stage = {"encode": 0.0, "initialize": 0.0, "generate": 0.0, "gather": 0.0, "host_enqueue": 0.0}
     n_instances = 0
 
     # live HIP-event measurement per kernel family (include/msam_hip.h msam_profile_collect_family)
@@ -145,6 +145,8 @@ def main():
         full = parallel.gather_label_tiles(labels, n_tiles * world) if world > 1 else labels
         if timed:
             torch.cuda.synchronize(); stage["gather"] += time.perf_counter() - t3
+        if not timed:
+            stage["host_enqueue"] += time.perf_counter() - t0    # host time to enqueue the whole step (no sync inside)
         # single synchronisation point of the step: convergence flags of the connected-component labelling
         if int(torch.stack(flags).sum().item()) != 0:
             raise RuntimeError("connected-component labelling did not converge in 2 passes")
@@ -222,7 +224,9 @@ def main():
                        "tiles_per_step_per_gpu": n_tiles, "encoder_batch": ENC_BATCH, "weights": "seeded random init "
                        "(synthetic.py variant 'blobs')", "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
                        "instances_last_tile": n_instances,
-                       "stage_seconds_per_tile_synced_pass": {k: round(v / n_tiles, 5) for k, v in stage.items()},
+                       "stage_seconds_per_tile_synced_pass": {k: round(v / n_tiles, 5) for k, v in stage.items()
+                                                              if k != "host_enqueue"},
+                       "host_enqueue_seconds_per_tile": round(stage["host_enqueue"] / (n_tiles * n_steps), 5),
                        "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC,
                        "whole_path_tflops_algorithmic": round(TILE_TFLOP_ALGORITHMIC * value / world, 2)},
             "roofline": roof,

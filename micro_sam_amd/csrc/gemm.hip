@@ -22,7 +22,7 @@ struct Epi {
 };
 
 template <bool GLDS>
-__global__ __launch_bounds__(256) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                    long ldw, int M, int N, int K, Epi e) {
     __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TILE_CHUNKS];
 
@@ -100,14 +100,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const u16* __restrict__ A, lo
         }                                                                                              \
     } while (0)
 
-    MSAM_ISSUE(0, 0);
-    MSAM_COMMIT(0);
-    __syncthreads();
-
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) MSAM_ISSUE(kt + 1, buf ^ 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 a[4], b[4];
@@ -123,8 +117,64 @@ __global__ __launch_bounds__(256) void gemm_kernel(const u16* __restrict__ A, lo
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
         }
-        if (kt + 1 < nk) MSAM_COMMIT(buf ^ 1);
+    };
+    if constexpr (GLDS) {
+        MSAM_ISSUE(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) MSAM_ISSUE(kt + 1, buf ^ 1);
+            compute(buf);
+            __syncthreads();
+        }
+    } else {
+        // register staging TWO k-tiles ahead (two register sets, roles swapped by the 2x unrolled loop): with one tile in
+        // flight the k-loop ran at HBM/L2 latency per tile (PMC: 72 % of the wave cycles waiting).  Buffer addressing and
+        // unconditional (clamped) loads keep the waits at vmcnt(8), see common.h.
+        const rsrc_t ra = make_rsrc(A, (uint32_t)min((long)M * lda * 2, 0xffffffffL));
+        const rsrc_t rw = make_rsrc(W, (uint32_t)min((long)N * ldw * 2, 0xffffffffL));
+        int aoff[4], woff[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            aoff[p] = (int)((const char*)a_src[p] - (const char*)A);
+            woff[p] = (int)((const char*)w_src[p] - (const char*)W);
+        }
+        uint4 sa0, sa1, sa2, sa3, sw0, sw1, sw2, sw3;          // second register set (first: ra0..rw3)
+#define G_LOAD(a0_, a1_, a2_, a3_, w0_, w1_, w2_, w3_, kt_)                                            \
+        do {                                                                                           \
+            const int so_ = (kt_) * BK * 2;                                                            \
+            a0_ = buf_load16(ra, aoff[0], so_); a1_ = buf_load16(ra, aoff[1], so_);                    \
+            a2_ = buf_load16(ra, aoff[2], so_); a3_ = buf_load16(ra, aoff[3], so_);                    \
+            w0_ = buf_load16(rw, woff[0], so_); w1_ = buf_load16(rw, woff[1], so_);                    \
+            w2_ = buf_load16(rw, woff[2], so_); w3_ = buf_load16(rw, woff[3], so_);                    \
+        } while (0)
+#define G_COMMIT(a0_, a1_, a2_, a3_, w0_, w1_, w2_, w3_, buf_)                                         \
+        do {                                                                                           \
+            lds[buf_][0][(0 * 32 + srow) * 8 + scp] = a0_; lds[buf_][0][(1 * 32 + srow) * 8 + scp] = a1_; \
+            lds[buf_][0][(2 * 32 + srow) * 8 + scp] = a2_; lds[buf_][0][(3 * 32 + srow) * 8 + scp] = a3_; \
+            lds[buf_][1][(0 * 32 + srow) * 8 + scp] = w0_; lds[buf_][1][(1 * 32 + srow) * 8 + scp] = w1_; \
+            lds[buf_][1][(2 * 32 + srow) * 8 + scp] = w2_; lds[buf_][1][(3 * 32 + srow) * 8 + scp] = w3_; \
+        } while (0)
+        G_LOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, 0);
+        G_COMMIT(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, 0);
+        G_LOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, min(1, nk - 1));
+        __syncthreads();
+        int kt = 0;
+        while (true) {
+            G_LOAD(sa0, sa1, sa2, sa3, sw0, sw1, sw2, sw3, min(kt + 2, nk - 1));
+            compute(kt & 1);
+            if (kt + 1 < nk) G_COMMIT(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, (kt & 1) ^ 1);
+            __syncthreads();
+            if (++kt >= nk) break;
+            G_LOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, min(kt + 2, nk - 1));
+            compute(kt & 1);
+            if (kt + 1 < nk) G_COMMIT(sa0, sa1, sa2, sa3, sw0, sw1, sw2, sw3, (kt & 1) ^ 1);
+            __syncthreads();
+            if (++kt >= nk) break;
+        }
+        wait_vmem_all();                                 // the clamped tail prefetches must not outlive the LDS reuse below
+#undef G_LOAD
+#undef G_COMMIT
     }
 
     // ---- epilogue: stage the fp32 C tile through LDS (reusing the operand buffers), then every thread
