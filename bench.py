@@ -159,6 +159,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     lib.msam_profile_enable(1)
+    stage["host_enqueue"] = 0.0
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step(False)
@@ -226,7 +227,7 @@ def main():
                        "instances_last_tile": n_instances,
                        "stage_seconds_per_tile_synced_pass": {k: round(v / n_tiles, 5) for k, v in stage.items()
                                                               if k != "host_enqueue"},
-                       "host_enqueue_seconds_per_tile": round(stage["host_enqueue"] / (n_tiles * n_steps), 5),
+                       "host_enqueue_seconds_per_tile": round(stage["host_enqueue"] / (n_tiles * args.steps), 5),
                        "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC,
                        "whole_path_tflops_algorithmic": round(TILE_TFLOP_ALGORITHMIC * value / world, 2)},
             "roofline": roof,

@@ -263,6 +263,12 @@ int msam_decoder_forward(const msam_decoder_t* dec, const void* consts, const vo
 int msam_postprocess_masks(const float* low_res, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                            float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits, float* logits,
                            void* stream);
+/* uncrop_masks (reference micro_sam/instance_segmentation.py:250, segment_anything.utils.amg.uncrop_masks): place the
+ * bit masks of a crop / tile, [N, ceil(crop_h/32), crop_w], at (x0, y0) of full-image bit masks [N, ceil(out_h/32), out_w]
+ * (zero outside the crop).  N <= 65535. */
+int msam_uncrop_bits(const uint32_t* bits_crop, int32_t N, int32_t crop_h, int32_t crop_w, int32_t x0, int32_t y0,
+                     int32_t out_h, int32_t out_w, uint32_t* bits_out, void* stream);
+
 /* Column-major run-length encoding of the bit masks (mask_to_rle_pytorch, _vendored.py:114-152).
  * Pass 1 (run_counts): number of runs per mask incl. the leading zero-run convention.
  * Pass 2 (rle_encode): counts written at offsets[n] (exclusive prefix sum of run counts, int64). */

@@ -98,6 +98,7 @@ _PROTOS = {
     "msam_t2i_fold_workspace_bytes": (_i64, [_i32]),
     "msam_t2i_fold_attention": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "msam_upscale_fused": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_uncrop_bits": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msam_i2t_fold_workspace_bytes": (_i64, [_i32]),
     "msam_i2t_fold_layer": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _vp]),
     "msam_profile_enable": (_i32, [_i32]),

@@ -307,6 +307,46 @@ extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t i
     return msam_check_launch("msam_postprocess_masks");
 }
 
+// uncrop_masks of the reference's AMGBase._to_mask_data (instance_segmentation.py:250): bit masks of a crop
+// [N, ceil(ch/32), cw] are placed at (x0, y0) of full-image bit masks [N, ceil(H/32), W] (zero outside the crop).  The
+// row offset is arbitrary, so an output word combines two source words shifted by y0 mod 32.
+__global__ __launch_bounds__(256) void uncrop_bits_kernel(const uint32_t* __restrict__ in, int ch, int cw, int x0, int y0,
+                                                          int H, int W, uint32_t* __restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x, yw = blockIdx.y, n = blockIdx.z;
+    if (x >= W) return;
+    const int wpc_in = (ch + 31) >> 5, wpc_out = (H + 31) >> 5;
+    uint32_t word = 0u;
+    const int xs = x - x0;
+    if (xs >= 0 && xs < cw) {
+        const int base = yw * 32 - y0;                       // source row of bit 0 of this output word
+        const uint32_t* src = in + (long)n * wpc_in * cw + xs;
+        if (base >= 0) {
+            const int wl = base >> 5, sh = base & 31;
+            if (wl < wpc_in) word = src[(long)wl * cw] >> sh;
+            if (sh && wl + 1 < wpc_in) word |= src[(long)(wl + 1) * cw] << (32 - sh);
+        } else if (base > -32) {
+            word = src[0] << (-base);
+        }
+        const int rows = min(32, H - yw * 32);                 // bits beyond the image stay zero
+        if (rows < 32) word &= (1u << rows) - 1u;
+    }
+    out[((long)n * wpc_out + yw) * W + x] = word;
+}
+
+extern "C" int msam_uncrop_bits(const uint32_t* bits_crop, int32_t N, int32_t crop_h, int32_t crop_w, int32_t x0, int32_t y0,
+                                int32_t out_h, int32_t out_w, uint32_t* bits_out, void* stream) {
+    if (!bits_crop || !bits_out || N <= 0 || crop_h <= 0 || crop_w <= 0 || out_h <= 0 || out_w <= 0 || x0 < 0 || y0 < 0 ||
+        x0 + crop_w > out_w || y0 + crop_h > out_h) {
+        msam_set_error("msam_uncrop_bits: bad arguments (the crop must lie inside the output image)");
+        return 1;
+    }
+    if (N > 65535) { msam_set_error("msam_uncrop_bits: at most 65535 masks per call"); return 1; }
+    dim3 grid((out_w + 255) / 256, (out_h + 31) / 32, N);
+    hipLaunchKernelGGL(uncrop_bits_kernel, grid, dim3(256), 0, (hipStream_t)stream, bits_crop, crop_h, crop_w, x0, y0, out_h,
+                       out_w, bits_out);
+    return msam_check_launch("msam_uncrop_bits");
+}
+
 extern "C" int msam_rle_run_counts(const uint32_t* bits, int32_t N, int32_t out_h, int32_t out_w, int32_t* n_runs,
                                    void* stream) {
     if (!bits || !n_runs || N <= 0 || out_h <= 0 || out_w <= 0) { msam_set_error("msam_rle_run_counts: bad arguments"); return 1; }

@@ -9,7 +9,8 @@ Differences to the reference are internal only:
 * the initialised state stays in HBM (``DeviceMaskData``: bit masks [N, H/32, W] instead of RLE lists); the reference's
   ``"rles"`` column is produced lazily by the HIP RLE kernels the first time it is read (state pickling, ``rle`` /
   ``binary_mask`` output); ``generate(output_mode="instance_segmentation")`` paints + labels on the device;
-* ``crop_n_layers > 0`` and the tiled generator are not provided this round (SURVEY.md 8(f) / DESIGN.md).
+* crops (``crop_n_layers > 0``) and tiles (``TiledAutomaticMaskGenerator``) decode at crop resolution; their bit masks
+  are placed into full-image bit masks by ``msam_uncrop_bits`` (the reference's ``uncrop_masks``).
 """
 from __future__ import annotations
 
@@ -171,8 +172,7 @@ class AMGBase(ABC):
         """``AMGBase._to_mask_data`` (reference :229-255) from the fused device post-processing results."""
         orig_h, orig_w = original_size
         x0, y0, x1, y1 = crop_box
-        if not (x0 == 0 and y0 == 0 and x1 == orig_w and y1 == orig_h):
-            raise NotImplementedError("micro_sam_amd: crops that differ from the full image are not provided this round")
+        full_image = (x0 == 0 and y0 == 0 and x1 == orig_w and y1 == orig_h)
         n_masks_per_prompt = iou_preds.shape[1]
         data = DeviceMaskData(mask_size=(orig_h, orig_w), iou_preds=iou_preds.flatten(0, 1))
         if points is not None:
@@ -182,7 +182,8 @@ class AMGBase(ABC):
         data["stability_score"] = counts[:, 0] / counts[:, 1]
         data["boxes"] = post["boxes"]
         data["area"] = counts[:, 2]                 # == area_from_rle of the mask
-        data["bits"] = post["bits"]                 # uncrop_masks is the identity for the full-image crop
+        # uncrop_masks: identity for the full-image crop, otherwise the crop's bit masks are placed in full-image bit masks
+        data["bits"] = post["bits"] if full_image else ops.uncrop_bits(post["bits"], crop_box, orig_h, orig_w)
         return data
 
     def get_state(self) -> Dict[str, Any]:
@@ -219,8 +220,6 @@ class AutomaticMaskGenerator(AMGBase):
             self.point_grids = point_grids
         else:
             raise ValueError("Can't have both points_per_side and point_grid be None or not None.")
-        if crop_n_layers != 0:
-            raise NotImplementedError("micro_sam_amd: crop_n_layers > 0 is not provided this round")
         self._predictor = predictor
         self._points_per_side = points_per_side
         self._points_per_batch = 64 if points_per_batch is None else points_per_batch
@@ -356,11 +355,80 @@ class AutomaticMaskGenerator(AMGBase):
         return masks
 
 
+def _process_tiled_embeddings(predictor, image, image_embeddings, tile_shape, halo, verbose, batch_size, mask, i):
+    """Reference instance_segmentation.py:534-561."""
+    if image_embeddings is None:
+        if tile_shape is None or halo is None:
+            raise ValueError("To compute tiled embeddings the parameters tile_shape and halo have to be passed.")
+        image_embeddings = util.precompute_image_embeddings(predictor, image, tile_shape=tile_shape, halo=halo,
+                                                            verbose=verbose, batch_size=batch_size, mask=mask)
+    feats = image_embeddings["features"]
+    tile_shape_, halo_ = tuple(feats.attrs["tile_shape"]), tuple(feats.attrs["halo"])
+    if tile_shape is None:
+        tile_shape = tile_shape_
+    elif tuple(tile_shape) != tile_shape_:
+        raise ValueError(f"Inconsistent tile_shape parameter {tile_shape} with precomputed embeedings: {tile_shape_}.")
+    if halo is None:
+        halo = halo_
+    elif tuple(halo) != halo_:
+        raise ValueError(f"Inconsistent halo parameter {halo} with precomputed embeedings: {halo_}.")
+    tiles_in_mask = feats.attrs.get("tiles_in_mask", None)
+    if tiles_in_mask is not None and i is not None:
+        tiles_in_mask = tiles_in_mask[str(i)]
+    return image_embeddings, tile_shape, halo, tiles_in_mask
+
+
+class TiledAutomaticMaskGenerator(AutomaticMaskGenerator):
+    """``AutomaticMaskGenerator`` on tiled embeddings (reference instance_segmentation.py:564-680): every tile (outer
+    block = tile + halo) is a crop box with its own precomputed embedding."""
+
+    def __init__(self, predictor: SamPredictor, points_per_side: Optional[int] = 32, points_per_batch: int = 64,
+                 point_grids: Optional[List[np.ndarray]] = None, stability_score_offset: float = 1.0,
+                 device_chunk: int = 1024) -> None:
+        super().__init__(predictor=predictor, points_per_side=points_per_side, points_per_batch=points_per_batch,
+                         point_grids=point_grids, stability_score_offset=stability_score_offset, device_chunk=device_chunk)
+
+    @torch.no_grad()
+    def initialize(self, image: np.ndarray, image_embeddings=None, i: Optional[int] = None,
+                   tile_shape=None, halo=None, verbose: bool = False, pbar_init: Optional[callable] = None,
+                   pbar_update: Optional[callable] = None, batch_size: int = 1, mask=None) -> None:
+        from .tiling import Blocking
+        original_size = image.shape[:2]
+        self._original_size = original_size
+        self._image_embeddings, tile_shape, halo, tiles_in_mask = _process_tiled_embeddings(
+            self._predictor, image, image_embeddings, tile_shape, halo, verbose=verbose, batch_size=batch_size, mask=mask, i=i)
+        image_embeddings = self._image_embeddings
+        tiling = Blocking([0, 0], original_size, tile_shape)
+        if tiles_in_mask is None:
+            n_tiles = tiling.number_of_blocks
+            tile_ids = range(n_tiles)
+        else:
+            n_tiles = len(tiles_in_mask)
+            tile_ids = tiles_in_mask
+        tiles = [tiling.get_block_with_halo(tile_id, list(halo)).outer_block for tile_id in tile_ids]
+        crop_boxes = [[tile.begin[1], tile.begin[0], tile.end[1], tile.end[0]] for tile in tiles]
+        _, pbar_init, pbar_update, pbar_close = util.handle_pbar(verbose, pbar_init, pbar_update)
+        pbar_init(n_tiles, "Compute masks for tile")
+        # only the image SHAPE is used below (the embeddings are precomputed): skip the host-side pixel conversion
+        image = np.broadcast_to(np.zeros((1, 1, 1), dtype=np.uint8), tuple(original_size) + (3,))
+        mask_data = []
+        for idx, tile_id in enumerate(tile_ids):
+            features = image_embeddings["features"][str(tile_id)]
+            tile_embeddings = {"features": features, "input_size": features.attrs["input_size"],
+                               "original_size": features.attrs["original_size"]}
+            util.set_precomputed(self._predictor, tile_embeddings, i)
+            mask_data.append(self._process_crop(image, crop_box=crop_boxes[idx], crop_layer_idx=0,
+                                                precomputed_embeddings=True))
+            pbar_update(1)
+        pbar_close()
+        self._is_initialized = True
+        self._crop_list = mask_data
+        self._crop_boxes = crop_boxes
+
+
 def get_instance_segmentation_generator(predictor: SamPredictor, is_tiled: bool = False, decoder=None,
                                         segmentation_mode: Optional[str] = None, **kwargs) -> AMGBase:
     """Factory with the reference's signature (:1631-1670); only the AMG mode exists in this build."""
-    if is_tiled:
-        raise NotImplementedError("micro_sam_amd: tiled automatic mask generation is not provided this round")
     if decoder is not None or (segmentation_mode not in (None, "amg")):
         raise NotImplementedError("micro_sam_amd: only segmentation_mode='amg' is provided (AIS/APG: SURVEY.md 8(f))")
-    return AutomaticMaskGenerator(predictor, **kwargs)
+    return (TiledAutomaticMaskGenerator if is_tiled else AutomaticMaskGenerator)(predictor, **kwargs)

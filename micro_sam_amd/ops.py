@@ -370,3 +370,21 @@ def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: in
                                               ln_eps, w2.data_ptr(), b2.data_ptr(), hyper.data_ptr(), hyper.shape[-1], mask0,
                                               nmask, out.data_ptr(), _lib.stream_ptr()), "msam_upscale_fused")
     return out
+
+
+def uncrop_bits(bits: torch.Tensor, crop_box, height: int, width: int) -> torch.Tensor:
+    """uncrop_masks on bit masks: [N, ceil(ch/32), cw] of crop_box = [x0, y0, x1, y1] -> [N, ceil(H/32), W] (int32 storage)."""
+    _lib.require_gpu()
+    x0, y0, x1, y1 = (int(v) for v in crop_box)
+    n = int(bits.shape[0])
+    out = torch.empty((n, (height + 31) // 32, width), dtype=torch.int32, device=bits.device)
+    if n == 0:
+        return out
+    bits = bits.contiguous()
+    lib = _lib.load()
+    step = 65535
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        _lib.check(lib.msam_uncrop_bits(bits[s:].data_ptr(), m, y1 - y0, x1 - x0, x0, y0, height, width, out[s:].data_ptr(),
+                                        _lib.stream_ptr()), "msam_uncrop_bits")
+    return out

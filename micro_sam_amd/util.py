@@ -224,23 +224,116 @@ def _compute_3d(input_, predictor, pbar_init, pbar_update, batch_size, keep_on_d
     return {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}
 
 
+def _get_tiles_in_mask(mask, tiling, halo, z=None):
+    """Reference util.py:748-762: ids of the tiles whose OUTER block contains mask foreground."""
+    tiles = []
+    for tile_id in range(tiling.number_of_blocks):
+        tile = tiling.get_block_with_halo(tile_id, list(halo))
+        outer_tile = tuple(slice(beg, end) for beg, end in zip(tile.outer_block.begin, tile.outer_block.end))
+        if z is not None:
+            outer_tile = (z,) + outer_tile
+        if np.asarray(mask[outer_tile]).astype("bool").sum() != 0:
+            tiles.append(tile_id)
+    return tiles
+
+
+def _compute_tiled_features_2d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask):
+    """Reference util.py:765-803; the zarr group is replaced by tiling.TiledFeatures (tensors stay on the device)."""
+    from .tiling import Blocking, TileArray, TiledFeatures
+    tiling = Blocking([0, 0], input_.shape[:2], tile_shape)
+    n_tiles = tiling.number_of_blocks
+    features = TiledFeatures(input_.shape[:2], tile_shape, halo)
+    n_batches = int(np.ceil(n_tiles / batch_size))
+    if mask is None:
+        tile_ids_for_batches = [range(b * batch_size, min((b + 1) * batch_size, n_tiles)) for b in range(n_batches)]
+        pbar_init(n_tiles, "Compute Image Embeddings 2D tiled")
+    else:
+        tiles_in_mask = _get_tiles_in_mask(mask, tiling, halo)
+        pbar_init(len(tiles_in_mask), "Compute Image Embeddings 2D tiled with mask")
+        tile_ids_for_batches = np.array_split(tiles_in_mask, n_batches)
+    for tile_ids in tile_ids_for_batches:
+        tile_ids = [int(t) for t in tile_ids]
+        if len(tile_ids) == 0:
+            continue
+        groups = {}
+        for tile_id in tile_ids:       # the encoder batches tiles of one shape (border tiles of a mosaic are smaller)
+            tile = tiling.get_block_with_halo(tile_id, list(halo))
+            outer_tile = tuple(slice(beg, end) for beg, end in zip(tile.outer_block.begin, tile.outer_block.end))
+            image = _to_image(input_[outer_tile])
+            groups.setdefault(image.shape[:2], []).append((tile_id, image))
+        for members in groups.values():
+            emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [im for _, im in members])
+            for k, (tile_id, _) in enumerate(members):
+                features[tile_id] = TileArray(emb[k:k + 1], original_sizes[k], input_sizes[k])
+        pbar_update(len(tile_ids))
+    if mask is not None:
+        features.attrs["tiles_in_mask"] = tiles_in_mask
+    return features
+
+
+def _compute_tiled_features_3d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask):
+    """Reference util.py:859-905 (per-slice tiles batched by shape)."""
+    from .tiling import Blocking, TileArray, TiledFeatures
+    assert input_.ndim == 3
+    shape = input_.shape[1:]
+    tiling = Blocking([0, 0], shape, tile_shape)
+    features = TiledFeatures(shape, tile_shape, halo)
+    n_slices = input_.shape[0]
+    tiles_in_mask_per_slice = None
+    if mask is not None:
+        tiles_in_mask_per_slice = {z: _get_tiles_in_mask(mask, tiling, halo, z=z) for z in range(n_slices)}
+    work = [(z, t) for z in range(n_slices)
+            for t in (range(tiling.number_of_blocks) if mask is None else tiles_in_mask_per_slice[z])]
+    pbar_init(len(work), "Compute Image Embeddings 3D tiled" + ("" if mask is None else " masked"))
+    store = {}
+    for start in range(0, len(work), batch_size):
+        chunk = work[start:start + batch_size]
+        groups = {}
+        for z, tile_id in chunk:
+            tile = tiling.get_block_with_halo(tile_id, list(halo))
+            outer_tile = (z,) + tuple(slice(beg, end) for beg, end in zip(tile.outer_block.begin, tile.outer_block.end))
+            image = _to_image(input_[outer_tile])
+            groups.setdefault(image.shape[:2], []).append((z, tile_id, image))
+        for members in groups.values():
+            emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [im for _, _, im in members])
+            for k, (z, tile_id, _) in enumerate(members):
+                if tile_id not in store:
+                    store[tile_id] = (torch.zeros((n_slices, 1) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),
+                                      original_sizes[k], input_sizes[k])
+                store[tile_id][0][z, 0] = emb[k]
+        pbar_update(len(chunk))
+    for tile_id, (data, original_size, input_size) in store.items():
+        features[tile_id] = TileArray(data, original_size, input_size)
+    if mask is not None:
+        features.attrs["tiles_in_mask"] = {str(z): per_slice for z, per_slice in tiles_in_mask_per_slice.items()}
+    return features
+
+
 def precompute_image_embeddings(predictor: SamPredictor, input_: np.ndarray, save_path=None, lazy_loading: bool = False,
                                 ndim: Optional[int] = None, tile_shape: Optional[Tuple[int, int]] = None,
                                 halo: Optional[Tuple[int, int]] = None, verbose: bool = True, batch_size: int = 1,
                                 mask=None, pbar_init: Optional[callable] = None, pbar_update: Optional[callable] = None,
                                 keep_on_device: bool = False) -> ImageEmbeddings:
     """Reference util.py:1133-1212.  ``keep_on_device`` (extension): return the features as a device tensor instead of
-    a host numpy array (``set_precomputed`` accepts both, as in the reference util.py:1248-1252)."""
+    a host numpy array (``set_precomputed`` accepts both, as in the reference util.py:1248-1252).  Tiled embeddings
+    (``tile_shape`` / ``halo``) are returned in a ``tiling.TiledFeatures`` container (device tensors) with the attrs of
+    the reference's zarr group; ``input_size`` / ``original_size`` are None for them (util.py:946,1034)."""
     ndim = input_.ndim if ndim is None else ndim
     if save_path is not None:
         raise NotImplementedError("micro_sam_amd: the zarr embedding cache (save_path) is not provided this round")
-    if tile_shape is not None:
-        raise NotImplementedError("micro_sam_amd: tiled embeddings (tile_shape / halo) are not provided this round")
+    if tile_shape is not None and halo is None:
+        raise ValueError("To compute tiled embeddings the parameters tile_shape and halo have to be passed.")
     _, pbar_init, pbar_update, pbar_close = handle_pbar(verbose, pbar_init, pbar_update)
-    if ndim == 2:
+    if ndim == 2 and tile_shape is None:
         embeddings = _compute_2d(input_, predictor, pbar_init, pbar_update, keep_on_device)
-    elif ndim == 3:
+    elif ndim == 2:
+        features = _compute_tiled_features_2d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask)
+        embeddings = {"features": features, "input_size": None, "original_size": None}
+    elif ndim == 3 and tile_shape is None:
         embeddings = _compute_3d(input_, predictor, pbar_init, pbar_update, batch_size, keep_on_device)
+    elif ndim == 3:
+        features = _compute_tiled_features_3d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask)
+        embeddings = {"features": features, "input_size": None, "original_size": None}
     else:
         raise ValueError(f"Invalid dimesionality {input_.ndim}, expect 2 or 3 dim data.")
     pbar_close()
@@ -251,7 +344,10 @@ def set_precomputed(predictor: SamPredictor, image_embeddings: ImageEmbeddings, 
                     tile_id: Optional[int] = None) -> SamPredictor:
     """Reference util.py:1215-1258."""
     if tile_id is not None:
-        raise NotImplementedError("micro_sam_amd: tiled embeddings are not provided this round")
+        tile_features = image_embeddings["features"][str(tile_id)]
+        tile_image_embeddings = {"features": tile_features, "input_size": tile_features.attrs["input_size"],
+                                 "original_size": tile_features.attrs["original_size"]}
+        return set_precomputed(predictor, tile_image_embeddings, i=i)
     device = predictor.device
     features = image_embeddings["features"]
     assert features.ndim in (4, 5), f"{features.ndim}"
@@ -259,10 +355,10 @@ def set_precomputed(predictor: SamPredictor, image_embeddings: ImageEmbeddings, 
         raise ValueError("The data is 3D so an index i is needed.")
     elif features.ndim == 4 and i is not None:
         raise ValueError("The data is 2D so an index is not needed.")
-    sel = features if i is None else features[i]
+    sel = features[:] if i is None else features[i]
     predictor.features = sel.to(device) if torch.is_tensor(sel) else torch.from_numpy(np.asarray(sel[:])).to(device)
-    predictor.original_size = image_embeddings["original_size"]
-    predictor.input_size = image_embeddings["input_size"]
+    predictor.original_size = tuple(image_embeddings["original_size"])
+    predictor.input_size = tuple(image_embeddings["input_size"])
     predictor.is_image_set = True
     return predictor
 

@@ -9,6 +9,7 @@ Restates the reference's own orchestration on top of the model / AMG oracles:
 * ``amg_initialize``      = ``AutomaticMaskGenerator.initialize`` -> ``_process_crop`` -> ``_process_batch``
                             -> ``AMGBase._to_mask_data`` (instance_segmentation.py:229-255,356-461),
                             single-crop (crop_n_layers=0) configuration.
+* ``batched_inference``   = ``inference.batched_inference`` (micro_sam/inference.py:154-286), float thresholds.
 * ``amg_generate``        = ``AutomaticMaskGenerator.generate`` -> ``_postprocess_batch`` ->
                             ``_postprocess_masks`` -> ``util.mask_data_to_segmentation``
                             (instance_segmentation.py:99-144,188-227,463-530; util.py:1773-1848).
@@ -95,6 +96,27 @@ def amg_initialize(sd, image: np.ndarray, features: torch.Tensor, input_size, or
     return {"crop_list": [data], "crop_boxes": crop_boxes, "original_size": original_size}
 
 
+@torch.no_grad()
+def amg_process_crop(sd, features: torch.Tensor, input_size, crop_box, original_size, point_grid: np.ndarray,
+                     points_per_batch: int = 64, precision: str = "fp32", stability_score_offset: float = 1.0) -> A.MaskData:
+    """AMG._process_crop / _process_batch for one crop or tile with a precomputed embedding
+    (instance_segmentation.py:356-401; tiles: :636-650).  crop_box = [x0, y0, x1, y1] in the full image of size
+    original_size; the prediction runs at the crop's own resolution, masks are padded back by uncrop_masks."""
+    x0, y0, x1, y1 = crop_box
+    cropped_im_size = (y1 - y0, x1 - x0)
+    points_for_image = point_grid * np.array(cropped_im_size)[None, ::-1]
+    data = A.MaskData()
+    for (points,) in A.batch_iterator(points_per_batch, points_for_image):
+        in_points = torch.as_tensor(S.apply_coords(points, cropped_im_size), dtype=torch.float)
+        in_labels = torch.ones(in_points.shape[0], dtype=torch.int)
+        masks, iou_preds, _ = S.predict_torch(sd, features, input_size, cropped_im_size, in_points[:, None, :],
+                                              in_labels[:, None], multimask_output=True, return_logits=True,
+                                              precision=precision)
+        data.cat(to_mask_data(masks, iou_preds, crop_box, original_size, points=points,
+                              stability_score_offset=stability_score_offset))
+    return data
+
+
 def postprocess_batch(data: A.MaskData, crop_box, original_size, pred_iou_thresh, stability_score_thresh,
                       box_nms_thresh) -> A.MaskData:
     """AMGBase._postprocess_batch, instance_segmentation.py:99-144."""
@@ -139,12 +161,17 @@ def postprocess_masks(mask_data: A.MaskData, output_mode: str = "binary_mask") -
 
 def amg_generate(state: Dict[str, Any], pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95,
                  box_nms_thresh: float = 0.7, output_mode: str = "instance_segmentation",
-                 with_background: bool = True):
-    """AutomaticMaskGenerator.generate, single crop.  instance_segmentation.py:463-530."""
+                 with_background: bool = True, crop_nms_thresh: float = 0.7):
+    """AutomaticMaskGenerator.generate (crops / tiles included).  instance_segmentation.py:463-530."""
     data = A.MaskData()
     for data_, crop_box in zip(state["crop_list"], state["crop_boxes"]):
         data.cat(postprocess_batch(deepcopy(data_), crop_box, state["original_size"], pred_iou_thresh,
                                    stability_score_thresh, box_nms_thresh))
+    if len(state["crop_boxes"]) > 1 and len(data["crop_boxes"]) > 0:
+        # duplicates between crops: prefer masks from smaller crops (instance_segmentation.py:512-520)
+        scores = 1 / A.box_area(data["crop_boxes"])
+        keep = A.batched_nms(data["boxes"].float(), scores, torch.zeros_like(data["boxes"][:, 0]), iou_threshold=crop_nms_thresh)
+        data.filter(keep)
     data.to_numpy()
     masks = postprocess_masks(data, output_mode)
     if output_mode == "instance_segmentation":
@@ -152,3 +179,45 @@ def amg_generate(state: Dict[str, Any], pred_iou_thresh: float = 0.88, stability
         masks = A.mask_data_to_segmentation(masks, shape=shape, with_background=with_background,
                                             merge_exclusively=False)
     return masks
+
+
+@torch.no_grad()
+def batched_inference(sd, features: torch.Tensor, input_size, original_size, batch_size: int, boxes=None, points=None,
+                      point_labels=None, multimasking: bool = False, return_instance_segmentation: bool = True,
+                      segmentation_ids=None, reduce_multimasking: bool = True, mask_threshold: float = 0.0,
+                      precision: str = "fp32"):
+    """inference.batched_inference (micro_sam/inference.py:154-286) on a precomputed embedding, float threshold.
+    boxes [N,4] xyxy / points [N,Np,2] / point_labels [N,Np] in original image coordinates."""
+    have_boxes, have_points = boxes is not None, points is not None
+    n_prompts = boxes.shape[0] if have_boxes else points.shape[0]
+    n_batches = int(np.ceil(float(n_prompts) / batch_size))
+    if have_boxes:
+        boxes = torch.tensor(S.apply_boxes(np.asarray(boxes), original_size), dtype=torch.float32)
+    if have_points:
+        points = torch.tensor(S.apply_coords(np.asarray(points), original_size), dtype=torch.float32)
+        point_labels = torch.tensor(np.asarray(point_labels), dtype=torch.float32)
+    cols = {"masks": [], "iou_preds": [], "stability_scores": [], "boxes": [], "logits": []}
+    for b in range(n_batches):
+        sl = slice(b * batch_size, min((b + 1) * batch_size, n_prompts))
+        bm, bi, bl = S.predict_torch(sd, features, input_size, original_size, points[sl] if have_points else None,
+                                     point_labels[sl] if have_points else None, boxes[sl] if have_boxes else None, None,
+                                     multimask_output=multimasking, return_logits=True, precision=precision)
+        if reduce_multimasking and multimasking:
+            _, mx = bi.max(axis=1)
+            bm = torch.cat([bm[i, m][None] for i, m in enumerate(mx)]).unsqueeze(1)
+            bi = torch.cat([bi[i, m][None] for i, m in enumerate(mx)]).unsqueeze(1)
+            bl = torch.cat([bl[i, m][None] for i, m in enumerate(mx)]).unsqueeze(1)
+        masks = bm.flatten(0, 1)
+        cols["stability_scores"].append(A.calculate_stability_score(masks, mask_threshold, 1.0))
+        masks = masks > mask_threshold
+        cols["masks"].append(masks); cols["iou_preds"].append(bi.flatten(0, 1)); cols["boxes"].append(A.batched_mask_to_box(masks))
+        cols["logits"].append(bl)
+    cat = {k: torch.cat(v) for k, v in cols.items()}
+    records = [{"segmentation": cat["masks"][i], "area": cat["masks"][i].sum(),
+                "bbox": A.box_xyxy_to_xywh(cat["boxes"][i]).tolist(), "predicted_iou": cat["iou_preds"][i].item(),
+                "stability_score": cat["stability_scores"][i].item(),
+                "seg_id": i + 1 if segmentation_ids is None else int(segmentation_ids[i]), "logits": cat["logits"][i]}
+               for i in range(len(cat["masks"]))]
+    if return_instance_segmentation:
+        return A.mask_data_to_segmentation(records, min_object_size=0)
+    return records

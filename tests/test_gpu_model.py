@@ -169,3 +169,132 @@ def test_precompute_3d_batched(ctx):
     assert p.features.shape == (1, 256, 64, 64) and p.original_size == (512, 512)
     with pytest.raises(ValueError):
         util.set_precomputed(p, emb)
+
+
+def test_batched_inference_vs_oracle(ctx):
+    """inference.batched_inference (reference inference.py:154-286): box + point prompts, best-of-3 reduction, records and
+    label image against the oracle's restatement on the same embedding (bf16-mode decoder), integer merge exact."""
+    from micro_sam_amd import inference, util
+    from oracle import pipeline_ref as R
+    p = ctx["predictor"]
+    p.reset_image()
+    emb = util.precompute_image_embeddings(p, ctx["tile"])
+    util.set_precomputed(p, emb)
+    feats = p.features.float().cpu()
+    g = np.random.default_rng(3)
+    n = 10
+    cx, cy = g.uniform(150, 870, n), g.uniform(150, 870, n)
+    wh = g.uniform(40, 140, (n, 2))
+    boxes = np.stack([cx - wh[:, 0], cy - wh[:, 1], cx + wh[:, 0], cy + wh[:, 1]], 1).astype(np.float32)
+    points = np.stack([cx, cy], 1)[:, None, :].astype(np.float32)
+    labels = np.ones((n, 1), dtype=np.int64)
+    for kw in (dict(boxes=boxes), dict(points=points, point_labels=labels, multimasking=True),
+               dict(boxes=boxes, points=points, point_labels=labels)):
+        recs = inference.batched_inference(p, None, batch_size=4, return_instance_segmentation=False, **kw)
+        ref = R.batched_inference(ctx["sd"], feats, p.input_size, p.original_size, 4, return_instance_segmentation=False,
+                                  precision="bf16", **kw)
+        assert len(recs) == len(ref) == n
+        dis = []
+        for a, b in zip(recs, ref):
+            ma, mb = a["segmentation"].cpu(), b["segmentation"]
+            assert ma.dtype == torch.bool and tuple(ma.shape) == (1024, 1024)
+            dis.append((ma != mb).float().mean().item())
+            assert abs(a["predicted_iou"] - b["predicted_iou"]) <= 5e-3
+            assert int(a["area"]) == int(ma.sum()) and a["seg_id"] == b["seg_id"]
+            # box of OUR mask (integer stage, exact): xywh of the occupied rows / columns
+            ys, xs = np.nonzero(ma.numpy())
+            if len(ys):
+                assert a["bbox"] == [int(xs.min()), int(ys.min()), int(xs.max() - xs.min()), int(ys.max() - ys.min())]
+        assert np.mean(dis) <= 0.01, dis
+        # the device merge equals the host merge of the reference over our own records (integer stage, exact)
+        seg = inference.batched_inference(p, None, batch_size=4, return_instance_segmentation=True, **kw)
+        host = util.mask_data_to_segmentation(recs, min_object_size=0)
+        assert seg.dtype == np.uint32 and np.array_equal(seg, host)
+    # stability score of a record = |{x > t+1}| / |{x > t-1}| of ITS upsampled logits
+    recs = inference.batched_inference(p, None, batch_size=8, boxes=boxes, return_instance_segmentation=False,
+                                       return_highres_logits=True)
+    for r in recs[:3]:
+        lg = r["logits"][0]
+        assert tuple(lg.shape) == (1024, 1024)
+        s = ((lg > 1.0).sum().float() / (lg > -1.0).sum().float()).item()
+        assert abs(s - r["stability_score"]) <= 1e-6
+        assert torch.equal(lg > 0.0, r["segmentation"])
+    with pytest.raises(NotImplementedError):
+        inference.batched_inference(p, None, 4, boxes=boxes, logits_masks=torch.zeros(n, 1, 256, 256))
+
+
+def _oracle_state_from(state):
+    from oracle import amg_ref as A
+    for d in state["crop_list"]:
+        d["rles"]                                  # the reference's column: materialised lazily from the device bit masks
+    crops = [A.MaskData(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in d.items() if k != "bits"})
+             for d in state["crop_list"]]
+    return {"crop_list": crops, "crop_boxes": state["crop_boxes"], "original_size": state["original_size"]}
+
+
+def test_tiled_amg_vs_oracle(ctx):
+    """Tiled embeddings + TiledAutomaticMaskGenerator (reference util.py:765-803, instance_segmentation.py:564-680) on a
+    600x720 image, tile 384 / halo 64: four outer tiles of four different shapes (non-square -> two-stage resize)."""
+    from micro_sam_amd import util
+    from micro_sam_amd.instance_segmentation import TiledAutomaticMaskGenerator, get_instance_segmentation_generator
+    from micro_sam_amd.synthetic import synthetic_tile
+    from micro_sam_amd.tiling import Blocking
+    from oracle import amg_ref as A
+    from oracle import pipeline_ref as PR
+    p, sd = ctx["predictor"], ctx["sd"]
+    image = synthetic_tile(5)[:600, :720]
+    tile_shape, halo = (384, 384), (64, 64)
+    emb = util.precompute_image_embeddings(p, image, tile_shape=tile_shape, halo=halo, batch_size=3, verbose=False)
+    feats = emb["features"]
+    assert emb["input_size"] is None and emb["original_size"] is None                     # reference util.py:946
+    assert len(feats) == 4 and tuple(feats.attrs["shape"]) == (600, 720) and tuple(feats.attrs["halo"]) == halo
+    tiling = Blocking([0, 0], image.shape, tile_shape)
+    for tid in range(4):
+        ob = tiling.get_block_with_halo(tid, list(halo)).outer_block
+        assert feats[str(tid)].shape == (1, 256, 64, 64) and feats[str(tid)].attrs["original_size"] == tuple(ob.shape)
+    # a tile embedding equals the embedding of the tile image computed on its own
+    ob = tiling.get_block_with_halo(3, list(halo)).outer_block
+    single = util.precompute_image_embeddings(p, image[ob.begin[0]:ob.end[0], ob.begin[1]:ob.end[1]], verbose=False)
+    assert np.abs(feats["3"][:].cpu().numpy() - single["features"]).max() <= 1e-4
+    util.set_precomputed(p, emb, tile_id=1)
+    assert p.original_size == feats["1"].attrs["original_size"] and p.features.shape == (1, 256, 64, 64)
+
+    amg = get_instance_segmentation_generator(p, is_tiled=True, points_per_side=4)
+    assert isinstance(amg, TiledAutomaticMaskGenerator)
+    with pytest.raises(ValueError):
+        amg.initialize(image, emb, tile_shape=(256, 256))                              # inconsistent with the embeddings
+    amg.initialize(image, emb)
+    assert len(amg.crop_list) == 4 and amg.crop_boxes[3] == [320, 320, 720, 600]
+    grid = A.build_all_layer_point_grids(4, 0, 1)[0]
+    for tid in range(4):
+        t = feats[str(tid)]
+        ref = PR.amg_process_crop(sd, t[:].float().cpu(), t.attrs["input_size"], amg.crop_boxes[tid], (600, 720), grid,
+                                  precision="bf16")
+        d = amg.crop_list[tid]
+        assert len(d["rles"]) == len(ref["rles"]) == 48
+        assert (d["iou_preds"].cpu() - ref["iou_preds"]).abs().max().item() <= 3e-3
+        assert torch.equal(d["points"], ref["points"])
+        dis = [float((A.rle_to_mask(a) != A.rle_to_mask(b)).mean()) for a, b in zip(d["rles"], ref["rles"])]
+        assert d["rles"][0]["size"] == [600, 720] and np.mean(dis) <= 0.01, np.mean(dis)
+    # integer stages incl. the cross-tile NMS: the oracle's generate on OUR state gives the identical label image
+    for kw in (dict(), dict(pred_iou_thresh=0.5, stability_score_thresh=0.5, box_nms_thresh=0.9)):
+        seg = amg.generate(**kw)
+        assert seg.shape == (600, 720) and seg.dtype == np.uint32
+        assert np.array_equal(seg, PR.amg_generate(_oracle_state_from(amg.get_state()), **kw))
+    assert amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5).max() > 0
+
+
+def test_amg_crop_layers(ctx):
+    """crop_n_layers = 1 (reference instance_segmentation.py:403-461): 1 + 4 crops, embeddings computed per crop."""
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_tile
+    from oracle import pipeline_ref as PR
+    p = ctx["predictor"]
+    image = synthetic_tile(6, (512, 512))
+    amg = AutomaticMaskGenerator(p, points_per_side=4, crop_n_layers=1)
+    amg.initialize(image)
+    assert len(amg.crop_list) == 5 and amg.crop_boxes[0] == [0, 0, 512, 512]
+    assert [len(d["iou_preds"]) for d in amg.crop_list] == [48] * 5
+    for kw in (dict(), dict(pred_iou_thresh=0.4, stability_score_thresh=0.4, box_nms_thresh=0.9, crop_nms_thresh=0.5)):
+        seg = amg.generate(**kw)
+        assert np.array_equal(seg, PR.amg_generate(_oracle_state_from(amg.get_state()), **kw))

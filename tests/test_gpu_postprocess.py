@@ -71,3 +71,25 @@ def test_rle_round_trip_at_full_size():
         assert int(r["counts"].sum()) == 1024 * 1024
         assert (amg_utils.rle_to_mask(r) == masks[i]).all()
         assert amg_utils.area_from_rle(r) == int(res["counts"][i, 2])
+
+
+@pytest.mark.parametrize("crop_box,size", [([0, 0, 64, 40], (40, 64)), ([37, 5, 137, 70], (131, 200)),
+                                           ([320, 320, 720, 600], (600, 720)), ([3, 33, 35, 65], (97, 40))])
+def test_uncrop_bits_matches_pad(crop_box, size):
+    """msam_uncrop_bits == segment_anything uncrop_masks (zero padding) on the unpacked masks, for row offsets that are
+    not multiples of the 32-row word."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import ops
+    from micro_sam_amd._vendored import pack_bits
+    x0, y0, x1, y1 = crop_box
+    h, w = size
+    g = torch.Generator().manual_seed(x0 * 7 + y0)
+    masks = torch.rand(5, y1 - y0, x1 - x0, generator=g) > 0.5
+    bits = pack_bits(masks.cuda())
+    out = ops.uncrop_bits(bits, crop_box, h, w)
+    assert tuple(out.shape) == (5, (h + 31) // 32, w)
+    ref = torch.zeros(5, h, w, dtype=torch.bool)
+    ref[:, y0:y1, x0:x1] = masks
+    assert torch.equal(ops.unpack_bits(out, h).cpu(), ref)
+    assert torch.equal(out.cpu(), pack_bits(ref.cuda()).cpu())
