@@ -298,3 +298,69 @@ def test_amg_crop_layers(ctx):
     for kw in (dict(), dict(pred_iou_thresh=0.4, stability_score_thresh=0.4, box_nms_thresh=0.9, crop_nms_thresh=0.5)):
         seg = amg.generate(**kw)
         assert np.array_equal(seg, PR.amg_generate(_oracle_state_from(amg.get_state()), **kw))
+
+
+def test_cache_amg_state_and_segment_slices(ctx, tmp_path):
+    """precompute_state.cache_amg_state (reference precompute_state.py:27-87) round trip through the reference's pickle
+    format, and multi_dimensional_segmentation.segment_slices (reference :385-416) == per-slice AMG + running offsets."""
+    import pickle
+    from micro_sam_amd import multi_dimensional_segmentation as mds
+    from micro_sam_amd import precompute_state, util
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_tile
+    p = ctx["predictor"]
+    vol = np.stack([synthetic_tile(s, (512, 512)) for s in (11, 12, 13)])
+    emb = util.precompute_image_embeddings(p, vol, ndim=3, batch_size=3, verbose=False)
+    kw = dict(points_per_side=6)
+    gen_kw = dict(pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    amg = precompute_state.cache_amg_state(p, vol, emb, str(tmp_path), verbose=False, i=1, **kw)
+    seg = amg.generate(**gen_kw)
+    with open(tmp_path / "amg_state" / "state-1.pkl", "rb") as f:
+        state = pickle.load(f)
+    assert set(state) == {"crop_list", "crop_boxes", "original_size"}
+    d = state["crop_list"][0]
+    assert "rles" in d._stats and "bits" not in d._stats and all(not (torch.is_tensor(v) and v.is_cuda) for v in d._stats.values())
+    assert d["rles"][0]["size"] == [512, 512] and sum(d["rles"][0]["counts"]) == 512 * 512
+    amg2 = precompute_state.cache_amg_state(p, vol, emb, str(tmp_path), verbose=False, i=1, **kw)      # loads the pickle
+    assert np.array_equal(amg2.generate(**gen_kw), seg)
+    # serial slice loop
+    out, _ = mds.segment_slices(vol, p, AutomaticMaskGenerator(p, **kw), batch_size=2, **gen_kw)
+    assert out.shape == vol.shape and out.dtype == np.uint32
+    offset = 0
+    for z in range(3):
+        a = AutomaticMaskGenerator(p, **kw)
+        a.initialize(vol[z], emb, i=z)
+        s = a.generate(**gen_kw)
+        expect = np.where(s != 0, s + offset, 0)
+        offset += int(s.max())
+        assert np.array_equal(out[z], expect)
+    assert np.array_equal(mds.segment_slices_sharded(vol, p, AutomaticMaskGenerator(p, **kw), batch_size=2, **gen_kw), out)
+
+
+def test_vit_l_encoder_and_decode_vs_oracle():
+    """vit_l (BASELINE config 3 model: D = 1024, 16 heads, 24 blocks, global blocks 5/11/17/23) through the same kernels:
+    embedding vs the bf16-mode oracle, then one decode on it."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    from oracle import amg_ref as A
+    from oracle import sam_ref as S
+    sd = synthetic_state_dict("vit_l", 1)
+    tile = synthetic_tile(21)
+    x = S.preprocess(torch.as_tensor(A.to_image(tile)).permute(2, 0, 1)[None])
+    with torch.no_grad():
+        ref = S.image_encoder(sd, x, model_type="vit_l", precision="bf16")
+    p = util.get_sam_model("vit_l", device="cuda", state_dict=sd)
+    assert p.model_type == "vit_l"
+    emb = util.precompute_image_embeddings(p, tile, verbose=False, keep_on_device=True)
+    d = (emb["features"].float().cpu() - ref).abs()
+    assert d.max().item() <= 0.08 and d.mean().item() <= 0.01, (d.max().item(), d.mean().item())
+    util.set_precomputed(p, emb)
+    pts = torch.tensor([[[300.0, 400.0]], [[700.0, 650.0]]], device="cuda")
+    lab = torch.ones((2, 1), dtype=torch.int32, device="cuda")
+    masks, iou, low = p.predict_torch(pts, lab, multimask_output=True, return_logits=True)
+    _, iou_r, low_r = S.predict_torch(sd, ref, (1024, 1024), (1024, 1024), pts.cpu(), lab.cpu(), multimask_output=True,
+                                      return_logits=True, precision="bf16")
+    assert tuple(masks.shape) == (2, 3, 1024, 1024) and (iou.cpu() - iou_r).abs().max().item() <= 1e-2
+    assert ((low.cpu() > 0) != (low_r > 0)).float().mean().item() <= 0.02
