@@ -1,0 +1,119 @@
+"""Turn the rocprofv3 outputs of a measurement run (gpurun_out/final_*) into the committed summaries under profiles/.
+
+Usage: python tools/summarize_profiles.py [round_tag]          (default r01)
+Inputs (written on the GPU box by the commands quoted in profiles/<tag>_bench_kernel_summary.md):
+  gpurun_out/final_bench.log                    python bench.py                          (bench line incl. cpu_baseline)
+  gpurun_out/final_prof/*/*_kernel_stats.csv   rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline
+  gpurun_out/final_fetch, final_write           rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes)
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+OUT = os.path.join(ROOT, "profiles")
+GO = os.path.join(ROOT, "gpurun_out")
+
+# algorithmic HBM bytes per launch at P = 1024 prompts: stream = 1024 * 4096 * 256 * 2 B = 2 GiB
+GiB = 1 << 30
+ALGO = {
+    "fold_i2t_kernel": ("layer-1 launches (the larger half): 2 GiB read + 2 GiB written in place; layer 0 writes 2 GiB only", 4 * GiB),
+    "fold_attn_kernel": ("2 GiB read + 64 MiB fp32 partials written", 2 * GiB + 64 * (1 << 20)),
+    "up_fused_kernel": ("2 GiB read + 0.75 GiB fp32 low-res logits written", 2 * GiB + 3 * 1024 * 65536 * 4),
+    "postprocess_kernel": ("0.75 GiB fp32 low-res read + 384 MiB bit masks written", 3 * 1024 * 65536 * 4 + 3072 * 128 * 1024),
+    "gemm_kernel": ("A and W read once, C written once (mixed shapes)", None),
+    "global_attention_kernel": ("q, k, v read once, out written (8 tiles x 12 heads)", None),
+}
+
+
+def one(pattern):
+    files = glob.glob(pattern)
+    if not files:
+        raise SystemExit(f"missing {pattern}")
+    return files[0]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    line = open(os.path.join(GO, "final_bench.log")).read().strip().splitlines()[-1]
+    bench = json.loads(line)
+    with open(os.path.join(OUT, f"{TAG}_bench_line.json"), "w") as f:
+        json.dump(bench, f, indent=1)
+    stats = one(os.path.join(GO, "final_prof", "*", "*_kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(OUT, f"{TAG}_bench_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(stats)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    prof_line = [l for l in open(os.path.join(GO, "final_prof.log")) if l.startswith("{")][-1]
+    pb = json.loads(prof_line)
+    tiles = pb["config"]["tiles_per_step_per_gpu"] * (pb["steps"] + pb["warmup"] + 1)      # + the instrumented pass
+    with open(os.path.join(OUT, f"{TAG}_bench_kernel_summary.md"), "w") as f:
+        f.write(f"# {TAG}: rocprofv3 kernel summary of `python bench.py --no-cpu-baseline` on one MI355X\n\n")
+        f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_prof -- python bench.py "
+                "--no-cpu-baseline`\n")
+        f.write(f"(bench line of this profiled run: {pb['value']} tiles/s; unprofiled run with cpu_baseline: {bench['value']} "
+                f"tiles/s, `{TAG}_bench_line.json`).\n\n")
+        f.write(f"GPU time {total / 1e6:.1f} ms over {tiles} tiles ({pb['warmup']} warm-up + {pb['steps']} timed + 1 instrumented "
+                f"step of {pb['config']['tiles_per_step_per_gpu']}) = **{total / 1e6 / tiles:.2f} ms per tile**.\n\n")
+        f.write("| kernel | calls | total ms | ms / tile | avg us | % |\n|---|---|---|---|---|---|\n")
+        for r in rows[:24]:
+            t = float(r["TotalDurationNs"])
+            f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {t / 1e6:.2f} | {t / 1e6 / tiles:.3f} | {float(r['AverageNs']) / 1e3:.1f} | "
+                    f"{float(r['Percentage']):.1f} |\n")
+        rf = bench["roofline"]
+        f.write("\nLive HIP-event measurement of the same kernels inside bench.py (timed region, unprofiled run):\n\n")
+        f.write("| kernel family | bound | achieved | peak | frac | avg launch us |\n|---|---|---|---|---|---|\n")
+        for k in [rf] + rf.get("other_kernels", []):
+            f.write(f"| {k['kernel'][:70]} | {k['bound']} | {k['achieved']} {k['unit']} | {k['peak']} | {k['frac']} | {k['avg_launch_us']} |\n")
+    # ---- PMC traffic
+    acc = {}
+    for name, key in (("final_fetch", "FETCH_SIZE"), ("final_write", "WRITE_SIZE")):
+        path = one(os.path.join(GO, name, "*", "*_counter_collection.csv"))
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != key:
+                continue
+            kn = r["Kernel_Name"]
+            short = next((s for s in ALGO if s in kn), None)
+            if short is None:
+                continue
+            acc.setdefault(short, {}).setdefault(key, []).append(float(r["Counter_Value"]))
+    table = {}
+    for short, d in acc.items():
+        fetch, write = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
+        # the large launches only (P = 1024 decoder passes / 8-tile encoder batches): top half by bytes
+        def top(v):
+            v = sorted(v, reverse=True)
+            return v[: max(1, len(v) // 2)] if short != "gemm_kernel" else v
+        ft, wt = top(fetch), top(write)
+        fk, wk = sum(ft) / max(len(ft), 1), sum(wt) / max(len(wt), 1)
+        # MI355X_MICROARCH.md (HBM section): counters are KiB; FETCH_SIZE reports half of the bytes of wide streaming reads
+        hbm = 2 * fk * 1024 + wk * 1024
+        table[short] = {"launches": len(fetch), "fetch_kib": fk, "write_kib": wk, "hbm_bytes_per_launch": hbm,
+                        "algorithmic_bytes_per_launch": ALGO[short][1], "algorithmic": ALGO[short][0]}
+    with open(os.path.join(OUT, f"{TAG}_pmc_traffic.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    with open(os.path.join(OUT, f"{TAG}_pmc_traffic.md"), "w") as f:
+        f.write(f"# {TAG}: HBM traffic from PMC counters (separate rocprofv3 passes of `python bench.py --steps 1 --warmup 1 "
+                "--no-cpu-baseline`)\n\n")
+        f.write("Commands: `rocprofv3 --kernel-trace --pmc FETCH_SIZE ...` and `rocprofv3 --kernel-trace --pmc WRITE_SIZE ...` "
+                "(one counter per pass, no other trace domain).\n\n")
+        f.write("Units: counter values are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of "
+                "the bytes of wide coalesced streaming reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is taken as is "
+                "(x 1024).  Averages over the larger half of each kernel's launches (the P = 1024 decoder passes).\n\n")
+        f.write("`postprocess_kernel` reads 4-byte elements through a small LDS patch (not 16-byte streaming loads); the x2 read "
+                "correction is uncalibrated for that access pattern, so its ratio is an upper bound.\n\n")
+        f.write("| kernel | launches | FETCH_SIZE avg (KiB) | WRITE_SIZE avg (KiB) | HBM bytes / launch (corrected) | algorithmic bytes "
+                "/ launch | ratio | algorithmic traffic |\n|---|---|---|---|---|---|---|---|\n")
+        for short, r in sorted(table.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+            alg = r["algorithmic_bytes_per_launch"]
+            ratio = "-" if alg is None else f"{r['hbm_bytes_per_launch'] / alg:.2f}"
+            f.write(f"| `{short}` | {r['launches']} | {r['fetch_kib']:.0f} | {r['write_kib']:.0f} | {r['hbm_bytes_per_launch'] / 1e9:.3f} GB | "
+                    f"{'-' if alg is None else f'{alg / 1e9:.3f} GB'} | {ratio} | {r['algorithmic']} |\n")
+    print("wrote", sorted(os.listdir(OUT)))
+
+
+if __name__ == "__main__":
+    main()
