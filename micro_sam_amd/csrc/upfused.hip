@@ -8,8 +8,8 @@
 //   stage 1   U^T [(sub, c1)][token] = W1 . keys^T     A = W1 rows (stationary, 128 VGPRs), B = keys tile (LDS, b128)
 //             + bias, LayerNorm2d over the 64 c1 of a (token, sub) = registers + 2 cross-lane steps, GELU, pack to bf16
 //   stage 2   Y^T [(sub2, c2)][pixel] = W2 . G1        A = W2 (LDS, k-permuted image), B = G1 (registers)
-//             + bias, GELU, split into bf16 hi + lo
-//   stage 3   out^T [mask][pixel] = H . G2             A = hyper weights of the prompt (hi + lo), B = G2 (registers)
+//             + bias, GELU, pack to fp16
+//   stage 3   out^T [mask][pixel] = H . G2             A = hyper weights of the prompt (fp16 hi + lo), B = G2 as fp16 (registers)
 // 4-wave workgroups on 16-token tiles, wave = sub-pixel of stage 1, two workgroups per CU: the stages of a wave are a long
 // serial chain (MFMA -> LayerNorm -> GELU -> MFMA -> GELU -> MFMA), so independent workgroups in different phases keep
 // both the MFMA and the VALU pipes busy (one 8-wave workgroup ran all waves in lock step: 2.05 ms vs this form).  One
@@ -118,11 +118,13 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
                 h8[0] = x0.x; h8[1] = x0.y; h8[2] = x0.z; h8[3] = x0.w; h8[4] = x1.x; h8[5] = x1.y; h8[6] = x1.z; h8[7] = x1.w;
             }
             wait_vmem_all();
+            // fp16 hi + lo (22 significant bits): stage 3 runs on the fp16 MFMA
+            hh = make_uint4(pack2h(h8[0], h8[1]), pack2h(h8[2], h8[3]), pack2h(h8[4], h8[5]), pack2h(h8[6], h8[7]));
+            const uint32_t hw_[4] = {hh.x, hh.y, hh.z, hh.w};
             float l8[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) l8[i] = h8[i] - bf2f(f2bf(h8[i]));
-            hh = make_uint4(pack2bf(h8[0], h8[1]), pack2bf(h8[2], h8[3]), pack2bf(h8[4], h8[5]), pack2bf(h8[6], h8[7]));
-            hl = make_uint4(pack2bf(l8[0], l8[1]), pack2bf(l8[2], l8[3]), pack2bf(l8[4], l8[5]), pack2bf(l8[6], l8[7]));
+            for (int i = 0; i < 4; ++i) { l8[2 * i] = h8[2 * i] - h2f(hw_[i] & 0xffff); l8[2 * i + 1] = h8[2 * i + 1] - h2f(hw_[i] >> 16); }
+            hl = make_uint4(pack2h(l8[0], l8[1]), pack2h(l8[2], l8[3]), pack2h(l8[4], l8[5]), pack2h(l8[6], l8[7]));
         }
         const unsigned char* B = lds + buf * XT_BYTES;
         // ---- stage 1: U^T rows (sub, c1 = 16 rt + 4 fg + r), column token fr
@@ -154,8 +156,9 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
-            u[rt][0] = gelu_erf(u[rt][0] * rstd * g4.x + b4.x); u[rt][1] = gelu_erf(u[rt][1] * rstd * g4.y + b4.y);
-            u[rt][2] = gelu_erf(u[rt][2] * rstd * g4.z + b4.z); u[rt][3] = gelu_erf(u[rt][3] * rstd * g4.w + b4.w);
+            const f32x2_t g01 = gelu_erf2(f32x2_t{u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y});
+            const f32x2_t g23 = gelu_erf2(f32x2_t{u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w});
+            u[rt][0] = g01.x; u[rt][1] = g01.y; u[rt][2] = g23.x; u[rt][3] = g23.y;
         }
         uint4 g1[2];
 #pragma unroll
@@ -175,22 +178,14 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
                 ya = mfma16(wa, g1[kk], ya);
                 yb = mfma16(wb, g1[kk], yb);
             }
-            float ga[4], gb[4];
-            ga[0] = gelu_erf(ya[0] + ba.x); ga[1] = gelu_erf(ya[1] + ba.y); ga[2] = gelu_erf(ya[2] + ba.z); ga[3] = gelu_erf(ya[3] + ba.w);
-            gb[0] = gelu_erf(yb[0] + bb.x); gb[1] = gelu_erf(yb[1] + bb.y); gb[2] = gelu_erf(yb[2] + bb.z); gb[3] = gelu_erf(yb[3] + bb.w);
-            const uint4 gh = make_uint4(pack2bf(ga[0], ga[1]), pack2bf(ga[2], ga[3]), pack2bf(gb[0], gb[1]), pack2bf(gb[2], gb[3]));
-            const uint32_t hw[4] = {gh.x, gh.y, gh.z, gh.w};
-            float la[4], lb[4];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                la[2 * x] = ga[2 * x] - bf2f((u16)(hw[x] & 0xffff)); la[2 * x + 1] = ga[2 * x + 1] - bf2f((u16)(hw[x] >> 16));
-                lb[2 * x] = gb[2 * x] - bf2f((u16)(hw[2 + x] & 0xffff)); lb[2 * x + 1] = gb[2 * x + 1] - bf2f((u16)(hw[2 + x] >> 16));
-            }
-            const uint4 gl = make_uint4(pack2bf(la[0], la[1]), pack2bf(la[2], la[3]), pack2bf(lb[0], lb[1]), pack2bf(lb[2], lb[3]));
+            // + bias, GELU (two values per packed instruction), fp16 for the hyper product (11-bit significand: the
+            // product keeps ~fp32 accuracy together with the hi + lo hyper weights; a bf16 operand would not)
+            const f32x2_t a01 = gelu_erf2(f32x2_t{ya[0] + ba.x, ya[1] + ba.y}), a23 = gelu_erf2(f32x2_t{ya[2] + ba.z, ya[3] + ba.w});
+            const f32x2_t b01 = gelu_erf2(f32x2_t{yb[0] + bb.x, yb[1] + bb.y}), b23 = gelu_erf2(f32x2_t{yb[2] + bb.z, yb[3] + bb.w});
+            const uint4 gh = make_uint4(pack2h(a01.x, a01.y), pack2h(a23.x, a23.y), pack2h(b01.x, b01.y), pack2h(b23.x, b23.y));
             f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-            o = mfma16(hh, gh, o);
-            o = mfma16(hl, gh, o);
-            o = mfma16(hh, gl, o);
+            o = mfma16h(hh, gh, o);
+            o = mfma16h(hl, gh, o);
             if (fg == 0) {                               // rows = masks r, column = token fr
                 const int yl = (sub >> 1) * 2 + (sub2 >> 1), xl = fr * 4 + (sub & 1) * 2 + (sub2 & 1);
                 pt[(0 * 4 + yl) * 64 + xl] = o[0];
