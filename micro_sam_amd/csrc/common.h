@@ -75,12 +75,12 @@ MSAM_DEVINL float gelu_erf(float x) {
 
 // two values at once: the cubic and the final FMA as packed fp32 (v_pk_fma_f32)
 MSAM_DEVINL f32x2_t gelu_erf2(f32x2_t x) {
-    const f32x2_t t = {fabsf(x.x), fabsf(x.y)};
+    const f32x2_t r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    const f32x2_t t = r * 2.0f - x;                  // |x| = 2 max(x, 0) - x (exact): packed ops have no abs modifier
     f32x2_t q = t * -0.0248758f + -0.49884797f;
     q = q * t + -1.12922424f;
     q = q * t + -1.00353579f;
     const f32x2_t e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
-    const f32x2_t r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
     return r - t * e;
 }
 // round-to-nearest-even fp32 -> packed fp16 (v_cvt_pk_f16_f32)

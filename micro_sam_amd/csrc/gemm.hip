@@ -232,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A,
         float v[4] = {(c.x + bias4[0]) + rt[pass].x, (c.y + bias4[1]) + rt[pass].y, (c.z + bias4[2]) + rt[pass].z,
                       (c.w + bias4[3]) + rt[pass].w};
         if (e.act == MSAM_ACT_GELU) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
+            const f32x2_t g01 = gelu_erf2(f32x2_t{v[0], v[1]}), g23 = gelu_erf2(f32x2_t{v[2], v[3]});
+            v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
         } else if (e.act == MSAM_ACT_RELU) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);

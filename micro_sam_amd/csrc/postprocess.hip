@@ -60,7 +60,9 @@ __global__ void finalize_boxes_kernel(int* __restrict__ boxes, int N) {
 
 // grid (ceil(out_w/256), N); thread = column x, loops over all 32-row words of its column (so a mask contributes
 // only ceil(W/256) x 7 atomics instead of one set per 32x256 patch - the atomics were the bottleneck)
-template <bool TWO_STAGE>
+// LOGITS (store the up-sampled logits as well) is a compile-time switch: as a run-time test it put a scalar branch and
+// the address arithmetic of the store between every two of the 32 unrolled pixels of the hot loop
+template <bool TWO_STAGE, bool LOGITS>
 __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ low_res, int in_h, int in_w, int out_h,
                                                           int out_w, float thr, float off, int* __restrict__ counts,
                                                           int* __restrict__ boxes, uint32_t* __restrict__ bits,
@@ -109,18 +111,23 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
 #pragma unroll
                 for (int k = 0; k < 10; ++k) t[k] = lerp_torch(ax.w0, tl[k * 66 + l0], ax.w1, tl[k * 66 + l1]);
                 const int nb = min(32, out_h - yw * 32);
-                uint32_t word = 0;
+                // the three predicates v > thr, v > thr + off, v > thr - off are collected as sign bits of (t - v) (strictly
+                // negative <=> v > t; t - v == +0 for equality) shifted into three words: 2 instructions per predicate and
+                // pixel instead of compare + add-with-carry / select + or; pixel 0 ends up in bit 31 -> bit reverse
+                uint32_t wm = 0, wh = 0, wl = 0;
 #pragma unroll
                 for (int b = 0; b < 32; ++b) {
                     float w1 = W1[b & 3];
                     if (b < 2 && yw == 0) w1 = 0.0f;
                     const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
-                    if (b < nb) {
-                        if (logits) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
-                        c_hi += v > hi_t; c_lo += v > lo_t;
-                        word |= (uint32_t)(v > thr) << b;
-                    }
+                    if (LOGITS) { if (b < nb) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v; }
+                    wm = __builtin_amdgcn_alignbit(wm, __float_as_uint(__fsub_rn(thr, v)), 31);
+                    wh = __builtin_amdgcn_alignbit(wh, __float_as_uint(__fsub_rn(hi_t, v)), 31);
+                    wl = __builtin_amdgcn_alignbit(wl, __float_as_uint(__fsub_rn(lo_t, v)), 31);
                 }
+                const uint32_t valid = nb < 32 ? (1u << nb) - 1u : 0xffffffffu;
+                const uint32_t word = __brev(wm) & valid;
+                c_hi += __popc(__brev(wh) & valid); c_lo += __popc(__brev(wl) & valid);
                 if (word) {
                     c_m += __popc(word); any = true;
                     ymin = min(ymin, yw * 32 + __ffs(word) - 1); ymax = yw * 32 + 31 - __clz(word);
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                     const float t0 = lerp_torch(ax2.w0, stage1(low, ay2.i0, ax2.i0), ax2.w1, stage1(low, ay2.i0, ax2.i1));
                     const float t1 = lerp_torch(ax2.w0, stage1(low, ay2.i1, ax2.i0), ax2.w1, stage1(low, ay2.i1, ax2.i1));
                     const float v = lerp_torch(ay2.w0, t0, ay2.w1, t1);
-                    if (logits) logits[((long)n * out_h + y) * out_w + x] = v;
+                    if (LOGITS) logits[((long)n * out_h + y) * out_w + x] = v;
                     c_hi += v > hi_t; c_lo += v > lo_t;
                     if (v > thr) { word |= 1u << b; ++c_m; any = true; ymin = min(ymin, y); ymax = y; }
                 }
@@ -297,12 +304,14 @@ extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, s, counts, boxes, N);
     dim3 grid((out_w + 255) / 256, N);
-    if (in_h == out_h && in_w == out_w)
-        hipLaunchKernelGGL(postprocess_kernel<false>, grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, out_w, thr, off,
-                           counts, boxes, bits, logits);
-    else
-        hipLaunchKernelGGL(postprocess_kernel<true>, grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, out_w, thr, off,
-                           counts, boxes, bits, logits);
+#define PP_LAUNCH(TS_, LG_) hipLaunchKernelGGL((postprocess_kernel<TS_, LG_>), grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, \
+                                              out_w, thr, off, counts, boxes, bits, logits)
+    const bool direct = in_h == out_h && in_w == out_w;
+    if (direct && !logits) PP_LAUNCH(false, false);
+    else if (direct) PP_LAUNCH(false, true);
+    else if (!logits) PP_LAUNCH(true, false);
+    else PP_LAUNCH(true, true);
+#undef PP_LAUNCH
     hipLaunchKernelGGL(finalize_boxes_kernel, dim3((N + 255) / 256), dim3(256), 0, s, boxes, N);
     return msam_check_launch("msam_postprocess_masks");
 }
