@@ -73,6 +73,7 @@ struct FoldArgs {
     int nitems, KS;                      // work items (prompt, key split)
     float* opart;                        // fp32 [P, KS, 64, 256]
     float* stats;                        // fp32 [P, KS, 64, 2]  (m, l)
+    const u16* wv; const float* bv; u16* out;   // KS == 1: value projection fused into the item epilogue, bf16 [P, Nt, 128]
 };
 
 __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
@@ -198,15 +199,52 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
             o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
             acc[ct] = mfma16(make_uint4(t0.x, t0.y, t1.x, t1.y), pb, o);
         }
-        if (tt == TPI - 1) {                             // work item complete: (m, l, O') partial of this key split
+        if (tt == TPI - 1) {                             // work item complete
             float lt = l;
             lt += __shfl_xor(lt, 16); lt += __shfl_xor(lt, 32);
-            const long col = (long)item * 64 + w * 16 + fr;
-            if (fg == 0) { a.stats[col * 2] = m; a.stats[col * 2 + 1] = lt; }
-            float* op = a.opart + col * C + fg * 4;
+            if (a.KS == 1) {
+                // whole prompt in this workgroup: out_{h,t} = (O'_{h,t} / l) Wv_h^T + bv_h right here (no fp32 partials, no
+                // finish kernel).  O'^T (rows = channels, columns = (h,t)) is already the MFMA B operand (k-slot map as
+                // above: slots i < 4 <-> channel tile 2 ks, i >= 4 <-> tile 2 ks + 1); it enters as bf16 hi + lo, the A
+                // operand = 16 rows of Wv of one of the wave's two heads, read with the same channel permutation.
+                const float inv = 1.f / lt;
+                const int p = item;
+                f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+                const u16* w0 = a.wv + (long)((2 * w) * 16 + fr) * C + fg * 4;
+                const u16* w1 = w0 + 16 * C;
 #pragma unroll
-            for (int ct = 0; ct < 16; ++ct)
-                *(float4*)(op + ct * 16) = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+                for (int ks = 0; ks < 8; ++ks) {
+                    float c8[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { c8[r] = acc[2 * ks][r] * inv; c8[4 + r] = acc[2 * ks + 1][r] * inv; }
+                    const uint4 bh = make_uint4(pack2bf(c8[0], c8[1]), pack2bf(c8[2], c8[3]), pack2bf(c8[4], c8[5]), pack2bf(c8[6], c8[7]));
+                    const uint32_t hw[4] = {bh.x, bh.y, bh.z, bh.w};
+                    float l8[8];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) { l8[2 * x] = c8[2 * x] - bf2f((u16)(hw[x] & 0xffff)); l8[2 * x + 1] = c8[2 * x + 1] - bf2f((u16)(hw[x] >> 16)); }
+                    const uint4 bl = make_uint4(pack2bf(l8[0], l8[1]), pack2bf(l8[2], l8[3]), pack2bf(l8[4], l8[5]), pack2bf(l8[6], l8[7]));
+                    const uint2 x0 = *(const uint2*)(w0 + (2 * ks) * 16), x1 = *(const uint2*)(w0 + (2 * ks + 1) * 16);
+                    const uint2 y0 = *(const uint2*)(w1 + (2 * ks) * 16), y1 = *(const uint2*)(w1 + (2 * ks + 1) * 16);
+                    const uint4 a0 = make_uint4(x0.x, x0.y, x1.x, x1.y), a1 = make_uint4(y0.x, y0.y, y1.x, y1.y);
+                    o0 = mfma16(a0, bh, o0); o0 = mfma16(a0, bl, o0);
+                    o1 = mfma16(a1, bh, o1); o1 = mfma16(a1, bl, o1);
+                }
+                const int hh = fr >> 3, t = fr & 7;
+                if (t < a.Nt) {                          // rows d = 4 fg + r of head 2w + hh, column = this lane's (head, token)
+                    const f32x4_t o = hh ? o1 : o0;
+                    const float4 b4 = *(const float4*)(a.bv + (2 * w + hh) * 16 + fg * 4);
+                    uint2 pk; pk.x = pack2bf(o[0] + b4.x, o[1] + b4.y); pk.y = pack2bf(o[2] + b4.z, o[3] + b4.w);
+                    *(uint2*)(a.out + ((long)p * a.Nt + t) * CI + (2 * w + hh) * 16 + fg * 4) = pk;
+                }
+                wait_vmem_all();                         // pins the waits of this (rare) branch, see common.h
+            } else {                                     // (m, l, O') partial of this key split
+                const long col = (long)item * 64 + w * 16 + fr;
+                if (fg == 0) { a.stats[col * 2] = m; a.stats[col * 2 + 1] = lt; }
+                float* op = a.opart + col * C + fg * 4;
+#pragma unroll
+                for (int ct = 0; ct < 16; ++ct)
+                    *(float4*)(op + ct * 16) = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
+            }
         }
         if (q + 1 < nq) FA_STORE(p0, p1, p2, p3, p4, p5, buf ^ 1);
         __syncthreads();
@@ -564,16 +602,18 @@ extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, cons
     FoldArgs a{};
     a.keys = (const u16*)keys; a.kv_shared = kv_shared; a.qprime = qprime; a.qtok = (const u16*)qtok; a.Nt = Nt;
     a.tabk = (const u16*)tabk; a.nitems = P * KS; a.KS = KS; a.opart = opart; a.stats = stats;
+    a.wv = (const u16*)wv; a.bv = bv; a.out = (u16*)out;
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
-    const double bytes = (double)(kv_shared ? 1 : P) * T * C * 2 + (double)P * KS * 64 * C * 4;
+    const double bytes = (double)(kv_shared ? 1 : P) * T * C * 2 + (KS > 1 ? (double)P * KS * 64 * C * 4 : 0.0);
     msam_profile_mark2(stream, 1, flops, bytes, 3);
     hipLaunchKernelGGL(fold_attn_kernel, dim3(grid), dim3(NTHR), 0, s, a);
     msam_profile_mark2(stream, 0, flops, bytes, 3);
     if (int e = msam_check_launch("fold_attn")) return e;
+    if (KS == 1) return 0;                               // the value projection ran in the attention kernel's epilogue
     hipLaunchKernelGGL(fold_finish_kernel, dim3(P * 8), dim3(128), 0, s, opart, stats, KS, Nt, (const u16*)wv, bv, (u16*)out);
     return msam_check_launch("fold_finish");
 }
