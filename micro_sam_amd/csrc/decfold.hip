@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - m0); s1[r] = __expf(s1[r] - m1); l0 += s0[r]; l1 += s1[r]; }
             l0 += __shfl_xor(l0, 16); l1 += __shfl_xor(l1, 16);
-            const float i0 = 1.f / l0, i1 = 1.f / l1;
+            const float i0 = __builtin_amdgcn_rcpf(l0), i1 = __builtin_amdgcn_rcpf(l1);     // 1 ulp; P is rounded to bf16 next
             uint2 q0, q1;
             q0.x = pack2bf(s0[0] * i0, s0[1] * i0); q0.y = pack2bf(s0[2] * i0, s0[3] * i0);
             q1.x = pack2bf(s1[0] * i1, s1[1] * i1); q1.y = pack2bf(s1[2] * i1, s1[3] * i1);
@@ -510,13 +510,14 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
             const float sq = red[0][tok][1] + red[1][tok][1] + red[2][tok][1] + red[3][tok][1];
             const float mean = su * (1.f / C);
             const float rstd = rsqrtf(fmaxf(sq * (1.f / C) - mean * mean, 0.f) + a.eps);
+            const float nmr = -mean * rstd;              // (x - mean) rstd = fma(x, rstd, -mean rstd): two FMAs per value
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int cbase = (w * 4 + i) * 16 + fg * 4;
                 const float4 g4 = *(const float4*)&prm[1][cbase], b4 = *(const float4*)&prm[2][cbase];
                 uint2 y;
-                y.x = pack2bf((o[i][n][0] - mean) * rstd * g4.x + b4.x, (o[i][n][1] - mean) * rstd * g4.y + b4.y);
-                y.y = pack2bf((o[i][n][2] - mean) * rstd * g4.z + b4.z, (o[i][n][3] - mean) * rstd * g4.w + b4.w);
+                y.x = pack2bf(fmaf(fmaf(o[i][n][0], rstd, nmr), g4.x, b4.x), fmaf(fmaf(o[i][n][1], rstd, nmr), g4.y, b4.y));
+                y.y = pack2bf(fmaf(fmaf(o[i][n][2], rstd, nmr), g4.z, b4.z), fmaf(fmaf(o[i][n][3], rstd, nmr), g4.w, b4.w));
                 *(uint2*)(B + xoff[i & 1] + (i >> 1) * SUB_BYTES + n * 16 * 64) = y;     // in place
             }
         }

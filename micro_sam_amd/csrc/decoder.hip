@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void prompt_tokens_kernel(
     const float* __restrict__ G, const float* __restrict__ point_embed, const float* __restrict__ not_a_point,
     const float* __restrict__ out_tokens, const float* __restrict__ points, const int* __restrict__ labels, int Np,
-    const float* __restrict__ boxes, int P, int Nt, float* __restrict__ tokens) {
+    const float* __restrict__ boxes, int P, int Nt, float* __restrict__ tokens, float* __restrict__ queries,
+    u16* __restrict__ queries_bf16) {
     const int p = blockIdx.x, c = threadIdx.x;           // 256 threads = 256 channels
     if (p >= P) return;
     float* tp = tokens + (long)p * Nt * C;
@@ -75,6 +76,12 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(
             tp[row * C + c] = (c < 128 ? s : co) + point_embed[(2 + k) * C + c];
         }
     }
+    // the transformer starts from queries = tokens (fp32 copy + the bf16 operand of the first projections)
+    for (int i = 0; i < Nt; ++i) {
+        const float v = tp[i * C + c];                   // written by this thread above
+        queries[((long)p * Nt + i) * C + c] = v;
+        queries_bf16[((long)p * Nt + i) * C + c] = f2bf(v);
+    }
 }
 
 // src[t][c] = emb[c][t] + no_mask[c]  (NCHW -> token-major); bf16 copy
@@ -100,6 +107,19 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
         if (b) { float4 y = *(const float4*)(b + i * 4); x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
         uint2 pk; pk.x = pack2bf(x.x, x.y); pk.y = pack2bf(x.z, x.w);
         *(uint2*)(out + i * 4) = pk;
+    }
+}
+
+// out_a = bf16(a + b), out_b = bf16(a): the (with PE, without PE) operand pair of an attention, one launch
+__global__ __launch_bounds__(256) void add_cast2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        u16* __restrict__ out_a, u16* __restrict__ out_b, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 x = *(const float4*)(a + i * 4), y = *(const float4*)(b + i * 4);
+        uint2 pa, pb;
+        pa.x = pack2bf(x.x + y.x, x.y + y.y); pa.y = pack2bf(x.z + y.z, x.w + y.w);
+        pb.x = pack2bf(x.x, x.y); pb.y = pack2bf(x.z, x.w);
+        *(uint2*)(out_a + i * 4) = pa;
+        *(uint2*)(out_b + i * 4) = pb;
     }
 }
 
@@ -588,12 +608,13 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
 #define CHECK(x) do { if ((e = (x))) return e; } while (0)
 #define ADD_CAST(a_, b_, out_) do { hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n4)), dim3(256), 0, cx.s, a_, b_, out_, n4); \
                                      CHECK(msam_check_launch("add_cast")); } while (0)
+#define ADD_CAST2(a_, b_, outa_, outb_) do { hipLaunchKernelGGL(add_cast2_kernel, dim3(grid_for(n4)), dim3(256), 0, cx.s, a_, b_, outa_, \
+                                                                 outb_, n4); CHECK(msam_check_launch("add_cast2")); } while (0)
 #define LN(x_, w_, b_, rows_, out_, dt_) CHECK(msam_layernorm(x_, w_, b_, 1e-5f, rows_, C, out_, dt_, 0, 0, cx.s))
 
     hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, cx.s, dec->pe_gauss, dec->point_embed, dec->not_a_point,
-                       dec->out_tokens, points, labels, Np, boxes, P, Nt, w.qpe);
+                       dec->out_tokens, points, labels, Np, boxes, P, Nt, w.qpe, w.queries, w.a);
     CHECK(msam_check_launch("prompt_tokens"));
-    hipMemcpyAsync(w.queries, w.qpe, (size_t)M * C * 4, hipMemcpyDeviceToDevice, cx.s);
 
     // test hook: MSAM_DEBUG_DEC_LAYERS=0/1 stops the two-way transformer early so that intermediate workspace buffers
     // can be compared with the oracle's per-layer taps (outputs are then NOT the model's outputs)
@@ -602,11 +623,12 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
     for (int li = 0; li < nlayers && li < 2; ++li) {
         const msam_twoway_layer_t& L = dec->layer[li];
         // (1) token self attention
-        ADD_CAST(w.queries, li == 0 ? nullptr : w.qpe, w.a);          // q = k input
-        ADD_CAST(w.queries, nullptr, w.b);                            // v input
+        // layer 0: q = k = v input = bf16(tokens), written by prompt_tokens_kernel; layer 1: q = k input carries the PE
+        const u16* sv = w.a;
+        if (li > 0) { ADD_CAST2(w.queries, w.qpe, w.a, w.b); sv = w.b; }
         CHECK(gemm(cx, w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_BF16, C));
         CHECK(gemm(cx, w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_BF16, C));
-        CHECK(gemm(cx, w.b, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_BF16, C));
+        CHECK(gemm(cx, sv, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_BF16, C));
         hipLaunchKernelGGL(token_self_attn_kernel, dim3(P), dim3(128), 0, cx.s, w.qs, w.ks, w.vs, Nt, w.attn_tok);
         CHECK(msam_check_launch("token_self_attn"));
         CHECK(gemm(cx, w.attn_tok, C, L.self_attn.o_w, M, C, C, L.self_attn.o_b, w.tmp, MSAM_F32, C, 0,
@@ -634,8 +656,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         CHECK(gemm(cx, w.mlp_h, 2048, L.mlp2_w, M, C, 2048, L.mlp2_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n3_w, L.n3_b, M, w.queries, MSAM_F32);
         // (4) image -> token attention, updates the image-token stream
-        ADD_CAST(w.queries, w.qpe, w.a);
-        ADD_CAST(w.queries, nullptr, w.b);
+        ADD_CAST2(w.queries, w.qpe, w.a, w.b);
         CHECK(gemm(cx, w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI));
         CHECK(gemm(cx, w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI));
         // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
@@ -682,6 +703,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
                              w.hyper, 128, mask0, nmask, low_res, cx.s));
 #undef CHECK
 #undef ADD_CAST
+#undef ADD_CAST2
 #undef LN
     return 0;
 }

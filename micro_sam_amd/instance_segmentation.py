@@ -229,9 +229,21 @@ class AutomaticMaskGenerator(AMGBase):
         self._stability_score_offset = stability_score_offset
 
     def _process_batch(self, points, im_size, crop_box, original_size):
-        transformed_points = self._predictor.transform.apply_coords(points, im_size)
-        in_points = torch.as_tensor(transformed_points, device=self._predictor.device, dtype=torch.float)
-        in_labels = torch.ones(in_points.shape[0], dtype=torch.int, device=in_points.device)
+        # the grid prompts of a crop size are the same for every image: keep their device copy (one H2D copy and one fill
+        # less per tile - each is a separate, serialising command on the stream)
+        key = (points.shape, tuple(im_size), float(points[0, 0]), float(points[-1, -1]))
+        cached = self._prompt_cache.get(key) if hasattr(self, "_prompt_cache") else None
+        if cached is None or cached[0].device != self._predictor.device or not np.array_equal(cached[2], points):
+            transformed_points = self._predictor.transform.apply_coords(points, im_size)
+            in_points = torch.as_tensor(transformed_points, device=self._predictor.device, dtype=torch.float)
+            in_labels = torch.ones(in_points.shape[0], dtype=torch.int, device=in_points.device)
+            if not hasattr(self, "_prompt_cache"):
+                self._prompt_cache = {}
+            if len(self._prompt_cache) > 64:
+                self._prompt_cache.clear()
+            self._prompt_cache[key] = (in_points, in_labels, np.array(points, copy=True))
+        else:
+            in_points, in_labels = cached[0], cached[1]
         iou_preds, post = self._predictor.predict_masks_device(
             in_points[:, None, :], in_labels[:, None], multimask_output=True,
             stability_score_offset=self._stability_score_offset)
