@@ -243,12 +243,25 @@ int msam_decoder_prepare_image(const msam_decoder_t* dec, const void* consts, co
                                void* image_state, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t msam_decoder_workspace_bytes(int32_t P);
 /* points: fp32 [P,Np,2] in the 1024-frame (after transform.apply_coords), labels: int32 [P,Np] (1/0/-1);
- * boxes: fp32 [P,4] or NULL.  (Mask prompts use the dense path of the Python shim.)
+ * boxes: fp32 [P,4] or NULL.  (Mask prompts: msam_decoder_forward_masks below.)
  * low_res: fp32 [P,C,256,256], iou: fp32 [P,C] with C = 3 (multimask) or 1. */
 int msam_decoder_forward(const msam_decoder_t* dec, const void* consts, const void* image_state,
                          const float* points, const int32_t* labels, int32_t Np, const float* boxes, int32_t P,
                          int32_t multimask, float* low_res, float* iou,
                          void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Same with mask prompts (reference: PromptEncoder._embed_masks + MaskDecoder with a per-prompt dense embedding;
+ * SamPredictor.predict_torch(mask_input=...), micro_sam/inference.py:248-255 `logits_masks`).  mask_input: fp32
+ * [P,1,256,256] low-res logits of a previous prediction (NULL: identical to msam_decoder_forward).  Weights of
+ * prompt_encoder.mask_downscaling: Conv2d(1,4,2,2) [4,1,2,2], LayerNorm2d(4), Conv2d(4,16,2,2) [16,4,2,2], LayerNorm2d(16),
+ * Conv2d(16,256,1) [256,16]; all fp32 device pointers. */
+typedef struct {
+    const float *c1_w, *c1_b, *ln1_w, *ln1_b, *c2_w, *c2_b, *ln2_w, *ln2_b, *c3_w, *c3_b;
+} msam_mask_prompt_t;
+int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const void* consts,
+                               const void* image_state, const float* points, const int32_t* labels, int32_t Np,
+                               const float* boxes, const float* mask_input, int32_t P, int32_t multimask, float* low_res,
+                               float* iou, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Mask post-processing:  Sam.postprocess_masks + AMGBase._to_mask_data

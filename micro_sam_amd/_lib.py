@@ -89,6 +89,11 @@ class DecoderParams(C.Structure):
     ]
 
 
+class MaskPromptParams(C.Structure):
+    """include/msam_hip.h msam_mask_prompt_t: fp32 weights of prompt_encoder.mask_downscaling."""
+    _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "ln1_w", "ln1_b", "c2_w", "c2_b", "ln2_w", "ln2_b", "c3_w", "c3_b")]
+
+
 _PROTOS = {
     "msam_last_error": (C.c_char_p, []),
     "msam_abi_version": (_i32, []),
@@ -99,6 +104,8 @@ _PROTOS = {
     "msam_t2i_fold_attention": (_i32, [_vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "msam_upscale_fused": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_uncrop_bits": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "msam_decoder_forward_masks": (_i32, [C.POINTER(DecoderParams), C.POINTER(MaskPromptParams), _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                                          _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "msam_i2t_fold_workspace_bytes": (_i64, [_i32]),
     "msam_i2t_fold_layer": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _vp]),
     "msam_profile_enable": (_i32, [_i32]),

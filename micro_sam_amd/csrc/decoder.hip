@@ -84,6 +84,83 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(
     }
 }
 
+// Mask prompts (PromptEncoder._embed_masks, segment_anything/modeling/prompt_encoder.py: mask_downscaling = Conv 2x2/2
+// (1->4), LayerNorm2d, GELU, Conv 2x2/2 (4->16), LayerNorm2d, GELU, Conv 1x1 (16->256)): the per-prompt decoder source
+// src_p = image embedding + dense prompt embedding, written as the bf16 image-token stream [P, 4096, 256].
+// grid (64 token rows, P); phase 1: 64 threads = the tokens of the row, 4x4 input pixels -> 16 channels;
+// phase 2: 256 threads = output channels.
+__global__ __launch_bounds__(256) void mask_src_kernel(const float* __restrict__ mask, msam_mask_prompt_t mp,
+                                                       const float* __restrict__ src_f32, const float* __restrict__ no_mask,
+                                                       u16* __restrict__ keys) {
+    __shared__ float h2s[64][17];
+    const int ty = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
+    if (tid < 64) {
+        const int tx = tid;
+        const float* m = mask + (long)p * 65536 + (long)(4 * ty) * 256 + 4 * tx;
+        float px[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const float4 r = *(const float4*)(m + y * 256);
+            px[y][0] = r.x; px[y][1] = r.y; px[y][2] = r.z; px[y][3] = r.w;
+        }
+        float h1[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v[4], mean = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    float a = mp.c1_b[ch];
+#pragma unroll
+                    for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 2; ++kx) a = fmaf(mp.c1_w[ch * 4 + ky * 2 + kx], px[2 * i + ky][2 * j + kx], a);
+                    v[ch] = a; mean += a;
+                }
+                mean *= 0.25f;
+                float var = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) { v[ch] -= mean; var += v[ch] * v[ch]; }
+                const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) h1[i][j][ch] = gelu_erf(v[ch] * rstd * mp.ln1_w[ch] + mp.ln1_b[ch]);
+            }
+        float v2[16], mean = 0.f;
+#pragma unroll
+        for (int co = 0; co < 16; ++co) {
+            float a = mp.c2_b[co];
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 2; ++kx) a = fmaf(mp.c2_w[((co * 4 + ci) * 2 + ky) * 2 + kx], h1[ky][kx][ci], a);
+            v2[co] = a; mean += a;
+        }
+        mean *= (1.f / 16.f);
+        float var = 0.f;
+#pragma unroll
+        for (int co = 0; co < 16; ++co) { v2[co] -= mean; var += v2[co] * v2[co]; }
+        const float rstd = 1.0f / sqrtf(var * (1.f / 16.f) + 1e-6f);
+#pragma unroll
+        for (int co = 0; co < 16; ++co) h2s[tx][co] = gelu_erf(v2[co] * rstd * mp.ln2_w[co] + mp.ln2_b[co]);
+    }
+    __syncthreads();
+    const int c = tid;
+    float w3[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w3[k] = mp.c3_w[c * 16 + k];
+    const float base = mp.c3_b[c] - no_mask[c];          // src_f32 already contains + no_mask_embed
+    for (int t = 0; t < 64; ++t) {
+        float a = base;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a = fmaf(w3[k], h2s[t][k], a);
+        const long token = (long)ty * 64 + t;
+        keys[((long)p * T + token) * C + c] = f2bf(src_f32[token * C + c] + a);
+    }
+}
+
 // src[t][c] = emb[c][t] + no_mask[c]  (NCHW -> token-major); bf16 copy
 __global__ __launch_bounds__(256) void src_prepare_kernel(const float* __restrict__ emb, const float* __restrict__ no_mask,
                                                           float* __restrict__ src_f32, u16* __restrict__ src_bf16) {
@@ -588,11 +665,21 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
                                     const float* points, const int32_t* labels, int32_t Np, const float* boxes, int32_t P,
                                     int32_t multimask, float* low_res, float* iou, void* workspace, int64_t workspace_bytes,
                                     void* stream) {
+    return msam_decoder_forward_masks(dec, nullptr, consts, image_state, points, labels, Np, boxes, nullptr, P, multimask,
+                                      low_res, iou, workspace, workspace_bytes, stream);
+}
+
+extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const void* consts,
+                                          const void* image_state, const float* points, const int32_t* labels, int32_t Np,
+                                          const float* boxes, const float* mask_input, int32_t P, int32_t multimask,
+                                          float* low_res, float* iou, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!dec || !consts || !image_state || !low_res || !iou || !workspace || P <= 0) {
         msam_set_error("msam_decoder_forward: null argument");
         return 1;
     }
     if ((!points || Np <= 0) && !boxes) { msam_set_error("msam_decoder_forward: need points and/or boxes"); return 1; }
+    if (mask_input && !mask_w) { msam_set_error("msam_decoder_forward: mask prompts need the mask_downscaling weights"); return 1; }
+    const bool own_src = mask_input != nullptr;          // per-prompt source stream (image embedding + dense mask embedding)
     if (!points) Np = 0;
     const int Nt = 5 + Np + (boxes ? 2 : (Np > 0 ? 1 : 0));
     if (Nt > 16) { msam_set_error("msam_decoder_forward: at most 16 tokens per prompt (<= 10 points)"); return 1; }
@@ -612,6 +699,10 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
                                                                  outb_, n4); CHECK(msam_check_launch("add_cast2")); } while (0)
 #define LN(x_, w_, b_, rows_, out_, dt_) CHECK(msam_layernorm(x_, w_, b_, 1e-5f, rows_, C, out_, dt_, 0, 0, cx.s))
 
+    if (own_src) {
+        hipLaunchKernelGGL(mask_src_kernel, dim3(64, P), dim3(256), 0, cx.s, mask_input, *mask_w, im.src_f32, dec->no_mask, w.keys);
+        CHECK(msam_check_launch("mask_src"));
+    }
     hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, cx.s, dec->pe_gauss, dec->point_embed, dec->not_a_point,
                        dec->out_tokens, points, labels, Np, boxes, P, Nt, w.qpe, w.queries, w.a);
     CHECK(msam_check_launch("prompt_tokens"));
@@ -637,7 +728,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         // (2) token -> image attention
         ADD_CAST(w.queries, w.qpe, w.a);
         CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_BF16, CI));
-        if (li == 0) {
+        if (li == 0 && !own_src) {
             // prompt-independent K / V^T of the shared embedding (prepare_image): 1 MiB, L2 resident
             if (Nt <= 8)
                 hipLaunchKernelGGL(t2i_shared4_kernel, dim3(((P + 3) / 4) * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, P, Nt,
@@ -646,7 +737,7 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
                 hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
             CHECK(msam_check_launch("t2i_attn"));
         } else {
-            CHECK(t2i_stream(cx, w, c, 1, L.t2i, P, Nt));
+            CHECK(t2i_stream(cx, w, c, li, L.t2i, P, Nt));
         }
         CHECK(gemm(cx, w.attn_tok, CI, L.t2i.o_w, M, C, CI, L.t2i.o_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n2_w, L.n2_b, M, w.queries, MSAM_F32);
@@ -662,15 +753,16 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
         // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
         // for up to 8 tokens per prompt, weights-stationary fused kernel (declayer.hip) otherwise
         if (Nt <= 8) {
-            CHECK(msam_i2t_fold_layer(li == 0 ? (const void*)im.src_bf16 : (const void*)w.keys, li == 0, w.ks, w.vs, P, Nt,
+            const bool shared = li == 0 && !own_src;
+            CHECK(msam_i2t_fold_layer(shared ? (const void*)im.src_bf16 : (const void*)w.keys, shared, w.ks, w.vs, P, Nt,
                                       L.i2t.q_w, c.tab_q[li], L.i2t.o_w, L.i2t.o_b, L.n4_w, L.n4_b, 1e-5f, w.keys, w.qimg,
                                       (int64_t)((char*)w.up1 - (char*)w.qimg), cx.s));
         } else {
             msam_image_layer_t g{};
             g.wo = L.i2t.o_w; g.bo = L.i2t.o_b; g.ln_w = L.n4_w; g.ln_b = L.n4_b; g.ln_eps = 1e-5f;
             g.ktok = w.ks; g.vtok = w.vs; g.Nt = Nt; g.out = w.keys; g.rows = (int)R;
-            if (li == 0) { g.xin = im.src_bf16; g.q_shared = im.q0; }
-            else { g.xin = w.keys; g.wq = L.i2t.q_w; g.bq = L.i2t.q_b; g.peq = c.pe_q[1]; }
+            if (li == 0 && !own_src) { g.xin = im.src_bf16; g.q_shared = im.q0; }
+            else { g.xin = w.keys; g.wq = L.i2t.q_w; g.bq = L.i2t.q_b; g.peq = c.pe_q[li]; }
             CHECK(msam_decoder_image_layer(&g, cx.s));
         }
     }

@@ -4,7 +4,7 @@
 (``msam_postprocess_masks``: upsample, threshold, stability counts, boxes, bit masks) -> records or a label image.
 
 Same names, argument meaning and error behaviour as the reference.  Differences that are documented limits of this
-build: mask prompts (``logits_masks``) and ``embedding_path`` raise ``NotImplementedError``; the tiled variant
+build: ``embedding_path`` (zarr cache) raises ``NotImplementedError``; the tiled variant
 (``batched_tiled_inference``) is not provided.
 """
 from typing import Any, Dict, List, Optional, Union
@@ -91,8 +91,6 @@ def batched_inference(predictor: SamPredictor, image: Optional[np.ndarray], batc
     uint32 label image of ``util.mask_data_to_segmentation(records, min_object_size=0)``."""
     n_prompts, have_boxes, have_points, have_logits = _validate_inputs(
         boxes, points, point_labels, multimasking, return_instance_segmentation, segmentation_ids, logits_masks)
-    if have_logits:
-        raise NotImplementedError("micro_sam_amd: mask prompts (logits_masks) are not provided in this build")
     if embedding_path is not None:
         raise NotImplementedError("micro_sam_amd: the zarr embedding cache is not provided in this build")
     if image is None:
@@ -119,7 +117,8 @@ def batched_inference(predictor: SamPredictor, image: Optional[np.ndarray], batc
         sl = slice(batch_idx * batch_size, min((batch_idx + 1) * batch_size, n_prompts))
         low, iou = predictor.model.decode(predictor.features, points[sl] if have_points else None,
                                           point_labels[sl].to(torch.int32) if have_points else None,
-                                          boxes[sl] if have_boxes else None, None, multimasking)
+                                          boxes[sl] if have_boxes else None,
+                                          logits_masks[sl] if have_logits else None, multimasking)
         if reduce_multimasking and multimasking:          # most likely of the three masks (reference :256-263)
             best = iou.argmax(dim=1)
             sel = torch.arange(low.shape[0], device=low.device)

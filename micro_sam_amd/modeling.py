@@ -406,6 +406,14 @@ class Sam(nn.Module):
                 wt, bs = pad_rows(wt, bs)
             p.iou_w[j], p.iou_b[j] = k(_bf16(wt)), k(_f32(bs))
         p.use_glds = int(self.use_glds)
+        ds = pe.mask_downscaling                                  # mask prompts: Conv, LN2d, GELU, Conv, LN2d, GELU, Conv
+        mp = _lib.MaskPromptParams()
+        mp.c1_w, mp.c1_b = k(_f32(ds[0].weight.reshape(-1))), k(_f32(ds[0].bias))
+        mp.ln1_w, mp.ln1_b = k(_f32(ds[1].weight)), k(_f32(ds[1].bias))
+        mp.c2_w, mp.c2_b = k(_f32(ds[3].weight.reshape(-1))), k(_f32(ds[3].bias))
+        mp.ln2_w, mp.ln2_b = k(_f32(ds[4].weight)), k(_f32(ds[4].bias))
+        mp.c3_w, mp.c3_b = k(_f32(ds[6].weight.reshape(PROMPT_DIM, 16))), k(_f32(ds[6].bias))
+        self._mask_params = mp
         lib = _lib.load()
         consts = torch.empty(lib.msam_decoder_const_bytes(), dtype=torch.uint8, device=dev)
         _lib.check(lib.msam_decoder_prepare_const(C.byref(p), consts.data_ptr(), _lib.stream_ptr()),
@@ -438,8 +446,6 @@ class Sam(nn.Module):
         """prompt_encoder + mask_decoder of ``SamPredictor.predict_torch`` for one image embedding [1,256,64,64].
 
         point_coords [P,Np,2] / boxes [P,4] are in the 1024 input frame.  Returns (low_res [P,C,256,256], iou [P,C])."""
-        if mask_input is not None:
-            raise NotImplementedError("micro_sam_amd: mask prompts are not supported by the HIP decoder this round")
         if features.numel() != PROMPT_DIM * GRID * GRID:
             raise ValueError(f"expected one image embedding [1,256,64,64], got {tuple(features.shape)}")
         p, _, consts = self._prepare_decoder()
@@ -461,10 +467,15 @@ class Sam(nn.Module):
         if self._dec_ws is None or self._dec_ws.numel() < need or self._dec_ws.device != dev:
             self._dec_ws = None
             self._dec_ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        _lib.check(lib.msam_decoder_forward(
-            C.byref(p), consts.data_ptr(), state.data_ptr(), _lib.ptr(pts), _lib.ptr(lbl), Np, _lib.ptr(bx), P,
-            1 if multimask_output else 0, low.data_ptr(), iou.data_ptr(), self._dec_ws.data_ptr(), self._dec_ws.numel(),
-            _lib.stream_ptr()), "msam_decoder_forward")
+        msk = None
+        if mask_input is not None:                       # low-res logits of a previous prediction, one per prompt
+            msk = mask_input.to(device=dev, dtype=torch.float32).reshape(-1, 4 * GRID, 4 * GRID).contiguous()
+            if msk.shape[0] != P:
+                raise ValueError(f"mask_input holds {msk.shape[0]} masks for {P} prompts")
+        _lib.check(lib.msam_decoder_forward_masks(
+            C.byref(p), C.byref(self._mask_params), consts.data_ptr(), state.data_ptr(), _lib.ptr(pts), _lib.ptr(lbl), Np,
+            _lib.ptr(bx), _lib.ptr(msk), P, 1 if multimask_output else 0, low.data_ptr(), iou.data_ptr(),
+            self._dec_ws.data_ptr(), self._dec_ws.numel(), _lib.stream_ptr()), "msam_decoder_forward")
         return low, iou
 
 

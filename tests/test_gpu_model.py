@@ -219,8 +219,21 @@ def test_batched_inference_vs_oracle(ctx):
         s = ((lg > 1.0).sum().float() / (lg > -1.0).sum().float()).item()
         assert abs(s - r["stability_score"]) <= 1e-6
         assert torch.equal(lg > 0.0, r["segmentation"])
-    with pytest.raises(NotImplementedError):
-        inference.batched_inference(p, None, 4, boxes=boxes, logits_masks=torch.zeros(n, 1, 256, 256))
+    # mask prompts: feed the low-res logits of the box prediction back together with the boxes (reference :248-255)
+    prev = torch.stack([r["logits"] for r in inference.batched_inference(p, None, 8, boxes=boxes,
+                                                                           return_instance_segmentation=False)])
+    assert tuple(prev.shape) == (n, 1, 256, 256)
+    recs = inference.batched_inference(p, None, 4, boxes=boxes, logits_masks=prev, return_instance_segmentation=False)
+    from oracle import sam_ref as S
+    with torch.no_grad():
+        bx = torch.tensor(S.apply_boxes(boxes, p.original_size), dtype=torch.float32)
+        _, iou_r, low_r = S.predict_torch(ctx["sd"], feats, p.input_size, p.original_size, None, None, bx, prev.cpu(),
+                                          multimask_output=False, return_logits=True, precision="bf16")
+    low = torch.stack([r["logits"] for r in recs]).cpu()
+    assert ((low > 0) != (low_r > 0)).float().mean().item() <= 0.01
+    assert max(abs(r["predicted_iou"] - float(iou_r[k, 0])) for k, r in enumerate(recs)) <= 5e-3
+    # the mask prompt matters: the prediction differs from the one without it
+    assert (low - prev.cpu()).abs().max().item() > 1e-3
 
 
 def _oracle_state_from(state):
