@@ -100,7 +100,7 @@ def main():
     # live HIP-event measurement per kernel family (include/msam_hip.h msam_profile_collect_family)
     NF = _lib.PROFILE_FAMILIES
     FAMILY = [
-        ("gemm_kernel (128x128x64 bf16 MFMA GEMM: encoder + token-side projections)", "mfma"),
+        ("gemm256_kernel / gemm_kernel (256x256x64 and 128x128x64 bf16 MFMA GEMM: encoder + token-side projections)", "mfma"),
         ("wsgemm_kernel / dec_image_layer_kernel (weights-stationary streaming kernels, > 8 tokens per prompt)", "hbm"),
         ("fold_i2t_kernel (folded image->token attention + out_proj + norm4: stream read (layer 1) + written in place)", "hbm"),
         ("fold_attn_kernel (folded token->image attention: stream read once)", "hbm"),

@@ -5,6 +5,7 @@
 // Two staging variants (msam_gemm_t.use_glds):
 //   0: global_load_dwordx4 -> VGPR -> ds_write_b128, next tile's loads in flight during the MFMA phase
 //   1: global_load_lds_dwordx4 (LDS-DMA), swizzle applied on the per-lane SOURCE address (LDS image linear)
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/msam_hip.h"
 
@@ -275,6 +276,188 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A,
             pk.z = pack2bf(src[4 * BN], src[5 * BN]); pk.w = pack2bf(src[6 * BN], src[7 * BN]);
             *(uint4*)(dst + i) = pk;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Large-shape variant (encoder projections, M = tiles * 4096): tile 256 x 256 x 64, 8 waves as 2 (M) x 4 (N), wave tile
+// 128 x 64 on v_mfma_f32_32x32x16_bf16 (twice the flops per LDS byte of the 16x16x32 form; the 128 x 128 tile above needs
+// 64 B/cycle/CU of operand traffic at MFMA peak, this one 32).  The product is formed TRANSPOSED (A operand = W rows,
+// B operand = A rows) so that a lane holds 4 consecutive output columns of one row.  Operands: register staging two
+// k-tiles ahead (buffer loads), double-buffered LDS (2 x 64 KB, dynamic); epilogue: the fp32 tile goes through the same
+// LDS in two column halves (256 x 128 fp32 = 128 KB, 16-byte chunks XOR-swizzled with the row) and is written out
+// row-wise with the residual rows requested up front, exactly like the 128 x 128 kernel.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+MSAM_DEVINL f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+constexpr int G2 = 256;                       // tile edge
+constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 8 chunks x 16 B = 128 KB
+
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
+                                                         long ldw, int M, int N, int K, Epi e) {
+    extern __shared__ __attribute__((aligned(16))) uint4 dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles_n = N / G2, tiles_m = (M + G2 - 1) / G2;
+    int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    {
+        int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * G2, n0 = tile_n * G2;
+    const int wm = wave >> 2, wn = wave & 3;
+    auto stage = [&](int buf, int op) -> uint4* { return dyn + (buf * 2 + op) * (G2 * 8); };
+
+    // staging map: thread t covers LDS chunk position (row = p*64 + t/8, c' = t%8) <- global chunk c' ^ swz(row)
+    const int srow = tid >> 3, scp = tid & 7;
+    int aoff[4], woff[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 64 + srow, gc = scp ^ swz(row);
+        const int ar = min(m0 + row, M - 1);
+        aoff[p] = (int)(((long)ar * lda + gc * 8) * 2);
+        woff[p] = (int)(((long)(n0 + row) * ldw + gc * 8) * 2);
+    }
+    const rsrc_t ra = make_rsrc(A, (uint32_t)min((long)M * lda * 2, 0xffffffffL));
+    const rsrc_t rw = make_rsrc(W, (uint32_t)min((long)N * ldw * 2, 0xffffffffL));
+    uint4 xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3;
+#define G2_LOAD(a0_, a1_, a2_, a3_, w0_, w1_, w2_, w3_, kt_)                                           \
+    do {                                                                                               \
+        const int so_ = (kt_) * BK * 2;                                                                \
+        a0_ = buf_load16(ra, aoff[0], so_); a1_ = buf_load16(ra, aoff[1], so_);                        \
+        a2_ = buf_load16(ra, aoff[2], so_); a3_ = buf_load16(ra, aoff[3], so_);                        \
+        w0_ = buf_load16(rw, woff[0], so_); w1_ = buf_load16(rw, woff[1], so_);                        \
+        w2_ = buf_load16(rw, woff[2], so_); w3_ = buf_load16(rw, woff[3], so_);                        \
+    } while (0)
+#define G2_COMMIT(a0_, a1_, a2_, a3_, w0_, w1_, w2_, w3_, buf_)                                        \
+    do {                                                                                               \
+        uint4* sa_ = stage(buf_, 0) + srow * 8 + scp; uint4* sw_ = stage(buf_, 1) + srow * 8 + scp;    \
+        sa_[0] = a0_; sa_[64 * 8] = a1_; sa_[128 * 8] = a2_; sa_[192 * 8] = a3_;                       \
+        sw_[0] = w0_; sw_[64 * 8] = w1_; sw_[128 * 8] = w2_; sw_[192 * 8] = w3_;                       \
+    } while (0)
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+    const int nk = K / BK;
+    auto compute = [&](int buf) {
+        const uint4* la = stage(buf, 0);
+        const uint4* lw = stage(buf, 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            uint4 wf[2], af[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wn * 64 + i * 32 + l31;
+                wf[i] = lw[row * 8 + ((s4 * 2 + lh) ^ swz(row))];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wm * 128 + j * 32 + l31;
+                af[j] = la[row * 8 + ((s4 * 2 + lh) ^ swz(row))];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[i], af[j], acc[i][j]);
+        }
+    };
+    G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+    G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+    G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(1, nk - 1));
+    __syncthreads();
+    int kt = 0;
+    while (true) {
+        G2_LOAD(ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3, min(kt + 2, nk - 1));
+        compute(kt & 1);
+        if (kt + 1 < nk) G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, (kt & 1) ^ 1);
+        __syncthreads();
+        if (++kt >= nk) break;
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(kt + 2, nk - 1));
+        compute(kt & 1);
+        if (kt + 1 < nk) G2_COMMIT(ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3, (kt & 1) ^ 1);
+        __syncthreads();
+        if (++kt >= nk) break;
+    }
+    wait_vmem_all();
+#undef G2_LOAD
+#undef G2_COMMIT
+
+    // ---- epilogue in two column halves of 128: C^T accumulators (row = n, column = m) -> ldsC[m][128] fp32, chunk-swizzled
+    float* ldsC = (float*)dyn;
+    const int c4 = tid & 31, rg = tid >> 5;                  // 16-byte column chunk, row group (16 rows per pass)
+    for (int h = 0; h < 2; ++h) {
+        if ((wn >> 1) == h) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = wm * 128 + j * 32 + l31;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int chunk = ((wn & 1) * 64 + i * 32 + 8 * g + lh * 4) >> 2;
+                        *(float4*)(ldsC + m * 128 + ((chunk ^ (m & 31)) << 2)) =
+                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    }
+                }
+        }
+        __syncthreads();
+        const int col = n0 + h * 128 + c4 * 4;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (e.bias) { const float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+        int which = 0, head = 0, d = 0;
+        if (e.out_mode == 1) {
+            const int D = e.heads * e.head_dim;
+            which = col / D; const int rem = col - which * D; head = rem / e.head_dim; d = rem - head * e.head_dim;
+        }
+        for (int grp = 0; grp < 2; ++grp) {              // residual rows of 8 passes at a time (register budget)
+        float4 rt[8];
+        if (e.resid_dtype == MSAM_F32) {
+#pragma unroll
+            for (int ps = 0; ps < 8; ++ps) {
+                const int row = min(m0 + (grp * 8 + ps) * 16 + rg, M - 1);
+                rt[ps] = *(const float4*)((const float*)e.resid + (long)row * e.ldr + col);
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int pass = grp * 8 + ps;
+            const int lr = pass * 16 + rg, row = m0 + lr;
+            const float4 c = *(const float4*)(ldsC + lr * 128 + ((c4 ^ (lr & 31)) << 2));
+            float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+            if (e.resid_dtype == MSAM_F32) { v[0] += rt[ps].x; v[1] += rt[ps].y; v[2] += rt[ps].z; v[3] += rt[ps].w; }
+            if (e.act == MSAM_ACT_GELU) {
+                const f32x2_t g01 = gelu_erf2(f32x2_t{v[0], v[1]}), g23 = gelu_erf2(f32x2_t{v[2], v[3]});
+                v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
+            } else if (e.act == MSAM_ACT_RELU) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
+            }
+            if (row < M) {
+                if (e.out_mode == 0) {
+                    if (e.out_dtype == MSAM_F32) {
+                        *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                        *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
+                    }
+                } else {
+                    u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
+                    const int b = row / e.tokens, t = row - b * e.tokens;
+                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    *(uint2*)(dst + ((long)(b * e.heads + head) * e.tokens + t) * e.head_dim + d) = pk;
+                }
+            }
+        }
+        }
+        __syncthreads();
     }
 }
 
@@ -562,6 +745,30 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     }
     int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
+    // large shapes (the encoder's projections): 256 x 256 tile kernel.  MSAM_GEMM256=0 keeps the 128 x 128 kernel (A/B runs)
+    static int use256 = -1;
+    if (use256 < 0) { const char* v = getenv("MSAM_GEMM256"); use256 = v ? atoi(v) : 1; }
+    // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
+    if (use256 && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 && p->out_mode != 2 && !p->table &&
+        (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
+        static bool attr256 = false;
+        if (!attr256) {
+            if (hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
+                msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
+                return 2;
+            }
+            attr256 = true;
+        }
+        if (prof) {
+            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
+            (void)hipEventRecord(g_prof[g_prof_n].a, s);
+        }
+        const int tiles256 = ((p->M + G2 - 1) / G2) * (p->N / G2);
+        hipLaunchKernelGGL(gemm256_kernel, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda,
+                           (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+        if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
+        return msam_check_launch("msam_gemm_bf16(256)");
+    }
     if (prof) {
         g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
         (void)hipEventRecord(g_prof[g_prof_n].a, s);

@@ -86,6 +86,31 @@ def test_gemm_layout_epilogues(env, glds):
     assert _close(vT, ref[:, 128:].reshape(2, 4096, 128).permute(0, 2, 1), 3e-2, 1e-2)
 
 
+def test_gemm_256_tile_kernel(env):
+    """Shapes with >= 256 tiles of 256 x 256 take gemm256_kernel (32x32x16 MFMA, transposed product): ragged M, every
+    epilogue it supports (bias, GELU -> bf16, fp32 residual in place, QKV head split)."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 16384 + 100, 1024, 192                     # 65 x 4 = 260 tiles, last row tile ragged
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    base = a.float() @ w.float().t() + bias
+    assert _close(ops.gemm(a, w, bias), base, 1e-3, 1e-4)
+    assert _close(ops.gemm(a, w, bias, act=ops.ACT_GELU, out_dtype=torch.bfloat16), F.gelu(base), 2e-2, 1e-2)
+    x = torch.randn(M, N, generator=g).to(dev)
+    ref = base + x
+    ops.gemm(a, w, bias, resid=x, out=x)
+    assert _close(x, ref, 1e-3, 1e-4)
+    B, heads, D = 6, 4, 256                               # 96 x 3 = 288 tiles
+    a = _bf(torch.randn(B * 4096, D, generator=g)).to(dev)
+    w = _bf(torch.randn(3 * D, D, generator=g) / math.sqrt(D)).to(dev)
+    bias = torch.randn(3 * D, generator=g).to(dev)
+    ref = (a.float() @ w.float().t() + bias).reshape(B, 4096, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    for t, r in zip(ops.gemm_qkv(a, w, bias, B, heads), ref):
+        assert _close(t, r, 3e-2, 1e-2)
+
+
 def test_gemm_argument_errors(env):
     ops, dev = env
     a = torch.zeros(128, 64, dtype=torch.bfloat16, device=dev)
