@@ -186,139 +186,197 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
 }
 
 // --------------------------------------------------------------------------------------------- global
-constexpr int GQ = 64;            // queries per workgroup (one image row)
+// Global attention of the ViT blocks 2, 5, 8, 11 (4096 keys, head_dim 64, decomposed relative position bias).
+// One workgroup = 128 queries (two image rows) of one (tile, head); wave = 32 queries = two 16-query score tiles that
+// share every K / V fragment (the kernel is bound by the L2 bandwidth of re-reading K / V once per workgroup: 128
+// queries per workgroup halve that traffic against one image row).  Transposed-score form: S^T = K . Q^T, online
+// softmax per lane column, O^T += V^T . P^T with V^T read from the row-major V tile by ds_read_b64_tr_b16.
+// Bias: rel_h[q][kh] (one scalar per query and key ROW) from an LDS table; rel_w[q][kw] only depends on the key column,
+// i.e. on the position inside a 32-key tile (2 phases) - the 16 values a lane ever needs live in registers.
+constexpr int GQ = 128;           // queries per workgroup
 constexpr int GKT = 32;           // keys per tile
-constexpr int GVT_RS = 40;        // V^T tile row stride in bf16 (80 B = 20 dwords = 4 * odd)
 constexpr int GB_RS = 68;         // bias table row stride in floats (272 B, multiple of 16 B)
 
-__global__ __launch_bounds__(256) void global_attention_kernel(
+typedef short gs16x4_t __attribute__((ext_vector_type(4)));
+MSAM_DEVINL uint2 g_tr16(const unsigned char* p) {
+    gs16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gs16x4_t __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+
+__global__ __launch_bounds__(256, 3) void global_attention_kernel(
     const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
     const u16* __restrict__ relw, int heads, u16* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint4 k_lds[2][GKT * 8];              // 8 KB
-    __shared__ __attribute__((aligned(16))) u16 vt_lds[2][HD * GVT_RS];           // 10 KB
-    __shared__ __attribute__((aligned(16))) float rh_lds[GQ * GB_RS];             // 17 KB  rel_h[q][kh]
-    __shared__ __attribute__((aligned(16))) float bw_lds[GQ * GB_RS];             // 17 KB  rel_w[q][kw]
+    __shared__ __attribute__((aligned(16))) uint4 k_lds[2][GKT * 8];                   // 8 KB
+    __shared__ __attribute__((aligned(16))) unsigned char v_lds[2][GKT * 128];         // 8 KB, [key][64 d] bf16
+    __shared__ __attribute__((aligned(16))) float rh_lds[GQ * GB_RS];                  // 34 KB  rel_h[q][kh] (rel_w scratch first)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     int bid = blockIdx.x;
-    const int qrow = bid & 63; bid >>= 6;
+    const int qpair = bid & 31; bid >>= 5;
     const int head = bid % heads, b = bid / heads;
     const int D = heads * HD;
     const long bh = ((long)b * heads + head) * TOK * HD;
     const u16* Qb = Q + bh; const u16* Kb = K + bh; const u16* Vb = V + bh;
 
-    const int ql = wave * 16 + fr;            // query column inside the image row = qw
-    const int qh = qrow, qw = ql;
-    uint4 qf[2];
+    const int qh = qpair * 2 + (wave >> 1);              // image row of this wave's 32 queries
+    const int qw0 = (wave & 1) * 32;                     // first column
+    uint4 qf[2][2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *(const uint4*)(Qb + (long)(qh * 64 + qw) * HD + ks * 32 + fg * 8);
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[j][ks] = *(const uint4*)(Qb + (long)(qh * 64 + qw0 + j * 16 + fr) * HD + ks * 32 + fg * 8);
 
-    // ---- prologue: rel_h[q][kh] = q . rel_pos_h[qh - kh + 63]  (A rows indexed by kh)
+    // ---- rel_w[q][kw] = q . rel_pos_w[qw - kw + 63]: T[j'][q] for all 127 rows j', scattered to kw = qw - j' + 63 of this
+    // wave's private scratch rows, then the 16 values per score tile this lane needs are pulled into registers
+    float* scr = rh_lds + (wave * 32) * GB_RS;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int kh = t * 16 + fr;
-        const u16* src = relh + (qh - kh + 63) * HD;
-        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-        c = mfma16(*(const uint4*)(src + fg * 8), qf[0], c);
-        c = mfma16(*(const uint4*)(src + 32 + fg * 8), qf[1], c);
-        *(float4*)(rh_lds + ql * GB_RS + t * 16 + fg * 4) = make_float4(c[0], c[1], c[2], c[3]);
-    }
-    // rel_w[q][kw] = q . rel_pos_w[qw - kw + 63]: compute T[j][q] for all 127 rows j, scatter to kw = qw - j + 63
+    for (int j = 0; j < 2; ++j) {
+        const int qw = qw0 + j * 16 + fr;
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt) {
-        const int j = jt * 16 + fr;
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-        if (j < 127) { a0 = *(const uint4*)(relw + j * HD + fg * 8); a1 = *(const uint4*)(relw + j * HD + 32 + fg * 8); }
-        f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-        c = mfma16(a0, qf[0], c);
-        c = mfma16(a1, qf[1], c);
+        for (int jt = 0; jt < 8; ++jt) {
+            const int jr = jt * 16 + fr;
+            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+            if (jr < 127) { a0 = *(const uint4*)(relw + jr * HD + fg * 8); a1 = *(const uint4*)(relw + jr * HD + 32 + fg * 8); }
+            f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+            c = mfma16(a0, qf[j][0], c);
+            c = mfma16(a1, qf[j][1], c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kw = qw - (jt * 16 + fg * 4 + r) + 63;
-            if (kw >= 0 && kw < 64) bw_lds[ql * GB_RS + kw] = c[r];
+            for (int r = 0; r < 4; ++r) {
+                const int kw = qw - (jt * 16 + fg * 4 + r) + 63;
+                if (kw >= 0 && kw < 64) scr[(j * 16 + fr) * GB_RS + kw] = c[r];
+            }
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    float4 bw[2][2][2];                                  // [score tile j][kw phase][key block t]
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bw[j][ph][t] = *(const float4*)(scr + (j * 16 + fr) * GB_RS + ph * 32 + t * 16 + fg * 4);
+    __builtin_amdgcn_wave_barrier();
+    // ---- rel_h[q][kh] = q . rel_pos_h[qh - kh + 63]  (A rows indexed by kh), into the same rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int kh = t * 16 + fr;
+            const u16* src = relh + (qh - kh + 63) * HD;
+            f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+            c = mfma16(*(const uint4*)(src + fg * 8), qf[j][0], c);
+            c = mfma16(*(const uint4*)(src + 32 + fg * 8), qf[j][1], c);
+            *(float4*)(scr + (j * 16 + fr) * GB_RS + t * 16 + fg * 4) = make_float4(c[0], c[1], c[2], c[3]);
+        }
 
-    // ---- K / V^T tile staging (register prefetch, double-buffered LDS)
-    const int k_row = tid >> 3, k_ch = tid & 7;          // K tile: 32 rows x 8 chunks
-    const int v_key = tid & 31, v_ch = tid >> 5;         // V tile: key fastest (LDS-friendly transposed writes)
+    // ---- K / V tile staging (register prefetch, double-buffered LDS); both tiles row-major [32 keys][128 B]
+    const int s_row = tid >> 3, s_ch = tid & 7;
     uint4 rk, rv;
-    rk = *(const uint4*)(Kb + (long)k_row * HD + k_ch * 8);
-    rv = *(const uint4*)(Vb + (long)v_key * HD + v_ch * 8);
+    rk = *(const uint4*)(Kb + (long)s_row * HD + s_ch * 8);
+    rv = *(const uint4*)(Vb + (long)s_row * HD + s_ch * 8);
+    // V image: 32-byte d-tile slot' = slot ^ ((key >> 1) & 3) so that the 4 keys of a transposing read hit distinct banks
+    const int v_dst = s_row * 128 + ((((s_ch >> 1) ^ ((s_row >> 1) & 3)) << 5) | ((s_ch & 1) << 4));
 #define G_COMMIT(buf_)                                                                   \
     do {                                                                                 \
-        k_lds[buf_][k_row * 8 + (k_ch ^ swz(k_row))] = rk;                               \
-        u16* vd_ = vt_lds[buf_] + (v_ch * 8) * GVT_RS + v_key;                           \
-        vd_[0 * GVT_RS] = (u16)(rv.x & 0xffff); vd_[1 * GVT_RS] = (u16)(rv.x >> 16);     \
-        vd_[2 * GVT_RS] = (u16)(rv.y & 0xffff); vd_[3 * GVT_RS] = (u16)(rv.y >> 16);     \
-        vd_[4 * GVT_RS] = (u16)(rv.z & 0xffff); vd_[5 * GVT_RS] = (u16)(rv.z >> 16);     \
-        vd_[6 * GVT_RS] = (u16)(rv.w & 0xffff); vd_[7 * GVT_RS] = (u16)(rv.w >> 16);     \
+        k_lds[buf_][s_row * 8 + (s_ch ^ swz(s_row))] = rk;                               \
+        *(uint4*)(v_lds[buf_] + v_dst) = rv;                                             \
     } while (0)
     G_COMMIT(0);
     __syncthreads();
 
-    f32x4_t o[4];
+    // transposing read of V: lane supplies the address of 4 d of key (fg*4 + (fr >> 2)) [+16 for the second block]
+    int troff[2];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    float m = NEG_BIG, l = 0.f;
+    for (int bk = 0; bk < 2; ++bk) {
+        const int key = bk * 16 + fg * 4 + (fr >> 2);
+        troff[bk] = key * 128 + (fr & 3) * 8;            // + ((dt ^ ((key >> 1) & 3)) << 5) per d-tile
+    }
+    const int vsw = (fg * 2 + (fr >> 3)) & 3;            // (key >> 1) & 3 for both blocks (16 >> 1 = 8 = 0 mod 4)
+
+    f32x4_t o[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
     const int NT = TOK / GKT;   // 128
     for (int kt = 0; kt < NT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < NT) {
-            rk = *(const uint4*)(Kb + (long)((kt + 1) * GKT + k_row) * HD + k_ch * 8);
-            rv = *(const uint4*)(Vb + (long)((kt + 1) * GKT + v_key) * HD + v_ch * 8);
+        {
+            const int nx = min(kt + 1, NT - 1);
+            rk = *(const uint4*)(Kb + (long)(nx * GKT + s_row) * HD + s_ch * 8);
+            rv = *(const uint4*)(Vb + (long)(nx * GKT + s_row) * HD + s_ch * 8);
         }
-        const int kh = kt >> 1, kw0 = (kt & 1) * 32;
-        f32x4_t s[2];
+        const int kh = kt >> 1, ph = kt & 1;
+        uint4 ka[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row = t * 16 + fr;
-            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(k_lds[buf][row * 8 + ((0 + fg) ^ swz(row))], qf[0], a);
-            a = mfma16(k_lds[buf][row * 8 + ((4 + fg) ^ swz(row))], qf[1], a);
-            s[t] = a;
+            ka[t][0] = k_lds[buf][row * 8 + ((0 + fg) ^ swz(row))];
+            ka[t][1] = k_lds[buf][row * 8 + ((4 + fg) ^ swz(row))];
         }
-        const float rh = rh_lds[ql * GB_RS + kh];
-        float mt = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float4 bw = *(const float4*)(bw_lds + ql * GB_RS + kw0 + t * 16 + fg * 4);
-            s[t][0] = s[t][0] * 0.125f + rh + bw.x; s[t][1] = s[t][1] * 0.125f + rh + bw.y;
-            s[t][2] = s[t][2] * 0.125f + rh + bw.z; s[t][3] = s[t][3] * 0.125f + rh + bw.w;
-            mt = fmaxf(mt, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
-        }
-        mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
-        const float mn = fmaxf(m, mt);
-        const float alpha = __expf(m - mn);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { float p = __expf(s[t][r] - mn); s[t][r] = p; ps += p; }
-        l = l * alpha + ps;      // per-lane partial row sum; the 4 lane groups are combined after the loop
-        uint4 pb;
-        pb.x = pack2bf(s[0][0], s[0][1]); pb.y = pack2bf(s[0][2], s[0][3]);
-        pb.z = pack2bf(s[1][0], s[1][1]); pb.w = pack2bf(s[1][2], s[1][3]);
+        uint4 va[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-            o[dt][0] *= alpha; o[dt][1] *= alpha; o[dt][2] *= alpha; o[dt][3] *= alpha;
-            const u16* vr = vt_lds[buf] + (dt * 16 + fr) * GVT_RS + fg * 4;
-            uint2 lo = *(const uint2*)(vr), hi = *(const uint2*)(vr + 16);
-            o[dt] = mfma16(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[dt]);
+            const uint2 lo = g_tr16(v_lds[buf] + troff[0] + ((dt ^ vsw) << 5));
+            const uint2 hi = g_tr16(v_lds[buf] + troff[1] + ((dt ^ vsw) << 5));
+            va[dt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4_t s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+                a = mfma16(ka[t][0], qf[j][0], a);
+                a = mfma16(ka[t][1], qf[j][1], a);
+                s[t] = a;
+            }
+            const float rh = scr[(j * 16 + fr) * GB_RS + kh];
+            float mt = NEG_BIG;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 bwv = ph ? bw[j][1][t] : bw[j][0][t];
+                s[t][0] = s[t][0] * 0.125f + rh + bwv.x; s[t][1] = s[t][1] * 0.125f + rh + bwv.y;
+                s[t][2] = s[t][2] * 0.125f + rh + bwv.z; s[t][3] = s[t][3] * 0.125f + rh + bwv.w;
+                mt = fmaxf(mt, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m[j], mt);
+            const float alpha = __expf(m[j] - mn);
+            m[j] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float p = __expf(s[t][r] - mn); s[t][r] = p; ps += p; }
+            l[j] = l[j] * alpha + ps;      // per-lane partial row sum; the 4 lane groups are combined after the loop
+            uint4 pb;
+            pb.x = pack2bf(s[0][0], s[0][1]); pb.y = pack2bf(s[0][2], s[0][3]);
+            pb.z = pack2bf(s[1][0], s[1][1]); pb.w = pack2bf(s[1][2], s[1][3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                o[j][dt][0] *= alpha; o[j][dt][1] *= alpha; o[j][dt][2] *= alpha; o[j][dt][3] *= alpha;
+                o[j][dt] = mfma16(va[dt], pb, o[j][dt]);
+            }
         }
         if (kt + 1 < NT) G_COMMIT(buf ^ 1);
         __syncthreads();
     }
 #undef G_COMMIT
-    l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
-    const float inv = 1.0f / l;
-    u16* dst = out + ((long)b * TOK + qh * 64 + qw) * D + head * HD + fg * 4;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        uint2 pk; pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv); pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-        *(uint2*)(dst + dt * 16) = pk;
+    for (int j = 0; j < 2; ++j) {
+        float lj = l[j];
+        lj += __shfl_xor(lj, 16); lj += __shfl_xor(lj, 32);
+        const float inv = 1.0f / lj;
+        u16* dst = out + ((long)b * TOK + qh * 64 + qw0 + j * 16 + fr) * D + head * HD + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 pk; pk.x = pack2bf(o[j][dt][0] * inv, o[j][dt][1] * inv); pk.y = pack2bf(o[j][dt][2] * inv, o[j][dt][3] * inv);
+            *(uint2*)(dst + dt * 16) = pk;
+        }
     }
 }
 
@@ -341,7 +399,7 @@ extern "C" int msam_global_attention(const void* q, const void* k, const void* v
         msam_set_error("msam_global_attention: bad arguments");
         return 1;
     }
-    hipLaunchKernelGGL(global_attention_kernel, dim3(B * heads * 64), dim3(256), 0, (hipStream_t)stream, (const u16*)q,
+    hipLaunchKernelGGL(global_attention_kernel, dim3(B * heads * 32), dim3(256), 0, (hipStream_t)stream, (const u16*)q,
                        (const u16*)k, (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, heads, (u16*)out);
     return msam_check_launch("msam_global_attention");
 }
