@@ -22,7 +22,7 @@ GO = os.path.join(ROOT, "gpurun_out")
 GiB = 1 << 30
 ALGO = {
     "fold_i2t_kernel": ("layer-1 launches (the larger half): 2 GiB read + 2 GiB written in place; layer 0 writes 2 GiB only", 4 * GiB),
-    "fold_attn_kernel": ("2 GiB read + 64 MiB fp32 partials written", 2 * GiB + 64 * (1 << 20)),
+    "fold_attn_kernel": ("2 GiB read (value projection fused: only [P,7,128] bf16 written)", 2 * GiB),
     "up_fused_kernel": ("2 GiB read + 0.75 GiB fp32 low-res logits written", 2 * GiB + 3 * 1024 * 65536 * 4),
     "postprocess_kernel": ("0.75 GiB fp32 low-res read + 384 MiB bit masks written", 3 * 1024 * 65536 * 4 + 3072 * 128 * 1024),
     "gemm_kernel": ("A and W read once, C written once (mixed shapes)", None),
