@@ -410,56 +410,6 @@ __global__ __launch_bounds__(256) void t2i_shared4_kernel(const u16* __restrict_
     }
 }
 
-// Image -> token cross attention: every image token attends over the Nt (<= 16) prompt tokens.
-//   S^T[j][t] = k_tok[j] . q_img[t]  (A = k_tok rows, B = q_img),  softmax over j = over the lane's registers and
-//   lane groups,  O^T[d][t] = V_tok^T[d][j] P^T[j][t].
-// grid = (16 chunks of 256 tokens, P); wave handles 4 tiles of 16 tokens x 8 heads.
-__global__ __launch_bounds__(256) void i2t_attn_kernel(const u16* __restrict__ qimg, int q_shared,
-                                                       const u16* __restrict__ ktok, const u16* __restrict__ vtok,
-                                                       int Nt, u16* __restrict__ out) {
-    const int p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fg = lane >> 4;
-    const u16* qb = qimg + (q_shared ? 0 : (long)p * T * CI);
-    u16* ob = out + (long)p * T * CI;
-    for (int head = 0; head < 8; ++head) {
-        // A operand for the scores: k_tok[j = fr][head*16 + fg*8 ..], fg < 2
-        uint4 ka = make_uint4(0, 0, 0, 0);
-        if (fg < 2 && fr < Nt) ka = *(const uint4*)(ktok + ((long)p * Nt + fr) * CI + head * 16 + fg * 8);
-        // A operand for PV: V^T[d = fr][j slot (fg, i)] = v_tok[j = fg*4 + i][head*16 + fr] for i < 4, else 0
-        uint4 va = make_uint4(0, 0, 0, 0);
-        {
-            u16 e[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int j = fg * 4 + i;
-                e[i] = j < Nt ? vtok[((long)p * Nt + j) * CI + head * 16 + fr] : (u16)0;
-            }
-            va.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16); va.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            const int t = blockIdx.x * 256 + (wave * 4 + tt) * 16 + fr;
-            uint4 qf = make_uint4(0, 0, 0, 0);
-            if (fg < 2) qf = *(const uint4*)(qb + (long)t * CI + head * 16 + fg * 8);
-            f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-            s = mfma16(ka, qf, s);                       // rows j = fg*4 + r, col t = fr
-            float mt = NEG_BIG;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[r] = (fg * 4 + r < Nt) ? s[r] * 0.25f : NEG_BIG; mt = fmaxf(mt, s[r]); }
-            mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mt); ps += s[r]; }
-            ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
-            uint4 pb; pb.x = pack2bf(s[0], s[1]); pb.y = pack2bf(s[2], s[3]); pb.z = 0; pb.w = 0;
-            f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-            o = mfma16(va, pb, o);                       // rows d = fg*4 + r, col t = fr
-            const float inv = 1.f / ps;
-            uint2 pkd; pkd.x = pack2bf(o[0] * inv, o[1] * inv); pkd.y = pack2bf(o[2] * inv, o[3] * inv);
-            *(uint2*)(ob + (long)t * CI + head * 16 + fg * 4) = pkd;
-        }
-    }
-}
-
 inline int grid_for(long items) { long g = (items + 255) / 256; return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g)); }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -477,31 +427,6 @@ int gemm(const Ctx& cx, const void* A, long lda, const void* W, int M, int N, in
     g.resid = resid; g.resid_dtype = resid_dtype; g.resid_rows = resid_rows; g.ldr = ldr;
     g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc; g.out_mode = 0; g.use_glds = cx.use_glds;
     return msam_gemm_bf16(&g, cx.s);
-}
-
-// K | V^T projection of an image-token stream x[rows,256] with the concatenated weight [Wk; Wv] (bf16 [256,256])
-int gemm_kv(const Ctx& cx, const void* x, int rows, const void* wkv, const float* bkv, const float* pek, void* k_out,
-            void* vT_out) {
-    msam_gemm_t g{};
-    g.A = x; g.lda = C; g.W = wkv; g.ldw = C; g.M = rows; g.N = 256; g.K = C; g.bias = bkv;
-    g.table = pek; g.table_rows = T; g.table_cols = CI; g.table_ld = CI;
-    g.out_mode = 2; g.k = k_out; g.v = vT_out; g.tokens = T; g.use_glds = cx.use_glds;
-    return msam_gemm_bf16(&g, cx.s);
-}
-
-// weights-stationary streaming GEMM on the per-prompt image-token stream (rows = P*4096)
-int wsgemm(const Ctx& cx, const void* A, const void* W, int M, int N, int K, const float* bias, void* out,
-           const float* table = nullptr, int table_cols = 0, const void* resid = nullptr, int resid_rows = 0, int ln_mode = 0,
-           const float* ln_w = nullptr, const float* ln_b = nullptr, float ln_eps = 1e-5f, void* k_out = nullptr,
-           void* vT_out = nullptr) {
-    msam_wsgemm_t g{};
-    g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.bias = bias;
-    g.table = table; g.table_rows = T; g.table_cols = table_cols; g.table_ld = CI;
-    g.resid = resid; g.resid_rows = resid_rows; g.ldr = C;
-    g.ln_mode = ln_mode; g.ln_w = ln_w; g.ln_b = ln_b; g.ln_eps = ln_eps;
-    g.out = out; g.ldc = N;
-    if (k_out) { g.kv_split = 1; g.k_out = k_out; g.vT_out = vT_out; g.tokens = T; }
-    return msam_wsgemm_bf16(&g, cx.s);
 }
 
 // K | V^T projection of the per-prompt stream as two N = 128 launches (k with the positional table, v transposed)

@@ -109,6 +109,27 @@ def test_decoder_box_prompt_single_mask(ctx):
     assert (iou.cpu() - iou_r).abs().max().item() <= 2e-3
 
 
+@pytest.mark.parametrize("with_box,n_pts", [(True, 3), (False, 6), (True, 9)])
+def test_decoder_many_tokens_fallback_path(ctx, with_box, n_pts):
+    """More than 8 tokens per prompt (box + several points: 10 / 12 / 16 tokens) take the un-folded kernels
+    (wsgemm K / V projection + t2i_attn_kernel + dec_image_layer_kernel): same outputs as the oracle."""
+    from oracle import sam_ref as S
+    sd, sam = ctx["sd"], ctx["predictor"].model
+    g = torch.Generator().manual_seed(40 + n_pts)
+    P = 3
+    pts = torch.rand(P, n_pts, 2, generator=g) * 900 + 60
+    lab = (torch.rand(P, n_pts, generator=g) > 0.3).to(torch.int32)
+    bx = torch.tensor([[100., 100., 400., 300.], [600., 200., 900., 700.], [300., 500., 800., 900.]]) if with_box else None
+    with torch.no_grad():
+        _, iou_r, low_r = S.predict_torch(sd, ctx["ref_b"], (1024, 1024), (1024, 1024), pts, lab, boxes=bx,
+                                          multimask_output=True, return_logits=True, precision="bf16")
+    low, iou = sam.decode(ctx["ref_b"].cuda(), pts.cuda(), lab.cuda(), boxes=None if bx is None else bx.cuda(),
+                          multimask_output=True)
+    assert low.shape == (P, 3, 256, 256)
+    assert (low.cpu() - low_r).abs().max().item() <= 0.03 * low_r.abs().max().item()
+    assert (iou.cpu() - iou_r).abs().max().item() <= 3e-3
+
+
 def test_amg_initialize_generate_vs_oracle(ctx):
     from micro_sam_amd import util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
