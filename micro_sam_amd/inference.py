@@ -3,9 +3,8 @@
 ``msam_decoder_forward`` -> (optional best-of-3 by predicted IoU) -> fused device post-processing
 (``msam_postprocess_masks``: upsample, threshold, stability counts, boxes, bit masks) -> records or a label image.
 
-Same names, argument meaning and error behaviour as the reference.  Differences that are documented limits of this
-build: ``embedding_path`` (zarr cache) raises ``NotImplementedError``; the tiled variant
-(``batched_tiled_inference``) is not provided.
+Same names, argument meaning and error behaviour as the reference (``embedding_path`` is the zarr v2 cache of
+``util.precompute_image_embeddings``).  The tiled variant (``batched_tiled_inference``) is not provided.
 """
 from typing import Any, Dict, List, Optional, Union
 
@@ -91,13 +90,11 @@ def batched_inference(predictor: SamPredictor, image: Optional[np.ndarray], batc
     uint32 label image of ``util.mask_data_to_segmentation(records, min_object_size=0)``."""
     n_prompts, have_boxes, have_points, have_logits = _validate_inputs(
         boxes, points, point_labels, multimasking, return_instance_segmentation, segmentation_ids, logits_masks)
-    if embedding_path is not None:
-        raise NotImplementedError("micro_sam_amd: the zarr embedding cache is not provided in this build")
     if image is None:
         predictor.get_image_embedding()          # raises RuntimeError when no embedding is set (reference :212-214)
     else:
         input_ = image if i is None else image[i]
-        image_embeddings = util.precompute_image_embeddings(predictor, input_, verbose=verbose_embeddings)
+        image_embeddings = util.precompute_image_embeddings(predictor, input_, embedding_path, verbose=verbose_embeddings)
         util.set_precomputed(predictor, image_embeddings)
 
     n_batches = int(np.ceil(float(n_prompts) / batch_size))

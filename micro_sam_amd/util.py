@@ -1,7 +1,8 @@
 """micro_sam.util's hot-path surface on the MI355X core: ``get_sam_model``, ``precompute_image_embeddings``,
 ``set_precomputed``, ``_to_image``, ``mask_data_to_segmentation`` (reference: micro_sam/util.py:318-476,618-681,
 902-1018,1133-1258,1773-1848).  Same names, argument meaning and error behaviour; what is not provided this round
-raises ``NotImplementedError`` naming the missing piece (zarr cache on disk, tiling) instead of silently differing.
+raises ``NotImplementedError`` naming the missing piece instead of silently differing.  The on-disk embedding cache
+(``save_path``) is a zarr v2 container written / read by ``zarr_store``.
 """
 from __future__ import annotations
 
@@ -197,30 +198,166 @@ def handle_pbar(verbose, pbar_init, pbar_update):
     return pbar, pbar_init, pbar_update, pbar_close
 
 
-def _compute_2d(input_, predictor, pbar_init, pbar_update, keep_on_device):
+# -- on-disk cache: zarr v2 container (reference util.py:684-747 writers, :1038-1094 signature) ------------------
+
+def _compute_data_signature(input_) -> str:
+    """Reference util.py:1036-1038."""
+    import hashlib
+    return hashlib.sha1(np.asarray(input_).tobytes()).hexdigest()
+
+
+def _get_embedding_signature(input_, predictor, tile_shape, halo, data_signature=None) -> Dict[str, Any]:
+    """Reference util.py:1042-1055."""
+    from . import __version__
+    if data_signature is None:
+        data_signature = _compute_data_signature(input_)
+    return {
+        "data_signature": data_signature,
+        "tile_shape": tile_shape if tile_shape is None else [int(x) for x in tile_shape],
+        "halo": halo if halo is None else [int(x) for x in halo],
+        "model_type": predictor.model_type,
+        "model_name": predictor.model_name,
+        "micro_sam_version": __version__,
+        "model_hash": getattr(predictor, "_hash", None),
+    }
+
+
+def _write_embedding_signature(f, input_, predictor, tile_shape, halo, input_size, original_size) -> None:
+    """Reference util.py:1061-1065 (one .zattrs update instead of one per key)."""
+    signature = _get_embedding_signature(input_, predictor, tile_shape, halo)
+    signature.update({"input_size": input_size, "original_size": original_size})
+    f.attrs.update(signature)
+
+
+def _check_saved_embeddings(input_, predictor, f, save_path, tile_shape, halo) -> None:
+    """Reference util.py:1068-1094: RuntimeError on a data / tiling / model_type mismatch, warning for the keys that
+    were added later (version, model hash, model name)."""
+    if "input_size" not in f.attrs:
+        return
+    attrs = f.attrs.asdict()
+    signature = _get_embedding_signature(input_, predictor, tile_shape, halo)
+    for key, val in signature.items():
+        if key not in attrs or attrs[key] != val:
+            if key in ("micro_sam_version", "model_hash", "model_name"):
+                warnings.warn(f"The signature for {key} in embeddings file {save_path} has a mismatch: "
+                              f"{attrs.get(key)} != {val}. This key was recently added, so your embeddings are likely "
+                              "correct. But please recompute them if model predictions don't look as expected.")
+            else:
+                raise RuntimeError(f"Embeddings file {save_path} is invalid due to mismatch in {key}: "
+                                   f"{attrs.get(key)} != {val}. Please recompute embeddings in a new file.")
+
+
+def _write_batch(features, tile_ids, batched_embeddings, original_sizes, input_sizes, slices=None, n_slices=None) -> None:
+    """Reference util.py:710-747: one dataset per tile ([1,256,64,64], or [Z,1,256,64,64] with chunk = one slice) with
+    the ``original_size`` / ``input_size`` attrs.  One device -> host copy for the whole batch; the chunk files are
+    written by a thread pool (file writes release the GIL)."""
+    from concurrent import futures
+    host = batched_embeddings.detach().float().cpu().numpy()
+    datasets = {}
+    if slices is not None:
+        for k, tile_id in enumerate(tile_ids):      # dataset creation is not thread-safe: done up front
+            name = str(tile_id)
+            if name in datasets:
+                continue
+            if name in features:
+                datasets[name] = features[name]
+                continue
+            ds = features.create_dataset(name, shape=(n_slices, 1) + host.shape[1:], dtype="float32",
+                                         chunks=(1, 1) + host.shape[1:])
+            ds.attrs.update({"original_size": original_sizes[k], "input_size": input_sizes[k]})
+            datasets[name] = ds
+
+    def _write_embed(k):
+        name = str(tile_ids[k])
+        if slices is None:
+            ds = features.create_dataset(name, data=host[k:k + 1])
+            ds.attrs.update({"original_size": original_sizes[k], "input_size": input_sizes[k]})
+        else:
+            datasets[name][slices[k]] = host[k:k + 1]
+
+    n = len(tile_ids)
+    if n == 1:
+        _write_embed(0)
+    elif n > 1:
+        with futures.ThreadPoolExecutor(min(os.cpu_count() or 1, n, 16)) as tp:
+            list(tp.map(_write_embed, range(n)))
+
+
+def _compute_2d(input_, predictor, f, save_path, pbar_init, pbar_update, keep_on_device):
+    """Reference util.py:907-934."""
+    if save_path is not None and "input_size" in f.attrs:          # cached: load and set
+        features = f["features"][:]
+        image_embeddings = {"features": features, "input_size": tuple(f.attrs["input_size"]),
+                            "original_size": tuple(f.attrs["original_size"])}
+        set_precomputed(predictor, image_embeddings)
+        if keep_on_device:
+            image_embeddings["features"] = predictor.features
+        return image_embeddings
     pbar_init(1, "Compute Image Embeddings 2D")
     predictor.reset_image()
     predictor.set_image(_to_image(input_))
     features = predictor.get_image_embedding()
-    features = features if keep_on_device else features.cpu().numpy()
+    host = None
+    if save_path is not None or not keep_on_device:
+        host = features.cpu().numpy()
     pbar_update(1)
-    return {"features": features, "input_size": predictor.input_size, "original_size": predictor.original_size}
+    if save_path is not None:
+        f.create_dataset("features", data=host)
+        _write_embedding_signature(f, input_, predictor, tile_shape=None, halo=None, input_size=predictor.input_size,
+                                   original_size=predictor.original_size)
+    return {"features": features if keep_on_device else host, "input_size": predictor.input_size,
+            "original_size": predictor.original_size}
 
 
-def _compute_3d(input_, predictor, pbar_init, pbar_update, batch_size, keep_on_device):
+def _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_update, batch_size, keep_on_device):
+    """Reference util.py:950-1018, including the resume of a partially written container (slices whose chunk is all
+    zero are recomputed)."""
+    if save_path is not None and "input_size" in f.attrs:
+        features = f["features"] if lazy_loading else f["features"][:]
+        return {"features": features, "input_size": tuple(f.attrs["input_size"]),
+                "original_size": tuple(f.attrs["original_size"])}
     n_slices = input_.shape[0]
+    save_features = save_path is not None
+    partial_features = False
+    ds = None
+    if save_features:
+        shape = (n_slices, 1, modeling.PROMPT_DIM, modeling.GRID, modeling.GRID)
+        chunks = (1,) + shape[1:]
+        if "features" in f:
+            partial_features = True
+            ds = f["features"]
+            if ds.shape != shape or ds.chunks != chunks:
+                raise RuntimeError("Invalid partial features")
+        else:
+            ds = f.create_dataset("features", shape=shape, chunks=chunks, dtype="float32")
     pbar_init(n_slices, "Compute Image Embeddings 3D")
     features = []
     input_sizes = original_sizes = None
     for z_start in range(0, n_slices, batch_size):
         z_stop = min(z_start + batch_size, n_slices)
-        images = [_to_image(input_[z]) for z in range(z_start, z_stop)]
-        emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, images)
-        features.append(emb.unsqueeze(1))          # [b,1,256,64,64]
+        zs = [z for z in range(z_start, z_stop)
+              if not (partial_features and ds.chunk_initialized((z, 0, 0, 0, 0)) and np.count_nonzero(ds[z]) != 0)]
+        if zs:
+            emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [_to_image(input_[z]) for z in zs])
+            if save_features:
+                host = emb.cpu().numpy()
+                for k, z in enumerate(zs):
+                    ds[z] = host[k:k + 1]
+            else:
+                features.append(emb.unsqueeze(1))          # [b,1,256,64,64]
         pbar_update(z_stop - z_start)
-    features = torch.cat(features)
-    if not keep_on_device:
-        features = features.cpu().numpy()
+    if input_sizes is None:          # every slice was already on disk: sizes from the data (what the encoder would report)
+        image = _to_image(input_[n_slices - 1])
+        original_sizes = [image.shape[:2]]
+        input_sizes = [tuple(predictor.transform.get_preprocess_shape(image.shape[0], image.shape[1], 1024))]
+    if save_features:
+        _write_embedding_signature(f, input_, predictor, tile_shape=None, halo=None, input_size=input_sizes[-1],
+                                   original_size=original_sizes[-1])
+        features = ds if lazy_loading else ds[:]
+    else:
+        features = torch.cat(features)
+        if not keep_on_device:
+            features = features.cpu().numpy()
     return {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}
 
 
@@ -237,12 +374,17 @@ def _get_tiles_in_mask(mask, tiling, halo, z=None):
     return tiles
 
 
-def _compute_tiled_features_2d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask):
-    """Reference util.py:765-803; the zarr group is replaced by tiling.TiledFeatures (tensors stay on the device)."""
+def _compute_tiled_features_2d(predictor, input_, tile_shape, halo, f, pbar_init, pbar_update, batch_size, mask):
+    """Reference util.py:765-803.  The embeddings stay on the device in a ``tiling.TiledFeatures`` (the reference's
+    in-memory zarr group); with a container ``f`` they are also written to its ``features`` group."""
     from .tiling import Blocking, TileArray, TiledFeatures
     tiling = Blocking([0, 0], input_.shape[:2], tile_shape)
     n_tiles = tiling.number_of_blocks
     features = TiledFeatures(input_.shape[:2], tile_shape, halo)
+    group = None
+    if f is not None:
+        group = f.require_group("features")
+        group.attrs.update({"shape": input_.shape[:2], "tile_shape": tile_shape, "halo": halo})
     n_batches = int(np.ceil(n_tiles / batch_size))
     if mask is None:
         tile_ids_for_batches = [range(b * batch_size, min((b + 1) * batch_size, n_tiles)) for b in range(n_batches)]
@@ -265,19 +407,29 @@ def _compute_tiled_features_2d(predictor, input_, tile_shape, halo, pbar_init, p
             emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [im for _, im in members])
             for k, (tile_id, _) in enumerate(members):
                 features[tile_id] = TileArray(emb[k:k + 1], original_sizes[k], input_sizes[k])
+            if group is not None:
+                _write_batch(group, [t for t, _ in members], emb, original_sizes, input_sizes)
         pbar_update(len(tile_ids))
+    if f is not None:
+        _write_embedding_signature(f, input_, predictor, tile_shape, halo, input_size=None, original_size=None)
     if mask is not None:
         features.attrs["tiles_in_mask"] = tiles_in_mask
+        if group is not None:
+            group.attrs["tiles_in_mask"] = tiles_in_mask
     return features
 
 
-def _compute_tiled_features_3d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask):
+def _compute_tiled_features_3d(predictor, input_, tile_shape, halo, f, pbar_init, pbar_update, batch_size, mask):
     """Reference util.py:859-905 (per-slice tiles batched by shape)."""
     from .tiling import Blocking, TileArray, TiledFeatures
     assert input_.ndim == 3
     shape = input_.shape[1:]
     tiling = Blocking([0, 0], shape, tile_shape)
     features = TiledFeatures(shape, tile_shape, halo)
+    group = None
+    if f is not None:
+        group = f.require_group("features")
+        group.attrs.update({"shape": shape, "tile_shape": tile_shape, "halo": halo})
     n_slices = input_.shape[0]
     tiles_in_mask_per_slice = None
     if mask is not None:
@@ -301,11 +453,19 @@ def _compute_tiled_features_3d(predictor, input_, tile_shape, halo, pbar_init, p
                     store[tile_id] = (torch.zeros((n_slices, 1) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),
                                       original_sizes[k], input_sizes[k])
                 store[tile_id][0][z, 0] = emb[k]
+            if group is not None:
+                _write_batch(group, [t for _, t, _ in members], emb, original_sizes, input_sizes,
+                             slices=[z for z, _, _ in members], n_slices=n_slices)
         pbar_update(len(chunk))
     for tile_id, (data, original_size, input_size) in store.items():
         features[tile_id] = TileArray(data, original_size, input_size)
     if mask is not None:
-        features.attrs["tiles_in_mask"] = {str(z): per_slice for z, per_slice in tiles_in_mask_per_slice.items()}
+        per_slice = {str(z): per_slice for z, per_slice in tiles_in_mask_per_slice.items()}
+        features.attrs["tiles_in_mask"] = per_slice
+        if group is not None:
+            group.attrs["tiles_in_mask"] = per_slice
+    if f is not None:
+        _write_embedding_signature(f, input_, predictor, tile_shape, halo, input_size=None, original_size=None)
     return features
 
 
@@ -315,24 +475,40 @@ def precompute_image_embeddings(predictor: SamPredictor, input_: np.ndarray, sav
                                 mask=None, pbar_init: Optional[callable] = None, pbar_update: Optional[callable] = None,
                                 keep_on_device: bool = False) -> ImageEmbeddings:
     """Reference util.py:1133-1212.  ``keep_on_device`` (extension): return the features as a device tensor instead of
-    a host numpy array (``set_precomputed`` accepts both, as in the reference util.py:1248-1252).  Tiled embeddings
-    (``tile_shape`` / ``halo``) are returned in a ``tiling.TiledFeatures`` container (device tensors) with the attrs of
-    the reference's zarr group; ``input_size`` / ``original_size`` are None for them (util.py:946,1034)."""
+    a host numpy array (``set_precomputed`` accepts both, as in the reference util.py:1248-1252).
+
+    ``save_path``: zarr v2 container (``zarr_store``, same layout and signature attrs as the reference's cache): an
+    existing container is validated against the input / tiling / model (``RuntimeError`` on a mismatch) and loaded,
+    otherwise the embeddings are computed and written.  Freshly computed tiled embeddings (``tile_shape`` / ``halo``)
+    are returned in a ``tiling.TiledFeatures`` container (device tensors) with the attrs of the reference's zarr group,
+    cached ones as the container's ``features`` group; ``input_size`` / ``original_size`` are None for them
+    (util.py:946,1034)."""
+    from . import zarr_store
     ndim = input_.ndim if ndim is None else ndim
-    if save_path is not None:
-        raise NotImplementedError("micro_sam_amd: the zarr embedding cache (save_path) is not provided this round")
     if tile_shape is not None and halo is None:
         raise ValueError("To compute tiled embeddings the parameters tile_shape and halo have to be passed.")
+    f = None
+    if save_path is not None:
+        save_path = os.fspath(save_path)
+        existed = os.path.exists(save_path)
+        f = zarr_store.open(save_path, mode="a")
+        if existed:
+            _check_saved_embeddings(input_, predictor, f, save_path, tile_shape, halo)
     _, pbar_init, pbar_update, pbar_close = handle_pbar(verbose, pbar_init, pbar_update)
+    cached_tiled = f is not None and tile_shape is not None and "input_size" in f.attrs
     if ndim == 2 and tile_shape is None:
-        embeddings = _compute_2d(input_, predictor, pbar_init, pbar_update, keep_on_device)
-    elif ndim == 2:
-        features = _compute_tiled_features_2d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask)
-        embeddings = {"features": features, "input_size": None, "original_size": None}
+        embeddings = _compute_2d(input_, predictor, f, save_path, pbar_init, pbar_update, keep_on_device)
     elif ndim == 3 and tile_shape is None:
-        embeddings = _compute_3d(input_, predictor, pbar_init, pbar_update, batch_size, keep_on_device)
+        embeddings = _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_update, batch_size,
+                                 keep_on_device)
+    elif ndim in (2, 3) and cached_tiled:          # reference util.py:937-943 / 1021-1027
+        embeddings = {"features": f["features"], "input_size": f.attrs["input_size"],
+                      "original_size": f.attrs["original_size"]}
+    elif ndim == 2:
+        features = _compute_tiled_features_2d(predictor, input_, tile_shape, halo, f, pbar_init, pbar_update, batch_size, mask)
+        embeddings = {"features": features, "input_size": None, "original_size": None}
     elif ndim == 3:
-        features = _compute_tiled_features_3d(predictor, input_, tile_shape, halo, pbar_init, pbar_update, batch_size, mask)
+        features = _compute_tiled_features_3d(predictor, input_, tile_shape, halo, f, pbar_init, pbar_update, batch_size, mask)
         embeddings = {"features": features, "input_size": None, "original_size": None}
     else:
         raise ValueError(f"Invalid dimesionality {input_.ndim}, expect 2 or 3 dim data.")

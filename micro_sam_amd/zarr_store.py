@@ -1,0 +1,367 @@
+"""Minimal zarr **v2** directory store for the embedding cache (``save_path`` of ``precompute_image_embeddings``).
+
+The reference keeps embeddings in a zarr container (``micro_sam/util.py:684-747`` dataset creation / ``_write_batch``,
+``:1038-1094`` signature attrs, ``:1184-1196`` open modes).  ``zarr`` itself is not available in this image, so this
+module writes / reads the on-disk format directly (zarr storage specification v2: a directory per group with
+``.zgroup`` / ``.zattrs``, a directory per array with ``.zarray`` / ``.zattrs`` and one file per chunk named by the
+``.``-joined chunk index).  Containers written here open unchanged with ``zarr.open`` (zarr-python 2 and 3 both read
+the v2 layout), which is the contract between a precompute box and an annotation laptop.
+
+Only the subset of the zarr API that micro_sam touches is provided: ``open(path, mode)``, ``Group.require_group /
+create_dataset / attrs / __contains__ / __getitem__``, ``Array.shape / chunks / dtype / ndim / attrs`` and basic
+indexing (ints and unit-step slices).  Chunks are written uncompressed by default (fp32 embeddings do not compress and
+the writer has to keep up with > 100 tiles/s); ``compressor="zlib"`` is available.  Reading supports the stdlib codecs
+(``zlib``, ``gzip``, ``bz2``, ``lzma``); a container compressed with blosc / zstd (zarr-python's defaults) raises
+``RuntimeError`` naming the codec.
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import threading
+from typing import Any, Dict, Iterator, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def _jsonable(v: Any) -> Any:
+    if isinstance(v, dict):
+        return {str(k): _jsonable(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_jsonable(x) for x in v]
+    if isinstance(v, np.ndarray):
+        return _jsonable(v.tolist())
+    if isinstance(v, np.generic):
+        return v.item()
+    if isinstance(v, range):
+        return list(v)
+    return v
+
+
+def _atomic_write(path: str, data: bytes) -> None:
+    tmp = f"{path}.{os.getpid()}.{threading.get_ident()}.tmp"
+    with io.open(tmp, "wb") as fh:
+        fh.write(data)
+    os.replace(tmp, path)
+
+
+class Attributes:
+    """``.zattrs``: a JSON object, re-read on access and rewritten on every update (like zarr's ``Attributes``).
+    Sequences come back as lists (JSON), exactly as with zarr - callers that need tuples convert."""
+
+    def __init__(self, path: str, read_only: bool = False) -> None:
+        self._path = path
+        self._read_only = read_only
+        self._lock = threading.Lock()
+
+    def _load(self) -> Dict[str, Any]:
+        try:
+            with io.open(self._path, "r") as fh:
+                return json.load(fh)
+        except FileNotFoundError:
+            return {}
+
+    def asdict(self) -> Dict[str, Any]:
+        return self._load()
+
+    def __getitem__(self, key: str) -> Any:
+        return self._load()[key]
+
+    def get(self, key: str, default: Any = None) -> Any:
+        return self._load().get(key, default)
+
+    def __contains__(self, key: object) -> bool:
+        return key in self._load()
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self._load())
+
+    def __len__(self) -> int:
+        return len(self._load())
+
+    def keys(self):
+        return self._load().keys()
+
+    def items(self):
+        return self._load().items()
+
+    def update(self, other: Dict[str, Any]) -> None:
+        if self._read_only:
+            raise PermissionError("zarr container opened read-only")
+        with self._lock:
+            d = self._load()
+            d.update({str(k): _jsonable(v) for k, v in other.items()})
+            _atomic_write(self._path, json.dumps(d, indent=4).encode())
+
+    def __setitem__(self, key: str, value: Any) -> None:
+        self.update({key: value})
+
+
+def _decode(raw: bytes, compressor: Optional[Dict[str, Any]]) -> bytes:
+    if compressor is None:
+        return raw
+    cid = compressor.get("id")
+    if cid == "zlib":
+        import zlib
+        return zlib.decompress(raw)
+    if cid == "gzip":
+        import gzip
+        return gzip.decompress(raw)
+    if cid == "bz2":
+        import bz2
+        return bz2.decompress(raw)
+    if cid == "lzma":
+        import lzma
+        return lzma.decompress(raw)
+    raise RuntimeError(f"micro_sam_amd.zarr_store: chunks compressed with '{cid}' cannot be read here (only the stdlib "
+                       "codecs zlib / gzip / bz2 / lzma and uncompressed chunks are supported); recompute the embeddings "
+                       "or re-save them with one of these codecs")
+
+
+def _encode(raw: bytes, compressor: Optional[Dict[str, Any]]) -> bytes:
+    if compressor is None:
+        return raw
+    if compressor.get("id") == "zlib":
+        import zlib
+        return zlib.compress(raw, int(compressor.get("level", 1)))
+    raise RuntimeError(f"micro_sam_amd.zarr_store: writing with compressor {compressor} is not supported")
+
+
+class Array:
+    """One zarr v2 array (C order, no filters)."""
+
+    def __init__(self, path: str, read_only: bool = False) -> None:
+        self._path = path
+        self._read_only = read_only
+        with io.open(os.path.join(path, ".zarray"), "r") as fh:
+            meta = json.load(fh)
+        if meta.get("zarr_format") != 2:
+            raise RuntimeError(f"{path}: unsupported zarr_format {meta.get('zarr_format')}")
+        if meta.get("order", "C") != "C" or meta.get("filters"):
+            raise RuntimeError(f"{path}: only C-order arrays without filters are supported")
+        self.shape: Tuple[int, ...] = tuple(int(s) for s in meta["shape"])
+        self.chunks: Tuple[int, ...] = tuple(int(s) for s in meta["chunks"])
+        self.dtype = np.dtype(meta["dtype"])
+        self._compressor = meta.get("compressor")
+        fv = meta.get("fill_value", 0)
+        self._fill = 0 if fv is None else (float(fv) if isinstance(fv, str) else fv)   # "NaN" / "Infinity" strings
+        self._sep = meta.get("dimension_separator", ".")
+        self.attrs = Attributes(os.path.join(path, ".zattrs"), read_only)
+
+    # -- geometry
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    @property
+    def name(self) -> str:
+        return os.path.basename(self._path)
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def _chunk_path(self, cidx: Sequence[int]) -> str:
+        if self._sep == "/":
+            return os.path.join(self._path, *[str(c) for c in cidx])
+        return os.path.join(self._path, ".".join(str(c) for c in cidx))
+
+    def _normalise(self, key) -> Tuple[Tuple[Tuple[int, int], ...], Tuple[bool, ...]]:
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            pos = key.index(Ellipsis)
+            key = key[:pos] + (slice(None),) * (self.ndim - (len(key) - 1)) + key[pos + 1:]
+        if len(key) > self.ndim:
+            raise IndexError(f"too many indices for a {self.ndim}-d array")
+        key = key + (slice(None),) * (self.ndim - len(key))
+        ranges, squeeze = [], []
+        for k, n in zip(key, self.shape):
+            if isinstance(k, (int, np.integer)):
+                k = int(k)
+                if k < 0:
+                    k += n
+                if not 0 <= k < n:
+                    raise IndexError(f"index {k} out of range for axis of length {n}")
+                ranges.append((k, k + 1)); squeeze.append(True)
+            elif isinstance(k, slice):
+                start, stop, step = k.indices(n)
+                if step != 1:
+                    raise IndexError("only unit-step slices are supported")
+                ranges.append((start, max(stop, start))); squeeze.append(False)
+            else:
+                raise IndexError(f"unsupported index {k!r}")
+        return tuple(ranges), tuple(squeeze)
+
+    def _chunk_ranges(self, ranges):
+        """Iterate (chunk index, slices inside the chunk, slices inside the selection)."""
+        per_axis = []
+        for (lo, hi), c in zip(ranges, self.chunks):
+            items = []
+            if hi > lo:
+                for ci in range(lo // c, (hi - 1) // c + 1):
+                    a, b = max(lo, ci * c), min(hi, (ci + 1) * c)
+                    items.append((ci, slice(a - ci * c, b - ci * c), slice(a - lo, b - lo)))
+            per_axis.append(items)
+        idx = [0] * len(per_axis)
+        if any(len(p) == 0 for p in per_axis):
+            return
+        while True:
+            sel = [per_axis[d][idx[d]] for d in range(len(per_axis))]
+            yield tuple(s[0] for s in sel), tuple(s[1] for s in sel), tuple(s[2] for s in sel)
+            d = len(per_axis) - 1
+            while d >= 0:
+                idx[d] += 1
+                if idx[d] < len(per_axis[d]):
+                    break
+                idx[d] = 0
+                d -= 1
+            if d < 0:
+                return
+
+    def _read_chunk(self, cidx) -> Optional[np.ndarray]:
+        try:
+            with io.open(self._chunk_path(cidx), "rb") as fh:
+                raw = fh.read()
+        except FileNotFoundError:
+            return None
+        buf = _decode(raw, self._compressor)
+        return np.frombuffer(buf, dtype=self.dtype).reshape(self.chunks)
+
+    def __getitem__(self, key) -> np.ndarray:
+        ranges, squeeze = self._normalise(key)
+        out = np.empty(tuple(hi - lo for lo, hi in ranges), dtype=self.dtype)
+        for cidx, in_chunk, in_sel in self._chunk_ranges(ranges):
+            chunk = self._read_chunk(cidx)
+            out[in_sel] = self._fill if chunk is None else chunk[in_chunk]
+        return out.reshape(tuple(s for s, q in zip(out.shape, squeeze) if not q))
+
+    def __setitem__(self, key, value) -> None:
+        if self._read_only:
+            raise PermissionError("zarr container opened read-only")
+        ranges, squeeze = self._normalise(key)
+        sel_shape = tuple(hi - lo for lo, hi in ranges)
+        value = np.asarray(value, dtype=self.dtype)
+        kept = tuple(s for s, q in zip(sel_shape, squeeze) if not q)
+        value = np.broadcast_to(value.reshape(value.shape[-len(kept):] if value.ndim > len(kept) and
+                                              int(np.prod(value.shape)) == int(np.prod(kept)) else value.shape), kept)
+        value = value.reshape(sel_shape)
+        for cidx, in_chunk, in_sel in self._chunk_ranges(ranges):
+            part = value[in_sel]
+            if part.shape == self.chunks:
+                chunk = np.ascontiguousarray(part)
+            else:
+                chunk = self._read_chunk(cidx)
+                chunk = np.full(self.chunks, self._fill, dtype=self.dtype) if chunk is None else chunk.copy()
+                chunk[in_chunk] = part
+            path = self._chunk_path(cidx)
+            if self._sep == "/":
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+            _atomic_write(path, _encode(chunk.tobytes(), self._compressor))
+
+    def chunk_initialized(self, cidx: Sequence[int]) -> bool:
+        return os.path.exists(self._chunk_path(cidx))
+
+
+class Group:
+    def __init__(self, path: str, read_only: bool = False) -> None:
+        self._path = path
+        self._read_only = read_only
+        self.attrs = Attributes(os.path.join(path, ".zattrs"), read_only)
+
+    @property
+    def path(self) -> str:
+        return self._path
+
+    def _child(self, name: str) -> str:
+        return os.path.join(self._path, str(name))
+
+    def __contains__(self, name: object) -> bool:
+        p = self._child(str(name))
+        return os.path.exists(os.path.join(p, ".zarray")) or os.path.exists(os.path.join(p, ".zgroup"))
+
+    def __getitem__(self, name: str):
+        p = self._child(name)
+        if os.path.exists(os.path.join(p, ".zarray")):
+            return Array(p, self._read_only)
+        if os.path.exists(os.path.join(p, ".zgroup")):
+            return Group(p, self._read_only)
+        raise KeyError(name)
+
+    def keys(self):
+        return sorted(n for n in os.listdir(self._path) if n in self)
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self) -> int:
+        return len(self.keys())
+
+    def require_group(self, name: str) -> "Group":
+        p = self._child(name)
+        if os.path.exists(os.path.join(p, ".zarray")):
+            raise RuntimeError(f"{p} is an array, not a group")
+        if not os.path.exists(os.path.join(p, ".zgroup")):
+            if self._read_only:
+                raise PermissionError("zarr container opened read-only")
+            _init_group(p)
+        return Group(p, self._read_only)
+
+    def create_dataset(self, name: str, data: Optional[np.ndarray] = None, shape: Optional[Sequence[int]] = None,
+                       chunks: Optional[Sequence[int]] = None, dtype: Any = None, compressor: Optional[str] = None,
+                       fill_value: Any = 0) -> Array:
+        """``group.create_dataset`` (zarr 2) / ``create_array`` (zarr 3) as used at reference util.py:685-707."""
+        if self._read_only:
+            raise PermissionError("zarr container opened read-only")
+        if name in self:
+            raise RuntimeError(f"dataset {name} exists already in {self._path}")
+        if data is not None:
+            data = np.asarray(data)
+            shape = data.shape if shape is None else tuple(shape)
+            dtype = data.dtype if dtype is None else dtype
+        if shape is None or dtype is None:
+            raise ValueError("create_dataset needs data or shape + dtype")
+        shape = tuple(int(s) for s in shape)
+        chunks = shape if chunks is None else tuple(int(c) for c in chunks)
+        chunks = tuple(max(c, 1) for c in chunks)
+        dt = np.dtype(dtype)
+        p = self._child(name)
+        os.makedirs(p, exist_ok=True)
+        meta = {"zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": dt.str,
+                "compressor": None if compressor is None else {"id": compressor, "level": 1},
+                "fill_value": fill_value, "order": "C", "filters": None, "dimension_separator": "."}
+        _atomic_write(os.path.join(p, ".zarray"), json.dumps(meta, indent=4).encode())
+        arr = Array(p)
+        if data is not None:
+            arr[...] = data
+        return arr
+
+    create_array = create_dataset
+
+
+def _init_group(path: str) -> None:
+    os.makedirs(path, exist_ok=True)
+    _atomic_write(os.path.join(path, ".zgroup"), json.dumps({"zarr_format": 2}, indent=4).encode())
+
+
+def open(path, mode: str = "a") -> Group:   # noqa: A001 - mirrors zarr.open
+    """``zarr.open(path, mode)`` for a directory container holding a root group (modes "r", "a", "w")."""
+    path = os.fspath(path)
+    if mode not in ("r", "a", "w"):
+        raise ValueError(f"unsupported mode {mode!r}")
+    if os.path.exists(os.path.join(path, "zarr.json")):
+        raise RuntimeError(f"{path} is a zarr v3 container; micro_sam_amd.zarr_store reads and writes the v2 layout only")
+    exists = os.path.exists(os.path.join(path, ".zgroup"))
+    if mode == "r":
+        if not exists:
+            raise FileNotFoundError(f"{path} is not a zarr v2 group")
+        return Group(path, read_only=True)
+    if mode == "w" and os.path.isdir(path):
+        import shutil
+        shutil.rmtree(path)
+        exists = False
+    if not exists:
+        if os.path.isdir(path) and os.listdir(path):
+            raise RuntimeError(f"{path} exists and is not a zarr v2 group")
+        _init_group(path)
+    return Group(path)

@@ -318,6 +318,61 @@ def test_tiled_amg_vs_oracle(ctx):
     assert amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5).max() > 0
 
 
+def test_zarr_cache_gpu(ctx, tmp_path):
+    """``save_path`` round trips through the zarr v2 container (reference util.py:907-934, 937-947, 950-1018): the cached
+    embeddings are bit-identical to the computed ones, a second call does not run the encoder, a tiled AMG initialised from
+    the container produces the identical state, ``batched_inference(embedding_path=...)`` works."""
+    from micro_sam_amd import inference, util, zarr_store
+    from micro_sam_amd.instance_segmentation import TiledAutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_tile
+    p = ctx["predictor"]
+    image = synthetic_tile(6, (512, 512))
+    path = str(tmp_path / "emb2d.zarr")
+    e1 = util.precompute_image_embeddings(p, image, save_path=path, verbose=False)
+    direct = util.precompute_image_embeddings(p, image, verbose=False)
+    assert np.array_equal(e1["features"], direct["features"])
+    calls = []
+    enc = p.model.image_encoder
+    orig = enc.forward_u8
+    enc.forward_u8 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        p.reset_image()
+        e2 = util.precompute_image_embeddings(p, image, save_path=path, verbose=False)
+        assert not calls and np.array_equal(e2["features"], e1["features"]) and p.is_image_set
+        assert p.features.device.type == "cuda" and p.original_size == (512, 512)
+        with pytest.raises(RuntimeError, match="data_signature"):
+            util.precompute_image_embeddings(p, image[::-1].copy(), save_path=path, verbose=False)
+        # volume: container [Z,1,256,64,64], chunk = one slice; lazy loading
+        vol = np.stack([synthetic_tile(s, (256, 256)) for s in (1, 2, 3)])
+        vpath = str(tmp_path / "vol.zarr")
+        v1 = util.precompute_image_embeddings(p, vol, save_path=vpath, batch_size=2, verbose=False)
+        n = len(calls)
+        v2 = util.precompute_image_embeddings(p, vol, save_path=vpath, lazy_loading=True, verbose=False)
+        assert len(calls) == n and v2["features"].shape == (3, 1, 256, 64, 64) and v2["features"].chunks == (1, 1, 256, 64, 64)
+        assert np.array_equal(v2["features"][1], v1["features"][1])
+        # tiled: AMG state from the container == from the in-memory embeddings
+        big = synthetic_tile(5)[:600, :720]
+        tpath = str(tmp_path / "tiled.zarr")
+        mem = util.precompute_image_embeddings(p, big, save_path=tpath, tile_shape=(384, 384), halo=(64, 64), batch_size=3,
+                                               verbose=False)
+        n = len(calls)
+        disk = util.precompute_image_embeddings(p, big, save_path=tpath, tile_shape=(384, 384), halo=(64, 64), verbose=False)
+        assert len(calls) == n and isinstance(disk["features"], zarr_store.Group)
+    finally:
+        enc.forward_u8 = orig
+    a_mem, a_disk = TiledAutomaticMaskGenerator(p, points_per_side=4), TiledAutomaticMaskGenerator(p, points_per_side=4)
+    a_mem.initialize(big, mem)
+    a_disk.initialize(big, disk)
+    assert np.array_equal(a_mem.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5),
+                          a_disk.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5))
+    for d0, d1 in zip(a_mem.crop_list, a_disk.crop_list):
+        assert torch.equal(d0["bits"], d1["bits"]) and torch.equal(d0["iou_preds"], d1["iou_preds"])
+    boxes = np.array([[50, 60, 200, 220], [300, 100, 480, 300]], dtype=np.float32)
+    seg_a = inference.batched_inference(p, image, 2, boxes=boxes, embedding_path=path, verbose_embeddings=False)
+    seg_b = inference.batched_inference(p, image, 2, boxes=boxes, verbose_embeddings=False)
+    assert np.array_equal(seg_a, seg_b)
+
+
 def test_amg_crop_layers(ctx):
     """crop_n_layers = 1 (reference instance_segmentation.py:403-461): 1 + 4 crops, embeddings computed per crop."""
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
