@@ -164,13 +164,17 @@ int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, voi
 int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
 
 /* ViT attention with decomposed relative position bias (segment_anything ImageEncoderViT Attention).
- * q,k,v: bf16 [B,heads,4096,64];
- * rel_h/rel_w: bf16 [2S-1,64]; qkv_bias: fp32 [3*D] (padding tokens of windowed blocks carry bias-only q/k/v);
- * out: bf16 [B*4096, heads*64] token-major. */
+ * head_dim = STORED channels per head, 64 or 96 (vit_h: true head_dim 80, zero-padded to 96 by the caller);
+ * scale = (true head_dim)^-0.5.
+ * q,k,v: bf16 [B,heads,4096,head_dim];
+ * rel_h/rel_w: bf16 [2S-1,head_dim]; qkv_bias: fp32 [3*heads*head_dim] (padding tokens of windowed blocks carry
+ * bias-only q/k/v);
+ * out: bf16 [B*4096, heads*head_dim] token-major. */
 int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
-                          const float* qkv_bias, int32_t B, int32_t heads, void* out, void* stream);
+                          const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale, void* out,
+                          void* stream);
 int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
-                          int32_t B, int32_t heads, void* out, void* stream);
+                          int32_t B, int32_t heads, int32_t head_dim, float scale, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Image encoder:  predictor.model.image_encoder(x)   (micro_sam/util.py:674)
@@ -192,6 +196,10 @@ typedef struct {
     const void* neck2_w;                           /* bf16 [256, 9*256], (ky,kx,c) column order */
     const float* neck3_w; const float* neck3_b;
     int32_t use_glds;
+    /* stored channels per head: 0 or embed_dim / heads when that is 64 (vit_b / vit_l); 96 for vit_h, whose 80-channel
+     * heads are zero-padded by the caller: qkv_w bf16 [3*heads*96, D] / qkv_b fp32 [3*heads*96] (zero rows), rel_h / rel_w
+     * bf16 [2S-1, 96] (zero columns), proj_w bf16 [D, heads*96] (zero columns). */
+    int32_t head_dim_stored;
 } msam_encoder_t;
 
 int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B);

@@ -63,7 +63,7 @@ class EncoderParams(C.Structure):
         ("proj_w", _blk), ("proj_b", _blk), ("ln2_w", _blk), ("ln2_b", _blk),
         ("lin1_w", _blk), ("lin1_b", _blk), ("lin2_w", _blk), ("lin2_b", _blk),
         ("neck0_w", _vp), ("neck1_w", _vp), ("neck1_b", _vp), ("neck2_w", _vp), ("neck3_w", _vp), ("neck3_b", _vp),
-        ("use_glds", _i32),
+        ("use_glds", _i32), ("head_dim_stored", _i32),
     ]
 
 
@@ -117,8 +117,8 @@ _PROTOS = {
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
-    "msam_window_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
-    "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "msam_window_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
+    "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),
     "msam_encoder_forward": (_i32, [C.POINTER(EncoderParams), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]),
     "msam_decoder_const_bytes": (_i64, []),

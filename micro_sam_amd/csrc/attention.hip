@@ -1,4 +1,8 @@
-// ViT attention with decomposed relative-position bias for the SAM image encoder (head_dim 64).
+// ViT attention with decomposed relative-position bias for the SAM image encoder.
+// Kernels are templated on the STORED head dimension HD in {64, 96}: vit_b / vit_l have head_dim 64; vit_h (head_dim 80)
+// runs with its heads zero-padded to 96 channels (= 3 MFMA k-steps of 32) by the host side - padded q / k channels
+// contribute 0 to every score, padded v channels produce 0 outputs that meet zero columns of the padded proj weight -
+// and the softmax scale of the TRUE head_dim is passed at run time.
 //
 // Both kernels compute the TRANSPOSED score tile S^T = K * Q^T with v_mfma_f32_16x16x32_bf16, so that in the
 // C layout (row = key = (l>>4)*4 + r, col = query = l & 15) every softmax statistic is a per-lane-column
@@ -21,7 +25,6 @@ int msam_check_launch(const char* what);
 
 namespace {
 
-constexpr int HD = 64;
 constexpr int TOK = 4096;
 constexpr float NEG_BIG = -1.0e30f;
 
@@ -36,11 +39,16 @@ constexpr int WS = 14, WN = 196, WKT = 13 /* key tiles */, WKP = 224 /* padded k
 constexpr int VT_RS = 232;    // V^T row stride in bf16 (464 B = 116 dwords = 4 * odd -> conflict-free b64 reads)
 constexpr int T_RS = 65;      // rel-pos table row stride (floats)
 
+template <int HD>
 __global__ __launch_bounds__(256) void window_attention_kernel(
     const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
-    const u16* __restrict__ relw, const float* __restrict__ qkv_bias, int heads, u16* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint4 k_lds[WKT * 16 * 8];            // 26 KB
-    __shared__ __attribute__((aligned(16))) u16 vt_lds[HD * VT_RS];               // 29 KB
+    const u16* __restrict__ relw, const float* __restrict__ qkv_bias, int heads, float scale, u16* __restrict__ out) {
+    constexpr int KS = HD / 32;                 // MFMA k-steps of the q.k contraction
+    constexpr int DT = HD / 16;                 // 16-channel output tiles
+    constexpr int CH = HD / 8;                  // 16-byte chunks per K / V row
+    constexpr int CHP = HD == 64 ? 8 : 16;      // chunk pitch of a k_lds row (the XOR swizzle needs a power of two)
+    __shared__ __attribute__((aligned(16))) uint4 k_lds[WKT * 16 * CHP];          // 26 KB (HD 64) / 52 KB (HD 96)
+    __shared__ __attribute__((aligned(16))) u16 vt_lds[HD * VT_RS];               // 29 KB / 43.5 KB
     __shared__ __attribute__((aligned(16))) float t_lds[4][16 * T_RS];            // 16.3 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,17 +65,17 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     const float* bv = qkv_bias + 2 * D + head * HD;
 
     // ---- stage K (row-major, swizzled chunks) and V^T
-    for (int c = tid; c < WKT * 16 * 8; c += 256) {
-        const int row = c >> 3, ch = c & 7;
+    for (int c = tid; c < WKT * 16 * CH; c += 256) {
+        const int row = c / CH, ch = c - row * CH;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (row < WN) {
             const int y = wy * WS + row / WS, x = wx * WS + row % WS;
             if (y < 64 && x < 64) val = *(const uint4*)(Kb + (long)(y * 64 + x) * HD + ch * 8);
             else val = bias_chunk_bf16(bk + ch * 8);
         }
-        k_lds[row * 8 + (ch ^ swz(row))] = val;
+        k_lds[row * CHP + (ch ^ swz(row))] = val;
     }
-    for (int c = tid; c < WKP * 8; c += 256) {
+    for (int c = tid; c < WKP * CH; c += 256) {
         const int key = c % WKP, ch = c / WKP;
         uint4 val = make_uint4(0, 0, 0, 0);
         if (key < WN) {
@@ -84,7 +92,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     }
 
     // ---- rel-pos rows as MFMA A operand: tile jt rows j = jt*16 + fr; j < 27 -> rel_h[j], 32 <= j < 59 -> rel_w[j-32]
-    uint4 ra[4][2];
+    uint4 ra[4][KS];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt) {
         const int j = jt * 16 + fr;
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         if (j < 27) src = relh + j * HD;
         else if (j >= 32 && j < 59) src = relw + (j - 32) * HD;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
             ra[jt][ks] = src ? *(const uint4*)(src + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
     }
     __syncthreads();
@@ -104,9 +112,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         const int qh = (qi < WN ? qi : WN - 1) / WS, qw = (qi < WN ? qi : WN - 1) % WS;
         const int qy = wy * WS + qh, qx = wx * WS + qw;
         const bool q_real = qi < WN && qy < 64 && qx < 64;
-        uint4 qf[2];
+        uint4 qf[KS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             if (q_real) qf[ks] = *(const uint4*)(Qb + (long)(qy * 64 + qx) * HD + ks * 32 + fg * 8);
             else if (qi < WN) qf[ks] = bias_chunk_bf16(bq + ks * 32 + fg * 8);
             else qf[ks] = make_uint4(0, 0, 0, 0);
@@ -115,8 +123,8 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
             f32x4_t t = {0.f, 0.f, 0.f, 0.f};
-            t = mfma16(ra[jt][0], qf[0], t);
-            t = mfma16(ra[jt][1], qf[1], t);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) t = mfma16(ra[jt][ks], qf[ks], t);
 #pragma unroll
             for (int r = 0; r < 4; ++r) tl[fr * T_RS + jt * 16 + fg * 4 + r] = t[r];
         }
@@ -126,8 +134,8 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         for (int kt = 0; kt < WKT; ++kt) {
             const int row = kt * 16 + fr;
             f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(k_lds[row * 8 + ((0 + fg) ^ swz(row))], qf[0], a);
-            a = mfma16(k_lds[row * 8 + ((4 + fg) ^ swz(row))], qf[1], a);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) a = mfma16(k_lds[row * CHP + ((ks * 4 + fg) ^ swz(row))], qf[ks], a);
             s[kt] = a;
         }
         __builtin_amdgcn_wave_barrier();
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
                 float v = NEG_BIG;
                 if (key < WN) {
                     const int kh = key / WS, kw = key - kh * WS;
-                    v = s[kt][r] * 0.125f + tl[fr * T_RS + (qh - kh + 13)] + tl[fr * T_RS + 32 + (qw - kw + 13)];
+                    v = s[kt][r] * scale + tl[fr * T_RS + (qh - kh + 13)] + tl[fr * T_RS + 32 + (qw - kw + 13)];
                 }
                 s[kt][r] = v;
                 m = fmaxf(m, v);
@@ -155,9 +163,9 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
             for (int r = 0; r < 4; ++r) { float p = __expf(s[kt][r] - m); s[kt][r] = p; l += p; }
         l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
         // O^T = V^T P^T
-        f32x4_t o[4];
+        f32x4_t o[DT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int t0 = 2 * u, t1 = 2 * u + 1;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
             if (t1 < WKT) { pb.z = pack2bf(s[t1][0], s[t1][1]); pb.w = pack2bf(s[t1][2], s[t1][3]); }
             else { pb.z = 0; pb.w = 0; }
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 const u16* vr = vt_lds + (dt * 16 + fr) * VT_RS + fg * 4;
                 uint2 lo = *(const uint2*)(vr + t0 * 16), hi = *(const uint2*)(vr + t1 * 16);
                 o[dt] = mfma16(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[dt]);
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
             const float inv = 1.0f / l;
             u16* dst = out + ((long)b * TOK + qy * 64 + qx) * D + head * HD + fg * 4;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 uint2 pk; pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv); pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
                 *(uint2*)(dst + dt * 16) = pk;
             }
@@ -203,11 +211,15 @@ MSAM_DEVINL uint2 g_tr16(const unsigned char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
-__global__ __launch_bounds__(256, 3) void global_attention_kernel(
+template <int HD>
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel(
     const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
-    const u16* __restrict__ relw, int heads, u16* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) uint4 k_lds[2][GKT * 8];                   // 8 KB
-    __shared__ __attribute__((aligned(16))) unsigned char v_lds[2][GKT * 128];         // 8 KB, [key][64 d] bf16
+    const u16* __restrict__ relw, int heads, float scale, u16* __restrict__ out) {
+    constexpr int KS = HD / 32, DT = HD / 16;
+    constexpr int CHP = HD == 64 ? 8 : 16;      // chunk pitch of a k_lds row
+    constexpr int VROW = HD == 64 ? 128 : 256;  // bytes per key of the V tile (32-byte d-tile slots, XOR-swizzled)
+    __shared__ __attribute__((aligned(16))) uint4 k_lds[2][GKT * CHP];                 // 8 KB (HD 64) / 16 KB
+    __shared__ __attribute__((aligned(16))) unsigned char v_lds[2][GKT * VROW];        // 8 KB / 16 KB, [key][HD d] bf16
     __shared__ __attribute__((aligned(16))) float rh_lds[GQ * GB_RS];                  // 34 KB  rel_h[q][kh] (rel_w scratch first)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,11 +233,11 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
 
     const int qh = qpair * 2 + (wave >> 1);              // image row of this wave's 32 queries
     const int qw0 = (wave & 1) * 32;                     // first column
-    uint4 qf[2][2];
+    uint4 qf[2][KS];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
             qf[j][ks] = *(const uint4*)(Qb + (long)(qh * 64 + qw0 + j * 16 + fr) * HD + ks * 32 + fg * 8);
 
     // ---- rel_w[q][kw] = q . rel_pos_w[qw - kw + 63]: T[j'][q] for all 127 rows j', scattered to kw = qw - j' + 63 of this
@@ -237,11 +249,12 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
             const int jr = jt * 16 + fr;
-            uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-            if (jr < 127) { a0 = *(const uint4*)(relw + jr * HD + fg * 8); a1 = *(const uint4*)(relw + jr * HD + 32 + fg * 8); }
             f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-            c = mfma16(a0, qf[j][0], c);
-            c = mfma16(a1, qf[j][1], c);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const uint4 a = jr < 127 ? *(const uint4*)(relw + jr * HD + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
+                c = mfma16(a, qf[j][ks], c);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kw = qw - (jt * 16 + fg * 4 + r) + 63;
@@ -266,22 +279,33 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
             const int kh = t * 16 + fr;
             const u16* src = relh + (qh - kh + 63) * HD;
             f32x4_t c = {0.f, 0.f, 0.f, 0.f};
-            c = mfma16(*(const uint4*)(src + fg * 8), qf[j][0], c);
-            c = mfma16(*(const uint4*)(src + 32 + fg * 8), qf[j][1], c);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) c = mfma16(*(const uint4*)(src + ks * 32 + fg * 8), qf[j][ks], c);
             *(float4*)(scr + (j * 16 + fr) * GB_RS + t * 16 + fg * 4) = make_float4(c[0], c[1], c[2], c[3]);
         }
 
-    // ---- K / V tile staging (register prefetch, double-buffered LDS); both tiles row-major [32 keys][128 B]
+    // ---- K / V tile staging (register prefetch, double-buffered LDS); both tiles row-major [32 keys][HD]
+    // chunks 0..7 of a row: one per thread; HD 96 has chunks 8..11 as well (second load, threads pair up on rows 0..31)
     const int s_row = tid >> 3, s_ch = tid & 7;
-    uint4 rk, rv;
+    const int s_row2 = (tid >> 2) & 31, s_ch2 = 8 + (tid & 3);
+    uint4 rk, rv, rk2, rv2;
     rk = *(const uint4*)(Kb + (long)s_row * HD + s_ch * 8);
     rv = *(const uint4*)(Vb + (long)s_row * HD + s_ch * 8);
+    if constexpr (HD > 64) {
+        rk2 = *(const uint4*)(Kb + (long)s_row2 * HD + s_ch2 * 8);
+        rv2 = *(const uint4*)(Vb + (long)s_row2 * HD + s_ch2 * 8);
+    }
     // V image: 32-byte d-tile slot' = slot ^ ((key >> 1) & 3) so that the 4 keys of a transposing read hit distinct banks
-    const int v_dst = s_row * 128 + ((((s_ch >> 1) ^ ((s_row >> 1) & 3)) << 5) | ((s_ch & 1) << 4));
+    const int v_dst = s_row * VROW + ((((s_ch >> 1) ^ ((s_row >> 1) & 3)) << 5) | ((s_ch & 1) << 4));
+    const int v_dst2 = s_row2 * VROW + ((((s_ch2 >> 1) ^ ((s_row2 >> 1) & 3)) << 5) | ((s_ch2 & 1) << 4));
 #define G_COMMIT(buf_)                                                                   \
     do {                                                                                 \
-        k_lds[buf_][s_row * 8 + (s_ch ^ swz(s_row))] = rk;                               \
+        k_lds[buf_][s_row * CHP + (s_ch ^ swz(s_row))] = rk;                             \
         *(uint4*)(v_lds[buf_] + v_dst) = rv;                                             \
+        if constexpr (HD > 64) {                                                         \
+            k_lds[buf_][s_row2 * CHP + (s_ch2 ^ swz(s_row2))] = rk2;                     \
+            *(uint4*)(v_lds[buf_] + v_dst2) = rv2;                                       \
+        }                                                                                \
     } while (0)
     G_COMMIT(0);
     __syncthreads();
@@ -291,15 +315,15 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
 #pragma unroll
     for (int bk = 0; bk < 2; ++bk) {
         const int key = bk * 16 + fg * 4 + (fr >> 2);
-        troff[bk] = key * 128 + (fr & 3) * 8;            // + ((dt ^ ((key >> 1) & 3)) << 5) per d-tile
+        troff[bk] = key * VROW + (fr & 3) * 8;           // + ((dt ^ ((key >> 1) & 3)) << 5) per d-tile
     }
     const int vsw = (fg * 2 + (fr >> 3)) & 3;            // (key >> 1) & 3 for both blocks (16 >> 1 = 8 = 0 mod 4)
 
-    f32x4_t o[2][4];
+    f32x4_t o[2][DT];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
     const int NT = TOK / GKT;   // 128
     for (int kt = 0; kt < NT; ++kt) {
@@ -308,18 +332,22 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
             const int nx = min(kt + 1, NT - 1);
             rk = *(const uint4*)(Kb + (long)(nx * GKT + s_row) * HD + s_ch * 8);
             rv = *(const uint4*)(Vb + (long)(nx * GKT + s_row) * HD + s_ch * 8);
+            if constexpr (HD > 64) {
+                rk2 = *(const uint4*)(Kb + (long)(nx * GKT + s_row2) * HD + s_ch2 * 8);
+                rv2 = *(const uint4*)(Vb + (long)(nx * GKT + s_row2) * HD + s_ch2 * 8);
+            }
         }
         const int kh = kt >> 1, ph = kt & 1;
-        uint4 ka[2][2];
+        uint4 ka[2][KS];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int row = t * 16 + fr;
-            ka[t][0] = k_lds[buf][row * 8 + ((0 + fg) ^ swz(row))];
-            ka[t][1] = k_lds[buf][row * 8 + ((4 + fg) ^ swz(row))];
-        }
-        uint4 va[4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+            for (int ks = 0; ks < KS; ++ks) ka[t][ks] = k_lds[buf][row * CHP + ((ks * 4 + fg) ^ swz(row))];
+        }
+        uint4 va[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
             const uint2 lo = g_tr16(v_lds[buf] + troff[0] + ((dt ^ vsw) << 5));
             const uint2 hi = g_tr16(v_lds[buf] + troff[1] + ((dt ^ vsw) << 5));
             va[dt] = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -330,8 +358,8 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-                a = mfma16(ka[t][0], qf[j][0], a);
-                a = mfma16(ka[t][1], qf[j][1], a);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a = mfma16(ka[t][ks], qf[j][ks], a);
                 s[t] = a;
             }
             const float rh = scr[(j * 16 + fr) * GB_RS + kh];
@@ -339,8 +367,8 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float4 bwv = ph ? bw[j][1][t] : bw[j][0][t];
-                s[t][0] = s[t][0] * 0.125f + rh + bwv.x; s[t][1] = s[t][1] * 0.125f + rh + bwv.y;
-                s[t][2] = s[t][2] * 0.125f + rh + bwv.z; s[t][3] = s[t][3] * 0.125f + rh + bwv.w;
+                s[t][0] = s[t][0] * scale + rh + bwv.x; s[t][1] = s[t][1] * scale + rh + bwv.y;
+                s[t][2] = s[t][2] * scale + rh + bwv.z; s[t][3] = s[t][3] * scale + rh + bwv.w;
                 mt = fmaxf(mt, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
             }
             mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
             pb.x = pack2bf(s[0][0], s[0][1]); pb.y = pack2bf(s[0][2], s[0][3]);
             pb.z = pack2bf(s[1][0], s[1][1]); pb.w = pack2bf(s[1][2], s[1][3]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < DT; ++dt) {
                 o[j][dt][0] *= alpha; o[j][dt][1] *= alpha; o[j][dt][2] *= alpha; o[j][dt][3] *= alpha;
                 o[j][dt] = mfma16(va[dt], pb, o[j][dt]);
             }
@@ -373,7 +401,7 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
         const float inv = 1.0f / lj;
         u16* dst = out + ((long)b * TOK + qh * 64 + qw0 + j * 16 + fr) * D + head * HD + fg * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
+        for (int dt = 0; dt < DT; ++dt) {
             uint2 pk; pk.x = pack2bf(o[j][dt][0] * inv, o[j][dt][1] * inv); pk.y = pack2bf(o[j][dt][2] * inv, o[j][dt][3] * inv);
             *(uint2*)(dst + dt * 16) = pk;
         }
@@ -383,23 +411,44 @@ __global__ __launch_bounds__(256, 3) void global_attention_kernel(
 }  // namespace
 
 extern "C" int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
-                                     const float* qkv_bias, int32_t B, int32_t heads, void* out, void* stream) {
+                                     const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale, void* out,
+                                     void* stream) {
     if (!q || !k || !v || !rel_h || !rel_w || !qkv_bias || !out || B <= 0 || heads <= 0) {
         msam_set_error("msam_window_attention: bad arguments");
         return 1;
     }
-    hipLaunchKernelGGL(window_attention_kernel, dim3(B * 25 * heads), dim3(256), 0, (hipStream_t)stream, (const u16*)q,
-                       (const u16*)k, (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, (u16*)out);
+    if (head_dim != 64 && head_dim != 96) {
+        msam_set_error("msam_window_attention: stored head_dim must be 64 or 96 (vit_h: 80 zero-padded to 96)");
+        return 1;
+    }
+    const dim3 grid(B * 25 * heads), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64)
+        hipLaunchKernelGGL(window_attention_kernel<64>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
+                           (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, scale, (u16*)out);
+    else
+        hipLaunchKernelGGL(window_attention_kernel<96>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
+                           (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, scale, (u16*)out);
     return msam_check_launch("msam_window_attention");
 }
 
 extern "C" int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
-                                     int32_t B, int32_t heads, void* out, void* stream) {
+                                     int32_t B, int32_t heads, int32_t head_dim, float scale, void* out, void* stream) {
     if (!q || !k || !v || !rel_h || !rel_w || !out || B <= 0 || heads <= 0) {
         msam_set_error("msam_global_attention: bad arguments");
         return 1;
     }
-    hipLaunchKernelGGL(global_attention_kernel, dim3(B * heads * 32), dim3(256), 0, (hipStream_t)stream, (const u16*)q,
-                       (const u16*)k, (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, heads, (u16*)out);
+    if (head_dim != 64 && head_dim != 96) {
+        msam_set_error("msam_global_attention: stored head_dim must be 64 or 96 (vit_h: 80 zero-padded to 96)");
+        return 1;
+    }
+    const dim3 grid(B * heads * 32), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64)
+        hipLaunchKernelGGL(global_attention_kernel<64>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
+                           (const u16*)rel_h, (const u16*)rel_w, heads, scale, (u16*)out);
+    else
+        hipLaunchKernelGGL(global_attention_kernel<96>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
+                           (const u16*)rel_h, (const u16*)rel_w, heads, scale, (u16*)out);
     return msam_check_launch("msam_global_attention");
 }

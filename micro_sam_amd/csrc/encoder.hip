@@ -15,27 +15,39 @@ namespace {
 constexpr long TOK = 4096;
 inline long al(long x) { return (x + 255) & ~255L; }
 struct EncWork { float* x; u16 *xn, *patches, *q, *k, *v, *attn, *hid, *n1, *col; float *n0, *n2; };
-long enc_bytes(int D, int B) {
+// DA = heads * stored head_dim: width of q / k / v / attention output (== D unless the heads are zero-padded, vit_h)
+long enc_bytes(int D, int DA, int B) {
     const long R = (long)B * TOK;
-    return al(R * D * 4) + al(R * D * 2) + al(R * 768 * 2) + 3 * al(R * D * 2) + al(R * D * 2) + al(R * 4 * D * 2) +
+    return al(R * D * 4) + al(R * D * 2) + al(R * 768 * 2) + 3 * al(R * DA * 2) + al(R * DA * 2) + al(R * 4 * D * 2) +
            al(R * 256 * 2) + al(R * 2304 * 2) + 2 * al(R * 256 * 4);
 }
-EncWork carve(void* base, int D, int B) {
+EncWork carve(void* base, int D, int DA, int B) {
     const long R = (long)B * TOK;
     char* p = (char*)base; EncWork w;
     auto take = [&](long b) { char* r = p; p += al(b); return r; };
     w.x = (float*)take(R * D * 4); w.xn = (u16*)take(R * D * 2); w.patches = (u16*)take(R * 768 * 2);
-    w.q = (u16*)take(R * D * 2); w.k = (u16*)take(R * D * 2); w.v = (u16*)take(R * D * 2);
-    w.attn = (u16*)take(R * D * 2); w.hid = (u16*)take(R * 4 * D * 2);
+    w.q = (u16*)take(R * DA * 2); w.k = (u16*)take(R * DA * 2); w.v = (u16*)take(R * DA * 2);
+    w.attn = (u16*)take(R * DA * 2); w.hid = (u16*)take(R * 4 * D * 2);
     w.n1 = (u16*)take(R * 256 * 2); w.col = (u16*)take(R * 2304 * 2);
     w.n0 = (float*)take(R * 256 * 4); w.n2 = (float*)take(R * 256 * 4);
     return w;
+}
+// stored head_dim: 64 as is (vit_b / vit_l); 80 (vit_h) must come zero-padded to 96; 0 = unsupported
+int stored_head_dim(const msam_encoder_t* enc) {
+    if (enc->heads <= 0 || enc->embed_dim % enc->heads) return 0;
+    const int hd = enc->embed_dim / enc->heads;
+    const int st = enc->head_dim_stored ? enc->head_dim_stored : hd;
+    if (hd == 64 && st == 64) return 64;
+    if (hd == 80 && st == 96) return 96;
+    return 0;
 }
 }  // namespace
 
 extern "C" int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B) {
     if (!enc || B <= 0) return 0;
-    return enc_bytes(enc->embed_dim, B);
+    const int hs = stored_head_dim(enc);
+    if (!hs) return 0;
+    return enc_bytes(enc->embed_dim, enc->heads * hs, B);
 }
 
 extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_f32, const uint8_t* img_u8, int32_t h,
@@ -43,13 +55,17 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
                                     int32_t tap_block, void* stream) {
     if (!enc || !out || !workspace || B <= 0 || (!img_f32 && !img_u8)) { msam_set_error("msam_encoder_forward: null argument"); return 1; }
     const int D = enc->embed_dim, H = enc->heads;
-    if (D % 128 || H <= 0 || D / H != 64 || enc->depth > MSAM_MAX_BLOCKS) {
-        msam_set_error("msam_encoder_forward: unsupported geometry (need embed_dim % 128 == 0 and head_dim == 64: vit_b / vit_l)");
+    const int HS = stored_head_dim(enc);
+    if (D % 128 || !HS || enc->depth > MSAM_MAX_BLOCKS) {
+        msam_set_error("msam_encoder_forward: unsupported geometry (need embed_dim % 128 == 0 and head_dim 64, or head_dim 80 "
+                       "with head_dim_stored = 96 and zero-padded qkv / rel_pos / proj weights: vit_b / vit_l / vit_h)");
         return 1;
     }
-    if (workspace_bytes < enc_bytes(D, B)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
+    const int DA = H * HS;
+    const float scale = 1.0f / sqrtf((float)(D / H));
+    if (workspace_bytes < enc_bytes(D, DA, B)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    EncWork w = carve(workspace, D, B);
+    EncWork w = carve(workspace, D, DA, B);
     const int R = (int)(B * TOK);
     int e;
 #define CHECK(x) do { if ((e = (x))) return e; } while (0)
@@ -71,14 +87,16 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
         CHECK(msam_layernorm(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
         {
             msam_gemm_t g{};
-            g.A = w.xn; g.lda = D; g.W = enc->qkv_w[i]; g.ldw = D; g.M = R; g.N = 3 * D; g.K = D; g.bias = enc->qkv_b[i];
-            g.out_mode = 1; g.q = w.q; g.k = w.k; g.v = w.v; g.heads = H; g.head_dim = 64; g.tokens = (int)TOK;
+            g.A = w.xn; g.lda = D; g.W = enc->qkv_w[i]; g.ldw = D; g.M = R; g.N = 3 * DA; g.K = D; g.bias = enc->qkv_b[i];
+            g.out_mode = 1; g.q = w.q; g.k = w.k; g.v = w.v; g.heads = H; g.head_dim = HS; g.tokens = (int)TOK;
             g.use_glds = enc->use_glds;
             CHECK(msam_gemm_bf16(&g, s));
         }
-        if (enc->is_global[i]) CHECK(msam_global_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], B, H, w.attn, s));
-        else CHECK(msam_window_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], enc->qkv_b[i], B, H, w.attn, s));
-        CHECK(gemm(w.attn, D, enc->proj_w[i], D, D, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0, 0, 0));
+        if (enc->is_global[i])
+            CHECK(msam_global_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], B, H, HS, scale, w.attn, s));
+        else
+            CHECK(msam_window_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], enc->qkv_b[i], B, H, HS, scale, w.attn, s));
+        CHECK(gemm(w.attn, DA, enc->proj_w[i], D, DA, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0, 0, 0));
         CHECK(msam_layernorm(w.x, enc->ln2_w[i], enc->ln2_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
         CHECK(gemm(w.xn, D, enc->lin1_w[i], 4 * D, D, enc->lin1_b[i], w.hid, MSAM_BF16, 4 * D, MSAM_ACT_GELU, nullptr, 0, 0,
                    nullptr, 0, 0, 0));

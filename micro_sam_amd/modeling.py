@@ -127,6 +127,26 @@ class ImageEncoderViT(nn.Module):
 
         p = _lib.EncoderParams()
         p.embed_dim, p.depth, p.heads = D, self.depth, self.num_heads
+        # stored head_dim: the attention kernels contract over multiples of 32 channels; vit_h's 80-channel heads are
+        # zero-padded to 96 (exact: padded q / k channels add 0 to every score, padded v channels give 0 outputs that meet
+        # zero columns of the padded proj weight)
+        H, hd = self.num_heads, D // self.num_heads
+        if hd not in (64, 80):
+            raise NotImplementedError(f"micro_sam_amd: head_dim {hd} is not supported (64: vit_b / vit_l, 80: vit_h)")
+        hs = 64 if hd == 64 else 96
+        p.head_dim_stored = hs
+
+        def pad_rows(t):            # [3*H*hd, ...] -> [3*H*hs, ...]
+            if hs == hd:
+                return t
+            t = t.detach().reshape(3, H, hd, -1)
+            return F.pad(t, (0, 0, 0, hs - hd)).reshape(3 * H * hs, *([t.shape[-1]] if t.shape[-1] > 1 else []))
+
+        def pad_cols(t, groups):    # [..., groups*hd] -> [..., groups*hs]
+            if hs == hd:
+                return t
+            t = t.detach().reshape(t.shape[0], groups, hd)
+            return F.pad(t, (0, hs - hd)).reshape(t.shape[0], groups * hs)
         p.patch_w = k(_bf16(self.patch_embed.proj.weight.reshape(D, 3 * PATCH * PATCH)))
         p.patch_b = k(_f32(self.patch_embed.proj.bias))
         p.pos_embed = k(_f32(self.pos_embed.reshape(GRID * GRID, D)))
@@ -134,10 +154,11 @@ class ImageEncoderViT(nn.Module):
             size = GRID if blk.window_size == 0 else blk.window_size
             p.is_global[i] = 1 if blk.window_size == 0 else 0
             p.ln1_w[i], p.ln1_b[i] = k(_f32(blk.norm1.weight)), k(_f32(blk.norm1.bias))
-            p.qkv_w[i], p.qkv_b[i] = k(_bf16(blk.attn.qkv.weight)), k(_f32(blk.attn.qkv.bias))
-            p.rel_h[i] = k(_bf16(_resize_rel_pos(blk.attn.rel_pos_h, size)))
-            p.rel_w[i] = k(_bf16(_resize_rel_pos(blk.attn.rel_pos_w, size)))
-            p.proj_w[i], p.proj_b[i] = k(_bf16(blk.attn.proj.weight)), k(_f32(blk.attn.proj.bias))
+            p.qkv_w[i] = k(_bf16(pad_rows(blk.attn.qkv.weight)))
+            p.qkv_b[i] = k(_f32(pad_rows(blk.attn.qkv.bias.reshape(-1, 1)).reshape(-1)))
+            p.rel_h[i] = k(_bf16(pad_cols(_resize_rel_pos(blk.attn.rel_pos_h, size), 1)))
+            p.rel_w[i] = k(_bf16(pad_cols(_resize_rel_pos(blk.attn.rel_pos_w, size), 1)))
+            p.proj_w[i], p.proj_b[i] = k(_bf16(pad_cols(blk.attn.proj.weight, H))), k(_f32(blk.attn.proj.bias))
             p.ln2_w[i], p.ln2_b[i] = k(_f32(blk.norm2.weight)), k(_f32(blk.norm2.bias))
             p.lin1_w[i], p.lin1_b[i] = k(_bf16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
             p.lin2_w[i], p.lin2_b[i] = k(_bf16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
@@ -157,8 +178,6 @@ class ImageEncoderViT(nn.Module):
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, tap_block: Optional[int] = None):
-        if self.embed_dim // self.num_heads != 64:
-            raise NotImplementedError("micro_sam_amd: the HIP encoder supports head_dim 64 (vit_b, vit_l) this round")
         assert x.dim() == 4 and x.shape[1:] == (3, IMG_SIZE, IMG_SIZE), x.shape
         params, _ = self._prepare()
         x = x.to(device=self.pos_embed.device, dtype=torch.float32).contiguous()

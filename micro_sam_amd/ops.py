@@ -105,20 +105,24 @@ def im2col3x3(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def window_attention(q, k, v, rel_h, rel_w, qkv_bias) -> torch.Tensor:
-    B, heads = q.shape[:2]
-    out = torch.empty((B * 4096, heads * 64), dtype=torch.bfloat16, device=q.device)
+def window_attention(q, k, v, rel_h, rel_w, qkv_bias, scale: Optional[float] = None) -> torch.Tensor:
+    """q, k, v bf16 [B,heads,4096,hd] with hd (stored head_dim) 64 or 96; ``scale`` defaults to hd ** -0.5 (pass the true
+    head_dim's scale for zero-padded heads)."""
+    B, heads, _, hd = q.shape
+    out = torch.empty((B * 4096, heads * hd), dtype=torch.bfloat16, device=q.device)
     _lib.check(_lib.load().msam_window_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
-                                                 qkv_bias.data_ptr(), B, heads, out.data_ptr(), _lib.stream_ptr()),
+                                                 qkv_bias.data_ptr(), B, heads, hd, float(hd ** -0.5 if scale is None else scale),
+                                                 out.data_ptr(), _lib.stream_ptr()),
                "msam_window_attention")
     return out
 
 
-def global_attention(q, k, v, rel_h, rel_w) -> torch.Tensor:
-    B, heads = q.shape[:2]
-    out = torch.empty((B * 4096, heads * 64), dtype=torch.bfloat16, device=q.device)
+def global_attention(q, k, v, rel_h, rel_w, scale: Optional[float] = None) -> torch.Tensor:
+    B, heads, _, hd = q.shape
+    out = torch.empty((B * 4096, heads * hd), dtype=torch.bfloat16, device=q.device)
     _lib.check(_lib.load().msam_global_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
-                                                 B, heads, out.data_ptr(), _lib.stream_ptr()), "msam_global_attention")
+                                                 B, heads, hd, float(hd ** -0.5 if scale is None else scale), out.data_ptr(),
+                                                 _lib.stream_ptr()), "msam_global_attention")
     return out
 
 

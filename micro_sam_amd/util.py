@@ -676,7 +676,9 @@ def masks_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, keep: 
     if with_background:
         bg_size = bg32[0].to(torch.int64)
         best = torch.argmax(sizes)                          # first maximum = smallest root index = smallest component id
-        drop_component = sizes[best] > bg_size              # label 0 wins ties (it is the smallest id)
+        # NB: ``sizes[best]`` with a 0-dim index tensor is an ``item()`` call = a host synchronisation (measured: the host
+        # waited for the whole decode of the tile here); the value at the first maximum is the maximum
+        drop_component = sizes.max() > bg_size              # label 0 wins ties (it is the smallest id)
         keep_root = keep_root & ~((idx == best) & drop_component)
     new_id = torch.cumsum(keep_root.to(torch.int64), 0) * keep_root      # consecutive ids in raster order of the roots
     labels = torch.where(fg, new_id[safe_roots], torch.zeros_like(roots))

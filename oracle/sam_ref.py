@@ -209,8 +209,10 @@ def layer_norm_2d(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-6) -> Tensor:
 
 
 def image_encoder(sd: Dict[str, Tensor], x: Tensor, model_type: str = "vit_b", precision: str = "fp32",
-                  return_blocks: bool = False):
-    """ImageEncoderViT.forward: [B,3,1024,1024] normalised -> [B,256,64,64].  Keys prefixed 'image_encoder.'."""
+                  return_blocks: bool = False, stop_after_block: Optional[int] = None):
+    """ImageEncoderViT.forward: [B,3,1024,1024] normalised -> [B,256,64,64].  Keys prefixed 'image_encoder.'.
+    ``stop_after_block`` (test hook, needs ``return_blocks``): return (None, residual streams of blocks 0..stop) without
+    running the rest of the network (the vit_h test checks the first blocks only: CPU time)."""
     cfg = VIT_CONFIGS[model_type[:5]]
     p = Prec(precision)
     pre = "image_encoder."
@@ -239,6 +241,8 @@ def image_encoder(sd: Dict[str, Tensor], x: Tensor, model_type: str = "vit_b", p
         x = x + y
         if return_blocks:
             taps.append(x.clone())
+            if stop_after_block is not None and i == stop_after_block:
+                return None, taps
     x = x.permute(0, 3, 1, 2)                                  # NCHW
     x = F.conv2d(p.r(x), p.r(sd[pre + "neck.0.weight"]))
     x = layer_norm_2d(x, sd[pre + "neck.1.weight"], sd[pre + "neck.1.bias"])

@@ -187,6 +187,45 @@ def test_vit_attention_vs_oracle(env, window):
     assert _close(out, ref.reshape(-1, D), 2e-2, 2e-2)
 
 
+@pytest.mark.parametrize("window", [True, False])
+def test_vit_attention_head_dim_80(env, window):
+    """vit_h geometry: 80-channel heads stored zero-padded to 96 channels (qkv rows / rel-pos columns), softmax scale of
+    the true head_dim; the padded output channels are exactly zero and the rest matches the oracle's 80-channel attention."""
+    import torch.nn.functional as F
+    ops, dev = env
+    from oracle import sam_ref as S
+    g = torch.Generator().manual_seed(16)
+    B, heads, hd, hs = 1, 4, 80, 96
+    D = heads * hd
+    Sz = 14 if window else 64
+    x = _bf(torch.randn(B, 64, 64, D, generator=g)).to(dev)
+    qkv_w = (torch.randn(3 * D, D, generator=g) * 1.3 / math.sqrt(D)).to(dev)
+    qkv_b = (torch.randn(3 * D, generator=g) * 0.3).to(dev)
+    rel_h = (torch.randn(2 * Sz - 1, hd, generator=g) * 0.08).to(dev)
+    rel_w = (torch.randn(2 * Sz - 1, hd, generator=g) * 0.08).to(dev)
+    w_pad = F.pad(qkv_w.reshape(3, heads, hd, D), (0, 0, 0, hs - hd)).reshape(3 * heads * hs, D)
+    b_pad = F.pad(qkv_b.reshape(3, heads, hd), (0, hs - hd)).reshape(-1).contiguous()
+    q, k, v = ops.gemm_qkv(x.reshape(-1, D), _bf(w_pad), b_pad, B, heads)
+    assert q.shape == (B, heads, 4096, hs) and bool((q[..., hd:] == 0).all()) and bool((v[..., hd:] == 0).all())
+    rh, rw = _bf(F.pad(rel_h, (0, hs - hd))), _bf(F.pad(rel_w, (0, hs - hd)))
+    if window:
+        out = ops.window_attention(q, k, v, rh, rw, b_pad, scale=hd ** -0.5)
+    else:
+        out = ops.global_attention(q, k, v, rh, rw, scale=hd ** -0.5)
+    out = out.reshape(-1, heads, hs)
+    assert bool((out[..., hd:] == 0).all())
+    sd = {"a.qkv.weight": qkv_w, "a.qkv.bias": qkv_b, "a.rel_pos_h": rel_h, "a.rel_pos_w": rel_w,
+          "a.proj.weight": torch.eye(D, device=dev), "a.proj.bias": torch.zeros(D, device=dev)}
+    p = S.Prec("bf16")
+    y = x.float()
+    if window:
+        yw, pad_hw = S._window_partition(y, 14)
+        ref = S._window_unpartition(S._attention_relpos(sd, "a.", yw, heads, p), 14, pad_hw, (64, 64))
+    else:
+        ref = S._attention_relpos(sd, "a.", y, heads, p)
+    assert _close(out[..., :hd].reshape(-1, D), ref.reshape(-1, D), 2e-2, 2e-2)
+
+
 @pytest.mark.parametrize("K", [128, 256])
 def test_gemm_fused_layernorm(env, K):
     """Row-complete 64x256 GEMM with LayerNorm(256) and LayerNorm(64 groups)+GELU epilogues (decoder norm4 / up-scaling)."""

@@ -453,3 +453,41 @@ def test_vit_l_encoder_and_decode_vs_oracle():
                                       return_logits=True, precision="bf16")
     assert tuple(masks.shape) == (2, 3, 1024, 1024) and (iou.cpu() - iou_r).abs().max().item() <= 1e-2
     assert ((low.cpu() > 0) != (low_r > 0)).float().mean().item() <= 0.02
+
+
+def test_vit_h_encoder_and_decode_vs_oracle():
+    """vit_h (BASELINE config 4 model: D = 1280, 16 heads of 80 channels, 32 blocks, global blocks 7/15/23/31): the heads are
+    stored zero-padded to 96 channels (modeling.ImageEncoderViT._prepare).  The residual stream after block 7 (7 windowed
+    blocks + the first global block) is compared with the bf16-mode oracle (the full 32-block oracle costs minutes of CPU);
+    the full encoder + one decode must run and give finite, unit-scale embeddings."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    from oracle import amg_ref as A
+    from oracle import sam_ref as S
+    sd = synthetic_state_dict("vit_h", 2)
+    tile = synthetic_tile(22)
+    x = S.preprocess(torch.as_tensor(A.to_image(tile)).permute(2, 0, 1)[None])
+    with torch.no_grad():
+        _, taps = S.image_encoder(sd, x, model_type="vit_h", precision="bf16", return_blocks=True, stop_after_block=7)
+    p = util.get_sam_model("vit_h", device="cuda", state_dict=sd)
+    assert p.model_type == "vit_h"
+    enc = p.model.image_encoder
+    for blk in (0, 7):
+        out, tap = enc(x.cuda(), tap_block=blk)
+        r = taps[blk].reshape(-1, 1280)
+        d = (tap.cpu() - r).abs()
+        assert d.max().item() <= 0.01 * r.abs().max().item() + 0.03, (blk, d.max().item(), r.abs().max().item())
+        assert d.mean().item() <= 0.004 * r.abs().mean().item() + 1e-3, (blk, d.mean().item(), r.abs().mean().item())
+    assert tuple(out.shape) == (1, 256, 64, 64) and torch.isfinite(out).all() and 0.5 < out.std().item() < 2.0
+    emb = util.precompute_image_embeddings(p, tile, verbose=False, keep_on_device=True)
+    assert (emb["features"] - out).abs().max().item() <= 1e-5
+    util.set_precomputed(p, emb)
+    pts = torch.tensor([[[300.0, 400.0]]], device="cuda")
+    lab = torch.ones((1, 1), dtype=torch.int32, device="cuda")
+    masks, iou, low = p.predict_torch(pts, lab, multimask_output=True, return_logits=True)
+    _, iou_r, low_r = S.predict_torch(sd, out.cpu(), (1024, 1024), (1024, 1024), pts.cpu(), lab.cpu(), multimask_output=True,
+                                      return_logits=True, precision="bf16")
+    assert tuple(masks.shape) == (1, 3, 1024, 1024) and (iou.cpu() - iou_r).abs().max().item() <= 1e-2
+    assert ((low.cpu() > 0) != (low_r > 0)).float().mean().item() <= 0.02
