@@ -74,8 +74,13 @@ MSAM_DEVINL float gelu_erf(float x) {
 }
 
 // two values at once: the cubic and the final FMA as packed fp32 (v_pk_fma_f32)
+// max(x, 0) as exactly one instruction: fmaxf() on a value that comes straight out of an MFMA makes the compiler insert a
+// canonicalising v_max_f32 x, x, x first (IEEE maxnum semantics), which doubled the max count of the up-scaling kernel.
+// v_med3_f32(x, 0, 3e38) needs no canonical input (activations never reach 3e38).  (NOT inline asm: the hazard recognizer does not see inside asm
+// statements, so an asm v_max reading a fresh MFMA result ran without the required wait states - wrong results.)
+MSAM_DEVINL float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f); }   // (+inf would be folded back to maxnum)
 MSAM_DEVINL f32x2_t gelu_erf2(f32x2_t x) {
-    const f32x2_t r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    const f32x2_t r = {relu1(x.x), relu1(x.y)};
     const f32x2_t t = r * 2.0f - x;                  // |x| = 2 max(x, 0) - x (exact): packed ops have no abs modifier
     f32x2_t q = t * -0.0248758f + -0.49884797f;
     q = q * t + -1.12922424f;

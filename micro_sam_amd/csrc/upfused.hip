@@ -95,6 +95,18 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_;                              \
     } while (0)
 
+    // biases as the initial accumulator values (C operand of the first MFMA of a chain): no separate add
+    f32x4_t b1v[4], b2a, b2b;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const float4 b4 = *(const float4*)(a.b1 + sub * 64 + rt * 16 + fg * 4);
+        b1v[rt] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
+    }
+    {
+        const float4 ba = *(const float4*)(a.b2 + fg * 4), bb = *(const float4*)(a.b2 + 16 + fg * 4);
+        b2a = f32x4_t{ba.x, ba.y, ba.z, ba.w}; b2b = f32x4_t{bb.x, bb.y, bb.z, bb.w};
+    }
+    wait_vmem_all();
     const int boff = fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);                     // stage-1 B fragment (token fr, k-step slot fg)
     const int w2off = fr * 128;                                                   // + row-tile * 2048, chunk swizzled below
     const int w2sw = (fr >> 1) & 7;
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         // ---- stage 1: U^T rows (sub, c1 = 16 rt + 4 fg + r), column token fr
         f32x4_t u[4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) u[rt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < 4; ++rt) u[rt] = b1v[rt];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const uint4 kf = *(const uint4*)(B + boff + ks * SUB_BYTES);
@@ -139,11 +151,7 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         }
         float s = 0.f;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const float4 b4 = *(const float4*)&prm[sub * 64 + rt * 16 + fg * 4];
-            u[rt][0] += b4.x; u[rt][1] += b4.y; u[rt][2] += b4.z; u[rt][3] += b4.w;
-            s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
-        }
+        for (int rt = 0; rt < 4; ++rt) s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
         s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
         const float mean = s * (1.f / 64.f);
         float ss = 0.f;
@@ -166,31 +174,54 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             g1[kk] = make_uint4(pack2bf(u[2 * kk][0], u[2 * kk][1]), pack2bf(u[2 * kk][2], u[2 * kk][3]),
                                 pack2bf(u[2 * kk + 1][0], u[2 * kk + 1][1]), pack2bf(u[2 * kk + 1][2], u[2 * kk + 1][3]));
         // ---- stages 2 and 3, one second-level sub-pixel at a time
+        // The four second-level sub-pixels are independent chains (LDS read -> MFMA -> GELU -> MFMA).  They are written as a
+        // software pipeline in ONE basic block - stage-2 MFMAs of sub-pixel s+1 ahead of the GELUs of s, the hyper product of
+        // s behind them - so that every MFMA result has a block of independent VALU work between its issue and its first
+        // use (no dependency stalls, MFMA pipe and VALU overlap inside the wave); results stay in registers and are stored
+        // by a single predicated block (a branch per sub-pixel cut the chains into separate basic blocks).
         float* pt = patch[q & 1];
-        const float4 ba = *(const float4*)&prm[384 + fg * 4], bb = *(const float4*)&prm[384 + 16 + fg * 4];
-#pragma unroll
-        for (int sub2 = 0; sub2 < 4; ++sub2) {
-            f32x4_t ya = {0.f, 0.f, 0.f, 0.f}, yb = ya;              // c2 = 4 fg + r and 16 + 4 fg + r
+        f32x4_t ya[4], yb[4], ov[4];
+        uint4 gh[4];
+        auto stage2 = [&](int s2) {                                  // c2 = 4 fg + r (ya) and 16 + 4 fg + r (yb)
+            f32x4_t xa = b2a, xb = b2b;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                const uint4 wa = *(const uint4*)(W2L + (sub2 * 2) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
-                const uint4 wb = *(const uint4*)(W2L + (sub2 * 2 + 1) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
-                ya = mfma16(wa, g1[kk], ya);
-                yb = mfma16(wb, g1[kk], yb);
+                const uint4 wa = *(const uint4*)(W2L + (s2 * 2) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
+                const uint4 wb = *(const uint4*)(W2L + (s2 * 2 + 1) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
+                xa = mfma16(wa, g1[kk], xa);
+                xb = mfma16(wb, g1[kk], xb);
             }
-            // + bias, GELU (two values per packed instruction), fp16 for the hyper product (11-bit significand: the
-            // product keeps ~fp32 accuracy together with the hi + lo hyper weights; a bf16 operand would not)
-            const f32x2_t a01 = gelu_erf2(f32x2_t{ya[0] + ba.x, ya[1] + ba.y}), a23 = gelu_erf2(f32x2_t{ya[2] + ba.z, ya[3] + ba.w});
-            const f32x2_t b01 = gelu_erf2(f32x2_t{yb[0] + bb.x, yb[1] + bb.y}), b23 = gelu_erf2(f32x2_t{yb[2] + bb.z, yb[3] + bb.w});
-            const uint4 gh = make_uint4(pack2h(a01.x, a01.y), pack2h(a23.x, a23.y), pack2h(b01.x, b01.y), pack2h(b23.x, b23.y));
+            ya[s2] = xa; yb[s2] = xb;
+        };
+        // GELU (two values per packed instruction), fp16 for the hyper product (11-bit significand: the product keeps ~fp32
+        // accuracy together with the hi + lo hyper weights; a bf16 operand would not)
+        auto act2 = [&](int s2) {
+            const f32x2_t a01 = gelu_erf2(f32x2_t{ya[s2][0], ya[s2][1]}), a23 = gelu_erf2(f32x2_t{ya[s2][2], ya[s2][3]});
+            const f32x2_t b01 = gelu_erf2(f32x2_t{yb[s2][0], yb[s2][1]}), b23 = gelu_erf2(f32x2_t{yb[s2][2], yb[s2][3]});
+            gh[s2] = make_uint4(pack2h(a01.x, a01.y), pack2h(a23.x, a23.y), pack2h(b01.x, b01.y), pack2h(b23.x, b23.y));
+        };
+        auto stage3 = [&](int s2) {
             f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-            o = mfma16h(hh, gh, o);
-            o = mfma16h(hl, gh, o);
-            if (fg == 0) {                               // rows = masks r, column = token fr
+            o = mfma16h(hh, gh[s2], o);
+            o = mfma16h(hl, gh[s2], o);
+            ov[s2] = o;
+        };
+        stage2(0); stage2(1);
+        act2(0);
+        stage2(2);
+        act2(1);
+        stage3(0); stage2(3);
+        act2(2);
+        stage3(1);
+        act2(3);
+        stage3(2); stage3(3);
+        if (fg == 0) {                                   // rows = masks r, column = token fr
+#pragma unroll
+            for (int sub2 = 0; sub2 < 4; ++sub2) {
                 const int yl = (sub >> 1) * 2 + (sub2 >> 1), xl = fr * 4 + (sub & 1) * 2 + (sub2 & 1);
-                pt[(0 * 4 + yl) * 64 + xl] = o[0];
-                pt[(1 * 4 + yl) * 64 + xl] = o[1];
-                pt[(2 * 4 + yl) * 64 + xl] = o[2];
+                pt[(0 * 4 + yl) * 64 + xl] = ov[sub2][0];
+                pt[(1 * 4 + yl) * 64 + xl] = ov[sub2][1];
+                pt[(2 * 4 + yl) * 64 + xl] = ov[sub2][2];
             }
         }
         UF_STORE(p0, p1, buf ^ 1);

@@ -1,0 +1,36 @@
+"""Per-kernel averages of rocprofv3 --pmc passes: python tools/pmc_summary.py gpurun_out/pmc_a gpurun_out/pmc_b ...
+Prints a markdown table (kernel x counter, mean over dispatches; counters summed over XCDs / SEs as rocprofv3 reports them)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+KEEP = ("up_fused", "fold_i2t", "fold_attn", "postprocess", "gemm256", "gemm_kernel", "global_attention", "window_attention",
+        "t2i_shared4", "cc_hook", "nms_sweep", "fused_i2t")
+
+
+def main():
+    vals = defaultdict(lambda: defaultdict(list))
+    for d in sys.argv[1:]:
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                name = r.get("Kernel_Name") or r.get("Kernel Name") or ""
+                short = next((k for k in KEEP if k in name), None)
+                if short is None:
+                    continue
+                vals[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    counters = sorted({c for k in vals for c in vals[k]})
+    print("| kernel | n | " + " | ".join(counters) + " |")
+    print("|---|---|" + "---|" * len(counters))
+    for k in sorted(vals):
+        n = max(len(v) for v in vals[k].values())
+        row = []
+        for c in counters:
+            v = vals[k].get(c)
+            row.append(f"{sum(v) / len(v):.4g}" if v else "")
+        print(f"| {k} | {n} | " + " | ".join(row) + " |")
+
+
+if __name__ == "__main__":
+    main()
