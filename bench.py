@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--glds", type=int, default=0)
+    ap.add_argument("--serial-generate", action="store_true",
+                    help="run generate() on the main stream (default: side stream overlapping the next tile's decode)")
     ap.add_argument("--device-chunk", type=int, default=1024,
                     help="grid prompts decoded per decoder pass (results do not depend on it)")
     args = ap.parse_args()
@@ -115,6 +117,9 @@ def main():
         for f in range(NF):
             prof[f]["launches"] += n_[f]; prof[f]["ms"] += ms_[f]; prof[f]["flops"] += fl_[f]; prof[f]["bytes"] += by_[f]
 
+    # generate() of tile i (small latency-bound launches) runs on a side stream underneath the decoder kernels of tile i+1
+    gen_stream = None if args.serial_generate else torch.cuda.Stream(device=dev)
+
     def step(timed: bool):
         """timed=True: instrumented pass with a device sync after every stage (stage breakdown only);
         timed=False: the production path, no extra synchronisation."""
@@ -136,11 +141,18 @@ def main():
                 torch.cuda.synchronize(); stage["initialize"] += time.perf_counter() - t1
             t2 = time.perf_counter()
             # generate() on the device, result kept in HBM (it feeds the all_gather); same labels as amg.generate()
-            lab, flag = amg.generate_device()
-            labels[i] = lab
+            if gen_stream is None or timed:
+                lab, flag = amg.generate_device()
+                labels[i] = lab
+            else:
+                lab, flag = amg.generate_device(stream=gen_stream)
+                with torch.cuda.stream(gen_stream):
+                    labels[i] = lab
             flags.append(flag)
             if timed:
                 torch.cuda.synchronize(); stage["generate"] += time.perf_counter() - t2
+        if gen_stream is not None and not timed:
+            torch.cuda.current_stream().wait_stream(gen_stream)          # label tiles complete before the gather
         t3 = time.perf_counter()
         full = parallel.gather_label_tiles(labels, n_tiles * world) if world > 1 else labels
         if timed:

@@ -306,16 +306,31 @@ class AutomaticMaskGenerator(AMGBase):
 
     @torch.no_grad()
     def generate_device(self, pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95,
-                        box_nms_thresh: float = 0.7, with_background: bool = True, min_object_size: int = 0):
+                        box_nms_thresh: float = 0.7, with_background: bool = True, min_object_size: int = 0,
+                        stream: Optional["torch.cuda.Stream"] = None):
         """``generate(output_mode="instance_segmentation")`` without a single host synchronisation: threshold filters as one
         boolean vector, device NMS on the valid subset, paint + connected components + relabel on the device.
 
         Returns (labels int32 [H,W] device tensor, flag int32[1] that reads 0 when the labelling converged).
-        Identical labels to ``generate()`` (same filters in the same order, same stable sorts)."""
+        Identical labels to ``generate()`` (same filters in the same order, same stable sorts).
+
+        ``stream``: run on this side stream (after everything enqueued so far on the current stream, i.e. after the
+        ``initialize`` that produced the state).  ``generate`` is a chain of ~60 small, latency-bound launches (one-wave NMS
+        sweep, union-find passes, scans over one label image) that leave the chip almost empty; on a side stream they run
+        underneath the next tile's decoder kernels instead of in front of them.  The state tensors are marked as in use by
+        that stream (``record_stream``) so that the next ``initialize`` cannot recycle their memory early; the CALLER must
+        make the consumer of the results wait for ``stream`` (``torch.cuda.current_stream().wait_stream(stream)``)."""
         if not self.is_initialized:
             raise RuntimeError("AutomaticMaskGenerator has not been initialized. Call initialize first.")
         if len(self.crop_list) != 1 or "bits" not in self.crop_list[0]:
             raise RuntimeError("generate_device needs the single-crop device state produced by initialize()")
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream(stream.device))
+            for k in ("iou_preds", "stability_score", "boxes", "area", "bits"):
+                self.crop_list[0][k].record_stream(stream)
+            with torch.cuda.stream(stream):
+                return self.generate_device(pred_iou_thresh, stability_score_thresh, box_nms_thresh, with_background,
+                                            min_object_size)
         data, crop_box = self.crop_list[0], self.crop_boxes[0]
         orig_h, orig_w = self.original_size
         valid = torch.ones_like(data["iou_preds"], dtype=torch.bool)

@@ -167,6 +167,13 @@ def test_amg_initialize_generate_vs_oracle(ctx):
     # sync-free device generate == generate == oracle
     lab, flag = amg.generate_device()
     assert int(flag.item()) == 0 and np.array_equal(lab.cpu().numpy().astype("uint32"), seg)
+    # ... and on a side stream (overlaps the next tile's decode in bench.py): same labels; the next initialize may start at once
+    side = torch.cuda.Stream()
+    lab_s, flag_s = amg.generate_device(pred_iou_thresh=0.5, stability_score_thresh=0.5, stream=side)
+    amg.initialize(tile, emb)                                           # recycles nothing the side stream still reads
+    torch.cuda.current_stream().wait_stream(side)
+    lab_m, _ = amg.generate_device(pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    assert int(flag_s.item()) == 0 and torch.equal(lab_s, lab_m) and int(lab_m.max().item()) > 0
     seg_lo = amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5, box_nms_thresh=0.9)
     cl2 = A.MaskData(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in state["crop_list"][0].items()})
     seg_lo_ref = PR.amg_generate({"crop_list": [cl2], "crop_boxes": state["crop_boxes"], "original_size": state["original_size"]},
