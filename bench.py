@@ -64,6 +64,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--glds", type=int, default=0)
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="tiles are decoded round-robin on this many HIP streams (each with its own predictor state and "
+                         "decoder workspace): the latency-bound token-side launches of one tile run underneath the "
+                         "streaming kernels of another")
     ap.add_argument("--serial-generate", action="store_true",
                     help="run generate() on the main stream (default: side stream overlapping the next tile's decode)")
     ap.add_argument("--device-chunk", type=int, default=1024,
@@ -119,6 +123,11 @@ def main():
 
     # generate() of tile i (small latency-bound launches) runs on a side stream underneath the decoder kernels of tile i+1
     gen_stream = None if args.serial_generate else torch.cuda.Stream(device=dev)
+    lanes = [(predictor, amg, torch.cuda.Stream(device=dev))]
+    for _ in range(1, max(args.lanes, 1)):
+        pk = util.get_sam_model("vit_b", device=dev, state_dict=sd)
+        pk.model.use_glds = args.glds
+        lanes.append((pk, AutomaticMaskGenerator(pk, device_chunk=args.device_chunk), torch.cuda.Stream(device=dev)))
 
     def step(timed: bool):
         """timed=True: instrumented pass with a device sync after every stage (stage breakdown only);
@@ -134,7 +143,20 @@ def main():
         emb = {"features": feats, "input_size": (1024, 1024), "original_size": (1024, 1024)}
         if timed:
             torch.cuda.synchronize(); stage["encode"] += time.perf_counter() - t0
-        for i in range(n_tiles):
+        if len(lanes) > 1 and not timed:
+            main = torch.cuda.current_stream()
+            for _, _, st in lanes:
+                st.wait_stream(main)                                    # embeddings ready
+            for i in range(n_tiles):
+                _, ak, st = lanes[i % len(lanes)]
+                with torch.cuda.stream(st):
+                    ak.initialize(tiles_np[i], emb, i=i)
+                    lab, flag = ak.generate_device()
+                    labels[i] = lab
+                flags.append(flag)
+            for _, _, st in lanes:
+                main.wait_stream(st)
+        for i in range(n_tiles if (len(lanes) == 1 or timed) else 0):
             t1 = time.perf_counter()
             amg.initialize(tiles_np[i], emb, i=i)
             if timed:

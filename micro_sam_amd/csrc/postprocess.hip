@@ -115,19 +115,40 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                 // negative <=> v > t; t - v == +0 for equality) shifted into three words: 2 instructions per predicate and
                 // pixel instead of compare + add-with-carry / select + or; pixel 0 ends up in bit 31 -> bit reverse
                 uint32_t wm = 0, wh = 0, wl = 0;
+                uint32_t word;
+                if (nb == 32) {
+                    // full word (every word of a 1024-row mask).  Only the mask bits are needed per lane; the two stability
+                    // counts are per-MASK totals, so each is one v_cmp into a scalar lane mask + a scalar popcount (SALU, a
+                    // separate issue port) instead of a subtract + alignbit per pixel on the VALU: 6 instead of 8 VALU
+                    // instructions per pixel in this VALU-bound loop (same comparisons: v > t  <=>  sign(t - v) set)
+                    int s_hi = 0, s_lo = 0;
 #pragma unroll
-                for (int b = 0; b < 32; ++b) {
-                    float w1 = W1[b & 3];
-                    if (b < 2 && yw == 0) w1 = 0.0f;
-                    const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
-                    if (LOGITS) { if (b < nb) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v; }
-                    wm = __builtin_amdgcn_alignbit(wm, __float_as_uint(__fsub_rn(thr, v)), 31);
-                    wh = __builtin_amdgcn_alignbit(wh, __float_as_uint(__fsub_rn(hi_t, v)), 31);
-                    wl = __builtin_amdgcn_alignbit(wl, __float_as_uint(__fsub_rn(lo_t, v)), 31);
+                    for (int b = 0; b < 32; ++b) {
+                        float w1 = W1[b & 3];
+                        if (b < 2 && yw == 0) w1 = 0.0f;
+                        const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
+                        if (LOGITS) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
+                        wm = __builtin_amdgcn_alignbit(wm, __float_as_uint(__fsub_rn(thr, v)), 31);
+                        s_hi += __popcll(__ballot(v > hi_t));
+                        s_lo += __popcll(__ballot(v > lo_t));
+                    }
+                    word = __brev(wm);
+                    if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { c_hi += s_hi; c_lo += s_lo; }   // first active lane
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 32; ++b) {
+                        float w1 = W1[b & 3];
+                        if (b < 2 && yw == 0) w1 = 0.0f;
+                        const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
+                        if (LOGITS) { if (b < nb) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v; }
+                        wm = __builtin_amdgcn_alignbit(wm, __float_as_uint(__fsub_rn(thr, v)), 31);
+                        wh = __builtin_amdgcn_alignbit(wh, __float_as_uint(__fsub_rn(hi_t, v)), 31);
+                        wl = __builtin_amdgcn_alignbit(wl, __float_as_uint(__fsub_rn(lo_t, v)), 31);
+                    }
+                    const uint32_t valid = (1u << nb) - 1u;
+                    word = __brev(wm) & valid;
+                    c_hi += __popc(__brev(wh) & valid); c_lo += __popc(__brev(wl) & valid);
                 }
-                const uint32_t valid = nb < 32 ? (1u << nb) - 1u : 0xffffffffu;
-                const uint32_t word = __brev(wm) & valid;
-                c_hi += __popc(__brev(wh) & valid); c_lo += __popc(__brev(wl) & valid);
                 if (word) {
                     c_m += __popc(word); any = true;
                     ymin = min(ymin, yw * 32 + __ffs(word) - 1); ymax = yw * 32 + 31 - __clz(word);
