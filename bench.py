@@ -22,8 +22,8 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TILES_PER_STEP = 8
-ENC_BATCH = 8
+TILES_PER_STEP = 16
+ENC_BATCH = 16     # M = 65536 rows: every encoder GEMM is a whole number of 256-workgroup rounds (B = 8 left 1.5-round tails)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 TILE_TFLOP_ALGORITHMIC = 4.64      # encoder 0.938 + AMG decode 3.70
@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--glds", type=int, default=0)
+    ap.add_argument("--tiles-per-step", type=int, default=TILES_PER_STEP, help="tiles per rank and step")
+    ap.add_argument("--enc-batch", type=int, default=ENC_BATCH, help="tiles per image-encoder call")
     ap.add_argument("--lanes", type=int, default=1,
                     help="tiles are decoded round-robin on this many HIP streams (each with its own predictor state and "
                          "decoder workspace): the latency-bound token-side launches of one tile run underneath the "
@@ -95,7 +97,8 @@ def main():
 
     n_steps = args.warmup + args.steps
     # distinct synthetic tiles per rank and step (seed = global tile index), staged in HBM before timing
-    n_tiles = TILES_PER_STEP
+    n_tiles = args.tiles_per_step
+    enc_batch = args.enc_batch
     tiles_np = [synthetic_tile(1000 + rank * n_tiles + i) for i in range(n_tiles)]
     tiles_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in tiles_np]).to(dev)
     torch.cuda.synchronize()
@@ -137,8 +140,8 @@ def main():
         flags = []
         t0 = time.perf_counter()
         feats = []
-        for s in range(0, n_tiles, ENC_BATCH):
-            feats.append(predictor.model.image_encoder.forward_u8(tiles_u8[s:s + ENC_BATCH]))
+        for s in range(0, n_tiles, enc_batch):
+            feats.append(predictor.model.image_encoder.forward_u8(tiles_u8[s:s + enc_batch]))
         feats = torch.cat(feats).unsqueeze(1)                       # [n,1,256,64,64] on device
         emb = {"features": feats, "input_size": (1024, 1024), "original_size": (1024, 1024)}
         if timed:
@@ -256,7 +259,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
                                    "AutomaticMaskGenerator (32x32 grid, multimask, default thresholds)",
-                       "tiles_per_step_per_gpu": n_tiles, "encoder_batch": ENC_BATCH, "weights": "seeded random init "
+                       "tiles_per_step_per_gpu": n_tiles, "encoder_batch": enc_batch, "weights": "seeded random init "
                        "(synthetic.py variant 'blobs')", "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
                        "instances_last_tile": n_instances,
                        "stage_seconds_per_tile_synced_pass": {k: round(v / n_tiles, 5) for k, v in stage.items()

@@ -139,6 +139,9 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and
  * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
+/* tuning / test hook: operand staging of the 256 x 256 tile kernel behind msam_gemm_bf16 (0 registers two tiles ahead,
+ * 1 registers with the LDS write behind the barrier, 2 LDS-DMA; -1 = built-in default or MSAM_GEMM256_STAGING). */
+int msam_gemm256_set_staging(int staging);
 int msam_profile_enable(int on);
 int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops);
 /* Per kernel family (arrays of MSAM_PROFILE_FAMILIES: launches, summed ms, flops, algorithmic HBM bytes):

@@ -117,6 +117,7 @@ _PROTOS = {
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "msam_gemm256_set_staging": (_i32, [_i32]),
     "msam_window_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),

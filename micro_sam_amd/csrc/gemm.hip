@@ -292,8 +292,16 @@ MSAM_DEVINL f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 constexpr int G2 = 256;                       // tile edge
+constexpr int G2_DEFAULT_STAGING = 1;   // measured: 3 - 6 % over 0 on the encoder shapes, LDS-DMA (2) no better (tools/gemm_bench.py)
+int g_gemm256_staging = -1;                   // test / tuning hook (msam_gemm256_set_staging), -1 = default / environment
 constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 8 chunks x 16 B = 128 KB
 
+// STAGING: 0 = registers, two k-tiles ahead, LDS write behind the MFMAs (before the barrier);
+//          1 = registers, ONE register set: LDS write of tile kt+1 right after the barrier (start of the iteration), loads of
+//              tile kt+2 re-issued at once - the write pass overlaps the MFMA phase instead of sitting in front of the barrier;
+//          2 = global_load_lds_dwordx4 (LDS-DMA) into the other LDS buffer while the MFMAs run (no staging registers, no
+//              ds_write pass; swizzle applied on the per-lane source address)
+template <int STAGING>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                          long ldw, int M, int N, int K, Epi e) {
     extern __shared__ __attribute__((aligned(16))) uint4 dyn[];
@@ -369,24 +377,63 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
                 for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[i], af[j], acc[i][j]);
         }
     };
-    G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
-    G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
-    G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(1, nk - 1));
-    __syncthreads();
-    int kt = 0;
-    while (true) {
-        G2_LOAD(ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3, min(kt + 2, nk - 1));
-        compute(kt & 1);
-        if (kt + 1 < nk) G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, (kt & 1) ^ 1);
+    if constexpr (STAGING == 0) {
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+        G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(1, nk - 1));
         __syncthreads();
-        if (++kt >= nk) break;
-        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(kt + 2, nk - 1));
-        compute(kt & 1);
-        if (kt + 1 < nk) G2_COMMIT(ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3, (kt & 1) ^ 1);
+        int kt = 0;
+        while (true) {
+            G2_LOAD(ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3, min(kt + 2, nk - 1));
+            compute(kt & 1);
+            if (kt + 1 < nk) G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, (kt & 1) ^ 1);
+            __syncthreads();
+            if (++kt >= nk) break;
+            G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(kt + 2, nk - 1));
+            compute(kt & 1);
+            if (kt + 1 < nk) G2_COMMIT(ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3, (kt & 1) ^ 1);
+            __syncthreads();
+            if (++kt >= nk) break;
+        }
+        wait_vmem_all();
+    } else if constexpr (STAGING == 1) {
+        (void)ya0; (void)yw0;
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+        G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(1, nk - 1));
         __syncthreads();
-        if (++kt >= nk) break;
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt+1 (in flight during the previous iteration) -> the buffer every wave finished reading before the barrier
+            if (kt + 1 < nk) G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, (kt & 1) ^ 1);
+            G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(kt + 2, nk - 1));
+            compute(kt & 1);
+            __syncthreads();
+        }
+        wait_vmem_all();
+    } else {
+        (void)xa0; (void)xw0; (void)ya0; (void)yw0;
+        // per-lane source pointers (swizzled chunk), wave-uniform LDS destination: wave w, pass p covers rows p*64 + w*8 .. +7
+        auto issue = [&](int kt, int buf) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint4* la = stage(buf, 0) + (p * 64 + wave * 8) * 8;
+                uint4* lw = stage(buf, 1) + (p * 64 + wave * 8) * 8;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)((const char*)A + aoff[p] + (long)kt * BK * 2),
+                    (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)((const char*)W + woff[p] + (long)kt * BK * 2),
+                    (__attribute__((address_space(3))) void*)lw, 16, 0, 0);
+            }
+        };
+        issue(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue(kt + 1, (kt & 1) ^ 1);
+            compute(kt & 1);
+            __syncthreads();
+        }
     }
-    wait_vmem_all();
 #undef G2_LOAD
 #undef G2_COMMIT
 
@@ -640,6 +687,12 @@ int g_prof_n = 0, g_prof_on = 0, g_prof_init = 0;
 
 extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
+extern "C" int msam_gemm256_set_staging(int staging) {
+    if (staging < -1 || staging > 2) { msam_set_error("msam_gemm256_set_staging: -1 (default), 0, 1 or 2"); return 1; }
+    g_gemm256_staging = staging;
+    return 0;
+}
+
 extern "C" int msam_profile_enable(int on) {
     if (on && !g_prof_init) {
         for (int i = 0; i < PROF_MAX; ++i) {
@@ -746,14 +799,20 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
     // large shapes (the encoder's projections): 256 x 256 tile kernel.  MSAM_GEMM256=0 keeps the 128 x 128 kernel (A/B runs)
-    static int use256 = -1;
-    if (use256 < 0) { const char* v = getenv("MSAM_GEMM256"); use256 = v ? atoi(v) : 1; }
+    static int use256 = -1, staging256 = 0;
+    if (use256 < 0) {
+        const char* v = getenv("MSAM_GEMM256"); use256 = v ? atoi(v) : 1;
+        const char* st = getenv("MSAM_GEMM256_STAGING"); staging256 = st ? atoi(st) : G2_DEFAULT_STAGING;
+    }
+    if (g_gemm256_staging >= 0) staging256 = g_gemm256_staging;
     // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
     if (use256 && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 && p->out_mode != 2 && !p->table &&
         (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr256 = false;
         if (!attr256) {
-            if (hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
                 msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
                 return 2;
             }
@@ -764,8 +823,10 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
             (void)hipEventRecord(g_prof[g_prof_n].a, s);
         }
         const int tiles256 = ((p->M + G2 - 1) / G2) * (p->N / G2);
-        hipLaunchKernelGGL(gemm256_kernel, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda,
-                           (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+#define G2_GO(ST_) hipLaunchKernelGGL(gemm256_kernel<ST_>, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda, \
+                                     (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e)
+        if (staging256 == 1) G2_GO(1); else if (staging256 == 2) G2_GO(2); else G2_GO(0);
+#undef G2_GO
         if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
         return msam_check_launch("msam_gemm_bf16(256)");
     }

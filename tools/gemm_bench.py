@@ -1,0 +1,47 @@
+"""GPU-box micro-benchmark of the encoder's GEMM shapes (vit_b, batch of 8 tiles: M = 32768) across the operand staging
+variants of the 256 x 256 tile kernel; each variant is checked against the first one (bit-identical accumulation order).
+    python tools/gemm_bench.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from micro_sam_amd import _lib, ops  # noqa: E402
+
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+g = torch.Generator().manual_seed(3)
+SHAPES = [(32768, 2304, 768, "qkv"), (32768, 768, 768, "proj"), (32768, 3072, 768, "lin1"), (32768, 768, 3072, "lin2"),
+          (32768, 3072, 1024, "vit_l lin1 (N=3072 stand-in)")]
+
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+for (M, N, K, name) in SHAPES:
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    w = (torch.rand(N, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = None
+    line = []
+    for st in (0, 1, 2, 0, 1, 2):
+        lib.msam_gemm256_set_staging(st)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        ms = timeit(lambda: ops.gemm(a, w, bias, out=out, act=ops.ACT_GELU))
+        if ref is None:
+            ref = out.clone()
+        same = bool(torch.equal(out, ref))
+        line.append(f"st{st}: {ms:.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF {'ok' if same else 'DIFF'}")
+    print(f"{name:8s} {M}x{N}x{K}  " + " | ".join(line), flush=True)
+lib.msam_gemm256_set_staging(-1)
