@@ -26,6 +26,7 @@ extern "C" {
 #define MSAM_MAX_BLOCKS 32
 #define MSAM_F32 1
 #define MSAM_BF16 2
+#define MSAM_FP8 3                       /* OCP e4m3 (gfx950), not the fnuz variant of MI300 */
 #define MSAM_ACT_NONE 0
 #define MSAM_ACT_GELU 1
 #define MSAM_ACT_RELU 2
@@ -63,6 +64,10 @@ typedef struct {
                                             0 none, 1 LayerNorm over the 256-wide row, 2 LayerNorm over each 64-column
                                             group followed by exact GELU; applied after bias/table/resid */
     const float* ln_w; const float* ln_b; float ln_eps;    /* [256] (mode 1) or [64] (mode 2) */
+    /* fp8 operands (BASELINE config 5): a_dtype = MSAM_FP8 -> A and W are OCP e4m3 bytes (lda / ldw / K in elements,
+     * K % 128 == 0, N % 256 == 0), out = act(acc * row_scale[m] * col_scale[n] + bias + resid); 0 / MSAM_BF16 = bf16 */
+    int32_t a_dtype;
+    const float* row_scale; const float* col_scale;        /* fp32 [M], [N] */
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 
@@ -139,6 +144,8 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and
  * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
+/* debug hook: phase timing of the folded image->token kernel (see csrc/decfold.hip, tools/i2t_timing.py) */
+int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out);
 /* tuning / test hook: operand staging of the 256 x 256 tile kernel behind msam_gemm_bf16 (0 registers two tiles ahead,
  * 1 registers with the LDS write behind the barrier, 2 LDS-DMA; -1 = built-in default or MSAM_GEMM256_STAGING). */
 int msam_gemm256_set_staging(int staging);
@@ -157,6 +164,12 @@ int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, do
 int msam_layernorm(const float* x, const float* weight, const float* bias, float eps, int64_t rows, int32_t dim,
                    void* out, int32_t out_dtype, int32_t gelu, int32_t out_nchw_hw, void* stream);
 
+/* fp8 activations (BASELINE config 5; OCP e4m3, one fp32 scale per row = per token: q = round(y * 448 / amax(row))).
+ * msam_layernorm_fp8: LayerNorm (fp32 statistics) of fp32 [rows, dim] straight to fp8 [rows, dim] + row_scale [rows];
+ * msam_quant_rows_fp8: bf16 [rows, dim] -> fp8 + row scales (attention output, MLP hidden). */
+int msam_layernorm_fp8(const float* x, const float* weight, const float* bias, float eps, int64_t rows, int32_t dim,
+                       void* out_fp8, float* row_scale, void* stream);
+int msam_quant_rows_fp8(const void* x_bf16, int64_t rows, int32_t dim, void* out_fp8, float* row_scale, void* stream);
 /* fp32 [B,3,1024,1024] (output of Sam.preprocess) -> bf16 patch matrix [B*4096, 768] (c,ky,kx order). */
 int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream);
 /* uint8 HWC [B,h,w,3] (h,w <= 1024; output of ResizeLongestSide.apply_image) -> normalised, zero padded bf16 patch

@@ -15,7 +15,7 @@ import torch
 from . import build as _build
 
 MSAM_MAX_BLOCKS = 32
-F32, BF16 = 1, 2
+F32, BF16, FP8 = 1, 2, 3
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -30,6 +30,7 @@ class GemmParams(C.Structure):
         ("out", _vp), ("out_dtype", _i32), ("ldc", _i64), ("out_mode", _i32),
         ("q", _vp), ("k", _vp), ("v", _vp), ("heads", _i32), ("head_dim", _i32), ("tokens", _i32),
         ("use_glds", _i32), ("ln_mode", _i32), ("ln_w", _vp), ("ln_b", _vp), ("ln_eps", _f32),
+        ("a_dtype", _i32), ("row_scale", _vp), ("col_scale", _vp),
     ]
 
 
@@ -118,6 +119,9 @@ _PROTOS = {
     "msam_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
     "msam_gemm256_set_staging": (_i32, [_i32]),
+    "msam_layernorm_fp8": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp]),
+    "msam_quant_rows_fp8": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "msam_debug_i2t_timing": (_i32, [_i32, _vp]),
     "msam_window_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),

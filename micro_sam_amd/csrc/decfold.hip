@@ -337,7 +337,14 @@ constexpr int PT_BYTES = TK * 64 * 2;
 // an immediate offset
 constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;
 
+// phase stamps of workgroup 0 / wave 0 (TIMING instantiation only; msam_debug_i2t_timing): [tile][12] shader-clock values
+__device__ unsigned long long g_i2t_stamps[64 * 12];
+int g_i2t_timing = 0;
+
+template <bool TIMING>
 __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
+#define I2T_STAMP(k_) do { if constexpr (TIMING) { if (blockIdx.x == 0 && threadIdx.x == 0 && q < 64)           \
+                                                       g_i2t_stamps[q * 12 + (k_)] = __builtin_readcyclecounter(); } } while (0)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + PT_BYTES];
     __shared__ float red[4][TK][2];
     __shared__ __attribute__((aligned(16))) float prm[3][C];                  // bo, ln_w, ln_b
@@ -391,6 +398,25 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
 
     uint4 kq[8], vq[4][2], kd, tb0, tb1;
     const int hh_row = fr >> 3, t_row = fr & 7;           // A-operand row fr of this wave's score tile = (head 2w+hh, token t)
+    // The residual and the out_proj bias enter the O^T accumulators through the MFMA instead of the VALU (the kernel is
+    // VALU-issue bound: PMC): bias = initial accumulator value (C operand of the first MFMA); residual = one more MFMA per
+    // output tile with a 16 x 32 slice of the identity as A operand (row r picks channel (i & 1) * 16 + r of the 32-channel
+    // k-step 2w + (i >> 1)) and the stream tile's own operand fragment as B - bf16 x 1.0 is exact in the fp32 accumulator.
+    uint4 ida[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+        const int target = par * 16 + fr;                 // k index of the one in row fr
+        uint32_t wv[4] = {0u, 0u, 0u, 0u};
+        if ((target >> 3) == fg) wv[(target & 7) >> 1] = (target & 1) ? 0x3F800000u : 0x00003F80u;
+        ida[par] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+    f32x4_t bo_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 b4 = *(const float4*)(a.bo + (w * 4 + i) * 16 + fg * 4);
+        bo_acc[i] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
+    }
+    wait_vmem_all();
     // per-lane LDS offsets: operand reads (token fr, slot fg), residual / result (token fr, channels (4w+i)*16 + fg*4 ..)
     const int boff = fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);
     int xoff[2];
@@ -407,6 +433,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
 
     int q = 0, buf = 0;
     auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& f0, uint4& f1, uint4& f2, uint4& f3) {
+        I2T_STAMP(0);
         FI_LOAD(f0, f1, f2, f3, min(q + 2, nq - 1));
         int p, key0;
         tile_pos(q, p, key0);
@@ -437,6 +464,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         s0 = mfma16(kd, tb0, s0);
         s1 = mfma16(kd, tb1, s1);
         FI_TAB(min(q + 1, nq - 1));
+        I2T_STAMP(1);
         // softmax over the 8 tokens of a head: rows fg*4 + r, i.e. token (fg & 1) * 4 + r of head 2w + (fg >> 1)
         {
             float m0 = NEG_BIG, m1 = NEG_BIG;
@@ -460,7 +488,9 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
             *(uint2*)(PT + po) = q0;
             *(uint2*)(PT + po + 16 * 128) = q1;
         }
+        I2T_STAMP(2);
         __syncthreads();                                 // (A) P^T complete
+        I2T_STAMP(3);
         // ---- O^T for channels 64w .. 64w+63
         f32x4_t o[4][2];
         {
@@ -471,38 +501,41 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
                 pf[0][kk] = *(const uint4*)(PT + po);
                 pf[1][kk] = *(const uint4*)(PT + po + 16 * 128);
             }
+            uint4 xk[2][2];                              // stream-tile operand fragments of this wave's k-steps 2w, 2w+1
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) xk[j][n] = *(const uint4*)(B + boff + (2 * w + j) * SUB_BYTES + n * 16 * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+                    f32x4_t c = bo_acc[i];
                     c = mfma16(vq[i][0], pf[n][0], c);
                     c = mfma16(vq[i][1], pf[n][1], c);
+                    c = mfma16(ida[i & 1], xk[i >> 1][n], c);
                     o[i][n] = c;
                 }
         }
-        // residual + bias; LayerNorm partial sums over this wave's 64 channels.  lane: token n*16 + fr, channels
-        // (4w + i)*16 + fg*4 + r  (sub-tile 2w + (i >> 1), slot (i & 1)*2 + (fg >> 1), byte (fg & 1)*8)
+        I2T_STAMP(4);
+        // LayerNorm partial sums over this wave's 64 channels (o already holds attention + bias + residual).  lane: token
+        // n*16 + fr, channels (4w + i)*16 + fg*4 + r  (sub-tile 2w + (i >> 1), slot (i & 1)*2 + (fg >> 1), byte (fg & 1)*8)
         float s1a[2] = {0.f, 0.f}, s2a[2] = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4 bo4 = *(const float4*)&prm[0][(w * 4 + i) * 16 + fg * 4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const uint2 xr = *(const uint2*)(B + xoff[i & 1] + (i >> 1) * SUB_BYTES + n * 16 * 64);
-                o[i][n][0] += bo4.x + bf2f((u16)(xr.x & 0xffff)); o[i][n][1] += bo4.y + bf2f((u16)(xr.x >> 16));
-                o[i][n][2] += bo4.z + bf2f((u16)(xr.y & 0xffff)); o[i][n][3] += bo4.w + bf2f((u16)(xr.y >> 16));
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { s1a[n] += o[i][n][r]; s2a[n] += o[i][n][r] * o[i][n][r]; }
-            }
-        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             s1a[n] += __shfl_xor(s1a[n], 16); s1a[n] += __shfl_xor(s1a[n], 32);
             s2a[n] += __shfl_xor(s2a[n], 16); s2a[n] += __shfl_xor(s2a[n], 32);
             if (fg == 0) { red[w][n * 16 + fr][0] = s1a[n]; red[w][n * 16 + fr][1] = s2a[n]; }
         }
+        I2T_STAMP(5);
         __syncthreads();                                 // (B) statistics of all four channel quarters
+        I2T_STAMP(6);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int tok = n * 16 + fr;
@@ -521,13 +554,17 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
                 *(uint2*)(B + xoff[i & 1] + (i >> 1) * SUB_BYTES + n * 16 * 64) = y;     // in place
             }
         }
+        I2T_STAMP(7);
         if (q + 1 < nq) FI_STORE(p0, p1, p2, p3, buf ^ 1);
+        I2T_STAMP(8);
         __syncthreads();                                 // (C) updated tile complete, next tile staged
+        I2T_STAMP(9);
         {
             const rsrc_t ro = make_rsrc(a.out + (long)p * T * C, T * C * 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) buf_store16(*(const uint4*)(B + kdst[i]), ro, voff, key0 * C * 2 + i * NTHR * 16);
         }
+        I2T_STAMP(10);
         buf ^= 1;
     };
     while (true) {
@@ -539,6 +576,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
 #undef FI_LOAD
 #undef FI_STORE
 #undef FI_TAB
+#undef I2T_STAMP
 }
 
 // V'^T[p][c][h*8 + t] = sum_d Wo[c][h*16 + d] v[p][t][h*16 + d]   (zero for t >= Nt)
@@ -649,7 +687,22 @@ extern "C" int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void
     const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
     const double bytes = (double)(x_shared ? 1 : P) * T * C * 2 + (double)P * T * C * 2;
     msam_profile_mark2(stream, 1, flops, bytes, 2);
-    hipLaunchKernelGGL(fold_i2t_kernel, dim3(grid), dim3(NTHR), 0, s, a);
+    if (g_i2t_timing) hipLaunchKernelGGL(fold_i2t_kernel<true>, dim3(grid), dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL(fold_i2t_kernel<false>, dim3(grid), dim3(NTHR), 0, s, a);
     msam_profile_mark2(stream, 0, flops, bytes, 2);
     return msam_check_launch("fold_i2t");
+}
+
+// Debug hook (tools/i2t_timing.py): enable != 0 routes msam_i2t_fold_layer to the instrumented instantiation; with a non-null
+// host buffer [64 * 12] the phase stamps of the last instrumented launch (workgroup 0, wave 0, first 64 tiles) are copied out.
+extern "C" int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out) {
+    g_i2t_timing = enable;
+    if (host_out) {
+        if (hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_i2t_stamps), sizeof(unsigned long long) * 64 * 12) != hipSuccess) {
+            msam_set_error("msam_debug_i2t_timing: copy failed");
+            return 2;
+        }
+    }
+    return 0;
 }

@@ -20,6 +20,7 @@ struct Epi {
     int act;
     void* out; int out_dtype; long ldc;
     int out_mode; u16* q; u16* k; u16* v; int heads, head_dim, tokens;
+    const float* row_scale; const float* col_scale;      // fp8 operands: C = acc * row_scale[m] * col_scale[n]
 };
 
 template <bool GLDS>
@@ -291,6 +292,17 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 MSAM_DEVINL f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+// 32 x 32 x 64 fp8 (OCP e4m3) through the block-scaled MX instruction with unit block scales (e8m0 127 = 2^0 in every byte):
+// the only large-K fp8 MFMA of gfx950 and the only one that runs at twice the bf16 rate.  A lane holds 32 consecutive
+// bytes of K for its row (lane >> 5 selects the 32-byte half of the 64-deep step); both operands use the same map, so any
+// consistent assignment of tile bytes to (lane half, byte) computes the same contraction.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+MSAM_DEVINL f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, f32x16_t c) {
+    const i32x8_t av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const i32x8_t bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0 /* A fp8 e4m3 */, 0 /* B fp8 e4m3 */, 0, 0x7F7F7F7F,
+                                                            0, 0x7F7F7F7F);
+}
 constexpr int G2 = 256;                       // tile edge
 constexpr int G2_DEFAULT_STAGING = 1;   // measured: 3 - 6 % over 0 on the encoder shapes, LDS-DMA (2) no better (tools/gemm_bench.py)
 int g_gemm256_staging = -1;                   // test / tuning hook (msam_gemm256_set_staging), -1 = default / environment
@@ -301,9 +313,14 @@ constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 
 //              tile kt+2 re-issued at once - the write pass overlaps the MFMA phase instead of sitting in front of the barrier;
 //          2 = global_load_lds_dwordx4 (LDS-DMA) into the other LDS buffer while the MFMAs run (no staging registers, no
 //              ds_write pass; swizzle applied on the per-lane source address)
-template <int STAGING>
+// FP8: A and W are fp8 e4m3 bytes (lda / ldw / K in elements = bytes), a k-tile is 128 elements (the same 128-byte LDS
+// rows, swizzle and staging map as bf16), two 32 x 32 x 64 MX MFMAs per 128-byte row instead of four 32 x 32 x 16 bf16 ones:
+// the same kernel time per byte, twice the elements per byte.  Row / column scales are applied in the epilogue.
+template <int STAGING, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                          long ldw, int M, int N, int K, Epi e) {
+    constexpr int ESZ = FP8 ? 1 : 2;              // bytes per operand element
+    constexpr int BKE = 128 / ESZ;                // elements per k-tile (128-byte rows)
     extern __shared__ __attribute__((aligned(16))) uint4 dyn[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
@@ -325,15 +342,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
     for (int p = 0; p < 4; ++p) {
         const int row = p * 64 + srow, gc = scp ^ swz(row);
         const int ar = min(m0 + row, M - 1);
-        aoff[p] = (int)(((long)ar * lda + gc * 8) * 2);
-        woff[p] = (int)(((long)(n0 + row) * ldw + gc * 8) * 2);
+        aoff[p] = (int)((long)ar * lda * ESZ + gc * 16);
+        woff[p] = (int)((long)(n0 + row) * ldw * ESZ + gc * 16);
     }
-    const rsrc_t ra = make_rsrc(A, (uint32_t)min((long)M * lda * 2, 0xffffffffL));
-    const rsrc_t rw = make_rsrc(W, (uint32_t)min((long)N * ldw * 2, 0xffffffffL));
+    const rsrc_t ra = make_rsrc(A, (uint32_t)min((long)M * lda * ESZ, 0xffffffffL));
+    const rsrc_t rw = make_rsrc(W, (uint32_t)min((long)N * ldw * ESZ, 0xffffffffL));
     uint4 xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, ya0, ya1, ya2, ya3, yw0, yw1, yw2, yw3;
 #define G2_LOAD(a0_, a1_, a2_, a3_, w0_, w1_, w2_, w3_, kt_)                                           \
     do {                                                                                               \
-        const int so_ = (kt_) * BK * 2;                                                                \
+        const int so_ = (kt_) * 128;                                                                   \
         a0_ = buf_load16(ra, aoff[0], so_); a1_ = buf_load16(ra, aoff[1], so_);                        \
         a2_ = buf_load16(ra, aoff[2], so_); a3_ = buf_load16(ra, aoff[3], so_);                        \
         w0_ = buf_load16(rw, woff[0], so_); w1_ = buf_load16(rw, woff[1], so_);                        \
@@ -354,10 +371,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #pragma unroll
             for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
 
-    const int nk = K / BK;
+    const int nk = K / BKE;
     auto compute = [&](int buf) {
         const uint4* la = stage(buf, 0);
         const uint4* lw = stage(buf, 1);
+        if constexpr (FP8) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {                 // two 64-byte steps per row; lane half lh owns 32 bytes of a step
+                const int c0 = s2 * 4 + lh * 2;
+                uint4 wf0[2], wf1[2], af0[4], af1[4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = wn * 64 + i * 32 + l31;
+                    wf0[i] = lw[row * 8 + (c0 ^ swz(row))]; wf1[i] = lw[row * 8 + ((c0 + 1) ^ swz(row))];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = wm * 128 + j * 32 + l31;
+                    af0[j] = la[row * 8 + (c0 ^ swz(row))]; af1[j] = la[row * 8 + ((c0 + 1) ^ swz(row))];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma32_f8(wf0[i], wf1[i], af0[j], af1[j], acc[i][j]);
+            }
+            return;
+        }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             uint4 wf[2], af[4];
@@ -419,10 +458,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
                 uint4* la = stage(buf, 0) + (p * 64 + wave * 8) * 8;
                 uint4* lw = stage(buf, 1) + (p * 64 + wave * 8) * 8;
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)((const char*)A + aoff[p] + (long)kt * BK * 2),
+                    (const __attribute__((address_space(1))) void*)((const char*)A + aoff[p] + (long)kt * 128),
                     (__attribute__((address_space(3))) void*)la, 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)((const char*)W + woff[p] + (long)kt * BK * 2),
+                    (const __attribute__((address_space(1))) void*)((const char*)W + woff[p] + (long)kt * 128),
                     (__attribute__((address_space(3))) void*)lw, 16, 0, 0);
             }
         };
@@ -459,6 +498,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
         const int col = n0 + h * 128 + c4 * 4;
         float bias4[4] = {0.f, 0.f, 0.f, 0.f};
         if (e.bias) { const float4 b = *(const float4*)(e.bias + col); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+        float cs4[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (FP8) { const float4 c = *(const float4*)(e.col_scale + col); cs4[0] = c.x; cs4[1] = c.y; cs4[2] = c.z; cs4[3] = c.w; }
         int which = 0, head = 0, d = 0;
         if (e.out_mode == 1) {
             const int D = e.heads * e.head_dim;
@@ -478,7 +519,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
             const int pass = grp * 8 + ps;
             const int lr = pass * 16 + rg, row = m0 + lr;
             const float4 c = *(const float4*)(ldsC + lr * 128 + ((c4 ^ (lr & 31)) << 2));
-            float v[4] = {c.x + bias4[0], c.y + bias4[1], c.z + bias4[2], c.w + bias4[3]};
+            float v[4];
+            if constexpr (FP8) {
+                const float rs = e.row_scale[min(row, M - 1)];
+                v[0] = fmaf(c.x * rs, cs4[0], bias4[0]); v[1] = fmaf(c.y * rs, cs4[1], bias4[1]);
+                v[2] = fmaf(c.z * rs, cs4[2], bias4[2]); v[3] = fmaf(c.w * rs, cs4[3], bias4[3]);
+            } else {
+                v[0] = c.x + bias4[0]; v[1] = c.y + bias4[1]; v[2] = c.z + bias4[2]; v[3] = c.w + bias4[3];
+            }
             if (e.resid_dtype == MSAM_F32) { v[0] += rt[ps].x; v[1] += rt[ps].y; v[2] += rt[ps].z; v[3] += rt[ps].w; }
             if (e.act == MSAM_ACT_GELU) {
                 const f32x2_t g01 = gelu_erf2(f32x2_t{v[0], v[1]}), g23 = gelu_erf2(f32x2_t{v[2], v[3]});
@@ -770,7 +818,9 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.act = p->act; e.out = p->out; e.out_dtype = p->out_dtype; e.ldc = p->ldc;
     e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
+    e.row_scale = nullptr; e.col_scale = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    if (p->ln_mode && p->a_dtype == MSAM_FP8) { msam_set_error("msam_gemm_bf16(fp8): no fused LayerNorm epilogue"); return 1; }
     if (p->ln_mode) {
         if (p->N != 256 || p->out_mode != 0 || !p->ln_w || !p->ln_b || p->ln_mode < 0 || p->ln_mode > 2) {
             msam_set_error("msam_gemm_bf16: fused LayerNorm needs N == 256, plain output and ln_w / ln_b");
@@ -796,8 +846,36 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         if (prof_ln) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
         return msam_check_launch("msam_gemm_bf16(ln)");
     }
-    int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     const bool prof = g_prof_on && g_prof_n < PROF_MAX;
+    if (p->a_dtype == MSAM_FP8) {
+        // fp8 e4m3 operands: 256 x 256 tile kernel only (the encoder's projections)
+        if (p->N % G2 || p->K % 128 || (p->lda % 16) || (p->ldw % 16) || p->ln_mode || p->out_mode == 2 || p->table ||
+            p->use_glds || !p->row_scale || !p->col_scale ||
+            (p->resid && (p->resid_dtype != MSAM_F32 || p->resid_rows))) {
+            msam_set_error("msam_gemm_bf16(fp8): need N % 256 == 0, K % 128 == 0, lda / ldw % 16 == 0, row_scale and col_scale, plain or qkv-split "
+                           "output, fp32 residual without row wrap, no table");
+            return 1;
+        }
+        static bool attr8 = false;
+        if (!attr8) {
+            if (hipFuncSetAttribute((const void*)gemm256_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
+                msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
+                return 2;
+            }
+            attr8 = true;
+        }
+        e.row_scale = p->row_scale; e.col_scale = p->col_scale;
+        if (prof) {
+            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
+            (void)hipEventRecord(g_prof[g_prof_n].a, s);
+        }
+        const int tiles8 = ((p->M + G2 - 1) / G2) * (p->N / G2);
+        hipLaunchKernelGGL((gemm256_kernel<1, true>), dim3(tiles8), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda,
+                           (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+        if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
+        return msam_check_launch("msam_gemm_bf16(fp8)");
+    }
+    int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
     // large shapes (the encoder's projections): 256 x 256 tile kernel.  MSAM_GEMM256=0 keeps the 128 x 128 kernel (A/B runs)
     static int use256 = -1, staging256 = 0;
     if (use256 < 0) {

@@ -84,6 +84,100 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// ---- fp8 (OCP e4m3) activations with one scale per row (= per token), BASELINE config 5 ------------------------------
+// q = round_e4m3(y * 448 / amax(row)), scale = amax / 448  (448 = largest e4m3 value; an all-zero row gets scale 1).
+MSAM_DEVINL uint32_t pack4_fp8(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (uint32_t)w;
+}
+MSAM_DEVINL float wave_max64(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// LayerNorm with fp8 output: one wave per row, dim == 256 * VEC; the normalised row never leaves the registers
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_fp8_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float eps, long rows, int dim,
+                                                            uint32_t* __restrict__ out, float* __restrict__ row_scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * dim;
+    float v[VEC * 4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const float4 t = *(const float4*)(xr + (i * 64 + lane) * 4);
+        v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
+        s += (t.x + t.y) + (t.z + t.w);
+    }
+    const float mean = wave_sum64(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC * 4; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)dim + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 w4 = *(const float4*)(w + c), b4 = *(const float4*)(b + c);
+        v[i * 4 + 0] = (v[i * 4 + 0] - mean) * rstd * w4.x + b4.x; v[i * 4 + 1] = (v[i * 4 + 1] - mean) * rstd * w4.y + b4.y;
+        v[i * 4 + 2] = (v[i * 4 + 2] - mean) * rstd * w4.z + b4.z; v[i * 4 + 3] = (v[i * 4 + 3] - mean) * rstd * w4.w + b4.w;
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i * 4]), fabsf(v[i * 4 + 1])), fmaxf(fabsf(v[i * 4 + 2]), fabsf(v[i * 4 + 3]))));
+    }
+    amax = wave_max64(amax);
+    const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / scale;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i)
+        out[(row * dim) / 4 + i * 64 + lane] = pack4_fp8(v[i * 4] * inv, v[i * 4 + 1] * inv, v[i * 4 + 2] * inv, v[i * 4 + 3] * inv);
+    if (lane == 0) row_scale[row] = scale;
+}
+
+// bf16 [rows, dim] -> fp8 [rows, dim] + row scales; one wave per row, 8 values (16 B) per lane and step, dim % 8 == 0, dim <= 5120
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const u16* __restrict__ x, long rows, int dim,
+                                                             uint2* __restrict__ out, float* __restrict__ row_scale) {
+    constexpr int MAXS = 10;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const u16* xr = x + row * dim;
+    uint4 raw[MAXS];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (c < dim) {
+            raw[i] = *(const uint4*)(xr + c);
+            const uint32_t ww[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                amax = fmaxf(amax, fmaxf(fabsf(bf2f((u16)(ww[k] & 0xffff))), fabsf(bf2f((u16)(ww[k] >> 16)))));
+        }
+    }
+    amax = wave_max64(amax);
+    const float scale = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / scale;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < dim) {
+            const uint32_t ww[4] = {raw[i].x, raw[i].y, raw[i].z, raw[i].w};
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f[2 * k] = bf2f((u16)(ww[k] & 0xffff)) * inv; f[2 * k + 1] = bf2f((u16)(ww[k] >> 16)) * inv; }
+            uint2 o; o.x = pack4_fp8(f[0], f[1], f[2], f[3]); o.y = pack4_fp8(f[4], f[5], f[6], f[7]);
+            out[(row * dim + c) / 8] = o;
+        }
+    }
+    if (lane == 0) row_scale[row] = scale;
+}
+
 // dim == 64 fast path: one 16-lane group per row (4 rows per wave), float4 per lane.
 __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ b, float eps, long rows,
@@ -204,6 +298,31 @@ extern "C" int msam_layernorm(const float* x, const float* weight, const float* 
     else { msam_set_error("msam_layernorm: dim > 1280 unsupported"); return 1; }
 #undef LN_LAUNCH
     return msam_check_launch("msam_layernorm");
+}
+
+extern "C" int msam_layernorm_fp8(const float* x, const float* weight, const float* bias, float eps, int64_t rows, int32_t dim,
+                                  void* out_fp8, float* row_scale, void* stream) {
+    if (!x || !weight || !bias || !out_fp8 || !row_scale || rows <= 0) { msam_set_error("msam_layernorm_fp8: bad arguments"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define LN8_LAUNCH(V) hipLaunchKernelGGL(layernorm_fp8_kernel<V>, grid, block, 0, s, x, weight, bias, eps, (long)rows, dim, \
+                                         (uint32_t*)out_fp8, row_scale)
+    if (dim == 768) LN8_LAUNCH(3);
+    else if (dim == 1024) LN8_LAUNCH(4);
+    else if (dim == 1280) LN8_LAUNCH(5);
+    else { msam_set_error("msam_layernorm_fp8: dim must be 768, 1024 or 1280"); return 1; }
+#undef LN8_LAUNCH
+    return msam_check_launch("msam_layernorm_fp8");
+}
+
+extern "C" int msam_quant_rows_fp8(const void* x_bf16, int64_t rows, int32_t dim, void* out_fp8, float* row_scale, void* stream) {
+    if (!x_bf16 || !out_fp8 || !row_scale || rows <= 0 || dim <= 0 || dim % 8 || dim > 5120) {
+        msam_set_error("msam_quant_rows_fp8: bad arguments (dim % 8 == 0, dim <= 5120)");
+        return 1;
+    }
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const u16*)x_bf16, (long)rows, dim, (uint2*)out_fp8, row_scale);
+    return msam_check_launch("msam_quant_rows_fp8");
 }
 
 extern "C" int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream) {

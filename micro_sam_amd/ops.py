@@ -42,6 +42,64 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+# ---- fp8 (OCP e4m3) encoder path, BASELINE config 5 -------------------------------------------------------------------
+
+def quant_rows_fp8(x: torch.Tensor):
+    """bf16 [rows, dim] -> (fp8 e4m3 [rows, dim], fp32 row scales [rows]) with q = round(x * 448 / amax(row))."""
+    _lib.require_gpu()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.dim() == 2
+    rows, dim = x.shape
+    out = torch.empty((rows, dim), dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().msam_quant_rows_fp8(x.data_ptr(), rows, dim, out.data_ptr(), scale.data_ptr(), _lib.stream_ptr()),
+               "msam_quant_rows_fp8")
+    return out, scale
+
+
+def layernorm_fp8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6):
+    """LayerNorm of fp32 [rows, dim] (dim in 768 / 1024 / 1280) straight to fp8 rows + row scales."""
+    _lib.require_gpu()
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+    rows, dim = x.shape
+    out = torch.empty((rows, dim), dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().msam_layernorm_fp8(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), float(eps), rows, dim,
+                                              out.data_ptr(), scale.data_ptr(), _lib.stream_ptr()), "msam_layernorm_fp8")
+    return out, scale
+
+
+def quant_weight_fp8(w: torch.Tensor):
+    """fp32 / bf16 weight [N, K] -> (fp8 e4m3 [N, K], fp32 per-output-channel scales [N]); torch's e4m3fn is the OCP format
+    of gfx950.  Host-side preparation (done once per model)."""
+    wf = w.detach().float()
+    amax = wf.abs().amax(dim=1)
+    scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (wf / scale[:, None]).to(torch.float8_e4m3fn).contiguous(), scale.contiguous()
+
+
+def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE, out_dtype: torch.dtype = torch.float32,
+             resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act((a8[M,K] @ w8[N,K]^T) * a_scale[:, None] * w_scale[None, :] + bias + resid) on the MX fp8 MFMA (unit block scales)."""
+    _lib.require_gpu()
+    assert a8.dtype == torch.float8_e4m3fn and w8.dtype == torch.float8_e4m3fn and a8.is_contiguous() and w8.is_contiguous()
+    M, K = a8.shape
+    N = w8.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a8.device)
+    p = _lib.GemmParams()
+    p.A, p.lda, p.W, p.ldw, p.M, p.N, p.K = a8.data_ptr(), K, w8.data_ptr(), K, M, N, K
+    p.bias = _lib.ptr(bias)
+    if resid is not None:
+        assert resid.dtype == torch.float32
+        p.resid, p.resid_dtype, p.resid_rows, p.ldr = resid.data_ptr(), F32, 0, resid.shape[1]
+    p.act = act
+    p.out, p.out_dtype, p.ldc = out.data_ptr(), (F32 if out.dtype == torch.float32 else BF16), N
+    p.a_dtype, p.row_scale, p.col_scale = _lib.FP8, a_scale.data_ptr(), w_scale.data_ptr()
+    _lib.check(_lib.load().msam_gemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_gemm_bf16(fp8)")
+    return out
+
+
 def gemm_qkv(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, heads: int, use_glds: int = 0):
     """QKV projection with the ViT attention layout epilogue: returns q, k, v as bf16 [B,heads,tokens,hd]."""
     M, K = a.shape

@@ -421,3 +421,59 @@ def test_upscale_fused(env, P, mask0, nmask):
     scale = ref.abs().max().item()
     err = (out[sel] - ref).abs()
     assert err.max().item() <= 6e-3 * scale and err.mean().item() <= 3e-4 * scale
+
+
+# ---------------------------------------------------------------------------------------------- fp8 (BASELINE config 5)
+
+def test_fp8_row_quant_and_layernorm(env):
+    """Row quantisation to OCP e4m3: scale = amax / 448, values round-to-nearest-even like torch's float8_e4m3fn cast."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(31)
+    x = _bf(torch.randn(1000, 3072, generator=g) * torch.rand(1000, 1, generator=g) * 5).to(dev)
+    x[7] = 0                                                                     # all-zero row: scale 1, zeros out
+    q, sc = ops.quant_rows_fp8(x)
+    amax = x.float().abs().amax(1)
+    ref_sc = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(sc, ref_sc, rtol=1e-6, atol=0)
+    ref_q = (x.float().cpu() * (1.0 / ref_sc.cpu())[:, None]).to(torch.float8_e4m3fn)            # cast on the host
+    assert (q.cpu().float() != ref_q.float()).float().mean().item() <= 1e-4           # (the reciprocal differs from a division by 1 ulp)
+    assert (q.float() * sc[:, None] - x.float()).abs().max().item() <= x.float().abs().max().item() * 0.07
+    assert float(q[7].float().abs().max()) == 0.0 and float(sc[7]) == 1.0
+    for D in (768, 1280):
+        xf = (torch.randn(513, D, generator=g) * 3 + 0.5).to(dev)
+        w = (torch.randn(D, generator=g) * 0.2 + 1).to(dev); b = (torch.randn(D, generator=g) * 0.1).to(dev)
+        q, sc = ops.layernorm_fp8(xf, w, b)
+        y = F.layer_norm(xf, (D,), w, b, eps=1e-6)
+        ya = y.abs().amax(1)
+        assert torch.allclose(sc, ya / 448.0, rtol=1e-4)
+        d = (q.float() * sc[:, None] - y).abs()
+        assert (d <= 0.0625 * y.abs() + ya[:, None] * 2.0 ** -9 + 1e-6).all()   # e4m3: 3 mantissa bits, subnormal step 2^-9
+
+
+@pytest.mark.parametrize("M,N,K,mode", [(4096 + 24, 2304, 768, "plain"), (8192, 768, 3072, "resid"), (4096, 3072, 768, "gelu")])
+def test_gemm_fp8_vs_torch(env, M, N, K, mode):
+    """fp8 x fp8 GEMM on the MX MFMA (unit block scales) with row / column scales in the epilogue: exact fp8 operands, so the
+    reference is a plain fp32 matmul of the dequantised operands (only the accumulation order differs)."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(40 + N)
+    a = _bf(torch.randn(M, K, generator=g)).to(dev)
+    a8, a_sc = ops.quant_rows_fp8(a)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K) * (torch.rand(N, 1, generator=g) + 0.5)).to(dev)   # asymmetric rows
+    w8, w_sc = ops.quant_weight_fp8(w.cpu())                                               # host-side cast
+    w8, w_sc = w8.to(dev), w_sc.to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ref = (a8.float() @ w8.float().t()) * a_sc[:, None] * w_sc[None, :] + bias
+    if mode == "plain":
+        out = ops.gemm_fp8(a8, a_sc, w8, w_sc, bias)
+        assert _close(out, ref, 2e-3, 2e-3)
+        # and the quantised product tracks the unquantised one to fp8 accuracy (sanity of the scales)
+        full = a.float() @ w.t() + bias
+        assert (out - full).abs().mean().item() <= 0.05 * full.abs().mean().item()
+    elif mode == "resid":
+        x = torch.randn(M, N, generator=g).to(dev)
+        keep = x.clone()
+        ops.gemm_fp8(a8, a_sc, w8, w_sc, bias, resid=x, out=x)                              # in place, like the encoder
+        assert _close(x, ref + keep, 2e-3, 2e-3)
+    else:
+        out = ops.gemm_fp8(a8, a_sc, w8, w_sc, bias, act=ops.ACT_GELU, out_dtype=torch.bfloat16)
+        assert _close(out, F.gelu(ref), 2e-2, 1e-2)

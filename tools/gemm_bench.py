@@ -45,3 +45,13 @@ for (M, N, K, name) in SHAPES:
         line.append(f"st{st}: {ms:.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF {'ok' if same else 'DIFF'}")
     print(f"{name:8s} {M}x{N}x{K}  " + " | ".join(line), flush=True)
 lib.msam_gemm256_set_staging(-1)
+# fp8 (MX MFMA, unit block scales) on the same shapes
+for (M, N, K, name) in SHAPES:
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    a8, a_sc = ops.quant_rows_fp8(a)
+    w8, w_sc = ops.quant_weight_fp8(torch.rand(N, K, generator=g) * 2 - 1)
+    w8, w_sc = w8.to(dev), w_sc.to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ms = timeit(lambda: ops.gemm_fp8(a8, a_sc, w8, w_sc, bias, out=out, act=ops.ACT_GELU))
+    print(f"{name:8s} {M}x{N}x{K}  fp8: {ms:.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF", flush=True)
