@@ -216,6 +216,14 @@ typedef struct {
      * heads are zero-padded by the caller: qkv_w bf16 [3*heads*96, D] / qkv_b fp32 [3*heads*96] (zero rows), rel_h / rel_w
      * bf16 [2S-1, 96] (zero columns), proj_w bf16 [D, heads*96] (zero columns). */
     int32_t head_dim_stored;
+    /* BASELINE config 5: fp8 != 0 runs qkv / proj / lin1 / lin2 of every block on fp8 e4m3 operands (MX MFMA): activations are
+     * quantised per token by msam_layernorm_fp8 / msam_quant_rows_fp8, the weights below are e4m3 [N, K] (same shapes as the
+     * bf16 ones, incl. the head padding) with one fp32 scale per output channel.  Attention, patch embedding and neck stay bf16. */
+    int32_t fp8;
+    const void* qkv_w8[MSAM_MAX_BLOCKS]; const float* qkv_cs[MSAM_MAX_BLOCKS];
+    const void* proj_w8[MSAM_MAX_BLOCKS]; const float* proj_cs[MSAM_MAX_BLOCKS];
+    const void* lin1_w8[MSAM_MAX_BLOCKS]; const float* lin1_cs[MSAM_MAX_BLOCKS];
+    const void* lin2_w8[MSAM_MAX_BLOCKS]; const float* lin2_cs[MSAM_MAX_BLOCKS];
 } msam_encoder_t;
 
 int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B);

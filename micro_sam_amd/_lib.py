@@ -64,7 +64,9 @@ class EncoderParams(C.Structure):
         ("proj_w", _blk), ("proj_b", _blk), ("ln2_w", _blk), ("ln2_b", _blk),
         ("lin1_w", _blk), ("lin1_b", _blk), ("lin2_w", _blk), ("lin2_b", _blk),
         ("neck0_w", _vp), ("neck1_w", _vp), ("neck1_b", _vp), ("neck2_w", _vp), ("neck3_w", _vp), ("neck3_b", _vp),
-        ("use_glds", _i32), ("head_dim_stored", _i32),
+        ("use_glds", _i32), ("head_dim_stored", _i32), ("fp8", _i32),
+        ("qkv_w8", _blk), ("qkv_cs", _blk), ("proj_w8", _blk), ("proj_cs", _blk),
+        ("lin1_w8", _blk), ("lin1_cs", _blk), ("lin2_w8", _blk), ("lin2_cs", _blk),
     ]
 
 

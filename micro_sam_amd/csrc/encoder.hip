@@ -14,14 +14,17 @@ int msam_check_launch(const char* what);
 namespace {
 constexpr long TOK = 4096;
 inline long al(long x) { return (x + 255) & ~255L; }
-struct EncWork { float* x; u16 *xn, *patches, *q, *k, *v, *attn, *hid, *n1, *col; float *n0, *n2; };
+struct EncWork { float* x; u16 *xn, *patches, *q, *k, *v, *attn, *hid, *n1, *col; float *n0, *n2;
+                 unsigned char *xn8, *attn8, *hid8; float *rs_x, *rs_a, *rs_h; };     // fp8 copies + row scales (fp8 mode)
 // DA = heads * stored head_dim: width of q / k / v / attention output (== D unless the heads are zero-padded, vit_h)
-long enc_bytes(int D, int DA, int B) {
+long enc_bytes(int D, int DA, int B, int fp8) {
     const long R = (long)B * TOK;
-    return al(R * D * 4) + al(R * D * 2) + al(R * 768 * 2) + 3 * al(R * DA * 2) + al(R * DA * 2) + al(R * 4 * D * 2) +
-           al(R * 256 * 2) + al(R * 2304 * 2) + 2 * al(R * 256 * 4);
+    long n = al(R * D * 4) + al(R * D * 2) + al(R * 768 * 2) + 3 * al(R * DA * 2) + al(R * DA * 2) + al(R * 4 * D * 2) +
+             al(R * 256 * 2) + al(R * 2304 * 2) + 2 * al(R * 256 * 4);
+    if (fp8) n += al(R * D) + al(R * DA) + al(R * 4 * D) + 3 * al(R * 4);
+    return n;
 }
-EncWork carve(void* base, int D, int DA, int B) {
+EncWork carve(void* base, int D, int DA, int B, int fp8) {
     const long R = (long)B * TOK;
     char* p = (char*)base; EncWork w;
     auto take = [&](long b) { char* r = p; p += al(b); return r; };
@@ -30,6 +33,11 @@ EncWork carve(void* base, int D, int DA, int B) {
     w.attn = (u16*)take(R * DA * 2); w.hid = (u16*)take(R * 4 * D * 2);
     w.n1 = (u16*)take(R * 256 * 2); w.col = (u16*)take(R * 2304 * 2);
     w.n0 = (float*)take(R * 256 * 4); w.n2 = (float*)take(R * 256 * 4);
+    w.xn8 = w.attn8 = w.hid8 = nullptr; w.rs_x = w.rs_a = w.rs_h = nullptr;
+    if (fp8) {
+        w.xn8 = (unsigned char*)take(R * D); w.attn8 = (unsigned char*)take(R * DA); w.hid8 = (unsigned char*)take(R * 4 * D);
+        w.rs_x = (float*)take(R * 4); w.rs_a = (float*)take(R * 4); w.rs_h = (float*)take(R * 4);
+    }
     return w;
 }
 // stored head_dim: 64 as is (vit_b / vit_l); 80 (vit_h) must come zero-padded to 96; 0 = unsupported
@@ -47,7 +55,7 @@ extern "C" int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32
     if (!enc || B <= 0) return 0;
     const int hs = stored_head_dim(enc);
     if (!hs) return 0;
-    return enc_bytes(enc->embed_dim, enc->heads * hs, B);
+    return enc_bytes(enc->embed_dim, enc->heads * hs, B, enc->fp8);
 }
 
 extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_f32, const uint8_t* img_u8, int32_t h,
@@ -63,9 +71,11 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
     }
     const int DA = H * HS;
     const float scale = 1.0f / sqrtf((float)(D / H));
-    if (workspace_bytes < enc_bytes(D, DA, B)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
+    if (workspace_bytes < enc_bytes(D, DA, B, enc->fp8)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
+    const bool fp8 = enc->fp8 != 0;
+    if (fp8 && (D % 128 || DA % 128)) { msam_set_error("msam_encoder_forward: fp8 needs embed_dim and heads * head_dim % 128 == 0"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    EncWork w = carve(workspace, D, DA, B);
+    EncWork w = carve(workspace, D, DA, B, enc->fp8);
     const int R = (int)(B * TOK);
     int e;
 #define CHECK(x) do { if ((e = (x))) return e; } while (0)
@@ -83,9 +93,27 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
     else CHECK(msam_patchify(img_f32, B, w.patches, s));
     CHECK(gemm(w.patches, 768, enc->patch_w, D, 768, enc->patch_b, w.x, MSAM_F32, D, 0, nullptr, 0, 0, enc->pos_embed,
                (int)TOK, D, D));
+    // fp8 projection: A fp8 [R, K] with row scales, W fp8 [N, K] with column scales
+    auto gemm8 = [&](const void* A8, const float* rs, const void* W8, const float* cs, int N, int K, const float* bias, void* o,
+                     int odt, long ldc, int act, const void* resid) {
+        msam_gemm_t g{};
+        g.A = A8; g.lda = K; g.W = W8; g.ldw = K; g.M = R; g.N = N; g.K = K; g.bias = bias;
+        g.resid = resid; g.resid_dtype = resid ? MSAM_F32 : 0; g.ldr = N; g.act = act; g.out = o; g.out_dtype = odt; g.ldc = ldc;
+        g.a_dtype = MSAM_FP8; g.row_scale = rs; g.col_scale = cs;
+        return msam_gemm_bf16(&g, s);
+    };
     for (int i = 0; i < enc->depth; ++i) {
-        CHECK(msam_layernorm(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
-        {
+        if (fp8) {
+            if (!enc->qkv_w8[i] || !enc->qkv_cs[i] || !enc->proj_w8[i] || !enc->proj_cs[i] || !enc->lin1_w8[i] || !enc->lin1_cs[i] ||
+                !enc->lin2_w8[i] || !enc->lin2_cs[i]) { msam_set_error("msam_encoder_forward: fp8 weights / scales missing"); return 1; }
+            CHECK(msam_layernorm_fp8(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn8, w.rs_x, s));
+            msam_gemm_t g{};
+            g.A = w.xn8; g.lda = D; g.W = enc->qkv_w8[i]; g.ldw = D; g.M = R; g.N = 3 * DA; g.K = D; g.bias = enc->qkv_b[i];
+            g.out_mode = 1; g.q = w.q; g.k = w.k; g.v = w.v; g.heads = H; g.head_dim = HS; g.tokens = (int)TOK;
+            g.a_dtype = MSAM_FP8; g.row_scale = w.rs_x; g.col_scale = enc->qkv_cs[i];
+            CHECK(msam_gemm_bf16(&g, s));
+        } else {
+            CHECK(msam_layernorm(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
             msam_gemm_t g{};
             g.A = w.xn; g.lda = D; g.W = enc->qkv_w[i]; g.ldw = D; g.M = R; g.N = 3 * DA; g.K = D; g.bias = enc->qkv_b[i];
             g.out_mode = 1; g.q = w.q; g.k = w.k; g.v = w.v; g.heads = H; g.head_dim = HS; g.tokens = (int)TOK;
@@ -96,12 +124,22 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
             CHECK(msam_global_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], B, H, HS, scale, w.attn, s));
         else
             CHECK(msam_window_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], enc->qkv_b[i], B, H, HS, scale, w.attn, s));
+        if (fp8) {
+            CHECK(msam_quant_rows_fp8(w.attn, R, DA, w.attn8, w.rs_a, s));
+            CHECK(gemm8(w.attn8, w.rs_a, enc->proj_w8[i], enc->proj_cs[i], D, DA, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x));
+            CHECK(msam_layernorm_fp8(w.x, enc->ln2_w[i], enc->ln2_b[i], 1e-6f, R, D, w.xn8, w.rs_x, s));
+            CHECK(gemm8(w.xn8, w.rs_x, enc->lin1_w8[i], enc->lin1_cs[i], 4 * D, D, enc->lin1_b[i], w.hid, MSAM_BF16, 4 * D,
+                        MSAM_ACT_GELU, nullptr));
+            CHECK(msam_quant_rows_fp8(w.hid, R, 4 * D, w.hid8, w.rs_h, s));
+            CHECK(gemm8(w.hid8, w.rs_h, enc->lin2_w8[i], enc->lin2_cs[i], D, 4 * D, enc->lin2_b[i], w.x, MSAM_F32, D, 0, w.x));
+        } else {
         CHECK(gemm(w.attn, DA, enc->proj_w[i], D, DA, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0, 0, 0));
         CHECK(msam_layernorm(w.x, enc->ln2_w[i], enc->ln2_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
         CHECK(gemm(w.xn, D, enc->lin1_w[i], 4 * D, D, enc->lin1_b[i], w.hid, MSAM_BF16, 4 * D, MSAM_ACT_GELU, nullptr, 0, 0,
                    nullptr, 0, 0, 0));
         CHECK(gemm(w.hid, 4 * D, enc->lin2_w[i], D, 4 * D, enc->lin2_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0,
                    0, 0));
+        }
         if (tap && tap_block == i)
             if (hipMemcpyAsync(tap, w.x, (size_t)R * D * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) {
                 msam_set_error("msam_encoder_forward: tap copy failed");

@@ -106,12 +106,23 @@ class ImageEncoderViT(nn.Module):
             nn.Conv2d(embed_dim, PROMPT_DIM, kernel_size=1, bias=False), LayerNorm2d(PROMPT_DIM),
             nn.Conv2d(PROMPT_DIM, PROMPT_DIM, kernel_size=3, padding=1, bias=False), LayerNorm2d(PROMPT_DIM))
         self.use_glds = 0
+        self.precision = "bf16"          # "fp8": qkv / proj / lin1 / lin2 on e4m3 operands (set_precision; BASELINE config 5)
         self._prep = None
         self._workspace = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     def invalidate(self) -> None:
         self._prep = None
+
+    def set_precision(self, precision: str) -> None:
+        """"bf16" (default: every matrix-product operand bf16) or "fp8": the four large projections of every block take OCP
+        e4m3 operands on the MX-scaled MFMA (per-token activation scales, per-output-channel weight scales; fp32
+        accumulation, scales applied in the GEMM epilogue); attention, patch embedding and neck stay bf16."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16' or 'fp8'")
+        if precision != self.precision:
+            self.precision = precision
+            self.invalidate()
 
     def _prepare(self):
         if self._prep is not None:
@@ -162,11 +173,19 @@ class ImageEncoderViT(nn.Module):
             p.ln2_w[i], p.ln2_b[i] = k(_f32(blk.norm2.weight)), k(_f32(blk.norm2.bias))
             p.lin1_w[i], p.lin1_b[i] = k(_bf16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
             p.lin2_w[i], p.lin2_b[i] = k(_bf16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
+            if self.precision == "fp8":
+                from .ops import quant_weight_fp8
+                for name, wt in (("qkv", pad_rows(blk.attn.qkv.weight)), ("proj", pad_cols(blk.attn.proj.weight, H)),
+                                 ("lin1", blk.mlp.lin1.weight), ("lin2", blk.mlp.lin2.weight)):
+                    w8, cs = quant_weight_fp8(wt.detach().float().cpu())          # e4m3 cast on the host (once per model)
+                    getattr(p, name + "_w8")[i] = k(w8.to(dev))
+                    getattr(p, name + "_cs")[i] = k(cs.to(dev))
         p.neck0_w = k(_bf16(self.neck[0].weight.reshape(PROMPT_DIM, D)))
         p.neck1_w, p.neck1_b = k(_f32(self.neck[1].weight)), k(_f32(self.neck[1].bias))
         p.neck2_w = k(_bf16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(PROMPT_DIM, 9 * PROMPT_DIM)))
         p.neck3_w, p.neck3_b = k(_f32(self.neck[3].weight)), k(_f32(self.neck[3].bias))
         p.use_glds = int(self.use_glds)
+        p.fp8 = 1 if self.precision == "fp8" else 0
         self._prep = (p, keep)
         return self._prep
 

@@ -63,8 +63,12 @@ class Prec:
     """Rounding policy (see module docstring)."""
 
     def __init__(self, precision: str = "fp32"):
-        assert precision in ("fp32", "bf16"), precision
-        self.bf16 = precision == "bf16"
+        assert precision in ("fp32", "bf16", "fp8"), precision
+        # "fp8" (BASELINE config 5): the bf16 policy everywhere, except that the four large projections of every encoder
+        # block (qkv, proj, lin1, lin2) take OCP e4m3 operands - activations with one scale per token, weights with one
+        # scale per output channel (linear_q)
+        self.bf16 = precision in ("bf16", "fp8")
+        self.fp8 = precision == "fp8"
 
     def r(self, x: Tensor) -> Tensor:
         """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode."""
@@ -76,6 +80,28 @@ class Prec:
 
     def matmul(self, a: Tensor, b: Tensor) -> Tensor:
         return torch.matmul(self.r(a), self.r(b))
+
+    @staticmethod
+    def quant_rows_e4m3(x: Tensor) -> Tensor:
+        """Per-row (last axis) e4m3 quantise / dequantise: q = round(x * (1 / scale)), scale = amax / 448 (1 for a zero row):
+        the arithmetic of msam_layernorm_fp8 / msam_quant_rows_fp8."""
+        amax = x.abs().amax(dim=-1, keepdim=True)
+        scale = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+        q = (x * (1.0 / scale)).to(torch.float8_e4m3fn).to(torch.float32)
+        return q * scale
+
+    def linear_q(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, src: str = "fp32") -> Tensor:
+        """One of the four large encoder projections.  fp8 mode: x is quantised per token from fp32 (LayerNorm outputs,
+        src="fp32") or from its bf16 copy (attention output, MLP hidden: src="bf16"), w per output channel
+        (micro_sam_amd.ops.quant_weight_fp8).  Other modes: ``linear``."""
+        if not self.fp8:
+            return self.linear(x, w, b)
+        xq = self.quant_rows_e4m3(x if src == "fp32" else self.r(x))
+        amax = w.abs().amax(dim=1, keepdim=True)
+        ws = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        wq = (w / ws).to(torch.float8_e4m3fn).to(torch.float32) * ws
+        y = F.linear(xq, wq)
+        return y if b is None else y + b
 
 
 # ----------------------------------------------------------------------------------------------
@@ -157,7 +183,7 @@ def _attention_relpos(sd: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int
     Bp, H, W, D = x.shape
     hd = D // num_heads
     scale = hd ** -0.5
-    qkv = p.linear(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"])
+    qkv = p.linear_q(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"], src="fp32")
     qkv = p.r(qkv)  # HIP path stores q, k, v in bf16
     qkv = qkv.reshape(Bp, H * W, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, Bp * num_heads, H * W, hd).unbind(0)
@@ -176,7 +202,7 @@ def _attention_relpos(sd: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int
     else:
         o = attn.softmax(dim=-1) @ v
     o = o.view(Bp, num_heads, H, W, hd).permute(0, 2, 3, 1, 4).reshape(Bp, H, W, D)
-    return p.linear(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    return p.linear_q(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"], src="bf16")
 
 
 def _window_partition(x: Tensor, ws: int):
@@ -235,9 +261,9 @@ def image_encoder(sd: Dict[str, Tensor], x: Tensor, model_type: str = "vit_b", p
             y = _window_unpartition(y, WINDOW, pad_hw, (H, W))
         x = shortcut + y
         y = F.layer_norm(x, (D,), sd[bp + "norm2.weight"], sd[bp + "norm2.bias"], eps=1e-6)
-        y = p.linear(y, sd[bp + "mlp.lin1.weight"], sd[bp + "mlp.lin1.bias"])
+        y = p.linear_q(y, sd[bp + "mlp.lin1.weight"], sd[bp + "mlp.lin1.bias"], src="fp32")
         y = F.gelu(y)                                          # exact erf GELU
-        y = p.linear(y, sd[bp + "mlp.lin2.weight"], sd[bp + "mlp.lin2.bias"])
+        y = p.linear_q(y, sd[bp + "mlp.lin2.weight"], sd[bp + "mlp.lin2.bias"], src="bf16")
         x = x + y
         if return_blocks:
             taps.append(x.clone())

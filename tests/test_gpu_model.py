@@ -498,3 +498,50 @@ def test_vit_h_encoder_and_decode_vs_oracle():
                                       return_logits=True, precision="bf16")
     assert tuple(masks.shape) == (1, 3, 1024, 1024) and (iou.cpu() - iou_r).abs().max().item() <= 1e-2
     assert ((low.cpu() > 0) != (low_r > 0)).float().mean().item() <= 0.02
+
+
+def test_fp8_encoder_vs_oracle(ctx):
+    """BASELINE config 5: encoder with fp8 (OCP e4m3) projections on the MX MFMA.  The oracle's fp8 mode quantises at the same
+    places (per-token activations, per-channel weights), so the embedding matches it like the bf16 path matches the bf16 oracle;
+    against the fp32 reference the error is reported honestly (larger than bf16, as expected for 3 mantissa bits).  The bf16
+    decoder then runs on the fp8 embedding: low-res sign agreement with the fp32 oracle."""
+    from oracle import sam_ref as S
+    p, sd = ctx["predictor"], ctx["sd"]
+    enc = p.model.image_encoder
+    with torch.no_grad():
+        ref8, taps8 = S.image_encoder(sd, ctx["x"], precision="fp8", return_blocks=True)
+    enc.set_precision("fp8")
+    try:
+        out, tap = enc(ctx["x"].cuda(), tap_block=2)
+        r = taps8[2].reshape(-1, 768)
+        dt = (tap.cpu() - r).abs()
+        d = (out.cpu() - ref8).abs()
+        print(f"fp8 encoder vs fp8-mode oracle: block-2 stream max |d| {dt.max().item():.4f} mean {dt.mean().item():.5f} "
+              f"(stream max {r.abs().max().item():.2f}); embedding max |d| {d.max().item():.4f} mean {d.mean().item():.5f}")
+        # the two implementations round at the same places, but a value that lands on the other side of an e4m3 rounding
+        # boundary (3 mantissa bits) moves by 6 % instead of bf16's 0.4 %: the agreement with the fp8-mode oracle is ~16x looser
+        # than in bf16 (measured: stream mean |d| 2 % of its mean magnitude after 3 blocks, embedding mean |d| 0.025); the
+        # meaningful check is the distance to the fp32 reference below
+        assert dt.max().item() <= 0.05 * r.abs().max().item() + 0.05 and dt.mean().item() <= 0.04 * r.abs().mean().item()
+        assert torch.isfinite(out).all() and d.mean().item() <= 0.05 and d.max().item() <= 0.5, (d.mean().item(), d.max().item())
+        d32 = (out.cpu() - ctx["ref_f"]).abs().mean().item()          # vs the fp32 reference CPU path
+        o32 = (ref8 - ctx["ref_f"]).abs().mean().item()                # the oracle's own fp8-vs-fp32 spread
+        b32 = (ctx["ref_b"] - ctx["ref_f"]).abs().mean().item()        # bf16-vs-fp32 spread for scale
+        print(f"fp8 encoder: mean |d| vs fp32 {d32:.4f} (oracle fp8 mode {o32:.4f}, bf16 mode {b32:.4f})")
+        assert d32 <= 1.25 * o32 + 5e-3
+        # uint8 entry point takes the same path
+        out8 = enc.forward_u8(torch.as_tensor(ctx["img"])[None].cuda())
+        assert (out8 - out).abs().max().item() <= 1e-5
+        # decode on the fp8 embedding (bf16 decoder): agreement of the low-res mask signs with the fp32 pipeline
+        pts = torch.tensor([[[300.0, 400.0]], [[700.0, 650.0]], [[128.0, 900.0]]], device="cuda")
+        lab = torch.ones((3, 1), dtype=torch.int32, device="cuda")
+        p.features, p.original_size, p.input_size, p.is_image_set = out, (1024, 1024), (1024, 1024), True
+        _, iou, low = p.predict_torch(pts, lab, multimask_output=True, return_logits=True)
+        _, iou_r, low_r = S.predict_torch(sd, ctx["ref_f"], (1024, 1024), (1024, 1024), pts.cpu(), lab.cpu(),
+                                          multimask_output=True, return_logits=True, precision="fp32")
+        flips = ((low.cpu() > 0) != (low_r > 0)).float().mean().item()
+        print(f"fp8 encoder + bf16 decoder: low-res sign disagreement vs the fp32 pipeline {flips:.4f}")
+        assert flips <= 0.05 and (iou.cpu() - iou_r).abs().max().item() <= 0.05
+    finally:
+        enc.set_precision("bf16")
+        p.reset_image()
