@@ -152,9 +152,10 @@ int msam_gemm256_set_staging(int staging);
 int msam_profile_enable(int on);
 int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops);
 /* Per kernel family (arrays of MSAM_PROFILE_FAMILIES: launches, summed ms, flops, algorithmic HBM bytes):
- * [0] tiled MFMA GEMM (gemm_kernel, MFMA-bound), [1] weights-stationary streaming kernels (wsgemm_kernel /
- * dec_image_layer_kernel), [2] fold_i2t_kernel, [3] fold_attn_kernel, [4] up_fused_kernel (the decoder kernels that stream
- * the per-prompt image-token stream once; HBM-bound), [5] reserved. */
+ * [0] gemm256_kernel (256 x 256 tile MFMA GEMM, bf16 or fp8: the encoder's large projections), [1] weights-stationary streaming
+ * kernels (wsgemm_kernel / dec_image_layer_kernel), [2] fold_i2t_kernel, [3] fold_attn_kernel, [4] up_fused_kernel (the decoder
+ * kernels that stream the per-prompt image-token stream once; HBM-bound), [5] gemm_kernel / gemm_ln_kernel (128 x 128 and
+ * 64 x 256 tile MFMA GEMMs: patch embedding, neck, the latency-bound token-side projections). */
 #define MSAM_PROFILE_FAMILIES 6
 int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 

@@ -838,7 +838,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         EpiLN ln{p->ln_w, p->ln_b, p->ln_eps, p->ln_mode};
         const bool prof_ln = g_prof_on && g_prof_n < PROF_MAX;
         if (prof_ln) {
-            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
+            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
             (void)hipEventRecord(g_prof[g_prof_n].a, s);
         }
         hipLaunchKernelGGL(gemm_ln_kernel, dim3((p->M + 63) / 64), dim3(256), LN_LDS, s, (const u16*)p->A, (long)p->lda,
@@ -866,7 +866,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         }
         e.row_scale = p->row_scale; e.col_scale = p->col_scale;
         if (prof) {
-            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
+            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
             (void)hipEventRecord(g_prof[g_prof_n].a, s);
         }
         const int tiles8 = ((p->M + G2 - 1) / G2) * (p->N / G2);
@@ -909,7 +909,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         return msam_check_launch("msam_gemm_bf16(256)");
     }
     if (prof) {
-        g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
+        g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
         (void)hipEventRecord(g_prof[g_prof_n].a, s);
     }
     if (p->use_glds)
