@@ -144,6 +144,8 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
  * msam_profile_collect synchronises them and returns the number of launches, their summed duration (ms) and
  * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
+/* tuning hook: s_setprio around the stage-1 MFMA cluster of up_fused_kernel (1 = on, default) */
+int msam_upscale_set_prio(int32_t prio);
 /* debug hook: phase timing of the folded image->token kernel (see csrc/decfold.hip, tools/i2t_timing.py) */
 int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out);
 /* tuning / test hook: operand staging of the 256 x 256 tile kernel behind msam_gemm_bf16 (0 registers two tiles ahead,

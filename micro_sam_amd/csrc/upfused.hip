@@ -24,6 +24,7 @@ void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int
 namespace {
 
 constexpr int T = 4096, C = 256, TK = 16, NTHR = 256;
+int g_uf_prio = 1;                    // tuning hook msam_upscale_set_prio
 constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;     // k-step sub-tiles [32 tokens][64 B] (+ pad), see decfold.hip
 constexpr int W2_BYTES = 128 * 128;
 constexpr int PATCH = 3 * 4 * 64;                                     // [mask][4 rows][64 pixels] fp32
@@ -38,6 +39,7 @@ struct UpArgs {
     float* out;                          // fp32 [P, nmask, 256, 256]
 };
 
+template <int UF_PRIO>
 __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
     __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
@@ -143,12 +145,16 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         f32x4_t u[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) u[rt] = b1v[rt];
+        // the MFMA-only phase of this wave gets issue priority: its 32 MFMAs go out back to back and the VALU phase of the
+        // SIMD's other wave (another workgroup, in a different phase) fills the slots in between
+        __builtin_amdgcn_s_setprio(UF_PRIO);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const uint4 kf = *(const uint4*)(B + boff + ks * SUB_BYTES);
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16(w1f[rt][ks], kf, u[rt]);
         }
+        __builtin_amdgcn_s_setprio(0);
         float s = 0.f;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
@@ -271,7 +277,10 @@ extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, c
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
     const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
     msam_profile_mark2(stream, 1, flops, bytes, 4);
-    hipLaunchKernelGGL(up_fused_kernel, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    if (g_uf_prio) hipLaunchKernelGGL(up_fused_kernel<1>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(up_fused_kernel<0>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     msam_profile_mark2(stream, 0, flops, bytes, 4);
     return msam_check_launch("up_fused");
 }
+
+extern "C" int msam_upscale_set_prio(int32_t prio) { g_uf_prio = prio; return 0; }
