@@ -304,7 +304,7 @@ MSAM_DEVINL f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& b0
                                                             0, 0x7F7F7F7F);
 }
 constexpr int G2 = 256;                       // tile edge
-constexpr int G2_DEFAULT_STAGING = 1;   // measured: 3 - 6 % over 0 on the encoder shapes, LDS-DMA (2) no better (tools/gemm_bench.py)
+constexpr int G2_DEFAULT_STAGING = 3;   // measured (tools/gemm_bench.py): 3 > 1 > 0 by 3 - 8 % each on the encoder shapes, LDS-DMA (2) no better
 int g_gemm256_staging = -1;                   // test / tuning hook (msam_gemm256_set_staging), -1 = default / environment
 constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 8 chunks x 16 B = 128 KB
 
@@ -448,6 +448,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
             compute(kt & 1);
             __syncthreads();
         }
+        wait_vmem_all();
+    } else if constexpr (STAGING == 3) {
+        // Ping-pong of the two M-halves of the workgroup (waves 0-3 = group A, waves 4-7 = group B; every SIMD holds one wave
+        // of each).  A k-tile is four slots per wave: R0 M0 R1 M1 - R = the LDS traffic of one k-half (12 ds_read_b128 of the
+        // fragments, a quarter of the wave's staging writes of tile k+1 and the re-issue of its loads for tile k+2), M = the
+        // 16 MFMAs of that k-half on fragments already in registers.  One barrier per slot; group B runs ONE slot behind
+        // group A (an extra barrier in front of its loop, one behind A's), so on every SIMD one wave is in an M slot (MFMA
+        // pipe busy back to back, raised priority) while the other does the LDS / global work of an R slot, instead of both
+        // reading and then both multiplying.  LDS protocol: tile k+1 is written in the R slots of iteration k (slots 4k .. 4k+3)
+        // into the buffer whose last read (group B, R1 of tile k-1) ended in slot 4k-1; its first read is in slot 4k+4.
+        (void)ya0; (void)yw0; (void)ya1; (void)yw1; (void)ya2; (void)yw2; (void)ya3; (void)yw3;
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+        G2_COMMIT(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, 0);
+        G2_LOAD(xa0, xa1, xa2, xa3, xw0, xw1, xw2, xw3, min(1, nk - 1));
+        __syncthreads();
+        const bool group_b = wm == 1;
+        if (group_b) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
+        uint4 wfr[2][2], afr[2][4];
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const uint4* la = stage(buf, 0);
+            const uint4* lw = stage(buf, 1);
+            uint4* sa = stage(buf ^ 1, 0) + srow * 8 + scp;
+            uint4* sw = stage(buf ^ 1, 1) + srow * 8 + scp;
+            const int so = min(kt + 2, nk - 1) * 128;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // ---- R slot of k-half h
+                if (kt + 1 < nk) {
+                    if (h == 0) { sa[0] = xa0; sa[64 * 8] = xa1; sw[0] = xw0; sw[64 * 8] = xw1; }
+                    else { sa[128 * 8] = xa2; sa[192 * 8] = xa3; sw[128 * 8] = xw2; sw[192 * 8] = xw3; }
+                }
+                if (h == 0) {
+                    xa0 = buf_load16(ra, aoff[0], so); xa1 = buf_load16(ra, aoff[1], so);
+                    xw0 = buf_load16(rw, woff[0], so); xw1 = buf_load16(rw, woff[1], so);
+                } else {
+                    xa2 = buf_load16(ra, aoff[2], so); xa3 = buf_load16(ra, aoff[3], so);
+                    xw2 = buf_load16(rw, woff[2], so); xw3 = buf_load16(rw, woff[3], so);
+                }
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int s4 = 2 * h + q2;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = wn * 64 + i * 32 + l31;
+                        wfr[q2][i] = lw[row * 8 + ((s4 * 2 + lh) ^ swz(row))];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = wm * 128 + j * 32 + l31;
+                        afr[q2][j] = la[row * 8 + ((s4 * 2 + lh) ^ swz(row))];
+                    }
+                }
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M slot
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wfr[q2][i], afr[q2][j], acc[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!group_b) { __syncthreads(); __builtin_amdgcn_sched_barrier(0); }
         wait_vmem_all();
     } else {
         (void)xa0; (void)xw0; (void)ya0; (void)yw0;
@@ -736,7 +805,7 @@ int g_prof_n = 0, g_prof_on = 0, g_prof_init = 0;
 extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
 extern "C" int msam_gemm256_set_staging(int staging) {
-    if (staging < -1 || staging > 2) { msam_set_error("msam_gemm256_set_staging: -1 (default), 0, 1 or 2"); return 1; }
+    if (staging < -1 || staging > 3) { msam_set_error("msam_gemm256_set_staging: -1 (default), 0, 1, 2 or 3"); return 1; }
     g_gemm256_staging = staging;
     return 0;
 }
@@ -890,7 +959,8 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         if (!attr256) {
             if (hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
                 hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
-                hipFuncSetAttribute((const void*)gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
+                hipFuncSetAttribute((const void*)gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
                 msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
                 return 2;
             }
@@ -903,7 +973,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         const int tiles256 = ((p->M + G2 - 1) / G2) * (p->N / G2);
 #define G2_GO(ST_) hipLaunchKernelGGL(gemm256_kernel<ST_>, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda, \
                                      (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e)
-        if (staging256 == 1) G2_GO(1); else if (staging256 == 2) G2_GO(2); else G2_GO(0);
+        if (staging256 == 1) G2_GO(1); else if (staging256 == 2) G2_GO(2); else if (staging256 == 3) G2_GO(3); else G2_GO(0);
 #undef G2_GO
         if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
         return msam_check_launch("msam_gemm_bf16(256)");

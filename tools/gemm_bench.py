@@ -1,4 +1,4 @@
-"""GPU-box micro-benchmark of the encoder's GEMM shapes (vit_b, batch of 8 tiles: M = 32768) across the operand staging
+"""GPU-box micro-benchmark of the encoder's GEMM shapes (vit_b, batch of 8 tiles: M = 65536) across the operand staging
 variants of the 256 x 256 tile kernel; each variant is checked against the first one (bit-identical accumulation order).
     python tools/gemm_bench.py"""
 import os
@@ -12,8 +12,8 @@ from micro_sam_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda", 0)
 lib = _lib.load()
 g = torch.Generator().manual_seed(3)
-SHAPES = [(32768, 2304, 768, "qkv"), (32768, 768, 768, "proj"), (32768, 3072, 768, "lin1"), (32768, 768, 3072, "lin2"),
-          (32768, 3072, 1024, "vit_l lin1 (N=3072 stand-in)")]
+SHAPES = [(65536, 2304, 768, "qkv"), (65536, 768, 768, "proj"), (65536, 3072, 768, "lin1"), (65536, 768, 3072, "lin2"),
+          (65536, 3072, 1024, "vit_l lin1 (N=3072 stand-in)")]
 
 
 def timeit(fn, n=10, warm=3):
@@ -35,7 +35,7 @@ for (M, N, K, name) in SHAPES:
     bias = torch.randn(N, generator=g).to(dev)
     ref = None
     line = []
-    for st in (0, 1, 2, 0, 1, 2):
+    for st in (0, 1, 3, 0, 1, 3, 3):
         lib.msam_gemm256_set_staging(st)
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         ms = timeit(lambda: ops.gemm(a, w, bias, out=out, act=ops.ACT_GELU))
