@@ -489,28 +489,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
                 }
 #pragma unroll
                 for (int q2 = 0; q2 < 2; ++q2) {
-                    const int s4 = 2 * h + q2;
+                    // 16-byte chunk of the 128-byte row: bf16 = k-step (2h + q2) of 16 elements, lane half lh; fp8 = the lane
+                    // half's 32 bytes (chunks 2 lh, 2 lh + 1) of the 64-byte step h
+                    const int ch = FP8 ? h * 4 + lh * 2 + q2 : (2 * h + q2) * 2 + lh;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int row = wn * 64 + i * 32 + l31;
-                        wfr[q2][i] = lw[row * 8 + ((s4 * 2 + lh) ^ swz(row))];
+                        wfr[q2][i] = lw[row * 8 + (ch ^ swz(row))];
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int row = wm * 128 + j * 32 + l31;
-                        afr[q2][j] = la[row * 8 + ((s4 * 2 + lh) ^ swz(row))];
+                        afr[q2][j] = la[row * 8 + (ch ^ swz(row))];
                     }
                 }
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- M slot
                 __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int q2 = 0; q2 < 2; ++q2)
+                if constexpr (FP8) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wfr[q2][i], afr[q2][j], acc[i][j]);
+                        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32_f8(wfr[0][i], wfr[1][i], afr[0][j], afr[1][j], acc[i][j]);
+                } else {
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wfr[q2][i], afr[q2][j], acc[i][j]);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
