@@ -146,6 +146,8 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
  * summed 2*M*N*K.  Not thread safe; at most 4096 launches between collects (later ones are not recorded). */
 /* tuning hook: s_setprio around the stage-1 MFMA cluster of up_fused_kernel (1 = on, default) */
 int msam_upscale_set_prio(int32_t prio);
+/* tuning hook: fold_attn_kernel operand staging (0 registers, 2 workgroups per CU; 1 LDS-DMA, 3 workgroups per CU) */
+int msam_fold_attn_set_dma(int32_t on);
 /* debug hook: phase timing of the folded image->token kernel (see csrc/decfold.hip, tools/i2t_timing.py) */
 int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out);
 /* tuning / test hook: operand staging of the 256 x 256 tile kernel behind msam_gemm_bf16 (0 registers two tiles ahead,

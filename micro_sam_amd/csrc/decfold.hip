@@ -35,6 +35,9 @@ constexpr int T = 4096, C = 256, CI = 128, TK = 32, NTHR = 256;
 constexpr int SUBT = 1024 + 32;
 constexpr int KEYS_BYTES = 16 * SUBT, TAB_BYTES = TK * CI * 2, BUF_BYTES = KEYS_BYTES + TAB_BYTES;
 constexpr float NEG_BIG = -1.0e30f;
+#ifndef FOLD_ATTN_DMA_DEFAULT
+#define FOLD_ATTN_DMA_DEFAULT 0
+#endif
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
@@ -76,7 +79,13 @@ struct FoldArgs {
     const u16* wv; const float* bv; u16* out;   // KS == 1: value projection fused into the item epilogue, bf16 [P, Nt, 128]
 };
 
-__global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
+// DMA: the stream and table tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, the
+// tile image's sub-tile order / half swap / chunk swizzle applied on the per-lane SOURCE address) into the other buffer while
+// the current tile is consumed: no staging registers (48 VGPRs) and no ds_write pass, which lets THREE workgroups share a CU.
+int g_fold_attn_dma = FOLD_ATTN_DMA_DEFAULT;         // tuning hook msam_fold_attn_set_dma
+
+template <bool DMA>
+__global__ __launch_bounds__(NTHR, DMA ? 3 : 2) void fold_attn_kernel(FoldArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 7 - ks_sh;
@@ -123,6 +132,36 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
         *(uint4*)(b_ + kdst[3]) = r3_; *(uint4*)(b_ + tdst[0]) = r4_; *(uint4*)(b_ + tdst[1]) = r5_; \
     } while (0)
 
+    // ---- LDS-DMA issue of tile q into buffer `dbuf` (DMA instantiation): wave w, piece n: stream sub-tile ct = 4w + n
+    // (lane l -> key l >> 1, stored half l & 1 = source half ^ key bit 3), table rows (2w + n) * 4 .. + 3 (lane l -> row l >> 4,
+    // stored chunk l & 15 = source chunk ^ (row & 15))
+    // (buffer form: descriptor + 32-bit per-lane offset + scalar tile offset - no 64-bit per-lane addresses to keep alive)
+    const int wv_ = __builtin_amdgcn_readfirstlane(w);
+    int dk_off[4], dt_off[2];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int ct = wv_ * 4 + n, row = lane >> 1, half = (lane & 1) ^ ((row >> 3) & 1);
+        dk_off[n] = row * (C * 2) + (ct * 2 + half) * 16;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int row = (wv_ * 2 + n) * 4 + (lane >> 4), c = (lane & 15) ^ (row & 15);
+        dt_off[n] = row * (CI * 2) + c * 16;
+    }
+    auto dma_tile = [&](int q, int dbuf) {
+        rsrc_t rk_; int ko_, to_;
+        tile_src(q, rk_, ko_, to_);
+        unsigned char* base = lds + dbuf * BUF_BYTES;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk_, (__attribute__((address_space(3))) void*)(base + (wv_ * 4 + n) * SUBT), 16,
+                                                 dk_off[n], ko_, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rtab, (__attribute__((address_space(3))) void*)(base + KEYS_BYTES + (wv_ * 2 + n) * 1024), 16,
+                                                 dt_off[n], to_, 0, 0);
+    };
+
     // ---- per-lane LDS read offsets
     int koff[2], toff[2], troff[2];
 #pragma unroll
@@ -141,15 +180,20 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
 
     // every global load of the steady state is unconditional (tile index clamped to the last tile): the compiler can
     // then count the younger loads / stores and wait with vmcnt(n > 0) instead of draining the prefetch (common.h)
-    FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, 0);
-    FA_STORE(ra0, ra1, ra2, ra3, ra4, ra5, 0);
-    FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, min(1, nq - 1));
+    if constexpr (DMA) {
+        dma_tile(0, 0);
+    } else {
+        FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, 0);
+        FA_STORE(ra0, ra1, ra2, ra3, ra4, ra5, 0);
+        FA_LOAD(ra0, ra1, ra2, ra3, ra4, ra5, min(1, nq - 1));
+    }
     __syncthreads();
 
     int q = 0, buf = 0;
     auto iteration = [&](uint4& p0, uint4& p1, uint4& p2, uint4& p3, uint4& p4, uint4& p5, uint4& f0, uint4& f1, uint4& f2,
                          uint4& f3, uint4& f4, uint4& f5) {
-        FA_LOAD(f0, f1, f2, f3, f4, f5, min(q + 2, nq - 1));
+        if constexpr (DMA) { if (q + 1 < nq) dma_tile(q + 1, buf ^ 1); }
+        else FA_LOAD(f0, f1, f2, f3, f4, f5, min(q + 2, nq - 1));
         const int tt = q & (TPI - 1);
         if (tt == 0) {                                   // new work item: folded queries of this wave's two heads
             item = (int)blockIdx.x + (q >> tpi_sh) * (int)gridDim.x;
@@ -246,8 +290,8 @@ __global__ __launch_bounds__(NTHR, 2) void fold_attn_kernel(FoldArgs a) {
                     *(float4*)(op + ct * 16) = make_float4(acc[ct][0], acc[ct][1], acc[ct][2], acc[ct][3]);
             }
         }
-        if (q + 1 < nq) FA_STORE(p0, p1, p2, p3, p4, p5, buf ^ 1);
-        __syncthreads();
+        if constexpr (!DMA) { if (q + 1 < nq) FA_STORE(p0, p1, p2, p3, p4, p5, buf ^ 1); }
+        __syncthreads();                                 // (with a DMA in flight the barrier's fence waits vmcnt(0): tile q+1 landed)
         buf ^= 1;
     };
     while (true) {
@@ -649,7 +693,12 @@ extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, cons
     const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
     const double bytes = (double)(kv_shared ? 1 : P) * T * C * 2 + (KS > 1 ? (double)P * KS * 64 * C * 4 : 0.0);
     msam_profile_mark2(stream, 1, flops, bytes, 3);
-    hipLaunchKernelGGL(fold_attn_kernel, dim3(grid), dim3(NTHR), 0, s, a);
+    if (g_fold_attn_dma) {
+        const int grid3 = a.nitems < 3 * cus ? a.nitems : 3 * cus;
+        hipLaunchKernelGGL(fold_attn_kernel<true>, dim3(grid3), dim3(NTHR), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(fold_attn_kernel<false>, dim3(grid), dim3(NTHR), 0, s, a);
+    }
     msam_profile_mark2(stream, 0, flops, bytes, 3);
     if (int e = msam_check_launch("fold_attn")) return e;
     if (KS == 1) return 0;                               // the value projection ran in the attention kernel's epilogue
@@ -706,3 +755,5 @@ extern "C" int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out) {
     }
     return 0;
 }
+
+extern "C" int msam_fold_attn_set_dma(int32_t on) { g_fold_attn_dma = on; return 0; }

@@ -360,6 +360,15 @@ def test_t2i_fold_attention(env, P, Nt, shared):
     ref = (a @ vh).permute(0, 2, 1, 3).reshape(P, Nt, 128)
     # scores reach |s| ~ 30 with these operands: bf16 rounding of the folded query gives ~1e-2 relative score error
     assert _close(out, ref, 6e-2, 3e-2)
+    # the LDS-DMA staging variant (tuning hook, off by default: measured 2.3x slower, profiles/r01_experiments.md) computes
+    # the same arithmetic
+    from micro_sam_amd import _lib
+    _lib.load().msam_fold_attn_set_dma(1)
+    try:
+        out_dma = ops.t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, kv_shared=shared)
+    finally:
+        _lib.load().msam_fold_attn_set_dma(0)
+    assert torch.equal(out_dma, out)
 
 
 @pytest.mark.parametrize("P,Nt,shared", [(3, 7, False), (2, 8, True), (70, 5, True), (520, 7, True)])
