@@ -70,6 +70,10 @@ typedef struct {
     const float* row_scale; const float* col_scale;        /* fp32 [M], [N] */
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
+/* n <= MSAM_GEMM_GROUP_MAX independent products (each as for msam_gemm_bf16; 128 x 128-tile bf16 path only: no fused LayerNorm,
+ * no fp8, no qkv-split output) in ONE launch: the decoder's token-side projections are latency-bound one at a time. */
+#define MSAM_GEMM_GROUP_MAX 5
+int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* stream);
 
 /* Weights-stationary streaming GEMM for the decoder's image-token stream (M = P*4096 rows, N,K in {128,256}):
  * out = epi(A[M,K] * W[N,K]^T), A / W / out bf16, contiguous rows (lda = K, ldw = K).  Same epilogue vocabulary as

@@ -416,6 +416,17 @@ inline int grid_for(long items) { long g = (items + 255) / 256; return (int)(g <
 
 struct Ctx { hipStream_t s; int use_glds; };
 
+// one product of a grouped launch (msam_gemm_group_bf16): the token-side projections are 7 168-row products, latency-bound
+// one launch at a time; independent ones (self-attention q / k / v, the k / v of image->token attention, the five output heads
+// layer by layer) go out together
+msam_gemm_t mk_gemm(const void* A, long lda, const void* W, int M, int N, int K, const float* bias, void* out, int out_dtype,
+                    long ldc, int act = 0) {
+    msam_gemm_t g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
+    g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc;
+    return g;
+}
+
 int gemm(const Ctx& cx, const void* A, long lda, const void* W, int M, int N, int K, const float* bias, void* out,
          int out_dtype, long ldc, int act = 0, const void* resid = nullptr, int resid_dtype = 0, long ldr = 0,
          int resid_rows = 0, const float* table = nullptr, int table_cols = 0, int ln_mode = 0,
@@ -541,7 +552,7 @@ long work_bytes(int P, int Nt) {
     b += 4 * align256(R * CI * 2);                // kimg, vT, qimg, attn_img
     b += align256(R * C * 2);                     // up1
     b += align256(R * C * 4);                     // pre
-    b += 2 * align256((long)P * C * 2);           // hh0, hh1
+    b += 2 * align256(5L * P * C * 2);            // hh0, hh1 (one [P, 256] block per head)
     b += align256((long)P * 4 * 128 * 4) + align256((long)P * 128 * 4);
     return b;
 }
@@ -558,7 +569,7 @@ Work carve_work(void* base, int P, int Nt) {
     w.attn_img = (u16*)take(R * CI * 2);
     w.up1 = (u16*)take(R * C * 2);
     w.pre = (float*)take(R * C * 4);
-    w.hh0 = (u16*)take((long)P * C * 2); w.hh1 = (u16*)take((long)P * C * 2);
+    w.hh0 = (u16*)take(5L * P * C * 2); w.hh1 = (u16*)take(5L * P * C * 2);
     w.hyper = (float*)take((long)P * 4 * 128 * 4); w.iou_full = (float*)take((long)P * 128 * 4);
     return w;
 }
@@ -642,9 +653,12 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
         // layer 0: q = k = v input = bf16(tokens), written by prompt_tokens_kernel; layer 1: q = k input carries the PE
         const u16* sv = w.a;
         if (li > 0) { ADD_CAST2(w.queries, w.qpe, w.a, w.b); sv = w.b; }
-        CHECK(gemm(cx, w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_BF16, C));
-        CHECK(gemm(cx, w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_BF16, C));
-        CHECK(gemm(cx, sv, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_BF16, C));
+        {
+            const msam_gemm_t qkv[3] = {mk_gemm(w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_BF16, C),
+                                        mk_gemm(w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_BF16, C),
+                                        mk_gemm(sv, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_BF16, C)};
+            CHECK(msam_gemm_group_bf16(qkv, 3, cx.s));
+        }
         hipLaunchKernelGGL(token_self_attn_kernel, dim3(P), dim3(128), 0, cx.s, w.qs, w.ks, w.vs, Nt, w.attn_tok);
         CHECK(msam_check_launch("token_self_attn"));
         CHECK(gemm(cx, w.attn_tok, C, L.self_attn.o_w, M, C, C, L.self_attn.o_b, w.tmp, MSAM_F32, C, 0,
@@ -673,8 +687,11 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
         LN(w.tmp, L.n3_w, L.n3_b, M, w.queries, MSAM_F32);
         // (4) image -> token attention, updates the image-token stream
         ADD_CAST2(w.queries, w.qpe, w.a, w.b);
-        CHECK(gemm(cx, w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI));
-        CHECK(gemm(cx, w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI));
+        {
+            const msam_gemm_t kv[2] = {mk_gemm(w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI),
+                                       mk_gemm(w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI)};
+            CHECK(msam_gemm_group_bf16(kv, 2, cx.s));
+        }
         // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
         // for up to 8 tokens per prompt, weights-stationary fused kernel (declayer.hip) otherwise
         if (Nt <= 8) {
@@ -702,15 +719,28 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
 
     // heads: hyper-network MLPs on mask tokens 1..4, IoU head on token 0 (bf16 copy of queries, strided rows)
     ADD_CAST(w.queries, nullptr, w.a);
-    for (int i = 0; i < 4; ++i) {
-        const u16* tok = w.a + (long)(1 + i) * C;
-        CHECK(gemm(cx, tok, (long)Nt * C, dec->hyp_w[i][0], P, C, C, dec->hyp_b[i][0], w.hh0, MSAM_BF16, C, MSAM_ACT_RELU));
-        CHECK(gemm(cx, w.hh0, C, dec->hyp_w[i][1], P, C, C, dec->hyp_b[i][1], w.hh1, MSAM_BF16, C, MSAM_ACT_RELU));
-        CHECK(gemm(cx, w.hh1, C, dec->hyp_w[i][2], P, 128, C, dec->hyp_b[i][2], w.hyper + (long)i * 128, MSAM_F32, 4 * 128));
+    // the five 3-layer MLPs (IoU head on token 0, hyper-networks on tokens 1..4) layer by layer, one grouped launch per layer
+    {
+        msam_gemm_t h[5];
+        const long PC = (long)P * C;
+        for (int i = 0; i < 5; ++i) {
+            const void* wt = i == 0 ? dec->iou_w[0] : dec->hyp_w[i - 1][0];
+            const float* bs = i == 0 ? dec->iou_b[0] : dec->hyp_b[i - 1][0];
+            h[i] = mk_gemm(w.a + (long)i * C, (long)Nt * C, wt, P, C, C, bs, w.hh0 + i * PC, MSAM_BF16, C, MSAM_ACT_RELU);
+        }
+        CHECK(msam_gemm_group_bf16(h, 5, cx.s));
+        for (int i = 0; i < 5; ++i) {
+            const void* wt = i == 0 ? dec->iou_w[1] : dec->hyp_w[i - 1][1];
+            const float* bs = i == 0 ? dec->iou_b[1] : dec->hyp_b[i - 1][1];
+            h[i] = mk_gemm(w.hh0 + i * PC, C, wt, P, C, C, bs, w.hh1 + i * PC, MSAM_BF16, C, MSAM_ACT_RELU);
+        }
+        CHECK(msam_gemm_group_bf16(h, 5, cx.s));
+        h[0] = mk_gemm(w.hh1, C, dec->iou_w[2], P, 128, C, dec->iou_b[2], w.iou_full, MSAM_F32, 128);
+        for (int i = 1; i < 5; ++i)
+            h[i] = mk_gemm(w.hh1 + i * PC, C, dec->hyp_w[i - 1][2], P, 128, C, dec->hyp_b[i - 1][2], w.hyper + (long)(i - 1) * 128,
+                           MSAM_F32, 4 * 128);
+        CHECK(msam_gemm_group_bf16(h, 5, cx.s));
     }
-    CHECK(gemm(cx, w.a, (long)Nt * C, dec->iou_w[0], P, C, C, dec->iou_b[0], w.hh0, MSAM_BF16, C, MSAM_ACT_RELU));
-    CHECK(gemm(cx, w.hh0, C, dec->iou_w[1], P, C, C, dec->iou_b[1], w.hh1, MSAM_BF16, C, MSAM_ACT_RELU));
-    CHECK(gemm(cx, w.hh1, C, dec->iou_w[2], P, 128, C, dec->iou_b[2], w.iou_full, MSAM_F32, 128));
     const int mask0 = multimask ? 1 : 0, nmask = multimask ? 3 : 1;
     hipLaunchKernelGGL(gather_iou_kernel, dim3((P * nmask + 255) / 256), dim3(256), 0, cx.s, w.iou_full, P, mask0, nmask, iou);
     CHECK(msam_check_launch("gather_iou"));

@@ -23,15 +23,16 @@ struct Epi {
     const float* row_scale; const float* col_scale;      // fp8 operands: C = acc * row_scale[m] * col_scale[n]
 };
 
+// body of the 128 x 128 tile kernel for workgroup `bid_in` of the product (shared by the plain and the grouped launch)
 template <bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
-                                                   long ldw, int M, int N, int K, Epi e) {
+__device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, const u16* __restrict__ W, long ldw, int M, int N,
+                                          int K, const Epi& e, int bid_in) {
     __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TILE_CHUNKS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM;
     // XCD-aware remap (bijective): consecutive tiles (sharing the A panel) run on one XCD / one L2
-    int nwg = tiles_m * tiles_n, bid = blockIdx.x;
+    int nwg = tiles_m * tiles_n, bid = bid_in;
     {
         int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -278,6 +279,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A,
             *(uint4*)(dst + i) = pk;
         }
     }
+}
+
+template <bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
+                                                   long ldw, int M, int N, int K, Epi e) {
+    gemm_body<GLDS>(A, lda, W, ldw, M, N, K, e, (int)blockIdx.x);
+}
+
+// Grouped launch: up to MSAM_GEMM_GROUP_MAX independent small products in ONE launch (blockIdx.y = product, blockIdx.x = its
+// tile; the decoder's token-side projections are 7 168-row products of 112 tiles each - latency-bound one at a time).
+struct GroupItem { const u16* A; long lda; const u16* W; long ldw; int M, N, K; Epi e; };
+struct GroupArgs { GroupItem it[MSAM_GEMM_GROUP_MAX]; };
+__global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
+    // the product's parameters are read from the kernel-argument segment itself (constant address space, scalar loads): indexing
+    // the by-value argument with blockIdx.y made the compiler copy the whole array to scratch
+    (void)g;
+#if defined(__HIP_DEVICE_COMPILE__)                  // (address-space-qualified struct copies do not parse in the host pass)
+    typedef const __attribute__((address_space(4))) GroupItem* ItemPtr;
+    ItemPtr it = (ItemPtr)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y;
+    const int M = it->M, N = it->N, K = it->K;
+    const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    if ((int)blockIdx.x >= tiles) return;
+    const Epi e = it->e;
+    gemm_body<false>(it->A, it->lda, it->W, it->ldw, M, N, K, e, (int)blockIdx.x);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -999,4 +1025,50 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
                            (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
     if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
     return msam_check_launch("msam_gemm_bf16");
+}
+
+// Grouped launch of independent 128 x 128-tile products (plain bf16 path only: no fused LayerNorm, no fp8, no LDS-DMA staging)
+extern "C" int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* stream) {
+    if (!items || n <= 0 || n > MSAM_GEMM_GROUP_MAX) { msam_set_error("msam_gemm_group_bf16: 1 .. MSAM_GEMM_GROUP_MAX products"); return 1; }
+    GroupArgs g;
+    int max_tiles = 0;
+    double flops = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const msam_gemm_t* p = items + i;
+        if (!p->A || !p->W || p->M <= 0 || p->N <= 0 || p->K <= 0 || p->N % BN || p->K % BK || (p->lda % 8) || (p->ldw % 8) ||
+            p->ln_mode || p->a_dtype == MSAM_FP8 || p->use_glds) {
+            msam_set_error("msam_gemm_group_bf16: every product needs N % 128 == 0, K % 64 == 0, lda / ldw % 8 == 0, bf16 operands, "
+                           "no fused LayerNorm");
+            return 1;
+        }
+        if ((p->out_mode == 0 && (!p->out || (p->ldc % 4))) || p->out_mode == 1 ||
+            (p->out_mode == 2 && (!p->k || !p->v || p->N != 256 || p->tokens % 128 || p->M % p->tokens)) ||
+            (p->table && ((p->table_cols % 4) || (p->table_ld % 4))) || (p->resid && (p->ldr % 4))) {
+            msam_set_error("msam_gemm_group_bf16: bad output / table / residual arguments (qkv-split output is not grouped)");
+            return 1;
+        }
+        GroupItem& it = g.it[i];
+        it.A = (const u16*)p->A; it.lda = p->lda; it.W = (const u16*)p->W; it.ldw = p->ldw; it.M = p->M; it.N = p->N; it.K = p->K;
+        Epi& e = it.e;
+        e.bias = p->bias; e.table = p->table; e.table_rows = p->table_rows > 0 ? p->table_rows : 1;
+        e.table_cols = p->table_cols; e.table_ld = p->table_ld;
+        e.resid = p->resid; e.resid_dtype = p->resid ? p->resid_dtype : 0; e.resid_rows = p->resid_rows; e.ldr = p->ldr;
+        e.act = p->act; e.out = p->out; e.out_dtype = p->out_dtype; e.ldc = p->ldc;
+        e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
+        e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
+        e.row_scale = nullptr; e.col_scale = nullptr;
+        const int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
+        if (tiles > max_tiles) max_tiles = tiles;
+        flops += 2.0 * p->M * (double)p->N * p->K;
+    }
+    for (int i = n; i < MSAM_GEMM_GROUP_MAX; ++i) g.it[i] = g.it[0];
+    hipStream_t s = (hipStream_t)stream;
+    const bool prof = g_prof_on && g_prof_n < PROF_MAX;
+    if (prof) {
+        g_prof[g_prof_n].flops = flops; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
+        (void)hipEventRecord(g_prof[g_prof_n].a, s);
+    }
+    hipLaunchKernelGGL(gemm_group_kernel, dim3(max_tiles, n), dim3(256), 0, s, g);
+    if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
+    return msam_check_launch("msam_gemm_group_bf16");
 }
