@@ -539,6 +539,15 @@ def set_precomputed(predictor: SamPredictor, image_embeddings: ImageEmbeddings, 
     return predictor
 
 
+def compute_iou(mask1: np.ndarray, mask2: np.ndarray) -> float:
+    """Intersection over union of the pixels that equal 1 in two label images (reference util.py:1266-1280; host arithmetic
+    in the reference as well - used between consecutive slices by the 3-d merging heuristics)."""
+    m1, m2 = np.asarray(mask1) == 1, np.asarray(mask2) == 1
+    overlap = np.logical_and(m1, m2).sum()
+    union = np.logical_or(m1, m2).sum()
+    return float(overlap) / (float(union) + 1e-7)
+
+
 # ------------------------------------------------------------------------------------------------ label image
 
 def _label_equal_value_components(seg: np.ndarray) -> np.ndarray:

@@ -35,3 +35,16 @@ def test_tiled_features_container():
     f[2] = TileArray(torch.zeros(1, 256, 64, 64), (280, 448), (640, 1024))
     assert "2" in f and 2 in f and len(f) == 1 and f["2"].ndim == 4 and f[2].attrs["input_size"] == (640, 1024)
     assert f.attrs["tile_shape"] == (384, 384) and f.attrs.get("tiles_in_mask", None) is None
+
+
+def test_compute_iou_known_answers():
+    """The reference's known-answer test test/test_util.py:66-79."""
+    from micro_sam_amd.util import compute_iou
+    x1, x2 = np.zeros((32, 32), dtype="uint32"), np.zeros((32, 32), dtype="uint32")
+    x1[:16] = 1
+    x2[16:] = 1
+    assert np.isclose(compute_iou(x1, x1), 1.0) and np.isclose(compute_iou(x1, x2), 0.0)
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        a, b = rng.random((32, 32)) > 0.5, rng.random((32, 32)) > 0.5
+        assert 0.0 < compute_iou(a, b) < 1.0
