@@ -327,7 +327,7 @@ def label_components(seg: np.ndarray) -> np.ndarray:
 def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape=None, min_object_size: int = 0,
                               max_object_size: Optional[int] = None, label_masks: bool = True,
                               with_background: bool = False, merge_exclusively: bool = True) -> np.ndarray:
-    """micro_sam/util.py:1773-1848 (without the tiled 'global_bbox' branch, which AMG never takes)."""
+    """micro_sam/util.py:1773-1848 (the tiled 'global_bbox' branch is only taken by apply_nms on tiled predictions)."""
     masks = sorted(masks, key=(lambda x: x["area"]), reverse=True)
     if shape is None:
         shape = next(iter(masks))["segmentation"].shape
@@ -340,9 +340,18 @@ def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape=None, min_objec
         this_mask = mask_data["segmentation"]
         this_mask = this_mask.cpu().numpy() if torch.is_tensor(this_mask) else this_mask
         this_seg_id = mask_data.get("seg_id", seg_id)
-        if merge_exclusively:
-            this_mask = np.logical_and(this_mask, segmentation == 0)
-        segmentation[this_mask] = this_seg_id
+        if "global_bbox" in mask_data:                    # tile-local mask placed through its boxes (util.py:1816-1824)
+            x, y, bw, bh = (int(v) for v in mask_data["bbox"])
+            gx, gy, gw, gh = (int(v) for v in mask_data["global_bbox"])
+            local = this_mask[y:y + bh, x:x + bw]
+            window = segmentation[gy:gy + gh, gx:gx + gw]               # a view: assignments land in `segmentation`
+            if merge_exclusively:
+                local = np.logical_and(local, window == 0)
+            window[local] = this_seg_id
+        else:
+            if merge_exclusively:
+                this_mask = np.logical_and(this_mask, segmentation == 0)
+            segmentation[this_mask] = this_seg_id
         seg_id = this_seg_id + 1
     if label_masks:
         segmentation = label_components(segmentation)
@@ -358,6 +367,129 @@ def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape=None, min_objec
     lut = np.zeros(int(segmentation.max()) + 1, dtype=segmentation.dtype)
     lut[ids] = np.arange(1, len(ids) + 1, dtype=segmentation.dtype)
     return lut[segmentation]
+
+
+# ----------------------------------------------------------------------------------------------
+# micro_sam/util.py:1589-1770, 1851-1957: mask NMS + merge (`apply_nms`), the post-processing of the prompt-based
+# generators (APG, batched_tiled_inference: SURVEY.md 8(f) rank 1).  Oracle first: the device kernels of that row do not
+# exist yet.  Pinned by the reference's known-answer test test/test_util.py:81-104 (tests/test_oracle_amg.py).
+# ----------------------------------------------------------------------------------------------
+
+def _boxes_overlap(boxes_xyxy: np.ndarray) -> np.ndarray:
+    """[N,N] bool: the boxes share a region of positive area (util.py:1589-1599)."""
+    b = np.asarray(boxes_xyxy, dtype=np.float64)
+    w = np.minimum(b[:, None, 2], b[None, :, 2]) - np.maximum(b[:, None, 0], b[None, :, 0])
+    h = np.minimum(b[:, None, 3], b[None, :, 3]) - np.maximum(b[:, None, 1], b[None, :, 1])
+    return (np.clip(w, 0, None) * np.clip(h, 0, None)) > 0
+
+
+def mask_overlap_matrix(masks: np.ndarray, boxes_xyxy: np.ndarray, intersection_over_min: bool) -> np.ndarray:
+    """Pairwise IoU (diagonal 1; util.py:1602-1621) or intersection over the smaller area (diagonal = a / (a + 1e-6);
+    util.py:1624-1648) of full-size masks [N,H,W]; pairs whose boxes do not overlap are 0."""
+    m = np.asarray(masks).reshape(len(masks), -1).astype(np.float64)
+    inter = m @ m.T
+    area = m.sum(1)
+    ov = _boxes_overlap(boxes_xyxy)
+    if intersection_over_min:
+        out = inter / (np.minimum(area[:, None], area[None, :]) + 1e-6)
+        out[~ov] = 0
+        return out
+    union = area[:, None] + area[None, :] - inter
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out = np.where(ov, inter / union, 0.0)
+    np.fill_diagonal(out, 1.0)
+    return out
+
+
+def tiled_mask_overlap_matrix(masks, boxes_xywh, global_boxes_xywh, intersection_over_min: bool) -> np.ndarray:
+    """Same for tile-local masks positioned by (bbox, global_bbox) pairs: only the overlap window of the two global boxes
+    is compared (util.py:1670-1722)."""
+    n = len(masks)
+    lb = np.asarray(boxes_xywh, dtype=np.int64)
+    gb = np.asarray(global_boxes_xywh, dtype=np.int64)
+    gxyxy = gb.copy()
+    gxyxy[:, 2] += gxyxy[:, 0]
+    gxyxy[:, 3] += gxyxy[:, 1]
+    ov = _boxes_overlap(gxyxy)
+    ms = [np.asarray(m.cpu() if torch.is_tensor(m) else m).astype(bool) for m in masks]
+    area = np.array([m.sum() for m in ms], dtype=np.float64)
+    out = np.zeros((n, n))
+    for i in range(n):
+        oi = gb[i, :2] - lb[i, :2]
+        for j in range(i + 1, n):
+            if not ov[i, j]:
+                continue
+            oj = gb[j, :2] - lb[j, :2]
+            x0, y0 = max(gxyxy[i, 0], gxyxy[j, 0]), max(gxyxy[i, 1], gxyxy[j, 1])
+            x1, y1 = min(gxyxy[i, 2], gxyxy[j, 2]), min(gxyxy[i, 3], gxyxy[j, 3])
+            a = ms[i][y0 - oi[1]:y1 - oi[1], x0 - oi[0]:x1 - oi[0]]
+            b = ms[j][y0 - oj[1]:y1 - oj[1], x0 - oj[0]:x1 - oj[0]]
+            inter = float(np.logical_and(a, b).sum())
+            den = min(area[i], area[j]) if intersection_over_min else area[i] + area[j] - inter
+            out[i, j] = out[j, i] = inter / den
+    np.fill_diagonal(out, 1.0)
+    return out
+
+
+def greedy_matrix_nms(overlap: np.ndarray, scores: np.ndarray, thresh: float) -> np.ndarray:
+    """Greedy suppression on a precomputed overlap matrix, candidates in descending score order; a candidate survives a
+    kept mask when overlap <= thresh (util.py:1651-1668, 1725-1746).  Returns the kept indices in score order."""
+    order = list(np.argsort(-np.asarray(scores, dtype=np.float64), kind="stable"))
+    keep = []
+    while order:
+        i = order.pop(0)
+        keep.append(int(i))
+        order = [j for j in order if overlap[i, j] <= thresh]
+    return np.asarray(keep, dtype=np.int64)
+
+
+def infer_tiled_shape(predictions) -> Tuple[int, int]:
+    """util.py:1757-1766."""
+    h = w = 0
+    for pred in predictions:
+        bx, gb = pred["bbox"], pred["global_bbox"]
+        mh, mw = pred["segmentation"].shape
+        h = max(h, gb[1] - bx[1] + mh)
+        w = max(w, gb[0] - bx[0] + mw)
+    return int(h), int(w)
+
+
+def apply_nms(predictions: List[Dict[str, Any]], min_size: int, shape=None, perform_box_nms: bool = False,
+              nms_thresh: float = 0.9, max_size: Optional[int] = None, intersection_over_min: bool = False) -> np.ndarray:
+    """util.py:1851-1957: size filters, NMS (boxes, masks, or tile-local masks) on score = predicted_iou * stability_score,
+    merge of the survivors to a label image."""
+    tiled = "global_bbox" in predictions[0]
+    if tiled and shape is None:
+        shape = infer_tiled_shape(predictions)
+    preds = [dict(p, area=int(np.asarray(p["segmentation"].cpu() if torch.is_tensor(p["segmentation"]) else p["segmentation"]).sum()))
+             for p in predictions]
+    if min_size > 0:
+        preds = [p for p in preds if p["area"] > min_size]
+    if max_size is not None:
+        preds = [p for p in preds if p["area"] < max_size]
+    if shape is None:
+        shape = predictions[0]["segmentation"].shape
+    if not preds:
+        return np.zeros(shape, dtype="uint32")
+    scores = np.array([float(p["predicted_iou"]) * float(p["stability_score"]) for p in preds], dtype=np.float32)
+    boxes = np.array([p["global_bbox"] if tiled else p["bbox"] for p in preds], dtype=np.float32)
+    xyxy = boxes.copy()
+    xyxy[:, 2] += xyxy[:, 0]
+    xyxy[:, 3] += xyxy[:, 1]
+    if perform_box_nms:
+        assert not intersection_over_min
+        keep = batched_nms(torch.as_tensor(xyxy), torch.as_tensor(scores), torch.zeros(len(preds)), nms_thresh).numpy()
+    elif tiled:
+        ovm = tiled_mask_overlap_matrix([p["segmentation"] for p in preds], [p["bbox"] for p in preds],
+                                        [p["global_bbox"] for p in preds], intersection_over_min)
+        keep = greedy_matrix_nms(ovm, scores, nms_thresh)
+    else:
+        stack = np.stack([np.asarray(p["segmentation"].cpu() if torch.is_tensor(p["segmentation"]) else p["segmentation"])
+                          for p in preds])
+        keep = greedy_matrix_nms(mask_overlap_matrix(stack, xyxy, intersection_over_min), scores, nms_thresh)
+    kept = [preds[int(i)] for i in keep]
+    records = [{k: p[k] for k in ("segmentation", "area", "bbox") + (("global_bbox",) if tiled else ())} for p in kept]
+    return mask_data_to_segmentation(records, shape=shape, min_object_size=min_size)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -97,3 +97,42 @@ def test_to_image_matches_reference_formula():
 def test_stability_score():
     m = torch.tensor([[[2.0, 0.5], [-0.5, -2.0]]])
     assert abs(A.calculate_stability_score(m, 0.0, 1.0).item() - 1 / 3) < 1e-7
+
+
+def test_apply_nms_tiled_known_answer_and_mask_nms():
+    """The reference's known-answer test test/test_util.py:81-104 (two border masks of a tiled prediction -> shape (4, 7), two
+    instances) plus self-consistency of the full-size mask NMS: IoU / IoMin suppression in score order."""
+    import torch
+    preds = [
+        {"segmentation": torch.ones((4, 4), dtype=torch.bool), "bbox": [0, 0, 4, 4], "global_bbox": [0, 0, 4, 4],
+         "predicted_iou": 1.0, "stability_score": 1.0},
+        {"segmentation": torch.ones((4, 2), dtype=torch.bool), "bbox": [0, 0, 2, 4], "global_bbox": [5, 0, 2, 4],
+         "predicted_iou": 1.0, "stability_score": 1.0},
+    ]
+    seg = A.apply_nms(preds, min_size=0)
+    assert seg.shape == (4, 7) and seg.max() == 2 and seg.dtype == np.uint32
+    assert (seg[:, :4] == 1).all() and (seg[:, 4] == 0).all() and (seg[:, 5:] == 2).all()
+    # full-size masks: a duplicate with a lower score is suppressed, a disjoint one survives
+    a = np.zeros((16, 16), bool); a[2:8, 2:8] = True
+    b = np.zeros((16, 16), bool); b[3:8, 2:8] = True                      # IoU 30/36 with a
+    c = np.zeros((16, 16), bool); c[10:14, 10:14] = True
+    inner = np.zeros((16, 16), bool); inner[3:5, 3:5] = True              # inside a: IoU 4/36, IoMin 1
+    def rec(m, score):
+        ys, xs = np.nonzero(m)
+        return {"segmentation": m, "bbox": [int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)],
+                "predicted_iou": score, "stability_score": 1.0}
+    seg = A.apply_nms([rec(a, 0.9), rec(b, 0.8), rec(c, 0.7)], min_size=0, nms_thresh=0.7)
+    assert seg.max() == 2 and (seg[a] == 1).all() and (seg[c] == 2).all()
+    seg_keep = A.apply_nms([rec(a, 0.9), rec(b, 0.8), rec(c, 0.7)], min_size=0, nms_thresh=0.9)     # 30/36 <= 0.9: b survives
+    assert seg_keep.max() == 2                       # b lies inside a: merged exclusively it adds no pixels, c is instance 2
+    iou_seg = A.apply_nms([rec(a, 0.9), rec(inner, 0.8)], min_size=0, nms_thresh=0.5)               # IoU 0.11: both kept
+    iomin_seg = A.apply_nms([rec(a, 0.9), rec(inner, 0.8)], min_size=0, nms_thresh=0.5, intersection_over_min=True)
+    assert iou_seg.max() == 1 and iomin_seg.max() == 1                    # merged exclusively: the inner mask is covered either way
+    m = A.mask_overlap_matrix(np.stack([a, b, c, inner]), np.array([[2, 2, 8, 8], [2, 3, 8, 8], [10, 10, 14, 14], [3, 3, 5, 5]]), False)
+    assert np.isclose(m[0, 1], 30 / 36) and m[0, 2] == 0 and np.isclose(m[0, 3], 4 / 36) and np.allclose(np.diag(m), 1)
+    mm = A.mask_overlap_matrix(np.stack([a, inner]), np.array([[2, 2, 8, 8], [3, 3, 5, 5]]), True)
+    assert np.isclose(mm[0, 1], 1.0, atol=1e-5)
+    assert list(A.greedy_matrix_nms(m, np.array([0.9, 0.8, 0.7, 0.6]), 0.7)) == [0, 2, 3]
+    # box NMS variant goes through the same torchvision-style batched_nms as the AMG path
+    seg_box = A.apply_nms([rec(a, 0.9), rec(b, 0.8), rec(c, 0.7)], min_size=0, perform_box_nms=True, nms_thresh=0.7)
+    assert seg_box.max() == 2
