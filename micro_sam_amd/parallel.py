@@ -37,6 +37,14 @@ def gather_label_tiles(local_labels: torch.Tensor, n_items: int, relabel_globall
     assert local_labels.shape[0] == counts[rank], (local_labels.shape, counts, rank)
     h, w = local_labels.shape[1:]
     n_max = max(counts)
+    if min(counts) == n_max:
+        # equal blocks (the usual case: tiles per rank fixed): gather straight into the output stack - no padding copy, no
+        # list of per-rank buffers, no concatenation (each of those is a pass over world x n x 4 MiB)
+        out = torch.empty((world * n_max, h, w), dtype=local_labels.dtype, device=local_labels.device)
+        dist.all_gather_into_tensor(out, local_labels.contiguous())
+        if relabel_globally:
+            _apply_offsets(out, out.flatten(1).amax(dim=1).to(torch.int64))
+        return out
     # all_gather needs equal shapes: pad the local block to n_max items
     padded = torch.zeros((n_max, h, w), dtype=local_labels.dtype, device=local_labels.device)
     padded[: counts[rank]] = local_labels

@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -35,8 +36,9 @@ def test_shard_range_is_a_contiguous_partition():
             assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
 
 
-def test_gather_label_tiles_matches_serial_offsets():
-    n_items, world = 5, 2
+@pytest.mark.parametrize("n_items", [5, 4])          # unequal blocks (padded list all_gather) / equal blocks (all_gather_into_tensor)
+def test_gather_label_tiles_matches_serial_offsets(n_items):
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
