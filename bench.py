@@ -1,17 +1,30 @@
 """Benchmark of the hot path: 1024^2 tiles/s, embed + AMG (vit_b, bf16 MFMA operands), BASELINE.json config 2.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  When the script is NOT already running under a launcher (no WORLD_SIZE in the
+environment) it re-executes itself under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1`` and fails loudly if fewer than N GPUs are visible; under a launcher WORLD_SIZE must equal N.
 
 One step = TILES_PER_STEP synthetic tiles per rank through: batched image encoder -> per tile AutomaticMaskGenerator
-initialize (32x32 grid prompts, fused mask post-processing to bit masks on the device) -> generate
-(default thresholds, box NMS, merge to a uint32 label image); with N > 1 the label tiles of all ranks are all-gathered
-(RCCL) inside the timed region.  Inputs (uint8 RGB tiles, output of util._to_image) are resident in HBM before the timed
-region.  Prints ONE JSON line on rank 0.
+initialize (32x32 grid prompts, fused mask post-processing to bit masks on the device) -> generate (default thresholds,
+box NMS, merge to a uint32 label image); with N > 1 the label tiles of all ranks are all-gathered (RCCL) inside the timed
+region.  Inputs (uint8 RGB tiles, output of util._to_image; 256 distinct tiles per rank, visited in order) are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0 with, next to the contract fields:
+
+  roofline          dominant kernel family of the timed region against the MFMA roofline SURVEY.md 8(d) defines
+                    (algorithmic FLOP of the reference's formulation per launch / live HIP-event duration / 2.5 PFLOP/s);
+                    the family's HBM figures and the other families are kept alongside; whole_path_frac = 4.64 TFLOP x tiles/s
+  cpu_baseline      the CPU oracle (restated reference path, fp32 torch) timed on full tiles on the host cores
+  mask_iou_vs_ref   per-instance mask IoU of the HIP path against that fp32 CPU reference on the same tiles (the metric says
+                    "mask IoU vs ref"): distribution over the instances the reference keeps, keep-set and label agreement
+  pcie_inclusive    tiles/s of a separate pass that also does util._to_image, the H2D upload and the label D2H download
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,34 +41,109 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0           # MI355X dense fp8 (MX-scaled MFMA), --encoder-dtype fp8 only
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6300 GB/s achievable)
 TILE_TFLOP_ALGORITHMIC = 4.64      # encoder 0.938 + AMG decode 3.70
+# SURVEY.md 8(d) per-prompt algorithmic work of the reference's formulation that each decoder stream kernel replaces
+# (GFLOP per prompt per launch): image->token attention of one layer = Q + out projections of 4096 image tokens (0.537);
+# token->image attention of layer 1 / final = K + V projections (0.537); up-scaling = ConvT1 0.537 + ConvT2 0.268 + hyper product 0.02
+ALG_GFLOP_PER_PROMPT = {2: 0.537, 3: 0.537, 4: 0.825}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(sd, tile_u8):
-    """The CPU oracle (restated reference hot path, fp32) on a bounded sample of the same workload:
-    one tile's encoder + 2 of its 16 decoder batches (+ their mask post-processing) + generate; the per-batch cost is
-    extrapolated to 16 batches.  Reported only, never used as a target."""
+def _make_tile(seed):
+    from micro_sam_amd.synthetic import synthetic_tile
+    return synthetic_tile(seed)
+
+
+def make_tiles(seeds):
+    """Distinct synthetic tiles (SURVEY.md 8(d) config 2 generator); a process pool, started before CUDA is touched."""
+    import multiprocessing as mp
+    n_proc = max(1, min(16, (os.cpu_count() or 2) // 2, len(seeds)))
+    if n_proc == 1:
+        return [_make_tile(s) for s in seeds]
+    with mp.get_context("fork").Pool(n_proc) as pool:
+        return pool.map(_make_tile, seeds, chunksize=4)
+
+
+def cpu_reference(sd, tiles_np, n_threads):
+    """The CPU oracle (restated reference hot path, fp32 torch) on FULL tiles: embedding + 16 decoder batches of 64 prompts +
+    mask post-processing + generate, no extrapolation.  Returns the baseline record and the per-tile states / label images
+    (the reference side of mask_iou_vs_ref).  Reported only, never used as a target."""
     from oracle import amg_ref as A
     from oracle import pipeline_ref as PR
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))   # more threads than this only slow the fp32 torch ops down
-    img = A.to_image(tile_u8)
-    t0 = time.perf_counter()
-    feats, osz, isz = PR.compute_embeddings(sd, [img], "vit_b", "fp32")
-    t_enc = time.perf_counter() - t0
-    tm = {}
-    t0 = time.perf_counter()
-    state = PR.amg_initialize(sd, img, feats, isz[0], osz[0], precision="fp32", timings=tm, max_batches=2)
-    t_init2 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    PR.amg_generate(state)
-    t_gen = time.perf_counter() - t0
-    per_tile = t_enc + 8.0 * t_init2 + t_gen
-    return {"value": 1.0 / per_tile, "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 tile: encoder {t_enc:.1f}s + 2/16 decoder batches {t_init2:.1f}s (x8 extrapolated) + "
-                      f"generate {t_gen:.1f}s, fp32 torch on host cores"}
+    torch.set_num_threads(n_threads)
+    per_tile, states, segs, stages = [], [], [], []
+    for tile in tiles_np:
+        img = A.to_image(tile)
+        t0 = time.perf_counter()
+        feats, osz, isz = PR.compute_embeddings(sd, [img], "vit_b", "fp32")
+        t1 = time.perf_counter()
+        tm = {}
+        state = PR.amg_initialize(sd, img, feats, isz[0], osz[0], precision="fp32", timings=tm)
+        t2 = time.perf_counter()
+        seg = PR.amg_generate(state)
+        t3 = time.perf_counter()
+        per_tile.append(t3 - t0)
+        stages.append({"encoder": round(t1 - t0, 2), "decode_x16": round(tm.get("decode", 0.0), 2),
+                       "mask_data_x16": round(tm.get("mask_data", 0.0), 2), "generate": round(t3 - t2, 2)})
+        states.append(state); segs.append(seg)
+        log(f"  cpu reference tile: {t3 - t0:.1f} s {stages[-1]}")
+    med = float(np.median(per_tile))
+    rec = {"value": round(1.0 / med, 5), "unit": "tiles/s", "cores": n_threads, "kind": "port",
+           "sample": f"{len(tiles_np)} full tiles (encoder + 16 x 64 prompts + post-processing + generate each), median "
+                     f"{med:.1f} s per tile, fp32 torch on {n_threads} host threads; no extrapolation",
+           "seconds_per_tile": [round(t, 2) for t in per_tile], "stages_seconds": stages}
+    return rec, states, segs
+
+
+def mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs):
+    """Per-instance mask IoU of the HIP path against the fp32 CPU reference (oracle/parity.py) on the same tiles."""
+    from micro_sam_amd import ops, util
+    from oracle import parity as PT
+    reps, labs = [], []
+    for tile, ref, seg_ref in zip(tiles_np, ref_states, ref_segs):
+        emb = util.precompute_image_embeddings(predictor, tile, verbose=False)
+        amg.initialize(tile, emb)
+        data = amg.crop_list[0]
+        n = len(data)
+        cand = data.shallow_copy()
+        cand["cand"] = torch.arange(n, device=data["iou_preds"].device)
+        kept_test = amg._postprocess_batch(cand, amg.crop_boxes[0], amg.original_size, 0.88, 0.95, 0.7)["cand"].cpu().numpy()
+        kept_ref = PT.kept_candidates(ref)
+        h = amg.original_size[0]
+        bits = data["bits"]
+        test_scores = {"iou_pred": data["iou_preds"].float().cpu().numpy(), "stability": data["stability_score"].float().cpu().numpy()}
+        rep = PT.iou_report(kept_ref, kept_test, PT.oracle_mask_fn(ref),
+                            lambda i: ops.unpack_bits(bits[i:i + 1], h)[0].cpu().numpy(),
+                            PT.oracle_scores(ref), test_scores)
+        reps.append(rep)
+        labs.append(PT.label_agreement(seg_ref, amg.generate().astype(seg_ref.dtype)))
+    out = PT.public(PT.merge_reports(reps))
+    out["tiles"] = len(reps)
+    out["labels"] = {k: (round(float(np.mean([la[k] for la in labs])), 5) if "frac" in k or "agreement" in k else
+                         [la[k] for la in labs]) for k in labs[0]}
+    out["reference"] = "fp32 CPU oracle (restated reference path) on the same tiles and weights"
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks."""
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to run a smaller job "
+                             f"under this label")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("bench.py: launching", " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -63,12 +151,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU reference leg (cpu_baseline, mask_iou_vs_ref)")
+    ap.add_argument("--cpu-tiles", type=int, default=3, help="full tiles the CPU reference runs (median reported)")
     ap.add_argument("--glds", type=int, default=0)
     ap.add_argument("--tiles-per-step", type=int, default=TILES_PER_STEP, help="tiles per rank and step")
+    ap.add_argument("--distinct-tiles", type=int, default=256, help="distinct synthetic tiles per rank, visited in order")
     ap.add_argument("--enc-batch", type=int, default=ENC_BATCH, help="tiles per image-encoder call")
     ap.add_argument("--encoder-dtype", choices=("bf16", "fp8"), default="bf16",
                     help="fp8: BASELINE config 5 (encoder projections on fp8 e4m3 MX MFMA, bf16 decoder); NOT the headline metric")
+    ap.add_argument("--weights", choices=("cells", "blobs", "field"), default="cells",
+                    help="synthetic checkpoint variant (micro_sam_amd/synthetic.py)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="tiles are decoded round-robin on this many HIP streams (each with its own predictor state and "
                          "decoder workspace): the latency-bound token-side launches of one tile run underneath the "
@@ -77,11 +169,39 @@ def main():
                     help="run generate() on the main stream (default: side stream overlapping the next tile's decode)")
     ap.add_argument("--device-chunk", type=int, default=1024,
                     help="grid prompts decoded per decoder pass (results do not depend on it)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only: gloo, no GPU work, prints the JSON line with n_gpus = world size")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if args.dry_run:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "1024^2 tiles/s embed+AMG (vit_b bf16)", "value": 0.0, "unit": "tiles/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True}), flush=True)
+        return
+
+    # distinct synthetic tiles per rank (seed = global tile index), generated before CUDA is initialised (fork pool)
+    n_tiles = args.tiles_per_step
+    enc_batch = args.enc_batch
+    n_distinct = max(n_tiles, (args.distinct_tiles // n_tiles) * n_tiles)
+    t_gen = time.perf_counter()
+    tiles_np = make_tiles([1000 + rank * n_distinct + i for i in range(n_distinct)])
+    log(f"rank {rank}: {n_distinct} distinct tiles generated in {time.perf_counter() - t_gen:.1f} s")
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -90,36 +210,31 @@ def main():
 
     from micro_sam_amd import _lib, parallel, util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
-    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    from micro_sam_amd.synthetic import synthetic_state_dict
 
-    sd = synthetic_state_dict("vit_b", 0, variant="blobs")
+    sd = synthetic_state_dict("vit_b", 0, variant=args.weights)
     predictor = util.get_sam_model("vit_b", device=dev, state_dict=sd)
     predictor.model.use_glds = args.glds
     predictor.model.image_encoder.use_glds = args.glds
     predictor.model.image_encoder.set_precision(args.encoder_dtype)
     amg = AutomaticMaskGenerator(predictor, device_chunk=args.device_chunk)   # reference defaults: 32x32 grid, 64 points per batch
 
-    n_steps = args.warmup + args.steps
-    # distinct synthetic tiles per rank and step (seed = global tile index), staged in HBM before timing
-    n_tiles = args.tiles_per_step
-    enc_batch = args.enc_batch
-    tiles_np = [synthetic_tile(1000 + rank * n_tiles + i) for i in range(n_tiles)]
-    tiles_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in tiles_np]).to(dev)
+    tiles_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in tiles_np]).to(dev)     # [n_distinct,1024,1024,3] in HBM
     torch.cuda.synchronize()
     lib = _lib.load()
     stage = {"encode": 0.0, "initialize": 0.0, "generate": 0.0, "gather": 0.0, "host_enqueue": 0.0}
-    n_instances = 0
+    n_instances = []
 
     # live HIP-event measurement per kernel family (include/msam_hip.h msam_profile_collect_family)
     NF = _lib.PROFILE_FAMILIES
     FAMILY = [
         ("gemm256_kernel (256x256 tile MFMA GEMM: the image encoder's qkv / proj / MLP projections)", "mfma"),
         ("wsgemm_kernel / dec_image_layer_kernel (weights-stationary streaming kernels, > 8 tokens per prompt)", "hbm"),
-        ("fold_i2t_kernel (folded image->token attention + out_proj + norm4: stream read (layer 1) + written in place)", "hbm"),
-        ("fold_attn_kernel (folded token->image attention: stream read once)", "hbm"),
-        ("up_fused_kernel (fused up-scaling + hyper product: stream read once, fp32 low-res logits written)", "hbm"),
-        ("gemm_kernel / gemm_ln_kernel (128x128 tile MFMA GEMM: patch embedding, neck and the ~39 latency-bound token-side "
-         "launches per tile)", "mfma"),
+        ("fold_i2t_kernel (folded image->token attention + out_proj + norm4 of one decoder layer)", "mfma"),
+        ("fold_attn_kernel (folded token->image attention of layer 1 / final)", "mfma"),
+        ("up_fused_kernel (fused up-scaling ConvT-LN-GELU-ConvT-GELU + hyper product)", "mfma"),
+        ("gemm_kernel / gemm_ln_kernel (128x128 tile MFMA GEMM: patch embedding, neck and the latency-bound token-side "
+         "launches)", "mfma"),
     ]
     prof = [{"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0} for _ in range(NF)]
 
@@ -136,17 +251,23 @@ def main():
         pk = util.get_sam_model("vit_b", device=dev, state_dict=sd)
         pk.model.use_glds = args.glds
         lanes.append((pk, AutomaticMaskGenerator(pk, device_chunk=args.device_chunk), torch.cuda.Stream(device=dev)))
+    shape_only = np.broadcast_to(np.zeros((1, 1), dtype=np.uint8), (1024, 1024))   # initialize() reads the image SHAPE only
 
-    def step(timed: bool):
+    def step(timed: bool, index: int, uploads=None):
         """timed=True: instrumented pass with a device sync after every stage (stage breakdown only);
-        timed=False: the production path, no extra synchronisation."""
-        nonlocal n_instances
+        timed=False: the production path, no extra synchronisation.  uploads: host tiles to convert + upload inside the step
+        (the PCIe-inclusive pass), else the resident uint8 tiles of step `index` are used."""
         labels = torch.empty((n_tiles, 1024, 1024), dtype=torch.int32, device=dev)
         flags = []
         t0 = time.perf_counter()
+        if uploads is not None:
+            batch_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in uploads]).to(dev, non_blocking=False)
+        else:
+            lo = (index * n_tiles) % n_distinct
+            batch_u8 = tiles_u8[lo:lo + n_tiles]
         feats = []
         for s in range(0, n_tiles, enc_batch):
-            feats.append(predictor.model.image_encoder.forward_u8(tiles_u8[s:s + enc_batch]))
+            feats.append(predictor.model.image_encoder.forward_u8(batch_u8[s:s + enc_batch]))
         feats = torch.cat(feats).unsqueeze(1)                       # [n,1,256,64,64] on device
         emb = {"features": feats, "input_size": (1024, 1024), "original_size": (1024, 1024)}
         if timed:
@@ -158,7 +279,7 @@ def main():
             for i in range(n_tiles):
                 _, ak, st = lanes[i % len(lanes)]
                 with torch.cuda.stream(st):
-                    ak.initialize(tiles_np[i], emb, i=i)
+                    ak.initialize(shape_only, emb, i=i)
                     lab, flag = ak.generate_device()
                     labels[i] = lab
                 flags.append(flag)
@@ -166,7 +287,7 @@ def main():
                 main.wait_stream(st)
         for i in range(n_tiles if (len(lanes) == 1 or timed) else 0):
             t1 = time.perf_counter()
-            amg.initialize(tiles_np[i], emb, i=i)
+            amg.initialize(shape_only, emb, i=i)
             if timed:
                 torch.cuda.synchronize(); stage["initialize"] += time.perf_counter() - t1
             t2 = time.perf_counter()
@@ -189,29 +310,39 @@ def main():
             torch.cuda.synchronize(); stage["gather"] += time.perf_counter() - t3
         if not timed:
             stage["host_enqueue"] += time.perf_counter() - t0    # host time to enqueue the whole step (no sync inside)
+        host_labels = full.cpu() if uploads is not None else None       # PCIe-inclusive pass: label D2H
         # single synchronisation point of the step: convergence flags of the connected-component labelling
         if int(torch.stack(flags).sum().item()) != 0:
             raise RuntimeError("connected-component labelling did not converge in 2 passes")
-        n_instances = int(labels[-1].max().item())
-        return full
+        if timed:
+            n_instances.extend(int(v) for v in labels.flatten(1).max(dim=1).values.tolist())
+        return host_labels if uploads is not None else full
 
-    for _ in range(args.warmup):
-        step(False)
+    for k in range(args.warmup):
+        step(False, k)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     lib.msam_profile_enable(1)
     stage["host_enqueue"] = 0.0
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(False)
-        collect()            # synchronises the step's GEMM events (end of step: nothing left in flight anyway)
+    for k in range(args.steps):
+        step(False, args.warmup + k)
+        collect()            # synchronises the step's kernel events (end of step: nothing left in flight anyway)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     lib.msam_profile_enable(0)
-    step(True)               # one extra instrumented pass (outside the timed region) for the stage breakdown
+    step(True, 0)            # one extra instrumented pass (outside the timed region) for the stage breakdown
+    # PCIe-inclusive pass (outside the timed region): util._to_image + H2D of the uint8 tiles + label D2H inside the clock
+    torch.cuda.synchronize()
+    t_p = time.perf_counter()
+    n_pcie = min(3, max(1, n_distinct // n_tiles))
+    for k in range(n_pcie):
+        step(False, k, uploads=tiles_np[k * n_tiles:(k + 1) * n_tiles])
+    torch.cuda.synchronize()
+    pcie_elapsed = time.perf_counter() - t_p
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,38 +356,50 @@ def main():
         def fam(f):
             d = prof[f]
             sec = d["ms"] * 1e-3
-            r = {"kernel": FAMILY[f][0], "bound": FAMILY[f][1], "launches": d["launches"],
-                 "seconds_per_tile": round(sec / tiles_timed, 5),
-                 "avg_launch_us": round(d["ms"] * 1e3 / max(d["launches"], 1), 2),
-                 "tflops": round(d["flops"] / sec / 1e12, 2) if sec > 0 else 0.0,
-                 "gbytes_per_s": round(d["bytes"] / sec / 1e9, 1) if sec > 0 and d["bytes"] > 0 else None,
-                 "avg_launch_gflop": round(d["flops"] / max(d["launches"], 1) / 1e9, 3),
-                 "avg_launch_mbytes": round(d["bytes"] / max(d["launches"], 1) / 1e6, 2)}
-            if FAMILY[f][1] == "mfma":
-                peak = PEAK_FP8_TFLOPS if (f == 0 and args.encoder_dtype == "fp8") else PEAK_BF16_TFLOPS
-                r.update(achieved=r["tflops"], peak=peak, unit="TFLOP/s", frac=round(r["tflops"] / peak, 4))
+            launches = max(d["launches"], 1)
+            exec_tflops = d["flops"] / sec / 1e12 if sec > 0 else 0.0
+            # algorithmic FLOP per launch: 2*M*N*K for the GEMM families; SURVEY 8(d)'s per-prompt figure x prompts per launch
+            # for the decoder stream kernels (one launch = device_chunk prompts of one tile)
+            if f in ALG_GFLOP_PER_PROMPT:
+                prompts_per_launch = min(args.device_chunk, 1024)
+                alg_flop = ALG_GFLOP_PER_PROMPT[f] * 1e9 * prompts_per_launch * d["launches"]
             else:
-                g = r["gbytes_per_s"] or 0.0
-                r.update(achieved=g, peak=PEAK_HBM_GBS, unit="GB/s", frac=round(g / PEAK_HBM_GBS, 4))
-            return r
+                alg_flop = d["flops"]
+            alg_tflops = alg_flop / sec / 1e12 if sec > 0 else 0.0
+            peak = PEAK_FP8_TFLOPS if (f == 0 and args.encoder_dtype == "fp8") else PEAK_BF16_TFLOPS
+            g = d["bytes"] / sec / 1e9 if sec > 0 and d["bytes"] > 0 else None
+            return {"kernel": FAMILY[f][0], "bound": FAMILY[f][1], "launches": d["launches"],
+                    "seconds_per_tile": round(sec / tiles_timed, 5),
+                    "avg_launch_us": round(d["ms"] * 1e3 / launches, 2),
+                    "achieved": round(alg_tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(alg_tflops / peak, 4),
+                    "avg_launch_gflop_algorithmic": round(alg_flop / launches / 1e9, 3),
+                    "executed_tflops": round(exec_tflops, 2),
+                    "hbm_gbytes_per_s": None if g is None else round(g, 1),
+                    "hbm_frac": None if g is None else round(g / PEAK_HBM_GBS, 4),
+                    "avg_launch_mbytes": round(d["bytes"] / launches / 1e6, 2)}
 
         fams = [fam(f) for f in range(NF) if prof[f]["launches"] > 0]
         fams.sort(key=lambda r: -r["seconds_per_tile"])
         # roofline of the dominant kernel (largest GPU time in the timed region); the others are kept alongside.
         # `traffic`: HBM bytes per launch from the PMC passes of profiles/ (FETCH_SIZE / WRITE_SIZE, separate runs), when a
         # table for this kernel is committed
-        dom = dict(fams[0]) if fams else {"bound": "hbm", "achieved": 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 0.0}
+        dom = dict(fams[0]) if fams else {"bound": "mfma", "achieved": 0.0, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": 0.0}
         traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            for name, rec in pmc.items():
-                if isinstance(rec, dict) and name.split("<")[0] in dom.get("kernel", ""):
-                    traffic = rec.get("hbm_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pmc = json.load(fh)
+                for kname, rec in pmc.items():
+                    if isinstance(rec, dict) and kname.split("<")[0] in dom.get("kernel", ""):
+                        traffic = rec.get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    break
+            except (OSError, ValueError):
+                pass
+        whole = TILE_TFLOP_ALGORITHMIC * value / world
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                 "traffic": traffic, **{k: v for k, v in dom.items() if k not in ("bound", "achieved", "peak", "unit", "frac")},
+                "whole_path_tflops": round(whole, 2), "whole_path_frac": round(whole / PEAK_BF16_TFLOPS, 4),
                 "other_kernels": fams[1:]}
         out = {
             "metric": "1024^2 tiles/s embed+AMG (vit_b bf16)" if args.encoder_dtype == "bf16" else
@@ -266,21 +409,41 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if args.encoder_dtype == "bf16" else "fp8 encoder projections + bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
                                    "AutomaticMaskGenerator (32x32 grid, multimask, default thresholds)",
-                       "tiles_per_step_per_gpu": n_tiles, "encoder_batch": enc_batch, "weights": "seeded random init "
-                       "(synthetic.py variant 'blobs')", "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
-                       "instances_last_tile": n_instances,
+                       "tiles_per_step_per_gpu": n_tiles, "encoder_batch": enc_batch,
+                       "distinct_tiles_per_gpu": n_distinct,
+                       "weights": f"seeded synthetic checkpoint (synthetic.py variant '{args.weights}')",
+                       "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
+                       "timed_region": "uint8 RGB tiles resident in HBM -> label tiles in HBM (all-gathered when N > 1); "
+                                       "util._to_image, H2D and label D2H are in pcie_inclusive, lazy RLE encoding in rle_side",
+                       "instances_per_tile": {"median": int(np.median(n_instances)), "min": int(min(n_instances)),
+                                              "max": int(max(n_instances))},
                        "stage_seconds_per_tile_synced_pass": {k: round(v / n_tiles, 5) for k, v in stage.items()
                                                               if k != "host_enqueue"},
                        "host_enqueue_seconds_per_tile": round(stage["host_enqueue"] / (n_tiles * args.steps), 5),
-                       "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC,
-                       "whole_path_tflops_algorithmic": round(TILE_TFLOP_ALGORITHMIC * value / world, 2)},
+                       "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC},
             "roofline": roof,
+            "pcie_inclusive": {"value": round(n_pcie * n_tiles / pcie_elapsed, 2), "unit": "tiles/s", "tiles": n_pcie * n_tiles,
+                               "includes": "util._to_image on the host, pageable H2D of uint8 RGB tiles (3 MiB each), label D2H (4 MiB each)"},
         }
+        # a15 side measurement: RLE encoding of one tile's candidate masks (lazy in the product: only when rles are read)
+        amg.initialize(shape_only, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]).unsqueeze(1),
+                                    "input_size": (1024, 1024), "original_size": (1024, 1024)}, i=0)
+        from micro_sam_amd import ops
+        bits = amg.crop_list[0]["bits"]
+        torch.cuda.synchronize(); t_r = time.perf_counter()
+        counts, offsets = ops.rle_encode(bits.contiguous(), 1024, 1024)
+        torch.cuda.synchronize()
+        out["rle_side"] = {"masks": int(bits.shape[0]), "ms_device": round((time.perf_counter() - t_r) * 1e3, 3),
+                           "total_runs": int(offsets[-1].item()) if offsets.numel() else 0}
         if not args.no_cpu_baseline and world == 1:
-            log("timing the CPU oracle on a bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(sd, tiles_np[0])
+            log(f"timing the CPU reference on {args.cpu_tiles} full tiles ...")
+            n_thr = min(os.cpu_count() or 1, 32)    # more threads than this only slow the fp32 torch ops down
+            ref_tiles = tiles_np[:args.cpu_tiles]
+            out["cpu_baseline"], ref_states, ref_segs = cpu_reference(sd, ref_tiles, n_thr)
+            out["mask_iou_vs_ref"] = mask_iou_vs_ref(predictor, amg, ref_tiles, ref_states, ref_segs)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
+            out["mask_iou_vs_ref"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -62,20 +62,43 @@ PIXEL_STD = (58.395, 57.12, 57.375)      # build_sam.py:133
 class Prec:
     """Rounding policy (see module docstring)."""
 
-    def __init__(self, precision: str = "fp32"):
+    def __init__(self, precision: str = "fp32", exact_sites=(), only_sites=None):
+        """``exact_sites`` / ``only_sites`` (ablation hooks, bf16 mode): decoder rounding sites kept in fp32 / the only sites
+        that round.  Sites: "stream" (the image-token stream as stored), "tok" (token-side projections and their stored
+        q / k / v / probabilities), "t2i0" (layer 0's shared K / V), "fold" (folded vectors K' / V' / Q'), "table"
+        (pe W^T + b tables), "probs" (attention probabilities of the folded kernels), "foldv" (per-head value projection
+        weights of the folded token->image attention), "up" (up-scaling operands), "head" (hyper-network / IoU MLPs)."""
         assert precision in ("fp32", "bf16", "fp8"), precision
+        self.exact_sites = set(exact_sites)
+        self.only_sites = None if only_sites is None else set(only_sites)
+        self.site_dtype = {}          # decoder site -> storage / operand dtype (default bfloat16); see ``Prec.hip()``
         # "fp8" (BASELINE config 5): the bf16 policy everywhere, except that the four large projections of every encoder
         # block (qkv, proj, lin1, lin2) take OCP e4m3 operands - activations with one scale per token, weights with one
         # scale per output channel (linear_q)
         self.bf16 = precision in ("bf16", "fp8")
         self.fp8 = precision == "fp8"
 
-    def r(self, x: Tensor) -> Tensor:
-        """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode."""
-        return x.to(torch.bfloat16).to(torch.float32) if self.bf16 else x
+    def rounds(self, site: Optional[str]) -> bool:
+        if not self.bf16:
+            return False
+        if site is None:
+            return self.only_sites is None
+        if self.only_sites is not None:
+            return site in self.only_sites
+        return site not in self.exact_sites
 
-    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
-        y = F.linear(self.r(x), self.r(w))
+    def r(self, x: Tensor, site: Optional[str] = None) -> Tensor:
+        """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode (or when the site is kept exact)."""
+        if not self.rounds(site):
+            return x
+        dt = self.site_dtype.get(site, torch.bfloat16)
+        if dt == "split":             # bf16 hi + lo operand pair (two / three MFMA passes): ~16 mantissa bits
+            hi = x.to(torch.bfloat16).to(torch.float32)
+            return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
+        return x.to(dt).to(torch.float32)
+
+    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, site: Optional[str] = None) -> Tensor:
+        y = F.linear(self.r(x, site), self.r(w, site))
         return y if b is None else y + b
 
     def matmul(self, a: Tensor, b: Tensor) -> Tensor:
@@ -355,7 +378,7 @@ def prompt_encoder(sd: Dict[str, Tensor], points: Optional[Tuple[Tensor, Tensor]
 
 def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads: int = 8,
                    q_pe: Optional[Tensor] = None, k_pe: Optional[Tensor] = None, mfma_pv: bool = False,
-                   fold: bool = False, fold_i2t: bool = False) -> Tensor:
+                   fold: bool = False, fold_i2t: bool = False, q_site: str = "tok", kv_site: str = "tok") -> Tensor:
     """q_pe / k_pe: positional encodings of the IMAGE-side operand.  fp32 mode adds them before the projection
     (upstream); bf16 mode follows the HIP dataflow (x + pe) W = x W + pe W with separately rounded operands.
     fold (bf16 mode only, token->image attention over the per-prompt stream with <= 8 tokens): the HIP path folds the
@@ -364,17 +387,17 @@ def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads
         return _dec_attention_folded(sd, pre, q, k, p, heads, k_pe)
     if p.bf16 and fold_i2t and k.shape[1] <= 8:
         return _dec_attention_i2t_folded(sd, pre, q, k, v, p, heads, q_pe)
-    def proj(x, pe, name):
+    def proj(x, pe, name, site):
         w, b = sd[pre + name + ".weight"], sd[pre + name + ".bias"]
         if pe is None:
-            return p.linear(x, w, b)
-        if not p.bf16:
-            return p.linear(x + pe, w, b)
-        return p.linear(x, w, b) + p.linear(pe, w)
-    q = proj(q, q_pe, "q_proj")
-    k = proj(k, k_pe, "k_proj")
-    v = p.linear(v, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"])
-    q, k, v = p.r(q), p.r(k), p.r(v)   # HIP path stores the projected q/k/v in bf16
+            return p.linear(x, w, b, site)
+        if not p.rounds(site):
+            return p.linear(x + pe, w, b, site)
+        return p.linear(x, w, b, site) + p.linear(pe, w, None, site)
+    q = proj(q, q_pe, "q_proj", q_site)
+    k = proj(k, k_pe, "k_proj", kv_site)
+    v = p.linear(v, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"], kv_site)
+    q, k, v = p.r(q, q_site), p.r(k, kv_site), p.r(v, kv_site)   # HIP path stores the projected q/k/v in bf16
     b, nq, c = q.shape
     def sep(t):
         return t.reshape(b, t.shape[1], heads, c // heads).transpose(1, 2)
@@ -383,11 +406,11 @@ def _dec_attention(sd, pre: str, q: Tensor, k: Tensor, v: Tensor, p: Prec, heads
     if p.bf16 and mfma_pv:
         # HIP cross attentions: un-normalised probabilities rounded to bf16 for the P.V MFMA, fp32 row sum
         e = torch.exp(attn - attn.max(dim=-1, keepdim=True).values)
-        out = (p.r(e) @ v) / e.sum(dim=-1, keepdim=True)
+        out = (p.r(e, kv_site) @ v) / e.sum(dim=-1, keepdim=True)
     else:
         out = torch.softmax(attn, dim=-1) @ v
     out = out.transpose(1, 2).reshape(b, nq, c)
-    return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+    return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"], q_site)
 
 
 def _dec_attention_folded(sd, pre: str, q: Tensor, keys: Tensor, p: Prec, heads: int, k_pe: Tensor) -> Tensor:
@@ -395,20 +418,20 @@ def _dec_attention_folded(sd, pre: str, q: Tensor, keys: Tensor, p: Prec, heads:
     probabilities rounded to bf16 for the P . keys MFMA, context kept in fp32 for the per-head value projection."""
     wk, bk = sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]
     wv, bv = sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]
-    q = p.r(p.linear(q, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]))            # [b, nq, 128]
+    q = p.r(p.linear(q, sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"], "tok"), "tok")            # [b, nq, 128]
     b, nq, ci = q.shape
     hd = ci // heads
     qh = q.reshape(b, nq, heads, hd).transpose(1, 2)                                     # [b, h, nq, 16]
-    wkh = p.r(wk).reshape(heads, hd, -1)                                                 # [h, 16, 256]
-    qf = p.r(torch.einsum("bhtd,hdc->bhtc", qh, wkh))                                    # folded queries, bf16
-    tab = p.r(p.linear(k_pe[:1], wk, bk))[0].reshape(-1, heads, hd)                      # [T, h, 16]
-    keys = p.r(keys)
+    wkh = p.r(wk, "fold").reshape(heads, hd, -1)                                         # [h, 16, 256]
+    qf = p.r(torch.einsum("bhtd,hdc->bhtc", qh, wkh), "fold")                            # folded queries, bf16
+    tab = p.r(p.linear(k_pe[:1], wk, bk, "table"), "table")[0].reshape(-1, heads, hd)    # [T, h, 16]
+    keys = p.r(keys, "stream")
     s = (torch.einsum("bhtc,bjc->bhtj", qf, keys) + torch.einsum("bhtd,jhd->bhtj", qh, tab)) / math.sqrt(hd)
     e = torch.exp(s - s.max(dim=-1, keepdim=True).values)
-    ctx = torch.einsum("bhtj,bjc->bhtc", p.r(e), keys) / e.sum(dim=-1, keepdim=True)     # [b, h, nq, 256] fp32
-    out = torch.einsum("bhtc,hdc->bhtd", ctx, p.r(wv).reshape(heads, hd, -1)) + bv.reshape(1, heads, 1, hd)
+    ctx = torch.einsum("bhtj,bjc->bhtc", p.r(e, "probs"), keys) / e.sum(dim=-1, keepdim=True)     # [b, h, nq, 256] fp32
+    out = torch.einsum("bhtc,hdc->bhtd", ctx, p.r(wv, "foldv").reshape(heads, hd, -1)) + bv.reshape(1, heads, 1, hd)
     out = out.transpose(1, 2).reshape(b, nq, ci)
-    return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"])
+    return p.linear(out, sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"], "tok")
 
 
 def _dec_attention_i2t_folded(sd, pre: str, keys: Tensor, k_in: Tensor, v_in: Tensor, p: Prec, heads: int,
@@ -417,18 +440,18 @@ def _dec_attention_i2t_folded(sd, pre: str, keys: Tensor, k_in: Tensor, v_in: Te
     softmax over the prompt tokens, normalised P rounded to bf16, out = P . bf16(Wo_h v_h) + bo (out_proj folded)."""
     wq, bq = sd[pre + "q_proj.weight"], sd[pre + "q_proj.bias"]
     wo, bo = sd[pre + "out_proj.weight"], sd[pre + "out_proj.bias"]
-    k = p.r(p.linear(k_in, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"]))        # [b, nt, 128]
-    v = p.r(p.linear(v_in, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"]))
+    k = p.r(p.linear(k_in, sd[pre + "k_proj.weight"], sd[pre + "k_proj.bias"], "tok"), "tok")        # [b, nt, 128]
+    v = p.r(p.linear(v_in, sd[pre + "v_proj.weight"], sd[pre + "v_proj.bias"], "tok"), "tok")
     b, nt, ci = k.shape
     hd = ci // heads
     kh = k.reshape(b, nt, heads, hd).transpose(1, 2)                                    # [b, h, nt, 16]
     vh = v.reshape(b, nt, heads, hd).transpose(1, 2)
-    kf = p.r(torch.einsum("bhtd,hdc->bhtc", kh, p.r(wq).reshape(heads, hd, -1)))        # K' [b, h, nt, 256]
-    vf = p.r(torch.einsum("chd,bhtd->bhtc", p.r(wo).reshape(-1, heads, hd), vh))        # V' [b, h, nt, 256]
-    tab = p.r(p.linear(q_pe[:1], wq, bq))[0].reshape(-1, heads, hd)                     # [T, h, 16]
-    keys = p.r(keys)
+    kf = p.r(torch.einsum("bhtd,hdc->bhtc", kh, p.r(wq, "fold").reshape(heads, hd, -1)), "fold")        # K' [b, h, nt, 256]
+    vf = p.r(torch.einsum("chd,bhtd->bhtc", p.r(wo, "fold").reshape(-1, heads, hd), vh), "fold")        # V' [b, h, nt, 256]
+    tab = p.r(p.linear(q_pe[:1], wq, bq, "table"), "table")[0].reshape(-1, heads, hd)   # [T, h, 16]
+    keys = p.r(keys, "stream")
     s = (torch.einsum("bjc,bhtc->bjht", keys, kf) + torch.einsum("jhd,bhtd->bjht", tab, kh)) / math.sqrt(hd)
-    a = p.r(torch.softmax(s, dim=-1))
+    a = p.r(torch.softmax(s, dim=-1), "probs")
     return torch.einsum("bjht,bhtc->bjc", a, vf) + bo
 
 
@@ -444,7 +467,7 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
     key_pe = image_pe.flatten(2).permute(0, 2, 1)
     queries = point_embedding
     query_pe = point_embedding
-    keys = p.r(keys)  # HIP path keeps the image-token stream in bf16
+    keys = p.r(keys, "stream")  # HIP path keeps the image-token stream in bf16
     for i in range(2):
         lp = f"{pre}layers.{i}."
         if i == 0:
@@ -455,15 +478,15 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
         queries = _ln(sd, lp + "norm1.", queries)
         q = queries + query_pe
         queries = queries + _dec_attention(sd, lp + "cross_attn_token_to_image.", q, keys, keys, p, k_pe=key_pe,
-                                           mfma_pv=True, fold=i > 0)
+                                           mfma_pv=True, fold=i > 0, kv_site="t2i0")
         queries = _ln(sd, lp + "norm2.", queries)
-        m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"])
-        m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"])
+        m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"], "tok")
+        m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"], "tok")
         queries = _ln(sd, lp + "norm3.", queries + m)
         q = queries + query_pe
         keys = keys + _dec_attention(sd, lp + "cross_attn_image_to_token.", keys, q, queries, p, q_pe=key_pe,
                                      mfma_pv=True, fold_i2t=True)
-        keys = p.r(_ln(sd, lp + "norm4.", keys))
+        keys = p.r(_ln(sd, lp + "norm4.", keys), "stream")
         if debug is not None:
             debug[f"queries{i}"] = queries.clone()
             debug[f"keys{i}"] = keys.clone()
@@ -477,15 +500,15 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
 
 
 def _mlp3(sd, pre: str, x: Tensor, p: Prec) -> Tensor:
-    x = F.relu(p.linear(x, sd[pre + "layers.0.weight"], sd[pre + "layers.0.bias"]))
-    x = F.relu(p.linear(x, sd[pre + "layers.1.weight"], sd[pre + "layers.1.bias"]))
-    return p.linear(x, sd[pre + "layers.2.weight"], sd[pre + "layers.2.bias"])
+    x = F.relu(p.linear(x, sd[pre + "layers.0.weight"], sd[pre + "layers.0.bias"], "head"))
+    x = F.relu(p.linear(x, sd[pre + "layers.1.weight"], sd[pre + "layers.1.bias"], "head"))
+    return p.linear(x, sd[pre + "layers.2.weight"], sd[pre + "layers.2.bias"], "head")
 
 
 def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor, dense: Tensor,
                  multimask_output: bool, precision: str = "fp32", debug: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
     """MaskDecoder.forward -> (low-res masks [B,C,256,256], iou [B,C])."""
-    p = Prec(precision)
+    p = precision if isinstance(precision, Prec) else Prec(precision)
     pre = "mask_decoder."
     output_tokens = torch.cat([sd[pre + "iou_token.weight"], sd[pre + "mask_tokens.weight"]], dim=0)
     output_tokens = output_tokens.unsqueeze(0).expand(sparse.size(0), -1, -1)
@@ -500,12 +523,12 @@ def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor,
     iou_token_out = hs[:, 0, :]
     mask_tokens_out = hs[:, 1:5, :]
     src = src.transpose(1, 2).view(b, c, h, w)
-    up = F.conv_transpose2d(p.r(src), p.r(sd[pre + "output_upscaling.0.weight"]), None, stride=2)
+    up = F.conv_transpose2d(p.r(src, "stream"), p.r(sd[pre + "output_upscaling.0.weight"], "up"), None, stride=2)
     up = up + sd[pre + "output_upscaling.0.bias"].view(1, -1, 1, 1)
     up = F.gelu(layer_norm_2d(up, sd[pre + "output_upscaling.1.weight"], sd[pre + "output_upscaling.1.bias"]))
     if debug is not None:
         debug["up1"] = up.clone()
-    up = F.conv_transpose2d(p.r(up), p.r(sd[pre + "output_upscaling.3.weight"]), None, stride=2)
+    up = F.conv_transpose2d(p.r(up, "up"), p.r(sd[pre + "output_upscaling.3.weight"], "up"), None, stride=2)
     up = F.gelu(up + sd[pre + "output_upscaling.3.bias"].view(1, -1, 1, 1))
     hyper = torch.stack(
         [_mlp3(sd, f"{pre}output_hypernetworks_mlps.{i}.", mask_tokens_out[:, i, :], p) for i in range(4)], dim=1)
