@@ -27,6 +27,7 @@ extern "C" {
 #define MSAM_F32 1
 #define MSAM_BF16 2
 #define MSAM_FP8 3                       /* OCP e4m3 (gfx950), not the fnuz variant of MI300 */
+#define MSAM_F16 4                       /* IEEE fp16: the mask decoder's 16-bit type (msam_decoder_dtype) */
 #define MSAM_ACT_NONE 0
 #define MSAM_ACT_GELU 1
 #define MSAM_ACT_RELU 2
@@ -65,7 +66,9 @@ typedef struct {
                                             group followed by exact GELU; applied after bias/table/resid */
     const float* ln_w; const float* ln_b; float ln_eps;    /* [256] (mode 1) or [64] (mode 2) */
     /* fp8 operands (BASELINE config 5): a_dtype = MSAM_FP8 -> A and W are OCP e4m3 bytes (lda / ldw / K in elements,
-     * K % 128 == 0, N % 256 == 0), out = act(acc * row_scale[m] * col_scale[n] + bias + resid); 0 / MSAM_BF16 = bf16 */
+     * K % 128 == 0, N % 256 == 0), out = act(acc * row_scale[m] * col_scale[n] + bias + resid); 0 / MSAM_BF16 = bf16;
+     * MSAM_F16 = A and W are IEEE fp16 (128 x 128 tile kernel, plain / grouped launches; 16-bit outputs follow out_dtype:
+     * MSAM_F16 -> fp16, MSAM_BF16 -> bf16) */
     int32_t a_dtype;
     const float* row_scale; const float* col_scale;        /* fp32 [M], [N] */
 } msam_gemm_t;
@@ -276,6 +279,9 @@ typedef struct {
 } msam_decoder_t;
 
 /* Per-image constants of the decoder (dense positional encoding etc.): computed once per model. */
+/* 16-bit type of the decoder weights in msam_decoder_t / msam_upscale_fused / msam_wsgemm_bf16 / ... and of the decoder's
+ * 16-bit tensors at the operator-level entry points: MSAM_F16 (default build) or MSAM_BF16 (built with -DMSAM_DEC_F16=0). */
+int msam_decoder_dtype(void);
 int64_t msam_decoder_const_bytes(void);
 int msam_decoder_prepare_const(const msam_decoder_t* dec, void* consts, void* stream);
 /* Per-tile image-side precompute: src tokens, layer-0 image projections (prompt independent). */
@@ -303,6 +309,23 @@ int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_mask_prompt
                                const void* image_state, const float* points, const int32_t* labels, int32_t Np,
                                const float* boxes, const float* mask_input, int32_t P, int32_t multimask, float* low_res,
                                float* iou, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The prompt encoder and the mask decoder as stand-alone module calls (the reference calls them directly:
+ * micro_sam/training/trainable_sam.py:96-106 `sam.prompt_encoder(points, boxes, masks)` and
+ * `sam.mask_decoder(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output)`).
+ * msam_prompt_encode: sparse fp32 [P, Ns, 256] with Ns = Np + (boxes ? 2 : (Np > 0 ? 1 : 0)) (not written when Ns == 0);
+ *   dense fp32 [P, 256, 64, 64] is written only for mask prompts (mask_input fp32 [P,1,256,256]); without masks the dense
+ *   embedding is the broadcast no_mask_embed, which the caller builds as a view.
+ * msam_decoder_forward_embeddings: sparse fp32 [P, Ns, 256] (0 <= Ns <= 11), dense fp32 [P, 256, 64, 64] or NULL = the
+ *   broadcast no_mask_embed already folded into image_state; `embedding` fp32 [256, 64, 64] is needed with a dense
+ *   embedding.  The positional encoding is the model's own (msam_decoder_prepare_const). */
+int msam_prompt_encode(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const float* points,
+                       const int32_t* labels, int32_t Np, const float* boxes, const float* mask_input, int32_t P,
+                       float* sparse, float* dense, void* stream);
+int msam_decoder_forward_embeddings(const msam_decoder_t* dec, const void* consts, const void* image_state,
+                                    const float* sparse, int32_t Ns, const float* dense, const float* embedding,
+                                    int32_t P, int32_t multimask, float* low_res, float* iou, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Mask post-processing:  Sam.postprocess_masks + AMGBase._to_mask_data

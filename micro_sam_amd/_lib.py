@@ -15,7 +15,7 @@ import torch
 from . import build as _build
 
 MSAM_MAX_BLOCKS = 32
-F32, BF16, FP8 = 1, 2, 3
+F32, BF16, FP8, F16 = 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -131,11 +131,15 @@ _PROTOS = {
     "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),
     "msam_encoder_forward": (_i32, [C.POINTER(EncoderParams), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "msam_decoder_dtype": (_i32, []),
     "msam_decoder_const_bytes": (_i64, []),
     "msam_decoder_prepare_const": (_i32, [C.POINTER(DecoderParams), _vp, _vp]),
     "msam_decoder_image_bytes": (_i64, []),
     "msam_decoder_prepare_image": (_i32, [C.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _i64, _vp]),
     "msam_decoder_workspace_bytes": (_i64, [_i32]),
+    "msam_prompt_encode": (_i32, [C.POINTER(DecoderParams), C.POINTER(MaskPromptParams), _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "msam_decoder_forward_embeddings": (_i32, [C.POINTER(DecoderParams), _vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp,
+                                               _i64, _vp]),
     "msam_decoder_forward": (_i32, [C.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp,
                                     _i64, _vp]),
     "msam_postprocess_masks": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -155,7 +159,8 @@ _lib: Optional[C.CDLL] = None
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    """libmsam_hip.so, or the ablation variant named by MSAM_LIB_VARIANT (build.variant_path; "decbf16" = bf16 decoder)."""
+    return _build.variant_path(os.environ.get("MSAM_LIB_VARIANT", ""))
 
 
 def load() -> C.CDLL:
@@ -179,6 +184,12 @@ def load() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def decoder_dtype() -> torch.dtype:
+    """16-bit type of the mask decoder's weights and tensors in this build of the library (``msam_decoder_dtype``):
+    torch.float16 (default) or torch.bfloat16 (``python -m micro_sam_amd.build --dec-bf16``)."""
+    return torch.float16 if load().msam_decoder_dtype() == F16 else torch.bfloat16
 
 
 def exported_symbols():

@@ -28,8 +28,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def variant_path(variant: str = "") -> str:
+    """Library file of a build variant: "" = default (fp16 mask decoder), "decbf16" = all-bf16 decoder of round 1
+    (-DMSAM_DEC_F16=0; ablation only, selected at run time with MSAM_LIB_VARIANT=decbf16)."""
+    return LIB_PATH if not variant else os.path.join(LIB_DIR, f"libmsam_hip_{variant}.so")
+
+
+def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
+    if variant:
+        return _build_variant(variant, force, verbose)
     if not force and not needs_build():
         return LIB_PATH
     objs = []
@@ -53,6 +61,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+def _build_variant(variant: str, force: bool, verbose: bool) -> str:
+    if variant != "decbf16":
+        raise ValueError(f"unknown build variant {variant!r}")
+    out = variant_path(variant)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, src.replace(".hip", f".{variant}.o"))
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-DMSAM_DEC_F16=0", "-c", os.path.join(CSRC, src),
+               "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out])
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB_PATH)
+    print(build(force="--force" in sys.argv, variant="decbf16" if "--dec-bf16" in sys.argv else ""))

@@ -95,6 +95,35 @@ MSAM_DEVINL uint32_t pack2h(float lo, float hi) {
 }
 MSAM_DEVINL float h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (u16)bits16); }
 
+MSAM_DEVINL u16 f2h(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
+
+// ---- the mask decoder's 16-bit type (decoder.hip, decfold.hip, declayer.hip, wsgemm.hip, upfused.hip and the decoder's
+// launches of the GEMM kernels).  MSAM_DEC_F16 = 1 (default): IEEE fp16 - 11 significand bits instead of bf16's 8 for the
+// per-prompt image-token stream, the folded vectors, the attention probabilities, the token-side activations and every
+// decoder weight, same MFMA rate and bytes (v_mfma_f32_16x16x32_f16).  Every decoder activation is a LayerNorm output, a
+// softmax probability, a GELU / ReLU of O(1..100) values or a projection of those: far inside fp16's range (65504), which is
+// why fp16 inference of SAM is common practice; the ENCODER stays bf16 ("vit_b bf16": un-normalised residual-stream
+// products).  Measured effect on the per-instance mask IoU vs the fp32 reference: DESIGN.md section 4.
+// MSAM_DEC_F16 = 0 rebuilds the all-bf16 decoder of round 1 (ablation: python -m micro_sam_amd.build --dec-bf16).
+#ifndef MSAM_DEC_F16
+#define MSAM_DEC_F16 1
+#endif
+#if MSAM_DEC_F16
+MSAM_DEVINL f32x4_t mfma16d(const uint4& a, const uint4& b, f32x4_t c) { return mfma16h(a, b, c); }
+MSAM_DEVINL uint32_t pack2d(float lo, float hi) { return pack2h(lo, hi); }
+MSAM_DEVINL u16 f2d(float f) { return f2h(f); }
+MSAM_DEVINL float d2f(u16 h) { return h2f(h); }
+#define MSAM_D16_ONE 0x3C00u
+#define MSAM_D16 4                        /* == MSAM_F16 (include/msam_hip.h) */
+#else
+MSAM_DEVINL f32x4_t mfma16d(const uint4& a, const uint4& b, f32x4_t c) { return mfma16(a, b, c); }
+MSAM_DEVINL uint32_t pack2d(float lo, float hi) { return pack2bf(lo, hi); }
+MSAM_DEVINL u16 f2d(float f) { return f2bf(f); }
+MSAM_DEVINL float d2f(u16 h) { return bf2f(h); }
+#define MSAM_D16_ONE 0x3F80u
+#define MSAM_D16 2                        /* == MSAM_BF16 */
+#endif
+
 // LDS swizzle for a [rows][64] bf16 tile (128-B rows, 8 chunks of 16 B): chunk' = chunk ^ swz(row).
 // Chosen so that the 16-lane service groups of ds_read_b128 (MI355X_MICROARCH, LDS table) hit 16 distinct
 // 16-B slots when lanes read rows (l & 15) at chunk c0 + (l >> 4).

@@ -53,18 +53,18 @@ __global__ __launch_bounds__(256) void fold_q_kernel(const u16* __restrict__ qto
     const int p = blockIdx.x >> 3, h = blockIdx.x & 7, c = threadIdx.x;
     if (c < 128) {
         const int t = c >> 4, d = c & 15;
-        q[t][d] = t < Nt ? bf2f(qtok[((long)p * Nt + t) * CI + h * 16 + d]) : 0.f;
+        q[t][d] = t < Nt ? d2f(qtok[((long)p * Nt + t) * CI + h * 16 + d]) : 0.f;
     }
     __syncthreads();
     float w[16];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) w[d] = bf2f(wk[(h * 16 + d) * C + c]);
+    for (int d = 0; d < 16; ++d) w[d] = d2f(wk[(h * 16 + d) * C + c]);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         float a = 0.f;
 #pragma unroll
         for (int d = 0; d < 16; ++d) a = fmaf(q[t][d], w[d], a);
-        qprime[(((long)p * 64) + h * 8 + t) * C + c] = f2bf(a);
+        qprime[(((long)p * 64) + h * 8 + t) * C + c] = f2d(a);
     }
 }
 
@@ -217,11 +217,11 @@ __global__ __launch_bounds__(NTHR, DMA ? 3 : 2) void fold_attn_kernel(FoldArgs a
         for (int ks = 0; ks < 8; ++ks) {
             const uint4 a0 = *(const uint4*)(B + koff[0] + ks * 2 * SUBT);
             const uint4 a1 = *(const uint4*)(B + koff[1] + ks * 2 * SUBT);
-            s0 = mfma16(a0, qb[ks], s0);
-            s1 = mfma16(a1, qb[ks], s1);
+            s0 = mfma16d(a0, qb[ks], s0);
+            s1 = mfma16d(a1, qb[ks], s1);
         }
-        s0 = mfma16(*(const uint4*)(B + toff[0]), qd, s0);
-        s1 = mfma16(*(const uint4*)(B + toff[1]), qd, s1);
+        s0 = mfma16d(*(const uint4*)(B + toff[0]), qd, s0);
+        s1 = mfma16d(*(const uint4*)(B + toff[1]), qd, s1);
         float mt = NEG_BIG;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s0[r] *= 0.25f; s1[r] *= 0.25f; mt = fmaxf(mt, fmaxf(s0[r], s1[r])); }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHR, DMA ? 3 : 2) void fold_attn_kernel(FoldArgs a
         for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mn); s1[r] = __expf(s1[r] - mn); ps += s0[r] + s1[r]; }
         l = l * alpha + ps;
         uint4 pb;
-        pb.x = pack2bf(s0[0], s0[1]); pb.y = pack2bf(s0[2], s0[3]); pb.z = pack2bf(s1[0], s1[1]); pb.w = pack2bf(s1[2], s1[3]);
+        pb.x = pack2d(s0[0], s0[1]); pb.y = pack2d(s0[2], s0[3]); pb.z = pack2d(s1[0], s1[1]); pb.w = pack2d(s1[2], s1[3]);
         // ---- O'^T += keys^T P^T over the 16 channel tiles
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NTHR, DMA ? 3 : 2) void fold_attn_kernel(FoldArgs a
             const uint2 t1 = lds_tr16(B + ct * SUBT + troff[1]);
             f32x4_t o = acc[ct];
             o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-            acc[ct] = mfma16(make_uint4(t0.x, t0.y, t1.x, t1.y), pb, o);
+            acc[ct] = mfma16d(make_uint4(t0.x, t0.y, t1.x, t1.y), pb, o);
         }
         if (tt == TPI - 1) {                             // work item complete
             float lt = l;
@@ -261,23 +261,23 @@ __global__ __launch_bounds__(NTHR, DMA ? 3 : 2) void fold_attn_kernel(FoldArgs a
                     float c8[8];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { c8[r] = acc[2 * ks][r] * inv; c8[4 + r] = acc[2 * ks + 1][r] * inv; }
-                    const uint4 bh = make_uint4(pack2bf(c8[0], c8[1]), pack2bf(c8[2], c8[3]), pack2bf(c8[4], c8[5]), pack2bf(c8[6], c8[7]));
+                    const uint4 bh = make_uint4(pack2d(c8[0], c8[1]), pack2d(c8[2], c8[3]), pack2d(c8[4], c8[5]), pack2d(c8[6], c8[7]));
                     const uint32_t hw[4] = {bh.x, bh.y, bh.z, bh.w};
                     float l8[8];
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) { l8[2 * x] = c8[2 * x] - bf2f((u16)(hw[x] & 0xffff)); l8[2 * x + 1] = c8[2 * x + 1] - bf2f((u16)(hw[x] >> 16)); }
-                    const uint4 bl = make_uint4(pack2bf(l8[0], l8[1]), pack2bf(l8[2], l8[3]), pack2bf(l8[4], l8[5]), pack2bf(l8[6], l8[7]));
+                    for (int x = 0; x < 4; ++x) { l8[2 * x] = c8[2 * x] - d2f((u16)(hw[x] & 0xffff)); l8[2 * x + 1] = c8[2 * x + 1] - d2f((u16)(hw[x] >> 16)); }
+                    const uint4 bl = make_uint4(pack2d(l8[0], l8[1]), pack2d(l8[2], l8[3]), pack2d(l8[4], l8[5]), pack2d(l8[6], l8[7]));
                     const uint2 x0 = *(const uint2*)(w0 + (2 * ks) * 16), x1 = *(const uint2*)(w0 + (2 * ks + 1) * 16);
                     const uint2 y0 = *(const uint2*)(w1 + (2 * ks) * 16), y1 = *(const uint2*)(w1 + (2 * ks + 1) * 16);
                     const uint4 a0 = make_uint4(x0.x, x0.y, x1.x, x1.y), a1 = make_uint4(y0.x, y0.y, y1.x, y1.y);
-                    o0 = mfma16(a0, bh, o0); o0 = mfma16(a0, bl, o0);
-                    o1 = mfma16(a1, bh, o1); o1 = mfma16(a1, bl, o1);
+                    o0 = mfma16d(a0, bh, o0); o0 = mfma16d(a0, bl, o0);
+                    o1 = mfma16d(a1, bh, o1); o1 = mfma16d(a1, bl, o1);
                 }
                 const int hh = fr >> 3, t = fr & 7;
                 if (t < a.Nt) {                          // rows d = 4 fg + r of head 2w + hh, column = this lane's (head, token)
                     const f32x4_t o = hh ? o1 : o0;
                     const float4 b4 = *(const float4*)(a.bv + (2 * w + hh) * 16 + fg * 4);
-                    uint2 pk; pk.x = pack2bf(o[0] + b4.x, o[1] + b4.y); pk.y = pack2bf(o[2] + b4.z, o[3] + b4.w);
+                    uint2 pk; pk.x = pack2d(o[0] + b4.x, o[1] + b4.y); pk.y = pack2d(o[2] + b4.z, o[3] + b4.w);
                     *(uint2*)(a.out + ((long)p * a.Nt + t) * CI + (2 * w + hh) * 16 + fg * 4) = pk;
                 }
                 wait_vmem_all();                         // pins the waits of this (rare) branch, see common.h
@@ -342,11 +342,11 @@ __global__ __launch_bounds__(128) void fold_finish_kernel(const float* __restric
         const uint32_t ww[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            acc = fmaf(ctx[t][c8 * 8 + 2 * x], bf2f((u16)(ww[x] & 0xffff)), acc);
-            acc = fmaf(ctx[t][c8 * 8 + 2 * x + 1], bf2f((u16)(ww[x] >> 16)), acc);
+            acc = fmaf(ctx[t][c8 * 8 + 2 * x], d2f((u16)(ww[x] & 0xffff)), acc);
+            acc = fmaf(ctx[t][c8 * 8 + 2 * x + 1], d2f((u16)(ww[x] >> 16)), acc);
         }
     }
-    out[((long)p * Nt + t) * CI + h * 16 + d] = f2bf(acc);
+    out[((long)p * Nt + t) * CI + h * 16 + d] = f2d(acc);
 }
 
 // ============================================================================================================
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
     for (int par = 0; par < 2; ++par) {
         const int target = par * 16 + fr;                 // k index of the one in row fr
         uint32_t wv[4] = {0u, 0u, 0u, 0u};
-        if ((target >> 3) == fg) wv[(target & 7) >> 1] = (target & 1) ? 0x3F800000u : 0x00003F80u;
+        if ((target >> 3) == fg) wv[(target & 7) >> 1] = (target & 1) ? (MSAM_D16_ONE << 16) : MSAM_D16_ONE;
         ida[par] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
     }
     f32x4_t bo_acc[4];
@@ -502,11 +502,11 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
         for (int ks = 0; ks < 8; ++ks) {
             const uint4 b0 = *(const uint4*)(B + boff + ks * SUB_BYTES);
             const uint4 b1 = *(const uint4*)(B + boff + ks * SUB_BYTES + 16 * 64);
-            s0 = mfma16(kq[ks], b0, s0);
-            s1 = mfma16(kq[ks], b1, s1);
+            s0 = mfma16d(kq[ks], b0, s0);
+            s1 = mfma16d(kq[ks], b1, s1);
         }
-        s0 = mfma16(kd, tb0, s0);
-        s1 = mfma16(kd, tb1, s1);
+        s0 = mfma16d(kd, tb0, s0);
+        s1 = mfma16d(kd, tb1, s1);
         FI_TAB(min(q + 1, nq - 1));
         I2T_STAMP(1);
         // softmax over the 8 tokens of a head: rows fg*4 + r, i.e. token (fg & 1) * 4 + r of head 2w + (fg >> 1)
@@ -525,8 +525,8 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
             l0 += __shfl_xor(l0, 16); l1 += __shfl_xor(l1, 16);
             const float i0 = __builtin_amdgcn_rcpf(l0), i1 = __builtin_amdgcn_rcpf(l1);     // 1 ulp; P is rounded to bf16 next
             uint2 q0, q1;
-            q0.x = pack2bf(s0[0] * i0, s0[1] * i0); q0.y = pack2bf(s0[2] * i0, s0[3] * i0);
-            q1.x = pack2bf(s1[0] * i1, s1[1] * i1); q1.y = pack2bf(s1[2] * i1, s1[3] * i1);
+            q0.x = pack2d(s0[0] * i0, s0[1] * i0); q0.y = pack2d(s0[2] * i0, s0[3] * i0);
+            q1.x = pack2d(s1[0] * i1, s1[1] * i1); q1.y = pack2d(s1[2] * i1, s1[3] * i1);
             // P^T tile [token][64 (h,t)] bf16, 128-byte rows, chunk' = chunk ^ ((token >> 1) & 7)  ((16 + fr) >> 1 & 7 == fr >> 1 & 7)
             const int po = fr * 128 + (((2 * w + (fg >> 1)) ^ ((fr >> 1) & 7)) << 4) + (fg & 1) * 8;
             *(uint2*)(PT + po) = q0;
@@ -555,9 +555,9 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     f32x4_t c = bo_acc[i];
-                    c = mfma16(vq[i][0], pf[n][0], c);
-                    c = mfma16(vq[i][1], pf[n][1], c);
-                    c = mfma16(ida[i & 1], xk[i >> 1][n], c);
+                    c = mfma16d(vq[i][0], pf[n][0], c);
+                    c = mfma16d(vq[i][1], pf[n][1], c);
+                    c = mfma16d(ida[i & 1], xk[i >> 1][n], c);
                     o[i][n] = c;
                 }
         }
@@ -593,8 +593,8 @@ __global__ __launch_bounds__(NTHR, 2) void fold_i2t_kernel(I2tArgs a) {
                 const int cbase = (w * 4 + i) * 16 + fg * 4;
                 const float4 g4 = *(const float4*)&prm[1][cbase], b4 = *(const float4*)&prm[2][cbase];
                 uint2 y;
-                y.x = pack2bf(fmaf(fmaf(o[i][n][0], rstd, nmr), g4.x, b4.x), fmaf(fmaf(o[i][n][1], rstd, nmr), g4.y, b4.y));
-                y.y = pack2bf(fmaf(fmaf(o[i][n][2], rstd, nmr), g4.z, b4.z), fmaf(fmaf(o[i][n][3], rstd, nmr), g4.w, b4.w));
+                y.x = pack2d(fmaf(fmaf(o[i][n][0], rstd, nmr), g4.x, b4.x), fmaf(fmaf(o[i][n][1], rstd, nmr), g4.y, b4.y));
+                y.y = pack2d(fmaf(fmaf(o[i][n][2], rstd, nmr), g4.z, b4.z), fmaf(fmaf(o[i][n][3], rstd, nmr), g4.w, b4.w));
                 *(uint2*)(B + xoff[i & 1] + (i >> 1) * SUB_BYTES + n * 16 * 64) = y;     // in place
             }
         }
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void fold_v_kernel(const u16* __restrict__ vto
     const int p = blockIdx.x, c = threadIdx.x;
     for (int i = c; i < 8 * CI; i += 256) {
         const int t = i >> 7, d = i & (CI - 1);
-        v[t][d] = t < Nt ? bf2f(vtok[((long)p * Nt + t) * CI + d]) : 0.f;
+        v[t][d] = t < Nt ? d2f(vtok[((long)p * Nt + t) * CI + d]) : 0.f;
     }
     __syncthreads();
     u16* dst = vfoldT + ((long)p * C + c) * 64;
@@ -639,14 +639,14 @@ __global__ __launch_bounds__(256) void fold_v_kernel(const u16* __restrict__ vto
         const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
         float wf[16];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { wf[2 * x] = bf2f((u16)(ww[x] & 0xffff)); wf[2 * x + 1] = bf2f((u16)(ww[x] >> 16)); }
+        for (int x = 0; x < 8; ++x) { wf[2 * x] = d2f((u16)(ww[x] & 0xffff)); wf[2 * x + 1] = d2f((u16)(ww[x] >> 16)); }
         uint32_t pk[4];
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2) {
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
             for (int d = 0; d < 16; ++d) { a0 = fmaf(wf[d], v[2 * t2][h * 16 + d], a0); a1 = fmaf(wf[d], v[2 * t2 + 1][h * 16 + d], a1); }
-            pk[t2] = pack2bf(a0, a1);
+            pk[t2] = pack2d(a0, a1);
         }
         *(uint4*)(dst + h * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }

@@ -110,16 +110,16 @@ __global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
 #pragma unroll
                     for (int kc = 0; kc < 8; ++kc) {
                         const int r0 = fr, r1 = 16 + fr;
-                        qa0 = mfma16(wst[kc], lk[r0 * CPR + ((kc * 4 + fg) ^ swzr(r0))], qa0);
-                        qa1 = mfma16(wst[kc], lk[r1 * CPR + ((kc * 4 + fg) ^ swzr(r1))], qa1);
+                        qa0 = mfma16d(wst[kc], lk[r0 * CPR + ((kc * 4 + fg) ^ swzr(r0))], qa0);
+                        qa1 = mfma16d(wst[kc], lk[r1 * CPR + ((kc * 4 + fg) ^ swzr(r1))], qa1);
                     }
                     const float4 b4 = *(const float4*)(a.bq + head * 16 + fg * 4);
                     const float4 pe0 = *(const float4*)(a.peq + (long)(t0 + fr) * CI + head * 16 + fg * 4);
                     const float4 pe1 = *(const float4*)(a.peq + (long)(t0 + 16 + fr) * CI + head * 16 + fg * 4);
-                    qb0.x = pack2bf(qa0[0] + b4.x + pe0.x, qa0[1] + b4.y + pe0.y);
-                    qb0.y = pack2bf(qa0[2] + b4.z + pe0.z, qa0[3] + b4.w + pe0.w);
-                    qb1.x = pack2bf(qa1[0] + b4.x + pe1.x, qa1[1] + b4.y + pe1.y);
-                    qb1.y = pack2bf(qa1[2] + b4.z + pe1.z, qa1[3] + b4.w + pe1.w);
+                    qb0.x = pack2d(qa0[0] + b4.x + pe0.x, qa0[1] + b4.y + pe0.y);
+                    qb0.y = pack2d(qa0[2] + b4.z + pe0.z, qa0[3] + b4.w + pe0.w);
+                    qb1.x = pack2d(qa1[0] + b4.x + pe1.x, qa1[1] + b4.y + pe1.y);
+                    qb1.y = pack2d(qa1[2] + b4.z + pe1.z, qa1[3] + b4.w + pe1.w);
                     // k_tok fragment with the SAME k-slot map: slots i < 4 <-> d = fg*4 + i
                     if (fr < a.Nt) {
                         const uint2 k2 = *(const uint2*)(a.ktok + ((long)p * a.Nt + fr) * CI + head * 16 + fg * 4);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
                 for (int mt = 0; mt < 2; ++mt) {
                     const int row = mt * 16 + fr;
                     f32x4_t s = {0.f, 0.f, 0.f, 0.f};
-                    s = mfma16(ka, mt == 0 ? qb0 : qb1, s);    // rows j = fg*4 + r, col token = fr
+                    s = mfma16d(ka, mt == 0 ? qb0 : qb1, s);    // rows j = fg*4 + r, col token = fr
                     float mx = NEG_BIG;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { s[r] = (fg * 4 + r < a.Nt) ? s[r] * 0.25f : NEG_BIG; mx = fmaxf(mx, s[r]); }
@@ -160,11 +160,11 @@ __global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mx); ps += s[r]; }
                     ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
-                    uint4 pb; pb.x = pack2bf(s[0], s[1]); pb.y = pack2bf(s[2], s[3]); pb.z = 0; pb.w = 0;
+                    uint4 pb; pb.x = pack2d(s[0], s[1]); pb.y = pack2d(s[2], s[3]); pb.z = 0; pb.w = 0;
                     f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-                    o = mfma16(va, pb, o);                     // rows d = fg*4 + r, col token = fr
+                    o = mfma16d(va, pb, o);                     // rows d = fg*4 + r, col token = fr
                     const float inv = 1.f / ps;
-                    uint2 pk; pk.x = pack2bf(o[0] * inv, o[1] * inv); pk.y = pack2bf(o[2] * inv, o[3] * inv);
+                    uint2 pk; pk.x = pack2d(o[0] * inv, o[1] * inv); pk.y = pack2d(o[2] * inv, o[3] * inv);
                     uint2* dst = (uint2*)(lp + row * 16 + ((head * 2 + (fg >> 1)) ^ swzr(row)));
                     dst[fg & 1] = pk;
                 }
@@ -187,8 +187,8 @@ __global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
                     const int r0 = fr, r1 = 16 + fr;
                     const uint4 af0 = lp[r0 * 16 + ((kc * 4 + fg) ^ swzr(r0))];
                     const uint4 af1 = lp[r1 * 16 + ((kc * 4 + fg) ^ swzr(r1))];
-                    oc00 = mfma16(af0, wst[kc], oc00); oc01 = mfma16(af0, wst[4 + kc], oc01);
-                    oc10 = mfma16(af1, wst[kc], oc10); oc11 = mfma16(af1, wst[4 + kc], oc11);
+                    oc00 = mfma16d(af0, wst[kc], oc00); oc01 = mfma16d(af0, wst[4 + kc], oc01);
+                    oc10 = mfma16d(af1, wst[kc], oc10); oc11 = mfma16d(af1, wst[4 + kc], oc11);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -213,15 +213,15 @@ __global__ __launch_bounds__(NTHR, 4) void dec_image_layer_kernel(LayerArgs a) {
                     } else {
                         rs = *(const uint2*)(a.xin + (long)(t0 + lr) * C + col);
                     }
-                    float v0 = c.x + b4.x + bf2f((u16)(rs.x & 0xffff)), v1 = c.y + b4.y + bf2f((u16)(rs.x >> 16));
-                    float v2 = c.z + b4.z + bf2f((u16)(rs.y & 0xffff)), v3 = c.w + b4.w + bf2f((u16)(rs.y >> 16));
+                    float v0 = c.x + b4.x + d2f((u16)(rs.x & 0xffff)), v1 = c.y + b4.y + d2f((u16)(rs.x >> 16));
+                    float v2 = c.z + b4.z + d2f((u16)(rs.y & 0xffff)), v3 = c.w + b4.w + d2f((u16)(rs.y >> 16));
                     const float mean = wave_sum64((v0 + v1) + (v2 + v3)) * (1.0f / 256.0f);
                     v0 -= mean; v1 -= mean; v2 -= mean; v3 -= mean;
                     const float var = wave_sum64((v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3)) * (1.0f / 256.0f);
                     const float rstd = 1.0f / sqrtf(var + a.eps);
                     uint2 pk;
-                    pk.x = pack2bf(v0 * rstd * w4.x + g4.x, v1 * rstd * w4.y + g4.y);
-                    pk.y = pack2bf(v2 * rstd * w4.z + g4.z, v3 * rstd * w4.w + g4.w);
+                    pk.x = pack2d(v0 * rstd * w4.x + g4.x, v1 * rstd * w4.y + g4.y);
+                    pk.y = pack2d(v2 * rstd * w4.z + g4.z, v3 * rstd * w4.w + g4.w);
                     *(uint2*)(a.out + (row0 + lr) * C + col) = pk;
                 }
             }

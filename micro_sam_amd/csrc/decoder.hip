@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void dense_pe_kernel(const float* __restrict__
     float s, c;
     pe_encode(G, (tx + 0.5f) / 64.f, (ty + 0.5f) / 64.f, j, s, c);
     pos_f32[t * C + j] = s; pos_f32[t * C + 128 + j] = c;
-    pos_bf16[t * C + j] = f2bf(s); pos_bf16[t * C + 128 + j] = f2bf(c);
+    pos_bf16[t * C + j] = f2d(s); pos_bf16[t * C + 128 + j] = f2d(c);
 }
 
 // tokens[p][0..4] = output tokens; then points (+0.5, label embeddings), padding point when no box, box corners.
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(
     for (int i = 0; i < Nt; ++i) {
         const float v = tp[i * C + c];                   // written by this thread above
         queries[((long)p * Nt + i) * C + c] = v;
-        queries_bf16[((long)p * Nt + i) * C + c] = f2bf(v);
+        queries_bf16[((long)p * Nt + i) * C + c] = f2d(v);
     }
 }
 
@@ -89,9 +89,10 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(
 // src_p = image embedding + dense prompt embedding, written as the bf16 image-token stream [P, 4096, 256].
 // grid (64 token rows, P); phase 1: 64 threads = the tokens of the row, 4x4 input pixels -> 16 channels;
 // phase 2: 256 threads = output channels.
+// dense_out != NULL: write the dense prompt embedding itself, fp32 NCHW [P, 256, 64, 64] (PromptEncoder.forward(masks=...))
 __global__ __launch_bounds__(256) void mask_src_kernel(const float* __restrict__ mask, msam_mask_prompt_t mp,
                                                        const float* __restrict__ src_f32, const float* __restrict__ no_mask,
-                                                       u16* __restrict__ keys) {
+                                                       u16* __restrict__ keys, float* __restrict__ dense_out) {
     __shared__ float h2s[64][17];
     const int ty = blockIdx.x, p = blockIdx.y, tid = threadIdx.x;
     if (tid < 64) {
@@ -151,13 +152,14 @@ __global__ __launch_bounds__(256) void mask_src_kernel(const float* __restrict__
     float w3[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) w3[k] = mp.c3_w[c * 16 + k];
-    const float base = mp.c3_b[c] - no_mask[c];          // src_f32 already contains + no_mask_embed
+    const float base = dense_out ? mp.c3_b[c] : mp.c3_b[c] - no_mask[c];          // src_f32 already contains + no_mask_embed
     for (int t = 0; t < 64; ++t) {
         float a = base;
 #pragma unroll
         for (int k = 0; k < 16; ++k) a = fmaf(w3[k], h2s[t][k], a);
         const long token = (long)ty * 64 + t;
-        keys[((long)p * T + token) * C + c] = f2bf(src_f32[token * C + c] + a);
+        if (dense_out) dense_out[((long)p * C + c) * T + token] = a;
+        else keys[((long)p * T + token) * C + c] = f2d(src_f32[token * C + c] + a);
     }
 }
 
@@ -172,7 +174,67 @@ __global__ __launch_bounds__(256) void src_prepare_kernel(const float* __restric
     for (int i = ty; i < 32; i += 8) {
         const float v = tile[tx][i] + no_mask[c0 + tx];
         src_f32[(long)(t0 + i) * C + c0 + tx] = v;
-        src_bf16[(long)(t0 + i) * C + c0 + tx] = f2bf(v);
+        src_bf16[(long)(t0 + i) * C + c0 + tx] = f2d(v);
+    }
+}
+
+// tokens[p] = [5 output tokens; sparse[p][0 .. Ns-1]] for caller-supplied sparse prompt embeddings (MaskDecoder.forward as a
+// stand-alone module call, micro_sam/training/trainable_sam.py:100-106)
+__global__ __launch_bounds__(256) void tokens_from_sparse_kernel(const float* __restrict__ out_tokens, const float* __restrict__ sparse,
+                                                                 int Ns, int P, int Nt, float* __restrict__ tokens,
+                                                                 float* __restrict__ queries, u16* __restrict__ queries16) {
+    const int p = blockIdx.x, c = threadIdx.x;
+    if (p >= P) return;
+    for (int i = 0; i < Nt; ++i) {
+        const float v = i < 5 ? out_tokens[i * C + c] : sparse[((long)p * Ns + (i - 5)) * C + c];
+        const long o = ((long)p * Nt + i) * C + c;
+        tokens[o] = v; queries[o] = v; queries16[o] = f2d(v);
+    }
+}
+
+// per-prompt decoder source from a caller-supplied dense prompt embedding: keys[p][t][c] = emb[c][t] + dense[p][c][t]
+// (NCHW fp32 -> token-major 16-bit stream); grid (T / 32, C / 32, P)
+__global__ __launch_bounds__(256) void dense_src_kernel(const float* __restrict__ emb, const float* __restrict__ dense,
+                                                        u16* __restrict__ keys) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, p = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* dp = dense + (long)p * C * T;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = emb[(long)(c0 + i) * T + t0 + tx] + dp[(long)(c0 + i) * T + t0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) keys[((long)p * T + t0 + i) * C + c0 + tx] = f2d(tile[tx][i]);
+}
+
+// sparse prompt embeddings only (PromptEncoder.forward as a stand-alone module call): [P, Ns, 256] fp32,
+// Ns = Np + (boxes ? 2 : (Np > 0 ? 1 : 0)), same arithmetic as prompt_tokens_kernel
+__global__ __launch_bounds__(256) void sparse_embed_kernel(
+    const float* __restrict__ G, const float* __restrict__ point_embed, const float* __restrict__ not_a_point,
+    const float* __restrict__ points, const int* __restrict__ labels, int Np, const float* __restrict__ boxes, int P, int Ns,
+    float* __restrict__ sparse) {
+    const int p = blockIdx.x, c = threadIdx.x;
+    if (p >= P) return;
+    float* tp = sparse + (long)p * Ns * C;
+    const int j = c & 127;
+    int row = 0;
+    for (int i = 0; i < Np; ++i, ++row) {
+        const float px = points[((long)p * Np + i) * 2] + 0.5f, py = points[((long)p * Np + i) * 2 + 1] + 0.5f;
+        const int lab = labels[(long)p * Np + i];
+        float s, co;
+        pe_encode(G, px / 1024.f, py / 1024.f, j, s, co);
+        float v = c < 128 ? s : co;
+        if (lab == -1) v = not_a_point[c];
+        else if (lab == 0) v += point_embed[0 * C + c];
+        else if (lab == 1) v += point_embed[1 * C + c];
+        tp[row * C + c] = v;
+    }
+    if (Np > 0 && !boxes) { tp[row * C + c] = not_a_point[c]; ++row; }
+    if (boxes) {
+        for (int k = 0; k < 2; ++k, ++row) {
+            const float bx = boxes[(long)p * 4 + 2 * k] + 0.5f, by = boxes[(long)p * 4 + 2 * k + 1] + 0.5f;
+            float s, co;
+            pe_encode(G, bx / 1024.f, by / 1024.f, j, s, co);
+            tp[row * C + c] = (c < 128 ? s : co) + point_embed[(2 + k) * C + c];
+        }
     }
 }
 
@@ -182,7 +244,7 @@ __global__ __launch_bounds__(256) void add_cast_kernel(const float* __restrict__
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 x = *(const float4*)(a + i * 4);
         if (b) { float4 y = *(const float4*)(b + i * 4); x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w; }
-        uint2 pk; pk.x = pack2bf(x.x, x.y); pk.y = pack2bf(x.z, x.w);
+        uint2 pk; pk.x = pack2d(x.x, x.y); pk.y = pack2d(x.z, x.w);
         *(uint2*)(out + i * 4) = pk;
     }
 }
@@ -193,8 +255,8 @@ __global__ __launch_bounds__(256) void add_cast2_kernel(const float* __restrict_
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 x = *(const float4*)(a + i * 4), y = *(const float4*)(b + i * 4);
         uint2 pa, pb;
-        pa.x = pack2bf(x.x + y.x, x.y + y.y); pa.y = pack2bf(x.z + y.z, x.w + y.w);
-        pb.x = pack2bf(x.x, x.y); pb.y = pack2bf(x.z, x.w);
+        pa.x = pack2d(x.x + y.x, x.y + y.y); pa.y = pack2d(x.z + y.z, x.w + y.w);
+        pb.x = pack2d(x.x, x.y); pb.y = pack2d(x.z, x.w);
         *(uint2*)(out_a + i * 4) = pa;
         *(uint2*)(out_b + i * 4) = pb;
     }
@@ -212,7 +274,7 @@ __global__ __launch_bounds__(128) void token_self_attn_kernel(const u16* __restr
         uint4 w = *(const uint4*)(q + base + (long)i * C + c4 * 8);
         const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { qv[c4 * 8 + 2 * x] = bf2f((u16)(ww[x] & 0xffff)); qv[c4 * 8 + 2 * x + 1] = bf2f((u16)(ww[x] >> 16)); }
+        for (int x = 0; x < 4; ++x) { qv[c4 * 8 + 2 * x] = d2f((u16)(ww[x] & 0xffff)); qv[c4 * 8 + 2 * x + 1] = d2f((u16)(ww[x] >> 16)); }
     }
     float s[16];
     float m = NEG_BIG;
@@ -226,8 +288,8 @@ __global__ __launch_bounds__(128) void token_self_attn_kernel(const u16* __restr
                 const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    acc += qv[c4 * 8 + 2 * x] * bf2f((u16)(ww[x] & 0xffff));
-                    acc += qv[c4 * 8 + 2 * x + 1] * bf2f((u16)(ww[x] >> 16));
+                    acc += qv[c4 * 8 + 2 * x] * d2f((u16)(ww[x] & 0xffff));
+                    acc += qv[c4 * 8 + 2 * x + 1] * d2f((u16)(ww[x] >> 16));
                 }
             }
             acc *= 0.17677669529663687f;     // 1/sqrt(32)
@@ -249,8 +311,8 @@ __global__ __launch_bounds__(128) void token_self_attn_kernel(const u16* __restr
                 const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
-                    o[c4 * 8 + 2 * x] += s[j] * bf2f((u16)(ww[x] & 0xffff));
-                    o[c4 * 8 + 2 * x + 1] += s[j] * bf2f((u16)(ww[x] >> 16));
+                    o[c4 * 8 + 2 * x] += s[j] * d2f((u16)(ww[x] & 0xffff));
+                    o[c4 * 8 + 2 * x + 1] += s[j] * d2f((u16)(ww[x] >> 16));
                 }
             }
         }
@@ -259,8 +321,8 @@ __global__ __launch_bounds__(128) void token_self_attn_kernel(const u16* __restr
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
         uint4 pk;
-        pk.x = pack2bf(o[c4 * 8 + 0] * inv, o[c4 * 8 + 1] * inv); pk.y = pack2bf(o[c4 * 8 + 2] * inv, o[c4 * 8 + 3] * inv);
-        pk.z = pack2bf(o[c4 * 8 + 4] * inv, o[c4 * 8 + 5] * inv); pk.w = pack2bf(o[c4 * 8 + 6] * inv, o[c4 * 8 + 7] * inv);
+        pk.x = pack2d(o[c4 * 8 + 0] * inv, o[c4 * 8 + 1] * inv); pk.y = pack2d(o[c4 * 8 + 2] * inv, o[c4 * 8 + 3] * inv);
+        pk.z = pack2d(o[c4 * 8 + 4] * inv, o[c4 * 8 + 5] * inv); pk.w = pack2d(o[c4 * 8 + 6] * inv, o[c4 * 8 + 7] * inv);
         *(uint4*)(out + base + (long)i * C + c4 * 8) = pk;
     }
 }
@@ -293,8 +355,8 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ q
         }
         const uint2 v0 = *(const uint2*)(vb + t0 + fg * 4), v1 = *(const uint2*)(vb + t0 + 16 + fg * 4);
         f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-        s0 = mfma16(ka0, qf, s0);
-        s1 = mfma16(ka1, qf, s1);
+        s0 = mfma16d(ka0, qf, s0);
+        s1 = mfma16d(ka1, qf, s1);
         float mt = NEG_BIG;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s0[r] *= 0.25f; s1[r] *= 0.25f; mt = fmaxf(mt, fmaxf(s0[r], s1[r])); }
@@ -306,9 +368,9 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ q
         for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mn); s1[r] = __expf(s1[r] - mn); ps += s0[r] + s1[r]; }
         l = l * alpha + ps;
         uint4 pb;
-        pb.x = pack2bf(s0[0], s0[1]); pb.y = pack2bf(s0[2], s0[3]); pb.z = pack2bf(s1[0], s1[1]); pb.w = pack2bf(s1[2], s1[3]);
+        pb.x = pack2d(s0[0], s0[1]); pb.y = pack2d(s0[2], s0[3]); pb.z = pack2d(s1[0], s1[1]); pb.w = pack2d(s1[2], s1[3]);
         o[0] *= alpha; o[1] *= alpha; o[2] *= alpha; o[3] *= alpha;
-        o = mfma16(make_uint4(v0.x, v0.y, v1.x, v1.y), pb, o);
+        o = mfma16d(make_uint4(v0.x, v0.y, v1.x, v1.y), pb, o);
     }
     l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
     // merge the 4 waves: lane (j = fr, fg) holds o[d = fg*4 + r]
@@ -327,7 +389,7 @@ __global__ __launch_bounds__(256) void t2i_attn_kernel(const u16* __restrict__ q
             for (int r = 0; r < 4; ++r) oo[r] += a * red[w][fr][2 + fg * 4 + r];
         }
         const float inv = 1.f / ll;
-        uint2 pkd; pkd.x = pack2bf(oo[0] * inv, oo[1] * inv); pkd.y = pack2bf(oo[2] * inv, oo[3] * inv);
+        uint2 pkd; pkd.x = pack2d(oo[0] * inv, oo[1] * inv); pkd.y = pack2d(oo[2] * inv, oo[3] * inv);
         *(uint2*)(out + ((long)p * Nt + fr) * CI + head * 16 + fg * 4) = pkd;
     }
 }
@@ -364,8 +426,8 @@ __global__ __launch_bounds__(256) void t2i_shared4_kernel(const u16* __restrict_
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             f32x4_t s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-            s0 = mfma16(ka0, qf[n], s0);
-            s1 = mfma16(ka1, qf[n], s1);
+            s0 = mfma16d(ka0, qf[n], s0);
+            s1 = mfma16d(ka1, qf[n], s1);
             float mt = NEG_BIG;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { s0[r] *= 0.25f; s1[r] *= 0.25f; mt = fmaxf(mt, fmaxf(s0[r], s1[r])); }
@@ -377,9 +439,9 @@ __global__ __launch_bounds__(256) void t2i_shared4_kernel(const u16* __restrict_
             for (int r = 0; r < 4; ++r) { s0[r] = __expf(s0[r] - mn); s1[r] = __expf(s1[r] - mn); ps += s0[r] + s1[r]; }
             l[n] = l[n] * alpha + ps;
             uint4 pb;
-            pb.x = pack2bf(s0[0], s0[1]); pb.y = pack2bf(s0[2], s0[3]); pb.z = pack2bf(s1[0], s1[1]); pb.w = pack2bf(s1[2], s1[3]);
+            pb.x = pack2d(s0[0], s0[1]); pb.y = pack2d(s0[2], s0[3]); pb.z = pack2d(s1[0], s1[1]); pb.w = pack2d(s1[2], s1[3]);
             o[n][0] *= alpha; o[n][1] *= alpha; o[n][2] *= alpha; o[n][3] *= alpha;
-            o[n] = mfma16(va, pb, o[n]);
+            o[n] = mfma16d(va, pb, o[n]);
         }
     }
 #pragma unroll
@@ -404,7 +466,7 @@ __global__ __launch_bounds__(256) void t2i_shared4_kernel(const u16* __restrict_
                 for (int r = 0; r < 4; ++r) oo[r] += a * red[w][c][2 + fg * 4 + r];
             }
             const float inv = 1.f / ll;
-            uint2 pkd; pkd.x = pack2bf(oo[0] * inv, oo[1] * inv); pkd.y = pack2bf(oo[2] * inv, oo[3] * inv);
+            uint2 pkd; pkd.x = pack2d(oo[0] * inv, oo[1] * inv); pkd.y = pack2d(oo[2] * inv, oo[3] * inv);
             *(uint2*)(out + ((long)p * Nt + tk) * CI + head * 16 + fg * 4) = pkd;
         }
     }
@@ -423,7 +485,7 @@ msam_gemm_t mk_gemm(const void* A, long lda, const void* W, int M, int N, int K,
                     long ldc, int act = 0) {
     msam_gemm_t g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
-    g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc;
+    g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc; g.a_dtype = MSAM_D16;
     return g;
 }
 
@@ -436,7 +498,8 @@ int gemm(const Ctx& cx, const void* A, long lda, const void* W, int M, int N, in
     g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K; g.bias = bias;
     g.table = table; g.table_rows = T; g.table_cols = table_cols; g.table_ld = CI;
     g.resid = resid; g.resid_dtype = resid_dtype; g.resid_rows = resid_rows; g.ldr = ldr;
-    g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc; g.out_mode = 0; g.use_glds = cx.use_glds;
+    g.act = act; g.out = out; g.out_dtype = out_dtype; g.ldc = ldc; g.out_mode = 0; g.a_dtype = MSAM_D16;
+    g.use_glds = MSAM_DEC_F16 ? 0 : cx.use_glds;
     return msam_gemm_bf16(&g, cx.s);
 }
 
@@ -494,6 +557,9 @@ inline long align256(long x) { return (x + 255) & ~255L; }
 }  // namespace
 
 extern "C" int64_t msam_decoder_const_bytes(void) { return CONST_BYTES; }
+// the 16-bit type of every decoder weight the caller hands over (msam_decoder_t, msam_upscale_fused, msam_wsgemm_bf16, ...)
+// and of the decoder's 16-bit intermediates: MSAM_F16 (default build) or MSAM_BF16 (MSAM_DEC_F16 = 0)
+extern "C" int msam_decoder_dtype(void) { return MSAM_D16; }
 extern "C" int64_t msam_decoder_image_bytes(void) { return IMAGE_BYTES; }
 
 extern "C" int msam_decoder_prepare_const(const msam_decoder_t* dec, void* consts, void* stream) {
@@ -511,11 +577,11 @@ extern "C" int msam_decoder_prepare_const(const msam_decoder_t* dec, void* const
         hipMemcpyAsync(c.bkv[i] + CI, t2i[i]->v_b, CI * 4, hipMemcpyDeviceToDevice, cx.s);
         // pos . Wk^T (no bias): added to the k half through the GEMM table epilogue
         if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, nullptr, c.pe_k[i], MSAM_F32, CI)) return e;
-        if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, t2i[i]->k_b, c.tab_k[i], MSAM_BF16, CI)) return e;
+        if (int e = gemm(cx, c.pos_bf16, C, t2i[i]->k_w, T, CI, C, t2i[i]->k_b, c.tab_k[i], MSAM_D16, CI)) return e;
     }
     for (int i = 0; i < 2; ++i) {
         if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, nullptr, c.pe_q[i], MSAM_F32, CI)) return e;
-        if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, dec->layer[i].i2t.q_b, c.tab_q[i], MSAM_BF16, CI))
+        if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, dec->layer[i].i2t.q_b, c.tab_q[i], MSAM_D16, CI))
             return e;
     }
     return 0;
@@ -532,7 +598,7 @@ extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void*
                        im.src_bf16);
     if (int e = msam_check_launch("src_prepare")) return e;
     if (int e = wsgemm_kv(cx, im.src_bf16, c.wkv[0], c.bkv[0], c.pe_k[0], T, im.k0, im.vT0)) return e;
-    return gemm(cx, im.src_bf16, C, dec->layer[0].i2t.q_w, T, CI, C, dec->layer[0].i2t.q_b, im.q0, MSAM_BF16, CI, 0,
+    return gemm(cx, im.src_bf16, C, dec->layer[0].i2t.q_w, T, CI, C, dec->layer[0].i2t.q_b, im.q0, MSAM_D16, CI, 0,
                 nullptr, 0, 0, 0, c.pe_q[0], CI);
 }
 
@@ -605,19 +671,69 @@ extern "C" int msam_decoder_forward(const msam_decoder_t* dec, const void* const
                                       low_res, iou, workspace, workspace_bytes, stream);
 }
 
+namespace {
+int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const void* consts,
+                const void* image_state, const float* points, const int32_t* labels, int32_t Np,
+                const float* boxes, const float* mask_input, const float* sparse, int32_t Ns, const float* dense,
+                const float* embedding, int32_t P, int32_t multimask,
+                float* low_res, float* iou, void* workspace, int64_t workspace_bytes, void* stream);
+}
+
 extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const void* consts,
                                           const void* image_state, const float* points, const int32_t* labels, int32_t Np,
                                           const float* boxes, const float* mask_input, int32_t P, int32_t multimask,
                                           float* low_res, float* iou, void* workspace, int64_t workspace_bytes, void* stream) {
+    return decoder_run(dec, mask_w, consts, image_state, points, labels, Np, boxes, mask_input, nullptr, 0, nullptr, nullptr, P,
+                       multimask, low_res, iou, workspace, workspace_bytes, stream);
+}
+
+extern "C" int msam_decoder_forward_embeddings(const msam_decoder_t* dec, const void* consts, const void* image_state,
+                                               const float* sparse, int32_t Ns, const float* dense, const float* embedding,
+                                               int32_t P, int32_t multimask, float* low_res, float* iou, void* workspace,
+                                               int64_t workspace_bytes, void* stream) {
+    if (!sparse && Ns != 0) { msam_set_error("msam_decoder_forward_embeddings: Ns > 0 needs the sparse embeddings"); return 1; }
+    if (Ns < 0 || Ns > 11) { msam_set_error("msam_decoder_forward_embeddings: 0 .. 11 sparse tokens per prompt"); return 1; }
+    if (dense && !embedding) { msam_set_error("msam_decoder_forward_embeddings: a dense embedding needs the image embedding"); return 1; }
+    return decoder_run(dec, nullptr, consts, image_state, nullptr, nullptr, 0, nullptr, nullptr, sparse ? sparse : (const float*)consts,
+                       Ns, dense, embedding, P, multimask, low_res, iou, workspace, workspace_bytes, stream);
+}
+
+extern "C" int msam_prompt_encode(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const float* points,
+                                  const int32_t* labels, int32_t Np, const float* boxes, const float* mask_input, int32_t P,
+                                  float* sparse, float* dense, void* stream) {
+    if (!dec || P <= 0) { msam_set_error("msam_prompt_encode: null argument"); return 1; }
+    if (!points) Np = 0;
+    const int Ns = Np + (boxes ? 2 : (Np > 0 ? 1 : 0));
+    if (Ns > 0) {
+        if (!sparse) { msam_set_error("msam_prompt_encode: null sparse output"); return 1; }
+        hipLaunchKernelGGL(sparse_embed_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, dec->pe_gauss, dec->point_embed,
+                           dec->not_a_point, points, labels, Np, boxes, P, Ns, sparse);
+        if (int e = msam_check_launch("sparse_embed")) return e;
+    }
+    if (mask_input) {
+        if (!mask_w || !dense) { msam_set_error("msam_prompt_encode: mask prompts need the mask_downscaling weights and a dense output"); return 1; }
+        hipLaunchKernelGGL(mask_src_kernel, dim3(64, P), dim3(256), 0, (hipStream_t)stream, mask_input, *mask_w, (const float*)nullptr,
+                           dec->no_mask, (u16*)nullptr, dense);
+        if (int e = msam_check_launch("mask_dense")) return e;
+    }
+    return 0;
+}
+
+namespace {
+int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const void* consts,
+                const void* image_state, const float* points, const int32_t* labels, int32_t Np,
+                const float* boxes, const float* mask_input, const float* sparse, int32_t Ns, const float* dense,
+                const float* embedding, int32_t P, int32_t multimask,
+                float* low_res, float* iou, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!dec || !consts || !image_state || !low_res || !iou || !workspace || P <= 0) {
         msam_set_error("msam_decoder_forward: null argument");
         return 1;
     }
-    if ((!points || Np <= 0) && !boxes) { msam_set_error("msam_decoder_forward: need points and/or boxes"); return 1; }
+    if (!sparse && (!points || Np <= 0) && !boxes) { msam_set_error("msam_decoder_forward: need points and/or boxes"); return 1; }
     if (mask_input && !mask_w) { msam_set_error("msam_decoder_forward: mask prompts need the mask_downscaling weights"); return 1; }
-    const bool own_src = mask_input != nullptr;          // per-prompt source stream (image embedding + dense mask embedding)
+    const bool own_src = mask_input != nullptr || dense != nullptr;   // per-prompt source stream (image embedding + dense embedding)
     if (!points) Np = 0;
-    const int Nt = 5 + Np + (boxes ? 2 : (Np > 0 ? 1 : 0));
+    const int Nt = sparse ? 5 + Ns : 5 + Np + (boxes ? 2 : (Np > 0 ? 1 : 0));
     if (Nt > 16) { msam_set_error("msam_decoder_forward: at most 16 tokens per prompt (<= 10 points)"); return 1; }
     if (workspace_bytes < work_bytes(P, Nt)) { msam_set_error("msam_decoder_forward: workspace too small"); return 1; }
     Ctx cx{(hipStream_t)stream, dec->use_glds};
@@ -635,13 +751,23 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
                                                                  outb_, n4); CHECK(msam_check_launch("add_cast2")); } while (0)
 #define LN(x_, w_, b_, rows_, out_, dt_) CHECK(msam_layernorm(x_, w_, b_, 1e-5f, rows_, C, out_, dt_, 0, 0, cx.s))
 
-    if (own_src) {
-        hipLaunchKernelGGL(mask_src_kernel, dim3(64, P), dim3(256), 0, cx.s, mask_input, *mask_w, im.src_f32, dec->no_mask, w.keys);
+    if (dense) {
+        hipLaunchKernelGGL(dense_src_kernel, dim3(T / 32, C / 32, P), dim3(256), 0, cx.s, embedding, dense, w.keys);
+        CHECK(msam_check_launch("dense_src"));
+    } else if (own_src) {
+        hipLaunchKernelGGL(mask_src_kernel, dim3(64, P), dim3(256), 0, cx.s, mask_input, *mask_w, im.src_f32, dec->no_mask, w.keys,
+                           (float*)nullptr);
         CHECK(msam_check_launch("mask_src"));
     }
-    hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, cx.s, dec->pe_gauss, dec->point_embed, dec->not_a_point,
-                       dec->out_tokens, points, labels, Np, boxes, P, Nt, w.qpe, w.queries, w.a);
-    CHECK(msam_check_launch("prompt_tokens"));
+    if (sparse) {
+        hipLaunchKernelGGL(tokens_from_sparse_kernel, dim3(P), dim3(256), 0, cx.s, dec->out_tokens, sparse, Ns, P, Nt, w.qpe,
+                           w.queries, w.a);
+        CHECK(msam_check_launch("tokens_from_sparse"));
+    } else {
+        hipLaunchKernelGGL(prompt_tokens_kernel, dim3(P), dim3(256), 0, cx.s, dec->pe_gauss, dec->point_embed, dec->not_a_point,
+                           dec->out_tokens, points, labels, Np, boxes, P, Nt, w.qpe, w.queries, w.a);
+        CHECK(msam_check_launch("prompt_tokens"));
+    }
 
     // test hook: MSAM_DEBUG_DEC_LAYERS=0/1 stops the two-way transformer early so that intermediate workspace buffers
     // can be compared with the oracle's per-layer taps (outputs are then NOT the model's outputs)
@@ -654,9 +780,9 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
         const u16* sv = w.a;
         if (li > 0) { ADD_CAST2(w.queries, w.qpe, w.a, w.b); sv = w.b; }
         {
-            const msam_gemm_t qkv[3] = {mk_gemm(w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_BF16, C),
-                                        mk_gemm(w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_BF16, C),
-                                        mk_gemm(sv, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_BF16, C)};
+            const msam_gemm_t qkv[3] = {mk_gemm(w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_D16, C),
+                                        mk_gemm(w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_D16, C),
+                                        mk_gemm(sv, C, L.self_attn.v_w, M, C, C, L.self_attn.v_b, w.vs, MSAM_D16, C)};
             CHECK(msam_gemm_group_bf16(qkv, 3, cx.s));
         }
         hipLaunchKernelGGL(token_self_attn_kernel, dim3(P), dim3(128), 0, cx.s, w.qs, w.ks, w.vs, Nt, w.attn_tok);
@@ -666,7 +792,7 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
         LN(w.tmp, L.n1_w, L.n1_b, M, w.queries, MSAM_F32);
         // (2) token -> image attention
         ADD_CAST(w.queries, w.qpe, w.a);
-        CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_BF16, CI));
+        CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_D16, CI));
         if (li == 0 && !own_src) {
             // prompt-independent K / V^T of the shared embedding (prepare_image): 1 MiB, L2 resident
             if (Nt <= 8)
@@ -682,14 +808,14 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
         LN(w.tmp, L.n2_w, L.n2_b, M, w.queries, MSAM_F32);
         // (3) token MLP
         ADD_CAST(w.queries, nullptr, w.a);
-        CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_BF16, 2048, MSAM_ACT_RELU));
+        CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_D16, 2048, MSAM_ACT_RELU));
         CHECK(gemm(cx, w.mlp_h, 2048, L.mlp2_w, M, C, 2048, L.mlp2_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n3_w, L.n3_b, M, w.queries, MSAM_F32);
         // (4) image -> token attention, updates the image-token stream
         ADD_CAST2(w.queries, w.qpe, w.a, w.b);
         {
-            const msam_gemm_t kv[2] = {mk_gemm(w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_BF16, CI),
-                                       mk_gemm(w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_BF16, CI)};
+            const msam_gemm_t kv[2] = {mk_gemm(w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_D16, CI),
+                                       mk_gemm(w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_D16, CI)};
             CHECK(msam_gemm_group_bf16(kv, 2, cx.s));
         }
         // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
@@ -711,7 +837,7 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
     if (dbg) return 0;   // test hook: leave queries / keys of the last executed layer in the workspace
     // final token -> image attention
     ADD_CAST(w.queries, w.qpe, w.a);
-    CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_BF16, CI));
+    CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_D16, CI));
     CHECK(t2i_stream(cx, w, c, 2, dec->final_attn, P, Nt));
     CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
                MSAM_F32, C));
@@ -726,13 +852,13 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
         for (int i = 0; i < 5; ++i) {
             const void* wt = i == 0 ? dec->iou_w[0] : dec->hyp_w[i - 1][0];
             const float* bs = i == 0 ? dec->iou_b[0] : dec->hyp_b[i - 1][0];
-            h[i] = mk_gemm(w.a + (long)i * C, (long)Nt * C, wt, P, C, C, bs, w.hh0 + i * PC, MSAM_BF16, C, MSAM_ACT_RELU);
+            h[i] = mk_gemm(w.a + (long)i * C, (long)Nt * C, wt, P, C, C, bs, w.hh0 + i * PC, MSAM_D16, C, MSAM_ACT_RELU);
         }
         CHECK(msam_gemm_group_bf16(h, 5, cx.s));
         for (int i = 0; i < 5; ++i) {
             const void* wt = i == 0 ? dec->iou_w[1] : dec->hyp_w[i - 1][1];
             const float* bs = i == 0 ? dec->iou_b[1] : dec->hyp_b[i - 1][1];
-            h[i] = mk_gemm(w.hh0 + i * PC, C, wt, P, C, C, bs, w.hh1 + i * PC, MSAM_BF16, C, MSAM_ACT_RELU);
+            h[i] = mk_gemm(w.hh0 + i * PC, C, wt, P, C, C, bs, w.hh1 + i * PC, MSAM_D16, C, MSAM_ACT_RELU);
         }
         CHECK(msam_gemm_group_bf16(h, 5, cx.s));
         h[0] = mk_gemm(w.hh1, C, dec->iou_w[2], P, 128, C, dec->iou_b[2], w.iou_full, MSAM_F32, 128);
@@ -754,3 +880,4 @@ extern "C" int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_
 #undef LN
     return 0;
 }
+}  // namespace

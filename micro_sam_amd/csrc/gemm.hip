@@ -24,7 +24,12 @@ struct Epi {
 };
 
 // body of the 128 x 128 tile kernel for workgroup `bid_in` of the product (shared by the plain and the grouped launch)
-template <bool GLDS>
+// F16: operands are IEEE fp16 (the mask decoder's 16-bit type, common.h MSAM_DEC_F16) - same tile, staging and epilogue, the
+// fp16 MFMA; 16-bit OUTPUTS follow e.out_dtype (MSAM_F16 -> fp16, else bf16) in both instantiations.
+MSAM_DEVINL uint32_t pack16(float lo, float hi, int dt) { return dt == MSAM_F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+MSAM_DEVINL float load16(u16 v, int dt) { return dt == MSAM_F16 ? h2f(v) : bf2f(v); }
+
+template <bool GLDS, bool F16 = false>
 __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, const u16* __restrict__ W, long ldw, int M, int N,
                                           int K, const Epi& e, int bid_in) {
     __shared__ __attribute__((aligned(16))) uint4 lds[2][2][TILE_CHUNKS];
@@ -118,7 +123,7 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = F16 ? mfma16h(a[i], b[j], acc[i][j]) : mfma16(a[i], b[j], acc[i][j]);
         }
     };
     if constexpr (GLDS) {
@@ -220,8 +225,8 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             } else {
                 const uint2 u = *(const uint2*)((const u16*)e.resid + (long)rr * e.ldr + col);
-                t.x += bf2f((u16)(u.x & 0xffff)); t.y += bf2f((u16)(u.x >> 16));
-                t.z += bf2f((u16)(u.y & 0xffff)); t.w += bf2f((u16)(u.y >> 16));
+                t.x += load16((u16)(u.x & 0xffff), e.resid_dtype); t.y += load16((u16)(u.x >> 16), e.resid_dtype);
+                t.z += load16((u16)(u.y & 0xffff), e.resid_dtype); t.w += load16((u16)(u.y >> 16), e.resid_dtype);
             }
         }
         rt[pass] = t;
@@ -245,19 +250,19 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
             if (e.out_dtype == MSAM_F32) {
                 *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
-                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                uint2 pk; pk.x = pack16(v[0], v[1], e.out_dtype); pk.y = pack16(v[2], v[3], e.out_dtype);
                 *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
             }
         } else if (e.out_mode == 1) {
             u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
             const int b = row / e.tokens, t = row - b * e.tokens;
-            uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+            uint2 pk; pk.x = pack16(v[0], v[1], e.out_dtype); pk.y = pack16(v[2], v[3], e.out_dtype);
             *(uint2*)(dst + ((long)(b * e.heads + head) * e.tokens + t) * e.head_dim + d) = pk;
         } else {
             // out_mode 2 (decoder K|V projection, N == 256): k half stored row-major [M,128]; the v half is
             // written back to LDS (activated, bf16-rounded values) and stored transposed below
             if (col < 128) {
-                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                uint2 pk; pk.x = pack16(v[0], v[1], e.out_dtype); pk.y = pack16(v[2], v[3], e.out_dtype);
                 *(uint2*)(e.k + (long)row * 128 + col) = pk;
             } else {
                 *(float4*)(ldsC + lr * BN + c4) = make_float4(v[0], v[1], v[2], v[3]);
@@ -274,23 +279,24 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
             if (m0 + th * 64 + i >= M) break;                               // M % 8 == 0 enforced by the launcher
             uint4 pk;
             const float* src = ldsC + (th * 64 + i) * BN + dd;
-            pk.x = pack2bf(src[0], src[BN]); pk.y = pack2bf(src[2 * BN], src[3 * BN]);
-            pk.z = pack2bf(src[4 * BN], src[5 * BN]); pk.w = pack2bf(src[6 * BN], src[7 * BN]);
+            pk.x = pack16(src[0], src[BN], e.out_dtype); pk.y = pack16(src[2 * BN], src[3 * BN], e.out_dtype);
+            pk.z = pack16(src[4 * BN], src[5 * BN], e.out_dtype); pk.w = pack16(src[6 * BN], src[7 * BN], e.out_dtype);
             *(uint4*)(dst + i) = pk;
         }
     }
 }
 
-template <bool GLDS>
+template <bool GLDS, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                    long ldw, int M, int N, int K, Epi e) {
-    gemm_body<GLDS>(A, lda, W, ldw, M, N, K, e, (int)blockIdx.x);
+    gemm_body<GLDS, F16>(A, lda, W, ldw, M, N, K, e, (int)blockIdx.x);
 }
 
 // Grouped launch: up to MSAM_GEMM_GROUP_MAX independent small products in ONE launch (blockIdx.y = product, blockIdx.x = its
 // tile; the decoder's token-side projections are 7 168-row products of 112 tiles each - latency-bound one at a time).
 struct GroupItem { const u16* A; long lda; const u16* W; long ldw; int M, N, K; Epi e; };
 struct GroupArgs { GroupItem it[MSAM_GEMM_GROUP_MAX]; };
+template <bool F16>
 __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
     // the product's parameters are read from the kernel-argument segment itself (constant address space, scalar loads): indexing
     // the by-value argument with blockIdx.y made the compiler copy the whole array to scratch
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
     if ((int)blockIdx.x >= tiles) return;
     const Epi e = it->e;
-    gemm_body<false>(it->A, it->lda, it->W, it->ldw, M, N, K, e, (int)blockIdx.x);
+    gemm_body<false, F16>(it->A, it->lda, it->W, it->ldw, M, N, K, e, (int)blockIdx.x);
 #endif
 }
 
@@ -924,7 +930,8 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
     e.row_scale = nullptr; e.col_scale = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (p->ln_mode && p->a_dtype == MSAM_FP8) { msam_set_error("msam_gemm_bf16(fp8): no fused LayerNorm epilogue"); return 1; }
+    if (p->ln_mode && (p->a_dtype == MSAM_FP8 || p->a_dtype == MSAM_F16)) { msam_set_error("msam_gemm_bf16(fp8 / fp16): no fused LayerNorm epilogue"); return 1; }
+    const bool f16 = p->a_dtype == MSAM_F16;
     if (p->ln_mode) {
         if (p->N != 256 || p->out_mode != 0 || !p->ln_w || !p->ln_b || p->ln_mode < 0 || p->ln_mode > 2) {
             msam_set_error("msam_gemm_bf16: fused LayerNorm needs N == 256, plain output and ln_w / ln_b");
@@ -988,7 +995,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     }
     if (g_gemm256_staging >= 0) staging256 = g_gemm256_staging;
     // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
-    if (use256 && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 && p->out_mode != 2 && !p->table &&
+    if (use256 && !f16 && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 && p->out_mode != 2 && !p->table &&
         (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr256 = false;
         if (!attr256) {
@@ -1017,7 +1024,10 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
         (void)hipEventRecord(g_prof[g_prof_n].a, s);
     }
-    if (p->use_glds)
+    if (f16)
+        hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(tiles), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
+                           (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+    else if (p->use_glds)
         hipLaunchKernelGGL(gemm_kernel<true>, dim3(tiles), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
                            (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
     else
@@ -1036,9 +1046,9 @@ extern "C" int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* s
     for (int i = 0; i < n; ++i) {
         const msam_gemm_t* p = items + i;
         if (!p->A || !p->W || p->M <= 0 || p->N <= 0 || p->K <= 0 || p->N % BN || p->K % BK || (p->lda % 8) || (p->ldw % 8) ||
-            p->ln_mode || p->a_dtype == MSAM_FP8 || p->use_glds) {
-            msam_set_error("msam_gemm_group_bf16: every product needs N % 128 == 0, K % 64 == 0, lda / ldw % 8 == 0, bf16 operands, "
-                           "no fused LayerNorm");
+            p->ln_mode || p->a_dtype == MSAM_FP8 || p->use_glds || (p->a_dtype == MSAM_F16) != (items[0].a_dtype == MSAM_F16)) {
+            msam_set_error("msam_gemm_group_bf16: every product needs N % 128 == 0, K % 64 == 0, lda / ldw % 8 == 0, bf16 operands "
+                           "(or fp16 for all of them), no fused LayerNorm");
             return 1;
         }
         if ((p->out_mode == 0 && (!p->out || (p->ldc % 4))) || p->out_mode == 1 ||
@@ -1068,7 +1078,8 @@ extern "C" int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* s
         g_prof[g_prof_n].flops = flops; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
         (void)hipEventRecord(g_prof[g_prof_n].a, s);
     }
-    hipLaunchKernelGGL(gemm_group_kernel, dim3(max_tiles, n), dim3(256), 0, s, g);
+    if (items[0].a_dtype == MSAM_F16) hipLaunchKernelGGL(gemm_group_kernel<true>, dim3(max_tiles, n), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_group_kernel<false>, dim3(max_tiles, n), dim3(256), 0, s, g);
     if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
     return msam_check_launch("msam_gemm_group_bf16");
 }

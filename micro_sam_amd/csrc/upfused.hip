@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         for (int ks = 0; ks < 8; ++ks) {
             const uint4 kf = *(const uint4*)(B + boff + ks * SUB_BYTES);
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16(w1f[rt][ks], kf, u[rt]);
+            for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16d(w1f[rt][ks], kf, u[rt]);
         }
         __builtin_amdgcn_s_setprio(0);
         float s = 0.f;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         uint4 g1[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-            g1[kk] = make_uint4(pack2bf(u[2 * kk][0], u[2 * kk][1]), pack2bf(u[2 * kk][2], u[2 * kk][3]),
-                                pack2bf(u[2 * kk + 1][0], u[2 * kk + 1][1]), pack2bf(u[2 * kk + 1][2], u[2 * kk + 1][3]));
+            g1[kk] = make_uint4(pack2d(u[2 * kk][0], u[2 * kk][1]), pack2d(u[2 * kk][2], u[2 * kk][3]),
+                                pack2d(u[2 * kk + 1][0], u[2 * kk + 1][1]), pack2d(u[2 * kk + 1][2], u[2 * kk + 1][3]));
         // ---- stages 2 and 3, one second-level sub-pixel at a time
         // The four second-level sub-pixels are independent chains (LDS read -> MFMA -> GELU -> MFMA).  They are written as a
         // software pipeline in ONE basic block - stage-2 MFMAs of sub-pixel s+1 ahead of the GELUs of s, the hyper product of
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             for (int kk = 0; kk < 2; ++kk) {
                 const uint4 wa = *(const uint4*)(W2L + (s2 * 2) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
                 const uint4 wb = *(const uint4*)(W2L + (s2 * 2 + 1) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));
-                xa = mfma16(wa, g1[kk], xa);
-                xb = mfma16(wb, g1[kk], xb);
+                xa = mfma16d(wa, g1[kk], xa);
+                xb = mfma16d(wb, g1[kk], xb);
             }
             ya[s2] = xa; yb[s2] = xb;
         };

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma16(a[mi], bfr[ni][kc], acc[mi][ni]);
+                for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma16d(a[mi], bfr[ni][kc], acc[mi][ni]);
         }
         // ---- fp32 tile -> LDS (row-complete epilogue); ldsC is private to the epilogue, ldsA[buf^1] gets the next tile
 #pragma unroll
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
                 const float4 t = *(const float4*)(e.table + (row % e.table_rows) * e.table_ld + col);
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             }
-            v[0] += bf2f((u16)(res[pass].x & 0xffff)); v[1] += bf2f((u16)(res[pass].x >> 16));
-            v[2] += bf2f((u16)(res[pass].y & 0xffff)); v[3] += bf2f((u16)(res[pass].y >> 16));
+            v[0] += d2f((u16)(res[pass].x & 0xffff)); v[1] += d2f((u16)(res[pass].x >> 16));
+            v[2] += d2f((u16)(res[pass].y & 0xffff)); v[3] += d2f((u16)(res[pass].y >> 16));
             if ((N == 256 && e.ln_mode) || (N == 128 && e.ln_mode == 2)) {
                 const float s = (v[0] + v[1]) + (v[2] + v[3]);
                 const float inv_n = e.ln_mode == 1 ? (1.0f / 256.0f) : (1.0f / 64.0f);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
             if (N == 128 && e.kv_split) {
                 *(float4*)(ldsC + lr * N + col) = make_float4(v[0], v[1], v[2], v[3]);     // all columns go out transposed
             } else if (!e.kv_split) {
-                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                uint2 pk; pk.x = pack2d(v[0], v[1]); pk.y = pack2d(v[2], v[3]);
                 if (e.head_major) {
                     const long b = row / e.tokens, t = row - b * e.tokens;
                     *(uint2*)(e.out + ((b * (N / 16) + (col >> 4)) * e.tokens + t) * 16 + (col & 15)) = pk;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
                     *(uint2*)(e.out + row * e.ldc + col) = pk;
                 }
             } else if (col < 128) {
-                uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                uint2 pk; pk.x = pack2d(v[0], v[1]); pk.y = pack2d(v[2], v[3]);
                 *(uint2*)(e.k_out + row * 128 + col) = pk;
             } else {
                 *(float4*)(ldsC + lr * N + col) = make_float4(v[0], v[1], v[2], v[3]);     // finished v values back
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(512, (N == 256 && K == 256) ? 2 : 4) void wsgemm_ke
                 const long b = row0 / e.tokens, t0 = row0 - b * e.tokens + g * 8;
                 const float* src = ldsC + (g * 8) * N + (N == 256 ? 128 : 0) + d;
                 uint4 p0;
-                p0.x = pack2bf(src[0 * N], src[1 * N]); p0.y = pack2bf(src[2 * N], src[3 * N]);
-                p0.z = pack2bf(src[4 * N], src[5 * N]); p0.w = pack2bf(src[6 * N], src[7 * N]);
+                p0.x = pack2d(src[0 * N], src[1 * N]); p0.y = pack2d(src[2 * N], src[3 * N]);
+                p0.z = pack2d(src[4 * N], src[5 * N]); p0.w = pack2d(src[6 * N], src[7 * N]);
                 *(uint4*)(e.vT_out + (b * 128 + d) * e.tokens + t0) = p0;
             }
         }

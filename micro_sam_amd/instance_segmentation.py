@@ -9,8 +9,12 @@ Differences to the reference are internal only:
 * the initialised state stays in HBM (``DeviceMaskData``: bit masks [N, H/32, W] instead of RLE lists); the reference's
   ``"rles"`` column is produced lazily by the HIP RLE kernels the first time it is read (state pickling, ``rle`` /
   ``binary_mask`` output); ``generate(output_mode="instance_segmentation")`` paints + labels on the device;
-* crops (``crop_n_layers > 0``) and tiles (``TiledAutomaticMaskGenerator``) decode at crop resolution; their bit masks
-  are placed into full-image bit masks by ``msam_uncrop_bits`` (the reference's ``uncrop_masks``).
+* crops (``crop_n_layers > 0``) and tiles (``TiledAutomaticMaskGenerator``) decode at crop resolution and KEEP their bit
+  masks at crop resolution in the state (``DeviceMaskData.crop_box``): 3072 candidates x 128 KiB per 1024^2 tile, however
+  large the image is.  ``msam_uncrop_bits`` (the reference's ``uncrop_masks``) places only the candidates that survive
+  ``_postprocess_batch`` into full-image bit masks (``generate``), and the lazily produced ``"rles"`` column uncrops in
+  chunks of 256 masks (the reference pads every candidate to the full image before it filters: O(192 H W) per batch,
+  micro_sam/instance_segmentation.py:250).
 """
 from __future__ import annotations
 
@@ -31,9 +35,21 @@ class DeviceMaskData(amg_utils.MaskData):
     ``data["rles"]`` (the reference's column) is materialised on first access by the HIP RLE kernels and cached;
     ``filter`` / ``cat`` keep both representations consistent."""
 
-    def __init__(self, mask_size=None, **kwargs) -> None:
+    def __init__(self, mask_size=None, crop_box=None, full_size=None, **kwargs) -> None:
         super().__init__(**kwargs)
-        self.mask_size = mask_size
+        self.mask_size = mask_size          # resolution of the "bits" column
+        self.crop_box = crop_box            # [x0, y0, x1, y1] when the bits are at crop resolution, else None
+        self.full_size = full_size          # (H, W) of the image the crop belongs to
+
+    def _is_cropped(self) -> bool:
+        return self.crop_box is not None and self.full_size is not None and tuple(self.mask_size) != tuple(self.full_size)
+
+    def full_bits(self, bits: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The (given rows of the) bit masks at full-image resolution (``uncrop_masks``)."""
+        bits = self._stats["bits"] if bits is None else bits
+        if not self._is_cropped():
+            return bits
+        return ops.uncrop_bits(bits.contiguous(), self.crop_box, self.full_size[0], self.full_size[1])
 
     def __getitem__(self, key: str):
         if key == "rles" and "rles" not in self._stats and "bits" in self._stats:
@@ -42,23 +58,45 @@ class DeviceMaskData(amg_utils.MaskData):
 
     def _encode_rles(self):
         bits = self._stats["bits"]
-        h, w = self.mask_size
         if bits.shape[0] == 0:
             return []
-        counts, offsets = ops.rle_encode(bits.contiguous(), h, w)
-        return ops.rles_to_list(counts, offsets, h, w, as_list=False)
+        if not self._is_cropped():
+            h, w = self.mask_size
+            counts, offsets = ops.rle_encode(bits.contiguous(), h, w)
+            return ops.rles_to_list(counts, offsets, h, w, as_list=False)
+        # RLEs are those of the masks padded to the full image (the reference's uncrop_masks precedes its RLE encoding):
+        # uncrop a bounded chunk at a time
+        h, w = self.full_size
+        out = []
+        for s in range(0, bits.shape[0], 256):
+            counts, offsets = ops.rle_encode(self.full_bits(bits[s:s + 256]), h, w)
+            out.extend(ops.rles_to_list(counts, offsets, h, w, as_list=False))
+        return out
 
     def shallow_copy(self) -> "DeviceMaskData":
-        out = DeviceMaskData(mask_size=self.mask_size)
+        out = DeviceMaskData(mask_size=self.mask_size, crop_box=self.crop_box, full_size=self.full_size)
         out._stats = dict(self._stats)
         return out
 
     def cat(self, new_stats) -> None:
-        if getattr(new_stats, "mask_size", None) is not None:
-            self.mask_size = new_stats.mask_size
+        new_cropped = isinstance(new_stats, DeviceMaskData) and new_stats._is_cropped()
+        same_crop = new_cropped and self.crop_box is not None and list(self.crop_box) == list(new_stats.crop_box)
         if "rles" in self._stats and "rles" not in new_stats._stats and "bits" in new_stats._stats:
             new_stats["rles"]                      # materialise so that both sides carry the column
-        for k, v in new_stats.items():
+        if new_cropped and not same_crop:
+            # joining the (filtered) masks of a crop / tile to full-image data: place them in full-image bit masks now
+            items = dict(new_stats.items())
+            if "bits" in items:
+                items["bits"] = new_stats.full_bits()
+            self.mask_size, self.crop_box = tuple(new_stats.full_size), None
+            self.full_size = tuple(new_stats.full_size)
+        else:
+            items = dict(new_stats.items())
+            if getattr(new_stats, "mask_size", None) is not None:
+                self.mask_size = new_stats.mask_size
+                if same_crop or (isinstance(new_stats, DeviceMaskData) and "bits" not in self._stats):
+                    self.crop_box, self.full_size = new_stats.crop_box, new_stats.full_size
+        for k, v in items.items():
             cur = self._stats.get(k)
             if cur is None:
                 self._stats[k] = v                 # columns are never mutated in place: no deep copy needed
@@ -81,11 +119,14 @@ class DeviceMaskData(amg_utils.MaskData):
             stats[k] = v.cpu() if torch.is_tensor(v) else v
         if "bits" in self._stats:
             stats["rles"] = self["rles"]
-        return {"_stats": stats, "mask_size": self.mask_size}
+        size = self.full_size if self._is_cropped() else self.mask_size
+        return {"_stats": stats, "mask_size": size}
 
     def __setstate__(self, state):
         self._stats = state["_stats"]
         self.mask_size = state["mask_size"]
+        self.crop_box = None
+        self.full_size = state["mask_size"]
 
 
 class AMGBase(ABC):
@@ -174,7 +215,9 @@ class AMGBase(ABC):
         x0, y0, x1, y1 = crop_box
         full_image = (x0 == 0 and y0 == 0 and x1 == orig_w and y1 == orig_h)
         n_masks_per_prompt = iou_preds.shape[1]
-        data = DeviceMaskData(mask_size=(orig_h, orig_w), iou_preds=iou_preds.flatten(0, 1))
+        data = DeviceMaskData(mask_size=(orig_h, orig_w) if full_image else (y1 - y0, x1 - x0),
+                              crop_box=None if full_image else list(crop_box), full_size=(orig_h, orig_w),
+                              iou_preds=iou_preds.flatten(0, 1))
         if points is not None:
             data["points"] = torch.as_tensor(points.repeat(n_masks_per_prompt, axis=0), dtype=torch.float)
         counts = post["counts"]
@@ -182,8 +225,9 @@ class AMGBase(ABC):
         data["stability_score"] = counts[:, 0] / counts[:, 1]
         data["boxes"] = post["boxes"]
         data["area"] = counts[:, 2]                 # == area_from_rle of the mask
-        # uncrop_masks: identity for the full-image crop, otherwise the crop's bit masks are placed in full-image bit masks
-        data["bits"] = post["bits"] if full_image else ops.uncrop_bits(post["bits"], crop_box, orig_h, orig_w)
+        # uncrop_masks: identity for the full-image crop; other crops keep their bit masks at crop resolution, only the
+        # survivors of _postprocess_batch are placed in full-image bit masks (DeviceMaskData.cat / full_bits)
+        data["bits"] = post["bits"]
         return data
 
     def get_state(self) -> Dict[str, Any]:
@@ -257,7 +301,9 @@ class AutomaticMaskGenerator(AMGBase):
             self._predictor.set_image(cropped_im)
         points_scale = np.array(cropped_im_size)[None, ::-1]
         points_for_image = self.point_grids[crop_layer_idx] * points_scale
-        data = DeviceMaskData(mask_size=tuple(self.original_size))
+        full_image = (x0 == 0 and y0 == 0 and (y1, x1) == tuple(self.original_size))
+        data = DeviceMaskData(mask_size=tuple(self.original_size) if full_image else tuple(cropped_im_size),
+                              crop_box=None if full_image else list(crop_box), full_size=tuple(self.original_size))
         n_batches = len(points_for_image) // self._points_per_batch + \
             int(len(points_for_image) % self._points_per_batch != 0)
         if pbar_init is not None:

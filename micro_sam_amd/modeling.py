@@ -32,6 +32,11 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.bfloat16).contiguous()
 
 
+def _d16(t: torch.Tensor) -> torch.Tensor:
+    """Decoder weights in the decoder's 16-bit type of this library build (fp16 by default, see csrc/common.h)."""
+    return t.detach().to(_lib.decoder_dtype()).contiguous()
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -235,7 +240,8 @@ class PositionEmbeddingRandom(nn.Module):
 
 
 class PromptEncoder(nn.Module):
-    """Parameter holder with upstream names; evaluated inside the fused decoder call."""
+    """Upstream parameter names; evaluated inside the fused decoder call (``Sam.decode``) or, as a stand-alone module call
+    (``sam.prompt_encoder(points, boxes, masks)``, micro_sam/training/trainable_sam.py:96-99), by ``msam_prompt_encode``."""
 
     def __init__(self) -> None:
         super().__init__()
@@ -252,6 +258,7 @@ class PromptEncoder(nn.Module):
             nn.Conv2d(16, PROMPT_DIM, kernel_size=1))
         self.no_mask_embed = nn.Embedding(1, PROMPT_DIM)
         self._dense_pe_fn = None
+        self._sam_ref = None
 
     def get_dense_pe(self) -> torch.Tensor:
         """[1,256,64,64] dense positional encoding (computed by the decoder's constant pass)."""
@@ -259,10 +266,13 @@ class PromptEncoder(nn.Module):
             raise RuntimeError("get_dense_pe: the prompt encoder is not attached to a Sam model")
         return self._dense_pe_fn()
 
+    @torch.no_grad()
     def forward(self, points, boxes, masks):
-        raise NotImplementedError(
-            "micro_sam_amd: prompt_encoder is evaluated inside Sam.decode / SamPredictor.predict_torch "
-            "(fused HIP decoder); the stand-alone module call is not provided this round")
+        """``(sparse [B, N, 256], dense [B, 256, 64, 64])`` as upstream ``PromptEncoder.forward``: points = (coords [B,Np,2] in
+        the 1024 input frame, labels [B,Np]) or None, boxes [B,4] or None, masks [B,1,256,256] or None."""
+        if self._sam_ref is None or self._sam_ref() is None:
+            raise RuntimeError("prompt_encoder: not attached to a Sam model")
+        return self._sam_ref()._prompt_encode(points, boxes, masks)
 
 
 # ------------------------------------------------------------------------------------------------ mask decoder
@@ -324,11 +334,18 @@ class MaskDecoder(nn.Module):
         self.output_hypernetworks_mlps = nn.ModuleList([_MLP(PROMPT_DIM, PROMPT_DIM, PROMPT_DIM // 8, 3)
                                                         for _ in range(self.num_mask_tokens)])
         self.iou_prediction_head = _MLP(PROMPT_DIM, 256, self.num_mask_tokens, 3)
+        self._sam_ref = None
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "micro_sam_amd: mask_decoder is evaluated inside Sam.decode / SamPredictor.predict_torch "
-            "(fused HIP decoder); the stand-alone module call is not provided this round")
+    @torch.no_grad()
+    def forward(self, image_embeddings: torch.Tensor, image_pe: torch.Tensor, sparse_prompt_embeddings: torch.Tensor,
+                dense_prompt_embeddings: torch.Tensor, multimask_output: bool):
+        """``(low_res_masks [B, C, 256, 256], iou_predictions [B, C])`` as upstream ``MaskDecoder.forward``
+        (micro_sam/training/trainable_sam.py:100-106) for ONE image embedding [1, 256, 64, 64]; ``image_pe`` must be the
+        model's own ``prompt_encoder.get_dense_pe()`` (its projections are precomputed tables of the HIP decoder)."""
+        if self._sam_ref is None or self._sam_ref() is None:
+            raise RuntimeError("mask_decoder: not attached to a Sam model")
+        return self._sam_ref()._decode_embeddings(image_embeddings, image_pe, sparse_prompt_embeddings,
+                                                  dense_prompt_embeddings, multimask_output)
 
 
 # ------------------------------------------------------------------------------------------------ Sam
@@ -350,6 +367,9 @@ class Sam(nn.Module):
         self._img_state = None      # (key, buffer)
         self._dec_ws = None
         self.prompt_encoder._dense_pe_fn = self._dense_pe
+        import weakref
+        self.prompt_encoder._sam_ref = weakref.ref(self)
+        self.mask_decoder._sam_ref = weakref.ref(self)
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     @property
@@ -394,10 +414,10 @@ class Sam(nn.Module):
             return t.data_ptr()
 
         def attn(dst, mod):
-            dst.q_w, dst.q_b = k(_bf16(mod.q_proj.weight)), k(_f32(mod.q_proj.bias))
-            dst.k_w, dst.k_b = k(_bf16(mod.k_proj.weight)), k(_f32(mod.k_proj.bias))
-            dst.v_w, dst.v_b = k(_bf16(mod.v_proj.weight)), k(_f32(mod.v_proj.bias))
-            dst.o_w, dst.o_b = k(_bf16(mod.out_proj.weight)), k(_f32(mod.out_proj.bias))
+            dst.q_w, dst.q_b = k(_d16(mod.q_proj.weight)), k(_f32(mod.q_proj.bias))
+            dst.k_w, dst.k_b = k(_d16(mod.k_proj.weight)), k(_f32(mod.k_proj.bias))
+            dst.v_w, dst.v_b = k(_d16(mod.v_proj.weight)), k(_f32(mod.v_proj.bias))
+            dst.o_w, dst.o_b = k(_d16(mod.out_proj.weight)), k(_f32(mod.out_proj.bias))
 
         p = _lib.DecoderParams()
         p.pe_gauss = k(_f32(pe.pe_layer.positional_encoding_gaussian_matrix))
@@ -413,16 +433,16 @@ class Sam(nn.Module):
             for j, nm in enumerate((blk.norm1, blk.norm2, blk.norm3, blk.norm4), start=1):
                 setattr(L, f"n{j}_w", k(_f32(nm.weight)))
                 setattr(L, f"n{j}_b", k(_f32(nm.bias)))
-            L.mlp1_w, L.mlp1_b = k(_bf16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
-            L.mlp2_w, L.mlp2_b = k(_bf16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
+            L.mlp1_w, L.mlp1_b = k(_d16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
+            L.mlp2_w, L.mlp2_b = k(_d16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
         attn(p.final_attn, md.transformer.final_attn_token_to_image)
         p.nf_w, p.nf_b = k(_f32(md.transformer.norm_final_attn.weight)), k(_f32(md.transformer.norm_final_attn.bias))
         up = md.output_upscaling
         # ConvTranspose2d weight [ci, co, ky, kx] -> GEMM weight rows n = (ky*2+kx)*co_n + co, cols ci
-        p.up1_w = k(_bf16(up[0].weight.permute(2, 3, 1, 0).reshape(4 * 64, PROMPT_DIM)))
+        p.up1_w = k(_d16(up[0].weight.permute(2, 3, 1, 0).reshape(4 * 64, PROMPT_DIM)))
         p.up1_b = k(_f32(up[0].bias.repeat(4)))
         p.up_ln_w, p.up_ln_b = k(_f32(up[1].weight)), k(_f32(up[1].bias))
-        p.up2_w = k(_bf16(up[3].weight.permute(2, 3, 1, 0).reshape(4 * 32, 64)))
+        p.up2_w = k(_d16(up[3].weight.permute(2, 3, 1, 0).reshape(4 * 32, 64)))
         p.up2_b = k(_f32(up[3].bias))
 
         def pad_rows(wt, bs, rows=128):
@@ -437,12 +457,12 @@ class Sam(nn.Module):
                 wt, bs = lin.weight.detach(), lin.bias.detach()
                 if j == 2:
                     wt, bs = pad_rows(wt, bs)
-                p.hyp_w[i][j], p.hyp_b[i][j] = k(_bf16(wt)), k(_f32(bs))
+                p.hyp_w[i][j], p.hyp_b[i][j] = k(_d16(wt)), k(_f32(bs))
         for j, lin in enumerate(md.iou_prediction_head.layers):
             wt, bs = lin.weight.detach(), lin.bias.detach()
             if j == 2:
                 wt, bs = pad_rows(wt, bs)
-            p.iou_w[j], p.iou_b[j] = k(_bf16(wt)), k(_f32(bs))
+            p.iou_w[j], p.iou_b[j] = k(_d16(wt)), k(_f32(bs))
         p.use_glds = int(self.use_glds)
         ds = pe.mask_downscaling                                  # mask prompts: Conv, LN2d, GELU, Conv, LN2d, GELU, Conv
         mp = _lib.MaskPromptParams()
@@ -476,6 +496,84 @@ class Sam(nn.Module):
                                                   None, 0, _lib.stream_ptr()), "msam_decoder_prepare_image")
         self._img_state = (key, state, feats)
         return state
+
+    def _workspace(self, P: int) -> torch.Tensor:
+        need = _lib.load().msam_decoder_workspace_bytes(P)
+        if self._dec_ws is None or self._dec_ws.numel() < need or self._dec_ws.device != self.device:
+            self._dec_ws = None
+            self._dec_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._dec_ws
+
+    @torch.no_grad()
+    def _prompt_encode(self, points, boxes, masks):
+        """``PromptEncoder.forward`` through ``msam_prompt_encode``."""
+        p, _, _ = self._prepare_decoder()
+        dev = self.device
+        pts = lbl = bx = msk = None
+        if points is not None:
+            pts = points[0].to(device=dev, dtype=torch.float32).contiguous()
+            lbl = points[1].to(device=dev, dtype=torch.int32).contiguous()
+            B, Np = pts.shape[0], pts.shape[1]
+        else:
+            Np = 0
+            B = boxes.shape[0] if boxes is not None else (masks.shape[0] if masks is not None else 1)
+        if boxes is not None:
+            bx = boxes.to(device=dev, dtype=torch.float32).reshape(-1, 4).contiguous()
+        if masks is not None:
+            msk = masks.to(device=dev, dtype=torch.float32).reshape(-1, 4 * GRID, 4 * GRID).contiguous()
+            if msk.shape[0] != B:
+                raise ValueError(f"masks holds {msk.shape[0]} masks for {B} prompts")
+        Ns = Np + (2 if boxes is not None else (1 if Np > 0 else 0))
+        sparse = torch.empty((B, Ns, PROMPT_DIM), dtype=torch.float32, device=dev)
+        dense = torch.empty((B, PROMPT_DIM, GRID, GRID), dtype=torch.float32, device=dev) if msk is not None else None
+        if Ns > 0 or msk is not None:
+            _lib.check(_lib.load().msam_prompt_encode(
+                C.byref(p), C.byref(self._mask_params), _lib.ptr(pts), _lib.ptr(lbl), Np, _lib.ptr(bx), _lib.ptr(msk), B,
+                _lib.ptr(sparse) if Ns > 0 else None, _lib.ptr(dense), _lib.stream_ptr()), "msam_prompt_encode")
+        if dense is None:
+            dense = self.prompt_encoder.no_mask_embed.weight.detach().to(dev).reshape(1, -1, 1, 1).expand(B, -1, GRID, GRID)
+        return sparse, dense
+
+    @torch.no_grad()
+    def _decode_embeddings(self, image_embeddings, image_pe, sparse, dense, multimask_output: bool):
+        """``MaskDecoder.forward`` through ``msam_decoder_forward_embeddings``."""
+        if image_embeddings.numel() != PROMPT_DIM * GRID * GRID:
+            raise NotImplementedError("micro_sam_amd: mask_decoder takes ONE image embedding [1,256,64,64] per call "
+                                      f"(got {tuple(image_embeddings.shape)})")
+        p, _, consts = self._prepare_decoder()
+        dev = self.device
+        own_pe = self._dense_pe()
+        if image_pe is not None and (tuple(image_pe.shape) != tuple(own_pe.shape) or
+                                     not torch.allclose(image_pe.to(device=dev, dtype=torch.float32), own_pe, atol=1e-5)):
+            raise NotImplementedError("micro_sam_amd: mask_decoder needs image_pe == prompt_encoder.get_dense_pe() "
+                                      "(the positional projections are precomputed tables)")
+        state = self._image_state(image_embeddings)
+        sp = sparse.to(device=dev, dtype=torch.float32).contiguous()
+        P, Ns = sp.shape[0], sp.shape[1]
+        if Ns > 11:
+            raise ValueError(f"at most 11 sparse prompt tokens per prompt, got {Ns}")
+        # the broadcast no_mask_embed (upstream: weight.reshape(1,-1,1,1).expand(...)) is already part of the prepared image
+        # state; any other dense embedding gives every prompt its own source stream
+        nm = self.prompt_encoder.no_mask_embed.weight.detach().to(dev).reshape(1, -1, 1, 1)
+        dn = dense.to(device=dev, dtype=torch.float32)
+        is_no_mask = (dn.stride(-1) == 0 and dn.stride(-2) == 0 and torch.equal(dn[:, :, :1, :1], nm.expand(dn.shape[0], -1, 1, 1))) \
+            or bool(torch.equal(dn, nm.expand_as(dn)))
+        dptr = eptr = None
+        if not is_no_mask:
+            if dn.shape[0] != P:
+                raise ValueError(f"dense_prompt_embeddings holds {dn.shape[0]} entries for {P} prompts")
+            dn = dn.contiguous()
+            emb = image_embeddings.to(device=dev, dtype=torch.float32).reshape(PROMPT_DIM, GRID * GRID).contiguous()
+            dptr, eptr = dn.data_ptr(), emb.data_ptr()
+        nc = 3 if multimask_output else 1
+        low = torch.empty((P, nc, 256, 256), dtype=torch.float32, device=dev)
+        iou = torch.empty((P, nc), dtype=torch.float32, device=dev)
+        ws = self._workspace(P)
+        _lib.check(_lib.load().msam_decoder_forward_embeddings(
+            C.byref(p), consts.data_ptr(), state.data_ptr(), sp.data_ptr() if Ns > 0 else None, Ns, dptr, eptr, P,
+            1 if multimask_output else 0, low.data_ptr(), iou.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+            "msam_decoder_forward_embeddings")
+        return low, iou
 
     @torch.no_grad()
     def decode(self, features: torch.Tensor, point_coords: Optional[torch.Tensor], point_labels: Optional[torch.Tensor],

@@ -8,7 +8,17 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F16, F32  # noqa: F401
+
+
+def _dec16(*tensors) -> torch.dtype:
+    """The decoder kernels take their 16-bit operands in the decoder type of this library build (``_lib.decoder_dtype()``:
+    fp16 by default); returns it after checking the given operands."""
+    dt = _lib.decoder_dtype()
+    for t in tensors:
+        if t is not None and t.dtype != dt:
+            raise TypeError(f"micro_sam_amd: decoder kernels of this build take {dt} operands, got {t.dtype}")
+    return dt
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
@@ -19,22 +29,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     """act(LN(a[M,K] @ w[N,K]^T + bias + table[row % rows, :table_cols] + resid)); a, w bf16.
     ln_mode 1: LayerNorm over the row (N == 256); 2: LayerNorm over 64-column groups + GELU."""
     _lib.require_gpu()
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.is_contiguous() and w.is_contiguous()
+    assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and a.is_contiguous() and w.is_contiguous()
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype, device=a.device)
     p = _lib.GemmParams()
     p.A, p.lda, p.W, p.ldw, p.M, p.N, p.K = a.data_ptr(), K, w.data_ptr(), K, M, N, K
+    if a.dtype == torch.float16:
+        p.a_dtype = F16
     p.bias = _lib.ptr(bias)
     if table is not None:
         p.table, p.table_rows, p.table_cols, p.table_ld = table.data_ptr(), table.shape[0], table_cols, table.shape[1]
     if resid is not None:
         p.resid = resid.data_ptr()
-        p.resid_dtype = F32 if resid.dtype == torch.float32 else BF16
+        p.resid_dtype = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[resid.dtype]
         p.resid_rows, p.ldr = resid_rows, resid.shape[1]
     p.act = act
-    p.out, p.out_dtype, p.ldc = out.data_ptr(), (F32 if out.dtype == torch.float32 else BF16), N
+    p.out, p.out_dtype, p.ldc = out.data_ptr(), {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[out.dtype], N
     p.use_glds = use_glds
     if ln_mode:
         p.ln_mode, p.ln_w, p.ln_b, p.ln_eps = ln_mode, ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
@@ -293,8 +305,10 @@ def wsgemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
            table_cols: int = 0, resid: Optional[torch.Tensor] = None, resid_rows: int = 0, ln_mode: int = 0,
            ln_w: Optional[torch.Tensor] = None, ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
            kv_split_tokens: int = 0, out: Optional[torch.Tensor] = None, head_major_tokens: int = 0):
-    """Weights-stationary decoder GEMM (see include/msam_hip.h).  Returns out bf16 [M,N], or (k, vT) with kv_split_tokens."""
+    """Weights-stationary decoder GEMM (see include/msam_hip.h).  Returns out [M,N] in the decoder's 16-bit type, or (k, vT)
+    with kv_split_tokens."""
     _lib.require_gpu()
+    d16 = _dec16(a, w, resid)
     M, K = a.shape
     N = w.shape[0]
     p = _lib.WsGemmParams()
@@ -303,19 +317,18 @@ def wsgemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if table is not None:
         p.table, p.table_rows, p.table_cols, p.table_ld = table.data_ptr(), table.shape[0], table_cols, table.shape[1]
     if resid is not None:
-        assert resid.dtype == torch.bfloat16
         p.resid, p.resid_rows, p.ldr = resid.data_ptr(), resid_rows, resid.shape[1]
     if ln_mode:
         p.ln_mode, p.ln_w, p.ln_b, p.ln_eps = ln_mode, ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
     ret = None
     if kv_split_tokens:
-        k = torch.empty((M, 128), dtype=torch.bfloat16, device=a.device)
-        vT = torch.empty((M // kv_split_tokens, 128, kv_split_tokens), dtype=torch.bfloat16, device=a.device)
+        k = torch.empty((M, 128), dtype=d16, device=a.device)
+        vT = torch.empty((M // kv_split_tokens, 128, kv_split_tokens), dtype=d16, device=a.device)
         p.kv_split, p.k_out, p.vT_out, p.tokens = 1, k.data_ptr(), vT.data_ptr(), kv_split_tokens
         ret = (k, vT)
     else:
         if out is None:
-            out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+            out = torch.empty((M, N), dtype=d16, device=a.device)
         p.out, p.ldc = out.data_ptr(), N
         if head_major_tokens:
             p.head_major, p.tokens = 1, head_major_tokens
@@ -379,7 +392,7 @@ def decoder_image_layer(xin, ktok, vtok, wo, bo, ln_w, ln_b, Nt, *, q_shared=Non
     _lib.require_gpu()
     rows = xin.shape[0] if rows is None else rows
     if out is None:
-        out = torch.empty((rows, 256), dtype=torch.bfloat16, device=xin.device)
+        out = torch.empty((rows, 256), dtype=_dec16(xin, ktok, vtok, wo, wq, q_shared), device=xin.device)
     p = _lib.ImageLayerParams()
     p.xin, p.q_shared = xin.data_ptr(), _lib.ptr(q_shared)
     p.wq, p.bq, p.peq = _lib.ptr(wq), _lib.ptr(bq), _lib.ptr(peq)
@@ -391,14 +404,14 @@ def decoder_image_layer(xin, ktok, vtok, wo, bo, ln_w, ln_b, Nt, *, q_shared=Non
 
 def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False):
     """Token -> image attention with folded K / V projections (include/msam_hip.h msam_t2i_fold_attention).
-    keys bf16 [Pk,4096,256], qtok bf16 [P,Nt,128] (Nt <= 8), wk / wv bf16 [128,256], tabk bf16 [4096,128], bv fp32 [128]
-    -> bf16 [P,Nt,128]."""
+    keys [Pk,4096,256], qtok [P,Nt,128] (Nt <= 8), wk / wv [128,256], tabk [4096,128] in the decoder's 16-bit type, bv fp32 [128]
+    -> [P,Nt,128]."""
     _lib.require_gpu()
     lib = _lib.load()
     P, Nt = qtok.shape[0], qtok.shape[1]
     nbytes = int(lib.msam_t2i_fold_workspace_bytes(P))
     work = torch.empty((nbytes,), dtype=torch.uint8, device=keys.device)
-    out = torch.empty((P, Nt, 128), dtype=torch.bfloat16, device=keys.device)
+    out = torch.empty((P, Nt, 128), dtype=_dec16(keys, qtok, wk, tabk, wv), device=keys.device)
     _lib.check(lib.msam_t2i_fold_attention(keys.data_ptr(), int(kv_shared), qtok.data_ptr(), P, Nt, wk.data_ptr(),
                                            tabk.data_ptr(), wv.data_ptr(), bv.data_ptr(), out.data_ptr(), work.data_ptr(),
                                            nbytes, _lib.stream_ptr()), "msam_t2i_fold_attention")
@@ -407,14 +420,14 @@ def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False)
 
 def i2t_fold_layer(xin, ktok, vtok, wq, tabq, wo, bo, ln_w, ln_b, *, x_shared: bool = False, ln_eps: float = 1e-5, out=None):
     """Folded image->token attention + out_proj + residual + LayerNorm (include/msam_hip.h msam_i2t_fold_layer).
-    xin bf16 [Px,4096,256], ktok / vtok bf16 [P,Nt,128] (Nt <= 8) -> bf16 [P,4096,256]."""
+    xin [Px,4096,256], ktok / vtok [P,Nt,128] (Nt <= 8) -> [P,4096,256], all in the decoder's 16-bit type."""
     _lib.require_gpu()
     lib = _lib.load()
     P, Nt = ktok.shape[0], ktok.shape[1]
     nbytes = int(lib.msam_i2t_fold_workspace_bytes(P))
     work = torch.empty((nbytes,), dtype=torch.uint8, device=xin.device)
     if out is None:
-        out = torch.empty((P, 4096, 256), dtype=torch.bfloat16, device=xin.device)
+        out = torch.empty((P, 4096, 256), dtype=_dec16(xin, ktok, vtok, wq, tabq, wo), device=xin.device)
     _lib.check(lib.msam_i2t_fold_layer(xin.data_ptr(), int(x_shared), ktok.data_ptr(), vtok.data_ptr(), P, Nt, wq.data_ptr(),
                                        tabq.data_ptr(), wo.data_ptr(), bo.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
                                        ln_eps, out.data_ptr(), work.data_ptr(), nbytes, _lib.stream_ptr()),
@@ -424,8 +437,9 @@ def i2t_fold_layer(xin, ktok, vtok, wq, tabq, wo, bo, ln_w, ln_b, *, x_shared: b
 
 def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: int, *, ln_eps: float = 1e-6):
     """Fused output up-scaling + hyper-network product (include/msam_hip.h msam_upscale_fused).
-    keys bf16 [P,4096,256], hyper fp32 [P,4,ld] -> fp32 [P,nmask,256,256]."""
+    keys [P,4096,256] (decoder 16-bit type), hyper fp32 [P,4,ld] -> fp32 [P,nmask,256,256]."""
     _lib.require_gpu()
+    _dec16(keys, w1, w2)
     P = keys.shape[0]
     out = torch.empty((P, nmask, 256, 256), dtype=torch.float32, device=keys.device)
     _lib.check(_lib.load().msam_upscale_fused(keys.data_ptr(), P, w1.data_ptr(), b1.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),

@@ -29,9 +29,11 @@ Precision modes
 ---------------
 ``precision="fp32"``  strict fp32 (the reference CPU path).
 ``precision="bf16"``  emulates the rounding points of the HIP pipeline (config 2 of BASELINE.json,
-                      "vit_b bf16"): every matrix-product operand is rounded to bfloat16, products are
-                      accumulated in fp32, everything else (LayerNorm, softmax, GELU, bias, residuals)
-                      stays fp32.  Tensors the HIP path *stores* in bf16 are rounded at the same place.
+                      "vit_b bf16"): every matrix-product operand is rounded to 16 bits - bfloat16 in the image
+                      encoder, ``DECODER_DTYPE`` (fp16 in the default library build) in the mask decoder -,
+                      products are accumulated in fp32, everything else (LayerNorm, softmax, GELU, bias,
+                      residuals) stays fp32.  Tensors the HIP path *stores* in 16 bits are rounded at the same
+                      place.  ``Prec(..., exact_sites / only_sites)`` and ``Prec.site_dtype`` are ablation hooks.
 """
 from __future__ import annotations
 
@@ -59,6 +61,12 @@ PIXEL_MEAN = (123.675, 116.28, 103.53)   # build_sam.py:132
 PIXEL_STD = (58.395, 57.12, 57.375)      # build_sam.py:133
 
 
+# 16-bit type of the HIP path's mask decoder (weights, image-token stream, folded vectors, probabilities, token-side
+# tensors): IEEE fp16 in the default build of libmsam_hip.so (csrc/common.h MSAM_DEC_F16), bf16 in the ablation build.
+# tests/conftest.py sets this from ``micro_sam_amd._lib.decoder_dtype()`` on a GPU box.
+DECODER_DTYPE = torch.float16
+
+
 class Prec:
     """Rounding policy (see module docstring)."""
 
@@ -71,7 +79,8 @@ class Prec:
         assert precision in ("fp32", "bf16", "fp8"), precision
         self.exact_sites = set(exact_sites)
         self.only_sites = None if only_sites is None else set(only_sites)
-        self.site_dtype = {}          # decoder site -> storage / operand dtype (default bfloat16); see ``Prec.hip()``
+        self.site_dtype = {}          # decoder site -> storage / operand dtype (default: DECODER_DTYPE)
+        self.dec_dtype = DECODER_DTYPE
         # "fp8" (BASELINE config 5): the bf16 policy everywhere, except that the four large projections of every encoder
         # block (qkv, proj, lin1, lin2) take OCP e4m3 operands - activations with one scale per token, weights with one
         # scale per output channel (linear_q)
@@ -91,7 +100,7 @@ class Prec:
         """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode (or when the site is kept exact)."""
         if not self.rounds(site):
             return x
-        dt = self.site_dtype.get(site, torch.bfloat16)
+        dt = self.site_dtype.get(site, torch.bfloat16 if site is None else self.dec_dtype)
         if dt == "split":             # bf16 hi + lo operand pair (two / three MFMA passes): ~16 mantissa bits
             hi = x.to(torch.bfloat16).to(torch.float32)
             return hi + (x - hi).to(torch.bfloat16).to(torch.float32)

@@ -16,3 +16,14 @@ def pytest_configure(config):
 def vit_b_sd():
     from micro_sam_amd.synthetic import synthetic_state_dict
     return synthetic_state_dict("vit_b", 0)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _oracle_decoder_dtype():
+    """The oracle's "bf16" (= HIP-like) mode rounds the decoder sites to the decoder type of the library that is loaded."""
+    import torch
+    if torch.cuda.is_available():
+        from micro_sam_amd import _lib
+        from oracle import sam_ref as S
+        S.DECODER_DTYPE = _lib.decoder_dtype()
+    yield

@@ -22,6 +22,16 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
+def _ddt():
+    """16-bit type of the decoder kernels in this library build (fp16 by default, bf16 with MSAM_DEC_F16 = 0)."""
+    from micro_sam_amd import _lib
+    return _lib.decoder_dtype()
+
+
+def _d(x):
+    return x.to(_ddt())
+
+
 def _close(got, ref, atol, rtol):
     got, ref = got.float(), ref.float()
     return bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= atol + rtol * ref.abs()).all())
@@ -260,8 +270,8 @@ def test_wsgemm_epilogues(env, N, K):
     g = torch.Generator().manual_seed(10 + N + K)
     P, T = 3, 4096
     M = P * T
-    a = _bf(torch.randn(M, K, generator=g)).to(dev)
-    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    a = _d(torch.randn(M, K, generator=g)).to(dev)
+    w = _d(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
     table = torch.randn(T, 128, generator=g).to(dev)
     base = a.float() @ w.float().t() + bias
@@ -269,10 +279,10 @@ def test_wsgemm_epilogues(env, N, K):
     assert _close(ops.wsgemm(a, w, bias, table=table, table_cols=128), ref, 3e-2, 1e-2)
     if N == 256:
         lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
-        resid = _bf(torch.randn(T, 256, generator=g)).to(dev)
+        resid = _d(torch.randn(T, 256, generator=g)).to(dev)
         ref1 = F.layer_norm(base + resid.float().repeat(P, 1), (256,), lw, lb, eps=1e-5)
         assert _close(ops.wsgemm(a, w, bias, resid=resid, resid_rows=T, ln_mode=1, ln_w=lw, ln_b=lb), ref1, 2e-2, 1e-2)
-        x = _bf(torch.randn(M, 256, generator=g)).to(dev)
+        x = _d(torch.randn(M, 256, generator=g)).to(dev)
         ref1b = F.layer_norm(base + x.float(), (256,), lw, lb, eps=1e-5)
         ops.wsgemm(a, w, bias, resid=x, ln_mode=1, ln_w=lw, ln_b=lb, out=x)                 # in-place stream update
         assert _close(x, ref1b, 2e-2, 1e-2)
@@ -300,22 +310,22 @@ def test_decoder_image_layer_fused(env, layer0, Nt):
     g = torch.Generator().manual_seed(20 + Nt + int(layer0))
     P, T = 2, 4096
     R = P * T
-    x = _bf(torch.randn(T if layer0 else R, 256, generator=g)).to(dev)
-    ktok = _bf(torch.randn(P * Nt, 128, generator=g)).to(dev)
-    vtok = _bf(torch.randn(P * Nt, 128, generator=g)).to(dev)
-    wo = _bf(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev)
+    x = _d(torch.randn(T if layer0 else R, 256, generator=g)).to(dev)
+    ktok = _d(torch.randn(P * Nt, 128, generator=g)).to(dev)
+    vtok = _d(torch.randn(P * Nt, 128, generator=g)).to(dev)
+    wo = _d(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev)
     bo = torch.randn(256, generator=g).to(dev)
     lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
-    wq = _bf(torch.randn(128, 256, generator=g) / 16).to(dev)
+    wq = _d(torch.randn(128, 256, generator=g) / 16).to(dev)
     bq = torch.randn(128, generator=g).to(dev)
     peq = torch.randn(T, 128, generator=g).to(dev)
     if layer0:
-        q_sh = _bf(torch.randn(T, 128, generator=g)).to(dev)
+        q_sh = _d(torch.randn(T, 128, generator=g)).to(dev)
         q = q_sh.float().repeat(P, 1)
         xres = x.float().repeat(P, 1)
         out = ops.decoder_image_layer(x, ktok, vtok, wo, bo, lw, lb, Nt, q_shared=q_sh, rows=R)
     else:
-        q = _bf(x.float() @ wq.float().t() + bq + peq.repeat(P, 1)).float()      # the kernel keeps q in bf16
+        q = _d(x.float() @ wq.float().t() + bq + peq.repeat(P, 1)).float()      # the kernel keeps q in bf16
         xres = x.float()
         out = ops.decoder_image_layer(x, ktok, vtok, wo, bo, lw, lb, Nt, wq=wq, bq=bq, peq=peq)
     qh = q.reshape(P, T, 8, 16).permute(0, 2, 1, 3)
@@ -323,8 +333,8 @@ def test_decoder_image_layer_fused(env, layer0, Nt):
     vh = vtok.float().reshape(P, Nt, 8, 16).permute(0, 2, 1, 3)
     s = (qh @ kh.transpose(-1, -2)) / 4.0
     e = torch.exp(s - s.amax(-1, keepdim=True))
-    attn = (_bf(e).float() @ vh) / e.sum(-1, keepdim=True)                      # un-normalised P in bf16, fp32 row sum
-    attn = _bf(attn.permute(0, 2, 1, 3).reshape(R, 128)).float()
+    attn = (_d(e).float() @ vh) / e.sum(-1, keepdim=True)                      # un-normalised P in bf16, fp32 row sum
+    attn = _d(attn.permute(0, 2, 1, 3).reshape(R, 128)).float()
     ref = F.layer_norm(xres + attn @ wo.float().t() + bo, (256,), lw, lb, eps=1e-5)
     assert _close(out, ref, 3e-2, 2e-2)
     if not layer0:                                                               # in-place update of the stream
@@ -341,14 +351,14 @@ def test_t2i_fold_attention(env, P, Nt, shared):
     g = torch.Generator().manual_seed(77 + P)
     T = 4096
     Pk = 1 if shared else P
-    keys = _bf(torch.randn(Pk, T, 256, generator=g)).to(dev)
+    keys = _d(torch.randn(Pk, T, 256, generator=g)).to(dev)
     pe = torch.randn(T, 256, generator=g).to(dev)
-    wk = _bf(torch.randn(128, 256, generator=g) / 16).to(dev)
-    wv = _bf(torch.randn(128, 256, generator=g) / 16).to(dev)
+    wk = _d(torch.randn(128, 256, generator=g) / 16).to(dev)
+    wv = _d(torch.randn(128, 256, generator=g) / 16).to(dev)
     bk = torch.randn(128, generator=g).to(dev); bv = torch.randn(128, generator=g).to(dev)
-    qtok = _bf(torch.randn(P, Nt, 128, generator=g) * 1.5).to(dev)
+    qtok = _d(torch.randn(P, Nt, 128, generator=g) * 1.5).to(dev)
     tab = pe @ wk.float().t() + bk
-    tabk = tab.to(torch.bfloat16)
+    tabk = tab.to(_ddt())
     out = ops.t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, kv_shared=shared)
     kf = keys.float().expand(P, T, 256)
     K = kf @ wk.float().t() + tabk.float()                                      # [P,T,128]
@@ -358,7 +368,7 @@ def test_t2i_fold_attention(env, P, Nt, shared):
     vh = V.reshape(P, T, 8, 16).permute(0, 2, 1, 3)
     a = torch.softmax((qh @ kh.transpose(-1, -2)) / 4.0, dim=-1)
     ref = (a @ vh).permute(0, 2, 1, 3).reshape(P, Nt, 128)
-    # scores reach |s| ~ 30 with these operands: bf16 rounding of the folded query gives ~1e-2 relative score error
+    # scores reach |s| ~ 30 with these operands: with a bf16 decoder the rounding of the folded query gives ~1e-2 relative score error
     assert _close(out, ref, 6e-2, 3e-2)
     # the LDS-DMA staging variant (tuning hook, off by default: measured 2.3x slower, profiles/r01_experiments.md) computes
     # the same arithmetic
@@ -378,14 +388,14 @@ def test_i2t_fold_layer(env, P, Nt, shared):
     g = torch.Generator().manual_seed(91 + P)
     T = 4096
     Px = 1 if shared else P
-    x = _bf(torch.randn(Px, T, 256, generator=g)).to(dev)
+    x = _d(torch.randn(Px, T, 256, generator=g)).to(dev)
     pe = torch.randn(T, 256, generator=g).to(dev)
-    wq = _bf(torch.randn(128, 256, generator=g) / 16).to(dev); bq = torch.randn(128, generator=g).to(dev)
-    wo = _bf(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev); bo = torch.randn(256, generator=g).to(dev)
+    wq = _d(torch.randn(128, 256, generator=g) / 16).to(dev); bq = torch.randn(128, generator=g).to(dev)
+    wo = _d(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev); bo = torch.randn(256, generator=g).to(dev)
     lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
-    ktok = _bf(torch.randn(P, Nt, 128, generator=g)).to(dev)
-    vtok = _bf(torch.randn(P, Nt, 128, generator=g)).to(dev)
-    tabq = (pe @ wq.float().t() + bq).to(torch.bfloat16)
+    ktok = _d(torch.randn(P, Nt, 128, generator=g)).to(dev)
+    vtok = _d(torch.randn(P, Nt, 128, generator=g)).to(dev)
+    tabq = (pe @ wq.float().t() + bq).to(_ddt())
     out = ops.i2t_fold_layer(x, ktok, vtok, wq, tabq, wo, bo, lw, lb, x_shared=shared)
     n = min(P, 4)                                                               # reference on the first / last prompts
     for sl in (slice(0, n), slice(P - n, P)):
@@ -409,20 +419,20 @@ def test_upscale_fused(env, P, mask0, nmask):
     """Fused ConvT + LayerNorm2d + GELU + ConvT + GELU + hyper product vs torch (conv_transpose2d on the same bf16 operands)."""
     ops, dev = env
     g = torch.Generator().manual_seed(5 + P)
-    keys = _bf(torch.randn(P, 4096, 256, generator=g)).to(dev)
-    ct1 = _bf(torch.randn(256, 64, 2, 2, generator=g) / 16).to(dev); cb1 = torch.randn(64, generator=g).to(dev)
+    keys = _d(torch.randn(P, 4096, 256, generator=g)).to(dev)
+    ct1 = _d(torch.randn(256, 64, 2, 2, generator=g) / 16).to(dev); cb1 = torch.randn(64, generator=g).to(dev)
     lw = (torch.randn(64, generator=g) * 0.2 + 1).to(dev); lb = (torch.randn(64, generator=g) * 0.3).to(dev)
-    ct2 = _bf(torch.randn(64, 32, 2, 2, generator=g) / 8).to(dev); cb2 = torch.randn(32, generator=g).to(dev)
+    ct2 = _d(torch.randn(64, 32, 2, 2, generator=g) / 8).to(dev); cb2 = torch.randn(32, generator=g).to(dev)
     hyper = torch.randn(P, 4, 128, generator=g).to(dev)
-    w1 = ct1.permute(2, 3, 1, 0).reshape(256, 256).contiguous().to(torch.bfloat16)
-    w2 = ct2.permute(2, 3, 1, 0).reshape(128, 64).contiguous().to(torch.bfloat16)
+    w1 = ct1.permute(2, 3, 1, 0).reshape(256, 256).contiguous().to(_ddt())
+    w2 = ct2.permute(2, 3, 1, 0).reshape(128, 64).contiguous().to(_ddt())
     out = ops.upscale_fused(keys, w1, cb1.repeat(4).contiguous(), lw, lb, w2, cb2, hyper, mask0, nmask)
     sel = list(range(min(P, 2))) + ([P - 1] if P > 2 else [])
     src = keys[sel].float().transpose(1, 2).reshape(len(sel), 256, 64, 64)
     up = F.conv_transpose2d(src, ct1.float(), cb1, stride=2)
     mu = up.mean(1, keepdim=True); var = ((up - mu) ** 2).mean(1, keepdim=True)
     up = (up - mu) / torch.sqrt(var + 1e-6) * lw.view(1, -1, 1, 1) + lb.view(1, -1, 1, 1)
-    up = _bf(F.gelu(up)).float()
+    up = _d(F.gelu(up)).float()
     up = F.gelu(F.conv_transpose2d(up, ct2.float(), cb2, stride=2))                   # [n,32,256,256]
     ref = torch.einsum("nmc,nchw->nmhw", hyper[sel][:, mask0:mask0 + nmask, :32], up)
     # stage 1 is rounded to bf16 in both; a rounding-boundary flip of one of the 64 stage-2 inputs moves an output by a few

@@ -1,0 +1,91 @@
+"""The prompt encoder and the mask decoder as stand-alone module calls - the reference calls them directly
+(micro_sam/training/trainable_sam.py:96-106): ``sam.prompt_encoder(points, boxes, masks)`` and
+``sam.mask_decoder(image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output)``.
+Compared with the oracle's prompt_encoder / mask_decoder (fp32 for the prompt encoder: exact arithmetic up to sin / cos;
+HIP-like rounding mode for the decoder, tolerances of tests/test_gpu_model.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(vit_b_sd):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_tile
+    predictor = util.get_sam_model("vit_b", device="cuda", state_dict=vit_b_sd)
+    tile = synthetic_tile(5)
+    predictor.set_image(util._to_image(tile))
+    return dict(sd=vit_b_sd, predictor=predictor, feats=predictor.get_image_embedding())
+
+
+def _prompts(P, Np, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    pts = torch.rand(P, Np, 2, generator=g) * 1000 + 10
+    lbl = (torch.rand(P, Np, generator=g) > 0.3).to(torch.int)
+    x0 = torch.rand(P, 2, generator=g) * 600 + 20
+    boxes = torch.cat([x0, x0 + torch.rand(P, 2, generator=g) * 350 + 30], dim=1)
+    masks = torch.randn(P, 1, 256, 256, generator=g) * 4
+    return pts, lbl, boxes, masks
+
+
+@pytest.mark.parametrize("kind", ["points", "boxes", "points+boxes", "masks", "points+masks"])
+def test_prompt_encoder_forward(ctx, kind):
+    from oracle import sam_ref as S
+    sam = ctx["predictor"].model
+    pts, lbl, boxes, masks = _prompts(6, 3, seed=len(kind))
+    points = (pts, lbl) if "points" in kind else None
+    bx = boxes if "boxes" in kind else None
+    mk = masks if "masks" in kind else None
+    sparse, dense = sam.prompt_encoder(None if points is None else (points[0].cuda(), points[1].cuda()),
+                                       None if bx is None else bx.cuda(), None if mk is None else mk.cuda())
+    with torch.no_grad():
+        rs, rd = S.prompt_encoder(ctx["sd"], points, bx, mk)
+    if points is None and bx is None:
+        assert sparse.shape == (6, 0, 256)
+    else:
+        assert sparse.shape == rs.shape
+        assert (sparse.cpu() - rs).abs().max().item() < 2e-4            # sinf / cosf of arguments up to ~ 2 pi * 4
+    assert dense.shape == (6, 256, 64, 64)
+    assert (dense.cpu() - rd).abs().max().item() < (2e-3 if mk is not None else 1e-6)
+    pe = sam.prompt_encoder.get_dense_pe()
+    assert (pe.cpu() - S.get_dense_pe(ctx["sd"])).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("kind,multimask", [("points", True), ("boxes", False), ("points+masks", True)])
+def test_mask_decoder_forward_matches_predict_torch_and_oracle(ctx, kind, multimask):
+    """The module-call path (prompt_encoder -> mask_decoder) gives the fused predict path's result, and the oracle's."""
+    from oracle import sam_ref as S
+    sam, p = ctx["predictor"].model, ctx["predictor"]
+    pts, lbl, boxes, masks = _prompts(5, 2, seed=7)
+    points = (pts, lbl) if "points" in kind else None
+    bx = boxes if "boxes" in kind else None
+    mk = masks if "masks" in kind else None
+    sparse, dense = sam.prompt_encoder(None if points is None else (points[0].cuda(), points[1].cuda()),
+                                       None if bx is None else bx.cuda(), None if mk is None else mk.cuda())
+    low, iou = sam.mask_decoder(image_embeddings=ctx["feats"], image_pe=sam.prompt_encoder.get_dense_pe(),
+                                sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=multimask)
+    low2, iou2 = sam.decode(ctx["feats"], None if points is None else pts.cuda(), None if points is None else lbl.cuda(),
+                            None if bx is None else bx.cuda(), None if mk is None else mk.cuda(), multimask)
+    # same kernels downstream of the token assembly: identical up to the fp32 -> fp32 copy of the sparse tokens
+    assert (low - low2).abs().max().item() <= 1e-3 * low2.abs().max().item() + 1e-4
+    assert (iou - iou2).abs().max().item() <= 1e-4
+    with torch.no_grad():
+        rs, rd = S.prompt_encoder(ctx["sd"], points, bx, mk)
+        rl, ri = S.mask_decoder(ctx["sd"], ctx["feats"].cpu(), S.get_dense_pe(ctx["sd"]), rs, rd, multimask, precision="bf16")
+    rng = (rl.max() - rl.min()).item()
+    d = (low.cpu() - rl).abs()
+    assert d.max().item() <= 0.03 * rng and d.mean().item() <= 0.006 * rng
+    assert (iou.cpu() - ri).abs().max().item() <= 2e-3
+    assert ((low.cpu() > 0) != (rl > 0)).float().mean().item() <= 0.01
+
+
+def test_mask_decoder_rejects_foreign_pe(ctx):
+    sam = ctx["predictor"].model
+    sparse = torch.zeros(1, 2, 256, device="cuda")
+    dense = sam.prompt_encoder.no_mask_embed.weight.detach().reshape(1, -1, 1, 1).expand(1, -1, 64, 64)
+    with pytest.raises(NotImplementedError):
+        sam.mask_decoder(ctx["feats"], torch.zeros(1, 256, 64, 64, device="cuda"), sparse, dense, True)
