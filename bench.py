@@ -18,7 +18,8 @@ in HBM before the timed region.  Prints ONE JSON line on rank 0 with, next to th
   cpu_baseline      the CPU oracle (restated reference path, fp32 torch) timed on full tiles on the host cores
   mask_iou_vs_ref   per-instance mask IoU of the HIP path against that fp32 CPU reference on the same tiles (the metric says
                     "mask IoU vs ref"): distribution over the instances the reference keeps, keep-set and label agreement
-  pcie_inclusive    tiles/s of a separate pass that also does util._to_image, the H2D upload and the label D2H download
+  pcie_inclusive    tiles/s of a separate pass that starts from the raw host tiles (H2D upload, util._to_image on the device)
+                    and ends with the label images back in host memory
 """
 import argparse
 import ctypes as C
@@ -251,6 +252,7 @@ def main():
         pk = util.get_sam_model("vit_b", device=dev, state_dict=sd)
         pk.model.use_glds = args.glds
         lanes.append((pk, AutomaticMaskGenerator(pk, device_chunk=args.device_chunk), torch.cuda.Stream(device=dev)))
+    pinned_labels = [None]
     shape_only = np.broadcast_to(np.zeros((1, 1), dtype=np.uint8), (1024, 1024))   # initialize() reads the image SHAPE only
 
     def step(timed: bool, index: int, uploads=None):
@@ -261,7 +263,10 @@ def main():
         flags = []
         t0 = time.perf_counter()
         if uploads is not None:
-            batch_u8 = torch.stack([torch.as_tensor(util._to_image(t)) for t in uploads]).to(dev, non_blocking=False)
+            # the product's raw-tile path (util._compute_embeddings_batched_raw): pinned staging + asynchronous H2D of the
+            # raw uint8 tiles (1 MiB each), util._to_image on the device
+            raw = util._upload_raw_tiles(predictor, uploads)
+            batch_u8 = torch.stack([util.to_image_device(raw[b]) for b in range(raw.shape[0])])
         else:
             lo = (index * n_tiles) % n_distinct
             batch_u8 = tiles_u8[lo:lo + n_tiles]
@@ -310,7 +315,11 @@ def main():
             torch.cuda.synchronize(); stage["gather"] += time.perf_counter() - t3
         if not timed:
             stage["host_enqueue"] += time.perf_counter() - t0    # host time to enqueue the whole step (no sync inside)
-        host_labels = full.cpu() if uploads is not None else None       # PCIe-inclusive pass: label D2H
+        host_labels = None
+        if uploads is not None:                                          # PCIe-inclusive pass: label D2H into pinned memory
+            if pinned_labels[0] is None or pinned_labels[0].shape != full.shape:
+                pinned_labels[0] = torch.empty(full.shape, dtype=full.dtype).pin_memory()
+            host_labels = pinned_labels[0].copy_(full, non_blocking=True)
         # single synchronisation point of the step: convergence flags of the connected-component labelling
         if int(torch.stack(flags).sum().item()) != 0:
             raise RuntimeError("connected-component labelling did not converge in 2 passes")
@@ -406,7 +415,10 @@ def main():
                       "1024^2 tiles/s embed+AMG (vit_b fp8 encoder + bf16 decoder, BASELINE configs[4])", "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.encoder_dtype == "bf16" else "fp8 encoder projections + bf16", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("bf16" if args.encoder_dtype == "bf16" else "fp8 projections + bf16") + " image encoder, " +
+                     ("fp16" if _lib.decoder_dtype() == torch.float16 else "bf16") + " mask decoder (16-bit MFMA operands, fp32 accumulation)",
+            "data": "synthetic",
             "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
                                    "AutomaticMaskGenerator (32x32 grid, multimask, default thresholds)",
                        "tiles_per_step_per_gpu": n_tiles, "encoder_batch": enc_batch,
@@ -423,7 +435,8 @@ def main():
                        "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC},
             "roofline": roof,
             "pcie_inclusive": {"value": round(n_pcie * n_tiles / pcie_elapsed, 2), "unit": "tiles/s", "tiles": n_pcie * n_tiles,
-                               "includes": "util._to_image on the host, pageable H2D of uint8 RGB tiles (3 MiB each), label D2H (4 MiB each)"},
+                               "includes": "pinned asynchronous H2D of the raw uint8 tiles (1 MiB each), util._to_image on the device "
+                                           "(msam_to_image), label D2H into pinned memory (4 MiB each)"},
         }
         # a15 side measurement: RLE encoding of one tile's candidate masks (lazy in the product: only when rles are read)
         amg.initialize(shape_only, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]).unsqueeze(1),

@@ -28,6 +28,8 @@ extern "C" {
 #define MSAM_BF16 2
 #define MSAM_FP8 3                       /* OCP e4m3 (gfx950), not the fnuz variant of MI300 */
 #define MSAM_F16 4                       /* IEEE fp16: the mask decoder's 16-bit type (msam_decoder_dtype) */
+#define MSAM_U8 5                        /* raw image tiles (msam_to_image) */
+#define MSAM_U16 6
 #define MSAM_ACT_NONE 0
 #define MSAM_ACT_GELU 1
 #define MSAM_ACT_RELU 2
@@ -169,6 +171,11 @@ int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flop
  * 64 x 256 tile MFMA GEMMs: patch embedding, neck, the latency-bound token-side projections). */
 #define MSAM_PROFILE_FAMILIES 6
 int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
+
+/* util._to_image (micro_sam/util.py:618-651) on the device, bit for bit: in [H,W,C] (C = 1: gray, replicated; C = 2: third
+ * channel zero; C > 3: first three) of dtype MSAM_U8 / MSAM_U16 / MSAM_F32 -> out uint8 [H,W,3] with per-channel
+ * ((x - min) / (max - min + 1e-7)) * 255 in float32, truncated.  workspace: 32 bytes. */
+int msam_to_image(const void* in, int32_t in_dtype, int32_t H, int32_t W, int32_t C, uint8_t* out, void* workspace, void* stream);
 
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
  * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.

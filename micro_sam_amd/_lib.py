@@ -15,7 +15,7 @@ import torch
 from . import build as _build
 
 MSAM_MAX_BLOCKS = 32
-F32, BF16, FP8, F16 = 1, 2, 3, 4
+F32, BF16, FP8, F16, U8, U16 = 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -116,6 +116,7 @@ _PROTOS = {
     "msam_profile_collect_family": (_i32, [_i32 * PROFILE_FAMILIES, C.c_double * PROFILE_FAMILIES, C.c_double * PROFILE_FAMILIES,
                                           C.c_double * PROFILE_FAMILIES]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "msam_to_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),

@@ -197,3 +197,80 @@ def batched_nms(boxes: torch.Tensor, scores: torch.Tensor, idxs: torch.Tensor, i
         iou = inter / (area[i] + area[j] - inter)
         alive[j] &= ~((iou > iou_threshold) & (cat[j] == cat[i]))
     return torch.as_tensor(np.asarray(keep, dtype=np.int64), device=boxes.device)
+
+
+def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str):
+    """``segment_anything.utils.amg.remove_small_regions`` (called at micro_sam/instance_segmentation.py:156-158): removes
+    small disconnected regions (mode "islands") or fills small holes (mode "holes") of a binary mask; 8-connectivity.
+    Returns (mask, changed).  Upstream labels with ``cv2.connectedComponentsWithStats`` (absent here); the result only
+    depends on the component SETS and sizes, which ``scipy.ndimage.label`` with a full 3x3 structure reproduces."""
+    from scipy import ndimage
+    assert mode in ("holes", "islands")
+    correct_holes = mode == "holes"
+    working = np.logical_xor(correct_holes, mask)
+    regions, n = ndimage.label(working, structure=np.ones((3, 3), dtype=np.uint8))
+    sizes = np.bincount(regions.ravel(), minlength=n + 1)[1:]                      # label 0 = background of `working`
+    small = [i + 1 for i, sz in enumerate(sizes) if sz < area_thresh]
+    if len(small) == 0:
+        return mask, False
+    fill_labels = [0] + small
+    if not correct_holes:
+        fill_labels = [i for i in range(n + 1) if i not in fill_labels]
+        if len(fill_labels) == 0:                                                   # every region below the threshold: keep the largest
+            fill_labels = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill_labels), True
+
+
+def coco_encode_rle(uncompressed_rle: Dict[str, Any]) -> Dict[str, Any]:
+    """``segment_anything.utils.amg.coco_encode_rle``: uncompressed column-major RLE -> COCO compressed RLE
+    (``{"size": [h, w], "counts": str}``).  Upstream calls ``pycocotools.mask.frPyObjects`` (absent here); this is the
+    published string coding of cocoapi ``rleToString`` (maskApi.c): counts are delta-coded against the count two places
+    back from the fourth on, then written as little-endian 5-bit groups, bit 5 = continuation, + 48."""
+    h, w = uncompressed_rle["size"]
+    cnts = [int(c) for c in np.asarray(uncompressed_rle["counts"]).tolist()]
+    out = []
+    for i, x in enumerate(cnts):
+        if i > 2:
+            x -= cnts[i - 2]
+        more = True
+        while more:
+            c = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            out.append(chr(c + 48))
+    return {"size": [int(h), int(w)], "counts": "".join(out)}
+
+
+def coco_decode_rle(rle: Dict[str, Any]) -> Dict[str, Any]:
+    """Inverse of ``coco_encode_rle`` (cocoapi ``rleFrString``): COCO compressed RLE -> uncompressed counts."""
+    s = rle["counts"]
+    s = s.decode("ascii") if isinstance(s, bytes) else s
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1; k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return {"size": list(rle["size"]), "counts": cnts}
+
+
+def mask_to_rle_numpy(mask: np.ndarray) -> Dict[str, Any]:
+    """Uncompressed column-major RLE of ONE host mask (``micro_sam/_vendored.py:104-152`` semantics: counts start with the
+    number of zeros, 0 if the mask starts with a one).  Host twin of the HIP RLE kernels for masks edited on the host."""
+    h, w = mask.shape
+    flat = np.asarray(mask, dtype=bool).reshape(-1, order="F")
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    bounds = np.concatenate([[0], change, [h * w]])
+    counts = np.diff(bounds).tolist()
+    if flat.size and flat[0]:
+        counts = [0] + counts
+    return {"size": [int(h), int(w)], "counts": counts}

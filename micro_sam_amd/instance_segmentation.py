@@ -175,11 +175,44 @@ class AMGBase(ABC):
             pass
         return data
 
+    def _postprocess_small_regions(self, mask_data, min_area, nms_thresh):
+        """Reference :146-186: remove small islands / fill small holes of every kept mask (host step, like the reference's
+        cv2 loop), recompute boxes, NMS that prefers unchanged masks, re-encode the changed ones."""
+        from ._vendored import batched_mask_to_box
+        rles = list(mask_data["rles"])
+        if len(rles) == 0:
+            return mask_data
+        for k in ("bits", "area"):                 # device columns go stale below: continue with the reference's columns
+            if k in mask_data:
+                del mask_data[k]
+        mask_data["rles"] = rles
+        new_masks, scores = [], []
+        for rle in rles:
+            mask = amg_utils.rle_to_mask(rle)
+            mask, changed = amg_utils.remove_small_regions(mask, min_area, mode="holes")
+            unchanged = not changed
+            mask, changed = amg_utils.remove_small_regions(mask, min_area, mode="islands")
+            unchanged = unchanged and not changed
+            new_masks.append(torch.as_tensor(mask, dtype=torch.int).unsqueeze(0))
+            scores.append(float(unchanged))
+        masks = torch.cat(new_masks, dim=0)
+        boxes = batched_mask_to_box(masks.to(torch.bool))
+        keep_by_nms = amg_utils.batched_nms(boxes.float(), torch.as_tensor(scores, dtype=torch.float),
+                                            torch.zeros_like(boxes[:, 0]), iou_threshold=nms_thresh)
+        box_col = torch.as_tensor(mask_data["boxes"]).clone()
+        for i_mask in keep_by_nms.tolist():
+            if scores[i_mask] == 0.0:
+                mask_data["rles"][i_mask] = amg_utils.mask_to_rle_numpy(masks[i_mask].numpy().astype(bool))
+                box_col[i_mask] = boxes[i_mask].to(box_col.dtype)
+        mask_data["boxes"] = box_col.numpy() if isinstance(mask_data["boxes"], np.ndarray) else box_col
+        mask_data.filter(keep_by_nms)
+        return mask_data
+
     def _postprocess_masks(self, mask_data, min_mask_region_area, box_nms_thresh, crop_nms_thresh, output_mode):
         if min_mask_region_area > 0:
-            raise NotImplementedError("micro_sam_amd: min_mask_region_area > 0 (cv2 small-region removal) is not provided")
+            mask_data = self._postprocess_small_regions(mask_data, min_mask_region_area, max(box_nms_thresh, crop_nms_thresh))
         if output_mode == "coco_rle":
-            raise NotImplementedError("micro_sam_amd: output_mode='coco_rle' needs pycocotools, not provided")
+            mask_data["segmentations"] = [amg_utils.coco_encode_rle(rle) for rle in mask_data["rles"]]
         elif output_mode in ("binary_mask", "instance_segmentation"):
             if "bits" in mask_data:
                 h, w = mask_data.mask_size

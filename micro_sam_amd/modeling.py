@@ -485,8 +485,10 @@ class Sam(nn.Module):
         return pos.t().reshape(1, PROMPT_DIM, GRID, GRID).contiguous()
 
     def _image_state(self, features: torch.Tensor) -> torch.Tensor:
+        # the cache entry keeps the caller's tensor alive and is matched by identity + version: a freed embedding whose
+        # address is handed to the next one can no longer alias it (SamPredictor.reset_image / set_image also drop it)
         key = (features.data_ptr(), features._version, tuple(features.shape))
-        if self._img_state is not None and self._img_state[0] == key:
+        if self._img_state is not None and self._img_state[0] == key and self._img_state[3] is features:
             return self._img_state[1]
         p, _, consts = self._prepare_decoder()
         lib = _lib.load()
@@ -494,7 +496,7 @@ class Sam(nn.Module):
         state = torch.empty(lib.msam_decoder_image_bytes(), dtype=torch.uint8, device=self.device)
         _lib.check(lib.msam_decoder_prepare_image(C.byref(p), consts.data_ptr(), feats.data_ptr(), state.data_ptr(),
                                                   None, 0, _lib.stream_ptr()), "msam_decoder_prepare_image")
-        self._img_state = (key, state, feats)
+        self._img_state = (key, state, feats, features)
         return state
 
     def _workspace(self, P: int) -> torch.Tensor:

@@ -154,6 +154,30 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return out
 
 
+def to_image(x: torch.Tensor) -> torch.Tensor:
+    """``util._to_image`` on the device (msam_to_image): [H,W] / [H,W,C] uint8 / uint16 (as int16 / uint16 storage) / float32
+    device tensor -> uint8 [H,W,3], bit-identical to the host formula."""
+    _lib.require_gpu()
+    if x.dim() == 2:
+        x = x[..., None]
+    if x.dim() != 3:
+        raise ValueError(f"Invalid input dimensionality {x.dim()}. Expect either a 2D input (=grayscale image) "
+                         "or a 3D input (= image with channels).")
+    if x.dtype == torch.uint8:
+        dt = _lib.U8
+    elif x.dtype in (torch.uint16,):
+        dt = _lib.U16
+    else:
+        x, dt = x.to(torch.float32), F32
+    x = x.contiguous()
+    H, W, Cc = x.shape
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=x.device)
+    ws = torch.empty((8,), dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().msam_to_image(x.data_ptr(), dt, H, W, Cc, out.data_ptr(), ws.data_ptr(), _lib.stream_ptr()),
+               "msam_to_image")
+    return out
+
+
 def patchify(img: torch.Tensor) -> torch.Tensor:
     B = img.shape[0]
     out = torch.empty((B * 4096, 768), dtype=torch.bfloat16, device=img.device)

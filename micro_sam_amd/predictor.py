@@ -26,6 +26,7 @@ class SamPredictor:
         return self.model.device
 
     def reset_image(self) -> None:
+        self.model._img_state = None            # prepared decoder state of the previous embedding
         self.is_image_set = False
         self.features = None
         self.orig_h = self.orig_w = self.input_h = self.input_w = None

@@ -47,13 +47,30 @@ def _compute_hash(path: str) -> str:
 
 def _load_checkpoint(checkpoint_path: str):
     """torch_em style ({'model_state', 'decoder_state'}, 'sam.' prefix) or plain SAM state dict (util.py:273-290)."""
-    state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    try:
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=True)      # plain tensors: no code execution
+    except Exception:
+        # torch_em checkpoints pickle optimizer / trainer objects next to the tensors: unpickling them runs code from the
+        # file - only load checkpoints you trust (same as the reference, micro_sam/util.py:277)
+        state = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
     if "model_state" in state:
         model_state = OrderedDict((k[len("sam."):] if k.startswith("sam.") else k, v)
                                   for k, v in state["model_state"].items())
     else:
         model_state = state
     return state, model_state
+
+
+def _hash_state_dict(state_dict) -> str:
+    """xxh128 over the sorted keys, shapes and bytes of a state dict: embedding caches computed with other weights of the
+    same model type are detected (``_check_saved_embeddings`` compares ``predictor._hash``)."""
+    import xxhash
+    h = xxhash.xxh128()
+    for k in sorted(state_dict):
+        t = state_dict[k].detach().cpu().contiguous()
+        h.update(k.encode()); h.update(str(tuple(t.shape)).encode()); h.update(str(t.dtype).encode())
+        h.update(t.view(torch.uint8).numpy().tobytes() if t.numel() else b"")
+    return f"xxh128:{h.hexdigest()}"
 
 
 def _validate_model_type(state) -> str:
@@ -90,6 +107,7 @@ def get_sam_model(model_type: str = _DEFAULT_MODEL, device: Optional[Union[str, 
             model_type = abbreviated = provided
     elif state_dict is not None:
         model_state = state_dict
+        model_hash = _hash_state_dict(state_dict)
     else:
         raise RuntimeError("micro_sam_amd.get_sam_model: no network access for model downloads - pass checkpoint_path "
                            "(a SAM / micro_sam checkpoint file) or state_dict.")
@@ -164,6 +182,61 @@ def _compute_embeddings_batched(predictor, batched_images):
     predictor.features = features[-1:]
     predictor.is_image_set = True
     return features, original_sizes, input_sizes
+
+
+def _device_to_image_ok(raw_images) -> bool:
+    """Raw tiles that need no resize (long side == the encoder's 1024) and have a dtype the device kernel takes."""
+    first = raw_images[0]
+    if not isinstance(first, np.ndarray) or first.ndim not in (2, 3):
+        return False
+    if any((not isinstance(im, np.ndarray)) or im.shape != first.shape or im.dtype != first.dtype for im in raw_images):
+        return False
+    return max(first.shape[:2]) == modeling.IMG_SIZE and first.dtype.kind in "uif" and first.dtype.itemsize <= 4
+
+
+def _upload_raw_tiles(predictor, raw_images) -> torch.Tensor:
+    """Host tiles -> one device tensor [B,H,W(,C)] (uint8 as is, anything else as float32) through a cached pinned staging
+    buffer and an asynchronous copy: 1 MiB per uint8 1024^2 tile crosses PCIe instead of the 3 MiB RGB copy."""
+    batch = np.stack(raw_images)
+    if batch.dtype != np.uint8:
+        batch = batch.astype(np.float32)
+    key = (batch.shape, batch.dtype.str)
+    pin = getattr(predictor, "_pin", None)
+    if pin is None or pin[0] != key:
+        pin = (key, torch.empty(batch.shape, dtype=torch.from_numpy(batch[:0]).dtype).pin_memory(), torch.cuda.Event())
+        predictor._pin = pin
+    else:
+        pin[2].synchronize()                              # the previous upload out of this buffer has completed
+    pin[1].copy_(torch.from_numpy(batch))
+    dev = pin[1].to(predictor.device, non_blocking=True)
+    pin[2].record()
+    return dev
+
+
+def to_image_device(raw: torch.Tensor) -> torch.Tensor:
+    """``_to_image`` on the device for a raw tile [H,W] / [H,W,C] already in HBM -> uint8 [H,W,3] (bit-identical)."""
+    from . import ops
+    if raw.dim() == 3 and raw.shape[-1] > 3:
+        warnings.warn(f"You provided an input with {raw.shape[-1]} channels. Only the first three will be used.")
+    return ops.to_image(raw)
+
+
+@torch.no_grad()
+def _compute_embeddings_batched_raw(predictor, raw_images):
+    """``_compute_embeddings_batched`` from RAW tiles: when no resize is needed the tiles are uploaded as they are and
+    ``_to_image`` + ``Sam.preprocess`` run on the device; otherwise the host path (``_to_image``, PIL resize)."""
+    if not _device_to_image_ok(raw_images):
+        return _compute_embeddings_batched(predictor, [_to_image(im) for im in raw_images])
+    predictor.reset_image()
+    dev = _upload_raw_tiles(predictor, raw_images)
+    batch = torch.stack([to_image_device(dev[b]) for b in range(dev.shape[0])])
+    features = predictor.model.image_encoder.forward_u8(batch)
+    size = tuple(raw_images[0].shape[:2])
+    predictor.original_size = size
+    predictor.input_size = size
+    predictor.features = features[-1:]
+    predictor.is_image_set = True
+    return features, [size] * len(raw_images), [size] * len(raw_images)
 
 
 def handle_pbar(verbose, pbar_init, pbar_update):
@@ -338,7 +411,7 @@ def _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_u
         zs = [z for z in range(z_start, z_stop)
               if not (partial_features and ds.chunk_initialized((z, 0, 0, 0, 0)) and np.count_nonzero(ds[z]) != 0)]
         if zs:
-            emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [_to_image(input_[z]) for z in zs])
+            emb, original_sizes, input_sizes = _compute_embeddings_batched_raw(predictor, [np.asarray(input_[z]) for z in zs])
             if save_features:
                 host = emb.cpu().numpy()
                 for k, z in enumerate(zs):
@@ -401,10 +474,10 @@ def _compute_tiled_features_2d(predictor, input_, tile_shape, halo, f, pbar_init
         for tile_id in tile_ids:       # the encoder batches tiles of one shape (border tiles of a mosaic are smaller)
             tile = tiling.get_block_with_halo(tile_id, list(halo))
             outer_tile = tuple(slice(beg, end) for beg, end in zip(tile.outer_block.begin, tile.outer_block.end))
-            image = _to_image(input_[outer_tile])
+            image = np.asarray(input_[outer_tile])               # raw tile: _to_image runs on the device when no resize is needed
             groups.setdefault(image.shape[:2], []).append((tile_id, image))
         for members in groups.values():
-            emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [im for _, im in members])
+            emb, original_sizes, input_sizes = _compute_embeddings_batched_raw(predictor, [im for _, im in members])
             for k, (tile_id, _) in enumerate(members):
                 features[tile_id] = TileArray(emb[k:k + 1], original_sizes[k], input_sizes[k])
             if group is not None:
@@ -444,10 +517,10 @@ def _compute_tiled_features_3d(predictor, input_, tile_shape, halo, f, pbar_init
         for z, tile_id in chunk:
             tile = tiling.get_block_with_halo(tile_id, list(halo))
             outer_tile = (z,) + tuple(slice(beg, end) for beg, end in zip(tile.outer_block.begin, tile.outer_block.end))
-            image = _to_image(input_[outer_tile])
+            image = np.asarray(input_[outer_tile])
             groups.setdefault(image.shape[:2], []).append((z, tile_id, image))
         for members in groups.values():
-            emb, original_sizes, input_sizes = _compute_embeddings_batched(predictor, [im for _, _, im in members])
+            emb, original_sizes, input_sizes = _compute_embeddings_batched_raw(predictor, [im for _, _, im in members])
             for k, (z, tile_id, _) in enumerate(members):
                 if tile_id not in store:
                     store[tile_id] = (torch.zeros((n_slices, 1) + tuple(emb.shape[1:]), dtype=emb.dtype, device=emb.device),

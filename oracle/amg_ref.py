@@ -198,6 +198,29 @@ def area_from_rle(rle: Dict[str, Any]) -> int:
     return sum(rle["counts"][1::2])
 
 
+def remove_small_regions(mask: np.ndarray, area_thresh: float, mode: str) -> Tuple[np.ndarray, bool]:
+    """segment_anything.utils.amg.remove_small_regions (call sites micro_sam/instance_segmentation.py:156-158): upstream
+    labels ``correct_holes ^ mask`` with cv2.connectedComponentsWithStats(..., 8) - cv2 is absent, 8-connected labelling
+    through scipy gives the same component sets and sizes (the label numbering only matters for the size tie-break of
+    "keep the largest", raster order of the first pixel in both).  PARITY UNPINNED against cv2 itself."""
+    from scipy import ndimage
+    assert mode in ["holes", "islands"]
+    correct_holes = mode == "holes"
+    working_mask = (correct_holes ^ mask).astype(np.uint8)
+    regions, n_labels = ndimage.label(working_mask, structure=np.ones((3, 3)))
+    sizes = np.array([(regions == i).sum() for i in range(1, n_labels + 1)])
+    small_regions = [i + 1 for i, s in enumerate(sizes) if s < area_thresh]
+    if len(small_regions) == 0:
+        return mask, False
+    fill_labels = [0] + small_regions
+    if not correct_holes:
+        fill_labels = [i for i in range(n_labels + 1) if i not in fill_labels]
+        if len(fill_labels) == 0:
+            fill_labels = [int(np.argmax(sizes)) + 1]
+    mask = np.isin(regions, fill_labels)
+    return mask, True
+
+
 def box_xyxy_to_xywh(box_xyxy: torch.Tensor) -> torch.Tensor:
     box_xywh = deepcopy(box_xyxy)
     box_xywh[2] = box_xywh[2] - box_xywh[0]

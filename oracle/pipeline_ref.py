@@ -137,8 +137,36 @@ def postprocess_batch(data: A.MaskData, crop_box, original_size, pred_iou_thresh
     return data
 
 
-def postprocess_masks(mask_data: A.MaskData, output_mode: str = "binary_mask") -> List[Dict[str, Any]]:
-    """AMGBase._postprocess_masks with min_mask_region_area == 0, instance_segmentation.py:188-227."""
+def postprocess_small_regions(mask_data: A.MaskData, min_area: float, nms_thresh: float) -> A.MaskData:
+    """AMGBase._postprocess_small_regions, instance_segmentation.py:146-186."""
+    if len(mask_data["rles"]) == 0:
+        return mask_data
+    new_masks, scores = [], []
+    for rle in mask_data["rles"]:
+        mask = A.rle_to_mask(rle)
+        mask, changed = A.remove_small_regions(mask, min_area, mode="holes")
+        unchanged = not changed
+        mask, changed = A.remove_small_regions(mask, min_area, mode="islands")
+        unchanged = unchanged and not changed
+        new_masks.append(torch.as_tensor(mask, dtype=torch.int).unsqueeze(0))
+        scores.append(float(unchanged))
+    masks = torch.cat(new_masks, dim=0)
+    boxes = A.batched_mask_to_box(masks.to(torch.bool))
+    keep = A.batched_nms(boxes.float(), torch.as_tensor(scores, dtype=torch.float), torch.zeros_like(boxes[:, 0]),
+                         iou_threshold=nms_thresh)
+    for i_mask in keep:
+        if scores[i_mask] == 0.0:
+            mask_data["rles"][i_mask] = A.mask_to_rle(masks[i_mask].unsqueeze(0).to(torch.bool))[0]
+            mask_data["boxes"][i_mask] = boxes[i_mask] if torch.is_tensor(mask_data["boxes"]) else boxes[i_mask].numpy()
+    mask_data.filter(keep)
+    return mask_data
+
+
+def postprocess_masks(mask_data: A.MaskData, output_mode: str = "binary_mask", min_mask_region_area: int = 0,
+                      box_nms_thresh: float = 0.7, crop_nms_thresh: float = 0.7) -> List[Dict[str, Any]]:
+    """AMGBase._postprocess_masks, instance_segmentation.py:188-227."""
+    if min_mask_region_area > 0:
+        mask_data = postprocess_small_regions(mask_data, min_mask_region_area, max(box_nms_thresh, crop_nms_thresh))
     if output_mode in ("binary_mask", "instance_segmentation"):
         mask_data["segmentations"] = [A.rle_to_mask(rle) for rle in mask_data["rles"]]
     elif output_mode == "rle":
@@ -161,7 +189,7 @@ def postprocess_masks(mask_data: A.MaskData, output_mode: str = "binary_mask") -
 
 def amg_generate(state: Dict[str, Any], pred_iou_thresh: float = 0.88, stability_score_thresh: float = 0.95,
                  box_nms_thresh: float = 0.7, output_mode: str = "instance_segmentation",
-                 with_background: bool = True, crop_nms_thresh: float = 0.7):
+                 with_background: bool = True, crop_nms_thresh: float = 0.7, min_mask_region_area: int = 0):
     """AutomaticMaskGenerator.generate (crops / tiles included).  instance_segmentation.py:463-530."""
     data = A.MaskData()
     for data_, crop_box in zip(state["crop_list"], state["crop_boxes"]):
@@ -173,7 +201,7 @@ def amg_generate(state: Dict[str, Any], pred_iou_thresh: float = 0.88, stability
         keep = A.batched_nms(data["boxes"].float(), scores, torch.zeros_like(data["boxes"][:, 0]), iou_threshold=crop_nms_thresh)
         data.filter(keep)
     data.to_numpy()
-    masks = postprocess_masks(data, output_mode)
+    masks = postprocess_masks(data, output_mode, min_mask_region_area, box_nms_thresh, crop_nms_thresh)
     if output_mode == "instance_segmentation":
         shape = next(iter(masks))["segmentation"].shape if len(masks) > 0 else state["original_size"]
         masks = A.mask_data_to_segmentation(masks, shape=shape, with_background=with_background,

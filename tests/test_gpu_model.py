@@ -179,9 +179,33 @@ def test_amg_initialize_generate_vs_oracle(ctx):
     seg_lo_ref = PR.amg_generate({"crop_list": [cl2], "crop_boxes": state["crop_boxes"], "original_size": state["original_size"]},
                                  pred_iou_thresh=0.5, stability_score_thresh=0.5, box_nms_thresh=0.9)
     assert seg_lo.max() > 0 and np.array_equal(seg_lo, seg_lo_ref)
-    for mode in ("binary_mask", "rle"):
+    for mode in ("binary_mask", "rle", "coco_rle"):
         recs = amg.generate(output_mode=mode, pred_iou_thresh=0.5, stability_score_thresh=0.5)
         assert isinstance(recs, list) and all("bbox" in r and "predicted_iou" in r for r in recs)
+    # coco_rle decodes to the rle output (cocoapi string coding restated in amg_utils)
+    from micro_sam_amd import amg_utils
+    rl = amg.generate(output_mode="rle", pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    assert [amg_utils.coco_decode_rle(r["segmentation"])["counts"] for r in recs] == [list(r["segmentation"]["counts"]) for r in rl]
+    # min_mask_region_area > 0 (reference _postprocess_small_regions, :146-186): records and label image equal the oracle's on OUR state
+    kw = dict(pred_iou_thresh=0.5, stability_score_thresh=0.5, min_mask_region_area=200)
+    recs_s = amg.generate(output_mode="binary_mask", **kw)
+    cl3 = A.MaskData(**{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in state["crop_list"][0].items() if k not in ("bits", "area")})
+    cl3["rles"] = [{"size": r["size"], "counts": list(np.asarray(r["counts"]).tolist())} for r in state["crop_list"][0]["rles"]]
+    st3 = {"crop_list": [cl3], "crop_boxes": state["crop_boxes"], "original_size": state["original_size"]}
+    ref_s = PR.amg_generate(deepcopy_state(st3), output_mode="binary_mask", **kw)
+    assert len(recs_s) == len(ref_s) > 0
+    changed = 0
+    for a, b in zip(recs_s, ref_s):
+        assert np.array_equal(a["segmentation"], b["segmentation"]) and a["bbox"] == b["bbox"] and a["area"] == b["area"]
+    plain = amg.generate(output_mode="binary_mask", pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    assert sum(int(r["area"]) for r in recs_s) != sum(int(r["area"]) for r in plain)          # the option did something
+    seg_s = amg.generate(**kw)
+    assert np.array_equal(seg_s, PR.amg_generate(deepcopy_state(st3), **kw))
+
+
+def deepcopy_state(st):
+    from copy import deepcopy
+    return deepcopy(st)
 
 
 def test_precompute_3d_batched(ctx):

@@ -1,4 +1,5 @@
 """Integer / byte post-processing parity: bit-exact against the CPU oracle (torch bilinear + reference formulas)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -93,3 +94,41 @@ def test_uncrop_bits_matches_pad(crop_box, size):
     ref[:, y0:y1, x0:x1] = masks
     assert torch.equal(ops.unpack_bits(out, h).cpu(), ref)
     assert torch.equal(out.cpu(), pack_bits(ref.cuda()).cpu())
+
+
+@pytest.mark.parametrize("dtype,shape", [("uint8", (1024, 1024)), ("uint16", (300, 200)), ("float32", (64, 80, 3)),
+                                         ("uint8", (128, 96, 2)), ("float32", (50, 60, 5)), ("uint8", (40, 40, 1))])
+def test_to_image_device_is_bit_identical(dtype, shape):
+    """util._to_image on the device (msam_to_image) == the host formula of the reference (micro_sam/util.py:618-651)."""
+    import warnings
+    from micro_sam_amd import util
+    rng = np.random.default_rng(abs(hash((dtype, shape))) % 1000)
+    if dtype == "float32":
+        x = (rng.normal(0, 30, size=shape) + 5).astype(np.float32)
+    else:
+        x = rng.integers(3, 250 if dtype == "uint8" else 60000, size=shape).astype(dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = util._to_image(x)
+        t = torch.from_numpy(x).cuda()                                   # uint16 takes the kernel's own uint16 path
+        got = util.to_image_device(t).cpu().numpy()
+        if dtype == "uint16":                                            # ... and the float32 path agrees (exact conversion)
+            assert np.array_equal(util.to_image_device(torch.from_numpy(x.astype(np.float32)).cuda()).cpu().numpy(), got)
+    assert got.shape == ref.shape and got.dtype == np.uint8
+    assert np.array_equal(got, ref)
+    const = np.full(shape[:2], 7, dtype=np.uint8)                       # max == min: everything maps to 0, no division blow-up
+    assert np.array_equal(util.to_image_device(torch.as_tensor(const).cuda()).cpu().numpy(), util._to_image(const))
+
+
+def test_raw_tile_fast_path_gives_the_same_embedding():
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    p = util.get_sam_model("vit_b", device="cuda", state_dict=synthetic_state_dict("vit_b", 0))
+    tiles = [synthetic_tile(s) for s in (11, 12)]
+    fast, osz, isz = util._compute_embeddings_batched_raw(p, tiles)
+    slow, osz2, isz2 = util._compute_embeddings_batched(p, [util._to_image(t) for t in tiles])
+    assert torch.equal(fast, slow) and list(osz) == [tuple(o) for o in osz2] and list(isz) == list(isz2)
+    small = [synthetic_tile(s, (512, 512)) for s in (1, 2)]             # needs the PIL resize: host path, same function
+    a, _, _ = util._compute_embeddings_batched_raw(p, small)
+    b, _, _ = util._compute_embeddings_batched(p, [util._to_image(t) for t in small])
+    assert torch.equal(a, b)

@@ -67,3 +67,63 @@ def test_single_process_path():
     x = torch.tensor([[[0, 1], [2, 0]], [[1, 1], [0, 3]]], dtype=torch.int32)
     out = parallel.gather_label_tiles(x, 2)
     assert out.tolist() == [[[0, 1], [2, 0]], [[3, 3], [0, 5]]]
+
+
+# ---- segment_slices_sharded (reference _segment_slices, micro_sam/multi_dimensional_segmentation.py:385-416) under gloo
+class _StubSegmentor:
+    """Deterministic per-slice 'segmentation' (no GPU): labels 1..K on the slice's bright columns."""
+
+    def initialize(self, image, image_embeddings=None, verbose=False, i=None):
+        self._img = image
+
+    def generate(self, **kwargs):
+        seg = np.zeros(self._img.shape, dtype="uint32")
+        k = int(self._img[0, 0]) % 4                       # K differs per slice, 0 for some
+        for j in range(k):
+            seg[:, 2 * j] = j + 1
+        return seg
+
+
+def _sharded_worker(rank, world, port, vol, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from micro_sam_amd import multi_dimensional_segmentation as M
+    from micro_sam_amd import util
+
+    class _P:
+        device = "cpu"
+    util.precompute_image_embeddings = lambda **kw: {"features": None, "input_size": None, "original_size": None}
+    out = M.segment_slices_sharded(vol, _P(), _StubSegmentor())
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_segment_slices_sharded_matches_serial_loop():
+    from micro_sam_amd import multi_dimensional_segmentation as M
+    from micro_sam_amd import util
+    rng = np.random.default_rng(3)
+    vol = rng.integers(0, 255, size=(5, 8, 8)).astype(np.uint8)
+    vol[:, 0, 0] = [3, 0, 2, 1, 3]                          # K per slice: 3, 0, 2, 1, 3
+
+    class _P:
+        device = "cpu"
+    orig = util.precompute_image_embeddings
+    util.precompute_image_embeddings = lambda **kw: {"features": None, "input_size": None, "original_size": None}
+    try:
+        serial, _ = M.segment_slices(vol, _P(), _StubSegmentor())
+    finally:
+        util.precompute_image_embeddings = orig
+    assert serial.max() == 9 and serial[1].max() == 0 and serial[2].max() == 5
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, vol, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert results[r].dtype == np.uint32 and np.array_equal(results[r], serial), r
