@@ -177,6 +177,20 @@ int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, do
  * ((x - min) / (max - min + 1e-7)) * 255 in float32, truncated.  workspace: 32 bytes. */
 int msam_to_image(const void* in, int32_t in_dtype, int32_t H, int32_t W, int32_t C, uint8_t* out, void* workspace, void* stream);
 
+/* ---- fine-tuning (micro_sam/training/sam_trainer.py:131-425, trainable_sam.py:12-114): backward
+ * kernels of the mask decoder's non-GEMM pieces (the GEMMs run msam_gemm_bf16 in both directions: dX = dY W, dW = dY^T X).
+ * msam_layernorm_backward: x, dy, dx fp32 [rows, dim] (dim 64 / 128 / 256), dweight / dbias fp32 [dim] ACCUMULATED
+ *   (zero them first).
+ * msam_attention_forward / backward: softmax(scale q k^T) v for q fp32 [BH, Nq, D], k / v fp32 [BH, Nk, D], D = 16 or 32;
+ *   lse fp32 [BH, Nq] (log-sum-exp of the scaled scores, saved for the backward pass), delta: workspace fp32 [BH, Nq]. */
+int msam_layernorm_backward(const float* x, const float* weight, const float* dy, float eps, int64_t rows, int32_t dim,
+                            float* dx, float* dweight, float* dbias, void* stream);
+int msam_attention_forward(const float* q, const float* k, const float* v, int32_t BH, int32_t Nq, int32_t Nk, int32_t D,
+                           float scale, float* out, float* lse, void* stream);
+int msam_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                            const float* lse, int32_t BH, int32_t Nq, int32_t Nk, int32_t D, float scale, float* dq, float* dk,
+                            float* dv, float* delta, void* stream);
+
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
  * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.
  * out_nchw_hw > 0: write fp32 output transposed to [rows/hw, dim, hw] (the encoder's NCHW result). */

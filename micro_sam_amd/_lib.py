@@ -116,6 +116,9 @@ _PROTOS = {
     "msam_profile_collect_family": (_i32, [_i32 * PROFILE_FAMILIES, C.c_double * PROFILE_FAMILIES, C.c_double * PROFILE_FAMILIES,
                                           C.c_double * PROFILE_FAMILIES]),
     "msam_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "msam_layernorm_backward": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "msam_attention_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "msam_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "msam_to_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

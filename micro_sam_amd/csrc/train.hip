@@ -1,0 +1,184 @@
+// Backward kernels for fine-tuning the mask decoder (reference micro_sam/training/sam_trainer.py:131-425,
+// trainable_sam.py:12-114): LayerNorm backward, and softmax attention forward / backward for the
+// decoder's shapes (8 heads, head dim 16 or 32, <= 16 prompt tokens on one side and 4096 image tokens or <= 16 tokens on the
+// other).  All fp32: these are the small, latency-bound pieces around the GEMMs (which run on the MFMA GEMM kernel in both
+// directions: dX = dY W, dW = dY^T X).  No atomics on the data path except the per-column parameter-gradient sums.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+namespace {
+
+// ---- LayerNorm backward over rows of `dim` <= 256 channels (one wave per row):
+//   xhat = (x - mean) * rstd;  g = dy * w;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dw += dy * xhat;  db += dy
+template <int V>   // V = dim / 64 values per lane (dim in {64, 128, 256})
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, float eps, long rows,
+                                                            float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
+    constexpr int DIM = V * 64;
+    __shared__ float sdw[4][DIM], sdb[4][DIM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float aw[V], ab[V], wv[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { aw[i] = 0.f; ab[i] = 0.f; wv[i] = w[i * 64 + lane]; }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        float xv[V], gy[V], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { xv[i] = x[row * DIM + i * 64 + lane]; gy[i] = dy[row * DIM + i * 64 + lane]; s += xv[i]; }
+        const float mean = wave_sum64(s) * (1.f / DIM);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) { xv[i] -= mean; q += xv[i] * xv[i]; }
+        const float rstd = 1.0f / sqrtf(wave_sum64(q) * (1.f / DIM) + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            xv[i] *= rstd;                                   // xhat
+            const float g = gy[i] * wv[i];
+            sg += g; sgx += g * xv[i];
+            aw[i] += gy[i] * xv[i]; ab[i] += gy[i];
+        }
+        const float mg = wave_sum64(sg) * (1.f / DIM), mgx = wave_sum64(sgx) * (1.f / DIM);
+#pragma unroll
+        for (int i = 0; i < V; ++i) dx[row * DIM + i * 64 + lane] = rstd * (gy[i] * wv[i] - mg - xv[i] * mgx);
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) { sdw[wave][i * 64 + lane] = aw[i]; sdb[wave][i * 64 + lane] = ab[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < DIM; c += 256) {
+        atomicAdd(dw + c, sdw[0][c] + sdw[1][c] + sdw[2][c] + sdw[3][c]);
+        atomicAdd(db + c, sdb[0][c] + sdb[1][c] + sdb[2][c] + sdb[3][c]);
+    }
+}
+
+// ---- attention, one thread per query row (forward, dQ) or per key row (dK, dV); q [BH, Nq, D], k / v [BH, Nk, D]
+template <int D>
+__global__ __launch_bounds__(128) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, int Nq, int Nk, float scale,
+                                                       float* __restrict__ out, float* __restrict__ lse) {
+    const int bh = blockIdx.y, i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= Nq) return;
+    float qv[D], acc[D];
+    const float* qp = q + ((long)bh * Nq + i) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = qp[d] * scale; acc[d] = 0.f; }
+    const float* kb = k + (long)bh * Nk * D;
+    const float* vb = v + (long)bh * Nk * D;
+    float m = -3.0e38f, l = 0.f;
+    for (int j = 0; j < Nk; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s = fmaf(qv[d], kb[(long)j * D + d], s);
+        const float mn = fmaxf(m, s), a = __expf(m - mn), p = __expf(s - mn);
+        l = l * a + p;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(p, vb[(long)j * D + d], acc[d] * a);
+        m = mn;
+    }
+    const float inv = 1.f / l;
+    float* op = out + ((long)bh * Nq + i) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) op[d] = acc[d] * inv;
+    lse[(long)bh * Nq + i] = m + __logf(l);
+}
+
+// delta_i = sum_d dO_i O_i;  dQ_i = scale * sum_j P_ij (dP_ij - delta_i) K_j,  P_ij = exp(scale q_i k_j - lse_i), dP_ij = dO_i V_j
+template <int D>
+__global__ __launch_bounds__(128) void attn_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ out,
+                                                         const float* __restrict__ dout, const float* __restrict__ lse, int Nq,
+                                                         int Nk, float scale, float* __restrict__ dq, float* __restrict__ delta) {
+    const int bh = blockIdx.y, i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= Nq) return;
+    const long ro = ((long)bh * Nq + i) * D;
+    float qv[D], dov[D], acc[D], dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = q[ro + d] * scale; dov[d] = dout[ro + d]; dl = fmaf(dov[d], out[ro + d], dl); acc[d] = 0.f; }
+    const float L = lse[(long)bh * Nq + i];
+    const float* kb = k + (long)bh * Nk * D;
+    const float* vb = v + (long)bh * Nk * D;
+    for (int j = 0; j < Nk; ++j) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s = fmaf(qv[d], kb[(long)j * D + d], s); dp = fmaf(dov[d], vb[(long)j * D + d], dp); }
+        const float ds = __expf(s - L) * (dp - dl);
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(ds, kb[(long)j * D + d], acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) dq[ro + d] = acc[d] * scale;
+    delta[(long)bh * Nq + i] = dl;
+}
+
+// dV_j = sum_i P_ij dO_i;  dK_j = scale * sum_i P_ij (dP_ij - delta_i) Q_i
+template <int D>
+__global__ __launch_bounds__(128) void attn_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta, int Nq,
+                                                          int Nk, float scale, float* __restrict__ dk, float* __restrict__ dv) {
+    const int bh = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= Nk) return;
+    const long ro = ((long)bh * Nk + j) * D;
+    float kv[D], vv[D], ak[D], av[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { kv[d] = k[ro + d]; vv[d] = v[ro + d]; ak[d] = 0.f; av[d] = 0.f; }
+    const float* qb = q + (long)bh * Nq * D;
+    const float* dob = dout + (long)bh * Nq * D;
+    for (int i = 0; i < Nq; ++i) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s = fmaf(qb[(long)i * D + d], kv[d], s); dp = fmaf(dob[(long)i * D + d], vv[d], dp); }
+        const float p = __expf(s * scale - lse[(long)bh * Nq + i]);
+        const float ds = p * (dp - delta[(long)bh * Nq + i]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { ak[d] = fmaf(ds, qb[(long)i * D + d], ak[d]); av[d] = fmaf(p, dob[(long)i * D + d], av[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { dk[ro + d] = ak[d] * scale; dv[ro + d] = av[d]; }
+}
+
+}  // namespace
+
+extern "C" int msam_layernorm_backward(const float* x, const float* weight, const float* dy, float eps, int64_t rows, int32_t dim,
+                                       float* dx, float* dweight, float* dbias, void* stream) {
+    if (!x || !weight || !dy || !dx || !dweight || !dbias || rows <= 0) { msam_set_error("msam_layernorm_backward: bad argument"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
+    if (dim == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    else if (dim == 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    else if (dim == 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    else { msam_set_error("msam_layernorm_backward: dim must be 64, 128 or 256"); return 1; }
+    return msam_check_launch("msam_layernorm_backward");
+}
+
+extern "C" int msam_attention_forward(const float* q, const float* k, const float* v, int32_t BH, int32_t Nq, int32_t Nk,
+                                      int32_t D, float scale, float* out, float* lse, void* stream) {
+    if (!q || !k || !v || !out || !lse || BH <= 0 || Nq <= 0 || Nk <= 0) { msam_set_error("msam_attention_forward: bad argument"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((Nq + 127) / 128, BH);
+    if (D == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(128), 0, s, q, k, v, Nq, Nk, scale, out, lse);
+    else if (D == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, s, q, k, v, Nq, Nk, scale, out, lse);
+    else { msam_set_error("msam_attention_forward: head dim must be 16 or 32"); return 1; }
+    return msam_check_launch("msam_attention_forward");
+}
+
+extern "C" int msam_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
+                                       const float* lse, int32_t BH, int32_t Nq, int32_t Nk, int32_t D, float scale, float* dq,
+                                       float* dk, float* dv, float* delta, void* stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !delta || BH <= 0 || Nq <= 0 || Nk <= 0) {
+        msam_set_error("msam_attention_backward: bad argument");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gq((Nq + 127) / 128, BH), gk((Nk + 127) / 128, BH);
+    if (D == 16) {
+        hipLaunchKernelGGL(attn_bwd_q_kernel<16>, gq, dim3(128), 0, s, q, k, v, out, dout, lse, Nq, Nk, scale, dq, delta);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<16>, gk, dim3(128), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv);
+    } else if (D == 32) {
+        hipLaunchKernelGGL(attn_bwd_q_kernel<32>, gq, dim3(128), 0, s, q, k, v, out, dout, lse, Nq, Nk, scale, dq, delta);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, gk, dim3(128), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv);
+    } else { msam_set_error("msam_attention_backward: head dim must be 16 or 32"); return 1; }
+    return msam_check_launch("msam_attention_backward");
+}

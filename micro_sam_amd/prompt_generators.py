@@ -1,0 +1,116 @@
+"""Prompt generators for training (reference ``micro_sam/prompt_generators.py``): host-side sampling logic, kept as in the
+reference where it is plain torch / numpy; ``PointAndBoxPromptGenerator`` is restated without kornia (absent here): the
+safety border the reference obtains by a binary dilation of the object (``dilation_strength``) is computed with
+``scipy.ndimage.binary_dilation``."""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+
+class PromptGeneratorBase:
+    def __call__(self, segmentation: torch.Tensor, prediction: Optional[torch.Tensor] = None, bbox_coordinates=None,
+                 center_coordinates=None):
+        raise NotImplementedError("PromptGeneratorBase is just a class template.")
+
+
+class PointAndBoxPromptGenerator(PromptGeneratorBase):
+    """Reference :58-250.  One-hot object masks [N, 1, H, W] (+ boxes [y0, x0, y1, x1]) -> point / box prompts.
+    Positive points: the object's centre when given, further ones random inside the object; negative points: random in the
+    bounding box dilated by ``dilation_strength`` outside the (dilated) object."""
+
+    def __init__(self, n_positive_points: int, n_negative_points: int, dilation_strength: int, get_point_prompts: bool = True,
+                 get_box_prompts: bool = False) -> None:
+        self.n_positive_points, self.n_negative_points = n_positive_points, n_negative_points
+        self.dilation_strength = dilation_strength
+        self.get_box_prompts, self.get_point_prompts = get_box_prompts, get_point_prompts
+        if not self.get_point_prompts and not self.get_box_prompts:
+            raise ValueError("You need to request box prompts, point prompts or both.")
+
+    def _sample(self, mask: np.ndarray, n: int) -> List[Tuple[int, int]]:
+        ys, xs = np.where(mask)
+        if len(ys) == 0 or n == 0:
+            return []
+        idx = np.random.choice(len(ys), size=min(n, len(ys)), replace=False)
+        return [(int(ys[i]), int(xs[i])) for i in idx]
+
+    def __call__(self, segmentation: torch.Tensor, bbox_coordinates: List[tuple], center_coordinates: Optional[List] = None,
+                 **kwargs):
+        from scipy import ndimage
+        seg = segmentation.numpy().astype(bool)
+        coords, labels, boxes = [], [], []
+        for i in range(seg.shape[0]):
+            obj = seg[i, 0]
+            y0, x0, y1, x1 = [int(v) for v in bbox_coordinates[i]]
+            if self.get_box_prompts:
+                boxes.append([x0, y0, x1, y1])                                   # SAM expects xyxy
+            if not self.get_point_prompts:
+                continue
+            pts, lab = [], []
+            if self.n_positive_points > 0:
+                if center_coordinates is not None:
+                    cy, cx = center_coordinates[i]
+                    pts.append((int(cy), int(cx)))
+                pts += self._sample(obj, self.n_positive_points - len(pts))
+                lab += [1] * len(pts)
+            if self.n_negative_points > 0:
+                d = self.dilation_strength
+                dil = ndimage.binary_dilation(obj, iterations=d) if d > 0 else obj
+                box = np.zeros_like(obj)
+                box[max(y0 - d, 0): y1 + d, max(x0 - d, 0): x1 + d] = True
+                neg = self._sample(box & ~dil, self.n_negative_points)
+                pts += neg
+                lab += [0] * len(neg)
+            while len(pts) < self.n_positive_points + self.n_negative_points:    # pad (reference _ensure_num_points)
+                extra = self._sample(obj, 1) or [(y0, x0)]
+                pts += extra; lab += [1]
+            coords.append([[x, y] for y, x in pts])                              # SAM expects (x, y)
+            labels.append(lab)
+        point_prompts = torch.tensor(coords, dtype=torch.float32) if self.get_point_prompts else None
+        label_prompts = torch.tensor(labels, dtype=torch.float32) if self.get_point_prompts else None
+        box_prompts = torch.tensor(boxes, dtype=torch.float32) if self.get_box_prompts else None
+        return point_prompts, label_prompts, box_prompts, None
+
+
+class IterativePromptGenerator(PromptGeneratorBase):
+    """Reference :252-377 (2-d): per object one positive point where the prediction misses the object (or, if nothing is
+    missed, where it is already right) and one negative point where it over-segments (or in the object's dilated bounding
+    box, or anywhere in the background)."""
+
+    def _get_positive_points(self, pos_region, overlap_region):
+        locs = [torch.where(r) for r in pos_region]
+        locs = [torch.where(o) if len(l[0]) == 0 else l for l, o in zip(locs, overlap_region)]
+        idx = [np.random.choice(len(l[0])) for l in locs]
+        return [[l[-1][i], l[-2][i]] for l, i in zip(locs, idx)], [1] * len(locs)
+
+    def _get_negative_locations_in_obj_bbox(self, true_object, custom_df=3):
+        loc = torch.where(true_object)
+        bbox = torch.stack([torch.min(loc[1]), torch.min(loc[2]), torch.max(loc[1]) + 1, torch.max(loc[2]) + 1])
+        bbox_mask = torch.zeros_like(true_object).squeeze(0)
+        bbox_mask[max(bbox[0] - custom_df, 0): min(bbox[2] + custom_df, true_object.shape[-2]),
+                  max(bbox[1] - custom_df, 0): min(bbox[3] + custom_df, true_object.shape[-1])] = 1
+        return torch.where(torch.abs(bbox_mask[None].to(true_object.device) - true_object))
+
+    def _get_negative_points(self, neg_region, true_object):
+        locs = [torch.where(r) for r in neg_region]
+        locs = [self._get_negative_locations_in_obj_bbox(t) if len(l[0]) == 0 else l for l, t in zip(locs, true_object)]
+        locs = [torch.where(t == 0) if len(l[0]) == 0 else l for l, t in zip(locs, true_object)]
+        idx = [np.random.choice(len(l[0])) for l in locs]
+        return [[l[-1][i], l[-2][i]] for l, i in zip(locs, idx)], [0] * len(locs)
+
+    def __call__(self, segmentation: torch.Tensor, prediction: torch.Tensor, **kwargs):
+        assert segmentation.shape == prediction.shape, "The segmentation and prediction tensors should have the same shape."
+        if segmentation.ndim != 4:
+            raise ValueError("The segmentation and prediction tensors should have '4' dimensions (NUM_OBJECTS x 1 x H x W).")
+        true_object = segmentation.to(prediction.device)
+        diff = prediction - true_object
+        neg_region = (diff == 1).to(torch.float32)
+        pos_region = diff == -1
+        overlap = torch.logical_and(prediction == 1, true_object == 1).to(torch.float32)
+        pc, pl = self._get_positive_points(pos_region, overlap)
+        nc, nl = self._get_negative_points(neg_region, true_object)
+        pc, nc = torch.tensor(pc)[:, None], torch.tensor(nc)[:, None]
+        pl, nl = torch.tensor(pl)[:, None], torch.tensor(nl)[:, None]
+        return torch.cat([pc, nc], dim=1), torch.cat([pl, nl], dim=1), None, None

@@ -1,0 +1,69 @@
+"""``ConvertToSamInputs`` (reference ``micro_sam/training/util.py:153-288``): data-loader batch -> SAM's batched inputs."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ..prompt_generators import PointAndBoxPromptGenerator
+
+
+def identity(x):
+    return x
+
+
+def _centers_and_boxes(gt: np.ndarray):
+    """Per id: the object pixel closest to its centre of mass and its bounding box [y0, x0, y1, x1) (the reference's
+    ``util.get_centers_and_bounding_boxes(gt, mode="p")`` picks the eccentricity centre through vigra, absent here)."""
+    centers, boxes = {}, {}
+    for i in np.unique(gt)[1:]:
+        ys, xs = np.where(gt == i)
+        cy, cx = ys.mean(), xs.mean()
+        k = int(np.argmin((ys - cy) ** 2 + (xs - cx) ** 2))
+        centers[int(i)] = (int(ys[k]), int(xs[k]))
+        boxes[int(i)] = (int(ys.min()), int(xs.min()), int(ys.max()) + 1, int(xs.max()) + 1)
+    return centers, boxes
+
+
+class ConvertToSamInputs:
+    def __init__(self, transform=None, dilation_strength: int = 10, box_distortion_factor: Optional[float] = None) -> None:
+        self.dilation_strength = dilation_strength
+        self.transform = transform
+        self.box_distortion_factor = box_distortion_factor
+
+    def _distort_boxes(self, bbox_coordinates, shape):
+        out = []
+        for y0, x0, y1, x1 in bbox_coordinates:
+            ly, lx = y1 - y0, x1 - x0
+            f = self.box_distortion_factor
+            out.append([int(round(max(0, y0 - np.random.uniform(0, f) * ly))), int(round(max(0, x0 - np.random.uniform(0, f) * lx))),
+                        int(round(min(shape[0], y1 + np.random.uniform(0, f) * ly))),
+                        int(round(min(shape[1], x1 + np.random.uniform(0, f) * lx)))])
+        return out
+
+    def __call__(self, x, y, n_pos, n_neg, get_boxes=False, n_samples=None):
+        get_points = not (n_pos == 0 and n_neg == 0)
+        gen = PointAndBoxPromptGenerator(n_positive_points=n_pos, n_negative_points=n_neg, dilation_strength=self.dilation_strength,
+                                         get_box_prompts=get_boxes, get_point_prompts=get_points)
+        batched_inputs, batched_ids = [], []
+        for image, gt in zip(x, y):
+            gt = gt.squeeze().numpy().astype(np.int64)
+            centers, boxes = _centers_and_boxes(gt)
+            cell_ids = np.unique(gt)[1:]
+            if n_samples is not None:
+                cell_ids = np.sort(np.random.choice(cell_ids, size=min(n_samples, len(cell_ids)), replace=False))
+            bbox = [boxes[int(i)] for i in cell_ids]
+            if self.box_distortion_factor is not None:
+                bbox = self._distort_boxes(bbox, gt.shape[-2:])
+            one_hot = torch.from_numpy(np.stack([(gt == i) for i in cell_ids])[:, None].astype(np.float32))
+            pts, lbl, bx, _ = gen(one_hot, bbox, [centers[int(i)] for i in cell_ids])
+            rec = {"image": image, "original_size": image.shape[1:]}
+            if get_boxes:
+                rec["boxes"] = bx if self.transform is None else self.transform.apply_boxes_torch(bx, gt.shape[-2:])
+            if get_points:
+                rec["point_coords"] = pts if self.transform is None else self.transform.apply_coords_torch(pts, gt.shape[-2:])
+                rec["point_labels"] = lbl
+            batched_inputs.append(rec)
+            batched_ids.append(cell_ids)
+        return batched_inputs, batched_ids

@@ -435,8 +435,11 @@ def test_cache_amg_state_and_segment_slices(ctx, tmp_path):
     gen_kw = dict(pred_iou_thresh=0.5, stability_score_thresh=0.5)
     amg = precompute_state.cache_amg_state(p, vol, emb, str(tmp_path), verbose=False, i=1, **kw)
     seg = amg.generate(**gen_kw)
-    with open(tmp_path / "amg_state" / "state-1.pkl", "rb") as f:
-        state = pickle.load(f)
+    # the file pickles the crop_list entries under the reference's class path (tests/test_amg_state_pickle.py shows a stock
+    # install reading it); load_amg_state reads it with or without segment_anything
+    raw = (tmp_path / "amg_state" / "state-1.pkl").read_bytes()
+    assert b"segment_anything.utils.amg" in raw and b"micro_sam_amd" not in raw
+    state = precompute_state.load_amg_state(tmp_path / "amg_state" / "state-1.pkl")
     assert set(state) == {"crop_list", "crop_boxes", "original_size"}
     d = state["crop_list"][0]
     assert "rles" in d._stats and "bits" not in d._stats and all(not (torch.is_tensor(v) and v.is_cuda) for v in d._stats.values())

@@ -70,9 +70,11 @@ def test_mask_decoder_forward_matches_predict_torch_and_oracle(ctx, kind, multim
                                 sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=multimask)
     low2, iou2 = sam.decode(ctx["feats"], None if points is None else pts.cuda(), None if points is None else lbl.cuda(),
                             None if bx is None else bx.cuda(), None if mk is None else mk.cuda(), multimask)
-    # same kernels downstream of the token assembly: identical up to the fp32 -> fp32 copy of the sparse tokens
-    assert (low - low2).abs().max().item() <= 1e-3 * low2.abs().max().item() + 1e-4
-    assert (iou - iou2).abs().max().item() <= 1e-4
+    # same kernels downstream of the token assembly.  With a mask prompt the per-prompt source stream is rounded to 16 bits from
+    # emb + dense (module path) vs (emb + no_mask) + (conv - no_mask) (fused path): a few stream values round differently
+    tol = 5e-3 if mk is not None else 1e-3
+    assert (low - low2).abs().max().item() <= tol * low2.abs().max().item() + 1e-4
+    assert (iou - iou2).abs().max().item() <= (1e-3 if mk is not None else 1e-4)
     with torch.no_grad():
         rs, rd = S.prompt_encoder(ctx["sd"], points, bx, mk)
         rl, ri = S.mask_decoder(ctx["sd"], ctx["feats"].cpu(), S.get_dense_pe(ctx["sd"]), rs, rd, multimask, precision="bf16")
