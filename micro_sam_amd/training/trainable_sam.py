@@ -111,6 +111,7 @@ class TrainableSAM(nn.Module):
         super().__init__()
         self.sam = sam
         self.transform = ResizeLongestSide(sam.image_encoder.img_size)
+        self._weights_dirty = False          # parameters changed since the inference kernels' 16-bit copies were made
 
     def preprocess(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
         x = self.transform.apply_image_torch(x)
@@ -141,10 +142,15 @@ class TrainableSAM(nn.Module):
             masks = image_record["mask_inputs"].to(dev, non_blocking=True) if "mask_inputs" in image_record else None
             sparse, dense = self.sam.prompt_encoder(points=points, boxes=boxes, masks=masks)
             if train:
+                self._weights_dirty = True
                 low_res_masks, iou_predictions = mask_decoder_forward(
                     self.sam.mask_decoder, curr_embedding.unsqueeze(0), self.sam.prompt_encoder.get_dense_pe(), sparse, dense,
                     multimask_output)
             else:
+                if self._weights_dirty:          # an optimizer step may have changed the decoder: rebuild the cached copies
+                    self.sam._dec = None
+                    self.sam._img_state = None
+                    self._weights_dirty = False
                 low_res_masks, iou_predictions = self.sam.mask_decoder(
                     image_embeddings=curr_embedding.unsqueeze(0), image_pe=self.sam.prompt_encoder.get_dense_pe(),
                     sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=multimask_output)

@@ -1,0 +1,226 @@
+"""Fine-tuning slice on the GPU (BASELINE configs[3] scaled down): the differentiable HIP primitives
+against torch autograd, the differentiable mask decoder (forward + parameter gradients) against the fp32 oracle, and the
+loss curve of 20 SamTrainer steps against the same training run on the fp32 oracle (same data, seeds, embeddings).
+
+Tolerances: fp32 kernels (LayerNorm, attention) 1e-4 relative; bf16-operand GEMMs (AMP-like) 2e-2 relative on outputs and
+gradients; per-parameter gradient cosine similarity >= 0.99; loss curve |d| <= 2 % + 2e-3 per step."""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def test_linear_forward_backward(dev):
+    from micro_sam_amd.training import functional as HF
+    g = torch.Generator().manual_seed(0)
+    for M, K, N in ((7 * 5, 256, 256), (4096 * 2, 256, 128), (300, 2048, 256), (50, 256, 32), (1000, 64, 128), (5, 256, 4)):
+        x = torch.randn(M, K, generator=g).to(dev).requires_grad_()
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).requires_grad_()
+        b = torch.randn(N, generator=g).to(dev).requires_grad_()
+        y = HF.linear(x, w, b)
+        dy = torch.randn(M, N, generator=g).to(dev)
+        y.backward(dy)
+        xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+        yr = F.linear(xr.to(torch.bfloat16).float(), wr.to(torch.bfloat16).float(), br)
+        yr.backward(dy)
+        assert _rel(y, yr) < 2e-3, (M, K, N)
+        assert _rel(x.grad, xr.grad) < 2e-2 and _rel(w.grad, wr.grad) < 2e-2 and _rel(b.grad, br.grad) < 1e-4, (M, K, N)
+
+
+@pytest.mark.parametrize("dim,eps", [(256, 1e-5), (64, 1e-6)])
+def test_layer_norm_forward_backward(dev, dim, eps):
+    from micro_sam_amd.training import functional as HF
+    g = torch.Generator().manual_seed(dim)
+    x = (torch.randn(3, 1000, dim, generator=g) * 2 + 0.5).to(dev).requires_grad_()
+    w = (torch.randn(dim, generator=g) * 0.2 + 1).to(dev).requires_grad_()
+    b = torch.randn(dim, generator=g).to(dev).requires_grad_()
+    dy = torch.randn(3, 1000, dim, generator=g).to(dev)
+    HF.layer_norm(x, w, b, eps).backward(dy)
+    xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    F.layer_norm(xr, (dim,), wr, br, eps).backward(dy)
+    assert _rel(HF.layer_norm(x, w, b, eps), F.layer_norm(xr, (dim,), wr, br, eps)) < 1e-5
+    assert _rel(x.grad, xr.grad) < 1e-4 and _rel(w.grad, wr.grad) < 1e-4 and _rel(b.grad, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("Nq,Nk,D", [(7, 4096, 16), (4096, 7, 16), (7, 7, 32), (9, 9, 32), (300, 130, 16)])
+def test_attention_forward_backward(dev, Nq, Nk, D):
+    from micro_sam_amd.training import functional as HF
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q = torch.randn(3, 8, Nq, D, generator=g).to(dev).requires_grad_()
+    k = torch.randn(3, 8, Nk, D, generator=g).to(dev).requires_grad_()
+    v = torch.randn(3, 8, Nk, D, generator=g).to(dev).requires_grad_()
+    do = torch.randn(3, 8, Nq, D, generator=g).to(dev)
+    out = HF.attention(q, k, v)
+    out.backward(do)
+    qr, kr, vr = (t.detach().clone().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(qr @ kr.transpose(-1, -2) / D ** 0.5, dim=-1) @ vr
+    ref.backward(do)
+    assert _rel(out, ref) < 1e-4
+    assert _rel(q.grad, qr.grad) < 2e-4 and _rel(k.grad, kr.grad) < 2e-4 and _rel(v.grad, vr.grad) < 2e-4
+
+
+def _setup(dev, n_obj=4, size=256, seed=0):
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_state_dict
+    from micro_sam_amd.training import TrainableSAM
+    sd = synthetic_state_dict("vit_b", 0)
+    predictor = util.get_sam_model("vit_b", device=dev, state_dict=sd)
+    model = TrainableSAM(predictor.model)
+    for n, p in model.sam.named_parameters():
+        p.requires_grad_(n.startswith("mask_decoder."))
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    ys, xs = [], []
+    for b in range(2):
+        y = np.zeros((size, size), dtype=np.int64)
+        img = rng.normal(40, 8, size=(size, size))
+        for k in range(n_obj + 1):
+            cy, cx = 40 + (k // 2) * 70 + rng.integers(0, 20), 50 + (k % 2) * 110 + rng.integers(0, 30)
+            m = (yy - cy) ** 2 + (xx - cx) ** 2 < (14 + 3 * k) ** 2
+            y[m] = k + 1; img[m] = 170 + 10 * k
+        ys.append(y); xs.append(np.clip(img, 0, 255))
+    x = torch.as_tensor(np.stack(xs), dtype=torch.float32)[:, None].repeat(1, 3, 1, 1)
+    y = torch.as_tensor(np.stack(ys))[:, None]
+    return sd, model, x, y
+
+
+class _OracleTrainable(torch.nn.Module):
+    """The fp32 reference model with TrainableSAM's interface: oracle prompt encoder / mask decoder / postprocess on CPU torch
+    autograd; the (frozen) image embeddings are the HIP encoder's."""
+
+    def __init__(self, sd, embeddings, input_size):
+        super().__init__()
+        from micro_sam_amd.transforms import ResizeLongestSide
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.params = torch.nn.ParameterDict()
+        for k in list(self.sd):
+            if k.startswith("mask_decoder."):
+                self.sd[k] = torch.nn.Parameter(self.sd[k])
+                self.params[k.replace(".", "/")] = self.sd[k]
+        self.emb, self.input_size = embeddings, input_size
+        self.transform = ResizeLongestSide(1024)
+
+    def image_embeddings_oft(self, batched_inputs):
+        for b in batched_inputs:
+            b["input_size"] = self.input_size
+        return self.emb, batched_inputs
+
+    def forward(self, batched_inputs, image_embeddings, multimask_output=False):
+        from oracle import sam_ref as S
+        outs = []
+        for rec, emb in zip(batched_inputs, image_embeddings):
+            points = (rec["point_coords"], rec["point_labels"]) if "point_coords" in rec else None
+            sparse, dense = S.prompt_encoder(self.sd, points, rec.get("boxes"), rec.get("mask_inputs"))
+            low, iou = S.mask_decoder(self.sd, emb[None], S.get_dense_pe(self.sd), sparse, dense, multimask_output, precision="fp32")
+            outs.append({"low_res_masks": low, "masks": S.postprocess_masks(low, rec["input_size"], rec["original_size"]),
+                         "iou_predictions": iou})
+        return outs
+
+
+def test_decoder_gradients_match_the_fp32_oracle(dev):
+    from micro_sam_amd.training import ConvertToSamInputs, SamTrainer
+    sd, model, x, y = _setup(dev)
+    np.random.seed(0); random.seed(0); torch.manual_seed(0)
+    conv = ConvertToSamInputs(transform=model.transform)
+    tr = SamTrainer(model, None, conv, n_sub_iteration=1, n_objects_per_batch=4, mask_prob=0.0)
+    bi, ids = conv(x, y, 1, 0, False, 4)
+    bi, y1h = tr._preprocess_batch(bi, y, ids)
+    emb, bi = model.image_embeddings_oft(bi)
+    outs = model(bi, emb, multimask_output=True)
+    loss, ml, il = tr._compute_loss(outs, y1h)
+    loss.backward()
+    ref = _OracleTrainable(sd, emb.cpu(), bi[0]["input_size"])
+    bi_c = [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in b.items()} for b in bi]
+    outs_r = ref(bi_c, emb.cpu(), multimask_output=True)
+    tr_r = SamTrainer(ref, None, conv, n_sub_iteration=1, n_objects_per_batch=4, mask_prob=0.0, device="cpu")
+    loss_r, _, _ = tr_r._compute_loss(outs_r, y1h.cpu())
+    loss_r.backward()
+    lo, lr = outs[0]["low_res_masks"].detach().cpu(), outs_r[0]["low_res_masks"].detach()
+    assert (lo - lr).abs().mean().item() <= 0.01 * (lr.max() - lr.min()).item()
+    assert abs(loss.item() - loss_r.item()) <= 0.02 * abs(loss_r.item()) + 2e-3, (loss.item(), loss_r.item())
+    worst = 1.0
+    for name, p in model.sam.mask_decoder.named_parameters():
+        gr = ref.sd["mask_decoder." + name].grad
+        assert p.grad is not None and gr is not None, name
+        a, b = p.grad.detach().cpu().flatten().double(), gr.flatten().double()
+        if b.norm() < 1e-10:
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos >= 0.99, (name, cos)
+        assert abs(a.norm().item() / b.norm().item() - 1.0) < 0.10, (name, a.norm().item(), b.norm().item())
+    print("worst per-parameter gradient cosine vs fp32 oracle:", worst)
+
+
+def test_loss_curve_of_20_steps_matches_the_fp32_oracle(dev):
+    from micro_sam_amd.training import ConvertToSamInputs, SamTrainer
+    sd, model, x, y = _setup(dev)
+    conv = ConvertToSamInputs(transform=model.transform)
+
+    def run(m, device, make_opt):
+        np.random.seed(3); random.seed(3); torch.manual_seed(3)
+        params = [p for p in m.parameters() if p.requires_grad]
+        tr = SamTrainer(m, make_opt(params), conv, n_sub_iteration=1, n_objects_per_batch=4, mask_prob=0.0, device=device)
+        return [h["loss"] for h in tr.fit(20, [(x, y)])]
+
+    # Plain SGD: the trajectory differs from the fp32 run in proportion to the gradient error (bf16 GEMM operands), so the two
+    # curves can be compared step by step.  (Adam / AdamW - the reference's optimizer - normalises every coordinate's first
+    # updates to +-lr whatever the gradient's magnitude: coordinates whose gradient is at the bf16 noise level move in
+    # different directions and the curves separate by several per cent after two steps although the gradients agree to
+    # cosine >= 0.99 - measured; the AdamW run below is checked for the same descent, not step by step.)
+    def sgd(params):
+        return torch.optim.SGD(params, lr=2e-3)
+
+    def adamw(params):
+        return torch.optim.AdamW(params, lr=1e-4)
+    # the frozen embeddings of the reference run are the HIP encoder's
+    with torch.no_grad():
+        bi, _ = conv(x, y, 1, 0, False, 4)
+        emb, bi = model.image_embeddings_oft(bi)
+    init = copy.deepcopy(model.sam.mask_decoder.state_dict())
+    curve_ref = run(_OracleTrainable(sd, emb.cpu(), bi[0]["input_size"]), "cpu", sgd)
+    curve = run(model, dev, sgd)
+    print("SGD   loss curve HIP   :", [round(v, 4) for v in curve])
+    print("SGD   loss curve oracle:", [round(v, 4) for v in curve_ref])
+    for a, b in zip(curve, curve_ref):
+        assert abs(a - b) <= 0.02 * abs(b) + 2e-3, (curve, curve_ref)
+    assert np.mean(curve[-3:]) < np.mean(curve[:3])
+    model.sam.mask_decoder.load_state_dict(init)
+    curve_ref_a = run(_OracleTrainable(sd, emb.cpu(), bi[0]["input_size"]), "cpu", adamw)
+    curve_a = run(model, dev, adamw)
+    print("AdamW loss curve HIP   :", [round(v, 4) for v in curve_a])
+    print("AdamW loss curve oracle:", [round(v, 4) for v in curve_ref_a])
+    assert abs(curve_a[0] - curve_ref_a[0]) <= 0.02 * curve_ref_a[0] and abs(curve_a[1] - curve_ref_a[1]) <= 0.02 * curve_ref_a[1]
+    assert np.mean(curve_a[-5:]) < 0.85 * np.mean(curve_a[:5]) and np.mean(curve_ref_a[-5:]) < 0.85 * np.mean(curve_ref_a[:5])
+    assert abs(np.mean(curve_a[-5:]) - np.mean(curve_ref_a[-5:])) <= 0.3 * np.mean(curve_ref_a[-5:])
+    # the inference kernels see the trained weights afterwards
+    model.eval()
+    with torch.no_grad():
+        outs = model(bi, emb, multimask_output=True)
+    assert torch.isfinite(outs[0]["masks"]).all()
+
+
+def test_iterative_prompting_with_mask_inputs_runs(dev):
+    from micro_sam_amd.training import ConvertToSamInputs, SamTrainer
+    sd, model, x, y = _setup(dev)
+    np.random.seed(5); random.seed(5); torch.manual_seed(5)
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    tr = SamTrainer(model, opt, ConvertToSamInputs(transform=model.transform), n_sub_iteration=3, n_objects_per_batch=3, mask_prob=1.0)
+    hist = tr.fit(2, [(x, y)])                                            # iteration 0: points + multimask, iteration 1: boxes
+    assert all(np.isfinite(h["loss"]) and 0 < h["loss"] < 3 for h in hist)

@@ -1,0 +1,148 @@
+"""Host-side logic of the fine-tuning slice (CPU): losses, prompt generators, input conversion, the trainer's iterative loss
+with a stub model, and the bucketed gradient all-reduce + the rank-0 mask-input decision under gloo (world size 2)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _disks(n=4, size=96, seed=0):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    y = np.zeros((size, size), dtype=np.int64)
+    for k in range(n):
+        cy, cx = 14 + (k // 2) * 44 + rng.integers(0, 6), 14 + (k % 2) * 44 + rng.integers(0, 6)
+        y[(yy - cy) ** 2 + (xx - cx) ** 2 < 100] = k + 1
+    return y
+
+
+def test_dice_loss_matches_definition():
+    from micro_sam_amd.training.sam_trainer import dice_loss_per_channel
+    g = torch.Generator().manual_seed(0)
+    p, t = torch.rand(1, 3, 8, 9, generator=g), (torch.rand(1, 3, 8, 9, generator=g) > 0.5).float()
+    got = dice_loss_per_channel(p, t)
+    ref = torch.stack([1 - 2 * (p[0, c] * t[0, c]).sum() / ((p[0, c] ** 2).sum() + (t[0, c] ** 2).sum()) for c in range(3)])
+    assert torch.allclose(got, ref, atol=1e-6)
+    assert torch.allclose(dice_loss_per_channel(t, t), torch.zeros(3), atol=1e-6)
+
+
+def test_prompt_generators_and_convert_inputs():
+    from micro_sam_amd.prompt_generators import IterativePromptGenerator
+    from micro_sam_amd.training import ConvertToSamInputs
+    np.random.seed(0)
+    y = _disks()
+    x = torch.zeros(1, 3, 96, 96)
+    conv = ConvertToSamInputs(transform=None)
+    bi, ids = conv(x, torch.as_tensor(y)[None, None], 1, 0, get_boxes=False, n_samples=3)
+    assert len(ids[0]) == 3 and bi[0]["point_coords"].shape == (3, 1, 2) and bi[0]["point_labels"].shape == (3, 1)
+    for k, i in enumerate(ids[0]):                                        # the positive point lies in its object, (x, y) order
+        px, py = bi[0]["point_coords"][k, 0].long().tolist()
+        assert y[py, px] == i
+    bi2, ids2 = conv(x, torch.as_tensor(y)[None, None], 0, 0, get_boxes=True, n_samples=None)
+    assert bi2[0]["boxes"].shape == (4, 4) and "point_coords" not in bi2[0]
+    x0, y0, x1, y1 = bi2[0]["boxes"][0].long().tolist()
+    assert (y[y0:y1, x0:x1] == ids2[0][0]).any() and not (y == ids2[0][0])[:, :x0].any()
+    # iterative prompts: positive where the prediction misses the object, negative where it over-segments
+    true = torch.as_tensor(np.stack([(y == i) for i in (1, 2)])[:, None]).float()
+    pred = true.clone()
+    pred[0, 0, :, :] = 0                                                  # object 0 completely missed
+    pred[1, 0, 0:5, 0:5] = 1                                              # object 1 over-segmented in the corner
+    c, l, _, _ = IterativePromptGenerator()(true, pred)
+    assert c.shape == (2, 2, 2) and l.tolist() == [[1, 0], [1, 0]]
+    assert true[0, 0, c[0, 0, 1], c[0, 0, 0]] == 1                        # positive point inside the missed object
+    assert pred[1, 0, c[1, 1, 1], c[1, 1, 0]] == 1 and true[1, 0, c[1, 1, 1], c[1, 1, 0]] == 0
+
+
+class _StubModel(torch.nn.Module):
+    """A differentiable stand-in with TrainableSAM's interface: masks = scale * (a Gaussian bump at the first prompt point)."""
+
+    def __init__(self):
+        super().__init__()
+        self.scale = torch.nn.Parameter(torch.tensor(1.0))
+        self.bias = torch.nn.Parameter(torch.tensor(-2.0))
+        from micro_sam_amd.transforms import ResizeLongestSide
+        self.transform = ResizeLongestSide(96)
+
+    def image_embeddings_oft(self, batched_inputs):
+        for b in batched_inputs:
+            b["input_size"] = (96, 96)
+        return torch.zeros(len(batched_inputs), 1), batched_inputs
+
+    def forward(self, batched_inputs, image_embeddings, multimask_output=False):
+        outs = []
+        yy, xx = torch.meshgrid(torch.arange(96.0), torch.arange(96.0), indexing="ij")
+        for rec in batched_inputs:
+            n = rec["point_coords"].shape[0] if "point_coords" in rec else rec["boxes"].shape[0]
+            if "point_coords" in rec:
+                cx, cy = rec["point_coords"][:, 0, 0], rec["point_coords"][:, 0, 1]
+            else:
+                cx, cy = rec["boxes"][:, [0, 2]].mean(1), rec["boxes"][:, [1, 3]].mean(1)
+            bump = torch.exp(-((yy[None] - cy[:, None, None]) ** 2 + (xx[None] - cx[:, None, None]) ** 2) / 150.0)
+            c = 3 if multimask_output else 1
+            masks = (self.scale * 6 * bump + self.bias)[:, None].repeat(1, c, 1, 1) * torch.linspace(1.0, 0.8, c)[None, :, None, None]
+            low = torch.nn.functional.interpolate(masks, (256, 256), mode="bilinear")
+            outs.append({"low_res_masks": low, "masks": masks, "iou_predictions": torch.sigmoid(self.bias).expand(n, c) * 0 + 0.5 + 0 * self.scale})
+        return outs
+
+
+def test_trainer_iterative_loss_decreases_with_stub_model():
+    from micro_sam_amd.training import ConvertToSamInputs, SamTrainer
+    np.random.seed(1); torch.manual_seed(1)
+    import random
+    random.seed(1)
+    model = _StubModel()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-2)
+    tr = SamTrainer(model, opt, ConvertToSamInputs(transform=None), n_sub_iteration=3, n_objects_per_batch=3, mask_prob=0.5, device="cpu")
+    y = torch.as_tensor(np.stack([_disks(seed=s) for s in (0, 1)]))[:, None]
+    x = torch.zeros(2, 3, 96, 96)
+    hist = tr.fit(12, [(x, y)])
+    assert len(hist) == 12 and all(np.isfinite(h["loss"]) for h in hist)
+    assert np.mean([h["loss"] for h in hist[-3:]]) < np.mean([h["loss"] for h in hist[:3]])
+    assert [h["iteration"] for h in hist] == list(range(12))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from micro_sam_amd.training.sam_trainer import SamTrainer, all_reduce_gradients
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(5, 7)), torch.nn.Parameter(torch.zeros(300)), torch.nn.Parameter(torch.zeros(3))]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    params[2].grad = None                                                 # a parameter without gradient is skipped
+    nbytes = all_reduce_gradients(params, bucket_bytes=256)               # small buckets: several all-reduces
+    import random
+    random.seed(100 + rank)                                               # ranks would decide differently on their own
+    tr = SamTrainer(torch.nn.Linear(1, 1), None, None, n_sub_iteration=2, mask_prob=0.5, device="cpu")
+    decisions = []
+    for _ in range(6):
+        _, use = tr._use_mask_inputs([{}], torch.zeros(1, 2, 1, 8, 8))
+        decisions.append(bool(use))
+    q.put((rank, [p.grad.clone() if p.grad is not None else None for p in params], nbytes, decisions))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_and_mask_decision_broadcast_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (g, n, d) for r, g, n, d in (q.get(timeout=180) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        g, nbytes, _ = res[r]
+        assert torch.allclose(g[0], torch.full((5, 7), 1.5)) and torch.allclose(g[1], torch.full((300,), 3.0)) and g[2] is None
+        assert nbytes == (35 + 300) * 4                                   # grads all-reduce bytes = 4 * N_trainable
+    assert res[0][2] == res[1][2] and any(res[0][2]) and not all(res[0][2])      # rank 0's decision everywhere
