@@ -177,6 +177,20 @@ int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, do
  * ((x - min) / (max - min + 1e-7)) * 255 in float32, truncated.  workspace: 32 bytes. */
 int msam_to_image(const void* in, int32_t in_dtype, int32_t H, int32_t W, int32_t C, uint8_t* out, void* workspace, void* stream);
 
+/* AutomaticMaskGenerator.generate(output_mode="instance_segmentation") of a single-crop device state in one call
+ * (micro_sam/instance_segmentation.py:99-144,463-530 + util.mask_data_to_segmentation micro_sam/util.py:1773-1848):
+ * threshold / crop-edge filters, greedy box NMS, paint by descending area, connected components, drop the largest component
+ * (with_background) and components below min_object_size, consecutive relabel.  1 <= N <= 4096 candidates: iou / stability
+ * fp32 [N], boxes int32 [N,4] xyxy in the crop frame, area int32 [N], bits uint32 [N, ceil(H/32), W]; crop_box: HOST int32[4]
+ * (x0, y0, x1, y1); labels int32 [H, W]; flag int32 [1] reads 0 when the component labelling converged.  No host
+ * synchronisation; 15 kernels on `stream`. */
+int64_t msam_amg_generate_workspace_bytes(int32_t N, int32_t H, int32_t W);
+int msam_amg_generate_labels(const float* iou, const float* stability, const int32_t* boxes, const int32_t* area,
+                             const uint32_t* bits, int32_t N, int32_t H, int32_t W, const int32_t* crop_box,
+                             float pred_iou_thresh, float stability_score_thresh, float box_nms_thresh,
+                             int32_t min_object_size, int32_t with_background, int32_t* labels, int32_t* flag,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fine-tuning (micro_sam/training/sam_trainer.py:131-425, trainable_sam.py:12-114): backward
  * kernels of the mask decoder's non-GEMM pieces (the GEMMs run msam_gemm_bf16 in both directions: dX = dY W, dW = dY^T X).
  * msam_layernorm_backward: x, dy, dx fp32 [rows, dim] (dim 64 / 128 / 256), dweight / dbias fp32 [dim] ACCUMULATED

@@ -119,6 +119,9 @@ _PROTOS = {
     "msam_layernorm_backward": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "msam_attention_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "msam_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "msam_amg_generate_workspace_bytes": (_i64, [_i32, _i32, _i32]),
+    "msam_amg_generate_labels": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(_i32), _f32, _f32, _f32, _i32, _i32,
+                                        _vp, _vp, _vp, _i64, _vp]),
     "msam_to_image": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "msam_patchify": (_i32, [_vp, _i32, _vp, _vp]),
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

@@ -412,6 +412,12 @@ class AutomaticMaskGenerator(AMGBase):
                                             min_object_size)
         data, crop_box = self.crop_list[0], self.crop_boxes[0]
         orig_h, orig_w = self.original_size
+        if 0 < len(data) <= 4096 and tuple(crop_box) == (0, 0, orig_w, orig_h) and not getattr(self, "_torch_glue_generate", False):
+            # the whole chain as 15 kernels of one library call (csrc/amgselect.hip); the torch-operator formulation below
+            # is kept for states with more than 4096 candidates and as the cross-check of tests/test_gpu_segment.py
+            return ops.amg_generate_labels(data["iou_preds"], data["stability_score"], data["boxes"], data["area"], data["bits"],
+                                           self.original_size, crop_box, pred_iou_thresh, stability_score_thresh, box_nms_thresh,
+                                           min_object_size=min_object_size, with_background=with_background)
         valid = torch.ones_like(data["iou_preds"], dtype=torch.bool)
         if pred_iou_thresh > 0.0:
             valid &= data["iou_preds"] > pred_iou_thresh

@@ -381,6 +381,40 @@ def box_nms_flags(boxes: torch.Tensor, scores: torch.Tensor, valid: torch.Tensor
     return keep
 
 
+_AMG_WS: Dict[Any, torch.Tensor] = {}
+
+
+def amg_generate_labels(iou: torch.Tensor, stability: torch.Tensor, boxes: torch.Tensor, area: torch.Tensor, bits: torch.Tensor,
+                        shape: Tuple[int, int], crop_box, pred_iou_thresh: float, stability_score_thresh: float,
+                        box_nms_thresh: float, min_object_size: int = 0, with_background: bool = True):
+    """``generate(output_mode="instance_segmentation")`` of a single-crop device state in one library call
+    (msam_amg_generate_labels: filters, box NMS, paint, connected components, relabel; N <= 4096 candidates).
+    Returns (labels int32 [H, W], flag int32 [1] that reads 0 when the component labelling converged)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    h, w = int(shape[0]), int(shape[1])
+    n = int(iou.shape[0])
+    dev = iou.device
+    need = int(lib.msam_amg_generate_workspace_bytes(n, h, w))
+    if need <= 0:
+        raise ValueError(f"amg_generate_labels: 1 <= N <= 4096 candidates, got {n}")
+    # one workspace per (device, stream): generate() of tile i runs on a side stream while tile i+1 is decoded
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _AMG_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _AMG_WS[key] = ws
+    labels = torch.empty((h, w), dtype=torch.int32, device=dev)
+    flag = torch.empty((1,), dtype=torch.int32, device=dev)
+    cb = (C.c_int32 * 4)(*[int(v) for v in crop_box])
+    _lib.check(lib.msam_amg_generate_labels(
+        iou.float().contiguous().data_ptr(), stability.float().contiguous().data_ptr(), boxes.to(torch.int32).contiguous().data_ptr(),
+        area.to(torch.int32).contiguous().data_ptr(), bits.contiguous().data_ptr(), n, h, w, cb, float(pred_iou_thresh),
+        float(stability_score_thresh), float(box_nms_thresh), int(min_object_size), int(bool(with_background)),
+        labels.data_ptr(), flag.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "msam_amg_generate_labels")
+    return labels, flag
+
+
 def paint_label_image_dev(bits: torch.Tensor, order: torch.Tensor, k_dev: torch.Tensor, height: int, width: int) -> torch.Tensor:
     """paint_label_image with the mask count taken from device memory (k_dev int32[1]); order int32 [N]."""
     label = torch.empty((height, width), dtype=torch.int32, device=bits.device)

@@ -78,3 +78,44 @@ def test_box_nms_matches_oracle(k):
     for thr in (0.7, 0.3):
         got = ops.box_nms(boxes.cuda(), scores.cuda(), thr).cpu()
         assert got.tolist() == A.nms(boxes, scores, thr).tolist()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(pred_iou_thresh=0.5, stability_score_thresh=0.5, box_nms_thresh=0.9),
+                                dict(pred_iou_thresh=0.0, stability_score_thresh=0.0, min_object_size=40),
+                                dict(pred_iou_thresh=0.6, stability_score_thresh=0.7, with_background=False)])
+def test_fused_generate_matches_the_operator_formulation(kw):
+    """msam_amg_generate_labels (15 kernels, csrc/amgselect.hip) == the torch-operator formulation of generate_device (itself
+    equal to generate() and to the oracle, tests/test_gpu_model.py) on a synthetic single-crop state with ties in scores and
+    areas, boxes near the image border, empty masks (stability 0 / 0 = NaN) and tiny components."""
+    _gpu()
+    from micro_sam_amd._vendored import pack_bits
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator, DeviceMaskData
+    rng = np.random.default_rng(7)
+    n, h, w = 600, 256, 320
+    masks = np.zeros((n, h, w), dtype=bool)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for i in range(n):
+        if i % 37 == 0:
+            continue                                                     # empty mask
+        cy, cx, r = rng.integers(0, h), rng.integers(0, w), rng.integers(2, 30)
+        masks[i] = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        if i % 5 == 0:
+            masks[i, rng.integers(0, h), rng.integers(0, w)] = True      # stray pixel: extra component
+    m = torch.as_tensor(masks).cuda()
+    area = m.flatten(1).sum(1).to(torch.int32)
+    from micro_sam_amd._vendored import batched_mask_to_box
+    data = DeviceMaskData(mask_size=(h, w), full_size=(h, w),
+                          iou_preds=torch.as_tensor(rng.integers(40, 100, size=n).astype(np.float32) / 100).cuda(),   # many ties
+                          points=torch.zeros(n, 2))
+    num = (area.float() * torch.as_tensor(rng.integers(80, 101, size=n).astype(np.float32) / 100).cuda()).round()
+    data["stability_score"] = num / area.float()                         # NaN for the empty masks
+    data["boxes"] = batched_mask_to_box(m).to(torch.int32)
+    data["area"] = area
+    data["bits"] = pack_bits(m)
+    amg = AutomaticMaskGenerator.__new__(AutomaticMaskGenerator)
+    amg._is_initialized, amg._crop_list, amg._crop_boxes, amg._original_size = True, [data], [[0, 0, w, h]], (h, w)
+    lab_f, flag_f = amg.generate_device(**kw)
+    amg._torch_glue_generate = True
+    lab_t, flag_t = amg.generate_device(**kw)
+    assert int(flag_f.item()) == 0 and int(flag_t.item()) == 0
+    assert lab_f.dtype == torch.int32 and torch.equal(lab_f, lab_t) and int(lab_f.max().item()) > 10
