@@ -177,6 +177,15 @@ int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, do
  * ((x - min) / (max - min + 1e-7)) * 255 in float32, truncated.  workspace: 32 bytes. */
 int msam_to_image(const void* in, int32_t in_dtype, int32_t H, int32_t W, int32_t C, uint8_t* out, void* workspace, void* stream);
 
+/* Greedy mask NMS (micro_sam/util.py:1589-1668 `_batched_mask_nms`): masks as bit masks uint32
+ * [K, ceil(H/32), W], order int32 [K] = mask indices by descending score, boxes fp32 [K,4] xyxy and area int32 [K] indexed by
+ * mask.  Pairs whose boxes share no area never suppress; overlap = intersection / union, or intersection / (min area + 1e-6)
+ * with intersection_over_min; a mask is dropped when its overlap with a kept, higher-scored mask is > thresh.
+ * keep_flags int32 [K] in sorted order; mask_scratch: K * ceil(K/64) uint64. */
+int msam_mask_nms(const uint32_t* bits, const int32_t* order, const float* boxes, const int32_t* area, int32_t K, int32_t H,
+                  int32_t W, float thresh, int32_t intersection_over_min, uint64_t* mask_scratch, int32_t* keep_flags,
+                  void* stream);
+
 /* AutomaticMaskGenerator.generate(output_mode="instance_segmentation") of a single-crop device state in one call
  * (micro_sam/instance_segmentation.py:99-144,463-530 + util.mask_data_to_segmentation micro_sam/util.py:1773-1848):
  * threshold / crop-edge filters, greedy box NMS, paint by descending area, connected components, drop the largest component

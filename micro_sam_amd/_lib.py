@@ -152,6 +152,7 @@ _PROTOS = {
     "msam_postprocess_masks": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "msam_rle_run_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_rle_encode": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "msam_mask_nms": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "msam_box_nms": (_i32, [_vp, _i32, _f32, _vp, _vp, _vp]),
     "msam_box_nms_valid": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "msam_paint_label_image_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),

@@ -222,6 +222,45 @@ __global__ __launch_bounds__(256) void nms_sweep64_kernel(const unsigned long lo
     }
 }
 
+// ---- mask NMS (micro_sam/util.py:1589-1668 _batched_mask_nms: IoU or intersection-over-min matrix of full-size masks +
+// greedy suppression).  The reference multiplies the flattened masks (masks_flat @ masks_flat.T);
+// on bit masks the same intersection is a popcount of AND over the overlap window of the two boxes - integer exact, no
+// GEMM.  One workgroup per pair (i < j) of SCORE-SORTED masks writes bit j of row i of the suppression matrix that the
+// box-NMS sweep kernels consume.
+__global__ __launch_bounds__(256) void mask_nms_matrix_kernel(const uint32_t* __restrict__ bits, const int* __restrict__ order,
+                                                              const float* __restrict__ boxes, const int* __restrict__ area,
+                                                              int K, int H, int W, float thr, int iomin,
+                                                              unsigned long long* __restrict__ mask) {
+    const int i = blockIdx.y, j = blockIdx.x;
+    if (j <= i || j >= K) return;
+    const int a = order[i], b = order[j];
+    // _overlap_matrix: the boxes share a region of positive area (float arithmetic on the xyxy boxes as given)
+    const float x1 = fmaxf(boxes[a * 4], boxes[b * 4]), y1 = fmaxf(boxes[a * 4 + 1], boxes[b * 4 + 1]);
+    const float x2 = fminf(boxes[a * 4 + 2], boxes[b * 4 + 2]), y2 = fminf(boxes[a * 4 + 3], boxes[b * 4 + 3]);
+    if (!(fmaxf(x2 - x1, 0.f) * fmaxf(y2 - y1, 0.f) > 0.f)) return;
+    // intersection over the window of the two boxes (everything outside it is 0 in at least one mask when the boxes are the
+    // masks' bounding boxes; the window is widened by one pixel against inclusive / exclusive box conventions)
+    const int wpc = (H + 31) >> 5;
+    const int cx0 = max(0, (int)floorf(x1) - 1), cx1 = min(W, (int)ceilf(x2) + 2);
+    const int wy0 = max(0, ((int)floorf(y1) - 1) >> 5), wy1 = min(wpc, (((int)ceilf(y2) + 1) >> 5) + 1);
+    const int ncol = cx1 - cx0, nrow = wy1 - wy0;
+    int cnt = 0;
+    for (int t = threadIdx.x; t < ncol * nrow; t += 256) {
+        const int wy = wy0 + t / ncol, x = cx0 + t % ncol;
+        cnt += __popc(bits[((long)a * wpc + wy) * W + x] & bits[((long)b * wpc + wy) * W + x]);
+    }
+    __shared__ int red[4];
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float inter = (float)(red[0] + red[1] + red[2] + red[3]);
+        const float aa = (float)area[a], ab = (float)area[b];
+        const float v = iomin ? __fdiv_rn(inter, __fadd_rn(fminf(aa, ab), 1e-6f)) : __fdiv_rn(inter, __fsub_rn(__fadd_rn(aa, ab), inter));
+        if (v > thr) atomicOr(&mask[(long)i * ((K + 63) >> 6) + (j >> 6)], 1ull << (j & 63));
+    }
+}
+
 }  // namespace
 
 extern "C" int msam_box_nms_valid(const float* boxes_sorted, const int32_t* valid_sorted, int32_t K, float iou_threshold,
@@ -315,4 +354,29 @@ extern "C" int msam_label_components(const int32_t* seg, int32_t H, int32_t W, i
     }
     if (iters_done) *iters_done = it;
     return msam_check_launch("msam_label_components");
+}
+
+// Greedy mask NMS: bits uint32 [K, ceil(H/32), W], order int32 [K] (descending score), boxes fp32 [K,4] xyxy and area int32 [K]
+// indexed by MASK (not by sorted position); keep_flags int32 [K] in sorted order.  mask_scratch: K * ceil(K/64) uint64.
+extern "C" int msam_mask_nms(const uint32_t* bits, const int32_t* order, const float* boxes, const int32_t* area, int32_t K,
+                             int32_t H, int32_t W, float thresh, int32_t intersection_over_min, uint64_t* mask_scratch,
+                             int32_t* keep_flags, void* stream) {
+    if (K < 0 || (K > 0 && (!bits || !order || !boxes || !area || !mask_scratch || !keep_flags)) || H <= 0 || W <= 0) {
+        msam_set_error("msam_mask_nms: bad arguments");
+        return 1;
+    }
+    if (K == 0) return 0;
+    if (K > 32768) { msam_set_error("msam_mask_nms: at most 32768 masks"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (K + 63) / 64;
+    if (hipMemsetAsync(mask_scratch, 0, (size_t)K * nblk * 8, s) != hipSuccess) { msam_set_error("msam_mask_nms: memset failed"); return 2; }
+    hipLaunchKernelGGL(mask_nms_matrix_kernel, dim3(K, K), dim3(256), 0, s, bits, order, boxes, area, K, H, W, thresh,
+                       intersection_over_min, (unsigned long long*)mask_scratch);
+    if (nblk <= 64)
+        hipLaunchKernelGGL(nms_sweep64_kernel, dim3(1), dim3(256), (64 + nblk * 64 + 256) * 8, s,
+                           (const unsigned long long*)mask_scratch, K, (const int*)nullptr, keep_flags);
+    else
+        hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K,
+                           (const int*)nullptr, keep_flags);
+    return msam_check_launch("msam_mask_nms");
 }

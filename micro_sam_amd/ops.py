@@ -325,6 +325,27 @@ def box_nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> 
     return order[keep.bool()]
 
 
+def mask_nms(bits: torch.Tensor, boxes_xyxy: torch.Tensor, areas: torch.Tensor, scores: torch.Tensor, thresh: float,
+             height: int, intersection_over_min: bool = False) -> torch.Tensor:
+    """Greedy mask NMS on bit masks [K, ceil(H/32), W] (msam_mask_nms; reference ``util._batched_mask_nms``): returns the kept
+    mask indices in descending score order (stable order for equal scores)."""
+    _lib.require_gpu()
+    k = int(bits.shape[0])
+    if k == 0:
+        return torch.zeros((0,), dtype=torch.int64, device=bits.device)
+    dev = bits.device
+    order = torch.sort(scores.to(dev).float(), descending=True, stable=True).indices
+    order32 = order.to(torch.int32).contiguous()
+    nblk = (k + 63) // 64
+    scratch = torch.empty((k * nblk,), dtype=torch.int64, device=dev)
+    keep_sorted = torch.empty((k,), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().msam_mask_nms(bits.contiguous().data_ptr(), order32.data_ptr(), boxes_xyxy.to(dev).float().contiguous().data_ptr(),
+                                         areas.to(dev).to(torch.int32).contiguous().data_ptr(), k, int(height), int(bits.shape[2]),
+                                         float(thresh), int(bool(intersection_over_min)), scratch.data_ptr(), keep_sorted.data_ptr(),
+                                         _lib.stream_ptr()), "msam_mask_nms")
+    return order[keep_sorted.bool()]
+
+
 def wsgemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, table: Optional[torch.Tensor] = None,
            table_cols: int = 0, resid: Optional[torch.Tensor] = None, resid_rows: int = 0, ln_mode: int = 0,
            ln_w: Optional[torch.Tensor] = None, ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,

@@ -688,6 +688,54 @@ def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape: Optional[Tuple
 
 
 @torch.no_grad()
+def apply_nms(predictions: List[Dict[str, Any]], min_size: int, shape: Optional[Tuple[int, int]] = None,
+              perform_box_nms: bool = False, nms_thresh: float = 0.9, max_size: Optional[int] = None,
+              intersection_over_min: bool = False) -> np.ndarray:
+    """Reference ``util.apply_nms`` (micro_sam/util.py:1851-1957) for full-image predictions (records with a dense
+    ``segmentation``, ``bbox`` xywh, ``predicted_iou``, ``stability_score``): size filters, NMS on
+    score = predicted_iou * stability_score - box NMS (``msam_box_nms``) or mask NMS on IoU / intersection-over-min
+    (``msam_mask_nms``: popcount of AND over bit masks instead of the reference's ``masks_flat @ masks_flat.T``) - and merge
+    of the survivors to a label image.  Tile-local predictions (``global_bbox``: ``_batched_tiled_mask_nms``) are not
+    provided."""
+    from . import ops
+    from ._vendored import pack_bits
+    if len(predictions) == 0:
+        return np.zeros(shape, dtype="uint32")
+    if "global_bbox" in predictions[0]:
+        raise NotImplementedError("micro_sam_amd.apply_nms: tile-local predictions (global_bbox) are not provided")
+    if perform_box_nms and intersection_over_min:
+        raise ValueError("intersection_over_min needs mask NMS (perform_box_nms=False)")
+
+    def dense(p):
+        m = p["segmentation"]
+        return m.cpu().numpy() if torch.is_tensor(m) else np.asarray(m)
+    preds = [dict(p, area=int(dense(p).sum())) for p in predictions]
+    if shape is None:
+        shape = dense(predictions[0]).shape
+    if min_size > 0:
+        preds = [p for p in preds if p["area"] > min_size]
+    if max_size is not None:
+        preds = [p for p in preds if p["area"] < max_size]
+    if not preds:
+        return np.zeros(shape, dtype="uint32")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    scores = torch.tensor([float(np.float32(p["predicted_iou"]) * np.float32(p["stability_score"])) for p in preds],
+                          dtype=torch.float32, device=dev)
+    xyxy = torch.tensor([p["bbox"] for p in preds], dtype=torch.float32, device=dev)
+    xyxy[:, 2] += xyxy[:, 0]
+    xyxy[:, 3] += xyxy[:, 1]
+    if perform_box_nms:
+        keep = ops.box_nms(xyxy, scores, nms_thresh)
+    else:
+        areas = torch.tensor([p["area"] for p in preds], dtype=torch.int32, device=dev)
+        bits = torch.cat([pack_bits(torch.as_tensor(np.stack([dense(p) for p in preds[s:s + 64]]).astype(bool), device=dev))
+                          for s in range(0, len(preds), 64)])
+        keep = ops.mask_nms(bits, xyxy, areas, scores, nms_thresh, shape[0], intersection_over_min)
+    kept = [preds[int(i)] for i in keep.cpu().tolist()]
+    records = [{k: p[k] for k in ("segmentation", "area", "bbox")} for p in kept]
+    return mask_data_to_segmentation(records, shape=shape, min_object_size=min_size)
+
+
 def mask_data_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, shape: Tuple[int, int],
                                      min_object_size: int = 0, with_background: bool = False) -> np.ndarray:
     """``mask_data_to_segmentation(..., label_masks=True, merge_exclusively=False)`` (reference util.py:1773-1848) computed

@@ -119,3 +119,41 @@ def test_fused_generate_matches_the_operator_formulation(kw):
     lab_t, flag_t = amg.generate_device(**kw)
     assert int(flag_f.item()) == 0 and int(flag_t.item()) == 0
     assert lab_f.dtype == torch.int32 and torch.equal(lab_f, lab_t) and int(lab_f.max().item()) > 10
+
+
+@pytest.mark.parametrize("mode", ["iou", "iomin", "box"])
+def test_apply_nms_matches_oracle(mode):
+    """util.apply_nms (reference micro_sam/util.py:1851-1957) with the device mask NMS (popcount of AND
+    over bit masks) == the oracle's restatement (dense float matrix products), keep set and label image."""
+    _gpu()
+    from micro_sam_amd import util
+    from oracle import amg_ref as A
+    rng = np.random.default_rng(11)
+    h, w = 200, 260
+    yy, xx = np.mgrid[0:h, 0:w]
+    preds = []
+    for i in range(90):
+        cy, cx = rng.integers(10, h - 10), rng.integers(10, w - 10)
+        if i % 3 == 1 and preds:                                          # near-duplicate of an earlier mask (suppressed by NMS)
+            q = preds[rng.integers(0, len(preds))]
+            m = np.roll(q["segmentation"], (int(rng.integers(-2, 3)), int(rng.integers(-2, 3))), axis=(0, 1))
+        elif i % 3 == 2 and preds:                                        # small mask inside an earlier one (IoMin ~ 1, IoU small)
+            q = preds[rng.integers(0, len(preds))]
+            ys, xs = np.where(q["segmentation"])
+            k = rng.integers(0, len(ys))
+            m = ((yy - ys[k]) ** 2 + (xx - xs[k]) ** 2 < 9) & q["segmentation"]
+        else:
+            r = rng.integers(4, 26)
+            m = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        if m.sum() == 0:
+            continue
+        ys, xs = np.where(m)
+        preds.append({"segmentation": m, "bbox": [int(xs.min()), int(ys.min()), int(xs.max() - xs.min()), int(ys.max() - ys.min())],
+                      "predicted_iou": float(rng.integers(50, 100)) / 100, "stability_score": float(rng.integers(80, 100)) / 100})
+    kw = dict(min_size=5, nms_thresh=0.6 if mode != "iomin" else 0.8, perform_box_nms=(mode == "box"),
+              intersection_over_min=(mode == "iomin"))
+    got = util.apply_nms([dict(p) for p in preds], **kw)
+    ref = A.apply_nms([dict(p) for p in preds], **kw)
+    assert got.shape == (h, w) and got.dtype == np.uint32 and got.max() > 5
+    assert np.array_equal(got, ref)
+    assert np.array_equal(util.apply_nms([dict(p) for p in preds], max_size=400, **kw), A.apply_nms([dict(p) for p in preds], max_size=400, **kw))
