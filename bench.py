@@ -443,6 +443,7 @@ def main():
                                     "input_size": (1024, 1024), "original_size": (1024, 1024)}, i=0)
         from micro_sam_amd import ops
         bits = amg.crop_list[0]["bits"]
+        ops.rle_encode(bits.contiguous(), 1024, 1024)               # first call: loads the RLE kernels' code object
         torch.cuda.synchronize(); t_r = time.perf_counter()
         counts, offsets = ops.rle_encode(bits.contiguous(), 1024, 1024)
         torch.cuda.synchronize()
