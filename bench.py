@@ -162,7 +162,7 @@ def main():
                     help="fp8: BASELINE config 5 (encoder projections on fp8 e4m3 MX MFMA, bf16 decoder); NOT the headline metric")
     ap.add_argument("--weights", choices=("cells", "blobs", "field"), default="cells",
                     help="synthetic checkpoint variant (micro_sam_amd/synthetic.py)")
-    ap.add_argument("--lanes", type=int, default=1,
+    ap.add_argument("--lanes", type=int, default=3,
                     help="tiles are decoded round-robin on this many HIP streams (each with its own predictor state and "
                          "decoder workspace): the latency-bound token-side launches of one tile run underneath the "
                          "streaming kernels of another")
@@ -343,7 +343,12 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     lib.msam_profile_enable(0)
-    step(True, 0)            # one extra instrumented pass (outside the timed region) for the stage breakdown
+    serial_labels = step(True, 0).clone()     # one extra instrumented pass (outside the timed region): stage breakdown, and
+    pipelined_labels = step(False, 0)         # the serial result that the pipelined (lanes / side stream) step must reproduce
+    torch.cuda.synchronize()
+    labels_equal = bool(torch.equal(serial_labels, pipelined_labels))
+    if not labels_equal:
+        raise RuntimeError("bench.py: the pipelined step (lanes / side-stream generate) does not reproduce the serial labels")
     # PCIe-inclusive pass (outside the timed region): util._to_image + H2D of the uint8 tiles + label D2H inside the clock
     torch.cuda.synchronize()
     t_p = time.perf_counter()
@@ -427,6 +432,7 @@ def main():
                        "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
                        "timed_region": "uint8 RGB tiles resident in HBM -> label tiles in HBM (all-gathered when N > 1); "
                                        "util._to_image, H2D and label D2H are in pcie_inclusive, lazy RLE encoding in rle_side",
+                       "decode_lanes": len(lanes), "pipelined_labels_equal_serial": labels_equal,
                        "instances_per_tile": {"median": int(np.median(n_instances)), "min": int(min(n_instances)),
                                               "max": int(max(n_instances))},
                        "stage_seconds_per_tile_synced_pass": {k: round(v / n_tiles, 5) for k, v in stage.items()

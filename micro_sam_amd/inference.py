@@ -182,3 +182,127 @@ def _records_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, sha
     new_id = torch.cumsum(is_root.to(torch.int64), 0)
     labels = torch.where(fg, new_id[roots.clamp(min=0)], torch.zeros_like(roots))
     return labels.reshape(h, w).to(torch.int32).cpu().numpy().astype("uint32")
+
+
+def _require_tiled_embeddings(predictor, image, image_embeddings, embedding_path, tile_shape, halo, verbose_embeddings):
+    """Reference inference.py:288-311."""
+    if image_embeddings is None:
+        assert image is not None
+        assert (tile_shape is not None) and (halo is not None)
+        shape = image.shape[:2]
+        image_embeddings = util.precompute_image_embeddings(predictor, image, embedding_path, ndim=2, tile_shape=tile_shape,
+                                                            halo=halo, verbose=verbose_embeddings)
+    else:
+        attrs = image_embeddings["features"].attrs
+        tile_shape_, halo_ = attrs["tile_shape"], attrs["halo"]
+        shape = attrs["shape"]
+        if tile_shape is None:
+            tile_shape = tile_shape_
+        elif any(ts != ts_ for ts, ts_ in zip(tile_shape, tile_shape_)):
+            raise ValueError(f"Incompatible tile shapes: {tile_shape} != {tile_shape_}")
+        if halo is None:
+            halo = halo_
+        elif any(ts != ts_ for ts, ts_ in zip(halo, halo_)):
+            raise ValueError(f"Incompatible tile shapes: {halo} != {halo_}")
+    return image_embeddings, tuple(shape), tuple(tile_shape), tuple(halo)
+
+
+def _merge_segmentations(this_seg, prev_seg, overlap_threshold=0.75):
+    """Reference inference.py:314-332: first come, first served - the earlier tiles' labels are preserved.  (The reference also
+    collects the new ids that overlap earlier ones by more than ``overlap_threshold`` but never uses that list.)"""
+    captured = prev_seg != 0
+    this_seg[captured] = prev_seg[captured]
+    return this_seg
+
+
+def _stitch_segmentation(masks, tile_ids, tiling, halo, output_shape):
+    """Reference inference.py:338-355."""
+    segmentation = np.zeros(output_shape, dtype="uint32")
+    for tile_id, this_seg in zip(tile_ids, masks):
+        tile = tiling.get_block_with_halo(tile_id, list(halo)).outer_block
+        bb = tuple(slice(b, e) for b, e in zip(tile.begin, tile.end))
+        if tile_id == 0:
+            segmentation[bb] = this_seg
+        else:
+            prev_seg = segmentation[bb]
+            assert prev_seg.shape == this_seg.shape, f"{tile_id}: {prev_seg.shape}, {this_seg.shape}"
+            segmentation[bb] = _merge_segmentations(this_seg, prev_seg)
+    return segmentation
+
+
+@torch.no_grad()
+def batched_tiled_inference(predictor: SamPredictor, image: Optional[np.ndarray], batch_size: int, image_embeddings=None,
+                            boxes: Optional[np.ndarray] = None, points: Optional[np.ndarray] = None,
+                            point_labels: Optional[np.ndarray] = None, multimasking: bool = False, embedding_path=None,
+                            return_instance_segmentation: bool = True, reduce_multimasking: bool = True,
+                            logits_masks: Optional[torch.Tensor] = None, verbose_embeddings: bool = True,
+                            mask_threshold: Optional[Union[float, str]] = None, tile_shape=None, halo=None,
+                            optimize_memory: bool = False, i: Optional[int] = None, **nms_kwargs):
+    """Reference ``inference.batched_tiled_inference`` (micro_sam/inference.py:358-538): prompts are assigned to the tile that
+    contains their centre, every tile runs ``batched_inference`` on its own embedding, the per-tile records are merged through
+    their ``global_bbox`` (or, with ``optimize_memory``, reduced per tile by ``util.apply_nms`` and stitched)."""
+    from .tiling import Blocking
+    segmentation_ids = None
+    n_prompts, have_boxes, have_points, have_logits = _validate_inputs(
+        boxes, points, point_labels, multimasking, return_instance_segmentation, segmentation_ids, logits_masks)
+    if have_logits:
+        raise NotImplementedError
+    image_embeddings, shape, tile_shape, halo = _require_tiled_embeddings(
+        predictor, image, image_embeddings, embedding_path, tile_shape, halo, verbose_embeddings)
+    tiling = Blocking([0, 0], shape, tile_shape)
+    box_to_tile, point_to_tile, label_to_tile = {}, {}, {}
+    tile_ids = []
+    for prompt_id in range(n_prompts):
+        this_tile_id = None
+        if have_boxes:
+            box = boxes[prompt_id]
+            center = np.array([(box[1] + box[3]) / 2, (box[0] + box[2]) / 2]).round().astype("int").tolist()
+            this_tile_id = tiling.coordinates_to_block_id(center)
+            tile = tiling.get_block_with_halo(this_tile_id, list(halo)).outer_block
+            offset, this_tile_shape = tile.begin, tile.shape
+            box_in_tile = np.array([max(box[1] - offset[0], 0), max(box[0] - offset[1], 0),
+                                    min(box[3] - offset[0], this_tile_shape[0]), min(box[2] - offset[1], this_tile_shape[1])])[None]
+            # (the reference stores the tile-local box in [MIN_Y, MIN_X, MAX_Y, MAX_X] order and hands it to batched_inference,
+            # which reads boxes as [MIN_X, MIN_Y, MAX_X, MAX_Y]: mirrored as is)
+            box_to_tile[this_tile_id] = np.concatenate([box_to_tile[this_tile_id], box_in_tile]) if this_tile_id in box_to_tile \
+                else box_in_tile
+        if have_points:
+            point = points[prompt_id, 0][::-1].round().astype("int").tolist()
+            if this_tile_id is None:
+                this_tile_id = tiling.coordinates_to_block_id(point)
+            else:
+                assert this_tile_id == tiling.coordinates_to_block_id(point)
+            tile = tiling.get_block_with_halo(this_tile_id, list(halo)).outer_block
+            point_in_tile = (points[prompt_id, 0] - np.array(tile.begin)[::-1])[None, None]
+            label_in_tile = point_labels[prompt_id][None]
+            if this_tile_id in point_to_tile:
+                point_to_tile[this_tile_id] = np.concatenate([point_to_tile[this_tile_id], point_in_tile])
+                label_to_tile[this_tile_id] = np.concatenate([label_to_tile[this_tile_id], label_in_tile])
+            else:
+                point_to_tile[this_tile_id], label_to_tile[this_tile_id] = point_in_tile, label_in_tile
+        tile_ids.append(this_tile_id)
+    tile_ids = sorted(list(set(tile_ids)))
+    masks = []
+    id_offset = 0
+    for tile_id in tile_ids:
+        util.set_precomputed(predictor, image_embeddings, tile_id=tile_id, i=i)
+        this_masks = batched_inference(
+            predictor=predictor, image=None, batch_size=batch_size, boxes=box_to_tile.get(tile_id),
+            points=point_to_tile.get(tile_id), point_labels=label_to_tile.get(tile_id), multimasking=multimasking,
+            return_instance_segmentation=False, segmentation_ids=segmentation_ids, reduce_multimasking=reduce_multimasking,
+            logits_masks=None, mask_threshold=mask_threshold)
+        if optimize_memory:
+            segmentation = util.apply_nms(this_masks, **nms_kwargs)
+            fg_mask = segmentation != 0
+            segmentation[fg_mask] += id_offset
+            id_offset = segmentation.max()
+            masks.append(segmentation)
+        else:
+            tile = tiling.get_block_with_halo(tile_id, list(halo)).outer_block
+            offset = np.array(tile.begin[::-1] + [0, 0])
+            masks.extend([{**mask, "global_bbox": (np.array(mask["bbox"]) + offset).tolist()} for mask in this_masks])
+    if optimize_memory:
+        return _stitch_segmentation(masks, tile_ids, tiling, halo, output_shape=shape)
+    if return_instance_segmentation:
+        masks = util.mask_data_to_segmentation(masks, shape=shape, min_object_size=0)
+    return masks

@@ -56,6 +56,14 @@ class Blocking:
             block_id //= n
         return coords[::-1]
 
+    def coordinates_to_block_id(self, coordinates: Sequence[int]) -> int:
+        """Id of the block that contains the point (bioimage_cpp ``Blocking.coordinates_to_block_id``; reference call sites
+        micro_sam/inference.py:463,480); coordinates outside the roi are clamped to the border blocks."""
+        block_id = 0
+        for c, rb, bs, n in zip(coordinates, self.roi_begin, self.block_shape, self.blocks_per_axis):
+            block_id = block_id * n + min(max((int(c) - rb) // bs, 0), n - 1)
+        return int(block_id)
+
     def get_block(self, block_id: int) -> Block:
         c = self._coords(int(block_id))
         begin = [rb + ci * bs for rb, ci, bs in zip(self.roi_begin, c, self.block_shape)]

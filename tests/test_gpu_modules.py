@@ -91,3 +91,44 @@ def test_mask_decoder_rejects_foreign_pe(ctx):
     dense = sam.prompt_encoder.no_mask_embed.weight.detach().reshape(1, -1, 1, 1).expand(1, -1, 64, 64)
     with pytest.raises(NotImplementedError):
         sam.mask_decoder(ctx["feats"], torch.zeros(1, 256, 64, 64, device="cuda"), sparse, dense, True)
+
+
+def test_batched_tiled_inference(vit_b_sd):
+    """inference.batched_tiled_inference (reference micro_sam/inference.py:358-538): one tile == batched_inference on the image;
+    2 x 2 tiles == the per-tile batched_inference records placed by their global_bbox; optimize_memory stitches per-tile NMS."""
+    from micro_sam_amd import inference, util
+    from micro_sam_amd.synthetic import synthetic_tile
+    p = util.get_sam_model("vit_b", device="cuda", state_dict=vit_b_sd)
+    image = synthetic_tile(31, (1024, 1024))
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(40, 980, size=12), rng.uniform(40, 980, size=12)], axis=1)[:, None, :]       # [N,1,2] (x, y)
+    lbl = np.ones((12, 1))
+    one = inference.batched_tiled_inference(p, image, 8, points=pts, point_labels=lbl, tile_shape=(1024, 1024), halo=(0, 0),
+                                            verbose_embeddings=False)
+    ref = inference.batched_inference(p, image, 8, points=pts, point_labels=lbl, verbose_embeddings=False)
+    assert one.shape == (1024, 1024) and np.array_equal(one, ref)
+    # 2 x 2 tiles with a halo: every prompt is decoded on the tile that contains it
+    emb = util.precompute_image_embeddings(p, image, tile_shape=(512, 512), halo=(64, 64), verbose=False)
+    recs = inference.batched_tiled_inference(p, None, 8, image_embeddings=emb, points=pts, point_labels=lbl,
+                                             return_instance_segmentation=False)
+    assert len(recs) == 12 and all("global_bbox" in r for r in recs)
+    from micro_sam_amd.tiling import Blocking
+    tiling = Blocking([0, 0], (1024, 1024), (512, 512))
+    by_tile = {}
+    for k in range(12):
+        by_tile.setdefault(tiling.coordinates_to_block_id([int(round(pts[k, 0, 1])), int(round(pts[k, 0, 0]))]), []).append(k)
+    n = 0
+    for tile_id in sorted(by_tile):
+        outer = tiling.get_block_with_halo(tile_id, [64, 64]).outer_block
+        util.set_precomputed(p, emb, tile_id=tile_id)
+        local = pts[by_tile[tile_id]] - np.array(outer.begin)[::-1]
+        exp = inference.batched_inference(p, None, 8, points=local, point_labels=lbl[by_tile[tile_id]], return_instance_segmentation=False)
+        for e in exp:
+            r = recs[n]; n += 1
+            assert torch.equal(torch.as_tensor(r["segmentation"]), torch.as_tensor(e["segmentation"])) and r["bbox"] == e["bbox"]
+            assert r["global_bbox"] == [e["bbox"][0] + outer.begin[1], e["bbox"][1] + outer.begin[0], e["bbox"][2], e["bbox"][3]]
+    seg = inference.batched_tiled_inference(p, None, 8, image_embeddings=emb, points=pts, point_labels=lbl)
+    assert seg.shape == (1024, 1024) and seg.max() >= 1
+    seg2 = inference.batched_tiled_inference(p, None, 8, image_embeddings=emb, points=pts, point_labels=lbl, optimize_memory=True,
+                                             min_size=0)
+    assert seg2.shape == (1024, 1024) and seg2.max() >= 1
