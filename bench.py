@@ -455,6 +455,19 @@ def main():
         torch.cuda.synchronize()
         out["rle_side"] = {"masks": int(bits.shape[0]), "ms_device": round((time.perf_counter() - t_r) * 1e3, 3),
                            "total_runs": int(offsets[-1].item()) if offsets.numel() else 0}
+        # f4 side measurement: latency of one interactive point prompt (SamPredictor.predict: numpy in, 3 masks + scores + low-res
+        # logits back on the host) on an embedding that is already set, as the napari annotator issues them
+        util.set_precomputed(predictor, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]),
+                                         "input_size": (1024, 1024), "original_size": (1024, 1024)})
+        rng = np.random.default_rng(0)
+        lat = []
+        for k in range(60):
+            pt = rng.uniform(32, 992, size=(1, 2))
+            torch.cuda.synchronize(); t_i = time.perf_counter()
+            predictor.predict(point_coords=pt, point_labels=np.ones(1), multimask_output=True)
+            lat.append((time.perf_counter() - t_i) * 1e3)
+        out["interactive_side"] = {"predict_ms_median": round(float(np.median(lat[10:])), 3), "predict_ms_p90": round(float(np.quantile(lat[10:], 0.9)), 3),
+                                   "what": "SamPredictor.predict(one point, multimask) incl. the D2H of 3 x 1024^2 masks"}
         if not args.no_cpu_baseline and world == 1:
             log(f"timing the CPU reference on {args.cpu_tiles} full tiles ...")
             n_thr = min(os.cpu_count() or 1, 32)    # more threads than this only slow the fp32 torch ops down

@@ -91,8 +91,6 @@ def get_sam_model(model_type: str = _DEFAULT_MODEL, device: Optional[Union[str, 
     environments have no network, so the reference's pooch download of named models is not available; without
     ``checkpoint_path`` or ``state_dict`` this raises."""
     device = get_device(device)
-    if peft_kwargs:
-        raise NotImplementedError("micro_sam_amd: PEFT surgery is not provided (SURVEY.md 8(f) rank 4)")
     abbreviated = model_type[:5]
     if abbreviated not in ("vit_b", "vit_l", "vit_h", "vit_t"):
         raise ValueError(f"Invalid model_type: {abbreviated}. Expect one of ('vit_h', 'vit_b', 'vit_l', 'vit_t')")
@@ -114,6 +112,13 @@ def get_sam_model(model_type: str = _DEFAULT_MODEL, device: Optional[Union[str, 
     if abbreviated == "vit_t":
         raise RuntimeError("vit_t (MobileSAM / TinyViT) is not provided by micro_sam_amd; use vit_b / vit_l.")
     sam = modeling.sam_model_registry[abbreviated](**model_kwargs)
+    if peft_kwargs and isinstance(peft_kwargs, dict):
+        # LoRA surgery of the image encoder before the weights are loaded (reference util.py:441-450); the low-rank
+        # updates are merged into the encoder's operand copies at inference (models/peft_sam.py)
+        from .models import peft_sam
+        peft_kwargs = dict(peft_kwargs)
+        peft_kwargs.pop("quantize", None)
+        sam = peft_sam.PEFT_Sam(sam, **peft_kwargs).sam
     if flexible_load_checkpoint:
         own = sam.state_dict()
         model_state = {k: v for k, v in model_state.items() if k in own and own[k].shape == v.shape}

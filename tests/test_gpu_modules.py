@@ -132,3 +132,46 @@ def test_batched_tiled_inference(vit_b_sd):
     seg2 = inference.batched_tiled_inference(p, None, 8, image_embeddings=emb, points=pts, point_labels=lbl, optimize_memory=True,
                                              min_size=0)
     assert seg2.shape == (1024, 1024) and seg2.max() >= 1
+
+
+def test_lora_surgery_merged_inference(vit_b_sd):
+    """get_sam_model(peft_kwargs=...) (reference micro_sam/util.py:441-450, models/peft_sam.py:50-146): LoRA on q / v (+ mlp) of
+    chosen blocks; the HIP encoder runs the merged weights, which equals a plain model carrying W + B A."""
+    from micro_sam_amd import util
+    from micro_sam_amd.models import peft_sam
+    from micro_sam_amd.synthetic import synthetic_tile
+    g = torch.Generator().manual_seed(0)
+    layers, rank = [0, 2, 7], 4
+    sd = dict(vit_b_sd)
+    merged = dict(vit_b_sd)
+    for i in layers:
+        pre = f"image_encoder.blocks.{i}."
+        w = sd.pop(pre + "attn.qkv.weight"); b = sd.pop(pre + "attn.qkv.bias")
+        sd[pre + "attn.qkv.qkv_proj.weight"], sd[pre + "attn.qkv.qkv_proj.bias"] = w, b
+        wm = w.clone()
+        for m, sl in (("q", slice(0, 768)), ("v", slice(1536, 2304))):
+            a = torch.randn(rank, 768, generator=g) * 0.05
+            bb = torch.randn(768, rank, generator=g) * 0.05
+            sd[pre + f"attn.qkv.w_a_linear_{m}.weight"], sd[pre + f"attn.qkv.w_b_linear_{m}.weight"] = a, bb
+            wm[sl] += bb @ a
+        merged[pre + "attn.qkv.weight"] = wm
+        for k, (din, dout) in (("1", (768, 3072)), ("2", (3072, 768))):
+            a = torch.randn(rank, din, generator=g) * 0.03
+            bb = torch.randn(dout, rank, generator=g) * 0.03
+            lw = sd.pop(pre + f"mlp.lin{k}.weight"); lb = sd.pop(pre + f"mlp.lin{k}.bias")
+            sd[pre + f"mlp.mlp_layer.lin{k}.weight"], sd[pre + f"mlp.mlp_layer.lin{k}.bias"] = lw, lb
+            sd[pre + f"mlp.w_a_linear_{k}.weight"], sd[pre + f"mlp.w_b_linear_{k}.weight"] = a, bb
+            merged[pre + f"mlp.lin{k}.weight"] = lw + bb @ a
+    p_lora = util.get_sam_model("vit_b", device="cuda", state_dict=sd,
+                                peft_kwargs=dict(rank=rank, peft_module=peft_sam.LoRASurgery, attention_layers_to_update=layers,
+                                                 update_matrices=["q", "v", "mlp"]))
+    p_merged = util.get_sam_model("vit_b", device="cuda", state_dict=merged)
+    p_plain = util.get_sam_model("vit_b", device="cuda", state_dict=dict(vit_b_sd))
+    img = util._to_image(synthetic_tile(9))
+    for p in (p_lora, p_merged, p_plain):
+        p.set_image(img)
+    assert torch.equal(p_lora.features, p_merged.features)
+    assert (p_lora.features - p_plain.features).abs().max().item() > 1e-2          # the update is visible
+    assert any("w_a_linear_q" in k for k in p_lora.model.state_dict())
+    with pytest.raises(NotImplementedError):
+        util.get_sam_model("vit_b", device="cuda", state_dict=dict(vit_b_sd), peft_kwargs=dict(rank=2, peft_module=torch.nn.Identity))
