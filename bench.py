@@ -255,7 +255,7 @@ def main():
     pinned_labels = [None]
     shape_only = np.broadcast_to(np.zeros((1, 1), dtype=np.uint8), (1024, 1024))   # initialize() reads the image SHAPE only
 
-    def step(timed: bool, index: int, uploads=None):
+    def step(timed: bool, index: int, uploads=None, serial: bool = False):
         """timed=True: instrumented pass with a device sync after every stage (stage breakdown only);
         timed=False: the production path, no extra synchronisation.  uploads: host tiles to convert + upload inside the step
         (the PCIe-inclusive pass), else the resident uint8 tiles of step `index` are used."""
@@ -277,7 +277,7 @@ def main():
         emb = {"features": feats, "input_size": (1024, 1024), "original_size": (1024, 1024)}
         if timed:
             torch.cuda.synchronize(); stage["encode"] += time.perf_counter() - t0
-        if len(lanes) > 1 and not timed:
+        if len(lanes) > 1 and not timed and not serial:
             main = torch.cuda.current_stream()
             for _, _, st in lanes:
                 st.wait_stream(main)                                    # embeddings ready
@@ -290,7 +290,7 @@ def main():
                 flags.append(flag)
             for _, _, st in lanes:
                 main.wait_stream(st)
-        for i in range(n_tiles if (len(lanes) == 1 or timed) else 0):
+        for i in range(n_tiles if (len(lanes) == 1 or timed or serial) else 0):
             t1 = time.perf_counter()
             amg.initialize(shape_only, emb, i=i)
             if timed:
@@ -332,17 +332,37 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    lib.msam_profile_enable(1)
+    # Per-kernel HIP-event brackets (msam_profile_*) measure a kernel's own duration only when nothing else shares the GPU with
+    # it.  With one decode lane they run inside the timed region; with several lanes kernels of different tiles overlap (that
+    # is the point of the lanes) and a bracket would also count the time a launch queues behind another lane's kernels, so the
+    # roofline pass is then a separate serial (one-lane) pass over the same steps right after the timed region.
+    profile_in_timed_region = len(lanes) == 1
+    lib.msam_profile_enable(1 if profile_in_timed_region else 0)
     stage["host_enqueue"] = 0.0
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(False, args.warmup + k)
-        collect()            # synchronises the step's kernel events (end of step: nothing left in flight anyway)
+        if profile_in_timed_region:
+            collect()        # synchronises the step's kernel events (end of step: nothing left in flight anyway)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     lib.msam_profile_enable(0)
+    prof_steps = args.steps
+    if not profile_in_timed_region:
+        prof_steps = max(1, min(args.steps, 5))
+        host_enqueue_timed = stage["host_enqueue"]
+        torch.cuda.synchronize()
+        lib.msam_profile_enable(1)
+        t_ser = time.perf_counter()
+        for k in range(prof_steps):
+            step(False, args.warmup + k, serial=True)
+            collect()
+        torch.cuda.synchronize()
+        serial_elapsed = time.perf_counter() - t_ser
+        lib.msam_profile_enable(0)
+        stage["host_enqueue"] = host_enqueue_timed
     serial_labels = step(True, 0).clone()     # one extra instrumented pass (outside the timed region): stage breakdown, and
     pipelined_labels = step(False, 0)         # the serial result that the pipelined (lanes / side stream) step must reproduce
     torch.cuda.synchronize()
@@ -365,7 +385,7 @@ def main():
     if rank == 0:
         total_tiles = n_tiles * args.steps * world
         value = total_tiles / elapsed
-        tiles_timed = n_tiles * args.steps
+        tiles_timed = n_tiles * prof_steps                  # tiles of the pass the kernel brackets were recorded in
 
         def fam(f):
             d = prof[f]
@@ -414,6 +434,11 @@ def main():
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
                 "traffic": traffic, **{k: v for k, v in dom.items() if k not in ("bound", "achieved", "peak", "unit", "frac")},
                 "whole_path_tflops": round(whole, 2), "whole_path_frac": round(whole / PEAK_BF16_TFLOPS, 4),
+                "measured_in": ("the timed region (one decode lane: no two kernels of the hot path share the GPU)" if profile_in_timed_region
+                                else f"a serial one-lane pass of {prof_steps} steps right after the timed region "
+                                     f"({n_tiles * prof_steps / serial_elapsed:.1f} tiles/s): in the timed region {len(lanes)} lanes "
+                                     "overlap the kernels of different tiles, so a HIP-event bracket there also counts queueing; "
+                                     "profiles/ holds the rocprofv3 summary of the same one-lane command (--lanes 1)"),
                 "other_kernels": fams[1:]}
         out = {
             "metric": "1024^2 tiles/s embed+AMG (vit_b bf16)" if args.encoder_dtype == "bf16" else
