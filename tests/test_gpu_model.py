@@ -583,3 +583,33 @@ def test_fp8_encoder_vs_oracle(ctx):
     finally:
         enc.set_precision("bf16")
         p.reset_image()
+
+
+def test_config3_vit_l_tiled_volume_segment_slices():
+    """BASELINE configs[2] scaled down: vit_l, a [2, 1536, 1536] volume, tiled embeddings (768 + 2 x 128 halo: outer tiles up to
+    1024^2) through multi_dimensional_segmentation.segment_slices with TiledAutomaticMaskGenerator (reference
+    multi_dimensional_segmentation.py:385-416 with a tiled segmentor, :419-481) == the per-slice tiled AMG with the reference's
+    running id offsets.  (The vit_l kernels themselves are compared with the oracle in test_vit_l_encoder_and_decode_vs_oracle.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import multi_dimensional_segmentation as mds
+    from micro_sam_amd import util
+    from micro_sam_amd.instance_segmentation import TiledAutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    p = util.get_sam_model("vit_l", device="cuda", state_dict=synthetic_state_dict("vit_l", 1))
+    vol = np.stack([synthetic_tile(s, (1536, 1536)) for s in (41, 42)])
+    kw = dict(pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    seg, emb = mds.segment_slices(vol, p, TiledAutomaticMaskGenerator(p, points_per_side=8), tile_shape=(768, 768), halo=(128, 128),
+                                  batch_size=4, **kw)
+    assert seg.shape == vol.shape and seg.dtype == np.uint32 and emb["input_size"] is None
+    offset = 0
+    for z in range(2):
+        amg = TiledAutomaticMaskGenerator(p, points_per_side=8)
+        amg.initialize(vol[z], image_embeddings=emb, i=z)
+        assert len(amg.crop_list) == 4 and amg.crop_boxes[0] == [0, 0, 896, 896] and amg.crop_boxes[3] == [640, 640, 1536, 1536]
+        assert all(d.mask_size != (1536, 1536) for d in amg.crop_list)                   # per-tile state at tile resolution
+        ref = amg.generate(**kw)
+        m = int(ref.max())
+        ref[ref != 0] += offset
+        offset += m
+        assert np.array_equal(seg[z], ref) and m > 0

@@ -15,7 +15,8 @@ import torch.nn.functional as F
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 
-from micro_sam_amd import _debug, _lib, modeling, ops  # noqa: E402
+from micro_sam_amd import _lib, modeling, ops  # noqa: E402
+import debug_helpers as _debug  # noqa: E402  (tools/debug_helpers.py)
 from micro_sam_amd import util as mutil  # noqa: E402
 from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile  # noqa: E402
 from oracle import amg_ref as A  # noqa: E402
