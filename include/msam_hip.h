@@ -117,7 +117,8 @@ int msam_decoder_image_layer(const msam_image_layer_t* p, void* stream);
  * TwoWayTransformer.final_attn_token_to_image):
  *   S = (keys + pe) Wk^T q / 4 is evaluated as keys . (Wk^T q) + (pe Wk^T + bk) . q, and softmax(S) (keys Wv^T + bv) as
  *   (softmax(S) keys) Wv^T + bv, so the per-prompt image-token stream is read once and no K / V stream is written.
- * keys: bf16 [Pk,4096,256] (kv_shared != 0: every prompt uses prompt 0's stream); qtok: bf16 [P,Nt,128] projected
+ * keys: bf16 [Pk,4096,256] (kv_shared = 1: every prompt uses prompt 0's stream; kv_shared = 2: per-prompt streams in the
+ * blocked layout msam_i2t01_fused writes); qtok: bf16 [P,Nt,128] projected
  * queries, 1 <= Nt <= 8; wk, wv: bf16 [128,256]; tabk: bf16 [4096,128] = pe Wk^T + bk; bv fp32 [128];
  * out: bf16 [P,Nt,128] (input of the attention's out_proj).  workspace >= msam_t2i_fold_workspace_bytes(P). */
 int64_t msam_t2i_fold_workspace_bytes(int32_t P);
@@ -138,6 +139,38 @@ int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void* ktok, con
                         const void* wq, const void* tabq, const void* wo, const float* bo, const float* ln_w,
                         const float* ln_b, float ln_eps, void* out, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Chained forms of the two-way transformer's image side for prompts that share ONE source (AMG: no mask prompts, every
+ * prompt of a tile starts from image embedding + no_mask_embed) - csrc/decfold_tok.hip.  The layer-0 output stream is never
+ * written: each wave recomputes its 16-token tile of it from the L2-resident source and feeds it, rounded to 16 bits exactly
+ * as the stream would have stored it, into the next stage.
+ * BLOCKED layout: [tile of 16 tokens][k-step s][lane = 16 g + token][8 channels 32 s + 8 g ..] (one MFMA operand fragment =
+ * 1 KiB contiguous; a tile stays contiguous: 8 KiB for 256 channels).
+ *   msam_chain_prepare_tables: blocked copies of the shared tables, once per decode: src d16 [4096,256] (the shared source),
+ *       q0 d16 [4096,128] = (src + pe) Wq0^T + bq0, tabk d16 [4096,128] = pe Wk^T + bk of the layer-1 token->image attention,
+ *       tabq1 d16 [4096,128] = pe Wq^T + bq of the layer-1 image->token block -> tables (>= msam_chain_tables_bytes());
+ *   msam_i2t_fold_operands: per-prompt operands of an image->token layer in MFMA fragment order (K' = Wq_h^T k_{t,h},
+ *       V'^T = Wo[:,16h:16h+16] v_{t,h} + bo / 8, block-diagonal k; ktok / vtok d16 [P,Nt,128], wq d16 [128,256], wo d16
+ *       [256,128]) into `operands` (>= msam_i2t_fold_operand_bytes(P)); with_kfold = 0 skips K' (layer 0 on a shared source
+ *       takes its scores from q0);
+ *   msam_i2t0_t2i_fused: layer-0 image->token block (tables, operands0, norm4 of layer 0) chained into the layer-1
+ *       token->image attention (qtok d16 [P,Nt,128] projected queries, wk / wv d16 [128,256], bv fp32 [128]): out d16
+ *       [P,Nt,128] as msam_t2i_fold_attention on the layer-0 output would give; no per-prompt stream is read or written;
+ *   msam_i2t01_fused: the same layer-0 block chained into the layer-1 image->token block (operands1, norm4 of layer 1):
+ *       out d16 [P] x blocked [256][8][64][8] = the layer-1 output stream in the BLOCKED layout (msam_t2i_fold_attention with
+ *       kv_shared = 2 and msam_upscale_fused_layout with keys_blocked = 1 read it).
+ * 1 <= Nt <= 8; one 8-wave workgroup per prompt at a time (meant for P >= ~half the CU count). */
+int64_t msam_chain_tables_bytes(void);
+int msam_chain_prepare_tables(const void* src, const void* q0, const void* tabk, const void* tabq1, void* tables, void* stream);
+int64_t msam_i2t_fold_operand_bytes(int32_t P);
+int msam_i2t_fold_operands(const void* ktok, const void* vtok, int32_t P, int32_t Nt, const void* wq, const void* wo,
+                           const float* bo, int32_t with_kfold, void* operands, void* stream);
+int64_t msam_i2t0_t2i_workspace_bytes(int32_t P);
+int msam_i2t0_t2i_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b, float ln_eps,
+                        const void* qtok, int32_t P, int32_t Nt, const void* wk, const void* wv, const float* bv, void* out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int msam_i2t01_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b, const void* operands1,
+                     const float* ln1_w, const float* ln1_b, float ln_eps, int32_t P, int32_t Nt, void* out, void* stream);
+
 /* Output up-scaling + hyper-network product of the mask decoder in one pass over the image-token stream (reference:
  * segment_anything/modeling/mask_decoder.py MaskDecoder.predict_masks: output_upscaling = ConvTranspose2d(256,64,2,2),
  * LayerNorm2d(64), GELU, ConvTranspose2d(64,32,2,2), GELU; masks = hyper_in @ upscaled).
@@ -148,6 +181,10 @@ int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void* ktok, con
 int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float* b1, const float* ln_w, const float* ln_b,
                        float ln_eps, const void* w2, const float* b2, const float* hyper, int32_t hyper_ld, int32_t mask0,
                        int32_t nmask, float* low_res, void* stream);
+/* the same with the stream layout stated: keys_blocked != 0 = the blocked layout msam_i2t01_fused writes */
+int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
+                              const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
+                              const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res, void* stream);
 
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
@@ -157,6 +194,10 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
 int msam_upscale_set_prio(int32_t prio);
 /* tuning hook: fold_attn_kernel operand staging (0 registers, 2 workgroups per CU; 1 LDS-DMA, 3 workgroups per CU) */
 int msam_fold_attn_set_dma(int32_t on);
+/* named integer tuning knobs of the decoder stream kernels (A/B experiments, tests): "i2t_variant" (1 = token-owner kernel,
+ * default; 0 = 4-wave tile kernel), "i2t_wg_per_cu", "dec_chain" (1 = the decoder takes the chained forms above when the
+ * prompts share one source, Nt <= 8 and P >= "dec_chain_min_p"; default 1 / 128).  Returns 0, 1 for an unknown key. */
+int msam_tune_set(const char* key, int32_t value);
 /* debug hook: phase timing of the folded image->token kernel (see csrc/decfold.hip, tools/i2t_timing.py) */
 int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out);
 /* tuning / test hook: operand staging of the 256 x 256 tile kernel behind msam_gemm_bf16 (0 registers two tiles ahead,

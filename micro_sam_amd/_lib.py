@@ -130,6 +130,15 @@ _PROTOS = {
     "msam_gemm256_set_staging": (_i32, [_i32]),
     "msam_gemm_group_bf16": (_i32, [_vp, _i32, _vp]),
     "msam_fold_attn_set_dma": (_i32, [_i32]),
+    "msam_tune_set": (_i32, [C.c_char_p, _i32]),
+    "msam_i2t_fold_operand_bytes": (_i64, [_i32]),
+    "msam_i2t_fold_operands": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "msam_i2t0_t2i_workspace_bytes": (_i64, [_i32]),
+    "msam_i2t0_t2i_fused": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "msam_i2t01_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
+    "msam_chain_tables_bytes": (_i64, []),
+    "msam_chain_prepare_tables": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "msam_upscale_fused_layout": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_upscale_set_prio": (_i32, [_i32]),
     "msam_layernorm_fp8": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp]),
     "msam_quant_rows_fp8": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
@@ -191,6 +200,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    # A/B knobs from the command line: MSAM_TUNE="dec_chain=0,i2t_variant=0" (include/msam_hip.h msam_tune_set)
+    for item in filter(None, os.environ.get("MSAM_TUNE", "").split(",")):
+        key, _, val = item.partition("=")
+        if lib.msam_tune_set(key.strip().encode(), int(val)) != 0:
+            raise RuntimeError(f"micro_sam_amd: MSAM_TUNE: unknown knob {key!r}")
     return lib
 
 

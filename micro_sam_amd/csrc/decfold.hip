@@ -22,6 +22,7 @@
 // kernel merges the splits, normalises and applies the per-head 256 -> 16 value projection.
 #include "common.h"
 #include "../../include/msam_hip.h"
+#include <string>
 
 void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
@@ -77,6 +78,7 @@ struct FoldArgs {
     float* opart;                        // fp32 [P, KS, 64, 256]
     float* stats;                        // fp32 [P, KS, 64, 2]  (m, l)
     const u16* wv; const float* bv; u16* out;   // KS == 1: value projection fused into the item epilogue, bf16 [P, Nt, 128]
+    int blocked;                         // keys in the blocked layout of decfold_tok.hip ([16-token tile][k-step][lane][8]) instead of row-major
 };
 
 // DMA: the stream and table tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16, the
@@ -99,7 +101,11 @@ __global__ __launch_bounds__(NTHR, DMA ? 3 : 2) void fold_attn_kernel(FoldArgs a
     int kdst[4], tdst[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
+        // 16-byte chunk id of the (contiguous) 32-key tile -> key row, channel chunk c: row-major [32][32 chunks], or blocked
+        // [2 blocks of 16 keys][k-step 8][lane group 4][key 16]
+        const int id = i * NTHR + tid;
+        const int row = a.blocked ? (id >> 9) * 16 + (id & 15) : id >> 5;
+        const int c = a.blocked ? ((id >> 6) & 7) * 4 + ((id >> 4) & 3) : id & 31;
         kdst[i] = (c >> 1) * SUBT + row * 32 + (((c & 1) ^ ((row >> 3) & 1)) << 4);
     }
 #pragma unroll
@@ -683,7 +689,7 @@ extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, cons
     hipLaunchKernelGGL(fold_q_kernel, dim3(P * 8), dim3(256), 0, s, (const u16*)qtok, (const u16*)wk, Nt, qprime);
     if (int e = msam_check_launch("fold_q")) return e;
     FoldArgs a{};
-    a.keys = (const u16*)keys; a.kv_shared = kv_shared; a.qprime = qprime; a.qtok = (const u16*)qtok; a.Nt = Nt;
+    a.keys = (const u16*)keys; a.kv_shared = kv_shared & 1; a.blocked = (kv_shared >> 1) & 1; a.qprime = qprime; a.qtok = (const u16*)qtok; a.Nt = Nt;
     a.tabk = (const u16*)tabk; a.nitems = P * KS; a.KS = KS; a.opart = opart; a.stats = stats;
     a.wv = (const u16*)wv; a.bv = bv; a.out = (u16*)out;
     int dev = 0, cus = 256;
@@ -691,9 +697,9 @@ extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, cons
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
-    const double bytes = (double)(kv_shared ? 1 : P) * T * C * 2 + (KS > 1 ? (double)P * KS * 64 * C * 4 : 0.0);
+    const double bytes = (double)((kv_shared & 1) ? 1 : P) * T * C * 2 + (KS > 1 ? (double)P * KS * 64 * C * 4 : 0.0);
     msam_profile_mark2(stream, 1, flops, bytes, 3);
-    if (g_fold_attn_dma) {
+    if (g_fold_attn_dma && !a.blocked) {
         const int grid3 = a.nitems < 3 * cus ? a.nitems : 3 * cus;
         hipLaunchKernelGGL(fold_attn_kernel<true>, dim3(grid3), dim3(NTHR), 0, s, a);
     } else {
@@ -706,7 +712,17 @@ extern "C" int msam_t2i_fold_attention(const void* keys, int32_t kv_shared, cons
     return msam_check_launch("fold_finish");
 }
 
-extern "C" int64_t msam_i2t_fold_workspace_bytes(int32_t P) { return (long)P * 64 * C * 2 * 2; }
+// token-owner form of the same layer (decfold_tok.hip), the default; g_tune_i2t_variant = 0 selects fold_i2t_kernel
+int64_t msam_i2t_tok_workspace_bytes(int32_t P);
+int msam_i2t_tok_layer(const void* xin, int32_t x_shared, const void* ktok, const void* vtok, int32_t P, int32_t Nt,
+                       const void* wq, const void* tabq, const void* wo, const float* bo, const float* ln_w,
+                       const float* ln_b, float ln_eps, void* out, void* workspace, int KS, void* stream);
+extern int g_tune_i2t_variant;
+
+extern "C" int64_t msam_i2t_fold_workspace_bytes(int32_t P) {
+    const int64_t a = (int64_t)P * 64 * C * 2 * 2, b = msam_i2t_tok_workspace_bytes(P);
+    return a > b ? a : b;
+}
 
 extern "C" int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void* ktok, const void* vtok, int32_t P,
                                    int32_t Nt, const void* wq, const void* tabq, const void* wo, const float* bo,
@@ -718,6 +734,9 @@ extern "C" int msam_i2t_fold_layer(const void* xin, int32_t x_shared, const void
     }
     if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t_fold_layer: 1 <= Nt <= 8 tokens per prompt"); return 1; }
     if (workspace_bytes < msam_i2t_fold_workspace_bytes(P)) { msam_set_error("msam_i2t_fold_layer: workspace too small"); return 1; }
+    if (g_tune_i2t_variant == 1)
+        return msam_i2t_tok_layer(xin, x_shared, ktok, vtok, P, Nt, wq, tabq, wo, bo, ln_w, ln_b, ln_eps, out, workspace,
+                                  key_splits(P), stream);
     hipStream_t s = (hipStream_t)stream;
     u16* kfold = (u16*)workspace;
     u16* vfoldT = kfold + (long)P * 64 * C;
@@ -757,3 +776,22 @@ extern "C" int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out) {
 }
 
 extern "C" int msam_fold_attn_set_dma(int32_t on) { g_fold_attn_dma = on; return 0; }
+
+// Tuning / A-B hook (tools/, tests): named integer knobs of the decoder stream kernels.  Returns 0, or 1 for an unknown key.
+//   "i2t_variant"     1 = token-owner kernel (decfold_tok.hip, default), 0 = fold_i2t_kernel
+//   "i2t_wg_per_cu"   workgroups per CU of the token-owner kernel's persistent grid (default 2)
+//   "dec_chain"       1 = decoder_run chains layer 0 into layer 1 on a shared source (decfold_tok.hip), 0 = one kernel per stage
+//   "dec_chain_min_p" smallest number of prompts for which it does (default 128)
+extern int g_tune_i2t_wg_per_cu, g_tune_chain_variant, g_tune_chain_tmask;
+int g_tune_dec_chain = 1, g_tune_dec_chain_min_p = 128;
+extern "C" int msam_tune_set(const char* key, int32_t value) {
+    const std::string k = key ? key : "";
+    if (k == "i2t_variant") g_tune_i2t_variant = value;
+    else if (k == "i2t_wg_per_cu") g_tune_i2t_wg_per_cu = value;
+    else if (k == "dec_chain") g_tune_dec_chain = value;
+    else if (k == "chain_variant") g_tune_chain_variant = value;
+    else if (k == "chain_tmask") g_tune_chain_tmask = value;
+    else if (k == "dec_chain_min_p") g_tune_dec_chain_min_p = value;
+    else { msam_set_error("msam_tune_set: unknown key"); return 1; }
+    return 0;
+}

@@ -1,0 +1,1084 @@
+// Image -> token cross attention + out_proj + residual + LayerNorm of a two-way block (reference:
+// segment_anything TwoWayAttentionBlock.cross_attn_image_to_token + norm4) in TOKEN-OWNER form: same folding as
+// fold_i2t_kernel (decfold.hip),
+//     S[j][(h,t)] = keys_j . K'_{h,t} / 4 + tabQ_{j,h} . k_{t,h} / 4,   P = softmax_t(S),
+//     keys_j <- LayerNorm(keys_j + sum_{(h,t)} P[j][(h,t)] V'_{h,t} + bo),
+// but every wave owns WHOLE image tokens: a wave takes a 16-token tile, holds all 64 score rows and all 256 output
+// channels of those tokens in its own accumulators, and never exchanges anything with another wave:
+//   * the stream tile goes global -> registers directly in MFMA B-operand layout (lane = token l & 15, 8 consecutive
+//     channels 32 s + 8 (l >> 4) ..; 16 B per lane, 64 B contiguous per token and instruction) - no LDS staging, no
+//     ds_write pass;
+//   * the per-prompt operands K' (64 x 256), V'^T (256 x 64) and the block-diagonal table operand live in LDS in
+//     FRAGMENT order (one MFMA A operand = 1 KiB contiguous, lane-major: conflict-free ds_read_b128 at immediate
+//     offsets from one base register), written once per prompt; the four waves of a workgroup share them;
+//   * the score rows are ordered so that one lane holds the 8 prompt tokens of a head (tiles 2a / 2a+1 = tokens 0..3 /
+//     4..7 of heads 4a + (l >> 4)): the softmax over the prompt tokens needs no cross-lane step, and the normalised
+//     probabilities ARE the B operand of the second product (k-slot 8 (l >> 4) + i = head 4a + (l >> 4), token i);
+//   * the output rows are ordered so that a lane's accumulators of tiles 2c, 2c+1 are 8 CONSECUTIVE channels
+//     32 c + 8 (l >> 4) ..: the LayerNorm result is packed and stored with the same 16-byte pattern the tile was loaded
+//     with; the LayerNorm statistics are in-lane sums + two cross-lane steps;
+//   * residual = one MFMA per output tile with a 0/1 selection matrix as A operand and the tile's own B fragment
+//     (x * 1.0 is exact in the fp32 accumulator); out_proj bias: sum_t P[h][t] = 1 for every head, so bo / 8 is added to
+//     every V'_{h,t} (t < Nt) by the fold kernel; 1/4 and log2(e) are folded into K' (softmax through v_exp_f32).
+// No barrier and no LDS write in the tile loop (fold_i2t_kernel: three barriers, ~230 KB of LDS traffic per 32 tokens).
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int family);
+
+int g_tune_i2t_variant = 1;          // 1: token-owner kernel (this file), 0: fold_i2t_kernel (decfold.hip)
+int g_tune_i2t_wg_per_cu = 2;
+int g_tune_chain_tmask = 255;        // experiment: tile index mask of the SHARED-table loads of the ring kernels (255 = off)
+int g_tune_chain_variant = 0;        // chained kernels: 0 = 8 waves, 4-fragment groups; 1 / 2 = 4 waves (one per SIMD), rings of 8 / 16;
+                                     // 3 = 8 waves on the ring code with G = 4
+
+namespace {
+
+constexpr int T = 4096, C = 256, CI = 128, NTHR = 256;
+constexpr int FRAG = 1024;                                  // one MFMA A operand: 64 lanes x 16 B
+constexpr int KT_OFF = 0, KT_BYTES = 4 * 2 * FRAG;          // [m][e]      table operand (block diagonal k_{t,h})
+constexpr int KF_OFF = KT_OFF + KT_BYTES, KF_BYTES = 4 * 8 * FRAG;     // [m][ks]     K'
+constexpr int VF_OFF = KF_OFF + KF_BYTES, VF_BYTES = 2 * 16 * FRAG;    // [a][ct]     V'^T
+constexpr int OPER_BYTES = VF_OFF + VF_BYTES;               // 73728 per prompt
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float SCALE = 0.25f * 1.4426950408889634f;        // 1 / sqrt(16) and log2(e)
+
+// Per prompt: the three operands in fragment order.  Fragment element (lane = fg * 16 + fr, i): A[row fr][k = 8 fg + i].
+//   K' [m][ks]: row (m, fr) = (head 4 (m >> 1) + (fr >> 2), token 4 (m & 1) + (fr & 3)), k = channel 32 ks + 8 fg + i
+//   KT [m][e] : same rows, k = table channel 32 (2 (m >> 1) + e) + 8 fg + i; k_{t,h} on the head's own 16 channels, else 0
+//   V'^T [a][ct]: row fr = channel 32 (ct >> 1) + 8 (fr >> 2) + 4 (ct & 1) + (fr & 3), k = (head 4a + fg, token i)
+__global__ __launch_bounds__(256) void fold_frag_kernel(const u16* __restrict__ ktok, const u16* __restrict__ vtok,
+                                                        const u16* __restrict__ wq, const u16* __restrict__ wo,
+                                                        const float* __restrict__ bo, int Nt, int with_kf,
+                                                        u16* __restrict__ oper) {
+    __shared__ __attribute__((aligned(16))) u16 img[OPER_BYTES / 2];
+    __shared__ float kk[8][CI], vv[8][CI];
+    const int p = blockIdx.x, c = threadIdx.x;
+    for (int i = c; i < 8 * CI; i += 256) {
+        const int t = i >> 7, d = i & (CI - 1);
+        kk[t][d] = t < Nt ? d2f(ktok[((long)p * Nt + t) * CI + d]) : 0.f;
+        vv[t][d] = t < Nt ? d2f(vtok[((long)p * Nt + t) * CI + d]) : 0.f;
+    }
+    for (int i = c; i < KT_BYTES / 16; i += 256) ((uint4*)img)[KT_OFF / 16 + i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // ---- K'[(h,t)][c] = SCALE * sum_d k[t][16h + d] Wq[16h + d][c]   (not needed by the layer-0 form on a shared source)
+    if (with_kf) {
+        const int ks = c >> 5, fg = (c >> 3) & 3, ii = c & 7;
+        for (int h = 0; h < 8; ++h) {
+            float w[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) w[d] = d2f(wq[(h * 16 + d) * C + c]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) acc = fmaf(kk[t][h * 16 + d], w[d], acc);
+                const int m = 2 * (h >> 2) + (t >> 2), fr = 4 * (h & 3) + (t & 3);
+                img[KF_OFF / 2 + ((m * 8 + ks) * 64 + fg * 16 + fr) * 8 + ii] = f2d(acc * SCALE);
+            }
+        }
+    }
+    // ---- table operand: SCALE * k[t][16h + d] at row (h,t), table channel 16h + d
+    for (int j = c; j < 8 * 8 * 16; j += 256) {
+        const int h = j >> 7, t = (j >> 4) & 7, d = j & 15;
+        const int m = 2 * (h >> 2) + (t >> 2), e = (h >> 1) & 1, fr = 4 * (h & 3) + (t & 3), fg = 2 * (h & 1) + (d >> 3);
+        img[KT_OFF / 2 + ((m * 2 + e) * 64 + fg * 16 + fr) * 8 + (d & 7)] = f2d(kk[t][h * 16 + d] * SCALE);
+    }
+    // ---- V'^T[c][(h,t)] = sum_d Wo[c][16h + d] v[t][16h + d] + bo[c] / 8   (t < Nt)
+    {
+        const int cp = c >> 5, within = c & 31, rho = 4 * (within >> 3) + (within & 3), ct = 2 * cp + ((within >> 2) & 1);
+        const float bo8 = bo[c] * 0.125f;
+        for (int h = 0; h < 8; ++h) {
+            const uint4 w0 = *(const uint4*)(wo + (long)c * CI + h * 16), w1 = *(const uint4*)(wo + (long)c * CI + h * 16 + 8);
+            const uint32_t ww[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            float wf[16];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) { wf[2 * x] = d2f((u16)(ww[x] & 0xffff)); wf[2 * x + 1] = d2f((u16)(ww[x] >> 16)); }
+            uint32_t pk[4];
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) { a0 = fmaf(wf[d], vv[2 * t2][h * 16 + d], a0); a1 = fmaf(wf[d], vv[2 * t2 + 1][h * 16 + d], a1); }
+                pk[t2] = pack2d(2 * t2 < Nt ? a0 + bo8 : 0.f, 2 * t2 + 1 < Nt ? a1 + bo8 : 0.f);
+            }
+            const int a = h >> 2, fg = h & 3;
+            *(uint4*)(img + VF_OFF / 2 + ((a * 16 + ct) * 64 + fg * 16 + rho) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+    __syncthreads();
+    uint4* dst = (uint4*)(oper + (long)p * (OPER_BYTES / 2));
+    for (int i = c; i < OPER_BYTES / 16; i += 256) dst[i] = ((const uint4*)img)[i];
+}
+
+
+// ---- per-wave constants shared by the kernels below
+struct WaveConst {
+    uint4 sel[2];          // residual selection operands: tile 2c + e, row rho picks k = 8 (rho >> 2) + 4 e + (rho & 3) of k-step c
+    f32x4_t sinit[2];      // initial score accumulators: 0, or -BIG for the rows of absent prompt tokens (token 4 (m & 1) + r >= Nt)
+};
+MSAM_DEVINL WaveConst wave_const(int fr, int fg, int Nt) {
+    WaveConst k;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        uint32_t wv[4] = {0u, 0u, 0u, 0u};
+        if (fg == (fr >> 2)) { const int i = 4 * e + (fr & 3); wv[i >> 1] = (i & 1) ? (MSAM_D16_ONE << 16) : MSAM_D16_ONE; }
+        k.sel[e] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+    }
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) k.sinit[par][r] = 4 * par + r < Nt ? 0.f : NEG_BIG;
+    return k;
+}
+
+#define TK_RD4(dst_, off_, stride_) do { _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) dst_[j_] = *(const uint4*)(L + (off_) + j_ * (stride_)); } while (0)
+#define TK_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// One 16-token tile through the image->token layer.  L = lds + lane * 16; KT / KF / VF = byte offsets of the operand
+// images in LDS; gp = ln_w + 8 (lane >> 4) in LDS (ln_b follows C floats later).  b[8]: the tile as B fragments (residual,
+// and the K' product when HAS_KF); tb[4]: B fragments of the table term: tabQ tile (HAS_KF) or, for layer 0 on the SHARED
+// source, the prompt-independent q = (src + pe) Wq^T + bq tile itself (S = q . k, no K' product).  y[8]: the LayerNorm output
+// as packed 16-bit values in the same fragment layout as b.  consumed() runs when b / tb have been read for the last time
+// (the caller issues its prefetch into them there).
+// The A operands come from LDS four at a time into two alternating register groups: the reads of group g+1 are in flight
+// while the MFMAs of group g issue (left to itself the compiler reads one fragment, waits for it and multiplies).
+template <int KT, int KF, int VF, bool HAS_KF, class F>
+MSAM_DEVINL void i2t_block(const unsigned char* L, const float* gp, float eps, const uint4* b, const uint4* tb,
+                           const WaveConst& wc, uint4* y, F&& consumed) {
+    f32x4_t s[4];
+    uint4 fa[4], fb[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) s[m] = wc.sinit[m & 1];
+    constexpr int G0 = HAS_KF ? 0 : 8;                   // groups 0..7: K' k-steps, 8..9: table operand
+    if (HAS_KF) TK_RD4(fa, KF, 8 * FRAG); else TK_RD4(fa, KT, 2 * FRAG);
+    TK_FENCE();
+#pragma unroll
+    for (int g = G0; g < 10; ++g) {
+        uint4* cur = (g & 1) ? fb : fa;
+        uint4* nxt = (g & 1) ? fa : fb;
+        if (g + 1 < 8) TK_RD4(nxt, KF + (g + 1) * FRAG, 8 * FRAG);
+        else if (g + 1 < 10) TK_RD4(nxt, KT + (g + 1 - 8) * FRAG, 2 * FRAG);
+        else TK_RD4(nxt, VF, FRAG);                      // first group of the second product
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            s[m] = mfma16d(cur[m], g < 8 ? b[g < 8 ? g : 0] : tb[2 * (m >> 1) + (g - 8)], s[m]);
+        TK_FENCE();
+    }
+    // ---- O^T accumulators start as the residual
+    f32x4_t o[16];
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) o[ct] = mfma16d(wc.sel[ct & 1], b[ct >> 1], f32x4_t{0.f, 0.f, 0.f, 0.f});
+    consumed();
+    TK_FENCE();
+    // ---- softmax over the 8 prompt tokens of a head, in lane; P packed = B operand of the second product
+    uint4 pk[2];
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {
+        const f32x4_t u = s[2 * a2], v = s[2 * a2 + 1];
+        const float mx = fmaxf(fmaxf(fmaxf(u[0], u[1]), fmaxf(u[2], u[3])), fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float eu[4], ev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { eu[r] = __builtin_amdgcn_exp2f(u[r] - mx); ev[r] = __builtin_amdgcn_exp2f(v[r] - mx); }
+        const float l = ((eu[0] + eu[1]) + (eu[2] + eu[3])) + ((ev[0] + ev[1]) + (ev[2] + ev[3]));
+        const float inv = __builtin_amdgcn_rcpf(l);          // 1 ulp; P is rounded to 16 bits next
+        pk[a2] = make_uint4(pack2d(eu[0] * inv, eu[1] * inv), pack2d(eu[2] * inv, eu[3] * inv),
+                            pack2d(ev[0] * inv, ev[1] * inv), pack2d(ev[2] * inv, ev[3] * inv));
+    }
+    TK_FENCE();
+    // ---- O^T += V'^T P^T: 8 groups of four output tiles (group q: k-step a2 = q >> 2, tiles 4 (q & 3) ..)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint4* cur = (q & 1) ? fb : fa;                   // group 0 was read into fa by the last score group (g = 9)
+        uint4* nxt = (q & 1) ? fa : fb;
+        if (q + 1 < 8) TK_RD4(nxt, VF + (q + 1) * 4 * FRAG, FRAG);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * (q & 3) + j] = mfma16d(cur[j], pk[q >> 2], o[4 * (q & 3) + j]);
+        TK_FENCE();
+    }
+    // ---- LayerNorm over the 256 channels of token fr: 64 values in this lane, the rest in lanes fr + 16 g
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1 += o[ct][r]; s2 = fmaf(o[ct][r], o[ct][r], s2); }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float mean = s1 * (1.f / C);
+    const float rstd = rsqrtf(fmaxf(s2 * (1.f / C) - mean * mean, 0.f) + eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int c2 = 0; c2 < 8; ++c2) {
+        const float4 g0 = *(const float4*)(gp + c2 * 32), g1 = *(const float4*)(gp + c2 * 32 + 4);
+        const float4 h0 = *(const float4*)(gp + C + c2 * 32), h1 = *(const float4*)(gp + C + c2 * 32 + 4);
+        const f32x4_t x0 = o[2 * c2], x1 = o[2 * c2 + 1];
+        y[c2].x = pack2d(fmaf(fmaf(x0[0], rstd, nmr), g0.x, h0.x), fmaf(fmaf(x0[1], rstd, nmr), g0.y, h0.y));
+        y[c2].y = pack2d(fmaf(fmaf(x0[2], rstd, nmr), g0.z, h0.z), fmaf(fmaf(x0[3], rstd, nmr), g0.w, h0.w));
+        y[c2].z = pack2d(fmaf(fmaf(x1[0], rstd, nmr), g1.x, h1.x), fmaf(fmaf(x1[1], rstd, nmr), g1.y, h1.y));
+        y[c2].w = pack2d(fmaf(fmaf(x1[2], rstd, nmr), g1.z, h1.z), fmaf(fmaf(x1[3], rstd, nmr), g1.w, h1.w));
+    }
+}
+
+struct TokArgs {
+    const u16* xin; int x_shared;        // d16 [Px, 4096, 256]
+    const u16* oper;                     // d16 [P, OPER_BYTES / 2]  (fold_frag_kernel)
+    const u16* tabq;                     // d16 [4096, 128]
+    const float* ln_w; const float* ln_b; float eps;
+    int Nt, nitems, KS;
+    u16* out;                            // d16 [P, 4096, 256] (may alias xin)
+};
+
+__global__ __launch_bounds__(NTHR, 2) void i2t_tok_kernel(TokArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[OPER_BYTES + 2 * C * 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    const int ks_sh = __builtin_ctz(a.KS), tpi_sh = 8 - ks_sh;          // 256 16-token tiles per prompt
+    const int TPI = 1 << tpi_sh, nt = TPI >> 2;                         // tiles per item / per wave
+    float* prm = (float*)(lds + OPER_BYTES);                            // ln_w [256], ln_b [256]
+    prm[tid] = a.ln_w[tid]; prm[C + tid] = a.ln_b[tid];
+    const WaveConst wc = wave_const(fr, fg, a.Nt);
+    const int voff = fr * (C * 2) + fg * 16;                 // stream / output: token row fr, 16-byte slot fg of a k-step
+    const int tvoff = fr * (CI * 2) + fg * 16;               // table
+    const rsrc_t rtab = make_rsrc(a.tabq, T * CI * 2);
+    const unsigned char* const L = lds + lane * 16;
+    const float* const gp = prm + fg * 8;
+
+    for (int item = (int)blockIdx.x; item < a.nitems; item += (int)gridDim.x) {
+        const int p = __builtin_amdgcn_readfirstlane(item >> ks_sh), split = __builtin_amdgcn_readfirstlane(item & (a.KS - 1));
+        __syncthreads();                                     // every wave is done with the previous prompt's operands
+        {
+            const uint4* src = (const uint4*)(a.oper + (long)p * (OPER_BYTES / 2));
+#pragma unroll 6
+            for (int i = tid; i < OPER_BYTES / 16; i += NTHR) ((uint4*)lds)[i] = src[i];
+        }
+        __syncthreads();
+        const rsrc_t rx = make_rsrc(a.xin + (long)(a.x_shared ? 0 : p) * T * C, T * C * 2);
+        const rsrc_t ro = make_rsrc(a.out + (long)p * T * C, T * C * 2);
+        const int tile0 = split * TPI + w;                   // this wave: tiles tile0 + 4 n
+
+        uint4 b[8], tb[4];
+#define TK_LOAD(tile_)                                                                             \
+        do {                                                                                       \
+            const int so_ = (tile_) * (16 * C * 2), to_ = (tile_) * (16 * CI * 2);                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) b[s_] = buf_load16(rx, voff, so_ + s_ * 64);      \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tb[s_] = buf_load16(rtab, tvoff, to_ + s_ * 64);  \
+        } while (0)
+        TK_LOAD(tile0);
+        // wait for the first tile HERE: the waits inside the loop are then set by the back edge alone (prefetch of the next tile
+        // with 8 younger stores: vmcnt(8)); entered with loads pending and no stores the loop header would need vmcnt(0),
+        // i.e. every iteration would also wait for the stores of the previous tile to reach L2
+        wait_vmem_all();
+        for (int n = 0; n < nt; ++n) {
+            // the operands in LDS are loop invariant: keep their reads inside the loop (hoisted they would need 400+ registers)
+            asm volatile("" ::: "memory");
+            const int tile = tile0 + 4 * n;
+            uint4 y[8];
+            i2t_block<KT_OFF, KF_OFF, VF_OFF, true>(L, gp, a.eps, b, tb, wc, y, [&]() {
+                // next tile of this wave into the (now free) fragment registers; unconditional (clamped) so that the compiler can
+                // count the younger stores and wait with vmcnt(n > 0) at the top of the next iteration
+                const int nx = tile0 + 4 * (n + 1 < nt ? n + 1 : nt - 1);
+                TK_LOAD(nx);
+            });
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2) buf_store16(y[c2], ro, voff, tile * (16 * C * 2) + c2 * 64);
+        }
+#undef TK_LOAD
+    }
+}
+
+// ============================================================================================================
+// Layer 0 on the SHARED source chained into layer 1 (AMG: every prompt of a tile starts from the same embedding).
+// keys1 = layer-0 output is never written: a wave recomputes its 16-token tile of keys1 from the L2-resident source
+// (src tile for the residual, q0 = (src + pe) Wq0^T + bq0 tile for the scores: two table-operand MFMAs per score tile instead of
+// the folded K' product) and feeds it - packed to 16 bits exactly as the stream would have stored it - straight into
+//   * i2t01_kernel: the layer-1 image->token block (its B fragments ARE the packed layer-0 output), result = keys2 -> HBM;
+//   * i2t0_t2i_kernel: the layer-1 token->image attention in token-owner form (below).
+// HBM traffic of the pair: 2 MiB per prompt written (keys2) instead of 2 written + 2 read + 2 read + 2 written.
+//
+// BLOCKED layout of everything these kernels load and store per tile.  A B / A operand fragment is "lane l & 15 = token, 8
+// channels 32 s + 8 (l >> 4) ..": on a row-major [token][channel] matrix consecutive lanes are a whole row (256 / 512 B) apart,
+// every lane is its own 16-byte request (64 per instruction instead of 8 x 128 B; measured: the loads alone set a floor of
+// 0.5 ms per 1024-prompt launch, profiles/r02_experiments.md).  The shared tables are therefore copied once per decode into
+//     blocked[tile of 16 tokens][k-step s][lane = 16 (l >> 4) + (l & 15)][8 channels]        (msam_chain_prepare_tables)
+// so that one fragment load is 1 KiB contiguous, lane-major; and the layer-1 output stream is WRITTEN in the same blocked
+// form (a tile stays 8 KiB contiguous): its two consumers, fold_attn_kernel and up_fused_kernel, stage whole tiles with
+// linear 16-byte chunks and only map chunk -> (token, channel chunk) differently (their `blocked` argument).
+struct ChainArgs {
+    const u16* src;                      // d16 blocked [256 tiles][8][64][8]   shared source (image embedding + no-mask embedding)
+    const u16* q0;                       // d16 blocked [256 tiles][4][64][8]   (src + pe) Wq0^T + bq0
+    const u16* oper0;                    // d16 [P, OPER_BYTES / 2] layer-0 operands (KT and VF parts used)
+    const float* ln0_w; const float* ln0_b;
+    const u16* oper1;                    // d16 [P, OPER_BYTES / 2] layer-1 operands
+    const u16* tabq1;                    // d16 blocked [256 tiles][4][64][8]
+    const float* ln1_w; const float* ln1_b;
+    float eps; int Nt, P;
+    u16* out;                            // d16 [P] blocked [256 tiles][8][64][8]  keys2
+};
+
+constexpr int NTHR8 = 512;
+// LDS images of the chained kernels (byte offsets)
+constexpr int C_KT0 = 0, C_VF0 = C_KT0 + KT_BYTES, C_KT1 = C_VF0 + VF_BYTES, C_KF1 = C_KT1 + KT_BYTES, C_VF1 = C_KF1 + KF_BYTES,
+              C_PRM = C_VF1 + VF_BYTES, C_LDS = C_PRM + 4 * C * 4;
+
+__global__ __launch_bounds__(NTHR8, 2) void i2t01_kernel(ChainArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    float* prm = (float*)(lds + C_PRM);                      // ln0_w, ln0_b, ln1_w, ln1_b
+    if (tid < C) { prm[tid] = a.ln0_w[tid]; prm[C + tid] = a.ln0_b[tid]; }
+    else { prm[2 * C + tid - C] = a.ln1_w[tid - C]; prm[3 * C + tid - C] = a.ln1_b[tid - C]; }
+    const WaveConst wc = wave_const(fr, fg, a.Nt);
+    const int voff = lane * 16, tvoff = lane * 16;      // blocked tables / stream: one fragment = 1 KiB contiguous, lane-major
+    const rsrc_t rsrc = make_rsrc(a.src, T * C * 2), rq0 = make_rsrc(a.q0, T * CI * 2), rtab = make_rsrc(a.tabq1, T * CI * 2);
+    const unsigned char* const L = lds + lane * 16;
+    const float* const gp0 = prm + fg * 8;
+    const float* const gp1 = prm + 2 * C + fg * 8;
+    constexpr int NT = 256 / 8;                              // tiles per wave and prompt
+
+    for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
+        __syncthreads();
+        {
+            const uint4* s0 = (const uint4*)(a.oper0 + (long)p * (OPER_BYTES / 2));
+            const uint4* s1 = (const uint4*)(a.oper1 + (long)p * (OPER_BYTES / 2));
+            for (int i = tid; i < KT_BYTES / 16; i += NTHR8) ((uint4*)(lds + C_KT0))[i] = s0[KT_OFF / 16 + i];
+            for (int i = tid; i < VF_BYTES / 16; i += NTHR8) ((uint4*)(lds + C_VF0))[i] = s0[VF_OFF / 16 + i];
+#pragma unroll 3
+            for (int i = tid; i < OPER_BYTES / 16; i += NTHR8) ((uint4*)(lds + C_KT1))[i] = s1[i];   // KT, KF, VF contiguous
+        }
+        __syncthreads();
+        const rsrc_t ro = make_rsrc(a.out + (long)p * T * C, T * C * 2);
+        uint4 b[8], qi[4], tb[4];
+#define CH_LOAD0(tile_)                                                                            \
+        do {                                                                                       \
+            const int so_ = (tile_) * (16 * C * 2), to_ = (tile_) * (16 * CI * 2);                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) b[s_] = buf_load16(rsrc, voff, so_ + s_ * FRAG);    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) qi[s_] = buf_load16(rq0, tvoff, to_ + s_ * FRAG);   \
+        } while (0)
+#define CH_LOAD1(tile_)                                                                            \
+        do {                                                                                       \
+            const int to_ = (tile_) * (16 * CI * 2);                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tb[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
+        } while (0)
+        CH_LOAD0(w); CH_LOAD1(w);
+        wait_vmem_all();                                     // see i2t_tok_kernel
+        for (int n = 0; n < NT; ++n) {
+            asm volatile("" ::: "memory");
+            const int tile = w + 8 * n, nx = w + 8 * (n + 1 < NT ? n + 1 : NT - 1);
+            uint4 y1[8], y2[8];
+            i2t_block<C_KT0, 0, C_VF0, false>(L, gp0, a.eps, b, qi, wc, y1, [&]() { CH_LOAD0(nx); });
+            i2t_block<C_KT1, C_KF1, C_VF1, true>(L, gp1, a.eps, y1, tb, wc, y2, [&]() { CH_LOAD1(nx); });
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2) buf_store16(y2[c2], ro, voff, tile * (16 * C * 2) + c2 * FRAG);
+        }
+#undef CH_LOAD0
+#undef CH_LOAD1
+    }
+}
+
+// ---- token -> image attention in token-owner form, on a tile that is already in registers.
+// The folded form (fold_attn_kernel) keeps O'[(h,t)][256 channels] per wave - 64 x 256 accumulators - which is why its
+// waves own (h,t) columns and all read the whole stream tile from LDS.  A wave that owns TOKENS instead projects its
+// tile to V = keys Wv^T first (8 heads x 16 channels) and accumulates O^T[d][(h,t)] per head: 32 accumulator registers.
+//   S[j][(h,t)]   = keys_j . Q'_{h,t} + tabK_j . q_{h,t}       A = the tile (rows = tokens), B = Q' / block-diagonal q (LDS)
+//   V[j][16h + d] = keys_j . Wv[16h + d]                        A = the tile, B = Wv rows (LDS, prompt independent)
+//   O^T_h[d][(h',t)] += sum_j V[j][16h + d] P[j][(h',t)]        A = V's accumulators, B = P's accumulators: an accumulator
+//        tile C[row = 4 (l >> 4) + r][col = l & 15] read as an operand has k = row, i.e. k = token for both - the transposes
+//        are free; only the columns of head h' = h are kept.  K = 16 tokens of the 32 k-slots (upper slots zero).
+// Softmax over the keys is online with a LAZY reference maximum per column: P = 2^(S - m_ref) with m_ref only raised (and
+// the accumulators rescaled) when some score exceeds it by more than 2^8 (one ballot per tile instead of cross-lane
+// maxima); the per-lane partial sums of P are reduced once per prompt.
+struct AttnState { f32x4_t o[8]; float m[4], l[4]; };
+
+template <int QD, int QF, int WV, class F>
+MSAM_DEVINL void t2i_block(const unsigned char* L, const uint4* y, const uint4* tk, AttnState& st, F&& consumed) {
+    f32x4_t s[4];
+    uint4 fa[4], fb[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) s[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    TK_RD4(fa, QF, 8 * FRAG);
+    TK_FENCE();
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {                            // groups 0..7: Q' k-steps, 8: block-diagonal q against the table tile
+        uint4* cur = (g & 1) ? fb : fa;
+        uint4* nxt = (g & 1) ? fa : fb;
+        if (g + 1 < 8) TK_RD4(nxt, QF + (g + 1) * FRAG, 8 * FRAG);
+        else if (g + 1 < 9) TK_RD4(nxt, QD, FRAG);
+        else TK_RD4(nxt, WV, 8 * FRAG);                      // first group of the V projection
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) s[ct] = mfma16d(g < 8 ? y[g < 8 ? g : 0] : tk[ct], cur[ct], s[ct]);
+        TK_FENCE();
+    }
+    consumed();
+    // ---- lazy online softmax over the keys (rows), per column fr of the four column tiles
+    float mloc[4];
+    bool need = false;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        mloc[ct] = fmaxf(fmaxf(s[ct][0], s[ct][1]), fmaxf(s[ct][2], s[ct][3]));
+        need = need || (mloc[ct] > st.m[ct] + 8.f);
+    }
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {            // wave-uniform: the reference maximum of some column is stale
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float mx = mloc[ct];
+            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(st.m[ct], mx), alpha = __builtin_amdgcn_exp2f(st.m[ct] - mn);
+            st.m[ct] = mn; st.l[ct] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st.o[2 * ct][r] *= alpha; st.o[2 * ct + 1][r] *= alpha; }
+        }
+    }
+    uint4 pb[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(s[ct][r] - st.m[ct]);
+        st.l[ct] += (e[0] + e[1]) + (e[2] + e[3]);
+        pb[ct] = make_uint4(pack2d(e[0], e[1]), pack2d(e[2], e[3]), 0u, 0u);
+    }
+    TK_FENCE();
+    // ---- V projection, four heads at a time, then O^T_h += V_h^T P
+#pragma unroll
+    for (int hv = 0; hv < 2; ++hv) {
+        f32x4_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int g = hv * 8 + ks;                       // group g: heads 4 hv .. + 3, k-step ks; group 0 was read into fb
+            uint4* cur = (g & 1) ? fa : fb;                   // by the last score group (g = 8: current fa, next fb)
+            uint4* nxt = (g & 1) ? fb : fa;
+            if (g + 1 < 16) TK_RD4(nxt, WV + (((g + 1) >> 3) * 32 + ((g + 1) & 7)) * FRAG, 8 * FRAG);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = mfma16d(y[ks], cur[j], v[j]);
+            TK_FENCE();
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int h = 4 * hv + j;
+            const uint4 va = make_uint4(pack2d(v[j][0], v[j][1]), pack2d(v[j][2], v[j][3]), 0u, 0u);
+            st.o[h] = mfma16d(va, pb[h >> 1], st.o[h]);
+        }
+        TK_FENCE();
+    }
+}
+
+struct FuseArgs {
+    const u16* src; const u16* q0;       // shared source and its layer-0 q (see ChainArgs)
+    const u16* oper0;                    // layer-0 image->token operands
+    const float* ln0_w; const float* ln0_b; float eps;
+    const u16* aoper;                    // d16 [P, AOPER_BYTES / 2]  layer-1 token->image operands: QD, QF (fold_attnfrag_kernel)
+    const u16* wvfrag;                   // d16 [WV_BYTES / 2]        Wv in fragment order (wv_frag_kernel)
+    const u16* tabk;                     // d16 blocked [256 tiles][4][64][8]  pe Wk^T + bk
+    const float* bv;                     // fp32 [128]
+    int Nt, P;
+    u16* out;                            // d16 [P, Nt, 128]
+    int tmask;                           // experiment knob (255): tile index mask of the shared-table loads
+};
+constexpr int QD_BYTES = 4 * FRAG, QF_BYTES = 4 * 8 * FRAG, AOPER_BYTES = QD_BYTES + QF_BYTES, WV_BYTES = 8 * 8 * FRAG;
+constexpr int F_KT0 = 0, F_VF0 = F_KT0 + KT_BYTES, F_QD = F_VF0 + VF_BYTES, F_QF = F_QD + QD_BYTES, F_WV = F_QF + QF_BYTES,
+              F_PRM = F_WV + WV_BYTES, F_LDS = F_PRM + 2 * C * 4;
+constexpr int MERGE_FLOATS = 64 + 64 + 64 * 16;              // per wave: m, l, O[(h,t)][d]
+static_assert(8 * MERGE_FLOATS * 4 <= F_WV, "merge scratch overlays the per-prompt operands");
+
+__global__ __launch_bounds__(NTHR8, 2) void i2t0_t2i_kernel(FuseArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[F_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    float* prm = (float*)(lds + F_PRM);
+    if (tid < C) prm[tid] = a.ln0_w[tid]; else prm[tid] = a.ln0_b[tid - C];
+    for (int i = tid; i < WV_BYTES / 16; i += NTHR8) ((uint4*)(lds + F_WV))[i] = ((const uint4*)a.wvfrag)[i];
+    const WaveConst wc = wave_const(fr, fg, a.Nt);
+    const int voff = lane * 16, tvoff = lane * 16;      // blocked tables / stream: one fragment = 1 KiB contiguous, lane-major
+    const rsrc_t rsrc = make_rsrc(a.src, T * C * 2), rq0 = make_rsrc(a.q0, T * CI * 2), rtab = make_rsrc(a.tabk, T * CI * 2);
+    const unsigned char* const L = lds + lane * 16;
+    const float* const gp0 = prm + fg * 8;
+    constexpr int NT = 256 / 8;
+
+    for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
+        __syncthreads();                                     // merge of the previous prompt done
+        {
+            const uint4* s0 = (const uint4*)(a.oper0 + (long)p * (OPER_BYTES / 2));
+            const uint4* s1 = (const uint4*)(a.aoper + (long)p * (AOPER_BYTES / 2));
+            for (int i = tid; i < KT_BYTES / 16; i += NTHR8) ((uint4*)(lds + F_KT0))[i] = s0[KT_OFF / 16 + i];
+            for (int i = tid; i < VF_BYTES / 16; i += NTHR8) ((uint4*)(lds + F_VF0))[i] = s0[VF_OFF / 16 + i];
+            for (int i = tid; i < AOPER_BYTES / 16; i += NTHR8) ((uint4*)(lds + F_QD))[i] = s1[i];        // QD, QF contiguous
+        }
+        __syncthreads();
+        AttnState st;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) st.o[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { st.m[ct] = NEG_BIG; st.l[ct] = 0.f; }
+        uint4 b[8], qi[4], tk[4];
+#define FU_LOAD0(tile_)                                                                            \
+        do {                                                                                       \
+            const int so_ = (tile_) * (16 * C * 2), to_ = (tile_) * (16 * CI * 2);                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) b[s_] = buf_load16(rsrc, voff, so_ + s_ * FRAG);    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) qi[s_] = buf_load16(rq0, tvoff, to_ + s_ * FRAG);   \
+        } while (0)
+#define FU_LOAD1(tile_)                                                                            \
+        do {                                                                                       \
+            const int to_ = (tile_) * (16 * CI * 2);                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tk[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
+        } while (0)
+        FU_LOAD0(w); FU_LOAD1(w);
+        for (int n = 0; n < NT; ++n) {
+            asm volatile("" ::: "memory");
+            const int nx = w + 8 * (n + 1 < NT ? n + 1 : NT - 1);
+            uint4 y1[8];
+            i2t_block<F_KT0, 0, F_VF0, false>(L, gp0, a.eps, b, qi, wc, y1, [&]() { FU_LOAD0(nx); });
+            t2i_block<F_QD, F_QF, F_WV>(L, y1, tk, st, [&]() { FU_LOAD1(nx); });
+        }
+#undef FU_LOAD0
+#undef FU_LOAD1
+        // ---- merge the eight waves' (m, l, O^T) and write out[p][t][16h + d] = O / l + bv
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { st.l[ct] += __shfl_xor(st.l[ct], 16); st.l[ct] += __shfl_xor(st.l[ct], 32); }
+        __syncthreads();                                     // every wave is done with the operands this scratch overlays
+        float* mg = (float*)lds + w * MERGE_FLOATS;
+        if (fg == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { mg[ct * 16 + fr] = st.m[ct]; mg[64 + ct * 16 + fr] = st.l[ct]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            if ((fr >> 3) == (h & 1))                        // column fr of column tile h >> 1 belongs to head h
+                *(float4*)(mg + 128 + (h * 8 + (fr & 7)) * 16 + fg * 4) = make_float4(st.o[h][0], st.o[h][1], st.o[h][2], st.o[h][3]);
+        __syncthreads();
+        {
+            const int col = tid >> 3, d0 = (tid & 7) * 2, h = col >> 3, t = col & 7;
+            const float* g0 = (const float*)lds;
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) mx = fmaxf(mx, g0[ww * MERGE_FLOATS + col]);
+            float lt = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) {
+                const float* gw = g0 + ww * MERGE_FLOATS;
+                const float sc = __builtin_amdgcn_exp2f(gw[col] - mx);
+                lt = fmaf(sc, gw[64 + col], lt);
+                o0 = fmaf(sc, gw[128 + col * 16 + d0], o0); o1 = fmaf(sc, gw[128 + col * 16 + d0 + 1], o1);
+            }
+            if (t < a.Nt) {
+                const float inv = 1.f / lt;
+                *(uint32_t*)(a.out + ((long)p * a.Nt + t) * CI + h * 16 + d0) =
+                    pack2d(fmaf(o0, inv, a.bv[h * 16 + d0]), fmaf(o1, inv, a.bv[h * 16 + d0 + 1]));
+            }
+        }
+    }
+}
+
+// ============================================================================================================
+// The same two chained kernels with the LDS operand reads organised as ONE stream per tile: every fragment of a tile, in the
+// order the MFMAs consume it, is fragment n of the stream; they are read in batches of G into a two-slot register ring, batch
+// k+1 while batch k is consumed - across the phase boundaries too (the batch after the last score batch is the first batch of
+// the next product), and across the tile boundary (the operands do not change within a prompt).  G = 4 is the scheme of the
+// kernels above; G = 8 / 16 keep 8 / 16 ds_read_b128 per wave in flight (the LDS latency under load is ~3 of the 16-cycle
+// MFMAs per batch of 4), which needs the registers of a 4-wave workgroup with ONE wave per SIMD (NW = 4: 512 VGPRs per wave).
+template <int G> struct Ring { uint4 buf[2][G]; };
+
+// ABL (ablation builds for tools/chain_ablation.py only; results are then meaningless): bit 0 no layer-0 score MFMAs, 1 no
+// layer-0 V'^T MFMAs, 2 no LayerNorm, 3 no attention score MFMAs, 4 no V-projection MFMAs, 5 no LDS operand reads, 6 no softmax exps
+template <int G, class Off, int ABL = 0>
+MSAM_DEVINL void ring_fill(Ring<G>& r, const unsigned char* L, int batch) {
+    if (ABL & 32) return;
+#pragma unroll
+    for (int j = 0; j < G; ++j) r.buf[batch & 1][j] = *(const uint4*)(L + Off::off((batch * G + j) % Off::N));
+}
+// at fragment n_ of the tile's stream: when it opens a batch, issue the reads of the next one
+#define RING_STEP(n_) do { if ((n_) % G == 0) { TK_FENCE(); ring_fill<G, Off, ABL>(ring, L, (n_) / G + 1); TK_FENCE(); } } while (0)
+#define RING_AT(n_) ring.buf[((n_) / G) & 1][(n_) % G]
+
+// image->token block (see i2t_block) on the fragments BASE .. of the stream: [8 or 40 score fragments][32 V'^T fragments]
+template <int G, class Off, int BASE, bool HAS_KF, int ABL = 0, class F>
+MSAM_DEVINL void i2t_block_r(Ring<G>& ring, const unsigned char* L, const float* gp, float eps, const uint4* b, const uint4* tb,
+                             const WaveConst& wc, uint4* y, F&& consumed) {
+    constexpr int NS = HAS_KF ? 40 : 8, G0 = HAS_KF ? 0 : 8;
+    f32x4_t s[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) s[m] = wc.sinit[m & 1];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int n = BASE + i, g = G0 + i / 4, m = i % 4;
+        RING_STEP(n);
+        if (!(ABL & 1)) s[m] = mfma16d(RING_AT(n), g < 8 ? b[g < 8 ? g : 0] : tb[2 * (m >> 1) + (g < 8 ? 0 : g - 8)], s[m]);
+        else if (i < 4) s[m][0] += __uint_as_float((RING_AT(n).x ^ tb[m].x) & 0x3fffffffu);
+    }
+    f32x4_t o[16];
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) o[ct] = mfma16d(wc.sel[ct & 1], b[ct >> 1], f32x4_t{0.f, 0.f, 0.f, 0.f});
+    consumed();
+    uint4 pk[2];
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2) {
+        const f32x4_t u = s[2 * a2], v = s[2 * a2 + 1];
+        const float mx = fmaxf(fmaxf(fmaxf(u[0], u[1]), fmaxf(u[2], u[3])), fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+        float eu[4], ev[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            eu[r] = (ABL & 64) ? u[r] - mx : __builtin_amdgcn_exp2f(u[r] - mx); ev[r] = (ABL & 64) ? v[r] - mx : __builtin_amdgcn_exp2f(v[r] - mx);
+        }
+        const float l = ((eu[0] + eu[1]) + (eu[2] + eu[3])) + ((ev[0] + ev[1]) + (ev[2] + ev[3]));
+        const float inv = __builtin_amdgcn_rcpf(l);
+        pk[a2] = make_uint4(pack2d(eu[0] * inv, eu[1] * inv), pack2d(eu[2] * inv, eu[3] * inv),
+                            pack2d(ev[0] * inv, ev[1] * inv), pack2d(ev[2] * inv, ev[3] * inv));
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int n = BASE + NS + i;
+        RING_STEP(n);
+        if (!(ABL & 2) || i % 16 == 0) o[i % 16] = mfma16d(RING_AT(n), pk[i / 16], o[i % 16]);
+    }
+    if (ABL & 4) {
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2)
+            y[c2] = make_uint4(pack2d(o[2 * c2][0], o[2 * c2][1]), pack2d(o[2 * c2][2], o[2 * c2][3]),
+                               pack2d(o[2 * c2 + 1][0], o[2 * c2 + 1][1]), pack2d(o[2 * c2 + 1][2], o[2 * c2 + 1][3]));
+        return;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1 += o[ct][r]; s2 = fmaf(o[ct][r], o[ct][r], s2); }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float mean = s1 * (1.f / C);
+    const float rstd = rsqrtf(fmaxf(s2 * (1.f / C) - mean * mean, 0.f) + eps);
+    const float nmr = -mean * rstd;
+#pragma unroll
+    for (int c2 = 0; c2 < 8; ++c2) {
+        const float4 g0 = *(const float4*)(gp + c2 * 32), g1 = *(const float4*)(gp + c2 * 32 + 4);
+        const float4 h0 = *(const float4*)(gp + C + c2 * 32), h1 = *(const float4*)(gp + C + c2 * 32 + 4);
+        const f32x4_t x0 = o[2 * c2], x1 = o[2 * c2 + 1];
+        y[c2].x = pack2d(fmaf(fmaf(x0[0], rstd, nmr), g0.x, h0.x), fmaf(fmaf(x0[1], rstd, nmr), g0.y, h0.y));
+        y[c2].y = pack2d(fmaf(fmaf(x0[2], rstd, nmr), g0.z, h0.z), fmaf(fmaf(x0[3], rstd, nmr), g0.w, h0.w));
+        y[c2].z = pack2d(fmaf(fmaf(x1[0], rstd, nmr), g1.x, h1.x), fmaf(fmaf(x1[1], rstd, nmr), g1.y, h1.y));
+        y[c2].w = pack2d(fmaf(fmaf(x1[2], rstd, nmr), g1.z, h1.z), fmaf(fmaf(x1[3], rstd, nmr), g1.w, h1.w));
+    }
+}
+
+// token->image block (see t2i_block) on the fragments BASE ..: [36 score fragments][64 Wv fragments, k-step major: all 8 heads]
+template <int G, class Off, int BASE, int ABL = 0, class F>
+MSAM_DEVINL void t2i_block_r(Ring<G>& ring, const unsigned char* L, const uint4* y, const uint4* tk, AttnState& st, F&& consumed) {
+    f32x4_t s[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) s[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const int n = BASE + i, g = i / 4, ct = i % 4;
+        RING_STEP(n);
+        if (!(ABL & 8)) s[ct] = mfma16d(g < 8 ? y[g < 8 ? g : 0] : tk[ct], RING_AT(n), s[ct]);
+        else if (i < 4) s[ct][0] += __uint_as_float((RING_AT(n).x ^ tk[ct].x ^ y[ct].x ^ y[4 + ct].y) & 0x3fffffffu);
+    }
+    consumed();
+    float mloc[4];
+    bool need = false;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        mloc[ct] = fmaxf(fmaxf(s[ct][0], s[ct][1]), fmaxf(s[ct][2], s[ct][3]));
+        need = need || (mloc[ct] > st.m[ct] + 8.f);
+    }
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float mx = mloc[ct];
+            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(st.m[ct], mx), alpha = __builtin_amdgcn_exp2f(st.m[ct] - mn);
+            st.m[ct] = mn; st.l[ct] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st.o[2 * ct][r] *= alpha; st.o[2 * ct + 1][r] *= alpha; }
+        }
+    }
+    uint4 pb[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = (ABL & 64) ? s[ct][r] - st.m[ct] : __builtin_amdgcn_exp2f(s[ct][r] - st.m[ct]);
+        st.l[ct] += (e[0] + e[1]) + (e[2] + e[3]);
+        pb[ct] = make_uint4(pack2d(e[0], e[1]), pack2d(e[2], e[3]), 0u, 0u);
+    }
+    f32x4_t v[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) v[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int n = BASE + 36 + i, ks = i / 8, h = i % 8;
+        RING_STEP(n);
+        if (!(ABL & 16) || ks == 0) v[h] = mfma16d(y[(ABL & 16) ? h : ks], RING_AT(n), v[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const uint4 va = make_uint4(pack2d(v[h][0], v[h][1]), pack2d(v[h][2], v[h][3]), 0u, 0u);
+        st.o[h] = mfma16d(va, pb[h >> 1], st.o[h]);
+    }
+}
+
+// fragment streams (byte offsets in the kernels' LDS images); N = fragments per tile incl. padding reads: a multiple of 2 G
+template <int G> struct ChainOff {                           // i2t01: [KT0 8][VF0 32][KF1 / KT1 40][VF1 32]
+    static constexpr int USED = 112, N = ((USED + 2 * G - 1) / (2 * G)) * (2 * G);
+    static __device__ constexpr int off(int n) {
+        if (n < 8) return C_KT0 + ((n % 4) * 2 + n / 4) * FRAG;
+        if (n < 40) return C_VF0 + (n - 8) * FRAG;
+        if (n < 80) { const int i = n - 40, g = i / 4, m = i % 4; return g < 8 ? C_KF1 + (m * 8 + g) * FRAG : C_KT1 + (m * 2 + (g - 8)) * FRAG; }
+        if (n < 112) return C_VF1 + (n - 80) * FRAG;
+        return C_KT0;                                        // padding
+    }
+};
+template <int G> struct FuseOff {                            // i2t0_t2i: [KT0 8][VF0 32][QF / QD 36][WV 64]
+    static constexpr int USED = 140, N = ((USED + 2 * G - 1) / (2 * G)) * (2 * G);
+    static __device__ constexpr int off(int n) {
+        if (n < 8) return F_KT0 + ((n % 4) * 2 + n / 4) * FRAG;
+        if (n < 40) return F_VF0 + (n - 8) * FRAG;
+        if (n < 76) { const int i = n - 40, g = i / 4, ct = i % 4; return g < 8 ? F_QF + (ct * 8 + g) * FRAG : F_QD + ct * FRAG; }
+        if (n < 140) { const int i = n - 76, ks = i / 8, h = i % 8; return F_WV + (h * 8 + ks) * FRAG; }
+        return F_KT0;                                        // padding
+    }
+};
+
+template <int NW, int G>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(ChainArgs a) {
+    typedef ChainOff<G> Off;
+    constexpr int ABL = 0;
+    constexpr int NTH = 64 * NW, NT = 256 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    float* prm = (float*)(lds + C_PRM);                      // ln0_w, ln0_b, ln1_w, ln1_b
+    for (int i = tid; i < 4 * C; i += NTH) prm[i] = i < C ? a.ln0_w[i] : i < 2 * C ? a.ln0_b[i - C] : i < 3 * C ? a.ln1_w[i - 2 * C] : a.ln1_b[i - 3 * C];
+    const WaveConst wc = wave_const(fr, fg, a.Nt);
+    const int voff = lane * 16, tvoff = lane * 16;      // blocked tables / stream: one fragment = 1 KiB contiguous, lane-major
+    const rsrc_t rsrc = make_rsrc(a.src, T * C * 2), rq0 = make_rsrc(a.q0, T * CI * 2), rtab = make_rsrc(a.tabq1, T * CI * 2);
+    const unsigned char* const L = lds + lane * 16;
+    const float* const gp0 = prm + fg * 8;
+    const float* const gp1 = prm + 2 * C + fg * 8;
+    Ring<G> ring;
+    for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
+        __syncthreads();
+        {
+            const uint4* s0 = (const uint4*)(a.oper0 + (long)p * (OPER_BYTES / 2));
+            const uint4* s1 = (const uint4*)(a.oper1 + (long)p * (OPER_BYTES / 2));
+            for (int i = tid; i < KT_BYTES / 16; i += NTH) ((uint4*)(lds + C_KT0))[i] = s0[KT_OFF / 16 + i];
+            for (int i = tid; i < VF_BYTES / 16; i += NTH) ((uint4*)(lds + C_VF0))[i] = s0[VF_OFF / 16 + i];
+#pragma unroll 3
+            for (int i = tid; i < OPER_BYTES / 16; i += NTH) ((uint4*)(lds + C_KT1))[i] = s1[i];
+        }
+        __syncthreads();
+        const rsrc_t ro = make_rsrc(a.out + (long)p * T * C, T * C * 2);
+        uint4 b[8], qi[4], tb[4];
+#define CH_LOAD0(tile_)                                                                            \
+        do {                                                                                       \
+            const int so_ = (tile_) * (16 * C * 2), to_ = (tile_) * (16 * CI * 2);                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) b[s_] = buf_load16(rsrc, voff, so_ + s_ * FRAG);    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) qi[s_] = buf_load16(rq0, tvoff, to_ + s_ * FRAG);   \
+        } while (0)
+#define CH_LOAD1(tile_)                                                                            \
+        do {                                                                                       \
+            const int to_ = (tile_) * (16 * CI * 2);                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tb[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
+        } while (0)
+        CH_LOAD0(w); CH_LOAD1(w);
+        wait_vmem_all();
+        ring_fill<G, Off>(ring, L, 0);
+        for (int n = 0; n < NT; ++n) {
+            asm volatile("" ::: "memory");
+            const int tile = w + NW * n, nx = w + NW * (n + 1 < NT ? n + 1 : NT - 1);
+            uint4 y1[8], y2[8];
+            i2t_block_r<G, Off, 0, false>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { CH_LOAD0(nx); });
+            i2t_block_r<G, Off, 40, true>(ring, L, gp1, a.eps, y1, tb, wc, y2, [&]() { CH_LOAD1(nx); });
+#pragma unroll
+            for (int i = Off::USED; i < Off::N; ++i) RING_STEP(i);
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2) buf_store16(y2[c2], ro, voff, tile * (16 * C * 2) + c2 * FRAG);
+        }
+#undef CH_LOAD0
+#undef CH_LOAD1
+    }
+}
+
+template <int NW, int G, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel(FuseArgs a) {
+    typedef FuseOff<G> Off;
+    constexpr int NTH = 64 * NW, NT = 256 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[F_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    float* prm = (float*)(lds + F_PRM);
+    for (int i = tid; i < 2 * C; i += NTH) prm[i] = i < C ? a.ln0_w[i] : a.ln0_b[i - C];
+    for (int i = tid; i < WV_BYTES / 16; i += NTH) ((uint4*)(lds + F_WV))[i] = ((const uint4*)a.wvfrag)[i];
+    const WaveConst wc = wave_const(fr, fg, a.Nt);
+    const int voff = lane * 16, tvoff = lane * 16;      // blocked tables / stream: one fragment = 1 KiB contiguous, lane-major
+    const rsrc_t rsrc = make_rsrc(a.src, T * C * 2), rq0 = make_rsrc(a.q0, T * CI * 2), rtab = make_rsrc(a.tabk, T * CI * 2);
+    const unsigned char* const L = lds + lane * 16;
+    const float* const gp0 = prm + fg * 8;
+    Ring<G> ring;
+    for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
+        __syncthreads();
+        {
+            const uint4* s0 = (const uint4*)(a.oper0 + (long)p * (OPER_BYTES / 2));
+            const uint4* s1 = (const uint4*)(a.aoper + (long)p * (AOPER_BYTES / 2));
+            for (int i = tid; i < KT_BYTES / 16; i += NTH) ((uint4*)(lds + F_KT0))[i] = s0[KT_OFF / 16 + i];
+            for (int i = tid; i < VF_BYTES / 16; i += NTH) ((uint4*)(lds + F_VF0))[i] = s0[VF_OFF / 16 + i];
+            for (int i = tid; i < AOPER_BYTES / 16; i += NTH) ((uint4*)(lds + F_QD))[i] = s1[i];
+        }
+        __syncthreads();
+        AttnState st;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) st.o[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { st.m[ct] = NEG_BIG; st.l[ct] = 0.f; }
+        uint4 b[8], qi[4], tk[4];
+#define FU_LOAD0(tile_)                                                                            \
+        do {                                                                                       \
+            const int so_ = (tile_) * (16 * C * 2), to_ = (tile_) * (16 * CI * 2);                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) b[s_] = buf_load16(rsrc, voff, so_ + s_ * FRAG);    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) qi[s_] = buf_load16(rq0, tvoff, to_ + s_ * FRAG);   \
+        } while (0)
+#define FU_LOAD1(tile_)                                                                            \
+        do {                                                                                       \
+            const int to_ = (tile_) * (16 * CI * 2);                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tk[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
+        } while (0)
+        FU_LOAD0(w & a.tmask); FU_LOAD1(w & a.tmask);
+        if (ABL & 32) {
+#pragma unroll
+            for (int j = 0; j < G; ++j) ring.buf[0][j] = ring.buf[1][j] = make_uint4(tid, lane, 0x3c003c00u, 0x3c003c00u);
+        }
+        ring_fill<G, Off, ABL>(ring, L, 0);
+        for (int n = 0; n < NT; ++n) {
+            asm volatile("" ::: "memory");
+            const int nx = (w + NW * (n + 1 < NT ? n + 1 : NT - 1)) & a.tmask;
+            uint4 y1[8];
+            i2t_block_r<G, Off, 0, false, ABL>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { FU_LOAD0(nx); });
+            t2i_block_r<G, Off, 40, ABL>(ring, L, y1, tk, st, [&]() { FU_LOAD1(nx); });
+#pragma unroll
+            for (int i = Off::USED; i < Off::N; ++i) RING_STEP(i);
+        }
+#undef FU_LOAD0
+#undef FU_LOAD1
+        // ---- merge the waves' (m, l, O^T) and write out[p][t][16h + d] = O / l + bv
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { st.l[ct] += __shfl_xor(st.l[ct], 16); st.l[ct] += __shfl_xor(st.l[ct], 32); }
+        __syncthreads();
+        float* mg = (float*)lds + w * MERGE_FLOATS;
+        if (fg == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { mg[ct * 16 + fr] = st.m[ct]; mg[64 + ct * 16 + fr] = st.l[ct]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            if ((fr >> 3) == (h & 1))
+                *(float4*)(mg + 128 + (h * 8 + (fr & 7)) * 16 + fg * 4) = make_float4(st.o[h][0], st.o[h][1], st.o[h][2], st.o[h][3]);
+        __syncthreads();
+        for (int idx = tid; idx < 512; idx += NTH) {
+            const int col = idx >> 3, d0 = (idx & 7) * 2, h = col >> 3, t = col & 7;
+            const float* g0 = (const float*)lds;
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) mx = fmaxf(mx, g0[ww * MERGE_FLOATS + col]);
+            float lt = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float* gw = g0 + ww * MERGE_FLOATS;
+                const float sc = __builtin_amdgcn_exp2f(gw[col] - mx);
+                lt = fmaf(sc, gw[64 + col], lt);
+                o0 = fmaf(sc, gw[128 + col * 16 + d0], o0); o1 = fmaf(sc, gw[128 + col * 16 + d0 + 1], o1);
+            }
+            if (t < a.Nt) {
+                const float inv = 1.f / lt;
+                *(uint32_t*)(a.out + ((long)p * a.Nt + t) * CI + h * 16 + d0) =
+                    pack2d(fmaf(o0, inv, a.bv[h * 16 + d0]), fmaf(o1, inv, a.bv[h * 16 + d0 + 1]));
+            }
+        }
+    }
+}
+
+// token -> image operands of one prompt in fragment order (B operands: lane = fg * 16 + fr holds B[k = 8 fg + i][col fr]):
+//   QD [ct]     : col fr = (head 2 ct + (fr >> 3), token fr & 7), k = table channel 32 ct + 8 fg + i: SCALE q[t][ch] on the head's
+//                 own 16 channels, else 0
+//   QF [ct][ks] : same columns, k = channel 32 ks + 8 fg + i: SCALE Q'_{h,t}[c],  Q'_{h,t} = Wk_h^T q_{h,t}
+__global__ __launch_bounds__(256) void fold_attnfrag_kernel(const u16* __restrict__ qtok, const u16* __restrict__ wk, int Nt,
+                                                            u16* __restrict__ aoper) {
+    __shared__ __attribute__((aligned(16))) u16 img[AOPER_BYTES / 2];
+    __shared__ float qq[8][CI];
+    const int p = blockIdx.x, c = threadIdx.x;
+    for (int i = c; i < 8 * CI; i += 256) {
+        const int t = i >> 7, d = i & (CI - 1);
+        qq[t][d] = t < Nt ? d2f(qtok[((long)p * Nt + t) * CI + d]) : 0.f;
+    }
+    for (int i = c; i < QD_BYTES / 16; i += 256) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    {
+        const int ks = c >> 5, fg = (c >> 3) & 3, ii = c & 7;
+        for (int h = 0; h < 8; ++h) {
+            float w[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) w[d] = d2f(wk[(h * 16 + d) * C + c]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) acc = fmaf(qq[t][h * 16 + d], w[d], acc);
+                const int ct = h >> 1, fr = (h & 1) * 8 + t;
+                img[QD_BYTES / 2 + ((ct * 8 + ks) * 64 + fg * 16 + fr) * 8 + ii] = f2d(acc * SCALE);
+            }
+        }
+    }
+    for (int j = c; j < 8 * 8 * 16; j += 256) {
+        const int h = j >> 7, t = (j >> 4) & 7, d = j & 15;
+        const int ct = h >> 1, fr = (h & 1) * 8 + t, fg = 2 * (h & 1) + (d >> 3);
+        img[(ct * 64 + fg * 16 + fr) * 8 + (d & 7)] = f2d(qq[t][h * 16 + d] * SCALE);
+    }
+    __syncthreads();
+    uint4* dst = (uint4*)(aoper + (long)p * (AOPER_BYTES / 2));
+    for (int i = c; i < AOPER_BYTES / 16; i += 256) dst[i] = ((const uint4*)img)[i];
+}
+
+// row-major [4096][W] -> blocked [tile][s][lane][8] (W = 256 or 128); one 16-byte chunk per thread
+__global__ __launch_bounds__(256) void to_blocked_kernel(const u16* __restrict__ src, const u16* __restrict__ q0,
+                                                         const u16* __restrict__ tabk, const u16* __restrict__ tabq,
+                                                         u16* __restrict__ out) {
+    const int id = blockIdx.x * 256 + threadIdx.x;           // chunk ids: src 4096 * 32, then three tables of 4096 * 16
+    const u16* in; int W, q; u16* o;
+    if (id < T * 32) { in = src; W = C; q = id; o = out; }
+    else {
+        const int j = id - T * 32, tb = j / (T * 16);
+        in = tb == 0 ? q0 : tb == 1 ? tabk : tabq; W = CI; q = j - tb * (T * 16); o = out + (long)T * C + (long)tb * T * CI;
+    }
+    // destination chunk q of the blocked image: tile, s, lane (fg, fr)
+    const int per_tile = 16 * W / 8, tile = q / per_tile, r = q % per_tile, sidx = r >> 6, lane = r & 63, fg = lane >> 4, fr = lane & 15;
+    ((uint4*)o)[q] = *(const uint4*)(in + (long)(tile * 16 + fr) * W + sidx * 32 + fg * 8);
+}
+
+// Wv [128][256] in fragment order: [dv][ks][lane][8]: col fr = row 16 dv + fr of Wv, k = channel 32 ks + 8 fg + i
+__global__ __launch_bounds__(256) void wv_frag_kernel(const u16* __restrict__ wv, u16* __restrict__ wvfrag) {
+    const int id = blockIdx.x * 256 + threadIdx.x;           // one 16-byte chunk each: 128 rows x 32 chunks
+    const int row = id >> 5, ch = id & 31, dv = row >> 4, fr = row & 15, ks = ch >> 2, fg = ch & 3;
+    ((uint4*)wvfrag)[(dv * 8 + ks) * 64 + fg * 16 + fr] = *(const uint4*)(wv + (long)row * C + ch * 8);
+}
+
+}  // namespace
+
+int64_t msam_i2t_tok_workspace_bytes(int32_t P) { return (int64_t)P * OPER_BYTES; }
+
+static int cu_count() {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus;
+}
+
+// same contract as msam_i2t_fold_layer (decfold.hip), which dispatches here
+int msam_i2t_tok_layer(const void* xin, int32_t x_shared, const void* ktok, const void* vtok, int32_t P, int32_t Nt,
+                       const void* wq, const void* tabq, const void* wo, const float* bo, const float* ln_w,
+                       const float* ln_b, float ln_eps, void* out, void* workspace, int KS, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    u16* oper = (u16*)workspace;
+    hipLaunchKernelGGL(fold_frag_kernel, dim3(P), dim3(256), 0, s, (const u16*)ktok, (const u16*)vtok, (const u16*)wq,
+                       (const u16*)wo, bo, Nt, 1, oper);
+    if (int e = msam_check_launch("fold_frag")) return e;
+    TokArgs a{};
+    a.xin = (const u16*)xin; a.x_shared = x_shared; a.oper = oper; a.tabq = (const u16*)tabq;
+    a.ln_w = ln_w; a.ln_b = ln_b; a.eps = ln_eps; a.Nt = Nt; a.KS = KS; a.nitems = P * KS; a.out = (u16*)out;
+    const int wgs = g_tune_i2t_wg_per_cu * cu_count();
+    const int grid = a.nitems < wgs ? a.nitems : wgs;
+    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32);
+    const double bytes = (double)(x_shared ? 1 : P) * T * C * 2 + (double)P * T * C * 2;
+    msam_profile_mark2(stream, 1, flops, bytes, 2);
+    hipLaunchKernelGGL(i2t_tok_kernel, dim3(grid), dim3(NTHR), 0, s, a);
+    msam_profile_mark2(stream, 0, flops, bytes, 2);
+    return msam_check_launch("i2t_tok");
+}
+
+// ---- chained forms on a shared source (include/msam_hip.h: msam_i2t_fold_operands, msam_i2t0_t2i_fused, msam_i2t01_fused)
+extern "C" int64_t msam_i2t_fold_operand_bytes(int32_t P) { return (int64_t)P * OPER_BYTES; }
+
+extern "C" int msam_i2t_fold_operands(const void* ktok, const void* vtok, int32_t P, int32_t Nt, const void* wq, const void* wo,
+                                      const float* bo, int32_t with_kfold, void* operands, void* stream) {
+    if (!ktok || !vtok || !wq || !wo || !bo || !operands || P <= 0) { msam_set_error("msam_i2t_fold_operands: null argument"); return 1; }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t_fold_operands: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    hipLaunchKernelGGL(fold_frag_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const u16*)ktok, (const u16*)vtok,
+                       (const u16*)wq, (const u16*)wo, bo, Nt, with_kfold, (u16*)operands);
+    return msam_check_launch("fold_frag");
+}
+
+extern "C" int64_t msam_chain_tables_bytes(void) { return (int64_t)T * C * 2 + 3L * T * CI * 2; }
+
+extern "C" int msam_chain_prepare_tables(const void* src, const void* q0, const void* tabk, const void* tabq1, void* tables,
+                                         void* stream) {
+    if (!src || !q0 || !tabk || !tabq1 || !tables) { msam_set_error("msam_chain_prepare_tables: null argument"); return 1; }
+    hipLaunchKernelGGL(to_blocked_kernel, dim3((T * 32 + 3 * T * 16) / 256), dim3(256), 0, (hipStream_t)stream, (const u16*)src,
+                       (const u16*)q0, (const u16*)tabk, (const u16*)tabq1, (u16*)tables);
+    return msam_check_launch("to_blocked");
+}
+
+extern "C" int64_t msam_i2t0_t2i_workspace_bytes(int32_t P) { return (int64_t)P * AOPER_BYTES + WV_BYTES; }
+
+extern "C" int msam_i2t0_t2i_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b,
+                                   float ln_eps, const void* qtok, int32_t P, int32_t Nt, const void* wk,
+                                   const void* wv, const float* bv, void* out, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
+    const u16* src = (const u16*)tables;
+    const u16* q0 = src ? src + (long)T * C : nullptr;
+    const u16* tabk = src ? q0 + (long)T * CI : nullptr;
+    if (!src || !operands0 || !ln0_w || !ln0_b || !qtok || !wk || !wv || !bv || !out || !workspace || P <= 0) {
+        msam_set_error("msam_i2t0_t2i_fused: null argument");
+        return 1;
+    }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t0_t2i_fused: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    if (workspace_bytes < msam_i2t0_t2i_workspace_bytes(P)) { msam_set_error("msam_i2t0_t2i_fused: workspace too small"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    u16* wvfrag = (u16*)workspace;
+    u16* aoper = wvfrag + WV_BYTES / 2;
+    hipLaunchKernelGGL(wv_frag_kernel, dim3(128 * 32 / 256), dim3(256), 0, s, (const u16*)wv, wvfrag);
+    if (int e = msam_check_launch("wv_frag")) return e;
+    hipLaunchKernelGGL(fold_attnfrag_kernel, dim3(P), dim3(256), 0, s, (const u16*)qtok, (const u16*)wk, Nt, aoper);
+    if (int e = msam_check_launch("fold_attnfrag")) return e;
+    FuseArgs a{};
+    a.src = (const u16*)src; a.q0 = (const u16*)q0; a.oper0 = (const u16*)operands0; a.ln0_w = ln0_w; a.ln0_b = ln0_b; a.eps = ln_eps;
+    a.aoper = aoper; a.wvfrag = wvfrag; a.tabk = (const u16*)tabk; a.bv = bv; a.Nt = Nt; a.P = P; a.out = (u16*)out; a.tmask = g_tune_chain_tmask;
+    const int cus = cu_count(), grid = P < cus ? P : cus;
+    // algorithmic work of the two stages it replaces (image->token layer 0 + token->image attention of layer 1)
+    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32) * 2;
+    msam_profile_mark2(stream, 1, flops, 0.0, 3);
+    switch (g_tune_chain_variant) {
+        case 1: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<4, 8>), dim3(grid), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<4, 16>), dim3(grid), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, s, a); break;
+#define ABL_CASE(m_) case 100 + m_: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, m_>), dim3(grid), dim3(512), 0, s, a); break;
+        ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(64) ABL_CASE(27) ABL_CASE(31) ABL_CASE(127)
+#undef ABL_CASE
+        default: hipLaunchKernelGGL(i2t0_t2i_kernel, dim3(grid), dim3(NTHR8), 0, s, a);
+    }
+    msam_profile_mark2(stream, 0, flops, 0.0, 3);
+    return msam_check_launch("i2t0_t2i");
+}
+
+extern "C" int msam_i2t01_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b,
+                                const void* operands1, const float* ln1_w, const float* ln1_b, float ln_eps,
+                                int32_t P, int32_t Nt, void* out, void* stream) {
+    const u16* src = (const u16*)tables;
+    const u16* q0 = src ? src + (long)T * C : nullptr;
+    const u16* tabq1 = src ? q0 + 2L * T * CI : nullptr;
+    if (!src || !operands0 || !ln0_w || !ln0_b || !operands1 || !ln1_w || !ln1_b || !out || P <= 0) {
+        msam_set_error("msam_i2t01_fused: null argument");
+        return 1;
+    }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t01_fused: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    ChainArgs a{};
+    a.src = (const u16*)src; a.q0 = (const u16*)q0; a.oper0 = (const u16*)operands0; a.ln0_w = ln0_w; a.ln0_b = ln0_b;
+    a.oper1 = (const u16*)operands1; a.tabq1 = (const u16*)tabq1; a.ln1_w = ln1_w; a.ln1_b = ln1_b; a.eps = ln_eps;
+    a.Nt = Nt; a.P = P; a.out = (u16*)out;
+    const int cus = cu_count(), grid = P < cus ? P : cus;
+    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32) * 2;
+    const double bytes = (double)P * T * C * 2;
+    msam_profile_mark2(stream, 1, flops, bytes, 2);
+    switch (g_tune_chain_variant) {
+        case 1: hipLaunchKernelGGL((i2t01_ring_kernel<4, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL((i2t01_ring_kernel<4, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        case 3: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL(i2t01_kernel, dim3(grid), dim3(NTHR8), 0, (hipStream_t)stream, a);
+    }
+    msam_profile_mark2(stream, 0, flops, bytes, 2);
+    return msam_check_launch("i2t01");
+}

@@ -602,6 +602,7 @@ extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void*
                 nullptr, 0, 0, 0, c.pe_q[0], CI);
 }
 
+extern int g_tune_dec_chain, g_tune_dec_chain_min_p;
 namespace {
 struct Work {
     float *qpe, *queries, *tmp; u16 *a, *b, *qs, *ks, *vs, *attn_tok, *mlp_h;
@@ -642,12 +643,12 @@ Work carve_work(void* base, int P, int Nt) {
 
 // token -> image attention over the per-prompt stream w.keys: folded form (one pass over the stream, decfold.hip) for
 // up to 8 tokens per prompt, explicit K / V^T projection + attention kernel otherwise
-int t2i_stream(const Ctx& cx, const Work& w, const Consts& c, int idx, const msam_attn_w_t& aw, int P, int Nt) {
+int t2i_stream(const Ctx& cx, const Work& w, const Consts& c, int idx, const msam_attn_w_t& aw, int P, int Nt, bool blocked = false) {
     const long R = (long)P * T;
     if (Nt <= 8) {
         // workspace of the folded form = the (then unused) K / V^T / q / attention stream buffers, contiguous in `Work`
         const int64_t avail = (int64_t)((char*)w.up1 - (char*)w.kimg);
-        return msam_t2i_fold_attention(w.keys, 0, w.qs, P, Nt, aw.k_w, c.tab_k[idx], aw.v_w, aw.v_b, w.attn_tok, w.kimg,
+        return msam_t2i_fold_attention(w.keys, blocked ? 2 : 0, w.qs, P, Nt, aw.k_w, c.tab_k[idx], aw.v_w, aw.v_b, w.attn_tok, w.kimg,
                                        avail, cx.s);
     }
     if (int e = wsgemm_kv(cx, w.keys, c.wkv[idx], c.bkv[idx], c.pe_k[idx], (int)R, w.kimg, w.vT)) return e;
@@ -773,6 +774,14 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     // can be compared with the oracle's per-layer taps (outputs are then NOT the model's outputs)
     const char* dbg = getenv("MSAM_DEBUG_DEC_LAYERS");
     const int nlayers = dbg ? atoi(dbg) : 2;
+    // Chained form (decfold_tok.hip): with one shared source the layer-0 output stream is not written; the layer-1
+    // token->image attention and the layer-1 image->token block recompute their tiles of it from the L2-resident source.
+    const bool chain = g_tune_dec_chain && !own_src && !dbg && Nt <= 8 && P >= g_tune_dec_chain_min_p;
+    // operand images in the (then unused) q / attention stream buffers: layer 0, layer 1; the attention's operands in vT
+    void* const oper0 = w.qimg; void* const oper1 = w.attn_img;
+    // blocked copies of the shared tables (source, layer-0 q, tabK / tabQ of layer 1) at the end of the attention workspace in vT
+    void* const tables = (char*)w.vT + (int64_t)R * CI * 2 - msam_chain_tables_bytes();
+    if (chain) CHECK(msam_chain_prepare_tables(im.src_bf16, im.q0, c.tab_k[1], c.tab_q[1], tables, cx.s));
     for (int li = 0; li < nlayers && li < 2; ++li) {
         const msam_twoway_layer_t& L = dec->layer[li];
         // (1) token self attention
@@ -801,6 +810,10 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
             else
                 hipLaunchKernelGGL(t2i_attn_kernel, dim3(P * 8), dim3(256), 0, cx.s, w.qs, im.k0, im.vT0, 1, Nt, w.attn_tok);
             CHECK(msam_check_launch("t2i_attn"));
+        } else if (chain) {
+            const msam_twoway_layer_t& L0 = dec->layer[0];
+            CHECK(msam_i2t0_t2i_fused(tables, oper0, L0.n4_w, L0.n4_b, 1e-5f, w.qs, P, Nt, L.t2i.k_w, L.t2i.v_w, L.t2i.v_b,
+                                      w.attn_tok, w.vT, (int64_t)R * CI * 2 - msam_chain_tables_bytes(), cx.s));
         } else {
             CHECK(t2i_stream(cx, w, c, li, L.t2i, P, Nt));
         }
@@ -820,7 +833,13 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         }
         // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
         // for up to 8 tokens per prompt, weights-stationary fused kernel (declayer.hip) otherwise
-        if (Nt <= 8) {
+        if (chain) {
+            CHECK(msam_i2t_fold_operands(w.ks, w.vs, P, Nt, L.i2t.q_w, L.i2t.o_w, L.i2t.o_b, li, li == 0 ? oper0 : oper1, cx.s));
+            if (li == 1) {
+                const msam_twoway_layer_t& L0 = dec->layer[0];
+                CHECK(msam_i2t01_fused(tables, oper0, L0.n4_w, L0.n4_b, oper1, L.n4_w, L.n4_b, 1e-5f, P, Nt, w.keys, cx.s));   // blocked stream
+            }
+        } else if (Nt <= 8) {
             const bool shared = li == 0 && !own_src;
             CHECK(msam_i2t_fold_layer(shared ? (const void*)im.src_bf16 : (const void*)w.keys, shared, w.ks, w.vs, P, Nt,
                                       L.i2t.q_w, c.tab_q[li], L.i2t.o_w, L.i2t.o_b, L.n4_w, L.n4_b, 1e-5f, w.keys, w.qimg,
@@ -838,7 +857,7 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     // final token -> image attention
     ADD_CAST(w.queries, w.qpe, w.a);
     CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_D16, CI));
-    CHECK(t2i_stream(cx, w, c, 2, dec->final_attn, P, Nt));
+    CHECK(t2i_stream(cx, w, c, 2, dec->final_attn, P, Nt, chain));
     CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
                MSAM_F32, C));
     LN(w.tmp, dec->nf_w, dec->nf_b, M, w.queries, MSAM_F32);
@@ -872,8 +891,8 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     CHECK(msam_check_launch("gather_iou"));
 
     // up-scaling (ConvT1 + LayerNorm2d + GELU + ConvT2 + GELU) and hyper-network product in one pass over the stream
-    CHECK(msam_upscale_fused(w.keys, P, dec->up1_w, dec->up1_b, dec->up_ln_w, dec->up_ln_b, 1e-6f, dec->up2_w, dec->up2_b,
-                             w.hyper, 128, mask0, nmask, low_res, cx.s));
+    CHECK(msam_upscale_fused_layout(w.keys, chain ? 1 : 0, P, dec->up1_w, dec->up1_b, dec->up_ln_w, dec->up_ln_b, 1e-6f, dec->up2_w,
+                                    dec->up2_b, w.hyper, 128, mask0, nmask, low_res, cx.s));
 #undef CHECK
 #undef ADD_CAST
 #undef ADD_CAST2

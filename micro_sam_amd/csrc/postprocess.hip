@@ -122,17 +122,35 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
                     // separate issue port) instead of a subtract + alignbit per pixel on the VALU: 6 instead of 8 VALU
                     // instructions per pixel in this VALU-bound loop (same comparisons: v > t  <=>  sign(t - v) set)
                     int s_hi = 0, s_lo = 0;
-#pragma unroll
-                    for (int b = 0; b < 32; ++b) {
-                        float w1 = W1[b & 3];
-                        if (b < 2 && yw == 0) w1 = 0.0f;
-                        const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
-                        if (LOGITS) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
-                        wm = __builtin_amdgcn_alignbit(wm, __float_as_uint(__fsub_rn(thr, v)), 31);
-                        s_hi += __popcll(__ballot(v > hi_t));
-                        s_lo += __popcll(__ballot(v > lo_t));
+                    // Decided words: every pixel of the word is a convex combination of two of the ten t[k] (vertical weights
+                    // w0 + w1 = 1 exactly), so it lies in [min t, max t] up to two fp32 roundings (< 0.003 for |t| < 8192).  If
+                    // that interval clears all three thresholds by 0.01 on the same side the 32 comparisons are known without
+                    // interpolating - for a real mask that is every word away from the object boundary.  The whole wave must be
+                    // decided (ballot): otherwise the exact per-pixel path below runs for all of its lanes.
+                    bool decided = false;
+                    if (!LOGITS) {
+                        const float tmin = fminf(fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), fminf(fminf(t[4], t[5]), fminf(fminf(t[6], t[7]), fminf(t[8], t[9]))));
+                        const float tmax = fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), fmaxf(fmaxf(t[4], t[5]), fmaxf(fmaxf(t[6], t[7]), fmaxf(t[8], t[9]))));
+                        const bool one = tmin > hi_t + 0.01f && tmax < 8192.f, zero = tmax < lo_t - 0.01f && tmin > -8192.f;
+                        if (__ballot(!(one || zero)) == 0) {
+                            decided = true;
+                            word = one ? 0xffffffffu : 0u;
+                            s_hi = s_lo = 32 * __popcll(__ballot(one));
+                        }
                     }
-                    word = __brev(wm);
+                    if (!decided) {
+#pragma unroll
+                        for (int b = 0; b < 32; ++b) {
+                            float w1 = W1[b & 3];
+                            if (b < 2 && yw == 0) w1 = 0.0f;
+                            const float v = lerp_torch(1.0f - w1, t[(b + 2) / 4], w1, t[(b + 2) / 4 + 1]);
+                            if (LOGITS) logits[((long)n * out_h + yw * 32 + b) * out_w + x] = v;
+                            wm = __builtin_amdgcn_alignbit(wm, __float_as_uint(__fsub_rn(thr, v)), 31);
+                            s_hi += __popcll(__ballot(v > hi_t));
+                            s_lo += __popcll(__ballot(v > lo_t));
+                        }
+                        word = __brev(wm);
+                    }
                     if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { c_hi += s_hi; c_lo += s_lo; }   // first active lane
                 } else {
 #pragma unroll

@@ -37,6 +37,7 @@ struct UpArgs {
     const float* hyper; int hyper_ld, mask0, nmask;    // fp32 [P, 4, hyper_ld]
     int nitems, KS;
     float* out;                          // fp32 [P, nmask, 256, 256]
+    int blocked;                         // keys in the blocked layout of decfold_tok.hip ([16-token tile][k-step][lane][8]) instead of row-major
 };
 
 template <int UF_PRIO>
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     int kdst[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int id = i * NTHR + tid, row = id >> 5, c = id & 31;
+        const int id = i * NTHR + tid;                       // 16-byte chunk of the (contiguous) 16-token tile -> token row, chunk c
+        const int row = a.blocked ? id & 15 : id >> 5, c = a.blocked ? (id >> 6) * 4 + ((id >> 4) & 3) : id & 31;
         kdst[i] = (c >> 2) * SUB_BYTES + row * 64 + (((c & 3) ^ ((row >> 2) & 3)) << 4);
     }
     auto tile_pos = [&](int q, int& p, int& key0) {
@@ -252,9 +254,20 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 
 }  // namespace
 
+extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
+                                         const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
+                                         const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res,
+                                         void* stream);
 extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float* b1, const float* ln_w,
                                   const float* ln_b, float ln_eps, const void* w2, const float* b2, const float* hyper,
                                   int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res, void* stream) {
+    return msam_upscale_fused_layout(keys, 0, P, w1, b1, ln_w, ln_b, ln_eps, w2, b2, hyper, hyper_ld, mask0, nmask, low_res, stream);
+}
+
+extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
+                                         const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
+                                         const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res,
+                                         void* stream) {
     if (!keys || !w1 || !b1 || !ln_w || !ln_b || !w2 || !b2 || !hyper || !low_res || P <= 0) {
         msam_set_error("msam_upscale_fused: null argument");
         return 1;
@@ -271,7 +284,7 @@ extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, c
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int ks = 1;
     while (P * ks < 2 * cus && ks < 16) ks *= 2;
-    a.KS = ks; a.nitems = P * ks; a.out = low_res;
+    a.KS = ks; a.nitems = P * ks; a.out = low_res; a.blocked = keys_blocked ? 1 : 0;
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double rows = (double)P * T;
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);

@@ -481,7 +481,7 @@ def decoder_image_layer(xin, ktok, vtok, wo, bo, ln_w, ln_b, Nt, *, q_shared=Non
     return out
 
 
-def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False):
+def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False, blocked: bool = False):
     """Token -> image attention with folded K / V projections (include/msam_hip.h msam_t2i_fold_attention).
     keys [Pk,4096,256], qtok [P,Nt,128] (Nt <= 8), wk / wv [128,256], tabk [4096,128] in the decoder's 16-bit type, bv fp32 [128]
     -> [P,Nt,128]."""
@@ -491,7 +491,7 @@ def t2i_fold_attention(keys, qtok, wk, tabk, wv, bv, *, kv_shared: bool = False)
     nbytes = int(lib.msam_t2i_fold_workspace_bytes(P))
     work = torch.empty((nbytes,), dtype=torch.uint8, device=keys.device)
     out = torch.empty((P, Nt, 128), dtype=_dec16(keys, qtok, wk, tabk, wv), device=keys.device)
-    _lib.check(lib.msam_t2i_fold_attention(keys.data_ptr(), int(kv_shared), qtok.data_ptr(), P, Nt, wk.data_ptr(),
+    _lib.check(lib.msam_t2i_fold_attention(keys.data_ptr(), 2 if blocked else int(kv_shared), qtok.data_ptr(), P, Nt, wk.data_ptr(),
                                            tabk.data_ptr(), wv.data_ptr(), bv.data_ptr(), out.data_ptr(), work.data_ptr(),
                                            nbytes, _lib.stream_ptr()), "msam_t2i_fold_attention")
     return out
@@ -514,16 +514,87 @@ def i2t_fold_layer(xin, ktok, vtok, wq, tabq, wo, bo, ln_w, ln_b, *, x_shared: b
     return out
 
 
-def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: int, *, ln_eps: float = 1e-6):
+def i2t_fold_operands(ktok, vtok, wq, wo, bo, *, with_kfold: bool = True):
+    """Per-prompt operands of an image->token layer in MFMA fragment order (include/msam_hip.h msam_i2t_fold_operands):
+    ktok / vtok [P,Nt,128], wq [128,256], wo [256,128] in the decoder's 16-bit type, bo fp32 [256] -> uint8 [P * bytes]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _dec16(ktok, vtok, wq, wo)
+    P, Nt = ktok.shape[0], ktok.shape[1]
+    oper = torch.empty((int(lib.msam_i2t_fold_operand_bytes(P)),), dtype=torch.uint8, device=ktok.device)
+    _lib.check(lib.msam_i2t_fold_operands(ktok.data_ptr(), vtok.data_ptr(), P, Nt, wq.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                          int(with_kfold), oper.data_ptr(), _lib.stream_ptr()), "msam_i2t_fold_operands")
+    return oper
+
+
+def to_blocked(x: torch.Tensor) -> torch.Tensor:
+    """[..., 4096, W] row-major -> the blocked layout of csrc/decfold_tok.hip, [..., 256 tiles, W / 32 k-steps, 4 lane groups, 16
+    tokens, 8 channels] flattened back to [..., 4096, W] (include/msam_hip.h "BLOCKED layout").  Host-side helper for tests / tools."""
+    W = x.shape[-1]
+    lead = x.shape[:-2]
+    n = len(lead)
+    y = x.reshape(*lead, 256, 16, W // 32, 4, 8).permute(*range(n), n, n + 2, n + 3, n + 1, n + 4)
+    return y.reshape(*lead, 4096, W).contiguous()
+
+
+def from_blocked(x: torch.Tensor) -> torch.Tensor:
+    """Inverse of :func:`to_blocked`."""
+    W = x.shape[-1]
+    lead = x.shape[:-2]
+    n = len(lead)
+    y = x.reshape(*lead, 256, W // 32, 4, 16, 8).permute(*range(n), n, n + 3, n + 1, n + 2, n + 4)
+    return y.reshape(*lead, 4096, W).contiguous()
+
+
+def chain_prepare_tables(src, q0, tabk, tabq1):
+    """Blocked copies of the shared tables of the chained kernels (include/msam_hip.h msam_chain_prepare_tables):
+    src [4096,256], q0 / tabk / tabq1 [4096,128] in the decoder's 16-bit type -> uint8 blob."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _dec16(src, q0, tabk, tabq1)
+    tables = torch.empty((int(lib.msam_chain_tables_bytes()),), dtype=torch.uint8, device=src.device)
+    _lib.check(lib.msam_chain_prepare_tables(src.data_ptr(), q0.data_ptr(), tabk.data_ptr(), tabq1.data_ptr(), tables.data_ptr(),
+                                             _lib.stream_ptr()), "msam_chain_prepare_tables")
+    return tables
+
+
+def i2t0_t2i_fused(tables, operands0, ln0_w, ln0_b, qtok, wk, wv, bv, *, ln_eps: float = 1e-5):
+    """Layer-0 image->token block on the shared source chained into the layer-1 token->image attention
+    (include/msam_hip.h msam_i2t0_t2i_fused): tables from chain_prepare_tables, qtok [P,Nt,128] -> [P,Nt,128]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    P, Nt = qtok.shape[0], qtok.shape[1]
+    nbytes = int(lib.msam_i2t0_t2i_workspace_bytes(P))
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=qtok.device)
+    out = torch.empty((P, Nt, 128), dtype=_dec16(qtok, wk, wv), device=qtok.device)
+    _lib.check(lib.msam_i2t0_t2i_fused(tables.data_ptr(), operands0.data_ptr(), ln0_w.data_ptr(), ln0_b.data_ptr(), ln_eps,
+                                       qtok.data_ptr(), P, Nt, wk.data_ptr(), wv.data_ptr(), bv.data_ptr(), out.data_ptr(),
+                                       work.data_ptr(), nbytes, _lib.stream_ptr()), "msam_i2t0_t2i_fused")
+    return out
+
+
+def i2t01_fused(tables, operands0, ln0_w, ln0_b, operands1, ln1_w, ln1_b, P: int, Nt: int, *, ln_eps: float = 1e-5):
+    """Layer-0 image->token block on the shared source chained into the layer-1 image->token block
+    (include/msam_hip.h msam_i2t01_fused) -> the layer-1 output stream [P,4096,256] in the BLOCKED layout (from_blocked)."""
+    _lib.require_gpu()
+    out = torch.empty((P, 4096, 256), dtype=_lib.decoder_dtype(), device=tables.device)
+    _lib.check(_lib.load().msam_i2t01_fused(tables.data_ptr(), operands0.data_ptr(), ln0_w.data_ptr(), ln0_b.data_ptr(),
+                                            operands1.data_ptr(), ln1_w.data_ptr(), ln1_b.data_ptr(), ln_eps, P, Nt,
+                                            out.data_ptr(), _lib.stream_ptr()), "msam_i2t01_fused")
+    return out
+
+
+def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: int, *, ln_eps: float = 1e-6, blocked: bool = False):
     """Fused output up-scaling + hyper-network product (include/msam_hip.h msam_upscale_fused).
     keys [P,4096,256] (decoder 16-bit type), hyper fp32 [P,4,ld] -> fp32 [P,nmask,256,256]."""
     _lib.require_gpu()
     _dec16(keys, w1, w2)
     P = keys.shape[0]
     out = torch.empty((P, nmask, 256, 256), dtype=torch.float32, device=keys.device)
-    _lib.check(_lib.load().msam_upscale_fused(keys.data_ptr(), P, w1.data_ptr(), b1.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
-                                              ln_eps, w2.data_ptr(), b2.data_ptr(), hyper.data_ptr(), hyper.shape[-1], mask0,
-                                              nmask, out.data_ptr(), _lib.stream_ptr()), "msam_upscale_fused")
+    _lib.check(_lib.load().msam_upscale_fused_layout(keys.data_ptr(), int(blocked), P, w1.data_ptr(), b1.data_ptr(), ln_w.data_ptr(),
+                                                     ln_b.data_ptr(), ln_eps, w2.data_ptr(), b2.data_ptr(), hyper.data_ptr(),
+                                                     hyper.shape[-1], mask0, nmask, out.data_ptr(), _lib.stream_ptr()),
+               "msam_upscale_fused_layout")
     return out
 
 

@@ -381,10 +381,21 @@ def test_t2i_fold_attention(env, P, Nt, shared):
     assert torch.equal(out_dma, out)
 
 
-@pytest.mark.parametrize("P,Nt,shared", [(3, 7, False), (2, 8, True), (70, 5, True), (520, 7, True)])
-def test_i2t_fold_layer(env, P, Nt, shared):
-    """Folded image->token attention + out_proj + residual + LayerNorm vs the unfolded fp32 formulation."""
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("P,Nt,shared", [(3, 7, False), (2, 8, True), (70, 5, True), (520, 7, True), (5, 1, False)])
+def test_i2t_fold_layer(env, P, Nt, shared, variant):
+    """Folded image->token attention + out_proj + residual + LayerNorm vs the unfolded fp32 formulation, for the token-owner
+    kernel (variant 1, csrc/decfold_tok.hip: the default) and the 4-wave tile kernel (variant 0, csrc/decfold.hip)."""
     ops, dev = env
+    from micro_sam_amd import _lib
+    _lib.load().msam_tune_set(b"i2t_variant", variant)
+    try:
+        _i2t_fold_layer_case(ops, dev, P, Nt, shared)
+    finally:
+        _lib.load().msam_tune_set(b"i2t_variant", 1)
+
+
+def _i2t_fold_layer_case(ops, dev, P, Nt, shared):
     g = torch.Generator().manual_seed(91 + P)
     T = 4096
     Px = 1 if shared else P
@@ -412,6 +423,90 @@ def test_i2t_fold_layer(env, P, Nt, shared):
         x2 = x.clone()
         ops.i2t_fold_layer(x2, ktok, vtok, wq, tabq, wo, bo, lw, lb, out=x2)
         assert torch.equal(x2, out)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("P,Nt", [(130, 7), (129, 8), (3, 5)])
+def test_chained_layer0_forms(env, P, Nt, variant):
+    """All builds of the chained kernels (msam_tune_set "chain_variant": 8 waves with 4-fragment groups; 4 waves with rings of 8 /
+    16 fragments; 8 waves on the ring code)."""
+    from micro_sam_amd import _lib
+    _lib.load().msam_tune_set(b"chain_variant", variant)
+    try:
+        _chained_layer0_case(env, P, Nt)
+    finally:
+        _lib.load().msam_tune_set(b"chain_variant", 0)
+
+
+def _chained_layer0_case(env, P, Nt):
+    """The chained kernels of csrc/decfold_tok.hip (layer-0 image->token block recomputed tile by tile from the shared source and
+    fed into the layer-1 token->image attention / the layer-1 image->token block) against the stage-by-stage kernels and the fp32
+    formulation."""
+    ops, dev = env
+    g = torch.Generator().manual_seed(300 + P)
+    T = 4096
+    src = _d(torch.randn(T, 256, generator=g)).to(dev)
+    pe = torch.randn(T, 256, generator=g).to(dev)
+
+    def layer():
+        wq = _d(torch.randn(128, 256, generator=g) / 16).to(dev); bq = torch.randn(128, generator=g).to(dev)
+        wo = _d(torch.randn(256, 128, generator=g) / math.sqrt(128)).to(dev); bo = torch.randn(256, generator=g).to(dev)
+        lw = (torch.randn(256, generator=g) * 0.2 + 1).to(dev); lb = torch.randn(256, generator=g).to(dev)
+        ktok = _d(torch.randn(P, Nt, 128, generator=g)).to(dev); vtok = _d(torch.randn(P, Nt, 128, generator=g)).to(dev)
+        tabq = (pe @ wq.float().t() + bq).to(_ddt())
+        return dict(wq=wq, wo=wo, bo=bo, lw=lw, lb=lb, ktok=ktok, vtok=vtok, tabq=tabq)
+
+    L0, L1 = layer(), layer()
+    q0 = (src.float() @ L0["wq"].float().t() + L0["tabq"].float()).to(_ddt())
+    # stage by stage: layer-0 block on the shared source, then layer 1 on its output
+    keys1 = ops.i2t_fold_layer(src[None], L0["ktok"], L0["vtok"], L0["wq"], L0["tabq"], L0["wo"], L0["bo"], L0["lw"], L0["lb"],
+                               x_shared=True)
+    keys2 = ops.i2t_fold_layer(keys1, L1["ktok"], L1["vtok"], L1["wq"], L1["tabq"], L1["wo"], L1["bo"], L1["lw"], L1["lb"])
+    op0 = ops.i2t_fold_operands(L0["ktok"], L0["vtok"], L0["wq"], L0["wo"], L0["bo"], with_kfold=False)
+    op1 = ops.i2t_fold_operands(L1["ktok"], L1["vtok"], L1["wq"], L1["wo"], L1["bo"])
+    wk = _d(torch.randn(128, 256, generator=g) / 16).to(dev); bk = torch.randn(128, generator=g).to(dev)
+    tabk = (pe @ wk.float().t() + bk).to(_ddt())
+    tables = ops.chain_prepare_tables(src, q0, tabk, L1["tabq"])
+    out2_blocked = ops.i2t01_fused(tables, op0, L0["lw"], L0["lb"], op1, L1["lw"], L1["lb"], P, Nt)
+    out2 = ops.from_blocked(out2_blocked)
+    # layer 0 takes its scores from the 16-bit q0 instead of the folded K' product: same arithmetic, other rounding points
+    sel = [0, P // 2, P - 1]
+    d2 = (out2[sel].float() - keys2[sel].float()).abs()
+    assert float(d2.mean()) < 4e-3 and _close(out2[sel], keys2[sel], 6e-2, 3e-2)
+    # fp32 formulation of both layers for a few prompts
+    def block(xf, Lw, sl):
+        q = xf @ Lw["wq"].float().t() + Lw["tabq"].float()
+        qh = q.reshape(-1, T, 8, 16).permute(0, 2, 1, 3)
+        kh = Lw["ktok"][sl].float().reshape(-1, Nt, 8, 16).permute(0, 2, 1, 3)
+        vh = Lw["vtok"][sl].float().reshape(-1, Nt, 8, 16).permute(0, 2, 1, 3)
+        a = torch.softmax((qh @ kh.transpose(-1, -2)) / 4.0, dim=-1)
+        attn = (a @ vh).permute(0, 2, 1, 3).reshape(-1, T, 128)
+        return F.layer_norm(xf + attn @ Lw["wo"].float().t() + Lw["bo"], (256,), Lw["lw"], Lw["lb"], eps=1e-5)
+    ref1 = block(src.float()[None].expand(len(sel), T, 256), L0, sel)
+    ref2 = block(ref1, L1, sel)
+    assert _close(out2[sel], ref2, 8e-2, 4e-2)
+    # token -> image attention of layer 1 on the (never written) layer-0 output
+    wv = _d(torch.randn(128, 256, generator=g) / 16).to(dev); bv = torch.randn(128, generator=g).to(dev)
+    qtok = _d(torch.randn(P, Nt, 128, generator=g) * 1.5).to(dev)
+    att_stage = ops.t2i_fold_attention(keys1, qtok, wk, tabk, wv, bv)
+    att = ops.i2t0_t2i_fused(tables, op0, L0["lw"], L0["lb"], qtok, wk, wv, bv)
+    K = ref1 @ wk.float().t() + tabk.float()
+    V = ref1 @ wv.float().t() + bv
+    qh = qtok[sel].float().reshape(-1, Nt, 8, 16).permute(0, 2, 1, 3)
+    kh = K.reshape(-1, T, 8, 16).permute(0, 2, 1, 3); vh = V.reshape(-1, T, 8, 16).permute(0, 2, 1, 3)
+    a = torch.softmax((qh @ kh.transpose(-1, -2)) / 4.0, dim=-1)
+    ref = (a @ vh).permute(0, 2, 1, 3).reshape(-1, Nt, 128)
+    assert _close(att[sel], ref, 6e-2, 3e-2)
+    assert _close(att, att_stage, 6e-2, 3e-2)
+    # the consumers of the blocked stream: same bits as on the row-major copy of it
+    assert torch.equal(ops.t2i_fold_attention(out2_blocked, qtok, wk, tabk, wv, bv, blocked=True),
+                       ops.t2i_fold_attention(out2, qtok, wk, tabk, wv, bv))
+    ct1 = _d(torch.randn(256, 256, generator=g) / 16).to(dev); cb1 = torch.randn(256, generator=g).to(dev)
+    ulw = (torch.randn(64, generator=g) * 0.2 + 1).to(dev); ulb = (torch.randn(64, generator=g) * 0.3).to(dev)
+    w2 = _d(torch.randn(128, 64, generator=g) / 8).to(dev); cb2 = torch.randn(32, generator=g).to(dev)
+    hyper = torch.randn(P, 4, 128, generator=g).to(dev)
+    assert torch.equal(ops.upscale_fused(out2_blocked, ct1, cb1, ulw, ulb, w2, cb2, hyper, 1, 3, blocked=True),
+                       ops.upscale_fused(out2, ct1, cb1, ulw, ulb, w2, cb2, hyper, 1, 3))
 
 
 @pytest.mark.parametrize("P,mask0,nmask", [(2, 1, 3), (3, 0, 1), (300, 1, 3)])

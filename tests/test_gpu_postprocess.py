@@ -42,6 +42,35 @@ def test_postprocess_and_rle_bit_exact(low_res, in_hw, out_hw):
     assert torch.equal(torch.nan_to_num(stab, nan=-1.0), torch.nan_to_num(ref_stab, nan=-1.0))
 
 
+def test_postprocess_decided_words_are_exact():
+    """Object-like logits (|v| of 10..40 away from the boundary): most 64-column x 32-row words are decided from the range of their
+    ten low-res rows without interpolation (postprocess_kernel, "decided words"); bits, counts and boxes must equal the
+    reference's per-pixel arithmetic, including masks whose stability thresholds (+-1) run through flat regions."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import ops
+    from oracle import amg_ref as A
+    from oracle import sam_ref as S
+    g = torch.Generator().manual_seed(16)
+    yy, xx = torch.meshgrid(torch.arange(256.0), torch.arange(256.0), indexing="ij")
+    low = torch.empty(8, 256, 256)
+    for i in range(8):
+        f = torch.zeros(256, 256)
+        for _ in range(1 + 2 * i):
+            cy, cx, r = (torch.rand(3, generator=g) * torch.tensor([256.0, 256.0, 30.0]) + torch.tensor([0.0, 0.0, 4.0])).tolist()
+            f = torch.maximum(f, torch.clamp(1.5 - torch.sqrt((yy - cy) ** 2 + (xx - cx) ** 2) / r, 0.0, 1.0))
+        low[i] = f * 45.0 - 14.0 + torch.randn(256, 256, generator=g) * 0.3
+    low[6] = low[6].clamp(-0.995, 0.995)          # a plateau just inside the +-1 stability band: never "decided"
+    low[7, :128] = 1.005                          # within 0.01 of the upper threshold: the exact path must run
+    ref_logits = S.postprocess_masks(low[None], (1024, 1024), (1024, 1024))[0]
+    res = ops.postprocess_masks(low.cuda(), (1024, 1024), (1024, 1024), 0.0, 1.0)
+    m = ref_logits > 0.0
+    counts_ref = torch.stack([(ref_logits > 1.0).sum((1, 2)), (ref_logits > -1.0).sum((1, 2)), m.sum((1, 2))], 1).int()
+    assert res["counts"].cpu().tolist() == counts_ref.tolist()
+    assert res["boxes"].cpu().tolist() == A.batched_mask_to_box(m).tolist()
+    assert bool((ops.unpack_bits(res["bits"], 1024).cpu() == m).all())
+
+
 def test_vendored_api_on_noisy_masks():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
