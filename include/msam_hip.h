@@ -196,7 +196,9 @@ int msam_upscale_set_prio(int32_t prio);
 int msam_fold_attn_set_dma(int32_t on);
 /* named integer tuning knobs of the decoder stream kernels (A/B experiments, tests): "i2t_variant" (1 = token-owner kernel,
  * default; 0 = 4-wave tile kernel), "i2t_wg_per_cu", "dec_chain" (1 = the decoder takes the chained forms above when the
- * prompts share one source, Nt <= 8 and P >= "dec_chain_min_p"; default 1 / 128).  Returns 0, 1 for an unknown key. */
+ * prompts share one source, Nt <= 8 and P >= "dec_chain_min_p"; default 1 / 128), "chain_variant" (builds of the chained
+ * kernels, 0 = default), "up_gelu16" (1 = the up-scaling's GELUs in packed fp16 arithmetic, default in the fp16 decoder build;
+ * 0 = packed fp32).  Returns 0, 1 for an unknown key. */
 int msam_tune_set(const char* key, int32_t value);
 /* debug hook: phase timing of the folded image->token kernel (see csrc/decfold.hip, tools/i2t_timing.py) */
 int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out);

@@ -25,6 +25,9 @@ namespace {
 
 constexpr int T = 4096, C = 256, TK = 16, NTHR = 256;
 int g_uf_prio = 1;                    // tuning hook msam_upscale_set_prio
+}
+int g_tune_up_gelu16 = 1;             // msam_tune_set "up_gelu16": GELUs in packed fp16 arithmetic (fp16 decoder build; 0 = packed fp32)
+namespace {
 constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;     // k-step sub-tiles [32 tokens][64 B] (+ pad), see decfold.hip
 constexpr int W2_BYTES = 128 * 128;
 constexpr int PATCH = 3 * 4 * 64;                                     // [mask][4 rows][64 pixels] fp32
@@ -40,7 +43,28 @@ struct UpArgs {
     int blocked;                         // keys in the blocked layout of decfold_tok.hip ([16-token tile][k-step][lane][8]) instead of row-major
 };
 
-template <int UF_PRIO>
+// erf-GELU of two values in PACKED fp16 arithmetic (G16 instantiation, fp16 decoder build only).  The result of either GELU
+// is rounded to fp16 anyway - it is the B operand of the next MFMA - so the polynomial can run on v_pk_fma_f16 (two values per
+// single-pass instruction; v_pk_fma_f32 takes two passes) and end as the packed operand word: convert, max, fma, 3 fma,
+// 2 v_exp_f16, fma = 9 single-pass instructions per pair instead of 2 v_med3 + 5 double-pass packed fp32 + 2 v_exp_f32 + 1 convert.
+// Same formula as gelu_erf (common.h): max(x, 0) - |x| 2^cubic(|x|); the exponent's fp16 rounding (|q| <= 8 where the term
+// matters) adds <= 1.2e-4 absolute to the 5.5e-5 of the cubic, against an output rounding of 2^-11 relative.
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+MSAM_DEVINL uint32_t gelu_pk_h(float x0, float x1) {
+    const f32x2_t xf = {x0, x1};
+    const h16x2_t x = __builtin_convertvector(xf, h16x2_t);
+    const h16x2_t zero = {(_Float16)0.f, (_Float16)0.f};
+    const h16x2_t r = __builtin_elementwise_max(x, zero);
+    const h16x2_t t = r * (_Float16)2.f - x;
+    h16x2_t q = t * (_Float16)-0.0248758f + (_Float16)-0.49884797f;
+    q = q * t + (_Float16)-1.12922424f;
+    q = q * t + (_Float16)-1.00353579f;
+    const h16x2_t e = {(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};
+    const h16x2_t g = r - t * e;
+    return __builtin_bit_cast(uint32_t, g);
+}
+
+template <int UF_PRIO, bool G16>
 __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
     __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
@@ -169,18 +193,22 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             for (int r = 0; r < 4; ++r) { u[rt][r] -= mean; ss += u[rt][r] * u[rt][r]; }
         ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
         const float rstd = rsqrtf(ss * (1.f / 64.f) + a.eps);
+        uint32_t g1w[4][2];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
-            const f32x2_t g01 = gelu_erf2(f32x2_t{u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y});
-            const f32x2_t g23 = gelu_erf2(f32x2_t{u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w});
-            u[rt][0] = g01.x; u[rt][1] = g01.y; u[rt][2] = g23.x; u[rt][3] = g23.y;
+            if (G16) {
+                g1w[rt][0] = gelu_pk_h(u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y);
+                g1w[rt][1] = gelu_pk_h(u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w);
+            } else {
+                const f32x2_t g01 = gelu_erf2(f32x2_t{u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y});
+                const f32x2_t g23 = gelu_erf2(f32x2_t{u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w});
+                g1w[rt][0] = pack2d(g01.x, g01.y); g1w[rt][1] = pack2d(g23.x, g23.y);
+            }
         }
         uint4 g1[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            g1[kk] = make_uint4(pack2d(u[2 * kk][0], u[2 * kk][1]), pack2d(u[2 * kk][2], u[2 * kk][3]),
-                                pack2d(u[2 * kk + 1][0], u[2 * kk + 1][1]), pack2d(u[2 * kk + 1][2], u[2 * kk + 1][3]));
+        for (int kk = 0; kk < 2; ++kk) g1[kk] = make_uint4(g1w[2 * kk][0], g1w[2 * kk][1], g1w[2 * kk + 1][0], g1w[2 * kk + 1][1]);
         // ---- stages 2 and 3, one second-level sub-pixel at a time
         // The four second-level sub-pixels are independent chains (LDS read -> MFMA -> GELU -> MFMA).  They are written as a
         // software pipeline in ONE basic block - stage-2 MFMAs of sub-pixel s+1 ahead of the GELUs of s, the hyper product of
@@ -204,6 +232,11 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         // GELU (two values per packed instruction), fp16 for the hyper product (11-bit significand: the product keeps ~fp32
         // accuracy together with the hi + lo hyper weights; a bf16 operand would not)
         auto act2 = [&](int s2) {
+            if (G16) {
+                gh[s2] = make_uint4(gelu_pk_h(ya[s2][0], ya[s2][1]), gelu_pk_h(ya[s2][2], ya[s2][3]),
+                                    gelu_pk_h(yb[s2][0], yb[s2][1]), gelu_pk_h(yb[s2][2], yb[s2][3]));
+                return;
+            }
             const f32x2_t a01 = gelu_erf2(f32x2_t{ya[s2][0], ya[s2][1]}), a23 = gelu_erf2(f32x2_t{ya[s2][2], ya[s2][3]});
             const f32x2_t b01 = gelu_erf2(f32x2_t{yb[s2][0], yb[s2][1]}), b23 = gelu_erf2(f32x2_t{yb[s2][2], yb[s2][3]});
             gh[s2] = make_uint4(pack2h(a01.x, a01.y), pack2h(a23.x, a23.y), pack2h(b01.x, b01.y), pack2h(b23.x, b23.y));
@@ -290,8 +323,14 @@ extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked,
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
     const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
     msam_profile_mark2(stream, 1, flops, bytes, 4);
-    if (g_uf_prio) hipLaunchKernelGGL(up_fused_kernel<1>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(up_fused_kernel<0>, dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+#if MSAM_DEC_F16
+    if (g_tune_up_gelu16) {
+        if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, true>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((up_fused_kernel<0, true>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    } else
+#endif
+    if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, false>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((up_fused_kernel<0, false>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     msam_profile_mark2(stream, 0, flops, bytes, 4);
     return msam_check_launch("up_fused");
 }

@@ -509,9 +509,20 @@ def _chained_layer0_case(env, P, Nt):
                        ops.upscale_fused(out2, ct1, cb1, ulw, ulb, w2, cb2, hyper, 1, 3))
 
 
+@pytest.mark.parametrize("gelu16", [1, 0])
 @pytest.mark.parametrize("P,mask0,nmask", [(2, 1, 3), (3, 0, 1), (300, 1, 3)])
-def test_upscale_fused(env, P, mask0, nmask):
-    """Fused ConvT + LayerNorm2d + GELU + ConvT + GELU + hyper product vs torch (conv_transpose2d on the same bf16 operands)."""
+def test_upscale_fused(env, P, mask0, nmask, gelu16):
+    """Fused ConvT + LayerNorm2d + GELU + ConvT + GELU + hyper product vs torch (conv_transpose2d on the same bf16 operands), with
+    the GELUs in packed fp16 arithmetic (default of the fp16 decoder build) and in packed fp32."""
+    from micro_sam_amd import _lib
+    _lib.load().msam_tune_set(b"up_gelu16", gelu16)
+    try:
+        _upscale_fused_case(env, P, mask0, nmask)
+    finally:
+        _lib.load().msam_tune_set(b"up_gelu16", 1)
+
+
+def _upscale_fused_case(env, P, mask0, nmask):
     ops, dev = env
     g = torch.Generator().manual_seed(5 + P)
     keys = _d(torch.randn(P, 4096, 256, generator=g)).to(dev)
