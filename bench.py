@@ -45,7 +45,10 @@ TILE_TFLOP_ALGORITHMIC = 4.64      # encoder 0.938 + AMG decode 
 # SURVEY.md 8(d) per-prompt algorithmic work of the reference's formulation that each decoder stream kernel replaces
 # (GFLOP per prompt per launch): image->token attention of one layer = Q + out projections of 4096 image tokens (0.537);
 # token->image attention of layer 1 / final = K + V projections (0.537); up-scaling = ConvT1 0.537 + ConvT2 0.268 + hyper product 0.02
-ALG_GFLOP_PER_PROMPT = {2: 0.537, 3: 0.537, 4: 0.825}
+# chained kernels (csrc/decfold_tok.hip): i2t0_t2i replaces the image->token attention of layer 0 AND the token->image attention of
+# layer 1 (2 x 0.537; it also recomputes nothing algorithmic), i2t01 the image->token attention of layer 1 (0.537; its
+# recomputation of the layer-0 tile is executed, not algorithmic, work)
+ALG_GFLOP_PER_PROMPT = {2: 0.537, 3: 0.537, 4: 0.825, 6: 1.074, 7: 0.537}
 
 
 def log(*a):
@@ -158,8 +161,10 @@ def main():
     ap.add_argument("--tiles-per-step", type=int, default=TILES_PER_STEP, help="tiles per rank and step")
     ap.add_argument("--distinct-tiles", type=int, default=256, help="distinct synthetic tiles per rank, visited in order")
     ap.add_argument("--enc-batch", type=int, default=ENC_BATCH, help="tiles per image-encoder call")
-    ap.add_argument("--encoder-dtype", choices=("bf16", "fp8"), default="bf16",
-                    help="fp8: BASELINE config 5 (encoder projections on fp8 e4m3 MX MFMA, bf16 decoder); NOT the headline metric")
+    ap.add_argument("--encoder-dtype", choices=("bf16", "fp16", "fp8"), default="bf16",
+                    help="bf16: the headline configuration (\"vit_b bf16\"); fp16: IEEE fp16 instead of bf16 operands in the image encoder "
+                         "(same kernels and MFMA rate; side measurement of what the bf16 operand rounding costs in mask IoU); fp8: "
+                         "BASELINE config 5 (encoder projections on fp8 e4m3 MX MFMA, bf16 decoder); NOT the headline metric")
     ap.add_argument("--weights", choices=("cells", "blobs", "field"), default="cells",
                     help="synthetic checkpoint variant (micro_sam_amd/synthetic.py)")
     ap.add_argument("--lanes", type=int, default=3,
@@ -231,11 +236,14 @@ def main():
     FAMILY = [
         ("gemm256_kernel (256x256 tile MFMA GEMM: the image encoder's qkv / proj / MLP projections)", "mfma"),
         ("wsgemm_kernel / dec_image_layer_kernel (weights-stationary streaming kernels, > 8 tokens per prompt)", "hbm"),
-        ("fold_i2t_kernel (folded image->token attention + out_proj + norm4 of one decoder layer)", "mfma"),
-        ("fold_attn_kernel (folded token->image attention of layer 1 / final)", "mfma"),
+        ("i2t_tok_kernel / fold_i2t_kernel (folded image->token attention + out_proj + norm4 of one decoder layer, stage-by-stage form)", "mfma"),
+        ("fold_attn_kernel (folded token->image attention: final attention; layer 1 in the stage-by-stage form)", "mfma"),
         ("up_fused_kernel (fused up-scaling ConvT-LN-GELU-ConvT-GELU + hyper product)", "mfma"),
         ("gemm_kernel / gemm_ln_kernel (128x128 tile MFMA GEMM: patch embedding, neck and the latency-bound token-side "
          "launches)", "mfma"),
+        ("i2t0_t2i_kernel (layer-0 image->token block recomputed per tile from the shared source, chained into the layer-1 "
+         "token->image attention; no per-prompt stream read or written)", "mfma"),
+        ("i2t01_kernel (layer-0 image->token block chained into the layer-1 image->token block; writes the layer-1 stream)", "mfma"),
     ]
     prof = [{"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0} for _ in range(NF)]
 
@@ -441,12 +449,14 @@ def main():
                                      "profiles/ holds the rocprofv3 summary of the same one-lane command (--lanes 1)"),
                 "other_kernels": fams[1:]}
         out = {
-            "metric": "1024^2 tiles/s embed+AMG (vit_b bf16)" if args.encoder_dtype == "bf16" else
-                      "1024^2 tiles/s embed+AMG (vit_b fp8 encoder + bf16 decoder, BASELINE configs[4])", "value": round(value, 4), "unit": "tiles/s",
+            "metric": {"bf16": "1024^2 tiles/s embed+AMG (vit_b bf16)",
+                       "fp16": "1024^2 tiles/s embed+AMG (vit_b, fp16 instead of bf16 operands in the image encoder: side measurement)",
+                       "fp8": "1024^2 tiles/s embed+AMG (vit_b fp8 encoder + bf16 decoder, BASELINE configs[4])"}[args.encoder_dtype],
+            "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("bf16" if args.encoder_dtype == "bf16" else "fp8 projections + bf16") + " image encoder, " +
+            "dtype": {"bf16": "bf16", "fp16": "fp16", "fp8": "fp8 projections + bf16"}[args.encoder_dtype] + " image encoder, " +
                      ("fp16" if _lib.decoder_dtype() == torch.float16 else "bf16") + " mask decoder (16-bit MFMA operands, fp32 accumulation)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
@@ -499,6 +509,12 @@ def main():
             ref_tiles = tiles_np[:args.cpu_tiles]
             out["cpu_baseline"], ref_states, ref_segs = cpu_reference(sd, ref_tiles, n_thr)
             out["mask_iou_vs_ref"] = mask_iou_vs_ref(predictor, amg, ref_tiles, ref_states, ref_segs)
+            if args.encoder_dtype == "bf16":
+                # what the bf16 rounding of the encoder's operands costs: the same comparison with IEEE fp16 operands in the encoder
+                # (same kernels and MFMA rate; throughput of that mode: python bench.py --encoder-dtype fp16)
+                predictor.model.image_encoder.set_precision("fp16")
+                out["mask_iou_vs_ref_fp16_encoder"] = mask_iou_vs_ref(predictor, amg, ref_tiles, ref_states, ref_segs)
+                predictor.model.image_encoder.set_precision("bf16")
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
             out["mask_iou_vs_ref"] = None

@@ -212,7 +212,7 @@ int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flop
  * kernels (wsgemm_kernel / dec_image_layer_kernel), [2] fold_i2t_kernel, [3] fold_attn_kernel, [4] up_fused_kernel (the decoder
  * kernels that stream the per-prompt image-token stream once; HBM-bound), [5] gemm_kernel / gemm_ln_kernel (128 x 128 and
  * 64 x 256 tile MFMA GEMMs: patch embedding, neck, the latency-bound token-side projections). */
-#define MSAM_PROFILE_FAMILIES 6
+#define MSAM_PROFILE_FAMILIES 8
 int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
 /* util._to_image (micro_sam/util.py:618-651) on the device, bit for bit: in [H,W,C] (C = 1: gray, replicated; C = 2: third
@@ -271,12 +271,15 @@ int msam_layernorm_fp8(const float* x, const float* weight, const float* bias, f
 int msam_quant_rows_fp8(const void* x_bf16, int64_t rows, int32_t dim, void* out_fp8, float* row_scale, void* stream);
 /* fp32 [B,3,1024,1024] (output of Sam.preprocess) -> bf16 patch matrix [B*4096, 768] (c,ky,kx order). */
 int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream);
+int msam_patchify16(const float* img, int32_t B, int32_t dtype16, void* out16, void* stream);
 /* uint8 HWC [B,h,w,3] (h,w <= 1024; output of ResizeLongestSide.apply_image) -> normalised, zero padded bf16 patch
  * matrix [B*4096,768]: fuses Sam.preprocess (micro_sam/util.py:670) into the patch gather. */
 int msam_patchify_u8(const uint8_t* img, int32_t B, int32_t h, int32_t w, void* out_bf16, void* stream);
+int msam_patchify_u8_16(const uint8_t* img, int32_t B, int32_t h, int32_t w, int32_t dtype16, void* out16, void* stream);
 /* bf16 [B,64,64,C] -> bf16 [B*4096, 9*C] rows for the 3x3 / pad 1 neck convolution ((ky,kx,c) column order). */
 int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, void* stream);
 int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
+int msam_cast_f32_to_16(const float* x, int32_t dtype16, void* out16, int64_t n, void* stream);
 
 /* ViT attention with decomposed relative position bias (segment_anything ImageEncoderViT Attention).
  * head_dim = STORED channels per head, 64 or 96 (vit_h: true head_dim 80, zero-padded to 96 by the caller);
@@ -288,8 +291,14 @@ int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* strea
 int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
                           const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale, void* out,
                           void* stream);
+/* the same with the 16-bit type stated (MSAM_BF16 / MSAM_F16: q, k, v, rel_h, rel_w and out) */
+int msam_window_attention16(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                            const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale, int32_t dtype16,
+                            void* out, void* stream);
 int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
                           int32_t B, int32_t heads, int32_t head_dim, float scale, void* out, void* stream);
+int msam_global_attention16(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w, int32_t B,
+                            int32_t heads, int32_t head_dim, float scale, int32_t dtype16, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Image encoder:  predictor.model.image_encoder(x)   (micro_sam/util.py:674)
@@ -323,6 +332,10 @@ typedef struct {
     const void* proj_w8[MSAM_MAX_BLOCKS]; const float* proj_cs[MSAM_MAX_BLOCKS];
     const void* lin1_w8[MSAM_MAX_BLOCKS]; const float* lin1_cs[MSAM_MAX_BLOCKS];
     const void* lin2_w8[MSAM_MAX_BLOCKS]; const float* lin2_cs[MSAM_MAX_BLOCKS];
+    /* 16-bit type of every matrix-product operand and stored activation of the encoder (weights above, rel_h / rel_w, LN outputs,
+     * q / k / v, attention output, MLP hidden): 0 or MSAM_BF16 = bfloat16 ("vit_b bf16"), MSAM_F16 = IEEE fp16 - the same kernels
+     * on the fp16 MFMAs of the same rate; the caller then hands over fp16 copies of the weights.  Not together with fp8. */
+    int32_t dtype16;
 } msam_encoder_t;
 
 int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B);

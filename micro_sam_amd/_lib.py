@@ -19,7 +19,7 @@ F32, BF16, FP8, F16, U8, U16 = 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-PROFILE_FAMILIES = 6          # include/msam_hip.h MSAM_PROFILE_FAMILIES
+PROFILE_FAMILIES = 8          # include/msam_hip.h MSAM_PROFILE_FAMILIES
 
 
 class GemmParams(C.Structure):
@@ -67,6 +67,7 @@ class EncoderParams(C.Structure):
         ("use_glds", _i32), ("head_dim_stored", _i32), ("fp8", _i32),
         ("qkv_w8", _blk), ("qkv_cs", _blk), ("proj_w8", _blk), ("proj_cs", _blk),
         ("lin1_w8", _blk), ("lin1_cs", _blk), ("lin2_w8", _blk), ("lin2_cs", _blk),
+        ("dtype16", _i32),
     ]
 
 
@@ -145,6 +146,11 @@ _PROTOS = {
     "msam_debug_i2t_timing": (_i32, [_i32, _vp]),
     "msam_window_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
     "msam_global_attention": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _vp, _vp]),
+    "msam_window_attention16": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp]),
+    "msam_global_attention16": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp]),
+    "msam_patchify16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "msam_patchify_u8_16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "msam_cast_f32_to_16": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),
     "msam_encoder_forward": (_i32, [C.POINTER(EncoderParams), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]),
     "msam_decoder_dtype": (_i32, []),

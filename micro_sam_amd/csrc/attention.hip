@@ -28,9 +28,17 @@ namespace {
 constexpr int TOK = 4096;
 constexpr float NEG_BIG = -1.0e30f;
 
-MSAM_DEVINL uint4 bias_chunk_bf16(const float* b) {   // 8 fp32 -> 8 bf16
+// F16 (both kernels): q / k / v / rel-pos tables and the output are IEEE fp16 instead of bf16 (the encoder's fp16 mode,
+// msam_encoder_t.dtype16): the fp16 MFMA of the same shape and rate, probabilities packed to fp16.
+template <bool F16> MSAM_DEVINL f32x4_t mma(const uint4& a, const uint4& b, f32x4_t c) {
+    if constexpr (F16) return mfma16h(a, b, c); else return mfma16(a, b, c);
+}
+template <bool F16> MSAM_DEVINL uint32_t pk2(float lo, float hi) {
+    if constexpr (F16) return pack2h(lo, hi); else return pack2bf(lo, hi);
+}
+template <bool F16> MSAM_DEVINL uint4 bias_chunk(const float* b) {   // 8 fp32 -> 8 x 16 bit
     uint4 r;
-    r.x = pack2bf(b[0], b[1]); r.y = pack2bf(b[2], b[3]); r.z = pack2bf(b[4], b[5]); r.w = pack2bf(b[6], b[7]);
+    r.x = pk2<F16>(b[0], b[1]); r.y = pk2<F16>(b[2], b[3]); r.z = pk2<F16>(b[4], b[5]); r.w = pk2<F16>(b[6], b[7]);
     return r;
 }
 
@@ -39,7 +47,7 @@ constexpr int WS = 14, WN = 196, WKT = 13 /* key tiles */, WKP = 224 /* padded k
 constexpr int VT_RS = 232;    // V^T row stride in bf16 (464 B = 116 dwords = 4 * odd -> conflict-free b64 reads)
 constexpr int T_RS = 65;      // rel-pos table row stride (floats)
 
-template <int HD>
+template <int HD, bool F16 = false>
 __global__ __launch_bounds__(256) void window_attention_kernel(
     const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
     const u16* __restrict__ relw, const float* __restrict__ qkv_bias, int heads, float scale, u16* __restrict__ out) {
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         if (row < WN) {
             const int y = wy * WS + row / WS, x = wx * WS + row % WS;
             if (y < 64 && x < 64) val = *(const uint4*)(Kb + (long)(y * 64 + x) * HD + ch * 8);
-            else val = bias_chunk_bf16(bk + ch * 8);
+            else val = bias_chunk<F16>(bk + ch * 8);
         }
         k_lds[row * CHP + (ch ^ swz(row))] = val;
     }
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         if (key < WN) {
             const int y = wy * WS + key / WS, x = wx * WS + key % WS;
             if (y < 64 && x < 64) val = *(const uint4*)(Vb + (long)(y * 64 + x) * HD + ch * 8);
-            else val = bias_chunk_bf16(bv + ch * 8);
+            else val = bias_chunk<F16>(bv + ch * 8);
         }
         const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (q_real) qf[ks] = *(const uint4*)(Qb + (long)(qy * 64 + qx) * HD + ks * 32 + fg * 8);
-            else if (qi < WN) qf[ks] = bias_chunk_bf16(bq + ks * 32 + fg * 8);
+            else if (qi < WN) qf[ks] = bias_chunk<F16>(bq + ks * 32 + fg * 8);
             else qf[ks] = make_uint4(0, 0, 0, 0);
         }
         // T^T[j][q] = R[j] . q  -> t_lds[q][j]
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         for (int jt = 0; jt < 4; ++jt) {
             f32x4_t t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) t = mfma16(ra[jt][ks], qf[ks], t);
+            for (int ks = 0; ks < KS; ++ks) t = mma<F16>(ra[jt][ks], qf[ks], t);
 #pragma unroll
             for (int r = 0; r < 4; ++r) tl[fr * T_RS + jt * 16 + fg * 4 + r] = t[r];
         }
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
             const int row = kt * 16 + fr;
             f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a = mfma16(k_lds[row * CHP + ((ks * 4 + fg) ^ swz(row))], qf[ks], a);
+            for (int ks = 0; ks < KS; ++ks) a = mma<F16>(k_lds[row * CHP + ((ks * 4 + fg) ^ swz(row))], qf[ks], a);
             s[kt] = a;
         }
         __builtin_amdgcn_wave_barrier();
@@ -170,14 +178,14 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         for (int u = 0; u < 7; ++u) {
             const int t0 = 2 * u, t1 = 2 * u + 1;
             uint4 pb;
-            pb.x = pack2bf(s[t0][0], s[t0][1]); pb.y = pack2bf(s[t0][2], s[t0][3]);
-            if (t1 < WKT) { pb.z = pack2bf(s[t1][0], s[t1][1]); pb.w = pack2bf(s[t1][2], s[t1][3]); }
+            pb.x = pk2<F16>(s[t0][0], s[t0][1]); pb.y = pk2<F16>(s[t0][2], s[t0][3]);
+            if (t1 < WKT) { pb.z = pk2<F16>(s[t1][0], s[t1][1]); pb.w = pk2<F16>(s[t1][2], s[t1][3]); }
             else { pb.z = 0; pb.w = 0; }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const u16* vr = vt_lds + (dt * 16 + fr) * VT_RS + fg * 4;
                 uint2 lo = *(const uint2*)(vr + t0 * 16), hi = *(const uint2*)(vr + t1 * 16);
-                o[dt] = mfma16(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[dt]);
+                o[dt] = mma<F16>(make_uint4(lo.x, lo.y, hi.x, hi.y), pb, o[dt]);
             }
         }
         if (q_real) {
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
             u16* dst = out + ((long)b * TOK + qy * 64 + qx) * D + head * HD + fg * 4;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                uint2 pk; pk.x = pack2bf(o[dt][0] * inv, o[dt][1] * inv); pk.y = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+                uint2 pk; pk.x = pk2<F16>(o[dt][0] * inv, o[dt][1] * inv); pk.y = pk2<F16>(o[dt][2] * inv, o[dt][3] * inv);
                 *(uint2*)(dst + dt * 16) = pk;
             }
         }
@@ -211,7 +219,7 @@ MSAM_DEVINL uint2 g_tr16(const unsigned char* p) {
     return __builtin_bit_cast(uint2, v);
 }
 
-template <int HD>
+template <int HD, bool F16 = false>
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel(
     const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
     const u16* __restrict__ relw, int heads, float scale, u16* __restrict__ out) {
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const uint4 a = jr < 127 ? *(const uint4*)(relw + jr * HD + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
-                c = mfma16(a, qf[j][ks], c);
+                c = mma<F16>(a, qf[j][ks], c);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
             const u16* src = relh + (qh - kh + 63) * HD;
             f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) c = mfma16(*(const uint4*)(src + ks * 32 + fg * 8), qf[j][ks], c);
+            for (int ks = 0; ks < KS; ++ks) c = mma<F16>(*(const uint4*)(src + ks * 32 + fg * 8), qf[j][ks], c);
             *(float4*)(scr + (j * 16 + fr) * GB_RS + t * 16 + fg * 4) = make_float4(c[0], c[1], c[2], c[3]);
         }
 
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
             for (int t = 0; t < 2; ++t) {
                 f32x4_t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) a = mfma16(ka[t][ks], qf[j][ks], a);
+                for (int ks = 0; ks < KS; ++ks) a = mma<F16>(ka[t][ks], qf[j][ks], a);
                 s[t] = a;
             }
             const float rh = scr[(j * 16 + fr) * GB_RS + kh];
@@ -382,12 +390,12 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
                 for (int r = 0; r < 4; ++r) { const float p = __expf(s[t][r] - mn); s[t][r] = p; ps += p; }
             l[j] = l[j] * alpha + ps;      // per-lane partial row sum; the 4 lane groups are combined after the loop
             uint4 pb;
-            pb.x = pack2bf(s[0][0], s[0][1]); pb.y = pack2bf(s[0][2], s[0][3]);
-            pb.z = pack2bf(s[1][0], s[1][1]); pb.w = pack2bf(s[1][2], s[1][3]);
+            pb.x = pk2<F16>(s[0][0], s[0][1]); pb.y = pk2<F16>(s[0][2], s[0][3]);
+            pb.z = pk2<F16>(s[1][0], s[1][1]); pb.w = pk2<F16>(s[1][2], s[1][3]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 o[j][dt][0] *= alpha; o[j][dt][1] *= alpha; o[j][dt][2] *= alpha; o[j][dt][3] *= alpha;
-                o[j][dt] = mfma16(va[dt], pb, o[j][dt]);
+                o[j][dt] = mma<F16>(va[dt], pb, o[j][dt]);
             }
         }
         if (kt + 1 < NT) G_COMMIT(buf ^ 1);
@@ -402,7 +410,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
         u16* dst = out + ((long)b * TOK + qh * 64 + qw0 + j * 16 + fr) * D + head * HD + fg * 4;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            uint2 pk; pk.x = pack2bf(o[j][dt][0] * inv, o[j][dt][1] * inv); pk.y = pack2bf(o[j][dt][2] * inv, o[j][dt][3] * inv);
+            uint2 pk; pk.x = pk2<F16>(o[j][dt][0] * inv, o[j][dt][1] * inv); pk.y = pk2<F16>(o[j][dt][2] * inv, o[j][dt][3] * inv);
             *(uint2*)(dst + dt * 16) = pk;
         }
     }
@@ -410,9 +418,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
 
 }  // namespace
 
-extern "C" int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
-                                     const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale, void* out,
-                                     void* stream) {
+extern "C" int msam_window_attention16(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                                       const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale,
+                                       int32_t dtype16, void* out, void* stream) {
     if (!q || !k || !v || !rel_h || !rel_w || !qkv_bias || !out || B <= 0 || heads <= 0) {
         msam_set_error("msam_window_attention: bad arguments");
         return 1;
@@ -421,19 +429,26 @@ extern "C" int msam_window_attention(const void* q, const void* k, const void* v
         msam_set_error("msam_window_attention: stored head_dim must be 64 or 96 (vit_h: 80 zero-padded to 96)");
         return 1;
     }
+    if (dtype16 != MSAM_BF16 && dtype16 != MSAM_F16) { msam_set_error("msam_window_attention: dtype16 must be MSAM_BF16 or MSAM_F16"); return 1; }
     const dim3 grid(B * 25 * heads), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (head_dim == 64)
-        hipLaunchKernelGGL(window_attention_kernel<64>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
-                           (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, scale, (u16*)out);
-    else
-        hipLaunchKernelGGL(window_attention_kernel<96>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
-                           (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, scale, (u16*)out);
+#define WA_GO(HD_, F16_) hipLaunchKernelGGL((window_attention_kernel<HD_, F16_>), grid, block, 0, s, (const u16*)q, (const u16*)k, \
+                                            (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, qkv_bias, heads, scale, (u16*)out)
+    if (dtype16 == MSAM_F16) { if (head_dim == 64) WA_GO(64, true); else WA_GO(96, true); }
+    else { if (head_dim == 64) WA_GO(64, false); else WA_GO(96, false); }
+#undef WA_GO
     return msam_check_launch("msam_window_attention");
 }
 
-extern "C" int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
-                                     int32_t B, int32_t heads, int32_t head_dim, float scale, void* out, void* stream) {
+extern "C" int msam_window_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                                     const float* qkv_bias, int32_t B, int32_t heads, int32_t head_dim, float scale, void* out,
+                                     void* stream) {
+    return msam_window_attention16(q, k, v, rel_h, rel_w, qkv_bias, B, heads, head_dim, scale, MSAM_BF16, out, stream);
+}
+
+extern "C" int msam_global_attention16(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                                       int32_t B, int32_t heads, int32_t head_dim, float scale, int32_t dtype16, void* out,
+                                       void* stream) {
     if (!q || !k || !v || !rel_h || !rel_w || !out || B <= 0 || heads <= 0) {
         msam_set_error("msam_global_attention: bad arguments");
         return 1;
@@ -442,13 +457,18 @@ extern "C" int msam_global_attention(const void* q, const void* k, const void* v
         msam_set_error("msam_global_attention: stored head_dim must be 64 or 96 (vit_h: 80 zero-padded to 96)");
         return 1;
     }
+    if (dtype16 != MSAM_BF16 && dtype16 != MSAM_F16) { msam_set_error("msam_global_attention: dtype16 must be MSAM_BF16 or MSAM_F16"); return 1; }
     const dim3 grid(B * heads * 32), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (head_dim == 64)
-        hipLaunchKernelGGL(global_attention_kernel<64>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
-                           (const u16*)rel_h, (const u16*)rel_w, heads, scale, (u16*)out);
-    else
-        hipLaunchKernelGGL(global_attention_kernel<96>, grid, block, 0, s, (const u16*)q, (const u16*)k, (const u16*)v,
-                           (const u16*)rel_h, (const u16*)rel_w, heads, scale, (u16*)out);
+#define GA_GO(HD_, F16_) hipLaunchKernelGGL((global_attention_kernel<HD_, F16_>), grid, block, 0, s, (const u16*)q, (const u16*)k, \
+                                            (const u16*)v, (const u16*)rel_h, (const u16*)rel_w, heads, scale, (u16*)out)
+    if (dtype16 == MSAM_F16) { if (head_dim == 64) GA_GO(64, true); else GA_GO(96, true); }
+    else { if (head_dim == 64) GA_GO(64, false); else GA_GO(96, false); }
+#undef GA_GO
     return msam_check_launch("msam_global_attention");
+}
+
+extern "C" int msam_global_attention(const void* q, const void* k, const void* v, const void* rel_h, const void* rel_w,
+                                     int32_t B, int32_t heads, int32_t head_dim, float scale, void* out, void* stream) {
+    return msam_global_attention16(q, k, v, rel_h, rel_w, B, heads, head_dim, scale, MSAM_BF16, out, stream);
 }

@@ -576,23 +576,23 @@ __global__ __launch_bounds__(NTHR8, 2) void i2t0_t2i_kernel(FuseArgs a) {
 // the next product), and across the tile boundary (the operands do not change within a prompt).  G = 4 is the scheme of the
 // kernels above; G = 8 / 16 keep 8 / 16 ds_read_b128 per wave in flight (the LDS latency under load is ~3 of the 16-cycle
 // MFMAs per batch of 4), which needs the registers of a 4-wave workgroup with ONE wave per SIMD (NW = 4: 512 VGPRs per wave).
-template <int G> struct Ring { uint4 buf[2][G]; };
+template <int G, int D = 2> struct Ring { uint4 buf[D][G]; };     // D slots: batches k .. k + D - 2 in flight behind batch k
 
 // ABL (ablation builds for tools/chain_ablation.py only; results are then meaningless): bit 0 no layer-0 score MFMAs, 1 no
 // layer-0 V'^T MFMAs, 2 no LayerNorm, 3 no attention score MFMAs, 4 no V-projection MFMAs, 5 no LDS operand reads, 6 no softmax exps
 template <int G, class Off, int ABL = 0>
-MSAM_DEVINL void ring_fill(Ring<G>& r, const unsigned char* L, int batch) {
+MSAM_DEVINL void ring_fill(Ring<G, Off::D>& r, const unsigned char* L, int batch) {
     if (ABL & 32) return;
 #pragma unroll
-    for (int j = 0; j < G; ++j) r.buf[batch & 1][j] = *(const uint4*)(L + Off::off((batch * G + j) % Off::N));
+    for (int j = 0; j < G; ++j) r.buf[batch % Off::D][j] = *(const uint4*)(L + Off::off((batch * G + j) % Off::N));
 }
 // at fragment n_ of the tile's stream: when it opens a batch, issue the reads of the next one
-#define RING_STEP(n_) do { if ((n_) % G == 0) { TK_FENCE(); ring_fill<G, Off, ABL>(ring, L, (n_) / G + 1); TK_FENCE(); } } while (0)
-#define RING_AT(n_) ring.buf[((n_) / G) & 1][(n_) % G]
+#define RING_STEP(n_) do { if ((n_) % G == 0) { TK_FENCE(); ring_fill<G, Off, ABL>(ring, L, (n_) / G + Off::D - 1); TK_FENCE(); } } while (0)
+#define RING_AT(n_) ring.buf[((n_) / G) % Off::D][(n_) % G]
 
 // image->token block (see i2t_block) on the fragments BASE .. of the stream: [8 or 40 score fragments][32 V'^T fragments]
 template <int G, class Off, int BASE, bool HAS_KF, int ABL = 0, class F>
-MSAM_DEVINL void i2t_block_r(Ring<G>& ring, const unsigned char* L, const float* gp, float eps, const uint4* b, const uint4* tb,
+MSAM_DEVINL void i2t_block_r(Ring<G, Off::D>& ring, const unsigned char* L, const float* gp, float eps, const uint4* b, const uint4* tb,
                              const WaveConst& wc, uint4* y, F&& consumed) {
     constexpr int NS = HAS_KF ? 40 : 8, G0 = HAS_KF ? 0 : 8;
     f32x4_t s[4];
@@ -660,8 +660,10 @@ MSAM_DEVINL void i2t_block_r(Ring<G>& ring, const unsigned char* L, const float*
 }
 
 // token->image block (see t2i_block) on the fragments BASE ..: [36 score fragments][64 Wv fragments, k-step major: all 8 heads]
-template <int G, class Off, int BASE, int ABL = 0, class F>
-MSAM_DEVINL void t2i_block_r(Ring<G>& ring, const unsigned char* L, const uint4* y, const uint4* tk, AttnState& st, F&& consumed) {
+// COMPACT: one accumulator per COLUMN tile instead of one per head - the two heads of a column tile own disjoint columns, so head
+// 2 ct accumulates with the probabilities of columns 8 .. 15 zeroed and head 2 ct + 1 with columns 0 .. 7 zeroed (16 registers less)
+template <int G, class Off, int BASE, int ABL = 0, bool COMPACT = false, class F>
+MSAM_DEVINL void t2i_block_r(Ring<G, Off::D>& ring, const unsigned char* L, const uint4* y, const uint4* tk, AttnState& st, F&& consumed) {
     f32x4_t s[4];
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) s[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -688,7 +690,10 @@ MSAM_DEVINL void t2i_block_r(Ring<G>& ring, const unsigned char* L, const uint4*
             const float mn = fmaxf(st.m[ct], mx), alpha = __builtin_amdgcn_exp2f(st.m[ct] - mn);
             st.m[ct] = mn; st.l[ct] *= alpha;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st.o[2 * ct][r] *= alpha; st.o[2 * ct + 1][r] *= alpha; }
+            for (int r = 0; r < 4; ++r) {
+                if (COMPACT) st.o[ct][r] *= alpha;
+                else { st.o[2 * ct][r] *= alpha; st.o[2 * ct + 1][r] *= alpha; }
+            }
         }
     }
     uint4 pb[4];
@@ -709,16 +714,23 @@ MSAM_DEVINL void t2i_block_r(Ring<G>& ring, const unsigned char* L, const uint4*
         RING_STEP(n);
         if (!(ABL & 16) || ks == 0) v[h] = mfma16d(y[(ABL & 16) ? h : ks], RING_AT(n), v[h]);
     }
+    const bool hi_cols = (__lane_id() & 8) != 0;               // this lane's column (l & 15) belongs to the odd head of its column tile
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
         const uint4 va = make_uint4(pack2d(v[h][0], v[h][1]), pack2d(v[h][2], v[h][3]), 0u, 0u);
-        st.o[h] = mfma16d(va, pb[h >> 1], st.o[h]);
+        if (COMPACT) {
+            const bool mine = hi_cols == ((h & 1) != 0);
+            const uint4 pm = make_uint4(mine ? pb[h >> 1].x : 0u, mine ? pb[h >> 1].y : 0u, 0u, 0u);
+            st.o[h >> 1] = mfma16d(va, pm, st.o[h >> 1]);
+        } else {
+            st.o[h] = mfma16d(va, pb[h >> 1], st.o[h]);
+        }
     }
 }
 
 // fragment streams (byte offsets in the kernels' LDS images); N = fragments per tile incl. padding reads: a multiple of 2 G
-template <int G> struct ChainOff {                           // i2t01: [KT0 8][VF0 32][KF1 / KT1 40][VF1 32]
-    static constexpr int USED = 112, N = ((USED + 2 * G - 1) / (2 * G)) * (2 * G);
+template <int G, int D_ = 2> struct ChainOff {               // i2t01: [KT0 8][VF0 32][KF1 / KT1 40][VF1 32]
+    static constexpr int D = D_, USED = 112, N = ((USED + D * G - 1) / (D * G)) * (D * G);
     static __device__ constexpr int off(int n) {
         if (n < 8) return C_KT0 + ((n % 4) * 2 + n / 4) * FRAG;
         if (n < 40) return C_VF0 + (n - 8) * FRAG;
@@ -727,8 +739,8 @@ template <int G> struct ChainOff {                           // i2t01: [KT0 8][V
         return C_KT0;                                        // padding
     }
 };
-template <int G> struct FuseOff {                            // i2t0_t2i: [KT0 8][VF0 32][QF / QD 36][WV 64]
-    static constexpr int USED = 140, N = ((USED + 2 * G - 1) / (2 * G)) * (2 * G);
+template <int G, int D_ = 2> struct FuseOff {                // i2t0_t2i: [KT0 8][VF0 32][QF / QD 36][WV 64]
+    static constexpr int D = D_, USED = 140, N = ((USED + D * G - 1) / (D * G)) * (D * G);
     static __device__ constexpr int off(int n) {
         if (n < 8) return F_KT0 + ((n % 4) * 2 + n / 4) * FRAG;
         if (n < 40) return F_VF0 + (n - 8) * FRAG;
@@ -738,9 +750,9 @@ template <int G> struct FuseOff {                            // i2t0_t2i: [KT0 8
     }
 };
 
-template <int NW, int G>
+template <int NW, int G, int D = 2>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(ChainArgs a) {
-    typedef ChainOff<G> Off;
+    typedef ChainOff<G, D> Off;
     constexpr int ABL = 0;
     constexpr int NTH = 64 * NW, NT = 256 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C_LDS];
@@ -753,7 +765,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(Ch
     const unsigned char* const L = lds + lane * 16;
     const float* const gp0 = prm + fg * 8;
     const float* const gp1 = prm + 2 * C + fg * 8;
-    Ring<G> ring;
+    Ring<G, D> ring;
     for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
         __syncthreads();
         {
@@ -780,7 +792,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(Ch
         } while (0)
         CH_LOAD0(w); CH_LOAD1(w);
         wait_vmem_all();
-        ring_fill<G, Off>(ring, L, 0);
+#pragma unroll
+        for (int k = 0; k + 1 < D; ++k) ring_fill<G, Off>(ring, L, k);
         for (int n = 0; n < NT; ++n) {
             asm volatile("" ::: "memory");
             const int tile = w + NW * n, nx = w + NW * (n + 1 < NT ? n + 1 : NT - 1);
@@ -797,9 +810,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(Ch
     }
 }
 
-template <int NW, int G, int ABL = 0>
+template <int NW, int G, int ABL = 0, int D = 2, bool COMPACT = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel(FuseArgs a) {
-    typedef FuseOff<G> Off;
+    typedef FuseOff<G, D> Off;
     constexpr int NTH = 64 * NW, NT = 256 / NW;
     __shared__ __attribute__((aligned(16))) unsigned char lds[F_LDS];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
@@ -811,7 +824,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel
     const rsrc_t rsrc = make_rsrc(a.src, T * C * 2), rq0 = make_rsrc(a.q0, T * CI * 2), rtab = make_rsrc(a.tabk, T * CI * 2);
     const unsigned char* const L = lds + lane * 16;
     const float* const gp0 = prm + fg * 8;
-    Ring<G> ring;
+    Ring<G, D> ring;
     for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
         __syncthreads();
         {
@@ -842,15 +855,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel
         FU_LOAD0(w & a.tmask); FU_LOAD1(w & a.tmask);
         if (ABL & 32) {
 #pragma unroll
-            for (int j = 0; j < G; ++j) ring.buf[0][j] = ring.buf[1][j] = make_uint4(tid, lane, 0x3c003c00u, 0x3c003c00u);
+            for (int j = 0; j < G; ++j)
+#pragma unroll
+                for (int k = 0; k < D; ++k) ring.buf[k][j] = make_uint4(tid, lane, 0x3c003c00u, 0x3c003c00u);
         }
-        ring_fill<G, Off, ABL>(ring, L, 0);
+#pragma unroll
+        for (int k = 0; k + 1 < D; ++k) ring_fill<G, Off, ABL>(ring, L, k);
         for (int n = 0; n < NT; ++n) {
             asm volatile("" ::: "memory");
             const int nx = (w + NW * (n + 1 < NT ? n + 1 : NT - 1)) & a.tmask;
             uint4 y1[8];
             i2t_block_r<G, Off, 0, false, ABL>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { FU_LOAD0(nx); });
-            t2i_block_r<G, Off, 40, ABL>(ring, L, y1, tk, st, [&]() { FU_LOAD1(nx); });
+            t2i_block_r<G, Off, 40, ABL, COMPACT>(ring, L, y1, tk, st, [&]() { FU_LOAD1(nx); });
 #pragma unroll
             for (int i = Off::USED; i < Off::N; ++i) RING_STEP(i);
         }
@@ -865,10 +881,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) { mg[ct * 16 + fr] = st.m[ct]; mg[64 + ct * 16 + fr] = st.l[ct]; }
         }
+        if (COMPACT) {
 #pragma unroll
-        for (int h = 0; h < 8; ++h)
-            if ((fr >> 3) == (h & 1))
-                *(float4*)(mg + 128 + (h * 8 + (fr & 7)) * 16 + fg * 4) = make_float4(st.o[h][0], st.o[h][1], st.o[h][2], st.o[h][3]);
+            for (int ct = 0; ct < 4; ++ct)                     // column fr of column tile ct = (head 2 ct + (fr >> 3), token fr & 7)
+                *(float4*)(mg + 128 + (ct * 16 + fr) * 16 + fg * 4) = make_float4(st.o[ct][0], st.o[ct][1], st.o[ct][2], st.o[ct][3]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < 8; ++h)
+                if ((fr >> 3) == (h & 1))
+                    *(float4*)(mg + 128 + (h * 8 + (fr & 7)) * 16 + fg * 4) = make_float4(st.o[h][0], st.o[h][1], st.o[h][2], st.o[h][3]);
+        }
         __syncthreads();
         for (int idx = tid; idx < 512; idx += NTH) {
             const int col = idx >> 3, d0 = (idx & 7) * 2, h = col >> 3, t = col & 7;
@@ -1038,19 +1060,21 @@ extern "C" int msam_i2t0_t2i_fused(const void* tables, const void* operands0, co
     a.src = (const u16*)src; a.q0 = (const u16*)q0; a.oper0 = (const u16*)operands0; a.ln0_w = ln0_w; a.ln0_b = ln0_b; a.eps = ln_eps;
     a.aoper = aoper; a.wvfrag = wvfrag; a.tabk = (const u16*)tabk; a.bv = bv; a.Nt = Nt; a.P = P; a.out = (u16*)out; a.tmask = g_tune_chain_tmask;
     const int cus = cu_count(), grid = P < cus ? P : cus;
-    // algorithmic work of the two stages it replaces (image->token layer 0 + token->image attention of layer 1)
-    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32) * 2;
-    msam_profile_mark2(stream, 1, flops, 0.0, 3);
+    // executed MFMA work: 164 16x16x32 MFMAs per 16-token tile (8 + 16 + 32 layer-0 block, 36 + 64 + 8 attention)
+    const double flops = (double)P * (T / 16) * 164.0 * 16384.0;
+    msam_profile_mark2(stream, 1, flops, 0.0, 6);
     switch (g_tune_chain_variant) {
         case 1: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<4, 8>), dim3(grid), dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<4, 16>), dim3(grid), dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 3, true>), dim3(grid), dim3(512), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 2, true>), dim3(grid), dim3(512), 0, s, a); break;
 #define ABL_CASE(m_) case 100 + m_: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, m_>), dim3(grid), dim3(512), 0, s, a); break;
         ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(64) ABL_CASE(27) ABL_CASE(31) ABL_CASE(127)
 #undef ABL_CASE
         default: hipLaunchKernelGGL(i2t0_t2i_kernel, dim3(grid), dim3(NTHR8), 0, s, a);
     }
-    msam_profile_mark2(stream, 0, flops, 0.0, 3);
+    msam_profile_mark2(stream, 0, flops, 0.0, 6);
     return msam_check_launch("i2t0_t2i");
 }
 
@@ -1070,15 +1094,16 @@ extern "C" int msam_i2t01_fused(const void* tables, const void* operands0, const
     a.oper1 = (const u16*)operands1; a.tabq1 = (const u16*)tabq1; a.ln1_w = ln1_w; a.ln1_b = ln1_b; a.eps = ln_eps;
     a.Nt = Nt; a.P = P; a.out = (u16*)out;
     const int cus = cu_count(), grid = P < cus ? P : cus;
-    const double flops = (double)P * T * (2.0 * 64 * C * 2 + 2.0 * 64 * 32) * 2;
-    const double bytes = (double)P * T * C * 2;
-    msam_profile_mark2(stream, 1, flops, bytes, 2);
+    const double flops = (double)P * (T / 16) * 144.0 * 16384.0;        // executed: 56 (layer-0 block) + 88 (layer-1 block) MFMAs per tile
+    const double bytes = (double)P * T * C * 2;                        // the layer-1 stream, written once
+    msam_profile_mark2(stream, 1, flops, bytes, 7);
     switch (g_tune_chain_variant) {
         case 1: hipLaunchKernelGGL((i2t01_ring_kernel<4, 8>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
         case 2: hipLaunchKernelGGL((i2t01_ring_kernel<4, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
-        case 3: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
+        case 3: case 5: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
+        case 4: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4, 3>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
         default: hipLaunchKernelGGL(i2t01_kernel, dim3(grid), dim3(NTHR8), 0, (hipStream_t)stream, a);
     }
-    msam_profile_mark2(stream, 0, flops, bytes, 2);
+    msam_profile_mark2(stream, 0, flops, bytes, 7);
     return msam_check_launch("i2t01");
 }

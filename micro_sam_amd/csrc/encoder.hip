@@ -2,7 +2,8 @@
 // Stands behind `predictor.model.image_encoder(x)` (micro_sam/util.py:674) and, with uint8 input, also fuses
 // `predictor.model.preprocess` (util.py:670).  Hyper-parameters: micro_sam/models/build_sam.py:40-113.
 //
-// Residual stream x: fp32 [B*4096, D].  Every GEMM operand is bf16 (LN output, attention output, GELU output).
+// Residual stream x: fp32 [B*4096, D].  Every GEMM operand is 16 bit (LN output, attention output, GELU output): bf16, or IEEE
+// fp16 when msam_encoder_t.dtype16 == MSAM_F16 (same kernels and MFMA rate, 11 instead of 8 significand bits).
 // Windowed blocks run on the 4096 real tokens only: the reference pads LN output with zeros to 70x70, so padding
 // tokens are exactly q/k/v = bias, which the window attention kernel synthesises (no partition / un-partition copies).
 #include "common.h"
@@ -73,6 +74,8 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
     const float scale = 1.0f / sqrtf((float)(D / H));
     if (workspace_bytes < enc_bytes(D, DA, B, enc->fp8)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
     const bool fp8 = enc->fp8 != 0;
+    const int dt = enc->dtype16 == MSAM_F16 ? MSAM_F16 : MSAM_BF16;        // the 16-bit type of every operand / stored activation
+    if (fp8 && dt == MSAM_F16) { msam_set_error("msam_encoder_forward: fp8 projections go with the bf16 mode only"); return 1; }
     if (fp8 && (D % 128 || DA % 128)) { msam_set_error("msam_encoder_forward: fp8 needs embed_dim and heads * head_dim % 128 == 0"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     EncWork w = carve(workspace, D, DA, B, enc->fp8);
@@ -86,11 +89,12 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
         g.table = table; g.table_rows = trows; g.table_cols = tcols; g.table_ld = tld;
         g.resid = resid; g.resid_dtype = rdt; g.ldr = ldr; g.act = act; g.out = o; g.out_dtype = odt; g.ldc = ldc;
         g.use_glds = enc->use_glds;
+        g.a_dtype = dt == MSAM_F16 ? MSAM_F16 : 0;
         return msam_gemm_bf16(&g, s);
     };
     // patch embedding (+ bias + absolute position embedding)
-    if (img_u8) CHECK(msam_patchify_u8(img_u8, B, h, w_, w.patches, s));
-    else CHECK(msam_patchify(img_f32, B, w.patches, s));
+    if (img_u8) CHECK(msam_patchify_u8_16(img_u8, B, h, w_, dt, w.patches, s));
+    else CHECK(msam_patchify16(img_f32, B, dt, w.patches, s));
     CHECK(gemm(w.patches, 768, enc->patch_w, D, 768, enc->patch_b, w.x, MSAM_F32, D, 0, nullptr, 0, 0, enc->pos_embed,
                (int)TOK, D, D));
     // fp8 projection: A fp8 [R, K] with row scales, W fp8 [N, K] with column scales
@@ -113,17 +117,18 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
             g.a_dtype = MSAM_FP8; g.row_scale = w.rs_x; g.col_scale = enc->qkv_cs[i];
             CHECK(msam_gemm_bf16(&g, s));
         } else {
-            CHECK(msam_layernorm(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
+            CHECK(msam_layernorm(w.x, enc->ln1_w[i], enc->ln1_b[i], 1e-6f, R, D, w.xn, dt, 0, 0, s));
             msam_gemm_t g{};
             g.A = w.xn; g.lda = D; g.W = enc->qkv_w[i]; g.ldw = D; g.M = R; g.N = 3 * DA; g.K = D; g.bias = enc->qkv_b[i];
             g.out_mode = 1; g.q = w.q; g.k = w.k; g.v = w.v; g.heads = H; g.head_dim = HS; g.tokens = (int)TOK;
             g.use_glds = enc->use_glds;
+            if (dt == MSAM_F16) { g.a_dtype = MSAM_F16; g.out_dtype = MSAM_F16; }
             CHECK(msam_gemm_bf16(&g, s));
         }
         if (enc->is_global[i])
-            CHECK(msam_global_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], B, H, HS, scale, w.attn, s));
+            CHECK(msam_global_attention16(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], B, H, HS, scale, dt, w.attn, s));
         else
-            CHECK(msam_window_attention(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], enc->qkv_b[i], B, H, HS, scale, w.attn, s));
+            CHECK(msam_window_attention16(w.q, w.k, w.v, enc->rel_h[i], enc->rel_w[i], enc->qkv_b[i], B, H, HS, scale, dt, w.attn, s));
         if (fp8) {
             CHECK(msam_quant_rows_fp8(w.attn, R, DA, w.attn8, w.rs_a, s));
             CHECK(gemm8(w.attn8, w.rs_a, enc->proj_w8[i], enc->proj_cs[i], D, DA, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x));
@@ -134,8 +139,8 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
             CHECK(gemm8(w.hid8, w.rs_h, enc->lin2_w8[i], enc->lin2_cs[i], D, 4 * D, enc->lin2_b[i], w.x, MSAM_F32, D, 0, w.x));
         } else {
         CHECK(gemm(w.attn, DA, enc->proj_w[i], D, DA, enc->proj_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0, 0, 0));
-        CHECK(msam_layernorm(w.x, enc->ln2_w[i], enc->ln2_b[i], 1e-6f, R, D, w.xn, MSAM_BF16, 0, 0, s));
-        CHECK(gemm(w.xn, D, enc->lin1_w[i], 4 * D, D, enc->lin1_b[i], w.hid, MSAM_BF16, 4 * D, MSAM_ACT_GELU, nullptr, 0, 0,
+        CHECK(msam_layernorm(w.x, enc->ln2_w[i], enc->ln2_b[i], 1e-6f, R, D, w.xn, dt, 0, 0, s));
+        CHECK(gemm(w.xn, D, enc->lin1_w[i], 4 * D, D, enc->lin1_b[i], w.hid, dt, 4 * D, MSAM_ACT_GELU, nullptr, 0, 0,
                    nullptr, 0, 0, 0));
         CHECK(gemm(w.hid, 4 * D, enc->lin2_w[i], D, 4 * D, enc->lin2_b[i], w.x, MSAM_F32, D, 0, w.x, MSAM_F32, D, nullptr, 0,
                    0, 0));
@@ -147,9 +152,9 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
             }
     }
     // neck: conv1x1 -> LayerNorm2d -> conv3x3 (pad 1) -> LayerNorm2d, output NCHW fp32
-    CHECK(msam_cast_f32_to_bf16(w.x, w.xn, (long)R * D, s));
+    CHECK(msam_cast_f32_to_16(w.x, dt, w.xn, (long)R * D, s));
     CHECK(gemm(w.xn, D, enc->neck0_w, 256, D, nullptr, w.n0, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
-    CHECK(msam_layernorm(w.n0, enc->neck1_w, enc->neck1_b, 1e-6f, R, 256, w.n1, MSAM_BF16, 0, 0, s));
+    CHECK(msam_layernorm(w.n0, enc->neck1_w, enc->neck1_b, 1e-6f, R, 256, w.n1, dt, 0, 0, s));
     CHECK(msam_im2col3x3(w.n1, B, 256, w.col, s));
     CHECK(gemm(w.col, 2304, enc->neck2_w, 256, 2304, nullptr, w.n2, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
     CHECK(msam_layernorm(w.n2, enc->neck3_w, enc->neck3_b, 1e-6f, R, 256, out, MSAM_F32, 0, (int)TOK, s));

@@ -321,8 +321,12 @@ __global__ __launch_bounds__(256, 2) void gemm_group_kernel(GroupArgs g) {
 // LDS in two column halves (256 x 128 fp32 = 128 KB, 16-byte chunks XOR-swizzled with the row) and is written out
 // row-wise with the residual rows requested up front, exactly like the 128 x 128 kernel.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
+template <bool F16 = false>
 MSAM_DEVINL f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 // 32 x 32 x 64 fp8 (OCP e4m3) through the block-scaled MX instruction with unit block scales (e8m0 127 = 2^0 in every byte):
 // the only large-K fp8 MFMA of gfx950 and the only one that runs at twice the bf16 rate.  A lane holds 32 consecutive
@@ -348,7 +352,8 @@ constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 
 // FP8: A and W are fp8 e4m3 bytes (lda / ldw / K in elements = bytes), a k-tile is 128 elements (the same 128-byte LDS
 // rows, swizzle and staging map as bf16), two 32 x 32 x 64 MX MFMAs per 128-byte row instead of four 32 x 32 x 16 bf16 ones:
 // the same kernel time per byte, twice the elements per byte.  Row / column scales are applied in the epilogue.
-template <int STAGING, bool FP8 = false>
+// F16: IEEE fp16 operands and 16-bit outputs (the image encoder's fp16 mode, msam_encoder_t.dtype16): same kernel, the fp16 MFMA.
+template <int STAGING, bool FP8 = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                          long ldw, int M, int N, int K, Epi e) {
     constexpr int ESZ = FP8 ? 1 : 2;              // bytes per operand element
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[i], af[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32<F16>(wf[i], af[j], acc[i][j]);
         }
     };
     if constexpr (STAGING == 0) {
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wfr[q2][i], afr[q2][j], acc[i][j]);
+                            for (int j = 0; j < 4; ++j) acc[i][j] = mfma32<F16>(wfr[q2][i], afr[q2][j], acc[i][j]);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __syncthreads();
@@ -650,13 +655,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
                     if (e.out_dtype == MSAM_F32) {
                         *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
-                        uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                        uint2 pk;
+                        if constexpr (F16) { pk.x = pack2h(v[0], v[1]); pk.y = pack2h(v[2], v[3]); }
+                        else { pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); }
                         *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
                     }
                 } else {
                     u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
                     const int b = row / e.tokens, t = row - b * e.tokens;
-                    uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+                    uint2 pk;
+                    if constexpr (F16) { pk.x = pack2h(v[0], v[1]); pk.y = pack2h(v[2], v[3]); }
+                    else { pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); }
                     *(uint2*)(dst + ((long)(b * e.heads + head) * e.tokens + t) * e.head_dim + d) = pk;
                 }
             }
@@ -995,14 +1004,16 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     }
     if (g_gemm256_staging >= 0) staging256 = g_gemm256_staging;
     // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
-    if (use256 && !f16 && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 && p->out_mode != 2 && !p->table &&
-        (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
+    // (fp16 operands: 16-bit outputs of this kernel are then fp16 as well - the encoder's fp16 mode; a bf16 output is not offered)
+    if (use256 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 &&
+        p->out_mode != 2 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr256 = false;
         if (!attr256) {
             if (hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
                 hipFuncSetAttribute((const void*)gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
                 hipFuncSetAttribute((const void*)gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
-                hipFuncSetAttribute((const void*)gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
+                hipFuncSetAttribute((const void*)gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm256_kernel<3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess) {
                 msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
                 return 2;
             }
@@ -1015,7 +1026,10 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         const int tiles256 = ((p->M + G2 - 1) / G2) * (p->N / G2);
 #define G2_GO(ST_) hipLaunchKernelGGL(gemm256_kernel<ST_>, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda, \
                                      (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e)
-        if (staging256 == 1) G2_GO(1); else if (staging256 == 2) G2_GO(2); else if (staging256 == 3) G2_GO(3); else G2_GO(0);
+        if (f16)
+            hipLaunchKernelGGL((gemm256_kernel<3, false, true>), dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda,
+                               (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+        else if (staging256 == 1) G2_GO(1); else if (staging256 == 2) G2_GO(2); else if (staging256 == 3) G2_GO(3); else G2_GO(0);
 #undef G2_GO
         if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
         return msam_check_launch("msam_gemm_bf16(256)");

@@ -7,6 +7,9 @@ void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
 
 namespace {
+// 16-bit outputs: MSAM_F16 -> IEEE fp16 (mask decoder; the image encoder's fp16 mode), anything else -> bf16
+MSAM_DEVINL uint32_t pk16(float lo, float hi, int dt) { return dt == MSAM_F16 ? pack2h(lo, hi) : pack2bf(lo, hi); }
+MSAM_DEVINL u16 cv16(float v, int dt) { return dt == MSAM_F16 ? f2h(v) : f2bf(v); }
 
 // One wave per row.  VEC = float4 loads per lane (dim == 256 * VEC) or 0 for the scalar path (dim <= 64*20).
 template <int VEC>
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             } else if (out_dtype == MSAM_F32) {
                 *(float4*)((float*)out + row * dim + c) = make_float4(y0, y1, y2, y3);
             } else {
-                uint2 pk; pk.x = pack2bf(y0, y1); pk.y = pack2bf(y2, y3);
+                uint2 pk; pk.x = pk16(y0, y1, out_dtype); pk.y = pk16(y2, y3, out_dtype);
                 *(uint2*)((u16*)out + row * dim + c) = pk;
             }
         }
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                     const long bimg = row / nchw_hw, t = row - bimg * nchw_hw;
                     ((float*)out)[(bimg * dim + c) * (long)nchw_hw + t] = y;
                 } else if (out_dtype == MSAM_F32) ((float*)out)[row * dim + c] = y;
-                else ((u16*)out)[row * dim + c] = f2bf(y);
+                else ((u16*)out)[row * dim + c] = cv16(y, out_dtype);
             }
         }
     }
@@ -195,11 +198,11 @@ __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restric
           y3 = d3 * rstd * ww.w + bb.w;
     if (gelu) { y0 = gelu_erf(y0); y1 = gelu_erf(y1); y2 = gelu_erf(y2); y3 = gelu_erf(y3); }
     if (out_dtype == MSAM_F32) *(float4*)((float*)out + row * 64 + c) = make_float4(y0, y1, y2, y3);
-    else { uint2 pk; pk.x = pack2bf(y0, y1); pk.y = pack2bf(y2, y3); *(uint2*)((u16*)out + row * 64 + c) = pk; }
+    else { uint2 pk; pk.x = pk16(y0, y1, out_dtype); pk.y = pk16(y2, y3, out_dtype); *(uint2*)((u16*)out + row * 64 + c) = pk; }
 }
 
 // thread -> 8 consecutive kx of one (patch, c, ky): out col = c*256 + ky*16 + kx
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, u16* __restrict__ out) {
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, u16* __restrict__ out, int dt) {
     const long total = (long)B * 4096 * 96;   // 768 / 8 chunks per patch row
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int chunk = (int)(i % 96);
@@ -209,14 +212,14 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const int c = chunk >> 5, ky = (chunk >> 1) & 15, kx0 = (chunk & 1) * 8;
         const float* src = img + (((long)b * 3 + c) * 1024 + (py * 16 + ky)) * 1024 + px * 16 + kx0;
         float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
-        uint4 pk; pk.x = pack2bf(a.x, a.y); pk.y = pack2bf(a.z, a.w); pk.z = pack2bf(d.x, d.y); pk.w = pack2bf(d.z, d.w);
+        uint4 pk; pk.x = pk16(a.x, a.y, dt); pk.y = pk16(a.z, a.w, dt); pk.z = pk16(d.x, d.y, dt); pk.w = pk16(d.z, d.w, dt);
         *(uint4*)(out + prow * 768 + chunk * 8) = pk;
     }
 }
 
 // Sam.preprocess fused: (u8 - mean) / std, zero pad to 1024 (micro_sam/models/build_sam.py:132-133)
 __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, int B, int h, int w,
-                                                          u16* __restrict__ out) {
+                                                          u16* __restrict__ out, int dt) {
     const float mean[3] = {123.675f, 116.28f, 103.53f};
     const float stdv[3] = {58.395f, 57.12f, 57.375f};
     const long total = (long)B * 4096 * 96;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
             v[j] = (y < h && x < w)
                        ? __fdiv_rn((float)img[(((long)b * h + y) * w + x) * 3 + c] - mean[c], stdv[c]) : 0.f;
         }
-        uint4 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+        uint4 pk; pk.x = pk16(v[0], v[1], dt); pk.y = pk16(v[2], v[3], dt); pk.z = pk16(v[4], v[5], dt); pk.w = pk16(v[6], v[7], dt);
         *(uint4*)(out + prow * 768 + chunk * 8) = pk;
     }
 }
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const u16* __restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, u16* __restrict__ out, long n) {
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, u16* __restrict__ out, long n, int dt) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 t = *(const float4*)(x + i * 4);
-        uint2 pk; pk.x = pack2bf(t.x, t.y); pk.y = pack2bf(t.z, t.w);
+        uint2 pk; pk.x = pk16(t.x, t.y, dt); pk.y = pk16(t.z, t.w, dt);
         *(uint2*)(out + i * 4) = pk;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = f2bf(x[n4 * 4 + threadIdx.x]);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = cv16(x[n4 * 4 + threadIdx.x], dt);
 }
 
 inline int grid_for(long work_items) {
@@ -325,21 +328,25 @@ extern "C" int msam_quant_rows_fp8(const void* x_bf16, int64_t rows, int32_t dim
     return msam_check_launch("msam_quant_rows_fp8");
 }
 
-extern "C" int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream) {
-    if (!img || !out_bf16 || B <= 0) { msam_set_error("msam_patchify: bad arguments"); return 1; }
+extern "C" int msam_patchify16(const float* img, int32_t B, int32_t dtype16, void* out16, void* stream) {
+    if (!img || !out16 || B <= 0) { msam_set_error("msam_patchify: bad arguments"); return 1; }
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img, B,
-                       (u16*)out_bf16);
+                       (u16*)out16, dtype16);
     return msam_check_launch("msam_patchify");
 }
+extern "C" int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream) { return msam_patchify16(img, B, MSAM_BF16, out_bf16, stream); }
 
-extern "C" int msam_patchify_u8(const uint8_t* img, int32_t B, int32_t h, int32_t w, void* out_bf16, void* stream) {
-    if (!img || !out_bf16 || B <= 0 || h <= 0 || w <= 0 || h > 1024 || w > 1024) {
+extern "C" int msam_patchify_u8_16(const uint8_t* img, int32_t B, int32_t h, int32_t w, int32_t dtype16, void* out16, void* stream) {
+    if (!img || !out16 || B <= 0 || h <= 0 || w <= 0 || h > 1024 || w > 1024) {
         msam_set_error("msam_patchify_u8: bad arguments (need 0 < h,w <= 1024)");
         return 1;
     }
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img,
-                       B, h, w, (u16*)out_bf16);
+                       B, h, w, (u16*)out16, dtype16);
     return msam_check_launch("msam_patchify_u8");
+}
+extern "C" int msam_patchify_u8(const uint8_t* img, int32_t B, int32_t h, int32_t w, void* out_bf16, void* stream) {
+    return msam_patchify_u8_16(img, B, h, w, MSAM_BF16, out_bf16, stream);
 }
 
 extern "C" int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, void* stream) {
@@ -349,9 +356,11 @@ extern "C" int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* ou
     return msam_check_launch("msam_im2col3x3");
 }
 
+extern "C" int msam_cast_f32_to_16(const float* x, int32_t dtype16, void* out16, int64_t n, void* stream) {
+    if (!x || !out16 || n <= 0) { msam_set_error("msam_cast_f32_to_16: bad arguments"); return 1; }
+    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out16, (long)n, dtype16);
+    return msam_check_launch("msam_cast_f32_to_16");
+}
 extern "C" int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream) {
-    if (!x || !out_bf16 || n <= 0) { msam_set_error("msam_cast_f32_to_bf16: bad arguments"); return 1; }
-    hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, x, (u16*)out_bf16,
-                       (long)n);
-    return msam_check_launch("msam_cast_f32_to_bf16");
+    return msam_cast_f32_to_16(x, MSAM_BF16, out_bf16, n, stream);
 }

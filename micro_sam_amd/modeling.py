@@ -120,11 +120,14 @@ class ImageEncoderViT(nn.Module):
         self._prep = None
 
     def set_precision(self, precision: str) -> None:
-        """"bf16" (default: every matrix-product operand bf16) or "fp8": the four large projections of every block take OCP
-        e4m3 operands on the MX-scaled MFMA (per-token activation scales, per-output-channel weight scales; fp32
-        accumulation, scales applied in the GEMM epilogue); attention, patch embedding and neck stay bf16."""
-        if precision not in ("bf16", "fp8"):
-            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16' or 'fp8'")
+        """"bf16" (default: every matrix-product operand bf16); "fp16": every operand and stored activation IEEE fp16 instead -
+        the same kernels on the fp16 MFMAs of the same rate, 11 instead of 8 significand bits (activations of the encoder are
+        LayerNorm outputs, q / k / v, softmax probabilities and GELU outputs: inside fp16's range; the residual stream stays
+        fp32); "fp8": the four large projections of every block take OCP e4m3 operands on the MX-scaled MFMA (per-token
+        activation scales, per-output-channel weight scales; fp32 accumulation, scales applied in the GEMM epilogue);
+        attention, patch embedding and neck stay bf16."""
+        if precision not in ("bf16", "fp16", "fp8"):
+            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16', 'fp16' or 'fp8'")
         if precision != self.precision:
             self.precision = precision
             self.invalidate()
@@ -143,6 +146,11 @@ class ImageEncoderViT(nn.Module):
 
         p = _lib.EncoderParams()
         p.embed_dim, p.depth, p.heads = D, self.depth, self.num_heads
+        f16 = self.precision == "fp16"
+        p.dtype16 = _lib.F16 if f16 else _lib.BF16
+
+        def _bf16(t):               # the encoder's 16-bit operand type (shadows the module-level bf16 helper in this method)
+            return t.detach().to(torch.float16 if f16 else torch.bfloat16).contiguous()
         # stored head_dim: the attention kernels contract over multiples of 32 channels; vit_h's 80-channel heads are
         # zero-padded to 96 (exact: padded q / k channels add 0 to every score, padded v channels give 0 outputs that meet
         # zero columns of the padded proj weight)

@@ -199,24 +199,36 @@ def im2col3x3(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _enc16(*tensors) -> int:
+    """MSAM_BF16 / MSAM_F16 of the encoder-side 16-bit operands (all of one type)."""
+    dts = {t.dtype for t in tensors}
+    if dts == {torch.bfloat16}:
+        return _lib.BF16
+    if dts == {torch.float16}:
+        return _lib.F16
+    raise ValueError(f"expected all-bfloat16 or all-float16 operands, got {sorted(str(d) for d in dts)}")
+
+
 def window_attention(q, k, v, rel_h, rel_w, qkv_bias, scale: Optional[float] = None) -> torch.Tensor:
-    """q, k, v bf16 [B,heads,4096,hd] with hd (stored head_dim) 64 or 96; ``scale`` defaults to hd ** -0.5 (pass the true
-    head_dim's scale for zero-padded heads)."""
+    """q, k, v 16 bit (bf16, or fp16: the encoder's fp16 mode) [B,heads,4096,hd] with hd (stored head_dim) 64 or 96; ``scale``
+    defaults to hd ** -0.5 (pass the true head_dim's scale for zero-padded heads)."""
     B, heads, _, hd = q.shape
-    out = torch.empty((B * 4096, heads * hd), dtype=torch.bfloat16, device=q.device)
-    _lib.check(_lib.load().msam_window_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
-                                                 qkv_bias.data_ptr(), B, heads, hd, float(hd ** -0.5 if scale is None else scale),
-                                                 out.data_ptr(), _lib.stream_ptr()),
+    dt = _enc16(q, k, v, rel_h, rel_w)
+    out = torch.empty((B * 4096, heads * hd), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.load().msam_window_attention16(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
+                                                   qkv_bias.data_ptr(), B, heads, hd, float(hd ** -0.5 if scale is None else scale),
+                                                   dt, out.data_ptr(), _lib.stream_ptr()),
                "msam_window_attention")
     return out
 
 
 def global_attention(q, k, v, rel_h, rel_w, scale: Optional[float] = None) -> torch.Tensor:
     B, heads, _, hd = q.shape
-    out = torch.empty((B * 4096, heads * hd), dtype=torch.bfloat16, device=q.device)
-    _lib.check(_lib.load().msam_global_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
-                                                 B, heads, hd, float(hd ** -0.5 if scale is None else scale), out.data_ptr(),
-                                                 _lib.stream_ptr()), "msam_global_attention")
+    dt = _enc16(q, k, v, rel_h, rel_w)
+    out = torch.empty((B * 4096, heads * hd), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.load().msam_global_attention16(q.data_ptr(), k.data_ptr(), v.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(),
+                                                   B, heads, hd, float(hd ** -0.5 if scale is None else scale), dt, out.data_ptr(),
+                                                   _lib.stream_ptr()), "msam_global_attention")
     return out
 
 

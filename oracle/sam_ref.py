@@ -65,6 +65,8 @@ PIXEL_STD = (58.395, 57.12, 57.375)      # build_sam.py:133
 # tensors): IEEE fp16 in the default build of libmsam_hip.so (csrc/common.h MSAM_DEC_F16), bf16 in the ablation build.
 # tests/conftest.py sets this from ``micro_sam_amd._lib.decoder_dtype()`` on a GPU box.
 DECODER_DTYPE = torch.float16
+# 16-bit operand type of the image encoder in the "bf16" policy (the product: bf16; torch.float16 = what-if ablation, tools/iou_ablation.py encfp16)
+ENCODER_DTYPE = torch.bfloat16
 
 
 class Prec:
@@ -100,7 +102,7 @@ class Prec:
         """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode (or when the site is kept exact)."""
         if not self.rounds(site):
             return x
-        dt = self.site_dtype.get(site, torch.bfloat16 if site is None else self.dec_dtype)
+        dt = self.site_dtype.get(site, ENCODER_DTYPE if site is None else self.dec_dtype)
         if dt == "split":             # bf16 hi + lo operand pair (two / three MFMA passes): ~16 mantissa bits
             hi = x.to(torch.bfloat16).to(torch.float32)
             return hi + (x - hi).to(torch.bfloat16).to(torch.float32)

@@ -3,6 +3,7 @@
     python tools/iou_ablation.py sites          per decoder rounding site: flipped pixels / IoU of the kept candidates
     python tools/iou_ablation.py paths          oracle emulation of (encoder, decoder) precision combinations on the full
                                                 32 x 32 grid of tile 1000 vs the fp32 reference (per-instance IoU report)
+    python tools/iou_ablation.py encfp16        what-if: fp16 instead of bf16 MFMA operands in the image encoder
 
 Embeddings / states are cached under /tmp/msam_ablation.
 """
@@ -96,8 +97,30 @@ def paths(sd, img):
               flush=True)
 
 
+def encfp16(sd, img):
+    """What-if: the image encoder's MFMA operands in fp16 instead of bf16 (same MFMA rate, 11 instead of 8 significand bits), decoder
+    fp16 as in the default build - the oracle's emulation on the full 32 x 32 grid of tile 1000 against the committed fp32 golden."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "cells_vit_b_tile1000.npz"))
+    kept_ref = g["kept"].astype(np.int64)
+    off, cnt = g["rle_offsets"], g["rle_counts"]
+    pos = {int(c): j for j, c in enumerate(kept_ref)}
+    ref_mask = lambda i: A.rle_to_mask({"size": [1024, 1024], "counts": cnt[off[pos[i]]:off[pos[i] + 1]]})
+    for name, edt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        t0 = time.time()
+        S.ENCODER_DTYPE = edt
+        S.DECODER_DTYPE = torch.float16
+        f, _, _ = PR.compute_embeddings(sd, [img], "vit_b", "bf16")
+        emb_err = float((f - embedding(sd, img, "fp32")).abs().mean())
+        st = PR.amg_initialize(sd, img, f, (1024, 1024), (1024, 1024), precision="bf16")
+        rep = PT.public(PT.iou_report(kept_ref, PT.kept_candidates(st), ref_mask, PT.oracle_mask_fn(st)))
+        rep.pop("worst")
+        print(f"encoder operands {name}, decoder fp16 (oracle emulation): embedding mean |d| {emb_err:.5f}  {json.dumps(rep)} "
+              f"({time.time() - t0:.0f}s)", flush=True)
+    S.ENCODER_DTYPE = torch.bfloat16
+
+
 if __name__ == "__main__":
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     sd_ = synthetic_state_dict("vit_b", 0, variant="cells")
     img_ = A.to_image(synthetic_tile(1000))
-    (sites if (len(sys.argv) < 2 or sys.argv[1] == "sites") else paths)(sd_, img_)
+    {"sites": sites, "paths": paths, "encfp16": encfp16}[sys.argv[1] if len(sys.argv) > 1 else "sites"](sd_, img_)

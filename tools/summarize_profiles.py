@@ -21,6 +21,10 @@ GO = os.path.join(ROOT, "gpurun_out")
 # algorithmic HBM bytes per launch at P = 1024 prompts: stream = 1024 * 4096 * 256 * 2 B = 2 GiB
 GiB = 1 << 30
 ALGO = {
+    "i2t01_kernel": ("2 GiB written (the layer-1 stream, blocked layout); the shared tables (5 MiB) and the per-prompt operands "
+                     "(144 KiB per prompt) come from L2", 2 * GiB),
+    "i2t0_t2i_kernel": ("no per-prompt stream: shared tables (5 MiB) + operands (112 KiB per prompt) from L2, [P,7,128] written",
+                        1024 * (112 * 1024 + 7 * 128 * 2)),
     "fold_i2t_kernel": ("layer-1 launches (the larger half): 2 GiB read + 2 GiB written in place; layer 0 writes 2 GiB only", 4 * GiB),
     "fold_attn_kernel": ("2 GiB read (value projection fused: only [P,7,128] bf16 written)", 2 * GiB),
     "up_fused_kernel": ("2 GiB read + 0.75 GiB fp32 low-res logits written", 2 * GiB + 3 * 1024 * 65536 * 4),
@@ -51,9 +55,10 @@ def main():
     pb = json.loads(prof_line)
     tiles = pb["config"]["tiles_per_step_per_gpu"] * (pb["steps"] + pb["warmup"] + 1)      # + the instrumented pass
     with open(os.path.join(OUT, f"{TAG}_bench_kernel_summary.md"), "w") as f:
-        f.write(f"# {TAG}: rocprofv3 kernel summary of `python bench.py --no-cpu-baseline` on one MI355X\n\n")
+        f.write(f"# {TAG}: rocprofv3 kernel summary of `python bench.py --no-cpu-baseline --lanes 1` on one MI355X\n\n")
         f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_prof -- python bench.py "
-                "--no-cpu-baseline`\n")
+                "--no-cpu-baseline --lanes 1` (one decode lane: kernels of different tiles do not overlap, the same order as the "
+                "serial roofline pass of bench.py)\n")
         f.write(f"(bench line of this profiled run: {pb['value']} tiles/s; unprofiled run with cpu_baseline: {bench['value']} "
                 f"tiles/s, `{TAG}_bench_line.json`).\n\n")
         f.write(f"GPU time {total / 1e6:.1f} ms over {tiles} tiles ({pb['warmup']} warm-up + {pb['steps']} timed + 1 instrumented "
