@@ -168,6 +168,26 @@ int64_t msam_i2t0_t2i_workspace_bytes(int32_t P);
 int msam_i2t0_t2i_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b, float ln_eps,
                         const void* qtok, int32_t P, int32_t Nt, const void* wk, const void* wv, const float* bv, void* out,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* Second form of msam_i2t0_t2i_fused (fewer LDS operand reads and MFMAs per tile; csrc/decfold_tok.hip "second form"): norm4 of
+ * layer 0 is folded into the attention's operands and the value projection is taken before that LayerNorm by linearity.
+ *   msam_chain_prepare_tables2: prompt-independent tables, once per decode: src d16 [4096,256] (row-major), wv / bv / wk of the
+ *       layer-1 token->image attention, ln0_w / ln0_b = norm4 of layer 0, wo0 d16 [256,128] / bo0 = out_proj of the layer-0
+ *       image->token attention -> tables2 (>= msam_chain_tables2_bytes());
+ *   msam_t2i_fold_values: per prompt, from the layer-0 image->token value tokens vtok0 d16 [P,Nt,128] (the same tensor that went
+ *       into msam_i2t_fold_operands for layer 0) -> mf (>= msam_t2i_fold_values_bytes(P));
+ *   msam_i2t0_t2i_fused_v2: same result as msam_i2t0_t2i_fused (other rounding points). */
+int64_t msam_chain_tables2_bytes(void);
+int msam_chain_prepare_tables2(const void* src, const void* wv, const float* bv, const void* wk, const float* ln0_w,
+                               const float* ln0_b, const void* wo0, const float* bo0, void* tables2, void* stream);
+int64_t msam_t2i_fold_values_bytes(int32_t P);
+int msam_t2i_fold_values(const void* vtok0, int32_t P, int32_t Nt, const void* tables2, void* mf, void* stream);
+/* msam_i2t_fold_operands and msam_t2i_fold_values in one launch */
+int msam_i2t_fold_operands_values(const void* ktok, const void* vtok, int32_t P, int32_t Nt, const void* wq, const void* wo,
+                                  const float* bo, int32_t with_kfold, const void* tables2, void* operands, void* mf, void* stream);
+int64_t msam_i2t0_t2i_v2_workspace_bytes(int32_t P);
+int msam_i2t0_t2i_fused_v2(const void* tables, const void* tables2, const void* operands0, const void* mf, const float* ln0_w,
+                           float ln_eps, const void* qtok, int32_t P, int32_t Nt, const void* wk, void* out, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 int msam_i2t01_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b, const void* operands1,
                      const float* ln1_w, const float* ln1_b, float ln_eps, int32_t P, int32_t Nt, void* out, void* stream);
 
@@ -197,7 +217,7 @@ int msam_fold_attn_set_dma(int32_t on);
 /* named integer tuning knobs of the decoder stream kernels (A/B experiments, tests): "i2t_variant" (1 = token-owner kernel,
  * default; 0 = 4-wave tile kernel), "i2t_wg_per_cu", "dec_chain" (1 = the decoder takes the chained forms above when the
  * prompts share one source, Nt <= 8 and P >= "dec_chain_min_p"; default 1 / 128), "chain_variant" (builds of the chained
- * kernels, 0 = default), "up_gelu16" (1 = the up-scaling's GELUs in packed fp16 arithmetic, default in the fp16 decoder build;
+ * kernels: 9 = default, second attention form; 6 = first form; csrc/decfold_tok.hip), "up_gelu16" (1 = the up-scaling's GELUs in packed fp16 arithmetic, default in the fp16 decoder build;
  * 0 = packed fp32).  Returns 0, 1 for an unknown key. */
 int msam_tune_set(const char* key, int32_t value);
 /* debug hook: phase timing of the folded image->token kernel (see csrc/decfold.hip, tools/i2t_timing.py) */

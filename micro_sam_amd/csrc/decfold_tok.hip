@@ -31,8 +31,9 @@ void msam_profile_mark2(void* stream, int begin, double flops, double bytes, int
 int g_tune_i2t_variant = 1;          // 1: token-owner kernel (this file), 0: fold_i2t_kernel (decfold.hip)
 int g_tune_i2t_wg_per_cu = 2;
 int g_tune_chain_tmask = 255;        // experiment: tile index mask of the SHARED-table loads of the ring kernels (255 = off)
-int g_tune_chain_variant = 0;        // chained kernels: 0 = 8 waves, 4-fragment groups; 1 / 2 = 4 waves (one per SIMD), rings of 8 / 16;
-                                     // 3 = 8 waves on the ring code with G = 4
+int g_tune_chain_variant = 9;        // chained kernels: 9 (default) = second form of the attention (V projection before the LayerNorm) + tile loads
+                                     // one phase ahead; 6 = first form, loads one phase ahead; 0 = first form, 4-fragment groups; 1 / 2 = 4 waves
+                                     // (one per SIMD), rings of 8 / 16; 3 = 8 waves on the ring code; 4 / 5 / 7 / 8 = ring depth 3 / compact accumulators
 
 namespace {
 
@@ -52,7 +53,8 @@ constexpr float SCALE = 0.25f * 1.4426950408889634f;        // 1 / sqrt(16) and 
 __global__ __launch_bounds__(256) void fold_frag_kernel(const u16* __restrict__ ktok, const u16* __restrict__ vtok,
                                                         const u16* __restrict__ wq, const u16* __restrict__ wo,
                                                         const float* __restrict__ bo, int Nt, int with_kf,
-                                                        u16* __restrict__ oper) {
+                                                        u16* __restrict__ oper, const unsigned char* __restrict__ t2 = nullptr,
+                                                        u16* __restrict__ mf = nullptr) {
     __shared__ __attribute__((aligned(16))) u16 img[OPER_BYTES / 2];
     __shared__ float kk[8][CI], vv[8][CI];
     const int p = blockIdx.x, c = threadIdx.x;
@@ -106,6 +108,28 @@ __global__ __launch_bounds__(256) void fold_frag_kernel(const u16* __restrict__ 
             }
             const int a = h >> 2, fg = h & 3;
             *(uint4*)(img + VF_OFF / 2 + ((a * 16 + ct) * 64 + fg * 16 + rho) * 8) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+    // ---- second form of the chained attention (t2 = its tables): M[(h,t)][d] = sum_e v[t][16h+e] WoWv[d][16h+e] + cd[d] / 8 as B
+    // fragments [a2][dv] (see fold_values_kernel; the 64 KiB of WoWv come from L2)
+    if (t2) {
+        const int d = c & 127, hh = c >> 7;
+        const float* wowv = (const float*)t2 + d * 128;                      // T2_WOWV = 0
+        const float cd8 = ((const float*)(t2 + 128 * 128 * 4))[d] * 0.125f;  // T2_CD
+        u16* mdst = mf + (long)p * (16 * FRAG / 2);
+        for (int h = hh * 4; h < hh * 4 + 4; ++h) {
+            float wv_[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wv_[e] = wowv[h * 16 + e];
+            uint32_t pk[4];
+#pragma unroll
+            for (int t2_ = 0; t2_ < 4; ++t2_) {
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { a0 = fmaf(wv_[e], vv[2 * t2_][h * 16 + e], a0); a1 = fmaf(wv_[e], vv[2 * t2_ + 1][h * 16 + e], a1); }
+                pk[t2_] = pack2d(2 * t2_ < Nt ? a0 + cd8 : 0.f, 2 * t2_ + 1 < Nt ? a1 + cd8 : 0.f);
+            }
+            *(uint4*)(mdst + ((((h >> 2) * 8 + (d >> 4)) * 64 + (h & 3) * 16 + (d & 15)) * 8)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         }
     }
     __syncthreads();
@@ -591,9 +615,11 @@ MSAM_DEVINL void ring_fill(Ring<G, Off::D>& r, const unsigned char* L, int batch
 #define RING_AT(n_) ring.buf[((n_) / G) % Off::D][(n_) % G]
 
 // image->token block (see i2t_block) on the fragments BASE .. of the stream: [8 or 40 score fragments][32 V'^T fragments]
-template <int G, class Off, int BASE, bool HAS_KF, int ABL = 0, class F>
+// AFFINE = false: y = the normalised values WITHOUT the LayerNorm weight / bias (the consumer has them folded into its operands);
+// pk_out / stat_out (optional): the packed probabilities of the block and (rstd, -mean rstd) of the lane's token (l & 15).
+template <int G, class Off, int BASE, bool HAS_KF, int ABL = 0, bool AFFINE = true, class F>
 MSAM_DEVINL void i2t_block_r(Ring<G, Off::D>& ring, const unsigned char* L, const float* gp, float eps, const uint4* b, const uint4* tb,
-                             const WaveConst& wc, uint4* y, F&& consumed) {
+                             const WaveConst& wc, uint4* y, F&& consumed, uint4* pk_out = nullptr, float* stat_out = nullptr) {
     constexpr int NS = HAS_KF ? 40 : 8, G0 = HAS_KF ? 0 : 8;
     f32x4_t s[4];
 #pragma unroll
@@ -647,6 +673,17 @@ MSAM_DEVINL void i2t_block_r(Ring<G, Off::D>& ring, const unsigned char* L, cons
     const float mean = s1 * (1.f / C);
     const float rstd = rsqrtf(fmaxf(s2 * (1.f / C) - mean * mean, 0.f) + eps);
     const float nmr = -mean * rstd;
+    if (pk_out) { pk_out[0] = pk[0]; pk_out[1] = pk[1]; }
+    if (stat_out) { stat_out[0] = rstd; stat_out[1] = nmr; }
+    if (!AFFINE) {
+#pragma unroll
+        for (int c2 = 0; c2 < 8; ++c2) {
+            const f32x4_t x0 = o[2 * c2], x1 = o[2 * c2 + 1];
+            y[c2] = make_uint4(pack2d(fmaf(x0[0], rstd, nmr), fmaf(x0[1], rstd, nmr)), pack2d(fmaf(x0[2], rstd, nmr), fmaf(x0[3], rstd, nmr)),
+                               pack2d(fmaf(x1[0], rstd, nmr), fmaf(x1[1], rstd, nmr)), pack2d(fmaf(x1[2], rstd, nmr), fmaf(x1[3], rstd, nmr)));
+        }
+        return;
+    }
 #pragma unroll
     for (int c2 = 0; c2 < 8; ++c2) {
         const float4 g0 = *(const float4*)(gp + c2 * 32), g1 = *(const float4*)(gp + c2 * 32 + 4);
@@ -750,7 +787,7 @@ template <int G, int D_ = 2> struct FuseOff {                // i2t0_t2i: [KT0 8
     }
 };
 
-template <int NW, int G, int D = 2>
+template <int NW, int G, int D = 2, bool LATE = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(ChainArgs a) {
     typedef ChainOff<G, D> Off;
     constexpr int ABL = 0;
@@ -790,7 +827,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(Ch
             const int to_ = (tile_) * (16 * CI * 2);                                               \
             _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tb[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
         } while (0)
-        CH_LOAD0(w); CH_LOAD1(w);
+        CH_LOAD0(w);
+        if (!LATE) CH_LOAD1(w);
         wait_vmem_all();
 #pragma unroll
         for (int k = 0; k + 1 < D; ++k) ring_fill<G, Off>(ring, L, k);
@@ -798,8 +836,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(Ch
             asm volatile("" ::: "memory");
             const int tile = w + NW * n, nx = w + NW * (n + 1 < NT ? n + 1 : NT - 1);
             uint4 y1[8], y2[8];
-            i2t_block_r<G, Off, 0, false>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { CH_LOAD0(nx); });
-            i2t_block_r<G, Off, 40, true>(ring, L, gp1, a.eps, y1, tb, wc, y2, [&]() { CH_LOAD1(nx); });
+            i2t_block_r<G, Off, 0, false>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { if (LATE) CH_LOAD1(tile); else CH_LOAD0(nx); });
+            i2t_block_r<G, Off, 40, true>(ring, L, gp1, a.eps, y1, tb, wc, y2, [&]() { if (LATE) CH_LOAD0(nx); else CH_LOAD1(nx); });
 #pragma unroll
             for (int i = Off::USED; i < Off::N; ++i) RING_STEP(i);
 #pragma unroll
@@ -810,7 +848,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t01_ring_kernel(Ch
     }
 }
 
-template <int NW, int G, int ABL = 0, int D = 2, bool COMPACT = false>
+// LATE: the tile loads are issued one phase (not one tile) ahead of their first use - the table tile of the attention during the
+// layer-0 block of the SAME tile, the source / q0 tile of the next tile during the V projection - so that their registers are free
+// in the phases that need them most (the loads hit L2: a phase is more than their latency).
+template <int NW, int G, int ABL = 0, int D = 2, bool COMPACT = false, bool LATE = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel(FuseArgs a) {
     typedef FuseOff<G, D> Off;
     constexpr int NTH = 64 * NW, NT = 256 / NW;
@@ -852,7 +893,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel
             const int to_ = (tile_) * (16 * CI * 2);                                               \
             _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tk[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
         } while (0)
-        FU_LOAD0(w & a.tmask); FU_LOAD1(w & a.tmask);
+        FU_LOAD0(w & a.tmask);
+        if (!LATE) FU_LOAD1(w & a.tmask);
         if (ABL & 32) {
 #pragma unroll
             for (int j = 0; j < G; ++j)
@@ -863,10 +905,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel
         for (int k = 0; k + 1 < D; ++k) ring_fill<G, Off, ABL>(ring, L, k);
         for (int n = 0; n < NT; ++n) {
             asm volatile("" ::: "memory");
-            const int nx = (w + NW * (n + 1 < NT ? n + 1 : NT - 1)) & a.tmask;
+            const int nx = (w + NW * (n + 1 < NT ? n + 1 : NT - 1)) & a.tmask, cur = (w + NW * n) & a.tmask;
             uint4 y1[8];
-            i2t_block_r<G, Off, 0, false, ABL>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { FU_LOAD0(nx); });
-            t2i_block_r<G, Off, 40, ABL, COMPACT>(ring, L, y1, tk, st, [&]() { FU_LOAD1(nx); });
+            i2t_block_r<G, Off, 0, false, ABL>(ring, L, gp0, a.eps, b, qi, wc, y1, [&]() { if (LATE) FU_LOAD1(cur); else FU_LOAD0(nx); });
+            t2i_block_r<G, Off, 40, ABL, COMPACT>(ring, L, y1, tk, st, [&]() { if (LATE) FU_LOAD0(nx); else FU_LOAD1(nx); });
 #pragma unroll
             for (int i = Off::USED; i < Off::N; ++i) RING_STEP(i);
         }
@@ -913,6 +955,336 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void i2t0_t2i_ring_kernel
             }
         }
     }
+}
+
+// ============================================================================================================
+// Second form of the chained attention (i2t0_t2i_v2_kernel): fewer LDS operand reads and MFMAs per tile (these kernels run at
+// the rate the LDS delivers fragments, profiles/r02_experiments.md).
+//  * The LayerNorm affine of the layer-0 block is folded into the attention's operands: gamma into Q' and Wv, beta into one
+//    constant per score column (beta . Q') and per output channel (Wv beta): the block emits x^ = (x - mean) rstd only - no
+//    weight / bias reads (32 of the 172 fragment-sized LDS reads per tile), two FMAs less per value.
+//  * The V projection is taken BEFORE the LayerNorm, by linearity:  x = src + P0 V''0 (out_proj bias inside V''0),
+//        V = x^ (gamma Wv)^T = rstd (src (gWv)^T + P0 (V''0 (gWv)^T) - mean rowsum(gWv)) = rstd (tabV + P0 M - mean gd)
+//    tabV [4096,128] and gd [128] are prompt independent (msam_chain_prepare_tables2); M [64,128] costs 16 MACs per entry per
+//    prompt (M[(h,t)][d] = sum_e v0[t][16h+e] WoWv[d][16h+e] + cd[d] / 8 with WoWv = (gWv) Wo, msam_t2i_fold_values).  Per tile:
+//    16 MFMAs / fragments (P0 from the layer-0 block's registers x M) instead of 64, plus ~3 VALU per value for the row / column
+//    terms; the row statistics of tokens 4 (l >> 4) + r come from the lanes that own those tokens (8 cross-lane reads).
+struct AttnOff2 {                                            // LDS image of the v2 kernel
+    static constexpr int KT0 = 0, VF0 = KT0 + KT_BYTES, QD2 = VF0 + VF_BYTES, QF2 = QD2 + 4 * FRAG, MF2 = QF2 + 32 * FRAG,
+                         COLC = MF2 + 16 * FRAG, GDT = COLC + 64 * 4, LDS = GDT + 128 * 4;
+};
+constexpr int AOPER2_BYTES = 4 * FRAG + 32 * FRAG;           // per prompt: [QD][QF (gamma folded)] + 64 column constants
+constexpr int AOPER2_STRIDE = AOPER2_BYTES + 256;
+constexpr int MF_BYTES = 16 * FRAG;                          // per prompt: M fragments [a2][dv]
+// tables2 blob: WoWv fp32 [128][128], cd / gd / bwv / kb fp32 [128] each, tabV d16 blocked-C [256 tiles][64 lanes][8 dv][4 rows]
+constexpr long T2_WOWV = 0, T2_CD = 128 * 128 * 4, T2_GD = T2_CD + 512, T2_BWV = T2_GD + 512, T2_KB = T2_BWV + 512,
+               T2_TABV = T2_KB + 512, T2_WVG = T2_TABV + (long)T * CI * 2 /* gamma Wv d16 [128][256] */,
+               T2_TABV_RM = T2_WVG + (long)CI * C * 2 /* row-major product before the relayout */, T2_BYTES = T2_TABV_RM + (long)T * CI * 2;
+
+template <int G, int D_ = 2> struct FuseOff2 {               // [KT0 8][VF0 32][QF / QD 36][MF 16]
+    static constexpr int D = D_, USED = 92, N = ((USED + D * G - 1) / (D * G)) * (D * G);
+    static __device__ constexpr int off(int n) {
+        if (n < 8) return AttnOff2::KT0 + ((n % 4) * 2 + n / 4) * FRAG;
+        if (n < 40) return AttnOff2::VF0 + (n - 8) * FRAG;
+        if (n < 76) { const int i = n - 40, g = i / 4, ct = i % 4; return g < 8 ? AttnOff2::QF2 + (ct * 8 + g) * FRAG : AttnOff2::QD2 + ct * FRAG; }
+        if (n < 92) { const int i = n - 76, dv = i / 2, a2 = i % 2; return AttnOff2::MF2 + (a2 * 8 + dv) * FRAG; }
+        return AttnOff2::KT0;
+    }
+};
+
+struct FuseArgs2 {
+    const u16* src; const u16* q0; const u16* tabk;   // blocked tables (msam_chain_prepare_tables)
+    const u16* tabv; const float* gd; const float* bwv;        // tables2
+    const u16* oper0;                    // layer-0 image->token operands (KT, VF)
+    const u16* aoper;                    // per prompt [QD][QF gamma][64 column constants]
+    const u16* mf;                       // per prompt M fragments
+    float eps; int Nt, P;
+    u16* out;
+};
+
+// colc / gd: this lane's column constants in LDS (float index 16 ct + (l & 15) / 16 dv + (l & 15), read where they are used)
+template <int G, class Off, int BASE, class F0, class F>
+MSAM_DEVINL void t2i_block_v2(Ring<G, Off::D>& ring, const unsigned char* L, const uint4* y, const uint4* tk, const uint4* tv,
+                              const uint4* pk0, float rstd, float nmr, const float* colc, const float* gd, AttnState& st, F0&& start,
+                              F&& consumed) {
+    constexpr int ABL = 0;
+    start();
+    f32x4_t s[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { const float c_ = colc[ct * 16]; s[ct] = f32x4_t{c_, c_, c_, c_}; }
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+        const int n = BASE + i, g = i / 4, ct = i % 4;
+        RING_STEP(n);
+        s[ct] = mfma16d(g < 8 ? y[g < 8 ? g : 0] : tk[ct], RING_AT(n), s[ct]);
+    }
+    consumed();
+    float mloc[4];
+    bool need = false;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        mloc[ct] = fmaxf(fmaxf(s[ct][0], s[ct][1]), fmaxf(s[ct][2], s[ct][3]));
+        need = need || (mloc[ct] > st.m[ct] + 8.f);
+    }
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float mx = mloc[ct];
+            mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(st.m[ct], mx), alpha = __builtin_amdgcn_exp2f(st.m[ct] - mn);
+            st.m[ct] = mn; st.l[ct] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st.o[2 * ct][r] *= alpha; st.o[2 * ct + 1][r] *= alpha; }
+        }
+    }
+    uint4 pb[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(s[ct][r] - st.m[ct]);
+        st.l[ct] += (e[0] + e[1]) + (e[2] + e[3]);
+        pb[ct] = make_uint4(pack2d(e[0], e[1]), pack2d(e[2], e[3]), 0u, 0u);
+    }
+    // statistics of the rows (tokens) 4 (l >> 4) + r of this lane's accumulators: owned by the lanes whose l & 15 is that token
+    float rr[4], nn[4];
+    const int row0 = (__lane_id() >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rr[r] = __shfl(rstd, row0 + r); nn[r] = __shfl(nmr, row0 + r); }
+    const uint32_t* tvw = (const uint32_t*)tv;               // [dv][2 words]: rows 0, 1 | rows 2, 3
+#pragma unroll
+    for (int dv = 0; dv < 8; ++dv) {
+        f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const int n = BASE + 36 + dv * 2 + a2;
+            RING_STEP(n);
+            v = mfma16d(pk0[a2], RING_AT(n), v);
+        }
+        const uint32_t w0 = tvw[2 * dv], w1 = tvw[2 * dv + 1];
+        const float t0 = d2f((u16)(w0 & 0xffff)), t1 = d2f((u16)(w0 >> 16)), t2 = d2f((u16)(w1 & 0xffff)), t3 = d2f((u16)(w1 >> 16));
+        const float g = gd[dv * 16];
+        const float v0 = fmaf(rr[0], v[0] + t0, nn[0] * g), v1 = fmaf(rr[1], v[1] + t1, nn[1] * g);
+        const float v2 = fmaf(rr[2], v[2] + t2, nn[2] * g), v3 = fmaf(rr[3], v[3] + t3, nn[3] * g);
+        const uint4 va = make_uint4(pack2d(v0, v1), pack2d(v2, v3), 0u, 0u);
+        st.o[dv] = mfma16d(va, pb[dv >> 1], st.o[dv]);
+    }
+}
+
+template <int NW, int G>
+__global__ __launch_bounds__(64 * NW, 2) void i2t0_t2i_v2_kernel(FuseArgs2 a) {
+    typedef FuseOff2<G, 2> Off;
+    constexpr int ABL = 0;
+    constexpr int NTH = 64 * NW, NT = 256 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[AttnOff2::LDS > 8 * MERGE_FLOATS * 4 ? AttnOff2::LDS : 8 * MERGE_FLOATS * 4];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
+    const WaveConst wc = wave_const(fr, fg, a.Nt);
+    const int voff = lane * 16, tvoff = lane * 16, vvoff = lane * 64;
+    const rsrc_t rsrc = make_rsrc(a.src, T * C * 2), rq0 = make_rsrc(a.q0, T * CI * 2), rtab = make_rsrc(a.tabk, T * CI * 2),
+                 rtv = make_rsrc(a.tabv, T * CI * 2);
+    const unsigned char* const L = lds + lane * 16;
+    if (tid < 128) ((float*)(lds + AttnOff2::GDT))[tid] = a.gd[tid];
+    const float* const colc = (const float*)(lds + AttnOff2::COLC) + fr;
+    const float* const gdl = (const float*)(lds + AttnOff2::GDT) + fr;
+    Ring<G, 2> ring;
+    for (int p = (int)blockIdx.x; p < a.P; p += (int)gridDim.x) {
+        __syncthreads();
+        {
+            const uint4* s0 = (const uint4*)(a.oper0 + (long)p * (OPER_BYTES / 2));
+            const uint4* s1 = (const uint4*)((const unsigned char*)a.aoper + (long)p * AOPER2_STRIDE);
+            const uint4* s2 = (const uint4*)((const unsigned char*)a.mf + (long)p * MF_BYTES);
+            for (int i = tid; i < KT_BYTES / 16; i += NTH) ((uint4*)(lds + AttnOff2::KT0))[i] = s0[KT_OFF / 16 + i];
+            for (int i = tid; i < VF_BYTES / 16; i += NTH) ((uint4*)(lds + AttnOff2::VF0))[i] = s0[VF_OFF / 16 + i];
+            for (int i = tid; i < AOPER2_BYTES / 16; i += NTH) ((uint4*)(lds + AttnOff2::QD2))[i] = s1[i];     // QD, QF contiguous
+            for (int i = tid; i < MF_BYTES / 16; i += NTH) ((uint4*)(lds + AttnOff2::MF2))[i] = s2[i];
+            for (int i = tid; i < 16; i += NTH) ((uint4*)(lds + AttnOff2::COLC))[i] = s1[AOPER2_BYTES / 16 + i];
+        }
+        __syncthreads();
+        AttnState st;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) st.o[h] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { st.m[ct] = NEG_BIG; st.l[ct] = 0.f; }
+        uint4 b[8], qi[4], tk[4], tv[4];
+#define F2_LOAD0(tile_)                                                                            \
+        do {                                                                                       \
+            const int so_ = (tile_) * (16 * C * 2), to_ = (tile_) * (16 * CI * 2);                 \
+            _Pragma("unroll") for (int s_ = 0; s_ < 8; ++s_) b[s_] = buf_load16(rsrc, voff, so_ + s_ * FRAG);    \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) qi[s_] = buf_load16(rq0, tvoff, to_ + s_ * FRAG);   \
+        } while (0)
+#define F2_LOAD1(tile_)                                                                            \
+        do {                                                                                       \
+            const int to_ = (tile_) * (16 * CI * 2);                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tk[s_] = buf_load16(rtab, tvoff, to_ + s_ * FRAG);  \
+        } while (0)
+#define F2_LOAD2(tile_)                                                                            \
+        do {                                                                                       \
+            const int to_ = (tile_) * (16 * CI * 2);                                               \
+            _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) tv[s_] = buf_load16(rtv, vvoff, to_ + s_ * 16);     \
+        } while (0)
+        F2_LOAD0(w);
+        ring_fill<G, Off>(ring, L, 0);
+        for (int n = 0; n < NT; ++n) {
+            asm volatile("" ::: "memory");
+            const int nx = w + NW * (n + 1 < NT ? n + 1 : NT - 1), cur = w + NW * n;
+            uint4 y1[8], pk0[2];
+            float stat[2];
+            i2t_block_r<G, Off, 0, false, 0, false>(ring, L, nullptr, a.eps, b, qi, wc, y1, [&]() { F2_LOAD1(cur); }, pk0, stat);
+            t2i_block_v2<G, Off, 40>(ring, L, y1, tk, tv, pk0, stat[0], stat[1], colc, gdl, st, [&]() { F2_LOAD2(cur); }, [&]() { F2_LOAD0(nx); });
+#pragma unroll
+            for (int i = Off::USED; i < Off::N; ++i) RING_STEP(i);
+        }
+#undef F2_LOAD0
+#undef F2_LOAD1
+#undef F2_LOAD2
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) { st.l[ct] += __shfl_xor(st.l[ct], 16); st.l[ct] += __shfl_xor(st.l[ct], 32); }
+        __syncthreads();
+        float* mg = (float*)lds + w * MERGE_FLOATS;
+        if (fg == 0) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { mg[ct * 16 + fr] = st.m[ct]; mg[64 + ct * 16 + fr] = st.l[ct]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            if ((fr >> 3) == (h & 1))
+                *(float4*)(mg + 128 + (h * 8 + (fr & 7)) * 16 + fg * 4) = make_float4(st.o[h][0], st.o[h][1], st.o[h][2], st.o[h][3]);
+        __syncthreads();
+        for (int idx = tid; idx < 512; idx += NTH) {
+            const int col = idx >> 3, d0 = (idx & 7) * 2, h = col >> 3, t = col & 7;
+            const float* g0 = (const float*)lds;
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) mx = fmaxf(mx, g0[ww * MERGE_FLOATS + col]);
+            float lt = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const float* gw = g0 + ww * MERGE_FLOATS;
+                const float sc = __builtin_amdgcn_exp2f(gw[col] - mx);
+                lt = fmaf(sc, gw[64 + col], lt);
+                o0 = fmaf(sc, gw[128 + col * 16 + d0], o0); o1 = fmaf(sc, gw[128 + col * 16 + d0 + 1], o1);
+            }
+            if (t < a.Nt) {
+                const float inv = 1.f / lt;
+                *(uint32_t*)(a.out + ((long)p * a.Nt + t) * CI + h * 16 + d0) =
+                    pack2d(fmaf(o0, inv, a.bwv[h * 16 + d0]), fmaf(o1, inv, a.bwv[h * 16 + d0 + 1]));
+            }
+        }
+    }
+}
+
+// ---- prompt-independent tables of the v2 form: WoWv = (gamma Wv) Wo0, cd = (gamma Wv) bo0, gd = rowsum(gamma Wv), bwv = bv + Wv beta,
+// kb = Wk beta; one block per d (128), thread e (128)
+__global__ __launch_bounds__(128) void tables2_small_kernel(const u16* __restrict__ wv, const float* __restrict__ bv,
+                                                            const u16* __restrict__ wk, const float* __restrict__ gam,
+                                                            const float* __restrict__ bet, const u16* __restrict__ wo0,
+                                                            const float* __restrict__ bo0, unsigned char* __restrict__ t2) {
+    __shared__ float wg[C], wr[C], kr[C];
+    const int d = blockIdx.x, e = threadIdx.x;
+    for (int c = e; c < C; c += 128) { wr[c] = d2f(wv[d * C + c]); wg[c] = wr[c] * gam[c]; kr[c] = d2f(wk[d * C + c]); }
+    __syncthreads();
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(wg[c], d2f(wo0[c * CI + e]), acc);
+    ((float*)(t2 + T2_WOWV))[d * 128 + e] = acc;
+    for (int c = e; c < C; c += 128) ((u16*)(t2 + T2_WVG))[d * C + c] = f2d(wg[c]);
+    if (e < 4) {
+        float v = 0.f;
+        for (int c = 0; c < C; ++c) v += e == 0 ? wg[c] * bo0[c] : e == 1 ? wg[c] : e == 2 ? wr[c] * bet[c] : kr[c] * bet[c];
+        if (e == 2) v += bv[d];
+        ((float*)(t2 + (e == 0 ? T2_CD : e == 1 ? T2_GD : e == 2 ? T2_BWV : T2_KB)))[d] = v;
+    }
+}
+// tabV = src (gamma Wv)^T comes from the MFMA GEMM as d16 row-major [4096][128]; this puts it into the blocked-C order the kernel
+// loads per tile: [tile][lane = 16 (row >> 2) + (d & 15)][dv = d >> 4][row & 3]; one 8-byte chunk (4 rows of one column) per thread
+__global__ __launch_bounds__(256) void tabv_relayout_kernel(const u16* __restrict__ rm, u16* __restrict__ tabv) {
+    const int id = blockIdx.x * 256 + threadIdx.x;           // chunk = (tile, lane, dv)
+    const int dv = id & 7, lane = (id >> 3) & 63, tile = id >> 9;
+    const int row0 = tile * 16 + (lane >> 4) * 4, d = dv * 16 + (lane & 15);
+    uint2 pk;
+    pk.x = (uint32_t)rm[(long)row0 * CI + d] | ((uint32_t)rm[(long)(row0 + 1) * CI + d] << 16);
+    pk.y = (uint32_t)rm[(long)(row0 + 2) * CI + d] | ((uint32_t)rm[(long)(row0 + 3) * CI + d] << 16);
+    ((uint2*)tabv)[id] = pk;
+}
+
+// per prompt: M fragments [a2][dv]: B[k = (head 4 a2 + fg, token i)][col d = 16 dv + fr] = sum_e v0[t][16h+e] WoWv[d][16h+e] + cd[d] / 8
+__global__ __launch_bounds__(256) void fold_values_kernel(const u16* __restrict__ vtok0, int Nt, const unsigned char* __restrict__ t2,
+                                                          u16* __restrict__ mf) {
+    __shared__ float vv[8][CI];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < 8 * CI; i += 256) {
+        const int t = i >> 7, dd = i & (CI - 1);
+        vv[t][dd] = t < Nt ? d2f(vtok0[((long)p * Nt + t) * CI + dd]) : 0.f;
+    }
+    __syncthreads();
+    const int d = tid & 127, hh = tid >> 7;
+    const float* wowv = (const float*)(t2 + T2_WOWV) + d * 128;
+    const float cd8 = ((const float*)(t2 + T2_CD))[d] * 0.125f;
+    u16* dst = mf + (long)p * (MF_BYTES / 2);
+    for (int h = hh * 4; h < hh * 4 + 4; ++h) {
+        float wv_[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wv_[e] = wowv[h * 16 + e];
+        uint32_t pk[4];
+#pragma unroll
+        for (int t2_ = 0; t2_ < 4; ++t2_) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { a0 = fmaf(wv_[e], vv[2 * t2_][h * 16 + e], a0); a1 = fmaf(wv_[e], vv[2 * t2_ + 1][h * 16 + e], a1); }
+            pk[t2_] = pack2d(2 * t2_ < Nt ? a0 + cd8 : 0.f, 2 * t2_ + 1 < Nt ? a1 + cd8 : 0.f);
+        }
+        const int a2 = h >> 2, fg = h & 3, dv = d >> 4, fr = d & 15;
+        *(uint4*)(dst + (((a2 * 8 + dv) * 64 + fg * 16 + fr) * 8)) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+}
+
+// per prompt: [QD][QF with gamma folded][64 column constants SCALE q . kb]  (see fold_attnfrag_kernel)
+__global__ __launch_bounds__(256) void fold_attnfrag2_kernel(const u16* __restrict__ qtok, const u16* __restrict__ wk,
+                                                             const float* __restrict__ gam, const unsigned char* __restrict__ t2,
+                                                             int Nt, unsigned char* __restrict__ aoper) {
+    __shared__ __attribute__((aligned(16))) u16 img[AOPER2_BYTES / 2];
+    __shared__ float qq[8][CI];
+    __shared__ float colc[64];
+    const int p = blockIdx.x, c = threadIdx.x;
+    for (int i = c; i < 8 * CI; i += 256) {
+        const int t = i >> 7, d = i & (CI - 1);
+        qq[t][d] = t < Nt ? d2f(qtok[((long)p * Nt + t) * CI + d]) : 0.f;
+    }
+    for (int i = c; i < 4 * FRAG / 16; i += 256) ((uint4*)img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    {
+        const int ks = c >> 5, fg = (c >> 3) & 3, ii = c & 7;
+        const float gs = gam[c] * SCALE;
+        for (int h = 0; h < 8; ++h) {
+            float w[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) w[d] = d2f(wk[(h * 16 + d) * C + c]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 16; ++d) acc = fmaf(qq[t][h * 16 + d], w[d], acc);
+                const int ct = h >> 1, fr = (h & 1) * 8 + t;
+                img[4 * FRAG / 2 + ((ct * 8 + ks) * 64 + fg * 16 + fr) * 8 + ii] = f2d(acc * gs);
+            }
+        }
+    }
+    for (int j = c; j < 8 * 8 * 16; j += 256) {
+        const int h = j >> 7, t = (j >> 4) & 7, d = j & 15;
+        const int ct = h >> 1, fr = (h & 1) * 8 + t, fg = 2 * (h & 1) + (d >> 3);
+        img[(ct * 64 + fg * 16 + fr) * 8 + (d & 7)] = f2d(qq[t][h * 16 + d] * SCALE);
+    }
+    if (c < 64) {
+        const int h = c >> 3, t = c & 7;
+        const float* kb = (const float*)(t2 + T2_KB);
+        float v = 0.f;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) v = fmaf(qq[t][h * 16 + d], kb[h * 16 + d], v);
+        colc[c] = v * SCALE;
+    }
+    __syncthreads();
+    uint4* dst = (uint4*)(aoper + (long)p * AOPER2_STRIDE);
+    for (int i = c; i < AOPER2_BYTES / 16; i += 256) dst[i] = ((const uint4*)img)[i];
+    if (c < 16) dst[AOPER2_BYTES / 16 + c] = ((const uint4*)colc)[c];
 }
 
 // token -> image operands of one prompt in fragment order (B operands: lane = fg * 16 + fr holds B[k = 8 fg + i][col fr]):
@@ -1034,6 +1406,17 @@ extern "C" int msam_chain_prepare_tables(const void* src, const void* q0, const 
     return msam_check_launch("to_blocked");
 }
 
+// layer-0 operands AND the M fragments of the second attention form in one launch (tables2 from msam_chain_prepare_tables2)
+extern "C" int msam_i2t_fold_operands_values(const void* ktok, const void* vtok, int32_t P, int32_t Nt, const void* wq, const void* wo,
+                                             const float* bo, int32_t with_kfold, const void* tables2, void* operands, void* mf,
+                                             void* stream) {
+    if (!ktok || !vtok || !wq || !wo || !bo || !operands || !tables2 || !mf || P <= 0) { msam_set_error("msam_i2t_fold_operands_values: null argument"); return 1; }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t_fold_operands_values: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    hipLaunchKernelGGL(fold_frag_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const u16*)ktok, (const u16*)vtok,
+                       (const u16*)wq, (const u16*)wo, bo, Nt, with_kfold, (u16*)operands, (const unsigned char*)tables2, (u16*)mf);
+    return msam_check_launch("fold_frag+values");
+}
+
 extern "C" int64_t msam_i2t0_t2i_workspace_bytes(int32_t P) { return (int64_t)P * AOPER_BYTES + WV_BYTES; }
 
 extern "C" int msam_i2t0_t2i_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b,
@@ -1069,6 +1452,9 @@ extern "C" int msam_i2t0_t2i_fused(const void* tables, const void* operands0, co
         case 3: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, s, a); break;
         case 4: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 3, true>), dim3(grid), dim3(512), 0, s, a); break;
         case 5: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 2, true>), dim3(grid), dim3(512), 0, s, a); break;
+        case 6: case 9: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 2, false, true>), dim3(grid), dim3(512), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 3, false, true>), dim3(grid), dim3(512), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, 0, 3, true, true>), dim3(grid), dim3(512), 0, s, a); break;
 #define ABL_CASE(m_) case 100 + m_: hipLaunchKernelGGL((i2t0_t2i_ring_kernel<8, 4, m_>), dim3(grid), dim3(512), 0, s, a); break;
         ABL_CASE(1) ABL_CASE(2) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(32) ABL_CASE(64) ABL_CASE(27) ABL_CASE(31) ABL_CASE(127)
 #undef ABL_CASE
@@ -1076,6 +1462,59 @@ extern "C" int msam_i2t0_t2i_fused(const void* tables, const void* operands0, co
     }
     msam_profile_mark2(stream, 0, flops, 0.0, 6);
     return msam_check_launch("i2t0_t2i");
+}
+
+// ---- second form (v2): tables2 once per decode, M fragments when the layer-0 value tokens exist, then the attention
+extern "C" int64_t msam_chain_tables2_bytes(void) { return T2_BYTES; }
+extern "C" int msam_chain_prepare_tables2(const void* src, const void* wv, const float* bv, const void* wk, const float* ln0_w,
+                                          const float* ln0_b, const void* wo0, const float* bo0, void* tables2, void* stream) {
+    if (!src || !wv || !bv || !wk || !ln0_w || !ln0_b || !wo0 || !bo0 || !tables2) { msam_set_error("msam_chain_prepare_tables2: null argument"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tables2_small_kernel, dim3(128), dim3(128), 0, s, (const u16*)wv, bv, (const u16*)wk, ln0_w, ln0_b,
+                       (const u16*)wo0, bo0, (unsigned char*)tables2);
+    if (int e = msam_check_launch("tables2_small")) return e;
+    msam_gemm_t g{};
+    g.A = src; g.lda = C; g.W = (unsigned char*)tables2 + T2_WVG; g.ldw = C; g.M = T; g.N = CI; g.K = C;
+    g.out = (unsigned char*)tables2 + T2_TABV_RM; g.out_dtype = MSAM_D16; g.ldc = CI; g.a_dtype = MSAM_D16 == MSAM_F16 ? MSAM_F16 : 0;
+    if (int e = msam_gemm_bf16(&g, stream)) return e;
+    hipLaunchKernelGGL(tabv_relayout_kernel, dim3(T / 16 * 64 * 8 / 256), dim3(256), 0, s, (const u16*)((unsigned char*)tables2 + T2_TABV_RM),
+                       (u16*)((unsigned char*)tables2 + T2_TABV));
+    return msam_check_launch("tabv_relayout");
+}
+extern "C" int64_t msam_t2i_fold_values_bytes(int32_t P) { return (int64_t)P * MF_BYTES; }
+extern "C" int msam_t2i_fold_values(const void* vtok0, int32_t P, int32_t Nt, const void* tables2, void* mf, void* stream) {
+    if (!vtok0 || !tables2 || !mf || P <= 0 || Nt < 1 || Nt > 8) { msam_set_error("msam_t2i_fold_values: bad arguments"); return 1; }
+    hipLaunchKernelGGL(fold_values_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, (const u16*)vtok0, Nt, (const unsigned char*)tables2,
+                       (u16*)mf);
+    return msam_check_launch("fold_values");
+}
+extern "C" int64_t msam_i2t0_t2i_v2_workspace_bytes(int32_t P) { return (int64_t)P * AOPER2_STRIDE; }
+extern "C" int msam_i2t0_t2i_fused_v2(const void* tables, const void* tables2, const void* operands0, const void* mf, const float* ln0_w,
+                                      float ln_eps, const void* qtok, int32_t P, int32_t Nt, const void* wk, void* out,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!tables || !tables2 || !operands0 || !mf || !ln0_w || !qtok || !wk || !out || !workspace || P <= 0) {
+        msam_set_error("msam_i2t0_t2i_fused_v2: null argument");
+        return 1;
+    }
+    if (Nt < 1 || Nt > 8) { msam_set_error("msam_i2t0_t2i_fused_v2: 1 <= Nt <= 8 tokens per prompt"); return 1; }
+    if (workspace_bytes < msam_i2t0_t2i_v2_workspace_bytes(P)) { msam_set_error("msam_i2t0_t2i_fused_v2: workspace too small"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned char* t2 = (const unsigned char*)tables2;
+    hipLaunchKernelGGL(fold_attnfrag2_kernel, dim3(P), dim3(256), 0, s, (const u16*)qtok, (const u16*)wk, ln0_w, t2, Nt,
+                       (unsigned char*)workspace);
+    if (int e = msam_check_launch("fold_attnfrag2")) return e;
+    const u16* src = (const u16*)tables;
+    FuseArgs2 a{};
+    a.src = src; a.q0 = src + (long)T * C; a.tabk = a.q0 + (long)T * CI;
+    a.tabv = (const u16*)(t2 + T2_TABV); a.gd = (const float*)(t2 + T2_GD); a.bwv = (const float*)(t2 + T2_BWV);
+    a.oper0 = (const u16*)operands0; a.aoper = (const u16*)workspace; a.mf = (const u16*)mf; a.eps = ln_eps; a.Nt = Nt; a.P = P;
+    a.out = (u16*)out;
+    const int cus = cu_count(), grid = P < cus ? P : cus;
+    const double flops = (double)P * (T / 16) * 116.0 * 16384.0;          // 8 + 16 + 32 layer-0 block, 36 + 16 + 8 attention
+    msam_profile_mark2(stream, 1, flops, 0.0, 6);
+    hipLaunchKernelGGL((i2t0_t2i_v2_kernel<8, 4>), dim3(grid), dim3(512), 0, s, a);
+    msam_profile_mark2(stream, 0, flops, 0.0, 6);
+    return msam_check_launch("i2t0_t2i_v2");
 }
 
 extern "C" int msam_i2t01_fused(const void* tables, const void* operands0, const float* ln0_w, const float* ln0_b,
@@ -1102,6 +1541,8 @@ extern "C" int msam_i2t01_fused(const void* tables, const void* operands0, const
         case 2: hipLaunchKernelGGL((i2t01_ring_kernel<4, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); break;
         case 3: case 5: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
         case 4: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4, 3>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
+        case 6: case 9: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4, 2, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
+        case 7: case 8: hipLaunchKernelGGL((i2t01_ring_kernel<8, 4, 3, true>), dim3(grid), dim3(512), 0, (hipStream_t)stream, a); break;
         default: hipLaunchKernelGGL(i2t01_kernel, dim3(grid), dim3(NTHR8), 0, (hipStream_t)stream, a);
     }
     msam_profile_mark2(stream, 0, flops, bytes, 7);

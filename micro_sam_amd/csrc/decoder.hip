@@ -602,7 +602,7 @@ extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void*
                 nullptr, 0, 0, 0, c.pe_q[0], CI);
 }
 
-extern int g_tune_dec_chain, g_tune_dec_chain_min_p;
+extern int g_tune_dec_chain, g_tune_dec_chain_min_p, g_tune_chain_variant;
 namespace {
 struct Work {
     float *qpe, *queries, *tmp; u16 *a, *b, *qs, *ks, *vs, *attn_tok, *mlp_h;
@@ -782,6 +782,14 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     // blocked copies of the shared tables (source, layer-0 q, tabK / tabQ of layer 1) at the end of the attention workspace in vT
     void* const tables = (char*)w.vT + (int64_t)R * CI * 2 - msam_chain_tables_bytes();
     if (chain) CHECK(msam_chain_prepare_tables(im.src_bf16, im.q0, c.tab_k[1], c.tab_q[1], tables, cx.s));
+    // second form of the chained attention (msam_tune_set "chain_variant" 9): its prompt-independent tables in front of `tables`,
+    // the per-prompt M fragments behind the layer-0 operands
+    const bool chain2 = chain && g_tune_chain_variant == 9;
+    void* const tables2 = (char*)tables - msam_chain_tables2_bytes();
+    void* const mfrag = (char*)oper0 + msam_i2t_fold_operand_bytes(P);
+    if (chain2)
+        CHECK(msam_chain_prepare_tables2(im.src_bf16, dec->layer[1].t2i.v_w, dec->layer[1].t2i.v_b, dec->layer[1].t2i.k_w,
+                                         dec->layer[0].n4_w, dec->layer[0].n4_b, dec->layer[0].i2t.o_w, dec->layer[0].i2t.o_b, tables2, cx.s));
     for (int li = 0; li < nlayers && li < 2; ++li) {
         const msam_twoway_layer_t& L = dec->layer[li];
         // (1) token self attention
@@ -812,8 +820,13 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
             CHECK(msam_check_launch("t2i_attn"));
         } else if (chain) {
             const msam_twoway_layer_t& L0 = dec->layer[0];
-            CHECK(msam_i2t0_t2i_fused(tables, oper0, L0.n4_w, L0.n4_b, 1e-5f, w.qs, P, Nt, L.t2i.k_w, L.t2i.v_w, L.t2i.v_b,
-                                      w.attn_tok, w.vT, (int64_t)R * CI * 2 - msam_chain_tables_bytes(), cx.s));
+            const int64_t avail = (int64_t)R * CI * 2 - msam_chain_tables_bytes() - msam_chain_tables2_bytes();
+            if (chain2)
+                CHECK(msam_i2t0_t2i_fused_v2(tables, tables2, oper0, mfrag, L0.n4_w, 1e-5f, w.qs, P, Nt, L.t2i.k_w, w.attn_tok, w.vT,
+                                             avail, cx.s));
+            else
+                CHECK(msam_i2t0_t2i_fused(tables, oper0, L0.n4_w, L0.n4_b, 1e-5f, w.qs, P, Nt, L.t2i.k_w, L.t2i.v_w, L.t2i.v_b,
+                                          w.attn_tok, w.vT, avail, cx.s));
         } else {
             CHECK(t2i_stream(cx, w, c, li, L.t2i, P, Nt));
         }
@@ -834,7 +847,10 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         // image->token attention + out_proj + residual + norm4 in ONE pass over the stream: folded form (decfold.hip)
         // for up to 8 tokens per prompt, weights-stationary fused kernel (declayer.hip) otherwise
         if (chain) {
-            CHECK(msam_i2t_fold_operands(w.ks, w.vs, P, Nt, L.i2t.q_w, L.i2t.o_w, L.i2t.o_b, li, li == 0 ? oper0 : oper1, cx.s));
+            if (li == 0 && chain2)
+                CHECK(msam_i2t_fold_operands_values(w.ks, w.vs, P, Nt, L.i2t.q_w, L.i2t.o_w, L.i2t.o_b, 0, tables2, oper0, mfrag, cx.s));
+            else
+                CHECK(msam_i2t_fold_operands(w.ks, w.vs, P, Nt, L.i2t.q_w, L.i2t.o_w, L.i2t.o_b, li, li == 0 ? oper0 : oper1, cx.s));
             if (li == 1) {
                 const msam_twoway_layer_t& L0 = dec->layer[0];
                 CHECK(msam_i2t01_fused(tables, oper0, L0.n4_w, L0.n4_b, oper1, L.n4_w, L.n4_b, 1e-5f, P, Nt, w.keys, cx.s));   // blocked stream

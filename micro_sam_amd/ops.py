@@ -585,6 +585,58 @@ def i2t0_t2i_fused(tables, operands0, ln0_w, ln0_b, qtok, wk, wv, bv, *, ln_eps:
     return out
 
 
+def chain_prepare_tables2(src, wv, bv, wk, ln0_w, ln0_b, wo0, bo0):
+    """Prompt-independent tables of the second form of the chained attention (include/msam_hip.h msam_chain_prepare_tables2)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _dec16(src, wv, wk, wo0)
+    t2 = torch.empty((int(lib.msam_chain_tables2_bytes()),), dtype=torch.uint8, device=src.device)
+    _lib.check(lib.msam_chain_prepare_tables2(src.data_ptr(), wv.data_ptr(), bv.data_ptr(), wk.data_ptr(), ln0_w.data_ptr(),
+                                              ln0_b.data_ptr(), wo0.data_ptr(), bo0.data_ptr(), t2.data_ptr(), _lib.stream_ptr()),
+               "msam_chain_prepare_tables2")
+    return t2
+
+
+def t2i_fold_values(vtok0, tables2):
+    """Per-prompt M fragments of the second form (include/msam_hip.h msam_t2i_fold_values): vtok0 [P,Nt,128]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    P, Nt = vtok0.shape[0], vtok0.shape[1]
+    mf = torch.empty((int(lib.msam_t2i_fold_values_bytes(P)),), dtype=torch.uint8, device=vtok0.device)
+    _lib.check(lib.msam_t2i_fold_values(vtok0.data_ptr(), P, Nt, tables2.data_ptr(), mf.data_ptr(), _lib.stream_ptr()),
+               "msam_t2i_fold_values")
+    return mf
+
+
+def i2t_fold_operands_values(ktok, vtok, wq, wo, bo, tables2, *, with_kfold: bool = False):
+    """:func:`i2t_fold_operands` and :func:`t2i_fold_values` in one launch (include/msam_hip.h msam_i2t_fold_operands_values)
+    -> (operands, mf)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _dec16(ktok, vtok, wq, wo)
+    P, Nt = ktok.shape[0], ktok.shape[1]
+    oper = torch.empty((int(lib.msam_i2t_fold_operand_bytes(P)),), dtype=torch.uint8, device=ktok.device)
+    mf = torch.empty((int(lib.msam_t2i_fold_values_bytes(P)),), dtype=torch.uint8, device=ktok.device)
+    _lib.check(lib.msam_i2t_fold_operands_values(ktok.data_ptr(), vtok.data_ptr(), P, Nt, wq.data_ptr(), wo.data_ptr(), bo.data_ptr(),
+                                                 int(with_kfold), tables2.data_ptr(), oper.data_ptr(), mf.data_ptr(),
+                                                 _lib.stream_ptr()), "msam_i2t_fold_operands_values")
+    return oper, mf
+
+
+def i2t0_t2i_fused_v2(tables, tables2, operands0, mf, ln0_w, qtok, wk, *, ln_eps: float = 1e-5):
+    """Second form of :func:`i2t0_t2i_fused` (include/msam_hip.h msam_i2t0_t2i_fused_v2) -> [P,Nt,128]."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    P, Nt = qtok.shape[0], qtok.shape[1]
+    nbytes = int(lib.msam_i2t0_t2i_v2_workspace_bytes(P))
+    work = torch.empty((nbytes,), dtype=torch.uint8, device=qtok.device)
+    out = torch.empty((P, Nt, 128), dtype=_dec16(qtok, wk), device=qtok.device)
+    _lib.check(lib.msam_i2t0_t2i_fused_v2(tables.data_ptr(), tables2.data_ptr(), operands0.data_ptr(), mf.data_ptr(), ln0_w.data_ptr(),
+                                          ln_eps, qtok.data_ptr(), P, Nt, wk.data_ptr(), out.data_ptr(), work.data_ptr(), nbytes,
+                                          _lib.stream_ptr()), "msam_i2t0_t2i_fused_v2")
+    return out
+
+
 def i2t01_fused(tables, operands0, ln0_w, ln0_b, operands1, ln1_w, ln1_b, P: int, Nt: int, *, ln_eps: float = 1e-5):
     """Layer-0 image->token block on the shared source chained into the layer-1 image->token block
     (include/msam_hip.h msam_i2t01_fused) -> the layer-1 output stream [P,4096,256] in the BLOCKED layout (from_blocked)."""

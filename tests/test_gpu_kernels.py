@@ -425,17 +425,18 @@ def _i2t_fold_layer_case(ops, dev, P, Nt, shared):
         assert torch.equal(x2, out)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("P,Nt", [(130, 7), (129, 8), (3, 5)])
 def test_chained_layer0_forms(env, P, Nt, variant):
-    """All builds of the chained kernels (msam_tune_set "chain_variant": 8 waves with 4-fragment groups; 4 waves with rings of 8 /
-    16 fragments; 8 waves on the ring code)."""
+    """All builds of the chained kernels (msam_tune_set "chain_variant": 0 = 8 waves with 4-fragment groups; 1 / 2 = 4 waves with
+    rings of 8 / 16 fragments; 3 = 8 waves on the ring code; 4 / 5 = ring depth 3 / compact attention accumulators; 6 / 7 / 8 = tile
+    loads one phase ahead with ring depth 2 / 3 / 3 + compact accumulators)."""
     from micro_sam_amd import _lib
     _lib.load().msam_tune_set(b"chain_variant", variant)
     try:
         _chained_layer0_case(env, P, Nt)
     finally:
-        _lib.load().msam_tune_set(b"chain_variant", 0)
+        _lib.load().msam_tune_set(b"chain_variant", 9)
 
 
 def _chained_layer0_case(env, P, Nt):
@@ -498,6 +499,16 @@ def _chained_layer0_case(env, P, Nt):
     ref = (a @ vh).permute(0, 2, 1, 3).reshape(-1, Nt, 128)
     assert _close(att[sel], ref, 6e-2, 3e-2)
     assert _close(att, att_stage, 6e-2, 3e-2)
+    # second form: norm4 folded into the operands, value projection before the LayerNorm
+    t2 = ops.chain_prepare_tables2(src, wv, bv, wk, L0["lw"], L0["lb"], L0["wo"], L0["bo"])
+    mf = ops.t2i_fold_values(L0["vtok"], t2)
+    op0b, mfb = ops.i2t_fold_operands_values(L0["ktok"], L0["vtok"], L0["wq"], L0["wo"], L0["bo"], t2)
+    assert torch.equal(mfb, mf)
+    o0, o0b = op0.view(P, -1), op0b.view(P, -1)                                    # (the K' part is not written without K fold)
+    assert torch.equal(o0b[:, :8192], o0[:, :8192]) and torch.equal(o0b[:, 40960:], o0[:, 40960:])
+    att2 = ops.i2t0_t2i_fused_v2(tables, t2, op0, mf, L0["lw"], qtok, wk)
+    assert _close(att2[sel], ref, 6e-2, 3e-2)
+    assert _close(att2, att_stage, 6e-2, 3e-2)
     # the consumers of the blocked stream: same bits as on the row-major copy of it
     assert torch.equal(ops.t2i_fold_attention(out2_blocked, qtok, wk, tabk, wv, bv, blocked=True),
                        ops.t2i_fold_attention(out2, qtok, wk, tabk, wv, bv))

@@ -222,3 +222,112 @@ def test_token_owner_attention_layout_matches_the_reference_formula(Nt):
     a = np.exp(sc - sc.max(-1, keepdims=True)); a /= a.sum(-1, keepdims=True)
     ref = (a @ vh).transpose(1, 0, 2).reshape(Nt, 128)
     assert np.abs(out - ref).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# second form of the chained attention (i2t0_t2i_v2): the LayerNorm affine is folded into the operands (gamma into Q' and Wv, beta
+# into per-column constants) and the V projection is taken BEFORE the LayerNorm by linearity:
+#     x = src + P0 V''0 (+ bo inside V''0),  x^ = (x - mean) rstd,   V = x^ (gamma Wv)^T
+#       = rstd (src (gWv)^T + P0 (V''0 (gWv)^T) - mean rowsum(gWv)) = rstd (tabV + P0 M - mean gd)
+# tabV [4096,128] and gd are prompt independent, M [64,128] = per-prompt 16-MAC products with WoWv = (gWv) Wo.
+def test_attention_v2_algebra_and_layouts():
+    g = np.random.default_rng(77)
+    Nt, ntile = 7, 2
+    T = 16 * ntile
+    src = g.standard_normal((T, 256)); pe = g.standard_normal((T, 256))
+    # layer-0 image->token block
+    wq0 = g.standard_normal((128, 256)) / 16; bq0 = g.standard_normal(128)
+    wo0 = g.standard_normal((256, 128)) / math.sqrt(128); bo0 = g.standard_normal(256)
+    gam = g.standard_normal(256) * 0.2 + 1; bet = g.standard_normal(256)
+    k0 = g.standard_normal((Nt, 128)); v0 = g.standard_normal((Nt, 128))
+    # layer-1 token->image attention
+    wk = g.standard_normal((128, 256)) / 16; bk = g.standard_normal(128)
+    wv = g.standard_normal((128, 256)) / 16; bv = g.standard_normal(128)
+    qtok = g.standard_normal((Nt, 128)) * 1.5
+    tabk = pe @ wk.T + bk
+    q0 = src @ wq0.T + (pe @ wq0.T + bq0)
+    # ---- reference: keys1 = LN(src + attn0 Wo^T + bo) gamma + beta, then the attention on keys1
+    qh = q0.reshape(T, 8, 16).transpose(1, 0, 2)
+    kh = k0.reshape(Nt, 8, 16).transpose(1, 0, 2); vh = v0.reshape(Nt, 8, 16).transpose(1, 0, 2)
+    sc = qh @ kh.transpose(0, 2, 1) / 4.0
+    p0 = np.exp(sc - sc.max(-1, keepdims=True)); p0 /= p0.sum(-1, keepdims=True)               # [8, T, Nt]
+    x = src + (p0 @ vh).transpose(1, 0, 2).reshape(T, 128) @ wo0.T + bo0
+    mean = x.mean(1, keepdims=True); rstd = 1 / np.sqrt(x.var(1, keepdims=True) + 1e-5)
+    keys1 = (x - mean) * rstd * gam + bet
+    K = keys1 @ wk.T + tabk; V = keys1 @ wv.T + bv
+    qh1 = qtok.reshape(Nt, 8, 16).transpose(1, 0, 2); kh1 = K.reshape(T, 8, 16).transpose(1, 0, 2); vh1 = V.reshape(T, 8, 16).transpose(1, 0, 2)
+    s1 = qh1 @ kh1.transpose(0, 2, 1) / 4.0
+    a1 = np.exp(s1 - s1.max(-1, keepdims=True)); a1 /= a1.sum(-1, keepdims=True)
+    ref = (a1 @ vh1).transpose(1, 0, 2).reshape(Nt, 128)
+    # ---- the kernel's form.  Prompt-independent tables:
+    wvg = wv * gam[None, :]
+    tabv = src @ wvg.T                                            # [T,128]
+    gd = wvg.sum(1); bwv = bv + wv @ bet
+    wowv = wvg @ wo0                                              # [128 d, 128 e]
+    cd = wvg @ bo0
+    # per prompt: M[(h,t)][d] = sum_e v0[t][16h+e] WoWv[d][16h+e] + cd[d] / 8   (the bo / 8 of V''0)
+    M = np.zeros((64, 128))
+    for h in range(8):
+        for t in range(Nt):
+            M[h * 8 + t] = wowv[:, h * 16:(h + 1) * 16] @ v0[t, h * 16:(h + 1) * 16] + cd / 8
+    # Q' with gamma folded, column constants beta . Q'
+    qp = np.zeros((64, 256))
+    for h in range(8):
+        for t in range(Nt):
+            qp[h * 8 + t] = wk[h * 16:(h + 1) * 16].T @ qtok[t, h * 16:(h + 1) * 16]
+    qpg = qp * gam[None, :] * SCALE
+    colc = (qp @ bet) * SCALE
+    # lane-level: fragments of M ([a2][dv]: B[k = (h,t) = 32 a2 + 8 fg + i][col d = 16 dv + fr]) and tabV in blocked-C layout
+    lanes = np.arange(64); fr = lanes & 15; fg = lanes >> 4
+    mfrag = lambda a2, dv: np.stack([M[32 * a2 + 8 * fg[l]:32 * a2 + 8 * fg[l] + 8, 16 * dv + fr[l]] for l in range(64)])
+    st = dict(o=[np.zeros((64, 4)) for _ in range(8)], m=[np.full(64, -1e30) for _ in range(4)], l=[np.zeros(64) for _ in range(4)])
+    for n in range(ntile):
+        sl = slice(16 * n, 16 * n + 16)
+        xh = (x[sl] - mean[sl]) * rstd[sl]                         # x^ of the tile (from the layer-0 block)
+        # P0 packed as the layer-0 block leaves it: lane (token fr, group fg): head 4 a2 + fg, tokens 0..7
+        pk = [np.stack([np.concatenate([p0[4 * a2 + fg[l], 16 * n + fr[l], :], np.zeros(8 - Nt)]) for l in range(64)]) for a2 in range(2)]
+        y = [np.stack([xh[fr[l], 32 * s_ + 8 * fg[l]:32 * s_ + 8 * fg[l] + 8] for l in range(64)]) for s_ in range(8)]
+        tk = [np.stack([tabk[16 * n + fr[l], 32 * s_ + 8 * fg[l]:32 * s_ + 8 * fg[l] + 8] for l in range(64)]) for s_ in range(4)]
+        s = [np.tile(np.array([colc[16 * ct + fr[l]] for l in range(64)])[:, None], (1, 4)) for ct in range(4)]     # column constants
+        qf = lambda ct, ks: np.stack([qpg[16 * ct + fr[l], 32 * ks + 8 * fg[l]:32 * ks + 8 * fg[l] + 8] for l in range(64)])
+        qdf = []
+        for ct in range(4):
+            f = np.zeros((64, 8))
+            for l in range(64):
+                h, t = 2 * ct + (fr[l] >> 3), fr[l] & 7
+                if (fg[l] >> 1) == (fr[l] >> 3) and t < Nt:
+                    f[l] = qtok[t, 32 * ct + 8 * fg[l]:32 * ct + 8 * fg[l] + 8] * SCALE
+            qdf.append(f)
+        for ct in range(4):
+            for ks in range(8):
+                s[ct] = mfma(y[ks], qf(ct, ks), s[ct])
+            s[ct] = mfma(tk[ct], qdf[ct], s[ct])
+        pb = []
+        for ct in range(4):
+            mx = s[ct].max(1); mx = np.maximum(mx, mx[lanes ^ 16]); mx = np.maximum(mx, mx[lanes ^ 32])
+            mn = np.maximum(st["m"][ct], mx); al = np.exp2(st["m"][ct] - mn)
+            st["m"][ct] = mn; st["l"][ct] *= al; st["o"][2 * ct] *= al[:, None]; st["o"][2 * ct + 1] *= al[:, None]
+            e = np.exp2(s[ct] - mn[:, None]); st["l"][ct] = st["l"][ct] + e.sum(1)
+            pb.append(np.concatenate([e, np.zeros((64, 4))], axis=1))
+        # V phase: A = P0 (same registers as pk), B = M fragments; then the per-row / per-column correction
+        row_mean = np.stack([[mean[16 * n + 4 * fg[l] + r, 0] for r in range(4)] for l in range(64)])     # what the shuffles fetch
+        row_rstd = np.stack([[rstd[16 * n + 4 * fg[l] + r, 0] for r in range(4)] for l in range(64)])
+        for dv in range(8):
+            v = np.zeros((64, 4))
+            for a2 in range(2):
+                v = mfma(pk[a2], mfrag(a2, dv), v)
+            tv = np.stack([[tabv[16 * n + 4 * fg[l] + r, 16 * dv + fr[l]] for r in range(4)] for l in range(64)])   # blocked-C tile
+            gdl = np.array([gd[16 * dv + fr[l]] for l in range(64)])[:, None]
+            v = row_rstd * (v + tv - row_mean * gdl)
+            va = np.concatenate([v, np.zeros((64, 4))], axis=1)
+            st["o"][dv] = mfma(va, pb[dv >> 1], st["o"][dv])
+    out = np.zeros((Nt, 128))
+    for ct in range(4):
+        st["l"][ct] = st["l"][ct] + st["l"][ct][lanes ^ 16]; st["l"][ct] = st["l"][ct] + st["l"][ct][lanes ^ 32]
+    for h in range(8):
+        for l in range(64):
+            if (fr[l] >> 3) == (h & 1) and (fr[l] & 7) < Nt:
+                for r in range(4):
+                    d = h * 16 + fg[l] * 4 + r
+                    out[fr[l] & 7, d] = st["o"][h][l, r] / st["l"][h >> 1][l] + bwv[d]
+    assert np.abs(out - ref).max() < 1e-9

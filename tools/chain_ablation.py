@@ -52,4 +52,4 @@ for v in (3, 227, 132):
         lib.msam_tune_set(b"chain_variant", v); lib.msam_tune_set(b"chain_tmask", tm)
         print(f"chain_variant {v:3d} tile mask {tm:3d}: {timeit():.3f} ms", flush=True)
 lib.msam_tune_set(b"chain_tmask", 255)
-lib.msam_tune_set(b"chain_variant", 0)
+lib.msam_tune_set(b"chain_variant", 9)

@@ -62,12 +62,19 @@ op0 = ops.i2t_fold_operands(L0["ktok"], L0["vtok"], L0["wq"], L0["wo"], L0["bo"]
 op1 = ops.i2t_fold_operands(L1["ktok"], L1["vtok"], L1["wq"], L1["wo"], L1["bo"])
 print(f"stage by stage (i2t layer 0 + t2i + i2t layer 1): {timeit(staged):.3f} ms", flush=True)
 lib = _lib.load()
-for variant in (0, 1, 2, 3):
+for variant in (0, 6):
     lib.msam_tune_set(b"chain_variant", variant)
     print(f"chain_variant {variant}: chained (operands + i2t0_t2i + operands + i2t01): {timeit(chained):.3f} ms", flush=True)
     print(f"  i2t0_t2i alone: {timeit(lambda: ops.i2t0_t2i_fused(tables, op0, L0['lw'], L0['lb'], qtok, wk, wv, bv)):.3f} ms", flush=True)
     print(f"  i2t01 alone:    {timeit(lambda: ops.i2t01_fused(tables, op0, L0['lw'], L0['lb'], op1, L1['lw'], L1['lb'], P, Nt)):.3f} ms", flush=True)
     a1, a2 = staged(), chained()
     print(f"  attention outputs vs stage by stage: max |d| {(a1.float() - a2.float()).abs().max().item():.4f}", flush=True)
-lib.msam_tune_set(b"chain_variant", 0)
+lib.msam_tune_set(b"chain_variant", 9)
+t2 = ops.chain_prepare_tables2(src, wv, bv, wk, L0["lw"], L0["lb"], L0["wo"], L0["bo"])
+mf = ops.t2i_fold_values(L0["vtok"], t2)
+print(f"second form: i2t0_t2i_v2 (incl. its fold kernel): {timeit(lambda: ops.i2t0_t2i_fused_v2(tables, t2, op0, mf, L0['lw'], qtok, wk)):.3f} ms; "
+      f"tables2 {timeit(lambda: ops.chain_prepare_tables2(src, wv, bv, wk, L0['lw'], L0['lb'], L0['wo'], L0['bo'])):.3f} ms; "
+      f"fold_values {timeit(lambda: ops.t2i_fold_values(L0['vtok'], t2)):.3f} ms", flush=True)
+a2 = ops.i2t0_t2i_fused_v2(tables, t2, op0, mf, L0["lw"], qtok, wk)
+print(f"  v2 attention outputs vs stage by stage: max |d| {(staged().float() - a2.float()).abs().max().item():.4f}", flush=True)
 print(f"fold operands (with K'): {timeit(lambda: ops.i2t_fold_operands(L1['ktok'], L1['vtok'], L1['wq'], L1['wo'], L1['bo'])):.3f} ms", flush=True)
