@@ -179,6 +179,11 @@ int msam_i2t0_t2i_fused(const void* tables, const void* operands0, const float* 
 int64_t msam_chain_tables2_bytes(void);
 int msam_chain_prepare_tables2(const void* src, const void* wv, const float* bv, const void* wk, const float* ln0_w,
                                const float* ln0_b, const void* wo0, const float* bo0, void* tables2, void* stream);
+/* the weight-only part of tables2 once per model (const2 >= msam_chain_const2_bytes()), then per decode the source-dependent rest */
+int64_t msam_chain_const2_bytes(void);
+int msam_chain_prepare_const2(const void* wv, const float* bv, const void* wk, const float* ln0_w, const float* ln0_b,
+                              const void* wo0, const float* bo0, void* const2, void* stream);
+int msam_chain_prepare_tables2_c(const void* src, const void* const2, void* tables2, void* stream);
 int64_t msam_t2i_fold_values_bytes(int32_t P);
 int msam_t2i_fold_values(const void* vtok0, int32_t P, int32_t Nt, const void* tables2, void* mf, void* stream);
 /* msam_i2t_fold_operands and msam_t2i_fold_values in one launch */

@@ -139,6 +139,9 @@ _PROTOS = {
     "msam_i2t01_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _vp, _vp]),
     "msam_chain_tables2_bytes": (_i64, []),
     "msam_chain_prepare_tables2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "msam_chain_const2_bytes": (_i64, []),
+    "msam_chain_prepare_const2": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "msam_chain_prepare_tables2_c": (_i32, [_vp, _vp, _vp, _vp]),
     "msam_t2i_fold_values_bytes": (_i64, [_i32]),
     "msam_t2i_fold_values": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
     "msam_i2t_fold_operands_values": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -1178,7 +1178,8 @@ __global__ __launch_bounds__(64 * NW, 2) void i2t0_t2i_v2_kernel(FuseArgs2 a) {
 __global__ __launch_bounds__(128) void tables2_small_kernel(const u16* __restrict__ wv, const float* __restrict__ bv,
                                                             const u16* __restrict__ wk, const float* __restrict__ gam,
                                                             const float* __restrict__ bet, const u16* __restrict__ wo0,
-                                                            const float* __restrict__ bo0, unsigned char* __restrict__ t2) {
+                                                            const float* __restrict__ bo0, unsigned char* __restrict__ t2,
+                                                            long wvg_off) {
     __shared__ float wg[C], wr[C], kr[C];
     const int d = blockIdx.x, e = threadIdx.x;
     for (int c = e; c < C; c += 128) { wr[c] = d2f(wv[d * C + c]); wg[c] = wr[c] * gam[c]; kr[c] = d2f(wk[d * C + c]); }
@@ -1186,7 +1187,7 @@ __global__ __launch_bounds__(128) void tables2_small_kernel(const u16* __restric
     float acc = 0.f;
     for (int c = 0; c < C; ++c) acc = fmaf(wg[c], d2f(wo0[c * CI + e]), acc);
     ((float*)(t2 + T2_WOWV))[d * 128 + e] = acc;
-    for (int c = e; c < C; c += 128) ((u16*)(t2 + T2_WVG))[d * C + c] = f2d(wg[c]);
+    for (int c = e; c < C; c += 128) ((u16*)(t2 + wvg_off))[d * C + c] = f2d(wg[c]);
     if (e < 4) {
         float v = 0.f;
         for (int c = 0; c < C; ++c) v += e == 0 ? wg[c] * bo0[c] : e == 1 ? wg[c] : e == 2 ? wr[c] * bet[c] : kr[c] * bet[c];
@@ -1471,10 +1472,36 @@ extern "C" int msam_chain_prepare_tables2(const void* src, const void* wv, const
     if (!src || !wv || !bv || !wk || !ln0_w || !ln0_b || !wo0 || !bo0 || !tables2) { msam_set_error("msam_chain_prepare_tables2: null argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(tables2_small_kernel, dim3(128), dim3(128), 0, s, (const u16*)wv, bv, (const u16*)wk, ln0_w, ln0_b,
-                       (const u16*)wo0, bo0, (unsigned char*)tables2);
+                       (const u16*)wo0, bo0, (unsigned char*)tables2, T2_WVG);
     if (int e = msam_check_launch("tables2_small")) return e;
     msam_gemm_t g{};
     g.A = src; g.lda = C; g.W = (unsigned char*)tables2 + T2_WVG; g.ldw = C; g.M = T; g.N = CI; g.K = C;
+    g.out = (unsigned char*)tables2 + T2_TABV_RM; g.out_dtype = MSAM_D16; g.ldc = CI; g.a_dtype = MSAM_D16 == MSAM_F16 ? MSAM_F16 : 0;
+    if (int e = msam_gemm_bf16(&g, stream)) return e;
+    hipLaunchKernelGGL(tabv_relayout_kernel, dim3(T / 16 * 64 * 8 / 256), dim3(256), 0, s, (const u16*)((unsigned char*)tables2 + T2_TABV_RM),
+                       (u16*)((unsigned char*)tables2 + T2_TABV));
+    return msam_check_launch("tabv_relayout");
+}
+// The weight-only part of tables2 (WoWv, cd, gd, bwv, kb and gamma Wv: everything but tabV) once per MODEL: const2 = the first
+// T2_TABV bytes of the tables2 layout followed by gamma Wv; msam_chain_prepare_tables2_c then costs one 66 KiB device copy, the
+// tabV GEMM (src x gamma Wv from const2) and its relayout per decode instead of the 128-block weight kernel.
+extern "C" int64_t msam_chain_const2_bytes(void) { return T2_TABV + (long)CI * C * 2; }
+extern "C" int msam_chain_prepare_const2(const void* wv, const float* bv, const void* wk, const float* ln0_w, const float* ln0_b,
+                                         const void* wo0, const float* bo0, void* const2, void* stream) {
+    if (!wv || !bv || !wk || !ln0_w || !ln0_b || !wo0 || !bo0 || !const2) { msam_set_error("msam_chain_prepare_const2: null argument"); return 1; }
+    hipLaunchKernelGGL(tables2_small_kernel, dim3(128), dim3(128), 0, (hipStream_t)stream, (const u16*)wv, bv, (const u16*)wk, ln0_w,
+                       ln0_b, (const u16*)wo0, bo0, (unsigned char*)const2, T2_TABV);
+    return msam_check_launch("tables2_small(const)");
+}
+extern "C" int msam_chain_prepare_tables2_c(const void* src, const void* const2, void* tables2, void* stream) {
+    if (!src || !const2 || !tables2) { msam_set_error("msam_chain_prepare_tables2_c: null argument"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(tables2, const2, (size_t)T2_TABV, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        msam_set_error("msam_chain_prepare_tables2_c: device copy failed");
+        return 2;
+    }
+    msam_gemm_t g{};
+    g.A = src; g.lda = C; g.W = (const unsigned char*)const2 + T2_TABV; g.ldw = C; g.M = T; g.N = CI; g.K = C;
     g.out = (unsigned char*)tables2 + T2_TABV_RM; g.out_dtype = MSAM_D16; g.ldc = CI; g.a_dtype = MSAM_D16 == MSAM_F16 ? MSAM_F16 : 0;
     if (int e = msam_gemm_bf16(&g, stream)) return e;
     hipLaunchKernelGGL(tabv_relayout_kernel, dim3(T / 16 * 64 * 8 / 256), dim3(256), 0, s, (const u16*)((unsigned char*)tables2 + T2_TABV_RM),

@@ -523,8 +523,10 @@ struct Consts {     // layout of the `consts` buffer
     float* pos_f32; u16* pos_bf16; float* pe_k[3]; float* pe_q[2]; u16* wkv[3]; float* bkv[3];
     u16* tab_k[3];  // bf16(pos Wk^T + bk): score table of the folded token->image attention (decfold.hip)
     u16* tab_q[2];  // bf16(pos Wq^T + bq): score table of the folded image->token attention
+    void* chain2;   // weight-only tables of the second form of the chained attention (msam_chain_prepare_const2)
 };
-constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4 + 5L * T * CI * 2;
+constexpr long CONST2_BYTES = 128L * 128 * 4 + 4 * 512 + (long)CI * C * 2;        // == msam_chain_const2_bytes() (checked in prepare_const)
+constexpr long CONST_BYTES = (long)T * C * 4 + (long)T * C * 2 + 5L * T * CI * 4 + 3L * C * C * 2 + 3L * C * 4 + 5L * T * CI * 2 + CONST2_BYTES;
 
 Consts carve_consts(void* base) {
     Consts c; char* p = (char*)base;
@@ -536,6 +538,7 @@ Consts carve_consts(void* base) {
     for (int i = 0; i < 3; ++i) { c.bkv[i] = (float*)p; p += (long)C * 4; }
     for (int i = 0; i < 3; ++i) { c.tab_k[i] = (u16*)p; p += (long)T * CI * 2; }
     for (int i = 0; i < 2; ++i) { c.tab_q[i] = (u16*)p; p += (long)T * CI * 2; }
+    c.chain2 = p;
     return c;
 }
 
@@ -584,7 +587,11 @@ extern "C" int msam_decoder_prepare_const(const msam_decoder_t* dec, void* const
         if (int e = gemm(cx, c.pos_bf16, C, dec->layer[i].i2t.q_w, T, CI, C, dec->layer[i].i2t.q_b, c.tab_q[i], MSAM_D16, CI))
             return e;
     }
-    return 0;
+    // weight-only tables of the chained attention's second form (decfold_tok.hip): layer-1 token->image Wv / bv / Wk, norm4 and the
+    // image->token out_proj of layer 0
+    if (msam_chain_const2_bytes() != CONST2_BYTES) { msam_set_error("msam_decoder_prepare_const: const2 size mismatch"); return 2; }
+    return msam_chain_prepare_const2(dec->layer[1].t2i.v_w, dec->layer[1].t2i.v_b, dec->layer[1].t2i.k_w, dec->layer[0].n4_w,
+                                     dec->layer[0].n4_b, dec->layer[0].i2t.o_w, dec->layer[0].i2t.o_b, c.chain2, stream);
 }
 
 extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void* consts, const float* embedding,
@@ -787,9 +794,7 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     const bool chain2 = chain && g_tune_chain_variant == 9;
     void* const tables2 = (char*)tables - msam_chain_tables2_bytes();
     void* const mfrag = (char*)oper0 + msam_i2t_fold_operand_bytes(P);
-    if (chain2)
-        CHECK(msam_chain_prepare_tables2(im.src_bf16, dec->layer[1].t2i.v_w, dec->layer[1].t2i.v_b, dec->layer[1].t2i.k_w,
-                                         dec->layer[0].n4_w, dec->layer[0].n4_b, dec->layer[0].i2t.o_w, dec->layer[0].i2t.o_b, tables2, cx.s));
+    if (chain2) CHECK(msam_chain_prepare_tables2_c(im.src_bf16, c.chain2, tables2, cx.s));
     for (int li = 0; li < nlayers && li < 2; ++li) {
         const msam_twoway_layer_t& L = dec->layer[li];
         // (1) token self attention

@@ -597,6 +597,21 @@ def chain_prepare_tables2(src, wv, bv, wk, ln0_w, ln0_b, wo0, bo0):
     return t2
 
 
+def chain_prepare_tables2_cached(src, wv, bv, wk, ln0_w, ln0_b, wo0, bo0):
+    """The same tables through the two-step path the decoder uses: weight-only part once (msam_chain_prepare_const2), then the
+    source-dependent rest (msam_chain_prepare_tables2_c).  Returns (tables2, const2)."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    _dec16(src, wv, wk, wo0)
+    c2 = torch.empty((int(lib.msam_chain_const2_bytes()),), dtype=torch.uint8, device=src.device)
+    _lib.check(lib.msam_chain_prepare_const2(wv.data_ptr(), bv.data_ptr(), wk.data_ptr(), ln0_w.data_ptr(), ln0_b.data_ptr(),
+                                             wo0.data_ptr(), bo0.data_ptr(), c2.data_ptr(), _lib.stream_ptr()), "msam_chain_prepare_const2")
+    t2 = torch.empty((int(lib.msam_chain_tables2_bytes()),), dtype=torch.uint8, device=src.device)
+    _lib.check(lib.msam_chain_prepare_tables2_c(src.data_ptr(), c2.data_ptr(), t2.data_ptr(), _lib.stream_ptr()),
+               "msam_chain_prepare_tables2_c")
+    return t2, c2
+
+
 def t2i_fold_values(vtok0, tables2):
     """Per-prompt M fragments of the second form (include/msam_hip.h msam_t2i_fold_values): vtok0 [P,Nt,128]."""
     _lib.require_gpu()

@@ -501,6 +501,9 @@ def _chained_layer0_case(env, P, Nt):
     assert _close(att, att_stage, 6e-2, 3e-2)
     # second form: norm4 folded into the operands, value projection before the LayerNorm
     t2 = ops.chain_prepare_tables2(src, wv, bv, wk, L0["lw"], L0["lb"], L0["wo"], L0["bo"])
+    t2c, _ = ops.chain_prepare_tables2_cached(src, wv, bv, wk, L0["lw"], L0["lb"], L0["wo"], L0["bo"])     # the decoder's two-step path
+    n_const, n_tabv = 128 * 128 * 4 + 4 * 512, 4096 * 128 * 2
+    assert torch.equal(t2c[:n_const + n_tabv], t2[:n_const + n_tabv])
     mf = ops.t2i_fold_values(L0["vtok"], t2)
     op0b, mfb = ops.i2t_fold_operands_values(L0["ktok"], L0["vtok"], L0["wq"], L0["wo"], L0["bo"], t2)
     assert torch.equal(mfb, mf)
