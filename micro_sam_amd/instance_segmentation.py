@@ -538,9 +538,251 @@ class TiledAutomaticMaskGenerator(AutomaticMaskGenerator):
         self._crop_boxes = crop_boxes
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Segmentation from a decoder's foreground / distance maps (SURVEY.md 8(f) rank 1; reference :688-1628)
+# ---------------------------------------------------------------------------------------------------------------
+
+def _get_centers(segmentation: np.ndarray, avoid_image_border: bool = True) -> np.ndarray:
+    """[N,2] (y, x) of the pixel farthest from the object boundary for every label (reference :1322-1355)."""
+    from ._label_image_ops import blockwise_distance_transform, find_outer_boundaries, label_regions
+    interior = ~find_outer_boundaries(segmentation)
+    if avoid_image_border:
+        interior[0, :] = interior[-1, :] = False
+        interior[:, 0] = interior[:, -1] = False
+    distances = blockwise_distance_transform(interior, halo=(16, 16), block_shape=(512, 512))
+    centers = []
+    for seg_id, bb, _ in label_regions(segmentation):
+        dist = np.where(segmentation[bb] == seg_id, distances[bb], 0)
+        cy, cx = np.unravel_index(np.argmax(dist), dist.shape)           # first maximum in raster order
+        centers.append((cy + bb[0].start, cx + bb[1].start))
+    return np.array(centers)
+
+
+def _derive_point_prompts(foreground: np.ndarray, center_distances: np.ndarray, boundary_distances: np.ndarray,
+                          foreground_threshold: float = 0.5, center_distance_threshold: float = 0.5,
+                          boundary_distance_threshold: float = 0.5):
+    """One positive point per connected component of {foreground, close to a centre, far from a boundary}
+    (reference :1358-1379); ``None`` when there is no component."""
+    seeds = (center_distances < center_distance_threshold) & (boundary_distances < boundary_distance_threshold)
+    seeds[foreground < foreground_threshold] = False
+    components = util._label_equal_value_components(seeds.astype("uint32"))
+    prompts = _get_centers(components)
+    if len(prompts) == 0:
+        return None
+    return {"points": prompts[:, None, ::-1], "point_labels": np.ones((len(prompts), 1))}
+
+
+def _derive_box_prompts(predictions, box_extension: float):
+    """Boxes around the masks of a first round of predictions, grown by ``box_extension`` (reference :1382-1391; the
+    clipping against ``shape[0]`` / ``shape[1]`` is the reference's)."""
+    shape = predictions[0]["segmentation"].shape
+    prompts = [[max(x - w * box_extension, 0), max(y - h * box_extension, 0),
+                min(x + (1 + box_extension) * w, shape[0]), min(y + (1 + box_extension) * h, shape[1])]
+               for (x, y, w, h) in (pred["bbox"] for pred in predictions)]
+    return {"boxes": np.array(prompts)}
+
+
+class InstanceSegmentationWithDecoder:
+    """State handling of the reference's decoder-based segmenters (:953-1207): ``initialize`` runs ``decoder(embeddings,
+    input_shape, original_shape) -> [1, 3, H, W]`` (foreground, centre distances, boundary distances) on the predictor's
+    embedding of the image.  The decoder is any callable with that signature - the reference's ``DecoderAdapter`` around
+    ``torch_em.model.UNETR`` (:688-828) is not part of this build (torch_em is not vendored in the reference).
+
+    ``generate`` of THIS class is the reference's seeded watershed (vigra / elf, :1083-1168) and is not provided;
+    ``AutomaticPromptGenerator`` below derives point prompts from the same state instead and is."""
+
+    def __init__(self, predictor: SamPredictor, decoder) -> None:
+        self._predictor = predictor
+        self._decoder = decoder
+        self._foreground = self._center_distances = self._boundary_distances = None
+        self._is_initialized = False
+
+    @property
+    def is_initialized(self):
+        return self._is_initialized
+
+    @torch.no_grad()
+    def initialize(self, image: np.ndarray, image_embeddings=None, i: Optional[int] = None, verbose: bool = False,
+                   pbar_init: Optional[callable] = None, pbar_update: Optional[callable] = None, ndim: int = 2) -> None:
+        _, pbar_init, pbar_update, pbar_close = util.handle_pbar(verbose, pbar_init, pbar_update)
+        pbar_init(1, "Initialize instance segmentation with decoder")
+        if image_embeddings is None:
+            image_embeddings = util.precompute_image_embeddings(self._predictor, image, ndim=ndim, verbose=verbose)
+        self._predictor = util.set_precomputed(self._predictor, image_embeddings, i=i)
+        output = self._decoder(self._predictor.features, tuple(self._predictor.input_size),
+                               tuple(self._predictor.original_size))
+        output = (output.float().cpu().numpy() if torch.is_tensor(output) else np.asarray(output)).squeeze(0)
+        assert output.shape[0] == 3, f"{output.shape}"
+        pbar_update(1)
+        pbar_close()
+        self._foreground, self._center_distances, self._boundary_distances = output[0], output[1], output[2]
+        self._i = i
+        self._is_initialized = True
+
+    def _to_masks(self, segmentation: np.ndarray, output_mode: str):
+        """Label image -> list of mask records (reference :1040-1081, 2-d)."""
+        from ._label_image_ops import label_regions
+        if output_mode != "binary_mask":
+            raise ValueError(f"Output mode {output_mode} is not supported. Choose one of 'instance_segmentation', 'binary_masks'")
+        assert segmentation.ndim == 2
+        shape = segmentation.shape
+        crop_box = [0, shape[1], 0, shape[0]]
+        return [{"segmentation": segmentation == seg_id, "area": area,
+                 "bbox": [bb[1].start, bb[1].stop - bb[1].start, bb[0].start, bb[0].stop - bb[0].start],    # [x0, w, y0, h]
+                 "crop_box": crop_box, "seg_id": seg_id} for seg_id, bb, area in label_regions(segmentation)]
+
+    def generate(self, *args, **kwargs):
+        raise NotImplementedError(
+            "micro_sam_amd: the seeded watershed of InstanceSegmentationWithDecoder.generate (vigra / elf) is not provided; "
+            "AutomaticPromptGenerator.generate works on the same state")
+
+    def get_state(self) -> Dict[str, Any]:
+        if not self.is_initialized:
+            raise RuntimeError("The state has not been computed yet. Call initialize first.")
+        return {"foreground": self._foreground, "center_distances": self._center_distances,
+                "boundary_distances": self._boundary_distances}
+
+    def set_state(self, state: Dict[str, Any]) -> None:
+        self._foreground = state["foreground"]
+        self._center_distances = state["center_distances"]
+        self._boundary_distances = state["boundary_distances"]
+        self._is_initialized = True
+
+    def clear_state(self):
+        self._foreground = self._center_distances = self._boundary_distances = None
+        self._is_initialized = False
+
+
+class TiledInstanceSegmentationWithDecoder(InstanceSegmentationWithDecoder):
+    """The same on tiled embeddings (reference :1210-1319): the decoder runs per tile (outer block), the inner blocks of
+    its three maps are written into full-image maps."""
+
+    @torch.no_grad()
+    def initialize(self, image: np.ndarray, image_embeddings=None, i: Optional[int] = None, tile_shape=None, halo=None,
+                   verbose: bool = False, pbar_init: Optional[callable] = None, pbar_update: Optional[callable] = None,
+                   batch_size: int = 1, mask=None) -> None:
+        from .tiling import Blocking
+        original_size = image.shape[:2]
+        self._image_embeddings, tile_shape, halo, tiles_in_mask = _process_tiled_embeddings(
+            self._predictor, image, image_embeddings, tile_shape, halo, verbose=verbose, batch_size=batch_size, mask=mask, i=i)
+        tiling = Blocking([0, 0], original_size, tile_shape)
+        _, pbar_init, pbar_update, pbar_close = util.handle_pbar(verbose, pbar_init, pbar_update)
+        maps = np.zeros((3,) + tuple(original_size), dtype="float32")
+        tile_ids = list(range(tiling.number_of_blocks)) if tiles_in_mask is None else list(tiles_in_mask)
+        pbar_init(len(tile_ids), "Initialize tiled instance segmentation with decoder" + ("" if tiles_in_mask is None else " and mask"))
+        for tile_id in tile_ids:
+            self._predictor = util.set_precomputed(self._predictor, self._image_embeddings, i=i, tile_id=tile_id)
+            output = self._decoder(self._predictor.features, tuple(self._predictor.input_size),
+                                   tuple(self._predictor.original_size))
+            output = (output.float().cpu().numpy() if torch.is_tensor(output) else np.asarray(output)).squeeze(0)
+            assert output.shape[0] == 3
+            block = tiling.get_block_with_halo(tile_id, halo=list(halo))
+            local = tuple(slice(b, e) for b, e in zip(block.inner_block_local.begin, block.inner_block_local.end))
+            inner = tuple(slice(b, e) for b, e in zip(block.inner_block.begin, block.inner_block.end))
+            maps[(slice(None),) + inner] = output[(slice(None),) + local]
+            pbar_update(1)
+        pbar_close()
+        self._i = i
+        self._foreground, self._center_distances, self._boundary_distances = maps[0], maps[1], maps[2]
+        self._is_initialized = True
+
+
+class AutomaticPromptGenerator(InstanceSegmentationWithDecoder):
+    """Instance segmentation from prompts derived from the decoder maps (reference :1394-1505): components of the
+    thresholded maps -> one point per component -> ``inference.batched_inference`` on the HIP decoder ->
+    ``util.apply_nms`` (device mask NMS) -> label image."""
+
+    def generate(self, min_size: int = 25, center_distance_threshold: float = 0.5, boundary_distance_threshold: float = 0.5,
+                 foreground_threshold: float = 0.5, multimasking: bool = False, batch_size: int = 32,
+                 nms_threshold: float = 0.9, intersection_over_min: bool = False, output_mode: str = "instance_segmentation",
+                 mask_threshold: Optional[Union[float, str]] = None, refine_with_box_prompts: bool = False,
+                 prompt_function: Optional[callable] = None) -> Union[List[Dict[str, Any]], np.ndarray]:
+        from .inference import batched_inference
+        if not self.is_initialized:
+            raise RuntimeError("AutomaticPromptGenerator has not been initialized. Call initialize first.")
+        foreground = self._foreground
+        prompt_function = _derive_point_prompts if prompt_function is None else prompt_function
+        prompts = prompt_function(foreground=foreground, center_distances=self._center_distances,
+                                  boundary_distances=self._boundary_distances, foreground_threshold=foreground_threshold,
+                                  center_distance_threshold=center_distance_threshold,
+                                  boundary_distance_threshold=boundary_distance_threshold)
+        if prompts is None:
+            return np.zeros(foreground.shape, dtype="uint32") if output_mode == "instance_segmentation" else []
+
+        def predict(prompts):
+            return batched_inference(self._predictor, image=None, batch_size=batch_size, return_instance_segmentation=False,
+                                     multimasking=multimasking, mask_threshold=mask_threshold, i=getattr(self, "_i", None),
+                                     **prompts)
+        predictions = predict(prompts)
+        if refine_with_box_prompts:
+            predictions = predict(_derive_box_prompts(predictions, box_extension=0.01))
+        segmentation = util.apply_nms(predictions, min_size=min_size, nms_thresh=nms_threshold,
+                                      intersection_over_min=intersection_over_min)
+        if output_mode != "instance_segmentation":
+            segmentation = self._to_masks(segmentation, output_mode)
+        return segmentation
+
+
+class TiledAutomaticPromptGenerator(TiledInstanceSegmentationWithDecoder):
+    """``AutomaticPromptGenerator`` on tiled embeddings (reference :1508-1628): the prompts are derived on the stitched
+    maps, every prompt is decoded on the tile that contains it (``inference.batched_tiled_inference``), the tile-local
+    records meet in ``util.apply_nms`` through their ``global_bbox``."""
+
+    def generate(self, min_size: int = 25, center_distance_threshold: float = 0.5, boundary_distance_threshold: float = 0.5,
+                 foreground_threshold: float = 0.5, multimasking: bool = False, batch_size: int = 32,
+                 nms_threshold: float = 0.9, intersection_over_min: bool = False, output_mode: str = "instance_segmentation",
+                 mask_threshold: Optional[Union[float, str]] = None, refine_with_box_prompts: bool = False,
+                 prompt_function: Optional[callable] = None, optimize_memory: bool = False):
+        from .inference import batched_tiled_inference
+        if not self.is_initialized:
+            raise RuntimeError("TiledAutomaticPromptGenerator has not been initialized. Call initialize first.")
+        if optimize_memory and (output_mode != "instance_segmentation" or refine_with_box_prompts):
+            raise ValueError("Invalid settings")
+        foreground = self._foreground
+        prompt_function = _derive_point_prompts if prompt_function is None else prompt_function
+        prompts = prompt_function(foreground, self._center_distances, self._boundary_distances,
+                                  foreground_threshold=foreground_threshold,
+                                  center_distance_threshold=center_distance_threshold,
+                                  boundary_distance_threshold=boundary_distance_threshold)
+        shape = foreground.shape
+        if prompts is None:
+            return np.zeros(shape, dtype="uint32") if output_mode == "instance_segmentation" else []
+        if optimize_memory:
+            prompts.update(dict(min_size=min_size, nms_thresh=nms_threshold, intersection_over_min=intersection_over_min))
+        # (the reference does not forward mask_threshold here either)
+        predictions = batched_tiled_inference(self._predictor, image=None, batch_size=batch_size,
+                                              image_embeddings=self._image_embeddings, return_instance_segmentation=False,
+                                              multimasking=multimasking, optimize_memory=optimize_memory,
+                                              i=getattr(self, "_i", None), **prompts)
+        if optimize_memory:
+            return predictions
+        if refine_with_box_prompts:
+            raise NotImplementedError
+        segmentation = util.apply_nms(predictions, shape=shape, min_size=min_size, nms_thresh=nms_threshold,
+                                      intersection_over_min=intersection_over_min)
+        if output_mode != "instance_segmentation":
+            segmentation = self._to_masks(segmentation, output_mode)
+        return segmentation
+
+    def get_state(self):
+        raise NotImplementedError
+
+    def set_state(self, state):
+        raise NotImplementedError
+
+
 def get_instance_segmentation_generator(predictor: SamPredictor, is_tiled: bool = False, decoder=None,
-                                        segmentation_mode: Optional[str] = None, **kwargs) -> AMGBase:
-    """Factory with the reference's signature (:1631-1670); only the AMG mode exists in this build."""
-    if decoder is not None or (segmentation_mode not in (None, "amg")):
-        raise NotImplementedError("micro_sam_amd: only segmentation_mode='amg' is provided (AIS/APG: SURVEY.md 8(f))")
-    return (TiledAutomaticMaskGenerator if is_tiled else AutomaticMaskGenerator)(predictor, **kwargs)
+                                        segmentation_mode: Optional[str] = None, **kwargs):
+    """Factory with the reference's signature and mode resolution (:1631-1690): ``amg`` without a decoder, with a decoder
+    the reference defaults to ``ais`` - whose watershed is not provided here, so ``apg`` has to be asked for."""
+    if segmentation_mode is None:
+        segmentation_mode = "amg" if decoder is None else "ais"
+    if segmentation_mode.lower() == "amg":
+        return (TiledAutomaticMaskGenerator if is_tiled else AutomaticMaskGenerator)(predictor, **kwargs)
+    if decoder is None:
+        raise ValueError(f"segmentation_mode={segmentation_mode!r} needs a decoder")
+    if segmentation_mode.lower() == "apg":
+        return (TiledAutomaticPromptGenerator if is_tiled else AutomaticPromptGenerator)(predictor, decoder, **kwargs)
+    if segmentation_mode.lower() == "ais":
+        raise NotImplementedError("micro_sam_amd: segmentation_mode='ais' (seeded watershed) is not provided; use 'apg'")
+    raise ValueError(f"Invalid segmentation_mode: {segmentation_mode!r}")

@@ -692,6 +692,93 @@ def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape: Optional[Tuple
     return new_ids[segmentation]
 
 
+def _infer_tiled_shape(predictions) -> Tuple[int, int]:
+    """Output shape spanned by tile-local records (reference util.py:1757-1766)."""
+    height = width = 0
+    for pred in predictions:
+        (bx, by), (gx, gy) = pred["bbox"][:2], pred["global_bbox"][:2]
+        mh, mw = pred["segmentation"].shape
+        height, width = max(height, int(gy - by) + mh), max(width, int(gx - bx) + mw)
+    return height, width
+
+
+def _tiled_overlap_scores(masks: List[np.ndarray], boxes: np.ndarray, global_boxes: np.ndarray,
+                          intersection_over_min: bool) -> Dict[Tuple[int, int], np.float32]:
+    """Overlap score of every pair (i < j) of tile-local masks whose global boxes share area (reference
+    ``_calculate_tiled_mask_overlap_matrix``, util.py:1769-1822): the two masks are compared on the intersection window
+    of their global xywh boxes only, IoU or intersection over the smaller area in float32.  Sparse: pairs that are not
+    returned score 0."""
+    gx0, gy0 = global_boxes[:, 0], global_boxes[:, 1]
+    gx1, gy1 = gx0 + global_boxes[:, 2], gy0 + global_boxes[:, 3]
+    off_x, off_y = gx0 - boxes[:, 0], gy0 - boxes[:, 1]          # tile origin of every record in the image
+    areas = np.array([m.sum() for m in masks], dtype=np.float32)
+    scores = {}
+    order = np.argsort(gx0, kind="stable")                        # sweep along x: candidates end once their x0 >= our x1
+    sorted_x0 = gx0[order]
+    for rank, i in enumerate(order):
+        hi = np.searchsorted(sorted_x0, gx1[i], side="left")
+        for j in order[rank + 1:hi]:
+            wx0, wx1 = max(gx0[i], gx0[j]), min(gx1[i], gx1[j])
+            wy0, wy1 = max(gy0[i], gy0[j]), min(gy1[i], gy1[j])
+            if wx1 <= wx0 or wy1 <= wy0:
+                continue
+            a = masks[i][wy0 - off_y[i]:wy1 - off_y[i], wx0 - off_x[i]:wx1 - off_x[i]]
+            b = masks[j][wy0 - off_y[j]:wy1 - off_y[j], wx0 - off_x[j]:wx1 - off_x[j]]
+            inter = np.float32(np.count_nonzero(a & b))
+            den = min(areas[i], areas[j]) if intersection_over_min else areas[i] + areas[j] - inter
+            with np.errstate(divide="ignore", invalid="ignore"):
+                scores[(min(i, j), max(i, j))] = np.float32(inter) / np.float32(den)
+    return scores
+
+
+def _apply_nms_tiled(predictions, min_size, shape, perform_box_nms, nms_thresh, max_size, intersection_over_min) -> np.ndarray:
+    """``apply_nms`` for tile-local records (reference util.py:1876-1957 with ``is_tiled``): a host computation in the
+    reference as well (``_batched_tiled_mask_nms`` moves everything to the CPU).  The masks come off the device once."""
+    from . import ops
+    if perform_box_nms and intersection_over_min:
+        raise ValueError("intersection_over_min needs mask NMS (perform_box_nms=False)")
+    if shape is None:
+        shape = _infer_tiled_shape(predictions)
+
+    def dense(p):
+        m = p["segmentation"]
+        return (m.cpu().numpy() if torch.is_tensor(m) else np.asarray(m)).astype(bool)
+    preds = [dict(p, segmentation=dense(p)) for p in predictions]
+    for p in preds:
+        p["area"] = int(p["segmentation"].sum())
+    if min_size > 0:
+        preds = [p for p in preds if p["area"] > min_size]
+    if max_size is not None:
+        preds = [p for p in preds if p["area"] < max_size]
+    if not preds:
+        return np.zeros(shape, dtype="uint32")
+    scores = np.array([np.float32(p["predicted_iou"]) * np.float32(p["stability_score"]) for p in preds], dtype=np.float32)
+    if perform_box_nms:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        xyxy = torch.tensor([p["global_bbox"] for p in preds], dtype=torch.float32, device=dev)
+        xyxy[:, 2] += xyxy[:, 0]
+        xyxy[:, 3] += xyxy[:, 1]
+        keep = ops.box_nms(xyxy, torch.as_tensor(scores, device=dev), nms_thresh).cpu().tolist()
+    else:
+        boxes = np.array([p["bbox"] for p in preds]).astype(np.int64)                   # .to(torch.long): truncation
+        global_boxes = np.array([p["global_bbox"] for p in preds]).astype(np.int64)
+        overlap = _tiled_overlap_scores([p["segmentation"] for p in preds], boxes, global_boxes, intersection_over_min)
+        suppressed = np.zeros(len(preds), dtype=bool)
+        partners = {}
+        for (i, j), v in overlap.items():
+            if not (v <= np.float32(nms_thresh)):                                       # nan (0/0) suppresses, as `<=` does
+                partners.setdefault(i, []).append(j)
+                partners.setdefault(j, []).append(i)
+        keep = []
+        for i in np.argsort(-scores.astype(np.float64), kind="stable").tolist():
+            if suppressed[i]:
+                continue
+            keep.append(i)
+            suppressed[partners.get(i, [])] = True
+    records = [{k: preds[i][k] for k in ("segmentation", "area", "bbox", "global_bbox")} for i in keep]
+    return mask_data_to_segmentation(records, shape=shape, min_object_size=min_size)
+
+
 @torch.no_grad()
 def apply_nms(predictions: List[Dict[str, Any]], min_size: int, shape: Optional[Tuple[int, int]] = None,
               perform_box_nms: bool = False, nms_thresh: float = 0.9, max_size: Optional[int] = None,
@@ -700,14 +787,14 @@ def apply_nms(predictions: List[Dict[str, Any]], min_size: int, shape: Optional[
     ``segmentation``, ``bbox`` xywh, ``predicted_iou``, ``stability_score``): size filters, NMS on
     score = predicted_iou * stability_score - box NMS (``msam_box_nms``) or mask NMS on IoU / intersection-over-min
     (``msam_mask_nms``: popcount of AND over bit masks instead of the reference's ``masks_flat @ masks_flat.T``) - and merge
-    of the survivors to a label image.  Tile-local predictions (``global_bbox``: ``_batched_tiled_mask_nms``) are not
-    provided."""
+    of the survivors to a label image.  Tile-local predictions (records with a ``global_bbox``, as
+    ``inference.batched_tiled_inference`` returns them) take the reference's host path (``_apply_nms_tiled``)."""
     from . import ops
     from ._vendored import pack_bits
     if len(predictions) == 0:
         return np.zeros(shape, dtype="uint32")
     if "global_bbox" in predictions[0]:
-        raise NotImplementedError("micro_sam_amd.apply_nms: tile-local predictions (global_bbox) are not provided")
+        return _apply_nms_tiled(predictions, min_size, shape, perform_box_nms, nms_thresh, max_size, intersection_over_min)
     if perform_box_nms and intersection_over_min:
         raise ValueError("intersection_over_min needs mask NMS (perform_box_nms=False)")
 

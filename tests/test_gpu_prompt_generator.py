@@ -1,0 +1,184 @@
+"""AutomaticPromptGenerator / TiledAutomaticPromptGenerator on the device (reference
+micro_sam/instance_segmentation.py:1394-1628; its tests: test/test_instance_segmentation.py:138-150).
+
+The reference's decoder (torch_em UNETR + trained weights) does not exist here; the tests drive the generators with a
+stand-in decoder that returns the ideal foreground / distance maps of a synthetic label image, which is all the
+generators read from it.  Checked: the derived prompts (exact vs oracle/apg_ref.py), the records of the prompt decode
+against the oracle's restated pipeline (same tolerances as test_batched_inference_vs_oracle), and every integer stage after
+it (mask NMS, merge, relabel) exactly: the oracle's apply_nms over the product's own records gives the identical image."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _disk_labels(shape, n, seed, rmin=18, rmax=42, margin=60):
+    g = np.random.default_rng(seed)
+    lab = np.zeros(shape, np.uint32)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    k = 0
+    for _ in range(20 * n):
+        cy, cx, r = g.integers(margin, shape[0] - margin), g.integers(margin, shape[1] - margin), g.integers(rmin, rmax)
+        m = (yy - cy) ** 2 + (xx - cx) ** 2 < r * r
+        grown = (yy - cy) ** 2 + (xx - cx) ** 2 < (r + 6) ** 2
+        if lab[grown].any():
+            continue
+        k += 1
+        lab[m] = k
+        if k == n:
+            break
+    return lab
+
+
+class _MapDecoder:
+    """decoder(embeddings, input_shape, original_shape) -> [1, 3, H, W]: crops of fixed full-image maps, tile by tile in the
+    order the generators visit the tiles (one call for an untiled image)."""
+
+    def __init__(self, maps, boxes=None):
+        self.maps, self.boxes, self.calls = np.stack(maps).astype("float32"), boxes, 0
+
+    def __call__(self, embeddings, input_shape, original_shape):
+        assert tuple(embeddings.shape) == (1, 256, 64, 64)
+        if self.boxes is None:
+            out = self.maps
+        else:
+            (y0, y1), (x0, x1) = self.boxes[self.calls % len(self.boxes)]
+            out = self.maps[:, y0:y1, x0:x1]
+        self.calls += 1
+        assert tuple(out.shape[1:]) == tuple(original_shape), (out.shape, original_shape)
+        return torch.from_numpy(np.ascontiguousarray(out))[None]
+
+
+def _cpu_records(recs):
+    return [{k: (v.cpu() if torch.is_tensor(v) else v) for k, v in r.items() if k != "logits"} for r in recs]
+
+
+@pytest.fixture(scope="module")
+def ctx(vit_b_sd):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_tile
+    from oracle import apg_ref as G
+    predictor = util.get_sam_model("vit_b", device="cuda", state_dict=vit_b_sd)
+    tile = synthetic_tile(7)
+    labels = _disk_labels((1024, 1024), 24, seed=1)
+    maps = G.decoder_maps_from_labels(labels)
+    return dict(sd=vit_b_sd, predictor=predictor, tile=tile, labels=labels, maps=maps)
+
+
+def test_automatic_prompt_generator_vs_oracle(ctx):
+    from micro_sam_amd import inference, util
+    from micro_sam_amd import instance_segmentation as IS
+    from oracle import amg_ref as A
+    from oracle import apg_ref as G
+    p, sd, tile, maps = ctx["predictor"], ctx["sd"], ctx["tile"], ctx["maps"]
+    n_obj = int(ctx["labels"].max())
+    assert n_obj >= 12
+    emb = util.precompute_image_embeddings(p, tile, verbose=False)
+    decoder = _MapDecoder(maps)
+    apg = IS.get_instance_segmentation_generator(p, is_tiled=False, decoder=decoder, segmentation_mode="apg")
+    assert isinstance(apg, IS.AutomaticPromptGenerator) and not apg.is_initialized
+    apg.initialize(tile, image_embeddings=emb)
+    assert apg.is_initialized and decoder.calls == 1
+    state = apg.get_state()
+    for k, m in zip(("foreground", "center_distances", "boundary_distances"), maps):
+        assert np.array_equal(state[k], m)
+
+    # 1) prompts: one per object, exact vs the oracle's restatement
+    prompts = IS._derive_point_prompts(*maps)
+    ref_prompts = G.derive_point_prompts(*maps)
+    assert np.array_equal(prompts["points"], ref_prompts["points"]) and len(prompts["points"]) == n_obj
+    assert sorted(int(ctx["labels"][y, x]) for x, y in prompts["points"][:, 0]) == list(range(1, n_obj + 1))
+
+    # 2) the decode of those prompts against the oracle's restated pipeline (bf16-mode decoder; best of three masks, the
+    #    point-prompt configuration whose tolerance test_batched_inference_vs_oracle established)
+    recs = inference.batched_inference(p, None, batch_size=32, return_instance_segmentation=False, multimasking=True, **prompts)
+    feats = p.features.float().cpu()
+    ref_recs = G.apg_generate(sd, feats, p.input_size, p.original_size, *maps, multimasking=True, precision="bf16",
+                              return_records=True)
+    assert len(recs) == len(ref_recs) == n_obj
+    dis = [(a["segmentation"].cpu() != b["segmentation"]).float().mean().item() for a, b in zip(recs, ref_recs)]
+    assert np.mean(dis) <= 0.01, dis
+    assert max(abs(a["predicted_iou"] - b["predicted_iou"]) for a, b in zip(recs, ref_recs)) <= 5e-3
+
+    # 3) generate == the oracle's NMS + merge over the product's own records (integer stages, exact)
+    for kw in (dict(), dict(min_size=0, nms_threshold=0.5), dict(min_size=200, nms_threshold=0.7, intersection_over_min=True)):
+        seg = apg.generate(multimasking=True, **kw)
+        ref = A.apply_nms(_cpu_records(recs), min_size=kw.get("min_size", 25), nms_thresh=kw.get("nms_threshold", 0.9),
+                          intersection_over_min=kw.get("intersection_over_min", False))
+        assert seg.shape == (1024, 1024) and seg.dtype == np.uint32 and np.array_equal(seg, ref)
+    seg = apg.generate()
+    assert seg.max() >= 1
+    # regenerate / state round trip (reference test/test_instance_segmentation.py:96-106)
+    assert np.array_equal(seg, apg.generate())
+    other = IS.AutomaticPromptGenerator(p, decoder)
+    other.set_state(apg.get_state())
+    assert np.array_equal(seg, other.generate())
+
+    # 4) records output
+    masks = apg.generate(output_mode="binary_mask")
+    assert [m["seg_id"] for m in masks] == list(range(1, int(seg.max()) + 1))
+    assert all(np.array_equal(m["segmentation"], seg == m["seg_id"]) and m["area"] == int((seg == m["seg_id"]).sum()) for m in masks)
+
+    # 5) single-mask decode (the default) and a second round with boxes around the first round's masks
+    recs1 = inference.batched_inference(p, None, batch_size=32, return_instance_segmentation=False, multimasking=False, **prompts)
+    assert np.array_equal(seg, A.apply_nms(_cpu_records(recs1), min_size=25, nms_thresh=0.9))
+    boxes = IS._derive_box_prompts(recs1, 0.01)
+    assert np.array_equal(boxes["boxes"], G.derive_box_prompts(_cpu_records(recs1), 0.01)["boxes"])
+    recs2 = inference.batched_inference(p, None, batch_size=32, return_instance_segmentation=False, multimasking=False, **boxes)
+    seg2 = apg.generate(refine_with_box_prompts=True)
+    assert np.array_equal(seg2, A.apply_nms(_cpu_records(recs2), min_size=25, nms_thresh=0.9))
+
+    # 6) another batch size
+    recs3 = inference.batched_inference(p, None, batch_size=8, return_instance_segmentation=False, multimasking=True, **prompts)
+    assert np.array_equal(apg.generate(multimasking=True, batch_size=8), A.apply_nms(_cpu_records(recs3), min_size=25, nms_thresh=0.9))
+
+    # 7) a custom prompt function (reference :1433-1441): every second derived point
+    def every_second(foreground, center_distances, boundary_distances, **kw):
+        pr = IS._derive_point_prompts(foreground, center_distances, boundary_distances, **kw)
+        return {"points": pr["points"][::2], "point_labels": pr["point_labels"][::2]}
+    seg4 = apg.generate(prompt_function=every_second, min_size=0)
+    recs4 = inference.batched_inference(p, None, batch_size=32, return_instance_segmentation=False, multimasking=False,
+                                        points=prompts["points"][::2], point_labels=prompts["point_labels"][::2])
+    assert np.array_equal(seg4, A.apply_nms(_cpu_records(recs4), min_size=0, nms_thresh=0.9))
+
+
+def test_tiled_automatic_prompt_generator(ctx):
+    """2 x 2 tiles of 512 with a halo of 64 (the layout tests/test_gpu_modules.py::test_batched_tiled_inference covers): the
+    decoder maps are stitched from the tiles' inner blocks, prompts are decoded on their own tile, the tile-local records
+    meet in apply_nms through their global boxes."""
+    from micro_sam_amd import inference, util
+    from micro_sam_amd import instance_segmentation as IS
+    from micro_sam_amd.tiling import Blocking
+    from oracle import amg_ref as A
+    p, tile, maps = ctx["predictor"], ctx["tile"], ctx["maps"]
+    tile_shape, halo = (512, 512), (64, 64)
+    emb = util.precompute_image_embeddings(p, tile, tile_shape=tile_shape, halo=halo, verbose=False)
+    tiling = Blocking([0, 0], tile.shape[:2], tile_shape)
+    outer = [tiling.get_block_with_halo(t, list(halo)).outer_block for t in range(4)]
+    decoder = _MapDecoder(maps, boxes=[((o.begin[0], o.end[0]), (o.begin[1], o.end[1])) for o in outer])
+    tapg = IS.get_instance_segmentation_generator(p, is_tiled=True, decoder=decoder, segmentation_mode="apg")
+    assert isinstance(tapg, IS.TiledAutomaticPromptGenerator)
+    tapg.initialize(tile, image_embeddings=emb)
+    assert decoder.calls == 4
+    for got, m in zip((tapg._foreground, tapg._center_distances, tapg._boundary_distances), maps):
+        assert got.shape == (1024, 1024) and np.array_equal(got, m)                  # inner blocks tile the image exactly
+
+    prompts = IS._derive_point_prompts(*maps)
+    recs = inference.batched_tiled_inference(p, None, 32, image_embeddings=emb, return_instance_segmentation=False,
+                                             multimasking=False, **prompts)
+    assert len(recs) == len(prompts["points"]) and all("global_bbox" in r for r in recs)
+    for kw in (dict(), dict(min_size=0, nms_threshold=0.5, intersection_over_min=True)):
+        seg = tapg.generate(**kw)
+        ref = A.apply_nms(_cpu_records(recs), shape=(1024, 1024), min_size=kw.get("min_size", 25),
+                          nms_thresh=kw.get("nms_threshold", 0.9), intersection_over_min=kw.get("intersection_over_min", False))
+        assert seg.shape == (1024, 1024) and seg.dtype == np.uint32 and np.array_equal(seg, ref)
+    assert np.array_equal(tapg.generate(), tapg.generate()) and tapg.generate().max() >= 1
+    masks = tapg.generate(output_mode="binary_mask")
+    assert len(masks) == int(tapg.generate().max())
+    seg_mem = tapg.generate(optimize_memory=True)
+    assert seg_mem.shape == (1024, 1024) and seg_mem.max() >= 1
+    with pytest.raises(NotImplementedError):
+        tapg.generate(refine_with_box_prompts=True)
