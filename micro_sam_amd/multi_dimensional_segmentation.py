@@ -8,6 +8,10 @@ contiguous block of slices per rank (one process per GPU) and assembles the volu
 
 The merge of the per-slice segmentations across z (``merge_instance_segmentation_3d``: overlap graph + multicut from the
 un-vendored ``elf`` / ``nifty``) is a host step on top of this output and is not part of this build.
+
+``segment_mask_in_volume`` (reference :105-233) is the interactive 3-d path: an object annotated in a few slices is
+carried through the volume slice by slice, each step one ``prompt_based_segmentation.segment_from_mask`` call (prompts
+derived from the neighbouring slice's mask, one decoder pass on the slice's precomputed embedding).
 """
 from typing import Optional, Tuple
 
@@ -58,3 +62,96 @@ def segment_slices_sharded(data: np.ndarray, predictor, segmentor, verbose: bool
     dev = predictor.device if world > 1 and dist.get_backend() == "nccl" else "cpu"
     out = parallel.gather_label_tiles(torch.as_tensor(local, device=dev), data.shape[0])
     return out.cpu().numpy().astype("uint32")
+
+
+# ------------------------------------------------------------------------------------------ interactive 3-d projection
+
+PROJECTION_MODES = ("box", "mask", "points", "points_and_mask", "single_point")
+_PROJECTIONS = {                      # (use_box, use_mask, use_points, use_single_point)
+    "mask": (True, True, False, False), "points": (False, False, True, False), "box": (True, False, False, False),
+    "points_and_mask": (False, True, True, False), "single_point": (False, False, True, True),
+}
+
+
+def _validate_projection(projection):
+    """Reference :48-72."""
+    if isinstance(projection, str):
+        if projection not in _PROJECTIONS:
+            raise ValueError("Choose projection method from 'mask' / 'points' / 'box' / 'points_and_mask' / 'single_point'. "
+                             f"You have passed the invalid option {projection}.")
+        return _PROJECTIONS[projection]
+    if isinstance(projection, dict):
+        assert len(projection.keys()) == 3, "There should be three parameters assigned for the projection method."
+        return projection["use_box"], projection["use_mask"], projection["use_points"], False
+    raise ValueError(f"{projection} is not a supported projection method.")
+
+
+def segment_mask_in_volume(segmentation: np.ndarray, predictor, image_embeddings, segmented_slices: np.ndarray,
+                           stop_lower: bool, stop_upper: bool, iou_threshold: float, projection,
+                           update_progress: Optional[callable] = None, box_extension: float = 0.0,
+                           verbose: bool = False) -> Tuple[np.ndarray, Tuple[int, int]]:
+    """Reference ``segment_mask_in_volume`` (:105-233).  ``segmentation`` [Z,H,W] holds the object (value 1) in the slices
+    ``segmented_slices``; it is extended in place: downwards from the lowest and upwards from the highest annotated slice
+    until the IoU between consecutive slices drops below ``iou_threshold`` (unless ``stop_lower`` / ``stop_upper``), and
+    between annotated slices from both ends towards the middle (a single middle slice is prompted with the union of its
+    two neighbours).  Returns the volume and the (lowest, highest) slice that now holds the object."""
+    from .prompt_based_segmentation import segment_from_mask
+    use_box, use_mask, use_points, use_single_point = _validate_projection(projection)
+    if update_progress is None:
+        def update_progress(*args):
+            pass
+    prompt_kw = dict(image_embeddings=image_embeddings, use_mask=use_mask, use_box=use_box, use_points=use_points,
+                     box_extension=box_extension)
+
+    def walk(z_start, z_stop, step, done, threshold=None):
+        """Carry the mask from ``z_start`` towards ``z_stop``; returns the last slice written."""
+        z = z_start + step
+        while True:
+            if verbose:
+                print(f"Segment {z_start} to {z_stop}: segmenting slice {z}")
+            previous = segmentation[z - step]
+            seg_z, _, _ = segment_from_mask(predictor, previous, i=z, return_all=True, use_single_point=use_single_point,
+                                            **prompt_kw)
+            if threshold is not None:
+                iou = util.compute_iou(previous, seg_z)
+                if iou < threshold:
+                    if verbose:
+                        print(f"Segmentation stopped at slice {z} due to IOU {iou} < {threshold}.")
+                    break
+            segmentation[z] = seg_z
+            z += step
+            if done(z, z_stop):
+                if verbose:
+                    print(f"Segment {z_start} to {z_stop}: stop at slice {z}")
+                break
+            update_progress(1)
+        return z - step
+
+    def fill_between(z, below, above):
+        """One slice prompted with the union of the object in two other slices."""
+        union = np.logical_or(segmentation[below] == 1, segmentation[above] == 1)
+        segmentation[z] = segment_from_mask(predictor, union, i=z, **prompt_kw)
+        update_progress(1)
+
+    z0, z1 = int(segmented_slices.min()), int(segmented_slices.max())
+    last = segmentation.shape[0] - 1
+    z_min = walk(z0, 0, -1, np.less, iou_threshold) if (z0 > 0 and not stop_lower) else z0
+    z_max = walk(z1, last, 1, np.greater, iou_threshold) if (z1 < last and not stop_upper) else z1
+    if z0 != z1:
+        for z_start, z_stop in zip(segmented_slices[:-1], segmented_slices[1:]):
+            gap = z_stop - z_start
+            z_mid = int((z_start + z_stop) // 2)
+            if gap == 1:
+                continue
+            if z_start == z0 and stop_lower:
+                walk(z_stop, z_start, -1, np.less_equal)
+            elif z_stop == z1 and stop_upper:
+                walk(z_start, z_stop, 1, np.greater_equal)
+            elif gap == 2:
+                fill_between(z_start + 1, z_start, z_stop)
+            else:
+                walk(z_start, z_mid, 1, np.greater_equal if gap % 2 == 0 else np.greater)
+                walk(z_stop, z_mid, -1, np.less_equal)
+                if gap % 2 == 0:          # the middle slice is equally far from both ends: union of its neighbours
+                    fill_between(z_mid, z_mid - 1, z_mid + 1)
+    return segmentation, (z_min, z_max)

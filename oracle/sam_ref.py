@@ -565,3 +565,25 @@ def predict_torch(sd, features: Tensor, input_size, original_size, point_coords:
     if not return_logits:
         masks = masks > 0.0
     return masks, iou, low_res
+
+
+@torch.no_grad()
+def predict(sd, features: Tensor, input_size, original_size, point_coords: Optional[np.ndarray] = None,
+            point_labels: Optional[np.ndarray] = None, box: Optional[np.ndarray] = None,
+            mask_input: Optional[np.ndarray] = None, multimask_output: bool = True, return_logits: bool = False,
+            precision: str = "fp32"):
+    """SamPredictor.predict (segment_anything/predictor.py, un-vendored; the reference's call sites:
+    micro_sam/prompt_based_segmentation.py:287,393,438,493): numpy prompts of ONE object in original image coordinates
+    (points [N,2] XY, labels [N], box [4] XYXY, mask_input [1,256,256]) -> (masks [C,H,W], iou [C], low_res [C,256,256])."""
+    coords = labels = boxes = masks_in = None
+    if point_coords is not None:
+        assert point_labels is not None
+        coords = torch.as_tensor(apply_coords(np.asarray(point_coords), original_size), dtype=torch.float32)[None]
+        labels = torch.as_tensor(np.asarray(point_labels), dtype=torch.int)[None]
+    if box is not None:
+        boxes = torch.as_tensor(apply_boxes(np.asarray(box), original_size), dtype=torch.float32)[None]
+    if mask_input is not None:
+        masks_in = torch.as_tensor(np.asarray(mask_input), dtype=torch.float32)[None]
+    masks, iou, low = predict_torch(sd, features, input_size, original_size, coords, labels, boxes, masks_in,
+                                    multimask_output=multimask_output, return_logits=return_logits, precision=precision)
+    return masks[0].numpy(), iou[0].numpy(), low[0].numpy()
