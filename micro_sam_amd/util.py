@@ -7,7 +7,6 @@ raises ``NotImplementedError`` naming the missing piece instead of silently diff
 from __future__ import annotations
 
 import os
-import pickle
 import warnings
 from collections import OrderedDict
 from typing import Any, Callable, Dict, List, Optional, Tuple, Union

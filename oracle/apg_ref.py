@@ -20,8 +20,6 @@ of ``test/test_instance_segmentation.py:20-39``, whose derived prompts must be t
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import numpy as np
 from scipy import ndimage as ndi
 
