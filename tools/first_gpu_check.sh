@@ -1,0 +1,10 @@
+#!/bin/bash
+# First GPU call of a round: the -m gpu tests that were written without GPU access at the end of round 2 (prompt generators,
+# prompt-based segmentation), then the whole -m gpu suite.  bash tools/first_gpu_check.sh   (through gpurun, ~10 min)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_prompt_generator.py tests/test_gpu_prompt_based_segmentation.py -m gpu -x -q \
+    > gpurun_out/first_new_tests.log 2>&1
+tail -15 gpurun_out/first_new_tests.log
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/first_full_suite.log 2>&1
+tail -5 gpurun_out/first_full_suite.log
