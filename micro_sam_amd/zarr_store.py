@@ -10,9 +10,15 @@ the v2 layout), which is the contract between a precompute box and an annotation
 Only the subset of the zarr API that micro_sam touches is provided: ``open(path, mode)``, ``Group.require_group /
 create_dataset / attrs / __contains__ / __getitem__``, ``Array.shape / chunks / dtype / ndim / attrs`` and basic
 indexing (ints and unit-step slices).  Chunks are written uncompressed by default (fp32 embeddings do not compress and
-the writer has to keep up with > 100 tiles/s); ``compressor="zlib"`` is available.  Reading supports the stdlib codecs
-(``zlib``, ``gzip``, ``bz2``, ``lzma``); a container compressed with blosc / zstd (zarr-python's defaults) raises
-``RuntimeError`` naming the codec.
+the writer has to keep up with > 100 tiles/s); ``compressor="zlib"`` is available.
+
+Reading also covers what the reference itself leaves on disk (it creates its datasets with zarr's defaults,
+``micro_sam/util.py:685-707``): v2 containers whose chunks are Blosc frames (zarr-python 2's default: LZ4 + byte shuffle) or
+``zstd`` / ``lz4`` / stdlib-codec streams (``zarr_codecs``), and - read-only - the zarr **v3** layout zarr-python 3 writes
+by default (``zarr.json`` per node with the attributes inside, chunk files under ``c/``, codec pipeline ``bytes`` +
+``zstd`` / ``gzip`` / ``blosc``; sharding and transposing codecs raise).  Both decoders are restated from the format
+specifications; neither zarr nor numcodecs is in this image to produce reference files (parity unpinned, see
+``zarr_codecs``).
 """
 from __future__ import annotations
 
@@ -98,7 +104,8 @@ class Attributes:
         self.update({key: value})
 
 
-def _decode(raw: bytes, compressor: Optional[Dict[str, Any]]) -> bytes:
+def _decode(raw: bytes, compressor: Optional[Dict[str, Any]], nbytes: Optional[int] = None) -> bytes:
+    """Chunk file -> chunk bytes for a numcodecs compressor config (v2 ``.zarray`` "compressor")."""
     if compressor is None:
         return raw
     cid = compressor.get("id")
@@ -114,9 +121,21 @@ def _decode(raw: bytes, compressor: Optional[Dict[str, Any]]) -> bytes:
     if cid == "lzma":
         import lzma
         return lzma.decompress(raw)
-    raise RuntimeError(f"micro_sam_amd.zarr_store: chunks compressed with '{cid}' cannot be read here (only the stdlib "
-                       "codecs zlib / gzip / bz2 / lzma and uncompressed chunks are supported); recompute the embeddings "
-                       "or re-save them with one of these codecs")
+    if cid == "blosc":
+        from .zarr_codecs import blosc_decompress
+        return blosc_decompress(raw)
+    if cid == "zstd":
+        from .zarr_codecs import zstd_decompress
+        if nbytes is None:
+            raise RuntimeError("micro_sam_amd.zarr_store: zstd chunks need the chunk size")
+        return zstd_decompress(raw, nbytes)
+    if cid == "lz4":                                    # numcodecs.LZ4: little-endian uint32 size + one LZ4 block
+        import struct
+        from .zarr_codecs import lz4_block_decompress
+        return lz4_block_decompress(raw[4:], struct.unpack_from("<I", raw, 0)[0])
+    raise RuntimeError(f"micro_sam_amd.zarr_store: chunks compressed with '{cid}' cannot be read here (supported: blosc with "
+                       "lz4 / zlib / zstd, zstd, lz4, zlib, gzip, bz2, lzma and uncompressed chunks); recompute the "
+                       "embeddings or re-save them with one of these codecs")
 
 
 def _encode(raw: bytes, compressor: Optional[Dict[str, Any]]) -> bytes:
@@ -225,7 +244,7 @@ class Array:
                 raw = fh.read()
         except FileNotFoundError:
             return None
-        buf = _decode(raw, self._compressor)
+        buf = _decode(raw, self._compressor, int(np.prod(self.chunks)) * self.dtype.itemsize)
         return np.frombuffer(buf, dtype=self.dtype).reshape(self.chunks)
 
     def __getitem__(self, key) -> np.ndarray:
@@ -339,6 +358,145 @@ class Group:
     create_array = create_dataset
 
 
+# ------------------------------------------------------------------------------------------ zarr v3, read-only
+
+class StaticAttributes(dict):
+    """Attributes of a v3 node (they live inside ``zarr.json``); read-only here."""
+
+    def asdict(self) -> Dict[str, Any]:
+        return dict(self)
+
+    def update(self, *args, **kwargs) -> None:      # noqa: D102
+        raise PermissionError("zarr v3 containers are read-only in micro_sam_amd.zarr_store")
+
+    __setitem__ = update
+
+
+_V3_DTYPES = {"bool": "?", "int8": "i1", "int16": "i2", "int32": "i4", "int64": "i8", "uint8": "u1", "uint16": "u2",
+              "uint32": "u4", "uint64": "u8", "float16": "f2", "float32": "f4", "float64": "f8", "complex64": "c8",
+              "complex128": "c16"}
+
+
+def _read_node_v3(path: str) -> Dict[str, Any]:
+    with io.open(os.path.join(path, "zarr.json"), "r") as fh:
+        meta = json.load(fh)
+    if meta.get("zarr_format") != 3:
+        raise RuntimeError(f"{path}: unsupported zarr_format {meta.get('zarr_format')}")
+    return meta
+
+
+class ArrayV3(Array):
+    """One zarr v3 array (regular chunk grid; codecs ``bytes`` followed by any of ``zstd`` / ``gzip`` / ``blosc`` /
+    ``crc32c``), read-only.  Indexing is inherited from the v2 array."""
+
+    def __init__(self, path: str) -> None:    # noqa: D107 - does not call the v2 constructor on purpose
+        self._path, self._read_only = path, True
+        meta = _read_node_v3(path)
+        if meta.get("node_type") != "array":
+            raise RuntimeError(f"{path} is not an array")
+        grid = meta["chunk_grid"]
+        if grid.get("name") != "regular":
+            raise RuntimeError(f"{path}: chunk grid '{grid.get('name')}' is not supported")
+        self.shape = tuple(int(v) for v in meta["shape"])
+        self.chunks = tuple(int(v) for v in grid["configuration"]["chunk_shape"])
+        dt = meta["data_type"]
+        if not isinstance(dt, str) or dt not in _V3_DTYPES:
+            raise RuntimeError(f"{path}: data type {dt!r} is not supported")
+        endian, self._byte_codecs = "<", []
+        for codec in meta.get("codecs", []):
+            name, conf = codec.get("name"), codec.get("configuration") or {}
+            if name == "bytes":
+                endian = ">" if conf.get("endian", "little") == "big" else "<"
+            elif name in ("zstd", "gzip", "blosc", "crc32c"):
+                self._byte_codecs.append((name, conf))
+            else:
+                raise RuntimeError(f"{path}: codec '{name}' is not supported (bytes, zstd, gzip, blosc, crc32c are)")
+        self.dtype = np.dtype(endian + _V3_DTYPES[dt])
+        fv = meta.get("fill_value", 0)
+        self._fill = 0 if fv is None else (float(fv.replace("Infinity", "inf")) if isinstance(fv, str) else fv)
+        enc = meta.get("chunk_key_encoding") or {"name": "default"}
+        conf = enc.get("configuration") or {}
+        self._v2_keys = enc.get("name") == "v2"
+        self._sep = conf.get("separator", "." if self._v2_keys else "/")
+        self._compressor = None
+        self.attrs = StaticAttributes(meta.get("attributes") or {})
+
+    def _chunk_path(self, cidx: Sequence[int]) -> str:
+        parts = [str(c) for c in cidx]
+        if self._v2_keys:
+            return os.path.join(self._path, *(parts if self._sep == "/" else [".".join(parts)]))
+        return os.path.join(self._path, *(["c"] + parts if self._sep == "/" else [self._sep.join(["c"] + parts)]))
+
+    def _read_chunk(self, cidx) -> Optional[np.ndarray]:
+        try:
+            with io.open(self._chunk_path(cidx), "rb") as fh:
+                buf = fh.read()
+        except FileNotFoundError:
+            return None
+        nbytes = int(np.prod(self.chunks)) * self.dtype.itemsize
+        for name, conf in reversed(self._byte_codecs):              # decoding runs the pipeline backwards
+            if name == "crc32c":
+                buf = buf[:-4]                                       # trailing checksum (not verified)
+            elif name == "gzip":
+                import gzip
+                buf = gzip.decompress(buf)
+            elif name == "zstd":
+                from .zarr_codecs import zstd_decompress
+                buf = zstd_decompress(buf, nbytes)
+            else:
+                from .zarr_codecs import blosc_decompress
+                buf = blosc_decompress(buf)
+        return np.frombuffer(buf, dtype=self.dtype).reshape(self.chunks)
+
+    def __setitem__(self, key, value) -> None:
+        raise PermissionError("zarr v3 containers are read-only in micro_sam_amd.zarr_store")
+
+
+class GroupV3:
+    """A zarr v3 group, read-only: what ``precompute_image_embeddings`` needs to LOAD a cache that zarr-python 3 wrote."""
+
+    def __init__(self, path: str) -> None:
+        self._path = path
+        meta = _read_node_v3(path)
+        if meta.get("node_type") != "group":
+            raise RuntimeError(f"{path} is not a group")
+        self.attrs = StaticAttributes(meta.get("attributes") or {})
+
+    @property
+    def path(self) -> str:
+        return self._path
+
+    def __contains__(self, name: object) -> bool:
+        return os.path.exists(os.path.join(self._path, str(name), "zarr.json"))
+
+    def __getitem__(self, name: str):
+        p = os.path.join(self._path, str(name))
+        if name not in self:
+            raise KeyError(name)
+        return ArrayV3(p) if _read_node_v3(p).get("node_type") == "array" else GroupV3(p)
+
+    def keys(self):
+        return sorted(n for n in os.listdir(self._path) if n in self)
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self) -> int:
+        return len(self.keys())
+
+    def require_group(self, name: str) -> "GroupV3":
+        if name in self:
+            return self[name]
+        raise PermissionError("zarr v3 containers are read-only in micro_sam_amd.zarr_store (the cache is incomplete: "
+                              "recompute it into a new save_path)")
+
+    def create_dataset(self, *args, **kwargs):
+        raise PermissionError("zarr v3 containers are read-only in micro_sam_amd.zarr_store (the cache is incomplete: "
+                              "recompute it into a new save_path)")
+
+    create_array = create_dataset
+
+
 def _init_group(path: str) -> None:
     os.makedirs(path, exist_ok=True)
     _atomic_write(os.path.join(path, ".zgroup"), json.dumps({"zarr_format": 2}, indent=4).encode())
@@ -350,7 +508,9 @@ def open(path, mode: str = "a") -> Group:   # noqa: A001 - mirrors zarr.open
     if mode not in ("r", "a", "w"):
         raise ValueError(f"unsupported mode {mode!r}")
     if os.path.exists(os.path.join(path, "zarr.json")):
-        raise RuntimeError(f"{path} is a zarr v3 container; micro_sam_amd.zarr_store reads and writes the v2 layout only")
+        if mode == "w":
+            raise RuntimeError(f"{path} is a zarr v3 container; micro_sam_amd.zarr_store writes the v2 layout only")
+        return GroupV3(path)                        # read-only, whatever the mode: a complete cache is only read
     exists = os.path.exists(os.path.join(path, ".zgroup"))
     if mode == "r":
         if not exists:
