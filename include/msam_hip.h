@@ -270,7 +270,7 @@ int msam_amg_generate_labels(const float* iou, const float* stability, const int
 
 /* ---- fine-tuning (micro_sam/training/sam_trainer.py:131-425, trainable_sam.py:12-114): backward
  * kernels of the mask decoder's non-GEMM pieces (the GEMMs run msam_gemm_bf16 in both directions: dX = dY W, dW = dY^T X).
- * msam_layernorm_backward: x, dy, dx fp32 [rows, dim] (dim 64 / 128 / 256), dweight / dbias fp32 [dim] ACCUMULATED
+ * msam_layernorm_backward: x, dy, dx fp32 [rows, dim] (dim 64 / 128 / 256; 768 / 1024 / 1280 for the encoder), dweight / dbias fp32 [dim] ACCUMULATED
  *   (zero them first).
  * msam_attention_forward / backward: softmax(scale q k^T) v for q fp32 [BH, Nq, D], k / v fp32 [BH, Nk, D], D = 16 or 32;
  *   lse fp32 [BH, Nq] (log-sum-exp of the scaled scores, saved for the backward pass), delta: workspace fp32 [BH, Nq]. */
@@ -281,6 +281,23 @@ int msam_attention_forward(const float* q, const float* k, const float* v, int32
 int msam_attention_backward(const float* q, const float* k, const float* v, const float* out, const float* dout,
                             const float* lse, int32_t BH, int32_t Nq, int32_t Nk, int32_t D, float scale, float* dq, float* dk,
                             float* dv, float* delta, void* stream);
+
+/* Attention of the image encoder with its decomposed relative position bias, forward + backward, for un-frozen fine-tuning
+ * (segment_anything/modeling/image_encoder.py Attention + add_decomposed_rel_pos; reference training entry
+ * micro_sam/training/trainable_sam.py:71-81 image_embeddings_oft): queries = keys = the tokens of ONE Gh x Gw grid (a 14 x 14
+ * window or the 64 x 64 image; Gw <= 64), key j = (kh, kw) = (j / Gw, j % Gw),
+ *   s_ij = scale q_i k_j + bias_h[i][kh] + bias_w[i][kw],  out = softmax_j(s) v.
+ * q / k / v / out / dout / dq / dk / dv fp32 [BH, Gh*Gw, D] (D = 64 or 80), bias_h / dbias_h fp32 [BH, Gh*Gw, Gh],
+ * bias_w / dbias_w fp32 [BH, Gh*Gw, Gw] (the caller forms the biases from the unscaled queries and the rel-pos tables and
+ * propagates their gradients), lse / delta fp32 [BH, Gh*Gw] (delta: workspace).  msam_layernorm_backward additionally
+ * takes the encoder widths 768 / 1024 / 1280. */
+int msam_relpos_attention_forward(const float* q, const float* k, const float* v, const float* bias_h, const float* bias_w,
+                                  int32_t BH, int32_t Gh, int32_t Gw, int32_t D, float scale, float* out, float* lse,
+                                  void* stream);
+int msam_relpos_attention_backward(const float* q, const float* k, const float* v, const float* bias_h, const float* bias_w,
+                                   const float* out, const float* dout, const float* lse, int32_t BH, int32_t Gh, int32_t Gw,
+                                   int32_t D, float scale, float* dq, float* dk, float* dv, float* dbias_h, float* dbias_w,
+                                   float* delta, void* stream);
 
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
  * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.

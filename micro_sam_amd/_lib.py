@@ -120,6 +120,9 @@ _PROTOS = {
     "msam_layernorm_backward": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "msam_attention_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
     "msam_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "msam_relpos_attention_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp]),
+    "msam_relpos_attention_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp,
+                                              _vp, _vp, _vp, _vp]),
     "msam_amg_generate_workspace_bytes": (_i64, [_i32, _i32, _i32]),
     "msam_amg_generate_labels": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, C.POINTER(_i32), _f32, _f32, _f32, _i32, _i32,
                                         _vp, _vp, _vp, _i64, _vp]),

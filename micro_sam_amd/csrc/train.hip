@@ -139,6 +139,128 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(const float* __restric
     for (int d = 0; d < D; ++d) { dk[ro + d] = ak[d] * scale; dv[ro + d] = av[d]; }
 }
 
+// ---- attention of the image encoder with its decomposed relative position bias, for fine-tuning the encoder (upstream
+// segment_anything/modeling/image_encoder.py add_decomposed_rel_pos; oracle/sam_ref.py _attention_relpos): queries and keys
+// are the tokens of ONE Gh x Gw grid (a 14 x 14 window or the 64 x 64 image), key j = (kh, kw) = (j / Gw, j % Gw),
+//   s_ij = scale q_i k_j + bias_h[i][kh] + bias_w[i][kw],   P = softmax_j(s),   O = P V.
+// bias_h [BH, N, Gh] / bias_w [BH, N, Gw] are the products of the (unscaled) queries with the interpolated rel-pos tables,
+// computed by the caller (their gradients flow back to q and to the tables through that product).  Same one-thread-per-row
+// fp32 form as the decoder's kernels above; head dim 64 (vit_b / vit_l) or 80 (vit_h).
+template <int D>
+__global__ __launch_bounds__(128) void relpos_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                         const float* __restrict__ v, const float* __restrict__ bias_h,
+                                                         const float* __restrict__ bias_w, int Gh, int Gw, float scale,
+                                                         float* __restrict__ out, float* __restrict__ lse) {
+    const int N = Gh * Gw;
+    const int bh = blockIdx.y, i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= N) return;
+    const long row = (long)bh * N + i;
+    float qv[D], acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = q[row * D + d] * scale; acc[d] = 0.f; }
+    const float* kb = k + (long)bh * N * D;
+    const float* vb = v + (long)bh * N * D;
+    const float* bhp = bias_h + row * Gh;
+    const float* bwp = bias_w + row * Gw;
+    float m = -3.0e38f, l = 0.f;
+    for (int kh = 0; kh < Gh; ++kh) {
+        const float bh_ = bhp[kh];
+        for (int kw = 0; kw < Gw; ++kw) {
+            const long j = (long)kh * Gw + kw;
+            float s = bh_ + bwp[kw];
+#pragma unroll
+            for (int d = 0; d < D; ++d) s = fmaf(qv[d], kb[j * D + d], s);
+            const float mn = fmaxf(m, s), a = __expf(m - mn), p = __expf(s - mn);
+            l = l * a + p;
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(p, vb[j * D + d], acc[d] * a);
+            m = mn;
+        }
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[row * D + d] = acc[d] * inv;
+    lse[row] = m + __logf(l);
+}
+
+// delta_i = sum_d dO_i O_i;  dS_ij = P_ij (dO_i V_j - delta_i);  dQ_i = scale sum_j dS_ij K_j;
+// dbias_h[i][kh] = sum_kw dS_i(kh,kw);  dbias_w[i][kw] = sum_kh dS_i(kh,kw)  (the per-thread column of an LDS array)
+template <int D>
+__global__ __launch_bounds__(128) void relpos_bwd_q_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const float* __restrict__ bias_h,
+                                                           const float* __restrict__ bias_w, const float* __restrict__ out,
+                                                           const float* __restrict__ dout, const float* __restrict__ lse, int Gh,
+                                                           int Gw, float scale, float* __restrict__ dq, float* __restrict__ dbias_h,
+                                                           float* __restrict__ dbias_w, float* __restrict__ delta) {
+    __shared__ float sdbw[64 * 128];                           // [kw][thread]
+    const int N = Gh * Gw;
+    const int bh = blockIdx.y, i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= N) return;
+    const long row = (long)bh * N + i;
+    float qv[D], dov[D], acc[D], dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        qv[d] = q[row * D + d] * scale; dov[d] = dout[row * D + d]; dl = fmaf(dov[d], out[row * D + d], dl); acc[d] = 0.f;
+    }
+    for (int kw = 0; kw < Gw; ++kw) sdbw[kw * 128 + threadIdx.x] = 0.f;
+    const float L = lse[row];
+    const float* kb = k + (long)bh * N * D;
+    const float* vb = v + (long)bh * N * D;
+    const float* bhp = bias_h + row * Gh;
+    const float* bwp = bias_w + row * Gw;
+    for (int kh = 0; kh < Gh; ++kh) {
+        const float bh_ = bhp[kh];
+        float dbh = 0.f;
+        for (int kw = 0; kw < Gw; ++kw) {
+            const long j = (long)kh * Gw + kw;
+            float s = bh_ + bwp[kw], dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) { s = fmaf(qv[d], kb[j * D + d], s); dp = fmaf(dov[d], vb[j * D + d], dp); }
+            const float ds = __expf(s - L) * (dp - dl);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(ds, kb[j * D + d], acc[d]);
+            dbh += ds;
+            sdbw[kw * 128 + threadIdx.x] += ds;
+        }
+        dbias_h[row * Gh + kh] = dbh;
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) dq[row * D + d] = acc[d] * scale;
+    for (int kw = 0; kw < Gw; ++kw) dbias_w[row * Gw + kw] = sdbw[kw * 128 + threadIdx.x];
+    delta[row] = dl;
+}
+
+// dV_j = sum_i P_ij dO_i;  dK_j = scale sum_i dS_ij Q_i
+template <int D>
+__global__ __launch_bounds__(128) void relpos_bwd_kv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                            const float* __restrict__ v, const float* __restrict__ bias_h,
+                                                            const float* __restrict__ bias_w, const float* __restrict__ dout,
+                                                            const float* __restrict__ lse, const float* __restrict__ delta, int Gh,
+                                                            int Gw, float scale, float* __restrict__ dk, float* __restrict__ dv) {
+    const int N = Gh * Gw;
+    const int bh = blockIdx.y, j = blockIdx.x * 128 + threadIdx.x;
+    if (j >= N) return;
+    const int kh = j / Gw, kw = j - kh * Gw;
+    const long ro = ((long)bh * N + j) * D;
+    float kv[D], vv[D], ak[D], av[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { kv[d] = k[ro + d]; vv[d] = v[ro + d]; ak[d] = 0.f; av[d] = 0.f; }
+    const float* qb = q + (long)bh * N * D;
+    const float* dob = dout + (long)bh * N * D;
+    for (int i = 0; i < N; ++i) {
+        const long row = (long)bh * N + i;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s = fmaf(qb[(long)i * D + d], kv[d], s); dp = fmaf(dob[(long)i * D + d], vv[d], dp); }
+        const float p = __expf(s * scale + bias_h[row * Gh + kh] + bias_w[row * Gw + kw] - lse[row]);
+        const float ds = p * (dp - delta[row]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { ak[d] = fmaf(ds, qb[(long)i * D + d], ak[d]); av[d] = fmaf(p, dob[(long)i * D + d], av[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) { dk[ro + d] = ak[d] * scale; dv[ro + d] = av[d]; }
+}
+
 }  // namespace
 
 extern "C" int msam_layernorm_backward(const float* x, const float* weight, const float* dy, float eps, int64_t rows, int32_t dim,
@@ -149,7 +271,11 @@ extern "C" int msam_layernorm_backward(const float* x, const float* weight, cons
     if (dim == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
     else if (dim == 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
     else if (dim == 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
-    else { msam_set_error("msam_layernorm_backward: dim must be 64, 128 or 256"); return 1; }
+    // the image encoder's widths (vit_b / vit_l / vit_h), for un-frozen fine-tuning
+    else if (dim == 768) hipLaunchKernelGGL(layernorm_bwd_kernel<12>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    else if (dim == 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    else if (dim == 1280) hipLaunchKernelGGL(layernorm_bwd_kernel<20>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    else { msam_set_error("msam_layernorm_backward: dim must be 64, 128, 256, 768, 1024 or 1280"); return 1; }
     return msam_check_launch("msam_layernorm_backward");
 }
 
@@ -181,4 +307,44 @@ extern "C" int msam_attention_backward(const float* q, const float* k, const flo
         hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, gk, dim3(128), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv);
     } else { msam_set_error("msam_attention_backward: head dim must be 16 or 32"); return 1; }
     return msam_check_launch("msam_attention_backward");
+}
+
+extern "C" int msam_relpos_attention_forward(const float* q, const float* k, const float* v, const float* bias_h,
+                                             const float* bias_w, int32_t BH, int32_t Gh, int32_t Gw, int32_t D, float scale,
+                                             float* out, float* lse, void* stream) {
+    if (!q || !k || !v || !bias_h || !bias_w || !out || !lse || BH <= 0 || Gh <= 0 || Gw <= 0 || Gw > 64) {
+        msam_set_error("msam_relpos_attention_forward: bad argument (grid width <= 64)");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((Gh * Gw + 127) / 128, BH);
+    if (D == 64) hipLaunchKernelGGL(relpos_fwd_kernel<64>, grid, dim3(128), 0, s, q, k, v, bias_h, bias_w, Gh, Gw, scale, out, lse);
+    else if (D == 80) hipLaunchKernelGGL(relpos_fwd_kernel<80>, grid, dim3(128), 0, s, q, k, v, bias_h, bias_w, Gh, Gw, scale, out, lse);
+    else { msam_set_error("msam_relpos_attention_forward: head dim must be 64 or 80"); return 1; }
+    return msam_check_launch("msam_relpos_attention_forward");
+}
+
+extern "C" int msam_relpos_attention_backward(const float* q, const float* k, const float* v, const float* bias_h,
+                                              const float* bias_w, const float* out, const float* dout, const float* lse,
+                                              int32_t BH, int32_t Gh, int32_t Gw, int32_t D, float scale, float* dq, float* dk,
+                                              float* dv, float* dbias_h, float* dbias_w, float* delta, void* stream) {
+    if (!q || !k || !v || !bias_h || !bias_w || !out || !dout || !lse || !dq || !dk || !dv || !dbias_h || !dbias_w || !delta ||
+        BH <= 0 || Gh <= 0 || Gw <= 0 || Gw > 64) {
+        msam_set_error("msam_relpos_attention_backward: bad argument (grid width <= 64)");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((Gh * Gw + 127) / 128, BH);
+    if (D == 64) {
+        hipLaunchKernelGGL(relpos_bwd_q_kernel<64>, grid, dim3(128), 0, s, q, k, v, bias_h, bias_w, out, dout, lse, Gh, Gw, scale, dq,
+                           dbias_h, dbias_w, delta);
+        hipLaunchKernelGGL(relpos_bwd_kv_kernel<64>, grid, dim3(128), 0, s, q, k, v, bias_h, bias_w, dout, lse, delta, Gh, Gw, scale,
+                           dk, dv);
+    } else if (D == 80) {
+        hipLaunchKernelGGL(relpos_bwd_q_kernel<80>, grid, dim3(128), 0, s, q, k, v, bias_h, bias_w, out, dout, lse, Gh, Gw, scale, dq,
+                           dbias_h, dbias_w, delta);
+        hipLaunchKernelGGL(relpos_bwd_kv_kernel<80>, grid, dim3(128), 0, s, q, k, v, bias_h, bias_w, dout, lse, delta, Gh, Gw, scale,
+                           dk, dv);
+    } else { msam_set_error("msam_relpos_attention_backward: head dim must be 64 or 80"); return 1; }
+    return msam_check_launch("msam_relpos_attention_backward");
 }

@@ -6,7 +6,9 @@ shapes and the tape, every forward / backward product runs a HIP kernel):
                   ``finetuning/specialists/training/light_microscopy/livecell_multi_gpu_finetuning.py:56-82``); parameters
                   and their gradients stay fp32;
 * ``layer_norm``  ``msam_layernorm`` / ``msam_layernorm_backward`` (fp32);
-* ``attention``   softmax(q k^T / sqrt(d)) v, ``msam_attention_forward`` / ``msam_attention_backward`` (fp32).
+* ``attention``   softmax(q k^T / sqrt(d)) v, ``msam_attention_forward`` / ``msam_attention_backward`` (fp32);
+* ``relpos_attention``  the image encoder's attention with its decomposed relative position bias on one token grid,
+                  ``msam_relpos_attention_forward`` / ``_backward`` (fp32; gradients also for the two bias tensors).
 
 There is no CPU / eager fallback: on a machine without the library these raise.
 """
@@ -100,7 +102,7 @@ class _LayerNorm(torch.autograd.Function):
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float) -> torch.Tensor:
-    """LayerNorm over the last dim (64, 128 or 256 channels)."""
+    """LayerNorm over the last dim (64, 128 or 256 channels; 768 / 1024 / 1280 for the image encoder)."""
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
@@ -137,3 +139,44 @@ class _Attention(torch.autograd.Function):
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """softmax(q k^T / sqrt(D)) v for q [B, H, Nq, D], k / v [B, H, Nk, D], D in (16, 32)."""
     return _Attention.apply(q, k, v)
+
+
+class _RelPosAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, bias_h, bias_w, scale):
+        # q / k / v [BH, N, D] with N = Gh * Gw tokens of one grid; bias_h [BH, N, Gh], bias_w [BH, N, Gw]
+        BH, N, D = q.shape
+        Gh, Gw = bias_h.shape[2], bias_w.shape[2]
+        if Gh * Gw != N:
+            raise ValueError(f"relpos_attention: {N} tokens are not a {Gh} x {Gw} grid")
+        qc, kc, vc = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
+        bh, bw = bias_h.float().contiguous(), bias_w.float().contiguous()
+        out = torch.empty_like(qc)
+        lse = torch.empty((BH, N), dtype=torch.float32, device=q.device)
+        _lib.check(_lib.load().msam_relpos_attention_forward(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), bh.data_ptr(), bw.data_ptr(),
+                                                             BH, Gh, Gw, D, float(scale), out.data_ptr(), lse.data_ptr(),
+                                                             _lib.stream_ptr()), "msam_relpos_attention_forward")
+        ctx.save_for_backward(qc, kc, vc, bh, bw, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qc, kc, vc, bh, bw, out, lse = ctx.saved_tensors
+        BH, N, D = qc.shape
+        Gh, Gw = bh.shape[2], bw.shape[2]
+        do = dout.float().contiguous()
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        dbh, dbw = torch.empty_like(bh), torch.empty_like(bw)
+        delta = torch.empty_like(lse)
+        _lib.check(_lib.load().msam_relpos_attention_backward(
+            qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), bh.data_ptr(), bw.data_ptr(), out.data_ptr(), do.data_ptr(), lse.data_ptr(),
+            BH, Gh, Gw, D, ctx.scale, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dbh.data_ptr(), dbw.data_ptr(), delta.data_ptr(),
+            _lib.stream_ptr()), "msam_relpos_attention_backward")
+        return dq, dk, dv, dbh, dbw, None
+
+
+def relpos_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias_h: torch.Tensor, bias_w: torch.Tensor,
+                     scale: float) -> torch.Tensor:
+    """softmax_j(scale q_i k_j + bias_h[i, j // Gw] + bias_w[i, j % Gw]) v for q / k / v [BH, Gh * Gw, D] (D = 64 or 80)."""
+    return _RelPosAttention.apply(q, k, v, bias_h, bias_w, scale)

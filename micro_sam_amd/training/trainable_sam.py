@@ -1,11 +1,14 @@
 """``TrainableSAM`` (reference ``micro_sam/training/trainable_sam.py:12-114``): the wrapper the trainer drives.
 
-Scope of this build (first slice): the MASK DECODER is trainable - its forward and backward run on the
-HIP kernels through ``training.functional`` (MFMA GEMM in both directions, LayerNorm / attention forward + backward
-kernels; elementwise glue, the 32-channel hyper-network product, the bilinear ``postprocess_masks`` and the losses are
-torch autograd ops on the device).  The image encoder and the prompt encoder are evaluated by the inference kernels
-without a tape, i.e. they are FROZEN (the reference's ``freeze=["image_encoder", "prompt_encoder"]`` setting,
-``micro_sam/training/util.py:get_trainable_sam_model``); un-freezing them needs their backward kernels (not provided).
+Scope of this build: every part of SAM can be trained.  Forward and backward of the parts whose
+parameters ``require_grad`` run on the HIP kernels through ``training.functional`` (MFMA GEMM in both directions, LayerNorm /
+attention forward + backward kernels; elementwise glue, the 32-channel hyper-network product, the bilinear
+``postprocess_masks`` and the losses are torch autograd ops on the device): ``mask_decoder_forward`` below,
+``encoders.image_encoder_forward`` and ``encoders.prompt_encoder_forward``.  Parts that are frozen (the reference's
+``freeze=[...]`` of ``micro_sam/training/util.py:get_trainable_sam_model``) are evaluated by the inference kernels without a
+tape.  The mask decoder path is measured against the fp32 oracle; the encoder paths were written after
+round 2's GPU minutes were spent and have their first GPU run pending (their composition is checked on the CPU against the
+oracle's autograd, tests/test_training_encoders_host.py).
 """
 from __future__ import annotations
 
@@ -18,6 +21,7 @@ from torch import nn
 from ..modeling import GRID, IMG_SIZE, PROMPT_DIM, Sam
 from ..transforms import ResizeLongestSide
 from . import functional as HF
+from .encoders import image_encoder_forward, prompt_encoder_forward
 
 
 def _dec_attention(mod, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
@@ -112,6 +116,7 @@ class TrainableSAM(nn.Module):
         self.sam = sam
         self.transform = ResizeLongestSide(sam.image_encoder.img_size)
         self._weights_dirty = False          # parameters changed since the inference kernels' 16-bit copies were made
+        self._encoder_dirty = False
 
     def preprocess(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
         x = self.transform.apply_image_torch(x)
@@ -121,18 +126,30 @@ class TrainableSAM(nn.Module):
         x = F.pad(x, (0, self.sam.image_encoder.img_size - w, 0, self.sam.image_encoder.img_size - h))
         return x, input_size
 
+    def _trains(self, module: nn.Module) -> bool:
+        return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
     def image_embeddings_oft(self, batched_inputs):
         input_images, input_size = self.preprocess(
             torch.stack([x["image"] for x in batched_inputs], dim=0).to(self.sam.device, non_blocking=True).float())
         for i in range(len(batched_inputs)):
             batched_inputs[i]["input_size"] = input_size
-        image_embeddings = self.sam.image_encoder(input_images)          # HIP encoder, no tape: frozen in this build
+        if self._trains(self.sam.image_encoder):
+            self._encoder_dirty = True
+            image_embeddings = image_encoder_forward(self.sam.image_encoder, input_images)      # with a tape
+        else:
+            if self._encoder_dirty:              # an optimizer step may have changed the encoder: rebuild its operand copies
+                self.sam.image_encoder.invalidate()
+                self._encoder_dirty = False
+            image_embeddings = self.sam.image_encoder(input_images)       # inference kernels, no tape
         return image_embeddings, batched_inputs
 
     def forward(self, batched_inputs: List[Dict[str, Any]], image_embeddings: torch.Tensor,
                 multimask_output: bool = False) -> List[Dict[str, Any]]:
         dev = self.sam.device
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.sam.mask_decoder.parameters())
+        train_prompt = self._trains(self.sam.prompt_encoder)
+        # the decoder needs a tape when it trains itself or when a gradient has to pass through it to the encoders
+        train = self._trains(self.sam.mask_decoder) or train_prompt or (torch.is_grad_enabled() and image_embeddings.requires_grad)
         outputs = []
         for image_record, curr_embedding in zip(batched_inputs, image_embeddings):
             points = None
@@ -140,7 +157,11 @@ class TrainableSAM(nn.Module):
                 points = (image_record["point_coords"].to(dev, non_blocking=True), image_record["point_labels"].to(dev, non_blocking=True))
             boxes = image_record["boxes"].to(dev, non_blocking=True) if "boxes" in image_record else None
             masks = image_record["mask_inputs"].to(dev, non_blocking=True) if "mask_inputs" in image_record else None
-            sparse, dense = self.sam.prompt_encoder(points=points, boxes=boxes, masks=masks)
+            if train_prompt:
+                self._weights_dirty = True
+                sparse, dense = prompt_encoder_forward(self.sam.prompt_encoder, points, boxes, masks)
+            else:
+                sparse, dense = self.sam.prompt_encoder(points=points, boxes=boxes, masks=masks)
             if train:
                 self._weights_dirty = True
                 low_res_masks, iou_predictions = mask_decoder_forward(
