@@ -5,9 +5,10 @@
 ``w_b_linear_q``, ...), so LoRA checkpoints of micro_sam ``load_state_dict`` unchanged.  At inference a low-rank update is
 a weight update - ``qkv(x) + B A x == (W + B A) x`` - so the HIP encoder needs no extra kernel: the modules expose the MERGED
 ``weight`` / ``bias`` that ``ImageEncoderViT._prepare`` turns into its 16-bit operand copies (exact; alpha = 1 as in the
-reference).  Training the LoRA matrices needs the encoder's backward pass, which this build does not have (the encoder is
-frozen in ``training.TrainableSAM``); the other PEFT methods of the reference (FacT, SSF, AdaptFormer, selective /
-classical surgery) are not provided.
+reference).  Training keeps the low-rank branches as separate products so that A and B receive gradients
+(``training/encoders.py`` ``_qkv_projection`` / ``_mlp``: the frozen projection plus ``alpha * B(A(x))``; first GPU run
+pending, composition checked on the CPU in tests/test_training_encoders_host.py).  The other PEFT methods of the reference
+(FacT, SSF, AdaptFormer, selective / classical surgery) are not provided.
 """
 from __future__ import annotations
 

@@ -13,7 +13,7 @@ The arithmetic follows ``oracle/sam_ref.image_encoder`` / ``prompt_encoder`` in 
 ``functional.linear`` does; the reference fine-tunes under AMP bf16).
 
 First run on a GPU pending (written without GPU access at the end of round 2): the composition is checked on the CPU against the
-oracle's autograd with the three primitives replaced by torch stand-ins (tests/test_training_host.py).
+oracle's autograd with the three primitives replaced by torch stand-ins (tests/test_training_encoders_host.py).
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ from typing import Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from ..modeling import GRID, IMG_SIZE, PATCH, PROMPT_DIM, WINDOW
+from ..modeling import GRID, IMG_SIZE, PATCH, PROMPT_DIM
 from . import functional as HF
 
 
@@ -36,13 +36,41 @@ def _rel_pos_table(rel_pos: torch.Tensor, size: int) -> torch.Tensor:
     return rel_pos[(idx[:, None] - idx[None, :]) + (size - 1)]
 
 
+def _qkv_projection(attn, x: torch.Tensor) -> torch.Tensor:
+    """``attn.qkv(x)``; with LoRA surgery (``models.peft_sam.AttentionLoRA``, reference models/peft_sam.py:81-95) the frozen
+    projection plus the low-rank branches ``alpha * B(A(x))`` on the q / k / v column blocks - the branches stay separate
+    products here so that A and B receive gradients (inference merges them into the weight)."""
+    mod = attn.qkv
+    if not hasattr(mod, "qkv_proj"):
+        return HF.linear(x, mod.weight, mod.bias)
+    out = HF.linear(x, mod.qkv_proj.weight, mod.qkv_proj.bias)
+    branches = []
+    for m in ("q", "k", "v"):
+        if hasattr(mod, f"w_a_linear_{m}"):
+            low = HF.linear(x, getattr(mod, f"w_a_linear_{m}").weight, None)
+            branches.append(mod.alpha * HF.linear(low, getattr(mod, f"w_b_linear_{m}").weight, None))
+        else:
+            branches.append(torch.zeros(x.shape[:-1] + (mod.dim,), dtype=out.dtype, device=out.device))
+    return out + torch.cat(branches, dim=-1)
+
+
+def _mlp(mlp, y: torch.Tensor) -> torch.Tensor:
+    """``MLPBlock.forward``; with ``MLPLoRA`` (reference models/peft_sam.py:127-131) both layers carry a low-rank branch."""
+    if not hasattr(mlp, "mlp_layer"):
+        return HF.linear(F.gelu(HF.linear(y, mlp.lin1.weight, mlp.lin1.bias)), mlp.lin2.weight, mlp.lin2.bias)
+    base = mlp.mlp_layer
+    h = HF.linear(y, base.lin1.weight, base.lin1.bias) + HF.linear(HF.linear(y, mlp.w_a_linear_1.weight, None), mlp.w_b_linear_1.weight, None)
+    h = F.gelu(h)
+    return HF.linear(h, base.lin2.weight, base.lin2.bias) + HF.linear(HF.linear(h, mlp.w_a_linear_2.weight, None), mlp.w_b_linear_2.weight, None)
+
+
 def _attention(attn, x: torch.Tensor) -> torch.Tensor:
     """Upstream ``Attention.forward`` on a [B', S, S, C] grid (a batch of windows or of whole images)."""
     Bp, S, _, C = x.shape
     heads = attn.num_heads
     hd = C // heads
     N = S * S
-    qkv = HF.linear(x.reshape(Bp, N, C), attn.qkv.weight, attn.qkv.bias)
+    qkv = _qkv_projection(attn, x.reshape(Bp, N, C))
     q, k, v = qkv.reshape(Bp, N, 3, heads, hd).permute(2, 0, 3, 1, 4).reshape(3, Bp * heads, N, hd).unbind(0)
     r_q = q.reshape(Bp * heads, S, S, hd)                                              # unscaled queries (upstream behaviour)
     bias_h = torch.einsum("bhwc,hkc->bhwk", r_q, _rel_pos_table(attn.rel_pos_h, S)).reshape(Bp * heads, N, S)
@@ -88,8 +116,7 @@ def image_encoder_forward(enc, x: torch.Tensor) -> torch.Tensor:
             y = _attention(blk.attn, y)
         x = shortcut + y
         y = HF.layer_norm(x, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
-        y = HF.linear(F.gelu(HF.linear(y, blk.mlp.lin1.weight, blk.mlp.lin1.bias)), blk.mlp.lin2.weight, blk.mlp.lin2.bias)
-        x = x + y
+        x = x + _mlp(blk.mlp, y)
     conv1, ln1, conv3, ln2 = enc.neck[0], enc.neck[1], enc.neck[2], enc.neck[3]
     y = HF.linear(x, conv1.weight.reshape(PROMPT_DIM, D), None)                         # 1 x 1 convolution
     y = HF.layer_norm(y, ln1.weight, ln1.bias, ln1.eps)                                 # LayerNorm2d = LayerNorm over the channels

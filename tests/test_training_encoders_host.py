@@ -158,3 +158,51 @@ def test_relpos_attention_kernel_formulas_match_autograd():
     want = (out[0].detach(), q.grad[0], k.grad[0], v.grad[0], bh.grad[0], bw.grad[0])
     for a, b in zip(got, want):
         assert np.allclose(a, b.numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_lora_branches_train_and_equal_the_merged_weights(torch_primitives, monkeypatch):
+    """LoRA surgery (reference models/peft_sam.py:35-131): the taped forward keeps the low-rank branches as separate products
+    (so that A and B get gradients); its output equals the oracle on the MERGED weights W + B A, and dA / dB equal the oracle's
+    autograd through that merge."""
+    from micro_sam_amd.models.peft_sam import LoRASurgery
+    enc, sd = _small_encoder(seed=7)
+    for p in enc.parameters():
+        p.requires_grad_(False)
+    surgeries = [LoRASurgery(rank=4, block=blk, update_matrices=["q", "v", "mlp"]) for blk in enc.blocks]
+    torch.manual_seed(8)
+    lora = {}
+    for i, blk in enumerate(enc.blocks):
+        for name, mod in (("attn.qkv", blk.attn.qkv), ("mlp", blk.mlp)):
+            for pn, p in mod.named_parameters():
+                if pn.startswith("w_"):
+                    with torch.no_grad():
+                        p.copy_(torch.randn_like(p) * 0.1)
+                    lora[f"blocks.{i}.{name}.{pn}"] = p
+    assert len(lora) == 2 * (4 + 4) and all(p.requires_grad for p in lora.values())
+    # the oracle on merged weights, with the LoRA matrices as leaves
+    leaves = {k: v.detach().clone().requires_grad_() for k, v in lora.items()}
+    msd = {k: v.detach() for k, v in sd.items()}
+    for i in range(2):
+        pre, D = f"image_encoder.blocks.{i}.", 128
+        w = msd[pre + "attn.qkv.weight"].clone()
+        upd_q = leaves[f"blocks.{i}.attn.qkv.w_b_linear_q.weight"] @ leaves[f"blocks.{i}.attn.qkv.w_a_linear_q.weight"]
+        upd_v = leaves[f"blocks.{i}.attn.qkv.w_b_linear_v.weight"] @ leaves[f"blocks.{i}.attn.qkv.w_a_linear_v.weight"]
+        msd[pre + "attn.qkv.weight"] = torch.cat([w[:D] + upd_q, w[D:2 * D], w[2 * D:] + upd_v])
+        for j in (1, 2):
+            msd[pre + f"mlp.lin{j}.weight"] = msd[pre + f"mlp.lin{j}.weight"] + \
+                leaves[f"blocks.{i}.mlp.w_b_linear_{j}.weight"] @ leaves[f"blocks.{i}.mlp.w_a_linear_{j}.weight"]
+    monkeypatch.setitem(S.VIT_CONFIGS, "vit_s", {"embed_dim": 128, "depth": 2, "num_heads": 2, "global_attn_indexes": (1,)})
+    x = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(1))
+    out = E.image_encoder_forward(enc, x)
+    ref = S.image_encoder(msd, x, model_type="vit_s", precision="fp32")
+    assert (out - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+    # the inference path's merged weight is the same matrix
+    assert torch.allclose(enc.blocks[0].attn.qkv.weight, msd["image_encoder.blocks.0.attn.qkv.weight"].detach(), atol=1e-6)
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(2))
+    (out * g).sum().backward()
+    (ref * g).sum().backward()
+    for k, p in lora.items():
+        r = leaves[k].grad
+        assert p.grad is not None and (p.grad - r).abs().max().item() <= 2e-3 * r.abs().max().item() + 1e-9, k
+    assert all(p.grad is None for n, p in enc.named_parameters() if ".w_" not in n)         # the frozen weights get no gradient
+    assert len(surgeries) == 2
