@@ -1,7 +1,8 @@
-"""``ConvertToSamInputs`` (reference ``micro_sam/training/util.py:153-288``): data-loader batch -> SAM's batched inputs."""
+"""``get_trainable_sam_model`` (reference ``micro_sam/training/util.py:77-151``) and ``ConvertToSamInputs`` (``:153-288``: data-loader
+batch -> SAM's batched inputs)."""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Dict, List, Optional, Union
 
 import numpy as np
 import torch
@@ -11,6 +12,36 @@ from ..prompt_generators import PointAndBoxPromptGenerator
 
 def identity(x):
     return x
+
+
+def get_trainable_sam_model(model_type: str = "vit_b", device=None, checkpoint_path=None,
+                            freeze: Optional[Union[str, List[str]]] = None, return_state: bool = False,
+                            peft_kwargs: Optional[Dict] = None, flexible_load_checkpoint: bool = False, **model_kwargs):
+    """Reference ``get_trainable_sam_model`` (training/util.py:77-151): the SAM of ``util.get_sam_model`` (checkpoint or the
+    ``state_dict=`` extension), optional LoRA surgery of the image encoder, the parts named in ``freeze`` (``image_encoder``,
+    ``prompt_encoder``, ``mask_decoder``) set to ``requires_grad = False``, wrapped in ``TrainableSAM``.  By default nothing is
+    frozen and the whole model trains."""
+    from .. import util as msam_util
+    from ..models import peft_sam
+    from .trainable_sam import TrainableSAM
+    device = msam_util.get_device(device)
+    _, sam, state = msam_util.get_sam_model(model_type=model_type, device=device, checkpoint_path=checkpoint_path, return_sam=True,
+                                            return_state=True, flexible_load_checkpoint=flexible_load_checkpoint, **model_kwargs)
+    use_peft = bool(peft_kwargs) and isinstance(peft_kwargs, dict)
+    if use_peft:
+        if model_type[:5] == "vit_t":
+            raise ValueError("'micro-sam' does not support parameter efficient finetuning for 'mobile-sam'.")
+        sam = peft_sam.PEFT_Sam(sam, **peft_kwargs).sam
+        sam.to(device)
+    if freeze is not None:
+        freeze = freeze if isinstance(freeze, list) else [freeze]
+        if use_peft and peft_kwargs.get("rank") is not None and "image_encoder" in freeze:
+            raise ValueError("You cannot use PEFT & freeze the image encoder at the same time.")
+        for name, param in sam.named_parameters():
+            if any(name.startswith(part) for part in freeze):
+                param.requires_grad = False
+    model = TrainableSAM(sam)
+    return (model, state) if return_state else model
 
 
 def _centers_and_boxes(gt: np.ndarray):

@@ -192,3 +192,30 @@ def test_unfrozen_training_steps(dev, vit_b_sd):
     with torch.no_grad():
         after, _ = model.image_embeddings_oft([dict(rec)])
     assert (after - before).abs().max().item() > 0                           # the inference copies were rebuilt
+
+
+def test_get_trainable_sam_model_freeze_and_lora(dev, vit_b_sd):
+    """training.get_trainable_sam_model (reference micro_sam/training/util.py:77-151): `freeze`, LoRA surgery, and one taped
+    step of a LoRA model - only the low-rank matrices receive gradients (B starts at zero, so dA = 0 and dB != 0)."""
+    from micro_sam_amd.synthetic import synthetic_tile
+    from micro_sam_amd.training import get_trainable_sam_model
+    m = get_trainable_sam_model("vit_b", device=dev, state_dict=vit_b_sd, freeze=["image_encoder", "prompt_encoder"])
+    assert {n.split(".")[0] for n, p in m.sam.named_parameters() if p.requires_grad} == {"mask_decoder"}
+    m = get_trainable_sam_model("vit_b", device=dev, state_dict=vit_b_sd)
+    assert all(p.requires_grad for p in m.sam.parameters())
+    with pytest.raises(ValueError):
+        get_trainable_sam_model("vit_b", device=dev, state_dict=vit_b_sd, peft_kwargs={"rank": 4}, freeze="image_encoder")
+    m = get_trainable_sam_model("vit_b", device=dev, state_dict=vit_b_sd, peft_kwargs={"rank": 4}, freeze=["prompt_encoder", "mask_decoder"])
+    trainable = [n for n, p in m.sam.named_parameters() if p.requires_grad]
+    assert len(trainable) == 12 * 4 and all(".w_a_linear_" in n or ".w_b_linear_" in n for n in trainable)
+    img = torch.as_tensor(np.repeat(synthetic_tile(3)[None], 3, axis=0).astype(np.float32))
+    emb, _ = m.image_embeddings_oft([{"image": img, "original_size": (1024, 1024)}])
+    assert emb.requires_grad
+    emb.square().mean().backward()
+    for n, p in m.sam.named_parameters():
+        if ".w_b_linear_" in n:
+            assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().sum()) > 0, n
+        elif ".w_a_linear_" in n:
+            assert p.grad is not None and float(p.grad.abs().sum()) == 0, n
+        else:
+            assert p.grad is None, n
