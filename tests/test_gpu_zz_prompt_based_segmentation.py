@@ -6,15 +6,20 @@ oracle's ``SamPredictor.predict`` restatement (bf16-mode decoder) on the SAME pr
 are pinned by the known answers of tests/test_prompt_based_segmentation_host.py - with the tolerances of
 test_batched_inference_vs_oracle; tile selection / placement and the 3-d projection loop are checked exactly against
 manual sequences of ``predict`` calls."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-# Written after round 2's GPU minutes were spent: every kernel these tests reach is covered by other -m gpu tests, but the
-# compositions below have not run on a GPU yet.  Until their first run (tools/first_gpu_check.sh) a failure is reported as
-# xfail instead of stopping the driver's `pytest -x`; the files sort last for the same reason.  Remove the mark after that run.
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first GPU run pending (written without GPU access at the end of round 2)")]
+# Written after round 2's GPU minutes were spent: every kernel these tests reach is compiled and (except the new training
+# kernels) covered by other -m gpu tests, but the tests below have not run on a GPU yet.  Until their first run they execute only
+# inside the subprocess that tests/test_gpu_zz_pending.py starts (MSAM_RUN_PENDING=1), so that a fault in never-run code cannot
+# take the rest of the -m gpu session down with it.  Remove this guard after that run (tools/first_gpu_check.sh).
+if os.environ.get("MSAM_RUN_PENDING") != "1":
+    pytest.skip("runs in the subprocess of tests/test_gpu_zz_pending.py until its first GPU run", allow_module_level=True)
+
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")

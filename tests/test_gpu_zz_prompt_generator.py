@@ -6,15 +6,20 @@ stand-in decoder that returns the ideal foreground / distance maps of a syntheti
 generators read from it.  Checked: the derived prompts (exact vs oracle/apg_ref.py), the records of the prompt decode
 against the oracle's restated pipeline (same tolerances as test_batched_inference_vs_oracle), and every integer stage after
 it (mask NMS, merge, relabel) exactly: the oracle's apply_nms over the product's own records gives the identical image."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-# Written after round 2's GPU minutes were spent: every kernel these tests reach is covered by other -m gpu tests, but the
-# compositions below have not run on a GPU yet.  Until their first run (tools/first_gpu_check.sh) a failure is reported as
-# xfail instead of stopping the driver's `pytest -x`; the files sort last for the same reason.  Remove the mark after that run.
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first GPU run pending (written without GPU access at the end of round 2)")]
+# Written after round 2's GPU minutes were spent: every kernel these tests reach is compiled and (except the new training
+# kernels) covered by other -m gpu tests, but the tests below have not run on a GPU yet.  Until their first run they execute only
+# inside the subprocess that tests/test_gpu_zz_pending.py starts (MSAM_RUN_PENDING=1), so that a fault in never-run code cannot
+# take the rest of the -m gpu session down with it.  Remove this guard after that run (tools/first_gpu_check.sh).
+if os.environ.get("MSAM_RUN_PENDING") != "1":
+    pytest.skip("runs in the subprocess of tests/test_gpu_zz_pending.py until its first GPU run", allow_module_level=True)
+
+pytestmark = pytest.mark.gpu
 
 
 def _disk_labels(shape, n, seed, rmin=18, rmax=42, margin=60):

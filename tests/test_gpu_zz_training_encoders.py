@@ -4,15 +4,21 @@ prompt encoder (values + parameter gradients) against the fp32 oracle's autograd
 
 Tolerances as in tests/test_gpu_training.py: fp32 kernels 1e-4 relative (2e-4 for attention gradients); bf16-operand GEMM
 compositions: outputs 2 % of the output range, per-parameter gradient cosine similarity >= 0.99."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-# Written after round 2's GPU minutes were spent: first GPU run pending (tools/first_gpu_check.sh).  Until then a failure is
-# reported as xfail instead of stopping the driver's `pytest -x`; the file sorts last for the same reason.
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="first GPU run pending (written without GPU access at the end of round 2)")]
+# Written after round 2's GPU minutes were spent: every kernel these tests reach is compiled and (except the new training
+# kernels) covered by other -m gpu tests, but the tests below have not run on a GPU yet.  Until their first run they execute only
+# inside the subprocess that tests/test_gpu_zz_pending.py starts (MSAM_RUN_PENDING=1), so that a fault in never-run code cannot
+# take the rest of the -m gpu session down with it.  Remove this guard after that run (tools/first_gpu_check.sh).
+if os.environ.get("MSAM_RUN_PENDING") != "1":
+    pytest.skip("runs in the subprocess of tests/test_gpu_zz_pending.py until its first GPU run", allow_module_level=True)
+
+pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
