@@ -157,7 +157,8 @@ def test_prompt_encoder_forward_and_gradients_vs_oracle(dev, vit_b_sd):
         sparse, dense = E.prompt_encoder_forward(pe, *dargs)
         rs, rd = S.prompt_encoder(sd, *args)
         assert (sparse.cpu() - rs).abs().max().item() < 2e-4
-        assert (dense.cpu() - rd).abs().max().item() < (2e-2 if args[2] is not None else 1e-6)       # bf16 operands in the convolutions
+        # (mask prompts: the three small convolutions take bf16 operands - 2 % of the embedding's range)
+        assert (dense.cpu() - rd).abs().max().item() <= (0.02 * (rd.max() - rd.min()).item() if args[2] is not None else 1e-6)
         gs, gd = torch.randn(rs.shape, generator=g), torch.randn(rd.shape, generator=g)
         ((sparse * gs.to(dev)).sum() + (dense * gd.to(dev)).sum()).backward()
         ((rs * gs).sum() + (rd * gd).sum()).backward()
