@@ -1,0 +1,107 @@
+"""The rel-pos attention training kernels of csrc/train.hip, executed on the CPU: their threads are independent (no cross-lane
+operations, a per-thread LDS column), so the kernel SOURCE compiles as host C++ behind a few macros and runs thread by thread.
+This checks the code that will run on the GPU - indexing, online softmax, the backward formulas - against torch autograd before
+its first GPU run (tests/test_gpu_zz_training_encoders.py checks the same on the device)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "micro_sam_amd", "csrc", "train.hip")
+
+SHIM = r"""
+#include <cmath>
+#include <cstdint>
+struct idx3 { int x, y, z; };
+static idx3 threadIdx, blockIdx;
+#define __global__
+#define __launch_bounds__(n)
+#define __restrict__
+#define __shared__ static
+#define __expf expf
+#define __logf logf
+namespace {
+%s
+}
+template <int D> static void run_fwd(const float* q, const float* k, const float* v, const float* bh, const float* bw, int BH, int Gh,
+                                     int Gw, float scale, float* out, float* lse) {
+    for (int by = 0; by < BH; ++by) for (int bx = 0; bx < (Gh * Gw + 127) / 128; ++bx) for (int tx = 0; tx < 128; ++tx) {
+        blockIdx = {bx, by, 0}; threadIdx = {tx, 0, 0};
+        relpos_fwd_kernel<D>(q, k, v, bh, bw, Gh, Gw, scale, out, lse);
+    }
+}
+template <int D> static void run_bwd(const float* q, const float* k, const float* v, const float* bh, const float* bw, const float* out,
+                                     const float* dout, const float* lse, int BH, int Gh, int Gw, float scale, float* dq, float* dk,
+                                     float* dv, float* dbh, float* dbw, float* delta) {
+    for (int by = 0; by < BH; ++by) for (int bx = 0; bx < (Gh * Gw + 127) / 128; ++bx) for (int tx = 0; tx < 128; ++tx) {
+        blockIdx = {bx, by, 0}; threadIdx = {tx, 0, 0};
+        relpos_bwd_q_kernel<D>(q, k, v, bh, bw, out, dout, lse, Gh, Gw, scale, dq, dbh, dbw, delta);
+    }
+    for (int by = 0; by < BH; ++by) for (int bx = 0; bx < (Gh * Gw + 127) / 128; ++bx) for (int tx = 0; tx < 128; ++tx) {
+        blockIdx = {bx, by, 0}; threadIdx = {tx, 0, 0};
+        relpos_bwd_kv_kernel<D>(q, k, v, bh, bw, dout, lse, delta, Gh, Gw, scale, dk, dv);
+    }
+}
+extern "C" void emu_fwd(int D, const float* q, const float* k, const float* v, const float* bh, const float* bw, int BH, int Gh, int Gw,
+                        float scale, float* out, float* lse) {
+    if (D == 64) run_fwd<64>(q, k, v, bh, bw, BH, Gh, Gw, scale, out, lse); else run_fwd<80>(q, k, v, bh, bw, BH, Gh, Gw, scale, out, lse);
+}
+extern "C" void emu_bwd(int D, const float* q, const float* k, const float* v, const float* bh, const float* bw, const float* out,
+                        const float* dout, const float* lse, int BH, int Gh, int Gw, float scale, float* dq, float* dk, float* dv,
+                        float* dbh, float* dbw, float* delta) {
+    if (D == 64) run_bwd<64>(q, k, v, bh, bw, out, dout, lse, BH, Gh, Gw, scale, dq, dk, dv, dbh, dbw, delta);
+    else run_bwd<80>(q, k, v, bh, bw, out, dout, lse, BH, Gh, Gw, scale, dq, dk, dv, dbh, dbw, delta);
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    text = open(SRC).read()
+    start = text.index("template <int D>\n__global__ __launch_bounds__(128) void relpos_fwd_kernel")
+    end = text.index("}  // namespace", start)
+    kernels = text[start:end]
+    assert all(f"relpos_{n}_kernel" in kernels for n in ("fwd", "bwd_q", "bwd_kv")) and "wave_sum64" not in kernels
+    d = tmp_path_factory.mktemp("emu")
+    cpp, so = os.path.join(d, "emu.cpp"), os.path.join(d, "emu.so")
+    open(cpp, "w").write(SHIM % kernels)
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-Wno-unknown-pragmas", cpp, "-o", so])
+    return ctypes.CDLL(so)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize("BH,Gh,Gw,D", [(3, 14, 14, 64), (2, 5, 9, 64), (2, 14, 14, 80), (1, 12, 11, 64), (1, 3, 64, 64)])
+def test_relpos_kernels_source_on_the_cpu(emu, BH, Gh, Gw, D):
+    g = torch.Generator().manual_seed(BH + Gh * Gw + D)
+    N = Gh * Gw
+    q, k, v = (torch.randn(BH, N, D, generator=g) for _ in range(3))
+    bh, bw = torch.randn(BH, N, Gh, generator=g), torch.randn(BH, N, Gw, generator=g)
+    dout = torch.randn(BH, N, D, generator=g)
+    scale = D ** -0.5
+    arrs = [t.numpy().astype(np.float32).copy() for t in (q, k, v, bh, bw)]
+    out, lse = np.zeros((BH, N, D), np.float32), np.zeros((BH, N), np.float32)
+    emu.emu_fwd(D, *map(_ptr, arrs), BH, Gh, Gw, ctypes.c_float(scale), _ptr(out), _ptr(lse))
+    ref_in = [t.double().clone().requires_grad_() for t in (q, k, v, bh, bw)]
+    s = (ref_in[0] * scale) @ ref_in[1].transpose(1, 2)
+    s = (s.view(BH, N, Gh, Gw) + ref_in[3][:, :, :, None] + ref_in[4][:, :, None, :]).view(BH, N, N)
+    ref = s.softmax(dim=-1) @ ref_in[2]
+    assert np.abs(out - ref.detach().numpy()).max() <= 1e-4 * ref.abs().max().item()
+    assert np.abs(lse - torch.logsumexp(s, dim=-1).detach().numpy()).max() <= 1e-4
+    ref.backward(dout.double())
+    do = dout.numpy().astype(np.float32).copy()
+    dq, dk, dv = (np.full((BH, N, D), np.nan, np.float32) for _ in range(3))
+    dbh, dbw, delta = np.full((BH, N, Gh), np.nan, np.float32), np.full((BH, N, Gw), np.nan, np.float32), np.zeros((BH, N), np.float32)
+    emu.emu_bwd(D, *map(_ptr, arrs), _ptr(out), _ptr(do), _ptr(lse), BH, Gh, Gw, ctypes.c_float(scale), _ptr(dq), _ptr(dk), _ptr(dv),
+                _ptr(dbh), _ptr(dbw), _ptr(delta))
+    for name, got, want in zip(("dq", "dk", "dv", "dbias_h", "dbias_w"), (dq, dk, dv, dbh, dbw), ref_in):
+        w = want.grad.numpy()
+        assert np.isfinite(got).all(), name                                                # every element was written
+        assert np.abs(got - w).max() <= 2e-4 * np.abs(w).max(), name
