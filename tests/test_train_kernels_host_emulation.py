@@ -105,3 +105,99 @@ def test_relpos_kernels_source_on_the_cpu(emu, BH, Gh, Gw, D):
         w = want.grad.numpy()
         assert np.isfinite(got).all(), name                                                # every element was written
         assert np.abs(got - w).max() <= 2e-4 * np.abs(w).max(), name
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layernorm_bwd_kernel<V> at the image encoder's widths: the kernel uses wave-wide sums and one __syncthreads, so a workgroup
+# is emulated with 256 host threads (4 waves) and barriers.
+# ---------------------------------------------------------------------------------------------------------------
+
+LN_SHIM = r"""
+#include <barrier>
+#include <cmath>
+#include <mutex>
+#include <thread>
+#include <vector>
+struct idx3 { int x, y, z; };
+static thread_local idx3 threadIdx, blockIdx;
+static idx3 gridDim;
+static std::barrier<>* wave_bar[4];
+static std::barrier<>* block_bar;
+static float wave_buf[4][64];
+static std::mutex atomic_mutex;
+static float wave_sum64(float v) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    wave_buf[w][l] = v;
+    wave_bar[w]->arrive_and_wait();
+    float s = 0.f;
+    for (int i = 0; i < 64; ++i) s += wave_buf[w][i];
+    wave_bar[w]->arrive_and_wait();
+    return s;
+}
+static void atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
+#define __syncthreads() block_bar->arrive_and_wait()
+#define __global__
+#define __launch_bounds__(n)
+#define __restrict__
+#define __shared__ static
+%s
+template <int V> static void run(const float* x, const float* w, const float* dy, float eps, long rows, float* dx, float* dw, float* db,
+                                 int grid) {
+    gridDim = {grid, 1, 1};
+    for (int bx = 0; bx < grid; ++bx) {
+        std::barrier<> b0(64), b1(64), b2(64), b3(64), bb(256);
+        wave_bar[0] = &b0; wave_bar[1] = &b1; wave_bar[2] = &b2; wave_bar[3] = &b3; block_bar = &bb;
+        std::vector<std::thread> ts;
+        for (int tx = 0; tx < 256; ++tx)
+            ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, 0, 0}; layernorm_bwd_kernel<V>(x, w, dy, eps, rows, dx, dw, db); });
+        for (auto& t : ts) t.join();
+    }
+}
+extern "C" int emu_ln_bwd(int dim, const float* x, const float* w, const float* dy, float eps, long rows, float* dx, float* dw, float* db,
+                          int grid) {
+    switch (dim) {
+        case 256: run<4>(x, w, dy, eps, rows, dx, dw, db, grid); return 0;
+        case 768: run<12>(x, w, dy, eps, rows, dx, dw, db, grid); return 0;
+        case 1024: run<16>(x, w, dy, eps, rows, dx, dw, db, grid); return 0;
+        case 1280: run<20>(x, w, dy, eps, rows, dx, dw, db, grid); return 0;
+    }
+    return 1;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def emu_ln(tmp_path_factory):
+    text = open(SRC).read()
+    start = text.index("template <int V>   // V = dim / 64 values per lane")
+    end = text.index("// ---- attention, one thread per query row", start)
+    kernel = text[start:end]
+    assert "layernorm_bwd_kernel" in kernel and "wave_sum64" in kernel
+    d = tmp_path_factory.mktemp("emu_ln")
+    cpp, so = os.path.join(d, "ln.cpp"), os.path.join(d, "ln.so")
+    open(cpp, "w").write(LN_SHIM % kernel)
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-shared", "-fPIC", "-pthread", "-Wno-unknown-pragmas", cpp, "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.emu_ln_bwd.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_long,
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return lib
+
+
+@pytest.mark.parametrize("dim", [256, 768, 1024, 1280])
+def test_layernorm_backward_kernel_source_on_the_cpu(emu_ln, dim):
+    """rows = 11 on a grid of 2 workgroups: waves take rows 0..3 / 4..7 and then loop (rows 8, 9, 10), one wave idles at the end."""
+    g = torch.Generator().manual_seed(dim)
+    rows = 11
+    x = (torch.randn(rows, dim, generator=g) * 2 + 0.5).requires_grad_()
+    w = (torch.randn(dim, generator=g) * 0.2 + 1).requires_grad_()
+    b = torch.randn(dim, generator=g).requires_grad_()
+    dy = torch.randn(rows, dim, generator=g)
+    torch.nn.functional.layer_norm(x, (dim,), w, b, 1e-6).backward(dy)
+    xa, wa, dya = (t.detach().numpy().astype(np.float32).copy() for t in (x, w, dy))
+    dx = np.full((rows, dim), np.nan, np.float32)
+    dw, db = np.zeros(dim, np.float32), np.zeros(dim, np.float32)           # accumulated by the kernel (the caller zeroes them)
+    assert emu_ln.emu_ln_bwd(dim, _ptr(xa), _ptr(wa), _ptr(dya), 1e-6, rows, _ptr(dx), _ptr(dw), _ptr(db), 2) == 0
+    for name, got, want in (("dx", dx, x.grad), ("dw", dw, w.grad), ("db", db, b.grad)):
+        want = want.numpy()
+        assert np.isfinite(got).all(), name
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max(), name
