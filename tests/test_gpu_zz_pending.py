@@ -20,7 +20,7 @@ def test_pending_gpu_suite(name):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     env = dict(os.environ, MSAM_RUN_PENDING="1")
-    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, name), "-m", "gpu", "-q", "-x", "--no-header", "-rA"],
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, name), "-m", "gpu", "-q", "--no-header", "-rA"],
                          cwd=os.path.dirname(HERE), env=env, capture_output=True, text=True, timeout=1200)
     tail = "\n".join((run.stdout + "\n" + run.stderr).splitlines()[-40:])
     print(tail)
