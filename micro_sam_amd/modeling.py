@@ -37,6 +37,12 @@ def _d16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(_lib.decoder_dtype()).contiguous()
 
 
+def _versions(params) -> int:
+    """Sum of the parameters' in-place version counters: changes whenever an optimizer step, ``copy_`` or ``load_state_dict``
+    writes a parameter, so cached 16-bit operand copies are rebuilt exactly when they went stale."""
+    return sum(p._version for p in params)
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -134,7 +140,9 @@ class ImageEncoderViT(nn.Module):
 
     def _prepare(self):
         if self._prep is not None:
-            return self._prep
+            if _versions(self._prep_params) == self._prep_versions:
+                return self._prep
+            self._prep = None       # a parameter was updated in place (optimizer step, copy_): rebuild the operand copies
         dev = self.pos_embed.device
         _lib.require_gpu(dev)
         D = self.embed_dim
@@ -200,6 +208,8 @@ class ImageEncoderViT(nn.Module):
         p.use_glds = int(self.use_glds)
         p.fp8 = 1 if self.precision == "fp8" else 0
         self._prep = (p, keep)
+        self._prep_params = tuple(self.parameters())
+        self._prep_versions = _versions(self._prep_params)
         return self._prep
 
     def _get_workspace(self, params, B: int) -> torch.Tensor:
@@ -410,7 +420,10 @@ class Sam(nn.Module):
     # -- decoder plumbing
     def _prepare_decoder(self):
         if self._dec is not None:
-            return self._dec
+            if _versions(self._dec_params) == self._dec_versions:
+                return self._dec
+            self._dec = None        # a parameter was updated in place (optimizer step, copy_): rebuild the 16-bit copies / tables
+            self._img_state = None
         dev = self.device
         _lib.require_gpu(dev)
         pe, md = self.prompt_encoder, self.mask_decoder
@@ -485,6 +498,8 @@ class Sam(nn.Module):
         _lib.check(lib.msam_decoder_prepare_const(C.byref(p), consts.data_ptr(), _lib.stream_ptr()),
                    "msam_decoder_prepare_const")
         self._dec = (p, keep, consts)
+        self._dec_params = tuple(self.prompt_encoder.parameters()) + tuple(self.mask_decoder.parameters())
+        self._dec_versions = _versions(self._dec_params)
         return self._dec
 
     def _dense_pe(self) -> torch.Tensor:
@@ -496,9 +511,9 @@ class Sam(nn.Module):
         # the cache entry keeps the caller's tensor alive and is matched by identity + version: a freed embedding whose
         # address is handed to the next one can no longer alias it (SamPredictor.reset_image / set_image also drop it)
         key = (features.data_ptr(), features._version, tuple(features.shape))
+        p, _, consts = self._prepare_decoder()      # first: drops the image state too when a decoder parameter changed
         if self._img_state is not None and self._img_state[0] == key and self._img_state[3] is features:
             return self._img_state[1]
-        p, _, consts = self._prepare_decoder()
         lib = _lib.load()
         feats = features.to(device=self.device, dtype=torch.float32).reshape(PROMPT_DIM, GRID * GRID).contiguous()
         state = torch.empty(lib.msam_decoder_image_bytes(), dtype=torch.uint8, device=self.device)

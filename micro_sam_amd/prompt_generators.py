@@ -18,8 +18,10 @@ class PromptGeneratorBase:
 
 class PointAndBoxPromptGenerator(PromptGeneratorBase):
     """Reference :58-250.  One-hot object masks [N, 1, H, W] (+ boxes [y0, x0, y1, x1]) -> point / box prompts.
-    Positive points: the object's centre when given, further ones random inside the object; negative points: random in the
-    bounding box dilated by ``dilation_strength`` outside the (dilated) object."""
+    Positive points: the object's centre when ``center_coordinates`` are given (the reference's training path passes none:
+    every positive point is a random object pixel), further ones random inside the object; negative points: random in the bounding
+    box grown by ``dilation_strength`` outside the object dilated ``dilation_strength`` times with a 3 x 3 square; missing points are
+    filled with random background pixels (label 0)."""
 
     def __init__(self, n_positive_points: int, n_negative_points: int, dilation_strength: int, get_point_prompts: bool = True,
                  get_box_prompts: bool = False) -> None:
@@ -29,11 +31,17 @@ class PointAndBoxPromptGenerator(PromptGeneratorBase):
         if not self.get_point_prompts and not self.get_box_prompts:
             raise ValueError("You need to request box prompts, point prompts or both.")
 
-    def _sample(self, mask: np.ndarray, n: int) -> List[Tuple[int, int]]:
+    @staticmethod
+    def _choice(mask: np.ndarray, n: int, replace_if_short: bool) -> List[Tuple[int, int]]:
+        """n pixels of ``mask``: without replacement; when the mask has fewer than n pixels either with replacement (positive
+        points, reference :121-125) or all of them (negative points, :160-163)."""
         ys, xs = np.where(mask)
-        if len(ys) == 0 or n == 0:
+        if n <= 0 or len(ys) == 0:
             return []
-        idx = np.random.choice(len(ys), size=min(n, len(ys)), replace=False)
+        if n > len(ys) and replace_if_short:
+            idx = np.random.choice(len(ys), size=n, replace=True)
+        else:
+            idx = np.random.choice(len(ys), size=min(n, len(ys)), replace=False)
         return [(int(ys[i]), int(xs[i])) for i in idx]
 
     def __call__(self, segmentation: torch.Tensor, bbox_coordinates: List[tuple], center_coordinates: Optional[List] = None,
@@ -41,6 +49,7 @@ class PointAndBoxPromptGenerator(PromptGeneratorBase):
         from scipy import ndimage
         seg = segmentation.numpy().astype(bool)
         coords, labels, boxes = [], [], []
+        square = np.ones((3, 3), dtype=bool)      # kornia dilation with torch.ones(3, 3): Chebyshev radius d (reference :143-146)
         for i in range(seg.shape[0]):
             obj = seg[i, 0]
             y0, x0, y1, x1 = [int(v) for v in bbox_coordinates[i]]
@@ -49,23 +58,24 @@ class PointAndBoxPromptGenerator(PromptGeneratorBase):
             if not self.get_point_prompts:
                 continue
             pts, lab = [], []
-            if self.n_positive_points > 0:
-                if center_coordinates is not None:
+            if self.n_positive_points > 0:                                       # reference _sample_positive_points :105-134
+                if center_coordinates is not None and center_coordinates[i] is not None:
                     cy, cx = center_coordinates[i]
                     pts.append((int(cy), int(cx)))
-                pts += self._sample(obj, self.n_positive_points - len(pts))
+                pts += self._choice(obj, self.n_positive_points - len(pts), replace_if_short=True)
                 lab += [1] * len(pts)
-            if self.n_negative_points > 0:
+            if self.n_negative_points > 0:                                       # reference _sample_negative_points :136-171
                 d = self.dilation_strength
-                dil = ndimage.binary_dilation(obj, iterations=d) if d > 0 else obj
+                dil = ndimage.binary_dilation(obj, structure=square, iterations=d) if d > 0 else obj
                 box = np.zeros_like(obj)
-                box[max(y0 - d, 0): y1 + d, max(x0 - d, 0): x1 + d] = True
-                neg = self._sample(box & ~dil, self.n_negative_points)
+                box[max(y0 - d, 0): min(y1 + d, obj.shape[0]), max(x0 - d, 0): min(x1 + d, obj.shape[1])] = True
+                neg = self._choice(box ^ dil, self.n_negative_points, replace_if_short=False)      # |box - dilated object|
                 pts += neg
                 lab += [0] * len(neg)
-            while len(pts) < self.n_positive_points + self.n_negative_points:    # pad (reference _ensure_num_points)
-                extra = self._sample(obj, 1) or [(y0, x0)]
-                pts += extra; lab += [1]
+            short = self.n_positive_points + self.n_negative_points - len(pts)
+            if short > 0:                                                        # reference _ensure_num_points :173-190:
+                pts += self._choice(~obj, short, replace_if_short=False)         # random background pixels, label 0
+                lab += [0] * short
             coords.append([[x, y] for y, x in pts])                              # SAM expects (x, y)
             labels.append(lab)
         point_prompts = torch.tensor(coords, dtype=torch.float32) if self.get_point_prompts else None

@@ -115,8 +115,6 @@ class TrainableSAM(nn.Module):
         super().__init__()
         self.sam = sam
         self.transform = ResizeLongestSide(sam.image_encoder.img_size)
-        self._weights_dirty = False          # parameters changed since the inference kernels' 16-bit copies were made
-        self._encoder_dirty = False
 
     def preprocess(self, x: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int]]:
         x = self.transform.apply_image_torch(x)
@@ -135,12 +133,10 @@ class TrainableSAM(nn.Module):
         for i in range(len(batched_inputs)):
             batched_inputs[i]["input_size"] = input_size
         if self._trains(self.sam.image_encoder):
-            self._encoder_dirty = True
             image_embeddings = image_encoder_forward(self.sam.image_encoder, input_images)      # with a tape
         else:
-            if self._encoder_dirty:              # an optimizer step may have changed the encoder: rebuild its operand copies
-                self.sam.image_encoder.invalidate()
-                self._encoder_dirty = False
+            # (the inference kernels' operand copies rebuild themselves when a parameter's version counter moved:
+            # modeling.ImageEncoderViT._prepare / Sam._prepare_decoder)
             image_embeddings = self.sam.image_encoder(input_images)       # inference kernels, no tape
         return image_embeddings, batched_inputs
 
@@ -158,20 +154,14 @@ class TrainableSAM(nn.Module):
             boxes = image_record["boxes"].to(dev, non_blocking=True) if "boxes" in image_record else None
             masks = image_record["mask_inputs"].to(dev, non_blocking=True) if "mask_inputs" in image_record else None
             if train_prompt:
-                self._weights_dirty = True
                 sparse, dense = prompt_encoder_forward(self.sam.prompt_encoder, points, boxes, masks)
             else:
                 sparse, dense = self.sam.prompt_encoder(points=points, boxes=boxes, masks=masks)
             if train:
-                self._weights_dirty = True
                 low_res_masks, iou_predictions = mask_decoder_forward(
                     self.sam.mask_decoder, curr_embedding.unsqueeze(0), self.sam.prompt_encoder.get_dense_pe(), sparse, dense,
                     multimask_output)
             else:
-                if self._weights_dirty:          # an optimizer step may have changed the decoder: rebuild the cached copies
-                    self.sam._dec = None
-                    self.sam._img_state = None
-                    self._weights_dirty = False
                 low_res_masks, iou_predictions = self.sam.mask_decoder(
                     image_embeddings=curr_embedding.unsqueeze(0), image_pe=self.sam.prompt_encoder.get_dense_pe(),
                     sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=multimask_output)

@@ -44,17 +44,16 @@ def get_trainable_sam_model(model_type: str = "vit_b", device=None, checkpoint_p
     return (model, state) if return_state else model
 
 
-def _centers_and_boxes(gt: np.ndarray):
-    """Per id: the object pixel closest to its centre of mass and its bounding box [y0, x0, y1, x1) (the reference's
-    ``util.get_centers_and_bounding_boxes(gt, mode="p")`` picks the eccentricity centre through vigra, absent here)."""
-    centers, boxes = {}, {}
-    for i in np.unique(gt)[1:]:
-        ys, xs = np.where(gt == i)
-        cy, cx = ys.mean(), xs.mean()
-        k = int(np.argmin((ys - cy) ** 2 + (xs - cx) ** 2))
-        centers[int(i)] = (int(ys[k]), int(xs[k]))
-        boxes[int(i)] = (int(ys.min()), int(xs.min()), int(ys.max()) + 1, int(xs.max()) + 1)
-    return centers, boxes
+def _bounding_boxes(gt: np.ndarray):
+    """Per id: the bounding box [y0, x0, y1, x1) (the boxes of the reference's ``util.get_centers_and_bounding_boxes(gt, mode="p")``;
+    its centres are not used on the training path: ``_get_prompt_lists`` (training/util.py:192-216) calls the prompt generator
+    without centre coordinates, so every positive training point is a random pixel of the object)."""
+    from scipy import ndimage
+    boxes = {}
+    for i, sl in enumerate(ndimage.find_objects(gt), start=1):
+        if sl is not None:
+            boxes[i] = (int(sl[0].start), int(sl[1].start), int(sl[0].stop), int(sl[1].stop))
+    return boxes
 
 
 class ConvertToSamInputs:
@@ -80,7 +79,7 @@ class ConvertToSamInputs:
         batched_inputs, batched_ids = [], []
         for image, gt in zip(x, y):
             gt = gt.squeeze().numpy().astype(np.int64)
-            centers, boxes = _centers_and_boxes(gt)
+            boxes = _bounding_boxes(gt)
             cell_ids = np.unique(gt)[1:]
             if n_samples is not None:
                 cell_ids = np.sort(np.random.choice(cell_ids, size=min(n_samples, len(cell_ids)), replace=False))
@@ -88,7 +87,7 @@ class ConvertToSamInputs:
             if self.box_distortion_factor is not None:
                 bbox = self._distort_boxes(bbox, gt.shape[-2:])
             one_hot = torch.from_numpy(np.stack([(gt == i) for i in cell_ids])[:, None].astype(np.float32))
-            pts, lbl, bx, _ = gen(one_hot, bbox, [centers[int(i)] for i in cell_ids])
+            pts, lbl, bx, _ = gen(one_hot, bbox)
             rec = {"image": image, "original_size": image.shape[1:]}
             if get_boxes:
                 rec["boxes"] = bx if self.transform is None else self.transform.apply_boxes_torch(bx, gt.shape[-2:])

@@ -88,6 +88,15 @@ class Prec:
         # scale per output channel (linear_q)
         self.bf16 = precision in ("bf16", "fp8")
         self.fp8 = precision == "fp8"
+        # encoder rounding sites (ablation hooks, tools/enc_ablation.py): ``enc_only`` = the only encoder sites that round
+        # (None: all), ``enc_blocks`` = the only blocks whose sites round (None: all; patch embedding = -1, neck = depth),
+        # ``enc_dtype`` = site -> operand dtype or "split" (default ENCODER_DTYPE).  Sites: "patch", "qkv.x", "qkv.w",
+        # "qkvstore" (q / k / v as stored), "relpos" (tables), "probs", "proj.x", "proj.w", "lin1.x", "lin1.w", "lin2.x",
+        # "lin2.w", "neck".
+        self.enc_only = None
+        self.enc_blocks = None
+        self.enc_dtype = {}
+        self.block = -1
 
     def rounds(self, site: Optional[str]) -> bool:
         if not self.bf16:
@@ -108,8 +117,26 @@ class Prec:
             return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
         return x.to(dt).to(torch.float32)
 
-    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, site: Optional[str] = None) -> Tensor:
-        y = F.linear(self.r(x, site), self.r(w, site))
+    def re(self, x: Tensor, site: str) -> Tensor:
+        """Encoder rounding site ``site`` of the current block (``self.block``)."""
+        if not self.bf16:
+            return x
+        if self.enc_only is not None and site not in self.enc_only:
+            return x
+        if self.enc_blocks is not None and self.block not in self.enc_blocks:
+            return x
+        dt = self.enc_dtype.get(site, ENCODER_DTYPE)
+        if dt == "split":
+            hi = x.to(torch.bfloat16).to(torch.float32)
+            return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
+        return x.to(dt).to(torch.float32)
+
+    def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, site: Optional[str] = None,
+               esite: Optional[str] = None) -> Tensor:
+        if esite is not None:
+            y = F.linear(self.re(x, esite + ".x"), self.re(w, esite + ".w"))
+        else:
+            y = F.linear(self.r(x, site), self.r(w, site))
         return y if b is None else y + b
 
     def matmul(self, a: Tensor, b: Tensor) -> Tensor:
@@ -124,12 +151,12 @@ class Prec:
         q = (x * (1.0 / scale)).to(torch.float8_e4m3fn).to(torch.float32)
         return q * scale
 
-    def linear_q(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, src: str = "fp32") -> Tensor:
+    def linear_q(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, src: str = "fp32", esite: Optional[str] = None) -> Tensor:
         """One of the four large encoder projections.  fp8 mode: x is quantised per token from fp32 (LayerNorm outputs,
         src="fp32") or from its bf16 copy (attention output, MLP hidden: src="bf16"), w per output channel
         (micro_sam_amd.ops.quant_weight_fp8).  Other modes: ``linear``."""
         if not self.fp8:
-            return self.linear(x, w, b)
+            return self.linear(x, w, b, esite=esite)
         xq = self.quant_rows_e4m3(x if src == "fp32" else self.r(x))
         amax = w.abs().amax(dim=1, keepdim=True)
         ws = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
@@ -217,13 +244,13 @@ def _attention_relpos(sd: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int
     Bp, H, W, D = x.shape
     hd = D // num_heads
     scale = hd ** -0.5
-    qkv = p.linear_q(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"], src="fp32")
-    qkv = p.r(qkv)  # HIP path stores q, k, v in bf16
+    qkv = p.linear_q(x, sd[pre + "qkv.weight"], sd[pre + "qkv.bias"], src="fp32", esite="qkv")
+    qkv = p.re(qkv, "qkvstore")  # HIP path stores q, k, v in bf16
     qkv = qkv.reshape(Bp, H * W, 3, num_heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv.reshape(3, Bp * num_heads, H * W, hd).unbind(0)
     attn = (q * scale) @ k.transpose(-2, -1)
-    Rh = _get_rel_pos(H, H, p.r(sd[pre + "rel_pos_h"]))
-    Rw = _get_rel_pos(W, W, p.r(sd[pre + "rel_pos_w"]))
+    Rh = _get_rel_pos(H, H, p.re(sd[pre + "rel_pos_h"], "relpos"))
+    Rw = _get_rel_pos(W, W, p.re(sd[pre + "rel_pos_w"], "relpos"))
     r_q = q.reshape(Bp * num_heads, H, W, hd)      # NB: unscaled q (upstream behaviour)
     rel_h = torch.einsum("bhwc,hkc->bhwk", r_q, Rh)
     rel_w = torch.einsum("bhwc,wkc->bhwk", r_q, Rw)
@@ -232,11 +259,11 @@ def _attention_relpos(sd: Dict[str, Tensor], pre: str, x: Tensor, num_heads: int
         # flash-style: unnormalised probabilities rounded to bf16, fp32 row sum of the unrounded values
         m = attn.max(dim=-1, keepdim=True).values
         e = torch.exp(attn - m)
-        o = (p.r(e) @ v) / e.sum(dim=-1, keepdim=True)
+        o = (p.re(e, "probs") @ v) / e.sum(dim=-1, keepdim=True)
     else:
         o = attn.softmax(dim=-1) @ v
     o = o.view(Bp, num_heads, H, W, hd).permute(0, 2, 3, 1, 4).reshape(Bp, H, W, D)
-    return p.linear_q(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"], src="bf16")
+    return p.linear_q(o, sd[pre + "proj.weight"], sd[pre + "proj.bias"], src="bf16", esite="proj")
 
 
 def _window_partition(x: Tensor, ws: int):
@@ -274,16 +301,18 @@ def image_encoder(sd: Dict[str, Tensor], x: Tensor, model_type: str = "vit_b", p
     ``stop_after_block`` (test hook, needs ``return_blocks``): return (None, residual streams of blocks 0..stop) without
     running the rest of the network (the vit_h test checks the first blocks only: CPU time)."""
     cfg = VIT_CONFIGS[model_type[:5]]
-    p = Prec(precision)
+    p = precision if isinstance(precision, Prec) else Prec(precision)
     pre = "image_encoder."
     D, heads = cfg["embed_dim"], cfg["num_heads"]
     w = sd[pre + "patch_embed.proj.weight"]
-    x = F.conv2d(p.r(x), p.r(w), None, stride=PATCH) + sd[pre + "patch_embed.proj.bias"].view(1, -1, 1, 1)
+    p.block = -1
+    x = F.conv2d(p.re(x, "patch"), p.re(w, "patch"), None, stride=PATCH) + sd[pre + "patch_embed.proj.bias"].view(1, -1, 1, 1)
     x = x.permute(0, 2, 3, 1)                                  # NHWC [B,64,64,D]
     x = x + sd[pre + "pos_embed"]
     taps = []
     for i in range(cfg["depth"]):
         bp = f"{pre}blocks.{i}."
+        p.block = i
         shortcut = x
         y = F.layer_norm(x, (D,), sd[bp + "norm1.weight"], sd[bp + "norm1.bias"], eps=1e-6)
         if i in cfg["global_attn_indexes"]:
@@ -295,18 +324,19 @@ def image_encoder(sd: Dict[str, Tensor], x: Tensor, model_type: str = "vit_b", p
             y = _window_unpartition(y, WINDOW, pad_hw, (H, W))
         x = shortcut + y
         y = F.layer_norm(x, (D,), sd[bp + "norm2.weight"], sd[bp + "norm2.bias"], eps=1e-6)
-        y = p.linear_q(y, sd[bp + "mlp.lin1.weight"], sd[bp + "mlp.lin1.bias"], src="fp32")
+        y = p.linear_q(y, sd[bp + "mlp.lin1.weight"], sd[bp + "mlp.lin1.bias"], src="fp32", esite="lin1")
         y = F.gelu(y)                                          # exact erf GELU
-        y = p.linear_q(y, sd[bp + "mlp.lin2.weight"], sd[bp + "mlp.lin2.bias"], src="bf16")
+        y = p.linear_q(y, sd[bp + "mlp.lin2.weight"], sd[bp + "mlp.lin2.bias"], src="bf16", esite="lin2")
         x = x + y
         if return_blocks:
             taps.append(x.clone())
             if stop_after_block is not None and i == stop_after_block:
                 return None, taps
     x = x.permute(0, 3, 1, 2)                                  # NCHW
-    x = F.conv2d(p.r(x), p.r(sd[pre + "neck.0.weight"]))
+    p.block = cfg["depth"]
+    x = F.conv2d(p.re(x, "neck"), p.re(sd[pre + "neck.0.weight"], "neck"))
     x = layer_norm_2d(x, sd[pre + "neck.1.weight"], sd[pre + "neck.1.bias"])
-    x = F.conv2d(p.r(x), p.r(sd[pre + "neck.2.weight"]), padding=1)
+    x = F.conv2d(p.re(x, "neck"), p.re(sd[pre + "neck.2.weight"], "neck"), padding=1)
     x = layer_norm_2d(x, sd[pre + "neck.3.weight"], sd[pre + "neck.3.bias"])
     return (x, taps) if return_blocks else x
 

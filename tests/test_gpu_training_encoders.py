@@ -11,13 +11,6 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-# Written after round 2's GPU minutes were spent: every kernel these tests reach is compiled and (except the new training
-# kernels) covered by other -m gpu tests, but the tests below have not run on a GPU yet.  Until their first run they execute only
-# inside the subprocess that tests/test_gpu_zz_pending.py starts (MSAM_RUN_PENDING=1), so that a fault in never-run code cannot
-# take the rest of the -m gpu session down with it.  Remove this guard after that run (tools/first_gpu_check.sh).
-if os.environ.get("MSAM_RUN_PENDING") != "1":
-    pytest.skip("runs in the subprocess of tests/test_gpu_zz_pending.py until its first GPU run", allow_module_level=True)
-
 pytestmark = pytest.mark.gpu
 
 

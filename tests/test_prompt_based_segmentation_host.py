@@ -1,6 +1,6 @@
 """Host half of micro_sam_amd.prompt_based_segmentation (reference micro_sam/prompt_based_segmentation.py:30-506): prompt
 conversions, tile selection and what reaches ``SamPredictor.predict``.  Known answers derived by hand from the reference's
-formulas; the device half is in tests/test_gpu_zz_prompt_based_segmentation.py."""
+formulas; the device half is in tests/test_gpu_prompt_based_segmentation.py."""
 import warnings
 
 import numpy as np

@@ -1,6 +1,6 @@
 """Host half of the reference's AutomaticPromptGenerator (micro_sam/instance_segmentation.py:1322-1628, SURVEY.md 8(f)
 rank 1): prompt derivation from decoder maps, state handling, the factory, tile-local ``apply_nms``.  CPU only - the
-device half (``batched_inference`` on the derived prompts) is in tests/test_gpu_zz_prompt_generator.py."""
+device half (``batched_inference`` on the derived prompts) is in tests/test_gpu_prompt_generator.py."""
 import numpy as np
 import pytest
 

@@ -1,7 +1,7 @@
 """The rel-pos attention training kernels of csrc/train.hip, executed on the CPU: their threads are independent (no cross-lane
 operations, a per-thread LDS column), so the kernel SOURCE compiles as host C++ behind a few macros and runs thread by thread.
 This checks the code that will run on the GPU - indexing, online softmax, the backward formulas - against torch autograd before
-its first GPU run (tests/test_gpu_zz_training_encoders.py checks the same on the device)."""
+its first GPU run (tests/test_gpu_training_encoders.py checks the same on the device)."""
 import ctypes
 import os
 import re

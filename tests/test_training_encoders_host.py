@@ -3,7 +3,7 @@
 (functional.linear / layer_norm / relpos_attention).  Here the primitives are replaced by torch stand-ins and the COMPOSITION -
 patch gather, window partition / padding, rel-pos tables and bias einsums, head split, residuals, the neck as GEMMs, the prompt
 encoder's embeddings and patch convolutions - is checked against the oracle's fp32 functions, values and gradients, on the
-CPU.  The primitives themselves are checked on the GPU (tests/test_gpu_zz_training_encoders.py); the formulas their backward
+CPU.  The primitives themselves are checked on the GPU (tests/test_gpu_training_encoders.py); the formulas their backward
 kernels implement are checked below against autograd through a numpy transcription of the kernels' loops."""
 import numpy as np
 import pytest

@@ -56,6 +56,37 @@ def test_prompt_generators_and_convert_inputs():
     assert pred[1, 0, c[1, 1, 1], c[1, 1, 0]] == 1 and true[1, 0, c[1, 1, 1], c[1, 1, 0]] == 0
 
 
+def test_point_prompts_follow_the_reference_distribution():
+    """Reference prompt_generators.py:105-190 as called by training/util.py:192-216 (no centre coordinates): positive points are
+    random object pixels (not always the centre), negatives keep a SQUARE (Chebyshev) safety border of ``dilation_strength`` around
+    the object, and missing points are filled with label-0 background pixels."""
+    from micro_sam_amd.prompt_generators import PointAndBoxPromptGenerator
+    np.random.seed(1)
+    yy, xx = np.mgrid[:64, :64]
+    obj = (yy - 32) ** 2 + (xx - 32) ** 2 <= 64                      # disk of radius 8: its grown box has free corners
+    oy, ox = np.where(obj)
+    seg = torch.as_tensor(obj[None, None]).float()
+    gen = PointAndBoxPromptGenerator(1, 4, dilation_strength=3)
+    seen_pos, min_cheb = set(), 99
+    for _ in range(100):
+        c, l, _, _ = gen(seg, [(24, 24, 41, 41)])
+        assert l.tolist() == [[1, 0, 0, 0, 0]]
+        px, py = c[0, 0].long().tolist()
+        assert obj[py, px]
+        seen_pos.add((px, py))
+        for x, y in c[0, 1:].long().tolist():
+            assert 21 <= x < 44 and 21 <= y < 44 and not obj[y, x]
+            min_cheb = min(min_cheb, int(np.maximum(np.abs(oy - y), np.abs(ox - x)).min()))
+    assert len(seen_pos) > 50                     # random object pixels - not one fixed centre
+    assert min_cheb == 4                          # square border: no negative within Chebyshev distance 3 (a diamond would allow 2-3)
+    # no negative region left (the dilated object covers the grown box): points are filled from the background with label 0
+    big = np.zeros((16, 16), dtype=bool); big[2:14, 2:14] = True
+    c, l, _, _ = PointAndBoxPromptGenerator(1, 2, dilation_strength=1)(torch.as_tensor(big[None, None]).float(), [(2, 2, 14, 14)])
+    assert l.tolist() == [[1, 0, 0]]
+    for x, y in c[0, 1:].long().tolist():
+        assert not big[y, x]
+
+
 class _StubModel(torch.nn.Module):
     """A differentiable stand-in with TrainableSAM's interface: masks = scale * (a Gaussian bump at the first prompt point)."""
 
