@@ -131,6 +131,125 @@ def mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs):
     return out
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) of the kernel sources + the ABI header: names the code a PMC / rocprof table was measured on
+    (tools/csrc_sha.py prints the same on the GPU box; tools/summarize_profiles.py stores it in profiles/<tag>_pmc_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "micro_sam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "msam_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC table - only when that table was measured on THIS code
+    (csrc_sha16 recorded with it); a table of other code is refused (a round-1 constant was shipped in round 2's line)."""
+    sha = csrc_sha16()
+    best = None
+    try:
+        names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json"))
+    except OSError:
+        names = []
+    for name in reversed(names):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        meta = pmc.get("_meta", {})
+        for kname, rec in pmc.items():
+            if kname != "_meta" and isinstance(rec, dict) and kname.split("<")[0] in kernel_name:
+                if meta.get("csrc_sha16") == sha:
+                    return rec.get("hbm_bytes_per_launch"), f"profiles/{name} (measured on this code, csrc_sha16 {sha})"
+                best = best or (f"profiles/{name} holds a table for this kernel measured on other code "
+                                f"(csrc_sha16 {meta.get('csrc_sha16')}, this code {sha}): not reported")
+    return None, best or "no PMC table for this kernel under profiles/"
+
+
+def api_inclusive(predictor, amg, tiles_np, n_api, enc_batch):
+    """SURVEY.md 8(d) config 2 through the drop-in API itself, host arrays in and out: precompute_image_embeddings(stack, ndim=3,
+    batch_size) -> per slice AutomaticMaskGenerator.initialize(i=z) + generate() (numpy uint32 label image back on the host)."""
+    from micro_sam_amd import util
+    stack = np.stack(tiles_np[:n_api])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = util.precompute_image_embeddings(predictor, stack, ndim=3, batch_size=enc_batch, verbose=False)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_inst = 0
+    for z in range(n_api):
+        amg.initialize(stack[z], emb, i=z)
+        seg = amg.generate()
+        n_inst += int(seg.max())
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return {"value": round(n_api / (t2 - t0), 2), "unit": "tiles/s", "tiles": n_api,
+            "embed_seconds_per_tile": round((t1 - t0) / n_api, 5), "amg_seconds_per_tile": round((t2 - t1) / n_api, 5),
+            "instances_per_tile_mean": round(n_inst / n_api, 1),
+            "what": f"util.precompute_image_embeddings(stack[{n_api},1024,1024] uint8 host array, ndim=3, batch_size={enc_batch}) then per "
+                    "slice AutomaticMaskGenerator.initialize(stack[z], emb, i=z) + generate() -> numpy label image; one stream, no "
+                    "decode lanes, host synchronisation wherever the API returns host data"}
+
+
+def bench_config3(args, rank, world, dev):
+    """BASELINE configs[2], one GPU's share: vit_l, Z slices of 2048 x 2048 (the 64-slice volume sharded per slice over 8 GPUs = 8 per
+    GPU), tiled embeddings (tile 768 + halo 128: outer tiles up to 1024^2, 9 per slice) + TiledAutomaticMaskGenerator per slice with the
+    reference's running id offsets (multi_dimensional_segmentation.segment_slices; the cross-slice merge of
+    automatic_3d_segmentation is the host step after the gather).  One step = all Z slices."""
+    from micro_sam_amd import multi_dimensional_segmentation as mds
+    from micro_sam_amd import util
+    from micro_sam_amd.instance_segmentation import TiledAutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    Z = args.slices
+    vol = np.stack([synthetic_tile(3000 + rank * Z + z, (2048, 2048)) for z in range(Z)])
+    sd = synthetic_state_dict("vit_l", 0, variant=args.weights)
+    predictor = util.get_sam_model("vit_l", device=dev, state_dict=sd)
+    predictor.model.image_encoder.set_precision(args.encoder_dtype)
+
+    def step():
+        seg, _ = mds.segment_slices(vol, predictor, TiledAutomaticMaskGenerator(predictor), tile_shape=(768, 768), halo=(128, 128),
+                                    batch_size=9)
+        return seg
+    for _ in range(args.warmup):
+        seg = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        seg = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n = Z * args.steps * world
+        print(json.dumps({
+            "metric": "2048^2 slices/s tiled embed+AMG (vit_l bf16), BASELINE configs[2] per-slice path", "value": round(n / elapsed, 4),
+            "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": f"{args.encoder_dtype} image encoder, " + ("fp16" if _lib_decoder_is_f16() else "bf16") + " mask decoder",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2] share of one GPU: vit_l, {Z} slices of 2048x2048 uint8, tile_shape 768 + halo 128 "
+                                   "(9 tiles per slice), TiledAutomaticMaskGenerator defaults (32x32 grid per tile), host arrays in / "
+                                   "uint32 label volume out (multi_dimensional_segmentation.segment_slices)",
+                       "tiles_per_second": round(9 * n / elapsed, 2), "instances_in_last_volume": int(seg.max()),
+                       "weights": f"seeded synthetic checkpoint (synthetic.py variant '{args.weights}')"},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+
+
+def _lib_decoder_is_f16():
+    from micro_sam_amd import _lib
+    return _lib.decoder_dtype() == torch.float16
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks."""
     if not args.dry_run:
@@ -175,6 +294,13 @@ def main():
                     help="run generate() on the main stream (default: side stream overlapping the next tile's decode)")
     ap.add_argument("--device-chunk", type=int, default=1024,
                     help="grid prompts decoded per decoder pass (results do not depend on it)")
+    ap.add_argument("--workload", choices=("config2", "config3"), default="config2",
+                    help="config2 (default): the headline metric; config3: BASELINE configs[2] per-slice path (vit_l, tiled 2048^2 slices)")
+    ap.add_argument("--slices", type=int, default=8, help="--workload config3: slices per GPU and step")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements (pcie_inclusive, api_inclusive, rle_side, interactive_side): profiling runs, so "
+                         "that per-kernel averages hold the hot path's launches only")
+    ap.add_argument("--api-tiles", type=int, default=32, help="tiles of the api_inclusive side measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: gloo, no GPU work, prints the JSON line with n_gpus = world size")
     args = ap.parse_args()
@@ -205,14 +331,27 @@ def main():
     enc_batch = args.enc_batch
     n_distinct = max(n_tiles, (args.distinct_tiles // n_tiles) * n_tiles)
     t_gen = time.perf_counter()
-    tiles_np = make_tiles([1000 + rank * n_distinct + i for i in range(n_distinct)])
+    tiles_np = make_tiles([1000 + rank * n_distinct + i for i in range(n_distinct)]) if args.workload == "config2" else []
     log(f"rank {rank}: {n_distinct} distinct tiles generated in {time.perf_counter() - t_gen:.1f} s")
 
-    if world > 1:
+    # MSAM_FORCE_DIST=1 at N = 1: a world-size-1 "nccl" group, label tiles gathered through RCCL (smoke run of the N > 1 code path)
+    force_dist = world == 1 and os.environ.get("MSAM_FORCE_DIST") == "1"
+    if force_dist:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ["MSAM_FORCE_COLLECTIVES"] = "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "config3":
+        bench_config3(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from micro_sam_amd import _lib, parallel, util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
@@ -318,7 +457,7 @@ def main():
         if gen_stream is not None and not timed:
             torch.cuda.current_stream().wait_stream(gen_stream)          # label tiles complete before the gather
         t3 = time.perf_counter()
-        full = parallel.gather_label_tiles(labels, n_tiles * world) if world > 1 else labels
+        full = parallel.gather_label_tiles(labels, n_tiles * world) if (world > 1 or force_dist) else labels
         if timed:
             torch.cuda.synchronize(); stage["gather"] += time.perf_counter() - t3
         if not timed:
@@ -380,7 +519,7 @@ def main():
     # PCIe-inclusive pass (outside the timed region): util._to_image + H2D of the uint8 tiles + label D2H inside the clock
     torch.cuda.synchronize()
     t_p = time.perf_counter()
-    n_pcie = min(3, max(1, n_distinct // n_tiles))
+    n_pcie = 0 if args.no_side else min(3, max(1, n_distinct // n_tiles))
     for k in range(n_pcie):
         step(False, k, uploads=tiles_np[k * n_tiles:(k + 1) * n_tiles])
     torch.cuda.synchronize()
@@ -426,21 +565,10 @@ def main():
         # `traffic`: HBM bytes per launch from the PMC passes of profiles/ (FETCH_SIZE / WRITE_SIZE, separate runs), when a
         # table for this kernel is committed
         dom = dict(fams[0]) if fams else {"bound": "mfma", "achieved": 0.0, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": 0.0}
-        traffic = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as fh:
-                    pmc = json.load(fh)
-                for kname, rec in pmc.items():
-                    if isinstance(rec, dict) and kname.split("<")[0] in dom.get("kernel", ""):
-                        traffic = rec.get("hbm_bytes_per_launch")
-                if traffic is not None:
-                    break
-            except (OSError, ValueError):
-                pass
+        traffic, traffic_source = pmc_traffic(dom.get("kernel", ""))
         whole = TILE_TFLOP_ALGORITHMIC * value / world
         roof = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"], "frac": dom["frac"],
-                "traffic": traffic, **{k: v for k, v in dom.items() if k not in ("bound", "achieved", "peak", "unit", "frac")},
+                "traffic": traffic, "traffic_source": traffic_source, **{k: v for k, v in dom.items() if k not in ("bound", "achieved", "peak", "unit", "frac")},
                 "whole_path_tflops": round(whole, 2), "whole_path_frac": round(whole / PEAK_BF16_TFLOPS, 4),
                 "measured_in": ("the timed region (one decode lane: no two kernels of the hot path share the GPU)" if profile_in_timed_region
                                 else f"a serial one-lane pass of {prof_steps} steps right after the timed region "
@@ -456,7 +584,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "fp16", "fp8": "fp8 projections + bf16"}[args.encoder_dtype] + " image encoder, " +
+            "dtype": {"bf16": "bf16", "fp16": "fp16", "fp8": "fp8 projections + bf16"}[args.encoder_dtype] + " image encoder (patch embedding "
+                     "+ neck, 1.2 % of its flops, on hi+lo operand pairs of that type), " +
                      ("fp16" if _lib.decoder_dtype() == torch.float16 else "bf16") + " mask decoder (16-bit MFMA operands, fp32 accumulation)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
@@ -464,7 +593,8 @@ def main():
                        "tiles_per_step_per_gpu": n_tiles, "encoder_batch": enc_batch,
                        "distinct_tiles_per_gpu": n_distinct,
                        "weights": f"seeded synthetic checkpoint (synthetic.py variant '{args.weights}')",
-                       "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles",
+                       "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles" +
+                                      (" (MSAM_FORCE_DIST: world-size-1 nccl group, the gather runs through RCCL)" if force_dist else ""),
                        "timed_region": "uint8 RGB tiles resident in HBM -> label tiles in HBM (all-gathered when N > 1); "
                                        "util._to_image, H2D and label D2H are in pcie_inclusive, lazy RLE encoding in rle_side",
                        "decode_lanes": len(lanes), "pipelined_labels_equal_serial": labels_equal,
@@ -475,34 +605,40 @@ def main():
                        "host_enqueue_seconds_per_tile": round(stage["host_enqueue"] / (n_tiles * args.steps), 5),
                        "tile_tflop_algorithmic": TILE_TFLOP_ALGORITHMIC},
             "roofline": roof,
-            "pcie_inclusive": {"value": round(n_pcie * n_tiles / pcie_elapsed, 2), "unit": "tiles/s", "tiles": n_pcie * n_tiles,
-                               "includes": "pinned asynchronous H2D of the raw uint8 tiles (1 MiB each), util._to_image on the device "
-                                           "(msam_to_image), label D2H into pinned memory (4 MiB each)"},
         }
-        # a15 side measurement: RLE encoding of one tile's candidate masks (lazy in the product: only when rles are read)
-        amg.initialize(shape_only, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]).unsqueeze(1),
-                                    "input_size": (1024, 1024), "original_size": (1024, 1024)}, i=0)
-        from micro_sam_amd import ops
-        bits = amg.crop_list[0]["bits"]
-        ops.rle_encode(bits.contiguous(), 1024, 1024)               # first call: loads the RLE kernels' code object
-        torch.cuda.synchronize(); t_r = time.perf_counter()
-        counts, offsets = ops.rle_encode(bits.contiguous(), 1024, 1024)
-        torch.cuda.synchronize()
-        out["rle_side"] = {"masks": int(bits.shape[0]), "ms_device": round((time.perf_counter() - t_r) * 1e3, 3),
-                           "total_runs": int(offsets[-1].item()) if offsets.numel() else 0}
-        # f4 side measurement: latency of one interactive point prompt (SamPredictor.predict: numpy in, 3 masks + scores + low-res
-        # logits back on the host) on an embedding that is already set, as the napari annotator issues them
-        util.set_precomputed(predictor, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]),
-                                         "input_size": (1024, 1024), "original_size": (1024, 1024)})
-        rng = np.random.default_rng(0)
-        lat = []
-        for k in range(60):
-            pt = rng.uniform(32, 992, size=(1, 2))
-            torch.cuda.synchronize(); t_i = time.perf_counter()
-            predictor.predict(point_coords=pt, point_labels=np.ones(1), multimask_output=True)
-            lat.append((time.perf_counter() - t_i) * 1e3)
-        out["interactive_side"] = {"predict_ms_median": round(float(np.median(lat[10:])), 3), "predict_ms_p90": round(float(np.quantile(lat[10:], 0.9)), 3),
-                                   "what": "SamPredictor.predict(one point, multimask) incl. the D2H of 3 x 1024^2 masks"}
+        if not args.no_side:
+            out["pcie_inclusive"] = {"value": round(n_pcie * n_tiles / pcie_elapsed, 2), "unit": "tiles/s", "tiles": n_pcie * n_tiles,
+                                     "includes": "pinned asynchronous H2D of the raw uint8 tiles (1 MiB each), util._to_image on the "
+                                                 "device (msam_to_image), label D2H into pinned memory (4 MiB each)"}
+            try:
+                out["api_inclusive"] = api_inclusive(predictor, amg, tiles_np, min(args.api_tiles, n_distinct), enc_batch)
+            except Exception as exc:            # a side measurement must not cost the bench line
+                out["api_inclusive"] = {"error": repr(exc)}
+        if not args.no_side:
+            # a15 side measurement: RLE encoding of one tile's candidate masks (lazy in the product: only when rles are read)
+            amg.initialize(shape_only, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]).unsqueeze(1),
+                                        "input_size": (1024, 1024), "original_size": (1024, 1024)}, i=0)
+            from micro_sam_amd import ops
+            bits = amg.crop_list[0]["bits"]
+            ops.rle_encode(bits.contiguous(), 1024, 1024)               # first call: loads the RLE kernels' code object
+            torch.cuda.synchronize(); t_r = time.perf_counter()
+            counts, offsets = ops.rle_encode(bits.contiguous(), 1024, 1024)
+            torch.cuda.synchronize()
+            out["rle_side"] = {"masks": int(bits.shape[0]), "ms_device": round((time.perf_counter() - t_r) * 1e3, 3),
+                               "total_runs": int(offsets[-1].item()) if offsets.numel() else 0}
+            # f4 side measurement: latency of one interactive point prompt (SamPredictor.predict: numpy in, 3 masks + scores + low-res
+            # logits back on the host) on an embedding that is already set, as the napari annotator issues them
+            util.set_precomputed(predictor, {"features": predictor.model.image_encoder.forward_u8(tiles_u8[:1]),
+                                             "input_size": (1024, 1024), "original_size": (1024, 1024)})
+            rng = np.random.default_rng(0)
+            lat = []
+            for k in range(60):
+                pt = rng.uniform(32, 992, size=(1, 2))
+                torch.cuda.synchronize(); t_i = time.perf_counter()
+                predictor.predict(point_coords=pt, point_labels=np.ones(1), multimask_output=True)
+                lat.append((time.perf_counter() - t_i) * 1e3)
+            out["interactive_side"] = {"predict_ms_median": round(float(np.median(lat[10:])), 3), "predict_ms_p90": round(float(np.quantile(lat[10:], 0.9)), 3),
+                                       "what": "SamPredictor.predict(one point, multimask) incl. the D2H of 3 x 1024^2 masks"}
         if not args.no_cpu_baseline and world == 1:
             log(f"timing the CPU reference on {args.cpu_tiles} full tiles ...")
             n_thr = min(os.cpu_count() or 1, 32)    # more threads than this only slow the fp32 torch ops down
@@ -519,11 +655,20 @@ def main():
                     out["mask_iou_vs_ref_fp16_encoder"] = {"error": repr(exc)}
                 finally:
                     predictor.model.image_encoder.set_precision("bf16")
+                # and what the hi + lo operand pairs at the patch embedding / neck buy: the same comparison with every operand plainly bf16
+                # (the arithmetic of rounds 1 and 2)
+                try:
+                    predictor.model.image_encoder.set_split_io(False)
+                    out["mask_iou_vs_ref_plain_bf16_encoder"] = mask_iou_vs_ref(predictor, amg, ref_tiles, ref_states, ref_segs)
+                except Exception as exc:
+                    out["mask_iou_vs_ref_plain_bf16_encoder"] = {"error": repr(exc)}
+                finally:
+                    predictor.model.image_encoder.set_split_io(True)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
             out["mask_iou_vs_ref"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -322,6 +322,14 @@ int msam_patchify_u8_16(const uint8_t* img, int32_t B, int32_t h, int32_t w, int
 int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, void* stream);
 int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
 int msam_cast_f32_to_16(const float* x, int32_t dtype16, void* out16, int64_t n, void* stream);
+/* hi + lo operand pairs of the encoder's "split" sites (patch embedding, neck: msam_encoder_t.split_io): a value enters its product
+ * as hi = round16(v), lo = round16(v - hi); rows are written [hi | lo | hi] (K -> 3K; the 3 x 3 gather writes [hi | lo], K -> 2K)
+ * against weight rows [Whi | Whi | Wlo], so plain 16-bit products over the widened K form hi*Whi + lo*Whi + hi*Wlo.  Same arguments
+ * as the plain forms; out16 rows are 2304 (patchify), 3 * dim (cast) or 18 * C (im2col) elements wide. */
+int msam_patchify_split16(const float* img, int32_t B, int32_t dtype16, void* out16, void* stream);
+int msam_patchify_u8_split16(const uint8_t* img, int32_t B, int32_t h, int32_t w, int32_t dtype16, void* out16, void* stream);
+int msam_im2col3x3_split16(const float* x_f32, int32_t B, int32_t C, int32_t dtype16, void* out16, void* stream);
+int msam_cast_f32_split16(const float* x, int32_t dtype16, void* out16, int64_t rows, int32_t dim, void* stream);
 
 /* ViT attention with decomposed relative position bias (segment_anything ImageEncoderViT Attention).
  * head_dim = STORED channels per head, 64 or 96 (vit_h: true head_dim 80, zero-padded to 96 by the caller);
@@ -378,6 +386,11 @@ typedef struct {
      * q / k / v, attention output, MLP hidden): 0 or MSAM_BF16 = bfloat16 ("vit_b bf16"), MSAM_F16 = IEEE fp16 - the same kernels
      * on the fp16 MFMAs of the same rate; the caller then hands over fp16 copies of the weights.  Not together with fp8. */
     int32_t dtype16;
+    /* split_io != 0: the patch embedding and the two neck convolutions - 1.2 % of the encoder's flops, and the sites whose 8-bit
+     * operand rounding costs most of the mask parity against the fp32 reference (profiles/r03_enc_ablation.txt) - take their
+     * operands as hi + lo pairs of the 16-bit type (msam_*_split16): patch_w is then [D, 3*768] = [Whi | Whi | Wlo], neck0_w
+     * [256, 3*D] and neck2_w [256, 3*2304] likewise (columns (ky,kx,c) within each block).  Same MFMA kernels, K widened. */
+    int32_t split_io;
 } msam_encoder_t;
 
 int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32_t B);

@@ -67,7 +67,7 @@ class EncoderParams(C.Structure):
         ("use_glds", _i32), ("head_dim_stored", _i32), ("fp8", _i32),
         ("qkv_w8", _blk), ("qkv_cs", _blk), ("proj_w8", _blk), ("proj_cs", _blk),
         ("lin1_w8", _blk), ("lin1_cs", _blk), ("lin2_w8", _blk), ("lin2_cs", _blk),
-        ("dtype16", _i32),
+        ("dtype16", _i32), ("split_io", _i32),
     ]
 
 
@@ -164,6 +164,10 @@ _PROTOS = {
     "msam_patchify16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_patchify_u8_16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msam_cast_f32_to_16": (_i32, [_vp, _i32, _vp, _i64, _vp]),
+    "msam_patchify_split16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "msam_patchify_u8_split16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "msam_im2col3x3_split16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_cast_f32_split16": (_i32, [_vp, _i32, _vp, _i64, _i32, _vp]),
     "msam_encoder_workspace_bytes": (_i64, [C.POINTER(EncoderParams), _i32]),
     "msam_encoder_forward": (_i32, [C.POINTER(EncoderParams), _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i64, _vp, _i32, _vp]),
     "msam_decoder_dtype": (_i32, []),

@@ -18,21 +18,22 @@ inline long al(long x) { return (x + 255) & ~255L; }
 struct EncWork { float* x; u16 *xn, *patches, *q, *k, *v, *attn, *hid, *n1, *col; float *n0, *n2;
                  unsigned char *xn8, *attn8, *hid8; float *rs_x, *rs_a, *rs_h; };     // fp8 copies + row scales (fp8 mode)
 // DA = heads * stored head_dim: width of q / k / v / attention output (== D unless the heads are zero-padded, vit_h)
-long enc_bytes(int D, int DA, int B, int fp8) {
+long enc_bytes(int D, int DA, int B, int fp8, int split) {
     const long R = (long)B * TOK;
+    const long colw = split ? 4608 : 2304;      // the neck's 3 x 3 gather: [hi | lo] in split mode
     long n = al(R * D * 4) + al(R * D * 2) + al(R * 768 * 2) + 3 * al(R * DA * 2) + al(R * DA * 2) + al(R * 4 * D * 2) +
-             al(R * 256 * 2) + al(R * 2304 * 2) + 2 * al(R * 256 * 4);
+             al(R * 256 * 2) + al(R * colw * 2) + 2 * al(R * 256 * 4);
     if (fp8) n += al(R * D) + al(R * DA) + al(R * 4 * D) + 3 * al(R * 4);
     return n;
 }
-EncWork carve(void* base, int D, int DA, int B, int fp8) {
+EncWork carve(void* base, int D, int DA, int B, int fp8, int split) {
     const long R = (long)B * TOK;
     char* p = (char*)base; EncWork w;
     auto take = [&](long b) { char* r = p; p += al(b); return r; };
     w.x = (float*)take(R * D * 4); w.xn = (u16*)take(R * D * 2); w.patches = (u16*)take(R * 768 * 2);
     w.q = (u16*)take(R * DA * 2); w.k = (u16*)take(R * DA * 2); w.v = (u16*)take(R * DA * 2);
     w.attn = (u16*)take(R * DA * 2); w.hid = (u16*)take(R * 4 * D * 2);
-    w.n1 = (u16*)take(R * 256 * 2); w.col = (u16*)take(R * 2304 * 2);
+    w.n1 = (u16*)take(R * 256 * 2); w.col = (u16*)take(R * (split ? 4608 : 2304) * 2);
     w.n0 = (float*)take(R * 256 * 4); w.n2 = (float*)take(R * 256 * 4);
     w.xn8 = w.attn8 = w.hid8 = nullptr; w.rs_x = w.rs_a = w.rs_h = nullptr;
     if (fp8) {
@@ -56,7 +57,7 @@ extern "C" int64_t msam_encoder_workspace_bytes(const msam_encoder_t* enc, int32
     if (!enc || B <= 0) return 0;
     const int hs = stored_head_dim(enc);
     if (!hs) return 0;
-    return enc_bytes(enc->embed_dim, enc->heads * hs, B, enc->fp8);
+    return enc_bytes(enc->embed_dim, enc->heads * hs, B, enc->fp8, enc->split_io);
 }
 
 extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_f32, const uint8_t* img_u8, int32_t h,
@@ -72,20 +73,22 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
     }
     const int DA = H * HS;
     const float scale = 1.0f / sqrtf((float)(D / H));
-    if (workspace_bytes < enc_bytes(D, DA, B, enc->fp8)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
+    if (workspace_bytes < enc_bytes(D, DA, B, enc->fp8, enc->split_io)) { msam_set_error("msam_encoder_forward: workspace too small"); return 1; }
     const bool fp8 = enc->fp8 != 0;
     const int dt = enc->dtype16 == MSAM_F16 ? MSAM_F16 : MSAM_BF16;        // the 16-bit type of every operand / stored activation
     if (fp8 && dt == MSAM_F16) { msam_set_error("msam_encoder_forward: fp8 projections go with the bf16 mode only"); return 1; }
     if (fp8 && (D % 128 || DA % 128)) { msam_set_error("msam_encoder_forward: fp8 needs embed_dim and heads * head_dim % 128 == 0"); return 1; }
     hipStream_t s = (hipStream_t)stream;
-    EncWork w = carve(workspace, D, DA, B, enc->fp8);
+    EncWork w = carve(workspace, D, DA, B, enc->fp8, enc->split_io);
+    const bool split = enc->split_io != 0;
     const int R = (int)(B * TOK);
     int e;
 #define CHECK(x) do { if ((e = (x))) return e; } while (0)
     auto gemm = [&](const void* A, long lda, const void* W, int N, int K, const float* bias, void* o, int odt, long ldc,
-                    int act, const void* resid, int rdt, long ldr, const float* table, int trows, int tcols, long tld) {
+                    int act, const void* resid, int rdt, long ldr, const float* table, int trows, int tcols, long tld,
+                    long ldw = 0) {
         msam_gemm_t g{};
-        g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = R; g.N = N; g.K = K; g.bias = bias;
+        g.A = A; g.lda = lda; g.W = W; g.ldw = ldw ? ldw : K; g.M = R; g.N = N; g.K = K; g.bias = bias;
         g.table = table; g.table_rows = trows; g.table_cols = tcols; g.table_ld = tld;
         g.resid = resid; g.resid_dtype = rdt; g.ldr = ldr; g.act = act; g.out = o; g.out_dtype = odt; g.ldc = ldc;
         g.use_glds = enc->use_glds;
@@ -93,10 +96,18 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
         return msam_gemm_bf16(&g, s);
     };
     // patch embedding (+ bias + absolute position embedding)
-    if (img_u8) CHECK(msam_patchify_u8_16(img_u8, B, h, w_, dt, w.patches, s));
-    else CHECK(msam_patchify16(img_f32, B, dt, w.patches, s));
-    CHECK(gemm(w.patches, 768, enc->patch_w, D, 768, enc->patch_b, w.x, MSAM_F32, D, 0, nullptr, 0, 0, enc->pos_embed,
-               (int)TOK, D, D));
+    if (split) {
+        // [hi | lo | hi] patch rows (2304 wide) in the neck's gather buffer (free until the neck) against [Whi | Whi | Wlo]
+        if (img_u8) CHECK(msam_patchify_u8_split16(img_u8, B, h, w_, dt, w.col, s));
+        else CHECK(msam_patchify_split16(img_f32, B, dt, w.col, s));
+        CHECK(gemm(w.col, 2304, enc->patch_w, D, 2304, enc->patch_b, w.x, MSAM_F32, D, 0, nullptr, 0, 0, enc->pos_embed,
+                   (int)TOK, D, D));
+    } else {
+        if (img_u8) CHECK(msam_patchify_u8_16(img_u8, B, h, w_, dt, w.patches, s));
+        else CHECK(msam_patchify16(img_f32, B, dt, w.patches, s));
+        CHECK(gemm(w.patches, 768, enc->patch_w, D, 768, enc->patch_b, w.x, MSAM_F32, D, 0, nullptr, 0, 0, enc->pos_embed,
+                   (int)TOK, D, D));
+    }
     // fp8 projection: A fp8 [R, K] with row scales, W fp8 [N, K] with column scales
     auto gemm8 = [&](const void* A8, const float* rs, const void* W8, const float* cs, int N, int K, const float* bias, void* o,
                      int odt, long ldc, int act, const void* resid) {
@@ -152,11 +163,25 @@ extern "C" int msam_encoder_forward(const msam_encoder_t* enc, const float* img_
             }
     }
     // neck: conv1x1 -> LayerNorm2d -> conv3x3 (pad 1) -> LayerNorm2d, output NCHW fp32
+    if (split) {
+        // conv1x1: x as [hi | lo | hi] rows (3 D wide, in the MLP hidden buffer: 4 D wide, free here) against [Whi | Whi | Wlo]
+        CHECK(msam_cast_f32_split16(w.x, dt, w.hid, R, D, s));
+        CHECK(gemm(w.hid, 3L * D, enc->neck0_w, 256, 3 * D, nullptr, w.n0, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
+        // LayerNorm2d in fp32 (in the LN-output buffer: D * 2 >= 256 * 4 bytes per token), gathered as [hi | lo]
+        float* n1f = (float*)w.xn;
+        CHECK(msam_layernorm(w.n0, enc->neck1_w, enc->neck1_b, 1e-6f, R, 256, n1f, MSAM_F32, 0, 0, s));
+        CHECK(msam_im2col3x3_split16(n1f, B, 256, dt, w.col, s));
+        // conv3x3: [hi | lo] x [Whi | Whi], then hi x Wlo accumulated on top (the third block of neck2_w's rows)
+        CHECK(gemm(w.col, 4608, enc->neck2_w, 256, 4608, nullptr, w.n2, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0, 6912));
+        CHECK(gemm(w.col, 4608, (const u16*)enc->neck2_w + 4608, 256, 2304, nullptr, w.n2, MSAM_F32, 256, 0, w.n2, MSAM_F32, 256,
+                   nullptr, 0, 0, 0, 6912));
+    } else {
     CHECK(msam_cast_f32_to_16(w.x, dt, w.xn, (long)R * D, s));
     CHECK(gemm(w.xn, D, enc->neck0_w, 256, D, nullptr, w.n0, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
     CHECK(msam_layernorm(w.n0, enc->neck1_w, enc->neck1_b, 1e-6f, R, 256, w.n1, dt, 0, 0, s));
     CHECK(msam_im2col3x3(w.n1, B, 256, w.col, s));
     CHECK(gemm(w.col, 2304, enc->neck2_w, 256, 2304, nullptr, w.n2, MSAM_F32, 256, 0, nullptr, 0, 0, nullptr, 0, 0, 0));
+    }
     CHECK(msam_layernorm(w.n2, enc->neck3_w, enc->neck3_b, 1e-6f, R, 256, out, MSAM_F32, 0, (int)TOK, s));
 #undef CHECK
     return 0;

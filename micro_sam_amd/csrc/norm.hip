@@ -201,8 +201,22 @@ __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restric
     else { uint2 pk; pk.x = pk16(y0, y1, out_dtype); pk.y = pk16(y2, y3, out_dtype); *(uint2*)((u16*)out + row * 64 + c) = pk; }
 }
 
+// hi + lo operand pairs ("split" sites: patch embedding and neck): a value enters its product as
+// hi = round16(v), lo = round16(v - hi) (~16 significand bits for bf16); rows are laid out [hi | lo | hi] (K -> 3K) against weight
+// rows [Whi | Whi | Wlo], so that ONE plain 16-bit GEMM over 3K forms hi*Whi + lo*Whi + hi*Wlo (the lo*Wlo term is 2^-16 relative).
+MSAM_DEVINL float rt16(float v, int dt) { return dt == MSAM_F16 ? h2f(f2h(v)) : bf2f(f2bf(v)); }
+MSAM_DEVINL void store8_split(u16* row, int K, int col, const float* v, int dt) {
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = v[j] - rt16(v[j], dt);
+    uint4 hi, lo;
+    hi.x = pk16(v[0], v[1], dt); hi.y = pk16(v[2], v[3], dt); hi.z = pk16(v[4], v[5], dt); hi.w = pk16(v[6], v[7], dt);
+    lo.x = pk16(l[0], l[1], dt); lo.y = pk16(l[2], l[3], dt); lo.z = pk16(l[4], l[5], dt); lo.w = pk16(l[6], l[7], dt);
+    *(uint4*)(row + col) = hi; *(uint4*)(row + K + col) = lo; *(uint4*)(row + 2 * K + col) = hi;
+}
+
 // thread -> 8 consecutive kx of one (patch, c, ky): out col = c*256 + ky*16 + kx
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, u16* __restrict__ out, int dt) {
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, u16* __restrict__ out, int dt, int split) {
     const long total = (long)B * 4096 * 96;   // 768 / 8 chunks per patch row
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int chunk = (int)(i % 96);
@@ -212,6 +226,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const int c = chunk >> 5, ky = (chunk >> 1) & 15, kx0 = (chunk & 1) * 8;
         const float* src = img + (((long)b * 3 + c) * 1024 + (py * 16 + ky)) * 1024 + px * 16 + kx0;
         float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+        if (split) {
+            const float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+            store8_split(out + prow * 2304, 768, chunk * 8, v, dt);
+            continue;
+        }
         uint4 pk; pk.x = pk16(a.x, a.y, dt); pk.y = pk16(a.z, a.w, dt); pk.z = pk16(d.x, d.y, dt); pk.w = pk16(d.z, d.w, dt);
         *(uint4*)(out + prow * 768 + chunk * 8) = pk;
     }
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 
 // Sam.preprocess fused: (u8 - mean) / std, zero pad to 1024 (micro_sam/models/build_sam.py:132-133)
 __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restrict__ img, int B, int h, int w,
-                                                          u16* __restrict__ out, int dt) {
+                                                          u16* __restrict__ out, int dt, int split) {
     const float mean[3] = {123.675f, 116.28f, 103.53f};
     const float stdv[3] = {58.395f, 57.12f, 57.375f};
     const long total = (long)B * 4096 * 96;
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const uint8_t* __restr
             v[j] = (y < h && x < w)
                        ? __fdiv_rn((float)img[(((long)b * h + y) * w + x) * 3 + c] - mean[c], stdv[c]) : 0.f;
         }
+        if (split) { store8_split(out + prow * 2304, 768, chunk * 8, v, dt); continue; }
         uint4 pk; pk.x = pk16(v[0], v[1], dt); pk.y = pk16(v[2], v[3], dt); pk.z = pk16(v[4], v[5], dt); pk.w = pk16(v[6], v[7], dt);
         *(uint4*)(out + prow * 768 + chunk * 8) = pk;
     }
@@ -256,6 +276,48 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const u16* __restrict__ 
         uint4 val = make_uint4(0, 0, 0, 0);
         if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) val = *(const uint4*)(x + (((long)b * 64 + yy) * 64 + xx) * C + c0);
         *(uint4*)(out + row * (9L * C) + chunk * 8) = val;
+    }
+}
+
+// split form of the neck's 3 x 3 gather: x fp32 [B,64,64,C] -> [B*4096, 2 * 9C] = [hi | lo] (the third [hi] block of the
+// [hi | lo | hi] scheme is the first one again: the caller runs a second product on columns 0 .. 9C-1 with lda = 18C)
+__global__ __launch_bounds__(256) void im2col3x3_split_kernel(const float* __restrict__ x, int B, int C, u16* __restrict__ out, int dt) {
+    const int cpr = 9 * C / 8;
+    const long total = (long)B * 4096 * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % cpr);
+        const long row = i / cpr;
+        const int b = (int)(row / 4096), t = (int)(row % 4096);
+        const int ty = t >> 6, tx = t & 63;
+        const int tap = (chunk * 8) / C, c0 = chunk * 8 - tap * C;
+        const int yy = ty + tap / 3 - 1, xx = tx + tap % 3 - 1;
+        uint4 hi = make_uint4(0, 0, 0, 0), lo = hi;
+        if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) {
+            const float* src = x + (((long)b * 64 + yy) * 64 + xx) * C + c0;
+            const float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+            float l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) l[j] = v[j] - rt16(v[j], dt);
+            hi.x = pk16(v[0], v[1], dt); hi.y = pk16(v[2], v[3], dt); hi.z = pk16(v[4], v[5], dt); hi.w = pk16(v[6], v[7], dt);
+            lo.x = pk16(l[0], l[1], dt); lo.y = pk16(l[2], l[3], dt); lo.z = pk16(l[4], l[5], dt); lo.w = pk16(l[6], l[7], dt);
+        }
+        u16* dst = out + row * (18L * C) + chunk * 8;
+        *(uint4*)dst = hi; *(uint4*)(dst + 9L * C) = lo;
+    }
+}
+
+// x fp32 [rows, dim] -> [rows, 3 * dim] = [hi | lo | hi]
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* __restrict__ x, u16* __restrict__ out, long rows, int dim, int dt) {
+    const int cpr = dim / 8;
+    const long total = rows * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % cpr);
+        const long row = i / cpr;
+        const float* src = x + row * dim + chunk * 8;
+        const float4 a = *(const float4*)src, d = *(const float4*)(src + 4);
+        const float v[8] = {a.x, a.y, a.z, a.w, d.x, d.y, d.z, d.w};
+        store8_split(out + row * (3L * dim), dim, chunk * 8, v, dt);
     }
 }
 
@@ -331,8 +393,14 @@ extern "C" int msam_quant_rows_fp8(const void* x_bf16, int64_t rows, int32_t dim
 extern "C" int msam_patchify16(const float* img, int32_t B, int32_t dtype16, void* out16, void* stream) {
     if (!img || !out16 || B <= 0) { msam_set_error("msam_patchify: bad arguments"); return 1; }
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img, B,
-                       (u16*)out16, dtype16);
+                       (u16*)out16, dtype16, 0);
     return msam_check_launch("msam_patchify");
+}
+extern "C" int msam_patchify_split16(const float* img, int32_t B, int32_t dtype16, void* out16, void* stream) {
+    if (!img || !out16 || B <= 0) { msam_set_error("msam_patchify_split16: bad arguments"); return 1; }
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img, B,
+                       (u16*)out16, dtype16, 1);
+    return msam_check_launch("msam_patchify_split16");
 }
 extern "C" int msam_patchify(const float* img, int32_t B, void* out_bf16, void* stream) { return msam_patchify16(img, B, MSAM_BF16, out_bf16, stream); }
 
@@ -342,8 +410,17 @@ extern "C" int msam_patchify_u8_16(const uint8_t* img, int32_t B, int32_t h, int
         return 1;
     }
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img,
-                       B, h, w, (u16*)out16, dtype16);
+                       B, h, w, (u16*)out16, dtype16, 0);
     return msam_check_launch("msam_patchify_u8");
+}
+extern "C" int msam_patchify_u8_split16(const uint8_t* img, int32_t B, int32_t h, int32_t w, int32_t dtype16, void* out16, void* stream) {
+    if (!img || !out16 || B <= 0 || h <= 0 || w <= 0 || h > 1024 || w > 1024) {
+        msam_set_error("msam_patchify_u8_split16: bad arguments (need 0 < h,w <= 1024)");
+        return 1;
+    }
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(grid_for((long)B * 4096 * 96)), dim3(256), 0, (hipStream_t)stream, img,
+                       B, h, w, (u16*)out16, dtype16, 1);
+    return msam_check_launch("msam_patchify_u8_split16");
 }
 extern "C" int msam_patchify_u8(const uint8_t* img, int32_t B, int32_t h, int32_t w, void* out_bf16, void* stream) {
     return msam_patchify_u8_16(img, B, h, w, MSAM_BF16, out_bf16, stream);
@@ -354,6 +431,20 @@ extern "C" int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* ou
     hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((long)B * 4096 * 9 * C / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const u16*)x_bf16, B, C, (u16*)out_bf16);
     return msam_check_launch("msam_im2col3x3");
+}
+
+extern "C" int msam_im2col3x3_split16(const float* x_f32, int32_t B, int32_t C, int32_t dtype16, void* out16, void* stream) {
+    if (!x_f32 || !out16 || B <= 0 || C <= 0 || C % 8) { msam_set_error("msam_im2col3x3_split16: bad arguments"); return 1; }
+    hipLaunchKernelGGL(im2col3x3_split_kernel, dim3(grid_for((long)B * 4096 * 9 * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                       x_f32, B, C, (u16*)out16, dtype16);
+    return msam_check_launch("msam_im2col3x3_split16");
+}
+
+extern "C" int msam_cast_f32_split16(const float* x, int32_t dtype16, void* out16, int64_t rows, int32_t dim, void* stream) {
+    if (!x || !out16 || rows <= 0 || dim <= 0 || dim % 8) { msam_set_error("msam_cast_f32_split16: bad arguments (dim % 8 == 0)"); return 1; }
+    hipLaunchKernelGGL(cast_split_kernel, dim3(grid_for(rows * (dim / 8))), dim3(256), 0, (hipStream_t)stream, x, (u16*)out16,
+                       (long)rows, dim, dtype16);
+    return msam_check_launch("msam_cast_f32_split16");
 }
 
 extern "C" int msam_cast_f32_to_16(const float* x, int32_t dtype16, void* out16, int64_t n, void* stream) {

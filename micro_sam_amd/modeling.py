@@ -118,6 +118,9 @@ class ImageEncoderViT(nn.Module):
             nn.Conv2d(PROMPT_DIM, PROMPT_DIM, kernel_size=3, padding=1, bias=False), LayerNorm2d(PROMPT_DIM))
         self.use_glds = 0
         self.precision = "bf16"          # "fp8": qkv / proj / lin1 / lin2 on e4m3 operands (set_precision; BASELINE config 5)
+        # patch embedding + neck (1.2 % of the flops) on hi + lo operand pairs: these two sites carry most of what the 8-bit operand
+        # rounding costs in mask parity (profiles/r03_enc_ablation.txt); set_split_io(False) = plain 16-bit
+        self.split_io = True
         self._prep = None
         self._workspace = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
@@ -136,6 +139,12 @@ class ImageEncoderViT(nn.Module):
             raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16', 'fp16' or 'fp8'")
         if precision != self.precision:
             self.precision = precision
+            self.invalidate()
+
+    def set_split_io(self, on: bool) -> None:
+        """hi + lo operand pairs at the patch embedding and the neck (default on); off = every operand plainly 16-bit (ablation)."""
+        if bool(on) != bool(self.split_io):
+            self.split_io = bool(on)
             self.invalidate()
 
     def _prepare(self):
@@ -179,7 +188,17 @@ class ImageEncoderViT(nn.Module):
                 return t
             t = t.detach().reshape(t.shape[0], groups, hd)
             return F.pad(t, (0, hs - hd)).reshape(t.shape[0], groups * hs)
-        p.patch_w = k(_bf16(self.patch_embed.proj.weight.reshape(D, 3 * PATCH * PATCH)))
+        split = bool(self.split_io)
+        p.split_io = 1 if split else 0
+
+        def _io(t):                 # weight of a split site: [Whi | Whi | Wlo] (msam_encoder_t.split_io), else the plain 16-bit copy
+            if not split:
+                return _bf16(t)
+            t = t.detach().float()
+            hi = _bf16(t)
+            lo = _bf16(t - hi.float())
+            return torch.cat([hi, hi, lo], dim=1).contiguous()
+        p.patch_w = k(_io(self.patch_embed.proj.weight.reshape(D, 3 * PATCH * PATCH)))
         p.patch_b = k(_f32(self.patch_embed.proj.bias))
         p.pos_embed = k(_f32(self.pos_embed.reshape(GRID * GRID, D)))
         for i, blk in enumerate(self.blocks):
@@ -201,9 +220,9 @@ class ImageEncoderViT(nn.Module):
                     w8, cs = quant_weight_fp8(wt.detach().float().cpu())          # e4m3 cast on the host (once per model)
                     getattr(p, name + "_w8")[i] = k(w8.to(dev))
                     getattr(p, name + "_cs")[i] = k(cs.to(dev))
-        p.neck0_w = k(_bf16(self.neck[0].weight.reshape(PROMPT_DIM, D)))
+        p.neck0_w = k(_io(self.neck[0].weight.reshape(PROMPT_DIM, D)))
         p.neck1_w, p.neck1_b = k(_f32(self.neck[1].weight)), k(_f32(self.neck[1].bias))
-        p.neck2_w = k(_bf16(self.neck[2].weight.permute(0, 2, 3, 1).reshape(PROMPT_DIM, 9 * PROMPT_DIM)))
+        p.neck2_w = k(_io(self.neck[2].weight.permute(0, 2, 3, 1).reshape(PROMPT_DIM, 9 * PROMPT_DIM)))
         p.neck3_w, p.neck3_b = k(_f32(self.neck[3].weight)), k(_f32(self.neck[3].bias))
         p.use_glds = int(self.use_glds)
         p.fp8 = 1 if self.precision == "fp8" else 0

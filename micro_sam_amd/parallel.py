@@ -15,6 +15,16 @@ import torch
 import torch.distributed as dist
 
 
+def collectives_active() -> bool:
+    """True when the collective code path has to run: a process group with more than one rank - or any initialised group when
+    ``MSAM_FORCE_COLLECTIVES=1`` (a world-size-1 "nccl" group drives the same RCCL calls on one GPU: the smoke test of the N > 1 path
+    that a single-GPU box can run, tests/test_gpu_rccl_smoke.py)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("MSAM_FORCE_COLLECTIVES") == "1"
+
+
 def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous block partition [start, stop) - keeps the z / tile order of the serial loop."""
     base, rem = divmod(n_items, world_size)
@@ -27,7 +37,7 @@ def gather_label_tiles(local_labels: torch.Tensor, n_items: int, relabel_globall
 
     Returns [n_items, H, W] (same dtype/device) on every rank; with ``relabel_globally`` ids of item i are shifted by the
     running offset sum(max_id[:i]) exactly like the reference's serial loop."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not collectives_active():
         out = local_labels.clone()
         if relabel_globally:
             _apply_offsets(out, out.flatten(1).amax(dim=1).to(torch.int64))

@@ -176,6 +176,17 @@ def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0, calibrated: b
     return sd
 
 
+def scale_mask_logits(sd, scale: float):
+    """Multiply every mask logit of the checkpoint by ``scale`` (in place, returns ``sd``): the last layer of the four
+    hyper-network MLPs is linear in the logits.  ``scale`` = 0.25 gives the softer mask boundaries (|logit| ~ 3 - 12 instead of
+    10 - 50) of the parity sensitivity runs (tests/test_gpu_parity_iou.py)."""
+    for i in range(4):
+        hp = f"mask_decoder.output_hypernetworks_mlps.{i}.layers.2."
+        sd[hp + "weight"] = sd[hp + "weight"] * scale
+        sd[hp + "bias"] = sd[hp + "bias"] * scale
+    return sd
+
+
 def synthetic_tile(seed: int, shape: Tuple[int, int] = (1024, 1024)) -> np.ndarray:
     """uint8 [H,W] cell-like tile: noisy background + blurred random ellipses."""
     from scipy.ndimage import gaussian_filter

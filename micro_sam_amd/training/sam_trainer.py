@@ -33,7 +33,8 @@ def dice_loss_per_channel(prediction: torch.Tensor, target: torch.Tensor, eps: f
 def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20) -> int:
     """Average the gradients over the ranks of the default process group: flat fp32 buckets of ``bucket_bytes`` (64 MiB: a few
     large RCCL all-reduces over xGMI instead of one per tensor), in place.  Returns the number of bytes reduced."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    from ..parallel import collectives_active
+    if not collectives_active():
         return 0
     world = dist.get_world_size()
     grads = [p.grad for p in parameters if p.requires_grad and p.grad is not None]

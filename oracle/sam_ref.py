@@ -67,6 +67,10 @@ PIXEL_STD = (58.395, 57.12, 57.375)      # build_sam.py:133
 DECODER_DTYPE = torch.float16
 # 16-bit operand type of the image encoder in the "bf16" policy (the product: bf16; torch.float16 = what-if ablation, tools/iou_ablation.py encfp16)
 ENCODER_DTYPE = torch.bfloat16
+# The product's image encoder takes the operands of the patch embedding and of the two neck convolutions as hi + lo pairs of the
+# 16-bit type (msam_encoder_t.split_io, micro_sam_amd.modeling.ImageEncoderViT.split_io; default on): the "bf16" policy rounds
+# these sites to hi + lo instead of to 16 bits.  False = the plain 16-bit policy of rounds 1 / 2 (set_split_io(False)).
+ENCODER_SPLIT_IO = True
 
 
 class Prec:
@@ -95,7 +99,7 @@ class Prec:
         # "lin2.w", "neck".
         self.enc_only = None
         self.enc_blocks = None
-        self.enc_dtype = {}
+        self.enc_dtype = {"patch": "split", "neck": "split"} if ENCODER_SPLIT_IO else {}
         self.block = -1
 
     def rounds(self, site: Optional[str]) -> bool:
@@ -126,9 +130,9 @@ class Prec:
         if self.enc_blocks is not None and self.block not in self.enc_blocks:
             return x
         dt = self.enc_dtype.get(site, ENCODER_DTYPE)
-        if dt == "split":
-            hi = x.to(torch.bfloat16).to(torch.float32)
-            return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
+        if dt == "split":             # hi + lo pair of the encoder's 16-bit type
+            hi = x.to(ENCODER_DTYPE).to(torch.float32)
+            return hi + (x - hi).to(ENCODER_DTYPE).to(torch.float32)
         return x.to(dt).to(torch.float32)
 
     def linear(self, x: Tensor, w: Tensor, b: Optional[Tensor] = None, site: Optional[str] = None,

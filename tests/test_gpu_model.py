@@ -80,6 +80,54 @@ def test_fp16_encoder_vs_oracle(ctx):
     assert (out8 - out).abs().max().item() <= 1e-5
 
 
+def test_split_io_sites(ctx):
+    """msam_encoder_t.split_io (default on): patch embedding + neck on hi + lo operand pairs.  The helper kernels write exactly
+    round16(v) / round16(v - hi); with the sites split the embedding lands several times closer to the fp32 reference than with every
+    operand plainly bf16 (set_split_io(False) - which must still match the oracle's plain policy)."""
+    from micro_sam_amd import _lib
+    from oracle import sam_ref as S
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(64, 768, generator=g) * 3).cuda()
+    out = torch.empty(64, 3 * 768, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.msam_cast_f32_split16(x.data_ptr(), _lib.BF16, out.data_ptr(), 64, 768, _lib.stream_ptr()), "cast_split")
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    assert torch.equal(out[:, :768], hi) and torch.equal(out[:, 768:1536], lo) and torch.equal(out[:, 1536:], hi)
+    n1 = torch.randn(1, 64, 64, 256, generator=g).cuda()
+    col = torch.empty(4096, 2 * 2304, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.msam_im2col3x3_split16(n1.data_ptr(), 1, 256, _lib.BF16, col.data_ptr(), _lib.stream_ptr()), "im2col_split")
+    ref = torch.nn.functional.unfold(n1.permute(0, 3, 1, 2), 3, padding=1)                  # [1, 256*9, 4096], rows (c, ky, kx)
+    ref = ref.reshape(256, 9, 4096).permute(2, 1, 0).reshape(4096, 2304)                    # -> columns (ky, kx, c)
+    rh = ref.to(torch.bfloat16)
+    assert torch.equal(col[:, :2304], rh) and torch.equal(col[:, 2304:], (ref - rh.float()).to(torch.bfloat16))
+    img8 = torch.as_tensor(ctx["img"])[None].cuda()
+    pat = torch.empty(4096, 2304, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.msam_patchify_u8_split16(img8.data_ptr(), 1, 1024, 1024, _lib.BF16, pat.data_ptr(), _lib.stream_ptr()), "patchify")
+    pr = ctx["x"][0].reshape(3, 64, 16, 64, 16).permute(1, 3, 0, 2, 4).reshape(4096, 768).cuda()
+    assert (pat[:, :768].float() + pat[:, 768:1536].float() - pr).abs().max().item() <= 3e-5      # hi + lo carries ~16 bits
+    assert torch.equal(pat[:, 1536:], pat[:, :768])
+
+    enc = ctx["predictor"].model.image_encoder
+    assert enc.split_io
+    out_split = enc(ctx["x"].cuda()).cpu()
+    enc.set_split_io(False)
+    try:
+        S.ENCODER_SPLIT_IO = False
+        with torch.no_grad():
+            ref_plain = S.image_encoder(ctx["sd"], ctx["x"], precision="bf16")
+        out_plain = enc(ctx["x"].cuda()).cpu()
+    finally:
+        S.ENCODER_SPLIT_IO = True
+        enc.set_split_io(True)
+    d_plain = (out_plain - ref_plain).abs()
+    assert d_plain.max().item() <= 0.06 and d_plain.mean().item() <= 0.008
+    e_split = (out_split - ctx["ref_f"]).abs().mean().item()
+    e_plain = (out_plain - ctx["ref_f"]).abs().mean().item()
+    print(f"embedding mean |d| vs fp32: split sites {e_split:.5f}, plain bf16 {e_plain:.5f}")
+    assert e_split < e_plain
+
+
 def test_set_image_and_predictor_api(ctx):
     p = ctx["predictor"]
     p.reset_image()

@@ -47,6 +47,7 @@ def decode(sd, f, sel_pts):
 def configs():
     def mk(only=None, blocks=None, dtype=None, default=torch.bfloat16):
         p = S.Prec("bf16")
+        p.enc_dtype = {}              # start from the plain 16-bit policy (the default policy splits patch + neck)
         p.enc_only = None if only is None else set(only)
         p.enc_blocks = None if blocks is None else set(blocks)
         if dtype:

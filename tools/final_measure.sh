@@ -1,28 +1,38 @@
 #!/bin/bash
-# Round-end measurement bundle, run on the GPU box through gpurun:  bash tools/final_measure.sh
-# Outputs under gpurun_out/ are turned into profiles/<tag>_* by tools/summarize_profiles.py.
+# Round-end measurement bundle, run on the GPU box through gpurun:  bash tools/final_measure.sh [quick]
+# Outputs under gpurun_out/ are turned into profiles/<tag>_* by tools/summarize_profiles.py (+ tools/pmc_summary.py for the SQ passes).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-rm -rf $O/final_prof $O/final_fetch $O/final_write
+rm -rf $O/final_prof $O/final_fetch $O/final_write $O/final_sq1 $O/final_sq2
+python $R/tools/csrc_sha.py > $O/final_csrc_sha.txt
 python $R/bench.py > $O/final_bench.log 2> $O/final_bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof -- python $R/bench.py --no-cpu-baseline --lanes 1 > $O/final_prof.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/final_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/final_write.log 2>&1
-python $R/bench.py --encoder-dtype fp8 --no-cpu-baseline > $O/final_fp8.log 2> $O/final_fp8.err
-python $R/bench.py --encoder-dtype fp16 --no-cpu-baseline > $O/final_fp16.log 2> $O/final_fp16.err
-python $R/bench.py --lanes 1 --no-cpu-baseline > $O/final_lanes1.log 2> $O/final_lanes1.err
-MSAM_TUNE="dec_chain=0" python $R/bench.py --no-cpu-baseline > $O/final_staged.log 2> $O/final_staged.err
+# rocprof passes: hot path only (--no-side), one decode lane (kernels of different tiles do not overlap)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof -- python $R/bench.py --no-cpu-baseline --no-side --lanes 1 > $O/final_prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side --lanes 1 > $O/final_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side --lanes 1 > $O/final_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $O/final_sq1 -- python $R/tools/pmc_tile.py > $O/final_sq1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $O/final_sq2 -- python $R/tools/pmc_tile.py > $O/final_sq2.log 2>&1
+python $R/tools/pmc_summary.py $O/final_sq1 $O/final_sq2 > $O/final_sq_table.md 2>&1
+if [ "$1" != "quick" ]; then
+python $R/bench.py --encoder-dtype fp8 --no-cpu-baseline --no-side > $O/final_fp8.log 2> $O/final_fp8.err
+python $R/bench.py --encoder-dtype fp16 --no-cpu-baseline --no-side > $O/final_fp16.log 2> $O/final_fp16.err
+python $R/bench.py --lanes 1 --no-cpu-baseline --no-side > $O/final_lanes1.log 2> $O/final_lanes1.err
+python $R/bench.py --workload config3 --steps 1 --warmup 1 --slices 4 > $O/final_config3.log 2> $O/final_config3.err
+fi
 python $R/tools/hbm_probe.py > $O/final_hbm_probe.log 2>&1
 cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/final_smoke.log 2>&1
 tail -1 $O/final_smoke.log
 python - <<PY
 import json
-for f in ("final_bench", "final_fp8", "final_fp16", "final_lanes1", "final_staged"):
-    d = json.loads(open("$O/" + f + ".log").read().strip().splitlines()[-1])
-    print(f, d["value"], d["ms_per_step"], d.get("cpu_baseline"))
+for f in ("final_bench", "final_fp8", "final_fp16", "final_lanes1", "final_config3"):
+    try:
+        d = json.loads(open("$O/" + f + ".log").read().strip().splitlines()[-1])
+        print(f, d["value"], d["ms_per_step"], d.get("cpu_baseline"), d.get("api_inclusive"))
+    except Exception as e:
+        print(f, "missing", e)
 PY
 cat $O/final_hbm_probe.log
-find $O/final_prof $O/final_fetch $O/final_write -type f -size +6M -delete
+find $O/final_prof $O/final_fetch $O/final_write $O/final_sq1 $O/final_sq2 -type f -size +6M -delete
 ls $O/final_prof/*/ | head; du -sh $O

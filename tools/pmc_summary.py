@@ -6,7 +6,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEEP = ("up_fused", "fold_i2t", "fold_attn", "postprocess", "gemm256", "gemm_kernel", "global_attention", "window_attention",
+KEEP = ("tok_layer", "up_fused", "fold_i2t", "fold_attn", "postprocess", "gemm256", "gemm_kernel", "global_attention", "window_attention",
         "t2i_shared4", "cc_hook", "nms_sweep", "fused_i2t", "i2t0_t2i", "i2t01", "i2t_tok")
 
 

@@ -12,7 +12,7 @@ from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator  # noqa: 
 from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile  # noqa: E402
 
 dev = torch.device("cuda", 0)
-sd = synthetic_state_dict("vit_b", 0, variant="blobs")
+sd = synthetic_state_dict("vit_b", 0, variant="cells")
 predictor = util.get_sam_model("vit_b", device=dev, state_dict=sd)
 amg = AutomaticMaskGenerator(predictor, device_chunk=1024)
 tiles_np = [synthetic_tile(1000 + i) for i in range(2)]

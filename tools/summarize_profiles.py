@@ -20,7 +20,11 @@ GO = os.path.join(ROOT, "gpurun_out")
 
 # algorithmic HBM bytes per launch at P = 1024 prompts: stream = 1024 * 4096 * 256 * 2 B = 2 GiB
 GiB = 1 << 30
+# key (the name bench.py's families use) -> (description, algorithmic bytes per launch); PATTERN maps a key to the substring of the
+# rocprof kernel name it stands for (the shipped chained kernels are i2t01_ring_kernel / i2t0_t2i_v2_kernel)
+PATTERN = {"i2t01_kernel": "i2t01", "i2t0_t2i_kernel": "i2t0_t2i", "gemm256_kernel": "gemm256_kernel"}
 ALGO = {
+    "gemm256_kernel": ("A [65536, K] and W read, C written (encoder projections of a 16-tile batch; mixed shapes)", None),
     "i2t01_kernel": ("2 GiB written (the layer-1 stream, blocked layout); the shared tables (5 MiB) and the per-prompt operands "
                      "(144 KiB per prompt) come from L2", 2 * GiB),
     "i2t0_t2i_kernel": ("no per-prompt stream: shared tables (5 MiB) + operands (112 KiB per prompt) from L2, [P,7,128] written",
@@ -55,9 +59,9 @@ def main():
     pb = json.loads(prof_line)
     tiles = pb["config"]["tiles_per_step_per_gpu"] * (pb["steps"] + pb["warmup"] + 1)      # + the instrumented pass
     with open(os.path.join(OUT, f"{TAG}_bench_kernel_summary.md"), "w") as f:
-        f.write(f"# {TAG}: rocprofv3 kernel summary of `python bench.py --no-cpu-baseline --lanes 1` on one MI355X\n\n")
+        f.write(f"# {TAG}: rocprofv3 kernel summary of `python bench.py --no-cpu-baseline --no-side --lanes 1` on one MI355X\n\n")
         f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_prof -- python bench.py "
-                "--no-cpu-baseline --lanes 1` (one decode lane: kernels of different tiles do not overlap, the same order as the "
+                "--no-cpu-baseline --no-side --lanes 1` (no side measurements: every launch belongs to the hot path; one decode lane: kernels of different tiles do not overlap, the same order as the "
                 "serial roofline pass of bench.py)\n")
         f.write(f"(bench line of this profiled run: {pb['value']} tiles/s; unprofiled run with cpu_baseline: {bench['value']} "
                 f"tiles/s, `{TAG}_bench_line.json`).\n\n")
@@ -81,7 +85,7 @@ def main():
             if r["Counter_Name"] != key:
                 continue
             kn = r["Kernel_Name"]
-            short = next((s for s in ALGO if s in kn), None)
+            short = next((s for s in ALGO if PATTERN.get(s, s) in kn), None)
             if short is None:
                 continue
             acc.setdefault(short, {}).setdefault(key, []).append(float(r["Counter_Value"]))
@@ -98,11 +102,16 @@ def main():
         hbm = 2 * fk * 1024 + wk * 1024
         table[short] = {"launches": len(fetch), "fetch_kib": fk, "write_kib": wk, "hbm_bytes_per_launch": hbm,
                         "algorithmic_bytes_per_launch": ALGO[short][1], "algorithmic": ALGO[short][0]}
+    sha_path = os.path.join(GO, "final_csrc_sha.txt")
+    table["_meta"] = {"csrc_sha16": open(sha_path).read().strip() if os.path.exists(sha_path) else None,
+                      "what": "sha16 of micro_sam_amd/csrc + include/msam_hip.h at measurement time (tools/csrc_sha.py); bench.py "
+                              "reports roofline.traffic from this table only while the sources still hash to it"}
     with open(os.path.join(OUT, f"{TAG}_pmc_traffic.json"), "w") as f:
         json.dump(table, f, indent=1)
+    table.pop("_meta")
     with open(os.path.join(OUT, f"{TAG}_pmc_traffic.md"), "w") as f:
         f.write(f"# {TAG}: HBM traffic from PMC counters (separate rocprofv3 passes of `python bench.py --steps 1 --warmup 1 "
-                "--no-cpu-baseline`)\n\n")
+                "--no-cpu-baseline --no-side`)\n\n")
         f.write("Commands: `rocprofv3 --kernel-trace --pmc FETCH_SIZE ...` and `rocprofv3 --kernel-trace --pmc WRITE_SIZE ...` "
                 "(one counter per pass, no other trace domain).\n\n")
         f.write("Units: counter values are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of "
