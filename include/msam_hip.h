@@ -530,8 +530,11 @@ int msam_paint_label_image(const uint32_t* bits, const int32_t* order, int32_t K
 /* As msam_paint_label_image with the number of masks read from device memory (k_dev: int32[1]). */
 int msam_paint_label_image_dev(const uint32_t* bits, const int32_t* order, const int32_t* k_dev, int32_t H, int32_t W,
                                int32_t* label, void* stream);
-/* Connected components (4-connectivity) of equal non-zero value (elf.parallel.label at util.py:1834):
- * roots[i] = smallest linear index of pixel i's component, -1 for background.  changed_flag: int32 device scratch.
+/* Connected components (4-connectivity) of equal non-zero value (elf.parallel.label(block_shape=(512, 512)) at util.py:1834-1838):
+ * roots[i] = KEY of the root of pixel i's component, -1 for background.  A pixel's key is its position in block-major order
+ * (512 x 512 blocks in raster order, raster order inside a block), the root is the component's smallest key; ascending root keys
+ * reproduce the reference's component numbering (per-block labels with running offsets, union across faces, consecutive by first
+ * occurrence).  For H, W <= 512 key == linear index.  changed_flag: int32 device scratch.
  * Synchronises the stream once per union pass (at most max_iters, default 8); iters_done (host, optional). */
 int msam_label_components(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
                           int32_t max_iters, int32_t* iters_done, void* stream);
@@ -543,6 +546,18 @@ int msam_component_sizes(const int32_t* roots, int32_t n, int32_t* sizes, int32_
  * changed_flag = flag of the last pass to be checked by the caller whenever convenient. */
 int msam_label_components_async(const int32_t* seg, int32_t H, int32_t W, int32_t* roots, int32_t* changed_flag,
                                 int32_t passes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Overlap of objects between consecutive slices:  merge_instance_segmentation_3d's edge extraction
+ * (micro_sam/multi_dimensional_segmentation.py:356-363 -> elf.tracking compute_edges_from_overlap -> nifty.ground_truth.overlap;
+ *  SURVEY.md 8(f) rank 3)
+ * ------------------------------------------------------------------------------------------------- */
+/* labels: int32 [Z, H, W] with ids consecutive across z.  For every pixel p and z < Z - 1 with a = labels[z][p] != 0 the pair
+ * (a, b = labels[z + 1][p]) is counted in an open-addressing table the caller provides (table_keys uint64 [capacity], table_counts
+ * int32 [capacity]; capacity a power of two >= 4 x the distinct pairs, initialised here).  edges: int32 [max_edges, 3] = (source,
+ * target (0 = background), pixels) in arbitrary order; n_edges: int32 [2] = {edges found, table-overflow flag}. */
+int msam_slice_overlaps(const int32_t* labels, int32_t Z, int32_t H, int32_t W, uint64_t* table_keys, int32_t* table_counts,
+                        int32_t capacity, int32_t* edges, int32_t max_edges, int32_t* n_edges, void* stream);
 
 #ifdef __cplusplus
 }

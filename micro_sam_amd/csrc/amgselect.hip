@@ -118,10 +118,12 @@ __global__ __launch_bounds__(NT) void amg_area_sort_kernel(const int* __restrict
     if (tid == 0) *k_dev = count;
 }
 
-// ---- relabel: roots int32 [n] (-1 = background, root pixel r has roots[r] == r), sizes[r] at roots
+// ---- relabel: roots int32 [n] per PIXEL = key of its component's root (-1 = background; common.h bm_key: block-major order, the
+// reference's numbering); the pixel bm_pix(q) of a root key q has roots[..] == q; sizes[q] at root keys.  The kernels below walk the
+// KEY space in ascending order, so components are numbered by ascending root key.
 constexpr int RB = 1024;           // pixels per block (256 threads x 4)
 
-__global__ __launch_bounds__(256) void relabel_stats_kernel(const int* __restrict__ roots, const int* __restrict__ sizes, int n,
+__global__ __launch_bounds__(256) void relabel_stats_kernel(const int* __restrict__ roots, const int* __restrict__ sizes, int n, int H, int W,
                                                             int min_size, int* __restrict__ blk_cnt, u64* __restrict__ blk_max) {
     __shared__ int scnt[4];
     __shared__ u64 smax[4];
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void relabel_stats_kernel(const int* __restric
     int cnt = 0; u64 mx = 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int p = base + k;
-        if (p < n && roots[p] == p) {
+        const int p = base + k;                                                              // a key
+        if (p < n && roots[bm_pix(p, H, W)] == p) {
             const int sz = sizes[p];
             if (sz >= min_size) ++cnt;
             const u64 key = ((u64)(uint32_t)sz << 32) | (u64)(0xffffffffu - (uint32_t)p);     // larger size, then smaller index
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(NT) void relabel_scan_kernel(int* __restrict__ blk_
     }
 }
 
-__global__ __launch_bounds__(256) void relabel_assign_kernel(const int* __restrict__ roots, const int* __restrict__ sizes, int n,
+__global__ __launch_bounds__(256) void relabel_assign_kernel(const int* __restrict__ roots, const int* __restrict__ sizes, int n, int H, int W,
                                                              int min_size, const int* __restrict__ blk_off,
                                                              const int* __restrict__ drop_idx, int* __restrict__ newid) {
     __shared__ int wsum[4];
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void relabel_assign_kernel(const int* __restri
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int p = base + k;
-        f[k] = (p < n && roots[p] == p && sizes[p] >= min_size && p != drop) ? 1 : 0;
+        f[k] = (p < n && roots[bm_pix(p, H, W)] == p && sizes[p] >= min_size && p != drop) ? 1 : 0;
         c += f[k];
     }
     int incl = c;                                   // inclusive scan over the 64 lanes of the wave
@@ -278,10 +280,10 @@ extern "C" int msam_amg_generate_labels(const float* iou, const float* stability
     if ((e = msam_paint_label_image_dev(bits, order2, small, H, W, painted, s))) return e;
     if ((e = msam_label_components_async(painted, H, W, roots, flag, 2, s))) return e;
     if ((e = msam_component_sizes(roots, n, sizes, small + 1, s))) return e;
-    hipLaunchKernelGGL(relabel_stats_kernel, dim3(nb), dim3(256), 0, s, roots, sizes, n, min_object_size, blk_cnt, blk_max);
+    hipLaunchKernelGGL(relabel_stats_kernel, dim3(nb), dim3(256), 0, s, roots, sizes, n, H, W, min_object_size, blk_cnt, blk_max);
     hipLaunchKernelGGL(relabel_scan_kernel, dim3(1), dim3(NT), 0, s, blk_cnt, blk_max, nb, small + 1, with_background,
                        min_object_size, blk_off, small + 2);
-    hipLaunchKernelGGL(relabel_assign_kernel, dim3(nb), dim3(256), 0, s, roots, sizes, n, min_object_size, blk_off, small + 2, newid);
+    hipLaunchKernelGGL(relabel_assign_kernel, dim3(nb), dim3(256), 0, s, roots, sizes, n, H, W, min_object_size, blk_off, small + 2, newid);
     hipLaunchKernelGGL(relabel_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, roots, newid, n, labels);
     return msam_check_launch("msam_amg_generate_labels");
 }

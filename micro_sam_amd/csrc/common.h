@@ -143,3 +143,28 @@ MSAM_DEVINL float wave_max64(float v) {
     v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 16)); v = fmaxf(v, __shfl_xor(v, 32));
     return v;
 }
+
+// ---- Component numbering of the reference (micro_sam/util.py:1834-1838: elf.parallel.label with block_shape (512, 512)): every
+// 512 x 512 block is labelled on its own (scikit-image: components in raster order of their first pixel) with a running offset in
+// block raster order, components are then united across block faces and the united labelling is made consecutive in order of first
+// occurrence over the ascending provisional ids - so a component's rank is the rank of its smallest provisional id, i.e. of its first
+// pixel in BLOCK-MAJOR order: key(y, x) = (pixels of all earlier blocks) + (y % 512) * block_width + (x % 512).  The connected-
+// component kernels keep that key as the union-find label (the smaller key is the root) and number the roots by ascending key.
+// Images of up to 512 x 512 are one block: key = raster index.
+MSAM_DEVINL int bm_key(int p, int H, int W) {                 // pixel index -> block-major key
+    const int y = p / W, x = p - y * W;
+    const int by = y >> 9, bx = x >> 9;
+    const int bh = min(512, H - (by << 9)), bw = min(512, W - (bx << 9));
+    return (by << 9) * W + (bx << 9) * bh + (y & 511) * bw + (x & 511);
+}
+MSAM_DEVINL int bm_pix(int q, int H, int W) {                 // block-major key -> pixel index
+    const int nby = (H + 511) >> 9, nbx = (W + 511) >> 9;
+    const int by = min(q / (W << 9), nby - 1);
+    const int rem = q - (by << 9) * W;
+    const int bh = min(512, H - (by << 9));
+    const int bx = min(rem / (bh << 9), nbx - 1);
+    const int rem2 = rem - (bx << 9) * bh;
+    const int bw = min(512, W - (bx << 9));
+    const int ly = rem2 / bw, lx = rem2 - ly * bw;
+    return ((by << 9) + ly) * W + (bx << 9) + lx;
+}

@@ -21,6 +21,8 @@ struct Epi {
     void* out; int out_dtype; long ldc;
     int out_mode; u16* q; u16* k; u16* v; int heads, head_dim, tokens;
     const float* row_scale; const float* col_scale;      // fp8 operands: C = acc * row_scale[m] * col_scale[n]
+    int dbg;                                             // timing experiments (msam_tune_set "gemm_dbg"; WRONG results when != 0): gemm256 only -
+                                                         // 1 = no global stores, 2 = no epilogue at all, 4 = no k-loop
 };
 
 // body of the 128 x 128 tile kernel for workgroup `bid_in` of the product (shared by the plain and the grouped launch)
@@ -341,6 +343,7 @@ MSAM_DEVINL f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& b0
 }
 constexpr int G2 = 256;                       // tile edge
 constexpr int G2_DEFAULT_STAGING = 3;   // measured (tools/gemm_bench.py): 3 > 1 > 0 by 3 - 8 % each on the encoder shapes, LDS-DMA (2) no better
+int g_tune_gemm_dbg = 0;                      // msam_tune_set "gemm_dbg" (Epi.dbg)
 int g_gemm256_staging = -1;                   // test / tuning hook (msam_gemm256_set_staging), -1 = default / environment
 constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 8 chunks x 16 B = 128 KB
 
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #pragma unroll
             for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
 
-    const int nk = K / BKE;
+    const int nk = (e.dbg & 4) ? 1 : K / BKE;
     auto compute = [&](int buf) {
         const uint4* la = stage(buf, 0);
         const uint4* lw = stage(buf, 1);
@@ -591,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #undef G2_LOAD
 #undef G2_COMMIT
 
+    if (e.dbg & 2) return;
     // ---- epilogue in two column halves of 128: C^T accumulators (row = n, column = m) -> ldsC[m][128] fp32, chunk-swizzled
     float* ldsC = (float*)dyn;
     const int c4 = tid & 31, rg = tid >> 5;                  // 16-byte column chunk, row group (16 rows per pass)
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #pragma unroll
                 for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
             }
-            if (row < M) {
+            if (row < M && !(e.dbg & 1)) {
                 if (e.out_mode == 0) {
                     if (e.out_dtype == MSAM_F32) {
                         *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
@@ -854,6 +858,7 @@ int g_prof_n = 0, g_prof_on = 0, g_prof_init = 0;
 
 extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
+void msam_gemm_set_dbg(int v) { g_tune_gemm_dbg = v; }     // msam_tune_set "gemm_dbg" (decfold.hip)
 extern "C" int msam_gemm256_set_staging(int staging) {
     if (staging < -1 || staging > 3) { msam_set_error("msam_gemm256_set_staging: -1 (default), 0, 1, 2 or 3"); return 1; }
     g_gemm256_staging = staging;
@@ -938,6 +943,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
     e.row_scale = nullptr; e.col_scale = nullptr;
+    e.dbg = g_tune_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     if (p->ln_mode && (p->a_dtype == MSAM_FP8 || p->a_dtype == MSAM_F16)) { msam_set_error("msam_gemm_bf16(fp8 / fp16): no fused LayerNorm epilogue"); return 1; }
     const bool f16 = p->a_dtype == MSAM_F16;

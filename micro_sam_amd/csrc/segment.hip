@@ -5,9 +5,12 @@
 //   paint : the reference paints masks in area-descending order, later (smaller) masks overwrite earlier ones, so
 //           label(y,x) = rank+1 of the LAST mask in paint order that covers the pixel.  One thread per (32-row word,
 //           column): walks the masks from last to first, assigns the still-unassigned bits, stops when all 32 are done.
-//   label : label-equivalence union-find: L[i] = i; hook(L[L[i]] <- min over equal-valued neighbours) + pointer-jumping
-//           compression, iterated until no hook fires.  The root of a component is its smallest linear index, so
-//           sorting roots == raster order of each component's first pixel (numbering rule in DESIGN.md).
+//   label : label-equivalence union-find over block-major KEYS (common.h bm_key): hook (smaller key becomes the root) +
+//           pointer-jumping compression, iterated until no hook fires.  The root key of a component is its first pixel in the
+//           reference's labelling order (elf.parallel.label over 512 x 512 blocks), so ascending root keys == its numbering.
+//   overlap : contingency table between consecutive slices of a label volume (the nifty.ground_truth.overlap behind
+//           elf.tracking compute_edges_from_overlap, called by merge_instance_segmentation_3d,
+//           micro_sam/multi_dimensional_segmentation.py:357): a scatter-add into an open-addressing hash table.
 #include "common.h"
 #include "../../include/msam_hip.h"
 
@@ -41,14 +44,17 @@ __global__ __launch_bounds__(256) void paint_kernel(const uint32_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void cc_init_kernel(const int* __restrict__ seg, int n, int* __restrict__ L) {
+// L[p] (pixel-indexed) holds the KEY (common.h bm_key: block-major order = the reference's component numbering) of the parent of
+// pixel p's tree node, -1 for background; the node of key q lives at pixel bm_pix(q).  Keys order the unions (smaller key = root),
+// so a converged root key is the component's first pixel in block-major order.
+__global__ __launch_bounds__(256) void cc_init_kernel(const int* __restrict__ seg, int H, int W, int* __restrict__ L) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) L[i] = seg[i] != 0 ? i : -1;
+    if (i < H * W) L[i] = seg[i] != 0 ? bm_key(i, H, W) : -1;
 }
 
-__device__ __forceinline__ int cc_find(const int* L, int i) {
+__device__ __forceinline__ int cc_find(const int* L, int i, int H, int W) {       // root KEY of the tree that pixel i is in
     int r = L[i];
-    while (true) { const int p = L[r]; if (p == r) break; r = p; }
+    while (true) { const int p = L[bm_pix(r, H, W)]; if (p == r) break; r = p; }
     return r;
 }
 
@@ -64,10 +70,10 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const int* __restrict__ se
     for (int d = 0; d < 2; ++d) {
         const int j = d == 0 ? (x + 1 < W ? i + 1 : -1) : (y + 1 < H ? i + W : -1);
         if (j < 0 || seg[j] != v) continue;
-        int a = cc_find(L, i), b = cc_find(L, j);
-        while (a != b) {                       // union by smaller index (lock-free)
+        int a = cc_find(L, i, H, W), b = cc_find(L, j, H, W);
+        while (a != b) {                       // union by smaller key (lock-free)
             if (a < b) { const int t = a; a = b; b = t; }      // a > b
-            const int old = atomicMin(&L[a], b);
+            const int old = atomicMin(&L[bm_pix(a, H, W)], b);
             if (old == a) { any = 1; break; }
             a = old;                            // someone hooked a elsewhere: continue from there
             any = 1;
@@ -76,12 +82,12 @@ __global__ __launch_bounds__(256) void cc_hook_kernel(const int* __restrict__ se
     if (any) *changed = 1;
 }
 
-__global__ __launch_bounds__(256) void cc_compress_kernel(int n, int* L) {
+__global__ __launch_bounds__(256) void cc_compress_kernel(int H, int W, int* L) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && L[i] >= 0) L[i] = cc_find(L, i);
+    if (i < H * W && L[i] >= 0) L[i] = cc_find(L, i, H, W);
 }
 
-// Component sizes keyed by root index: sizes[root] += 1 for every foreground pixel.  A plain scatter-add puts hundreds
+// Component sizes keyed by root KEY: sizes[root key] += 1 for every foreground pixel.  A plain scatter-add puts hundreds
 // of thousands of atomics on the few addresses of the big components; here every workgroup first aggregates its 4096
 // pixels in an LDS open-addressing table (runs of equal roots are pre-summed per thread), then flushes one global
 // atomic per distinct root.
@@ -261,6 +267,70 @@ __global__ __launch_bounds__(256) void mask_nms_matrix_kernel(const uint32_t* __
     }
 }
 
+
+// ---- slice-to-slice overlap table.  Pair (a, b) = (labels[z][p], labels[z + 1][p]) with a != 0; key = a << 32 | b.
+// Every thread walks PER consecutive pixels and pre-sums runs of equal pairs, a workgroup aggregates its pairs in an LDS table,
+// then flushes one global update per distinct pair: objects are hundreds to thousands of pixels, so the global table sees a few
+// atomics per (object pair, workgroup) instead of one per pixel.
+typedef unsigned long long u64;
+constexpr u64 OV_EMPTY = ~0ull;
+__device__ __forceinline__ unsigned ov_hash(u64 k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; return (unsigned)k; }
+
+__device__ __forceinline__ void ov_global_add(u64* __restrict__ keys, int* __restrict__ counts, unsigned mask, u64 key, int c,
+                                              int* __restrict__ overflow) {
+    unsigned h = ov_hash(key) & mask;
+    for (unsigned probe = 0; probe <= mask; ++probe, h = (h + 1) & mask) {
+        const u64 prev = atomicCAS(&keys[h], OV_EMPTY, key);
+        if (prev == OV_EMPTY || prev == key) { atomicAdd(&counts[h], c); return; }
+        if (probe >= 4096) break;
+    }
+    atomicExch(overflow, 1);
+}
+
+__global__ __launch_bounds__(256) void overlap_count_kernel(const int* __restrict__ labels, long slice, long pairs_px,
+                                                            u64* __restrict__ keys, int* __restrict__ counts, unsigned mask,
+                                                            int* __restrict__ overflow) {
+    constexpr int TAB = 1024, PER = 16;
+    __shared__ u64 lk[TAB];
+    __shared__ int lv[TAB];
+    for (int i = threadIdx.x; i < TAB; i += 256) { lk[i] = OV_EMPTY; lv[i] = 0; }
+    __syncthreads();
+    auto flush = [&](u64 key, int c) {
+        if (c == 0) return;
+        unsigned h = ov_hash(key) & (TAB - 1);
+        for (int probe = 0; probe < 24; ++probe, h = (h + 1) & (TAB - 1)) {
+            const u64 prev = atomicCAS(&lk[h], OV_EMPTY, key);
+            if (prev == OV_EMPTY || prev == key) { atomicAdd(&lv[h], c); return; }
+        }
+        ov_global_add(keys, counts, mask, key, c, overflow);          // LDS table crowded
+    };
+    const long base = ((long)blockIdx.x * 256 + threadIdx.x) * PER;
+    u64 cur = OV_EMPTY; int cnt = 0;
+    for (int k = 0; k < PER; ++k) {
+        const long i = base + k;                                     // pixel of the stack [Z - 1, H * W]: slice pairs are contiguous
+        if (i >= pairs_px) break;
+        const int a = labels[i], b = labels[i + slice];
+        if (a == 0) { flush(cur, cnt); cur = OV_EMPTY; cnt = 0; continue; }
+        const u64 key = ((u64)(uint32_t)a << 32) | (u64)(uint32_t)b;
+        if (key == cur) ++cnt;
+        else { flush(cur, cnt); cur = key; cnt = 1; }
+    }
+    if (cur != OV_EMPTY) flush(cur, cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < TAB; i += 256)
+        if (lk[i] != OV_EMPTY) ov_global_add(keys, counts, mask, lk[i], lv[i], overflow);
+}
+
+// table -> (source, target, count) triples in arbitrary order; n_out[0] counts them (the caller sorts)
+__global__ __launch_bounds__(256) void overlap_compact_kernel(const u64* __restrict__ keys, const int* __restrict__ counts, unsigned cap,
+                                                              int* __restrict__ out, int max_out, int* __restrict__ n_out) {
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap || keys[i] == OV_EMPTY) return;
+    const int slot = atomicAdd(n_out, 1);
+    if (slot >= max_out) return;
+    out[3 * slot] = (int)(keys[i] >> 32); out[3 * slot + 1] = (int)(uint32_t)keys[i]; out[3 * slot + 2] = counts[i];
+}
+
 }  // namespace
 
 extern "C" int msam_box_nms_valid(const float* boxes_sorted, const int32_t* valid_sorted, int32_t K, float iou_threshold,
@@ -325,11 +395,11 @@ extern "C" int msam_label_components_async(const int32_t* seg, int32_t H, int32_
     if (!seg || !roots || !changed_flag || H <= 0 || W <= 0 || passes <= 0) { msam_set_error("msam_label_components_async: bad arguments"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     const int n = H * W, grid = (n + 255) / 256;
-    hipLaunchKernelGGL(cc_init_kernel, dim3(grid), dim3(256), 0, s, seg, n, roots);
+    hipLaunchKernelGGL(cc_init_kernel, dim3(grid), dim3(256), 0, s, seg, H, W, roots);
     for (int it = 0; it < passes; ++it) {
         if (hipMemsetAsync(changed_flag, 0, sizeof(int), s) != hipSuccess) { msam_set_error("msam_label_components_async: memset"); return 2; }
         hipLaunchKernelGGL(cc_hook_kernel, dim3(grid), dim3(256), 0, s, seg, H, W, roots, changed_flag);
-        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid), dim3(256), 0, s, n, roots);
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid), dim3(256), 0, s, H, W, roots);
     }
     return msam_check_launch("msam_label_components_async");
 }
@@ -339,14 +409,14 @@ extern "C" int msam_label_components(const int32_t* seg, int32_t H, int32_t W, i
     if (!seg || !roots || !changed_flag || H <= 0 || W <= 0) { msam_set_error("msam_label_components: bad arguments"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     const int n = H * W, grid = (n + 255) / 256;
-    hipLaunchKernelGGL(cc_init_kernel, dim3(grid), dim3(256), 0, s, seg, n, roots);
+    hipLaunchKernelGGL(cc_init_kernel, dim3(grid), dim3(256), 0, s, seg, H, W, roots);
     int it = 0;
     // the union loop inside cc_hook_kernel already merges whole trees, so one hook pass + compression is complete;
     // further passes only confirm convergence (changed == 0) - bounded by max_iters
     for (; it < (max_iters > 0 ? max_iters : 8); ++it) {
         if (hipMemsetAsync(changed_flag, 0, sizeof(int), s) != hipSuccess) { msam_set_error("msam_label_components: memset"); return 2; }
         hipLaunchKernelGGL(cc_hook_kernel, dim3(grid), dim3(256), 0, s, seg, H, W, roots, changed_flag);
-        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid), dim3(256), 0, s, n, roots);
+        hipLaunchKernelGGL(cc_compress_kernel, dim3(grid), dim3(256), 0, s, H, W, roots);
         int h = 0;
         if (hipMemcpyAsync(&h, changed_flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) { msam_set_error("msam_label_components: readback"); return 2; }
@@ -379,4 +449,31 @@ extern "C" int msam_mask_nms(const uint32_t* bits, const int32_t* order, const f
         hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), nblk * 8, s, (const unsigned long long*)mask_scratch, K,
                            (const int*)nullptr, keep_flags);
     return msam_check_launch("msam_mask_nms");
+}
+
+// Overlap table between consecutive slices (reference: elf.tracking.tracking_utilities.compute_edges_from_overlap ->
+// nifty.ground_truth.overlap per slice pair; micro_sam/multi_dimensional_segmentation.py:357).  labels: int32 [Z, H, W], ids consecutive
+// across z as _segment_slices leaves them.  table_keys: uint64 [capacity], table_counts: int32 [capacity] (capacity a power of two, at
+// least 4 x the number of distinct (object, object-or-background) pairs; both initialised here).  edges: int32 [max_edges, 3] =
+// (source id in slice z, target id in slice z + 1 (0 = background), overlapping pixels), unordered; n_edges: int32 [2] = {number of
+// edges found (may exceed max_edges: only max_edges are written), overflow flag (table too small)}.
+extern "C" int msam_slice_overlaps(const int32_t* labels, int32_t Z, int32_t H, int32_t W, uint64_t* table_keys, int32_t* table_counts,
+                                   int32_t capacity, int32_t* edges, int32_t max_edges, int32_t* n_edges, void* stream) {
+    if (!labels || !table_keys || !table_counts || !edges || !n_edges || Z < 1 || H <= 0 || W <= 0 || capacity < 1024 ||
+        (capacity & (capacity - 1)) || max_edges <= 0) {
+        msam_set_error("msam_slice_overlaps: bad arguments (capacity: a power of two >= 1024)");
+        return 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(table_keys, 0xff, (size_t)capacity * 8, s) != hipSuccess || hipMemsetAsync(table_counts, 0, (size_t)capacity * 4, s) != hipSuccess ||
+        hipMemsetAsync(n_edges, 0, 8, s) != hipSuccess) { msam_set_error("msam_slice_overlaps: memset failed"); return 2; }
+    if (Z >= 2) {
+        const long slice = (long)H * W, pairs_px = slice * (Z - 1);
+        const long per_wg = 256L * 16;
+        hipLaunchKernelGGL(overlap_count_kernel, dim3((unsigned)((pairs_px + per_wg - 1) / per_wg)), dim3(256), 0, s, labels, slice, pairs_px,
+                           (u64*)table_keys, table_counts, (unsigned)(capacity - 1), n_edges + 1);
+        hipLaunchKernelGGL(overlap_compact_kernel, dim3((capacity + 255) / 256), dim3(256), 0, s, (const u64*)table_keys, table_counts,
+                           (unsigned)capacity, edges, max_edges, n_edges);
+    }
+    return msam_check_launch("msam_slice_overlaps");
 }

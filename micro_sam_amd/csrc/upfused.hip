@@ -50,6 +50,13 @@ struct UpArgs {
 // Same formula as gelu_erf (common.h): max(x, 0) - |x| 2^cubic(|x|); the exponent's fp16 rounding (|q| <= 8 where the term
 // matters) adds <= 1.2e-4 absolute to the 5.5e-5 of the cubic, against an output rounding of 2^-11 relative.
 typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+// EXPM: 1 = 2^q through v_exp_f16 (quarter-rate transcendental, one per value); 3 = 2^q in packed full-rate arithmetic: q is clamped
+// to >= -13, split into r = round(q) (the fp16 magic-number add: q + 1536 has ulp 1) and f = q - r in [-1/2, 1/2], 2^f is a cubic
+// (3e-5 relative), and 2^r is added into the exponent field with packed 16-bit integer ops ((bits(q + 1536) << 10) mod 2^16 =
+// r << 10); the clamp leaves |x| 2^-13 <= 1e-3 instead of ~0 beyond |x| = 3.45, below half an fp16 ulp of the positive outputs there;
+// 2 = timing experiment only (no exponential at all: WRONG results, msam_tune_set("up_gelu16", 2)).
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+template <int EXPM>
 MSAM_DEVINL uint32_t gelu_pk_h(float x0, float x1) {
     const f32x2_t xf = {x0, x1};
     const h16x2_t x = __builtin_convertvector(xf, h16x2_t);
@@ -59,12 +66,28 @@ MSAM_DEVINL uint32_t gelu_pk_h(float x0, float x1) {
     h16x2_t q = t * (_Float16)-0.0248758f + (_Float16)-0.49884797f;
     q = q * t + (_Float16)-1.12922424f;
     q = q * t + (_Float16)-1.00353579f;
-    const h16x2_t e = {(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};
+    h16x2_t e;
+    if constexpr (EXPM == 2) {
+        e = q;
+    } else if constexpr (EXPM == 3) {
+        const h16x2_t lim = {(_Float16)-13.f, (_Float16)-13.f};
+        const h16x2_t qc = __builtin_elementwise_max(q, lim);
+        const h16x2_t sm = qc + (_Float16)1536.f;
+        const h16x2_t rr = sm - (_Float16)1536.f;
+        const h16x2_t f = qc - rr;
+        h16x2_t pz = f * (_Float16)0.0555041f + (_Float16)0.2402265f;
+        pz = pz * f + (_Float16)0.6931472f;
+        pz = pz * f + (_Float16)1.0f;
+        const u16x2_t sh = __builtin_bit_cast(u16x2_t, sm) << (unsigned short)10;
+        e = __builtin_bit_cast(h16x2_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, pz) + sh));
+    } else {
+        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};
+    }
     const h16x2_t g = r - t * e;
     return __builtin_bit_cast(uint32_t, g);
 }
 
-template <int UF_PRIO, bool G16>
+template <int UF_PRIO, int G16>
 __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
     __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
@@ -198,8 +221,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         for (int rt = 0; rt < 4; ++rt) {
             const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
             if (G16) {
-                g1w[rt][0] = gelu_pk_h(u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y);
-                g1w[rt][1] = gelu_pk_h(u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w);
+                g1w[rt][0] = gelu_pk_h<G16>(u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y);
+                g1w[rt][1] = gelu_pk_h<G16>(u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w);
             } else {
                 const f32x2_t g01 = gelu_erf2(f32x2_t{u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y});
                 const f32x2_t g23 = gelu_erf2(f32x2_t{u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w});
@@ -233,8 +256,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         // accuracy together with the hi + lo hyper weights; a bf16 operand would not)
         auto act2 = [&](int s2) {
             if (G16) {
-                gh[s2] = make_uint4(gelu_pk_h(ya[s2][0], ya[s2][1]), gelu_pk_h(ya[s2][2], ya[s2][3]),
-                                    gelu_pk_h(yb[s2][0], yb[s2][1]), gelu_pk_h(yb[s2][2], yb[s2][3]));
+                gh[s2] = make_uint4(gelu_pk_h<G16>(ya[s2][0], ya[s2][1]), gelu_pk_h<G16>(ya[s2][2], ya[s2][3]),
+                                    gelu_pk_h<G16>(yb[s2][0], yb[s2][1]), gelu_pk_h<G16>(yb[s2][2], yb[s2][3]));
                 return;
             }
             const f32x2_t a01 = gelu_erf2(f32x2_t{ya[s2][0], ya[s2][1]}), a23 = gelu_erf2(f32x2_t{ya[s2][2], ya[s2][3]});
@@ -324,13 +347,15 @@ extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked,
     const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
     msam_profile_mark2(stream, 1, flops, bytes, 4);
 #if MSAM_DEC_F16
-    if (g_tune_up_gelu16) {
-        if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, true>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((up_fused_kernel<0, true>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    if (g_tune_up_gelu16 == 2) hipLaunchKernelGGL((up_fused_kernel<1, 2>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else if (g_tune_up_gelu16 == 3) hipLaunchKernelGGL((up_fused_kernel<1, 3>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else if (g_tune_up_gelu16) {
+        if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((up_fused_kernel<0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     } else
 #endif
-    if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, false>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((up_fused_kernel<0, false>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((up_fused_kernel<0, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     msam_profile_mark2(stream, 0, flops, bytes, 4);
     return msam_check_launch("up_fused");
 }

@@ -177,8 +177,7 @@ def _records_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, sha
     painted = ops.paint_label_image(bits, order, h, w)
     roots = ops.label_components(painted).to(torch.int64)
     fg = roots >= 0
-    idx = torch.arange(h * w, device=dev)
-    is_root = fg & (roots == idx)
+    is_root = util._root_marks(roots)
     new_id = torch.cumsum(is_root.to(torch.int64), 0)
     labels = torch.where(fg, new_id[roots.clamp(min=0)], torch.zeros_like(roots))
     return labels.reshape(h, w).to(torch.int32).cpu().numpy().astype("uint32")

@@ -6,8 +6,14 @@
 contiguous block of slices per rank (one process per GPU) and assembles the volume with the two collectives of
 ``parallel.gather_label_tiles``; its result equals the serial loop's on every rank.
 
-The merge of the per-slice segmentations across z (``merge_instance_segmentation_3d``: overlap graph + multicut from the
-un-vendored ``elf`` / ``nifty``) is a host step on top of this output and is not part of this build.
+``merge_instance_segmentation_3d`` / ``automatic_3d_segmentation`` (reference :312-382, :419-481): the overlap
+of objects between consecutive slices is counted on the device (``ops.slice_overlaps``: one scatter-add pass over the label volume
+into a hash table in HBM), the graph problem on those few thousand edges is solved on the host.  The reference delegates both to
+un-vendored libraries (``elf.tracking.tracking_utilities.compute_edges_from_overlap`` -> ``nifty.ground_truth.overlap``;
+``elf.segmentation.multicut``), absent here: the edge list is restated from their published behaviour (score = overlap / size of the
+source object; edges to label 0 are not emitted), the costs follow the reference's own lines :365-373, and the multicut is solved by
+greedy additive edge contraction (the warm start of elf's default Kernighan-Lin solver) - PARITY UNPINNED for the solver: on overlap
+graphs of stacked slices (chains of near-1 and near-0 scores) both agree, in general a different local optimum is possible.
 
 ``segment_mask_in_volume`` (reference :105-233) is the interactive 3-d path: an object annotated in a few slices is
 carried through the volume slice by slice, each step one ``prompt_based_segmentation.segment_from_mask`` call (prompts
@@ -62,6 +68,183 @@ def segment_slices_sharded(data: np.ndarray, predictor, segmentor, verbose: bool
     dev = predictor.device if world > 1 and dist.get_backend() == "nccl" else "cpu"
     out = parallel.gather_label_tiles(torch.as_tensor(local, device=dev), data.shape[0])
     return out.cpu().numpy().astype("uint32")
+
+
+# ------------------------------------------------------------------------------------------ merge across z
+
+def compute_edges_from_overlap(segmentation: np.ndarray, device=None):
+    """``elf.tracking.tracking_utilities.compute_edges_from_overlap`` (called at reference :357): for every object of slice z and
+    every object of slice z + 1 that it overlaps, an edge {"source", "target", "score"} with score = overlapping pixels / pixels of
+    the source object (``overlapArraysNormalized``).  Counting runs on the device; returns (uv_ids int64 [E,2], scores float64 [E])
+    sorted by (source, target)."""
+    from . import ops
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    vol = torch.as_tensor(np.ascontiguousarray(segmentation).astype(np.int32, copy=False)).to(dev)
+    table = ops.slice_overlaps(vol)
+    return edges_from_overlap_table(table)
+
+
+def edges_from_overlap_table(table: np.ndarray):
+    """(source, target, pixels) rows incl. target 0 -> (uv_ids, scores): the source object's size is the sum of its row (its pixels
+    over background included), edges to the background are dropped."""
+    if len(table) == 0:
+        return np.zeros((0, 2), dtype=np.int64), np.zeros((0,), dtype=np.float64)
+    src, inv = np.unique(table[:, 0], return_inverse=True)
+    size = np.bincount(inv, weights=table[:, 2].astype(np.float64))
+    score = table[:, 2] / size[inv]
+    fg = table[:, 1] != 0
+    return table[fg, :2].astype(np.int64), score[fg]
+
+
+def compute_edge_costs(probs: np.ndarray, beta: float = 0.5) -> np.ndarray:
+    """``elf.segmentation.multicut.compute_edge_costs`` without weighting: log((1 - p) / p) + log((1 - beta) / beta), p clipped to
+    [0.001, 0.999]."""
+    p_min = 0.001
+    p = (1.0 - 2 * p_min) * np.asarray(probs, dtype=np.float64) + p_min
+    return np.log((1.0 - p) / p) + np.log((1.0 - beta) / beta)
+
+
+def multicut_gaec(n_nodes: int, uv_ids: np.ndarray, costs: np.ndarray) -> np.ndarray:
+    """Multicut by greedy additive edge contraction: repeatedly contract the edge with the largest positive cost, summing the costs
+    of parallel edges, until no positive edge is left (positive = attractive, as in elf / nifty).  Returns consecutive node labels
+    int64 [n_nodes] (label of node 0 first)."""
+    import heapq
+    adj = [dict() for _ in range(n_nodes)]
+    for (u, v), c in zip(uv_ids.tolist(), costs.tolist()):
+        if u == v:
+            continue
+        adj[u][v] = adj[u].get(v, 0.0) + c
+        adj[v][u] = adj[v].get(u, 0.0) + c
+    parent = list(range(n_nodes))
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    heap = [(-c, min(u, v), max(u, v)) for u in range(n_nodes) for v, c in adj[u].items() if u < v and c > 0]
+    heapq.heapify(heap)
+    alive = [True] * n_nodes
+    while heap:
+        negc, u, v = heapq.heappop(heap)
+        if not (alive[u] and alive[v]) or adj[u].get(v) != -negc:
+            continue                                        # stale entry
+        if len(adj[u]) < len(adj[v]):
+            u, v = v, u                                     # merge the smaller neighbourhood (v) into u
+        alive[v] = False
+        parent[v] = u
+        del adj[u][v]
+        for w, c in adj[v].items():
+            if w == u:
+                continue
+            del adj[w][v]
+            nc = adj[u].get(w, 0.0) + c
+            adj[u][w] = nc
+            adj[w][u] = nc
+            if nc > 0:
+                heapq.heappush(heap, (-nc, min(u, w), max(u, w)))
+        adj[v] = {}
+    roots = np.array([find(i) for i in range(n_nodes)], dtype=np.int64)
+    _, first = np.unique(roots, return_index=True)
+    order = np.argsort(first)                               # labels in order of the smallest node id of each cluster
+    lut = np.empty(len(order), dtype=np.int64)
+    lut[order] = np.arange(len(order))
+    return lut[np.searchsorted(np.sort(np.unique(roots)), roots)]
+
+
+def _relabel_sequential(seg: np.ndarray, offset: int = 1) -> np.ndarray:
+    """``skimage.segmentation.relabel_sequential(seg, offset)[0]``: non-zero labels -> offset, offset + 1, ... in ascending order."""
+    ids = np.unique(seg)
+    ids = ids[ids != 0]
+    lut = np.zeros(int(seg.max()) + 1, dtype=seg.dtype)
+    lut[ids] = np.arange(offset, offset + len(ids), dtype=seg.dtype)
+    return lut[seg]
+
+
+def _preprocess_closing(slice_segmentation: np.ndarray, gap_closing: int) -> np.ndarray:
+    """Reference :236-297: binary closing along z only; a closed object replaces the original ones unless it would merge more than
+    one of them; slices within ``gap_closing`` of either end are only renumbered."""
+    from scipy import ndimage
+    structure = np.zeros((3, 1, 1))
+    structure[:, 0, 0] = 1
+    closed = ndimage.binary_closing(slice_segmentation > 0, iterations=gap_closing, structure=structure)
+    out = np.zeros_like(slice_segmentation)
+    n_slices = out.shape[0]
+    offset = 1
+    for z in range(n_slices):
+        seg_z = slice_segmentation[z]
+        if z < gap_closing or z >= n_slices - gap_closing:
+            new = _relabel_sequential(seg_z, offset)
+            offset = int(new.max()) + 1
+            out[z] = new
+            continue
+        closed_z, n_closed = ndimage.label(closed[z], structure=np.ones((3, 3)))      # skimage.measure.label: full connectivity
+        pairs = np.unique(np.stack([closed_z.reshape(-1), seg_z.reshape(-1).astype(np.int64)], axis=1), axis=0)
+        pairs = pairs[(pairs[:, 0] != 0) & (pairs[:, 1] != 0)]
+        ids_initial, ids_closed = [], []
+        for cid in range(1, n_closed + 1):
+            matched = pairs[pairs[:, 0] == cid, 1]
+            if len(matched) > 1:
+                ids_initial.extend(matched.tolist())
+            else:
+                ids_closed.append(cid)
+        new = np.zeros_like(seg_z)
+        cm = np.isin(closed_z, ids_closed)
+        new[cm] = closed_z[cm]
+        if ids_initial:
+            im = np.isin(seg_z, ids_initial)
+            new[im] = _relabel_sequential(seg_z[im], offset=int(new.max()) + 1)
+        new = _relabel_sequential(new, offset)
+        if new.max() > 0:
+            offset = int(new.max()) + 1
+        out[z] = new
+    return out
+
+
+def _filter_z_extent(segmentation: np.ndarray, min_z_extent: int) -> np.ndarray:
+    """Reference :300-309: drop objects that span fewer than ``min_z_extent`` slices."""
+    from scipy import ndimage
+    drop = [i + 1 for i, sl in enumerate(ndimage.find_objects(segmentation)) if sl is not None and sl[0].stop - sl[0].start < min_z_extent]
+    if drop:
+        segmentation[np.isin(segmentation, drop)] = 0
+    return segmentation
+
+
+def merge_instance_segmentation_3d(slice_segmentation: np.ndarray, beta: float = 0.5, with_background: bool = True,
+                                   gap_closing: Optional[int] = None, min_z_extent: Optional[int] = None, verbose: bool = False,
+                                   device=None) -> np.ndarray:
+    """Reference :312-382: objects of consecutive slices are nodes joined by their normalised overlap; edge costs
+    ``compute_edge_costs(overlap)``, the multicut is solved on ``1 - costs`` (reference :365-373: a large overlap is attractive) and
+    every slice object takes its cluster's label.  ``with_background``: edges that touch label 0 are maximally repulsive (none is
+    emitted here: the background is not a node).  ``beta`` is accepted as in the reference, which hands it to the solver call only."""
+    if gap_closing is not None and gap_closing > 0:
+        slice_segmentation = _preprocess_closing(slice_segmentation, gap_closing)
+    uv_ids, overlaps = compute_edges_from_overlap(slice_segmentation, device=device)
+    if len(uv_ids) == 0:
+        return slice_segmentation
+    n_nodes = int(slice_segmentation.max()) + 1
+    costs = compute_edge_costs(overlaps)
+    if with_background:
+        costs[(uv_ids == 0).any(axis=1)] = -8.0
+    node_labels = multicut_gaec(n_nodes, uv_ids, 1.0 - costs)
+    if node_labels[0] != 0:                                 # keep the background at label 0
+        node_labels = np.where(node_labels == node_labels[0], 0, np.where(node_labels < node_labels[0], node_labels + 1, node_labels))
+    segmentation = node_labels[slice_segmentation].astype(slice_segmentation.dtype)
+    if min_z_extent is not None and min_z_extent > 0:
+        segmentation = _filter_z_extent(segmentation, min_z_extent)
+    return segmentation
+
+
+def automatic_3d_segmentation(volume: np.ndarray, predictor, segmentor, embedding_path=None, with_background: bool = True,
+                              gap_closing: Optional[int] = None, min_z_extent: Optional[int] = None,
+                              tile_shape: Optional[Tuple[int, int]] = None, halo: Optional[Tuple[int, int]] = None,
+                              verbose: bool = False, return_embeddings: bool = False, batch_size: int = 1, **kwargs):
+    """Reference :419-481: per-slice segmentation (``segment_slices``) merged across z (``merge_instance_segmentation_3d``)."""
+    segmentation, image_embeddings = segment_slices(volume, predictor, segmentor, embedding_path=embedding_path, verbose=verbose,
+                                                    tile_shape=tile_shape, halo=halo, batch_size=batch_size, **kwargs)
+    segmentation = merge_instance_segmentation_3d(segmentation, beta=0.5, with_background=with_background, gap_closing=gap_closing,
+                                                  min_z_extent=min_z_extent, verbose=verbose, device=predictor.device)
+    return (segmentation, image_embeddings) if return_embeddings else segmentation
 
 
 # ------------------------------------------------------------------------------------------ interactive 3-d projection

@@ -310,8 +310,10 @@ def paint_label_image(bits: torch.Tensor, order: torch.Tensor, height: int, widt
 
 
 def label_components(seg: torch.Tensor) -> torch.Tensor:
-    """4-connected components of equal non-zero value of an int32 [H,W] image: root (smallest linear index) per pixel,
-    -1 for background, int32 [H*W]."""
+    """4-connected components of equal non-zero value of an int32 [H,W] image: per pixel the KEY of its component's root,
+    -1 for background, int32 [H*W].  Keys are positions in block-major order (512 x 512 blocks in raster order, raster order inside
+    a block: csrc/common.h bm_key) and the root is the component's smallest key - so ascending root keys are the component numbers
+    of the reference's ``elf.parallel.label(block_shape=(512, 512))`` (util.py:1834); for H, W <= 512 a key is the linear index."""
     h, w = seg.shape
     seg = seg.contiguous()
     roots = torch.empty((h * w,), dtype=torch.int32, device=seg.device)
@@ -465,6 +467,34 @@ def label_components_async(seg: torch.Tensor, passes: int = 2):
     _lib.check(_lib.load().msam_label_components_async(seg.data_ptr(), h, w, roots.data_ptr(), flag.data_ptr(), passes,
                                                        _lib.stream_ptr()), "msam_label_components_async")
     return roots, flag
+
+
+def slice_overlaps(labels: torch.Tensor) -> np.ndarray:
+    """Overlap table between consecutive slices of a device label volume int32 [Z,H,W] (ids consecutive across z):
+    int64 [E, 3] rows (source id in slice z, target id in slice z + 1 - 0 = background -, overlapping pixels), sorted by
+    (source, target).  The scatter-add of ``nifty.ground_truth.overlap`` behind the reference's ``compute_edges_from_overlap``
+    (multi_dimensional_segmentation.py:357) as an open-addressing hash table in HBM (msam_slice_overlaps); the table is
+    enlarged and the pass repeated when it overflows."""
+    _lib.require_gpu(labels.device)
+    assert labels.dim() == 3 and labels.dtype == torch.int32
+    labels = labels.contiguous()
+    z, h, w = labels.shape
+    cap, max_edges = 1 << 18, 1 << 17
+    while True:
+        keys = torch.empty((cap,), dtype=torch.int64, device=labels.device)
+        counts = torch.empty((cap,), dtype=torch.int32, device=labels.device)
+        edges = torch.empty((max_edges, 3), dtype=torch.int32, device=labels.device)
+        n = torch.empty((2,), dtype=torch.int32, device=labels.device)
+        _lib.check(_lib.load().msam_slice_overlaps(labels.data_ptr(), z, h, w, keys.data_ptr(), counts.data_ptr(), cap, edges.data_ptr(),
+                                                   max_edges, n.data_ptr(), _lib.stream_ptr()), "msam_slice_overlaps")
+        n_edges, overflow = (int(v) for v in n.cpu().tolist())
+        if not overflow and n_edges <= max_edges and 4 * n_edges <= cap:
+            break
+        if cap >= 1 << 28:
+            raise RuntimeError("slice_overlaps: more than 2^26 distinct overlapping pairs")
+        cap, max_edges = cap * 4, max_edges * 4
+    e = edges[:n_edges].cpu().numpy().astype(np.int64)
+    return e[np.lexsort((e[:, 1], e[:, 0]))] if n_edges else e.reshape(0, 3)
 
 
 def component_sizes(roots: torch.Tensor):

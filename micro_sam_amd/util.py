@@ -627,11 +627,22 @@ def compute_iou(mask1: np.ndarray, mask2: np.ndarray) -> float:
 
 # ------------------------------------------------------------------------------------------------ label image
 
-def _label_equal_value_components(seg: np.ndarray) -> np.ndarray:
-    """4-connected components of equal non-zero value, numbered in raster order of their first pixel
-    (``elf.parallel.label`` in the reference util.py:1834; numbering rule documented in DESIGN.md).
+def _block_major_keys(h: int, w: int, block: int = 512) -> np.ndarray:
+    """Position of every pixel in block-major order (blocks of ``block`` x ``block`` in raster order, raster order inside a block):
+    the order in which ``elf.parallel.label(block_shape=(512, 512))`` meets the pixels (csrc/common.h bm_key on the device)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    by, bx = yy // block, xx // block
+    bh, bw = np.minimum(block, h - by * block), np.minimum(block, w - bx * block)
+    return (by * block) * w + (bx * block) * bh + (yy % block) * bw + (xx % block)
 
-    Components are found on the (2H-1)x(2W-1) pixel/link lattice with scipy's binary labelling."""
+
+def _label_equal_value_components(seg: np.ndarray) -> np.ndarray:
+    """4-connected components of equal non-zero value, numbered the way the reference's ``elf.parallel.label(segmentation,
+    block_shape=(512, 512))`` (util.py:1834-1838) numbers them: 512 x 512 blocks are labelled one by one in raster order with a
+    running offset, united across block faces and made consecutive by first occurrence - a component's id is the rank of its first
+    pixel in block-major order (plain raster order for images of up to 512 x 512).
+
+    Components are found on the (2H-1)x(2W-1) pixel/link lattice with scipy's binary labelling, then renumbered."""
     from scipy import ndimage
     h, w = seg.shape
     lat = np.zeros((2 * h - 1, 2 * w - 1), dtype=bool)
@@ -639,8 +650,15 @@ def _label_equal_value_components(seg: np.ndarray) -> np.ndarray:
     lat[::2, ::2] = fg
     lat[::2, 1::2] = fg[:, 1:] & (seg[:, 1:] == seg[:, :-1])
     lat[1::2, ::2] = fg[1:, :] & (seg[1:, :] == seg[:-1, :])
-    lab, _ = ndimage.label(lat)           # default structure: 4-connectivity; labels in raster order
-    return lab[::2, ::2].astype(seg.dtype)
+    lab, n = ndimage.label(lat)           # default structure: 4-connectivity; labels in raster order
+    lab = lab[::2, ::2]
+    if n and (h > 512 or w > 512):
+        first = ndimage.minimum(_block_major_keys(h, w), lab, index=np.arange(1, n + 1))    # first block-major position per component
+        rank = np.empty(n + 1, dtype=np.int64)
+        rank[0] = 0
+        rank[1 + np.argsort(first, kind="stable")] = np.arange(1, n + 1)
+        lab = rank[lab]
+    return lab.astype(seg.dtype)
 
 
 def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape: Optional[Tuple[int, int]] = None,
@@ -827,13 +845,23 @@ def apply_nms(predictions: List[Dict[str, Any]], min_size: int, shape: Optional[
     return mask_data_to_segmentation(records, shape=shape, min_object_size=min_size)
 
 
+def _root_marks(roots: torch.Tensor) -> torch.Tensor:
+    """``ops.label_components`` gives every pixel the KEY of its component's root (-1: background; keys = positions in the
+    reference's block-major numbering order, csrc/common.h bm_key).  Returns bool [n]: True at the keys that are roots - no
+    data-dependent shape, no host synchronisation."""
+    marks = torch.zeros(roots.numel() + 1, dtype=torch.bool, device=roots.device)
+    marks[roots + 1] = True
+    return marks[1:]
+
+
 def mask_data_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, shape: Tuple[int, int],
                                      min_object_size: int = 0, with_background: bool = False) -> np.ndarray:
     """``mask_data_to_segmentation(..., label_masks=True, merge_exclusively=False)`` (reference util.py:1773-1848) computed
     on the device from bit masks [K, ceil(H/32), W] and their areas [K]; returns the uint32 label image on the host.
 
     Same semantics as the host function above: stable area-descending paint order, later masks overwrite, 4-connected
-    components of equal value numbered in raster order of their first pixel, drop components smaller than
+    components of equal value numbered as ``elf.parallel.label(block_shape=(512, 512))`` numbers them (block by block, raster
+    order of the first pixel inside a block: csrc/common.h bm_key), drop components smaller than
     ``min_object_size`` and (``with_background``) the largest one counting label 0, relabel consecutively."""
     from . import ops
     h, w = int(shape[0]), int(shape[1])
@@ -847,9 +875,8 @@ def mask_data_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, sh
     painted = ops.paint_label_image(bits, order, h, w)
     roots = ops.label_components(painted).to(torch.int64)
     fg = roots >= 0
-    idx = torch.arange(h * w, device=dev)
-    is_root = fg & (roots == idx)
-    comp_of_root = torch.cumsum(is_root.to(torch.int64), 0)                  # 1..C at root positions (raster order)
+    is_root = _root_marks(roots)
+    comp_of_root = torch.cumsum(is_root.to(torch.int64), 0)                  # 1..C at the root keys (the reference's block-major order)
     cid = torch.where(fg, comp_of_root[roots.clamp(min=0)], torch.zeros_like(roots))
     n_comp = int(comp_of_root[-1].item())
     sizes = torch.bincount(cid, minlength=n_comp + 1)
@@ -892,15 +919,15 @@ def masks_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, keep: 
     sizes32, bg32 = ops.component_sizes(roots32)
     sizes = sizes32.to(torch.int64)
     idx = torch.arange(h * w, device=dev)
-    is_root = fg & (roots == idx)
+    is_root = _root_marks(roots)
     keep_root = is_root & (sizes >= min_object_size)
     if with_background:
         bg_size = bg32[0].to(torch.int64)
-        best = torch.argmax(sizes)                          # first maximum = smallest root index = smallest component id
+        best = torch.argmax(sizes)                          # first maximum = smallest root key = smallest component id
         # NB: ``sizes[best]`` with a 0-dim index tensor is an ``item()`` call = a host synchronisation (measured: the host
         # waited for the whole decode of the tile here); the value at the first maximum is the maximum
         drop_component = sizes.max() > bg_size              # label 0 wins ties (it is the smallest id)
         keep_root = keep_root & ~((idx == best) & drop_component)
-    new_id = torch.cumsum(keep_root.to(torch.int64), 0) * keep_root      # consecutive ids in raster order of the roots
+    new_id = torch.cumsum(keep_root.to(torch.int64), 0) * keep_root      # consecutive ids in ascending order of the root keys
     labels = torch.where(fg, new_id[safe_roots], torch.zeros_like(roots))
     return labels.reshape(h, w).to(torch.int32), flag

@@ -20,12 +20,19 @@ Pinned by the reference's known-answer tests (tests/test_oracle_amg.py): box of 
 ``[3,7,4,8]`` (test/test_vendored.py:12-25); ``sum(counts) == H*W`` and RLE round trip
 (test/test_vendored.py:63-78).
 
-PARITY UNPINNED for one thing: the *numbering* of connected components produced by
-``elf.parallel.label`` (block-wise labelling + union-find merge; elf / nifty are not in the container and
-the reference's tests are permutation invariant).  This oracle numbers components in
-raster order of their first pixel (what ``skimage.measure.label`` yields for a single block, i.e. for
-every image up to 512x512 such as the reference's own test fixtures).  4-connectivity, components are
-regions of equal non-zero value.
+The *numbering* of connected components follows ``elf.parallel.label`` (python-elf >= 0.9, ``setup.cfg:55``; absent from the
+container, so restated from its published algorithm, ``elf/parallel/label.py``): (1) every block of ``block_shape`` - (512, 512) at
+the call site ``micro_sam/util.py:1834-1838`` - is labelled on its own with ``skimage.measure.label`` (components of equal non-zero
+value, 4-connectivity, numbered in raster order of their first pixel), (2) block b's labels are shifted by the running sum of the
+maximal labels of the blocks before it (block raster order), (3) labels that touch across a block face with equal input value
+are united (union-find), (4) the united labelling is made consecutive in order of FIRST OCCURRENCE over the ascending provisional
+labels (``vigra.analysis.relabelConsecutive(ufd.find(arange), keep_zeros=True)``), which makes the outcome independent of the
+union-find's choice of representatives: a component's id is the rank of its smallest provisional label.
+``label_components_literal`` is that procedure step by step; ``label_components`` is its closed form (rank of the component's first
+pixel in block-major order) and the two are compared on random label images incl. ragged block grids (tests/test_oracle_amg.py).
+For an image of up to 512 x 512 (one block: the reference's own test fixtures) this is plain raster order.  elf / nifty / vigra are
+not importable here and the reference's tests are permutation invariant: the scheme is pinned to the published
+algorithm, not to a run of the library.
 """
 from __future__ import annotations
 
@@ -313,19 +320,29 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 # elf.parallel.{label, unique, isin, relabel_consecutive} + util.mask_data_to_segmentation
 # ----------------------------------------------------------------------------------------------
 
-def label_components(seg: np.ndarray) -> np.ndarray:
-    """Connected components (4-connectivity) of equal non-zero value, numbered 1.. in raster order of
-    each component's first pixel.  (Numbering rule: see module docstring - parity unpinned.)"""
+LABEL_BLOCK = 512          # block_shape of the reference's elf.parallel.label call (micro_sam/util.py:1834)
+
+
+def block_major_keys(h: int, w: int, block: int = LABEL_BLOCK) -> np.ndarray:
+    """int64 [h, w]: position of every pixel in block-major order (blocks in raster order, raster order inside a block)."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    by, bx = yy // block, xx // block
+    bh = np.minimum(block, h - by * block)
+    bw = np.minimum(block, w - bx * block)
+    return (by * block) * w + (bx * block) * bh + (yy % block) * bw + (xx % block)
+
+
+def label_components(seg: np.ndarray, block: int = LABEL_BLOCK) -> np.ndarray:
+    """Connected components (4-connectivity) of equal non-zero value, numbered 1.. as ``elf.parallel.label(block_shape=(512, 512))``
+    numbers them (module docstring): by the block-major position of each component's first pixel."""
     h, w = seg.shape
     n = h * w
-    flat = seg.reshape(-1)
-    parent = np.arange(n, dtype=np.int64)
-    # iterative min-label propagation with pointer jumping (vectorised union-find)
-    idx = np.arange(n, dtype=np.int64).reshape(h, w)
+    key = block_major_keys(h, w, block)
+    parent = np.arange(n, dtype=np.int64)                  # union-find over KEYS: the smaller key is the root
     right = (seg[:, 1:] == seg[:, :-1]) & (seg[:, 1:] != 0)
     down = (seg[1:, :] == seg[:-1, :]) & (seg[1:, :] != 0)
-    ea = np.concatenate([idx[:, :-1][right], idx[:-1, :][down]])
-    eb = np.concatenate([idx[:, 1:][right], idx[1:, :][down]])
+    ea = np.concatenate([key[:, :-1][right], key[:-1, :][down]])
+    eb = np.concatenate([key[:, 1:][right], key[1:, :][down]])
     while True:
         pa, pb = parent[ea], parent[eb]
         lo = np.minimum(pa, pb)
@@ -339,12 +356,52 @@ def label_components(seg: np.ndarray) -> np.ndarray:
             if (pp == parent).all():
                 break
             parent = pp
-    roots = parent
+    roots = parent[key.reshape(-1)]      # per pixel: key of its component's first pixel
+    flat = seg.reshape(-1)
     out = np.zeros(n, dtype=seg.dtype)
     fg = flat != 0
-    root_ids = np.unique(roots[fg])      # sorted == raster order of the first pixel
+    root_ids = np.unique(roots[fg])      # ascending keys == the reference's numbering order
     out[fg] = (np.searchsorted(root_ids, roots[fg]) + 1).astype(seg.dtype)
     return out.reshape(h, w)
+
+
+def label_components_literal(seg: np.ndarray, block: int = LABEL_BLOCK) -> np.ndarray:
+    """``elf.parallel.label`` step by step (module docstring): per-block labels with running offsets, union across block faces,
+    consecutive relabelling in order of first occurrence over the provisional labels.  Slow; the check of ``label_components``."""
+    h, w = seg.shape
+    prov = np.zeros((h, w), dtype=np.int64)
+    offset = 0
+    for y0 in range(0, h, block):                          # (1) + (2): block raster order
+        for x0 in range(0, w, block):
+            sub = label_components(seg[y0:y0 + block, x0:x0 + block], block=1 << 30).astype(np.int64)      # one block: raster order
+            prov[y0:y0 + block, x0:x0 + block] = np.where(sub != 0, sub + offset, 0)
+            offset += int(sub.max())
+    parent = list(range(offset + 1))                       # (3): deliberately NOT union-by-minimum - any representative will do
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    def faces(la, lb, va, vb):
+        for a, b in {(int(a), int(b)) for a, b, x, y in zip(la, lb, va, vb) if a != 0 and b != 0 and x == y}:
+            ra, rb = find(a), find(b)
+            if ra != rb:
+                parent[min(ra, rb) if (ra + rb) % 2 else max(ra, rb)] = max(ra, rb) if (ra + rb) % 2 else min(ra, rb)
+    for y0 in range(block, h, block):
+        faces(prov[y0 - 1], prov[y0], seg[y0 - 1], seg[y0])
+    for x0 in range(block, w, block):
+        faces(prov[:, x0 - 1], prov[:, x0], seg[:, x0 - 1], seg[:, x0])
+    mapping, nxt = {0: 0}, 1                               # (4): first occurrence over ascending provisional labels
+    lut = np.zeros(offset + 1, dtype=np.int64)
+    for lab in range(1, offset + 1):
+        r = find(lab)
+        if r not in mapping:
+            mapping[r] = nxt
+            nxt += 1
+        lut[lab] = mapping[r]
+    return lut[prov].astype(seg.dtype)
 
 
 def mask_data_to_segmentation(masks: List[Dict[str, Any]], shape=None, min_object_size: int = 0,

@@ -21,7 +21,7 @@ def _random_masks(rng, n, h, w):
     return out
 
 
-@pytest.mark.parametrize("shape,n", [((64, 96), 5), ((300, 200), 40), ((1024, 1024), 200), ((1024, 1024), 0)])
+@pytest.mark.parametrize("shape,n", [((64, 96), 5), ((300, 200), 40), ((1024, 1024), 200), ((1024, 1024), 0), ((700, 1100), 120)])
 @pytest.mark.parametrize("with_background", [True, False])
 def test_mask_data_to_segmentation_device(shape, n, with_background):
     _gpu()
@@ -49,7 +49,8 @@ def test_label_components_worst_cases():
     from micro_sam_amd import ops
     from oracle import amg_ref as A
     rng = np.random.default_rng(0)
-    cases = [rng.integers(0, 3, size=(257, 130)), np.ones((64, 64), dtype=int), np.zeros((33, 17), dtype=int)]
+    cases = [rng.integers(0, 3, size=(257, 130)), np.ones((64, 64), dtype=int), np.zeros((33, 17), dtype=int),
+             rng.integers(0, 3, size=(600, 700)), np.ones((1030, 520), dtype=int)]          # more than one 512 x 512 block
     spiral = np.zeros((101, 101), dtype=int)                # one long snake: deep union-find chains
     spiral[::2, :] = 1; spiral[1::4, -1] = 1; spiral[3::4, 0] = 1
     cases.append(spiral)
@@ -58,11 +59,13 @@ def test_label_components_worst_cases():
         ref = A.label_components(seg.astype("uint32"))
         fg = seg.reshape(-1) != 0
         assert (roots[~fg] == -1).all()
-        # same partition, and every root is the smallest linear index of its component
+        # same partition in the reference's numbering order (ascending root keys), and every root key is the smallest block-major
+        # key of its component (csrc/common.h bm_key; = the linear index for a single 512 x 512 block)
         _, inv = np.unique(roots[fg], return_inverse=True)
         assert np.array_equal(inv + 1, ref.reshape(-1)[fg])
-        idx = np.arange(seg.size)[fg]
-        assert (roots[fg] <= idx).all() and (roots[roots[fg]] == roots[fg]).all()
+        keys = A.block_major_keys(*seg.shape).reshape(-1)
+        pix_of_key = np.argsort(keys)
+        assert (roots[fg] <= keys[fg]).all() and (roots[pix_of_key[roots[fg]]] == roots[fg]).all()
 
 
 @pytest.mark.parametrize("k", [1, 63, 64, 65, 700, 3072])
@@ -157,3 +160,36 @@ def test_apply_nms_matches_oracle(mode):
     assert got.shape == (h, w) and got.dtype == np.uint32 and got.max() > 5
     assert np.array_equal(got, ref)
     assert np.array_equal(util.apply_nms([dict(p) for p in preds], max_size=400, **kw), A.apply_nms([dict(p) for p in preds], max_size=400, **kw))
+
+
+def test_slice_overlaps_and_merge_3d():
+    """ops.slice_overlaps (msam_slice_overlaps: scatter-add of consecutive-slice label pairs into a hash table in HBM) == the numpy
+    contingency table, incl. pairs with the background and an object that spans two 512-row halves; then the reference's own merge
+    tests (test/test_multi_dimensional_segmentation.py:15-66) through merge_instance_segmentation_3d with the device counter."""
+    _gpu()
+    from scipy import ndimage
+    from micro_sam_amd import multi_dimensional_segmentation as M
+    from micro_sam_amd import ops
+    from test_merge_3d_host import _blobs, _stack, numpy_overlap_table      # tests/ is on sys.path (pytest prepend import mode)
+    rng = np.random.default_rng(3)
+    vol = np.zeros((6, 300, 520), dtype=np.int32)
+    offset = 0
+    for z in range(6):
+        lab = ndimage.label(ndimage.gaussian_filter(rng.random((300, 520)), 3) > 0.52)[0]
+        lab[lab != 0] += offset
+        offset = max(offset, int(lab.max()))
+        vol[z] = lab
+    got = ops.slice_overlaps(torch.as_tensor(vol).cuda())
+    ref = numpy_overlap_table(vol)
+    assert got.shape == ref.shape and np.array_equal(got, ref) and (ref[:, 1] == 0).any()
+    assert ops.slice_overlaps(torch.as_tensor(vol[:1]).cuda()).shape == (0, 3)            # a single slice: no pairs
+    seg = _blobs(0, 512)
+    stacked = _stack(seg, 5)
+    merged = M.merge_instance_segmentation_3d(stacked)
+    ids0 = np.unique(merged[0])
+    assert len(ids0) > 10
+    for z in range(1, 5):
+        assert np.array_equal(ids0, np.unique(merged[z]))
+    merged = M.merge_instance_segmentation_3d(_stack(seg, 5, blank=(2,)), gap_closing=1)
+    for z in range(1, 5):
+        assert np.array_equal(np.unique(merged[0]), np.unique(merged[z]))

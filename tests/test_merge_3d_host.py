@@ -1,0 +1,87 @@
+"""merge_instance_segmentation_3d (reference micro_sam/multi_dimensional_segmentation.py:236-382), host half: edge scores from an
+overlap table, edge costs, the greedy-additive-edge-contraction multicut, gap closing, z-extent filter.  The two checks of the
+reference's own test (test/test_multi_dimensional_segmentation.py:15-66: stacked identical slices merge completely, with and without an
+empty middle slice closed by gap_closing) run here with the overlap table counted in numpy; the device counter is compared with the same
+numpy table in tests/test_gpu_segment.py."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from micro_sam_amd import multi_dimensional_segmentation as M
+
+
+def numpy_overlap_table(vol):
+    rows = []
+    for z in range(vol.shape[0] - 1):
+        a, b = vol[z].reshape(-1).astype(np.int64), vol[z + 1].reshape(-1).astype(np.int64)
+        m = a != 0
+        if m.any():
+            pr, c = np.unique(np.stack([a[m], b[m]], 1), axis=0, return_counts=True)
+            rows.append(np.concatenate([pr, c[:, None]], 1))
+    if not rows:
+        return np.zeros((0, 3), dtype=np.int64)
+    t = np.concatenate(rows)
+    return t[np.lexsort((t[:, 1], t[:, 0]))]
+
+
+@pytest.fixture()
+def host_overlaps(monkeypatch):
+    monkeypatch.setattr(M, "compute_edges_from_overlap", lambda seg, device=None: M.edges_from_overlap_table(numpy_overlap_table(seg)))
+
+
+def _blobs(seed=0, n=256):
+    rng = np.random.default_rng(seed)
+    return ndimage.label(ndimage.gaussian_filter(rng.random((n, n)), 4) > 0.5)[0]
+
+
+def _stack(seg, n_slices, blank=()):
+    out, offset = [], 0
+    for z in range(n_slices):
+        if z in blank:
+            out.append(np.zeros_like(seg))
+            continue
+        s = seg.copy()
+        s[s != 0] += offset
+        offset = s.max()
+        out.append(s)
+    return np.stack(out).astype(np.uint32)
+
+
+def test_stacked_slices_merge_completely(host_overlaps):
+    vol = _stack(_blobs(), 5)
+    merged = M.merge_instance_segmentation_3d(vol)
+    ids0 = np.unique(merged[0])
+    assert len(ids0) > 10 and ids0[0] == 0
+    for z in range(1, 5):
+        assert np.array_equal(ids0, np.unique(merged[z]))
+    assert np.array_equal(merged[0] != 0, vol[0] != 0)
+
+
+def test_gap_closing_bridges_an_empty_slice(host_overlaps):
+    vol = _stack(_blobs(1), 5, blank=(2,))
+    merged = M.merge_instance_segmentation_3d(vol, gap_closing=1)
+    ids0 = np.unique(merged[0])
+    for z in range(1, 5):
+        assert np.array_equal(ids0, np.unique(merged[z]))
+    plain = M.merge_instance_segmentation_3d(vol)                       # without closing the gap splits every object in two
+    assert len(np.unique(plain)) > len(ids0)
+
+
+def test_scores_costs_and_contraction():
+    # object 1 (100 px): 90 over object 3, 10 over background; object 2 (50 px): 5 over object 3, 45 over object 4
+    table = np.array([[1, 0, 10], [1, 3, 90], [2, 3, 5], [2, 4, 45]])
+    uv, score = M.edges_from_overlap_table(table)
+    assert uv.tolist() == [[1, 3], [2, 3], [2, 4]] and np.allclose(score, [0.9, 0.1, 0.9])
+    costs = M.compute_edge_costs(score)
+    assert np.allclose(costs, np.log((1 - (0.998 * score + 0.001)) / (0.998 * score + 0.001)))
+    lab = M.multicut_gaec(5, uv, 1.0 - costs)
+    assert lab[1] == lab[3] and lab[2] == lab[4] and lab[1] != lab[2] and lab[0] == 0 and len(set(lab.tolist())) == 3
+    # a repulsive edge is never contracted, even through a chain of attractive ones whose sum stays negative
+    lab = M.multicut_gaec(3, np.array([[0, 1], [1, 2], [0, 2]]), np.array([2.0, 2.0, -5.0]))
+    assert len(set(lab.tolist())) == 2
+    # z-extent filter
+    vol = np.zeros((4, 8, 8), dtype=np.uint32)
+    vol[0:3, :4] = 1; vol[1, 5:] = 2
+    out = M._filter_z_extent(vol.copy(), 2)
+    assert (out == 1).sum() == (vol == 1).sum() and not (out == 2).any()
+    assert M._relabel_sequential(np.array([[0, 7, 7], [3, 0, 9]]), 5).tolist() == [[0, 6, 6], [5, 0, 7]]

@@ -136,3 +136,33 @@ def test_apply_nms_tiled_known_answer_and_mask_nms():
     # box NMS variant goes through the same torchvision-style batched_nms as the AMG path
     seg_box = A.apply_nms([rec(a, 0.9), rec(b, 0.8), rec(c, 0.7)], min_size=0, perform_box_nms=True, nms_thresh=0.7)
     assert seg_box.max() == 2
+
+
+def test_component_numbering_follows_the_blockwise_label_of_the_reference():
+    """micro_sam/util.py:1834-1838 labels with elf.parallel.label(block_shape=(512, 512)): per-block labels with running offsets,
+    union across faces, consecutive by first occurrence.  The oracle's closed form (rank of the first pixel in block-major order)
+    equals that procedure restated step by step - on ragged block grids too - and the product's host function follows it; on images
+    of more than one block it differs from plain raster numbering."""
+    from micro_sam_amd import util
+    rng = np.random.default_rng(0)
+    differs = 0
+    for (h, w, blk) in [(40, 52, 16), (33, 47, 16), (64, 64, 16), (20, 20, 32), (50, 30, 8), (17, 70, 16)]:
+        for dens in (2, 4):
+            seg = rng.integers(0, dens, size=(h, w)).astype(np.uint32)
+            closed = A.label_components(seg, block=blk)
+            assert np.array_equal(closed, A.label_components_literal(seg, block=blk)), (h, w, blk)
+            raster = A.label_components(seg, block=1 << 30)
+            assert closed.max() == raster.max() and np.array_equal(closed != 0, raster != 0)
+            differs += int(not np.array_equal(closed, raster))
+    assert differs >= 8
+    # the reference's block size on an image of 2 x 3 blocks (ragged): the product's host function == the oracle
+    seg = np.zeros((700, 1100), dtype=np.uint32)
+    yy, xx = np.mgrid[0:700, 0:1100]
+    for k in range(60):
+        cy, cx, r = rng.integers(0, 700), rng.integers(0, 1100), rng.integers(5, 60)
+        seg[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = k + 1
+    ref = A.label_components(seg)
+    assert np.array_equal(util._label_equal_value_components(seg), ref)
+    assert not np.array_equal(ref, A.label_components(seg, block=1 << 30))
+    assert np.array_equal(A.block_major_keys(700, 1100), util._block_major_keys(700, 1100))
+    assert np.array_equal(np.sort(A.block_major_keys(700, 1100).reshape(-1)), np.arange(700 * 1100))     # a permutation

@@ -81,6 +81,8 @@ def configs():
     out.append(("fix: lin1+lin2 hi+lo (act + weights)", mk(dtype=sp(["lin1.x", "lin1.w", "lin2.x", "lin2.w"]))))
     out.append(("fix: qkv+proj hi+lo (act + weights)", mk(dtype=sp(["qkv.x", "qkv.w", "proj.x", "proj.w"]))))
     out.append(("fix: neck + patch hi+lo", mk(dtype=sp(["neck", "patch"]))))
+    if os.environ.get("ABL_ONLY"):                     # e.g. ABL_ONLY="fix: neck" python tools/enc_ablation.py : a subset by name prefix
+        out = [c for c in out if any(c[0].startswith(pre) for pre in os.environ["ABL_ONLY"].split("|"))]
     return out
 
 

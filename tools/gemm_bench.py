@@ -55,3 +55,23 @@ for (M, N, K, name) in SHAPES:
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ms = timeit(lambda: ops.gemm_fp8(a8, a_sc, w8, w_sc, bias, out=out, act=ops.ACT_GELU))
     print(f"{name:8s} {M}x{N}x{K}  fp8: {ms:.3f} ms {2 * M * N * K / ms / 1e9:7.1f} TF", flush=True)
+
+# where the time of the 256 x 256 kernel goes (timing experiments, WRONG results): full / no global stores / k-loop only / epilogue only;
+# real epilogues of the encoder: qkv head-split bf16 store, proj + lin2 with the fp32 residual read and written in place, lin1 GELU
+print("\ngemm_dbg experiments (ms): full | no stores (1) | k-loop only (2) | prologue + epilogue only (4)", flush=True)
+for (M, N, K, name) in SHAPES[:4]:
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    w = (torch.rand(N, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    resid = name in ("proj", "lin2")
+    out = torch.zeros(M, N, dtype=torch.float32 if resid else torch.bfloat16, device=dev)
+    line = []
+    for dbg in (0, 1, 2, 4, 0):
+        lib.msam_tune_set(b"gemm_dbg", dbg)
+        if resid:
+            ms = timeit(lambda: ops.gemm(a, w, bias, out=out, resid=out))
+        else:
+            ms = timeit(lambda: ops.gemm(a, w, bias, out=out, act=ops.ACT_GELU if name == "lin1" else 0))
+        line.append(f"{ms:.3f}")
+    lib.msam_tune_set(b"gemm_dbg", 0)
+    print(f"{name:6s} {M}x{N}x{K} resid={int(resid)}: " + " | ".join(line) + f"   ({2 * M * N * K / float(line[0]) / 1e9:.0f} TF full)", flush=True)
