@@ -268,6 +268,16 @@ int msam_amg_generate_labels(const float* iou, const float* stability, const int
                              int32_t min_object_size, int32_t with_background, int32_t* labels, int32_t* flag,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
+/* util.mask_data_to_segmentation(label_masks=True, merge_exclusively=False) (micro_sam/util.py:1773-1848) for masks that are already
+ * selected: paint `order` (int32 [K] mask indices into bits, the paint order: later masks overwrite; K from k_dev int32[1] in device
+ * memory when k_dev != NULL), connected components in the reference's numbering, drop components below min_object_size and - with_background -
+ * the largest one counting label 0, consecutive relabel.  labels int32 [H, W]; flag int32 [1] reads 0 when the labelling converged.
+ * 7 kernels on `stream`, no host synchronisation. */
+int64_t msam_labels_from_masks_workspace_bytes(int32_t H, int32_t W);
+int msam_labels_from_masks(const uint32_t* bits, const int32_t* order, int32_t K, const int32_t* k_dev, int32_t H, int32_t W,
+                           int32_t min_object_size, int32_t with_background, int32_t* labels, int32_t* flag,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- fine-tuning (micro_sam/training/sam_trainer.py:131-425, trainable_sam.py:12-114): backward
  * kernels of the mask decoder's non-GEMM pieces (the GEMMs run msam_gemm_bf16 in both directions: dX = dY W, dW = dY^T X).
  * msam_layernorm_backward: x, dy, dx fp32 [rows, dim] (dim 64 / 128 / 256; 768 / 1024 / 1280 for the encoder), dweight / dbias fp32 [dim] ACCUMULATED

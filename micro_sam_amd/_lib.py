@@ -190,6 +190,8 @@ _PROTOS = {
     "msam_paint_label_image_dev": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "msam_label_components_async": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "msam_component_sizes": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "msam_labels_from_masks_workspace_bytes": (_i64, [_i32, _i32]),
+    "msam_labels_from_masks": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "msam_slice_overlaps": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, C.POINTER(_i32), _vp]),

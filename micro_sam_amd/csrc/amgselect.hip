@@ -287,3 +287,43 @@ extern "C" int msam_amg_generate_labels(const float* iou, const float* stability
     hipLaunchKernelGGL(relabel_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, roots, newid, n, labels);
     return msam_check_launch("msam_amg_generate_labels");
 }
+
+// util.mask_data_to_segmentation(label_masks=True, merge_exclusively=False) for K masks that are already selected (reference
+// micro_sam/util.py:1773-1848): paint in the given order (later masks overwrite), connected components, drop components below
+// min_object_size and - with_background - the largest one counting label 0, consecutive relabel: the tail of
+// msam_amg_generate_labels as its own entry point (7 kernels, no host synchronisation).  bits uint32 [*, ceil(H/32), W]; order int32 [K]
+// = mask indices in paint order (the caller sorts by area, stable, descending); K may also come from device memory (k_dev != NULL).
+extern "C" int64_t msam_labels_from_masks_workspace_bytes(int32_t H, int32_t W) {
+    if (H <= 0 || W <= 0) return 0;
+    const int64_t n = (int64_t)H * W, nb = (n + RB - 1) / RB;
+    return 256 + al256(4 * n) * 4 + al256(4 * nb) * 2 + al256(8 * nb) + 256;
+}
+
+extern "C" int msam_labels_from_masks(const uint32_t* bits, const int32_t* order, int32_t K, const int32_t* k_dev, int32_t H, int32_t W,
+                                      int32_t min_object_size, int32_t with_background, int32_t* labels, int32_t* flag,
+                                      void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!bits || !order || !labels || !flag || !workspace || H <= 0 || W <= 0 || (K < 0 && !k_dev)) {
+        msam_set_error("msam_labels_from_masks: bad argument");
+        return 1;
+    }
+    if (workspace_bytes < msam_labels_from_masks_workspace_bytes(H, W)) { msam_set_error("msam_labels_from_masks: workspace too small"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    const int n = H * W, nb = (n + RB - 1) / RB;
+    char* p = (char*)workspace;
+    auto take = [&](int64_t bytes) { char* r = p; p += al256(bytes); return r; };
+    int* small = (int*)take(256);                    // [1] bg count, [2] drop index
+    int* painted = (int*)take(4LL * n); int* roots = (int*)take(4LL * n); int* sizes = (int*)take(4LL * n); int* newid = (int*)take(4LL * n);
+    int* blk_cnt = (int*)take(4LL * nb); int* blk_off = (int*)take(4LL * nb);
+    u64* blk_max = (u64*)take(8LL * nb);
+    int e;
+    if (k_dev) { if ((e = msam_paint_label_image_dev(bits, order, k_dev, H, W, painted, s))) return e; }
+    else if ((e = msam_paint_label_image(bits, order, K, H, W, painted, s))) return e;
+    if ((e = msam_label_components_async(painted, H, W, roots, flag, 2, s))) return e;
+    if ((e = msam_component_sizes(roots, n, sizes, small + 1, s))) return e;
+    hipLaunchKernelGGL(relabel_stats_kernel, dim3(nb), dim3(256), 0, s, roots, sizes, n, H, W, min_object_size, blk_cnt, blk_max);
+    hipLaunchKernelGGL(relabel_scan_kernel, dim3(1), dim3(NT), 0, s, blk_cnt, blk_max, nb, small + 1, with_background,
+                       min_object_size, blk_off, small + 2);
+    hipLaunchKernelGGL(relabel_assign_kernel, dim3(nb), dim3(256), 0, s, roots, sizes, n, H, W, min_object_size, blk_off, small + 2, newid);
+    hipLaunchKernelGGL(relabel_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, roots, newid, n, labels);
+    return msam_check_launch("msam_labels_from_masks");
+}

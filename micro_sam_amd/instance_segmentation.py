@@ -434,6 +434,18 @@ class AutomaticMaskGenerator(AMGBase):
                  with_background: bool = True) -> Union[List[Dict[str, Any]], np.ndarray]:
         if not self.is_initialized:
             raise RuntimeError("AutomaticMaskGenerator has not been initialized. Call initialize first.")
+        if (output_mode == "instance_segmentation" and min_mask_region_area == 0 and len(self.crop_list) == 1
+                and isinstance(self.crop_list[0], DeviceMaskData) and "bits" in self.crop_list[0]
+                and 0 < len(self.crop_list[0]) <= 4096
+                and tuple(self.crop_boxes[0]) == (0, 0, self.original_size[1], self.original_size[0])
+                and not getattr(self, "_general_generate", False)):
+            # the default call on a single-crop device state: the whole of _postprocess_batch + mask_data_to_segmentation as ONE
+            # library call (generate_device: 15 kernels, no host synchronisation) and one download of label image + flag
+            labels, flag = self.generate_device(pred_iou_thresh, stability_score_thresh, box_nms_thresh, with_background)
+            out = torch.cat([labels.reshape(-1), flag]).cpu().numpy()
+            if out[-1] == 0:
+                return out[:-1].reshape(self.original_size).astype("uint32")
+            # (two union passes did not converge: the general path below iterates until they do)
         data = DeviceMaskData()
         for data_, crop_box in zip(self.crop_list, self.crop_boxes):
             # filter() re-binds columns and never mutates them in place: a shallow copy protects the state

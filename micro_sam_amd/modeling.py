@@ -666,8 +666,15 @@ class Sam(nn.Module):
 def build_sam(model_type: str = "vit_b", num_multimask_outputs: int = 3) -> Sam:
     """micro_sam/models/build_sam.py:87-142 (image_size fixed at 1024)."""
     key = model_type[:5]
+    if key == "vit_t":
+        # MobileSAM (micro_sam/util.py:435-439): TinyViT image encoder - torch operators, see models/tiny_vit.py - with the same
+        # prompt encoder and mask decoder (the HIP path)
+        from .models.tiny_vit import TinyViT
+        sam = Sam(TinyViT(), PromptEncoder(), MaskDecoder(num_multimask_outputs))
+        sam.eval()
+        return sam
     if key not in VIT_CONFIGS:
-        raise ValueError(f"Invalid model_type: {model_type}. Expect one of {tuple(VIT_CONFIGS)} (vit_t: not supported)")
+        raise ValueError(f"Invalid model_type: {model_type}. Expect one of {tuple(VIT_CONFIGS) + ('vit_t',)}")
     cfg = VIT_CONFIGS[key]
     sam = Sam(ImageEncoderViT(cfg["embed_dim"], cfg["depth"], cfg["num_heads"], cfg["global_attn_indexes"]),
               PromptEncoder(), MaskDecoder(num_multimask_outputs))
@@ -679,4 +686,5 @@ sam_model_registry = {
     "vit_b": lambda **kw: build_sam("vit_b", **kw),
     "vit_l": lambda **kw: build_sam("vit_l", **kw),
     "vit_h": lambda **kw: build_sam("vit_h", **kw),
+    "vit_t": lambda **kw: build_sam("vit_t", **kw),
 }

@@ -450,6 +450,31 @@ def amg_generate_labels(iou: torch.Tensor, stability: torch.Tensor, boxes: torch
     return labels, flag
 
 
+def labels_from_masks(bits: torch.Tensor, order: torch.Tensor, shape: Tuple[int, int], k_dev: Optional[torch.Tensor] = None,
+                      min_object_size: int = 0, with_background: bool = False):
+    """``util.mask_data_to_segmentation(label_masks=True, merge_exclusively=False)`` of selected masks in one library call
+    (msam_labels_from_masks: paint in ``order`` - later masks overwrite -, connected components in the reference's numbering, size /
+    background filter, consecutive relabel).  ``order`` int32 [K] indexes ``bits``; with ``k_dev`` (int32[1] on the device) only its
+    first k_dev[0] entries are painted.  Returns (labels int32 [H, W], flag int32[1]: 0 = the labelling converged); no host sync."""
+    _lib.require_gpu()
+    lib = _lib.load()
+    h, w = int(shape[0]), int(shape[1])
+    dev = bits.device
+    need = int(lib.msam_labels_from_masks_workspace_bytes(h, w))
+    key = ("lfm", dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _AMG_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _AMG_WS[key] = ws
+    labels = torch.empty((h, w), dtype=torch.int32, device=dev)
+    flag = torch.empty((1,), dtype=torch.int32, device=dev)
+    order = order.to(torch.int32).contiguous()
+    _lib.check(lib.msam_labels_from_masks(bits.contiguous().data_ptr(), order.data_ptr(), int(order.numel()), _lib.ptr(k_dev), h, w,
+                                          int(min_object_size), int(bool(with_background)), labels.data_ptr(), flag.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "msam_labels_from_masks")
+    return labels, flag
+
+
 def paint_label_image_dev(bits: torch.Tensor, order: torch.Tensor, k_dev: torch.Tensor, height: int, width: int) -> torch.Tensor:
     """paint_label_image with the mask count taken from device memory (k_dev int32[1]); order int32 [N]."""
     label = torch.empty((height, width), dtype=torch.int32, device=bits.device)

@@ -49,6 +49,8 @@ def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0, calibrated: b
     ``calibrated``: apply the hyper-network calibration stored in ``data/synthetic_calib.json`` (written by
     ``tools/calibrate_synthetic.py``) when one exists for (model_type, seed, variant)."""
     assert variant in ("field", "blobs", "cells"), variant
+    if model_type[:5] == "vit_t":
+        return _synthetic_vit_t(seed, variant)
     cfg = VIT_CONFIGS[model_type[:5]]
     D, depth, heads = cfg["embed_dim"], cfg["depth"], cfg["num_heads"]
     hd = D // heads
@@ -173,6 +175,37 @@ def synthetic_state_dict(model_type: str = "vit_b", seed: int = 0, calibrated: b
     if variant == "cells":
         cal = _load_calibration().get(f"{model_type[:5]}/{seed}/cells") if calibrated else None
         _design_cells(sd, D, depth, g, iou_offset=None if cal is None else cal["iou_offset"])
+    return sd
+
+
+def _synthetic_vit_t(seed: int, variant: str):
+    """MobileSAM-shaped checkpoint: prompt encoder / mask decoder of the vit_b checkpoint of the same seed ("field" or "blobs"; the
+    designed "cells" variant is tied to the ViT encoder), TinyViT-5M encoder with seeded random weights (BatchNorm running statistics
+    away from (0, 1) and non-zero attention offset biases, so that those paths are exercised) + its unused classification head."""
+    from .models.tiny_vit import TinyViT
+    base = synthetic_state_dict("vit_b", seed, variant="field" if variant == "cells" else variant)
+    sd = OrderedDict((k, v) for k, v in base.items() if not k.startswith("image_encoder."))
+    g = torch.Generator().manual_seed(seed + 7919)
+    with torch.no_grad():
+        enc = TinyViT()
+        for name, t in enc.state_dict().items():
+            if name.endswith("num_batches_tracked"):
+                v = t.clone()
+            elif name.endswith("running_var"):
+                v = torch.rand(t.shape, generator=g) * 0.5 + 0.75
+            elif name.endswith("running_mean"):
+                v = torch.randn(t.shape, generator=g) * 0.1
+            elif name.endswith("attention_biases"):
+                v = torch.randn(t.shape, generator=g) * 0.5
+            elif t.dim() == 1 and ("bn.weight" in name or "norm" in name or name.endswith(".1.weight") or name.endswith(".3.weight")) \
+                    and name.endswith("weight"):
+                v = torch.randn(t.shape, generator=g) * 0.05 + 1.0
+            elif t.dim() == 1:
+                v = torch.randn(t.shape, generator=g) * 0.02
+            else:
+                fan_in = t[0].numel()
+                v = torch.randn(t.shape, generator=g) * (1.0 / fan_in ** 0.5)
+            sd["image_encoder." + name] = v
     return sd
 
 

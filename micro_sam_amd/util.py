@@ -108,8 +108,8 @@ def get_sam_model(model_type: str = _DEFAULT_MODEL, device: Optional[Union[str, 
     else:
         raise RuntimeError("micro_sam_amd.get_sam_model: no network access for model downloads - pass checkpoint_path "
                            "(a SAM / micro_sam checkpoint file) or state_dict.")
-    if abbreviated == "vit_t":
-        raise RuntimeError("vit_t (MobileSAM / TinyViT) is not provided by micro_sam_amd; use vit_b / vit_l.")
+    if abbreviated == "vit_t" and peft_kwargs and isinstance(peft_kwargs, dict):
+        raise ValueError("'micro-sam' does not support parameter efficient finetuning for 'mobile-sam'.")
     sam = modeling.sam_model_registry[abbreviated](**model_kwargs)
     if peft_kwargs and isinstance(peft_kwargs, dict):
         # LoRA surgery of the image encoder before the weights are loaded (reference util.py:441-450); the low-rank
@@ -869,6 +869,28 @@ def mask_data_to_segmentation_device(bits: torch.Tensor, areas: torch.Tensor, sh
     k = int(bits.shape[0])
     if k == 0:
         return np.zeros((h, w), dtype="uint32")
+    areas = areas.to(dev)
+    # stable area-descending paint order; masks below min_object_size sink to the end and are cut off by k_dev (no compaction,
+    # no host synchronisation before the single download of the result)
+    sel = areas >= min_object_size if min_object_size > 0 else torch.ones_like(areas, dtype=torch.bool)
+    key = torch.where(sel, areas.to(torch.int64), torch.full((k,), -1, dtype=torch.int64, device=dev))
+    order = torch.sort(key, descending=True, stable=True).indices.to(torch.int32)
+    k_dev = sel.sum().to(torch.int32).reshape(1)
+    labels, flag = ops.labels_from_masks(bits, order, (h, w), k_dev=k_dev, min_object_size=min_object_size,
+                                         with_background=with_background)
+    out = torch.cat([labels.reshape(-1), flag]).cpu().numpy()              # one download: the label image + the convergence flag
+    if out[-1] != 0:                                                       # two union passes did not converge: iterate on the host's clock
+        return _mask_data_to_segmentation_device_iterative(bits, areas, shape, min_object_size, with_background)
+    return out[:-1].reshape(h, w).astype("uint32")
+
+
+def _mask_data_to_segmentation_device_iterative(bits: torch.Tensor, areas: torch.Tensor, shape: Tuple[int, int],
+                                                min_object_size: int = 0, with_background: bool = False) -> np.ndarray:
+    """The same result with the union passes repeated until none changes anything (a host synchronisation per pass) and the
+    relabelling as torch operators: the fallback of ``mask_data_to_segmentation_device`` and its cross-check in the tests."""
+    from . import ops
+    h, w = int(shape[0]), int(shape[1])
+    dev = bits.device
     order = torch.sort(areas.to(dev), descending=True, stable=True).indices
     if min_object_size > 0:
         order = order[areas.to(dev)[order] >= min_object_size]

@@ -218,6 +218,9 @@ def test_amg_initialize_generate_vs_oracle(ctx):
     seg = amg.generate()
     assert seg.shape == tile.shape and seg.dtype == np.uint32
     assert np.array_equal(seg, amg.generate())                          # regenerate == (reference test_instance_segmentation.py:73-107)
+    amg._general_generate = True                                        # the general path (filters / NMS as operators, then the fused
+    assert np.array_equal(seg, amg.generate())                          # paint + label + relabel call) == the one-call default path
+    amg._general_generate = False
     state = amg.get_state()
     amg2 = AutomaticMaskGenerator(p, points_per_side=8, points_per_batch=16)
     amg2.set_state(state)
@@ -686,3 +689,37 @@ def test_config3_vit_l_tiled_volume_segment_slices():
         ref[ref != 0] += offset
         offset += m
         assert np.array_equal(seg[z], ref) and m > 0
+
+
+def test_config1_vit_t_plumbing():
+    """BASELINE configs[0]: vit_t (MobileSAM) - get_sam_model -> precompute_image_embeddings -> AutomaticMaskGenerator on one 512 x 512
+    tile, the checks of the reference's test/test_instance_segmentation.py:73-121 that do not need trained weights (shapes, regenerate
+    ==, state round trip ==).  The TinyViT encoder runs torch operators (models/tiny_vit.py) and must equal the CPU restatement; the
+    decoder / AMG half is the HIP path."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import util
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_state_dict, three_disk_fixture
+    from oracle import sam_ref as S
+    from oracle import tinyvit_ref as T
+    sd = synthetic_state_dict("vit_t", 0, variant="blobs")
+    predictor = util.get_sam_model("vit_t", device="cuda", state_dict=sd)
+    assert predictor.model_type == "vit_t"
+    mask, image = three_disk_fixture(512)
+    emb = util.precompute_image_embeddings(predictor, image, verbose=False)
+    assert emb["features"].shape == (1, 256, 64, 64) and emb["original_size"] == (512, 512)
+    x = S.preprocess(torch.as_tensor(S.apply_image(util._to_image(image))).permute(2, 0, 1)[None])
+    ref = T.image_encoder(sd, x)
+    got = torch.as_tensor(emb["features"]).float().cpu()
+    assert (got - ref).abs().max().item() < 5e-3, (got - ref).abs().max().item()
+    amg = AutomaticMaskGenerator(predictor, points_per_side=16)
+    amg.initialize(image, emb)
+    seg = amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    assert seg.shape == mask.shape and seg.dtype == np.uint32
+    assert np.array_equal(seg, amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5))        # regenerate ==
+    amg2 = AutomaticMaskGenerator(predictor, points_per_side=16)
+    amg2.set_state(amg.get_state())
+    assert np.array_equal(seg, amg2.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5))       # state round trip ==
+    with pytest.raises(ValueError):
+        util.get_sam_model("vit_t", device="cuda", state_dict=sd, peft_kwargs={"rank": 4})

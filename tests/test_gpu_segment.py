@@ -39,6 +39,9 @@ def test_mask_data_to_segmentation_device(shape, n, with_background):
                                                 with_background=with_background)
     assert got.dtype == np.uint32 and got.shape == tuple(shape)
     assert np.array_equal(got, ref), f"{(got != ref).sum()} pixels differ, max ids {got.max()} vs {ref.max()}"
+    if n:      # the fallback (union passes iterated under host control, torch-operator relabel) gives the same image
+        assert np.array_equal(util._mask_data_to_segmentation_device_iterative(
+            bits, torch.as_tensor(areas, dtype=torch.int32).cuda(), shape, with_background=with_background), ref)
     # the host implementation of the product agrees as well
     host = util.mask_data_to_segmentation(recs, shape=shape, with_background=with_background, merge_exclusively=False)
     assert np.array_equal(host, ref)
