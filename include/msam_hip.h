@@ -73,6 +73,11 @@ typedef struct {
      * MSAM_F16 -> fp16, MSAM_BF16 -> bf16) */
     int32_t a_dtype;
     const float* row_scale; const float* col_scale;        /* fp32 [M], [N] */
+    /* split_k > 1 (128 x 128-tile bf16 / fp16 path): the contraction is cut into split_k slices, one workgroup per (tile, slice),
+     * partial tiles are added into `out` with fp32 atomics (out is zeroed first).  For products with a small output and a very long
+     * contraction (the weight gradients of fine-tuning: dW = dY^T X over all rows).  Plain fp32 output with ldc == N, no bias /
+     * table / residual / activation; K % (64 * split_k) == 0.  0 / 1 = off. */
+    int32_t split_k;
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 /* n <= MSAM_GEMM_GROUP_MAX independent products (each as for msam_gemm_bf16; 128 x 128-tile bf16 path only: no fused LayerNorm,

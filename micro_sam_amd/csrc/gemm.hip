@@ -21,6 +21,9 @@ struct Epi {
     void* out; int out_dtype; long ldc;
     int out_mode; u16* q; u16* k; u16* v; int heads, head_dim, tokens;
     const float* row_scale; const float* col_scale;      // fp8 operands: C = acc * row_scale[m] * col_scale[n]
+    int splitk_len;                                      // > 0: split-K launch (msam_gemm_t.split_k): workgroup blockIdx.y contracts over
+                                                         // k in [y * splitk_len, (y + 1) * splitk_len) and ADDS its fp32 tile to `out`
+                                                         // (atomics; plain fp32 output, zeroed by the launcher; no bias / epilogue)
     int dbg;                                             // timing experiments (msam_tune_set "gemm_dbg"; WRONG results when != 0): gemm256 only -
                                                          // 1 = no global stores, 2 = no epilogue at all, 4 = no k-loop
 };
@@ -249,7 +252,10 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
             for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
         }
         if (e.out_mode == 0) {
-            if (e.out_dtype == MSAM_F32) {
+            if (e.splitk_len > 0) {
+                float* o = (float*)e.out + (long)row * e.ldc + col;
+                atomicAdd(o, v[0]); atomicAdd(o + 1, v[1]); atomicAdd(o + 2, v[2]); atomicAdd(o + 3, v[3]);
+            } else if (e.out_dtype == MSAM_F32) {
                 *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
                 uint2 pk; pk.x = pack16(v[0], v[1], e.out_dtype); pk.y = pack16(v[2], v[3], e.out_dtype);
@@ -291,6 +297,9 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
 template <bool GLDS, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                    long ldw, int M, int N, int K, Epi e) {
+    if (e.splitk_len > 0) {                      // split-K: this workgroup's slice of the contraction (operands are K-contiguous)
+        A += (long)blockIdx.y * e.splitk_len; W += (long)blockIdx.y * e.splitk_len; K = e.splitk_len;
+    }
     gemm_body<GLDS, F16>(A, lda, W, ldw, M, N, K, e, (int)blockIdx.x);
 }
 
@@ -943,6 +952,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
     e.row_scale = nullptr; e.col_scale = nullptr;
+    e.splitk_len = 0;
     e.dbg = g_tune_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
     if (p->ln_mode && (p->a_dtype == MSAM_FP8 || p->a_dtype == MSAM_F16)) { msam_set_error("msam_gemm_bf16(fp8 / fp16): no fused LayerNorm epilogue"); return 1; }
@@ -1011,7 +1021,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     if (g_gemm256_staging >= 0) staging256 = g_gemm256_staging;
     // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
     // (fp16 operands: 16-bit outputs of this kernel are then fp16 as well - the encoder's fp16 mode; a bf16 output is not offered)
-    if (use256 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 &&
+    if (use256 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 &&
         p->out_mode != 2 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr256 = false;
         if (!attr256) {
@@ -1039,6 +1049,23 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
 #undef G2_GO
         if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
         return msam_check_launch("msam_gemm_bf16(256)");
+    }
+    if (p->split_k > 1) {
+        // split-K (training: dW = dY^T X contracts over hundreds of thousands of rows into a 128 x 256 tile or two - a handful of
+        // workgroups would walk the whole contraction one after the other): split_k slices of K, one workgroup per (tile, slice), fp32
+        // atomic accumulation into the zeroed output
+        if (p->out_mode != 0 || p->out_dtype != MSAM_F32 || p->bias || p->table || p->resid || p->act || p->ldc != p->N ||
+            p->K % (p->split_k * BK)) {
+            msam_set_error("msam_gemm_bf16(split_k): plain fp32 output with ldc == N, no bias / table / residual / activation, K % (split_k * 64) == 0");
+            return 1;
+        }
+        if (hipMemsetAsync(p->out, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) { msam_set_error("msam_gemm_bf16(split_k): memset failed"); return 2; }
+        e.splitk_len = p->K / p->split_k;
+        if (f16) hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(tiles, p->split_k), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
+                                    (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+        else hipLaunchKernelGGL(gemm_kernel<false>, dim3(tiles, p->split_k), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
+                                (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+        return msam_check_launch("msam_gemm_bf16(split_k)");
     }
     if (prof) {
         g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;

@@ -139,6 +139,121 @@ __global__ __launch_bounds__(128) void attn_bwd_kv_kernel(const float* __restric
     for (int d = 0; d < D; ++d) { dk[ro + d] = ak[d] * scale; dv[ro + d] = av[d]; }
 }
 
+// ---- the same three passes when ONE side of the attention is short (the two-way transformer: 5 - 16 prompt tokens against 4096
+// image tokens): one 256-thread workgroup per row of the short side, the loop over the long side split over the threads, results
+// merged by a block reduction.  One thread per row left 25 x 8 x 7 = 1 400 threads walking 4096 keys each (1 - 3 ms per call, half of a
+// fine-tuning step's kernel time: profiles/r03_train_profile.md).
+__device__ __forceinline__ float block_sum256(float v, float* red) {        // red: 4 floats of LDS per concurrent use; all 256 threads call
+    v = wave_sum64(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max256(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_rowblock_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                const float* __restrict__ v, int Nq, int Nk, float scale,
+                                                                float* __restrict__ out, float* __restrict__ lse) {
+    __shared__ float red[4];
+    const int bh = blockIdx.y, i = blockIdx.x;
+    float qv[D], acc[D];
+    const float* qp = q + ((long)bh * Nq + i) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = qp[d] * scale; acc[d] = 0.f; }
+    const float* kb = k + (long)bh * Nk * D;
+    const float* vb = v + (long)bh * Nk * D;
+    float m = -3.0e38f, l = 0.f;
+    for (int j = threadIdx.x; j < Nk; j += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) s = fmaf(qv[d], kb[(long)j * D + d], s);
+        const float mn = fmaxf(m, s), a = __expf(m - mn), p = __expf(s - mn);
+        l = l * a + p;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(p, vb[(long)j * D + d], acc[d] * a);
+        m = mn;
+    }
+    const float M = block_max256(m, red);
+    const float r = __expf(m - M);                       // threads without a key: m = -3e38 -> r = 0
+    const float L = block_sum256(l * r, red);
+    float* op = out + ((long)bh * Nq + i) * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float t = block_sum256(acc[d] * r, red);
+        if (threadIdx.x == 0) op[d] = t / L;
+    }
+    if (threadIdx.x == 0) lse[(long)bh * Nq + i] = M + __logf(L);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_q_rowblock_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                  const float* __restrict__ v, const float* __restrict__ out,
+                                                                  const float* __restrict__ dout, const float* __restrict__ lse, int Nq,
+                                                                  int Nk, float scale, float* __restrict__ dq, float* __restrict__ delta) {
+    __shared__ float red[4];
+    const int bh = blockIdx.y, i = blockIdx.x;
+    const long ro = ((long)bh * Nq + i) * D;
+    float qv[D], dov[D], acc[D], dl = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = q[ro + d] * scale; dov[d] = dout[ro + d]; dl = fmaf(dov[d], out[ro + d], dl); acc[d] = 0.f; }
+    const float L = lse[(long)bh * Nq + i];
+    const float* kb = k + (long)bh * Nk * D;
+    const float* vb = v + (long)bh * Nk * D;
+    for (int j = threadIdx.x; j < Nk; j += 256) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s = fmaf(qv[d], kb[(long)j * D + d], s); dp = fmaf(dov[d], vb[(long)j * D + d], dp); }
+        const float ds = __expf(s - L) * (dp - dl);
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = fmaf(ds, kb[(long)j * D + d], acc[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float t = block_sum256(acc[d], red);
+        if (threadIdx.x == 0) dq[ro + d] = t * scale;
+    }
+    if (threadIdx.x == 0) delta[(long)bh * Nq + i] = dl;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_kv_rowblock_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                                   const float* __restrict__ v, const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta, int Nq,
+                                                                   int Nk, float scale, float* __restrict__ dk, float* __restrict__ dv) {
+    __shared__ float red[4];
+    const int bh = blockIdx.y, j = blockIdx.x;
+    const long ro = ((long)bh * Nk + j) * D;
+    float kv[D], vv[D], ak[D], av[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { kv[d] = k[ro + d]; vv[d] = v[ro + d]; ak[d] = 0.f; av[d] = 0.f; }
+    const float* qb = q + (long)bh * Nq * D;
+    const float* dob = dout + (long)bh * Nq * D;
+    for (int i = threadIdx.x; i < Nq; i += 256) {
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { s = fmaf(qb[(long)i * D + d], kv[d], s); dp = fmaf(dob[(long)i * D + d], vv[d], dp); }
+        const float p = __expf(s * scale - lse[(long)bh * Nq + i]);
+        const float ds = p * (dp - delta[(long)bh * Nq + i]);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { ak[d] = fmaf(ds, qb[(long)i * D + d], ak[d]); av[d] = fmaf(p, dob[(long)i * D + d], av[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float tk = block_sum256(ak[d], red), tv = block_sum256(av[d], red);
+        if (threadIdx.x == 0) { dk[ro + d] = tk * scale; dv[ro + d] = tv; }
+    }
+}
+
 // ---- attention of the image encoder with its decomposed relative position bias, for fine-tuning the encoder (upstream
 // segment_anything/modeling/image_encoder.py add_decomposed_rel_pos; oracle/sam_ref.py _attention_relpos): queries and keys
 // are the tokens of ONE Gh x Gw grid (a 14 x 14 window or the 64 x 64 image), key j = (kh, kw) = (j / Gw, j % Gw),
@@ -283,10 +398,16 @@ extern "C" int msam_attention_forward(const float* q, const float* k, const floa
                                       int32_t D, float scale, float* out, float* lse, void* stream) {
     if (!q || !k || !v || !out || !lse || BH <= 0 || Nq <= 0 || Nk <= 0) { msam_set_error("msam_attention_forward: bad argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
+    if (D != 16 && D != 32) { msam_set_error("msam_attention_forward: head dim must be 16 or 32"); return 1; }
+    if (Nq <= 64 && Nk >= 1024) {                    // few queries, many keys: a workgroup per query row (see the kernels)
+        const dim3 grid(Nq, BH);
+        if (D == 16) hipLaunchKernelGGL(attn_fwd_rowblock_kernel<16>, grid, dim3(256), 0, s, q, k, v, Nq, Nk, scale, out, lse);
+        else hipLaunchKernelGGL(attn_fwd_rowblock_kernel<32>, grid, dim3(256), 0, s, q, k, v, Nq, Nk, scale, out, lse);
+        return msam_check_launch("msam_attention_forward");
+    }
     const dim3 grid((Nq + 127) / 128, BH);
     if (D == 16) hipLaunchKernelGGL(attn_fwd_kernel<16>, grid, dim3(128), 0, s, q, k, v, Nq, Nk, scale, out, lse);
-    else if (D == 32) hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, s, q, k, v, Nq, Nk, scale, out, lse);
-    else { msam_set_error("msam_attention_forward: head dim must be 16 or 32"); return 1; }
+    else hipLaunchKernelGGL(attn_fwd_kernel<32>, grid, dim3(128), 0, s, q, k, v, Nq, Nk, scale, out, lse);
     return msam_check_launch("msam_attention_forward");
 }
 
@@ -298,14 +419,19 @@ extern "C" int msam_attention_backward(const float* q, const float* k, const flo
         return 1;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (D != 16 && D != 32) { msam_set_error("msam_attention_backward: head dim must be 16 or 32"); return 1; }
     const dim3 gq((Nq + 127) / 128, BH), gk((Nk + 127) / 128, BH);
-    if (D == 16) {
-        hipLaunchKernelGGL(attn_bwd_q_kernel<16>, gq, dim3(128), 0, s, q, k, v, out, dout, lse, Nq, Nk, scale, dq, delta);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<16>, gk, dim3(128), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv);
-    } else if (D == 32) {
-        hipLaunchKernelGGL(attn_bwd_q_kernel<32>, gq, dim3(128), 0, s, q, k, v, out, dout, lse, Nq, Nk, scale, dq, delta);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<32>, gk, dim3(128), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv);
-    } else { msam_set_error("msam_attention_backward: head dim must be 16 or 32"); return 1; }
+    const bool q_rows = Nq <= 64 && Nk >= 1024;     // a workgroup per query row for (delta, dQ)
+    const bool k_rows = Nk <= 64 && Nq >= 1024;     // a workgroup per key row for (dK, dV)
+#define ATTN_BWD(D_)                                                                                                          \
+    do {                                                                                                                      \
+        if (q_rows) hipLaunchKernelGGL(attn_bwd_q_rowblock_kernel<D_>, dim3(Nq, BH), dim3(256), 0, s, q, k, v, out, dout, lse, Nq, Nk, scale, dq, delta); \
+        else hipLaunchKernelGGL(attn_bwd_q_kernel<D_>, gq, dim3(128), 0, s, q, k, v, out, dout, lse, Nq, Nk, scale, dq, delta);     \
+        if (k_rows) hipLaunchKernelGGL(attn_bwd_kv_rowblock_kernel<D_>, dim3(Nk, BH), dim3(256), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv); \
+        else hipLaunchKernelGGL(attn_bwd_kv_kernel<D_>, gk, dim3(128), 0, s, q, k, v, dout, lse, delta, Nq, Nk, scale, dk, dv);      \
+    } while (0)
+    if (D == 16) ATTN_BWD(16); else ATTN_BWD(32);
+#undef ATTN_BWD
     return msam_check_launch("msam_attention_backward");
 }
 

@@ -442,9 +442,9 @@ class AutomaticMaskGenerator(AMGBase):
             # the default call on a single-crop device state: the whole of _postprocess_batch + mask_data_to_segmentation as ONE
             # library call (generate_device: 15 kernels, no host synchronisation) and one download of label image + flag
             labels, flag = self.generate_device(pred_iou_thresh, stability_score_thresh, box_nms_thresh, with_background)
-            out = torch.cat([labels.reshape(-1), flag]).cpu().numpy()
+            out = util.fetch_to_host(torch.cat([labels.reshape(-1), flag]), tag="labels")
             if out[-1] == 0:
-                return out[:-1].reshape(self.original_size).astype("uint32")
+                return out[:-1].reshape(self.original_size).view(np.uint32)
             # (two union passes did not converge: the general path below iterates until they do)
         data = DeviceMaskData()
         for data_, crop_box in zip(self.crop_list, self.crop_boxes):

@@ -25,9 +25,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          out_dtype: torch.dtype = torch.float32, resid: Optional[torch.Tensor] = None, resid_rows: int = 0,
          table: Optional[torch.Tensor] = None, table_cols: int = 0, use_glds: int = 0,
          out: Optional[torch.Tensor] = None, ln_mode: int = 0, ln_w: Optional[torch.Tensor] = None,
-         ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
+         ln_b: Optional[torch.Tensor] = None, ln_eps: float = 1e-5, split_k: int = 0) -> torch.Tensor:
     """act(LN(a[M,K] @ w[N,K]^T + bias + table[row % rows, :table_cols] + resid)); a, w bf16.
-    ln_mode 1: LayerNorm over the row (N == 256); 2: LayerNorm over 64-column groups + GELU."""
+    ln_mode 1: LayerNorm over the row (N == 256); 2: LayerNorm over 64-column groups + GELU.
+    split_k > 1: the contraction in split_k slices accumulated with fp32 atomics (plain fp32 output, K % (64 * split_k) == 0)."""
     _lib.require_gpu()
     assert a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16) and a.is_contiguous() and w.is_contiguous()
     M, K = a.shape
@@ -48,6 +49,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.act = act
     p.out, p.out_dtype, p.ldc = out.data_ptr(), {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}[out.dtype], N
     p.use_glds = use_glds
+    p.split_k = int(split_k)
     if ln_mode:
         p.ln_mode, p.ln_w, p.ln_b, p.ln_eps = ln_mode, ln_w.data_ptr(), ln_b.data_ptr(), ln_eps
     _lib.check(_lib.load().msam_gemm_bf16(C.byref(p), _lib.stream_ptr()), "msam_gemm_bf16")

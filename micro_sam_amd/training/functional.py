@@ -30,15 +30,27 @@ def _pad_to(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return out
 
 
-def _mm_nt(a16: torch.Tensor, b16: torch.Tensor) -> torch.Tensor:
-    """fp32 [M, N] = a16 [M, K] @ b16 [N, K]^T on the MFMA GEMM kernel; K is zero-padded to a multiple of 64 and N to a
-    multiple of 128 (the kernel's tile constraints), M is arbitrary."""
+def _mm_nt(a16: torch.Tensor, b16: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+    """fp32 [M, N] = a16 [M, K] @ b16 [N, K]^T (+ bias [N], fused into the GEMM epilogue) on the MFMA GEMM kernel; K is zero-padded to a
+    multiple of 64 and N to a multiple of 128 (the kernel's tile constraints), M is arbitrary.  A small output with a very long
+    contraction (the weight gradients: M, N <= a few hundred, K = all rows of the batch) is cut into slices of K that run on separate
+    workgroups and accumulate with fp32 atomics (``split_k``) - two workgroups would otherwise walk the whole contraction serially."""
     M, K = a16.shape
     N = b16.shape[0]
-    Kp, Np = (K + 63) // 64 * 64, (N + 127) // 128 * 128
+    Np = (N + 127) // 128 * 128
+    tiles = ((M + 127) // 128) * (Np // 128)
+    split = 0
+    if bias is None and K >= 8192 and tiles < 128:
+        split = 1
+        while split * 2 * tiles <= 512 and K // (split * 2) >= 1024:
+            split *= 2
+    unit = 64 * max(split, 1)
+    Kp = (K + unit - 1) // unit * unit
     a = _pad_to(a16, M, Kp)
     b = _pad_to(b16, Np, Kp)
-    out = ops.gemm(a, b, None, out_dtype=torch.float32)
+    if bias is not None and Np != N:
+        bias = torch.nn.functional.pad(bias.float(), (0, Np - N))
+    out = ops.gemm(a, b, None if bias is None else bias.float().contiguous(), out_dtype=torch.float32, split_k=split if split > 1 else 0)
     return out if Np == N else out[:, :N]
 
 
@@ -49,9 +61,7 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, shape[-1])
         a16 = x2.to(torch.bfloat16)
         w16 = weight.to(torch.bfloat16)
-        y = _mm_nt(a16, w16)
-        if bias is not None:
-            y = y + bias
+        y = _mm_nt(a16, w16, None if bias is None else bias.detach())
         ctx.save_for_backward(a16, w16)
         ctx.has_bias = bias is not None
         ctx.in_shape = shape

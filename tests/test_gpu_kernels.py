@@ -616,3 +616,23 @@ def test_gemm_fp8_vs_torch(env, M, N, K, mode):
     else:
         out = ops.gemm_fp8(a8, a_sc, w8, w_sc, bias, act=ops.ACT_GELU, out_dtype=torch.bfloat16)
         assert _close(out, F.gelu(ref), 2e-2, 1e-2)
+
+
+def test_gemm_split_k_matches_the_plain_product():
+    """msam_gemm_t.split_k: a small output with a very long contraction (fine-tuning's weight gradients dW = dY^T X) cut into slices
+    that accumulate with fp32 atomics == the same product on one workgroup chain (up to the summation order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for M, N, K, split in ((128, 256, 16384, 16), (200, 128, 8192, 8), (128, 128, 4096, 64)):
+        a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        w = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        ref = a.float() @ w.float().t()
+        plain = ops.gemm(a, w, None, out_dtype=torch.float32)
+        got = ops.gemm(a, w, None, out_dtype=torch.float32, split_k=split)
+        scale = ref.abs().max().item()
+        assert (plain - ref).abs().max().item() <= 2e-3 * scale
+        assert (got - ref).abs().max().item() <= 2e-3 * scale and (got - plain).abs().max().item() <= 1e-4 * scale
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, w, torch.zeros(N, device="cuda"), out_dtype=torch.float32, split_k=4)       # no bias in split-K mode

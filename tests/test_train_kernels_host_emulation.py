@@ -201,3 +201,117 @@ def test_layernorm_backward_kernel_source_on_the_cpu(emu_ln, dim):
         want = want.numpy()
         assert np.isfinite(got).all(), name
         assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max(), name
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The decoder's attention when one side is short (workgroup per row of the short side, block reductions): attn_fwd_rowblock /
+# attn_bwd_q_rowblock / attn_bwd_kv_rowblock.  Same thread + barrier emulation; __shfl_xor through a per-wave exchange buffer.
+# ---------------------------------------------------------------------------------------------------------------
+
+RB_SHIM = r"""
+#include <barrier>
+#include <cmath>
+#include <thread>
+#include <vector>
+struct idx3 { int x, y, z; };
+static thread_local idx3 threadIdx, blockIdx;
+static std::barrier<>* wave_bar[4];
+static std::barrier<>* block_bar;
+static float wave_buf[4][64];
+static float wave_sum64(float v) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    wave_buf[w][l] = v;
+    wave_bar[w]->arrive_and_wait();
+    float s = 0.f;
+    for (int i = 0; i < 64; ++i) s += wave_buf[w][i];
+    wave_bar[w]->arrive_and_wait();
+    return s;
+}
+static float __shfl_xor(float v, int o) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    wave_buf[w][l] = v;
+    wave_bar[w]->arrive_and_wait();
+    const float r = wave_buf[w][l ^ o];
+    wave_bar[w]->arrive_and_wait();
+    return r;
+}
+#define __syncthreads() block_bar->arrive_and_wait()
+#define __global__
+#define __device__
+#define __forceinline__ inline
+#define __launch_bounds__(n)
+#define __restrict__
+#define __shared__ static
+#define __expf expf
+#define __logf logf
+%s
+template <class F> static void launch(int gx, int gy, F f) {
+    for (int by = 0; by < gy; ++by) for (int bx = 0; bx < gx; ++bx) {
+        std::barrier<> b0(64), b1(64), b2(64), b3(64), bb(256);
+        wave_bar[0] = &b0; wave_bar[1] = &b1; wave_bar[2] = &b2; wave_bar[3] = &b3; block_bar = &bb;
+        std::vector<std::thread> ts;
+        for (int tx = 0; tx < 256; ++tx) ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0}; f(); });
+        for (auto& t : ts) t.join();
+    }
+}
+template <int D> static void run(int mode, const float* q, const float* k, const float* v, const float* out_in, const float* dout,
+                                 const float* lse_in, const float* delta_in, int BH, int Nq, int Nk, float scale, float* o0, float* o1) {
+    if (mode == 0) launch(Nq, BH, [=] { attn_fwd_rowblock_kernel<D>(q, k, v, Nq, Nk, scale, o0, o1); });
+    if (mode == 1) launch(Nq, BH, [=] { attn_bwd_q_rowblock_kernel<D>(q, k, v, out_in, dout, lse_in, Nq, Nk, scale, o0, o1); });
+    if (mode == 2) launch(Nk, BH, [=] { attn_bwd_kv_rowblock_kernel<D>(q, k, v, dout, lse_in, delta_in, Nq, Nk, scale, o0, o1); });
+}
+extern "C" void emu_rb(int D, int mode, const float* q, const float* k, const float* v, const float* out_in, const float* dout,
+                       const float* lse_in, const float* delta_in, int BH, int Nq, int Nk, float scale, float* o0, float* o1) {
+    if (D == 16) run<16>(mode, q, k, v, out_in, dout, lse_in, delta_in, BH, Nq, Nk, scale, o0, o1);
+    else run<32>(mode, q, k, v, out_in, dout, lse_in, delta_in, BH, Nq, Nk, scale, o0, o1);
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def emu_rb(tmp_path_factory):
+    text = open(SRC).read()
+    start = text.index("__device__ __forceinline__ float block_sum256")
+    end = text.index("// ---- attention of the image encoder with its decomposed relative position bias", start)
+    kernels = text[start:end]
+    assert all(n in kernels for n in ("attn_fwd_rowblock_kernel", "attn_bwd_q_rowblock_kernel", "attn_bwd_kv_rowblock_kernel"))
+    d = tmp_path_factory.mktemp("emu_rb")
+    cpp, so = os.path.join(d, "rb.cpp"), os.path.join(d, "rb.so")
+    open(cpp, "w").write(RB_SHIM % kernels)
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-shared", "-fPIC", "-pthread", "-Wno-unknown-pragmas", cpp, "-o", so])
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("D", [16, 32])
+def test_rowblock_attention_kernels_source_on_the_cpu(emu_rb, D):
+    g = torch.Generator().manual_seed(D)
+    scale = ctypes.c_float(D ** -0.5)
+
+    def check(BH, Nq, Nk, modes):
+        q, k, v = torch.randn(BH, Nq, D, generator=g), torch.randn(BH, Nk, D, generator=g), torch.randn(BH, Nk, D, generator=g)
+        dout = torch.randn(BH, Nq, D, generator=g)
+        ref_in = [t.double().clone().requires_grad_() for t in (q, k, v)]
+        s = (ref_in[0] * D ** -0.5) @ ref_in[1].transpose(1, 2)
+        ref = s.softmax(-1) @ ref_in[2]
+        ref.backward(dout.double())
+        lse_ref = torch.logsumexp(s, -1).detach().float().numpy().copy()
+        out_ref = ref.detach().float().numpy().copy()
+        delta_ref = (dout * ref.detach().float()).sum(-1).numpy().copy()
+        qa, ka, va, do = (t.numpy().astype(np.float32).copy() for t in (q, k, v, dout))
+        if 0 in modes:
+            out, lse = np.full((BH, Nq, D), np.nan, np.float32), np.full((BH, Nq), np.nan, np.float32)
+            emu_rb.emu_rb(D, 0, _ptr(qa), _ptr(ka), _ptr(va), None, None, None, None, BH, Nq, Nk, scale, _ptr(out), _ptr(lse))
+            assert np.abs(out - out_ref).max() <= 1e-4 * np.abs(out_ref).max() and np.abs(lse - lse_ref).max() <= 1e-4
+        if 1 in modes:
+            dq, delta = np.full((BH, Nq, D), np.nan, np.float32), np.full((BH, Nq), np.nan, np.float32)
+            emu_rb.emu_rb(D, 1, _ptr(qa), _ptr(ka), _ptr(va), _ptr(out_ref), _ptr(do), _ptr(lse_ref), None, BH, Nq, Nk, scale, _ptr(dq), _ptr(delta))
+            w = ref_in[0].grad.numpy()
+            assert np.abs(dq - w).max() <= 2e-4 * np.abs(w).max() and np.abs(delta - delta_ref).max() <= 1e-4 * np.abs(delta_ref).max()
+        if 2 in modes:
+            dk, dv = np.full((BH, Nk, D), np.nan, np.float32), np.full((BH, Nk, D), np.nan, np.float32)
+            emu_rb.emu_rb(D, 2, _ptr(qa), _ptr(ka), _ptr(va), None, _ptr(do), _ptr(lse_ref), _ptr(delta_ref), BH, Nq, Nk, scale, _ptr(dk), _ptr(dv))
+            for got, want in ((dk, ref_in[1].grad.numpy()), (dv, ref_in[2].grad.numpy())):
+                assert np.isfinite(got).all() and np.abs(got - want).max() <= 2e-4 * np.abs(want).max()
+    check(2, 3, 1100, (0, 1))          # few queries, many keys (not a multiple of 256; the last threads see 4 keys, some 5)
+    check(1, 2, 200, (0, 1))           # fewer keys than threads: idle threads must drop out of the merge
+    check(2, 1100, 3, (2,))            # few keys, many queries

@@ -31,6 +31,8 @@ def test_tinyvit_module_matches_the_restated_architecture():
         ref = T.image_encoder(sd, x)
     assert out.shape == (1, 256, 64, 64) and torch.isfinite(out).all()
     assert (out - ref).abs().max().item() < 2e-4, (out - ref).abs().max().item()
+    from micro_sam_amd import util
+    assert util._hash_state_dict(sd).startswith("xxh128:") and util._validate_model_type(sd) == "vit_t"      # 0-dim BatchNorm counters hash too
     # uint8 path = Sam.preprocess + forward
     img = (torch.rand(1, 700, 1024, 3, generator=g) * 255).to(torch.uint8)
     xf = img.permute(0, 3, 1, 2).float()
