@@ -21,10 +21,10 @@ struct Epi {
     void* out; int out_dtype; long ldc;
     int out_mode; u16* q; u16* k; u16* v; int heads, head_dim, tokens;
     const float* row_scale; const float* col_scale;      // fp8 operands: C = acc * row_scale[m] * col_scale[n]
-    int splitk_len;                                      // > 0: split-K launch (msam_gemm_t.split_k): workgroup blockIdx.y contracts over
+    int splitk_len = 0;                                  // > 0: split-K launch (msam_gemm_t.split_k): workgroup blockIdx.y contracts over
                                                          // k in [y * splitk_len, (y + 1) * splitk_len) and ADDS its fp32 tile to `out`
                                                          // (atomics; plain fp32 output, zeroed by the launcher; no bias / epilogue)
-    int dbg;                                             // timing experiments (msam_tune_set "gemm_dbg"; WRONG results when != 0): gemm256 only -
+    int dbg = 0;                                         // timing experiments (msam_tune_set "gemm_dbg"; WRONG results when != 0): gemm256 only -
                                                          // 1 = no global stores, 2 = no epilogue at all, 4 = no k-loop
 };
 
@@ -1087,7 +1087,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
 // Grouped launch of independent 128 x 128-tile products (plain bf16 path only: no fused LayerNorm, no fp8, no LDS-DMA staging)
 extern "C" int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* stream) {
     if (!items || n <= 0 || n > MSAM_GEMM_GROUP_MAX) { msam_set_error("msam_gemm_group_bf16: 1 .. MSAM_GEMM_GROUP_MAX products"); return 1; }
-    GroupArgs g;
+    GroupArgs g{};
     int max_tiles = 0;
     double flops = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -1114,6 +1114,7 @@ extern "C" int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* s
         e.out_mode = p->out_mode; e.q = (u16*)p->q; e.k = (u16*)p->k; e.v = (u16*)p->v;
         e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
         e.row_scale = nullptr; e.col_scale = nullptr;
+        e.splitk_len = 0; e.dbg = 0;
         const int tiles = ((p->M + BM - 1) / BM) * (p->N / BN);
         if (tiles > max_tiles) max_tiles = tiles;
         flops += 2.0 * p->M * (double)p->N * p->K;

@@ -86,41 +86,51 @@ class PointAndBoxPromptGenerator(PromptGeneratorBase):
 
 class IterativePromptGenerator(PromptGeneratorBase):
     """Reference :252-377 (2-d): per object one positive point where the prediction misses the object (or, if nothing is
-    missed, where it is already right) and one negative point where it over-segments (or in the object's dilated bounding
-    box, or anywhere in the background)."""
+    missed, where it is already right) and one negative point where it over-segments (or in the object's bounding box grown by 3 px,
+    or anywhere in the background).
 
-    def _get_positive_points(self, pos_region, overlap_region):
-        locs = [torch.where(r) for r in pos_region]
-        locs = [torch.where(o) if len(l[0]) == 0 else l for l, o in zip(locs, overlap_region)]
-        idx = [np.random.choice(len(l[0])) for l in locs]
-        return [[l[-1][i], l[-2][i]] for l, i in zip(locs, idx)], [1] * len(locs)
+    Same regions, same fallbacks and the same uniform choice inside a region as the reference, but for ALL objects at once on the
+    tensors' device: the reference walks the objects in Python with a ``torch.where`` (a device synchronisation and a host round trip)
+    per object and region - 25 objects x 7 sub-iterations x 2 images x 3-4 regions per training step.  A uniformly random pixel of a
+    region is the arg-max of i.i.d. uniform scores restricted to the region (torch's generator instead of ``np.random.choice``: the
+    same distribution, a different stream)."""
 
-    def _get_negative_locations_in_obj_bbox(self, true_object, custom_df=3):
-        loc = torch.where(true_object)
-        bbox = torch.stack([torch.min(loc[1]), torch.min(loc[2]), torch.max(loc[1]) + 1, torch.max(loc[2]) + 1])
-        bbox_mask = torch.zeros_like(true_object).squeeze(0)
-        bbox_mask[max(bbox[0] - custom_df, 0): min(bbox[2] + custom_df, true_object.shape[-2]),
-                  max(bbox[1] - custom_df, 0): min(bbox[3] + custom_df, true_object.shape[-1])] = 1
-        return torch.where(torch.abs(bbox_mask[None].to(true_object.device) - true_object))
-
-    def _get_negative_points(self, neg_region, true_object):
-        locs = [torch.where(r) for r in neg_region]
-        locs = [self._get_negative_locations_in_obj_bbox(t) if len(l[0]) == 0 else l for l, t in zip(locs, true_object)]
-        locs = [torch.where(t == 0) if len(l[0]) == 0 else l for l, t in zip(locs, true_object)]
-        idx = [np.random.choice(len(l[0])) for l in locs]
-        return [[l[-1][i], l[-2][i]] for l, i in zip(locs, idx)], [0] * len(locs)
+    @staticmethod
+    def _pick(regions: List[torch.Tensor]) -> torch.Tensor:
+        """regions: bool [N, H, W] in order of preference -> int64 [N, 2] (x, y) of a uniformly random pixel of the first non-empty
+        region of every object ((0, 0) if all are empty)."""
+        n, h, w = regions[0].shape
+        chosen = regions[-1]
+        for r in reversed(regions[:-1]):
+            nonempty = r.flatten(1).any(dim=1).view(n, 1, 1)
+            chosen = torch.where(nonempty, r, chosen)
+        scores = torch.rand((n, h * w), device=chosen.device)
+        scores = torch.where(chosen.flatten(1), scores, torch.full_like(scores, -1.0))
+        idx = scores.argmax(dim=1)
+        return torch.stack([idx % w, idx // w], dim=1)
 
     def __call__(self, segmentation: torch.Tensor, prediction: torch.Tensor, **kwargs):
         assert segmentation.shape == prediction.shape, "The segmentation and prediction tensors should have the same shape."
         if segmentation.ndim != 4:
             raise ValueError("The segmentation and prediction tensors should have '4' dimensions (NUM_OBJECTS x 1 x H x W).")
-        true_object = segmentation.to(prediction.device)
-        diff = prediction - true_object
-        neg_region = (diff == 1).to(torch.float32)
-        pos_region = diff == -1
-        overlap = torch.logical_and(prediction == 1, true_object == 1).to(torch.float32)
-        pc, pl = self._get_positive_points(pos_region, overlap)
-        nc, nl = self._get_negative_points(neg_region, true_object)
-        pc, nc = torch.tensor(pc)[:, None], torch.tensor(nc)[:, None]
-        pl, nl = torch.tensor(pl)[:, None], torch.tensor(nl)[:, None]
-        return torch.cat([pc, nc], dim=1), torch.cat([pl, nl], dim=1), None, None
+        true = segmentation.to(prediction.device)[:, 0] == 1                         # [N, H, W]
+        pred = prediction[:, 0] == 1
+        n, h, w = true.shape
+        pos_region = true & ~pred                                                  # diff == -1: missed
+        neg_region = pred & ~true                                                  # diff == 1: over-segmented
+        overlap = pred & true
+        # negative fallback 1: the object's bounding box grown by 3 px, minus the object (reference _get_negative_locations_in_obj_bbox)
+        rows, cols = true.any(dim=2), true.any(dim=1)                              # [N, H], [N, W]
+        yy = torch.arange(h, device=true.device).view(1, h)
+        xx = torch.arange(w, device=true.device).view(1, w)
+        big = max(h, w) + 8
+        y0 = torch.where(rows, yy, big).amin(dim=1, keepdim=True); y1 = torch.where(rows, yy, -big).amax(dim=1, keepdim=True) + 1
+        x0 = torch.where(cols, xx, big).amin(dim=1, keepdim=True); x1 = torch.where(cols, xx, -big).amax(dim=1, keepdim=True) + 1
+        in_y = (yy >= (y0 - 3).clamp(min=0)) & (yy < (y1 + 3).clamp(max=h))
+        in_x = (xx >= (x0 - 3).clamp(min=0)) & (xx < (x1 + 3).clamp(max=w))
+        bbox_ring = (in_y.view(n, h, 1) & in_x.view(n, 1, w)) ^ true               # |bbox mask - object|
+        pc = self._pick([pos_region, overlap, true])
+        nc = self._pick([neg_region, bbox_ring, ~true])
+        coords = torch.stack([pc, nc], dim=1).cpu()                                # [N, 2, 2]: (positive, negative) x (x, y)
+        labels = torch.tensor([[1, 0]]).expand(n, 2).clone()
+        return coords, labels, None, None

@@ -170,7 +170,7 @@ class SamTrainer:
     # ---- reference :291-327
     def _update_prompts(self, batched_inputs, y_one_hot, masks, logits_masks, use_mask_inputs):
         for x1, x2, _inp, logits in zip(masks, y_one_hot, batched_inputs, logits_masks):
-            net_coords, net_labels, _, _ = self.prompt_generator(x2.cpu(), x1.cpu())
+            net_coords, net_labels, _, _ = self.prompt_generator(x2, x1)       # on the masks' device, all objects at once
             net_coords = self.model.transform.apply_coords_torch(net_coords, y_one_hot.shape[-2:])
             _inp["point_coords"] = torch.cat([_inp["point_coords"].cpu(), net_coords], dim=1) if "point_coords" in _inp else net_coords
             _inp["point_labels"] = torch.cat([_inp["point_labels"].cpu(), net_labels.float()], dim=1) \

@@ -56,6 +56,35 @@ def test_prompt_generators_and_convert_inputs():
     assert pred[1, 0, c[1, 1, 1], c[1, 1, 0]] == 1 and true[1, 0, c[1, 1, 1], c[1, 1, 0]] == 0
 
 
+def test_iterative_prompts_regions_and_fallbacks():
+    """IterativePromptGenerator (reference prompt_generators.py:252-377) for all objects at once: the point comes from the first
+    non-empty region in the reference's order of preference, uniformly."""
+    from micro_sam_amd.prompt_generators import IterativePromptGenerator
+    torch.manual_seed(0)
+    true = torch.zeros(3, 1, 40, 50)
+    true[0, 0, 10:20, 10:20] = 1; true[1, 0, 5:9, 30:40] = 1; true[2, 0, 25:35, 5:15] = 1
+    pred = true.clone()
+    pred[0, 0, 10:20, 10:15] = 0                     # object 0: left half missed            -> positive in the missed half
+    pred[1, 0, 20:24, 20:24] = 1                     # object 1: over-segmented far away     -> negative in that patch, positive on the object
+    gen = IterativePromptGenerator()                 # object 2: perfect prediction          -> positive on the object, negative in the 3-px ring
+    seen = set()
+    for _ in range(60):
+        c, l, _, _ = gen(true, pred)
+        assert c.shape == (3, 2, 2) and l.tolist() == [[1, 0]] * 3
+        (px, py), (nx, ny) = c[0].tolist()
+        assert 10 <= py < 20 and 10 <= px < 15 and (not (10 <= ny < 20 and 10 <= nx < 20)) and 7 <= ny < 23 and 7 <= nx < 23
+        (px, py), (nx, ny) = c[1].tolist()
+        assert 5 <= py < 9 and 30 <= px < 40 and 20 <= ny < 24 and 20 <= nx < 24
+        (px, py), (nx, ny) = c[2].tolist()
+        assert 25 <= py < 35 and 5 <= px < 15 and 22 <= ny < 38 and 2 <= nx < 18 and not (25 <= ny < 35 and 5 <= nx < 15)
+        seen.add((px, py))
+    assert len(seen) > 30                             # uniform over the 100 object pixels, not a fixed one
+    # an object that fills the image and is predicted perfectly: no ring, no background -> the degenerate (0, 0)
+    full = torch.ones(1, 1, 8, 8)
+    c, _, _, _ = gen(full, full)
+    assert c[0, 1].tolist() == [0, 0]
+
+
 def test_point_prompts_follow_the_reference_distribution():
     """Reference prompt_generators.py:105-190 as called by training/util.py:192-216 (no centre coordinates): positive points are
     random object pixels (not always the centre), negatives keep a SQUARE (Chebyshev) safety border of ``dilation_strength`` around
