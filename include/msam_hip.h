@@ -78,6 +78,10 @@ typedef struct {
      * contraction (the weight gradients of fine-tuning: dW = dY^T X over all rows).  Plain fp32 output with ldc == N, no bias /
      * table / residual / activation; K % (64 * split_k) == 0.  0 / 1 = off. */
     int32_t split_k;
+    /* ln_mode 1 only (the mask decoder's token side): the normalised row is ALSO written as 16-bit operand copies for the next
+     * products - ln_out_a [M,256] = round16(y + ln_add[row]) (ln_add fp32 [M,256] or NULL), ln_out_b [M,256] = round16(y); the 16-bit
+     * type is the operands' (a_dtype).  NULL = not written.  One launch instead of GEMM + LayerNorm + add/cast launches. */
+    const float* ln_add; void* ln_out_a; void* ln_out_b;
 } msam_gemm_t;
 int msam_gemm_bf16(const msam_gemm_t* p, void* stream);
 /* n <= MSAM_GEMM_GROUP_MAX independent products (each as for msam_gemm_bf16; 128 x 128-tile bf16 path only: no fused LayerNorm,

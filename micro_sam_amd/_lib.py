@@ -31,6 +31,7 @@ class GemmParams(C.Structure):
         ("q", _vp), ("k", _vp), ("v", _vp), ("heads", _i32), ("head_dim", _i32), ("tokens", _i32),
         ("use_glds", _i32), ("ln_mode", _i32), ("ln_w", _vp), ("ln_b", _vp), ("ln_eps", _f32),
         ("a_dtype", _i32), ("row_scale", _vp), ("col_scale", _vp), ("split_k", _i32),
+        ("ln_add", _vp), ("ln_out_a", _vp), ("ln_out_b", _vp),
     ]
 
 

@@ -503,6 +503,20 @@ int gemm(const Ctx& cx, const void* A, long lda, const void* W, int M, int N, in
     return msam_gemm_bf16(&g, cx.s);
 }
 
+// Token-side product with everything behind it in ONE launch (gemm_ln_kernel<F16>, round 3): queries = LayerNorm(A W^T + bias + resid),
+// and the 16-bit operand copies of the next products: out_a = round16(queries + add) (add = the positional encoding of the prompt
+// tokens, or NULL), out_b = round16(queries).  Was: GEMM, LayerNorm, add_cast[2] = 3 dependent latency-bound launches.
+int gemm_ln_tok(const Ctx& cx, const void* A, long lda, const void* W, int M, int K, const float* bias, const float* resid,
+                const float* ln_w, const float* ln_b, float* queries, const float* add, void* out_a, void* out_b) {
+    msam_gemm_t g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.M = M; g.N = C; g.K = K; g.bias = bias;
+    g.resid = resid; g.resid_dtype = resid ? MSAM_F32 : 0; g.ldr = C;
+    g.out = queries; g.out_dtype = MSAM_F32; g.ldc = C; g.a_dtype = MSAM_D16;
+    g.ln_mode = 1; g.ln_w = ln_w; g.ln_b = ln_b; g.ln_eps = 1e-5f;
+    g.ln_add = add; g.ln_out_a = out_a; g.ln_out_b = out_b;
+    return msam_gemm_bf16(&g, cx.s);
+}
+
 // K | V^T projection of the per-prompt stream as two N = 128 launches (k with the positional table, v transposed)
 int wsgemm_kv(const Ctx& cx, const void* x, const u16* wkv, const float* bkv, const float* pek, int rows, void* k_out,
               void* vT_out) {
@@ -610,6 +624,7 @@ extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void*
 }
 
 extern int g_tune_dec_chain, g_tune_dec_chain_min_p, g_tune_chain_variant;
+int g_tune_tok_fuse = 1;              // msam_tune_set "tok_fuse"
 namespace {
 struct Work {
     float *qpe, *queries, *tmp; u16 *a, *b, *qs, *ks, *vs, *attn_tok, *mlp_h;
@@ -784,6 +799,8 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     // Chained form (decfold_tok.hip): with one shared source the layer-0 output stream is not written; the layer-1
     // token->image attention and the layer-1 image->token block recompute their tiles of it from the L2-resident source.
     const bool chain = g_tune_dec_chain && !own_src && !dbg && Nt <= 8 && P >= g_tune_dec_chain_min_p;
+    // token side: product + LayerNorm + operand copies per launch (gemm_ln_tok; msam_tune_set "tok_fuse" 0 = one launch per step)
+    const bool fuse_tok = g_tune_tok_fuse != 0 && !dbg;
     // operand images in the (then unused) q / attention stream buffers: layer 0, layer 1; the attention's operands in vT
     void* const oper0 = w.qimg; void* const oper1 = w.attn_img;
     // blocked copies of the shared tables (source, layer-0 q, tabK / tabQ of layer 1) at the end of the attention workspace in vT
@@ -800,7 +817,12 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         // (1) token self attention
         // layer 0: q = k = v input = bf16(tokens), written by prompt_tokens_kernel; layer 1: q = k input carries the PE
         const u16* sv = w.a;
-        if (li > 0) { ADD_CAST2(w.queries, w.qpe, w.a, w.b); sv = w.b; }
+        if (li > 0) {
+            // (w.a, w.b) = round16(queries + pe), round16(queries): written behind norm3 of the previous layer (step 3) and still
+            // valid - step 4 only reads them and updates the image-token stream
+            if (!fuse_tok) ADD_CAST2(w.queries, w.qpe, w.a, w.b);
+            sv = w.b;
+        }
         {
             const msam_gemm_t qkv[3] = {mk_gemm(w.a, C, L.self_attn.q_w, M, C, C, L.self_attn.q_b, w.qs, MSAM_D16, C),
                                         mk_gemm(w.a, C, L.self_attn.k_w, M, C, C, L.self_attn.k_b, w.ks, MSAM_D16, C),
@@ -809,11 +831,16 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         }
         hipLaunchKernelGGL(token_self_attn_kernel, dim3(P), dim3(128), 0, cx.s, w.qs, w.ks, w.vs, Nt, w.attn_tok);
         CHECK(msam_check_launch("token_self_attn"));
+        if (fuse_tok) {
+            CHECK(gemm_ln_tok(cx, w.attn_tok, C, L.self_attn.o_w, M, C, L.self_attn.o_b, li == 0 ? nullptr : w.queries, L.n1_w, L.n1_b,
+                              w.queries, w.qpe, w.a, nullptr));
+        } else {
         CHECK(gemm(cx, w.attn_tok, C, L.self_attn.o_w, M, C, C, L.self_attn.o_b, w.tmp, MSAM_F32, C, 0,
                    li == 0 ? nullptr : w.queries, li == 0 ? 0 : MSAM_F32, C));
         LN(w.tmp, L.n1_w, L.n1_b, M, w.queries, MSAM_F32);
         // (2) token -> image attention
         ADD_CAST(w.queries, w.qpe, w.a);
+        }
         CHECK(gemm(cx, w.a, C, L.t2i.q_w, M, CI, C, L.t2i.q_b, w.qs, MSAM_D16, CI));
         if (li == 0 && !own_src) {
             // prompt-independent K / V^T of the shared embedding (prepare_image): 1 MiB, L2 resident
@@ -835,15 +862,23 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         } else {
             CHECK(t2i_stream(cx, w, c, li, L.t2i, P, Nt));
         }
+        if (fuse_tok) {
+            CHECK(gemm_ln_tok(cx, w.attn_tok, CI, L.t2i.o_w, M, CI, L.t2i.o_b, w.queries, L.n2_w, L.n2_b, w.queries, nullptr, w.a, nullptr));
+        } else {
         CHECK(gemm(cx, w.attn_tok, CI, L.t2i.o_w, M, C, CI, L.t2i.o_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n2_w, L.n2_b, M, w.queries, MSAM_F32);
         // (3) token MLP
         ADD_CAST(w.queries, nullptr, w.a);
+        }
         CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_D16, 2048, MSAM_ACT_RELU));
+        if (fuse_tok) {
+            CHECK(gemm_ln_tok(cx, w.mlp_h, 2048, L.mlp2_w, M, 2048, L.mlp2_b, w.queries, L.n3_w, L.n3_b, w.queries, w.qpe, w.a, w.b));
+        } else {
         CHECK(gemm(cx, w.mlp_h, 2048, L.mlp2_w, M, C, 2048, L.mlp2_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n3_w, L.n3_b, M, w.queries, MSAM_F32);
         // (4) image -> token attention, updates the image-token stream
         ADD_CAST2(w.queries, w.qpe, w.a, w.b);
+        }
         {
             const msam_gemm_t kv[2] = {mk_gemm(w.a, C, L.i2t.k_w, M, CI, C, L.i2t.k_b, w.ks, MSAM_D16, CI),
                                        mk_gemm(w.b, C, L.i2t.v_w, M, CI, C, L.i2t.v_b, w.vs, MSAM_D16, CI)};
@@ -876,15 +911,20 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
     }
     if (dbg) return 0;   // test hook: leave queries / keys of the last executed layer in the workspace
     // final token -> image attention
-    ADD_CAST(w.queries, w.qpe, w.a);
+    if (!fuse_tok) ADD_CAST(w.queries, w.qpe, w.a);          // (fused form: w.a = round16(queries + pe) already, see above)
     CHECK(gemm(cx, w.a, C, dec->final_attn.q_w, M, CI, C, dec->final_attn.q_b, w.qs, MSAM_D16, CI));
     CHECK(t2i_stream(cx, w, c, 2, dec->final_attn, P, Nt, chain));
+    if (fuse_tok) {
+        CHECK(gemm_ln_tok(cx, w.attn_tok, CI, dec->final_attn.o_w, M, CI, dec->final_attn.o_b, w.queries, dec->nf_w, dec->nf_b, w.queries,
+                          nullptr, w.a, nullptr));
+    } else {
     CHECK(gemm(cx, w.attn_tok, CI, dec->final_attn.o_w, M, C, CI, dec->final_attn.o_b, w.tmp, MSAM_F32, C, 0, w.queries,
                MSAM_F32, C));
     LN(w.tmp, dec->nf_w, dec->nf_b, M, w.queries, MSAM_F32);
 
     // heads: hyper-network MLPs on mask tokens 1..4, IoU head on token 0 (bf16 copy of queries, strided rows)
     ADD_CAST(w.queries, nullptr, w.a);
+    }
     // the five 3-layer MLPs (IoU head on token 0, hyper-networks on tokens 1..4) layer by layer, one grouped launch per layer
     {
         msam_gemm_t h[5];

@@ -695,8 +695,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 //                                          ln_mode 2: LayerNorm over each 64-column group + GELU (LayerNorm2d + GELU of
 //                                                     the first up-scaling stage; columns = (sub-pixel, channel))
 // This removes the fp32 pre-norm round trip through HBM (write 4 B + read 4 B per element) of the unfused form.
-struct EpiLN { const float* ln_w; const float* ln_b; float eps; int mode; };
+// add / out_a / out_b (msam_gemm_t.ln_add / ln_out_a / ln_out_b; the decoder's token side, round 3): besides the plain output the
+// normalised row is also written as 16-bit operand copies for the NEXT products - out_a = round16(v + add[row]) (the queries with
+// their positional encoding), out_b = round16(v) - which were separate add_cast launches behind a separate LayerNorm launch.
+struct EpiLN { const float* ln_w; const float* ln_b; float eps; int mode; const float* add; u16* out_a; u16* out_b; int dt16; };
 
+template <bool F16>
 __global__ __launch_bounds__(256) void gemm_ln_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W,
                                                       long ldw, int M, int K, Epi e, EpiLN ln) {
     extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];
@@ -763,7 +767,7 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const u16* __restrict__ A,
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = F16 ? mfma16h(a[i], b[j], acc[i][j]) : mfma16(a[i], b[j], acc[i][j]);
         }
         if (kt + 1 < nk) LN_COMMIT(buf ^ 1);
         __syncthreads();
@@ -806,8 +810,8 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const u16* __restrict__ A,
                 v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
             } else {
                 uint2 t = *(const uint2*)((const u16*)e.resid + (long)rr * e.ldr + col);
-                v[0] += bf2f((u16)(t.x & 0xffff)); v[1] += bf2f((u16)(t.x >> 16));
-                v[2] += bf2f((u16)(t.y & 0xffff)); v[3] += bf2f((u16)(t.y >> 16));
+                v[0] += load16((u16)(t.x & 0xffff), e.resid_dtype); v[1] += load16((u16)(t.x >> 16), e.resid_dtype);
+                v[2] += load16((u16)(t.y & 0xffff), e.resid_dtype); v[3] += load16((u16)(t.y >> 16), e.resid_dtype);
             }
         }
         if (ln.mode) {
@@ -827,8 +831,18 @@ __global__ __launch_bounds__(256) void gemm_ln_kernel(const u16* __restrict__ A,
         if (e.out_dtype == MSAM_F32) {
             *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-            uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+            uint2 pk; pk.x = pack16(v[0], v[1], e.out_dtype); pk.y = pack16(v[2], v[3], e.out_dtype);
             *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
+        }
+        if (ln.out_b) {
+            uint2 pk; pk.x = pack16(v[0], v[1], ln.dt16); pk.y = pack16(v[2], v[3], ln.dt16);
+            *(uint2*)(ln.out_b + (long)row * LN_ + col) = pk;
+        }
+        if (ln.out_a) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ln.add) t = *(const float4*)(ln.add + (long)row * LN_ + col);
+            uint2 pk; pk.x = pack16(v[0] + t.x, v[1] + t.y, ln.dt16); pk.y = pack16(v[2] + t.z, v[3] + t.w, ln.dt16);
+            *(uint2*)(ln.out_a + (long)row * LN_ + col) = pk;
         }
     }
 }
@@ -955,7 +969,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.splitk_len = 0;
     e.dbg = g_tune_gemm_dbg;
     hipStream_t s = (hipStream_t)stream;
-    if (p->ln_mode && (p->a_dtype == MSAM_FP8 || p->a_dtype == MSAM_F16)) { msam_set_error("msam_gemm_bf16(fp8 / fp16): no fused LayerNorm epilogue"); return 1; }
+    if (p->ln_mode && p->a_dtype == MSAM_FP8) { msam_set_error("msam_gemm_bf16(fp8): no fused LayerNorm epilogue"); return 1; }
     const bool f16 = p->a_dtype == MSAM_F16;
     if (p->ln_mode) {
         if (p->N != 256 || p->out_mode != 0 || !p->ln_w || !p->ln_b || p->ln_mode < 0 || p->ln_mode > 2) {
@@ -965,20 +979,24 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         static bool attr_set = false;
         constexpr int LN_LDS = 2 * (64 * 8 + 256 * 8) * 16;     // 80 KB dynamic LDS
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)gemm_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)gemm_ln_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm_ln_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LN_LDS) != hipSuccess) {
                 msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
                 return 2;
             }
             attr_set = true;
         }
-        EpiLN ln{p->ln_w, p->ln_b, p->ln_eps, p->ln_mode};
+        if ((p->ln_out_a || p->ln_out_b) && p->ln_mode != 1) { msam_set_error("msam_gemm_bf16: ln_out_a / ln_out_b go with ln_mode 1"); return 1; }
+        EpiLN ln{p->ln_w, p->ln_b, p->ln_eps, p->ln_mode, p->ln_add, (u16*)p->ln_out_a, (u16*)p->ln_out_b, f16 ? MSAM_F16 : MSAM_BF16};
         const bool prof_ln = g_prof_on && g_prof_n < PROF_MAX;
         if (prof_ln) {
             g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 5;
             (void)hipEventRecord(g_prof[g_prof_n].a, s);
         }
-        hipLaunchKernelGGL(gemm_ln_kernel, dim3((p->M + 63) / 64), dim3(256), LN_LDS, s, (const u16*)p->A, (long)p->lda,
-                           (const u16*)p->W, (long)p->ldw, p->M, p->K, e, ln);
+        if (f16) hipLaunchKernelGGL(gemm_ln_kernel<true>, dim3((p->M + 63) / 64), dim3(256), LN_LDS, s, (const u16*)p->A, (long)p->lda,
+                                    (const u16*)p->W, (long)p->ldw, p->M, p->K, e, ln);
+        else hipLaunchKernelGGL(gemm_ln_kernel<false>, dim3((p->M + 63) / 64), dim3(256), LN_LDS, s, (const u16*)p->A, (long)p->lda,
+                                (const u16*)p->W, (long)p->ldw, p->M, p->K, e, ln);
         if (prof_ln) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
         return msam_check_launch("msam_gemm_bf16(ln)");
     }
