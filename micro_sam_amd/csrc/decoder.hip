@@ -624,7 +624,12 @@ extern "C" int msam_decoder_prepare_image(const msam_decoder_t* dec, const void*
 }
 
 extern int g_tune_dec_chain, g_tune_dec_chain_min_p, g_tune_chain_variant;
-int g_tune_tok_fuse = 1;              // msam_tune_set "tok_fuse"
+// msam_tune_set "tok_fuse": 1 = product + LayerNorm + operand copies of the token side in one launch each (gemm_ln_tok: 18 fewer launches
+// per decode).  Measured (profiles/r03_experiments.md): 151.7 vs 154.4 tiles/s with one decode lane, 167.9 vs 168.7 with three - the
+// row-complete 64 x 256 tile kernel walks K = 2048 of the MLP on 112 workgroups and gives the saved launches back; the token side is
+// bound by the latency INSIDE each small product (a dependent chain of 4 - 32 k-tiles on a fraction of the chip), not by launch count.
+// Default off; kept as a tested option.
+int g_tune_tok_fuse = 0;
 namespace {
 struct Work {
     float *qpe, *queries, *tmp; u16 *a, *b, *qs, *ks, *vs, *attn_tok, *mlp_h;

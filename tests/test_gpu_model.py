@@ -691,6 +691,30 @@ def test_config3_vit_l_tiled_volume_segment_slices():
         assert np.array_equal(seg[z], ref) and m > 0
 
 
+def test_token_side_fused_launches_give_the_same_decode(ctx):
+    """msam_tune_set("tok_fuse", 1): the token side's product + LayerNorm + 16-bit operand copies in one launch each
+    (gemm_ln_kernel<F16> with ln_out_a / ln_out_b) == the one-launch-per-step sequence (same arithmetic; the LayerNorm sums run in a
+    different order)."""
+    from micro_sam_amd import _lib
+    sam = ctx["predictor"].model
+    feats = ctx["ref_b"].cuda()
+    g = torch.Generator().manual_seed(9)
+    P = 256
+    pts = (torch.rand(P, 1, 2, generator=g) * 1024).cuda()
+    lbl = torch.ones(P, 1, dtype=torch.int).cuda()
+    lib = _lib.load()
+    try:
+        lib.msam_tune_set(b"tok_fuse", 0)
+        low0, iou0 = sam.decode(feats, pts, lbl)
+        lib.msam_tune_set(b"tok_fuse", 1)
+        low1, iou1 = sam.decode(feats, pts, lbl)
+    finally:
+        lib.msam_tune_set(b"tok_fuse", 0)
+    scale = low0.abs().max().item()
+    assert torch.isfinite(low1).all() and (low1 - low0).abs().max().item() <= 2e-3 * scale
+    assert (iou1 - iou0).abs().max().item() <= 2e-3
+
+
 def test_config1_vit_t_plumbing():
     """BASELINE configs[0]: vit_t (MobileSAM) - get_sam_model -> precompute_image_embeddings -> AutomaticMaskGenerator on one 512 x 512
     tile, the checks of the reference's test/test_instance_segmentation.py:73-121 that do not need trained weights (shapes, regenerate
