@@ -341,6 +341,13 @@ int msam_patchify_u8_16(const uint8_t* img, int32_t B, int32_t h, int32_t w, int
 int msam_im2col3x3(const void* x_bf16, int32_t B, int32_t C, void* out_bf16, void* stream);
 int msam_cast_f32_to_bf16(const float* x, void* out_bf16, int64_t n, void* stream);
 int msam_cast_f32_to_16(const float* x, int32_t dtype16, void* out16, int64_t n, void* stream);
+/* ResizeLongestSide.apply_image (micro_sam/util.py:663: Pillow's BILINEAR resize of the uint8 RGB image) on the device: one
+ * fixed-point resampling pass along one axis, out[o] = clip8((2^21 + sum_t in[first[o] + t] * coef[o][t]) >> 22).  in: uint8 [B,H,W,C];
+ * axis 1 = along W -> out [B,H,n_out,C], axis 0 = along H -> out [B,n_out,W,C]; bounds int32 [n_out,2] = (first tap, taps), coefs int32
+ * [n_out,ksize] (device memory; micro_sam_amd.transforms.pil_bilinear_tables = Pillow's precompute_coeffs + normalize_coeffs_8bpc).
+ * Pillow's order: horizontal pass into an 8-bit intermediate image, then the vertical pass. */
+int msam_resample_u8(const uint8_t* in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t axis, int32_t n_out,
+                     const int32_t* bounds, const int32_t* coefs, int32_t ksize, uint8_t* out, void* stream);
 /* hi + lo operand pairs of the encoder's "split" sites (patch embedding, neck: msam_encoder_t.split_io): a value enters its product
  * as hi = round16(v), lo = round16(v - hi); rows are written [hi | lo | hi] (K -> 3K; the 3 x 3 gather writes [hi | lo], K -> 2K)
  * against weight rows [Whi | Whi | Wlo], so plain 16-bit products over the widened K form hi*Whi + lo*Whi + hi*Wlo.  Same arguments

@@ -165,6 +165,7 @@ _PROTOS = {
     "msam_patchify16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_patchify_u8_16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msam_cast_f32_to_16": (_i32, [_vp, _i32, _vp, _i64, _vp]),
+    "msam_resample_u8": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
     "msam_patchify_split16": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_patchify_u8_split16": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "msam_im2col3x3_split16": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

@@ -58,6 +58,38 @@ __global__ __launch_bounds__(256) void to_image_kernel(const T* __restrict__ in,
     }
 }
 
+// ---- Pillow's BILINEAR resize of an 8-bit image (ResizeLongestSide.apply_image, reference micro_sam/util.py:663; libImaging/Resample.c):
+// one pass along one axis - out[o] = clip8((2^21 + sum_t in[first[o] + t] * coef[o][t]) >> 22) with the fixed-point tables of
+// micro_sam_amd/transforms.py pil_bilinear_tables (computed exactly as Pillow computes them; tests/test_resize_host.py pins tables and
+// passes to Pillow itself).  The caller runs the horizontal pass into an 8-bit intermediate image and then the vertical pass, as
+// Pillow does.  in: uint8 [B, H, W, C]; axis 1 = along W (out [B, H, n_out, C]), axis 0 = along H (out [B, n_out, W, C]).
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ in, int B, int H, int W, int C, int axis, int n_out,
+                                                          const int* __restrict__ bounds, const int* __restrict__ coefs, int ksize,
+                                                          uint8_t* __restrict__ out) {
+    const int oh = axis == 0 ? n_out : H, ow = axis == 1 ? n_out : W;
+    const long total = (long)B * oh * ow * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int x = (int)(r % ow); r /= ow;
+        const int y = (int)(r % oh);
+        const int b = (int)(r / oh);
+        const int o = axis == 1 ? x : y;
+        const int first = bounds[2 * o], n = bounds[2 * o + 1];
+        const int* k = coefs + (long)o * ksize;
+        int acc = 1 << 21;
+        if (axis == 1) {
+            const uint8_t* src = in + (((long)b * H + y) * W + first) * C + c;
+            for (int t = 0; t < n; ++t) acc += (int)src[(long)t * C] * k[t];
+        } else {
+            const uint8_t* src = in + (((long)b * H + first) * W + x) * C + c;
+            for (int t = 0; t < n; ++t) acc += (int)src[(long)t * W * C] * k[t];
+        }
+        const int v = acc >> 22;
+        out[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
 template <typename T>
 int run(const void* in, long npix, int C, uint8_t* out, uint32_t* mm, hipStream_t s) {
     const int nch = C > 3 ? 3 : C;
@@ -85,4 +117,16 @@ extern "C" int msam_to_image(const void* in, int32_t in_dtype, int32_t H, int32_
         case MSAM_F32: return run<float>(in, npix, C, out, mm, s);
         default: msam_set_error("msam_to_image: input dtype must be MSAM_U8, MSAM_U16 or MSAM_F32"); return 1;
     }
+}
+
+extern "C" int msam_resample_u8(const uint8_t* in, int32_t B, int32_t H, int32_t W, int32_t C, int32_t axis, int32_t n_out,
+                                const int32_t* bounds, const int32_t* coefs, int32_t ksize, uint8_t* out, void* stream) {
+    if (!in || !out || !bounds || !coefs || B <= 0 || H <= 0 || W <= 0 || C <= 0 || n_out <= 0 || ksize <= 0 || (axis != 0 && axis != 1)) {
+        msam_set_error("msam_resample_u8: bad argument");
+        return 1;
+    }
+    const long total = (long)B * (axis == 0 ? n_out : H) * (axis == 1 ? n_out : W) * C;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, B, H, W, C, axis, n_out, bounds, coefs, ksize, out);
+    return msam_check_launch("msam_resample_u8");
 }

@@ -180,6 +180,43 @@ def to_image(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_RESAMPLE_TABLES: Dict[Any, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def resize_bilinear_u8(images: torch.Tensor, newh: int, neww: int) -> torch.Tensor:
+    """``ResizeLongestSide.apply_image`` on the device: Pillow's BILINEAR resize of uint8 [B,H,W,C] images (horizontal pass into an
+    8-bit intermediate, then vertical; a pass is skipped when that size does not change), bit-identical to
+    ``np.array(Image.fromarray(img).resize((neww, newh), Image.BILINEAR))`` (msam_resample_u8; tables cached per size and device)."""
+    _lib.require_gpu()
+    from .transforms import pil_bilinear_tables
+    assert images.dtype == torch.uint8 and images.dim() == 4
+    x = images.contiguous()
+    B, H, W, Cc = x.shape
+    lib = _lib.load()
+
+    def tables(n_in, n_out):
+        key = (n_in, n_out, x.device.index)
+        t = _RESAMPLE_TABLES.get(key)
+        if t is None:
+            b, c = pil_bilinear_tables(n_in, n_out)
+            t = (torch.as_tensor(b).to(x.device).contiguous(), torch.as_tensor(c).to(x.device).contiguous())
+            _RESAMPLE_TABLES[key] = t
+        return t
+    if neww != W:
+        b, c = tables(W, neww)
+        out = torch.empty((B, H, neww, Cc), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.msam_resample_u8(x.data_ptr(), B, H, W, Cc, 1, neww, b.data_ptr(), c.data_ptr(), int(c.shape[1]), out.data_ptr(),
+                                        _lib.stream_ptr()), "msam_resample_u8")
+        x, W = out, neww
+    if newh != H:
+        b, c = tables(H, newh)
+        out = torch.empty((B, newh, W, Cc), dtype=torch.uint8, device=x.device)
+        _lib.check(lib.msam_resample_u8(x.data_ptr(), B, H, W, Cc, 0, newh, b.data_ptr(), c.data_ptr(), int(c.shape[1]), out.data_ptr(),
+                                        _lib.stream_ptr()), "msam_resample_u8")
+        x = out
+    return x
+
+
 def patchify(img: torch.Tensor) -> torch.Tensor:
     B = img.shape[0]
     out = torch.empty((B * 4096, 768), dtype=torch.bfloat16, device=img.device)

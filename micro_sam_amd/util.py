@@ -199,13 +199,14 @@ def _compute_embeddings_batched(predictor, batched_images):
 
 
 def _device_to_image_ok(raw_images) -> bool:
-    """Raw tiles that need no resize (long side == the encoder's 1024) and have a dtype the device kernel takes."""
+    """Raw tiles of one shape with a dtype the device kernels take (``_to_image`` and - when the long side is not the encoder's
+    1024 - Pillow's resize run on the device, both bit-identical to the host functions)."""
     first = raw_images[0]
     if not isinstance(first, np.ndarray) or first.ndim not in (2, 3):
         return False
     if any((not isinstance(im, np.ndarray)) or im.shape != first.shape or im.dtype != first.dtype for im in raw_images):
         return False
-    return max(first.shape[:2]) == modeling.IMG_SIZE and first.dtype.kind in "uif" and first.dtype.itemsize <= 4
+    return first.dtype.kind in "uif" and first.dtype.itemsize <= 4 and min(first.shape[:2]) >= 1
 
 
 def _upload_raw_tiles(predictor, raw_images) -> torch.Tensor:
@@ -244,13 +245,17 @@ def _compute_embeddings_batched_raw(predictor, raw_images):
     predictor.reset_image()
     dev = _upload_raw_tiles(predictor, raw_images)
     batch = torch.stack([to_image_device(dev[b]) for b in range(dev.shape[0])])
-    features = predictor.model.image_encoder.forward_u8(batch)
     size = tuple(raw_images[0].shape[:2])
+    input_size = tuple(predictor.transform.get_preprocess_shape(size[0], size[1], modeling.IMG_SIZE))
+    if input_size != size:                   # ResizeLongestSide.apply_image: Pillow's bilinear resize, on the device
+        from . import ops
+        batch = ops.resize_bilinear_u8(batch, input_size[0], input_size[1])
+    features = predictor.model.image_encoder.forward_u8(batch)
     predictor.original_size = size
-    predictor.input_size = size
+    predictor.input_size = input_size
     predictor.features = features[-1:]
     predictor.is_image_set = True
-    return features, [size] * len(raw_images), [size] * len(raw_images)
+    return features, [size] * len(raw_images), [input_size] * len(raw_images)
 
 
 def handle_pbar(verbose, pbar_init, pbar_update):

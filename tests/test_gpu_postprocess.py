@@ -6,6 +6,11 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
 SIZES = [((1024, 1024), (1024, 1024)), ((1024, 768), (1024, 768)), ((1024, 1024), (512, 512)), ((683, 1024), (400, 600))]
 
 
@@ -161,3 +166,31 @@ def test_raw_tile_fast_path_gives_the_same_embedding():
     a, _, _ = util._compute_embeddings_batched_raw(p, small)
     b, _, _ = util._compute_embeddings_batched(p, [util._to_image(t) for t in small])
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,new", [((896, 896, 3), (1024, 1024)), ((512, 512, 3), (1024, 1024)), ((600, 450, 3), (1024, 768)),
+                                       ((1400, 1100, 3), (1024, 805)), ((768, 1024, 3), (768, 1024)), ((301, 517, 3), (596, 1024))])
+def test_resize_on_the_device_is_pillow(shape, new):
+    """ops.resize_bilinear_u8 (msam_resample_u8, the two fixed-point passes of Pillow's BILINEAR resize) == Pillow, bit for bit; and a
+    tile that needs the resize gives the same embedding through the raw-tile device path as through the host path (PIL)."""
+    _gpu()
+    from PIL import Image
+    from micro_sam_amd import ops
+    rng = np.random.default_rng(shape[0] + shape[1])
+    imgs = rng.integers(0, 256, size=(2,) + shape, dtype=np.uint8)
+    got = ops.resize_bilinear_u8(torch.as_tensor(imgs).cuda(), new[0], new[1]).cpu().numpy()
+    for b in range(2):
+        ref = np.array(Image.fromarray(imgs[b]).resize((new[1], new[0]), Image.BILINEAR))
+        assert got[b].shape == ref.shape and np.array_equal(got[b], ref)
+
+
+def test_raw_tile_path_with_resize_matches_the_host_path(vit_b_sd):
+    _gpu()
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_tile
+    p = util.get_sam_model("vit_b", device="cuda", state_dict=vit_b_sd)
+    tile = synthetic_tile(7, (896, 640))                                  # long side 896 -> Pillow resize to 1024 x 731
+    f_raw, osz, isz = util._compute_embeddings_batched_raw(p, [tile])
+    assert osz == [(896, 640)] and isz == [(1024, 731)]
+    f_host, _, isz_h = util._compute_embeddings_batched(p, [util._to_image(tile)])
+    assert isz_h == isz and torch.equal(f_raw, f_host)
