@@ -585,6 +585,14 @@ int msam_label_components_async(const int32_t* seg, int32_t H, int32_t W, int32_
 int msam_slice_overlaps(const int32_t* labels, int32_t Z, int32_t H, int32_t W, uint64_t* table_keys, int32_t* table_counts,
                         int32_t capacity, int32_t* edges, int32_t max_edges, int32_t* n_edges, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Seeded watershed of InstanceSegmentationWithDecoder.generate (micro_sam/instance_segmentation.py:1083-1168 ->
+ * torch_em watershed_from_center_and_boundary_distances -> skimage.segmentation.watershed).  HOST function
+ * (host pointers, no stream): the reference's CPU step, restated from scikit-image's published priority flood.
+ * image fp32 [H,W], markers int32 [H,W] (0 = none), mask uint8 [H,W] or NULL, out int32 [H,W].
+ * ------------------------------------------------------------------------------------------------- */
+int msam_host_seeded_watershed(const float* image, const int32_t* markers, const uint8_t* mask, int32_t H, int32_t W, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,7 @@ _PROTOS = {
     "msam_component_sizes": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "msam_labels_from_masks_workspace_bytes": (_i64, [_i32, _i32]),
     "msam_labels_from_masks": (_i32, [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "msam_host_seeded_watershed": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "msam_slice_overlaps": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, C.POINTER(_i32), _vp]),

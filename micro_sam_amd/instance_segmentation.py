@@ -594,14 +594,63 @@ def _derive_box_prompts(predictions, box_extension: float):
     return {"boxes": np.array(prompts)}
 
 
+def _gaussian(x: np.ndarray, sigma: float) -> np.ndarray:
+    from scipy import ndimage
+    return ndimage.gaussian_filter(np.asarray(x, dtype=np.float32), sigma, mode="mirror", truncate=3.0)
+
+
+def seeded_watershed(heights: np.ndarray, markers: np.ndarray, mask: Optional[np.ndarray] = None) -> np.ndarray:
+    """``skimage.segmentation.watershed(heights, markers=markers, mask=mask)`` (connectivity 1, no compactness) through the
+    library's host priority flood (msam_host_seeded_watershed)."""
+    import ctypes as C
+    from . import _lib
+    h = np.ascontiguousarray(heights, dtype=np.float32)
+    m = np.ascontiguousarray(markers, dtype=np.int32)
+    assert h.ndim == 2 and m.shape == h.shape
+    mk = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+    out = np.empty(h.shape, dtype=np.int32)
+    _lib.check(_lib.load().msam_host_seeded_watershed(h.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p),
+                                                      None if mk is None else mk.ctypes.data_as(C.c_void_p), h.shape[0], h.shape[1],
+                                                      out.ctypes.data_as(C.c_void_p)), "msam_host_seeded_watershed")
+    return out
+
+
+def watershed_from_center_and_boundary_distances(center_distances, boundary_distances, foreground_map,
+                                                 center_distance_threshold: float = 0.5, boundary_distance_threshold: float = 0.5,
+                                                 foreground_threshold: float = 0.5, distance_smoothing: float = 1.6,
+                                                 min_size: int = 0) -> np.ndarray:
+    """``torch_em.util.segmentation.watershed_from_center_and_boundary_distances`` (called at reference :1131-1140), restated:
+    smooth both distance maps, seeds where both are below their thresholds inside the foreground, label the seeds (8-connected,
+    raster order), flood the smoothed boundary distances from them inside the foreground mask, drop objects below ``min_size``
+    and renumber consecutively."""
+    from scipy import ndimage
+    center = _gaussian(center_distances, distance_smoothing) if distance_smoothing > 0 else np.asarray(center_distances, np.float32)
+    boundary = _gaussian(boundary_distances, distance_smoothing) if distance_smoothing > 0 else np.asarray(boundary_distances, np.float32)
+    fg = np.asarray(foreground_map) > foreground_threshold
+    seeds = (center < center_distance_threshold) & (boundary < boundary_distance_threshold)
+    seeds[~fg] = False
+    markers, _ = ndimage.label(seeds, structure=np.ones((3, 3), dtype=bool))
+    seg = seeded_watershed(boundary, markers, fg).astype(np.uint32)
+    if min_size > 0:
+        ids, sizes = np.unique(seg, return_counts=True)
+        seg[np.isin(seg, ids[sizes < min_size])] = 0
+        keep = np.unique(seg)
+        keep = keep[keep != 0]
+        lut = np.zeros(int(seg.max()) + 1, dtype=np.uint32)
+        lut[keep] = np.arange(1, len(keep) + 1, dtype=np.uint32)
+        seg = lut[seg]
+    return seg
+
+
 class InstanceSegmentationWithDecoder:
     """State handling of the reference's decoder-based segmenters (:953-1207): ``initialize`` runs ``decoder(embeddings,
     input_shape, original_shape) -> [1, 3, H, W]`` (foreground, centre distances, boundary distances) on the predictor's
     embedding of the image.  The decoder is any callable with that signature - the reference's ``DecoderAdapter`` around
     ``torch_em.model.UNETR`` (:688-828) is not part of this build (torch_em is not vendored in the reference).
 
-    ``generate`` of THIS class is the reference's seeded watershed (vigra / elf, :1083-1168) and is not provided;
-    ``AutomaticPromptGenerator`` below derives point prompts from the same state instead and is."""
+    ``generate`` is the reference's seeded watershed (:1083-1168) on the host, as in the reference (restated over scipy and the
+    library's priority flood: vigra / scikit-image / torch_em are absent); ``AutomaticPromptGenerator`` below derives point prompts
+    from the same state instead."""
 
     def __init__(self, predictor: SamPredictor, decoder) -> None:
         self._predictor = predictor
@@ -643,10 +692,30 @@ class InstanceSegmentationWithDecoder:
                  "bbox": [bb[1].start, bb[1].stop - bb[1].start, bb[0].start, bb[0].stop - bb[0].start],    # [x0, w, y0, h]
                  "crop_box": crop_box, "seg_id": seg_id} for seg_id, bb, area in label_regions(segmentation)]
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError(
-            "micro_sam_amd: the seeded watershed of InstanceSegmentationWithDecoder.generate (vigra / elf) is not provided; "
-            "AutomaticPromptGenerator.generate works on the same state")
+    def generate(self, center_distance_threshold: float = 0.5, boundary_distance_threshold: float = 0.5,
+                 foreground_threshold: float = 0.5, foreground_smoothing: float = 1.0, distance_smoothing: float = 1.6,
+                 min_size: int = 0, output_mode: str = "instance_segmentation", tile_shape=None, halo=None, n_threads=None,
+                 optimize_memory: bool = False, segmentation=None):
+        """Reference :1083-1168 (``tile_shape`` / ``halo`` / ``n_threads`` / ``optimize_memory`` only parallelise the reference's host
+        post-processing and are accepted and ignored): Gaussian smoothing of the three maps, seeds = connected components of
+        {centre distance < t, boundary distance < t, foreground > t}, seeded watershed of the smoothed boundary distances inside
+        the foreground (``watershed_from_center_and_boundary_distances``), size filter.  Host arithmetic as in the reference -
+        restated over scipy + the library's priority flood because vigra / scikit-image / torch_em are absent: the Gaussian is
+        vigra's (window 3 sigma, mirrored border) through ``scipy.ndimage.gaussian_filter(truncate=3, mode="mirror")``, the seeds are
+        8-connected (scikit-image's ``label`` default), the flood is scikit-image's published algorithm (csrc/watershed.hip).
+        PARITY UNPINNED against those libraries."""
+        if not self.is_initialized:
+            raise RuntimeError("InstanceSegmentationWithDecoder has not been initialized. Call initialize first.")
+        seg = watershed_from_center_and_boundary_distances(
+            self._center_distances, self._boundary_distances,
+            _gaussian(self._foreground, foreground_smoothing) if foreground_smoothing > 0 else self._foreground,
+            center_distance_threshold, boundary_distance_threshold, foreground_threshold, distance_smoothing, min_size)
+        if segmentation is not None:
+            segmentation[:] = seg
+            seg = segmentation
+        if output_mode == "instance_segmentation":
+            return seg
+        return self._to_masks(seg, output_mode)
 
     def get_state(self) -> Dict[str, Any]:
         if not self.is_initialized:

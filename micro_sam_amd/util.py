@@ -240,7 +240,8 @@ def to_image_device(raw: torch.Tensor) -> torch.Tensor:
 def _compute_embeddings_batched_raw(predictor, raw_images):
     """``_compute_embeddings_batched`` from RAW tiles: when no resize is needed the tiles are uploaded as they are and
     ``_to_image`` + ``Sam.preprocess`` run on the device; otherwise the host path (``_to_image``, PIL resize)."""
-    if not _device_to_image_ok(raw_images):
+    on_gpu = str(predictor.device).startswith("cuda") and torch.cuda.is_available()
+    if not (on_gpu and _device_to_image_ok(raw_images)):
         return _compute_embeddings_batched(predictor, [_to_image(im) for im in raw_images])
     predictor.reset_image()
     dev = _upload_raw_tiles(predictor, raw_images)
