@@ -210,8 +210,9 @@ def bench_config3(args, rank, world, dev):
     predictor.model.image_encoder.set_precision(args.encoder_dtype)
 
     def step():
+        # batch_size = all tiles of the share: tiles are batched by shape, a slice alone has 4 + 1 + 2 + 2 tiles of four shapes
         seg, _ = mds.segment_slices(vol, predictor, TiledAutomaticMaskGenerator(predictor), tile_shape=(768, 768), halo=(128, 128),
-                                    batch_size=9)
+                                    batch_size=9 * Z)
         return seg
     for _ in range(args.warmup):
         seg = step()
@@ -417,19 +418,23 @@ def main():
         else:
             lo = (index * n_tiles) % n_distinct
             batch_u8 = tiles_u8[lo:lo + n_tiles]
-        feats = []
+        # embeddings of the step: [n,1,256,64,64] on the device, filled one encoder batch at a time; an event after every batch lets the
+        # decode lanes start on the tiles of batch j while the encoder works on batch j + 1 (--tiles-per-step > --enc-batch)
+        feats = torch.empty((n_tiles, 1, 256, 64, 64), dtype=torch.float32, device=dev)
+        enc_done = []
         for s in range(0, n_tiles, enc_batch):
-            feats.append(predictor.model.image_encoder.forward_u8(batch_u8[s:s + enc_batch]))
-        feats = torch.cat(feats).unsqueeze(1)                       # [n,1,256,64,64] on device
+            feats[s:s + enc_batch, 0] = predictor.model.image_encoder.forward_u8(batch_u8[s:s + enc_batch])
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            enc_done.append(ev)
         emb = {"features": feats, "input_size": (1024, 1024), "original_size": (1024, 1024)}
         if timed:
             torch.cuda.synchronize(); stage["encode"] += time.perf_counter() - t0
         if len(lanes) > 1 and not timed and not serial:
             main = torch.cuda.current_stream()
-            for _, _, st in lanes:
-                st.wait_stream(main)                                    # embeddings ready
             for i in range(n_tiles):
                 _, ak, st = lanes[i % len(lanes)]
+                st.wait_event(enc_done[i // enc_batch])                 # this tile's embedding is ready
                 with torch.cuda.stream(st):
                     ak.initialize(shape_only, emb, i=i)
                     lab, flag = ak.generate_device()
