@@ -36,7 +36,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TILES_PER_STEP = 16
+TILES_PER_STEP = 64     # 4 encoder batches of 16; the decode lanes start on a batch's tiles while the encoder works on the next batch
 ENC_BATCH = 16     # M = 65536 rows: every encoder GEMM is a whole number of 256-workgroup rounds (B = 8 left 1.5-round tails)
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0           # MI355X dense fp8 (MX-scaled MFMA), --encoder-dtype fp8 only
