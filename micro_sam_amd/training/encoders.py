@@ -12,8 +12,10 @@ directions), every LayerNorm ``functional.layer_norm``, the attention with its d
 The arithmetic follows ``oracle/sam_ref.image_encoder`` / ``prompt_encoder`` in their fp32 form with bf16 GEMM operands (what
 ``functional.linear`` does; the reference fine-tunes under AMP bf16).
 
-First run on a GPU pending (written without GPU access at the end of round 2): the composition is checked on the CPU against the
-oracle's autograd with the three primitives replaced by torch stand-ins (tests/test_training_encoders_host.py).
+Round 3: the attention takes ``functional.relpos_attention_auto`` - by default the two products as library batched GEMMs on bf16
+operands with fp32 scores / softmax (``functional.RELPOS_ATTENTION_IMPL``), the hand-written fp32 kernels as the checked reference.
+The composition is checked on the CPU against the oracle's autograd with the primitives replaced by torch stand-ins
+(tests/test_training_encoders_host.py) and on the GPU against the oracle (tests/test_gpu_training_encoders.py).
 """
 from __future__ import annotations
 
@@ -75,7 +77,7 @@ def _attention(attn, x: torch.Tensor) -> torch.Tensor:
     r_q = q.reshape(Bp * heads, S, S, hd)                                              # unscaled queries (upstream behaviour)
     bias_h = torch.einsum("bhwc,hkc->bhwk", r_q, _rel_pos_table(attn.rel_pos_h, S)).reshape(Bp * heads, N, S)
     bias_w = torch.einsum("bhwc,wkc->bhwk", r_q, _rel_pos_table(attn.rel_pos_w, S)).reshape(Bp * heads, N, S)
-    o = HF.relpos_attention(q, k, v, bias_h, bias_w, attn.scale)
+    o = HF.relpos_attention_auto(q, k, v, bias_h, bias_w, attn.scale)
     o = o.reshape(Bp, heads, S, S, hd).permute(0, 2, 3, 1, 4).reshape(Bp, S, S, C)
     return HF.linear(o, attn.proj.weight, attn.proj.bias)
 

@@ -17,6 +17,8 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import os
+
 import torch
 
 from .. import _lib, ops
@@ -190,3 +192,29 @@ def relpos_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias_h: 
                      scale: float) -> torch.Tensor:
     """softmax_j(scale q_i k_j + bias_h[i, j // Gw] + bias_w[i, j % Gw]) v for q / k / v [BH, Gh * Gw, D] (D = 64 or 80)."""
     return _RelPosAttention.apply(q, k, v, bias_h, bias_w, scale)
+
+
+# Which implementation the image encoder's attention takes under autograd (training/encoders.py):
+#   "gemm"   (default) the two products as plain library batched GEMMs on bf16 operands (torch.bmm = rocBLAS / hipBLASLt on MFMA; what
+#            the reference's AMP does), scores + decomposed bias + softmax in fp32 torch operators, backward by autograd.  The score
+#            matrix is materialised (24 heads x 4096^2 fp32 = 1.6 GB per global block of vit_b at batch 2: 288 GB of HBM hold it) - the
+#            one-thread-per-row fp32 kernels were 34 % of a whole-model step (profiles/r03_train_profile.md);
+#   "kernel" the hand-written fp32 kernels (msam_relpos_attention_forward / _backward): no score matrix in HBM, exact fp32, slow -
+#            the checked reference of the composite (tests/test_gpu_training_encoders.py) and the low-memory option.
+RELPOS_ATTENTION_IMPL = os.environ.get("MSAM_RELPOS_IMPL", "gemm")
+
+
+def relpos_attention_gemm(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias_h: torch.Tensor, bias_w: torch.Tensor,
+                          scale: float) -> torch.Tensor:
+    BH, N, _ = q.shape
+    gh, gw = bias_h.shape[-1], bias_w.shape[-1]
+    s = torch.bmm((q * scale).to(torch.bfloat16), k.to(torch.bfloat16).transpose(1, 2)).float()
+    s = (s.view(BH, N, gh, gw) + bias_h.unsqueeze(-1) + bias_w.unsqueeze(-2)).view(BH, N, N)
+    p = torch.softmax(s, dim=-1)
+    return torch.bmm(p.to(torch.bfloat16), v.to(torch.bfloat16)).float()
+
+
+def relpos_attention_auto(q, k, v, bias_h, bias_w, scale: float) -> torch.Tensor:
+    if RELPOS_ATTENTION_IMPL == "gemm":
+        return relpos_attention_gemm(q, k, v, bias_h, bias_w, scale)
+    return relpos_attention(q, k, v, bias_h, bias_w, scale)

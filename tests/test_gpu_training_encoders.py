@@ -53,6 +53,26 @@ def test_relpos_attention_forward_backward(dev, BH, Gh, Gw, D):
         assert _rel(a.grad.double(), b.grad) < 2e-4, name
 
 
+@pytest.mark.parametrize("BH,Gh,Gw,D", [(6, 14, 14, 64), (2, 64, 64, 64), (3, 14, 14, 80)])
+def test_relpos_attention_gemm_route_against_the_fp32_kernels(dev, BH, Gh, Gw, D):
+    """The default training route (torch.bmm on bf16 operands, fp32 softmax; functional.relpos_attention_gemm) against the hand-written
+    fp32 kernels on the same inputs: values and all five gradients within bf16 operand rounding."""
+    from micro_sam_amd.training import functional as HF
+    g = torch.Generator().manual_seed(BH + Gh + D)
+    N = Gh * Gw
+    ins = [torch.randn(BH, N, D, generator=g) for _ in range(3)] + [torch.randn(BH, N, Gh, generator=g), torch.randn(BH, N, Gw, generator=g)]
+    do = torch.randn(BH, N, D, generator=g).to(dev)
+    a = [t.to(dev).requires_grad_() for t in ins]
+    b = [t.to(dev).requires_grad_() for t in ins]
+    out = HF.relpos_attention_gemm(*a, D ** -0.5)
+    ref = HF.relpos_attention(*b, D ** -0.5)
+    assert out.dtype == torch.float32 and _rel(out, ref) < 2e-2
+    out.backward(do)
+    ref.backward(do)
+    for name, x, y in zip(("dq", "dk", "dv", "dbias_h", "dbias_w"), a, b):
+        assert _rel(x.grad, y.grad) < 3e-2, name
+
+
 @pytest.mark.parametrize("dim", [768, 1024, 1280])
 def test_layer_norm_backward_encoder_widths(dev, dim):
     from micro_sam_amd.training import functional as HF

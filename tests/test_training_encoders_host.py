@@ -29,6 +29,7 @@ def torch_primitives(monkeypatch):
     monkeypatch.setattr(HF, "linear", lambda x, w, b=None: F.linear(x, w, b))
     monkeypatch.setattr(HF, "layer_norm", lambda x, w, b, eps: F.layer_norm(x, (x.shape[-1],), w, b, eps))
     monkeypatch.setattr(HF, "relpos_attention", _dense_relpos_attention)
+    monkeypatch.setattr(HF, "RELPOS_ATTENTION_IMPL", "kernel")      # the composition is checked exactly; the bf16 GEMM route below
 
 
 def _small_encoder(seed=0):
@@ -158,6 +159,27 @@ def test_relpos_attention_kernel_formulas_match_autograd():
     want = (out[0].detach(), q.grad[0], k.grad[0], v.grad[0], bh.grad[0], bw.grad[0])
     for a, b in zip(got, want):
         assert np.allclose(a, b.numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_relpos_attention_gemm_route_is_the_dense_attention_at_bf16_operand_precision():
+    """The default training route (library batched GEMMs on bf16 operands, fp32 scores and softmax) against the fp64 dense attention."""
+    g = torch.Generator().manual_seed(6)
+    Gh, Gw, D = 14, 14, 64
+    N = Gh * Gw
+    q, k, v = (torch.randn(3, N, D, generator=g).requires_grad_() for _ in range(3))
+    bh = torch.randn(3, N, Gh, generator=g).requires_grad_()
+    bw = torch.randn(3, N, Gw, generator=g).requires_grad_()
+    dout = torch.randn(3, N, D, generator=g)
+    out = HF.relpos_attention_gemm(q, k, v, bh, bw, D ** -0.5)
+    assert out.dtype == torch.float32
+    out.backward(dout)
+    ref_in = [t.detach().double().requires_grad_() for t in (q, k, v, bh, bw)]
+    ref = _dense_relpos_attention(*ref_in, D ** -0.5)
+    ref.backward(dout.double())
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()
+    assert rel(out, ref) < 2e-2
+    for a, b in zip((q, k, v, bh, bw), ref_in):
+        assert rel(a.grad, b.grad) < 3e-2
 
 
 def test_lora_branches_train_and_equal_the_merged_weights(torch_primitives, monkeypatch):
