@@ -239,6 +239,10 @@ int msam_debug_i2t_timing(int32_t enable, uint64_t* host_out);
 /* tuning / test hook: operand staging of the 256 x 256 tile kernel behind msam_gemm_bf16 (0 registers two tiles ahead,
  * 1 registers with the LDS write behind the barrier, 2 LDS-DMA; -1 = built-in default or MSAM_GEMM256_STAGING). */
 int msam_gemm256_set_staging(int staging);
+/* debug hook: timeline of the two-workgroups-per-CU kernel (staging 4).  device_words = 64 uint64 per workgroup of the persistent grid
+ * (2 per CU): [0] HW_ID, [1] XCC_ID, then s_memrealtime stamps (100 MHz): per tile its start and the end of its k-loop, last = exit;
+ * NULL switches it off (tools/gemm_probe.py). */
+int msam_gemm_set_trace(void* device_words);
 int msam_profile_enable(int on);
 int msam_profile_collect(int32_t* launches, double* total_ms, double* total_flops);
 /* Per kernel family (arrays of MSAM_PROFILE_FAMILIES: launches, summed ms, flops, algorithmic HBM bytes):

@@ -784,6 +784,9 @@ extern "C" int msam_fold_attn_set_dma(int32_t on) { g_fold_attn_dma = on; return
 //   "dec_chain_min_p" smallest number of prompts for which it does (default 128)
 extern int g_tune_i2t_wg_per_cu, g_tune_chain_variant, g_tune_chain_tmask, g_tune_up_gelu16;
 void msam_gemm_set_dbg(int v);
+void msam_gemm_set_gw(int delay, int cls);
+void msam_gemm_set_g3(int delay);
+void msam_gemm_set_g3_epi(int v);
 extern int g_tune_tok_fuse;
 int g_tune_dec_chain = 1, g_tune_dec_chain_min_p = 128;
 extern "C" int msam_tune_set(const char* key, int32_t value) {
@@ -795,6 +798,10 @@ extern "C" int msam_tune_set(const char* key, int32_t value) {
     else if (k == "chain_tmask") g_tune_chain_tmask = value;
     else if (k == "up_gelu16") g_tune_up_gelu16 = value;
     else if (k == "gemm_dbg") msam_gemm_set_dbg(value);
+    else if (k == "gw_delay") msam_gemm_set_gw(value, -1);
+    else if (k == "gw_class") msam_gemm_set_gw(-2, value);
+    else if (k == "g3_delay") msam_gemm_set_g3(value);
+    else if (k == "g3_epi") msam_gemm_set_g3_epi(value);
     else if (k == "tok_fuse") g_tune_tok_fuse = value;
     else if (k == "dec_chain_min_p") g_tune_dec_chain_min_p = value;
     else { msam_set_error("msam_tune_set: unknown key"); return 1; }

@@ -5,6 +5,7 @@
 // Two staging variants (msam_gemm_t.use_glds):
 //   0: global_load_dwordx4 -> VGPR -> ds_write_b128, next tile's loads in flight during the MFMA phase
 //   1: global_load_lds_dwordx4 (LDS-DMA), swizzle applied on the per-lane SOURCE address (LDS image linear)
+#include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/msam_hip.h"
@@ -24,8 +25,11 @@ struct Epi {
     int splitk_len = 0;                                  // > 0: split-K launch (msam_gemm_t.split_k): workgroup blockIdx.y contracts over
                                                          // k in [y * splitk_len, (y + 1) * splitk_len) and ADDS its fp32 tile to `out`
                                                          // (atomics; plain fp32 output, zeroed by the launcher; no bias / epilogue)
+    unsigned long long* trace = nullptr;                 // gemm2w_kernel debug timeline (msam_gemm_set_trace): 64 words per workgroup
+    int direct_epi = 0;                                  // gemm256_kernel: epilogue from the accumulators (epi_direct) instead of the LDS transposition
+    int gw_delay = 0, gw_class = 0;                      // gemm2w_kernel: start delay of the second workgroup class (units of s_sleep 100), class rule
     int dbg = 0;                                         // timing experiments (msam_tune_set "gemm_dbg"; WRONG results when != 0): gemm256 only -
-                                                         // 1 = no global stores, 2 = no epilogue at all, 4 = no k-loop
+                                                         // 1 = no global stores, 2 = no epilogue at all, 4 = no k-loop, 8 / 16 = operands always from k-tile 0
 };
 
 // body of the 128 x 128 tile kernel for workgroup `bid_in` of the product (shared by the plain and the grouped launch)
@@ -350,9 +354,81 @@ MSAM_DEVINL f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& b0
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 0 /* A fp8 e4m3 */, 0 /* B fp8 e4m3 */, 0, 0x7F7F7F7F,
                                                             0, 0x7F7F7F7F);
 }
+// Epilogue straight from the accumulators of the 128 x 64 wave tile (transposed 32x32x16 product): acc[i][j][4 g + x] =
+// C[m0 + wm*128 + j*32 + l31][n0 + wn*64 + i*32 + 8 g + 4 lh + x] - a lane holds 4 consecutive columns of one row (16 B fp32 / 8 B
+// 16-bit stores; the lane pair (l, l + 32) and the four g cover 128 / 64 contiguous bytes of a row).  No LDS, no barrier.
+template <bool F16>
+MSAM_DEVINL void epi_direct(const f32x16_t (&acc)[2][4], int m0, int n0, int wm, int wn, int l31, int lh, int M, const Epi& e) {
+    // loads first (one latency per tile, not one per value): the bias of the lane's 8 column groups
+    const int colb = n0 + wn * 64 + lh * 4;
+    const int Dqkv = e.heads * e.head_dim;
+    const bool has_res = e.resid_dtype == MSAM_F32 && e.resid;
+    float4 bias4[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias4[i][g] = e.bias ? *(const float4*)(e.bias + colb + i * 32 + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // steps (i, j): the residual of step s + 1 is requested before step s is worked on
+    float4 rt[2][4];
+    auto load_res = [&](int i, int j, float4 (&r)[4]) {
+        const int rc = min(m0 + wm * 128 + j * 32 + l31, M - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r[g] = *(const float4*)((const float*)e.resid + (long)rc * e.ldr + colb + i * 32 + 8 * g);
+    };
+    if (has_res) load_res(0, 0, rt[0]);
+#pragma unroll
+    for (int st8 = 0; st8 < 8; ++st8) {
+        const int i = st8 >> 2, j = st8 & 3;
+        const int row = m0 + wm * 128 + j * 32 + l31;
+        const int rc = min(row, M - 1);
+        if (has_res && st8 + 1 < 8) load_res((st8 + 1) >> 2, (st8 + 1) & 3, rt[(st8 + 1) & 1]);
+        long rowoff = 0;
+        if (e.out_mode == 1) {
+            const int b = rc / e.tokens, t = rc - b * e.tokens;
+            rowoff = ((long)b * e.heads * e.tokens + t) * e.head_dim;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = colb + i * 32 + 8 * g;
+            const float4 b4 = bias4[i][g];
+            float v[4] = {acc[i][j][4 * g] + b4.x, acc[i][j][4 * g + 1] + b4.y, acc[i][j][4 * g + 2] + b4.z, acc[i][j][4 * g + 3] + b4.w};
+            if (has_res) {
+                const float4 r4 = rt[st8 & 1][g];
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            if (e.act == MSAM_ACT_GELU) {
+                const f32x2_t g01 = gelu_erf2(f32x2_t{v[0], v[1]}), g23 = gelu_erf2(f32x2_t{v[2], v[3]});
+                v[0] = g01.x; v[1] = g01.y; v[2] = g23.x; v[3] = g23.y;
+            } else if (e.act == MSAM_ACT_RELU) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = fmaxf(v[x], 0.f);
+            }
+            if (row < M && !(e.dbg & 1)) {
+                if (e.out_mode == 0 && e.out_dtype == MSAM_F32) {
+                    *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 pk;
+                    if constexpr (F16) { pk.x = pack2h(v[0], v[1]); pk.y = pack2h(v[2], v[3]); }
+                    else { pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); }
+                    if (e.out_mode == 0) {
+                        *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
+                    } else {                              // q / k / v head split: column -> (which, head, d)
+                        const int which = col / Dqkv, rem = col - which * Dqkv, head = rem / e.head_dim, d = rem - head * e.head_dim;
+                        u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
+                        *(uint2*)(dst + rowoff + (long)head * e.tokens * e.head_dim + d) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
 constexpr int G2 = 256;                       // tile edge
 constexpr int G2_DEFAULT_STAGING = 3;   // measured (tools/gemm_bench.py): 3 > 1 > 0 by 3 - 8 % each on the encoder shapes, LDS-DMA (2) no better
 int g_tune_gemm_dbg = 0;                      // msam_tune_set "gemm_dbg" (Epi.dbg)
+unsigned long long* g_gw_trace = nullptr;
+int g_tune_gw_delay = -1, g_tune_gw_class = 0, g_tune_g3_delay = -1, g_tune_g3_epi = 0;   // "g3_epi": 1 = gemm256_kernel's epilogue from the accumulators; "g3_delay": start-phase spread of gemm256_kernel's first wave // msam_tune_set "gw_delay" (-1 = from K) / "gw_class" (gemm2w_kernel)
 int g_gemm256_staging = -1;                   // test / tuning hook (msam_gemm256_set_staging), -1 = default / environment
 constexpr int G2_LDS = 2 * 2 * G2 * 8 * 16;   // 2 stages x (A, W) x 256 rows x 8 chunks x 16 B = 128 KB
 
@@ -383,6 +459,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
     const int m0 = tile_m * G2, n0 = tile_n * G2;
     const int wm = wave >> 2, wn = wave & 3;
     auto stage = [&](int buf, int op) -> uint4* { return dyn + (buf * 2 + op) * (G2 * 8); };
+    // De-phasing of the CUs (round 3): every workgroup of the first dispatch wave (one per CU) starts a class-dependent fraction of a
+    // tile period late.  Started together, all CUs walk their tiles in lockstep: nothing is written during the k-loops and every CU
+    // writes its 128 KB tile (or reads and writes its fp32 residual tile) at the same moment - an HBM burst that the k-loops of the
+    // other classes now cover.  Later workgroups inherit the phase of the workgroup whose CU they take over.
+    if (e.gw_delay > 0 && (int)blockIdx.x < e.gw_class) {
+        const int cls = (blockIdx.x >> 3) & 3;
+        for (int d = 0; d < cls * e.gw_delay; ++d) __builtin_amdgcn_s_sleep(100);
+    }
 
     // staging map: thread t covers LDS chunk position (row = p*64 + t/8, c' = t%8) <- global chunk c' ^ swz(row)
     const int srow = tid >> 3, scp = tid & 7;
@@ -521,7 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
             const uint4* lw = stage(buf, 1);
             uint4* sa = stage(buf ^ 1, 0) + srow * 8 + scp;
             uint4* sw = stage(buf ^ 1, 1) + srow * 8 + scp;
-            const int so = min(kt + 2, nk - 1) * 128;
+            const int so = (e.dbg & 8) ? 0 : min(kt + 2, nk - 1) * 128;      // dbg 8: every k-tile = tile 0 (cache hits: is the k-loop bound by the operand stream?)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 // ---- R slot of k-half h
@@ -604,6 +688,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
 #undef G2_COMMIT
 
     if (e.dbg & 2) return;
+    if constexpr (!FP8) {
+        if (e.direct_epi) { epi_direct<F16>(acc, m0, n0, wm, wn, l31, lh, M, e); return; }
+    }
     // ---- epilogue in two column halves of 128: C^T accumulators (row = n, column = m) -> ldsC[m][128] fp32, chunk-swizzled
     float* ldsC = (float*)dyn;
     const int c4 = tid & 31, rg = tid >> 5;                  // 16-byte column chunk, row group (16 rows per pass)
@@ -686,6 +773,168 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Two-workgroups-per-CU variant of the large-shape kernel (staging 4; round 3): tile 256 (M) x 128 (N) x 32, 4 waves as
+// 2 (M) x 2 (N) - the same 128 x 64 wave tile on the 32x32x16 MFMA and the same transposed product as gemm256_kernel - but
+// TWO independent workgroups per CU (one wave of each on every SIMD, 256 registers per wave, 72 KB of LDS each) instead of one
+// 8-wave workgroup, so that a workgroup's epilogue (and its k-loop's LDS latencies) run under the OTHER workgroup's MFMAs: with one
+// workgroup per CU the epilogue of the K = 768 shapes was 30 - 45 % on top of the k-loop and nothing could hide it
+// (profiles/r03_experiments.md section 1).
+// * operands: LDS-DMA (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass) into a ring of THREE stages of
+//   (256 + 128) rows x 64 B, two k-tiles ahead; ONE barrier per k-tile, in front of it a COUNTED s_waitcnt vmcnt(6) (the six DMA
+//   loads of the newest tile stay in flight).  The DMA instruction is inline assembly: through the builtin the compiler's wait-count
+//   pass puts a vmcnt(0) in front of every ds_read that may alias the DMA's LDS destination, which serialises the ring.
+//   Ordering: tile kt is waited for (vmcnt) by every wave at the end of iteration kt - 1, then the barrier, then read in iteration
+//   kt; stage (kt + 2) % 3 is re-filled at the top of iteration kt, after the barrier that ended its last reads (iteration kt - 1).
+// * LDS rows of 64 B (4 chunks of 16 B), chunk' = chunk ^ ((row >> 2) & 3): the 16-lane service groups of ds_read_b128
+//   ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... MI355X_MICROARCH LDS table) hit 16 distinct 16-byte slots when the lanes read
+//   rows (l & 31) of a 32-row fragment at one logical chunk; applied on the DMA's per-lane SOURCE address (LDS image linear).
+// * epilogue straight from the accumulators: a lane holds 4 consecutive columns of one row (16 B fp32 / 8 B 16-bit stores; the
+//   lane pair (l, l + 32) and the four g cover 128 / 64 contiguous bytes of a row) - no LDS transposition, no barrier.
+// bf16 / fp16 operands only (fp8 keeps gemm256_kernel<1, true>).
+constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 32;
+constexpr int GW_STAGE = (GW_BM + GW_BN) * 64;        // bytes per stage
+constexpr int GW_LDS = 3 * GW_STAGE;                  // 73 728 B: two workgroups per CU
+typedef unsigned int u32x4_t_gw __attribute__((ext_vector_type(4)));
+MSAM_DEVINL void gw_dma16(const u32x4_t_gw& rsrc, int voff, int soff, unsigned lds_addr) {
+    // m0 = LDS base of this wave-instruction (lane l lands at m0 + 16 l); one wait state between the SALU write of m0 and its use
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr)
+                 : "memory");
+}
+MSAM_DEVINL u32x4_t_gw gw_rsrc(const void* base, long bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    const unsigned n = (unsigned)(bytes < 0xffffffffL ? bytes : 0xffffffffL);
+    return u32x4_t_gw{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b),
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) & 0xffffu,
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)n), 0x00020000u};
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void gemm2w_kernel(const u16* __restrict__ A, long lda, const u16* __restrict__ W, long ldw,
+                                                        int M, int N, int K, Epi e) {
+    extern __shared__ __attribute__((aligned(16))) uint4 dyn[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int tiles_n = N / GW_BN, tiles_m = (M + GW_BM - 1) / GW_BM;
+    const int nwg = tiles_m * tiles_n;
+    const int wm = wave >> 1, wn = wave & 1;
+    const u32x4_t_gw ra = gw_rsrc(A, (long)M * lda * 2), rw = gw_rsrc(W, (long)N * ldw * 2);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dyn;
+    const unsigned lds_a = lds0 + (unsigned)wave * (64 * 64), lds_w = lds0 + GW_BM * 64 + (unsigned)wave * (32 * 64);
+    // fragment reads: row = 32-row fragment base + l31, logical chunk 2 s + lh, physical chunk ^ ((l31 >> 2) & 3)
+    const int fl = (l31 >> 2) & 3;
+    const int c0 = (lh ^ fl) << 4, c1 = ((2 + lh) ^ fl) << 4;
+    const char* ldsb = (const char*)dyn;
+    const int fa = (wm * 128 + l31) * 64, fw = GW_BM * 64 + (wn * 64 + l31) * 64;
+    const int nk = (e.dbg & 4) ? 1 : K / GW_BK;
+
+    // Persistent workgroups (grid = 2 per CU), static schedule: workgroup b takes the virtual ids b, b + grid, ... (id -> tile by the
+    // XCD-aware map).  The SECOND workgroup of every CU starts half a tile late, so that from then on its epilogues fall into the
+    // other workgroup's k-loops and vice versa (started together, the two reach their epilogues together and nothing overlaps).
+    {
+        bool late;
+        if (e.gw_class == 1) late = (blockIdx.x >> 3) & 1;
+        else if (e.gw_class == 2) late = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1;          // HW_ID.WAVE_ID parity
+        else late = (int)(blockIdx.x >> 3) >= (int)(gridDim.x >> 4);                             // dispatch order: one per CU first
+        if (late)
+            for (int d = 0; d < e.gw_delay; ++d) __builtin_amdgcn_s_sleep(100);
+    }
+    int tr_n = 0;
+    auto stamp = [&]() {
+        if (e.trace && tid == 0 && tr_n < 62) e.trace[(long)blockIdx.x * 64 + 2 + tr_n++] = __builtin_amdgcn_s_memrealtime();
+    };
+    if (e.trace && tid == 0) {
+        e.trace[(long)blockIdx.x * 64] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID
+        e.trace[(long)blockIdx.x * 64 + 1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+    for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
+    stamp();                                                       // tile start
+    int bid;
+    {
+        int xcd = vid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * GW_BM, n0 = tile_n * GW_BN;
+    if (vid != (int)blockIdx.x) __builtin_amdgcn_s_barrier();      // the previous tile's last fragment reads are done: the ring is free
+
+    // DMA map: wave w, A instruction q (0..3) covers rows w*64 + q*16 + lane/4, W instruction q (0..1) rows w*32 + q*16 + lane/4;
+    // lane l writes physical chunk l & 3 of its row <- global chunk (l & 3) ^ ((row >> 2) & 3)
+    int aoff[4], woff[2];
+    {
+        const int r4 = lane >> 2, pc = lane & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = wave * 64 + q * 16 + r4;
+            aoff[q] = (int)((long)min(m0 + row, M - 1) * lda * 2 + ((pc ^ ((row >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = wave * 32 + q * 16 + r4;
+            woff[q] = (int)((long)(n0 + row) * ldw * 2 + ((pc ^ ((row >> 2) & 3)) << 4));
+        }
+    }
+    auto issue = [&](int kt, int st) {
+        const int so = (e.dbg & 8) ? 0 : kt * 64;
+        const int sow = (e.dbg & 24) ? 0 : kt * 64;          // dbg 16: only the weights from k-tile 0
+        const unsigned sb = (unsigned)st * GW_STAGE;
+        gw_dma16(ra, aoff[0], so, lds_a + sb); gw_dma16(ra, aoff[1], so, lds_a + sb + 1024);
+        gw_dma16(rw, woff[0], sow, lds_w + sb);
+        gw_dma16(ra, aoff[2], so, lds_a + sb + 2048); gw_dma16(ra, aoff[3], so, lds_a + sb + 3072);
+        gw_dma16(rw, woff[1], sow, lds_w + sb + 1024);
+    };
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+    issue(0, 0);
+    if (nk > 1) { issue(1, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 2 < nk;
+        if (more) issue(kt + 2, st >= 1 ? st - 1 : 2);
+        const char* sa = ldsb + st * GW_STAGE + fa;
+        const char* sw = ldsb + st * GW_STAGE + fw;
+        uint4 wf[2][2], af[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[0][i] = *(const uint4*)(sw + i * 2048 + c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[0][j] = *(const uint4*)(sa + j * 2048 + c0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[1][i] = *(const uint4*)(sw + i * 2048 + c1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[1][j] = *(const uint4*)(sa + j * 2048 + c1);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32<F16>(wf[s2][i], af[s2][j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        if (kt + 1 < nk) {
+            if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    stamp();                                                       // k-loop done
+    if (e.dbg & 2) continue;
+
+    // ---- epilogue from the accumulators: acc[i][j][4 g + x] = C[m0 + wm*128 + j*32 + l31][n0 + wn*64 + i*32 + 8 g + 4 lh + x]
+    epi_direct<F16>(acc, m0, n0, wm, wn, l31, lh, M, e);
+    }                                                      // persistent tile loop
+    stamp();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -881,9 +1130,22 @@ int g_prof_n = 0, g_prof_on = 0, g_prof_init = 0;
 
 extern "C" int msam_profile_collect_family(int32_t* launches, double* ms, double* flops, double* bytes);
 
+static int msam_num_cus() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+extern "C" int msam_gemm_set_trace(void* p) { g_gw_trace = (unsigned long long*)p; return 0; }
+void msam_gemm_set_gw(int delay, int cls) { if (delay >= -1) g_tune_gw_delay = delay; if (cls >= 0) g_tune_gw_class = cls; }
+void msam_gemm_set_g3(int delay) { g_tune_g3_delay = delay; }
+void msam_gemm_set_g3_epi(int v) { g_tune_g3_epi = v; }
 void msam_gemm_set_dbg(int v) { g_tune_gemm_dbg = v; }     // msam_tune_set "gemm_dbg" (decfold.hip)
 extern "C" int msam_gemm256_set_staging(int staging) {
-    if (staging < -1 || staging > 3) { msam_set_error("msam_gemm256_set_staging: -1 (default), 0, 1, 2 or 3"); return 1; }
+    if (staging < -1 || staging > 4) { msam_set_error("msam_gemm256_set_staging: -1 (default), 0, 1, 2, 3 or 4"); return 1; }
     g_gemm256_staging = staging;
     return 0;
 }
@@ -1037,6 +1299,43 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         const char* st = getenv("MSAM_GEMM256_STAGING"); staging256 = st ? atoi(st) : G2_DEFAULT_STAGING;
     }
     if (g_gemm256_staging >= 0) staging256 = g_gemm256_staging;
+    // staging 4: the two-workgroups-per-CU kernel (256 x 128 tiles, LDS-DMA ring, epilogue from the accumulators)
+    if (use256 && staging256 == 4 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds &&
+        ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % GW_BN == 0 && p->K % GW_BK == 0 && p->lda % 8 == 0 && p->ldw % 8 == 0 &&
+        p->out_mode != 2 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
+        static bool attr2w = false;
+        if (!attr2w) {
+            if (hipFuncSetAttribute((const void*)gemm2w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gemm2w_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS) != hipSuccess) {
+                msam_set_error("msam_gemm_bf16: cannot raise the dynamic LDS limit");
+                return 2;
+            }
+            attr2w = true;
+            if (getenv("MSAM_GEMM_OCC")) {
+                int nb = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gemm2w_kernel<false>, 256, GW_LDS);
+                fprintf(stderr, "gemm2w_kernel: %d workgroups per CU (dynamic LDS %d)\n", nb, GW_LDS);
+            }
+        }
+        if (prof) {
+            g_prof[g_prof_n].flops = 2.0 * p->M * (double)p->N * p->K; g_prof[g_prof_n].bytes = 0; g_prof[g_prof_n].family = 0;
+            (void)hipEventRecord(g_prof[g_prof_n].a, s);
+        }
+        const int tiles2w = ((p->M + GW_BM - 1) / GW_BM) * (p->N / GW_BN);
+        const int gmul = (g_tune_gemm_dbg >> 8) & 15 ? (g_tune_gemm_dbg >> 8) & 15 : 2;         // gemm_dbg bits 8-11: workgroups per CU of the persistent grid
+        const int grid2w = tiles2w < gmul * msam_num_cus() ? tiles2w : gmul * msam_num_cus();
+        e.gw_class = g_tune_gw_class;
+        e.trace = g_gw_trace;
+        e.gw_delay = g_tune_gw_delay >= 0 ? g_tune_gw_delay : (p->K / GW_BK) / 4;
+        if (f16)
+            hipLaunchKernelGGL(gemm2w_kernel<true>, dim3(grid2w), dim3(256), GW_LDS, s, (const u16*)p->A, (long)p->lda, (const u16*)p->W,
+                               (long)p->ldw, p->M, p->N, p->K, e);
+        else
+            hipLaunchKernelGGL(gemm2w_kernel<false>, dim3(grid2w), dim3(256), GW_LDS, s, (const u16*)p->A, (long)p->lda, (const u16*)p->W,
+                               (long)p->ldw, p->M, p->N, p->K, e);
+        if (prof) { (void)hipEventRecord(g_prof[g_prof_n].b, s); ++g_prof_n; }
+        return msam_check_launch("msam_gemm_bf16(2w)");
+    }
     // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
     // (fp16 operands: 16-bit outputs of this kernel are then fp16 as well - the encoder's fp16 mode; a bf16 output is not offered)
     if (use256 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 &&
@@ -1058,6 +1357,9 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
             (void)hipEventRecord(g_prof[g_prof_n].a, s);
         }
         const int tiles256 = ((p->M + G2 - 1) / G2) * (p->N / G2);
+        e.gw_class = msam_num_cus();                                  // workgroups of the first dispatch wave
+        e.gw_delay = g_tune_g3_delay >= 0 ? g_tune_g3_delay : 0;
+        e.direct_epi = g_tune_g3_epi;
 #define G2_GO(ST_) hipLaunchKernelGGL(gemm256_kernel<ST_>, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda, \
                                      (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e)
         if (f16)

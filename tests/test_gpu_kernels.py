@@ -96,10 +96,27 @@ def test_gemm_layout_epilogues(env, glds):
     assert _close(vT, ref[:, 128:].reshape(2, 4096, 128).permute(0, 2, 1), 3e-2, 1e-2)
 
 
-def test_gemm_256_tile_kernel(env):
-    """Shapes with >= 256 tiles of 256 x 256 take gemm256_kernel (32x32x16 MFMA, transposed product): ragged M, every
-    epilogue it supports (bias, GELU -> bf16, fp32 residual in place, QKV head split)."""
+@pytest.fixture(params=[-1, 3, 4])
+def staging256(request):
+    """Operand staging / tiling variant of the large-shape GEMM (msam_gemm256_set_staging): -1 = the default, 3 = one 8-wave
+    256 x 256 workgroup per CU (ping-pong of its two halves), 4 = two 4-wave 256 x 128 workgroups per CU (LDS-DMA ring, epilogue
+    from the accumulators)."""
+    from micro_sam_amd import _lib
+    assert _lib.load().msam_gemm256_set_staging(request.param) == 0
+    yield request.param
+    _lib.load().msam_gemm256_set_staging(-1)
+
+
+def test_gemm_256_tile_kernel(env, staging256):
+    """Shapes with >= 256 tiles of 256 x 256 take gemm256_kernel / gemm2w_kernel (32x32x16 MFMA, transposed product): ragged M,
+    every epilogue they support (bias, GELU -> bf16, fp32 residual in place, QKV head split), K with 1, 2, 3 and more k-tiles."""
     ops, dev = env
+    g = torch.Generator().manual_seed(19)
+    for K in (64, 128, 320):                              # 2 / 4 / 10 k-tiles of 32: prologue-only, ring wrap-around
+        M, N = 16384 + 37, 1024
+        a = _bf(torch.randn(M, K, generator=g)).to(dev)
+        w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+        assert _close(ops.gemm(a, w), a.float() @ w.float().t(), 1e-3, 1e-4), K
     g = torch.Generator().manual_seed(9)
     M, N, K = 16384 + 100, 1024, 192                     # 65 x 4 = 260 tiles, last row tile ragged
     a = _bf(torch.randn(M, K, generator=g)).to(dev)

@@ -35,8 +35,8 @@ for (M, N, K, name) in SHAPES:
     bias = torch.randn(N, generator=g).to(dev)
     ref = None
     line = []
-    for st in (0, 1, 3, 0, 1, 3, 3):
-        lib.msam_gemm256_set_staging(st)
+    for st in (3, 4, 3, 4, 4):
+        assert lib.msam_gemm256_set_staging(st) == 0
         out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
         ms = timeit(lambda: ops.gemm(a, w, bias, out=out, act=ops.ACT_GELU))
         if ref is None:
@@ -58,20 +58,24 @@ for (M, N, K, name) in SHAPES:
 
 # where the time of the 256 x 256 kernel goes (timing experiments, WRONG results): full / no global stores / k-loop only / epilogue only;
 # real epilogues of the encoder: qkv head-split bf16 store, proj + lin2 with the fp32 residual read and written in place, lin1 GELU
-print("\ngemm_dbg experiments (ms): full | no stores (1) | k-loop only (2) | prologue + epilogue only (4)", flush=True)
-for (M, N, K, name) in SHAPES[:4]:
-    a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
-    w = (torch.rand(N, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    resid = name in ("proj", "lin2")
-    out = torch.zeros(M, N, dtype=torch.float32 if resid else torch.bfloat16, device=dev)
-    line = []
-    for dbg in (0, 1, 2, 4, 0):
-        lib.msam_tune_set(b"gemm_dbg", dbg)
-        if resid:
-            ms = timeit(lambda: ops.gemm(a, w, bias, out=out, resid=out))
-        else:
-            ms = timeit(lambda: ops.gemm(a, w, bias, out=out, act=ops.ACT_GELU if name == "lin1" else 0))
-        line.append(f"{ms:.3f}")
-    lib.msam_tune_set(b"gemm_dbg", 0)
-    print(f"{name:6s} {M}x{N}x{K} resid={int(resid)}: " + " | ".join(line) + f"   ({2 * M * N * K / float(line[0]) / 1e9:.0f} TF full)", flush=True)
+for ST in (3, 4):
+  print(f"\ngemm_dbg experiments, staging {ST} (ms): full | no stores (1) | k-loop only (2) | prologue + epilogue only (4)", flush=True)
+  for (M, N, K, name) in SHAPES[:4]:
+      a = (torch.rand(M, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+      w = (torch.rand(N, K, generator=g) * 2 - 1).to(torch.bfloat16).to(dev)
+      bias = torch.randn(N, generator=g).to(dev)
+      resid = name in ("proj", "lin2")
+      out = torch.zeros(M, N, dtype=torch.float32 if resid else torch.bfloat16, device=dev)
+      line = []
+      for dbg in (0, 1, 2, 4, 0):
+          lib.msam_tune_set(b"gemm_dbg", dbg)
+          assert lib.msam_gemm256_set_staging(ST) == 0
+          if resid:
+              ms = timeit(lambda: ops.gemm(a, w, bias, out=out, resid=out))
+          else:
+              ms = timeit(lambda: ops.gemm(a, w, bias, out=out, act=ops.ACT_GELU if name == "lin1" else 0))
+          line.append(f"{ms:.3f}")
+      lib.msam_tune_set(b"gemm_dbg", 0)
+      print(f"{name:6s} {M}x{N}x{K} resid={int(resid)}: " + " | ".join(line) + f"   ({2 * M * N * K / float(line[0]) / 1e9:.0f} TF full)", flush=True)
+
+lib.msam_gemm256_set_staging(-1)

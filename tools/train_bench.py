@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--sub-iterations", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--op-profile", type=int, default=0, help="print the N heaviest torch operators (by device time, with input shapes) of one step")
     args = ap.parse_args()
     from micro_sam_amd.synthetic import synthetic_state_dict
     from micro_sam_amd.training import ConvertToSamInputs, SamTrainer, get_trainable_sam_model
@@ -70,6 +71,15 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    if args.op_profile:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            trainer.train_iteration(*batches[0])
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=args.op_profile,
+                                                                 max_name_column_width=40, max_shapes_column_width=70))
+        print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=30, max_name_column_width=60))
+        return
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
