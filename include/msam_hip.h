@@ -322,6 +322,13 @@ int msam_relpos_attention_backward(const float* q, const float* k, const float* 
                                    int32_t D, float scale, float* dq, float* dk, float* dv, float* dbias_h, float* dbias_w,
                                    float* delta, void* stream);
 
+/* Operands of a weight gradient in one pass (training; micro_sam_amd/training/functional.py _Linear): x [M, K] fp32 or bf16 (x_dtype
+ * MSAM_F32 / MSAM_BF16), row stride ldx elements -> out16 [M, K] bf16 copy, outT [K, M] bf16 transpose, colsum [K] fp32 column sums
+ * ADDED to the caller's buffer (atomics; the bias gradient).  Any of the three outputs may be NULL.  K % 4 == 0, ldx % 4 == 0.
+ * Replaces torch's cast + strided transpose copy + sum launches behind the reference's autograd (torch.nn.functional.linear backward). */
+int msam_cast_transpose(const void* x, int32_t x_dtype, int64_t M, int32_t K, int64_t ldx, void* out16, void* outT, float* colsum,
+                        void* stream);
+
 /* Row LayerNorm over the last dim (torch.nn.LayerNorm / LayerNorm2d on token-major data).
  * x fp32 [rows, dim] -> out (fp32 or bf16) [rows, dim]; optional exact GELU afterwards.
  * out_nchw_hw > 0: write fp32 output transposed to [rows/hw, dim, hw] (the encoder's NCHW result). */

@@ -132,6 +132,7 @@ _PROTOS = {
     "msam_patchify_u8": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "msam_cast_transpose": (_i32, [_vp, _i32, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "msam_gemm256_set_staging": (_i32, [_i32]),
     "msam_gemm_set_trace": (_i32, [_vp]),
     "msam_gemm_group_bf16": (_i32, [_vp, _i32, _vp]),

@@ -376,6 +376,74 @@ __global__ __launch_bounds__(128) void relpos_bwd_kv_kernel(const float* __restr
     for (int d = 0; d < D; ++d) { dk[ro + d] = ak[d] * scale; dv[ro + d] = av[d]; }
 }
 
+// ---- cast + transpose + column sums of a row-major matrix in one pass (the operands of the weight gradient dW = dY^T X)
+// x [M, K] fp32 (SRC16 = false) or bf16 (SRC16 = true), row stride ldx.  One workgroup per 64 x 64 tile:
+//   out16 [M, K]  bf16 copy (optional)            - coalesced 8-byte writes,
+//   outT  [K, M]  bf16 transpose (optional)       - through a padded LDS tile, 8-byte writes along M,
+//   colsum [K]    fp32 column sums (optional)     - per-workgroup partial sums in LDS, one atomicAdd per column (the caller zeroes it).
+// The unfused form was three to four torch launches per operand (cast, strided transpose copy at 0.5 TB/s, sum): 30 % of a fine-tuning
+// step's device time (profiles/r03_experiments.md section 8).  K % 4 == 0, ldx % 4 == 0; M arbitrary.
+template <bool SRC16>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const void* __restrict__ xin, long M, int K, long ldx, unsigned short* __restrict__ out16,
+                                                             unsigned short* __restrict__ outT, float* __restrict__ colsum) {
+    __shared__ unsigned short tile[64][68];          // [m][k], rows padded to 136 B
+    __shared__ float csum[64];
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64;
+    const long m0 = (long)blockIdx.y * 64;
+    const int c4 = (tid & 15) * 4, r0 = tid >> 4;     // 4 consecutive columns, rows r0 + 16 p
+    if (tid < 64) csum[tid] = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + 16 * p;
+        const long m = m0 + r;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (m < M && k0 + c4 < K) {
+            if (SRC16) {
+                const uint2 u = *(const uint2*)((const unsigned short*)xin + m * ldx + k0 + c4);
+                v0 = __uint_as_float(u.x << 16); v1 = __uint_as_float(u.x & 0xffff0000u);
+                v2 = __uint_as_float(u.y << 16); v3 = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+                const float4 f = *(const float4*)((const float*)xin + m * ldx + k0 + c4);
+                v0 = f.x; v1 = f.y; v2 = f.z; v3 = f.w;
+            }
+        }
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        const unsigned short h0 = f2bf(v0), h1 = f2bf(v1), h2 = f2bf(v2), h3 = f2bf(v3);
+        tile[r][c4] = h0; tile[r][c4 + 1] = h1; tile[r][c4 + 2] = h2; tile[r][c4 + 3] = h3;
+        if (out16 && m < M && k0 + c4 < K) {
+            uint2 pk; pk.x = (unsigned)h0 | ((unsigned)h1 << 16); pk.y = (unsigned)h2 | ((unsigned)h3 << 16);
+            *(uint2*)(out16 + m * (long)K + k0 + c4) = pk;
+        }
+    }
+    __syncthreads();
+    if (colsum) { atomicAdd(&csum[c4], s0); atomicAdd(&csum[c4 + 1], s1); atomicAdd(&csum[c4 + 2], s2); atomicAdd(&csum[c4 + 3], s3); }
+    if (outT) {
+        const int mq = (tid & 15) * 4, kr0 = tid >> 4;   // 4 consecutive rows m of the source = 4 consecutive columns of outT
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int kk = kr0 + 16 * p;
+            if (k0 + kk >= K) continue;
+            const long m = m0 + mq;
+            unsigned short* dst = outT + (long)(k0 + kk) * M + m;
+            if (m + 3 < M && (M & 3) == 0) {
+                uint2 pk;
+                pk.x = (unsigned)tile[mq][kk] | ((unsigned)tile[mq + 1][kk] << 16);
+                pk.y = (unsigned)tile[mq + 2][kk] | ((unsigned)tile[mq + 3][kk] << 16);
+                *(uint2*)dst = pk;
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    if (m + i < M) dst[i] = tile[mq + i][kk];
+            }
+        }
+    }
+    if (colsum) {
+        __syncthreads();
+        if (tid < 64 && k0 + tid < K) atomicAdd(colsum + k0 + tid, csum[tid]);
+    }
+}
+
 }  // namespace
 
 extern "C" int msam_layernorm_backward(const float* x, const float* weight, const float* dy, float eps, int64_t rows, int32_t dim,
@@ -473,4 +541,19 @@ extern "C" int msam_relpos_attention_backward(const float* q, const float* k, co
                            dk, dv);
     } else { msam_set_error("msam_relpos_attention_backward: head dim must be 64 or 80"); return 1; }
     return msam_check_launch("msam_relpos_attention_backward");
+}
+
+extern "C" int msam_cast_transpose(const void* x, int32_t x_dtype, int64_t M, int32_t K, int64_t ldx, void* out16, void* outT, float* colsum,
+                                   void* stream) {
+    if (!x || M <= 0 || K <= 0 || (K & 3) || (ldx & 3) || ldx < K) { msam_set_error("msam_cast_transpose: need K % 4 == 0, ldx % 4 == 0, ldx >= K"); return 1; }
+    if (x_dtype != MSAM_F32 && x_dtype != MSAM_BF16) { msam_set_error("msam_cast_transpose: source fp32 or bf16"); return 1; }
+    if ((M + 63) / 64 > 65535) { msam_set_error("msam_cast_transpose: M <= 4 194 240"); return 1; }
+    const dim3 grid((K + 63) / 64, (unsigned)((M + 63) / 64));
+    if (x_dtype == MSAM_F32)
+        hipLaunchKernelGGL(cast_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, K, (long)ldx, (unsigned short*)out16,
+                           (unsigned short*)outT, colsum);
+    else
+        hipLaunchKernelGGL(cast_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, K, (long)ldx, (unsigned short*)out16,
+                           (unsigned short*)outT, colsum);
+    return msam_check_launch("msam_cast_transpose");
 }

@@ -156,6 +156,21 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return out
 
 
+def cast_transpose(x: torch.Tensor, want16: bool = True, want_t: bool = True, want_sum: bool = False):
+    """x [M, K] fp32 / bf16 with contiguous rows -> (bf16 copy [M, K] | None, bf16 transpose [K, M] | None, fp32 column sums [K] | None)
+    in one pass (msam_cast_transpose): the operands of a weight gradient dW = dY^T X and the bias gradient."""
+    _lib.require_gpu()
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, torch.bfloat16)
+    M, K = x.shape
+    o16 = torch.empty((M, K), dtype=torch.bfloat16, device=x.device) if want16 else None
+    oT = torch.empty((K, M), dtype=torch.bfloat16, device=x.device) if want_t else None
+    cs = torch.zeros((K,), dtype=torch.float32, device=x.device) if want_sum else None
+    _lib.check(_lib.load().msam_cast_transpose(x.data_ptr(), F32 if x.dtype == torch.float32 else BF16, M, K, x.stride(0),
+                                               o16.data_ptr() if want16 else None, oT.data_ptr() if want_t else None,
+                                               cs.data_ptr() if want_sum else None, _lib.stream_ptr()), "msam_cast_transpose")
+    return o16, oT, cs
+
+
 def to_image(x: torch.Tensor) -> torch.Tensor:
     """``util._to_image`` on the device (msam_to_image): [H,W] / [H,W,C] uint8 / uint16 (as int16 / uint16 storage) / float32
     device tensor -> uint8 [H,W,3], bit-identical to the host formula."""

@@ -18,6 +18,7 @@ import ctypes as C
 import math
 
 import os
+import weakref
 
 import torch
 
@@ -32,13 +33,15 @@ def _pad_to(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
     return out
 
 
-def _mm_nt(a16: torch.Tensor, b16: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
+def _mm_nt(a16: torch.Tensor, b16: torch.Tensor, bias: torch.Tensor = None, n: int = None) -> torch.Tensor:
     """fp32 [M, N] = a16 [M, K] @ b16 [N, K]^T (+ bias [N], fused into the GEMM epilogue) on the MFMA GEMM kernel; K is zero-padded to a
-    multiple of 64 and N to a multiple of 128 (the kernel's tile constraints), M is arbitrary.  A small output with a very long
+    multiple of 64 and N to a multiple of 128 (the kernel's tile constraints; ``n`` = valid rows of an operand padded beforehand), M is
+    arbitrary.  A small output with a very long
     contraction (the weight gradients: M, N <= a few hundred, K = all rows of the batch) is cut into slices of K that run on separate
     workgroups and accumulate with fp32 atomics (``split_k``) - two workgroups would otherwise walk the whole contraction serially."""
     M, K = a16.shape
-    N = b16.shape[0]
+    N = b16.shape[0] if n is None else n             # n: rows of b16 that count (b16 already zero-padded to the tile, _weight16)
+    K = max(K, b16.shape[1])
     Np = (N + 127) // 128 * 128
     tiles = ((M + 127) // 128) * (Np // 128)
     split = 0
@@ -56,32 +59,79 @@ def _mm_nt(a16: torch.Tensor, b16: torch.Tensor, bias: torch.Tensor = None) -> t
     return out if Np == N else out[:, :N]
 
 
+# bf16 copies of the weights, W [N, K] and W^T [K, N], per parameter and parameter version: the mask decoder's weights are used by
+# 2 images x 8 sub-iterations per optimiser step (reference sam_trainer.py:252-292), the casts and the transposition are the same 16 times
+_W16 = {}
+
+
+def _weight16(weight: torch.Tensor):
+    base = weight._base if weight._base is not None else weight
+    if not isinstance(base, torch.nn.Parameter):
+        w16 = weight.detach().to(torch.bfloat16).contiguous()
+        return w16, w16.t().contiguous()
+    key = (id(base), tuple(weight.shape), tuple(weight.stride()), weight.storage_offset())
+    hit = _W16.get(key)
+    if hit is not None and hit[0]() is base and hit[1] == base._version:
+        return hit[2], hit[3]
+    if len(_W16) > 4096:                     # parameters of discarded models
+        for k in [k for k, v in _W16.items() if v[0]() is None]:
+            del _W16[k]
+    w16 = weight.detach().to(torch.bfloat16)
+    N, K = w16.shape
+    w16t = _pad_to(w16.t(), (K + 127) // 128 * 128, (N + 63) // 64 * 64)          # padded to the product kernel's tiles once, not per call
+    w16 = _pad_to(w16, (N + 127) // 128 * 128, (K + 63) // 64 * 64)
+    _W16[key] = (weakref.ref(base), base._version, w16, w16t)
+    return w16, w16t
+
+
+def _fusable(t: torch.Tensor) -> bool:
+    """msam_cast_transpose takes it: rows contiguous, widths in fours, fp32 or bf16 (everything the model's linears see)."""
+    return (t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0 and t.shape[0] <= 4_000_000
+            and t.dtype in (torch.float32, torch.bfloat16) and t.is_cuda and t.data_ptr() % 16 == 0)
+
+
 class _Linear(torch.autograd.Function):
+    """y = x W^T + b.  The weight gradient dW = dY^T X contracts over the rows, and the product kernel wants both operands contiguous
+    along the contraction: X^T is written next to the bf16 copy of X in the forward pass, dY^T / the bf16 copy of dY / the bias
+    gradient in ONE pass over dY in the backward pass (ops.cast_transpose) - torch's cast + strided transpose copy + sum were 30 % of a
+    fine-tuning step (profiles/r03_experiments.md section 8)."""
+
     @staticmethod
     def forward(ctx, x, weight, bias):
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        a16 = x2.to(torch.bfloat16)
-        w16 = weight.to(torch.bfloat16)
-        y = _mm_nt(a16, w16, None if bias is None else bias.detach())
-        ctx.save_for_backward(a16, w16)
+        need_dw = weight.requires_grad
+        if _fusable(x2):
+            a16, a16t, _ = ops.cast_transpose(x2, True, need_dw, False)
+        else:
+            a16 = x2.to(torch.bfloat16)
+            a16t = a16.t().contiguous() if need_dw else None
+        w16, w16t = _weight16(weight)
+        y = _mm_nt(a16, w16, None if bias is None else bias.detach(), n=weight.shape[0])
+        ctx.save_for_backward(a16t if need_dw else None, w16t)
         ctx.has_bias = bias is not None
         ctx.in_shape = shape
         return y.reshape(*shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        a16, w16 = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
-        dy16 = dy2.to(torch.bfloat16)
-        dx = dw = db = None
+        a16t, w16t = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        want_dw = ctx.needs_input_grad[1] and a16t is not None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if _fusable(dy2):
+            dy16, dy16t, db = ops.cast_transpose(dy2, ctx.needs_input_grad[0], want_dw, want_db)
+        else:
+            dy2 = dy2.contiguous()
+            dy16 = dy2.to(torch.bfloat16)
+            dy16t = dy16.t().contiguous() if want_dw else None
+            db = dy2.float().sum(dim=0) if want_db else None
+        dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _mm_nt(dy16, w16.t().contiguous()).reshape(ctx.in_shape)            # dY [M,N] @ W [N,K]
-        if ctx.needs_input_grad[1]:
-            dw = _mm_nt(dy16.t().contiguous(), a16.t().contiguous())                 # dY^T [N,M] @ X [M,K]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy2.sum(dim=0)
-        return dx, dw, db
+            dx = _mm_nt(dy16, w16t, n=ctx.in_shape[-1]).reshape(ctx.in_shape)        # dY [M,N] @ W [N,K]
+        if want_dw:
+            dw = _mm_nt(dy16t, a16t)                                                 # dY^T [N,M] @ X [M,K]
+        return dx, dw, db if want_db else None
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:

@@ -45,6 +45,38 @@ def test_linear_forward_backward(dev):
         assert _rel(x.grad, xr.grad) < 2e-2 and _rel(w.grad, wr.grad) < 2e-2 and _rel(b.grad, br.grad) < 1e-4, (M, K, N)
 
 
+@pytest.mark.parametrize("M,K,src", [(102400, 256, torch.float32), (130, 68, torch.float32), (4097, 128, torch.bfloat16), (37, 8, torch.float32)])
+def test_cast_transpose_is_torch_cast_transpose_and_sum(dev, M, K, src):
+    """msam_cast_transpose (bf16 copy, bf16 transpose and column sums in one pass) against the three torch operators it replaces:
+    the 16-bit outputs bit for bit, the sums within fp32 summation order; also on a row-strided view."""
+    from micro_sam_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    full = (torch.randn(M, K + 4, generator=g) * 3).to(src).to(dev)
+    for x in (full[:, :K].contiguous(), full[:, :K]):
+        o16, ot, cs = ops.cast_transpose(x, True, True, True)
+        want = x.to(torch.bfloat16)
+        assert torch.equal(o16, want) and torch.equal(ot, want.t().contiguous())
+        ref = x.float().sum(0)
+        assert (cs - ref).abs().max().item() <= 1e-5 * x.float().abs().sum(0).max().item()
+    _, ot, _ = ops.cast_transpose(full[:, :K], False, True, False)
+    assert torch.equal(ot, full[:, :K].to(torch.bfloat16).t().contiguous())
+
+
+def test_linear_with_a_frozen_weight_and_a_3d_input(dev):
+    """No weight gradient -> no transposes are formed; the input gradient and the bias gradient are unchanged."""
+    from micro_sam_amd.training import functional as HF
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 50, 256, generator=g).to(dev).requires_grad_()
+    w = (torch.randn(128, 256, generator=g) / 16).to(dev)
+    b = torch.randn(128, generator=g).to(dev).requires_grad_()
+    y = HF.linear(x, w, b)
+    dy = torch.randn(3, 50, 128, generator=g).to(dev)
+    y.backward(dy)
+    xr, br = x.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    F.linear(xr.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), br).backward(dy)
+    assert _rel(x.grad, xr.grad) < 2e-2 and _rel(b.grad, br.grad) < 1e-4
+
+
 @pytest.mark.parametrize("dim,eps", [(256, 1e-5), (64, 1e-6)])
 def test_layer_norm_forward_backward(dev, dim, eps):
     from micro_sam_amd.training import functional as HF

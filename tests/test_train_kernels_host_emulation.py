@@ -315,3 +315,90 @@ def test_rowblock_attention_kernels_source_on_the_cpu(emu_rb, D):
     check(2, 3, 1100, (0, 1))          # few queries, many keys (not a multiple of 256; the last threads see 4 keys, some 5)
     check(1, 2, 200, (0, 1))           # fewer keys than threads: idle threads must drop out of the merge
     check(2, 1100, 3, (2,))            # few keys, many queries
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# cast_transpose_kernel (operands of the weight gradients): 256 host threads per workgroup, barriers, LDS atomics under a mutex.
+# ---------------------------------------------------------------------------------------------------------------
+
+CT_SHIM = r"""
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+struct idx3 { int x, y, z; };
+static thread_local idx3 threadIdx, blockIdx;
+static std::barrier<>* block_bar;
+static std::mutex atomic_mutex;
+struct uint2 { unsigned x, y; };
+struct float4 { float x, y, z, w; };
+static float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+static unsigned short f2bf(float f) {                 // round to nearest even (what the device's (__bf16) conversion does)
+    unsigned u; std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static void atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
+#define __syncthreads() block_bar->arrive_and_wait()
+#define __global__
+#define __launch_bounds__(n)
+#define __restrict__
+#define __shared__ static
+%s
+extern "C" void emu_cast_transpose(int src16, const void* x, long M, int K, long ldx, unsigned short* out16, unsigned short* outT, float* colsum) {
+    for (int by = 0; by < (M + 63) / 64; ++by) for (int bx = 0; bx < (K + 63) / 64; ++bx) {
+        std::barrier<> bb(256);
+        block_bar = &bb;
+        std::vector<std::thread> ts;
+        for (int tx = 0; tx < 256; ++tx)
+            ts.emplace_back([=] {
+                threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0};
+                if (src16) cast_transpose_kernel<true>(x, M, K, ldx, out16, outT, colsum);
+                else cast_transpose_kernel<false>(x, M, K, ldx, out16, outT, colsum);
+            });
+        for (auto& t : ts) t.join();
+    }
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def emu_ct(tmp_path_factory):
+    text = open(SRC).read()
+    start = text.index("template <bool SRC16>\n__global__ __launch_bounds__(256) void cast_transpose_kernel")
+    end = text.index("}  // namespace", start)
+    d = tmp_path_factory.mktemp("emu_ct")
+    cpp, so = os.path.join(d, "ct.cpp"), os.path.join(d, "ct.so")
+    open(cpp, "w").write(CT_SHIM % text[start:end])
+    subprocess.check_call(["g++", "-std=c++20", "-O1", "-shared", "-fPIC", "-pthread", "-Wno-unknown-pragmas", cpp, "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.emu_cast_transpose.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]
+    return lib
+
+
+@pytest.mark.parametrize("M,K,ldx,src16", [(130, 68, 68, False), (64, 128, 132, False), (37, 8, 8, True), (200, 64, 64, True), (129, 256, 256, False)])
+def test_cast_transpose_kernel_source_on_the_cpu(emu_ct, M, K, ldx, src16):
+    """Ragged M (with and without M % 4 == 0: vector / scalar stores of the transpose), K below and across a tile, a row stride > K."""
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, ldx, generator=g) * 3
+    if src16:
+        x = x.to(torch.bfloat16)
+        src = x.view(torch.int16).numpy().copy()
+    else:
+        src = x.numpy().astype(np.float32).copy()
+    ref16 = x[:, :K].to(torch.bfloat16)
+    out16 = np.full((M, K), 0x7fc0, np.uint16)
+    outT = np.full((K, M), 0x7fc0, np.uint16)
+    cs = np.zeros(K, np.float32)
+    emu_ct.emu_cast_transpose(int(src16), _ptr(src), M, K, ldx, _ptr(out16), _ptr(outT), _ptr(cs))
+    want = ref16.view(torch.int16).numpy().view(np.uint16)
+    assert (out16 == want).all() and (outT == want.T).all()
+    assert np.abs(cs - x[:, :K].float().sum(0).numpy()).max() <= 1e-4 * max(1.0, float(x.float().abs().sum(0).max()))
+    # outputs are optional
+    outT2 = np.zeros((K, M), np.uint16)
+    emu_ct.emu_cast_transpose(int(src16), _ptr(src), M, K, ldx, None, _ptr(outT2), None)
+    assert (outT2 == want.T).all()

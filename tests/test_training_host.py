@@ -206,3 +206,27 @@ def test_gradient_all_reduce_and_mask_decision_broadcast_gloo():
         assert torch.allclose(g[0], torch.full((5, 7), 1.5)) and torch.allclose(g[1], torch.full((300,), 3.0)) and g[2] is None
         assert nbytes == (35 + 300) * 4                                   # grads all-reduce bytes = 4 * N_trainable
     assert res[0][2] == res[1][2] and any(res[0][2]) and not all(res[0][2])      # rank 0's decision everywhere
+
+
+def test_weight16_cache_follows_the_parameter_version():
+    """The bf16 operand copies of a weight (W and W^T, zero-padded to the product kernel's tiles) are formed once per parameter
+    version: same objects on the second use, new ones after an in-place update; views of a parameter are cached per view."""
+    from micro_sam_amd.training import functional as HF
+    p = torch.nn.Parameter(torch.randn(32, 200))
+    w16, w16t = HF._weight16(p)
+    assert w16.shape == (128, 256) and w16t.shape == (256, 64) and w16.dtype == torch.bfloat16
+    assert torch.equal(w16[:32, :200], p.detach().to(torch.bfloat16)) and float(w16[32:].abs().sum()) == 0 and float(w16[:, 200:].abs().sum()) == 0
+    assert torch.equal(w16t[:200, :32], p.detach().to(torch.bfloat16).t())
+    again = HF._weight16(p)
+    assert again[0] is w16 and again[1] is w16t
+    with torch.no_grad():
+        p.add_(1.0)
+    new = HF._weight16(p)
+    assert new[0] is not w16 and torch.equal(new[0][:32, :200], p.detach().to(torch.bfloat16))
+    conv = torch.nn.Parameter(torch.randn(256, 4, 8, 8))
+    v1, _ = HF._weight16(conv.reshape(256, -1))
+    v2, _ = HF._weight16(conv.reshape(256, -1))
+    assert v1 is v2 and v1.shape == (256, 256)
+    plain = torch.randn(16, 64)                       # not a parameter: no caching, no padding
+    a, b = HF._weight16(plain)
+    assert a.shape == (16, 64) and b.shape == (64, 16)

@@ -2,5 +2,8 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out/c13
 mkdir -p $O
-timeout 400 python tools/train_bench.py --model vit_b --op-profile 45 > $O/opprof.log 2>&1
-grep -v amdgpu.ids $O/opprof.log | cut -c1-260 | head -120
+timeout 600 python -m pytest tests/test_gpu_training.py tests/test_gpu_training_encoders.py -q -x 2>&1 | tail -4 | tee $O/tests.log
+rm -f $O/train.log
+for args in "--model vit_b --freeze image_encoder prompt_encoder" "--model vit_b" "--model vit_h"; do
+  timeout 400 python tools/train_bench.py $args --steps 4 --warmup 2 2>&1 | tail -1 | tee -a $O/train.log
+done
