@@ -271,13 +271,20 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
         }
     }
     __builtin_amdgcn_wave_barrier();
-    float4 bw[2][2][2];                                  // [score tile j][kw phase][key block t]
+    // Softmax in the base-2 domain (round 3): scores, both bias terms and the running maximum carry the factor log2(e), the
+    // exponential is the bare v_exp_f32; the per-element work is written on float pairs (v_pk_fma_f32 / v_pk_add_f32: two values
+    // per issue slot) - the loop was bound by its VALU count (171 VALU against 16 MFMA per 32-key tile, 25 % MFMA busy).
+    constexpr float LOG2E = 1.4426950408889634f;
+    f32x2_t bw[2][2][2][2];                              // [score tile j][kw phase][key block t][pair], times log2(e)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) bw[j][ph][t] = *(const float4*)(scr + (j * 16 + fr) * GB_RS + ph * 32 + t * 16 + fg * 4);
+            for (int t = 0; t < 2; ++t) {
+                const float4 v4 = *(const float4*)(scr + (j * 16 + fr) * GB_RS + ph * 32 + t * 16 + fg * 4);
+                bw[j][ph][t][0] = f32x2_t{v4.x * LOG2E, v4.y * LOG2E}; bw[j][ph][t][1] = f32x2_t{v4.z * LOG2E, v4.w * LOG2E};
+            }
     __builtin_amdgcn_wave_barrier();
     // ---- rel_h[q][kh] = q . rel_pos_h[qh - kh + 63]  (A rows indexed by kh), into the same rows
 #pragma unroll
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
             f32x4_t c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) c = mma<F16>(*(const uint4*)(src + ks * 32 + fg * 8), qf[j][ks], c);
-            *(float4*)(scr + (j * 16 + fr) * GB_RS + t * 16 + fg * 4) = make_float4(c[0], c[1], c[2], c[3]);
+            *(float4*)(scr + (j * 16 + fr) * GB_RS + t * 16 + fg * 4) = make_float4(c[0] * LOG2E, c[1] * LOG2E, c[2] * LOG2E, c[3] * LOG2E);
         }
 
     // ---- K / V tile staging (register prefetch, double-buffered LDS); both tiles row-major [32 keys][HD]
@@ -334,8 +341,14 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
         for (int dt = 0; dt < DT; ++dt) o[j][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     float m[2] = {NEG_BIG, NEG_BIG}, l[2] = {0.f, 0.f};
     const int NT = TOK / GKT;   // 128
-    for (int kt = 0; kt < NT; ++kt) {
-        const int buf = kt & 1;
+    const float c2s = scale * LOG2E;
+    const f32x2_t c2 = {c2s, c2s};
+    // two 32-key tiles per trip = one key row kh of the 64 x 64 grid: the kw phase and the LDS buffer are compile-time
+    for (int kh = 0; kh < NT / 2; ++kh) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+        const int kt = kh * 2 + ph;
+        const int buf = ph;
         {
             const int nx = min(kt + 1, NT - 1);
             rk = *(const uint4*)(Kb + (long)(nx * GKT + s_row) * HD + s_ch * 8);
@@ -345,7 +358,6 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
                 rv2 = *(const uint4*)(Vb + (long)(nx * GKT + s_row2) * HD + s_ch2 * 8);
             }
         }
-        const int kh = kt >> 1, ph = kt & 1;
         uint4 ka[2][KS];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -370,36 +382,52 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void global_attention_kernel
                 for (int ks = 0; ks < KS; ++ks) a = mma<F16>(ka[t][ks], qf[j][ks], a);
                 s[t] = a;
             }
-            const float rh = scr[(j * 16 + fr) * GB_RS + kh];
+            const float rh = scr[(j * 16 + fr) * GB_RS + kh];           // already times log2(e)
+            const f32x2_t rh2 = {rh, rh};
+            f32x2_t e[2][2];                                            // base-2 logits, pairs (0, 1) and (2, 3) of key block t
             float mt = NEG_BIG;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const float4 bwv = ph ? bw[j][1][t] : bw[j][0][t];
-                s[t][0] = s[t][0] * scale + rh + bwv.x; s[t][1] = s[t][1] * scale + rh + bwv.y;
-                s[t][2] = s[t][2] * scale + rh + bwv.z; s[t][3] = s[t][3] * scale + rh + bwv.w;
-                mt = fmaxf(mt, fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3])));
+                e[t][0] = f32x2_t{s[t][0], s[t][1]} * c2 + (rh2 + bw[j][ph][t][0]);
+                e[t][1] = f32x2_t{s[t][2], s[t][3]} * c2 + (rh2 + bw[j][ph][t][1]);
+                mt = fmaxf(mt, fmaxf(fmaxf(e[t][0].x, e[t][0].y), fmaxf(e[t][1].x, e[t][1].y)));
             }
             mt = fmaxf(mt, __shfl_xor(mt, 16)); mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mn = fmaxf(m[j], mt);
-            const float alpha = __expf(m[j] - mn);
-            m[j] = mn;
-            float ps = 0.f;
+            // the running maximum moves in a few of the 128 tiles: rescale the accumulators only then (alpha = 2^0 = 1 otherwise, exactly)
+            if (__builtin_amdgcn_ballot_w64(mn > m[j]) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m[j] - mn);
+                const f32x2_t al2 = {alpha, alpha};
+                l[j] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const f32x2_t o01 = f32x2_t{o[j][dt][0], o[j][dt][1]} * al2, o23 = f32x2_t{o[j][dt][2], o[j][dt][3]} * al2;
+                    o[j][dt][0] = o01.x; o[j][dt][1] = o01.y; o[j][dt][2] = o23.x; o[j][dt][3] = o23.y;
+                }
+                m[j] = mn;
+            }
+            const f32x2_t nm2 = {-mn, -mn};
+            f32x2_t psv = {0.f, 0.f};
+            float pv[2][4];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float p = __expf(s[t][r] - mn); s[t][r] = p; ps += p; }
-            l[j] = l[j] * alpha + ps;      // per-lane partial row sum; the 4 lane groups are combined after the loop
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x2_t x = e[t][h2] + nm2;
+                    const f32x2_t p = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                    psv += p;
+                    pv[t][2 * h2] = p.x; pv[t][2 * h2 + 1] = p.y;
+                }
+            l[j] += psv.x + psv.y;         // per-lane partial row sum; the 4 lane groups are combined after the loop
             uint4 pb;
-            pb.x = pk2<F16>(s[0][0], s[0][1]); pb.y = pk2<F16>(s[0][2], s[0][3]);
-            pb.z = pk2<F16>(s[1][0], s[1][1]); pb.w = pk2<F16>(s[1][2], s[1][3]);
+            pb.x = pk2<F16>(pv[0][0], pv[0][1]); pb.y = pk2<F16>(pv[0][2], pv[0][3]);
+            pb.z = pk2<F16>(pv[1][0], pv[1][1]); pb.w = pk2<F16>(pv[1][2], pv[1][3]);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[j][dt][0] *= alpha; o[j][dt][1] *= alpha; o[j][dt][2] *= alpha; o[j][dt][3] *= alpha;
-                o[j][dt] = mma<F16>(va[dt], pb, o[j][dt]);
-            }
+            for (int dt = 0; dt < DT; ++dt) o[j][dt] = mma<F16>(va[dt], pb, o[j][dt]);
         }
         if (kt + 1 < NT) G_COMMIT(buf ^ 1);
         __syncthreads();
+        }
     }
 #undef G_COMMIT
 #pragma unroll
