@@ -48,7 +48,7 @@ constexpr int VT_RS = 232;    // V^T row stride in bf16 (464 B = 116 dwords = 4 
 constexpr int T_RS = 65;      // rel-pos table row stride (floats)
 
 template <int HD, bool F16 = false>
-__global__ __launch_bounds__(256) void window_attention_kernel(
+__global__ __launch_bounds__(256, 2) void window_attention_kernel(
     const u16* __restrict__ Q, const u16* __restrict__ K, const u16* __restrict__ V, const u16* __restrict__ relh,
     const u16* __restrict__ relw, const float* __restrict__ qkv_bias, int heads, float scale, u16* __restrict__ out) {
     constexpr int KS = HD / 32;                 // MFMA k-steps of the q.k contraction
@@ -72,30 +72,52 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     const float* bk = qkv_bias + D + head * HD;
     const float* bv = qkv_bias + 2 * D + head * HD;
 
-    // ---- stage K (row-major, swizzled chunks) and V^T
-    for (int c = tid; c < WKT * 16 * CH; c += 256) {
+    // ---- stage K (row-major, swizzled chunks) and V^T.  All global loads of the workgroup are issued before the first LDS write
+    // (round 3: a load -> wait -> write loop made 14 dependent memory latencies per workgroup; with 2 workgroups per CU the kernel
+    // spent most of its 52 us per workgroup waiting for them).
+    constexpr int KIT = (WKT * 16 * CH + 255) / 256, VIT = (WKP * CH + 255) / 256;
+    uint4 kreg[KIT], vreg[VIT];
+#pragma unroll
+    for (int i = 0; i < KIT; ++i) {
+        const int c = tid + 256 * i;
         const int row = c / CH, ch = c - row * CH;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (row < WN) {
+        if (c < WKT * 16 * CH && row < WN) {
             const int y = wy * WS + row / WS, x = wx * WS + row % WS;
             if (y < 64 && x < 64) val = *(const uint4*)(Kb + (long)(y * 64 + x) * HD + ch * 8);
             else val = bias_chunk<F16>(bk + ch * 8);
         }
-        k_lds[row * CHP + (ch ^ swz(row))] = val;
+        kreg[i] = val;
     }
-    for (int c = tid; c < WKP * CH; c += 256) {
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+        const int c = tid + 256 * i;
         const int key = c % WKP, ch = c / WKP;
         uint4 val = make_uint4(0, 0, 0, 0);
-        if (key < WN) {
+        if (c < WKP * CH && key < WN) {
             const int y = wy * WS + key / WS, x = wx * WS + key % WS;
             if (y < 64 && x < 64) val = *(const uint4*)(Vb + (long)(y * 64 + x) * HD + ch * 8);
             else val = bias_chunk<F16>(bv + ch * 8);
         }
-        const uint32_t wv[4] = {val.x, val.y, val.z, val.w};
+        vreg[i] = val;
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vt_lds[(ch * 8 + 2 * i) * VT_RS + key] = (u16)(wv[i] & 0xffff);
-            vt_lds[(ch * 8 + 2 * i + 1) * VT_RS + key] = (u16)(wv[i] >> 16);
+    for (int i = 0; i < KIT; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c / CH, ch = c - row * CH;
+        if (c < WKT * 16 * CH) k_lds[row * CHP + (ch ^ swz(row))] = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VIT; ++i) {
+        const int c = tid + 256 * i;
+        const int key = c % WKP, ch = c / WKP;
+        if (c < WKP * CH) {
+            const uint32_t wv[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                vt_lds[(ch * 8 + 2 * j) * VT_RS + key] = (u16)(wv[j] & 0xffff);
+                vt_lds[(ch * 8 + 2 * j + 1) * VT_RS + key] = (u16)(wv[j] >> 16);
+            }
         }
     }
 
@@ -114,19 +136,30 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     __syncthreads();
 
     float* tl = t_lds[wave];
+    // Q fragments (B operand) of query tile qt: query qi = qt*16 + fr; the NEXT tile's are requested while this one is worked on
+    auto load_q = [&](int qt, uint4 (&dstq)[KS]) {
+        const int qi = qt * 16 + fr;
+        const int qh = (qi < WN ? qi : WN - 1) / WS, qw = (qi < WN ? qi : WN - 1) % WS;
+        const int qy = wy * WS + qh, qx = wx * WS + qw;
+        const bool q_real = qi < WN && qy < 64 && qx < 64;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (q_real) dstq[ks] = *(const uint4*)(Qb + (long)(qy * 64 + qx) * HD + ks * 32 + fg * 8);
+            else if (qi < WN) dstq[ks] = bias_chunk<F16>(bq + ks * 32 + fg * 8);
+            else dstq[ks] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    uint4 qnext[KS];
+    load_q(wave, qnext);
     for (int qt = wave; qt < WKT; qt += 4) {
-        // Q fragments (B operand): query qi = qt*16 + fr
         const int qi = qt * 16 + fr;
         const int qh = (qi < WN ? qi : WN - 1) / WS, qw = (qi < WN ? qi : WN - 1) % WS;
         const int qy = wy * WS + qh, qx = wx * WS + qw;
         const bool q_real = qi < WN && qy < 64 && qx < 64;
         uint4 qf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (q_real) qf[ks] = *(const uint4*)(Qb + (long)(qy * 64 + qx) * HD + ks * 32 + fg * 8);
-            else if (qi < WN) qf[ks] = bias_chunk<F16>(bq + ks * 32 + fg * 8);
-            else qf[ks] = make_uint4(0, 0, 0, 0);
-        }
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qnext[ks];
+        if (qt + 4 < WKT) load_q(qt + 4, qnext);
         // T^T[j][q] = R[j] . q  -> t_lds[q][j]
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
@@ -148,12 +181,16 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         }
         __builtin_amdgcn_wave_barrier();
         // scale, rel-pos bias, mask padding keys; column-wise (per query) softmax
+        // (the key -> (kh, kw) arithmetic is kept INSIDE the query-tile loop: hoisted, its 104 per-lane values pushed the kernel to 353
+        // registers = one wave per SIMD, one workgroup per CU)
+        int fgv = fg;
+        asm volatile("" : "+v"(fgv));
         float m = NEG_BIG;
 #pragma unroll
         for (int kt = 0; kt < WKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + fg * 4 + r;
+                const int key = kt * 16 + fgv * 4 + r;
                 float v = NEG_BIG;
                 if (key < WN) {
                     const int kh = key / WS, kw = key - kh * WS;
