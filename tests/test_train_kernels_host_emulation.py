@@ -64,7 +64,7 @@ extern "C" void emu_bwd(int D, const float* q, const float* k, const float* v, c
 def emu(tmp_path_factory):
     text = open(SRC).read()
     start = text.index("template <int D>\n__global__ __launch_bounds__(128) void relpos_fwd_kernel")
-    end = text.index("}  // namespace", start)
+    end = text.index("// ---- cast + transpose + column sums", start)
     kernels = text[start:end]
     assert all(f"relpos_{n}_kernel" in kernels for n in ("fwd", "bwd_q", "bwd_kv")) and "wave_sum64" not in kernels
     d = tmp_path_factory.mktemp("emu")
