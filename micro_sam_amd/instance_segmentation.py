@@ -154,19 +154,22 @@ class AMGBase(ABC):
 
     def _postprocess_batch(self, data, crop_box, original_size, pred_iou_thresh, stability_score_thresh, box_nms_thresh):
         orig_h, orig_w = original_size
+        # The reference filters the columns three times (predicted IoU, stability, crop edge) and once more by the NMS result
+        # (:106-133).  The three tests are independent of each other, so they are ANDed here and every column is gathered ONCE with
+        # the final index list (survivors of the tests, in NMS order): same rows in the same order, one host synchronisation per crop
+        # instead of one per column and test (boolean indexing of a device tensor waits for its count).
+        keep = ~amg_utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h])
         if pred_iou_thresh > 0.0:
-            data.filter(data["iou_preds"] > pred_iou_thresh)
+            keep = keep & (data["iou_preds"] > pred_iou_thresh).to(keep.device)
         if stability_score_thresh > 0.0:
-            data.filter(data["stability_score"] >= stability_score_thresh)
-        keep_mask = ~amg_utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h])
-        if not torch.all(keep_mask):
-            data.filter(keep_mask)
-        if data["boxes"].is_cuda:
-            keep_by_nms = ops.box_nms(data["boxes"], data["iou_preds"], box_nms_thresh)      # one category
+            keep = keep & (data["stability_score"] >= stability_score_thresh).to(keep.device)
+        idx = torch.nonzero(keep).squeeze(1)
+        boxes, scores = data["boxes"][idx], data["iou_preds"][idx]
+        if boxes.is_cuda:
+            keep_by_nms = ops.box_nms(boxes, scores, box_nms_thresh)                         # one category
         else:
-            keep_by_nms = amg_utils.batched_nms(data["boxes"].float(), data["iou_preds"],
-                                                torch.zeros_like(data["boxes"][:, 0]), iou_threshold=box_nms_thresh)
-        data.filter(keep_by_nms)
+            keep_by_nms = amg_utils.batched_nms(boxes.float(), scores, torch.zeros_like(boxes[:, 0]), iou_threshold=box_nms_thresh)
+        data.filter(idx[keep_by_nms.to(idx.device)])
         data["boxes"] = amg_utils.uncrop_boxes_xyxy(data["boxes"], crop_box)
         data["crop_boxes"] = torch.tensor([crop_box for _ in range(int(data["iou_preds"].shape[0]))])
         try:
