@@ -49,3 +49,35 @@ def test_remove_small_regions():
     tiny = np.zeros((6, 6), dtype=bool); tiny[0, 0] = True; tiny[4, 4:6] = True
     kept, _ = amg_utils.remove_small_regions(tiny, 10, "islands")       # everything below the threshold: keep the largest
     assert kept.sum() == 2 and kept[4, 4]
+
+
+def test_postprocess_batch_single_gather_equals_the_sequential_filters():
+    """``AMGBase._postprocess_batch`` (reference instance_segmentation.py:99-144) filters the columns by predicted IoU, by
+    stability, by the crop-edge test and by the NMS result, one after the other.  The product ANDs the three independent tests and
+    gathers every column once with the final index list: same rows, same order, for tensor, numpy and list columns - checked here
+    against the oracle's literal restatement on random candidates (crop inside the image: the edge test matters)."""
+    from micro_sam_amd import amg_utils
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
+    from oracle import amg_ref as A
+    from oracle import pipeline_ref as PR
+    g = torch.Generator().manual_seed(11)
+    crop_box, original_size = [100, 50, 612, 562], (700, 800)
+    for n in (0, 1, 257):
+        x0 = torch.randint(0, 400, (n,), generator=g); y0 = torch.randint(0, 400, (n,), generator=g)
+        w = torch.randint(1, 200, (n,), generator=g); h = torch.randint(1, 200, (n,), generator=g)
+        boxes = torch.stack([x0, y0, torch.clamp(x0 + w, max=512), torch.clamp(y0 + h, max=512)], dim=1)
+        boxes[::7, 0] = 0                                        # some touch the crop edge (and not the image edge)
+        cols = {"iou_preds": torch.rand(n, generator=g) * 0.3 + 0.75, "stability_score": torch.rand(n, generator=g) * 0.2 + 0.85,
+                "boxes": boxes, "points": torch.rand(n, 2, generator=g) * 512, "cand": torch.arange(n),
+                "rles": [{"size": [512, 512], "counts": [i, 512 * 512 - i]} for i in range(n)]}
+        ref = A.MaskData(**{k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in cols.items()})
+        ref = PR.postprocess_batch(ref, crop_box, original_size, 0.88, 0.95, 0.7)
+        got = amg_utils.MaskData(**{k: (v.clone() if torch.is_tensor(v) else list(v)) for k, v in cols.items()})
+        got["area_np"] = np.arange(n) * 3                       # a numpy column as well
+        got = AutomaticMaskGenerator._postprocess_batch(None, got, crop_box, original_size, 0.88, 0.95, 0.7)
+        assert torch.equal(got["cand"], ref["cand"]), n
+        for k in ("iou_preds", "stability_score", "boxes", "points", "crop_boxes"):
+            assert torch.equal(torch.as_tensor(got[k]).double(), torch.as_tensor(ref[k]).double()), (n, k)
+        assert got["rles"] == ref["rles"] and np.array_equal(got["area_np"], ref["cand"].numpy() * 3)
+        if n == 257:
+            assert 0 < len(ref["cand"]) < n
