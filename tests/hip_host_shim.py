@@ -38,8 +38,12 @@ struct f32x2_t {                                             // clang's ext_vect
     float x, y;
     f32x2_t operator*(const f32x2_t& o) const { return {x * o.x, y * o.y}; }
     f32x2_t operator+(const f32x2_t& o) const { return {x + o.x, y + o.y}; }
+    f32x2_t operator-(const f32x2_t& o) const { return {x - o.x, y - o.y}; }
+    f32x2_t operator*(float s) const { return {x * s, y * s}; }
+    f32x2_t operator+(float s) const { return {x + s, y + s}; }
     f32x2_t& operator+=(const f32x2_t& o) { x += o.x; y += o.y; return *this; }
 };
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 typedef float f32x16_t __attribute__((vector_size(64)));
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
@@ -164,6 +168,25 @@ static inline f32x16_t mfma32_emu(const uint4& a, const uint4& b, f32x16_t c, bo
     wave_bar[w]->arrive_and_wait();
     return d;
 }
+// LDS-DMA (global_load_lds_dwordx4): lane l lands at the wave-uniform LDS base + 16 l; performed at once
+static inline void __builtin_amdgcn_global_load_lds(const void* g, void* l, int size, int, int) {
+    std::memcpy((char*)l + (threadIdx.x & 63) * size, g, size);
+}
+static inline void wait_vmem_all() {}
+// raw buffer addressing (common.h make_rsrc / buf_load16 / buf_store16): base + per-lane byte offset + scalar byte offset, reads
+// outside the descriptor's range return zeros, writes outside it are dropped
+struct rsrc_t { char* base; uint32_t bytes; };
+static inline rsrc_t make_rsrc(const void* base, uint32_t bytes) { return rsrc_t{(char*)base, bytes}; }
+static inline uint4 buf_load16(rsrc_t r, int voff, int soff) {
+    uint4 v{0, 0, 0, 0};
+    const long o = (long)voff + soff;
+    if (o >= 0 && o + 16 <= (long)r.bytes) std::memcpy(&v, r.base + o, 16);
+    return v;
+}
+static inline void buf_store16(const uint4& v, rsrc_t r, int voff, int soff) {
+    const long o = (long)voff + soff;
+    if (o >= 0 && o + 16 <= (long)r.bytes) std::memcpy(r.base + o, &v, 16);
+}
 static inline void atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
 static inline void atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
 #define __expf expf
@@ -187,6 +210,7 @@ template <class F> static void launch_grid(int gx, int gy, F f) {
         for (auto& t : ts) t.join();
     }
 }
+// (kernels whose workgroups leave early - "if (bid >= tiles) return" before any barrier - are launched with exactly their tiles)
 """
 
 

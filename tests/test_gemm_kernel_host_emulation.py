@@ -1,0 +1,146 @@
+"""gemm_kernel (csrc/gemm.hip: the 128 x 128 x 64 MFMA tile kernel behind msam_gemm_bf16 - patch embedding, neck, the decoder's token
+side, every product of the training path) executed on the CPU behind tests/hip_host_shim.py: operand staging with the chunk swizzle
+(register staging and the LDS-DMA form), the 16x16x32 MFMA in its register layout, the epilogues (bias, row table, fp32 / 16-bit residual,
+GELU / ReLU, fp32 / bf16 output, q / k / v head split, split-K accumulation) on a ragged M - against fp64 products of the same bf16
+operands.  Device run of the same kernel: tests/test_gpu_kernels.py."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_host_shim import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ENTRY = r"""
+extern "C" void emu_gemm(int glds, const u16* A, long lda, const u16* W, long ldw, int M, int N, int K, const float* bias, const float* table,
+                         int table_rows, int table_cols, long table_ld, const void* resid, int resid_dtype, int resid_rows, long ldr, int act,
+                         void* out, int out_dtype, long ldc, int out_mode, u16* q, u16* k, u16* v, int heads, int head_dim, int tokens,
+                         int split_k) {
+    Epi e{};
+    e.bias = bias; e.table = table; e.table_rows = table_rows; e.table_cols = table_cols; e.table_ld = table_ld;
+    e.resid = resid; e.resid_dtype = resid_dtype; e.resid_rows = resid_rows; e.ldr = ldr; e.act = act;
+    e.out = out; e.out_dtype = out_dtype; e.ldc = ldc; e.out_mode = out_mode; e.q = q; e.k = k; e.v = v;
+    e.heads = heads; e.head_dim = head_dim; e.tokens = tokens; e.row_scale = nullptr; e.col_scale = nullptr;
+    e.splitk_len = split_k > 1 ? K / split_k : 0;
+    const int tiles = ((M + 127) / 128) * (N / 128);
+    if (glds) launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<true, false>(A, lda, W, ldw, M, N, K, e); });
+    else launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<false, false>(A, lda, W, ldw, M, N, K, e); });
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    common = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "common.h")).read()
+    a = common.index("MSAM_DEVINL float relu1(float x)")
+    gelu = common[a:common.index("// round-to-nearest-even fp32 -> packed fp16", a)]
+    text = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "gemm.hip")).read()
+    start = text.index("constexpr int BM = 128, BN = 128, BK = 64;")
+    end = text.index("// Grouped launch: up to MSAM_GEMM_GROUP_MAX independent small products in ONE launch")
+    header = '#include "%s"\n' % os.path.join(ROOT, "include", "msam_hip.h")
+    body = header + gelu + text[start:end]
+    assert "gemm_body" in body and "gemm_kernel" in body
+    lib = build(str(tmp_path_factory.mktemp("emu_gemm")), "gemm", body, ENTRY)
+    vp, i, l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+    lib.emu_gemm.argtypes = [i, vp, l, vp, l, i, i, i, vp, vp, i, i, l, vp, i, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, i]
+    return lib
+
+
+MSAM_F32, MSAM_BF16 = 1, 2          # include/msam_hip.h
+ACT_GELU, ACT_RELU = 1, 2
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _bits(t):
+    return _bf(t).view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def _from_bits(a):
+    return torch.from_numpy(a.view(np.int16)).view(torch.bfloat16).double()
+
+
+def test_header_constants():
+    text = open(os.path.join(ROOT, "include", "msam_hip.h")).read()
+    for name, val in (("MSAM_F32", MSAM_F32), ("MSAM_BF16", MSAM_BF16), ("MSAM_ACT_GELU", ACT_GELU), ("MSAM_ACT_RELU", ACT_RELU)):
+        assert f"#define {name} {val}" in text or f"{name} = {val}" in text or f"{name}  {val}" in text, name
+
+
+@pytest.mark.parametrize("glds", [0, 1])
+def test_gemm_kernel_source_on_the_cpu(emu, glds):
+    g = torch.Generator().manual_seed(21 + glds)
+    M, N, K = 200, 256, 192                                                       # 2 x 2 tiles, ragged last row tile, 3 k-tiles
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    prod = a.double() @ w.double().t()
+    A, W, B = _bits(a), _bits(w), bias.numpy().astype(np.float32).copy()
+
+    def run(**kw):
+        d = dict(bias=None, table=None, table_rows=0, table_cols=0, table_ld=0, resid=None, resid_dtype=0, resid_rows=0, ldr=0, act=0,
+                 out=None, out_dtype=MSAM_F32, ldc=N, out_mode=0, q=None, k=None, v=None, heads=0, head_dim=0, tokens=0, split_k=0)
+        d.update(kw)
+        emu.emu_gemm(glds, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(d["bias"]), _ptr(d["table"]), d["table_rows"], d["table_cols"], d["table_ld"],
+                     _ptr(d["resid"]), d["resid_dtype"], d["resid_rows"], d["ldr"], d["act"], _ptr(d["out"]), d["out_dtype"], d["ldc"],
+                     d["out_mode"], _ptr(d["q"]), _ptr(d["k"]), _ptr(d["v"]), d["heads"], d["head_dim"], d["tokens"], d["split_k"])
+
+    # bias, fp32 output
+    out = np.full((M, N), np.nan, np.float32)
+    run(bias=B, out=out)
+    ref = prod + bias.double()
+    assert np.isfinite(out).all() and np.abs(out - ref.numpy()).max() <= 2e-5 * ref.abs().max().item()
+    # GELU, bf16 output
+    out16 = np.zeros((M, N), np.uint16)
+    run(bias=B, act=ACT_GELU, out=out16, out_dtype=MSAM_BF16)
+    want = F.gelu(ref)
+    assert (_from_bits(out16) - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+    # row table on the first 128 columns (rows wrap at 7) + fp32 residual with row wrap + ReLU
+    table = torch.randn(7, 128, generator=g)
+    resid = torch.randn(50, N, generator=g)
+    T_, R_ = table.numpy().astype(np.float32).copy(), resid.numpy().astype(np.float32).copy()
+    out = np.full((M, N), np.nan, np.float32)
+    run(table=T_, table_rows=7, table_cols=128, table_ld=128, resid=R_, resid_dtype=MSAM_F32, resid_rows=50, ldr=N, act=ACT_RELU, out=out)
+    rows = torch.arange(M)
+    want = prod + resid.double()[rows % 50]
+    want[:, :128] += table.double()[rows % 7]
+    want = torch.relu(want)
+    assert np.abs(out - want.numpy()).max() <= 2e-5 * want.abs().max().item()
+    # 16-bit residual, in place on an fp32 output is not offered: bf16 residual into fp32 output
+    r16 = _bf(torch.randn(M, N, generator=g))
+    R16 = _bits(r16)
+    out = np.full((M, N), np.nan, np.float32)
+    run(resid=R16, resid_dtype=MSAM_BF16, ldr=N, out=out)
+    assert np.abs(out - (prod + r16.double()).numpy()).max() <= 2e-5 * prod.abs().max().item()
+
+
+def test_gemm_kernel_qkv_split_and_split_k_on_the_cpu(emu):
+    g = torch.Generator().manual_seed(5)
+    # q / k / v head split: rows = (b, token), columns = (which, head, d)
+    Bn, tokens, heads, hd, K = 2, 64, 2, 64, 128
+    M, N = Bn * tokens, 3 * heads * hd
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    A, W, B = _bits(a), _bits(w), bias.numpy().astype(np.float32).copy()
+    q, k, v = (np.zeros((Bn, heads, tokens, hd), np.uint16) for _ in range(3))
+    emu.emu_gemm(0, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), None, 0, 0, 0, None, 0, 0, 0, 0, None, MSAM_BF16, N, 1, _ptr(q), _ptr(k), _ptr(v),
+                 heads, hd, tokens, 0)
+    ref = (a.double() @ w.double().t() + bias.double()).reshape(Bn, tokens, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    for got, want in zip((q, k, v), ref):
+        assert (_from_bits(got) - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+    # split-K: 4 slices of the contraction accumulate into the zeroed fp32 output
+    M, N, K = 128, 128, 1024
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    A, W = _bits(a), _bits(w)
+    out = np.zeros((M, N), np.float32)
+    emu.emu_gemm(0, _ptr(A), K, _ptr(W), K, M, N, K, None, None, 0, 0, 0, None, 0, 0, 0, 0, _ptr(out), MSAM_F32, N, 0, None, None, None, 0, 0, 0, 4)
+    ref = a.double() @ w.double().t()
+    assert np.abs(out - ref.numpy()).max() <= 3e-5 * ref.abs().max().item()
