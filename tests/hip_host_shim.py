@@ -29,7 +29,7 @@ using std::min; using std::max;
 struct idx3 { int x, y, z; };
 static thread_local idx3 threadIdx, blockIdx;
 static idx3 gridDim;
-static std::barrier<>* wave_bar[4];
+static std::barrier<>* wave_bar[8];
 static std::barrier<>* block_bar;
 static std::mutex atomic_mutex;
 typedef unsigned short u16;
@@ -89,8 +89,8 @@ static inline int swz(int row) { return ((row >> 1) & 7) ^ (((row + 4) >> 3) & 1
 static inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 // ---- wave collectives: every lane of the wave takes part
-static long long wave_buf[4][64];
-static uint4 wave_a[4][64], wave_b[4][64];
+static long long wave_buf[8][64];
+static uint4 wave_a[8][64], wave_b[8][64], wave_a2[8][64], wave_b2[8][64];
 static inline long long wave_xchg(long long v, int src_lane_xor) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_buf[w][l] = v;
@@ -114,7 +114,7 @@ static inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return
 static inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
 // ds_read_b64_tr_b16 as the kernels use it: inside every group of 16 lanes, lane r receives element (r % 4) of the four 16-bit values
 // read by lanes 4 j + r / 4 (j = 0..3) - a 16 x 4 <-> 4 x 16 transpose of the block the group addressed
-static uint2 wave_tr[4][64];
+static uint2 wave_tr[8][64];
 static inline uint2 ds_read_tr16_b64_emu(const unsigned char* p) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     std::memcpy(&wave_tr[w][l], p, 8);
@@ -187,11 +187,44 @@ static inline void buf_store16(const uint4& v, rsrc_t r, int voff, int soff) {
     const long o = (long)voff + soff;
     if (o >= 0 && o + 16 <= (long)r.bytes) std::memcpy(r.base + o, &v, 16);
 }
+// v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 e4m3 operands and unit block scales: lane l holds the 32 bytes k = 32 (l / 32) .. + 31 of
+// row (A) / column (B) l % 32; D as the 32x32x16 form
+static inline float e4m3_to_f(uint8_t b) {
+    const int ex = (b >> 3) & 15, man = b & 7;
+    float v = ex == 0 ? std::ldexp((float)man, -9) : (ex == 15 && man == 7 ? NAN : std::ldexp(1.0f + man / 8.0f, ex - 7));
+    return (b & 0x80) ? -v : v;
+}
+static inline f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, f32x16_t c) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    wave_a[w][l] = a0; wave_a2[w][l] = a1; wave_b[w][l] = b0; wave_b2[w][l] = b1;
+    wave_bar[w]->arrive_and_wait();
+    auto byte = [](const uint4& lo, const uint4& hi, int i) { const uint4& q = i < 16 ? lo : hi; return (uint8_t)(((&q.x)[(i & 15) >> 2] >> (8 * (i & 3))) & 255u); };
+    f32x16_t d;
+    for (int g = 0; g < 4; ++g)
+        for (int x = 0; x < 4; ++x) {
+            const int row = 8 * g + 4 * (l >> 5) + x, col = l & 31;
+            double s = c[4 * g + x];
+            for (int kb = 0; kb < 2; ++kb)
+                for (int i = 0; i < 32; ++i)
+                    s += (double)e4m3_to_f(byte(wave_a[w][kb * 32 + row], wave_a2[w][kb * 32 + row], i)) *
+                         (double)e4m3_to_f(byte(wave_b[w][kb * 32 + col], wave_b2[w][kb * 32 + col], i));
+            d[4 * g + x] = (float)s;
+        }
+    wave_bar[w]->arrive_and_wait();
+    return d;
+}
+template <bool F16 = false> static inline f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) { return mfma32_emu(a, b, c, F16); }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __builtin_amdgcn_s_barrier();
 static inline void atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
 static inline void atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
 #define __expf expf
 #define __logf logf
 #define __syncthreads() block_bar->arrive_and_wait()
+static inline void __builtin_amdgcn_s_barrier() { block_bar->arrive_and_wait(); }
 #define MSAM_DEVINL static inline
 #define __global__
 #define __device__
@@ -200,13 +233,15 @@ static inline void atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(atom
 #define __restrict__
 #define __shared__ static
 // one workgroup of 256 threads after the other: f() is the kernel call
-template <class F> static void launch_grid(int gx, int gy, F f) {
+template <class F> static void launch_grid(int gx, int gy, F f, int threads = 256) {
     gridDim = {gx, gy, 1};
     for (int by = 0; by < gy; ++by) for (int bx = 0; bx < gx; ++bx) {
-        std::barrier<> b0(64), b1(64), b2(64), b3(64), bb(256);
-        wave_bar[0] = &b0; wave_bar[1] = &b1; wave_bar[2] = &b2; wave_bar[3] = &b3; block_bar = &bb;
+        std::barrier<> b0(64), b1(64), b2(64), b3(64), b4(64), b5(64), b6(64), b7(64), bb(threads);
+        std::barrier<>* wb[8] = {&b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7};
+        for (int i = 0; i < 8; ++i) wave_bar[i] = wb[i];
+        block_bar = &bb;
         std::vector<std::thread> ts;
-        for (int tx = 0; tx < 256; ++tx) ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0}; f(); });
+        for (int tx = 0; tx < threads; ++tx) ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0}; f(); });
         for (auto& t : ts) t.join();
     }
 }

@@ -30,6 +30,24 @@ extern "C" void emu_gemm(int glds, const u16* A, long lda, const u16* W, long ld
     if (glds) launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<true, false>(A, lda, W, ldw, M, N, K, e); });
     else launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<false, false>(A, lda, W, ldw, M, N, K, e); });
 }
+// the 256 x 256 tile kernel: staging 0..3 (bf16), fp8 = staging 1 with e4m3 operands and row / column scales
+extern "C" void emu_gemm256(int staging, int fp8, int direct_epi, const u16* A, long lda, const u16* W, long ldw, int M, int N, int K,
+                            const float* bias, const void* resid, int resid_dtype, long ldr, int act, void* out, int out_dtype, long ldc,
+                            int out_mode, u16* q, u16* k, u16* v, int heads, int head_dim, int tokens, const float* row_scale,
+                            const float* col_scale) {
+    Epi e{};
+    e.bias = bias; e.resid = resid; e.resid_dtype = resid_dtype; e.ldr = ldr; e.act = act; e.out = out; e.out_dtype = out_dtype; e.ldc = ldc;
+    e.out_mode = out_mode; e.q = q; e.k = k; e.v = v; e.heads = heads; e.head_dim = head_dim; e.tokens = tokens;
+    e.row_scale = row_scale; e.col_scale = col_scale; e.direct_epi = direct_epi;
+    const int tiles = ((M + 255) / 256) * (N / 256);
+    if (fp8) { launch_grid(tiles, 1, [=] { gemm256_kernel<1, true>(A, lda, W, ldw, M, N, K, e); }, 512); return; }
+    switch (staging) {
+        case 0: launch_grid(tiles, 1, [=] { gemm256_kernel<0>(A, lda, W, ldw, M, N, K, e); }, 512); break;
+        case 1: launch_grid(tiles, 1, [=] { gemm256_kernel<1>(A, lda, W, ldw, M, N, K, e); }, 512); break;
+        case 2: launch_grid(tiles, 1, [=] { gemm256_kernel<2>(A, lda, W, ldw, M, N, K, e); }, 512); break;
+        default: launch_grid(tiles, 1, [=] { gemm256_kernel<3>(A, lda, W, ldw, M, N, K, e); }, 512); break;
+    }
+}
 """
 
 
@@ -40,13 +58,22 @@ def emu(tmp_path_factory):
     gelu = common[a:common.index("// round-to-nearest-even fp32 -> packed fp16", a)]
     text = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "gemm.hip")).read()
     start = text.index("constexpr int BM = 128, BN = 128, BK = 64;")
-    end = text.index("// Grouped launch: up to MSAM_GEMM_GROUP_MAX independent small products in ONE launch")
+    end = text.index("// Two-workgroups-per-CU variant of the large-shape kernel")
+    end = text.rindex("// ----", start, end)
     header = '#include "%s"\n' % os.path.join(ROOT, "include", "msam_hip.h")
-    body = header + gelu + text[start:end]
-    assert "gemm_body" in body and "gemm_kernel" in body
+    body = text[start:end]
+    # clang-only pieces of the 256 x 256 kernel: its MFMA helpers (the shim's emulation has the same names and layouts) and the
+    # dynamic-LDS declaration (a static 160 KB array here)
+    a = body.index("typedef float f32x16_t __attribute__((ext_vector_type(16)));")
+    b = body.index("// Epilogue straight from the accumulators of the 128 x 64 wave tile")
+    body = body[:a] + body[b:]
+    body = body.replace("extern __shared__ __attribute__((aligned(16))) uint4 dyn[];", "static uint4 dyn[10240];")
+    body = header + gelu + body
+    assert "gemm_body" in body and "gemm_kernel" in body and "gemm256_kernel" in body and "extern __shared__" not in body
     lib = build(str(tmp_path_factory.mktemp("emu_gemm")), "gemm", body, ENTRY)
     vp, i, l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
     lib.emu_gemm.argtypes = [i, vp, l, vp, l, i, i, i, vp, vp, i, i, l, vp, i, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, i]
+    lib.emu_gemm256.argtypes = [i, i, i, vp, l, vp, l, i, i, i, vp, vp, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, vp, vp]
     return lib
 
 
@@ -144,3 +171,54 @@ def test_gemm_kernel_qkv_split_and_split_k_on_the_cpu(emu):
     emu.emu_gemm(0, _ptr(A), K, _ptr(W), K, M, N, K, None, None, 0, 0, 0, None, 0, 0, 0, 0, _ptr(out), MSAM_F32, N, 0, None, None, None, 0, 0, 0, 4)
     ref = a.double() @ w.double().t()
     assert np.abs(out - ref.numpy()).max() <= 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("staging", [3, 0, 1, 2])
+def test_gemm256_kernel_source_on_the_cpu(emu, staging):
+    """The encoder's 256 x 256 tile kernel (8 waves, 32x32x16 MFMA, transposed product): every operand staging form incl. the
+    ping-pong schedule of its two wave groups (staging 3: the groups run one barrier slot apart) on a ragged M, with the LDS-transposed
+    epilogue and (staging 3) the epilogue straight from the accumulators: bias + GELU -> bf16, fp32 residual in place."""
+    g = torch.Generator().manual_seed(40 + staging)
+    M, N, K = 300, 256, 192                                                       # two row tiles (second ragged), 3 k-tiles of 64
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    A, W, B = _bits(a), _bits(w), bias.numpy().astype(np.float32).copy()
+    ref = a.double() @ w.double().t() + bias.double()
+    for direct in ((0, 1) if staging == 3 else (0,)):
+        out16 = np.zeros((M, N), np.uint16)
+        emu.emu_gemm256(staging, 0, direct, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), None, 0, 0, ACT_GELU, _ptr(out16), MSAM_BF16, N, 0,
+                        None, None, None, 0, 0, 0, None, None)
+        want = F.gelu(ref)
+        assert (_from_bits(out16) - want).abs().max().item() <= 1.2e-2 * want.abs().max().item(), direct
+        x = torch.randn(M, N, generator=g)
+        X = x.numpy().astype(np.float32).copy()
+        emu.emu_gemm256(staging, 0, direct, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), _ptr(X), MSAM_F32, N, 0, _ptr(X), MSAM_F32, N, 0,
+                        None, None, None, 0, 0, 0, None, None)
+        assert np.abs(X - (ref + x.double()).numpy()).max() <= 2e-5 * ref.abs().max().item(), direct
+
+
+def test_gemm256_kernel_qkv_split_and_fp8_on_the_cpu(emu):
+    g = torch.Generator().manual_seed(50)
+    Bn, tokens, heads, hd, K = 1, 256, 4, 64, 128
+    M, N = Bn * tokens, 3 * heads * hd                                            # 256 x 768: three column tiles
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    A, W, B = _bits(a), _bits(w), bias.numpy().astype(np.float32).copy()
+    q, k, v = (np.zeros((Bn, heads, tokens, hd), np.uint16) for _ in range(3))
+    emu.emu_gemm256(3, 0, 0, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), None, 0, 0, 0, None, MSAM_BF16, N, 1, _ptr(q), _ptr(k), _ptr(v),
+                    heads, hd, tokens, None, None)
+    ref = (a.double() @ w.double().t() + bias.double()).reshape(Bn, tokens, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    for got, want in zip((q, k, v), ref):
+        assert (_from_bits(got) - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+    # fp8 e4m3 operands (k-tiles of 128 bytes), per-row / per-column scales applied in the epilogue
+    M, N, K = 256, 256, 256
+    a8 = (torch.randn(M, K, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    w8 = (torch.randn(N, K, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    rs, cs = torch.rand(M, generator=g) + 0.5, torch.rand(N, generator=g) + 0.5
+    A8, W8 = a8.view(torch.uint8).numpy().copy(), w8.view(torch.uint8).numpy().copy()
+    RS, CS = rs.numpy().astype(np.float32).copy(), cs.numpy().astype(np.float32).copy()
+    out = np.full((M, N), np.nan, np.float32)
+    emu.emu_gemm256(1, 1, 0, _ptr(A8), K, _ptr(W8), K, M, N, K, None, None, 0, 0, 0, _ptr(out), MSAM_F32, N, 0, None, None, None, 0, 0, 0,
+                    _ptr(RS), _ptr(CS))
+    want = (a8.double() @ w8.double().t()) * rs.double()[:, None] * cs.double()[None, :]
+    assert np.abs(out - want.numpy()).max() <= 2e-5 * want.abs().max().item()
