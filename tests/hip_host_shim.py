@@ -215,6 +215,8 @@ static inline f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& 
 }
 template <bool F16 = false> static inline f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) { return mfma32_emu(a, b, c, F16); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
+static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}

@@ -30,6 +30,15 @@ extern "C" void emu_gemm(int glds, const u16* A, long lda, const u16* W, long ld
     if (glds) launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<true, false>(A, lda, W, ldw, M, N, K, e); });
     else launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<false, false>(A, lda, W, ldw, M, N, K, e); });
 }
+// the two-workgroups-per-CU kernel (staging 4): persistent grid of `grid` workgroups over the 256 x 128 tiles
+extern "C" void emu_gemm2w(int grid, const u16* A, long lda, const u16* W, long ldw, int M, int N, int K, const float* bias,
+                           const void* resid, int resid_dtype, long ldr, int act, void* out, int out_dtype, long ldc, int out_mode, u16* q,
+                           u16* k, u16* v, int heads, int head_dim, int tokens) {
+    Epi e{};
+    e.bias = bias; e.resid = resid; e.resid_dtype = resid_dtype; e.ldr = ldr; e.act = act; e.out = out; e.out_dtype = out_dtype; e.ldc = ldc;
+    e.out_mode = out_mode; e.q = q; e.k = k; e.v = v; e.heads = heads; e.head_dim = head_dim; e.tokens = tokens;
+    launch_grid(grid, 1, [=] { gemm2w_kernel<false>(A, lda, W, ldw, M, N, K, e); });
+}
 // the 256 x 256 tile kernel: staging 0..3 (bf16), fp8 = staging 1 with e4m3 operands and row / column scales
 extern "C" void emu_gemm256(int staging, int fp8, int direct_epi, const u16* A, long lda, const u16* W, long ldw, int M, int N, int K,
                             const float* bias, const void* resid, int resid_dtype, long ldr, int act, void* out, int out_dtype, long ldc,
@@ -68,11 +77,40 @@ def emu(tmp_path_factory):
     b = body.index("// Epilogue straight from the accumulators of the 128 x 64 wave tile")
     body = body[:a] + body[b:]
     body = body.replace("extern __shared__ __attribute__((aligned(16))) uint4 dyn[];", "static uint4 dyn[10240];")
-    body = header + gelu + body
+    # the two-workgroups-per-CU kernel: its LDS-DMA instruction is inline assembly and its LDS addresses are address-space casts -
+    # here the descriptor is (base, bytes), the DMA an immediate copy into the static LDS image at the same byte offsets, the counted
+    # waits nothing (the copy has landed); what runs is the kernel's own ring protocol, swizzle, fragment reads and epilogue
+    a2 = text.index("constexpr int GW_BM = 256, GW_BN = 128, GW_BK = 32;")
+    b2 = text.index("// Row-complete variant for N == 256 with a fused LayerNorm epilogue", a2)
+    b2 = text.rindex("// ----", a2, b2)
+    gw = text[a2:b2]
+    c = gw.index("typedef unsigned int u32x4_t_gw")
+    d = gw.index("template <bool F16>", c)
+    gw = gw[:c] + """struct u32x4_t_gw { const char* base; long bytes; };
+static uint4 dyn[10240];
+static inline void gw_dma16(const u32x4_t_gw& r, int voff, int soff, unsigned lds_addr) {
+    uint4 v{0, 0, 0, 0};
+    const long o = (long)voff + soff;
+    if (o >= 0 && o + 16 <= r.bytes) std::memcpy(&v, r.base + o, 16);
+    std::memcpy((char*)dyn + lds_addr + (threadIdx.x & 63) * 16, &v, 16);
+}
+static inline u32x4_t_gw gw_rsrc(const void* base, long bytes) { return u32x4_t_gw{(const char*)base, bytes}; }
+""" + gw[d:]
+    gw = gw.replace("extern __shared__ __attribute__((aligned(16))) uint4 dyn[];", "")
+    gw = gw.replace("const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dyn;", "const unsigned lds0 = 0;")
+    gw = gw.replace('asm volatile("s_waitcnt vmcnt(6)" ::: "memory")', "(void)0").replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "(void)0")
+    assert "asm volatile" not in gw and "address_space" not in gw
+    body = body.replace("static uint4 dyn[10240];", "")            # one LDS image for both kernels (declared in front of gemm2w)
+    body = header + gelu + body.replace("uint4 dyn_placeholder;", "")
+    # gemm256_kernel refers to dyn before gemm2w's declaration: declare it first
+    body = body.replace(header, header + "static uint4 dyn[10240];\n", 1)
+    gw = gw.replace("static uint4 dyn[10240];\n", "")
+    body = body + gw
     assert "gemm_body" in body and "gemm_kernel" in body and "gemm256_kernel" in body and "extern __shared__" not in body
     lib = build(str(tmp_path_factory.mktemp("emu_gemm")), "gemm", body, ENTRY)
     vp, i, l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
     lib.emu_gemm.argtypes = [i, vp, l, vp, l, i, i, i, vp, vp, i, i, l, vp, i, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, i]
+    lib.emu_gemm2w.argtypes = [i, vp, l, vp, l, i, i, i, vp, vp, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i]
     lib.emu_gemm256.argtypes = [i, i, i, vp, l, vp, l, i, i, i, vp, vp, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, vp, vp]
     return lib
 
@@ -222,3 +260,24 @@ def test_gemm256_kernel_qkv_split_and_fp8_on_the_cpu(emu):
                     _ptr(RS), _ptr(CS))
     want = (a8.double() @ w8.double().t()) * rs.double()[:, None] * cs.double()[None, :]
     assert np.abs(out - want.numpy()).max() <= 2e-5 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("K", [64, 96, 320])
+def test_gemm2w_kernel_source_on_the_cpu(emu, K):
+    """The two-workgroups-per-CU kernel (256 x 128 tiles, LDS-DMA ring of three stages, persistent over tiles): 2 / 3 / 10 k-tiles of 32
+    (prologue only, one ring wrap, several), a ragged M, fewer workgroups than tiles (each walks several tiles: the ring is re-used
+    across tiles), epilogue from the accumulators with bias + GELU -> bf16 and with the fp32 residual in place."""
+    g = torch.Generator().manual_seed(60 + K)
+    M, N = 700, 256                                                                # 3 x 2 tiles, last row tile ragged
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
+    bias = torch.randn(N, generator=g)
+    A, W, B = _bits(a), _bits(w), bias.numpy().astype(np.float32).copy()
+    ref = a.double() @ w.double().t() + bias.double()
+    out16 = np.zeros((M, N), np.uint16)
+    emu.emu_gemm2w(4, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), None, 0, 0, ACT_GELU, _ptr(out16), MSAM_BF16, N, 0, None, None, None, 0, 0, 0)
+    want = F.gelu(ref)
+    assert (_from_bits(out16) - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
+    x = torch.randn(M, N, generator=g)
+    X = x.numpy().astype(np.float32).copy()
+    emu.emu_gemm2w(6, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), _ptr(X), MSAM_F32, N, 0, _ptr(X), MSAM_F32, N, 0, None, None, None, 0, 0, 0)
+    assert np.abs(X - (ref + x.double()).numpy()).max() <= 2e-5 * ref.abs().max().item()
