@@ -30,6 +30,13 @@ extern "C" void emu_gemm(int glds, const u16* A, long lda, const u16* W, long ld
     if (glds) launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<true, false>(A, lda, W, ldw, M, N, K, e); });
     else launch_grid(tiles, split_k > 1 ? split_k : 1, [=] { gemm_kernel<false, false>(A, lda, W, ldw, M, N, K, e); });
 }
+extern "C" void emu_gemm_ln(const u16* A, long lda, const u16* W, long ldw, int M, int K, const float* bias, void* out, int out_dtype,
+                            const float* ln_w, const float* ln_b, float eps, int mode, const float* add, u16* out_a, u16* out_b) {
+    Epi e{};
+    e.bias = bias; e.out = out; e.out_dtype = out_dtype; e.ldc = 256;
+    EpiLN ln{ln_w, ln_b, eps, mode, add, out_a, out_b, MSAM_BF16};
+    launch_grid((M + 63) / 64, 1, [=] { gemm_ln_kernel<false>(A, lda, W, ldw, M, K, e, ln); });
+}
 // the two-workgroups-per-CU kernel (staging 4): persistent grid of `grid` workgroups over the 256 x 128 tiles
 extern "C" void emu_gemm2w(int grid, const u16* A, long lda, const u16* W, long ldw, int M, int N, int K, const float* bias,
                            const void* resid, int resid_dtype, long ldr, int act, void* out, int out_dtype, long ldc, int out_mode, u16* q,
@@ -63,8 +70,11 @@ extern "C" void emu_gemm256(int staging, int fp8, int direct_epi, const u16* A, 
 @pytest.fixture(scope="module")
 def emu(tmp_path_factory):
     common = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "common.h")).read()
+    a0 = common.index("MSAM_DEVINL float gelu_erf(float x)")
     a = common.index("MSAM_DEVINL float relu1(float x)")
-    gelu = common[a:common.index("// round-to-nearest-even fp32 -> packed fp16", a)]
+    gelu = common[a0:common.index("// two values at once", a0)] + common[a:common.index("// round-to-nearest-even fp32 -> packed fp16", a)]
+    w0 = common.index("MSAM_DEVINL float wave_sum_xor16(float v)")
+    gelu += common[w0:common.index("MSAM_DEVINL float wave_max64(float v)", w0)]
     text = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "gemm.hip")).read()
     start = text.index("constexpr int BM = 128, BN = 128, BK = 64;")
     end = text.index("// Two-workgroups-per-CU variant of the large-shape kernel")
@@ -105,11 +115,16 @@ static inline u32x4_t_gw gw_rsrc(const void* base, long bytes) { return u32x4_t_
     # gemm256_kernel refers to dyn before gemm2w's declaration: declare it first
     body = body.replace(header, header + "static uint4 dyn[10240];\n", 1)
     gw = gw.replace("static uint4 dyn[10240];\n", "")
-    body = body + gw
+    # the row-complete 64 x 256 kernel with the fused LayerNorm epilogues (decoder token side / up-scaling stage 1)
+    a3 = text.index("struct EpiLN {")
+    b3 = text.index("thread_local char g_err[512]", a3)
+    ln = text[a3:b3].replace("extern __shared__ __attribute__((aligned(16))) uint4 dyn_lds[];", "uint4* dyn_lds = dyn;")
+    body = body + gw + ln
     assert "gemm_body" in body and "gemm_kernel" in body and "gemm256_kernel" in body and "extern __shared__" not in body
     lib = build(str(tmp_path_factory.mktemp("emu_gemm")), "gemm", body, ENTRY)
     vp, i, l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
     lib.emu_gemm.argtypes = [i, vp, l, vp, l, i, i, i, vp, vp, i, i, l, vp, i, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, i]
+    lib.emu_gemm_ln.argtypes = [vp, l, vp, l, i, i, vp, vp, i, vp, vp, ctypes.c_float, i, vp, vp, vp]
     lib.emu_gemm2w.argtypes = [i, vp, l, vp, l, i, i, i, vp, vp, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i]
     lib.emu_gemm256.argtypes = [i, i, i, vp, l, vp, l, i, i, i, vp, vp, i, l, i, vp, i, l, i, vp, vp, vp, i, i, i, vp, vp]
     return lib
@@ -281,3 +296,31 @@ def test_gemm2w_kernel_source_on_the_cpu(emu, K):
     X = x.numpy().astype(np.float32).copy()
     emu.emu_gemm2w(6, _ptr(A), K, _ptr(W), K, M, N, K, _ptr(B), _ptr(X), MSAM_F32, N, 0, _ptr(X), MSAM_F32, N, 0, None, None, None, 0, 0, 0)
     assert np.abs(X - (ref + x.double()).numpy()).max() <= 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gemm_ln_kernel_source_on_the_cpu(emu, mode):
+    """Row-complete product (N = 256) with the LayerNorm in the epilogue: mode 1 = LayerNorm over the row (+ the 16-bit operand copies
+    out_a = round16(v + add), out_b = round16(v) for the next products), mode 2 = LayerNorm over each 64-column group + GELU."""
+    g = torch.Generator().manual_seed(70 + mode)
+    M, K = 150, 128                                                               # ragged last 64-row tile
+    a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(256, K, generator=g) / K ** 0.5)
+    bias = torch.randn(256, generator=g)
+    n = 256 if mode == 1 else 64
+    lw, lb = torch.randn(n, generator=g) * 0.3 + 1, torch.randn(n, generator=g) * 0.3
+    add = torch.randn(M, 256, generator=g)
+    A, W, B = _bits(a), _bits(w), bias.numpy().astype(np.float32).copy()
+    LW, LB, ADD = (t.numpy().astype(np.float32).copy() for t in (lw, lb, add))
+    out = np.full((M, 256), np.nan, np.float32)
+    oa, ob = np.zeros((M, 256), np.uint16), np.zeros((M, 256), np.uint16)
+    emu.emu_gemm_ln(_ptr(A), K, _ptr(W), K, M, K, _ptr(B), _ptr(out), MSAM_F32, _ptr(LW), _ptr(LB), 1e-5, mode,
+                    _ptr(ADD) if mode == 1 else None, _ptr(oa) if mode == 1 else None, _ptr(ob) if mode == 1 else None)
+    y = a.double() @ w.double().t() + bias.double()
+    if mode == 1:
+        want = F.layer_norm(y, (256,), lw.double(), lb.double(), 1e-5)
+    else:
+        want = F.gelu(F.layer_norm(y.reshape(M, 4, 64), (64,), lw.double(), lb.double(), 1e-5)).reshape(M, 256)
+    assert np.isfinite(out).all() and np.abs(out - want.numpy()).max() <= 2e-4 * want.abs().max().item()
+    if mode == 1:
+        assert (_from_bits(ob) - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+        assert (_from_bits(oa) - (want + add.double())).abs().max().item() <= 1e-2 * (want + add.double()).abs().max().item()
