@@ -112,6 +112,7 @@ static inline unsigned long long __ballot(int pred) {
 }
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
 static inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
+static inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 // ds_read_b64_tr_b16 as the kernels use it: inside every group of 16 lanes, lane r receives element (r % 4) of the four 16-bit values
 // read by lanes 4 j + r / 4 (j = 0..3) - a 16 x 4 <-> 4 x 16 transpose of the block the group addressed
 static uint2 wave_tr[8][64];

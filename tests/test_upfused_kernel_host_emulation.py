@@ -1,0 +1,116 @@
+"""up_fused_kernel (csrc/upfused.hip: the mask decoder's output up-scaling ConvT 2x2 - LayerNorm2d - GELU - ConvT 2x2 - GELU and the
+hyper-network product in one pass, all stages in transposed form so that one stage's accumulators are the next MFMA's operand; the
+largest kernel of the benchmarked path) executed on the CPU behind tests/hip_host_shim.py, in its packed-fp16-GELU and packed-fp32-GELU
+instantiations, row-major and blocked stream layout, against torch's conv_transpose2d formulation on the same fp16 operands (the
+comparison of tests/test_gpu_kernels.py::test_upscale_fused)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_host_shim import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the fp16 decoder build (common.h MSAM_DEC_F16 = 1): the decoder's 16-bit type is IEEE fp16
+DEC = r"""
+constexpr int T = 4096, C = 256, TK = 16, NTHR = 256;
+static inline f32x4_t mfma16d(const uint4& a, const uint4& b, f32x4_t c) { return mfma16h(a, b, c); }
+static inline uint32_t pack2d(float lo, float hi) { return pack2h(lo, hi); }
+static inline u16 f2d(float f) { return f2h(f); }
+static inline float d2f(u16 h) { return h16_to_f(h); }
+// gelu_pk_h: the GELU of two values in PACKED fp16 arithmetic (v_pk_fma_f16 / v_exp_f16 on the device) - here every operation in fp32
+// followed by a rounding to fp16, fused multiply-adds rounded once
+static inline float rh(float x) { return h16_to_f(f2h(x)); }
+template <int EXPM> static inline uint32_t gelu_pk_h(float x0, float x1) {
+    float g[2];
+    const float xs[2] = {x0, x1};
+    for (int i = 0; i < 2; ++i) {
+        const float x = rh(xs[i]);
+        const float r = x > 0.f ? x : 0.f;
+        const float t = rh(std::fmaf(r, 2.f, -x));
+        float q = rh(std::fmaf(t, rh(-0.0248758f), rh(-0.49884797f)));
+        q = rh(std::fmaf(q, t, rh(-1.12922424f)));
+        q = rh(std::fmaf(q, t, rh(-1.00353579f)));
+        const float e = rh(std::exp2(q));
+        g[i] = rh(std::fmaf(-t, e, r));
+    }
+    return pack2h(g[0], g[1]);
+}
+"""
+
+ENTRY = r"""
+extern "C" void emu_up_fused(int g16, const u16* keys, int blocked, int P, const u16* w1, const float* b1, const float* lnw, const float* lnb,
+                             float eps, const u16* w2, const float* b2, const float* hyper, int hyper_ld, int mask0, int nmask, float* out) {
+    UpArgs a{};
+    a.keys = keys; a.w1 = w1; a.b1 = b1; a.lnw = lnw; a.lnb = lnb; a.eps = eps; a.w2 = w2; a.b2 = b2; a.hyper = hyper; a.hyper_ld = hyper_ld;
+    a.mask0 = mask0; a.nmask = nmask; a.KS = 2; a.nitems = P * 2; a.out = out; a.blocked = blocked;
+    if (g16) launch_grid(3, 1, [=] { up_fused_kernel<1, 1>(a); });          // 3 workgroups over 2 P items: uneven shares
+    else launch_grid(3, 1, [=] { up_fused_kernel<1, 0>(a); });
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    common = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "common.h")).read()
+    a = common.index("MSAM_DEVINL float relu1(float x)")
+    gelu = common[a:common.index("// round-to-nearest-even fp32 -> packed fp16", a)]
+    text = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "upfused.hip")).read()
+    s0 = text.index("constexpr int SUB_BYTES = TK * 64 + 64")
+    s1 = text.index("// erf-GELU of two values in PACKED fp16 arithmetic")
+    k0 = text.index("template <int UF_PRIO, int G16>")
+    k1 = text.index("}  // namespace", k0)
+    body = DEC + gelu + text[s0:s1] + text[k0:k1]
+    assert "up_fused_kernel" in body and "_Float16" not in body
+    lib = build(str(tmp_path_factory.mktemp("emu_up")), "up", body, ENTRY)
+    vp, i = ctypes.c_void_p, ctypes.c_int
+    lib.emu_up_fused.argtypes = [i, vp, i, i, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, i, i, i, vp]
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _h(t):
+    return t.to(torch.float16)
+
+
+def _bits(t):
+    return _h(t).contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+@pytest.mark.parametrize("g16,blocked", [(1, 0), (0, 0), (1, 1)])
+def test_up_fused_kernel_source_on_the_cpu(emu, g16, blocked):
+    g = torch.Generator().manual_seed(5 + g16 + 2 * blocked)
+    P, mask0, nmask = 1, 1, 3                         # two half-prompt items over three workgroups: one of them has nothing to do
+    keys = _h(torch.randn(P, 4096, 256, generator=g))
+    ct1 = _h(torch.randn(256, 64, 2, 2, generator=g) / 16); cb1 = torch.randn(64, generator=g)
+    lw, lb = torch.randn(64, generator=g) * 0.2 + 1, torch.randn(64, generator=g) * 0.3
+    ct2 = _h(torch.randn(64, 32, 2, 2, generator=g) / 8); cb2 = torch.randn(32, generator=g)
+    hyper = torch.randn(P, 4, 128, generator=g)
+    w1 = ct1.permute(2, 3, 1, 0).reshape(256, 256).contiguous()
+    w2 = ct2.permute(2, 3, 1, 0).reshape(128, 64).contiguous()
+    stream = keys
+    if blocked:            # [16-token tile][k-step of 32 channels][lane = 16 (lane >> 4) + token][8]: decfold_tok.hip's stream layout
+        stream = keys.reshape(P, 256, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+    out = np.full((P, nmask, 256, 256), np.nan, np.float32)
+    arrs = [_bits(stream), _bits(w1), cb1.repeat(4).numpy().astype(np.float32).copy(), lw.numpy().astype(np.float32).copy(),
+            lb.numpy().astype(np.float32).copy(), _bits(w2), cb2.numpy().astype(np.float32).copy(), hyper.numpy().astype(np.float32).copy()]
+    emu.emu_up_fused(g16, _ptr(arrs[0]), blocked, P, _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]), 1e-6, _ptr(arrs[5]),
+                     _ptr(arrs[6]), _ptr(arrs[7]), 128, mask0, nmask, _ptr(out))
+    src = keys.float().transpose(1, 2).reshape(P, 256, 64, 64)
+    up = F.conv_transpose2d(src, ct1.float(), cb1, stride=2)
+    mu = up.mean(1, keepdim=True); var = ((up - mu) ** 2).mean(1, keepdim=True)
+    up = (up - mu) / torch.sqrt(var + 1e-6) * lw.view(1, -1, 1, 1) + lb.view(1, -1, 1, 1)
+    up = _h(F.gelu(up)).float()
+    up = F.gelu(F.conv_transpose2d(up, ct2.float(), cb2, stride=2))
+    ref = torch.einsum("nmc,nchw->nmhw", hyper[:, mask0:mask0 + nmask, :32], up)
+    assert np.isfinite(out).all()
+    scale = ref.abs().max().item()
+    err = np.abs(out - ref.numpy())
+    assert err.max() <= 6e-3 * scale and err.mean() <= 3e-4 * scale, (err.max() / scale, err.mean() / scale)
