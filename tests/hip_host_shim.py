@@ -184,6 +184,12 @@ static inline uint4 buf_load16(rsrc_t r, int voff, int soff) {
     if (o >= 0 && o + 16 <= (long)r.bytes) std::memcpy(&v, r.base + o, 16);
     return v;
 }
+static inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t r, void* lds, int size, int voff, int soff, int imm, int) {
+    char v[16] = {0};
+    const long o = (long)voff + soff + imm;
+    if (o >= 0 && o + size <= (long)r.bytes) std::memcpy(v, r.base + o, size);
+    std::memcpy((char*)lds + (threadIdx.x & 63) * size, v, size);
+}
 static inline void buf_store16(const uint4& v, rsrc_t r, int voff, int soff) {
     const long o = (long)voff + soff;
     if (o >= 0 && o + 16 <= (long)r.bytes) std::memcpy(r.base + o, &v, 16);
@@ -215,6 +221,58 @@ static inline f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& 
     return d;
 }
 template <bool F16 = false> static inline f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) { return mfma32_emu(a, b, c, F16); }
+static inline unsigned long long __builtin_readcyclecounter() { return 0; }
+static inline uint8_t f_to_e4m3(float f) {                  // OCP e4m3 (fn): round to nearest even, saturating (v_cvt_pk_fp8_f32)
+    uint32_t u; std::memcpy(&u, &f, 4);
+    const uint8_t sign = (u >> 24) & 0x80;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return sign | 0x7f;
+    float a = std::fabs(f);
+    if (a >= 448.f) return sign | 0x7e;
+    if (a < std::ldexp(1.f, -10)) return sign;                // below half of the smallest subnormal (2^-9)
+    int e; std::frexp(a, &e);                                 // a = m 2^e, m in [0.5, 1)
+    int ex = e - 1;                                           // a = 1.xxx 2^ex
+    if (ex < -6) ex = -6;                                     // subnormal range: fixed exponent
+    const float q = std::ldexp(a, 3 - ex);                    // units of 2^(ex - 3): integer part = mantissa incl. the hidden bit
+    float r = std::nearbyint(q);                              // current rounding mode: to nearest even
+    int m = (int)r;
+    int be = ex + 7;
+    if (ex == -6 && m < 8) be = 0;                            // subnormal
+    else { if (m == 16) { m = 8; ++be; } m -= 8; if (ex == -6 && be == 0) be = 1; }
+    if (be > 15 || (be == 15 && m > 6)) return sign | 0x7e;
+    return sign | (uint8_t)(be << 3) | (uint8_t)m;
+}
+static inline int __builtin_amdgcn_cvt_pk_fp8_f32(float a, float b, int old, bool hi) {
+    const uint32_t pk = (uint32_t)f_to_e4m3(a) | ((uint32_t)f_to_e4m3(b) << 8);
+    const uint32_t o = (uint32_t)old;
+    return (int)(hi ? ((o & 0x0000ffffu) | (pk << 16)) : ((o & 0xffff0000u) | pk));
+}
+static inline int __lane_id() { return threadIdx.x & 63; }
+static inline long long wave_read(long long v, int src_lane) {          // value of `v` in lane src_lane of this wave
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    wave_buf[w][l] = v;
+    wave_bar[w]->arrive_and_wait();
+    const long long r = wave_buf[w][src_lane & 63];
+    wave_bar[w]->arrive_and_wait();
+    return r;
+}
+static inline int __shfl(int v, int src) { return (int)wave_read(v, src); }
+static inline float __shfl(float v, int src) { return __uint_as_float((uint32_t)wave_read(__float_as_uint(v), src)); }
+static inline int __shfl_up(int v, int d) { const int l = threadIdx.x & 63; const int r = (int)wave_read(v, l >= d ? l - d : l); return r; }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)wave_read(v, lane); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __fdiv_rn(float a, float b) { return a / b; }
+static inline float __fadd_rn(float a, float b) { return a + b; }
+static inline float __fsub_rn(float a, float b) { return a - b; }
+static inline float __fmul_rn(float a, float b) { return a * b; }
+static inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (s & 31)); }
+static inline uint32_t __brev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; ++i) r |= ((x >> i) & 1u) << (31 - i); return r; }
+static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffs(uint32_t x) { return __builtin_ffs((int)x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
+static inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
 static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
@@ -222,8 +280,22 @@ static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_barrier();
-static inline void atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
-static inline void atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); *p += v; }
+static inline float atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_mutex); const float o = *p; *p += v; return o; }
+static inline int atomicAdd(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; *p += v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { std::lock_guard<std::mutex> g(atomic_mutex); const unsigned o = *p; *p += v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { std::lock_guard<std::mutex> g(atomic_mutex); const auto o = *p; *p += v; return o; }
+static inline int atomicMin(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; *p = std::min(o, v); return o; }
+static inline int atomicMax(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; *p = std::max(o, v); return o; }
+static inline unsigned atomicMin(unsigned* p, unsigned v) { std::lock_guard<std::mutex> g(atomic_mutex); const unsigned o = *p; *p = std::min(o, v); return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { std::lock_guard<std::mutex> g(atomic_mutex); const unsigned o = *p; *p = std::max(o, v); return o; }
+static inline int atomicOr(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; *p |= v; return o; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { std::lock_guard<std::mutex> g(atomic_mutex); const unsigned o = *p; *p |= v; return o; }
+static inline int atomicCAS(int* p, int cmp, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; if (o == cmp) *p = v; return o; }
+static inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long cmp, unsigned long long v) {
+    std::lock_guard<std::mutex> g(atomic_mutex); const auto o = *p; if (o == cmp) *p = v; return o;
+}
+static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { std::lock_guard<std::mutex> g(atomic_mutex); const auto o = *p; *p |= v; return o; }
+static inline int atomicExch(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; *p = v; return o; }
 #define __expf expf
 #define __logf logf
 #define __syncthreads() block_bar->arrive_and_wait()
@@ -237,16 +309,23 @@ static inline void __builtin_amdgcn_s_barrier() { block_bar->arrive_and_wait(); 
 #define __shared__ static
 // one workgroup of 256 threads after the other: f() is the kernel call
 template <class F> static void launch_grid(int gx, int gy, F f, int threads = 256) {
+    // the workgroups run one after the other on ONE set of host threads (created per launch, not per workgroup)
     gridDim = {gx, gy, 1};
-    for (int by = 0; by < gy; ++by) for (int bx = 0; bx < gx; ++bx) {
-        std::barrier<> b0(64), b1(64), b2(64), b3(64), b4(64), b5(64), b6(64), b7(64), bb(threads);
-        std::barrier<>* wb[8] = {&b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7};
-        for (int i = 0; i < 8; ++i) wave_bar[i] = wb[i];
-        block_bar = &bb;
-        std::vector<std::thread> ts;
-        for (int tx = 0; tx < threads; ++tx) ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0}; f(); });
-        for (auto& t : ts) t.join();
-    }
+    std::barrier<> b0(64), b1(64), b2(64), b3(64), b4(64), b5(64), b6(64), b7(64), bb(threads), next(threads);
+    std::barrier<>* wb[8] = {&b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7};
+    for (int i = 0; i < 8; ++i) wave_bar[i] = wb[i];
+    block_bar = &bb;
+    std::vector<std::thread> ts;
+    for (int tx = 0; tx < threads; ++tx)
+        ts.emplace_back([=, &next] {
+            for (int by = 0; by < gy; ++by)
+                for (int bx = 0; bx < gx; ++bx) {
+                    threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0};
+                    f();
+                    next.arrive_and_wait();                   // LDS (static arrays) is free for the next workgroup
+                }
+        });
+    for (auto& t : ts) t.join();
 }
 // (kernels whose workgroups leave early - "if (bid >= tiles) return" before any barrier - are launched with exactly their tiles)
 """
@@ -260,4 +339,202 @@ def build(tmpdir, name: str, kernel_source: str, entry_points: str, opt: str = "
         fh.write(PRELUDE + "\n" + kernel_source + "\n" + entry_points)
     subprocess.check_call(["g++", "-std=c++20", opt, "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-Wno-unknown-pragmas",
                            "-Wno-attributes", "-Wno-psabi", cpp, "-o", so])
+    return ctypes.CDLL(so)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Whole-file builds: a complete csrc/*.hip file - kernels AND its extern "C" entry points - compiled for the host.  The file's
+# `#include "common.h"` finds a generated header (the prelude above + the decoder-type helpers + the portable tail of the real common.h
+# + a minimal HIP runtime whose hipLaunchKernelGGL runs the workgroups one after the other on host threads), so what is exercised is
+# the library's C ABI itself: argument checks, derived launch parameters, kernel, epilogue.
+# ------------------------------------------------------------------------------------------------------------------------------
+
+RUNTIME = r"""
+// ---- the decoder's 16-bit type (common.h MSAM_DEC_F16 = 1: IEEE fp16)
+#define MSAM_DEC_F16 1
+static inline f32x4_t mfma16d(const uint4& a, const uint4& b, f32x4_t c) { return mfma16h(a, b, c); }
+static inline uint32_t pack2d(float lo, float hi) { return pack2h(lo, hi); }
+static inline u16 f2d(float f) { return f2h(f); }
+static inline float d2f(u16 h) { return h16_to_f(h); }
+#define MSAM_D16_ONE 0x3C00u
+#define MSAM_D16 4
+// ---- minimal HIP runtime: one stream, launches run to completion before they return
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+enum { hipDeviceAttributeMultiprocessorCount = 0, hipFuncAttributeMaxDynamicSharedMemorySize = 0, hipMemcpyDeviceToDevice = 0,
+       hipMemcpyDeviceToHost = 1 };
+static inline int emu_cus() { const char* v = std::getenv("MSAM_EMU_CUS"); return v ? std::atoi(v) : 2; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "host emulation"; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = emu_cus(); return hipSuccess; }
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, int, hipStream_t) { std::memmove(d, s_, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 2; return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+static inline hipError_t hipMemcpyFromSymbol(void* d, const void* sym, size_t n) { std::memcpy(d, sym, n); return hipSuccess; }
+#define hipLaunchKernelGGL(kern_, grid_, block_, shmem_, stream_, ...)                                 \
+    do {                                                                                               \
+        const dim3 g__ = (grid_), b__ = (block_);                                                      \
+        launch_grid((int)g__.x, (int)g__.y, [=] { kern_(__VA_ARGS__); }, (int)b__.x);                  \
+    } while (0)
+"""
+
+
+def host_common_h(root: str) -> str:
+    """The header a host-compiled csrc file includes instead of csrc/common.h."""
+    common = open(os.path.join(root, "micro_sam_amd", "csrc", "common.h")).read()
+    g0 = common.index("MSAM_DEVINL float gelu_erf(float x)")
+    g1 = common.index("// round-to-nearest-even fp32 -> packed fp16")
+    t0 = common.index("MSAM_DEVINL float wave_sum_xor16(float v)")
+    tail = common[t0:]
+    tail = tail[: tail.rindex("#endif")] if tail.rstrip().endswith("#endif") else tail
+    return ("#pragma once\n#include <cstdlib>\n" + PRELUDE.replace("static inline int swz(int row)", "static inline int swz_unused(int row)") +
+            "static inline int swz(int row) { return ((row >> 1) & 7) ^ (((row + 4) >> 3) & 1); }\n" + RUNTIME + common[g0:g1] + tail)
+
+
+def build_file(tmpdir: str, root: str, hip_name: str, replacements=(), extra: str = "", opt: str = "-O1"):
+    """Compile micro_sam_amd/csrc/<hip_name> as a whole for the host.  ``replacements`` = (old, new) pairs for the few clang-only
+    helper definitions of a file (each must occur exactly once); dynamic LDS declarations become static 160 KB arrays."""
+    import re
+    src = open(os.path.join(root, "micro_sam_amd", "csrc", hip_name)).read()
+    for old, new in replacements:
+        assert src.count(old) == 1, (hip_name, old[:60], src.count(old))
+        src = src.replace(old, new)
+    src = re.sub(r"extern\s+__shared__\s+(__attribute__\(\(aligned\(16\)\)\)\s+)?(\w[\w\s]*?)\s+(\w+)\[\];",
+                 lambda m: f"static {m.group(2)} {m.group(3)}[163840 / sizeof({m.group(2)})];", src)
+    src = src.replace('"+v"', '"+r"')
+    csrc = os.path.join(tmpdir, "pkg", "csrc")
+    os.makedirs(csrc, exist_ok=True)
+    os.makedirs(os.path.join(tmpdir, "include"), exist_ok=True)
+    with open(os.path.join(csrc, "common.h"), "w") as fh:
+        fh.write(host_common_h(root))
+    with open(os.path.join(tmpdir, "include", "msam_hip.h"), "w") as fh:
+        fh.write(open(os.path.join(root, "include", "msam_hip.h")).read())
+    cpp = os.path.join(csrc, hip_name.replace(".hip", "_host.cpp"))
+    so = os.path.join(tmpdir, hip_name.replace(".hip", "_host.so"))
+    with open(cpp, "w") as fh:
+        fh.write(src + "\n" + extra)
+    subprocess.check_call(["g++", "-std=c++20", opt, "-ffp-contract=off", "-shared", "-fPIC", "-pthread", "-Wno-unknown-pragmas",
+                           "-Wno-attributes", "-Wno-psabi", "-Wno-unused-value", cpp, "-o", so])
+    return ctypes.CDLL(so)
+
+
+# the library-wide helpers other files expect from gemm.hip (msam_set_error, msam_check_launch, the profiling marks)
+ERROR_STUBS = r"""
+#include <string.h>
+static char g_emu_err[512];
+void msam_set_error(const char* msg) { strncpy(g_emu_err, msg, 511); }
+int msam_check_launch(const char*) { return 0; }
+void msam_profile_mark2(void*, int, double, double, int) {}
+void msam_profile_mark(void*, int, double) {}
+extern "C" const char* emu_last_error() { return g_emu_err; }
+"""
+
+
+# ---- the few clang-only helper definitions of the library, file by file: (start marker, end marker, host text) - the text between the
+# markers (start inclusive, end exclusive) is replaced
+_PKH = """static inline float rh_(float x) { return h16_to_f(f2h(x)); }
+template <int EXPM> static inline uint32_t gelu_pk_h(float x0, float x1) {      // packed fp16 arithmetic: every operation rounded to fp16
+    float g[2]; const float xs[2] = {x0, x1};
+    for (int i = 0; i < 2; ++i) {
+        const float x = rh_(xs[i]); const float r = x > 0.f ? x : 0.f; const float t = rh_(std::fmaf(r, 2.f, -x));
+        float q = rh_(std::fmaf(t, rh_(-0.0248758f), rh_(-0.49884797f)));
+        q = rh_(std::fmaf(q, t, rh_(-1.12922424f))); q = rh_(std::fmaf(q, t, rh_(-1.00353579f)));
+        g[i] = rh_(std::fmaf(-t, rh_(std::exp2(q)), r));
+    }
+    return pack2h(g[0], g[1]);
+}
+"""
+_GW = """struct u32x4_t_gw { const char* base; long bytes; };
+static char* gw_lds_base = nullptr;
+static inline void gw_dma16(const u32x4_t_gw& r, int voff, int soff, unsigned lds_addr) {
+    uint4 v{0, 0, 0, 0};
+    const long o = (long)voff + soff;
+    if (o >= 0 && o + 16 <= r.bytes) std::memcpy(&v, r.base + o, 16);
+    std::memcpy(gw_lds_base + lds_addr + (threadIdx.x & 63) * 16, &v, 16);
+}
+static inline u32x4_t_gw gw_rsrc(const void* base, long bytes) { return u32x4_t_gw{(const char*)base, bytes}; }
+
+"""
+FILE_PATCHES = {
+    "upfused.hip": [("typedef _Float16 h16x2_t", "template <int UF_PRIO, int G16>", _PKH)],
+    "attention.hip": [("typedef short gs16x4_t", "template <int HD, bool F16 = false>\n__global__ __launch_bounds__(256, HD == 64 ? 3 : 2)",
+                       "static inline uint2 g_tr16(const unsigned char* p) { return ds_read_tr16_b64_emu(p); }\n\n")],
+    "decfold.hip": [("typedef short s16x4_t", "// Q'[p][h*8 + t][c]", "static inline uint2 lds_tr16(const unsigned char* p) { return ds_read_tr16_b64_emu(p); }\n\n")],
+    "gemm.hip": [("typedef float f32x16_t __attribute__((ext_vector_type(16)));", "// Epilogue straight from the accumulators of the 128 x 64 wave tile", ""),
+                 ("typedef unsigned int u32x4_t_gw", "template <bool F16>\n__global__ __launch_bounds__(256, 2) void gemm2w_kernel", _GW)],
+}
+TEXT_PATCHES = {
+    "gemm.hip": [("const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dyn;", "const unsigned lds0 = 0; gw_lds_base = (char*)dyn;"),
+                 ('asm volatile("s_waitcnt vmcnt(6)" ::: "memory")', "(void)0"), ('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "(void)0")],
+}
+
+
+def patched_source(root: str, hip_name: str) -> str:
+    src = open(os.path.join(root, "micro_sam_amd", "csrc", hip_name)).read()
+    for start, end, text in FILE_PATCHES.get(hip_name, []):
+        assert src.count(start) == 1, (hip_name, start)
+        a = src.index(start)
+        b = src.index(end, a)
+        src = src[:a] + text + src[b:]
+    for old, new in TEXT_PATCHES.get(hip_name, []):
+        assert old in src, (hip_name, old)
+        src = src.replace(old, new)
+    return src
+
+
+def build_library(tmpdir: str, root: str, files=None, jobs: int = 8):
+    """Every csrc/*.hip file (or ``files``) compiled for the host and linked into one shared object with the library's C ABI
+    (include/msam_hip.h): the kernels run on host threads behind the same entry points the GPU build exports."""
+    import re
+    from concurrent.futures import ThreadPoolExecutor
+    csrc_dir = os.path.join(root, "micro_sam_amd", "csrc")
+    names = files or sorted(n for n in os.listdir(csrc_dir) if n.endswith(".hip"))
+    csrc = os.path.join(tmpdir, "pkg", "csrc")
+    os.makedirs(csrc, exist_ok=True)
+    os.makedirs(os.path.join(tmpdir, "include"), exist_ok=True)
+    with open(os.path.join(csrc, "common.h"), "w") as fh:
+        fh.write(host_common_h(root))
+    with open(os.path.join(tmpdir, "include", "msam_hip.h"), "w") as fh:
+        fh.write(open(os.path.join(root, "include", "msam_hip.h")).read())
+    for n in os.listdir(csrc_dir):                                # other headers of csrc (none clang-specific)
+        if n.endswith(".h") and n != "common.h":
+            with open(os.path.join(csrc, n), "w") as fh:
+                fh.write(open(os.path.join(csrc_dir, n)).read())
+    objs = []
+
+    def compile_one(name):
+        src = patched_source(root, name)
+        src = re.sub(r"extern\s+__shared__\s+(__attribute__\(\(aligned\(16\)\)\)\s+)?(\w[\w\s]*?)\s+(\w+)\[\];",
+                     lambda m: f"static {m.group(2)} {m.group(3)}[163840 / sizeof({m.group(2)})];", src)
+        src = src.replace('"+v"', '"+r"')
+        cpp = os.path.join(csrc, name.replace(".hip", "_host.cpp"))
+        obj = cpp.replace(".cpp", ".o")
+        with open(cpp, "w") as fh:
+            fh.write(src)
+        subprocess.check_call(["g++", "-std=c++20", "-O1", "-ffp-contract=off", "-c", "-fPIC", "-pthread", "-Wno-unknown-pragmas",
+                               "-Wno-attributes", "-Wno-psabi", "-Wno-unused-value", cpp, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(compile_one, names))
+    if "gemm.hip" not in names:
+        stub = os.path.join(csrc, "stubs.cpp")
+        with open(stub, "w") as fh:
+            fh.write("#include <cstring>\n" + ERROR_STUBS)
+        subprocess.check_call(["g++", "-std=c++20", "-O1", "-c", "-fPIC", stub, "-o", stub.replace(".cpp", ".o")])
+        objs.append(stub.replace(".cpp", ".o"))
+    so = os.path.join(tmpdir, "libmsam_hip_host.so")
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", so] + objs)
     return ctypes.CDLL(so)
