@@ -56,11 +56,11 @@ def _pack(masks):
     return (m << np.arange(32, dtype=np.uint32)[None, None, :, None]).sum(2).astype(np.uint32)
 
 
-@pytest.mark.parametrize("H,W,n,seed", [(96, 128, 60, 0), (600, 530, 40, 1)])
+@pytest.mark.parametrize("H,W,n,seed", [(96, 128, 60, 0), (530, 150, 40, 1), (150, 530, 30, 2)])
 def test_amg_generate_labels_is_the_oracles_generate(lib, H, W, n, seed):
     """generate(output_mode="instance_segmentation") as ONE call (filters, box NMS, paint, connected components in the reference's
     block-major numbering, size filter, consecutive relabel: 15 kernels) against oracle/pipeline_ref.amg_generate on the same
-    candidates - identical label images, ids included; the second case spans two 512-blocks in both directions."""
+    candidates - identical label images, ids included; the other cases span two 512-blocks vertically / horizontally."""
     from oracle import amg_ref as A
     from oracle import pipeline_ref as PR
     rng = np.random.default_rng(seed)

@@ -211,12 +211,13 @@ def low_res():
 @pytest.mark.parametrize("in_hw,out_hw", [((1024, 768), (1024, 768)), ((1024, 1024), (512, 512)), ((683, 1024), (400, 600)), ((1024, 640), (1500, 938))])
 def test_general_resampling_path_source_on_the_cpu(emu, low_res, in_hw, out_hw):
     """Identity, x 1/2, a non-integer reduction and an enlargement: logits bit for bit, then bits / counts / boxes."""
-    _check(emu, low_res, in_hw, out_hw, want_logits=True)
+    n = 1 if out_hw[0] * out_hw[1] > 600_000 else 3
+    _check(emu, low_res[:n], in_hw, out_hw, want_logits=True)
     _check(emu, low_res[:1], in_hw, out_hw, want_logits=False)
 
 
 def test_x4_path_source_on_the_cpu(emu, low_res):
-    _check(emu, low_res[:2], (1024, 1024), (1024, 1024), want_logits=True)
+    _check(emu, low_res[:1], (1024, 1024), (1024, 1024), want_logits=True)
 
 
 def test_x4_path_decided_words_source_on_the_cpu(emu):
