@@ -18,7 +18,8 @@ import subprocess
 
 PRELUDE = r"""
 #include <algorithm>
-#include <barrier>
+#include <condition_variable>
+#include <cstdio>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -27,11 +28,49 @@ PRELUDE = r"""
 #include <vector>
 using std::min; using std::max;
 struct idx3 { int x, y, z; };
-static thread_local idx3 threadIdx, blockIdx;
+// ---- execution layer: a wave = ONE host thread whose 64 lanes are user-level contexts (switched in a few nanoseconds by ctx_switch
+// below); a wave-level synchronisation is a round of the wave's scheduler, __syncthreads a condition-variable barrier between the
+// wave threads.  (One host thread per lane - the first form of this shim - spent its time in 64-thread barriers on 8 cores.)
+#if !defined(__x86_64__)
+#error "tests/hip_host_shim.py: the lane contexts are switched by x86-64 assembly"
+#endif
+extern "C" void msam_ctx_switch(void** save_sp, void* load_sp);
+asm(".text\n.weak msam_ctx_switch\n.type msam_ctx_switch,@function\nmsam_ctx_switch:\n"
+    "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+    "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"
+    "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"
+    ".size msam_ctx_switch, .-msam_ctx_switch\n");
+struct LaneCtx { void* sp; idx3 tid; int wait; bool done; };              // wait: 0 runnable, 1 at a wave sync, 2 at __syncthreads
+struct BlockBarrier {                                                         // between the wave threads of a workgroup; waves that
+    std::mutex m; std::condition_variable cv; int expected = 0, arrived = 0; unsigned gen = 0;   // have finished the block drop out
+    void arrive_and_wait() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned g = gen;
+        if (++arrived >= expected) { arrived = 0; ++gen; cv.notify_all(); return; }
+        cv.wait(lk, [&] { return gen != g; });
+    }
+    void drop() { std::lock_guard<std::mutex> lk(m); if (--expected > 0 && arrived >= expected) { arrived = 0; ++gen; cv.notify_all(); } }
+};
+struct WaveCtx { LaneCtx lane[64]; void* sched_sp; int cur; int index; void (*entry)(void*); void* arg; BlockBarrier* bar; };
+static thread_local WaveCtx* WV = nullptr;
+static thread_local idx3 blockIdx;
+#define threadIdx (WV->lane[WV->cur].tid)
 static idx3 gridDim;
-static std::barrier<>* wave_bar[8];
-static std::barrier<>* block_bar;
 static std::mutex atomic_mutex;
+static inline void lane_yield(int why) {
+    LaneCtx& L = WV->lane[WV->cur];
+    L.wait = why;
+    msam_ctx_switch(&L.sp, WV->sched_sp);
+}
+static inline void wave_sync() { lane_yield(1); }
+static inline void block_sync() { lane_yield(2); }
+static void lane_trampoline() {
+    WaveCtx* w = WV;
+    w->entry(w->arg);
+    w->lane[w->cur].done = true;
+    msam_ctx_switch(&w->lane[w->cur].sp, w->sched_sp);                         // never resumed
+    std::abort();
+}
 typedef unsigned short u16;
 typedef float f32x4_t __attribute__((vector_size(16)));
 struct f32x2_t {                                             // clang's ext_vector_type(2) as far as the kernels use it (.x / .y, * + +=)
@@ -94,9 +133,9 @@ static uint4 wave_a[8][64], wave_b[8][64], wave_a2[8][64], wave_b2[8][64];
 static inline long long wave_xchg(long long v, int src_lane_xor) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_buf[w][l] = v;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     const long long r = wave_buf[w][l ^ src_lane_xor];
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return r;
 }
 static inline int __shfl_xor(int v, int o) { return (int)wave_xchg(v, o); }
@@ -104,10 +143,10 @@ static inline float __shfl_xor(float v, int o) { return __uint_as_float((uint32_
 static inline unsigned long long __ballot(int pred) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_buf[w][l] = pred ? 1 : 0;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     unsigned long long m = 0;
     for (int i = 0; i < 64; ++i) m |= (unsigned long long)(wave_buf[w][i] != 0) << i;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return m;
 }
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred ? 1 : 0); }
@@ -119,7 +158,7 @@ static uint2 wave_tr[8][64];
 static inline uint2 ds_read_tr16_b64_emu(const unsigned char* p) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     std::memcpy(&wave_tr[w][l], p, 8);
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     const int g0 = l & ~15, r = l & 15;
     u16 e[4];
     for (int j = 0; j < 4; ++j) {
@@ -127,10 +166,10 @@ static inline uint2 ds_read_tr16_b64_emu(const unsigned char* p) {
         const uint32_t wd = (r & 2) ? src.y : src.x;
         e[j] = (u16)((r & 1) ? (wd >> 16) : (wd & 0xffffu));
     }
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return uint2{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
 }
-static inline void __builtin_amdgcn_wave_barrier() { wave_bar[threadIdx.x >> 6]->arrive_and_wait(); }
+static inline void __builtin_amdgcn_wave_barrier() { wave_sync(); }
 static inline float elem16(const uint4& v, int j, bool f16) {
     const uint32_t wd = (&v.x)[j >> 1];
     const u16 b = (u16)((j & 1) ? (wd >> 16) : (wd & 0xffffu));
@@ -139,7 +178,7 @@ static inline float elem16(const uint4& v, int j, bool f16) {
 static inline f32x4_t mfma16_emu(const uint4& a, const uint4& b, f32x4_t c, bool f16) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_a[w][l] = a; wave_b[w][l] = b;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     f32x4_t d;
     for (int i = 0; i < 4; ++i) {
         const int row = (l >> 4) * 4 + i, col = l & 15;
@@ -148,7 +187,7 @@ static inline f32x4_t mfma16_emu(const uint4& a, const uint4& b, f32x4_t c, bool
             for (int j = 0; j < 8; ++j) s += (double)elem16(wave_a[w][kb * 16 + row], j, f16) * (double)elem16(wave_b[w][kb * 16 + col], j, f16);
         d[i] = (float)s;
     }
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return d;
 }
 static inline f32x4_t mfma16(const uint4& a, const uint4& b, f32x4_t c) { return mfma16_emu(a, b, c, false); }
@@ -156,7 +195,7 @@ static inline f32x4_t mfma16h(const uint4& a, const uint4& b, f32x4_t c) { retur
 static inline f32x16_t mfma32_emu(const uint4& a, const uint4& b, f32x16_t c, bool f16) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_a[w][l] = a; wave_b[w][l] = b;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     f32x16_t d;
     for (int g = 0; g < 4; ++g)
         for (int x = 0; x < 4; ++x) {
@@ -166,7 +205,7 @@ static inline f32x16_t mfma32_emu(const uint4& a, const uint4& b, f32x16_t c, bo
                 for (int j = 0; j < 8; ++j) s += (double)elem16(wave_a[w][kb * 32 + row], j, f16) * (double)elem16(wave_b[w][kb * 32 + col], j, f16);
             d[4 * g + x] = (float)s;
         }
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return d;
 }
 // LDS-DMA (global_load_lds_dwordx4): lane l lands at the wave-uniform LDS base + 16 l; performed at once
@@ -204,7 +243,7 @@ static inline float e4m3_to_f(uint8_t b) {
 static inline f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, f32x16_t c) {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_a[w][l] = a0; wave_a2[w][l] = a1; wave_b[w][l] = b0; wave_b2[w][l] = b1;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     auto byte = [](const uint4& lo, const uint4& hi, int i) { const uint4& q = i < 16 ? lo : hi; return (uint8_t)(((&q.x)[(i & 15) >> 2] >> (8 * (i & 3))) & 255u); };
     f32x16_t d;
     for (int g = 0; g < 4; ++g)
@@ -217,7 +256,7 @@ static inline f32x16_t mfma32_f8(const uint4& a0, const uint4& a1, const uint4& 
                          (double)e4m3_to_f(byte(wave_b[w][kb * 32 + col], wave_b2[w][kb * 32 + col], i));
             d[4 * g + x] = (float)s;
         }
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return d;
 }
 template <bool F16 = false> static inline f32x16_t mfma32(const uint4& a, const uint4& b, f32x16_t c) { return mfma32_emu(a, b, c, F16); }
@@ -250,9 +289,9 @@ static inline int __lane_id() { return threadIdx.x & 63; }
 static inline long long wave_read(long long v, int src_lane) {          // value of `v` in lane src_lane of this wave
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     wave_buf[w][l] = v;
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     const long long r = wave_buf[w][src_lane & 63];
-    wave_bar[w]->arrive_and_wait();
+    wave_sync();
     return r;
 }
 static inline int __shfl(int v, int src) { return (int)wave_read(v, src); }
@@ -298,8 +337,8 @@ static inline unsigned long long atomicOr(unsigned long long* p, unsigned long l
 static inline int atomicExch(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); const int o = *p; *p = v; return o; }
 #define __expf expf
 #define __logf logf
-#define __syncthreads() block_bar->arrive_and_wait()
-static inline void __builtin_amdgcn_s_barrier() { block_bar->arrive_and_wait(); }
+#define __syncthreads() block_sync()
+static inline void __builtin_amdgcn_s_barrier() { block_sync(); }
 #define MSAM_DEVINL static inline
 #define __global__
 #define __device__
@@ -309,21 +348,55 @@ static inline void __builtin_amdgcn_s_barrier() { block_bar->arrive_and_wait(); 
 #define __shared__ static
 // one workgroup of 256 threads after the other: f() is the kernel call
 template <class F> static void launch_grid(int gx, int gy, F f, int threads = 256) {
-    // the workgroups run one after the other on ONE set of host threads (created per launch, not per workgroup)
     gridDim = {gx, gy, 1};
-    std::barrier<> b0(64), b1(64), b2(64), b3(64), b4(64), b5(64), b6(64), b7(64), bb(threads), next(threads);
-    std::barrier<>* wb[8] = {&b0, &b1, &b2, &b3, &b4, &b5, &b6, &b7};
-    for (int i = 0; i < 8; ++i) wave_bar[i] = wb[i];
-    block_bar = &bb;
+    const int nw = (threads + 63) / 64;
+    constexpr size_t STACK = 256 * 1024;
+    BlockBarrier bar, next;
+    next.expected = nw;
     std::vector<std::thread> ts;
-    for (int tx = 0; tx < threads; ++tx)
-        ts.emplace_back([=, &next] {
+    for (int w = 0; w < nw; ++w)
+        ts.emplace_back([=, &bar, &next] {
+            F fn = f;
+            WaveCtx* wv = new WaveCtx();
+            char* stacks = (char*)std::malloc(64 * STACK);
+            wv->index = w; wv->bar = &bar; wv->arg = &fn;
+            wv->entry = [](void* a) { (*(F*)a)(); };
+            WV = wv;
+            const int lanes = std::min(64, threads - w * 64);
             for (int by = 0; by < gy; ++by)
                 for (int bx = 0; bx < gx; ++bx) {
-                    threadIdx = {tx, 0, 0}; blockIdx = {bx, by, 0};
-                    f();
-                    next.arrive_and_wait();                   // LDS (static arrays) is free for the next workgroup
+                    blockIdx = {bx, by, 0};
+                    if (w == 0) { std::lock_guard<std::mutex> lk(bar.m); bar.expected = nw; bar.arrived = 0; }
+                    next.arrive_and_wait();                                    // the block barrier is set up; LDS of the last block is free
+                    for (int l = 0; l < 64; ++l) {
+                        LaneCtx& L = wv->lane[l];
+                        L.tid = {w * 64 + l, 0, 0}; L.wait = 0; L.done = l >= lanes;
+                        void** top = (void**)(stacks + (size_t)(l + 1) * STACK);   // 16-byte aligned
+                        top[-1] = nullptr;                                      // (return address slot of the trampoline's frame)
+                        top[-2] = (void*)&lane_trampoline;
+                        for (int i = 3; i <= 8; ++i) top[-i] = nullptr;         // rbp rbx r12 r13 r14 r15
+                        L.sp = (void*)(top - 8);
+                    }
+                    while (true) {
+                        int live = 0, w1 = 0, w2 = 0;
+                        bool progress = false;
+                        for (int l = 0; l < 64; ++l) {
+                            LaneCtx& L = wv->lane[l];
+                            if (L.done) continue;
+                            if (L.wait == 0) { wv->cur = l; msam_ctx_switch(&wv->sched_sp, L.sp); progress = true; }
+                            if (L.done) continue;
+                            ++live; w1 += L.wait == 1; w2 += L.wait == 2;
+                        }
+                        if (live == 0) break;
+                        if (w1 == live) { for (int l = 0; l < 64; ++l) wv->lane[l].wait = 0; }
+                        else if (w2 == live) { bar.arrive_and_wait(); for (int l = 0; l < 64; ++l) wv->lane[l].wait = 0; }
+                        else if (!progress) { std::fprintf(stderr, "hip_host_shim: divergent barrier in wave %d (%d live, %d at a wave sync, %d at __syncthreads)\n", w, live, w1, w2); std::abort(); }
+                    }
+                    bar.drop();                                                 // this wave takes no further part in the block's barriers
+                    next.arrive_and_wait();                                    // every wave has left the block: its barrier may be reset
                 }
+            std::free(stacks);
+            delete wv;
         });
     for (auto& t : ts) t.join();
 }
