@@ -549,7 +549,9 @@ FILE_PATCHES = {
                  ("typedef unsigned int u32x4_t_gw", "template <bool F16>\n__global__ __launch_bounds__(256, 2) void gemm2w_kernel", _GW)],
 }
 TEXT_PATCHES = {
-    "gemm.hip": [("const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dyn;", "const unsigned lds0 = 0; gw_lds_base = (char*)dyn;"),
+    "gemm.hip": [("#if defined(__HIP_DEVICE_COMPILE__)                  // (address-space-qualified struct copies do not parse in the host pass)", "#if 1"),
+                 ("    typedef const __attribute__((address_space(4))) GroupItem* ItemPtr;\n    ItemPtr it = (ItemPtr)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y;",
+                  "    const GroupItem* it = &g.it[blockIdx.y];          // (the device reads its kernel-argument segment)"),("const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dyn;", "const unsigned lds0 = 0; gw_lds_base = (char*)dyn;"),
                  ('asm volatile("s_waitcnt vmcnt(6)" ::: "memory")', "(void)0"), ('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "(void)0")],
 }
 

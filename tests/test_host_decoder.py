@@ -1,0 +1,67 @@
+"""The mask decoder END TO END on the CPU: the product's own Python layer (micro_sam_amd.modeling.Sam.decode: weight packing,
+msam_decoder_prepare_const / _prepare_image / _forward_masks) drives the library's C ABI, behind which the kernel SOURCES run on host
+threads (tests/hip_host_shim.build_library) - compared with the oracle's predict_torch (fp16 decoder policy) on the same embedding and
+prompts, with the tolerances of the device test (tests/test_gpu_model.py::test_decoder_vs_oracle).  Two routes: the stage-by-stage
+kernels (few prompts) and the CHAINED kernels of the benchmarked AMG path (i2t0_t2i_v2 / i2t01_ring: forced for 8 prompts through
+msam_tune_set("dec_chain_min_p", 1)).
+
+TEST INFRASTRUCTURE: the library handle, require_gpu and the stream accessor of micro_sam_amd._lib are patched for the duration of the
+test; the product itself has no CPU path and fails loudly without its GPU build."""
+import os
+
+import pytest
+import torch
+
+from hip_host_shim import build_library
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_sam(tmp_path_factory):
+    from micro_sam_amd import _lib, modeling
+    from micro_sam_amd.synthetic import synthetic_state_dict
+    os.environ["MSAM_EMU_CUS"] = "4"
+    host = build_library(str(tmp_path_factory.mktemp("host_dec")), ROOT)
+    for name, (res, args) in _lib._PROTOS.items():
+        fn = getattr(host, name)
+        fn.restype, fn.argtypes = res, args
+    saved = (_lib._lib, _lib.require_gpu, _lib.stream_ptr, _lib.ptr)
+    _lib._lib = host
+    _lib.require_gpu = lambda device=None: torch.device("cpu") if device is None else torch.device(device)
+    _lib.stream_ptr = lambda: None
+    _lib.ptr = lambda t: None if t is None else t.data_ptr()
+    sd = synthetic_state_dict("vit_b", 0, variant="cells")
+    sam = modeling.build_sam("vit_b")
+    sam.load_state_dict(sd)
+    sam.eval()
+    try:
+        yield host, sam, sd
+    finally:
+        _lib._lib, _lib.require_gpu, _lib.stream_ptr, _lib.ptr = saved
+        os.environ.pop("MSAM_EMU_CUS", None)
+
+
+@pytest.mark.parametrize("chain", [0, 1])
+def test_decode_on_the_host_library_matches_the_oracle(host_sam, chain):
+    from oracle import sam_ref as S
+    host, sam, sd = host_sam
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(1, 256, 64, 64, generator=g) * 0.6
+    P = 8 if chain else 2          # (the chained form keeps its tables in the workspace of the stage-by-stage form: P >= 8 prompts)
+    pts = torch.rand(P, 1, 2, generator=g) * 1024
+    lbl = torch.ones(P, 1, dtype=torch.int)
+    with torch.no_grad():
+        _, iou_b, low_b = S.predict_torch(sd, feats, (1024, 1024), (1024, 1024), pts, lbl, return_logits=True, precision="bf16")
+    assert host.msam_tune_set(b"dec_chain_min_p", 1 if chain else 128) == 0
+    try:
+        sam.invalidate()
+        low, iou = sam.decode(feats, pts, lbl)
+    finally:
+        host.msam_tune_set(b"dec_chain_min_p", 128)
+    scale = low_b.abs().max().item()
+    d = (low - low_b).abs()
+    assert torch.isfinite(low).all() and d.max().item() <= 0.03 * scale and d.mean().item() <= 0.006 * scale, (d.max().item() / scale, d.mean().item() / scale)
+    assert (iou - iou_b).abs().max().item() <= 2e-3
+    pe = sam.prompt_encoder.get_dense_pe()
+    assert (pe - S.get_dense_pe(sd)).abs().max().item() <= 2e-4
