@@ -572,10 +572,22 @@ def patched_source(root: str, hip_name: str) -> str:
 def build_library(tmpdir: str, root: str, files=None, jobs: int = 8):
     """Every csrc/*.hip file (or ``files``) compiled for the host and linked into one shared object with the library's C ABI
     (include/msam_hip.h): the kernels run on host threads behind the same entry points the GPU build exports."""
+    import hashlib
     import re
+    import tempfile
     from concurrent.futures import ThreadPoolExecutor
     csrc_dir = os.path.join(root, "micro_sam_amd", "csrc")
     names = files or sorted(n for n in os.listdir(csrc_dir) if n.endswith(".hip"))
+    if files is None:
+        # one build per state of the sources and of this shim, shared by the test modules of a run (and by later runs)
+        h = hashlib.sha1(open(__file__.replace(".pyc", ".py"), "rb").read())
+        for n in sorted(os.listdir(csrc_dir)) + ["../../include/msam_hip.h"]:
+            h.update(open(os.path.join(csrc_dir, n), "rb").read())
+        tmpdir = os.path.join(tempfile.gettempdir(), "msam_host_lib_" + h.hexdigest()[:16])
+        cached = os.path.join(tmpdir, "libmsam_hip_host.so")
+        if os.path.exists(cached):
+            return ctypes.CDLL(cached)
+        os.makedirs(tmpdir, exist_ok=True)
     csrc = os.path.join(tmpdir, "pkg", "csrc")
     os.makedirs(csrc, exist_ok=True)
     os.makedirs(os.path.join(tmpdir, "include"), exist_ok=True)
@@ -611,5 +623,6 @@ def build_library(tmpdir: str, root: str, files=None, jobs: int = 8):
         subprocess.check_call(["g++", "-std=c++20", "-O1", "-c", "-fPIC", stub, "-o", stub.replace(".cpp", ".o")])
         objs.append(stub.replace(".cpp", ".o"))
     so = os.path.join(tmpdir, "libmsam_hip_host.so")
-    subprocess.check_call(["g++", "-shared", "-pthread", "-o", so] + objs)
+    subprocess.check_call(["g++", "-shared", "-pthread", "-o", so + ".tmp"] + objs)
+    os.replace(so + ".tmp", so)                                    # (complete before it becomes visible to a concurrent run)
     return ctypes.CDLL(so)
