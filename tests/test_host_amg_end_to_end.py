@@ -1,7 +1,7 @@
 """embed (oracle encoder) -> AutomaticMaskGenerator.initialize -> generate of the PRODUCT on the CPU: micro_sam_amd's own Python layer
 (SamPredictor, AutomaticMaskGenerator, ops) over the library's C ABI, the kernel SOURCES running on host threads
 (tests/hip_host_shim.build_library), against the oracle pipeline (fp32 CPU reference) on the same embedding: per-instance mask IoU,
-keep set, scores, and the label image - the comparison tests/test_gpu_parity_iou.py makes on the device, on a 5 x 5 prompt grid.
+keep set, scores, and the label image - the comparison tests/test_gpu_parity_iou.py makes on the device, on a 4 x 4 prompt grid.
 
 TEST INFRASTRUCTURE: micro_sam_amd._lib (library handle, require_gpu, stream accessors) and torch.cuda.current_stream are patched for
 the duration of the test; the product has no CPU path."""
@@ -15,7 +15,7 @@ import torch
 from hip_host_shim import build_library
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GRID = 5
+GRID = 4
 
 
 @pytest.fixture(scope="module")
@@ -85,7 +85,7 @@ def test_scores_and_boxes_close_to_the_reference(run):
 
 def test_per_instance_iou_and_labels(run):
     rep, lab = run["rep"], run["lab"]
-    assert rep["n_instances"] >= 5
+    assert rep["n_instances"] >= 4
     assert rep["min"] >= 0.99 and rep["frac_ge_0.99"] == 1.0, rep["worst"][:3]
     ks = rep["keep_set"]
     assert ks["ref_only"] + ks["test_only"] <= max(2, 0.15 * rep["n_instances"]), ks
