@@ -65,3 +65,31 @@ def test_decode_on_the_host_library_matches_the_oracle(host_sam, chain):
     assert (iou - iou_b).abs().max().item() <= 2e-3
     pe = sam.prompt_encoder.get_dense_pe()
     assert (pe - S.get_dense_pe(sd)).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("kind", ["points", "boxes", "points+boxes", "masks", "points+masks"])
+def test_prompt_encoder_module_call_on_the_host_library(host_sam, kind):
+    """``sam.prompt_encoder(points, boxes, masks)`` (msam_prompt_encode: Fourier features of the points / box corners, the learned
+    embeddings, the mask down-scaling convolutions with their LayerNorm2d + GELU) against the oracle's prompt encoder - the comparison
+    of tests/test_gpu_modules.py::test_prompt_encoder_forward."""
+    from oracle import sam_ref as S
+    _, sam, sd = host_sam
+    g = torch.Generator().manual_seed(len(kind))
+    P, Np = 6, 3
+    pts = torch.rand(P, Np, 2, generator=g) * 1000 + 10
+    lbl = (torch.rand(P, Np, generator=g) > 0.3).to(torch.int)
+    x0 = torch.rand(P, 2, generator=g) * 600 + 20
+    boxes = torch.cat([x0, x0 + torch.rand(P, 2, generator=g) * 350 + 30], dim=1)
+    masks = torch.randn(P, 1, 256, 256, generator=g) * 4
+    points = (pts, lbl) if "points" in kind else None
+    bx = boxes if "boxes" in kind else None
+    mk = masks if "masks" in kind else None
+    sparse, dense = sam.prompt_encoder(points, bx, mk)
+    with torch.no_grad():
+        rs, rd = S.prompt_encoder(sd, points, bx, mk)
+    if points is None and bx is None:
+        assert sparse.shape == (P, 0, 256)
+    else:
+        assert sparse.shape == rs.shape and (sparse - rs).abs().max().item() < 2e-4
+    assert dense.shape == (P, 256, 64, 64)
+    assert (dense - rd).abs().max().item() < (2e-3 if mk is not None else 1e-6)
