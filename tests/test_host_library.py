@@ -211,3 +211,41 @@ def test_gemm_through_the_abi(lib):
     assert lib.msam_gemm_bf16(C.byref(p), None) == 0, _err(lib)
     ref2 = a2.double() @ w2.double().t()
     assert np.abs(out2 - ref2.numpy()).max() <= 3e-5 * ref2.abs().max().item()
+
+
+@pytest.mark.parametrize("case", ["single", "all_rejected", "ragged_size", "no_background", "nested"])
+def test_amg_generate_labels_edge_cases(lib, case):
+    """One candidate; every candidate rejected by the thresholds; an image whose sides are not multiples of 32; with_background=False
+    (the largest component is NOT set to zero); nested / overlapping masks painted by descending area - each against the oracle."""
+    from oracle import amg_ref as A
+    from oracle import pipeline_ref as PR
+    rng = np.random.default_rng({"single": 1, "all_rejected": 2, "ragged_size": 3, "no_background": 4, "nested": 5}[case])
+    H, W, n = (75, 101, 20) if case == "ragged_size" else (64, 96, 1 if case == "single" else 24)
+    masks = _blobs(rng, n, H, W)
+    if case == "nested":
+        yy, xx = np.mgrid[0:H, 0:W]
+        for i in range(6):                                     # concentric discs: smaller ones end up on top
+            masks[i] = (yy - 32) ** 2 + (xx - 48) ** 2 < (30 - 4 * i) ** 2
+    iou = rng.uniform(0.9, 1.0, n).astype(np.float32)
+    stab = rng.uniform(0.96, 1.0, n).astype(np.float32)
+    if case == "all_rejected":
+        iou[:] = 0.5
+    mt = torch.from_numpy(masks)
+    boxes = A.batched_mask_to_box(mt).numpy().astype(np.int32)
+    area = masks.reshape(n, -1).sum(1).astype(np.int32)
+    bits = _pack(masks)
+    lib.msam_amg_generate_workspace_bytes.restype = C.c_int64
+    need = lib.msam_amg_generate_workspace_bytes(n, H, W)
+    ws = np.zeros(need, np.uint8)
+    labels = np.full((H, W), -7, np.int32)
+    flag = np.full(1, -1, np.int32)
+    crop = (C.c_int32 * 4)(0, 0, W, H)
+    wb = 0 if case == "no_background" else 1
+    rc = lib.msam_amg_generate_labels(_p(iou), _p(stab), _p(boxes), _p(area), _p(bits), n, H, W, crop, C.c_float(0.88), C.c_float(0.95),
+                                      C.c_float(0.7), 0, wb, _p(labels), _p(flag), _p(ws), C.c_int64(need), None)
+    assert rc == 0 and flag[0] == 0, _err(lib)
+    data = A.MaskData(iou_preds=torch.from_numpy(iou), stability_score=torch.from_numpy(stab), boxes=torch.from_numpy(boxes).long(),
+                      rles=A.mask_to_rle(mt), points=torch.zeros(n, 2))
+    state = {"crop_list": [data], "crop_boxes": [[0, 0, W, H]], "original_size": (H, W)}
+    seg = np.asarray(PR.amg_generate(state, with_background=bool(wb)))
+    assert np.array_equal(labels.astype(np.int64), seg.astype(np.int64)), case
