@@ -24,7 +24,7 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from . import parallel, util
+from . import _lib, parallel, util
 
 
 def segment_slices(data: np.ndarray, predictor, segmentor, embedding_path=None, verbose: bool = False,
@@ -78,7 +78,7 @@ def compute_edges_from_overlap(segmentation: np.ndarray, device=None):
     the source object (``overlapArraysNormalized``).  Counting runs on the device; returns (uv_ids int64 [E,2], scores float64 [E])
     sorted by (source, target)."""
     from . import ops
-    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    dev = _lib.require_gpu(device)
     vol = torch.as_tensor(np.ascontiguousarray(segmentation).astype(np.int32, copy=False)).to(dev)
     table = ops.slice_overlaps(vol)
     return edges_from_overlap_table(table)

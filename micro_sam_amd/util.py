@@ -14,7 +14,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 import numpy as np
 import torch
 
-from . import modeling
+from . import _lib, modeling
 from .predictor import SamPredictor
 
 ImageEmbeddings = Dict[str, Any]
@@ -839,7 +839,7 @@ def _apply_nms_tiled(predictions, min_size, shape, perform_box_nms, nms_thresh, 
         return np.zeros(shape, dtype="uint32")
     scores = np.array([np.float32(p["predicted_iou"]) * np.float32(p["stability_score"]) for p in preds], dtype=np.float32)
     if perform_box_nms:
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = _lib.require_gpu()
         xyxy = torch.tensor([p["global_bbox"] for p in preds], dtype=torch.float32, device=dev)
         xyxy[:, 2] += xyxy[:, 0]
         xyxy[:, 3] += xyxy[:, 1]
@@ -895,7 +895,7 @@ def apply_nms(predictions: List[Dict[str, Any]], min_size: int, shape: Optional[
         preds = [p for p in preds if p["area"] < max_size]
     if not preds:
         return np.zeros(shape, dtype="uint32")
-    dev = torch.device("cuda", torch.cuda.current_device())
+    dev = _lib.require_gpu()
     scores = torch.tensor([float(np.float32(p["predicted_iou"]) * np.float32(p["stability_score"])) for p in preds],
                           dtype=torch.float32, device=dev)
     xyxy = torch.tensor([p["bbox"] for p in preds], dtype=torch.float32, device=dev)
