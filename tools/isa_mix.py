@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Static instruction mix of a kernel's loops, from the gfx950 assembly hipcc emits for one source file (no GPU needed).
+
+    python tools/isa_mix.py micro_sam_amd/csrc/upfused.hip 'up_fused_kernelILi1ELi1E' [-D MSAM_DEC_F16=1]
+
+For every backward branch of the matching kernel it prints the instruction classes between the loop head and the branch (MFMA, plain
+VALU, packed VALU, transcendental, LDS, VMEM, SALU) with the most frequent opcodes, and an ISSUE estimate in SIMD cycles from
+/opt/skills/guides/MI355X_MICROARCH.md: a wave's VALU instruction issues over 2 cycles (packed fp32 twice that, a transcendental 5/3 of a
+plain VALU), a 16x16x32 16-bit MFMA occupies the matrix pipe ~17 cycles (32x32x16: 32).  The estimate is what the loop would cost with
+no stalls at all - compare it with the measured time per trip to see how far a kernel is from its issue ceilings (profiles/r03_experiments.md
+section 10 does this for up_fused_kernel)."""
+import argparse
+import collections
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+
+def classify(op):
+    if op.startswith("v_mfma"):
+        return "mfma"
+    if op.startswith(("v_exp", "v_rsq", "v_rcp", "v_log", "v_sqrt", "v_sin", "v_cos")):
+        return "trans"
+    if op.startswith("v_pk_"):
+        return "vpk"
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("buffer_", "global_", "flat_", "scratch_")):
+        return "vmem"
+    if op.startswith("s_"):
+        return "salu"
+    return "other"
+
+
+def issue_cycles(ops):
+    valu = mfma = 0.0
+    for op, n in ops.items():
+        k = classify(op)
+        if k == "mfma":
+            mfma += n * (32 if "32x32" in op else 17)
+        elif k == "trans":
+            valu += n * 2 * 5 / 3
+        elif k == "vpk":
+            valu += n * (4 if op.endswith("_f32") else 2)
+        elif k == "valu":
+            valu += n * 2
+    return valu, mfma
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("source")
+    ap.add_argument("kernel", help="regex over the mangled kernel names")
+    ap.add_argument("-D", action="append", default=[])
+    ap.add_argument("--top", type=int, default=14)
+    a = ap.parse_args()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *[f"-D{x}" for x in a.D], "-o", out,
+               a.source]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    names = [n for n in re.findall(r"^(\S+):\s*; @", text, re.M) if re.search(a.kernel, n)]
+    if not names:
+        sys.exit("no kernel matches; kernels: " + ", ".join(re.findall(r"^(\S+):\s*; @", text, re.M)))
+    for name in names:
+        body = text[text.index(name + ":"):]
+        body = body[:body.index(".Lfunc_end")]
+        m = re.search(r"; NumVgprs: (\d+)", text[text.index(name + ":"):])
+        m2 = re.search(r"; NumAgprs: (\d+)", text[text.index(name + ":"):])
+        m3 = re.search(r"; ScratchSize: (\d+)", text[text.index(name + ":"):])
+        print(f"== {name}: VGPRs {m.group(1) if m else '?'}, AGPRs {m2.group(1) if m2 else '?'}, scratch {m3.group(1) if m3 else '?'} B")
+        lines = body.split("\n")
+        labels = {mm.group(1): i for i, l in enumerate(lines) if (mm := re.match(r"^(\.LBB\d+_\d+):", l))}
+        for i, l in enumerate(lines):
+            mm = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+            if not mm or mm.group(1) not in labels or labels[mm.group(1)] >= i:
+                continue
+            ops = collections.Counter()
+            for x in lines[labels[mm.group(1)]:i + 1]:
+                x = x.strip()
+                if not x or x[0] in ".;/" or x.endswith(":"):
+                    continue
+                ops[x.split()[0]] += 1
+            cls = collections.Counter()
+            for op, n in ops.items():
+                cls[classify(op)] += n
+            valu, mfma = issue_cycles(ops)
+            print(f"-- loop {mm.group(1)} .. line {i}: {sum(ops.values())} instructions  " + "  ".join(f"{k} {v}" for k, v in sorted(cls.items())))
+            print(f"   issue estimate: VALU {valu:.0f} cycles, MFMA {mfma:.0f} cycles per trip")
+            print("   " + ", ".join(f"{op} {n}" for op, n in ops.most_common(a.top)))
+
+
+if __name__ == "__main__":
+    main()
