@@ -295,6 +295,20 @@ static inline long long wave_read(long long v, int src_lane) {          // value
     return r;
 }
 static inline int __shfl(int v, int src) { return (int)wave_read(v, src); }
+// v_permlane16_swap / v_permlane32_swap (gfx950): rows of 16 (32) lanes; the ODD rows of the first operand are exchanged with the EVEN
+// rows of the second; the builtin returns both registers
+struct u32pair_t { uint32_t v[2]; uint32_t operator[](int i) const { return v[i]; } };
+static inline u32pair_t permlane_swap_emu(uint32_t a, uint32_t b, int row) {
+    const int l = threadIdx.x & 63;
+    const bool odd = (l / row) & 1;
+    const long long other = wave_read((long long)a | ((long long)b << 32), odd ? l - row : l + row);
+    u32pair_t r;
+    r.v[0] = odd ? (uint32_t)((unsigned long long)other >> 32) : a;      // odd row of the first operand <- even row of the second
+    r.v[1] = odd ? b : (uint32_t)other;                                   // even row of the second operand <- odd row of the first
+    return r;
+}
+static inline u32pair_t __builtin_amdgcn_permlane16_swap(uint32_t a, uint32_t b, bool, bool) { return permlane_swap_emu(a, b, 16); }
+static inline u32pair_t __builtin_amdgcn_permlane32_swap(uint32_t a, uint32_t b, bool, bool) { return permlane_swap_emu(a, b, 32); }
 static inline float __shfl(float v, int src) { return __uint_as_float((uint32_t)wave_read(__float_as_uint(v), src)); }
 static inline int __shfl_up(int v, int d) { const int l = threadIdx.x & 63; const int r = (int)wave_read(v, l >= d ? l - d : l); return r; }
 static inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)wave_read(v, lane); }
@@ -476,11 +490,12 @@ def host_common_h(root: str) -> str:
             "static inline int swz(int row) { return ((row >> 1) & 7) ^ (((row + 4) >> 3) & 1); }\n" + RUNTIME + common[g0:g1] + tail)
 
 
-def build_file(tmpdir: str, root: str, hip_name: str, replacements=(), extra: str = "", opt: str = "-O1"):
+def build_file(tmpdir: str, root: str, hip_name: str, replacements=(), extra: str = "", opt: str = "-O1", source: str = None):
     """Compile micro_sam_amd/csrc/<hip_name> as a whole for the host.  ``replacements`` = (old, new) pairs for the few clang-only
-    helper definitions of a file (each must occur exactly once); dynamic LDS declarations become static 160 KB arrays."""
+    helper definitions of a file (each must occur exactly once); dynamic LDS declarations become static 160 KB arrays.  ``source``:
+    the file's text if it is not the one on disk (tools/uf_lab.py's variants of a kernel)."""
     import re
-    src = open(os.path.join(root, "micro_sam_amd", "csrc", hip_name)).read()
+    src = source if source is not None else open(os.path.join(root, "micro_sam_amd", "csrc", hip_name)).read()
     for old, new in replacements:
         assert src.count(old) == 1, (hip_name, old[:60], src.count(old))
         src = src.replace(old, new)
