@@ -51,16 +51,19 @@ def _run(lib, arrs, P, nmask):
     return out
 
 
-@pytest.fixture(scope="module")
-def case(tmp_path_factory):
-    os.environ["MSAM_EMU_CUS"] = "2"
-    g = torch.Generator().manual_seed(11)
-    P = 1
+def _inputs(P, seed):
+    g = torch.Generator().manual_seed(seed)
     keys = torch.randn(P, 4096, 256, generator=g)
     keys[:, :, :64] += 1.5                                   # channel means away from zero: the one-pass variance has something to cancel
-    arrs = [_bits(keys), _bits(torch.randn(256, 256, generator=g) / 16), (torch.randn(256, generator=g) * 0.5 + 1.0).numpy().copy(),
+    return [_bits(keys), _bits(torch.randn(256, 256, generator=g) / 16), (torch.randn(256, generator=g) * 0.5 + 1.0).numpy().copy(),
             (torch.randn(64, generator=g) * 0.2 + 1).numpy().copy(), (torch.randn(64, generator=g) * 0.3).numpy().copy(),
             _bits(torch.randn(128, 64, generator=g) / 8), torch.randn(32, generator=g).numpy().copy(), torch.randn(P, 4, 128, generator=g).numpy().copy()]
+
+
+@pytest.fixture(scope="module")
+def case(tmp_path_factory):
+    os.environ["MSAM_EMU_CUS"] = "2"                         # one prompt as four quarter-prompt items over four workgroups
+    arrs, P = _inputs(1, 11), 1
     base = _run(_host_lib(tmp_path_factory.mktemp("uf_base"), "base"), arrs, P, 3)
     assert np.isfinite(base).all()
     yield arrs, P, base
@@ -77,3 +80,16 @@ def test_candidate_variants_compute_the_shipped_function(case, tmp_path, name):
         scale = float(np.abs(base).max())
         err = np.abs(out - base)
         assert err.max() <= 2e-3 * scale and err.mean() <= 1e-4 * scale, (err.max() / scale, err.mean() / scale)
+
+
+def test_pipelined_variant_across_prompts_of_one_workgroup(tmp_path):
+    """Three whole prompts over two workgroups: the first one runs prompts 0 and 2 back to back (512 tiles: the prefetched stage 1 crosses the
+    prompt boundary, the hyper weights change under it), one and two masks."""
+    os.environ["MSAM_EMU_CUS"] = "1"
+    try:
+        arrs, P = _inputs(3, 12), 3
+        base_lib, lib = _host_lib(tmp_path / "b", "base"), _host_lib(tmp_path / "p", "R_pipelined")
+        for nmask in (1, 2):
+            assert np.array_equal(_run(lib, arrs, P, nmask), _run(base_lib, arrs, P, nmask))
+    finally:
+        os.environ.pop("MSAM_EMU_CUS", None)

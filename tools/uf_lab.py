@@ -94,6 +94,9 @@ V["base"] = dict(kind="base", doc="the shipped source, unchanged", patches=[])
 V["R_permlane"] = dict(kind="exact", doc="LayerNorm2d sums through v_permlane16/32_swap instead of four ds_bpermute round trips", patches=_PERMLANE)
 V["R_ln_one_pass"] = dict(kind="close", doc="both LayerNorm sums in one exchange (variance = E[u^2] - mean^2), centring folded into one fma per value; permlane sums",
                           patches=[_PERMLANE[0], (_LN_TWO_PASS, _LN_ONE_PASS)] + _AFFINE)
+V["R_pipelined"] = dict(kind="exact", doc="tile q + 1's stage-1 MFMAs under tile q's LayerNorm2d + GELU inside every wave (tools/uf_lab_pipelined.inc); biases from LDS",
+                        patches=[_PERMLANE[0], ("template <int UF_PRIO, int G16>\n__global__", "}  // namespace\n\nextern \"C\" int msam_upscale_fused_layout(",
+                                                open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "uf_lab_pipelined.inc")).read())])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 V["T_no_ln_stats"] = dict(kind="timing", doc="no LayerNorm statistics (no sums, no exchange, no rsqrt); affine and GELU stay",
                           patches=[(_LN_TWO_PASS, "        const float rstd = a.eps + 1.f;\n")])
@@ -123,9 +126,17 @@ void msam_profile_mark2(void*, int, double, double, int) {}
 
 
 def variant_source(name: str) -> str:
-    """The shipped source with the variant's patches applied; every patched text must occur exactly once."""
+    """The shipped source with the variant's patches applied: (old, new) - the text must occur exactly once - or (start, end, new) -
+    everything from the start marker up to (not including) the end marker is replaced."""
     src = open(SRC).read()
-    for old, new in V[name]["patches"]:
+    for patch in V[name]["patches"]:
+        if len(patch) == 3:
+            start, end, new = patch
+            assert src.count(start) == 1, (name, start[:70], src.count(start))
+            i = src.index(start)
+            src = src[:i] + new + src[src.index(end, i):]
+            continue
+        old, new = patch
         assert src.count(old) == 1, (name, old[:70], src.count(old))
         src = src.replace(old, new)
     return src
