@@ -147,7 +147,11 @@ def build(name: str, outdir: str):
     src = variant_source(name)
     src = src.replace('#include "common.h"', f'#include "{ROOT}/micro_sam_amd/csrc/common.h"')
     src = src.replace('#include "../../include/msam_hip.h"', f'#include "{ROOT}/include/msam_hip.h"')
-    path, so = os.path.join(outdir, name + ".hip"), os.path.join(outdir, name + ".so")
+    import hashlib
+    tag = hashlib.sha256((variant_source(name) + open(os.path.join(ROOT, "micro_sam_amd", "csrc", "common.h")).read()).encode()).hexdigest()[:10]
+    path, so = os.path.join(outdir, name + ".hip"), os.path.join(outdir, f"{name}.{tag}.so")
+    if os.path.exists(so) and os.path.exists(so + ".json"):          # built before from the same text (e.g. in the build container)
+        return so, json.load(open(so + ".json"))
     with open(path, "w") as fh:
         fh.write(src + STUBS)
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
@@ -166,6 +170,8 @@ def build(name: str, outdir: str):
                 m = re.search(pat, b)
                 if m:
                     res[key] = int(m.group(1))
+    with open(so + ".json", "w") as fh:
+        json.dump(res, fh)
     return so, res
 
 
@@ -176,7 +182,7 @@ def main():
     ap.add_argument("--prompts", type=int, default=1024)
     ap.add_argument("--launches", type=int, default=20)
     ap.add_argument("--build-only", action="store_true", help="compile every variant (works without a GPU) and print its register use")
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "uf_lab"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "tools", "lab_build"), help="objects are cached here by source hash (git-ignored, travels with gpurun)")
     a = ap.parse_args()
     names = [n for n in V if not a.only or n in a.only.split(",")]
     if a.list:
