@@ -97,6 +97,20 @@ V["R_ln_one_pass"] = dict(kind="close", doc="both LayerNorm sums in one exchange
 V["R_pipelined"] = dict(kind="exact", doc="tile q + 1's stage-1 MFMAs under tile q's LayerNorm2d + GELU inside every wave (tools/uf_lab_pipelined.inc); biases from LDS",
                         patches=[_PERMLANE[0], ("template <int UF_PRIO, int G16>\n__global__", "}  // namespace\n\nextern \"C\" int msam_upscale_fused_layout(",
                                                 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "uf_lab_pipelined.inc")).read())])
+# Two workgroups share a CU (one wave of each per SIMD); they are launched together and run the same stage sequence at the same speed, so
+# they stay IN PHASE: both in the MFMA phase, then both in the VALU phase.  The SQ counters of the shipped kernel (profiles/r03_pmc_sq_counters.md)
+# say exactly that: per tile and wave 1770 VALU-active + 896 MFMA-busy cycles = 2666 of the 2725 the SIMD spends - a sum, not a maximum.  A start
+# offset of half a tile period for one workgroup of each pair is preserved by the same argument (equal speeds), and lets one workgroup's MFMA
+# phase run under the other's VALU phase.  Which workgroups share a CU is the dispatcher's choice: both pairings are here.
+_LOOP_START = "    int q = 0, buf = 0;\n"
+def _dephase(cond, sleeps):
+    return [(_LOOP_START, f"    if ({cond}) {{\n        _Pragma(\"unroll\") for (int i_ = 0; i_ < {sleeps}; ++i_) __builtin_amdgcn_s_sleep(7);   // 7 x 64 cycles each\n    }}\n" + _LOOP_START)]
+V["R_dephase_half"] = dict(kind="exact", doc="second half of the grid starts ~1350 cycles late (half the tile period of a de-phased pair): co-resident workgroups i, i + grid / 2",
+                           patches=_dephase("(int)blockIdx.x >= ((int)gridDim.x >> 1)", 3))
+V["R_dephase_odd"] = dict(kind="exact", doc="odd workgroups start ~1350 cycles late: de-phases co-resident workgroups 2 j, 2 j + 1",
+                          patches=_dephase("(int)blockIdx.x & 1", 3))
+V["R_dephase_half_long"] = dict(kind="exact", doc="as R_dephase_half with ~2700 cycles (half of the 5350-cycle tile period the in-phase pair shows today)",
+                                patches=_dephase("(int)blockIdx.x >= ((int)gridDim.x >> 1)", 6))
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 V["T_no_ln_stats"] = dict(kind="timing", doc="no LayerNorm statistics (no sums, no exchange, no rsqrt); affine and GELU stay",
                           patches=[(_LN_TWO_PASS, "        const float rstd = a.eps + 1.f;\n")])
