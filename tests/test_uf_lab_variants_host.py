@@ -70,7 +70,7 @@ def case(tmp_path_factory):
     os.environ.pop("MSAM_EMU_CUS", None)
 
 
-@pytest.mark.parametrize("name", [n for n, v in lab.V.items() if v["kind"] in ("exact", "close")])
+@pytest.mark.parametrize("name", [n for n, v in lab.V.items() if v["kind"] in ("exact", "close") and v.get("host_checked", True)])
 def test_candidate_variants_compute_the_shipped_function(case, tmp_path, name):
     arrs, P, base = case
     out = _run(_host_lib(tmp_path, name), arrs, P, 3)

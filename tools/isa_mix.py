@@ -4,11 +4,11 @@
     python tools/isa_mix.py micro_sam_amd/csrc/upfused.hip 'up_fused_kernelILi1ELi1E' [-D MSAM_DEC_F16=1]
 
 For every backward branch of the matching kernel it prints the instruction classes between the loop head and the branch (MFMA, plain
-VALU, packed VALU, transcendental, LDS, VMEM, SALU) with the most frequent opcodes, and an ISSUE estimate in SIMD cycles from
-/opt/skills/guides/MI355X_MICROARCH.md: a wave's VALU instruction issues over 2 cycles (packed fp32 twice that, a transcendental 5/3 of a
-plain VALU), a 16x16x32 16-bit MFMA occupies the matrix pipe ~17 cycles (32x32x16: 32).  The estimate is what the loop would cost with
-no stalls at all - compare it with the measured time per trip to see how far a kernel is from its issue ceilings (profiles/r03_experiments.md
-section 10 does this for up_fused_kernel)."""
+VALU, packed VALU, transcendental, LDS, VMEM, SALU) with the most frequent opcodes, and an estimate of the pipe time in SIMD cycles:
+4 cycles per vector instruction (packed or not), 9 per transcendental, 16 (17) per 16x16x32 16-bit MFMA, 32 per 32x32x16 - calibrated on
+up_fused_kernel, whose tile loop this model prices at 1749 VALU + 952 MFMA cycles against SQ_ACTIVE_INST_VALU = 1770 and
+SQ_VALU_MFMA_BUSY_CYCLES = 896 per tile and wave (profiles/r03_experiments.md section 10).  In the decoder's kernels the two times ADD UP to
+the measured duration (section 11), so the sum is the number to watch."""
 import argparse
 import collections
 import os
@@ -43,11 +43,9 @@ def issue_cycles(ops):
         if k == "mfma":
             mfma += n * (32 if "32x32" in op else 17)
         elif k == "trans":
-            valu += n * 2 * 5 / 3
-        elif k == "vpk":
-            valu += n * (4 if op.endswith("_f32") else 2)
-        elif k == "valu":
-            valu += n * 2
+            valu += n * 9
+        elif k in ("vpk", "valu"):
+            valu += n * 4
     return valu, mfma
 
 
@@ -92,7 +90,7 @@ def main():
                 cls[classify(op)] += n
             valu, mfma = issue_cycles(ops)
             print(f"-- loop {mm.group(1)} .. line {i}: {sum(ops.values())} instructions  " + "  ".join(f"{k} {v}" for k, v in sorted(cls.items())))
-            print(f"   issue estimate: VALU {valu:.0f} cycles, MFMA {mfma:.0f} cycles per trip")
+            print(f"   pipe-time estimate: VALU {valu:.0f} + MFMA {mfma:.0f} = {valu + mfma:.0f} cycles per trip")
             print("   " + ", ".join(f"{op} {n}" for op, n in ops.most_common(a.top)))
 
 

@@ -97,6 +97,19 @@ V["R_ln_one_pass"] = dict(kind="close", doc="both LayerNorm sums in one exchange
 V["R_pipelined"] = dict(kind="exact", doc="tile q + 1's stage-1 MFMAs under tile q's LayerNorm2d + GELU inside every wave (tools/uf_lab_pipelined.inc); biases from LDS",
                         patches=[_PERMLANE[0], ("template <int UF_PRIO, int G16>\n__global__", "}  // namespace\n\nextern \"C\" int msam_upscale_fused_layout(",
                                                 open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "uf_lab_pipelined.inc")).read())])
+# v_exp_f16 has no packed form: the compiler emits one plain and one SDWA (source half select) instruction and packs the two results.  With
+# the destination half selected as well (dst_unused:UNUSED_PRESERVE) the two results land in one register and the v_pack_b32_f16 goes: one
+# vector instruction less per GELU pair (24 per tile).  gfx940-family hazard: a write with a destination select needs one wait state before
+# the register is read again (the second instruction preserves - reads - the other half).  Inline asm: not exercised by the host build
+# (the whole packed-fp16 GELU is restated there); the GPU run compares bit for bit with the shipped kernel.
+_EXP_PAIR = "        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};\n"
+_EXP_SDWA = ('        uint32_t ew_;\n'
+             '        asm("v_exp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\\n\\ts_nop 0\\n\\t"\n'
+             '            "v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\\n\\ts_nop 0"\n'
+             '            : "=&v"(ew_) : "v"(__builtin_bit_cast(uint32_t, q)));\n'
+             '        e = __builtin_bit_cast(h16x2_t, ew_);\n')
+V["R_exp_sdwa"] = dict(kind="exact", host_checked=False, doc="both v_exp_f16 of a GELU pair write their half of one register (SDWA destination select): no v_pack_b32_f16",
+                       patches=[(_EXP_PAIR, _EXP_SDWA)])
 # Two workgroups share a CU (one wave of each per SIMD); they are launched together and run the same stage sequence at the same speed, so
 # they stay IN PHASE: both in the MFMA phase, then both in the VALU phase.  The SQ counters of the shipped kernel (profiles/r03_pmc_sq_counters.md)
 # say exactly that: per tile and wave 1770 VALU-active + 896 MFMA-busy cycles = 2666 of the 2725 the SIMD spends - a sum, not a maximum.  A start
