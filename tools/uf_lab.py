@@ -124,6 +124,11 @@ V["R_dephase_odd"] = dict(kind="exact", doc="odd workgroups start ~1350 cycles l
                           patches=_dephase("(int)blockIdx.x & 1", 3))
 V["R_dephase_half_long"] = dict(kind="exact", doc="as R_dephase_half with ~2700 cycles (half of the 5350-cycle tile period the in-phase pair shows today)",
                                 patches=_dephase("(int)blockIdx.x >= ((int)gridDim.x >> 1)", 6))
+# combinations (the candidates are independent: in-wave overlap, one vector instruction less per GELU pair, a start offset)
+_PIPE_LOOP_START = "    int q = 0;\n"
+V["R_pipe_sdwa"] = dict(kind="exact", host_checked=False, doc="R_pipelined + R_exp_sdwa", patches=V["R_pipelined"]["patches"] + V["R_exp_sdwa"]["patches"])
+V["R_pipe_sdwa_dephase"] = dict(kind="exact", host_checked=False, doc="R_pipelined + R_exp_sdwa + the second half of the grid ~700 cycles late",
+                                patches=V["R_pipe_sdwa"]["patches"] + [(_PIPE_LOOP_START, "    if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) {\n        __builtin_amdgcn_s_sleep(11);\n    }\n" + _PIPE_LOOP_START)])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 V["T_no_ln_stats"] = dict(kind="timing", doc="no LayerNorm statistics (no sums, no exchange, no rsqrt); affine and GELU stay",
                           patches=[(_LN_TWO_PASS, "        const float rstd = a.eps + 1.f;\n")])
