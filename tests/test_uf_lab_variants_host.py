@@ -93,3 +93,22 @@ def test_pipelined_variant_across_prompts_of_one_workgroup(tmp_path):
             assert np.array_equal(_run(lib, arrs, P, nmask), _run(base_lib, arrs, P, nmask))
     finally:
         os.environ.pop("MSAM_EMU_CUS", None)
+
+
+def test_the_host_build_notices_a_missing_barrier(tmp_path):
+    """Negative control for the checks above: the waves of a workgroup are concurrent host threads, so the pipelined variant WITHOUT its per-tile
+    barrier (staging buffers and output patches reused while other waves still read them) does not reproduce the shipped kernel's output."""
+    os.environ["MSAM_EMU_CUS"] = "1"
+    try:
+        good = lab.V["R_pipelined"]["patches"]
+        text = good[1][2]
+        barrier = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
+        assert text.count(barrier) == 1
+        lab.V["_no_barrier"] = dict(kind="exact", doc="", patches=[good[0], (good[1][0], good[1][1], text.replace(barrier, "        (void)0;\n"))])
+        arrs, P = _inputs(2, 5), 2
+        base = _run(_host_lib(tmp_path / "b", "base"), arrs, P, 3)
+        out = _run(_host_lib(tmp_path / "n", "_no_barrier"), arrs, P, 3)
+        assert (out != base).mean() > 0.05
+    finally:
+        lab.V.pop("_no_barrier", None)
+        os.environ.pop("MSAM_EMU_CUS", None)
