@@ -129,6 +129,9 @@ _PIPE_LOOP_START = "    int q = 0;\n"
 V["R_pipe_sdwa"] = dict(kind="exact", host_checked=False, doc="R_pipelined + R_exp_sdwa", patches=V["R_pipelined"]["patches"] + V["R_exp_sdwa"]["patches"])
 V["R_pipe_sdwa_dephase"] = dict(kind="exact", host_checked=False, doc="R_pipelined + R_exp_sdwa + the second half of the grid ~700 cycles late",
                                 patches=V["R_pipe_sdwa"]["patches"] + [(_PIPE_LOOP_START, "    if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) {\n        __builtin_amdgcn_s_sleep(11);\n    }\n" + _PIPE_LOOP_START)])
+_PIPE_BARRIER = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
+V["T_pipe_no_barrier"] = dict(kind="timing", doc="R_pipelined without its per-tile barrier (racy): the barrier's share in the pipelined form",
+                              patches=V["R_pipelined"]["patches"] + [(_PIPE_BARRIER, "        (void)0;\n")])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 V["T_no_ln_stats"] = dict(kind="timing", doc="no LayerNorm statistics (no sums, no exchange, no rsqrt); affine and GELU stay",
                           patches=[(_LN_TWO_PASS, "        const float rstd = a.eps + 1.f;\n")])
