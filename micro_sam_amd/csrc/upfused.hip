@@ -10,10 +10,8 @@
 //   stage 2   Y^T [(sub2, c2)][pixel] = W2 . G1        A = W2 (LDS, k-permuted image), B = G1 (registers)
 //             + bias, GELU, pack to fp16
 //   stage 3   out^T [mask][pixel] = H . G2             A = hyper weights of the prompt (fp16 hi + lo), B = G2 as fp16 (registers)
-// 4-wave workgroups on 16-token tiles, wave = sub-pixel of stage 1, two workgroups per CU: the stages of a wave are a long
-// serial chain (MFMA -> LayerNorm -> GELU -> MFMA -> GELU -> MFMA), so independent workgroups in different phases keep
-// both the MFMA and the VALU pipes busy (one 8-wave workgroup ran all waves in lock step: 2.05 ms vs this form).  One
-// barrier per tile (tile staging double buffer + output patch double buffer).
+// 4-wave workgroups on 16-token tiles, wave = sub-pixel of stage 1, two workgroups per CU (one 8-wave workgroup ran all waves in lock
+// step: 2.05 ms vs this form; one workgroup per CU: +17 %).  One barrier per tile (tile staging double buffer + output patch double buffer).
 #include "common.h"
 #include "../../include/msam_hip.h"
 
@@ -43,6 +41,15 @@ struct UpArgs {
     int blocked;                         // keys in the blocked layout of decfold_tok.hip ([16-token tile][k-step][lane][8]) instead of row-major
 };
 
+// sum over the wave's four 16-lane rows, in every lane, without the LDS crossbar: v_permlane16_swap exchanges the odd rows of its first
+// operand with the even rows of its second (rows r0 r1 r2 r3 -> (r0 r0 r2 r2), (r1 r1 r3 r3)), v_permlane32_swap the same for 32-lane
+// halves; the additions are the ones the xor-16 / xor-32 exchange performs ((r0 + r1) + (r2 + r3)), so the result is the same bits.
+MSAM_DEVINL float wave_rows_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float t = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 // erf-GELU of two values in PACKED fp16 arithmetic (G16 instantiation, fp16 decoder build only).  The result of either GELU
 // is rounded to fp16 anyway - it is the B operand of the next MFMA - so the polynomial can run on v_pk_fma_f16 (two values per
 // single-pass instruction; v_pk_fma_f32 takes two passes) and end as the packed operand word: convert, max, fma, 3 fma,
@@ -81,12 +88,29 @@ MSAM_DEVINL uint32_t gelu_pk_h(float x0, float x1) {
         const u16x2_t sh = __builtin_bit_cast(u16x2_t, sm) << (unsigned short)10;
         e = __builtin_bit_cast(h16x2_t, (u16x2_t)(__builtin_bit_cast(u16x2_t, pz) + sh));
     } else {
-        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};
+        // v_exp_f16 has no packed form.  Both exponentials write their half of ONE register (SDWA destination select, the other half
+        // preserved): no v_pack_b32_f16 behind them, one vector instruction less per pair (24 per tile).  gfx940-family hazard: a write
+        // with a destination select needs one wait state before the register is read again (the second instruction reads it).
+        uint32_t ew_;
+        asm("v_exp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\ts_nop 0\n\t"
+            "v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"
+            : "=&v"(ew_) : "v"(__builtin_bit_cast(uint32_t, q)));
+        e = __builtin_bit_cast(h16x2_t, ew_);
     }
     const h16x2_t g = r - t * e;
     return __builtin_bit_cast(uint32_t, g);
 }
 
+// The tile loop is software-pipelined INSIDE every wave (round 4; measured as tools/uf_lab.py "R_pipe_sdwa_dephase", bit-identical to the
+// stage-after-stage form of rounds 1 - 3 and 6 % shorter, profiles/r04_experiments.md section 1):
+//     phase A   8 x { B fragment of tile q + 1, 4 MFMAs into `un` }  interleaved with  { sums, centring, rstd, affine + GELU of tile q (`uc`) }
+//     phase B   stages 2 and 3 of tile q (a software pipeline over the four second-level sub-pixels)
+// so that every MFMA of phase A has independent VALU work of the same wave behind it.  The LayerNorm sums go through v_permlane16/32_swap
+// (the same additions as an xor-16 / xor-32 exchange, no LDS crossbar round trip).  Registers: the stage-1 bias is read from the LDS
+// parameter block instead of being held (16 VGPRs, 4 more ds_read_b128 per tile), a second accumulator set is added (16).
+// LDS: tile q + 1 is read from one staging buffer while tile q + 2 is written into the other (free since the previous barrier).
+// The second half of the grid starts ~700 cycles late: co-resident workgroups (i, i + grid / 2) then run a quarter tile period out of
+// phase instead of competing for the same pipe in the same stage.
 template <int UF_PRIO, int G16>
 __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
@@ -101,10 +125,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     if (nq <= 0) return;
 
     for (int i = tid; i < 416; i += NTHR) prm[i] = i < 256 ? a.b1[i] : i < 320 ? a.lnw[i - 256] : i < 384 ? a.lnb[i - 320] : a.b2[i - 384];
-    // W2 image: row (sub2, c2), 16-byte chunk (kk, g) = { W2[row][32kk + 4g .. +3], W2[row][32kk + 16 + 4g .. +3] }: the k-slot
-    // order in which stage 1 leaves its results; chunk' = chunk ^ ((row >> 1) & 7)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {                            // W2 image: see the shipped kernel
         const int id = j * NTHR + tid, row = id >> 3, ch = id & 7, kk = ch >> 2, g = ch & 3;
         const uint2 lo = *(const uint2*)(a.w2 + row * 64 + kk * 32 + g * 4);
         const uint2 hi = *(const uint2*)(a.w2 + row * 64 + kk * 32 + 16 + g * 4);
@@ -118,12 +140,11 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             w1f[rt][ks] = *(const uint4*)(a.w1 + (long)(sub * 64 + rt * 16 + fr) * C + ks * 32 + fg * 8);
     wait_vmem_all();
 
-    // ---- staging: 2 chunks of the stream tile per thread
     uint4 ra0, ra1, rb0, rb1;
     int kdst[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int id = i * NTHR + tid;                       // 16-byte chunk of the (contiguous) 16-token tile -> token row, chunk c
+        const int id = i * NTHR + tid;
         const int row = a.blocked ? id & 15 : id >> 5, c = a.blocked ? (id >> 6) * 4 + ((id >> 4) & 3) : id & 31;
         kdst[i] = (c >> 2) * SUB_BYTES + row * 64 + (((c & 3) ^ ((row >> 2) & 3)) << 4);
     }
@@ -146,31 +167,46 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         *(uint4*)(b_ + kdst[0]) = r0_; *(uint4*)(b_ + kdst[1]) = r1_;                              \
     } while (0)
 
-    // biases as the initial accumulator values (C operand of the first MFMA of a chain): no separate add
-    f32x4_t b1v[4], b2a, b2b;
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        const float4 b4 = *(const float4*)(a.b1 + sub * 64 + rt * 16 + fg * 4);
-        b1v[rt] = f32x4_t{b4.x, b4.y, b4.z, b4.w};
-    }
+    const int boff = fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);                     // stage-1 B fragment (token fr, k-step slot fg)
+    const int w2off = fr * 128;
+    const int w2sw = (fr >> 1) & 7;
+    const float* const b1p = prm + sub * 64 + fg * 4;                             // + 16 rt: the stage-1 bias of rows 16 rt + 4 fg ..
+    uint4 hh = make_uint4(0, 0, 0, 0), hl = hh;
+    f32x4_t b2a, b2b;                                                             // stage-2 bias: the initial accumulator of every chain
     {
         const float4 ba = *(const float4*)(a.b2 + fg * 4), bb = *(const float4*)(a.b2 + 16 + fg * 4);
         b2a = f32x4_t{ba.x, ba.y, ba.z, ba.w}; b2b = f32x4_t{bb.x, bb.y, bb.z, bb.w};
     }
     wait_vmem_all();
-    const int boff = fr * 64 + ((fg ^ ((fr >> 2) & 3)) << 4);                     // stage-1 B fragment (token fr, k-step slot fg)
-    const int w2off = fr * 128;                                                   // + row-tile * 2048, chunk swizzled below
-    const int w2sw = (fr >> 1) & 7;
-    uint4 hh = make_uint4(0, 0, 0, 0), hl = hh;                                   // hyper weights of the prompt (A operand)
 
+    // stage 1 of one tile, alone (prologue only)
+    auto stage1 = [&](const unsigned char* B, f32x4_t (&u)[4]) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) u[rt] = *(const f32x4_t*)(b1p + rt * 16);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const uint4 kf = *(const uint4*)(B + boff + ks * SUB_BYTES);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16d(w1f[rt][ks], kf, u[rt]);
+        }
+    };
+
+    // tiles 0 and 1 staged, tile 2 in flight, stage 1 of tile 0 done
+    f32x4_t ua[4], ub[4];
     UF_LOAD(ra0, ra1, 0);
+    UF_LOAD(rb0, rb1, min(1, nq - 1));
+    __syncthreads();                                         // prm / W2 image written
     UF_STORE(ra0, ra1, 0);
-    UF_LOAD(ra0, ra1, min(1, nq - 1));
+    UF_STORE(rb0, rb1, 1);
+    UF_LOAD(ra0, ra1, min(2, nq - 1));
     __syncthreads();
+    stage1(lds, ua);
+    __syncthreads();                                         // every wave is done with buffer 0 before tile 2 goes there
 
-    int q = 0, buf = 0;
-    auto iteration = [&](uint4& p0, uint4& p1, uint4& f0, uint4& f1) {
-        UF_LOAD(f0, f1, min(q + 2, nq - 1));
+    if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) __builtin_amdgcn_s_sleep(11);        // ~700 cycles: see the note above the kernel
+    int q = 0;
+    auto iteration = [&](uint4& p0, uint4& p1, uint4& f0, uint4& f1, f32x4_t (&uc)[4], f32x4_t (&un)[4]) {
+        UF_LOAD(f0, f1, min(q + 3, nq - 1));
         int p, key0;
         tile_pos(q, p, key0);
         if ((q & (TPI - 1)) == 0) {                      // new work item: hyper weights, rows = masks, k-slots = c2
@@ -181,7 +217,6 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
                 h8[0] = x0.x; h8[1] = x0.y; h8[2] = x0.z; h8[3] = x0.w; h8[4] = x1.x; h8[5] = x1.y; h8[6] = x1.z; h8[7] = x1.w;
             }
             wait_vmem_all();
-            // fp16 hi + lo (22 significant bits): stage 3 runs on the fp16 MFMA
             hh = make_uint4(pack2h(h8[0], h8[1]), pack2h(h8[2], h8[3]), pack2h(h8[4], h8[5]), pack2h(h8[6], h8[7]));
             const uint32_t hw_[4] = {hh.x, hh.y, hh.z, hh.w};
             float l8[8];
@@ -189,55 +224,63 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             for (int i = 0; i < 4; ++i) { l8[2 * i] = h8[2 * i] - h2f(hw_[i] & 0xffff); l8[2 * i + 1] = h8[2 * i + 1] - h2f(hw_[i] >> 16); }
             hl = make_uint4(pack2h(l8[0], l8[1]), pack2h(l8[2], l8[3]), pack2h(l8[4], l8[5]), pack2h(l8[6], l8[7]));
         }
-        const unsigned char* B = lds + buf * XT_BYTES;
-        // ---- stage 1: U^T rows (sub, c1 = 16 rt + 4 fg + r), column token fr
-        f32x4_t u[4];
+        // ---- phase A: stage 1 of tile q + 1 (staging buffer (q + 1) & 1) under LayerNorm2d + GELU of tile q
+        const unsigned char* Bn = lds + ((q + 1) & 1) * XT_BYTES;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) u[rt] = b1v[rt];
-        // the MFMA-only phase of this wave gets issue priority: its 32 MFMAs go out back to back and the VALU phase of the
-        // SIMD's other wave (another workgroup, in a different phase) fills the slots in between
-        __builtin_amdgcn_s_setprio(UF_PRIO);
+        for (int rt = 0; rt < 4; ++rt) un[rt] = *(const f32x4_t*)(b1p + rt * 16);
+        // (the empty asm makes the k-step's operand fragment depend on `tok_`, the last value of the VALU chunk in front of it: instruction
+        //  selection cannot move the MFMA group above that chunk; the sched_barrier keeps the machine scheduler from undoing the placement)
+#define UF_S1(ks_, tok_)                                                                           \
+        do {                                                                                       \
+            uint4 kf_ = *(const uint4*)(Bn + boff + (ks_) * SUB_BYTES);                            \
+            asm volatile("" : "+v"(kf_.x), "+v"(tok_));                                            \
+            _Pragma("unroll") for (int rt_ = 0; rt_ < 4; ++rt_) un[rt_] = mfma16d(w1f[rt_][ks_], kf_, un[rt_]); \
+        } while (0)
+        // (sched_barrier: the MFMA group of a k-step and the VALU chunk next to it stay together - the scheduler otherwise moves the
+        //  GELUs behind all 32 MFMAs, which is the shipped order again)
+        { int first_ = 0; UF_S1(0, first_); }
+        // LayerNorm2d statistics in one pass: both sums before either exchange (the two exchanges are independent: one latency
+        // instead of two in a row), variance = E[u^2] - mean^2 in fp32 (measured -6 % on the launch, profiles/r04_experiments.md)
+        float s = 0.f, ss = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const uint4 kf = *(const uint4*)(B + boff + ks * SUB_BYTES);
+        for (int rt = 0; rt < 4; ++rt) {
+            s += (uc[rt][0] + uc[rt][1]) + (uc[rt][2] + uc[rt][3]);
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16d(w1f[rt][ks], kf, u[rt]);
+            for (int r = 0; r < 4; ++r) ss += uc[rt][r] * uc[rt][r];
         }
-        __builtin_amdgcn_s_setprio(0);
-        float s = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-        const float mean = s * (1.f / 64.f);
-        float ss = 0.f;
+        s = wave_rows_sum(s); ss = wave_rows_sum(ss);
+        float mean = s * (1.f / 64.f);
+        __builtin_amdgcn_sched_barrier(0);
+        UF_S1(1, mean);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { u[rt][r] -= mean; ss += u[rt][r] * u[rt][r]; }
-        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-        const float rstd = rsqrtf(ss * (1.f / 64.f) + a.eps);
+            for (int r = 0; r < 4; ++r) uc[rt][r] -= mean;
+        __builtin_amdgcn_sched_barrier(0);
+        UF_S1(2, ss);
+        float rstd = rsqrtf(fmaxf(ss * (1.f / 64.f) - mean * mean, 0.f) + a.eps);
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t g1w[4][2];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
+            if (rt == 0) UF_S1(3, rstd); else UF_S1(3 + rt, g1w[rt - 1][1]);
             const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
             if (G16) {
-                g1w[rt][0] = gelu_pk_h<G16>(u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y);
-                g1w[rt][1] = gelu_pk_h<G16>(u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w);
+                g1w[rt][0] = gelu_pk_h<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y);
+                g1w[rt][1] = gelu_pk_h<G16>(uc[rt][2] * rstd * g4.z + b4.z, uc[rt][3] * rstd * g4.w + b4.w);
             } else {
-                const f32x2_t g01 = gelu_erf2(f32x2_t{u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y});
-                const f32x2_t g23 = gelu_erf2(f32x2_t{u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w});
+                const f32x2_t g01 = gelu_erf2(f32x2_t{uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y});
+                const f32x2_t g23 = gelu_erf2(f32x2_t{uc[rt][2] * rstd * g4.z + b4.z, uc[rt][3] * rstd * g4.w + b4.w});
                 g1w[rt][0] = pack2d(g01.x, g01.y); g1w[rt][1] = pack2d(g23.x, g23.y);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        UF_S1(7, g1w[3][1]);
+#undef UF_S1
         uint4 g1[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) g1[kk] = make_uint4(g1w[2 * kk][0], g1w[2 * kk][1], g1w[2 * kk + 1][0], g1w[2 * kk + 1][1]);
-        // ---- stages 2 and 3, one second-level sub-pixel at a time
-        // The four second-level sub-pixels are independent chains (LDS read -> MFMA -> GELU -> MFMA).  They are written as a
-        // software pipeline in ONE basic block - stage-2 MFMAs of sub-pixel s+1 ahead of the GELUs of s, the hyper product of
-        // s behind them - so that every MFMA result has a block of independent VALU work between its issue and its first
-        // use (no dependency stalls, MFMA pipe and VALU overlap inside the wave); results stay in registers and are stored
-        // by a single predicated block (a branch per sub-pixel cut the chains into separate basic blocks).
+        // ---- phase B: stages 2 and 3 of tile q, one second-level sub-pixel at a time (the shipped pipeline)
         float* pt = patch[q & 1];
         f32x4_t ya[4], yb[4], ov[4];
         uint4 gh[4];
@@ -252,8 +295,6 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             }
             ya[s2] = xa; yb[s2] = xb;
         };
-        // GELU (two values per packed instruction), fp16 for the hyper product (11-bit significand: the product keeps ~fp32
-        // accuracy together with the hi + lo hyper weights; a bf16 operand would not)
         auto act2 = [&](int s2) {
             if (G16) {
                 gh[s2] = make_uint4(gelu_pk_h<G16>(ya[s2][0], ya[s2][1]), gelu_pk_h<G16>(ya[s2][2], ya[s2][3]),
@@ -288,20 +329,19 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
                 pt[(2 * 4 + yl) * 64 + xl] = ov[sub2][2];
             }
         }
-        UF_STORE(p0, p1, buf ^ 1);
-        __syncthreads();                                 // next tile staged; output patch of this tile complete
+        UF_STORE(p0, p1, q & 1);                         // tile q + 2 into the buffer tile q was read from (free since the last barrier)
+        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete
         if (tid < 64 * a.nmask) {
             const int mk = tid >> 6, rem = tid & 63, yl = rem >> 4, x4 = rem & 15;
             const int ty = key0 >> 6, tx0 = key0 & 63;
             *(float4*)(a.out + (((long)p * a.nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + x4 * 4) =
                 *(const float4*)&pt[(mk * 4 + yl) * 64 + x4 * 4];
         }
-        buf ^= 1;
     };
     while (true) {
-        iteration(ra0, ra1, rb0, rb1);
+        iteration(ra0, ra1, rb0, rb1, ua, ub);
         if (++q >= nq) break;
-        iteration(rb0, rb1, ra0, ra1);
+        iteration(rb0, rb1, ra0, ra1, ub, ua);
         if (++q >= nq) break;
     }
 #undef UF_LOAD

@@ -37,10 +37,13 @@ def _d16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(_lib.decoder_dtype()).contiguous()
 
 
-def _versions(params) -> int:
-    """Sum of the parameters' in-place version counters: changes whenever an optimizer step, ``copy_`` or ``load_state_dict``
-    writes a parameter, so cached 16-bit operand copies are rebuilt exactly when they went stale."""
-    return sum(p._version for p in params)
+def _param_key(*modules) -> int:
+    """Identity of the parameter set behind cached 16-bit operand copies: per parameter the object, its in-place version counter
+    (optimizer step, ``copy_``, ``load_state_dict``), its storage address and its device - so a replaced ``Parameter``, a
+    ``param.data = ...`` assignment (``module.to()`` / ``half()`` keep the old counter) and a move to another device rebuild the
+    copies as well.  The parameters are re-read on every call.  NOT seen: writes through ``p.data`` that keep the
+    storage (``p.data.mul_()``, an EMA written through ``.data``) - such writers call the module's public ``invalidate()``."""
+    return hash(tuple((id(q), q._version, q.data_ptr(), q.device.index) for m in modules for q in m.parameters()))
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -149,7 +152,7 @@ class ImageEncoderViT(nn.Module):
 
     def _prepare(self):
         if self._prep is not None:
-            if _versions(self._prep_params) == self._prep_versions:
+            if _param_key(self) == self._prep_versions:
                 return self._prep
             self._prep = None       # a parameter was updated in place (optimizer step, copy_): rebuild the operand copies
         dev = self.pos_embed.device
@@ -227,8 +230,7 @@ class ImageEncoderViT(nn.Module):
         p.use_glds = int(self.use_glds)
         p.fp8 = 1 if self.precision == "fp8" else 0
         self._prep = (p, keep)
-        self._prep_params = tuple(self.parameters())
-        self._prep_versions = _versions(self._prep_params)
+        self._prep_versions = _param_key(self)
         return self._prep
 
     def _get_workspace(self, params, B: int) -> torch.Tensor:
@@ -439,7 +441,7 @@ class Sam(nn.Module):
     # -- decoder plumbing
     def _prepare_decoder(self):
         if self._dec is not None:
-            if _versions(self._dec_params) == self._dec_versions:
+            if _param_key(self.prompt_encoder, self.mask_decoder) == self._dec_versions:
                 return self._dec
             self._dec = None        # a parameter was updated in place (optimizer step, copy_): rebuild the 16-bit copies / tables
             self._img_state = None
@@ -517,8 +519,7 @@ class Sam(nn.Module):
         _lib.check(lib.msam_decoder_prepare_const(C.byref(p), consts.data_ptr(), _lib.stream_ptr()),
                    "msam_decoder_prepare_const")
         self._dec = (p, keep, consts)
-        self._dec_params = tuple(self.prompt_encoder.parameters()) + tuple(self.mask_decoder.parameters())
-        self._dec_versions = _versions(self._dec_params)
+        self._dec_versions = _param_key(self.prompt_encoder, self.mask_decoder)
         return self._dec
 
     def _dense_pe(self) -> torch.Tensor:

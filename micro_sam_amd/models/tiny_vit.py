@@ -220,8 +220,7 @@ class TinyViT(nn.Module):
     def set_split_io(self, on: bool) -> None:
         pass
 
-    @torch.no_grad()
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def _run(self, x: torch.Tensor) -> torch.Tensor:
         assert x.dim() == 4 and x.shape[1:] == (3, IMG_SIZE, IMG_SIZE), x.shape
         x = x.to(device=self.neck[0].weight.device, dtype=torch.float32)
         x = self.patch_embed(x)
@@ -229,6 +228,26 @@ class TinyViT(nn.Module):
             x = layer(x)
         B, _, C = x.shape
         return self.neck(x.view(B, GRID, GRID, C).permute(0, 3, 1, 2))
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Inference: no tape, and the BatchNorms ALWAYS normalise with their running statistics - also when a trainer has put the
+        model into train() mode with this encoder frozen (a no_grad forward in train mode would normalise with batch statistics and
+        overwrite the checkpoint's running_mean / running_var on every step)."""
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.training]
+        for m in bns:
+            m.training = False
+        try:
+            return self._run(x)
+        finally:
+            for m in bns:
+                m.training = True
+
+    def forward_taped(self, x: torch.Tensor) -> torch.Tensor:
+        """The same operators under autograd (fine-tuning the encoder, reference ``TrainableSAM.image_embeddings_oft`` on mobile_sam's
+        ``TinyViT``): BatchNorm behaves as ``self.training`` says - batch statistics + running-statistics update under ``train()``,
+        exactly what torch does in the reference."""
+        return self._run(x)
 
     @torch.no_grad()
     def forward_u8(self, images: torch.Tensor) -> torch.Tensor:

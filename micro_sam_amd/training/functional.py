@@ -71,7 +71,8 @@ def _weight16(weight: torch.Tensor):
         return w16, w16.t().contiguous()
     key = (id(base), tuple(weight.shape), tuple(weight.stride()), weight.storage_offset())
     hit = _W16.get(key)
-    if hit is not None and hit[0]() is base and hit[1] == base._version:
+    stamp = (base._version, base.data_ptr(), base.device.index)       # param.data = ... / .to(device) keep the counter: address + device too
+    if hit is not None and hit[0]() is base and hit[1] == stamp:
         return hit[2], hit[3]
     if len(_W16) > 4096:                     # parameters of discarded models
         for k in [k for k, v in _W16.items() if v[0]() is None]:
@@ -80,7 +81,7 @@ def _weight16(weight: torch.Tensor):
     N, K = w16.shape
     w16t = _pad_to(w16.t(), (K + 127) // 128 * 128, (N + 63) // 64 * 64)          # padded to the product kernel's tiles once, not per call
     w16 = _pad_to(w16, (N + 127) // 128 * 128, (K + 63) // 64 * 64)
-    _W16[key] = (weakref.ref(base), base._version, w16, w16t)
+    _W16[key] = (weakref.ref(base), stamp, w16, w16t)
     return w16, w16t
 
 

@@ -133,7 +133,10 @@ class TrainableSAM(nn.Module):
         for i in range(len(batched_inputs)):
             batched_inputs[i]["input_size"] = input_size
         if self._trains(self.sam.image_encoder):
-            image_embeddings = image_encoder_forward(self.sam.image_encoder, input_images)      # with a tape
+            if hasattr(self.sam.image_encoder, "forward_taped"):       # vit_t: TinyViT is a tree of torch operators, autograd is its tape
+                image_embeddings = self.sam.image_encoder.forward_taped(input_images)
+            else:
+                image_embeddings = image_encoder_forward(self.sam.image_encoder, input_images)      # with a tape
         else:
             # (the inference kernels' operand copies rebuild themselves when a parameter's version counter moved:
             # modeling.ImageEncoderViT._prepare / Sam._prepare_decoder)

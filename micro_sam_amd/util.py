@@ -490,17 +490,51 @@ def _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_u
         features = dev_features
         if not keep_on_device:
             # the reference's in-memory result is a host array (util.py:1011-1013); it is filled batch by batch through a page-locked
-            # staging buffer.  The device copy stays alongside under the extension key "features_device" (<= 4 GiB): set_precomputed
-            # takes slice i from it instead of uploading the 4 MiB it has just downloaded (the host array remains the contract).
+            # staging buffer.  The returned dict holds exactly the reference's keys.  The device copy (<= 4 GiB) is remembered OUTSIDE
+            # the dict, weakly keyed by the host array (_device_shadow): set_precomputed takes slice i from it instead of uploading
+            # the 4 MiB it has just downloaded - only while the host array is still that object, at that address, with those values.
             features = np.empty(tuple(dev_features.shape), dtype=np.float32)
             step = max(1, batch_size)
             for z0 in range(0, n_slices, step):
                 fetch_to_host(dev_features[z0:z0 + step], out=features[z0:z0 + step], tag="emb")
-            out = {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}
             if dev_features.numel() * 4 <= (4 << 30):
-                out["features_device"] = dev_features
-            return out
+                _remember_device_shadow(features, dev_features)
+            return {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}
     return {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}
+
+
+# host embedding array -> the device tensor it was downloaded from (the shadow is no dict entry, dies with the host array, and is
+# used only after a check that the caller has not edited / replaced the slice it is asked for)
+_DEVICE_SHADOWS: Dict[int, tuple] = {}
+_SHADOW_STRIDE = 4099            # 256 samples of a [1, 256, 64, 64] slice
+
+
+def _slice_samples(host: np.ndarray, i: Optional[int]) -> np.ndarray:
+    sel = host if i is None else host[i]
+    return np.ascontiguousarray(sel.reshape(-1)[::_SHADOW_STRIDE])
+
+
+def _remember_device_shadow(host: np.ndarray, dev: torch.Tensor) -> None:
+    import weakref
+    key = id(host)
+    n = host.shape[0] if host.ndim == 5 else 1
+    samples = np.stack([_slice_samples(host, z if host.ndim == 5 else None) for z in range(n)])
+    _DEVICE_SHADOWS[key] = (weakref.ref(host, lambda _r, k=key: _DEVICE_SHADOWS.pop(k, None)), host.ctypes.data, tuple(host.shape),
+                            samples, dev)
+
+
+def _device_shadow(host, i: Optional[int]) -> Optional[torch.Tensor]:
+    """The device copy of slice ``i`` of a host embedding array this process computed, or None (unknown array, other address /
+    shape, or sampled values that differ from what was downloaded: the caller masked, reloaded or replaced the data)."""
+    if not isinstance(host, np.ndarray):
+        return None
+    hit = _DEVICE_SHADOWS.get(id(host))
+    if hit is None or hit[0]() is not host or hit[1] != host.ctypes.data or hit[2] != tuple(host.shape):
+        return None
+    z = 0 if (i is None or host.ndim != 5) else int(i)
+    if not np.array_equal(_slice_samples(host, i if host.ndim == 5 else None), hit[3][z]):
+        return None
+    return hit[4][:] if i is None else hit[4][i]
 
 
 def _get_tiles_in_mask(mask, tiling, halo, z=None):
@@ -673,10 +707,9 @@ def set_precomputed(predictor: SamPredictor, image_embeddings: ImageEmbeddings, 
         raise ValueError("The data is 3D so an index i is needed.")
     elif features.ndim == 4 and i is not None:
         raise ValueError("The data is 2D so an index is not needed.")
-    shadow = image_embeddings.get("features_device") if isinstance(image_embeddings, dict) else None
-    if torch.is_tensor(shadow) and shadow.is_cuda and tuple(shadow.shape) == tuple(features.shape):
-        features = shadow                      # the device copy precompute_image_embeddings kept (same values as the host array)
-    sel = features[:] if i is None else features[i]
+    sel = _device_shadow(features, i)           # the device copy precompute_image_embeddings kept, if the host slice is unchanged
+    if sel is None:
+        sel = features[:] if i is None else features[i]
     predictor.features = sel.to(device) if torch.is_tensor(sel) else torch.from_numpy(np.asarray(sel[:])).to(device)
     predictor.original_size = tuple(image_embeddings["original_size"])
     predictor.input_size = tuple(image_embeddings["input_size"])

@@ -82,33 +82,30 @@ def test_candidate_variants_compute_the_shipped_function(case, tmp_path, name):
         assert err.max() <= 2e-3 * scale and err.mean() <= 1e-4 * scale, (err.max() / scale, err.mean() / scale)
 
 
-def test_pipelined_variant_across_prompts_of_one_workgroup(tmp_path):
+def test_pipelined_loop_across_prompts_of_one_workgroup(tmp_path):
     """Three whole prompts over two workgroups: the first one runs prompts 0 and 2 back to back (512 tiles: the prefetched stage 1 crosses the
-    prompt boundary, the hyper weights change under it), one and two masks."""
+    prompt boundary, the hyper weights change under it), one and two masks - against each prompt launched alone."""
     os.environ["MSAM_EMU_CUS"] = "1"
     try:
         arrs, P = _inputs(3, 12), 3
-        base_lib, lib = _host_lib(tmp_path / "b", "base"), _host_lib(tmp_path / "p", "R_pipelined")
+        lib = _host_lib(tmp_path / "b", "base")
         for nmask in (1, 2):
-            assert np.array_equal(_run(lib, arrs, P, nmask), _run(base_lib, arrs, P, nmask))
+            together = _run(lib, arrs, P, nmask)
+            for p in range(P):
+                alone = _run(lib, [np.ascontiguousarray(arrs[0][p:p + 1])] + arrs[1:7] + [np.ascontiguousarray(arrs[7][p:p + 1])], 1, nmask)
+                assert np.array_equal(together[p:p + 1], alone), p
     finally:
         os.environ.pop("MSAM_EMU_CUS", None)
 
 
 def test_the_host_build_notices_a_missing_barrier(tmp_path):
-    """Negative control for the checks above: the waves of a workgroup are concurrent host threads, so the pipelined variant WITHOUT its per-tile
+    """Negative control for the checks above: the waves of a workgroup are concurrent host threads, so the kernel WITHOUT its per-tile
     barrier (staging buffers and output patches reused while other waves still read them) does not reproduce the shipped kernel's output."""
     os.environ["MSAM_EMU_CUS"] = "1"
     try:
-        good = lab.V["R_pipelined"]["patches"]
-        text = good[1][2]
-        barrier = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
-        assert text.count(barrier) == 1
-        lab.V["_no_barrier"] = dict(kind="exact", doc="", patches=[good[0], (good[1][0], good[1][1], text.replace(barrier, "        (void)0;\n"))])
         arrs, P = _inputs(2, 5), 2
         base = _run(_host_lib(tmp_path / "b", "base"), arrs, P, 3)
-        out = _run(_host_lib(tmp_path / "n", "_no_barrier"), arrs, P, 3)
+        out = _run(_host_lib(tmp_path / "n", "T_no_barrier"), arrs, P, 3)
         assert (out != base).mean() > 0.05
     finally:
-        lab.V.pop("_no_barrier", None)
         os.environ.pop("MSAM_EMU_CUS", None)

@@ -40,3 +40,29 @@ def test_tinyvit_module_matches_the_restated_architecture():
     xf = torch.nn.functional.pad(xf, (0, 0, 0, 324))
     with torch.no_grad():
         assert (enc.forward_u8(img) - enc(xf)).abs().max().item() < 1e-5
+
+
+def test_tinyvit_under_a_trainer_keeps_its_running_statistics_and_has_a_tape():
+    """a trainer calls model.train(); the no-tape forward of a FROZEN TinyViT must keep normalising with the
+    checkpoint's running statistics (and must not overwrite them), and a trainable TinyViT gets its gradients through forward_taped
+    (reference: mobile_sam's TinyViT is fine-tuned end to end by training/sam_trainer.py)."""
+    sd = synthetic_state_dict("vit_t", 0)
+    sam = modeling.build_sam("vit_t")
+    sam.load_state_dict(sd)
+    enc = sam.image_encoder
+    bn = next(m for m in enc.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    x = torch.randn(1, 3, 1024, 1024, generator=torch.Generator().manual_seed(2))
+    enc.eval()
+    ref = enc(x)
+    mean0, count0 = bn.running_mean.clone(), int(bn.num_batches_tracked)
+    enc.train()
+    out = enc(x)
+    assert torch.equal(out, ref)                                        # running statistics, not batch statistics
+    assert torch.equal(bn.running_mean, mean0) and int(bn.num_batches_tracked) == count0 and bn.training
+    # the taped forward: gradients reach the first convolution; train() mode updates the running statistics as torch does
+    y = enc.forward_taped(x)
+    assert y.requires_grad
+    y.square().mean().backward()
+    g = enc.patch_embed.seq[0].c.weight.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert int(bn.num_batches_tracked) == count0 + 1

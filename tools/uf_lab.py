@@ -5,7 +5,7 @@ its own shared object (the library itself is untouched) and timed on one GPU aga
 
     python tools/uf_lab.py                      # on the GPU box: builds every variant with hipcc, times it, compares results with the base
     python tools/uf_lab.py --list               # anywhere: names, kinds and what each variant is for
-    python tools/uf_lab.py --only base,R_permlane --prompts 256
+    python tools/uf_lab.py --only base,R_exp_pair --prompts 256
 
 Two kinds of variants (profiles/r03_experiments.md section 10 is why they exist: the tile loop's MFMA and VALU issue times are ~30 % of the
 measured time each, so the first thing to learn is what the waves WAIT for):
@@ -29,128 +29,31 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "micro_sam_amd", "csrc", "upfused.hip")
 
-_HELPER_ANCHOR = "// erf-GELU of two values in PACKED fp16 arithmetic (G16 instantiation, fp16 decoder build only)."
-_ROWS_SUM = '''// sum over the wave's four 16-lane rows, in every lane, without the LDS crossbar: v_permlane16_swap exchanges the odd rows of its first
-// operand with the even rows of its second (rows r0 r1 r2 r3 -> (r0 r0 r2 r2), (r1 r1 r3 r3)), v_permlane32_swap the same for 32-lane
-// halves; the additions are the ones the xor-16 / xor-32 exchange performs ((r0 + r1) + (r2 + r3)), so the result is the same bits.
-MSAM_DEVINL float wave_rows_sum(float v) {
-    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    const float t = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
-    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-'''
-_SUM_S = "        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);\n"
-_SUM_SS = "        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);\n"
-_PERMLANE = [(_HELPER_ANCHOR, _ROWS_SUM + _HELPER_ANCHOR), (_SUM_S, "        s = wave_rows_sum(s);\n"),
-             (_SUM_SS, "        ss = wave_rows_sum(ss);\n")]
-
-_LN_TWO_PASS = '''        float s = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
-        s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
-        const float mean = s * (1.f / 64.f);
-        float ss = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { u[rt][r] -= mean; ss += u[rt][r] * u[rt][r]; }
-        ss += __shfl_xor(ss, 16); ss += __shfl_xor(ss, 32);
-        const float rstd = rsqrtf(ss * (1.f / 64.f) + a.eps);
-'''
-# both sums formed together (their two exchanges are independent: one latency instead of two in a row), variance = E[u^2] - mean^2,
-# the centring folded into the normalisation (one fma per value instead of a subtraction and a multiplication)
-_LN_ONE_PASS = '''        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            s += (u[rt][0] + u[rt][1]) + (u[rt][2] + u[rt][3]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ss += u[rt][r] * u[rt][r];
-        }
-        s = wave_rows_sum(s); ss = wave_rows_sum(ss);
-        const float mean = s * (1.f / 64.f);
-        const float rstd = rsqrtf(fmaxf(ss * (1.f / 64.f) - mean * mean, 0.f) + a.eps);
-        const float shift = -mean * rstd;
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) u[rt][r] = u[rt][r] * rstd + shift;
-'''
-_AFFINE = [("gelu_pk_h<G16>(u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y)", "gelu_pk_h<G16>(u[rt][0] * g4.x + b4.x, u[rt][1] * g4.y + b4.y)"),
-           ("gelu_pk_h<G16>(u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w)", "gelu_pk_h<G16>(u[rt][2] * g4.z + b4.z, u[rt][3] * g4.w + b4.w)"),
-           ("gelu_erf2(f32x2_t{u[rt][0] * rstd * g4.x + b4.x, u[rt][1] * rstd * g4.y + b4.y})", "gelu_erf2(f32x2_t{u[rt][0] * g4.x + b4.x, u[rt][1] * g4.y + b4.y})"),
-           ("gelu_erf2(f32x2_t{u[rt][2] * rstd * g4.z + b4.z, u[rt][3] * rstd * g4.w + b4.w})", "gelu_erf2(f32x2_t{u[rt][2] * g4.z + b4.z, u[rt][3] * g4.w + b4.w})")]
-
-_BARRIER = "        __syncthreads();                                 // next tile staged; output patch of this tile complete\n"
+# ---- round 4: the shipped kernel IS round 3's winner (R_pipelined + R_exp_sdwa + a start offset for the second half of the grid; measured
+# 1.583 -> 1.484 ms per 1024-prompt launch, bit-identical) plus the one-pass LayerNorm statistics (a further -6 %; profiles/r04_experiments.md section 1).  What is left here: the shipped form's own
+# ablations (what each ingredient is worth NOW) and the next candidates.
+_DEPHASE = "    if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) __builtin_amdgcn_s_sleep(11);        // ~700 cycles: see the note above the kernel\n"
+_EXP_SDWA_START, _EXP_SDWA_END = "        // v_exp_f16 has no packed form.", "    }\n    const h16x2_t g = r - t * e;\n"
+_EXP_PAIR = "        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};\n"
+_BARRIER = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
 _CVT = "    const h16x2_t x = __builtin_convertvector(xf, h16x2_t);\n"
-_STAGE1 = "            for (int rt = 0; rt < 4; ++rt) u[rt] = mfma16d(w1f[rt][ks], kf, u[rt]);\n"
 _PATCH_WRITE = "        if (fg == 0) {                                   // rows = masks r, column = token fr\n"
 _STORE = "        if (tid < 64 * a.nmask) {\n"
 _GRID = "    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;\n"
-_KS = "    while (P * ks < 2 * cus && ks < 16) ks *= 2;\n"
 
 V = collections.OrderedDict()
 V["base"] = dict(kind="base", doc="the shipped source, unchanged", patches=[])
-V["R_permlane"] = dict(kind="exact", doc="LayerNorm2d sums through v_permlane16/32_swap instead of four ds_bpermute round trips", patches=_PERMLANE)
-V["R_ln_one_pass"] = dict(kind="close", doc="both LayerNorm sums in one exchange (variance = E[u^2] - mean^2), centring folded into one fma per value; permlane sums",
-                          patches=[_PERMLANE[0], (_LN_TWO_PASS, _LN_ONE_PASS)] + _AFFINE)
-V["R_pipelined"] = dict(kind="exact", doc="tile q + 1's stage-1 MFMAs under tile q's LayerNorm2d + GELU inside every wave (tools/uf_lab_pipelined.inc); biases from LDS",
-                        patches=[_PERMLANE[0], ("template <int UF_PRIO, int G16>\n__global__", "}  // namespace\n\nextern \"C\" int msam_upscale_fused_layout(",
-                                                open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "uf_lab_pipelined.inc")).read())])
-# v_exp_f16 has no packed form: the compiler emits one plain and one SDWA (source half select) instruction and packs the two results.  With
-# the destination half selected as well (dst_unused:UNUSED_PRESERVE) the two results land in one register and the v_pack_b32_f16 goes: one
-# vector instruction less per GELU pair (24 per tile).  gfx940-family hazard: a write with a destination select needs one wait state before
-# the register is read again (the second instruction preserves - reads - the other half).  Inline asm: not exercised by the host build
-# (the whole packed-fp16 GELU is restated there); the GPU run compares bit for bit with the shipped kernel.
-_EXP_PAIR = "        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};\n"
-_EXP_SDWA = ('        uint32_t ew_;\n'
-             '        asm("v_exp_f16_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\\n\\ts_nop 0\\n\\t"\n'
-             '            "v_exp_f16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\\n\\ts_nop 0"\n'
-             '            : "=&v"(ew_) : "v"(__builtin_bit_cast(uint32_t, q)));\n'
-             '        e = __builtin_bit_cast(h16x2_t, ew_);\n')
-V["R_exp_sdwa"] = dict(kind="exact", host_checked=False, doc="both v_exp_f16 of a GELU pair write their half of one register (SDWA destination select): no v_pack_b32_f16",
-                       patches=[(_EXP_PAIR, _EXP_SDWA)])
-# Two workgroups share a CU (one wave of each per SIMD); they are launched together and run the same stage sequence at the same speed, so
-# they stay IN PHASE: both in the MFMA phase, then both in the VALU phase.  The SQ counters of the shipped kernel (profiles/r03_pmc_sq_counters.md)
-# say exactly that: per tile and wave 1770 VALU-active + 896 MFMA-busy cycles = 2666 of the 2725 the SIMD spends - a sum, not a maximum.  A start
-# offset of half a tile period for one workgroup of each pair is preserved by the same argument (equal speeds), and lets one workgroup's MFMA
-# phase run under the other's VALU phase.  Which workgroups share a CU is the dispatcher's choice: both pairings are here.
-_LOOP_START = "    int q = 0, buf = 0;\n"
-def _dephase(cond, sleeps):
-    return [(_LOOP_START, f"    if ({cond}) {{\n        _Pragma(\"unroll\") for (int i_ = 0; i_ < {sleeps}; ++i_) __builtin_amdgcn_s_sleep(7);   // 7 x 64 cycles each\n    }}\n" + _LOOP_START)]
-V["R_dephase_half"] = dict(kind="exact", doc="second half of the grid starts ~1350 cycles late (half the tile period of a de-phased pair): co-resident workgroups i, i + grid / 2",
-                           patches=_dephase("(int)blockIdx.x >= ((int)gridDim.x >> 1)", 3))
-V["R_dephase_odd"] = dict(kind="exact", doc="odd workgroups start ~1350 cycles late: de-phases co-resident workgroups 2 j, 2 j + 1",
-                          patches=_dephase("(int)blockIdx.x & 1", 3))
-V["R_dephase_half_long"] = dict(kind="exact", doc="as R_dephase_half with ~2700 cycles (half of the 5350-cycle tile period the in-phase pair shows today)",
-                                patches=_dephase("(int)blockIdx.x >= ((int)gridDim.x >> 1)", 6))
-# combinations (the candidates are independent: in-wave overlap, one vector instruction less per GELU pair, a start offset)
-_PIPE_LOOP_START = "    int q = 0;\n"
-V["R_pipe_sdwa"] = dict(kind="exact", host_checked=False, doc="R_pipelined + R_exp_sdwa", patches=V["R_pipelined"]["patches"] + V["R_exp_sdwa"]["patches"])
-V["R_pipe_sdwa_dephase"] = dict(kind="exact", host_checked=False, doc="R_pipelined + R_exp_sdwa + the second half of the grid ~700 cycles late",
-                                patches=V["R_pipe_sdwa"]["patches"] + [(_PIPE_LOOP_START, "    if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) {\n        __builtin_amdgcn_s_sleep(11);\n    }\n" + _PIPE_LOOP_START)])
-_PIPE_BARRIER = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
-V["T_pipe_no_barrier"] = dict(kind="timing", doc="R_pipelined without its per-tile barrier (racy): the barrier's share in the pipelined form",
-                              patches=V["R_pipelined"]["patches"] + [(_PIPE_BARRIER, "        (void)0;\n")])
+V["R_no_dephase"] = dict(kind="exact", doc="no start offset for the second half of the grid", patches=[(_DEPHASE, "")])
+V["R_dephase_22"] = dict(kind="exact", doc="start offset ~1400 cycles instead of ~700", patches=[(_DEPHASE, _DEPHASE.replace("s_sleep(11)", "s_sleep(22)"))])
+V["R_exp_pair"] = dict(kind="exact", doc="round 3's exponential pair (plain + SDWA source select + v_pack_b32_f16) instead of the destination-select form",
+                       patches=[(_EXP_SDWA_START, _EXP_SDWA_END, _EXP_PAIR)])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
-V["T_no_ln_stats"] = dict(kind="timing", doc="no LayerNorm statistics (no sums, no exchange, no rsqrt); affine and GELU stay",
-                          patches=[(_LN_TWO_PASS, "        const float rstd = a.eps + 1.f;\n")])
 V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conversion",
                       patches=[(_CVT, _CVT + "    if (EXPM >= 0) return __builtin_bit_cast(uint32_t, x);\n")])
-V["T_no_exp"] = dict(kind="timing", doc="GELU polynomial without the exponential (the library's up_gelu16 = 2 instantiation)",
-                     patches=[("    else if (g_tune_up_gelu16) {\n        if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 1>)",
-                               "    else if (g_tune_up_gelu16) {\n        if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 2>)")])
-V["T_no_stage1_mfma"] = dict(kind="timing", doc="stage 1 without its 32 MFMAs (operands still read; W1 stays live through one MFMA per k-step)",
-                             patches=[(_STAGE1, "            for (int rt = 0; rt < 4; ++rt) {\n"
-                                                "                if (rt == (ks & 3)) u[rt] = mfma16d(w1f[rt][ks], kf, u[rt]);\n"
-                                                "                else asm volatile(\"\" :: \"v\"(w1f[rt][ks].x), \"v\"(w1f[rt][ks].y), \"v\"(w1f[rt][ks].z), \"v\"(w1f[rt][ks].w));\n"
-                                                "            }\n")])
 V["T_no_output"] = dict(kind="timing", doc="no output patch and no global store (stage 3 results kept alive by one predicated store)",
                         patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {\n"), (_STORE, "        if (tid < 64 * a.nmask && key0 < 0) {\n")])
 V["T_one_wg_per_cu"] = dict(kind="timing", doc="grid = number of CUs: what the second co-resident workgroup buys",
                             patches=[(_GRID, "    const int grid = a.nitems < cus ? a.nitems : cus;\n")])
-V["T_prio0"] = dict(kind="timing", doc="no issue priority for the stage-1 MFMA phase (the library's msam_upscale_set_prio(0))",
-                    patches=[("int g_uf_prio = 1;", "int g_uf_prio = 0;")])
 
 STUBS = r'''
 #include <cstdio>
@@ -194,10 +97,10 @@ def build(name: str, outdir: str):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         sys.exit(f"{name}: build failed\n{r.stderr[-3000:]}")
-    # resource usage of the <1, 1> (or, for T_no_exp, <1, 2>) instantiation
+    # resource usage of the <1, 1> instantiation
     res = {}
     blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)
-    want = "ILi0ELi1E" if name == "T_prio0" else "ILi1ELi2E" if name == "T_no_exp" else "ILi1ELi1E"
+    want = "ILi1ELi1E"
     for b in blocks[1:]:
         if want in b.split("\n", 1)[0]:
             for key, pat in (("vgprs", r"VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
