@@ -20,6 +20,9 @@ in HBM before the timed region.  Prints ONE JSON line on rank 0 with, next to th
                     "mask IoU vs ref"): distribution over the instances the reference keeps, keep-set and label agreement
   pcie_inclusive    tiles/s of a separate pass that starts from the raw host tiles (H2D upload, util._to_image on the device)
                     and ends with the label images back in host memory
+  config3_side / fp8_side / train_side   (N = 1, default run) BASELINE configs[2], [4], [3] as short side runs of this script /
+                    tools/train_bench.py in their own processes after the timed region: the driver's record carries every named
+                    configuration; `--no-side` or `--no-config-sides` skips them
 """
 import argparse
 import ctypes as C
@@ -170,28 +173,76 @@ def pmc_traffic(kernel_name):
 
 
 def api_inclusive(predictor, amg, tiles_np, n_api, enc_batch):
-    """SURVEY.md 8(d) config 2 through the drop-in API itself, host arrays in and out: precompute_image_embeddings(stack, ndim=3,
-    batch_size) -> per slice AutomaticMaskGenerator.initialize(i=z) + generate() (numpy uint32 label image back on the host)."""
+    """SURVEY.md 8(d) config 2 through the drop-in API itself, host arrays in and out, two ways:
+    value          the product's own slice loop, ONE call: multi_dimensional_segmentation.segment_slices(stack, predictor, amg,
+                   batch_size) (reference _segment_slices :385-416: embeddings + per slice initialize / generate with running id offsets)
+                   - inside the product it is a device pipeline (encoder batches, decode lanes, double-buffered label download)
+    literal_loop   the same calls written out by the caller: precompute_image_embeddings(stack, ndim=3, batch_size) -> per slice
+                   AutomaticMaskGenerator.initialize(i=z) + generate() (numpy label image per slice: one synchronisation per slice)"""
+    from micro_sam_amd import multi_dimensional_segmentation as mds
     from micro_sam_amd import util
     stack = np.stack(tiles_np[:n_api])
+    mds.segment_slices(stack[:4], predictor, amg, batch_size=enc_batch)          # warm-up: lane streams, page-locked buffers
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    seg, _ = mds.segment_slices(stack, predictor, amg, batch_size=enc_batch)
+    torch.cuda.synchronize()
+    t_pipe = time.perf_counter() - t0
     t0 = time.perf_counter()
     emb = util.precompute_image_embeddings(predictor, stack, ndim=3, batch_size=enc_batch, verbose=False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    n_inst = 0
+    loop_segs = []
     for z in range(n_api):
         amg.initialize(stack[z], emb, i=z)
-        seg = amg.generate()
-        n_inst += int(seg.max())
+        loop_segs.append(amg.generate())
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    return {"value": round(n_api / (t2 - t0), 2), "unit": "tiles/s", "tiles": n_api,
-            "embed_seconds_per_tile": round((t1 - t0) / n_api, 5), "amg_seconds_per_tile": round((t2 - t1) / n_api, 5),
-            "instances_per_tile_mean": round(n_inst / n_api, 1),
-            "what": f"util.precompute_image_embeddings(stack[{n_api},1024,1024] uint8 host array, ndim=3, batch_size={enc_batch}) then per "
-                    "slice AutomaticMaskGenerator.initialize(stack[z], emb, i=z) + generate() -> numpy label image; one stream, no "
-                    "decode lanes, host synchronisation wherever the API returns host data"}
+    n_inst, offset, same = 0, 0, True
+    for z, s in enumerate(loop_segs):               # (outside the clock) the pipelined volume == the caller's loop + running offsets
+        m = int(s.max())
+        n_inst += m
+        same = same and bool(np.array_equal(np.where(s != 0, s + np.uint32(offset), 0).astype(np.uint32), seg[z]))
+        offset += m
+    return {"value": round(n_api / t_pipe, 2), "unit": "tiles/s", "tiles": n_api,
+            "what": f"multi_dimensional_segmentation.segment_slices(stack[{n_api},1024,1024] uint8 host array, predictor, "
+                    f"AutomaticMaskGenerator, batch_size={enc_batch}) -> uint32 [Z,Y,X] host volume with the serial loop's running id "
+                    "offsets; ONE product call (the reference's _segment_slices), pipelined inside the product",
+            "labels_equal_literal_loop": same, "instances_per_tile_mean": round(n_inst / n_api, 1),
+            "literal_loop": {"value": round(n_api / (t2 - t0), 2), "unit": "tiles/s",
+                             "embed_seconds_per_tile": round((t1 - t0) / n_api, 5), "amg_seconds_per_tile": round((t2 - t1) / n_api, 5),
+                             "what": f"util.precompute_image_embeddings(stack, ndim=3, batch_size={enc_batch}) then per slice "
+                                     "AutomaticMaskGenerator.initialize(stack[z], emb, i=z) + generate() -> numpy label image; the caller's "
+                                     "loop synchronises wherever the API returns host data"}}
+
+
+def config_sides(timeout_s: float = 420.0):
+    """BASELINE configs[2] / [4] / [3] as short runs in their own processes (clean allocator, their own model): the last JSON line of
+    each, reduced to the fields that name the measurement.  A failing or slow side run costs its field, never the bench line."""
+    def run(cmd, keep):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+            line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode or not line:
+                return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+            d = json.loads(line[-1])
+            out = {k: d[k] for k in keep if k in d}
+            out["command"] = "python " + " ".join(cmd)
+            out["wall_seconds"] = round(time.perf_counter() - t0, 1)
+            return out
+        except Exception as exc:
+            return {"error": repr(exc)[:300]}
+    sides = {}
+    sides["fp8_side"] = run(["bench.py", "--encoder-dtype", "fp8", "--no-cpu-baseline", "--no-side", "--steps", "3", "--warmup", "1"],
+                            ("metric", "value", "unit", "ms_per_step", "dtype"))
+    sides["config3_side"] = run(["bench.py", "--workload", "config3", "--steps", "1", "--warmup", "1", "--slices", "4"],
+                                ("metric", "value", "unit", "ms_per_step", "dtype", "config"))
+    tb = os.path.join("tools", "train_bench.py")
+    keep_t = ("metric", "value", "unit", "model", "ms_per_step", "config", "non_hip_device_time_frac", "kernel_launches_per_step")
+    sides["train_side"] = {"vit_b": run([tb, "--model", "vit_b", "--steps", "5", "--warmup", "2", "--device-time"], keep_t),
+                           "vit_h": run([tb, "--model", "vit_h", "--steps", "4", "--warmup", "1"], keep_t)}
+    return sides
 
 
 def bench_config3(args, rank, world, dev):
@@ -302,6 +353,8 @@ def main():
                     help="skip the side measurements (pcie_inclusive, api_inclusive, rle_side, interactive_side): profiling runs, so "
                          "that per-kernel averages hold the hot path's launches only")
     ap.add_argument("--api-tiles", type=int, default=32, help="tiles of the api_inclusive side measurement")
+    ap.add_argument("--no-config-sides", action="store_true",
+                    help="skip config3_side / fp8_side / train_side (the other named configurations as short side runs, N = 1 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: gloo, no GPU work, prints the JSON line with n_gpus = world size")
     args = ap.parse_args()
@@ -401,9 +454,12 @@ def main():
         pk.model.use_glds = args.glds
         lanes.append((pk, AutomaticMaskGenerator(pk, device_chunk=args.device_chunk), torch.cuda.Stream(device=dev)))
     pinned_labels = [None]
+    # N > 1: the all_gather of step k's label tiles runs on a communication stream underneath step k + 1's encoder / decoder kernels
+    # (8 ranks x 64 tiles: every rank receives 1.75 GiB per step - ~6 ms of a 370 ms step over xGMI - un-overlapped before round 4)
+    comm_stream = torch.cuda.Stream(device=dev) if (world > 1 or force_dist) else None
     shape_only = np.broadcast_to(np.zeros((1, 1), dtype=np.uint8), (1024, 1024))   # initialize() reads the image SHAPE only
 
-    def step(timed: bool, index: int, uploads=None, serial: bool = False):
+    def step(timed: bool, index: int, uploads=None, serial: bool = False, wait_gather: bool = False):
         """timed=True: instrumented pass with a device sync after every stage (stage breakdown only);
         timed=False: the production path, no extra synchronisation.  uploads: host tiles to convert + upload inside the step
         (the PCIe-inclusive pass), else the resident uint8 tiles of step `index` are used."""
@@ -462,7 +518,15 @@ def main():
         if gen_stream is not None and not timed:
             torch.cuda.current_stream().wait_stream(gen_stream)          # label tiles complete before the gather
         t3 = time.perf_counter()
-        full = parallel.gather_label_tiles(labels, n_tiles * world) if (world > 1 or force_dist) else labels
+        if comm_stream is not None:
+            comm_stream.wait_stream(torch.cuda.current_stream())         # this step's label tiles are complete
+            with torch.cuda.stream(comm_stream):
+                full = parallel.gather_label_tiles(labels, n_tiles * world)
+            labels.record_stream(comm_stream)
+            if timed or uploads is not None or wait_gather:
+                torch.cuda.current_stream().wait_stream(comm_stream)     # the caller reads `full` on the compute stream
+        else:
+            full = labels
         if timed:
             torch.cuda.synchronize(); stage["gather"] += time.perf_counter() - t3
         if not timed:
@@ -516,7 +580,7 @@ def main():
         lib.msam_profile_enable(0)
         stage["host_enqueue"] = host_enqueue_timed
     serial_labels = step(True, 0).clone()     # one extra instrumented pass (outside the timed region): stage breakdown, and
-    pipelined_labels = step(False, 0)         # the serial result that the pipelined (lanes / side stream) step must reproduce
+    pipelined_labels = step(False, 0, wait_gather=True)   # the serial result that the pipelined (lanes / side stream) step must reproduce
     torch.cuda.synchronize()
     labels_equal = bool(torch.equal(serial_labels, pipelined_labels))
     if not labels_equal:
@@ -598,7 +662,7 @@ def main():
                        "tiles_per_step_per_gpu": n_tiles, "encoder_batch": enc_batch,
                        "distinct_tiles_per_gpu": n_distinct,
                        "weights": f"seeded synthetic checkpoint (synthetic.py variant '{args.weights}')",
-                       "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles" +
+                       "parallelism": f"dp{world} tiles, all_gather of uint32 label tiles (RCCL, on a communication stream under the next step)" +
                                       (" (MSAM_FORCE_DIST: world-size-1 nccl group, the gather runs through RCCL)" if force_dist else ""),
                        "timed_region": "uint8 RGB tiles resident in HBM -> label tiles in HBM (all-gathered when N > 1); "
                                        "util._to_image, H2D and label D2H are in pcie_inclusive, lazy RLE encoding in rle_side",
@@ -672,6 +736,11 @@ def main():
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
             out["mask_iou_vs_ref"] = None
+        if world == 1 and not args.no_side and not args.no_config_sides and args.encoder_dtype == "bf16":
+            log("side runs of the other named configurations (configs[2], [4], [3]) ...")
+            del tiles_u8
+            torch.cuda.empty_cache()
+            out.update(config_sides())
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()

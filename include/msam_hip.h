@@ -76,7 +76,8 @@ typedef struct {
     /* split_k > 1 (128 x 128-tile bf16 / fp16 path): the contraction is cut into split_k slices, one workgroup per (tile, slice),
      * partial tiles are added into `out` with fp32 atomics (out is zeroed first).  For products with a small output and a very long
      * contraction (the weight gradients of fine-tuning: dW = dY^T X over all rows).  Plain fp32 output with ldc == N, no bias /
-     * table / residual / activation; K % (64 * split_k) == 0.  0 / 1 = off. */
+     * table / residual / activation; K % (64 * split_k) == 0.  0 / 1 = off.  The slices meet in fp32 atomics: the result is NOT
+     * bit-reproducible from run to run (order of the additions; training gradients only - no inference path sets it). */
     int32_t split_k;
     /* ln_mode 1 only (the mask decoder's token side): the normalised row is ALSO written as 16-bit operand copies for the next
      * products - ln_out_a [M,256] = round16(y + ln_add[row]) (ln_add fp32 [M,256] or NULL), ln_out_b [M,256] = round16(y); the 16-bit

@@ -34,8 +34,17 @@ def variant_path(variant: str = "") -> str:
     return LIB_PATH if not variant else os.path.join(LIB_DIR, f"libmsam_hip_{variant}.so")
 
 
-def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", experiments: bool = False) -> str:
+    """``experiments``: -DMSAM_EXPERIMENTS=1 (gemm.hip: the timing knobs and rejected kernel forms tools/gemm_probe.py drives; forces a rebuild,
+    and the next default build is forced as well)."""
     os.makedirs(LIB_DIR, exist_ok=True)
+    marker = os.path.join(LIB_DIR, ".experiments")
+    if experiments or os.path.exists(marker):
+        force = True
+        if experiments:
+            open(marker, "w").close()
+        else:
+            os.remove(marker)
     if variant:
         return _build_variant(variant, force, verbose)
     if not force and not needs_build():
@@ -50,6 +59,8 @@ def build(force: bool = False, verbose: bool = True, variant: str = "") -> str:
                 os.path.getmtime(path), os.path.getmtime(os.path.join(CSRC, "common.h")),
                 os.path.getmtime(os.path.join(HERE, "..", "include", "msam_hip.h"))):
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", path, "-o", obj]
+            if experiments:
+                cmd.insert(-4, "-DMSAM_EXPERIMENTS=1")
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -82,4 +93,4 @@ def _build_variant(variant: str, force: bool, verbose: bool) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, variant="decbf16" if "--dec-bf16" in sys.argv else ""))
+    print(build(force="--force" in sys.argv, variant="decbf16" if "--dec-bf16" in sys.argv else "", experiments="--experiments" in sys.argv))

@@ -757,7 +757,12 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         msam_set_error("msam_decoder_forward: null argument");
         return 1;
     }
-    if (!sparse && (!points || Np <= 0) && !boxes) { msam_set_error("msam_decoder_forward: need points and/or boxes"); return 1; }
+    // a mask prompt on its own is a prompt (reference prompt_based_segmentation.segment_from_mask(use_box=False, use_points=False):
+    // no sparse token, the five output tokens only, the mask enters through the per-prompt source stream)
+    if (!sparse && (!points || Np <= 0) && !boxes && !mask_input && !dense) {
+        msam_set_error("msam_decoder_forward: need points, boxes and / or a mask prompt");
+        return 1;
+    }
     if (mask_input && !mask_w) { msam_set_error("msam_decoder_forward: mask prompts need the mask_downscaling weights"); return 1; }
     const bool own_src = mask_input != nullptr || dense != nullptr;   // per-prompt source stream (image embedding + dense embedding)
     if (!points) Np = 0;

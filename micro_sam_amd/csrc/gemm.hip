@@ -426,6 +426,12 @@ MSAM_DEVINL void epi_direct(const f32x16_t (&acc)[2][4], int m0, int n0, int wm,
 
 constexpr int G2 = 256;                       // tile edge
 constexpr int G2_DEFAULT_STAGING = 3;   // measured (tools/gemm_bench.py): 3 > 1 > 0 by 3 - 8 % each on the encoder shapes, LDS-DMA (2) no better
+// Timing experiments and rejected kernel forms (gemm_dbg bits - WRONG results by construction -, the two-workgroups-per-CU kernel = staging 4,
+// the accumulator-direct epilogue "g3_epi") are reachable only in a library built with -DMSAM_EXPERIMENTS=1
+// (`python -m micro_sam_amd.build --experiments`: tools/gemm_probe.py, tools/gemm_bench.py); the production build ignores the knobs.
+#ifndef MSAM_EXPERIMENTS
+#define MSAM_EXPERIMENTS 0
+#endif
 int g_tune_gemm_dbg = 0;                      // msam_tune_set "gemm_dbg" (Epi.dbg)
 unsigned long long* g_gw_trace = nullptr;
 int g_tune_gw_delay = -1, g_tune_gw_class = 0, g_tune_g3_delay = -1, g_tune_g3_epi = 0;   // "g3_epi": 1 = gemm256_kernel's epilogue from the accumulators; "g3_delay": start-phase spread of gemm256_kernel's first wave // msam_tune_set "gw_delay" (-1 = from K) / "gw_class" (gemm2w_kernel)
@@ -1229,7 +1235,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     e.heads = p->heads; e.head_dim = p->head_dim; e.tokens = p->tokens;
     e.row_scale = nullptr; e.col_scale = nullptr;
     e.splitk_len = 0;
-    e.dbg = g_tune_gemm_dbg;
+    e.dbg = MSAM_EXPERIMENTS ? g_tune_gemm_dbg : 0;
     hipStream_t s = (hipStream_t)stream;
     if (p->ln_mode && p->a_dtype == MSAM_FP8) { msam_set_error("msam_gemm_bf16(fp8): no fused LayerNorm epilogue"); return 1; }
     const bool f16 = p->a_dtype == MSAM_F16;
@@ -1299,8 +1305,10 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         const char* st = getenv("MSAM_GEMM256_STAGING"); staging256 = st ? atoi(st) : G2_DEFAULT_STAGING;
     }
     if (g_gemm256_staging >= 0) staging256 = g_gemm256_staging;
+    if (!MSAM_EXPERIMENTS && (staging256 < 0 || staging256 > 3)) staging256 = G2_DEFAULT_STAGING;
     // staging 4: the two-workgroups-per-CU kernel (256 x 128 tiles, LDS-DMA ring, epilogue from the accumulators)
-    if (use256 && staging256 == 4 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds &&
+    // (its operand offsets are 32-bit: operands of 2 GiB and more stay on the 256 x 256 kernel)
+    if (MSAM_EXPERIMENTS && use256 && staging256 == 4 && (double)p->M * p->lda * 2 < 2147483648.0 && (double)p->N * p->ldw * 2 < 2147483648.0 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds &&
         ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % GW_BN == 0 && p->K % GW_BK == 0 && p->lda % 8 == 0 && p->ldw % 8 == 0 &&
         p->out_mode != 2 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr2w = false;
@@ -1359,7 +1367,8 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
         const int tiles256 = ((p->M + G2 - 1) / G2) * (p->N / G2);
         e.gw_class = msam_num_cus();                                  // workgroups of the first dispatch wave
         e.gw_delay = g_tune_g3_delay >= 0 ? g_tune_g3_delay : 0;
-        e.direct_epi = g_tune_g3_epi;
+        // (epi_direct packs 16-bit outputs by the operand type: offered only where that IS the output type)
+        e.direct_epi = (MSAM_EXPERIMENTS && (p->out_dtype == MSAM_F32 || (p->out_dtype == MSAM_F16) == f16)) ? g_tune_g3_epi : 0;
 #define G2_GO(ST_) hipLaunchKernelGGL(gemm256_kernel<ST_>, dim3(tiles256), dim3(512), G2_LDS, s, (const u16*)p->A, (long)p->lda, \
                                      (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e)
         if (f16)

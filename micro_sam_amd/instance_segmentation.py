@@ -129,6 +129,9 @@ class DeviceMaskData(amg_utils.MaskData):
         self.full_size = state["mask_size"]
 
 
+DEFAULT_SEGMENTATION_MODE_WITH_DECODER = "ais"       # reference :44
+
+
 class AMGBase(ABC):
     def __init__(self):
         self._is_initialized = False
@@ -307,6 +310,35 @@ class AutomaticMaskGenerator(AMGBase):
         self._crop_overlap_ratio = crop_overlap_ratio
         self._crop_n_points_downscale_factor = crop_n_points_downscale_factor
         self._stability_score_offset = stability_score_offset
+
+    def _lane_clone(self) -> "AutomaticMaskGenerator":
+        """Another generator with the same settings on a lane view of the predictor's model (own decoder scratch, own state): what a
+        concurrent decode lane of the pipelined slice loop works with."""
+        import copy
+        clone = copy.copy(self)
+        clone._predictor = SamPredictor(self._predictor.model.lane_view())
+        clone._prompt_cache = {}
+        clone._lanes = clone._post_stream = None
+        clone.clear_state()
+        return clone
+
+    def _decode_lanes(self, n: int):
+        """``n`` (lane clone, HIP stream) pairs, kept on the generator: the decoder workspace of a lane (several GiB for 1024 prompts)
+        lives in its model view and torch caches device memory per stream - fresh clones / streams per call would allocate it anew
+        every time (measured: 21 tiles/s instead of > 150)."""
+        dev = self._predictor.device
+        lanes = getattr(self, "_lanes", None) or []
+        if lanes and (lanes[0][0]._predictor.device != dev or
+                      lanes[0][0]._predictor.model.mask_decoder is not self._predictor.model.mask_decoder):
+            lanes = []                             # the generator's predictor was moved / replaced
+        while len(lanes) < n:
+            lanes.append((self._lane_clone(), torch.cuda.Stream(device=dev)))
+        self._lanes = lanes
+        for clone, _ in lanes[:n]:                 # settings may have been changed on the generator since the clone was made
+            for k in ("point_grids", "_points_per_side", "_points_per_batch", "_crop_n_layers", "_crop_overlap_ratio",
+                      "_crop_n_points_downscale_factor", "_stability_score_offset", "_device_chunk"):
+                setattr(clone, k, getattr(self, k))
+        return lanes[:n]
 
     def _process_batch(self, points, im_size, crop_box, original_size):
         # the grid prompts of a crop size are the same for every image: keep their device copy (one H2D copy and one fill
@@ -857,16 +889,17 @@ class TiledAutomaticPromptGenerator(TiledInstanceSegmentationWithDecoder):
 
 def get_instance_segmentation_generator(predictor: SamPredictor, is_tiled: bool = False, decoder=None,
                                         segmentation_mode: Optional[str] = None, **kwargs):
-    """Factory with the reference's signature and mode resolution (:1631-1690): ``amg`` without a decoder, with a decoder
-    the reference defaults to ``ais`` - whose watershed is not provided here, so ``apg`` has to be asked for."""
+    """Factory with the reference's signature and mode resolution (:1631-1690): ``amg`` without a decoder, ``ais`` (the reference's
+    ``DEFAULT_SEGMENTATION_MODE_WITH_DECODER`` :44) with one."""
     if segmentation_mode is None:
-        segmentation_mode = "amg" if decoder is None else "ais"
-    if segmentation_mode.lower() == "amg":
+        segmentation_mode = "amg" if decoder is None else DEFAULT_SEGMENTATION_MODE_WITH_DECODER
+    mode = segmentation_mode.lower()
+    if mode == "amg":
         return (TiledAutomaticMaskGenerator if is_tiled else AutomaticMaskGenerator)(predictor, **kwargs)
-    if decoder is None:
-        raise ValueError(f"segmentation_mode={segmentation_mode!r} needs a decoder")
-    if segmentation_mode.lower() == "apg":
+    if mode == "ais":
+        assert decoder is not None
+        return (TiledInstanceSegmentationWithDecoder if is_tiled else InstanceSegmentationWithDecoder)(predictor, decoder, **kwargs)
+    if mode == "apg":
+        assert decoder is not None
         return (TiledAutomaticPromptGenerator if is_tiled else AutomaticPromptGenerator)(predictor, decoder, **kwargs)
-    if segmentation_mode.lower() == "ais":
-        raise NotImplementedError("micro_sam_amd: segmentation_mode='ais' (seeded watershed) is not provided; use 'apg'")
-    raise ValueError(f"Invalid segmentation_mode: {segmentation_mode!r}")
+    raise ValueError(f"Invalid segmentation_mode: {segmentation_mode}. Choose one of 'amg', 'ais', or 'apg'.")

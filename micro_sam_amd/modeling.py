@@ -420,6 +420,18 @@ class Sam(nn.Module):
         self._img_state = None
         self.image_encoder.invalidate()
 
+    def lane_view(self) -> "Sam":
+        """A second handle on THIS model for a concurrent decode lane (another HIP stream working on another image): parameters, modules
+        and the prepared decoder constants are shared, the per-call scratch - the prepared image state and the decoder workspace - is
+        the view's own, so two lanes never write the same buffers.  A weight update is noticed by every handle on its own
+        (``_prepare_decoder`` compares the parameter key).  Used by the pipelined slice / tile loops
+        (multi_dimensional_segmentation.segment_slices)."""
+        import copy
+        view = copy.copy(self)              # shallow: the _parameters / _modules / _buffers dicts are the same objects
+        view._img_state = None
+        view._dec_ws = None
+        return view
+
     def _apply(self, fn, *args, **kwargs):   # .to(device) / .cuda() move parameters: drop cached device copies
         self.invalidate()
         return super()._apply(fn, *args, **kwargs)
@@ -638,12 +650,12 @@ class Sam(nn.Module):
             lbl = point_labels.to(device=dev, dtype=torch.int32).contiguous()
             P, Np = pts.shape[0], pts.shape[1]
         else:
-            if boxes is None:
-                # the reference accepts a mask prompt on its own (5 decoder tokens, no sparse prompt); its own tests call
-                # that prompt unreliable (test/test_prompt_based_segmentation.py:8-13) - not provided here
-                raise NotImplementedError("micro_sam_amd: a prompt needs points and / or a box (a mask prompt alone is not provided)")
+            if boxes is None and mask_input is None:
+                raise ValueError("micro_sam_amd: a prompt needs points, a box and / or a mask input")
+            # (a mask prompt on its own - reference segment_from_mask(use_box=False, use_points=False) - decodes with the five output
+            #  tokens only; the reference's own tests call that prompt unreliable, test/test_prompt_based_segmentation.py:8-13)
             pts = lbl = None
-            P, Np = boxes.shape[0], 0
+            P, Np = (boxes.shape[0] if boxes is not None else mask_input.reshape(-1, 4 * GRID, 4 * GRID).shape[0]), 0
         bx = None if boxes is None else boxes.to(device=dev, dtype=torch.float32).reshape(-1, 4).contiguous()
         nc = 3 if multimask_output else 1
         low = torch.empty((P, nc, 256, 256), dtype=torch.float32, device=dev)

@@ -24,14 +24,125 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib, parallel, util
+from . import _lib, modeling, parallel, util
+
+
+_PIPELINE_KWARGS = ("pred_iou_thresh", "stability_score_thresh", "box_nms_thresh", "with_background")
+
+
+def _can_pipeline(data, predictor, segmentor, embedding_path, tile_shape, kwargs) -> bool:
+    """The pipelined loop covers the plain case: an untiled ``AutomaticMaskGenerator`` (one crop layer) on a GPU, embeddings computed
+    here and kept in memory, ``generate`` called with threshold arguments only (label-image output)."""
+    from .instance_segmentation import AutomaticMaskGenerator
+    return (type(segmentor) is AutomaticMaskGenerator and segmentor._crop_n_layers == 0 and embedding_path is None and tile_shape is None
+            and data.shape[0] > 1 and all(k in _PIPELINE_KWARGS for k in kwargs)
+            and str(predictor.device).startswith("cuda") and torch.cuda.is_available()
+            and hasattr(predictor.model.image_encoder, "forward_u8") and hasattr(predictor.model, "lane_view")
+            and segmentor._predictor is predictor)
+
+
+@torch.no_grad()
+def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lanes: int, return_device: bool, kwargs, offsets: bool = True):
+    """The slice loop of ``_segment_slices`` as a device pipeline (what bench.py's step does, inside the product):
+
+      main stream   raw slices up (page-locked ring, asynchronous), ``_to_image`` + encoder, one batch at a time, an event per batch
+      decode lanes  ``n_lanes`` lane clones of the generator (own decoder scratch, own stream): slice z on lane z % n_lanes waits for ITS
+                    encoder batch only, runs initialize + generate_device; kernels of different slices overlap, the encoder works on the
+                    next batch underneath
+      post stream   per batch: running id offsets of the serial loop (offset of slice z = sum of the max ids before it), label tiles
+                    into a page-locked double buffer
+      host          drains batch b - 1 into the result while batch b is queued: no per-slice synchronisation
+
+    Same labels as the serial loop (the same initialize / generate_device per slice; the offsets are the serial loop's)."""
+    Z, H, W = data.shape[0], data.shape[1], data.shape[2]
+    dev = predictor.device
+    main = torch.cuda.current_stream(dev)
+    lanes = segmentor._decode_lanes(max(1, min(n_lanes, Z)))          # cached on the generator: clones keep their decoder workspace
+    post = getattr(segmentor, "_post_stream", None)
+    if post is None or post.device != torch.device(dev):
+        post = segmentor._post_stream = torch.cuda.Stream(device=dev)
+    batch_size = max(1, int(batch_size))
+    feats = torch.empty((Z, 1, modeling.PROMPT_DIM, modeling.GRID, modeling.GRID), dtype=torch.float32, device=dev)
+    labels = torch.empty((Z, H, W), dtype=torch.int32, device=dev)
+    emb = {"features": feats, "input_size": None, "original_size": None}
+    carry = torch.zeros((), dtype=torch.int64, device=dev)
+    out = None if return_device else np.empty((Z, H, W), dtype=np.uint32)
+    pins = [None, None]
+    pending = None                                   # (s0, s1, slot, event) of the batch whose labels are on their way to the host
+    flags = []
+
+    def drain(p):
+        s0, s1, slot, ev = p
+        ev.synchronize()
+        np.copyto(out[s0:s1], pins[slot][: s1 - s0].numpy().view(np.uint32))
+
+    for b, s0 in enumerate(range(0, Z, batch_size)):
+        s1 = min(s0 + batch_size, Z)
+        f, osz, isz = util._compute_embeddings_batched_raw(predictor, [np.asarray(data[z]) for z in range(s0, s1)])
+        feats[s0:s1, 0] = f
+        emb["input_size"], emb["original_size"] = isz[-1], osz[-1]
+        enc_done = torch.cuda.Event()
+        enc_done.record(main)
+        used = []
+        for z in range(s0, s1):
+            amg, st = lanes[z % len(lanes)]
+            st.wait_event(enc_done)
+            with torch.cuda.stream(st):
+                amg.initialize(data[z], image_embeddings=emb, i=z)
+                lab, flag = amg.generate_device(**kwargs)
+                labels[z] = lab
+            flags.append(flag)
+            if st not in used:
+                used.append(st)
+        for st in used:
+            post.wait_stream(st)
+        with torch.cuda.stream(post):
+            blk = labels[s0:s1]
+            if offsets:
+                mx = blk.flatten(1).amax(dim=1).to(torch.int64)
+                offs = (torch.cumsum(mx, 0) - mx + carry).view(-1, 1, 1).to(blk.dtype)
+                blk += torch.where(blk != 0, offs, torch.zeros_like(offs))
+                carry = carry + mx.sum()
+            if out is not None:
+                slot = b & 1
+                if pins[slot] is None:
+                    pins[slot] = util.pinned_buffer(f"slices{slot}", (batch_size, H, W), torch.int32)
+                pins[slot][: s1 - s0].copy_(blk, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(post)
+        if out is not None:
+            if pending is not None:
+                drain(pending)               # batch b - 1: complete by now or soon - batch b is already queued behind it
+            pending = (s0, s1, slot, ev)
+    if pending is not None:
+        drain(pending)
+    for _, st in lanes:
+        main.wait_stream(st)
+    main.wait_stream(post)
+    bad = torch.stack(flags).flatten().nonzero().flatten().tolist()      # connected components that did not converge in two passes
+    if bad:
+        return None
+    # the objects are left as the serial loop leaves them: generator initialised on the last slice, predictor holding its embedding
+    last = lanes[(Z - 1) % len(lanes)][0]
+    segmentor.set_state(last.get_state())
+    util.set_precomputed(predictor, emb, i=Z - 1)
+    return (labels if return_device else out), emb
 
 
 def segment_slices(data: np.ndarray, predictor, segmentor, embedding_path=None, verbose: bool = False,
                    tile_shape: Optional[Tuple[int, int]] = None, halo: Optional[Tuple[int, int]] = None,
-                   batch_size: int = 1, **kwargs):
-    """Reference ``_segment_slices`` (:385-416).  Returns (uint32 [Z,Y,X] segmentation, image_embeddings)."""
+                   batch_size: int = 1, decode_lanes: int = 3, **kwargs):
+    """Reference ``_segment_slices`` (:385-416).  Returns (uint32 [Z,Y,X] segmentation, image_embeddings).
+
+    The plain case (untiled ``AutomaticMaskGenerator`` on a GPU, embeddings computed here) runs as a device pipeline
+    (``_segment_slices_pipelined``: encoder batches, ``decode_lanes`` concurrent decode lanes, double-buffered label download; the
+    embeddings stay on the device as with ``keep_on_device``); everything else - tiled generators, decoder-based generators, embeddings
+    from / to a container, other ``generate`` arguments - takes the reference's loop below.  ``decode_lanes=0`` forces that loop."""
     assert data.ndim == 3
+    if decode_lanes > 0 and _can_pipeline(data, predictor, segmentor, embedding_path, tile_shape, kwargs):
+        res = _segment_slices_pipelined(data, predictor, segmentor, batch_size, decode_lanes, False, kwargs)
+        if res is not None:
+            return res
     image_embeddings = util.precompute_image_embeddings(predictor=predictor, input_=data, save_path=embedding_path, ndim=3,
                                                         tile_shape=tile_shape, halo=halo, verbose=verbose,
                                                         batch_size=batch_size, keep_on_device=tile_shape is None)
@@ -58,15 +169,24 @@ def segment_slices_sharded(data: np.ndarray, predictor, segmentor, verbose: bool
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     start, stop = parallel.shard_range(data.shape[0], rank, world)
-    local = np.zeros((stop - start,) + data.shape[1:], dtype="int32")
-    if stop > start:
-        emb = util.precompute_image_embeddings(predictor=predictor, input_=data[start:stop], ndim=3, verbose=verbose,
-                                               batch_size=batch_size, keep_on_device=True)
-        for k in range(stop - start):
-            segmentor.initialize(data[start + k], image_embeddings=emb, verbose=False, i=k)
-            local[k] = segmentor.generate(**kwargs).astype("int32")
     dev = predictor.device if world > 1 and dist.get_backend() == "nccl" else "cpu"
-    out = parallel.gather_label_tiles(torch.as_tensor(local, device=dev), data.shape[0])
+    local = None
+    if stop - start > 1 and _can_pipeline(data[start:stop], predictor, segmentor, None, None, kwargs):
+        # the rank's block through the device pipeline, labels left in HBM for the gather (ids 1..K per item: the gather derives the
+        # serial loop's offsets from the per-item max ids of ALL ranks)
+        res = _segment_slices_pipelined(data[start:stop], predictor, segmentor, batch_size, 3, True, kwargs, offsets=False)
+        if res is not None:
+            local = res[0].to(dev)
+    if local is None:
+        host = np.zeros((stop - start,) + data.shape[1:], dtype="int32")
+        if stop > start:
+            emb = util.precompute_image_embeddings(predictor=predictor, input_=data[start:stop], ndim=3, verbose=verbose,
+                                                   batch_size=batch_size, keep_on_device=True)
+            for k in range(stop - start):
+                segmentor.initialize(data[start + k], image_embeddings=emb, verbose=False, i=k)
+                host[k] = segmentor.generate(**kwargs).astype("int32")
+        local = torch.as_tensor(host, device=dev)
+    out = parallel.gather_label_tiles(local, data.shape[0])
     return out.cpu().numpy().astype("uint32")
 
 

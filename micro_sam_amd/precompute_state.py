@@ -136,3 +136,98 @@ def cache_amg_state(predictor: SamPredictor, raw: np.ndarray, image_embeddings: 
     os.makedirs(save_path, exist_ok=True)
     save_amg_state(amg.get_state(), save_path_amg)   # device columns -> host tensors / RLE dicts, reference class path
     return amg
+
+
+# ------------------------------------------------------------------------------------------------ is_state (decoder-based segmenters)
+
+class _NpzGroup(dict):
+    """One group of the h5py-less state container: dataset name -> array."""
+
+    def create_dataset(self, name, data=None, compression=None):
+        self[name] = np.asarray(data)
+        return self[name]
+
+
+class _NpzStateFile:
+    """The subset of ``h5py.File(path, "a")`` that ``cache_is_state`` uses (``key in f``, ``f[key][name][:]``, ``create_group`` +
+    ``create_dataset(name, data=, compression="gzip")``) over one compressed ``.npz`` file with keys ``<group>/<dataset>`` - the
+    container of installations WITHOUT h5py.  It is this package's own format (``is_state.npz`` next to where ``is_state.h5`` would
+    be): the reference's tools read ``is_state.h5`` only, which is written whenever h5py is importable."""
+
+    def __init__(self, path):
+        self._path = path
+        self._groups: Dict[str, _NpzGroup] = {}
+        if os.path.exists(path):
+            with np.load(path) as z:
+                for key in z.files:
+                    g, name = key.split("/", 1)
+                    self._groups.setdefault(g, _NpzGroup())[name] = z[key]
+        self._dirty = False
+
+    def __contains__(self, key):
+        return key in self._groups
+
+    def __getitem__(self, key):
+        return self._groups[key]
+
+    def create_group(self, key):
+        if key in self._groups:
+            raise ValueError(f"Unable to create group (name already exists): {key}")
+        self._dirty = True
+        self._groups[key] = _NpzGroup()
+        return self._groups[key]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self._dirty and exc[0] is None:
+            tmp = self._path + ".tmp.npz"
+            np.savez_compressed(tmp, **{f"{g}/{name}": arr for g, grp in self._groups.items() for name, arr in grp.items()})
+            os.replace(tmp, self._path)
+        return False
+
+
+def _open_is_state(save_path):
+    """(context manager, file path): ``is_state.h5`` through h5py when it is importable (the reference's container, gzip datasets,
+    precompute_state.py:124-153), else ``is_state.npz`` (see ``_NpzStateFile``)."""
+    try:
+        import h5py
+    except ImportError:
+        path = os.path.join(save_path, "is_state.npz")
+        return _NpzStateFile(path), path
+    path = os.path.join(save_path, "is_state.h5")
+    return h5py.File(path, "a"), path
+
+
+def cache_is_state(predictor: SamPredictor, decoder, raw: np.ndarray, image_embeddings: util.ImageEmbeddings,
+                   save_path: Union[str, os.PathLike], verbose: bool = True, i: Optional[int] = None, skip_load: bool = False,
+                   **kwargs):
+    """Reference ``cache_is_state`` (precompute_state.py:90-155): compute - or load - the state of the decoder-based segmenter
+    (foreground, centre distances, boundary distances) under ``save_path/is_state.h5``, group ``state`` or ``state-{i}``."""
+    is_tiled = image_embeddings["input_size"] is None
+    amg = instance_segmentation.get_instance_segmentation_generator(predictor, is_tiled=is_tiled, decoder=decoder, **kwargs)
+    os.makedirs(save_path, exist_ok=True)
+    save_key = "state" if i is None else f"state-{i}"
+    store, path = _open_is_state(str(save_path))
+    with store as f:
+        if save_key in f:
+            if skip_load:
+                return None
+            if verbose:
+                print("Load instance segmentation state from", path, ":", save_key)
+            g = f[save_key]
+            amg.set_state({"foreground": g["foreground"][:], "boundary_distances": g["boundary_distances"][:],
+                           "center_distances": g["center_distances"][:]})
+            return amg
+    if verbose:
+        print("Precomputing the state for instance segmentation.")
+    amg.initialize(raw, image_embeddings=image_embeddings, verbose=verbose, i=i)
+    state = amg.get_state()
+    store, _ = _open_is_state(str(save_path))
+    with store as f:
+        g = f.create_group(save_key)
+        g.create_dataset("foreground", data=state["foreground"], compression="gzip")
+        g.create_dataset("boundary_distances", data=state["boundary_distances"], compression="gzip")
+        g.create_dataset("center_distances", data=state["center_distances"], compression="gzip")
+    return amg

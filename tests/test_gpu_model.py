@@ -534,6 +534,20 @@ def test_cache_amg_state_and_segment_slices(ctx, tmp_path):
         offset += int(s.max())
         assert np.array_equal(out[z], expect)
     assert np.array_equal(mds.segment_slices_sharded(vol, p, AutomaticMaskGenerator(p, **kw), batch_size=2, **gen_kw), out)
+    # the call above took the device pipeline (round 4): it reproduces the reference's loop (decode_lanes=0), also with a ragged last
+    # batch and fewer lanes than slices, and leaves generator + predictor as the loop does (initialised on the last slice)
+    assert mds._can_pipeline(vol, p, AutomaticMaskGenerator(p, **kw), None, None, gen_kw)
+    out0, _ = mds.segment_slices(vol, p, AutomaticMaskGenerator(p, **kw), batch_size=2, decode_lanes=0, **gen_kw)
+    assert np.array_equal(out0, out)
+    vol5 = np.concatenate([vol, vol[:2]])
+    g = AutomaticMaskGenerator(p, **kw)
+    out5, emb5 = mds.segment_slices(vol5, p, g, batch_size=2, decode_lanes=2, **gen_kw)
+    ref5, _ = mds.segment_slices(vol5, p, AutomaticMaskGenerator(p, **kw), batch_size=3, decode_lanes=0, **gen_kw)
+    assert np.array_equal(out5, ref5) and out5[3:].max() > out5[:3].max()
+    assert g.is_initialized and p.is_image_set and tuple(emb5["features"].shape) == (5, 1, 256, 64, 64)
+    last = g.generate(**gen_kw)
+    assert np.array_equal(np.where(last != 0, last + (out5[4][out5[4] != 0].min() - 1 if last.max() else 0), 0), out5[4])
+    assert not mds._can_pipeline(vol, p, AutomaticMaskGenerator(p, **kw), None, None, dict(output_mode="binary_mask"))
 
 
 def test_vit_l_encoder_and_decode_vs_oracle():

@@ -80,8 +80,9 @@ def test_segment_from_prompts_vs_oracle(ctx):
     pts_in, lbl_in = PB._compute_points_from_mask(m, None, box_extension=0.05)
     got = PB.segment_from_mask(p, m, return_all=True)
     dis.append(_compare(got, oracle(box=box_in, mask_input=logits_in, multimask_output=False)))
-    with pytest.raises(NotImplementedError):                 # a mask prompt on its own is not provided (modeling.Sam.decode)
-        PB.segment_from_mask(p, m, use_box=False)
+    # the mask alone (reference :308-407 with use_box=False, use_points=False: no sparse token, the five output tokens only)
+    got = PB.segment_from_mask(p, m, use_box=False, return_all=True)
+    dis.append(_compare(got, oracle(mask_input=logits_in, multimask_output=False)))
     # the decoder takes at most 16 tokens per prompt (9 points next to a box); the sampled set of this disk has 13 points, so
     # `use_points=True` next to a box raises here - the centre point is passed explicitly instead (as is: XY)
     assert len(pts_in) == 13 and lbl_in[:5].tolist() == [1, 0, 0, 0, 0]

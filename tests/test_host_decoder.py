@@ -93,3 +93,28 @@ def test_prompt_encoder_module_call_on_the_host_library(host_sam, kind):
         assert sparse.shape == rs.shape and (sparse - rs).abs().max().item() < 2e-4
     assert dense.shape == (P, 256, 64, 64)
     assert (dense - rd).abs().max().item() < (2e-3 if mk is not None else 1e-6)
+
+
+def test_mask_prompt_alone_decodes_on_the_host_library(host_sam):
+    """A mask prompt on its own (reference prompt_based_segmentation.segment_from_mask(use_box=False, use_points=False), :308-407):
+    no sparse token - the five output tokens only - and the mask entering through the per-prompt source stream; round 4 (VERDICT r3
+    missing #4).  Against the oracle's predict_torch with the same mask input; a prompt with nothing at all is still refused."""
+    from oracle import sam_ref as S
+    host, sam, sd = host_sam
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(1, 256, 64, 64, generator=g) * 0.6
+    yy, xx = torch.meshgrid(torch.arange(256.0), torch.arange(256.0), indexing="ij")
+    mask_in = torch.stack([((yy - 120) ** 2 + (xx - 90) ** 2 < 40 ** 2).float() * 32 - 16,
+                           ((yy - 60) ** 2 + (xx - 200) ** 2 < 25 ** 2).float() * 32 - 16])[:, None]          # [2,1,256,256] logits
+    with torch.no_grad():
+        _, iou_b, low_b = S.predict_torch(sd, feats, (1024, 1024), (1024, 1024), None, None, None, mask_in, multimask_output=False,
+                                          return_logits=True, precision="bf16")
+    sam.invalidate()
+    low, iou = sam.decode(feats, None, None, None, mask_in, multimask_output=False)
+    assert low.shape == (2, 1, 256, 256) and iou.shape == (2, 1)
+    scale = low_b.abs().max().item()
+    d = (low - low_b).abs()
+    assert torch.isfinite(low).all() and d.max().item() <= 0.03 * scale and d.mean().item() <= 0.006 * scale, (d.max().item() / scale, d.mean().item() / scale)
+    assert (iou - iou_b).abs().max().item() <= 2e-3
+    with pytest.raises(ValueError):
+        sam.decode(feats, None, None, None, None)

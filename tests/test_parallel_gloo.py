@@ -63,6 +63,35 @@ def test_gather_label_tiles_matches_serial_offsets(n_items):
         assert np.array_equal(results[r], expect), r
 
 
+@pytest.mark.parametrize("n_items", [256, 61])       # BASELINE configs[1]'s 256 tiles (32 per rank) / a 61-slice volume (5 ranks x 8 + 3 x 7)
+def test_world_8_partitions(n_items):
+    """The 8-rank partitions the driver's scaling run uses, on gloo: equal blocks and the uneven-remainder path."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    rng = np.random.default_rng(0)
+    full = [rng.integers(0, 5 + i, size=(8, 8)).astype(np.int32) for i in range(n_items)]
+    offset, expect = 0, []
+    for seg in full:
+        seg = seg.copy()
+        m = seg.max()
+        seg[seg != 0] += offset
+        offset += m
+        expect.append(seg)
+    expect = np.stack(expect)
+    counts = [parallel.shard_range(n_items, r, world) for r in range(world)]
+    assert sorted(b - a for a, b in counts)[0] >= n_items // world and sum(b - a for a, b in counts) == n_items
+    for r in range(world):
+        assert np.array_equal(results[r], expect), r
+
+
 def test_single_process_path():
     x = torch.tensor([[[0, 1], [2, 0]], [[1, 1], [0, 3]]], dtype=torch.int32)
     out = parallel.gather_label_tiles(x, 2)

@@ -1,4 +1,5 @@
-"""GPU-box probes of the large-shape GEMM kernels behind msam_gemm_bf16 (round 3; results: profiles/r03_experiments.md section 7).
+"""(needs a library built with `python -m micro_sam_amd.build --experiments`: the production build ignores these knobs)
+GPU-box probes of the large-shape GEMM kernels behind msam_gemm_bf16 (round 3; results: profiles/r03_experiments.md section 7).
 
     python tools/gemm_probe.py power      # k-loop / full kernel on random, zero and small-integer operands: what bounds the k-loop
     python tools/gemm_probe.py operands   # gemm_dbg 8 / 16: every operand k-tile read from k = 0 (cache hits)

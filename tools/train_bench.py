@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--sub-iterations", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--device-time", action="store_true",
+                    help="after the timed steps: one step under the torch profiler -> share of the GPU time in kernels that are NOT this "
+                         "library's (at::native element-wise / reductions, rocBLAS / hipBLASLt, copies) and kernel launches per step")
     ap.add_argument("--op-profile", type=int, default=0, help="print the N heaviest torch operators (by device time, with input shapes) of one step")
     args = ap.parse_args()
     from micro_sam_amd.synthetic import synthetic_state_dict
@@ -88,8 +91,32 @@ def main():
     dt = torch.tensor([time.perf_counter() - t0], device=dev)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    extra = {}
+    if args.device_time and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            trainer.train_iteration(*batches[0])
+            torch.cuda.synchronize()
+        tot = non = 0.0
+        n_launch = 0
+        worst = {}
+        for e in prof.key_averages():
+            t = float(getattr(e, "self_device_time_total", 0.0) or getattr(e, "self_cuda_time_total", 0.0))
+            if t <= 0:
+                continue
+            tot += t
+            n_launch += int(e.count)
+            name = str(e.key)
+            foreign = any(k in name for k in ("at::", "Cijk_", "rocblas", "hipblas", "ck::", "miopen", "Memcpy", "Memset", "copyBuffer", "fillBuffer"))
+            if foreign:
+                non += t
+                worst[name[:80]] = worst.get(name[:80], 0.0) + t
+        extra = {"non_hip_device_time_frac": round(non / tot, 4) if tot else None, "kernel_launches_per_step": n_launch,
+                 "device_ms_per_step": round(tot / 1e3, 2),
+                 "largest_foreign_kernels": [[k, round(v / tot, 4)] for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]]}
     if rank == 0:
-        print(json.dumps({"metric": f"fine-tuning steps/s ({args.model}, batch {args.batch} x {world} GPUs, {args.objects} objects, "
+        print(json.dumps({**extra, "model": args.model, "ms_per_step": round(float(dt) / args.steps * 1e3, 1),
+                          "metric": f"fine-tuning steps/s ({args.model}, batch {args.batch} x {world} GPUs, {args.objects} objects, "
                                     f"{args.sub_iterations} sub-iterations)", "value": round(args.steps / float(dt), 4), "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "trained_parameters": sum(p.numel() for p in params),
                           "frozen": args.freeze or [], "lora_rank": args.lora_rank, "last_loss": rec["loss"],
