@@ -188,22 +188,36 @@ def api_inclusive(predictor, amg, tiles_np, n_api, enc_batch):
     seg, _ = mds.segment_slices(stack, predictor, amg, batch_size=enc_batch)
     torch.cuda.synchronize()
     t_pipe = time.perf_counter() - t0
+    loop_segs = np.zeros(stack.shape, dtype=np.uint32)          # (allocated and touched before the clock, as a caller's result volume is)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     emb = util.precompute_image_embeddings(predictor, stack, ndim=3, batch_size=enc_batch, verbose=False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    loop_segs = []
     for z in range(n_api):
         amg.initialize(stack[z], emb, i=z)
-        loop_segs.append(amg.generate())
+        loop_segs[z] = amg.generate()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    n_inst, offset, same = 0, 0, True
+    n_inst, offset, differing = 0, 0, []
     for z, s in enumerate(loop_segs):               # (outside the clock) the pipelined volume == the caller's loop + running offsets
         m = int(s.max())
         n_inst += m
-        same = same and bool(np.array_equal(np.where(s != 0, s + np.uint32(offset), 0).astype(np.uint32), seg[z]))
+        if not np.array_equal(np.where(s != 0, s + np.uint32(offset), 0).astype(np.uint32), seg[z]):
+            differing.append(z)
         offset += m
+    same = not differing
+    if differing:
+        log(f"api_inclusive: pipelined volume differs from the caller's loop in slices {differing}")
+        if os.environ.get("MSAM_API_DEBUG"):
+            third, _ = mds.segment_slices(stack, predictor, amg, batch_size=enc_batch, decode_lanes=0)
+            again, _ = mds.segment_slices(stack, predictor, amg, batch_size=enc_batch)
+            z = differing[0]
+            off = int(sum(int(loop_segs[k].max()) for k in range(z)))
+            exp = np.where(loop_segs[z] != 0, loop_segs[z] + np.uint32(off), 0).astype(np.uint32)
+            log(f"  slice {z}: px differing pipeline/loop {int((exp != seg[z]).sum())}, serial-product/loop {int((exp != third[z]).sum())}, "
+                f"pipeline-again/loop {int((exp != again[z]).sum())}, pipeline/pipeline-again {int((seg[z] != again[z]).sum())}; max ids loop "
+                f"{int(loop_segs[z].max())} pipeline {int(seg[z].max())} serial-product {int(third[z].max())}; fg px loop {int((exp != 0).sum())} pipeline {int((seg[z] != 0).sum())}")
     return {"value": round(n_api / t_pipe, 2), "unit": "tiles/s", "tiles": n_api,
             "what": f"multi_dimensional_segmentation.segment_slices(stack[{n_api},1024,1024] uint8 host array, predictor, "
                     f"AutomaticMaskGenerator, batch_size={enc_batch}) -> uint32 [Z,Y,X] host volume with the serial loop's running id "
@@ -352,7 +366,7 @@ def main():
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side measurements (pcie_inclusive, api_inclusive, rle_side, interactive_side): profiling runs, so "
                          "that per-kernel averages hold the hot path's launches only")
-    ap.add_argument("--api-tiles", type=int, default=32, help="tiles of the api_inclusive side measurement")
+    ap.add_argument("--api-tiles", type=int, default=TILES_PER_STEP, help="tiles of the api_inclusive side measurement (default: one step's worth)")
     ap.add_argument("--no-config-sides", action="store_true",
                     help="skip config3_side / fp8_side / train_side (the other named configurations as short side runs, N = 1 only)")
     ap.add_argument("--dry-run", action="store_true",
@@ -459,7 +473,18 @@ def main():
     comm_stream = torch.cuda.Stream(device=dev) if (world > 1 or force_dist) else None
     shape_only = np.broadcast_to(np.zeros((1, 1), dtype=np.uint8), (1024, 1024))   # initialize() reads the image SHAPE only
 
-    def step(timed: bool, index: int, uploads=None, serial: bool = False, wait_gather: bool = False):
+    flag_ring = [torch.zeros(1, dtype=torch.int64).pin_memory() for _ in range(2)]
+    flag_pending = []                  # (page-locked word, event) of steps whose convergence flags have not been read yet
+
+    def check_flags(keep: int = 0):
+        """Read the convergence flags of all but the `keep` most recent steps (their event has fired or is waited for)."""
+        while len(flag_pending) > keep:
+            word, ev = flag_pending.pop(0)
+            ev.synchronize()
+            if int(word.item()) != 0:
+                raise RuntimeError("connected-component labelling did not converge in 2 passes")
+
+    def step(timed: bool, index: int, uploads=None, serial: bool = False, wait_gather: bool = False, defer_flags: bool = False):
         """timed=True: instrumented pass with a device sync after every stage (stage breakdown only);
         timed=False: the production path, no extra synchronisation.  uploads: host tiles to convert + upload inside the step
         (the PCIe-inclusive pass), else the resident uint8 tiles of step `index` are used."""
@@ -536,9 +561,15 @@ def main():
             if pinned_labels[0] is None or pinned_labels[0].shape != full.shape:
                 pinned_labels[0] = torch.empty(full.shape, dtype=full.dtype).pin_memory()
             host_labels = pinned_labels[0].copy_(full, non_blocking=True)
-        # single synchronisation point of the step: convergence flags of the connected-component labelling
-        if int(torch.stack(flags).sum().item()) != 0:
-            raise RuntimeError("connected-component labelling did not converge in 2 passes")
+        # single synchronisation point of the step: convergence flags of the connected-component labelling.  In the timed loop the
+        # flags of step k are read while step k + 1 is already queued (defer_flags: a page-locked word + an event per step), so that the
+        # GPU does not drain at every step boundary - the next step's first encoder batch runs under this step's last decode lanes
+        word = flag_ring[index & 1]
+        word.copy_(torch.stack(flags).sum().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        flag_pending.append((word, ev))
+        check_flags(keep=1 if defer_flags else 0)
         if timed:
             n_instances.extend(int(v) for v in labels.flatten(1).max(dim=1).values.tolist())
         return host_labels if uploads is not None else full
@@ -557,9 +588,10 @@ def main():
     stage["host_enqueue"] = 0.0
     t_start = time.perf_counter()
     for k in range(args.steps):
-        step(False, args.warmup + k)
+        step(False, args.warmup + k, defer_flags=not profile_in_timed_region)
         if profile_in_timed_region:
             collect()        # synchronises the step's kernel events (end of step: nothing left in flight anyway)
+    check_flags()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

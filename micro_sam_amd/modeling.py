@@ -37,13 +37,31 @@ def _d16(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(_lib.decoder_dtype()).contiguous()
 
 
-def _param_key(*modules) -> int:
+class _ParamWatch:
     """Identity of the parameter set behind cached 16-bit operand copies: per parameter the object, its in-place version counter
-    (optimizer step, ``copy_``, ``load_state_dict``), its storage address and its device - so a replaced ``Parameter``, a
+    (optimizer step, ``copy_``, ``load_state_dict``), its storage address and its device - so a replaced ``Parameter``
+    (``module.weight = nn.Parameter(...)`` updates the module's ``_parameters`` dict, which is what is read here), a
     ``param.data = ...`` assignment (``module.to()`` / ``half()`` keep the old counter) and a move to another device rebuild the
-    copies as well.  The parameters are re-read on every call.  NOT seen: writes through ``p.data`` that keep the
-    storage (``p.data.mul_()``, an EMA written through ``.data``) - such writers call the module's public ``invalidate()``."""
-    return hash(tuple((id(q), q._version, q.data_ptr(), q.device.index) for m in modules for q in m.parameters()))
+    copies as well.  The (dict, name) slots are collected once per module tree - walking ``parameters()`` on every
+    call cost 0.4 ms per decode (measured, round 4) - and again after ``invalidate()``, which is also what code that ADDS modules or
+    writes through ``p.data`` in place (``p.data.mul_()``, an EMA) has to call."""
+
+    def __init__(self, *modules) -> None:
+        self._modules = modules
+        self._slots = None
+
+    def reset(self) -> None:
+        self._slots = None
+
+    def key(self) -> int:
+        if self._slots is None:
+            self._slots = [(m._parameters, name) for root in self._modules for m in root.modules() for name in m._parameters]
+        acc = []
+        for d, name in self._slots:
+            q = d.get(name)
+            if q is not None:
+                acc.append((id(q), q._version, q.data_ptr(), q.device.index))
+        return hash(tuple(acc))
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -125,11 +143,13 @@ class ImageEncoderViT(nn.Module):
         # rounding costs in mask parity (profiles/r03_enc_ablation.txt); set_split_io(False) = plain 16-bit
         self.split_io = True
         self._prep = None
+        self._watch = _ParamWatch(self)
         self._workspace = None
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
 
     def invalidate(self) -> None:
         self._prep = None
+        self._watch.reset()
 
     def set_precision(self, precision: str) -> None:
         """"bf16" (default: every matrix-product operand bf16); "fp16": every operand and stored activation IEEE fp16 instead -
@@ -152,7 +172,7 @@ class ImageEncoderViT(nn.Module):
 
     def _prepare(self):
         if self._prep is not None:
-            if _param_key(self) == self._prep_versions:
+            if self._watch.key() == self._prep_versions:
                 return self._prep
             self._prep = None       # a parameter was updated in place (optimizer step, copy_): rebuild the operand copies
         dev = self.pos_embed.device
@@ -230,7 +250,7 @@ class ImageEncoderViT(nn.Module):
         p.use_glds = int(self.use_glds)
         p.fp8 = 1 if self.precision == "fp8" else 0
         self._prep = (p, keep)
-        self._prep_versions = _param_key(self)
+        self._prep_versions = self._watch.key()
         return self._prep
 
     def _get_workspace(self, params, B: int) -> torch.Tensor:
@@ -403,6 +423,7 @@ class Sam(nn.Module):
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
         self.use_glds = 0
         self._dec = None            # (params, keep-alive tensors, consts buffer)
+        self._watch = _ParamWatch(self.prompt_encoder, self.mask_decoder)
         self._img_state = None      # (key, buffer)
         self._dec_ws = None
         self.prompt_encoder._dense_pe_fn = self._dense_pe
@@ -418,6 +439,7 @@ class Sam(nn.Module):
     def invalidate(self) -> None:
         self._dec = None
         self._img_state = None
+        self._watch.reset()
         self.image_encoder.invalidate()
 
     def lane_view(self) -> "Sam":
@@ -453,7 +475,7 @@ class Sam(nn.Module):
     # -- decoder plumbing
     def _prepare_decoder(self):
         if self._dec is not None:
-            if _param_key(self.prompt_encoder, self.mask_decoder) == self._dec_versions:
+            if self._watch.key() == self._dec_versions:
                 return self._dec
             self._dec = None        # a parameter was updated in place (optimizer step, copy_): rebuild the 16-bit copies / tables
             self._img_state = None
@@ -531,7 +553,7 @@ class Sam(nn.Module):
         _lib.check(lib.msam_decoder_prepare_const(C.byref(p), consts.data_ptr(), _lib.stream_ptr()),
                    "msam_decoder_prepare_const")
         self._dec = (p, keep, consts)
-        self._dec_versions = _param_key(self.prompt_encoder, self.mask_decoder)
+        self._dec_versions = self._watch.key()
         return self._dec
 
     def _dense_pe(self) -> torch.Tensor:

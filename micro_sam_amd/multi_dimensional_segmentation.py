@@ -65,7 +65,8 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
     feats = torch.empty((Z, 1, modeling.PROMPT_DIM, modeling.GRID, modeling.GRID), dtype=torch.float32, device=dev)
     labels = torch.empty((Z, H, W), dtype=torch.int32, device=dev)
     emb = {"features": feats, "input_size": None, "original_size": None}
-    carry = torch.zeros((), dtype=torch.int64, device=dev)
+    carry = None                                     # running id offset: lives on the post stream (allocated, updated and read there only -
+    #                                                  a tensor of the main stream's pool dropped here would be recycled under the post stream's reads)
     out = None if return_device else np.empty((Z, H, W), dtype=np.uint32)
     pins = [None, None]
     pending = None                                   # (s0, s1, slot, event) of the batch whose labels are on their way to the host
@@ -76,8 +77,10 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
         ev.synchronize()
         np.copyto(out[s0:s1], pins[slot][: s1 - s0].numpy().view(np.uint32))
 
-    for b, s0 in enumerate(range(0, Z, batch_size)):
-        s1 = min(s0 + batch_size, Z)
+    # (the encoder batches are exactly the caller's batch_size: the encoder's GEMM kernels are chosen by the row count, so another
+    #  internal schedule - e.g. a short first batch to start the lanes earlier - could move last bits of the embeddings)
+    bounds = [(s0, min(s0 + batch_size, Z)) for s0 in range(0, Z, batch_size)]
+    for b, (s0, s1) in enumerate(bounds):
         f, osz, isz = util._compute_embeddings_batched_raw(predictor, [np.asarray(data[z]) for z in range(s0, s1)])
         feats[s0:s1, 0] = f
         emb["input_size"], emb["original_size"] = isz[-1], osz[-1]
@@ -99,6 +102,8 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
         with torch.cuda.stream(post):
             blk = labels[s0:s1]
             if offsets:
+                if carry is None:
+                    carry = torch.zeros((), dtype=torch.int64, device=dev)
                 mx = blk.flatten(1).amax(dim=1).to(torch.int64)
                 offs = (torch.cumsum(mx, 0) - mx + carry).view(-1, 1, 1).to(blk.dtype)
                 blk += torch.where(blk != 0, offs, torch.zeros_like(offs))
@@ -111,6 +116,8 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
                 ev = torch.cuda.Event()
                 ev.record(post)
         if out is not None:
+            out[s0:s1].fill(0)               # first touch of the result's pages (fresh allocation: ~10 ms of page faults per 64 MiB) now,
+            #                                  while the device works, instead of inside the drain at the end of the pipeline
             if pending is not None:
                 drain(pending)               # batch b - 1: complete by now or soon - batch b is already queued behind it
             pending = (s0, s1, slot, ev)

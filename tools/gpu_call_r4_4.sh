@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_prompt_based_segmentation.py tests/test_gpu_modules.py -x -q 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "set_image or lora or amg_initialize" 2>&1 | tail -3
 timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "segment_slices" 2>&1 | tail -3
 timeout 900 python bench.py --no-cpu-baseline --no-config-sides --steps 2 > gpurun_out/r4_4_bench.log 2> gpurun_out/r4_4_bench.err; tail -c 400 gpurun_out/r4_4_bench.err
 python - <<'PY'
