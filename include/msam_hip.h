@@ -451,6 +451,11 @@ typedef struct {
     msam_attn_w_t self_attn, t2i, i2t;
     const float *n1_w, *n1_b, *n2_w, *n2_b, *n3_w, *n3_b, *n4_w, *n4_b;
     const void* mlp1_w; const float* mlp1_b; const void* mlp2_w; const float* mlp2_b;
+    /* optional (NULL = plain 16-bit operands): the two MLP weights as hi + lo pairs of the decoder's 16-bit type, rows
+     * [Whi | Whi | Wlo]: lin1 [2048, 3 * 256], lin2 [256, 3 * 2048].  With both set the MLP's activations enter their products as
+     * [hi | lo | hi] rows as well (msam_cast_f32_split16; ~22 significand bits with fp16): the ReLU hidden of the token MLP is the
+     * decoder's most rounding-sensitive tensor (profiles/r04_experiments.md section 3). */
+    const void* mlp1_ws; const void* mlp2_ws;
 } msam_twoway_layer_t;
 typedef struct {
     /* prompt encoder */

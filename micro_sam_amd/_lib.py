@@ -81,7 +81,7 @@ class TwoWayLayer(C.Structure):
     _fields_ = [("self_attn", AttnW), ("t2i", AttnW), ("i2t", AttnW),
                 ("n1_w", _vp), ("n1_b", _vp), ("n2_w", _vp), ("n2_b", _vp), ("n3_w", _vp), ("n3_b", _vp),
                 ("n4_w", _vp), ("n4_b", _vp),
-                ("mlp1_w", _vp), ("mlp1_b", _vp), ("mlp2_w", _vp), ("mlp2_b", _vp)]
+                ("mlp1_w", _vp), ("mlp1_b", _vp), ("mlp2_w", _vp), ("mlp2_b", _vp), ("mlp1_ws", _vp), ("mlp2_ws", _vp)]
 
 
 class DecoderParams(C.Structure):

@@ -880,11 +880,27 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         // (3) token MLP
         ADD_CAST(w.queries, nullptr, w.a);
         }
-        CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_D16, 2048, MSAM_ACT_RELU));
-        if (fuse_tok) {
-            CHECK(gemm_ln_tok(cx, w.mlp_h, 2048, L.mlp2_w, M, 2048, L.mlp2_b, w.queries, L.n3_w, L.n3_b, w.queries, w.qpe, w.a, w.b));
+        // token MLP.  mlp_split (round 4): both products on hi + lo operand pairs - the LayerNorm output (fp32, w.queries) and the ReLU
+        // hidden (kept in fp32) are laid out as [hi | lo | hi] rows against [Whi | Whi | Wlo] weight rows, one plain 16-bit GEMM over
+        // 3 K each.  The 2048-wide hidden is the decoder's most rounding-sensitive tensor (on generic weights its fp16 rounding alone
+        // was 60 % of the low-res logit error, profiles/r04_experiments.md section 3); the scratch lives in the otherwise unused w.pre
+        const bool mlp_split = L.mlp1_ws != nullptr && L.mlp2_ws != nullptr;
+        const void* mlp_h = w.mlp_h; const void* mlp2_w = L.mlp2_w; int mlp2_k = 2048;
+        if (mlp_split) {
+            u16* a3 = (u16*)w.pre;
+            float* h32 = (float*)((char*)a3 + align256((long)M * 3 * C * 2));
+            u16* h3 = (u16*)((char*)h32 + align256((long)M * 2048 * 4));
+            CHECK(msam_cast_f32_split16(w.queries, MSAM_D16, a3, M, C, cx.s));
+            CHECK(gemm(cx, a3, 3 * C, L.mlp1_ws, M, 2048, 3 * C, L.mlp1_b, h32, MSAM_F32, 2048, MSAM_ACT_RELU));
+            CHECK(msam_cast_f32_split16(h32, MSAM_D16, h3, M, 2048, cx.s));
+            mlp_h = h3; mlp2_w = L.mlp2_ws; mlp2_k = 3 * 2048;
         } else {
-        CHECK(gemm(cx, w.mlp_h, 2048, L.mlp2_w, M, C, 2048, L.mlp2_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
+        CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_D16, 2048, MSAM_ACT_RELU));
+        }
+        if (fuse_tok) {
+            CHECK(gemm_ln_tok(cx, mlp_h, mlp2_k, mlp2_w, M, mlp2_k, L.mlp2_b, w.queries, L.n3_w, L.n3_b, w.queries, w.qpe, w.a, w.b));
+        } else {
+        CHECK(gemm(cx, mlp_h, mlp2_k, mlp2_w, M, C, mlp2_k, L.mlp2_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n3_w, L.n3_b, M, w.queries, MSAM_F32);
         // (4) image -> token attention, updates the image-token stream
         ADD_CAST2(w.queries, w.qpe, w.a, w.b);

@@ -64,6 +64,14 @@ class _ParamWatch:
         return hash(tuple(acc))
 
 
+def _split16(w: torch.Tensor) -> torch.Tensor:
+    """Weight [N, K] as hi + lo pairs of the decoder's 16-bit type, rows [Whi | Whi | Wlo] (against activation rows [hi | lo | hi])."""
+    w = w.detach().to(torch.float32)
+    hi = w.to(_lib.decoder_dtype())
+    lo = (w - hi.to(torch.float32)).to(_lib.decoder_dtype())
+    return torch.cat([hi, hi, lo], dim=1).contiguous()
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -423,6 +431,9 @@ class Sam(nn.Module):
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
         self.use_glds = 0
         self._dec = None            # (params, keep-alive tensors, consts buffer)
+        # the two products of the token MLP on hi + lo operand pairs (round 4: the ReLU hidden is the decoder's most rounding-sensitive
+        # tensor; 0.2 % of the decoder's flops); set_split_token_mlp(False) = the plain 16-bit operands of rounds 1 - 3
+        self.split_token_mlp = True
         self._watch = _ParamWatch(self.prompt_encoder, self.mask_decoder)
         self._img_state = None      # (key, buffer)
         self._dec_ws = None
@@ -441,6 +452,12 @@ class Sam(nn.Module):
         self._img_state = None
         self._watch.reset()
         self.image_encoder.invalidate()
+
+    def set_split_token_mlp(self, on: bool) -> None:
+        if bool(on) != bool(self.split_token_mlp):
+            self.split_token_mlp = bool(on)
+            self._dec = None
+            self._img_state = None
 
     def lane_view(self) -> "Sam":
         """A second handle on THIS model for a concurrent decode lane (another HIP stream working on another image): parameters, modules
@@ -511,6 +528,8 @@ class Sam(nn.Module):
                 setattr(L, f"n{j}_b", k(_f32(nm.bias)))
             L.mlp1_w, L.mlp1_b = k(_d16(blk.mlp.lin1.weight)), k(_f32(blk.mlp.lin1.bias))
             L.mlp2_w, L.mlp2_b = k(_d16(blk.mlp.lin2.weight)), k(_f32(blk.mlp.lin2.bias))
+            if self.split_token_mlp:
+                L.mlp1_ws, L.mlp2_ws = k(_split16(blk.mlp.lin1.weight)), k(_split16(blk.mlp.lin2.weight))
         attn(p.final_attn, md.transformer.final_attn_token_to_image)
         p.nf_w, p.nf_b = k(_f32(md.transformer.norm_final_attn.weight)), k(_f32(md.transformer.norm_final_attn.bias))
         up = md.output_upscaling

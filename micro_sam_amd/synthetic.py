@@ -220,15 +220,15 @@ def scale_mask_logits(sd, scale: float):
     return sd
 
 
-def synthetic_tile(seed: int, shape: Tuple[int, int] = (1024, 1024)) -> np.ndarray:
-    """uint8 [H,W] cell-like tile: noisy background + blurred random ellipses (SURVEY.md 8(d) config 2)."""
+def _synthetic_tile(seed: int, shape: Tuple[int, int], with_labels: bool):
     from scipy.ndimage import gaussian_filter
     rng = np.random.default_rng(seed)
     h, w = shape
     img = np.clip(rng.normal(40.0, 10.0, size=shape), 0, 255).astype(np.float32)
+    labels = np.zeros(shape, dtype=np.int32) if with_labels else None
     n_obj = int(rng.integers(40, 121) * (h * w) / (1024 * 1024)) or 1
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
-    for _ in range(n_obj):
+    for k in range(n_obj):
         cy, cx = rng.uniform(0, h), rng.uniform(0, w)
         a, b = rng.uniform(8, 40, size=2)
         th = rng.uniform(0, np.pi)
@@ -240,9 +240,22 @@ def synthetic_tile(seed: int, shape: Tuple[int, int] = (1024, 1024)) -> np.ndarr
         v = -dx * np.sin(th) + dy * np.cos(th)
         inside = (u / a) ** 2 + (v / b) ** 2 < 1.0
         img[y0:y1, x0:x1][inside] = val
+        if with_labels:
+            labels[y0:y1, x0:x1][inside] = k + 1                 # later ellipses cover earlier ones, as in the image
     img = gaussian_filter(img, 1.5)
     img = img + rng.normal(0.0, 6.0, size=shape).astype(np.float32)
-    return np.clip(img, 0, 255).astype(np.uint8)
+    return np.clip(img, 0, 255).astype(np.uint8), labels
+
+
+def synthetic_tile(seed: int, shape: Tuple[int, int] = (1024, 1024)) -> np.ndarray:
+    """uint8 [H,W] cell-like tile: noisy background + blurred random ellipses (SURVEY.md 8(d) config 2)."""
+    return _synthetic_tile(seed, shape, False)[0]
+
+
+def synthetic_tile_with_labels(seed: int, shape: Tuple[int, int] = (1024, 1024)) -> Tuple[np.ndarray, np.ndarray]:
+    """``synthetic_tile(seed, shape)`` (the same pixels) and the instance label image of its ellipses (int32, 0 = background; an ellipse
+    covered completely by later ones has no pixel left): training pairs for the fine-tuning path (tools/trained_parity.py)."""
+    return _synthetic_tile(seed, shape, True)
 
 
 def three_disk_fixture(size: int = 256) -> Tuple[np.ndarray, np.ndarray]:

@@ -85,8 +85,11 @@ class Prec:
         assert precision in ("fp32", "bf16", "fp8"), precision
         self.exact_sites = set(exact_sites)
         self.only_sites = None if only_sites is None else set(only_sites)
-        self.site_dtype = {}          # decoder site -> storage / operand dtype (default: DECODER_DTYPE)
         self.dec_dtype = DECODER_DTYPE
+        # decoder site -> storage / operand dtype (default: DECODER_DTYPE).  The two products of the token MLP take their operands as
+        # hi + lo pairs of the decoder's 16-bit type (round 4: csrc/decoder.hip mlp_split - the 2048-wide ReLU hidden of layer 0 carried
+        # 60 % of the decoder's logit error on generic weights, profiles/r04_experiments.md section 3)
+        self.site_dtype = {"tok.mlp": "split16" if DECODER_DTYPE == torch.float16 else "split"}
         # "fp8" (BASELINE config 5): the bf16 policy everywhere, except that the four large projections of every encoder
         # block (qkv, proj, lin1, lin2) take OCP e4m3 operands - activations with one scale per token, weights with one
         # scale per output channel (linear_q)
@@ -107,18 +110,30 @@ class Prec:
             return False
         if site is None:
             return self.only_sites is None
+        # sub-sites: "tok.x" / "tok.w" (operands of the token-side products), "tok.mlp(.x / .w)" (the two MLP products) < "tok"
+        chain = [site] + [site.rsplit(".", n)[0] for n in range(1, site.count(".") + 1)]
         if self.only_sites is not None:
-            return site in self.only_sites
-        return site not in self.exact_sites
+            return any(c in self.only_sites for c in chain)
+        return not any(c in self.exact_sites for c in chain)
 
     def r(self, x: Tensor, site: Optional[str] = None) -> Tensor:
         """Round to bf16 (and back to fp32) in bf16 mode; identity in fp32 mode (or when the site is kept exact)."""
         if not self.rounds(site):
             return x
-        dt = self.site_dtype.get(site, ENCODER_DTYPE if site is None else self.dec_dtype)
+        if site is None:
+            dt = ENCODER_DTYPE
+        else:
+            dt = self.dec_dtype
+            for n in range(site.count("."), -1, -1):          # the most specific entry wins: "tok.lin.w" > "tok.lin" > "tok"
+                key = site.rsplit(".", n)[0] if n else site
+                if key in self.site_dtype:
+                    dt = self.site_dtype[key]
         if dt == "split":             # bf16 hi + lo operand pair (two / three MFMA passes): ~16 mantissa bits
             hi = x.to(torch.bfloat16).to(torch.float32)
             return hi + (x - hi).to(torch.bfloat16).to(torch.float32)
+        if dt == "split16":           # fp16 hi + lo operand pair: ~22 significand bits (the mask decoder's token side since round 4)
+            hi = x.to(torch.float16).to(torch.float32)
+            return hi + (x - hi).to(torch.float16).to(torch.float32)
         return x.to(dt).to(torch.float32)
 
     def re(self, x: Tensor, site: str) -> Tensor:
@@ -140,7 +155,9 @@ class Prec:
         if esite is not None:
             y = F.linear(self.re(x, esite + ".x"), self.re(w, esite + ".w"))
         else:
-            y = F.linear(self.r(x, site), self.r(w, site))
+            # operands of a token-side product: sub-sites "<site>.x" (activations) / "<site>.w" (weights) of "tok" / "tok.mlp"
+            tok = site is not None and site.split(".")[0] == "tok"
+            y = F.linear(self.r(x, site + ".x" if tok else site), self.r(w, site + ".w" if tok else site))
         return y if b is None else y + b
 
     def matmul(self, a: Tensor, b: Tensor) -> Tensor:
@@ -525,8 +542,8 @@ def two_way_transformer(sd, image_embedding: Tensor, image_pe: Tensor, point_emb
         queries = queries + _dec_attention(sd, lp + "cross_attn_token_to_image.", q, keys, keys, p, k_pe=key_pe,
                                            mfma_pv=True, fold=i > 0, kv_site="t2i0")
         queries = _ln(sd, lp + "norm2.", queries)
-        m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"], "tok")
-        m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"], "tok")
+        m = p.linear(queries, sd[lp + "mlp.lin1.weight"], sd[lp + "mlp.lin1.bias"], "tok.mlp")
+        m = p.linear(F.relu(m), sd[lp + "mlp.lin2.weight"], sd[lp + "mlp.lin2.bias"], "tok.mlp")
         queries = _ln(sd, lp + "norm3.", queries + m)
         q = queries + query_pe
         keys = keys + _dec_attention(sd, lp + "cross_attn_image_to_token.", keys, q, queries, p, q_pe=key_pe,
