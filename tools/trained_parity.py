@@ -115,6 +115,10 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
         abl["product_with_fp16_encoder_operands"] = dict(short(rd), embedding_mean_abs_err=float(
             (torch.as_tensor(emb16["features"]).float().cpu() - feats).abs().mean()))
         predictor.model.image_encoder.set_precision("bf16")
+        predictor.model.set_split_token_mlp(False)               # rounds 1 - 3: the token MLP on plain fp16 operands
+        rp, _, _ = product_report(emb)
+        abl["product_with_plain_token_mlp"] = short(rp)
+        predictor.model.set_split_token_mlp(True)
         extra["ablations"] = abl
     return rep, lab, extra
 
