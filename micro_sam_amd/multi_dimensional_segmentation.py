@@ -77,9 +77,14 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
         ev.synchronize()
         np.copyto(out[s0:s1], pins[slot][: s1 - s0].numpy().view(np.uint32))
 
-    # (the encoder batches are exactly the caller's batch_size: the encoder's GEMM kernels are chosen by the row count, so another
-    #  internal schedule - e.g. a short first batch to start the lanes earlier - could move last bits of the embeddings)
-    bounds = [(s0, min(s0 + batch_size, Z)) for s0 in range(0, Z, batch_size)]
+    # batch schedule: a short first encoder batch - the decode lanes start after 4 slices' worth of encoder time instead of a whole
+    # batch's -, full batches after it.  The encoder's output does not depend on how slices are batched (every kernel forms a row's
+    # products in the same order whatever the row count: tests/test_gpu_model.py::test_encoder_bits_do_not_depend_on_the_batch)
+    bounds, s0 = [], 0
+    while s0 < Z:
+        s1 = min(s0 + (min(4, batch_size) if s0 == 0 and Z > batch_size else batch_size), Z)
+        bounds.append((s0, s1))
+        s0 = s1
     for b, (s0, s1) in enumerate(bounds):
         f, osz, isz = util._compute_embeddings_batched_raw(predictor, [np.asarray(data[z]) for z in range(s0, s1)])
         feats[s0:s1, 0] = f

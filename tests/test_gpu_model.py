@@ -550,6 +550,19 @@ def test_cache_amg_state_and_segment_slices(ctx, tmp_path):
     assert not mds._can_pipeline(vol, p, AutomaticMaskGenerator(p, **kw), None, None, dict(output_mode="binary_mask"))
 
 
+def test_encoder_bits_do_not_depend_on_the_batch(ctx):
+    """The embedding of a tile is the same bits whatever batch it is encoded in (the 256- and 128-tile GEMM kernels form a row's products
+    in the same order; attention and LayerNorm are per tile): the pipelined slice loop relies on it for its short first encoder batch."""
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_tile
+    enc = ctx["predictor"].model.image_encoder
+    tiles = torch.stack([torch.as_tensor(util._to_image(synthetic_tile(2000 + i))) for i in range(8)]).cuda()
+    ref = enc.forward_u8(tiles).clone()
+    for b in (1, 3, 4):
+        out = torch.cat([enc.forward_u8(tiles[s:s + b]) for s in range(0, 8, b)])
+        assert torch.equal(out, ref), b
+
+
 def test_vit_l_encoder_and_decode_vs_oracle():
     """vit_l (BASELINE config 3 model: D = 1024, 16 heads, 24 blocks, global blocks 5/11/17/23) through the same kernels:
     embedding vs the bf16-mode oracle, then one decode on it."""
