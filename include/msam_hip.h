@@ -220,6 +220,12 @@ int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float*
 int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
                               const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
                               const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res, void* stream);
+/* the same with the output type stated: low_res_dtype MSAM_F32 (fp32 [P,nmask,256,256]) or MSAM_F16 (fp16: what
+ * msam_postprocess_masks16 reads - the AMG path keeps its low-res logits in 16 bits between the two kernels) */
+int msam_upscale_fused_out(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
+                           const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
+                           const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, void* low_res,
+                           int32_t low_res_dtype, void* stream);
 
 /* Live measurement of the GEMM kernel (the dominant kernel of the hot path) for bench.py's roofline leg:
  * after msam_profile_enable(1) every msam_gemm_bf16 launch is bracketed by HIP events on its stream;
@@ -474,6 +480,8 @@ typedef struct {
                                                              is zero-padded to 128 output rows */
     const void* iou_w[3]; const float* iou_b[3];           /* IoU head, last layer zero-padded to 128 rows */
     int32_t use_glds;
+    int32_t low_res_dtype;           /* type of the `low_res` buffer the msam_decoder_forward_* calls write: 0 / MSAM_F32 = fp32 (the
+                                      * predict_torch contract), MSAM_F16 = fp16 (the AMG path: msam_postprocess_masks16 reads it back) */
 } msam_decoder_t;
 
 /* Per-image constants of the decoder (dense positional encoding etc.): computed once per model. */
@@ -538,6 +546,11 @@ int msam_decoder_forward_embeddings(const msam_decoder_t* dec, const void* const
 int msam_postprocess_masks(const float* low_res, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h, int32_t out_w,
                            float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits, float* logits,
                            void* stream);
+/* the same from low-res logits of type low_res_dtype: MSAM_F32 or MSAM_F16 (every value widened to fp32 on load, the arithmetic
+ * - and so every integer output - is that of msam_postprocess_masks on the widened values) */
+int msam_postprocess_masks16(const void* low_res, int32_t low_res_dtype, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h,
+                             int32_t out_w, float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits, float* logits,
+                             void* stream);
 /* uncrop_masks (reference micro_sam/instance_segmentation.py:250, segment_anything.utils.amg.uncrop_masks): place the
  * bit masks of a crop / tile, [N, ceil(crop_h/32), crop_w], at (x0, y0) of full-image bit masks [N, ceil(out_h/32), out_w]
  * (zero outside the crop).  N <= 65535. */

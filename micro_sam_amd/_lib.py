@@ -90,7 +90,7 @@ class DecoderParams(C.Structure):
         ("layer", TwoWayLayer * 2), ("final_attn", AttnW), ("nf_w", _vp), ("nf_b", _vp),
         ("up1_w", _vp), ("up1_b", _vp), ("up_ln_w", _vp), ("up_ln_b", _vp), ("up2_w", _vp), ("up2_b", _vp),
         ("hyp_w", (_vp * 3) * 4), ("hyp_b", (_vp * 3) * 4), ("iou_w", _vp * 3), ("iou_b", _vp * 3),
-        ("use_glds", _i32),
+        ("use_glds", _i32), ("low_res_dtype", _i32),
     ]
 
 
@@ -156,6 +156,7 @@ _PROTOS = {
     "msam_chain_tables_bytes": (_i64, []),
     "msam_chain_prepare_tables": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "msam_upscale_fused_layout": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_upscale_fused_out": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp]),
     "msam_upscale_set_prio": (_i32, [_i32]),
     "msam_layernorm_fp8": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _vp, _vp]),
     "msam_quant_rows_fp8": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
@@ -186,6 +187,7 @@ _PROTOS = {
     "msam_decoder_forward": (_i32, [C.POINTER(DecoderParams), _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp,
                                     _i64, _vp]),
     "msam_postprocess_masks": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "msam_postprocess_masks16": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "msam_rle_run_counts": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_rle_encode": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "msam_mask_nms": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),

@@ -19,6 +19,10 @@ int msam_check_launch(const char* what);
 namespace {
 
 struct Axis { int i0, i1; float w0, w1; };
+// fp16 low-res logits as stored by up_fused_kernel (msam_upscale_fused_out, MSAM_F16): widened to fp32 on load
+struct lowh_t { unsigned short bits; };
+MSAM_DEVINL float lowf(float v) { return v; }
+MSAM_DEVINL float lowf(lowh_t v) { return h2f(v.bits); }
 
 MSAM_DEVINL Axis axis_weights(int dst, float scale, int in_size) {
     // torch: scale * (dst + 0.5) - 0.5 with separately rounded mul / sub
@@ -35,11 +39,12 @@ MSAM_DEVINL Axis axis_weights(int dst, float scale, int in_size) {
 MSAM_DEVINL float lerp_torch(float w0, float p0, float w1, float p1) { return __fmaf_rn(w0, p0, __fmul_rn(w1, p1)); }
 
 // value of the 1024x1024 intermediate (x4 up-sampling of the 256x256 low-res mask) at (Y, X)
-MSAM_DEVINL float stage1(const float* __restrict__ low, int Y, int X) {
+template <typename TL>
+MSAM_DEVINL float stage1(const TL* __restrict__ low, int Y, int X) {
     const Axis ay = axis_weights(Y, 0.25f, 256), ax = axis_weights(X, 0.25f, 256);
-    const float* r0 = low + ay.i0 * 256; const float* r1 = low + ay.i1 * 256;
-    const float t0 = lerp_torch(ax.w0, r0[ax.i0], ax.w1, r0[ax.i1]);
-    const float t1 = lerp_torch(ax.w0, r1[ax.i0], ax.w1, r1[ax.i1]);
+    const TL* r0 = low + ay.i0 * 256; const TL* r1 = low + ay.i1 * 256;
+    const float t0 = lerp_torch(ax.w0, lowf(r0[ax.i0]), ax.w1, lowf(r0[ax.i1]));
+    const float t1 = lerp_torch(ax.w0, lowf(r1[ax.i0]), ax.w1, lowf(r1[ax.i1]));
     return lerp_torch(ay.w0, t0, ay.w1, t1);
 }
 
@@ -62,8 +67,9 @@ __global__ void finalize_boxes_kernel(int* __restrict__ boxes, int N) {
 // only ceil(W/256) x 7 atomics instead of one set per 32x256 patch - the atomics were the bottleneck)
 // LOGITS (store the up-sampled logits as well) is a compile-time switch: as a run-time test it put a scalar branch and
 // the address arithmetic of the store between every two of the 32 unrolled pixels of the hot loop
-template <bool TWO_STAGE, bool LOGITS>
-__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ low_res, int in_h, int in_w, int out_h,
+// TL: type of the low-res logits (float, or lowh_t = the AMG path's 16-bit hand-over from up_fused_kernel; widened on load)
+template <bool TWO_STAGE, bool LOGITS, typename TL>
+__global__ __launch_bounds__(256) void postprocess_kernel(const TL* __restrict__ low_res, int in_h, int in_w, int out_h,
                                                           int out_w, float thr, float off, int* __restrict__ counts,
                                                           int* __restrict__ boxes, uint32_t* __restrict__ bits,
                                                           float* __restrict__ logits) {
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
     __shared__ float tile[2][10 * 66];
     const int x = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
     const int wpc = (out_h + 31) >> 5;
-    const float* low = low_res + (long)n * 65536;
+    const TL* low = low_res + (long)n * 65536;
     const float hi_t = thr + off, lo_t = thr - off;
     int c_hi = 0, c_lo = 0, c_m = 0, ymin = 0x7fffffff, ymax = -1;
     bool any = false;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
         float nx[3] = {0.f, 0.f, 0.f};
 #define PP_LOAD(yw_)                                                                               \
         _Pragma("unroll") for (int k = 0; k < 3; ++k)                                              \
-            if (threadIdx.x + k * 256 < 660) nx[k] = low[min(max((yw_) * 8 - 1 + sr[k], 0), 255) * 256 + sc[k]];
+            if (threadIdx.x + k * 256 < 660) nx[k] = lowf(low[min(max((yw_) * 8 - 1 + sr[k], 0), 255) * 256 + sc[k]]);
 #define PP_STORE(buf_)                                                                             \
         _Pragma("unroll") for (int k = 0; k < 3; ++k)                                              \
             if (threadIdx.x + k * 256 < 660) tile[buf_][threadIdx.x + k * 256] = nx[k];
@@ -193,9 +199,9 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const float* __restric
         auto low_row = [&](int r, float& va, float& vb) {
             if (r == lr[0]) { va = la[0]; vb = lb[0]; return; }
             if (r == lr[1]) { va = la[1]; vb = lb[1]; return; }
-            const float* row = low + r * 256;
-            va = lerp_torch(axa.w0, row[axa.i0], axa.w1, row[axa.i1]);
-            vb = lerp_torch(axb.w0, row[axb.i0], axb.w1, row[axb.i1]);
+            const TL* row = low + r * 256;
+            va = lerp_torch(axa.w0, lowf(row[axa.i0]), axa.w1, lowf(row[axa.i1]));
+            vb = lerp_torch(axb.w0, lowf(row[axb.i0]), axb.w1, lowf(row[axb.i1]));
             lr[lnext] = r; la[lnext] = va; lb[lnext] = vb; lnext ^= 1;
         };
         int ir[2] = {-1, -1};                    // cached intermediate rows Y
@@ -363,10 +369,11 @@ __global__ __launch_bounds__(256) void rle_encode_kernel(const uint32_t* __restr
 
 }  // namespace
 
-extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h,
-                                      int32_t out_w, float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits,
-                                      float* logits, void* stream) {
+extern "C" int msam_postprocess_masks16(const void* low_res, int32_t low_res_dtype, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h,
+                                        int32_t out_w, float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits,
+                                        float* logits, void* stream) {
     if (!low_res || !counts || !boxes || !bits || N <= 0) { msam_set_error("msam_postprocess_masks: null argument"); return 1; }
+    if (low_res_dtype != MSAM_F32 && low_res_dtype != MSAM_F16) { msam_set_error("msam_postprocess_masks16: low_res_dtype is MSAM_F32 or MSAM_F16"); return 1; }
     if (in_h <= 0 || in_w <= 0 || in_h > 1024 || in_w > 1024 || out_h <= 0 || out_w <= 0) {
         msam_set_error("msam_postprocess_masks: bad sizes");
         return 1;
@@ -375,8 +382,15 @@ extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(init_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, s, counts, boxes, N);
     dim3 grid((out_w + 255) / 256, N);
-#define PP_LAUNCH(TS_, LG_) hipLaunchKernelGGL((postprocess_kernel<TS_, LG_>), grid, dim3(256), 0, s, low_res, in_h, in_w, out_h, \
-                                              out_w, thr, off, counts, boxes, bits, logits)
+#define PP_LAUNCH(TS_, LG_)                                                                                                              \
+    do {                                                                                                                                 \
+        if (low_res_dtype == MSAM_F16)                                                                                                   \
+            hipLaunchKernelGGL((postprocess_kernel<TS_, LG_, lowh_t>), grid, dim3(256), 0, s, (const lowh_t*)low_res, in_h, in_w,        \
+                               out_h, out_w, thr, off, counts, boxes, bits, logits);                                                     \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((postprocess_kernel<TS_, LG_, float>), grid, dim3(256), 0, s, (const float*)low_res, in_h, in_w, out_h,   \
+                               out_w, thr, off, counts, boxes, bits, logits);                                                            \
+    } while (0)
     const bool direct = in_h == out_h && in_w == out_w;
     if (direct && !logits) PP_LAUNCH(false, false);
     else if (direct) PP_LAUNCH(false, true);
@@ -385,6 +399,12 @@ extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t i
 #undef PP_LAUNCH
     hipLaunchKernelGGL(finalize_boxes_kernel, dim3((N + 255) / 256), dim3(256), 0, s, boxes, N);
     return msam_check_launch("msam_postprocess_masks");
+}
+
+extern "C" int msam_postprocess_masks(const float* low_res, int32_t N, int32_t in_h, int32_t in_w, int32_t out_h,
+                                      int32_t out_w, float thr, float off, int32_t* counts, int32_t* boxes, uint32_t* bits,
+                                      float* logits, void* stream) {
+    return msam_postprocess_masks16(low_res, MSAM_F32, N, in_h, in_w, out_h, out_w, thr, off, counts, boxes, bits, logits, stream);
 }
 
 // uncrop_masks of the reference's AMGBase._to_mask_data (instance_segmentation.py:250): bit masks of a crop

@@ -37,7 +37,8 @@ struct UpArgs {
     const u16* w2; const float* b2;      // bf16 [128 = sub2*32 + c2][64], fp32 [32]
     const float* hyper; int hyper_ld, mask0, nmask;    // fp32 [P, 4, hyper_ld]
     int nitems, KS;
-    float* out;                          // fp32 [P, nmask, 256, 256]
+    void* out;                           // fp32 or (out16) fp16 [P, nmask, 256, 256]
+    int out16;
     int blocked;                         // keys in the blocked layout of decfold_tok.hip ([16-token tile][k-step][lane][8]) instead of row-major
 };
 
@@ -334,8 +335,12 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         if (tid < 64 * a.nmask) {
             const int mk = tid >> 6, rem = tid & 63, yl = rem >> 4, x4 = rem & 15;
             const int ty = key0 >> 6, tx0 = key0 & 63;
-            *(float4*)(a.out + (((long)p * a.nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + x4 * 4) =
-                *(const float4*)&pt[(mk * 4 + yl) * 64 + x4 * 4];
+            const float4 o4 = *(const float4*)&pt[(mk * 4 + yl) * 64 + x4 * 4];
+            const long oi = (((long)p * a.nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + x4 * 4;
+            // fp16 low-res logits (the AMG path: msam_postprocess_masks16 reads them back - half the round trip of 0.8 GB per tile;
+            // 2^-11 relative, i.e. <= 5e-4 where the thresholds 0, +-1 are decided, against a logit error of ~3e-2)
+            if (a.out16) *(uint2*)((unsigned short*)a.out + oi) = make_uint2(pack2h(o4.x, o4.y), pack2h(o4.z, o4.w));
+            else *(float4*)((float*)a.out + oi) = o4;
         }
     };
     while (true) {
@@ -350,20 +355,31 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 
 }  // namespace
 
+extern "C" int msam_upscale_fused_out(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
+                                      const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
+                                      const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, void* low_res,
+                                      int32_t low_res_dtype, void* stream);
 extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
                                          const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
                                          const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res,
-                                         void* stream);
+                                         void* stream) {
+    return msam_upscale_fused_out(keys, keys_blocked, P, w1, b1, ln_w, ln_b, ln_eps, w2, b2, hyper, hyper_ld, mask0, nmask, low_res,
+                                  MSAM_F32, stream);
+}
 extern "C" int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float* b1, const float* ln_w,
                                   const float* ln_b, float ln_eps, const void* w2, const float* b2, const float* hyper,
                                   int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res, void* stream) {
     return msam_upscale_fused_layout(keys, 0, P, w1, b1, ln_w, ln_b, ln_eps, w2, b2, hyper, hyper_ld, mask0, nmask, low_res, stream);
 }
 
-extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
-                                         const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
-                                         const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res,
-                                         void* stream) {
+extern "C" int msam_upscale_fused_out(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
+                                      const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
+                                      const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, void* low_res,
+                                      int32_t low_res_dtype, void* stream) {
+    if (low_res_dtype != MSAM_F32 && low_res_dtype != MSAM_F16) {
+        msam_set_error("msam_upscale_fused_out: low_res_dtype is MSAM_F32 or MSAM_F16");
+        return 1;
+    }
     if (!keys || !w1 || !b1 || !ln_w || !ln_b || !w2 || !b2 || !hyper || !low_res || P <= 0) {
         msam_set_error("msam_upscale_fused: null argument");
         return 1;
@@ -380,11 +396,11 @@ extern "C" int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked,
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int ks = 1;
     while (P * ks < 2 * cus && ks < 16) ks *= 2;
-    a.KS = ks; a.nitems = P * ks; a.out = low_res; a.blocked = keys_blocked ? 1 : 0;
+    a.KS = ks; a.nitems = P * ks; a.out = low_res; a.out16 = low_res_dtype == MSAM_F16; a.blocked = keys_blocked ? 1 : 0;
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double rows = (double)P * T;
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
-    const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * 4;
+    const double bytes = rows * C * 2 + (double)P * nmask * 256 * 256 * (low_res_dtype == MSAM_F16 ? 2 : 4);
     msam_profile_mark2(stream, 1, flops, bytes, 4);
 #if MSAM_DEC_F16
     if (g_tune_up_gelu16 == 2) hipLaunchKernelGGL((up_fused_kernel<1, 2>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);

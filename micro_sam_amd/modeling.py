@@ -434,6 +434,9 @@ class Sam(nn.Module):
         # the two products of the token MLP on hi + lo operand pairs (round 4: the ReLU hidden is the decoder's most rounding-sensitive
         # tensor; 0.2 % of the decoder's flops); set_split_token_mlp(False) = the plain 16-bit operands of rounds 1 - 3
         self.split_token_mlp = True
+        # type of the low-res logits between the decoder's up-scaling kernel and the fused post-processing on the AMG path
+        # (predict_masks_device); torch.float32 = rounds 1 - 3
+        self.amg_low_res_dtype = torch.float16
         self._watch = _ParamWatch(self.prompt_encoder, self.mask_decoder)
         self._img_state = None      # (key, buffer)
         self._dec_ws = None
@@ -667,6 +670,7 @@ class Sam(nn.Module):
         low = torch.empty((P, nc, 256, 256), dtype=torch.float32, device=dev)
         iou = torch.empty((P, nc), dtype=torch.float32, device=dev)
         ws = self._workspace(P)
+        p.low_res_dtype = _lib.F32
         _lib.check(_lib.load().msam_decoder_forward_embeddings(
             C.byref(p), consts.data_ptr(), state.data_ptr(), sp.data_ptr() if Ns > 0 else None, Ns, dptr, eptr, P,
             1 if multimask_output else 0, low.data_ptr(), iou.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
@@ -676,10 +680,14 @@ class Sam(nn.Module):
     @torch.no_grad()
     def decode(self, features: torch.Tensor, point_coords: Optional[torch.Tensor], point_labels: Optional[torch.Tensor],
                boxes: Optional[torch.Tensor] = None, mask_input: Optional[torch.Tensor] = None,
-               multimask_output: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+               multimask_output: bool = True, low_res_dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
         """prompt_encoder + mask_decoder of ``SamPredictor.predict_torch`` for one image embedding [1,256,64,64].
 
-        point_coords [P,Np,2] / boxes [P,4] are in the 1024 input frame.  Returns (low_res [P,C,256,256], iou [P,C])."""
+        point_coords [P,Np,2] / boxes [P,4] are in the 1024 input frame.  Returns (low_res [P,C,256,256], iou [P,C]).
+        ``low_res_dtype=torch.float16``: the low-res logits leave the up-scaling kernel as fp16 (the AMG path: 3072 masks per tile
+        are handed to the fused post-processing and never returned - half the HBM round trip; ``predict_torch`` keeps fp32)."""
+        if low_res_dtype not in (torch.float32, torch.float16):
+            raise ValueError("low_res_dtype is torch.float32 or torch.float16")
         if features.numel() != PROMPT_DIM * GRID * GRID:
             raise ValueError(f"expected one image embedding [1,256,64,64], got {tuple(features.shape)}")
         p, _, consts = self._prepare_decoder()
@@ -699,8 +707,9 @@ class Sam(nn.Module):
             P, Np = (boxes.shape[0] if boxes is not None else mask_input.reshape(-1, 4 * GRID, 4 * GRID).shape[0]), 0
         bx = None if boxes is None else boxes.to(device=dev, dtype=torch.float32).reshape(-1, 4).contiguous()
         nc = 3 if multimask_output else 1
-        low = torch.empty((P, nc, 256, 256), dtype=torch.float32, device=dev)
+        low = torch.empty((P, nc, 256, 256), dtype=low_res_dtype, device=dev)
         iou = torch.empty((P, nc), dtype=torch.float32, device=dev)
+        p.low_res_dtype = _lib.F16 if low_res_dtype == torch.float16 else _lib.F32      # (read by this call only: set per call)
         need = lib.msam_decoder_workspace_bytes(P)
         if self._dec_ws is None or self._dec_ws.numel() < need or self._dec_ws.device != dev:
             self._dec_ws = None

@@ -294,7 +294,9 @@ def postprocess_masks(low_res: torch.Tensor, input_size: Tuple[int, int], origin
     Returns dict(counts int32 [N,3] = (#>thr+off, #>thr-off, #>thr), boxes int32 [N,4] xyxy, bits uint32
     [N, ceil(H/32), W] as int32 storage, logits fp32 [N,H,W] when requested)."""
     _lib.require_gpu()
-    low_res = low_res.to(torch.float32).contiguous()
+    # fp16 low-res logits (the AMG path's hand-over from the decoder) are read as they are: widened on load
+    low_res = low_res.contiguous() if low_res.dtype == torch.float16 else low_res.to(torch.float32).contiguous()
+    low_dt = _lib.F16 if low_res.dtype == torch.float16 else _lib.F32
     N = low_res.shape[0]
     H, W = int(original_size[0]), int(original_size[1])
     dev = low_res.device
@@ -306,8 +308,8 @@ def postprocess_masks(low_res: torch.Tensor, input_size: Tuple[int, int], origin
     step = 65535
     for s in range(0, N, step):
         n = min(step, N - s)
-        _lib.check(lib.msam_postprocess_masks(
-            low_res[s:].data_ptr(), n, int(input_size[0]), int(input_size[1]), H, W, float(mask_threshold),
+        _lib.check(lib.msam_postprocess_masks16(
+            low_res[s:].data_ptr(), low_dt, n, int(input_size[0]), int(input_size[1]), H, W, float(mask_threshold),
             float(stability_offset), counts[s:].data_ptr(), boxes[s:].data_ptr(), bits[s:].data_ptr(),
             None if logits is None else logits[s:].data_ptr(), _lib.stream_ptr()), "msam_postprocess_masks")
     out = {"counts": counts, "boxes": boxes, "bits": bits}

@@ -110,7 +110,9 @@ class SamPredictor:
         Returns (iou [B,C], dict(counts, boxes, bits)) - see ops.postprocess_masks."""
         if not self.is_image_set:
             raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
-        low, iou = self.model.decode(self.features, point_coords, point_labels, boxes, None, multimask_output)
+        # the low-res logits go from the up-scaling kernel to the post-processing kernel as fp16 (never returned to the caller)
+        low, iou = self.model.decode(self.features, point_coords, point_labels, boxes, None, multimask_output,
+                                     low_res_dtype=self.model.amg_low_res_dtype)
         from .ops import postprocess_masks
         b, c = low.shape[:2]
         res = postprocess_masks(low.reshape(b * c, 256, 256), self.input_size, self.original_size,

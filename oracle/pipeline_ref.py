@@ -81,7 +81,7 @@ def amg_initialize(sd, image: np.ndarray, features: torch.Tensor, input_size, or
         in_labels = torch.ones(in_points.shape[0], dtype=torch.int)
         masks, iou_preds, _ = S.predict_torch(
             sd, features, input_size, original_size, in_points[:, None, :], in_labels[:, None],
-            multimask_output=True, return_logits=True, precision=precision)
+            multimask_output=True, return_logits=True, precision=precision, low_res_fp16=True)
         t1 = time.perf_counter()
         batch = to_mask_data(masks, iou_preds, crop_box, original_size, points=points,
                              stability_score_offset=stability_score_offset)

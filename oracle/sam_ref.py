@@ -607,11 +607,14 @@ def mask_decoder(sd, image_embeddings: Tensor, image_pe: Tensor, sparse: Tensor,
 def predict_torch(sd, features: Tensor, input_size, original_size, point_coords: Optional[Tensor],
                   point_labels: Optional[Tensor], boxes: Optional[Tensor] = None, mask_input: Optional[Tensor] = None,
                   multimask_output: bool = True, return_logits: bool = False, precision: str = "fp32",
-                  debug: Optional[dict] = None):
-    """SamPredictor.predict_torch -> (masks, iou, low_res)."""
+                  debug: Optional[dict] = None, low_res_fp16: bool = False):
+    """SamPredictor.predict_torch -> (masks, iou, low_res).  ``low_res_fp16`` (HIP-like modes only): the AMG path of
+    the product hands its low-res logits from the up-scaling kernel to the post-processing kernel as fp16 (round 4)."""
     points = (point_coords, point_labels) if point_coords is not None else None
     sparse, dense = prompt_encoder(sd, points, boxes, mask_input)
     low_res, iou = mask_decoder(sd, features, get_dense_pe(sd), sparse, dense, multimask_output, precision, debug)
+    if low_res_fp16 and (precision if isinstance(precision, Prec) else Prec(precision)).bf16:
+        low_res = low_res.to(torch.float16).to(torch.float32)
     masks = postprocess_masks(low_res, input_size, original_size)
     if not return_logits:
         masks = masks > 0.0

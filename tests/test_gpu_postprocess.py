@@ -47,6 +47,21 @@ def test_postprocess_and_rle_bit_exact(low_res, in_hw, out_hw):
     assert torch.equal(torch.nan_to_num(stab, nan=-1.0), torch.nan_to_num(ref_stab, nan=-1.0))
 
 
+def test_postprocess_of_fp16_low_res_logits_is_the_fp32_arithmetic_on_the_widened_values():
+    """msam_postprocess_masks16 with MSAM_F16 input (round 4: the AMG path keeps its low-res logits in 16 bits between up_fused_kernel
+    and the post-processing): every output equals the fp32 kernel's on the same values widened to fp32, both resampling paths."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import ops
+    g = torch.Generator().manual_seed(23)
+    low16 = (torch.randn(9, 256, 256, generator=g) * 6).to(torch.float16).cuda()
+    for in_hw, out_hw in (((1024, 1024), (1024, 1024)), ((683, 1024), (517, 775))):
+        a = ops.postprocess_masks(low16, in_hw, out_hw, 0.0, 1.0, want_logits=True)
+        b = ops.postprocess_masks(low16.float(), in_hw, out_hw, 0.0, 1.0, want_logits=True)
+        for k in ("counts", "boxes", "bits", "logits"):
+            assert torch.equal(a[k], b[k]), (k, in_hw, out_hw)
+
+
 def test_postprocess_decided_words_are_exact():
     """Object-like logits (|v| of 10..40 away from the boundary): most 64-column x 32-row words are decided from the range of their
     ten low-res rows without interpolation (postprocess_kernel, "decided words"); bits, counts and boxes must equal the

@@ -66,6 +66,11 @@ static void atomicMin(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mute
 static void atomicMax(int* p, int v) { std::lock_guard<std::mutex> g(atomic_mutex); *p = std::max(*p, v); }
 #define __syncthreads() block_bar->arrive_and_wait()
 #define MSAM_DEVINL static inline
+static float h2f(uint32_t b) {                                // IEEE half -> float (csrc/common.h h2f), bit by bit
+    const uint32_t sg = (b >> 15) & 1u, e = (b >> 10) & 31u, m = b & 1023u;
+    float v = e == 0 ? std::ldexp((float)m, -24) : e == 31 ? (m ? NAN : INFINITY) : std::ldexp((float)(m | 1024u), (int)e - 25);
+    return sg ? -v : v;
+}
 #define __global__
 #define __launch_bounds__(n)
 #define __restrict__
@@ -80,7 +85,7 @@ template <bool TS, bool LG> static void run(const float* low, int in_h, int in_w
         for (int tx = 0; tx < 256; ++tx)
             ts.emplace_back([=] {
                 threadIdx = {tx, 0, 0}; blockIdx = {bx, n, 0};
-                postprocess_kernel<TS, LG>(low, in_h, in_w, out_h, out_w, thr, off, counts, boxes, bits, logits);
+                postprocess_kernel<TS, LG, float>(low, in_h, in_w, out_h, out_w, thr, off, counts, boxes, bits, logits);
             });
         for (auto& t : ts) t.join();
     }

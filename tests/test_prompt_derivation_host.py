@@ -172,9 +172,9 @@ def test_generator_factory_modes():
                       IS.AutomaticPromptGenerator)
     assert isinstance(IS.get_instance_segmentation_generator(p, True, decoder=dec, segmentation_mode="APG"),
                       IS.TiledAutomaticPromptGenerator)
-    with pytest.raises(NotImplementedError):                   # the reference's default with a decoder is the watershed
-        IS.get_instance_segmentation_generator(p, False, decoder=dec)
-    with pytest.raises(ValueError):
+    # the reference's default with a decoder is the watershed ("ais", instance_segmentation.py:44)
+    assert type(IS.get_instance_segmentation_generator(p, False, decoder=dec)) is IS.InstanceSegmentationWithDecoder
+    with pytest.raises(AssertionError):                        # reference: `assert decoder is not None`
         IS.get_instance_segmentation_generator(p, False, segmentation_mode="apg")
     with pytest.raises(ValueError):
         IS.get_instance_segmentation_generator(p, False, decoder=dec, segmentation_mode="xyz")

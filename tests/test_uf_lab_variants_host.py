@@ -109,3 +109,23 @@ def test_the_host_build_notices_a_missing_barrier(tmp_path):
         assert (out != base).mean() > 0.05
     finally:
         os.environ.pop("MSAM_EMU_CUS", None)
+
+
+def test_fp16_low_res_output_is_the_rounded_fp32_output(tmp_path):
+    """msam_upscale_fused_out(low_res_dtype = MSAM_F16) (round 4: the AMG path's hand-over to msam_postprocess_masks16) writes exactly the
+    fp16 rounding of what the fp32 form writes."""
+    os.environ["MSAM_EMU_CUS"] = "2"
+    try:
+        arrs, P = _inputs(1, 21), 1
+        lib = _host_lib(tmp_path, "base")
+        vp, i32 = ctypes.c_void_p, ctypes.c_int32
+        lib.msam_upscale_fused_out.restype = i32
+        lib.msam_upscale_fused_out.argtypes = [vp, i32, i32, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, i32, i32, i32, vp, i32, vp]
+        ref = _run(lib, arrs, P, 3)
+        out16 = np.zeros((P, 3, 256, 256), np.float16)
+        p = [a.ctypes.data_as(vp) for a in arrs]
+        assert lib.msam_upscale_fused_out(p[0], 1, P, p[1], p[2], p[3], p[4], 1e-6, p[5], p[6], p[7], 128, 1, 3, out16.ctypes.data_as(vp), 4, None) == 0
+        assert np.array_equal(out16.view(np.uint16), ref.astype(np.float16).view(np.uint16))
+        assert lib.msam_upscale_fused_out(p[0], 1, P, p[1], p[2], p[3], p[4], 1e-6, p[5], p[6], p[7], 128, 1, 3, out16.ctypes.data_as(vp), 2, None) == 1
+    finally:
+        os.environ.pop("MSAM_EMU_CUS", None)
