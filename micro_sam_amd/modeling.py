@@ -435,8 +435,12 @@ class Sam(nn.Module):
         # tensor; 0.2 % of the decoder's flops); set_split_token_mlp(False) = the plain 16-bit operands of rounds 1 - 3
         self.split_token_mlp = True
         # type of the low-res logits between the decoder's up-scaling kernel and the fused post-processing on the AMG path
-        # (predict_masks_device); torch.float32 = rounds 1 - 3
-        self.amg_low_res_dtype = torch.float16
+        # (predict_masks_device): torch.float32 (default), or torch.float16 = half the 1.6 GB round trip per tile for ~2 % more tiles/s -
+        # NOT the default: the bilinear up-sampling interpolates between neighbours of the full logit magnitude, so fp16's 2^-11
+        # relative rounding moves zero crossings as much as the whole decoder's arithmetic does (measured: 2 more of 152 instances
+        # below IoU 0.999 on the bench tile, profiles/r04_experiments.md section 4).  MSAM_AMG_LOW_RES=fp16 selects it process-wide.
+        import os
+        self.amg_low_res_dtype = torch.float16 if os.environ.get("MSAM_AMG_LOW_RES", "fp32") == "fp16" else torch.float32
         self._watch = _ParamWatch(self.prompt_encoder, self.mask_decoder)
         self._img_state = None      # (key, buffer)
         self._dec_ws = None

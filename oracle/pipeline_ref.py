@@ -16,6 +16,7 @@ Restates the reference's own orchestration on top of the model / AMG oracles:
 """
 from __future__ import annotations
 
+import os
 import time
 from copy import deepcopy
 from typing import Any, Dict, List, Optional, Tuple
@@ -81,7 +82,7 @@ def amg_initialize(sd, image: np.ndarray, features: torch.Tensor, input_size, or
         in_labels = torch.ones(in_points.shape[0], dtype=torch.int)
         masks, iou_preds, _ = S.predict_torch(
             sd, features, input_size, original_size, in_points[:, None, :], in_labels[:, None],
-            multimask_output=True, return_logits=True, precision=precision, low_res_fp16=True)
+            multimask_output=True, return_logits=True, precision=precision, low_res_fp16=os.environ.get("MSAM_AMG_LOW_RES", "fp32") == "fp16")
         t1 = time.perf_counter()
         batch = to_mask_data(masks, iou_preds, crop_box, original_size, points=points,
                              stability_score_offset=stability_score_offset)
