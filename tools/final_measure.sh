@@ -16,17 +16,16 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $O/final_sq2 -- python $R/tools/pmc_tile.py > $O/final_sq2.log 2>&1
 python $R/tools/pmc_summary.py $O/final_sq1 $O/final_sq2 > $O/final_sq_table.md 2>&1
 if [ "$1" != "quick" ]; then
-python $R/bench.py --encoder-dtype fp8 --no-cpu-baseline --no-side > $O/final_fp8.log 2> $O/final_fp8.err
+# (round 4: configs 3 / 4 / 5 are side fields of the default bench line itself - fp8_side, config3_side, train_side)
 python $R/bench.py --encoder-dtype fp16 --no-cpu-baseline --no-side > $O/final_fp16.log 2> $O/final_fp16.err
 python $R/bench.py --lanes 1 --no-cpu-baseline --no-side > $O/final_lanes1.log 2> $O/final_lanes1.err
-python $R/bench.py --workload config3 --steps 1 --warmup 1 --slices 4 > $O/final_config3.log 2> $O/final_config3.err
 fi
 python $R/tools/hbm_probe.py > $O/final_hbm_probe.log 2>&1
 cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/final_smoke.log 2>&1
 tail -1 $O/final_smoke.log
 python - <<PY
 import json
-for f in ("final_bench", "final_fp8", "final_fp16", "final_lanes1", "final_config3"):
+for f in ("final_bench", "final_fp16", "final_lanes1"):
     try:
         d = json.loads(open("$O/" + f + ".log").read().strip().splitlines()[-1])
         print(f, d["value"], d["ms_per_step"], d.get("cpu_baseline"), d.get("api_inclusive"))
