@@ -587,11 +587,12 @@ class Sam(nn.Module):
         pos = consts[: GRID * GRID * PROMPT_DIM * 4].view(torch.float32).reshape(GRID * GRID, PROMPT_DIM)
         return pos.t().reshape(1, PROMPT_DIM, GRID, GRID).contiguous()
 
-    def _image_state(self, features: torch.Tensor) -> torch.Tensor:
+    def _image_state(self, features: torch.Tensor, prepared=None) -> torch.Tensor:
         # the cache entry keeps the caller's tensor alive and is matched by identity + version: a freed embedding whose
         # address is handed to the next one can no longer alias it (SamPredictor.reset_image / set_image also drop it)
         key = (features.data_ptr(), features._version, tuple(features.shape))
-        p, _, consts = self._prepare_decoder()      # first: drops the image state too when a decoder parameter changed
+        # first: drops the image state too when a decoder parameter changed (`prepared`: the caller has just done it)
+        p, _, consts = prepared if prepared is not None else self._prepare_decoder()
         if self._img_state is not None and self._img_state[0] == key and self._img_state[3] is features:
             return self._img_state[1]
         lib = _lib.load()
@@ -694,8 +695,9 @@ class Sam(nn.Module):
             raise ValueError("low_res_dtype is torch.float32 or torch.float16")
         if features.numel() != PROMPT_DIM * GRID * GRID:
             raise ValueError(f"expected one image embedding [1,256,64,64], got {tuple(features.shape)}")
-        p, _, consts = self._prepare_decoder()
-        state = self._image_state(features)
+        prepared = self._prepare_decoder()
+        p, _, consts = prepared
+        state = self._image_state(features, prepared)
         lib = _lib.load()
         dev = self.device
         if point_coords is not None:

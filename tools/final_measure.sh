@@ -10,8 +10,8 @@ python $R/tools/csrc_sha.py > $O/final_csrc_sha.txt
 python $R/bench.py > $O/final_bench.log 2> $O/final_bench.err
 # rocprof passes: hot path only (--no-side), one decode lane (kernels of different tiles do not overlap)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_prof -- python $R/bench.py --no-cpu-baseline --no-side --lanes 1 > $O/final_prof.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_fetch -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side --lanes 1 > $O/final_fetch.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_write -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-side --lanes 1 > $O/final_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/final_fetch -- python $R/bench.py --steps 1 --warmup 1 --tiles-per-step 16 --distinct-tiles 16 --no-cpu-baseline --no-side --lanes 1 > $O/final_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/final_write -- python $R/bench.py --steps 1 --warmup 1 --tiles-per-step 16 --distinct-tiles 16 --no-cpu-baseline --no-side --lanes 1 > $O/final_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --output-format csv -d $O/final_sq1 -- python $R/tools/pmc_tile.py > $O/final_sq1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $O/final_sq2 -- python $R/tools/pmc_tile.py > $O/final_sq2.log 2>&1
 python $R/tools/pmc_summary.py $O/final_sq1 $O/final_sq2 > $O/final_sq_table.md 2>&1

@@ -42,7 +42,8 @@ def one(pattern):
     files = glob.glob(pattern)
     if not files:
         raise SystemExit(f"missing {pattern}")
-    return files[0]
+    # gpurun merges new files INTO gpurun_out: results of earlier calls (even earlier rounds) stay next to them - take the newest
+    return max(files, key=os.path.getmtime)
 
 
 def main():
