@@ -211,9 +211,32 @@ def compute_edges_from_overlap(segmentation: np.ndarray, device=None):
     sorted by (source, target)."""
     from . import ops
     dev = _lib.require_gpu(device)
+    _check_ids_unique_per_slice(segmentation)
     vol = torch.as_tensor(np.ascontiguousarray(segmentation).astype(np.int32, copy=False)).to(dev)
     table = ops.slice_overlaps(vol)
     return edges_from_overlap_table(table)
+
+
+def _check_ids_unique_per_slice(segmentation: np.ndarray) -> None:
+    """The overlap table sums a source object's pixels per ID: an id that occurs in two slices (a volume that did not come out of
+    ``segment_slices``, whose running offsets make every id slice-local) would have the sizes of two objects added up - silently wrong
+    scores.  One pass over the per-slice id ranges; a full check only where two slices' ranges overlap."""
+    seg = np.asarray(segmentation)
+    if seg.ndim != 3 or seg.shape[0] < 2:
+        return
+    seen_max = 0
+    for z in range(seg.shape[0]):
+        ids = seg[z][seg[z] != 0]
+        if ids.size == 0:
+            continue
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo <= seen_max:                       # ranges overlap: look at the ids themselves
+            prev = np.unique(seg[:z][(seg[:z] >= lo) & (seg[:z] != 0)])
+            both = np.intersect1d(prev, np.unique(ids))
+            if both.size:
+                raise ValueError(f"compute_edges_from_overlap: object ids must be unique across slices (id {int(both[0])} occurs in slice {z} "
+                                 "and in an earlier one); relabel the slices with running offsets first, as segment_slices does")
+        seen_max = max(seen_max, hi)
 
 
 def edges_from_overlap_table(table: np.ndarray):

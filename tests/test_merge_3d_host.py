@@ -87,3 +87,17 @@ def test_scores_costs_and_contraction():
     out = M._filter_z_extent(vol.copy(), 2)
     assert (out == 1).sum() == (vol == 1).sum() and not (out == 2).any()
     assert M._relabel_sequential(np.array([[0, 7, 7], [3, 0, 9]]), 5).tolist() == [[0, 6, 6], [5, 0, 7]]
+
+
+def test_ids_must_be_unique_across_slices():
+    """compute_edges_from_overlap sums object sizes per id: a volume whose slices reuse ids is refused - slice-local id
+    ranges (what segment_slices writes) and interleaved but disjoint ids pass."""
+    import pytest
+    ok = np.zeros((3, 4, 4), dtype=np.uint32)
+    ok[0, :2] = 1; ok[0, 2:] = 2; ok[1, :2] = 3; ok[2, 1:3] = 4
+    M._check_ids_unique_per_slice(ok)
+    inter = ok.copy(); inter[0, 2:] = 7; inter[1, 2:] = 5           # ranges overlap, ids do not
+    M._check_ids_unique_per_slice(inter)
+    bad = ok.copy(); bad[2, 3] = 1
+    with pytest.raises(ValueError, match="unique across slices"):
+        M._check_ids_unique_per_slice(bad)
