@@ -887,6 +887,20 @@ class TiledAutomaticPromptGenerator(TiledInstanceSegmentationWithDecoder):
         raise NotImplementedError
 
 
+# ---- the decoder module itself (reference :688-870; models/unetr.py: torch_em's UNETR restated, widths read from the checkpoint)
+from .models.unetr import DecoderAdapter, get_decoder, get_unetr  # noqa: E402,F401
+
+
+def get_predictor_and_decoder(model_type: str, checkpoint_path=None, device=None, peft_kwargs: Optional[Dict] = None):
+    """Reference ``get_predictor_and_decoder`` (:831-870): the predictor and the instance segmentation decoder of a checkpoint that
+    holds both (``{"model_state", "decoder_state"}``)."""
+    predictor, state = util.get_sam_model(model_type=model_type, checkpoint_path=checkpoint_path, device=device, return_state=True,
+                                          peft_kwargs=peft_kwargs)
+    if "decoder_state" not in state:
+        raise ValueError(f"The checkpoint at '{checkpoint_path}' or the chosen model '{model_type}' does not contain a decoder state")
+    return predictor, get_decoder(predictor.model.image_encoder, state["decoder_state"], predictor.device)
+
+
 def get_instance_segmentation_generator(predictor: SamPredictor, is_tiled: bool = False, decoder=None,
                                         segmentation_mode: Optional[str] = None, **kwargs):
     """Factory with the reference's signature and mode resolution (:1631-1690): ``amg`` without a decoder, ``ais`` (the reference's
