@@ -30,6 +30,7 @@ def test_ais_and_apg_with_the_unetr_decoder(vit_b_sd, tmp_path):
     st = seg.get_state()
     assert st["foreground"].shape == (512, 512) and np.isfinite(st["center_distances"]).all() and 0 <= st["foreground"].min() <= st["foreground"].max() <= 1
     # the adapter on the predictor's embedding == the module's own decoder path
+    proto.eval()                                              # (BatchNorm on its running statistics, as get_unetr leaves the loaded module)
     with torch.no_grad():
         direct = proto.to("cuda").postprocess_masks(proto.decode(predictor.features.float()), predictor.input_size, predictor.original_size)
     assert np.allclose(direct[0, 0].cpu().numpy(), st["foreground"], atol=1e-4)
