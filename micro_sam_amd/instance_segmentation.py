@@ -571,14 +571,39 @@ class TiledAutomaticMaskGenerator(AutomaticMaskGenerator):
         # only the image SHAPE is used below (the embeddings are precomputed): skip the host-side pixel conversion
         image = np.broadcast_to(np.zeros((1, 1, 1), dtype=np.uint8), tuple(original_size) + (3,))
         mask_data = []
+        # round 4: the tiles of one image are decoded on `tile_lanes` concurrent lanes (lane clones on their own HIP streams, as in the
+        # pipelined slice loop): the kernels of different tiles overlap instead of running one tile after the other.  Every lane waits for
+        # an event recorded on the caller's stream first (whatever produced / still reads the previous state is ordered before it), the
+        # caller's stream waits for all lanes at the end: the state is complete when initialize returns, as in the serial loop.
+        n_lanes = min(int(getattr(self, "tile_lanes", 3)), n_tiles)
+        lanes = None
+        if n_lanes > 1 and str(self._predictor.device).startswith("cuda") and torch.cuda.is_available() \
+                and hasattr(self._predictor.model, "lane_view"):
+            lanes = self._decode_lanes(n_lanes)
+            main = torch.cuda.current_stream(self._predictor.device)
+            start = torch.cuda.Event()
+            start.record(main)
         for idx, tile_id in enumerate(tile_ids):
             features = image_embeddings["features"][str(tile_id)]
             tile_embeddings = {"features": features, "input_size": features.attrs["input_size"],
                                "original_size": features.attrs["original_size"]}
-            util.set_precomputed(self._predictor, tile_embeddings, i)
-            mask_data.append(self._process_crop(image, crop_box=crop_boxes[idx], crop_layer_idx=0,
-                                                precomputed_embeddings=True))
+            if lanes is None:
+                util.set_precomputed(self._predictor, tile_embeddings, i)
+                mask_data.append(self._process_crop(image, crop_box=crop_boxes[idx], crop_layer_idx=0,
+                                                    precomputed_embeddings=True))
+            else:
+                clone, st = lanes[idx % n_lanes]
+                clone._original_size = original_size
+                st.wait_event(start)
+                with torch.cuda.stream(st):
+                    util.set_precomputed(clone._predictor, tile_embeddings, i)
+                    mask_data.append(clone._process_crop(image, crop_box=crop_boxes[idx], crop_layer_idx=0,
+                                                         precomputed_embeddings=True))
             pbar_update(1)
+        if lanes is not None:
+            for _, st in lanes[:n_lanes]:
+                main.wait_stream(st)
+            util.set_precomputed(self._predictor, tile_embeddings, i)        # the predictor holds the last tile, as after the serial loop
         pbar_close()
         self._is_initialized = True
         self._crop_list = mask_data

@@ -423,6 +423,14 @@ def test_tiled_amg_vs_oracle(ctx):
         assert seg.shape == (600, 720) and seg.dtype == np.uint32
         assert np.array_equal(seg, PR.amg_generate(_oracle_state_from(amg.get_state()), **kw))
     assert amg.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5).max() > 0
+    # round 4: the four tiles were decoded on concurrent lanes (tile_lanes = 3); one tile after the other gives the identical state
+    serial = get_instance_segmentation_generator(p, is_tiled=True, points_per_side=4)
+    serial.tile_lanes = 1
+    serial.initialize(image, emb)
+    for a, b in zip(serial.crop_list, amg.crop_list):
+        for k in ("iou_preds", "stability_score", "boxes", "area", "bits"):
+            assert torch.equal(torch.nan_to_num(a[k].float(), nan=-1.0), torch.nan_to_num(b[k].float(), nan=-1.0)), k
+    assert np.array_equal(serial.generate(), amg.generate()) and p.original_size == feats["3"].attrs["original_size"]
 
 
 def test_zarr_cache_gpu(ctx, tmp_path):
