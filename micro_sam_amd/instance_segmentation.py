@@ -311,28 +311,35 @@ class AutomaticMaskGenerator(AMGBase):
         self._crop_n_points_downscale_factor = crop_n_points_downscale_factor
         self._stability_score_offset = stability_score_offset
 
-    def _lane_clone(self) -> "AutomaticMaskGenerator":
+    def _lane_clone(self, lane_predictor: Optional[SamPredictor] = None) -> "AutomaticMaskGenerator":
         """Another generator with the same settings on a lane view of the predictor's model (own decoder scratch, own state): what a
-        concurrent decode lane of the pipelined slice loop works with."""
+        concurrent decode lane of the pipelined slice / tile loops works with."""
         import copy
         clone = copy.copy(self)
-        clone._predictor = SamPredictor(self._predictor.model.lane_view())
+        clone._predictor = lane_predictor if lane_predictor is not None else SamPredictor(self._predictor.model.lane_view())
         clone._prompt_cache = {}
         clone._lanes = clone._post_stream = None
         clone.clear_state()
         return clone
 
     def _decode_lanes(self, n: int):
-        """``n`` (lane clone, HIP stream) pairs, kept on the generator: the decoder workspace of a lane (several GiB for 1024 prompts)
-        lives in its model view and torch caches device memory per stream - fresh clones / streams per call would allocate it anew
-        every time (measured: 21 tiles/s instead of > 150)."""
+        """``n`` (lane clone, HIP stream) pairs.  The expensive part of a lane - the model view with its decoder workspace (several GiB for
+        1024 prompts) and its stream (torch caches device memory per stream) - is kept on the PREDICTOR, so generators that come and go
+        (one per call of a caller's loop) find it again; the clones themselves are kept on the generator.  Fresh views / streams per call
+        allocated the workspaces anew every time (measured: 21 tiles/s instead of > 150)."""
         dev = self._predictor.device
+        pool = getattr(self._predictor, "_lane_pool", None) or []
+        if pool and (pool[0][0].device != dev or pool[0][0].model.mask_decoder is not self._predictor.model.mask_decoder):
+            pool = []                              # the predictor was moved / its model replaced
+        while len(pool) < n:
+            pool.append((SamPredictor(self._predictor.model.lane_view()), torch.cuda.Stream(device=dev)))
+        self._predictor._lane_pool = pool
         lanes = getattr(self, "_lanes", None) or []
-        if lanes and (lanes[0][0]._predictor.device != dev or
-                      lanes[0][0]._predictor.model.mask_decoder is not self._predictor.model.mask_decoder):
-            lanes = []                             # the generator's predictor was moved / replaced
+        if lanes and any(l[0]._predictor is not p for l, (p, _) in zip(lanes, pool)):
+            lanes = []
         while len(lanes) < n:
-            lanes.append((self._lane_clone(), torch.cuda.Stream(device=dev)))
+            lp, st = pool[len(lanes)]
+            lanes.append((self._lane_clone(lp), st))
         self._lanes = lanes
         for clone, _ in lanes[:n]:                 # settings may have been changed on the generator since the clone was made
             for k in ("point_grids", "_points_per_side", "_points_per_batch", "_crop_n_layers", "_crop_overlap_ratio",
