@@ -121,8 +121,10 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
                 ev = torch.cuda.Event()
                 ev.record(post)
         if out is not None:
-            out[s0:s1].fill(0)               # first touch of the result's pages (fresh allocation: ~10 ms of page faults per 64 MiB) now,
-            #                                  while the device works, instead of inside the drain at the end of the pipeline
+            if b == len(bounds) - 1:
+                out[s0:s1].fill(0)           # first touch of the LAST batch's result pages (fresh allocation: ~10 ms of page faults per 64 MiB)
+                #                              now, while the device works: its drain is the one nothing overlaps (earlier batches fault their
+                #                              pages inside their own, overlapped, drains - touching them twice only costs host time)
             if pending is not None:
                 drain(pending)               # batch b - 1: complete by now or soon - batch b is already queued behind it
             pending = (s0, s1, slot, ev)
