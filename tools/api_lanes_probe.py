@@ -1,3 +1,4 @@
+"""GPU-box probe (round 4): tiles/s of the pipelined multi_dimensional_segmentation.segment_slices over decode lanes x encoder batch sizes (64 tiles)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())

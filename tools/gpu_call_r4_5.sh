@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_model.py -x -q -k "decoder or amg_initialize or set_image" 2>&1 | tail -3
 timeout 900 python -m pytest tests/test_gpu_parity_iou.py -x -q 2>&1 | tail -3
 timeout 900 python tools/trained_parity.py --steps 100 --thresholds 0.5 0.8 --ablations 2>/dev/null | tee gpurun_out/trained_parity4.log | cut -c1-1800
-timeout 900 python tools/_probe4.py 2>/dev/null | tee gpurun_out/probe4b.log
+timeout 900 python tools/logit_error_probe.py 2>/dev/null | tee gpurun_out/probe4b.log
 timeout 900 python bench.py --no-cpu-baseline --no-config-sides --steps 2 > gpurun_out/r4_5_bench.log 2> gpurun_out/r4_5_bench.err; tail -c 300 gpurun_out/r4_5_bench.err
 python - <<'PY'
 import json

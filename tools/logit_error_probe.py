@@ -1,3 +1,5 @@
+"""GPU-box probe (round 4): low-res logit error of the HIP mask decoder and of the oracle's emulation of its rounding policy against the fp32 oracle, on the designed
+checkpoint, after 100 fine-tuning steps and after a 1 % random perturbation of every weight (profiles/r04_experiments.md section 3)."""
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
