@@ -57,7 +57,9 @@ typedef struct {
     int64_t ldr;
     int32_t act;                         /* MSAM_ACT_* applied last */
     void* out; int32_t out_dtype; int64_t ldc;   /* plain output (out_mode 0) */
-    int32_t out_mode;                    /* 0 plain, 1 qkv-split (ViT attention layout), 2 kv-split (decoder) */
+    int32_t out_mode;                    /* 0 plain, 1 qkv-split (ViT attention layout), 2 kv-split (decoder), 3 = `out` as hi + lo pairs of the
+                                          * 16-bit out_dtype, rows [hi | lo | hi] with ldc == 3 N (128 x 128 tile path only: the A operand of a
+                                          * product against [Whi | Whi | Wlo] weight rows, msam_twoway_layer_t.mlp2_ws) */
     void* q; void* k; void* v;           /* out_mode 1: q,k,v -> [B,heads,tokens,hd] bf16
                                             out_mode 2 (N == 256): k <- cols 0..127 as [M,128] bf16,
                                             v <- cols 128..255 transposed [M/tokens,128,tokens] bf16 */

@@ -630,6 +630,7 @@ extern int g_tune_dec_chain, g_tune_dec_chain_min_p, g_tune_chain_variant;
 // bound by the latency INSIDE each small product (a dependent chain of 4 - 32 k-tiles on a fraction of the chip), not by launch count.
 // Default off; kept as a tested option.
 int g_tune_tok_fuse = 0;
+int g_tune_mlp_split_fused = 1;           // msam_tune_set "mlp_split_fused": 0 = fp32 hidden + separate cast launch (the A/B and test form)
 namespace {
 struct Work {
     float *qpe, *queries, *tmp; u16 *a, *b, *qs, *ks, *vs, *attn_tok, *mlp_h;
@@ -877,8 +878,8 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
         } else {
         CHECK(gemm(cx, w.attn_tok, CI, L.t2i.o_w, M, C, CI, L.t2i.o_b, w.tmp, MSAM_F32, C, 0, w.queries, MSAM_F32, C));
         LN(w.tmp, L.n2_w, L.n2_b, M, w.queries, MSAM_F32);
-        // (3) token MLP
-        ADD_CAST(w.queries, nullptr, w.a);
+        // (3) token MLP (mlp_split reads the fp32 LayerNorm output itself: no plain 16-bit copy needed)
+        if (!(L.mlp1_ws != nullptr && L.mlp2_ws != nullptr)) ADD_CAST(w.queries, nullptr, w.a);
         }
         // token MLP.  mlp_split (round 4): both products on hi + lo operand pairs - the LayerNorm output (fp32, w.queries) and the ReLU
         // hidden (kept in fp32) are laid out as [hi | lo | hi] rows against [Whi | Whi | Wlo] weight rows, one plain 16-bit GEMM over
@@ -891,8 +892,15 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
             float* h32 = (float*)((char*)a3 + align256((long)M * 3 * C * 2));
             u16* h3 = (u16*)((char*)h32 + align256((long)M * 2048 * 4));
             CHECK(msam_cast_f32_split16(w.queries, MSAM_D16, a3, M, C, cx.s));
-            CHECK(gemm(cx, a3, 3 * C, L.mlp1_ws, M, 2048, 3 * C, L.mlp1_b, h32, MSAM_F32, 2048, MSAM_ACT_RELU));
-            CHECK(msam_cast_f32_split16(h32, MSAM_D16, h3, M, 2048, cx.s));
+            if (g_tune_mlp_split_fused) {
+                // the ReLU hidden leaves lin1's epilogue as [hi | lo | hi] rows (msam_gemm_t.out_mode 3): no fp32 copy, no second cast launch
+                msam_gemm_t g1 = mk_gemm(a3, 3 * C, L.mlp1_ws, M, 2048, 3 * C, L.mlp1_b, h3, MSAM_D16, 3 * 2048, MSAM_ACT_RELU);
+                g1.out_mode = 3;
+                CHECK(msam_gemm_bf16(&g1, cx.s));
+            } else {
+                CHECK(gemm(cx, a3, 3 * C, L.mlp1_ws, M, 2048, 3 * C, L.mlp1_b, h32, MSAM_F32, 2048, MSAM_ACT_RELU));
+                CHECK(msam_cast_f32_split16(h32, MSAM_D16, h3, M, 2048, cx.s));
+            }
             mlp_h = h3; mlp2_w = L.mlp2_ws; mlp2_k = 3 * 2048;
         } else {
         CHECK(gemm(cx, w.a, C, L.mlp1_w, M, 2048, C, L.mlp1_b, w.mlp_h, MSAM_D16, 2048, MSAM_ACT_RELU));

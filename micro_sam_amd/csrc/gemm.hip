@@ -265,6 +265,17 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
                 uint2 pk; pk.x = pack16(v[0], v[1], e.out_dtype); pk.y = pack16(v[2], v[3], e.out_dtype);
                 *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
             }
+        } else if (e.out_mode == 3) {
+            // hi + lo operand pairs of the 16-bit output type, rows [hi | lo | hi] of 3 N (ldc = 3 N): the A operand of a product
+            // against [Whi | Whi | Wlo] weight rows - the same values norm.hip's cast_split_kernel writes from an fp32 copy of this
+            // tile, without the fp32 round trip and the extra launch (the token MLP's ReLU hidden, decoder.hip mlp_split)
+            uint2 hi, lo;
+            hi.x = pack16(v[0], v[1], e.out_dtype); hi.y = pack16(v[2], v[3], e.out_dtype);
+            lo.x = pack16(v[0] - load16((u16)(hi.x & 0xffff), e.out_dtype), v[1] - load16((u16)(hi.x >> 16), e.out_dtype), e.out_dtype);
+            lo.y = pack16(v[2] - load16((u16)(hi.y & 0xffff), e.out_dtype), v[3] - load16((u16)(hi.y >> 16), e.out_dtype), e.out_dtype);
+            u16* o = (u16*)e.out + (long)row * e.ldc + col;
+            const long third = e.ldc / 3;
+            *(uint2*)o = hi; *(uint2*)(o + third) = lo; *(uint2*)(o + 2 * third) = hi;
         } else if (e.out_mode == 1) {
             u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
             const int b = row / e.tokens, t = row - b * e.tokens;
@@ -1213,6 +1224,11 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     }
     if ((p->lda % 8) || (p->ldw % 8)) { msam_set_error("msam_gemm_bf16: lda/ldw must be multiples of 8"); return 1; }
     if (p->out_mode == 0 && (p->ldc % 4)) { msam_set_error("msam_gemm_bf16: ldc must be a multiple of 4"); return 1; }
+    if (p->out_mode == 3 && (!p->out || p->ldc != 3L * p->N || p->N % 4 || p->out_dtype == MSAM_F32 || p->ln_mode || p->split_k > 1 || p->a_dtype == MSAM_FP8)) {
+        msam_set_error("msam_gemm_bf16: out_mode 3 (hi + lo pairs) needs a 16-bit output with ldc == 3 N, no fused LayerNorm / split-K / fp8");
+        return 1;
+    }
+    if (p->out_mode < 0 || p->out_mode > 3) { msam_set_error("msam_gemm_bf16: out_mode is 0 .. 3"); return 1; }
     if ((p->table && ((p->table_cols % 4) || (p->table_ld % 4))) || (p->resid && (p->ldr % 4))) {
         msam_set_error("msam_gemm_bf16: table_cols/table_ld/ldr must be multiples of 4");
         return 1;
@@ -1310,7 +1326,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     // (its operand offsets are 32-bit: operands of 2 GiB and more stay on the 256 x 256 kernel)
     if (MSAM_EXPERIMENTS && use256 && staging256 == 4 && (double)p->M * p->lda * 2 < 2147483648.0 && (double)p->N * p->ldw * 2 < 2147483648.0 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds &&
         ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % GW_BN == 0 && p->K % GW_BK == 0 && p->lda % 8 == 0 && p->ldw % 8 == 0 &&
-        p->out_mode != 2 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
+        p->out_mode != 2 && p->out_mode != 3 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr2w = false;
         if (!attr2w) {
             if (hipFuncSetAttribute((const void*)gemm2w_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GW_LDS) != hipSuccess ||
@@ -1347,7 +1363,7 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
     // (measured: 3 - 14 % faster than the 128 x 128 kernel from one workgroup per CU upwards, slower below)
     // (fp16 operands: 16-bit outputs of this kernel are then fp16 as well - the encoder's fp16 mode; a bf16 output is not offered)
     if (use256 && p->split_k <= 1 && (!f16 || p->out_dtype != MSAM_BF16) && !p->use_glds && ((p->M + G2 - 1) / G2) * (p->N / G2) >= 256 && p->N % G2 == 0 &&
-        p->out_mode != 2 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
+        p->out_mode != 2 && p->out_mode != 3 && !p->table && (!p->resid || (p->resid_dtype == MSAM_F32 && !p->resid_rows))) {
         static bool attr256 = false;
         if (!attr256) {
             if (hipFuncSetAttribute((const void*)gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS) != hipSuccess ||

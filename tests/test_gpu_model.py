@@ -750,6 +750,26 @@ def test_token_side_fused_launches_give_the_same_decode(ctx):
     assert (iou1 - iou0).abs().max().item() <= 2e-3
 
 
+def test_token_mlp_hidden_pairs_from_the_epilogue_are_the_separate_cast(ctx):
+    """msam_gemm_t.out_mode 3 (round 4): lin1 writes the ReLU hidden as [hi | lo | hi] rows in its epilogue - bit-identical to the fp32 hidden
+    + msam_cast_f32_split16 launch it replaces (msam_tune_set "mlp_split_fused" 0), at the AMG's launch (1024 prompts, chained kernels)."""
+    from micro_sam_amd import _lib
+    sam = ctx["predictor"].model
+    feats = ctx["ref_b"].cuda()
+    g = torch.Generator().manual_seed(10)
+    P = 1024
+    pts = (torch.rand(P, 1, 2, generator=g) * 1024).cuda()
+    lbl = torch.ones(P, 1, dtype=torch.int).cuda()
+    lib = _lib.load()
+    try:
+        low1, iou1 = sam.decode(feats, pts, lbl)
+        lib.msam_tune_set(b"mlp_split_fused", 0)
+        low0, iou0 = sam.decode(feats, pts, lbl)
+    finally:
+        lib.msam_tune_set(b"mlp_split_fused", 1)
+    assert torch.equal(low1, low0) and torch.equal(iou1, iou0)
+
+
 def test_config1_vit_t_plumbing():
     """BASELINE configs[0]: vit_t (MobileSAM) - get_sam_model -> precompute_image_embeddings -> AutomaticMaskGenerator on one 512 x 512
     tile, the checks of the reference's test/test_instance_segmentation.py:73-121 that do not need trained weights (shapes, regenerate

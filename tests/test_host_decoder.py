@@ -118,3 +118,27 @@ def test_mask_prompt_alone_decodes_on_the_host_library(host_sam):
     assert (iou - iou_b).abs().max().item() <= 2e-3
     with pytest.raises(ValueError):
         sam.decode(feats, None, None, None, None)
+
+
+def test_hidden_as_operand_pairs_from_the_product_epilogue_is_the_separate_cast(host_sam):
+    """msam_gemm_t.out_mode 3 (round 4): lin1's epilogue writes the ReLU hidden as [hi | lo | hi] rows itself - the same bits as the fp32
+    hidden + msam_cast_f32_split16 launch it replaces (msam_tune_set "mlp_split_fused" 0), so the whole decode is bit-identical."""
+    host, sam, _ = host_sam
+    g = torch.Generator().manual_seed(13)
+    feats = torch.randn(1, 256, 64, 64, generator=g) * 0.6
+    pts = torch.rand(3, 2, 2, generator=g) * 1024
+    lbl = torch.ones(3, 2, dtype=torch.int)
+    sam.invalidate()
+    low1, iou1 = sam.decode(feats, pts, lbl)
+    assert host.msam_tune_set(b"mlp_split_fused", 0) == 0
+    try:
+        low0, iou0 = sam.decode(feats, pts, lbl)
+    finally:
+        host.msam_tune_set(b"mlp_split_fused", 1)
+    assert torch.equal(low1, low0) and torch.equal(iou1, iou0)
+    sam.set_split_token_mlp(False)                           # and the plain-operand MLP of rounds 1 - 3 is a different (less exact) result
+    try:
+        lowp, _ = sam.decode(feats, pts, lbl)
+    finally:
+        sam.set_split_token_mlp(True)
+    assert not torch.equal(lowp, low1) and (lowp - low1).abs().max().item() < 0.05 * low1.abs().max().item()
