@@ -68,6 +68,10 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
     t0 = time.perf_counter()
     feats, osz, isz = PR.compute_embeddings(sd, [img], "vit_b", "fp32")
     ref = PR.amg_initialize(sd, img, feats, isz[0], osz[0], points_per_side=points_per_side, precision="fp32")
+    if pred_iou_thresh is None:
+        # the fine-tuned IoU head's predictions move from run to run (the training is not reproducible): a fixed threshold in the middle of
+        # their distribution keeps 36 or 190 instances; the lower quartile of the REFERENCE's predictions keeps three quarters of the candidates
+        pred_iou_thresh = float(np.nanquantile(PT.oracle_scores(ref)["iou_pred"], 0.25))
     seg_ref = PR.amg_generate(ref, pred_iou_thresh=pred_iou_thresh, stability_score_thresh=stability_score_thresh)
     t_ref = time.perf_counter() - t0
     kept_ref = PT.kept_candidates(ref, pred_iou_thresh, stability_score_thresh)
@@ -95,6 +99,7 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
     extra = {"ref_iou_pred_quantiles": [round(float(v), 3) for v in np.nanquantile(rs["iou_pred"], q)],
              "ref_stability_quantiles": [round(float(v), 3) for v in np.nanquantile(rs["stability"], q)],
              "iou_pred_max_abs_diff": float(np.abs(rs["iou_pred"] - scores["iou_pred"]).max()),
+             "pred_iou_thresh": round(float(pred_iou_thresh), 4), "stability_score_thresh": float(stability_score_thresh),
              "oracle_seconds": round(t_ref, 1),
              "embedding_mean_abs_err": float((torch.as_tensor(emb["features"]).float().cpu() - feats).abs().mean()),
              "embedding_mean_abs": float(feats.abs().mean())}
