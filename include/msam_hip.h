@@ -512,6 +512,7 @@ int msam_decoder_forward(const msam_decoder_t* dec, const void* consts, const vo
  * Conv2d(16,256,1) [256,16]; all fp32 device pointers. */
 typedef struct {
     const float *c1_w, *c1_b, *ln1_w, *ln1_b, *c2_w, *c2_b, *ln2_w, *ln2_b, *c3_w, *c3_b;
+    int32_t exact_gelu;              /* 1: the two GELUs as 0.5 x (1 + erf(x / sqrt 2)) with the library erff (strict mode); 0: the 5.5e-5 form */
 } msam_mask_prompt_t;
 int msam_decoder_forward_masks(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, const void* consts,
                                const void* image_state, const float* points, const int32_t* labels, int32_t Np,
@@ -624,6 +625,55 @@ int msam_slice_overlaps(const int32_t* labels, int32_t Z, int32_t H, int32_t W, 
  * image fp32 [H,W], markers int32 [H,W] (0 = none), mask uint8 [H,W] or NULL, out int32 [H,W].
  * ------------------------------------------------------------------------------------------------- */
 int msam_host_seeded_watershed(const float* image, const int32_t* markers, const uint8_t* mask, int32_t H, int32_t W, int32_t* out);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The "strict" precision mode (micro_sam_amd.strict, Sam.set_precision("strict")): the reference's own formulation of
+ * ImageEncoderViT / PromptEncoder / MaskDecoder (segment_anything behind micro_sam/util.py:674 `predictor.model.image_encoder(x)` and
+ * micro_sam/instance_segmentation.py:361-366 `predictor.predict_torch(...)`) on fp32 kernels - every tensor fp32, products on the
+ * f32-input MFMA (exact fp32 products, fp32 accumulation), erf GELU, expf softmax, IEEE divisions - for callers who need the
+ * reference's results to fp32 rounding rather than the 16-bit throughput path.  The host side sequences these building blocks.
+ * ------------------------------------------------------------------------------------------------- */
+/* out[m][n] = act(sum_k (A[m][k] + A2[m % a2_rows][k]) * W[n][k] + bias[n]) + res[m % res_rows][n]   (torch.nn.functional.linear with
+ * the surrounding adds of the reference: `(x + pe) @ W.T + b`, `x + mlp(x)`, `conv(x) + pos_embed`).  All fp32; K, lda, ldw, lda2 % 4
+ * == 0, operands 16-byte aligned; A2 / bias / res may be NULL; a2_rows / res_rows 0 = M. */
+typedef struct {
+    const float* A; int64_t lda;
+    const float* A2; int64_t lda2; int64_t a2_rows;
+    const float* W; int64_t ldw;
+    int64_t M; int32_t N, K;
+    const float* bias; int32_t act;      /* MSAM_ACT_NONE / MSAM_ACT_GELU (exact erf form) / MSAM_ACT_RELU, applied before the residual */
+    const float* res; int64_t ldr; int64_t res_rows;
+    float* out; int64_t ldc;
+} msam_sgemm_t;
+int msam_strict_gemm(const msam_sgemm_t* p, void* stream);
+/* torch.nn.LayerNorm / LayerNorm2d rows: x fp32 [rows, dim <= 1280] -> out fp32 (may be x), optional exact GELU afterwards;
+ * out_nchw_hw > 0: output transposed to [rows / hw, dim, hw] (the encoder's NCHW result). */
+int msam_strict_layernorm(const float* x, const float* weight, const float* bias, float eps, int64_t rows, int32_t dim, float* out,
+                          int32_t gelu, int32_t out_nchw_hw, void* stream);
+/* Attention of one ViT block with add_decomposed_rel_pos, from the qkv projection's rows: qkv fp32 [B * grid^2, 3 * heads * head_dim]
+ * (q | k | v, heads inside), qkv_bias fp32 [3 * heads * head_dim] (= the q / k / v of the zero-padded window border), rel_h / rel_w fp32
+ * [2 S - 1, head_dim] with S = window or grid (already resized to that length), window 14 (any grid <= 64: windows of the zero-padded
+ * grid) or 0 (global, grid 64), head_dim 64 or 80; scores = (scale q) . k + q . R_h + q . R_w, softmax, @ v -> out fp32
+ * [B * grid^2, heads * head_dim]. */
+int msam_strict_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
+                                 int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream);
+/* Attention of the two-way transformer: q fp32 [B, Nq, H * D] (row stride ldq, batch stride in floats; 0 = one tensor shared by every
+ * batch entry), k / v [B, Nk, H * D], out [B, Nq, H * D]; softmax((q . k) / denom) @ v; D = 16 or 32, Nq <= 16 or Nk <= 16. */
+int msam_strict_attention(const float* q, int64_t ldq, int64_t q_batch_stride, const float* k, int64_t ldk, int64_t k_batch_stride,
+                          const float* v, int64_t ldv, int64_t v_batch_stride, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t D,
+                          float denom, float* out, int64_t ldo, int64_t out_batch_stride, void* stream);
+/* Patch gather: img fp32 [B,3,1024,1024] (after Sam.preprocess) or img_u8 uint8 HWC [B,h,w,3] (Sam.preprocess fused: (x - mean) / std,
+ * zero padding) -> fp32 [B * 4096, 768], columns (c, ky, kx). */
+int msam_strict_patchify(const float* img, const uint8_t* img_u8, int32_t B, int32_t h, int32_t w, float* out, void* stream);
+/* x fp32 [B,64,64,C] -> fp32 [B * 4096, 9 C], columns (ky, kx, c): the 3 x 3 / pad 1 neck convolution as a product. */
+int msam_strict_im2col3x3(const float* x, int32_t B, int32_t C, float* out, void* stream);
+/* src fp32 [P, 4096, 256] = embedding [256, 4096]^T + dense: dense_stride 0 -> the no_mask_embed vector [256] (P = 1: shared by every
+ * prompt), else dense [P, 256, 4096] (mask prompts).  P <= 8191. */
+int msam_strict_source(const float* embedding, const float* dense, int64_t dense_stride, int32_t P, float* src, void* stream);
+/* masks = hyper_in @ upscaled_embedding, un-shuffled: up fp32 [P * 4096 * 4, 128] (row = (prompt, token, first 2 x 2 sub-pixel), column =
+ * second sub-pixel * 32 + channel), hyper fp32 [P, 4, hyper_ld] -> low_res fp32 [P, nmask, 256, 256] of masks mask0 .. mask0 + nmask - 1. */
+int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, int64_t P, float* low_res,
+                            void* stream);
 
 #ifdef __cplusplus
 }

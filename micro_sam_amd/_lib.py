@@ -94,9 +94,16 @@ class DecoderParams(C.Structure):
     ]
 
 
+class SGemmParams(C.Structure):
+    """include/msam_hip.h msam_sgemm_t (the strict mode's fp32 product)."""
+    _fields_ = [("A", _vp), ("lda", _i64), ("A2", _vp), ("lda2", _i64), ("a2_rows", _i64), ("W", _vp), ("ldw", _i64),
+                ("M", _i64), ("N", _i32), ("K", _i32), ("bias", _vp), ("act", _i32), ("res", _vp), ("ldr", _i64), ("res_rows", _i64),
+                ("out", _vp), ("ldc", _i64)]
+
+
 class MaskPromptParams(C.Structure):
     """include/msam_hip.h msam_mask_prompt_t: fp32 weights of prompt_encoder.mask_downscaling."""
-    _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "ln1_w", "ln1_b", "c2_w", "c2_b", "ln2_w", "ln2_b", "c3_w", "c3_b")]
+    _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "ln1_w", "ln1_b", "c2_w", "c2_b", "ln2_w", "ln2_b", "c3_w", "c3_b")] + [("exact_gelu", _i32)]
 
 
 _PROTOS = {
@@ -202,6 +209,15 @@ _PROTOS = {
     "msam_slice_overlaps": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, C.POINTER(_i32), _vp]),
+    "msam_strict_gemm": (_i32, [C.POINTER(SGemmParams), _vp]),
+    "msam_strict_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _vp]),
+    "msam_strict_relpos_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "msam_strict_attention": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64,
+                                     _i64, _vp]),
+    "msam_strict_patchify": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "msam_strict_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "msam_strict_source": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "msam_strict_hyper_masks": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
 }
 OPTIONAL = set()
 

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmsam_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "decoder.hip", "postprocess.hip", "encoder.hip", "segment.hip", "wsgemm.hip", "declayer.hip", "decfold.hip", "decfold_tok.hip", "upfused.hip", "image.hip", "train.hip", "amgselect.hip", "watershed.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "decoder.hip", "postprocess.hip", "encoder.hip", "segment.hip", "wsgemm.hip", "declayer.hip", "decfold.hip", "decfold_tok.hip", "upfused.hip", "image.hip", "train.hip", "amgselect.hip", "watershed.hip", "strict.hip"]
 ARCH = "gfx950"
 
 

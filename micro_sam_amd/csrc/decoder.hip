@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256) void prompt_tokens_kernel(
     }
 }
 
+MSAM_DEVINL float gelu_exact_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 // Mask prompts (PromptEncoder._embed_masks, segment_anything/modeling/prompt_encoder.py: mask_downscaling = Conv 2x2/2
 // (1->4), LayerNorm2d, GELU, Conv 2x2/2 (4->16), LayerNorm2d, GELU, Conv 1x1 (16->256)): the per-prompt decoder source
 // src_p = image embedding + dense prompt embedding, written as the bf16 image-token stream [P, 4096, 256].
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void mask_src_kernel(const float* __restrict__
                 for (int ch = 0; ch < 4; ++ch) { v[ch] -= mean; var += v[ch] * v[ch]; }
                 const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) h1[i][j][ch] = gelu_erf(v[ch] * rstd * mp.ln1_w[ch] + mp.ln1_b[ch]);
+                for (int ch = 0; ch < 4; ++ch) { const float z_ = v[ch] * rstd * mp.ln1_w[ch] + mp.ln1_b[ch]; h1[i][j][ch] = mp.exact_gelu ? gelu_exact_f(z_) : gelu_erf(z_); }
             }
         float v2[16], mean = 0.f;
 #pragma unroll
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void mask_src_kernel(const float* __restrict__
         for (int co = 0; co < 16; ++co) { v2[co] -= mean; var += v2[co] * v2[co]; }
         const float rstd = 1.0f / sqrtf(var * (1.f / 16.f) + 1e-6f);
 #pragma unroll
-        for (int co = 0; co < 16; ++co) h2s[tx][co] = gelu_erf(v2[co] * rstd * mp.ln2_w[co] + mp.ln2_b[co]);
+        for (int co = 0; co < 16; ++co) { const float z_ = v2[co] * rstd * mp.ln2_w[co] + mp.ln2_b[co]; h2s[tx][co] = mp.exact_gelu ? gelu_exact_f(z_) : gelu_erf(z_); }
     }
     __syncthreads();
     const int c = tid;

@@ -1,0 +1,623 @@
+// The "strict" precision mode (Sam.set_precision("strict")): the reference's OWN formulation of SAM - no folding, no 16-bit streams -
+// on fp32 kernels, for callers who need the north-star tolerance (mask IoU >= 0.999 per instance, identical ids vs the reference CPU
+// path) instead of the 16-bit throughput path.  What the reference runs through torch's fp32 CPU operators
+// (segment_anything ImageEncoderViT / PromptEncoder / MaskDecoder behind micro_sam/util.py:674 and instance_segmentation.py:361-366)
+// runs here as:
+//   sgemm_kernel          y = act((A + A2) W^T + b) + R on v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation - bit for bit a
+//                         k-ordered fmaf chain (MI355X_MICROARCH.md "FP32-input MFMA"), 1/16 of the bf16 MFMA rate
+//   sln_kernel            LayerNorm / LayerNorm2d rows, two-pass statistics, optional exact erf GELU
+//   srelpos_kernel        the image encoder's attention (14 x 14 windows with the zero-padded border, or the 64 x 64 grid) with the
+//                         decomposed relative position bias, straight from the qkv rows: fp32 VALU, accurate expf
+//   sattn_short / _long   the two-way transformer's attentions (<= 16 tokens on one side), fp32 VALU
+//   shyper_kernel         masks = hyper_in @ upscaled + the un-shuffle of the two transposed convolutions' 4 x 4 pixel blocks
+//   spatchify / sim2col / ssrc   the exact gathers (Sam.preprocess fused for uint8 input: (x - mean) / std with IEEE division)
+// GELU is 0.5 x (1 + erf(x / sqrt 2)) with the library erff, exponentials are expf, divisions are IEEE: every step is the
+// reference's step to fp32 rounding; what differs from the CPU result is the order of the additions inside a product.
+// The host side (micro_sam_amd/strict.py) sequences these calls; cost and measured parity: DESIGN.md section 4.
+#include "common.h"
+#include "../../include/msam_hip.h"
+
+void msam_set_error(const char* msg);
+int msam_check_launch(const char* what);
+
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+MSAM_DEVINL f32x16_t mfma32f(float a, float b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+namespace {
+
+MSAM_DEVINL float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+MSAM_DEVINL float4 ld4(const float* p) { return *(const float4*)p; }
+MSAM_DEVINL float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ------------------------------------------------------------------------------------------------------------------ sgemm
+// 128 x 128 output tile, k-tiles of 32, 4 waves x (64 x 64 = 2 x 2 MFMA tiles of 32 x 32), register-staged double buffer, one barrier
+// per k-tile.  v_mfma_f32_32x32x2_f32 contracts over k = lane / 32: lane (i, h) feeds elements h * 16 + s of the 32-wide k-tile in step
+// s = 0..15 (both operands use the same assignment, so the instruction sums the pair {s, 16 + s} - any assignment that is the same on both
+// sides is a valid contraction order); a lane's 16 steps are 64 contiguous bytes of its LDS row = 4 ds_read_b128.  Row pitch 36 floats:
+// the 16 lanes of a ds_read_b128 service group land on 16 different 16-byte bank groups.
+constexpr int SG_PITCH = 36;
+struct SGemmArgs {
+    const float* A; long lda; const float* A2; long lda2; long a2_rows;
+    const float* W; long ldw; long M; int N, K;
+    const float* bias; int act; const float* res; long ldr; long res_rows;
+    float* out; long ldc;
+};
+
+__global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][128 * SG_PITCH];
+    __shared__ __attribute__((aligned(16))) float Ws[2][128 * SG_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ntn = (a.N + 127) / 128;
+    const long bid = blockIdx.x;
+    const int tn = (int)(bid % ntn);
+    const long m0 = (bid / ntn) * 128;
+    const int n0 = tn * 128;
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+    const float* ap[4]; const float* a2p[4]; const float* wp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long m = m0 + srow + 32 * j;
+        if (m >= a.M) m = a.M - 1;
+        ap[j] = a.A + m * a.lda + sc4;
+        a2p[j] = a.A2 ? a.A2 + (m % a.a2_rows) * a.lda2 + sc4 : nullptr;
+        int n = n0 + srow + 32 * j;
+        if (n >= a.N) n = a.N - 1;
+        wp[j] = a.W + (long)n * a.ldw + sc4;
+    }
+    float4 ra[4], rw[4];
+    auto gload = [&](int k0) {
+        const bool in = k0 + sc4 < a.K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 v = zero4(), u = zero4();
+            if (in) {
+                v = ld4(ap[j] + k0);
+                if (a.A2) { const float4 t = ld4(a2p[j] + k0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                u = ld4(wp[j] + k0);
+            }
+            ra[j] = v; rw[j] = u;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(float4*)&As[buf][(srow + 32 * j) * SG_PITCH + sc4] = ra[j];
+            *(float4*)&Ws[buf][(srow + 32 * j) * SG_PITCH + sc4] = rw[j];
+        }
+    };
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = w >> 1, wn = w & 1, li = lane & 31, lh = lane >> 5;
+    const int nk = (a.K + 31) / 32;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload((kt + 1) * 32);
+        const float* pa = &As[kt & 1][(wm * 64 + li) * SG_PITCH + lh * 16];
+        const float* pw = &Ws[kt & 1][(wn * 64 + li) * SG_PITCH + lh * 16];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 a0 = ld4(pa + s4 * 4), a1 = ld4(pa + 32 * SG_PITCH + s4 * 4);
+            const float4 b0 = ld4(pw + s4 * 4), b1 = ld4(pw + 32 * SG_PITCH + s4 * 4);
+            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = mfma32f(av0[e], bv0[e], acc[0][0]);
+                acc[0][1] = mfma32f(av0[e], bv1[e], acc[0][1]);
+                acc[1][0] = mfma32f(av1[e], bv0[e], acc[1][0]);
+                acc[1][1] = mfma32f(av1[e], bv1[e], acc[1][1]);
+            }
+        }
+        if (kt + 1 < nk) sstore((kt + 1) & 1);
+        __syncthreads();
+    }
+    // D of the 32 x 32 tile: lane (col = l & 31, half = l >> 5), register r -> row (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + li;
+            if (n >= a.N) continue;
+            const float bs = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                float v = acc[i][j][r] + bs;
+                if (a.act == MSAM_ACT_GELU) v = gelu_exact(v);
+                else if (a.act == MSAM_ACT_RELU) v = fmaxf(v, 0.f);
+                if (a.res) v += a.res[(a.res_rows >= a.M ? m : m % a.res_rows) * a.ldr + n];
+                a.out[m * a.ldc + n] = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row (any dim <= 1280); two-pass statistics as torch.nn.LayerNorm / upstream LayerNorm2d
+__global__ __launch_bounds__(256) void sln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                  float eps, long rows, int dim, float* __restrict__ out, int gelu, int nchw_hw) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * dim;
+    float v[20];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < dim ? xr[c] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum64(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) { const int c = i * 64 + lane; const float d = c < dim ? v[i] - mean : 0.f; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        const int c = i * 64 + lane;
+        if (c < dim) {
+            float y = (v[i] - mean) * rstd * w[c] + b[c];
+            if (gelu) y = gelu_exact(y);
+            if (nchw_hw > 0) {
+                const long bimg = row / nchw_hw, t = row - bimg * nchw_hw;
+                out[(bimg * dim + c) * (long)nchw_hw + t] = y;
+            } else out[row * dim + c] = y;
+        }
+    }
+}
+// dim == 64 (LayerNorm2d of the up-scaling: 16.7 M rows per 1024 prompts): 16 lanes per row, float4 per lane
+__global__ __launch_bounds__(256) void sln64_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                    float eps, long rows, float* __restrict__ out, int gelu) {
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int c = (threadIdx.x & 15) * 4;
+    if (row >= rows) return;
+    const float4 t = ld4(x + row * 64 + c);
+    const float mean = wave_sum_xor16((t.x + t.y) + (t.z + t.w)) * (1.0f / 64.0f);
+    const float d0 = t.x - mean, d1 = t.y - mean, d2 = t.z - mean, d3 = t.w - mean;
+    const float var = wave_sum_xor16((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 64.0f);
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float4 ww = ld4(w + c), bb = ld4(b + c);
+    float y0 = d0 * rstd * ww.x + bb.x, y1 = d1 * rstd * ww.y + bb.y, y2 = d2 * rstd * ww.z + bb.z, y3 = d3 * rstd * ww.w + bb.w;
+    if (gelu) { y0 = gelu_exact(y0); y1 = gelu_exact(y1); y2 = gelu_exact(y2); y3 = gelu_exact(y3); }
+    *(float4*)(out + row * 64 + c) = make_float4(y0, y1, y2, y3);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ encoder attention
+// One thread per query, one workgroup per (image, window, head, block of 256 queries).  The query's two bias rows q . R_h[qh - kh],
+// q . R_w[qw - kw] (UNSCALED query, upstream add_decomposed_rel_pos) go to LDS once ([S][256] each, the thread's own column), keys and
+// values pass through LDS in chunks of 16 (read as broadcasts), softmax online with expf.  Tokens of a window that lie outside the
+// G x G grid are the zero padding the reference applies AFTER norm1: their q / k / v rows are the qkv bias.
+struct SRelArgs {
+    const float* qkv; const float* bqkv; const float* rel_h; const float* rel_w; float* out;
+    int B, heads, G, window, Dm; float scale;
+};
+constexpr int SR_KC = 16;
+
+template <int HD, int S>
+__global__ __launch_bounds__(256) void srelpos_kernel(SRelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sr_lds[];
+    float* const bh = sr_lds;                       // [S][256]
+    float* const bw = sr_lds + S * 256;             // [S][256]
+    float* const kv = sr_lds + 2 * S * 256;         // [2][KC][HD]
+    constexpr int S2 = S * S, QB = (S2 + 255) / 256;
+    const int tid = threadIdx.x;
+    const int nW = a.window ? (a.G + S - 1) / S : 1, nwin = nW * nW;
+    int bid = blockIdx.x;
+    const int qb = bid % QB; bid /= QB;
+    const int h = bid % a.heads; bid /= a.heads;
+    const int win = bid % nwin;
+    const int b = bid / nwin;
+    const int wy = win / nW, wx = win % nW;
+    const int T = a.G * a.G;
+    const long ld = 3L * a.Dm;
+    auto row_ptr = [&](int gi, int which) -> const float* {        // grid index inside the window -> the token's q / k / v slice
+        const int ty = wy * S + gi / S, tx = wx * S + gi % S;
+        if (ty >= a.G || tx >= a.G) return a.bqkv + (long)which * a.Dm + h * HD;
+        return a.qkv + ((long)b * T + ty * a.G + tx) * ld + (long)which * a.Dm + h * HD;
+    };
+    const int qi = qb * 256 + tid;
+    const bool valid = qi < S2;
+    const int qic = valid ? qi : S2 - 1;
+    const int qh = qic / S, qw = qic % S;
+    float q[HD], acc[HD];
+    {
+        const float* qp = row_ptr(qic, 0);
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) { const float4 t = ld4(qp + d); q[d] = t.x; q[d + 1] = t.y; q[d + 2] = t.z; q[d + 3] = t.w; }
+    }
+    for (int r = 0; r < S; ++r) {
+        const float* rh = a.rel_h + (long)(qh - r + S - 1) * HD;
+        const float* rw = a.rel_w + (long)(qw - r + S - 1) * HD;
+        float sh = 0.f, sw = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4 u = ld4(rh + d), v = ld4(rw + d);
+            sh = fmaf(q[d], u.x, sh); sh = fmaf(q[d + 1], u.y, sh); sh = fmaf(q[d + 2], u.z, sh); sh = fmaf(q[d + 3], u.w, sh);
+            sw = fmaf(q[d], v.x, sw); sw = fmaf(q[d + 1], v.y, sw); sw = fmaf(q[d + 2], v.z, sw); sw = fmaf(q[d + 3], v.w, sw);
+        }
+        bh[r * 256 + tid] = sh; bw[r * 256 + tid] = sw;
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] *= a.scale; acc[d] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    constexpr int V4 = HD / 4;
+    for (int j0 = 0; j0 < S2; j0 += SR_KC) {
+        __syncthreads();
+        for (int idx = tid; idx < 2 * SR_KC * V4; idx += 256) {
+            const int which = idx / (SR_KC * V4), rem = idx % (SR_KC * V4), kk = rem / V4, c4 = rem % V4;
+            const int j = j0 + kk;
+            float4 t = zero4();
+            if (j < S2) t = ld4(row_ptr(j, 1 + which) + c4 * 4);
+            *(float4*)&kv[(which * SR_KC + kk) * HD + c4 * 4] = t;
+        }
+        __syncthreads();
+        if (!valid) continue;
+        // eight keys per online-softmax step (the 16-key chunk in two steps: the fully unrolled 16-key form spilled registers)
+#pragma unroll 1
+        for (int k0 = 0; k0 < SR_KC; k0 += 8) {
+            float s[8];
+            float cm = -3.0e38f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int j = j0 + k0 + kk;
+                const float* kp = &kv[(k0 + kk) * HD];
+                float dot = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 t = ld4(kp + d);
+                    dot = fmaf(q[d], t.x, dot); dot = fmaf(q[d + 1], t.y, dot); dot = fmaf(q[d + 2], t.z, dot); dot = fmaf(q[d + 3], t.w, dot);
+                }
+                const int jc = j < S2 ? j : S2 - 1;
+                s[kk] = j < S2 ? (dot + bh[(jc / S) * 256 + tid]) + bw[(jc % S) * 256 + tid] : -3.0e38f;
+                cm = fmaxf(cm, s[kk]);
+            }
+            const float mn = fmaxf(m, cm), alpha = expf(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] *= alpha;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float p = j0 + k0 + kk < S2 ? expf(s[kk] - mn) : 0.f;
+                l += p;
+                const float* vp = &kv[(SR_KC + k0 + kk) * HD];
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    const float4 t = ld4(vp + d);
+                    acc[d] = fmaf(p, t.x, acc[d]); acc[d + 1] = fmaf(p, t.y, acc[d + 1]);
+                    acc[d + 2] = fmaf(p, t.z, acc[d + 2]); acc[d + 3] = fmaf(p, t.w, acc[d + 3]);
+                }
+            }
+            m = mn;
+        }
+    }
+    if (!valid) return;
+    const int ty = wy * S + qh, tx = wx * S + qw;
+    if (ty >= a.G || tx >= a.G) return;                              // padded query rows are dropped by window_unpartition
+    float* op = a.out + ((long)b * T + ty * a.G + tx) * a.Dm + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) *(float4*)(op + d) = make_float4(acc[d] / l, acc[d + 1] / l, acc[d + 2] / l, acc[d + 3] / l);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ decoder attention
+// q [B, Nq, H*D] (row stride ldq, batch stride sqb; 0 = shared by every batch entry), k / v [B, Nk, H*D], out [B, Nq, H*D] rows ldo.
+// scores = (q . k) / denom (upstream: attn / sqrt(c_per_head)), softmax, @ v.
+struct SAttnArgs {
+    const float* q; long ldq, sqb; const float* k; long ldk, skb; const float* v; long ldv, svb; float* out; long ldo, sob;
+    int B, H, Nq, Nk; float denom;
+};
+
+// Nk <= 16 (image -> token attention, self attention of the tokens): one thread per (batch, query, head)
+template <int D>
+__global__ __launch_bounds__(256) void sattn_short_kernel(SAttnArgs a) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)a.B * a.Nq * a.H;
+    if (gid >= total) return;
+    const int h = (int)(gid % a.H);
+    const long bi = gid / a.H;
+    const int i = (int)(bi % a.Nq);
+    const long b = bi / a.Nq;
+    const float* qp = a.q + b * a.sqb + (long)i * a.ldq + h * D;
+    float q[D];
+#pragma unroll
+    for (int d = 0; d < D; d += 4) { const float4 t = ld4(qp + d); q[d] = t.x; q[d + 1] = t.y; q[d + 2] = t.z; q[d + 3] = t.w; }
+    float s[16];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        s[j] = -3.0e38f;
+        if (j < a.Nk) {
+            const float* kp = a.k + b * a.skb + (long)j * a.ldk + h * D;
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 t = ld4(kp + d);
+                dot = fmaf(q[d], t.x, dot); dot = fmaf(q[d + 1], t.y, dot); dot = fmaf(q[d + 2], t.z, dot); dot = fmaf(q[d + 3], t.w, dot);
+            }
+            s[j] = dot / a.denom;
+            m = fmaxf(m, s[j]);
+        }
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s[j] = j < a.Nk ? expf(s[j] - m) : 0.f; l += s[j]; }
+    float o[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < a.Nk) {
+            const float p = s[j] / l;
+            const float* vp = a.v + b * a.svb + (long)j * a.ldv + h * D;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 t = ld4(vp + d);
+                o[d] = fmaf(p, t.x, o[d]); o[d + 1] = fmaf(p, t.y, o[d + 1]); o[d + 2] = fmaf(p, t.z, o[d + 2]); o[d + 3] = fmaf(p, t.w, o[d + 3]);
+            }
+        }
+    float* op = a.out + b * a.sob + (long)i * a.ldo + h * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) *(float4*)(op + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+}
+
+// Nq <= 16, long key side (token -> image attention over the 4096 image tokens): one workgroup per (batch, head); thread (t, slice) walks
+// the keys slice, slice + NS, ... for query t with an online softmax; the NS partial (m, l, acc) of a query are merged through LDS.
+template <int D, int NQP>
+__global__ __launch_bounds__(256) void sattn_long_kernel(SAttnArgs a) {
+    constexpr int NS = 256 / NQP;
+    __shared__ float red_m[256], red_l[256];
+    __shared__ __attribute__((aligned(16))) float red_o[256 * D];
+    const int tid = threadIdx.x, t = tid % NQP, sl = tid / NQP;
+    const int h = blockIdx.x % a.H;
+    const long b = blockIdx.x / a.H;
+    const bool act = t < a.Nq;
+    float q[D], o[D];
+    {
+        const float* qp = a.q + b * a.sqb + (long)(act ? t : 0) * a.ldq + h * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) { const float4 x = ld4(qp + d); q[d] = x.x; q[d + 1] = x.y; q[d + 2] = x.z; q[d + 3] = x.w; }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+    if (act)
+        for (int j = sl; j < a.Nk; j += NS) {
+            const float* kp = a.k + b * a.skb + (long)j * a.ldk + h * D;
+            const float* vp = a.v + b * a.svb + (long)j * a.ldv + h * D;
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 x = ld4(kp + d);
+                dot = fmaf(q[d], x.x, dot); dot = fmaf(q[d + 1], x.y, dot); dot = fmaf(q[d + 2], x.z, dot); dot = fmaf(q[d + 3], x.w, dot);
+            }
+            const float s = dot / a.denom;
+            const float mn = fmaxf(m, s), alpha = expf(m - mn), p = expf(s - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const float4 x = ld4(vp + d);
+                o[d] = fmaf(p, x.x, o[d] * alpha); o[d + 1] = fmaf(p, x.y, o[d + 1] * alpha);
+                o[d + 2] = fmaf(p, x.z, o[d + 2] * alpha); o[d + 3] = fmaf(p, x.w, o[d + 3] * alpha);
+            }
+            m = mn;
+        }
+    red_m[tid] = m; red_l[tid] = l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) red_o[tid * D + d] = o[d];
+    __syncthreads();
+    for (int idx = tid; idx < a.Nq * D; idx += 256) {
+        const int tt = idx / D, d = idx % D;
+        float M = -3.0e38f;
+        for (int s2 = 0; s2 < NS; ++s2) M = fmaxf(M, red_m[s2 * NQP + tt]);
+        float L = 0.f, O = 0.f;
+        for (int s2 = 0; s2 < NS; ++s2) {
+            const float wgt = expf(red_m[s2 * NQP + tt] - M);
+            L = fmaf(red_l[s2 * NQP + tt], wgt, L);
+            O = fmaf(red_o[(s2 * NQP + tt) * D + d], wgt, O);
+        }
+        a.out[b * a.sob + (long)tt * a.ldo + h * D + d] = O / L;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ gathers
+// fp32 [B,3,1024,1024] -> [B*4096, 768] (c, ky, kx);  uint8 HWC [B,h,w,3] -> the same with Sam.preprocess ((x - mean) / std, zero pad)
+__global__ __launch_bounds__(256) void spatchify_kernel(const float* __restrict__ img, const uint8_t* __restrict__ img8, int B, int h, int w,
+                                                        float* __restrict__ out) {
+    const float mean[3] = {123.675f, 116.28f, 103.53f};
+    const float stdv[3] = {58.395f, 57.12f, 57.375f};
+    const long total = (long)B * 4096 * 192;                  // 768 / 4 chunks per patch row
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % 192);
+        const long prow = i / 192;
+        const int b = (int)(prow / 4096), pidx = (int)(prow % 4096);
+        const int py = pidx >> 6, px = pidx & 63;
+        const int c = chunk >> 6, ky = (chunk >> 2) & 15, kx0 = (chunk & 3) * 4;
+        const int y = py * 16 + ky, x0 = px * 16 + kx0;
+        float4 v;
+        if (img) v = ld4(img + (((long)b * 3 + c) * 1024 + y) * 1024 + x0);
+        else {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j;
+                t[j] = (y < h && x < w) ? __fdiv_rn((float)img8[(((long)b * h + y) * w + x) * 3 + c] - mean[c], stdv[c]) : 0.f;
+            }
+            v = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        *(float4*)(out + prow * 768 + chunk * 4) = v;
+    }
+}
+// x fp32 [B,64,64,C] -> [B*4096, 9*C], column (ky*3+kx)*C + c, zero padding 1
+__global__ __launch_bounds__(256) void sim2col_kernel(const float* __restrict__ x, int B, int C, float* __restrict__ out) {
+    const int cpr = 9 * C / 4;
+    const long total = (long)B * 4096 * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int chunk = (int)(i % cpr);
+        const long row = i / cpr;
+        const int b = (int)(row / 4096), t = (int)(row % 4096);
+        const int ty = t >> 6, tx = t & 63;
+        const int tap = (chunk * 4) / C, c0 = chunk * 4 - tap * C;
+        const int yy = ty + tap / 3 - 1, xx = tx + tap % 3 - 1;
+        float4 val = zero4();
+        if (yy >= 0 && yy < 64 && xx >= 0 && xx < 64) val = ld4(x + (((long)b * 64 + yy) * 64 + xx) * C + c0);
+        *(float4*)(out + row * (9L * C) + chunk * 4) = val;
+    }
+}
+// src[p][t][c] = emb[c][t] + dense[p][c][t]  (dense_stride 0: the broadcast no_mask_embed vector dense[c])
+__global__ __launch_bounds__(256) void ssrc_kernel(const float* __restrict__ emb, const float* __restrict__ dense, long dense_stride,
+                                                   float* __restrict__ src) {
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = (blockIdx.y & 7) * 32, p = blockIdx.y >> 3;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const long o = (long)(c0 + i) * 4096 + t0 + tx;
+        tile[i][tx] = emb[o] + (dense_stride ? dense[(long)p * dense_stride + o] : dense[c0 + i]);
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) src[((long)p * 4096 + t0 + i) * 256 + c0 + tx] = tile[tx][i];
+}
+// up [P*4096*4, 128]: row (p, token, s1 = ky*2+kx), column s2*32 + c2 (the two 2 x 2 stride-2 transposed convolutions as per-pixel linear
+// maps); low[p][m][4 ty + 2 ky + ky2][4 tx + 2 kx + kx2] = sum_c hyper[p][mask0 + m][c] * up[...][s2*32 + c]
+__global__ __launch_bounds__(256) void shyper_kernel(const float* __restrict__ up, const float* __restrict__ hyper, int hyper_ld, int mask0,
+                                                     int nmask, long P, float* __restrict__ low) {
+    __shared__ float hs[4 * 32];
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long p = gid >> 16;                                       // 65536 pixels per prompt: a block never straddles two prompts
+    if (threadIdx.x < nmask * 32) hs[threadIdx.x] = hyper[(p * 4 + mask0 + threadIdx.x / 32) * hyper_ld + (threadIdx.x & 31)];
+    __syncthreads();
+    if (p >= P) return;
+    const int s2 = (int)(gid & 3), s1 = (int)((gid >> 2) & 3), tok = (int)((gid >> 4) & 4095);
+    const float* u = up + gid * 32;
+    float x[32];
+#pragma unroll
+    for (int c = 0; c < 32; c += 4) { const float4 t = ld4(u + c); x[c] = t.x; x[c + 1] = t.y; x[c + 2] = t.z; x[c + 3] = t.w; }
+    const int y = 4 * (tok >> 6) + 2 * (s1 >> 1) + (s2 >> 1), xx = 4 * (tok & 63) + 2 * (s1 & 1) + (s2 & 1);
+    for (int mk = 0; mk < nmask; ++mk) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc = fmaf(hs[mk * 32 + c], x[c], acc);
+        low[((p * nmask + mk) * 256 + y) * 256 + xx] = acc;
+    }
+}
+
+int grid1d(long n, int per_block) {
+    const long g = (n + per_block - 1) / per_block;
+    return (int)(g < 1 ? 1 : (g > 0x7fffffffL ? 0x7fffffffL : g));
+}
+
+}  // namespace
+
+extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
+    if (!p || !p->A || !p->W || !p->out || p->M <= 0 || p->N <= 0 || p->K <= 0) { msam_set_error("msam_strict_gemm: null argument or empty shape"); return 1; }
+    if (p->K % 4 || p->lda % 4 || p->ldw % 4 || ((uintptr_t)p->A | (uintptr_t)p->W) % 16 || (p->A2 && (p->lda2 % 4 || (uintptr_t)p->A2 % 16))) {
+        msam_set_error("msam_strict_gemm: K, lda, ldw (, lda2) must be multiples of 4 and the operands 16-byte aligned");
+        return 1;
+    }
+    if (p->act != MSAM_ACT_NONE && p->act != MSAM_ACT_GELU && p->act != MSAM_ACT_RELU) { msam_set_error("msam_strict_gemm: unknown activation"); return 1; }
+    SGemmArgs a{};
+    a.A = p->A; a.lda = p->lda; a.A2 = p->A2; a.lda2 = p->lda2; a.a2_rows = p->a2_rows > 0 ? p->a2_rows : p->M;
+    a.W = p->W; a.ldw = p->ldw; a.M = p->M; a.N = p->N; a.K = p->K; a.bias = p->bias; a.act = p->act;
+    a.res = p->res; a.ldr = p->ldr; a.res_rows = p->res_rows > 0 ? p->res_rows : p->M; a.out = p->out; a.ldc = p->ldc;
+    const long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
+    if (blocks > 0x7fffffffL) { msam_set_error("msam_strict_gemm: too many tiles for one launch"); return 1; }
+    hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return msam_check_launch("strict_gemm");
+}
+
+extern "C" int msam_strict_layernorm(const float* x, const float* weight, const float* bias, float eps, int64_t rows, int32_t dim,
+                                     float* out, int32_t gelu, int32_t out_nchw_hw, void* stream) {
+    if (!x || !weight || !bias || !out || rows <= 0 || dim <= 0 || dim > 1280) { msam_set_error("msam_strict_layernorm: null argument or dim > 1280"); return 1; }
+    if (dim == 64 && out_nchw_hw <= 0 && ((uintptr_t)x | (uintptr_t)out | (uintptr_t)weight | (uintptr_t)bias) % 16 == 0)
+        hipLaunchKernelGGL(sln64_kernel, dim3(grid1d(rows, 16)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, eps, (long)rows, out, gelu);
+    else
+        hipLaunchKernelGGL(sln_kernel, dim3(grid1d(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, eps, (long)rows, dim, out, gelu,
+                           out_nchw_hw);
+    return msam_check_launch("strict_layernorm");
+}
+
+extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B,
+                                            int32_t heads, int32_t head_dim, int32_t grid, int32_t window, float scale, float* out,
+                                            void* stream) {
+    if (!qkv || !qkv_bias || !rel_h || !rel_w || !out || B <= 0 || heads <= 0) { msam_set_error("msam_strict_relpos_attention: null argument"); return 1; }
+    if ((head_dim != 64 && head_dim != 80) || (window != 0 && window != 14) || (window == 0 && grid != 64) || grid < 1 || grid > 64) {
+        msam_set_error("msam_strict_relpos_attention: head_dim 64 / 80; window 14 (any grid <= 64) or 0 = global on the 64 x 64 grid");
+        return 1;
+    }
+    SRelArgs a{qkv, qkv_bias, rel_h, rel_w, out, B, heads, grid, window, heads * head_dim, scale};
+    const int S = window ? 14 : 64;
+    const int nW = window ? (grid + S - 1) / S : 1, QB = (S * S + 255) / 256;
+    const long blocks = (long)B * nW * nW * heads * QB;
+    const size_t lds = (size_t)(2 * S * 256 + 2 * SR_KC * head_dim) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define MSAM_SREL(HD_, S_)                                                                                                            \
+    do {                                                                                                                              \
+        (void)hipFuncSetAttribute((const void*)srelpos_kernel<HD_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL((srelpos_kernel<HD_, S_>), dim3((unsigned)blocks), dim3(256), lds, s, a);                                 \
+    } while (0)
+    if (head_dim == 64) { if (window) MSAM_SREL(64, 14); else MSAM_SREL(64, 64); }
+    else { if (window) MSAM_SREL(80, 14); else MSAM_SREL(80, 64); }
+#undef MSAM_SREL
+    return msam_check_launch("strict_relpos_attention");
+}
+
+extern "C" int msam_strict_attention(const float* q, int64_t ldq, int64_t q_batch_stride, const float* k, int64_t ldk, int64_t k_batch_stride,
+                                     const float* v, int64_t ldv, int64_t v_batch_stride, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                                     int32_t D, float denom, float* out, int64_t ldo, int64_t out_batch_stride, void* stream) {
+    if (!q || !k || !v || !out || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) { msam_set_error("msam_strict_attention: null argument or empty shape"); return 1; }
+    if ((D != 16 && D != 32) || (Nq > 16 && Nk > 16) || ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 ||
+        q_batch_stride % 4 || k_batch_stride % 4 || v_batch_stride % 4 || out_batch_stride % 4 ||
+        ((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16) {
+        msam_set_error("msam_strict_attention: head dim 16 or 32, one side <= 16 tokens, strides in multiples of 4 floats, 16-byte aligned");
+        return 1;
+    }
+    SAttnArgs a{q, ldq, q_batch_stride, k, ldk, k_batch_stride, v, ldv, v_batch_stride, out, ldo, out_batch_stride, B, H, Nq, Nk, denom};
+    hipStream_t s = (hipStream_t)stream;
+    if (Nk <= 16) {
+        const int g = grid1d((long)B * Nq * H, 256);
+        if (D == 16) hipLaunchKernelGGL(sattn_short_kernel<16>, dim3(g), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(sattn_short_kernel<32>, dim3(g), dim3(256), 0, s, a);
+    } else {
+        const dim3 g((unsigned)((long)B * H));
+        if (D == 16) { if (Nq <= 8) hipLaunchKernelGGL((sattn_long_kernel<16, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((sattn_long_kernel<16, 16>), g, dim3(256), 0, s, a); }
+        else { if (Nq <= 8) hipLaunchKernelGGL((sattn_long_kernel<32, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((sattn_long_kernel<32, 16>), g, dim3(256), 0, s, a); }
+    }
+    return msam_check_launch("strict_attention");
+}
+
+extern "C" int msam_strict_patchify(const float* img, const uint8_t* img_u8, int32_t B, int32_t h, int32_t w, float* out, void* stream) {
+    if ((!img && !img_u8) || !out || B <= 0 || (img_u8 && (h <= 0 || w <= 0 || h > 1024 || w > 1024))) {
+        msam_set_error("msam_strict_patchify: one of img / img_u8, 0 < h, w <= 1024");
+        return 1;
+    }
+    hipLaunchKernelGGL(spatchify_kernel, dim3(grid1d((long)B * 4096 * 192, 256 * 4)), dim3(256), 0, (hipStream_t)stream, img, img_u8, B, h, w, out);
+    return msam_check_launch("strict_patchify");
+}
+
+extern "C" int msam_strict_im2col3x3(const float* x, int32_t B, int32_t C, float* out, void* stream) {
+    if (!x || !out || B <= 0 || C <= 0 || C % 4) { msam_set_error("msam_strict_im2col3x3: null argument or C % 4 != 0"); return 1; }
+    hipLaunchKernelGGL(sim2col_kernel, dim3(grid1d((long)B * 4096 * (9 * C / 4), 256 * 4)), dim3(256), 0, (hipStream_t)stream, x, B, C, out);
+    return msam_check_launch("strict_im2col3x3");
+}
+
+extern "C" int msam_strict_source(const float* embedding, const float* dense, int64_t dense_stride, int32_t P, float* src, void* stream) {
+    if (!embedding || !dense || !src || P <= 0 || P > 8191) { msam_set_error("msam_strict_source: null argument or more than 8191 prompts per call"); return 1; }
+    hipLaunchKernelGGL(ssrc_kernel, dim3(4096 / 32, (256 / 32) * P), dim3(256), 0, (hipStream_t)stream, embedding, dense, (long)dense_stride, src);
+    return msam_check_launch("strict_source");
+}
+
+extern "C" int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, int64_t P,
+                                       float* low_res, void* stream) {
+    if (!up || !hyper || !low_res || P <= 0 || nmask < 1 || mask0 < 0 || mask0 + nmask > 4 || hyper_ld < 32) {
+        msam_set_error("msam_strict_hyper_masks: 1 <= nmask masks out of 4, hyper_ld >= 32");
+        return 1;
+    }
+    hipLaunchKernelGGL(shyper_kernel, dim3((unsigned)(P * 256)), dim3(256), 0, (hipStream_t)stream, up, hyper, hyper_ld, mask0, nmask, (long)P, low_res);
+    return msam_check_launch("strict_hyper_masks");
+}

@@ -165,9 +165,10 @@ class ImageEncoderViT(nn.Module):
         LayerNorm outputs, q / k / v, softmax probabilities and GELU outputs: inside fp16's range; the residual stream stays
         fp32); "fp8": the four large projections of every block take OCP e4m3 operands on the MX-scaled MFMA (per-token
         activation scales, per-output-channel weight scales; fp32 accumulation, scales applied in the GEMM epilogue);
-        attention, patch embedding and neck stay bf16."""
-        if precision not in ("bf16", "fp16", "fp8"):
-            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16', 'fp16' or 'fp8'")
+        attention, patch embedding and neck stay bf16; "fp32": the strict mode (micro_sam_amd/strict.py) - the reference's formulation
+        on fp32 kernels (f32-input MFMA products, erf GELU, expf softmax), ~1/16 of the MFMA rate, results to fp32 rounding."""
+        if precision not in ("bf16", "fp16", "fp8", "fp32"):
+            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16', 'fp16', 'fp8' or 'fp32'")
         if precision != self.precision:
             self.precision = precision
             self.invalidate()
@@ -267,9 +268,19 @@ class ImageEncoderViT(nn.Module):
             self._workspace = torch.empty(need, dtype=torch.uint8, device=self.pos_embed.device)
         return self._workspace
 
+    def _strict(self):
+        if getattr(self, "_strict_enc", None) is None:
+            from .strict import StrictEncoder
+            self._strict_enc = StrictEncoder(self)
+        return self._strict_enc
+
     @torch.no_grad()
     def forward(self, x: torch.Tensor, tap_block: Optional[int] = None):
         assert x.dim() == 4 and x.shape[1:] == (3, IMG_SIZE, IMG_SIZE), x.shape
+        if self.precision == "fp32":
+            if tap_block is not None:
+                raise NotImplementedError("micro_sam_amd: tap_block is a test hook of the 16-bit encoder")
+            return self._strict().forward(x=x)
         params, _ = self._prepare()
         x = x.to(device=self.pos_embed.device, dtype=torch.float32).contiguous()
         B = x.shape[0]
@@ -287,6 +298,8 @@ class ImageEncoderViT(nn.Module):
     def forward_u8(self, images: torch.Tensor) -> torch.Tensor:
         """uint8 HWC batch [B,h,w,3] (after ``ResizeLongestSide.apply_image``): ``Sam.preprocess`` fused on device."""
         assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] == 3, images.shape
+        if self.precision == "fp32":
+            return self._strict().forward(images_u8=images)
         params, _ = self._prepare()
         images = images.to(self.pos_embed.device).contiguous()
         B, h, w = images.shape[:3]
@@ -434,6 +447,7 @@ class Sam(nn.Module):
         # the two products of the token MLP on hi + lo operand pairs (round 4: the ReLU hidden is the decoder's most rounding-sensitive
         # tensor; 0.2 % of the decoder's flops); set_split_token_mlp(False) = the plain 16-bit operands of rounds 1 - 3
         self.split_token_mlp = True
+        self.precision = "default"          # set_precision("strict"): the fp32 formulation (micro_sam_amd/strict.py)
         # type of the low-res logits between the decoder's up-scaling kernel and the fused post-processing on the AMG path
         # (predict_masks_device): torch.float32 (default), or torch.float16 = half the 1.6 GB round trip per tile for ~2 % more tiles/s -
         # NOT the default: the bilinear up-sampling interpolates between neighbours of the full logit magnitude, so fp16's 2^-11
@@ -459,6 +473,31 @@ class Sam(nn.Module):
         self._img_state = None
         self._watch.reset()
         self.image_encoder.invalidate()
+
+    def set_precision(self, mode: str) -> None:
+        """"default": the 16-bit throughput path (bf16 image encoder, fp16 folded / chained mask decoder; DESIGN.md sections 3, 4).
+        "strict": the reference's formulation on fp32 kernels for the image encoder, the prompt encoder and the mask decoder
+        (micro_sam_amd/strict.py): results equal to the reference CPU path up to fp32 rounding, at ~1/30 of the default throughput.
+        The integer post-processing is the same (bit-exact) code in both modes."""
+        if mode not in ("default", "strict"):
+            raise ValueError(f"Invalid precision mode {mode!r}: expect 'default' or 'strict'")
+        if mode == getattr(self, "precision", "default"):
+            return
+        self.precision = mode
+        if hasattr(self.image_encoder, "set_precision"):                 # (vit_t: TinyViT runs fp32 torch operators in both modes)
+            self.image_encoder.set_precision("fp32" if mode == "strict" else "bf16")
+        self._img_state = None
+
+    def _strict_decoder(self):
+        if getattr(self, "_strict_dec", None) is None:
+            from .strict import StrictDecoder
+            self._strict_dec = StrictDecoder(self)
+        return self._strict_dec
+
+    def _decode_strict(self, features, sparse, dense, multimask_output: bool):
+        _, _, consts = self._prepare_decoder()
+        pos = consts[: GRID * GRID * PROMPT_DIM * 4].view(torch.float32).reshape(GRID * GRID, PROMPT_DIM)
+        return self._strict_decoder().decode(features, sparse, dense, pos, multimask_output)
 
     def set_split_token_mlp(self, on: bool) -> None:
         if bool(on) != bool(self.split_token_mlp):
@@ -633,6 +672,7 @@ class Sam(nn.Module):
         sparse = torch.empty((B, Ns, PROMPT_DIM), dtype=torch.float32, device=dev)
         dense = torch.empty((B, PROMPT_DIM, GRID, GRID), dtype=torch.float32, device=dev) if msk is not None else None
         if Ns > 0 or msk is not None:
+            self._mask_params.exact_gelu = 1 if self.precision == "strict" else 0       # (read by this call only)
             _lib.check(_lib.load().msam_prompt_encode(
                 C.byref(p), C.byref(self._mask_params), _lib.ptr(pts), _lib.ptr(lbl), Np, _lib.ptr(bx), _lib.ptr(msk), B,
                 _lib.ptr(sparse) if Ns > 0 else None, _lib.ptr(dense), _lib.stream_ptr()), "msam_prompt_encode")
@@ -648,6 +688,13 @@ class Sam(nn.Module):
                                       f"(got {tuple(image_embeddings.shape)})")
         p, _, consts = self._prepare_decoder()
         dev = self.device
+        if self.precision == "strict":
+            nm = self.prompt_encoder.no_mask_embed.weight.detach().to(dev).reshape(1, -1, 1, 1)
+            dn = dense.to(device=dev, dtype=torch.float32)
+            no_mask = (dn.stride(-1) == 0 and dn.stride(-2) == 0 and torch.equal(dn[:, :, :1, :1], nm.expand(dn.shape[0], -1, 1, 1))) \
+                or bool(torch.equal(dn, nm.expand_as(dn)))
+            return self._decode_strict(image_embeddings, sparse.to(device=dev, dtype=torch.float32), None if no_mask else dn,
+                                       multimask_output)
         own_pe = self._dense_pe()
         if image_pe is not None and (tuple(image_pe.shape) != tuple(own_pe.shape) or
                                      not torch.allclose(image_pe.to(device=dev, dtype=torch.float32), own_pe, atol=1e-5)):
@@ -695,6 +742,14 @@ class Sam(nn.Module):
             raise ValueError("low_res_dtype is torch.float32 or torch.float16")
         if features.numel() != PROMPT_DIM * GRID * GRID:
             raise ValueError(f"expected one image embedding [1,256,64,64], got {tuple(features.shape)}")
+        if self.precision == "strict":
+            if point_coords is None and boxes is None and mask_input is None:
+                raise ValueError("micro_sam_amd: a prompt needs points, a box and / or a mask input")
+            pts = None if point_coords is None else (point_coords, point_labels)
+            msk = None if mask_input is None else mask_input.reshape(-1, 1, 4 * GRID, 4 * GRID)
+            sparse, dense = self._prompt_encode(pts, None if boxes is None else boxes.reshape(-1, 4), msk)
+            low, iou = self._decode_strict(features, sparse, dense if mask_input is not None else None, multimask_output)
+            return (low if low_res_dtype == torch.float32 else low.to(low_res_dtype)), iou
         prepared = self._prepare_decoder()
         p, _, consts = prepared
         state = self._image_state(features, prepared)

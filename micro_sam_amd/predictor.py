@@ -25,6 +25,11 @@ class SamPredictor:
     def device(self) -> torch.device:
         return self.model.device
 
+    def set_precision(self, mode: str) -> None:
+        """"default" (16-bit throughput path) or "strict" (the reference's formulation in fp32: ``Sam.set_precision``).  Embeddings
+        computed before the switch stay what they are: call ``set_image`` / ``precompute_image_embeddings`` again for strict ones."""
+        self.model.set_precision(mode)
+
     def reset_image(self) -> None:
         self.model._img_state = None            # prepared decoder state of the previous embedding
         self.is_image_set = False

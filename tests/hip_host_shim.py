@@ -208,6 +208,26 @@ static inline f32x16_t mfma32_emu(const uint4& a, const uint4& b, f32x16_t c, bo
     wave_sync();
     return d;
 }
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate): lane l holds A[row = l % 32][k = l / 32], B[k = l / 32][col = l % 32]; D as the 32x32x16
+// form.  The device result is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md section 3), which is what runs here.
+static inline f32x16_t __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16_t c, int, int, int) {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    wave_buf[w][l] = (long long)(((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a));
+    wave_sync();
+    f32x16_t d;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31;
+        float s = c[r];
+        for (int k = 0; k < 2; ++k) {
+            const float av = __uint_as_float((uint32_t)(unsigned long long)wave_buf[w][k * 32 + row]);
+            const float bv = __uint_as_float((uint32_t)((unsigned long long)wave_buf[w][k * 32 + col] >> 32));
+            s = std::fmaf(av, bv, s);
+        }
+        d[r] = s;
+    }
+    wave_sync();
+    return d;
+}
 // LDS-DMA (global_load_lds_dwordx4): lane l lands at the wave-uniform LDS base + 16 l; performed at once
 static inline void __builtin_amdgcn_global_load_lds(const void* g, void* l, int size, int, int) {
     std::memcpy((char*)l + (threadIdx.x & 63) * size, g, size);
@@ -564,6 +584,7 @@ FILE_PATCHES = {
                  ("typedef unsigned int u32x4_t_gw", "template <bool F16>\n__global__ __launch_bounds__(256, 2) void gemm2w_kernel", _GW)],
 }
 TEXT_PATCHES = {
+    "strict.hip": [("typedef float f32x16_t __attribute__((ext_vector_type(16)));", "")],
     "gemm.hip": [("#if defined(__HIP_DEVICE_COMPILE__)                  // (address-space-qualified struct copies do not parse in the host pass)", "#if 1"),
                  ("    typedef const __attribute__((address_space(4))) GroupItem* ItemPtr;\n    ItemPtr it = (ItemPtr)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.y;",
                   "    const GroupItem* it = &g.it[blockIdx.y];          // (the device reads its kernel-argument segment)"),("const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)dyn;", "const unsigned lds0 = 0; gw_lds_base = (char*)dyn;"),
