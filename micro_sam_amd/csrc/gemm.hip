@@ -1444,9 +1444,11 @@ extern "C" int msam_gemm_group_bf16(const msam_gemm_t* items, int32_t n, void* s
             return 1;
         }
         if ((p->out_mode == 0 && (!p->out || (p->ldc % 4))) || p->out_mode == 1 ||
-            (p->out_mode == 2 && (!p->k || !p->v || p->N != 256 || p->tokens % 128 || p->M % p->tokens)) ||
+            (p->out_mode == 2 && (!p->k || !p->v || p->N != 256 || p->tokens % 128 || p->M % p->tokens)) || p->out_mode > 3 || p->out_mode < 0 ||
+            (p->out_mode == 3 && (!p->out || p->ldc != 3L * p->N || p->N % 4 || p->out_dtype == MSAM_F32)) ||
             (p->table && ((p->table_cols % 4) || (p->table_ld % 4))) || (p->resid && (p->ldr % 4))) {
-            msam_set_error("msam_gemm_group_bf16: bad output / table / residual arguments (qkv-split output is not grouped)");
+            msam_set_error("msam_gemm_group_bf16: bad output / table / residual arguments (qkv-split output is not grouped; out_mode 3 needs a "
+                           "16-bit output with ldc == 3 N)");
             return 1;
         }
         GroupItem& it = g.it[i];

@@ -102,8 +102,9 @@ MSAM_DEVINL uint32_t gelu_pk_h(float x0, float x1) {
     return __builtin_bit_cast(uint32_t, g);
 }
 
-// The tile loop is software-pipelined INSIDE every wave (round 4; measured as tools/uf_lab.py "R_pipe_sdwa_dephase", bit-identical to the
-// stage-after-stage form of rounds 1 - 3 and 6 % shorter, profiles/r04_experiments.md section 1):
+// The tile loop is software-pipelined INSIDE every wave (round 4; measured as tools/uf_lab.py "R_pipe_sdwa_dephase": the pipelining and the
+// destination-select exponentials are bit-identical to the stage-after-stage form of rounds 1 - 3 and 6 % shorter, profiles/r04_experiments.md
+// section 1; the one-pass LayerNorm statistics shipped with them are NOT bit-identical to rounds 1 - 3 - see msam_tune_set "up_ln_two_pass"):
 //     phase A   8 x { B fragment of tile q + 1, 4 MFMAs into `un` }  interleaved with  { sums, centring, rstd, affine + GELU of tile q (`uc`) }
 //     phase B   stages 2 and 3 of tile q (a software pipeline over the four second-level sub-pixels)
 // so that every MFMA of phase A has independent VALU work of the same wave behind it.  The LayerNorm sums go through v_permlane16/32_swap

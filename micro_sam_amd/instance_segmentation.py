@@ -334,6 +334,19 @@ class AutomaticMaskGenerator(AMGBase):
         while len(pool) < n:
             pool.append((SamPredictor(self._predictor.model.lane_view()), torch.cuda.Stream(device=dev)))
         self._predictor._lane_pool = pool
+        # a lane view is a shallow snapshot of the Sam object: settings changed on the main model since (set_precision,
+        # set_split_token_mlp, use_glds, amg_low_res_dtype) are carried over here, and a view whose prepared decoder constants were
+        # built under other settings rebuilds them (lanes could decode with other settings than the serial path)
+        main = self._predictor.model
+        for lp, _ in pool[:n]:
+            lm, stale = lp.model, False
+            for k in ("precision", "split_token_mlp", "use_glds", "amg_low_res_dtype"):
+                if getattr(lm, k, None) != getattr(main, k, None):
+                    setattr(lm, k, getattr(main, k))
+                    stale = stale or k in ("split_token_mlp", "use_glds")
+            if stale:
+                lm._dec = None
+                lm._img_state = None
         lanes = getattr(self, "_lanes", None) or []
         if lanes and any(l[0]._predictor is not p for l, (p, _) in zip(lanes, pool)):
             lanes = []
@@ -546,13 +559,18 @@ def _process_tiled_embeddings(predictor, image, image_embeddings, tile_shape, ha
 
 class TiledAutomaticMaskGenerator(AutomaticMaskGenerator):
     """``AutomaticMaskGenerator`` on tiled embeddings (reference instance_segmentation.py:564-680): every tile (outer
-    block = tile + halo) is a crop box with its own precomputed embedding."""
+    block = tile + halo) is a crop box with its own precomputed embedding.
+
+    ``tile_lanes`` (not in the reference): the tiles of an image are decoded on this many concurrent lanes - lane views of the model on
+    their own HIP streams, each with its own decoder workspace (~3 GiB for 1024 prompts per pass); 1 = the reference's serial loop
+    with one workspace.  Same results either way."""
 
     def __init__(self, predictor: SamPredictor, points_per_side: Optional[int] = 32, points_per_batch: int = 64,
                  point_grids: Optional[List[np.ndarray]] = None, stability_score_offset: float = 1.0,
-                 device_chunk: int = 1024) -> None:
+                 device_chunk: int = 1024, tile_lanes: int = 3) -> None:
         super().__init__(predictor=predictor, points_per_side=points_per_side, points_per_batch=points_per_batch,
                          point_grids=point_grids, stability_score_offset=stability_score_offset, device_chunk=device_chunk)
+        self.tile_lanes = max(1, int(tile_lanes))
 
     @torch.no_grad()
     def initialize(self, image: np.ndarray, image_embeddings=None, i: Optional[int] = None,

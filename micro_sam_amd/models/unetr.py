@@ -262,6 +262,14 @@ def get_unetr(image_encoder: nn.Module, decoder_state: Optional["OrderedDict[str
         decoder_state = OrderedDict((k, v) for k, v in decoder_state.items() if not k.startswith("encoder"))
         try:
             widths = _widths_from_state(decoder_state)
+            if "out" in widths and widths["out"][1] != out_channels:
+                # the reference builds the UNETR with the REQUESTED number of output channels: a checkpoint with another head is a
+                # size mismatch - an error when loading strictly, a re-initialised out_conv (with the warning below) when
+                # flexible_load_checkpoint re-heads a pretrained decoder
+                if not flexible_load_checkpoint:
+                    raise RuntimeError(f"The parameters for 'out_conv.weight' could not be found or has a size mismatch "
+                                       f"({widths['out'][1]} output channels in the checkpoint, {out_channels} requested).")
+                widths["out"] = (widths["out"][0], out_channels)
         except RuntimeError:
             if not flexible_load_checkpoint:
                 raise

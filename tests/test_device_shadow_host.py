@@ -16,6 +16,11 @@ def test_shadow_is_used_only_for_the_unchanged_host_array():
     assert util._device_shadow(host.copy(), 1) is None       # another array with the same values: unknown
     host[2] *= 0.5                                           # the caller masks one slice: that slice falls back to the host data
     assert util._device_shadow(host, 2) is None and util._device_shadow(host, 0) is not None
+    # an edit that a strided sample cannot see - half of every channel of slice 1 zeroed, a single value of slice 0 changed
+    host[1, 0, :, 32:, :] = 0
+    assert util._device_shadow(host, 1) is None
+    host[0, 0, 200, 63, 63] += 1.0
+    assert util._device_shadow(host, 0) is None
     n = len(util._DEVICE_SHADOWS)
     del host
     gc.collect()

@@ -31,7 +31,7 @@ def test_parity_on_a_fine_tuned_checkpoint():
     dist = TP.weight_distance(sd, synthetic_state_dict("vit_b", 0, variant="cells"))
     assert all(v > 1e-4 for v in dist.values()), dist                     # every part of the model moved
     assert sum(losses[-10:]) < sum(losses[:10])                           # and it trained
-    rep, lab, extra = TP.compare(sd, tile_seed=1000, points_per_side=16, pred_iou_thresh=None, stability_score_thresh=0.8, ablations=True)
+    rep, lab, extra = TP.compare(sd, tile_seed=1000, points_per_side=16, pred_iou_thresh=None, stability_score_thresh=0.8, ablations=True, strict=True)
     pub = PT.public(rep)
     pub.pop("worst", None)
     print("\ntrained checkpoint (100 steps):", json.dumps({"weights_moved": dist, "iou": pub, "labels": lab, **extra}))
@@ -52,6 +52,11 @@ def test_parity_on_a_fine_tuned_checkpoint():
     ks = rep["keep_set"]
     assert ks["ref_only"] + ks["test_only"] <= 0.06 * rep["n_instances"], ks
     assert lab["foreground_agreement"] >= 0.99          # (0.9953 - 0.9999 over four runs: one kept mask more or less is its whole area)
+    # the strict precision mode on the same (trained) weights: the reference's result up to fp32 rounding
+    st = extra["strict"]
+    assert st["frac_ge_0.999"] >= 0.95 and st["min"] >= 0.99, st
+    assert st["keep_set"]["ref_only"] + st["keep_set"]["test_only"] <= 0.02 * st["n_instances"], st
+    assert st["embedding_max_abs_err"] <= 2e-3 and st["iou_pred_max_abs_diff"] <= 1e-4, st
     abl = extra["ablations"]
     # the hi + lo token MLP is what carries it: the plain-operand decoder of rounds 1 - 3 on the same weights
     assert abl["product_with_plain_token_mlp"]["frac_ge_0.999"] <= rep["frac_ge_0.999"] - 0.2, abl

@@ -1,0 +1,79 @@
+"""Timing of the strict precision mode on one GPU (DESIGN.md section 4 "cost"): the fp32 image encoder per tile, the fp32 decode of the
+32 x 32 prompt grid per tile, the whole tile (precompute + AutomaticMaskGenerator.initialize + generate) next to the default path, and the
+f32-input MFMA product's rate on the encoder's / decoder's shapes.  Prints one JSON line; `--out` also writes it."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--tiles", type=int, default=2)
+    a = ap.parse_args()
+    from micro_sam_amd import strict, util
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    sd = synthetic_state_dict("vit_b", 0, variant="cells")
+    predictor = util.get_sam_model("vit_b", device="cuda", state_dict=sd)
+    tiles = [synthetic_tile(1000 + i) for i in range(a.tiles)]
+    amg = AutomaticMaskGenerator(predictor, device_chunk=1024)
+    rec = {}
+
+    def whole_tile(tile):
+        emb = util.precompute_image_embeddings(predictor, tile, verbose=False)
+        amg.initialize(tile, emb)
+        return amg.generate()
+
+    for mode in ("default", "strict"):
+        predictor.set_precision(mode)
+        t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
+        t_enc = timed(lambda: [util.precompute_image_embeddings(predictor, t, verbose=False) for t in tiles]) / len(tiles)
+        rec[mode] = {"seconds_per_tile_api_loop": round(t_tile, 4), "tiles_per_s_api_loop": round(1.0 / t_tile, 2),
+                     "encoder_seconds_per_tile": round(t_enc, 4), "decode_and_generate_seconds_per_tile": round(t_tile - t_enc, 4)}
+    # the f32-input MFMA product on the path's shapes
+    dev = torch.device("cuda")
+    shapes = {"enc_qkv": (4096 * 4, 2304, 768), "enc_lin1": (4096 * 4, 3072, 768), "enc_lin2": (4096 * 4, 768, 3072),
+              "dec_t2i_kv": (128 * 4096, 128, 256), "dec_up1": (128 * 4096, 256, 256), "dec_up2": (128 * 16384, 128, 64),
+              "dec_i2t_out": (128 * 4096, 256, 128)}
+    g = {}
+    for name, (M, N, K) in shapes.items():
+        A = torch.randn(M, K, device=dev)
+        W = torch.randn(N, K, device=dev) / K ** 0.5
+        out = torch.empty(M, N, device=dev)
+        t = timed(lambda: strict.gemm(A, W, out=out), reps=5)
+        g[name] = {"M": M, "N": N, "K": K, "us": round(t * 1e6, 1), "tflops": round(2.0 * M * N * K / t / 1e12, 1),
+                   "gbytes_per_s": round((M * K + M * N) * 4 / t / 1e9, 0)}
+    rec["strict_gemm"] = g
+    rec["fp32_mfma_peak_tflops"] = 157.3
+    line = json.dumps(rec)
+    print(line)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as fh:
+            fh.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -51,7 +51,7 @@ def train_checkpoint(steps: int = 120, seed: int = 0, lr: float = 1e-5, n_object
 
 @torch.no_grad()
 def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda", threads: int = 32, pred_iou_thresh: float = 0.88,
-            stability_score_thresh: float = 0.95, ablations: bool = False):
+            stability_score_thresh: float = 0.95, ablations: bool = False, strict: bool = False):
     """HIP path vs fp32 CPU oracle on the same state_dict and tile: per-instance IoU report (oracle/parity.py) + label agreement.
     One crop layer, `points_per_side`^2 prompts.  ``ablations``: the same report for (B) the HIP decoder on the ORACLE's fp32 embedding
     (decoder arithmetic alone), (C) the oracle's fp32 decoder on the HIP embedding (encoder arithmetic alone), (D) the product with
@@ -103,9 +103,22 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
              "oracle_seconds": round(t_ref, 1),
              "embedding_mean_abs_err": float((torch.as_tensor(emb["features"]).float().cpu() - feats).abs().mean()),
              "embedding_mean_abs": float(feats.abs().mean())}
+    def short(r):
+        return {k: (round(r[k], 4) if isinstance(r[k], float) else r[k]) for k in ("n_instances", "frac_ge_0.999", "frac_ge_0.99", "min", "median", "keep_set")}
+    if strict:
+        # the strict precision mode (micro_sam_amd/strict.py: the reference's formulation on fp32 kernels) on the same weights and tile
+        predictor.set_precision("strict")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        emb_s = util.precompute_image_embeddings(predictor, tile, verbose=False)
+        rs_, labs_, sc_ = product_report(emb_s)
+        torch.cuda.synchronize()
+        extra["strict"] = dict(short(rs_), labels=labs_, seconds=round(time.perf_counter() - t0, 2),
+                               iou_pred_max_abs_diff=float(np.abs(rs["iou_pred"] - sc_["iou_pred"]).max()),
+                               embedding_mean_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().mean()),
+                               embedding_max_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().max()))
+        predictor.set_precision("default")
     if ablations:
-        def short(r):
-            return {k: (round(r[k], 4) if isinstance(r[k], float) else r[k]) for k in ("n_instances", "frac_ge_0.999", "frac_ge_0.99", "min", "median", "keep_set")}
         abl = {}
         rb, _, _ = product_report({"features": feats.numpy(), "input_size": isz[0], "original_size": osz[0]})
         abl["hip_decoder_on_fp32_embedding"] = short(rb)
@@ -148,6 +161,7 @@ def main():
     ap.add_argument("--points-per-side", type=int, default=16)
     ap.add_argument("--thresholds", type=float, nargs=2, default=(0.88, 0.95))
     ap.add_argument("--ablations", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="also report the strict (fp32) precision mode on the same weights")
     a = ap.parse_args()
     from micro_sam_amd.synthetic import synthetic_state_dict
     from oracle import parity as PT
@@ -156,7 +170,8 @@ def main():
         t0 = time.perf_counter()
         sd, losses = train_checkpoint(steps, a.seed, a.lr, log=lambda m: print(m, file=sys.stderr, flush=True)) if steps > 0 else (base, [])
         t_train = time.perf_counter() - t0
-        rep, lab, extra = compare(sd, a.tile, a.points_per_side, pred_iou_thresh=a.thresholds[0], stability_score_thresh=a.thresholds[1], ablations=a.ablations)
+        rep, lab, extra = compare(sd, a.tile, a.points_per_side, pred_iou_thresh=a.thresholds[0], stability_score_thresh=a.thresholds[1], ablations=a.ablations,
+                                  strict=a.strict)
         pub = PT.public(rep)
         pub.pop("worst", None)
         print(json.dumps({"steps": steps, "lr": a.lr, "train_seconds": round(t_train, 1),
