@@ -134,6 +134,31 @@ def mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs):
     return out
 
 
+def strict_leg(predictor, amg, tiles_np, ref_states, ref_segs, cpu_tiles_per_s):
+    """mask_iou_vs_ref in the strict precision mode + that mode's throughput through the literal API sequence (per tile
+    precompute_image_embeddings -> AutomaticMaskGenerator.initialize -> generate, host arrays in and out)."""
+    from micro_sam_amd import util
+    predictor.set_precision("strict")
+    rep = mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs)        # (also the warm-up of the strict kernels)
+
+    def whole(tile):
+        emb = util.precompute_image_embeddings(predictor, tile, verbose=False)
+        amg.initialize(tile, emb)
+        return amg.generate()
+    n = 6
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(n):
+        whole(tiles_np[k % len(tiles_np)])
+    torch.cuda.synchronize()
+    tps = n / (time.perf_counter() - t0)
+    rep["tiles_per_s"] = round(tps, 2)
+    rep["times_cpu_baseline"] = round(tps / cpu_tiles_per_s, 1) if cpu_tiles_per_s else None
+    rep["mode"] = ("predictor.set_precision('strict'): image encoder, prompt encoder and mask decoder in the reference's formulation on fp32 "
+                   "kernels (f32-input MFMA products, erf GELU, expf softmax); tiles_per_s = the literal per-tile API loop, one lane")
+    return rep
+
+
 def csrc_sha16():
     """sha256 (first 16 hex digits) of the kernel sources + the ABI header: names the code a PMC / rocprof table was measured on
     (tools/csrc_sha.py prints the same on the GPU box; tools/summarize_profiles.py stores it in profiles/<tag>_pmc_traffic.json)."""
@@ -252,6 +277,17 @@ def config_sides(timeout_s: float = 420.0):
                             ("metric", "value", "unit", "ms_per_step", "dtype"))
     sides["config3_side"] = run(["bench.py", "--workload", "config3", "--steps", "1", "--warmup", "1", "--slices", "4"],
                                 ("metric", "value", "unit", "ms_per_step", "dtype", "config"))
+    # parity on weights that are not hand-designed (tools/trained_parity.py: the "cells" checkpoint after 100 AdamW steps of this package's
+    # trainer), default and strict precision mode against the fp32 CPU oracle of the same run
+    tp = run([os.path.join("tools", "trained_parity.py"), "--steps", "100", "--strict", "--quartile", "--stability-thresh", "0.8"],
+             ("steps", "train_seconds", "weight_distance_from_designed", "iou", "labels", "strict", "pred_iou_thresh", "stability_score_thresh",
+              "embedding_mean_abs_err", "oracle_seconds"))
+    if "iou" in tp:
+        tp["default"] = {"iou": tp.pop("iou"), "labels": tp.pop("labels")}
+        tp["what"] = ("per-instance mask IoU vs the fp32 CPU oracle on a fine-tuned (non-designed) checkpoint, tile 1000, 16 x 16 prompts, "
+                      "thresholds = lower quartile of the reference's predicted IoUs / stability 0.8 (the fine-tuned masks are soft: the "
+                      "default thresholds keep nothing); 'default' = the 16-bit path, 'strict' = set_precision('strict')")
+    sides["mask_iou_vs_ref_trained"] = tp
     tb = os.path.join("tools", "train_bench.py")
     keep_t = ("metric", "value", "unit", "model", "ms_per_step", "config", "non_hip_device_time_frac", "kernel_launches_per_step")
     sides["train_side"] = {"vit_b": run([tb, "--model", "vit_b", "--steps", "5", "--warmup", "2", "--device-time"], keep_t),
@@ -746,6 +782,15 @@ def main():
             ref_tiles = tiles_np[:args.cpu_tiles]
             out["cpu_baseline"], ref_states, ref_segs = cpu_reference(sd, ref_tiles, n_thr)
             out["mask_iou_vs_ref"] = mask_iou_vs_ref(predictor, amg, ref_tiles, ref_states, ref_segs)
+            # the strict precision mode (predictor.set_precision("strict"): the reference's formulation on fp32 kernels, micro_sam_amd/strict.py)
+            # on the same tiles against the same reference: the point of the speed / parity curve that meets the north-star statement
+            try:
+                out["mask_iou_vs_ref_strict"] = strict_leg(predictor, amg, ref_tiles, ref_states, ref_segs, out["cpu_baseline"]["value"])
+            except Exception as exc:            # a side measurement must not cost the bench line
+                out["mask_iou_vs_ref_strict"] = {"error": repr(exc)}
+            finally:
+                predictor.set_precision("default")
+                predictor.model.image_encoder.set_precision(args.encoder_dtype)
             if args.encoder_dtype == "bf16":
                 # what the bf16 rounding of the encoder's operands costs: the same comparison with IEEE fp16 operands in the encoder
                 # (same kernels and MFMA rate; throughput of that mode: python bench.py --encoder-dtype fp16)

@@ -102,6 +102,33 @@ MSAM_DEVINL uint32_t gelu_pk_h(float x0, float x1) {
     return __builtin_bit_cast(uint32_t, g);
 }
 
+// Two GELU pairs per call (round 5; tools/uf_lab.py "R_exp_quad", measured -2.4 % on the launch and bit-identical on the device): the
+// four destination-select exponentials are interleaved (A.lo, B.lo, A.hi, B.hi), so the wait state a destination-select write needs before
+// its register is read again is filled by the other pair's instruction - one s_nop per two pairs instead of four (59 instead of 169 s_nop
+// per tile and wave, profiles/r04_experiments.md section 9).
+template <int EXPM>
+MSAM_DEVINL void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g01, uint32_t& g23) {
+    if constexpr (EXPM != 1) {                       // the other instantiations (timing / packed-exponential forms): pair by pair
+        g01 = gelu_pk_h<EXPM == 0 ? 1 : EXPM>(x0, x1); g23 = gelu_pk_h<EXPM == 0 ? 1 : EXPM>(x2, x3);
+        return;
+    }
+    const h16x2_t zero = {(_Float16)0.f, (_Float16)0.f};
+    const h16x2_t xa = __builtin_convertvector(f32x2_t{x0, x1}, h16x2_t), xb = __builtin_convertvector(f32x2_t{x2, x3}, h16x2_t);
+    const h16x2_t ra = __builtin_elementwise_max(xa, zero), rb = __builtin_elementwise_max(xb, zero);
+    const h16x2_t ta = ra * (_Float16)2.f - xa, tb = rb * (_Float16)2.f - xb;
+    h16x2_t qa = ta * (_Float16)-0.0248758f + (_Float16)-0.49884797f, qb = tb * (_Float16)-0.0248758f + (_Float16)-0.49884797f;
+    qa = qa * ta + (_Float16)-1.12922424f; qb = qb * tb + (_Float16)-1.12922424f;
+    qa = qa * ta + (_Float16)-1.00353579f; qb = qb * tb + (_Float16)-1.00353579f;
+    uint32_t ea_, eb_;
+    asm("v_exp_f16_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"
+        "v_exp_f16_sdwa %1, %3 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"
+        "v_exp_f16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "v_exp_f16_sdwa %1, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"
+        : "=&v"(ea_), "=&v"(eb_) : "v"(__builtin_bit_cast(uint32_t, qa)), "v"(__builtin_bit_cast(uint32_t, qb)));
+    g01 = __builtin_bit_cast(uint32_t, (h16x2_t)(ra - ta * __builtin_bit_cast(h16x2_t, ea_)));
+    g23 = __builtin_bit_cast(uint32_t, (h16x2_t)(rb - tb * __builtin_bit_cast(h16x2_t, eb_)));
+}
+
 // The tile loop is software-pipelined INSIDE every wave (round 4; measured as tools/uf_lab.py "R_pipe_sdwa_dephase": the pipelining and the
 // destination-select exponentials are bit-identical to the stage-after-stage form of rounds 1 - 3 and 6 % shorter, profiles/r04_experiments.md
 // section 1; the one-pass LayerNorm statistics shipped with them are NOT bit-identical to rounds 1 - 3 - see msam_tune_set "up_ln_two_pass"):
@@ -268,8 +295,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             if (rt == 0) UF_S1(3, rstd); else UF_S1(3 + rt, g1w[rt - 1][1]);
             const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
             if (G16) {
-                g1w[rt][0] = gelu_pk_h<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y);
-                g1w[rt][1] = gelu_pk_h<G16>(uc[rt][2] * rstd * g4.z + b4.z, uc[rt][3] * rstd * g4.w + b4.w);
+                gelu_pk_h2<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y, uc[rt][2] * rstd * g4.z + b4.z,
+                                uc[rt][3] * rstd * g4.w + b4.w, g1w[rt][0], g1w[rt][1]);
             } else {
                 const f32x2_t g01 = gelu_erf2(f32x2_t{uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y});
                 const f32x2_t g23 = gelu_erf2(f32x2_t{uc[rt][2] * rstd * g4.z + b4.z, uc[rt][3] * rstd * g4.w + b4.w});
@@ -299,8 +326,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         };
         auto act2 = [&](int s2) {
             if (G16) {
-                gh[s2] = make_uint4(gelu_pk_h<G16>(ya[s2][0], ya[s2][1]), gelu_pk_h<G16>(ya[s2][2], ya[s2][3]),
-                                    gelu_pk_h<G16>(yb[s2][0], yb[s2][1]), gelu_pk_h<G16>(yb[s2][2], yb[s2][3]));
+                gelu_pk_h2<G16>(ya[s2][0], ya[s2][1], ya[s2][2], ya[s2][3], gh[s2].x, gh[s2].y);
+                gelu_pk_h2<G16>(yb[s2][0], yb[s2][1], yb[s2][2], yb[s2][3], gh[s2].z, gh[s2].w);
                 return;
             }
             const f32x2_t a01 = gelu_erf2(f32x2_t{ya[s2][0], ya[s2][1]}), a23 = gelu_erf2(f32x2_t{ya[s2][2], ya[s2][3]});

@@ -231,3 +231,64 @@ def cache_is_state(predictor: SamPredictor, decoder, raw: np.ndarray, image_embe
         g.create_dataset("boundary_distances", data=state["boundary_distances"], compression="gzip")
         g.create_dataset("center_distances", data=state["center_distances"], compression="gzip")
     return amg
+
+
+def _precompute_state_for_file(predictor, input_path, output_path, key, ndim, tile_shape, halo, precompute_amg_state, decoder, verbose):
+    """Reference ``_precompute_state_for_file`` (precompute_state.py:158-192): embeddings of one image / volume into ``<output>.zarr``,
+    then - optionally - the AMG (or, with a decoder, the AIS) state next to them, per slice for volumes."""
+    from functools import partial
+    from pathlib import Path
+    image_data = input_path if isinstance(input_path, np.ndarray) else util.load_image_data(input_path, key)
+    output_path = str(Path(output_path).with_suffix(".zarr"))
+    embeddings = util.precompute_image_embeddings(predictor, image_data, output_path, ndim=ndim, tile_shape=tile_shape, halo=halo,
+                                                  verbose=verbose)
+    if not precompute_amg_state:
+        return
+    if decoder is None:
+        cache_function = partial(cache_amg_state, predictor=predictor, image_embeddings=embeddings, save_path=output_path)
+    else:
+        cache_function = partial(cache_is_state, predictor=predictor, decoder=decoder, image_embeddings=embeddings, save_path=output_path)
+    if ndim is None:
+        ndim = image_data.ndim
+    if ndim == 2:
+        cache_function(raw=image_data, verbose=verbose)
+    else:
+        _, pbar_init, pbar_update, pbar_close = util.handle_pbar(verbose, None, None)
+        pbar_init(image_data.shape[0], "Precompute instance segmentation state")
+        for i in range(image_data.shape[0]):
+            cache_function(raw=image_data, i=i, verbose=False)
+            pbar_update(1)
+        pbar_close()
+
+
+def _precompute_state_for_files(predictor, input_files, output_path, key=None, ndim=None, tile_shape=None, halo=None,
+                                precompute_amg_state: bool = False, decoder=None):
+    """Reference ``_precompute_state_for_files`` (:195-224): one ``.zarr`` per input, named after the file (arrays: ``embedding_%05d``)."""
+    os.makedirs(output_path, exist_ok=True)
+    for idx, file_path in enumerate(input_files):
+        name = f"embedding_{idx:05}.tif" if isinstance(file_path, np.ndarray) else os.path.basename(file_path)
+        _precompute_state_for_file(predictor, file_path, os.path.join(output_path, name), key=key, ndim=ndim, tile_shape=tile_shape,
+                                   halo=halo, precompute_amg_state=precompute_amg_state, decoder=decoder, verbose=False)
+
+
+def precompute_state(input_path, output_path, pattern: Optional[str] = None, model_type: str = util._DEFAULT_MODEL,
+                     checkpoint_path=None, key: Optional[str] = None, ndim: Optional[int] = None, tile_shape=None, halo=None,
+                     precompute_amg_state: bool = False, state_dict=None, device=None) -> None:
+    """Reference ``precompute_state`` (precompute_state.py:227-278): embeddings - and optionally the automatic-segmentation state - for
+    one image file / container dataset / in-memory array, or (``pattern``) for every matching file of a folder.  ``state_dict`` /
+    ``device`` (extensions): a model without a checkpoint file (there is no download here) and its device.  A checkpoint that carries a
+    ``decoder_state`` (the reference's ``*_lm`` / ``*_em`` models) gives the AIS state through ``models.unetr.get_decoder``."""
+    from glob import glob
+    predictor, state = util.get_sam_model(model_type=model_type, device=device, checkpoint_path=checkpoint_path, return_state=True,
+                                          state_dict=state_dict)
+    decoder = None
+    if isinstance(state, dict) and "decoder_state" in state:
+        from .models.unetr import get_decoder
+        decoder = get_decoder(predictor.model.image_encoder, state["decoder_state"], device=predictor.device)
+    if pattern is None:
+        _precompute_state_for_file(predictor, input_path, output_path, key, ndim=ndim, tile_shape=tile_shape, halo=halo,
+                                   precompute_amg_state=precompute_amg_state, decoder=decoder, verbose=True)
+    else:
+        input_files = sorted(glob(os.path.join(input_path, pattern)))
+        _precompute_state_for_files(predictor, input_files, output_path, key=key, ndim=ndim, tile_shape=tile_shape, halo=halo,
+                                    precompute_amg_state=precompute_amg_state, decoder=decoder)

@@ -585,6 +585,61 @@ def _device_shadow(host, i: Optional[int]) -> Optional[torch.Tensor]:
     return hit[4][:] if i is None else hit[4][i]
 
 
+def load_image_data(path: Union[str, os.PathLike], key: Optional[str] = None, lazy_loading: bool = False):
+    """Reference ``util.load_image_data`` (util.py:1334-1353): image data of a file, or of dataset / pattern ``key`` inside a container
+    or folder.  The reference reads through imageio and ``elf.io.open_file``; neither is vendored, so the readers here are the ones this
+    environment has, each optional: ``.npy`` / ``.npz`` (numpy), image files through imageio when importable, else Pillow (a multi-page
+    TIFF becomes a stack), zarr / n5-style directories through the package's own zarr reader (``lazy_loading`` keeps the array object),
+    hdf5 through h5py when importable, and a folder with a glob pattern as ``key`` = the sorted images stacked (elf's image-stack
+    wrapper).  Anything else raises with the reason."""
+    path = os.fspath(path)
+    ext = os.path.splitext(path)[1].lower()
+
+    def read_image(p):
+        if os.path.splitext(p)[1].lower() == ".npy":
+            return np.load(p)
+        try:
+            import imageio.v3 as iio
+            return np.asarray(iio.imread(p))
+        except ImportError:
+            pass
+        from PIL import Image
+        with Image.open(p) as im:
+            n = getattr(im, "n_frames", 1)
+            if n == 1:
+                return np.asarray(im)
+            frames = []
+            for k in range(n):
+                im.seek(k)
+                frames.append(np.asarray(im))
+            return np.stack(frames)
+    if key is None:
+        if os.path.isdir(path):
+            raise ValueError(f"load_image_data: {path} is a folder / container: a key (dataset name or glob pattern) is needed")
+        return read_image(path)
+    if os.path.isdir(path) and any(ch in key for ch in "*?["):
+        import glob as _glob
+        files = sorted(_glob.glob(os.path.join(path, key)))
+        if not files:
+            raise ValueError(f"load_image_data: no file matches {key!r} in {path}")
+        return np.stack([read_image(f) for f in files])
+    if ext == ".npz":
+        with np.load(path) as f:
+            return f[key]
+    if ext in (".h5", ".hdf5", ".hdf"):
+        try:
+            import h5py
+        except ImportError as exc:
+            raise RuntimeError("load_image_data: reading hdf5 needs h5py, which is not installed here") from exc
+        with h5py.File(path, "r") as f:
+            return f[key] if lazy_loading else f[key][:]
+    if os.path.isdir(path):                       # zarr (v2 / v3) directory store
+        from . import zarr_store
+        arr = zarr_store.open(path, mode="r")[key]
+        return arr if lazy_loading else arr[:]
+    raise ValueError(f"load_image_data: do not know how to read {key!r} from {path}")
+
+
 def _get_tiles_in_mask(mask, tiling, halo, z=None):
     """Reference util.py:748-762: ids of the tiles whose OUTER block contains mask foreground."""
     tiles = []

@@ -563,6 +563,9 @@ template <int EXPM> static inline uint32_t gelu_pk_h(float x0, float x1) {      
     }
     return pack2h(g[0], g[1]);
 }
+template <int EXPM> static inline void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g01, uint32_t& g23) {
+    g01 = gelu_pk_h<EXPM>(x0, x1); g23 = gelu_pk_h<EXPM>(x2, x3);           // (the device form interleaves the four exponentials: same values)
+}
 """
 _GW = """struct u32x4_t_gw { const char* base; long bytes; };
 static char* gw_lds_base = nullptr;

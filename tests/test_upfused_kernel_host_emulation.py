@@ -40,6 +40,10 @@ template <int EXPM> static inline uint32_t gelu_pk_h(float x0, float x1) {
     }
     return pack2h(g[0], g[1]);
 }
+// gelu_pk_h2 (round 5): two pairs per call - on the device their four exponentials are interleaved, the values are those of two calls
+template <int EXPM> static inline void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g01, uint32_t& g23) {
+    g01 = gelu_pk_h<EXPM>(x0, x1); g23 = gelu_pk_h<EXPM>(x2, x3);
+}
 """
 
 ENTRY = r"""

@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--thresholds", type=float, nargs=2, default=(0.88, 0.95))
     ap.add_argument("--ablations", action="store_true")
     ap.add_argument("--strict", action="store_true", help="also report the strict (fp32) precision mode on the same weights")
+    ap.add_argument("--quartile", action="store_true", help="predicted-IoU threshold = lower quartile of the reference's predictions (the test's choice)")
+    ap.add_argument("--stability-thresh", type=float, default=None)
     a = ap.parse_args()
     from micro_sam_amd.synthetic import synthetic_state_dict
     from oracle import parity as PT
@@ -170,8 +172,9 @@ def main():
         t0 = time.perf_counter()
         sd, losses = train_checkpoint(steps, a.seed, a.lr, log=lambda m: print(m, file=sys.stderr, flush=True)) if steps > 0 else (base, [])
         t_train = time.perf_counter() - t0
-        rep, lab, extra = compare(sd, a.tile, a.points_per_side, pred_iou_thresh=a.thresholds[0], stability_score_thresh=a.thresholds[1], ablations=a.ablations,
-                                  strict=a.strict)
+        rep, lab, extra = compare(sd, a.tile, a.points_per_side, pred_iou_thresh=None if a.quartile else a.thresholds[0],
+                                  stability_score_thresh=a.thresholds[1] if a.stability_thresh is None else a.stability_thresh,
+                                  ablations=a.ablations, strict=a.strict)
         pub = PT.public(rep)
         pub.pop("worst", None)
         print(json.dumps({"steps": steps, "lr": a.lr, "train_seconds": round(t_train, 1),

@@ -45,8 +45,7 @@ V = collections.OrderedDict()
 V["base"] = dict(kind="base", doc="the shipped source, unchanged", patches=[])
 V["R_no_dephase"] = dict(kind="exact", doc="no start offset for the second half of the grid", patches=[(_DEPHASE, "")])
 V["R_dephase_22"] = dict(kind="exact", doc="start offset ~1400 cycles instead of ~700", patches=[(_DEPHASE, _DEPHASE.replace("s_sleep(11)", "s_sleep(22)"))])
-V["R_exp_pair"] = dict(kind="exact", doc="round 3's exponential pair (plain + SDWA source select + v_pack_b32_f16) instead of the destination-select form",
-                       patches=[(_EXP_SDWA_START, _EXP_SDWA_END, _EXP_PAIR)])
+_R_EXP_PAIR_PATCH = (_EXP_SDWA_START, _EXP_SDWA_END, _EXP_PAIR)            # (used together with R_exp_by_pair below: the shipped kernel calls gelu_pk_h2)
 # parity candidate (profiles/r04_experiments.md section 3: the ConvT2 weights W2 are the largest remaining rounding site of the decoder on generic weights,
 # mean logit error 0.015 of 0.032): W2 as fp16 hi + lo pairs - a second LDS image (+16 KiB) and a second MFMA per (row tile, k-step) in stage 2 (+16 MFMAs per
 # tile and wave).  The lab (and tests/test_uf_lab_variants_host.py) hands `w2` over as [2][128][64]: hi image, lo image; the shipped kernel reads the first.
@@ -74,44 +73,19 @@ V["R_gelu32"] = dict(kind="close", host_checked=False, doc="both GELUs in packed
                      patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 0;")])
 V["R_gelu32_w2_split"] = dict(kind="close", host_checked=False, doc="R_gelu32 + R_w2_split",
                               patches=V["R_gelu32"]["patches"] + V["R_w2_split"]["patches"])
-# two GELU pairs per call with their four destination-select exponentials interleaved (A.lo, B.lo, A.hi, B.hi): the wait state a destination-select
-# write needs before its register is read again is filled by the other pair's instruction - one s_nop per two pairs instead of four (profiles/r04_experiments.md
-# section 9: 48 of the loop's 169 s_nop).  Same arithmetic: bit-identical to the base on the device (inline assembly: not exercised by the host build)
-_QUAD_ANCHOR = "// The tile loop is software-pipelined INSIDE every wave (round 4;"
-_QUAD_FN = '''template <int EXPM>
-MSAM_DEVINL void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g01, uint32_t& g23) {
-    if constexpr (EXPM != 1) {                       // the other instantiations (timing / packed-exponential forms): pair by pair
-        g01 = gelu_pk_h<EXPM == 0 ? 1 : EXPM>(x0, x1); g23 = gelu_pk_h<EXPM == 0 ? 1 : EXPM>(x2, x3);
-        return;
-    }
-    const h16x2_t zero = {(_Float16)0.f, (_Float16)0.f};
-    const h16x2_t xa = __builtin_convertvector(f32x2_t{x0, x1}, h16x2_t), xb = __builtin_convertvector(f32x2_t{x2, x3}, h16x2_t);
-    const h16x2_t ra = __builtin_elementwise_max(xa, zero), rb = __builtin_elementwise_max(xb, zero);
-    const h16x2_t ta = ra * (_Float16)2.f - xa, tb = rb * (_Float16)2.f - xb;
-    h16x2_t qa = ta * (_Float16)-0.0248758f + (_Float16)-0.49884797f, qb = tb * (_Float16)-0.0248758f + (_Float16)-0.49884797f;
-    qa = qa * ta + (_Float16)-1.12922424f; qb = qb * tb + (_Float16)-1.12922424f;
-    qa = qa * ta + (_Float16)-1.00353579f; qb = qb * tb + (_Float16)-1.00353579f;
-    uint32_t ea_, eb_;
-    asm("v_exp_f16_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\\n\\t"
-        "v_exp_f16_sdwa %1, %3 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\\n\\t"
-        "v_exp_f16_sdwa %0, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\\n\\t"
-        "v_exp_f16_sdwa %1, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\\n\\ts_nop 0"
-        : "=&v"(ea_), "=&v"(eb_) : "v"(__builtin_bit_cast(uint32_t, qa)), "v"(__builtin_bit_cast(uint32_t, qb)));
-    g01 = __builtin_bit_cast(uint32_t, (h16x2_t)(ra - ta * __builtin_bit_cast(h16x2_t, ea_)));
-    g23 = __builtin_bit_cast(uint32_t, (h16x2_t)(rb - tb * __builtin_bit_cast(h16x2_t, eb_)));
-}
-
-'''
-_QUAD_S1 = ("                g1w[rt][0] = gelu_pk_h<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y);\n"
-            "                g1w[rt][1] = gelu_pk_h<G16>(uc[rt][2] * rstd * g4.z + b4.z, uc[rt][3] * rstd * g4.w + b4.w);\n")
+# round 5: "R_exp_quad" (two GELU pairs per call, their four destination-select exponentials interleaved: one s_nop per two pairs instead of
+# four) IS the shipped form now (csrc/upfused.hip gelu_pk_h2).  Its reverse - pair by pair, round 4's shipped form - stays as the A/B:
 _QUAD_S1_NEW = ("                gelu_pk_h2<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y, uc[rt][2] * rstd * g4.z + b4.z,\n"
                 "                                uc[rt][3] * rstd * g4.w + b4.w, g1w[rt][0], g1w[rt][1]);\n")
-_QUAD_S2 = ("                gh[s2] = make_uint4(gelu_pk_h<G16>(ya[s2][0], ya[s2][1]), gelu_pk_h<G16>(ya[s2][2], ya[s2][3]),\n"
-            "                                    gelu_pk_h<G16>(yb[s2][0], yb[s2][1]), gelu_pk_h<G16>(yb[s2][2], yb[s2][3]));\n")
+_QUAD_S1 = ("                g1w[rt][0] = gelu_pk_h<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y);\n"
+            "                g1w[rt][1] = gelu_pk_h<G16>(uc[rt][2] * rstd * g4.z + b4.z, uc[rt][3] * rstd * g4.w + b4.w);\n")
 _QUAD_S2_NEW = ("                gelu_pk_h2<G16>(ya[s2][0], ya[s2][1], ya[s2][2], ya[s2][3], gh[s2].x, gh[s2].y);\n"
                 "                gelu_pk_h2<G16>(yb[s2][0], yb[s2][1], yb[s2][2], yb[s2][3], gh[s2].z, gh[s2].w);\n")
-V["R_exp_quad"] = dict(kind="exact", host_checked=False, doc="two GELU pairs per call, their four destination-select exponentials interleaved: one s_nop per two pairs instead of four",
-                       patches=[(_QUAD_ANCHOR, _QUAD_FN + _QUAD_ANCHOR), (_QUAD_S1, _QUAD_S1_NEW), (_QUAD_S2, _QUAD_S2_NEW)])
+_QUAD_S2 = ("                gh[s2] = make_uint4(gelu_pk_h<G16>(ya[s2][0], ya[s2][1]), gelu_pk_h<G16>(ya[s2][2], ya[s2][3]),\n"
+            "                                    gelu_pk_h<G16>(yb[s2][0], yb[s2][1]), gelu_pk_h<G16>(yb[s2][2], yb[s2][3]));\n")
+V["R_exp_pair"] = dict(kind="exact", doc="round 3's exponential pair (plain + SDWA source select + v_pack_b32_f16), pair by pair",
+                       patches=[_R_EXP_PAIR_PATCH, (_QUAD_S1_NEW, _QUAD_S1), (_QUAD_S2_NEW, _QUAD_S2)])
+V["R_exp_by_pair"] = dict(kind="exact", doc="round 4's shipped form: one GELU pair per call (two s_nop per pair)", patches=[(_QUAD_S1_NEW, _QUAD_S1), (_QUAD_S2_NEW, _QUAD_S2)])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conversion",
                       patches=[(_CVT, _CVT + "    if (EXPM >= 0) return __builtin_bit_cast(uint32_t, x);\n")])
