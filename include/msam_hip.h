@@ -33,6 +33,7 @@ extern "C" {
 #define MSAM_ACT_NONE 0
 #define MSAM_ACT_GELU 1
 #define MSAM_ACT_RELU 2
+#define MSAM_ACT_SIGMOID 3               /* msam_strict_gemm only */
 
 const char* msam_last_error(void);
 int msam_abi_version(void);
@@ -644,6 +645,13 @@ typedef struct {
     const float* bias; int32_t act;      /* MSAM_ACT_NONE / MSAM_ACT_GELU (exact erf form) / MSAM_ACT_RELU, applied before the residual */
     const float* res; int64_t ldr; int64_t res_rows;
     float* out; int64_t ldc;
+    /* the convolutional decoder of AIS (models/unetr_hip.py; reference micro_sam/instance_segmentation.py:710-733), channels-last fp32: */
+    const float* col_scale; const float* col_shift;    /* both or neither: v = (acc + bias) * scale[n] + shift[n] before the activation
+                                                        * (BatchNorm2d on its running statistics: scale = w / sqrt(var + eps), shift = b - mean * scale) */
+    int32_t conv_h, conv_w, conv_c;      /* conv_c > 0: A is [B, conv_h, conv_w, conv_c] and the product is the 3 x 3 / padding 1 convolution as an implicit
+                                          * GEMM (the loader gathers the taps): M == B conv_h conv_w, K == 9 conv_c, weight columns (ky, kx, c); lda / A2 unused */
+    int32_t shuffle_h, shuffle_w, shuffle_c;   /* shuffle_c > 0: ConvTranspose2d(kernel 2, stride 2) store - N == 4 shuffle_c columns (ky*2+kx)*shuffle_c + co of input
+                                                * pixel (b, y, x) (M == B shuffle_h shuffle_w) go to out[((b*2H + 2y+ky)*2W + 2x+kx) * ldc + co]; no residual */
 } msam_sgemm_t;
 int msam_strict_gemm(const msam_sgemm_t* p, void* stream);
 /* torch.nn.LayerNorm / LayerNorm2d rows: x fp32 [rows, dim <= 1280] -> out fp32 (may be x), optional exact GELU afterwards;
@@ -674,6 +682,16 @@ int msam_strict_source(const float* embedding, const float* dense, int64_t dense
  * second sub-pixel * 32 + channel), hyper fp32 [P, 4, hyper_ld] -> low_res fp32 [P, nmask, 256, 256] of masks mask0 .. mask0 + nmask - 1. */
 int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, int64_t P, float* low_res,
                             void* stream);
+/* torch.nn.InstanceNorm2d (no affine; torch_em ConvBlock2d) on channels-last data: x fp32 [B, HW, C] with pixel pitch ldx (>= C: a column
+ * slice of a wider buffer) -> out fp32 [B, HW, C] dense; C % 4 == 0, C <= 1024.  workspace: 2 B ceil(HW / 2048) C + 2 B C floats. */
+int msam_strict_instance_norm(const float* x, int64_t ldx, int32_t B, int64_t HW, int32_t C, float eps, float* out, float* workspace,
+                              int64_t workspace_floats, void* stream);
+/* torch.nn.functional.interpolate(mode="bilinear", align_corners=False) on channels-last fp32: the h x w window of in [B, pitch_h, pitch_w]
+ * pixels of pixel_pitch >= C floats each (the first C are read: a column slice of a wider buffer) -> out [B, H2, W2, C] dense, or NCHW
+ * [B, C, H2, W2] with out_nchw (UNETR.postprocess_masks: resize, crop the padding, resize; the x2 up-sampling of torch_em's Upsampler2d).
+ * scale_h / scale_w = the source step per output pixel (h / H2, or 1 / scale_factor). */
+int msam_strict_resize_bilinear(const float* in, int32_t B, int32_t h, int32_t w, int32_t pitch_h, int32_t pitch_w, int64_t pixel_pitch, int32_t C,
+                                int32_t H2, int32_t W2, float scale_h, float scale_w, int32_t out_nchw, float* out, void* stream);
 
 #ifdef __cplusplus
 }

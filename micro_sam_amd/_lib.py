@@ -16,7 +16,7 @@ from . import build as _build
 
 MSAM_MAX_BLOCKS = 32
 F32, BF16, FP8, F16, U8, U16 = 1, 2, 3, 4, 5, 6
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 PROFILE_FAMILIES = 8          # include/msam_hip.h MSAM_PROFILE_FAMILIES
@@ -98,7 +98,8 @@ class SGemmParams(C.Structure):
     """include/msam_hip.h msam_sgemm_t (the strict mode's fp32 product)."""
     _fields_ = [("A", _vp), ("lda", _i64), ("A2", _vp), ("lda2", _i64), ("a2_rows", _i64), ("W", _vp), ("ldw", _i64),
                 ("M", _i64), ("N", _i32), ("K", _i32), ("bias", _vp), ("act", _i32), ("res", _vp), ("ldr", _i64), ("res_rows", _i64),
-                ("out", _vp), ("ldc", _i64)]
+                ("out", _vp), ("ldc", _i64), ("col_scale", _vp), ("col_shift", _vp), ("conv_h", _i32), ("conv_w", _i32), ("conv_c", _i32),
+                ("shuffle_h", _i32), ("shuffle_w", _i32), ("shuffle_c", _i32)]
 
 
 class MaskPromptParams(C.Structure):
@@ -218,6 +219,8 @@ _PROTOS = {
     "msam_strict_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_strict_source": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "msam_strict_hyper_masks": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "msam_strict_instance_norm": (_i32, [_vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _i64, _vp]),
+    "msam_strict_resize_bilinear": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp]),
 }
 OPTIONAL = set()
 

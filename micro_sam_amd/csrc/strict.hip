@@ -41,8 +41,14 @@ struct SGemmArgs {
     const float* W; long ldw; long M; int N, K;
     const float* bias; int act; const float* res; long ldr; long res_rows;
     float* out; long ldc;
-};
+    const float* col_scale; const float* col_shift;      // v = v * scale[n] + shift[n] after the bias (BatchNorm2d on running statistics)
+    int conv_h, conv_w, conv_c;                          // CONV: A = [B, H, W, C] channels-last, K = 9 C, columns (ky, kx, c): 3 x 3 / pad 1
+    int shuf_h, shuf_w, shuf_c;                          // 2 x 2 / stride 2 transposed convolution: column (ky*2+kx)*shuf_c + co of input pixel
+};                                                       // (b, y, x) is stored at output pixel (b, 2y+ky, 2x+kx), channel co
 
+// CONV: the 3 x 3 gather is done by the tile loader (implicit GEMM): row m = pixel (b, y, x), k = (tap, c) -> x[b][y + tap/3 - 1][x + tap%3 - 1][c],
+// zero outside the image (the reference's padding=1) - no im2col matrix in HBM (4.8 GB for the 1024^2 x 128-channel head of the UNETR decoder).
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][128 * SG_PITCH];
     __shared__ __attribute__((aligned(16))) float Ws[2][128 * SG_PITCH];
@@ -54,12 +60,20 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
     const int n0 = tn * 128;
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
     const float* ap[4]; const float* a2p[4]; const float* wp[4];
+    int py[4], px[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         long m = m0 + srow + 32 * j;
         if (m >= a.M) m = a.M - 1;
-        ap[j] = a.A + m * a.lda + sc4;
-        a2p[j] = a.A2 ? a.A2 + (m % a.a2_rows) * a.lda2 + sc4 : nullptr;
+        if (CONV) {
+            const long pix = m % ((long)a.conv_h * a.conv_w);
+            py[j] = (int)(pix / a.conv_w); px[j] = (int)(pix % a.conv_w);
+            ap[j] = a.A + m * a.lda;                     // lda = pixel pitch (>= conv_c: the input may be a column slice of a wider buffer)
+        } else {
+            py[j] = px[j] = 0;
+            ap[j] = a.A + m * a.lda + sc4;
+        }
+        a2p[j] = (!CONV && a.A2) ? a.A2 + (m % a.a2_rows) * a.lda2 + sc4 : nullptr;
         int n = n0 + srow + 32 * j;
         if (n >= a.N) n = a.N - 1;
         wp[j] = a.W + (long)n * a.ldw + sc4;
@@ -67,12 +81,22 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
     float4 ra[4], rw[4];
     auto gload = [&](int k0) {
         const bool in = k0 + sc4 < a.K;
+        int dy = 0, dx = 0, coff = 0;
+        if (CONV && in) {
+            const int k = k0 + sc4, tap = k / a.conv_c;
+            dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1;
+            coff = (dy * a.conv_w + dx) * (int)a.lda + (k - tap * a.conv_c);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 v = zero4(), u = zero4();
             if (in) {
-                v = ld4(ap[j] + k0);
-                if (a.A2) { const float4 t = ld4(a2p[j] + k0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                if (CONV) {
+                    if ((unsigned)(py[j] + dy) < (unsigned)a.conv_h && (unsigned)(px[j] + dx) < (unsigned)a.conv_w) v = ld4(ap[j] + coff);
+                } else {
+                    v = ld4(ap[j] + k0);
+                    if (a.A2) { const float4 t = ld4(a2p[j] + k0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                }
                 u = ld4(wp[j] + k0);
             }
             ra[j] = v; rw[j] = u;
@@ -126,15 +150,25 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
             const int n = n0 + wn * 64 + j * 32 + li;
             if (n >= a.N) continue;
             const float bs = a.bias ? a.bias[n] : 0.f;
+            const float cs = a.col_scale ? a.col_scale[n] : 1.f, ct = a.col_scale ? a.col_shift[n] : 0.f;
+            const int sub = a.shuf_c > 0 ? n / a.shuf_c : 0, co = a.shuf_c > 0 ? n - sub * a.shuf_c : n;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.M) continue;
                 float v = acc[i][j][r] + bs;
+                if (a.col_scale) v = v * cs + ct;
                 if (a.act == MSAM_ACT_GELU) v = gelu_exact(v);
                 else if (a.act == MSAM_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (a.act == MSAM_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
                 if (a.res) v += a.res[(a.res_rows >= a.M ? m : m % a.res_rows) * a.ldr + n];
-                a.out[m * a.ldc + n] = v;
+                long row = m;
+                if (a.shuf_c > 0) {
+                    const long hw = (long)a.shuf_h * a.shuf_w, b = m / hw, pix = m - b * hw;
+                    const int y = (int)(pix / a.shuf_w), x = (int)(pix - (long)y * a.shuf_w);
+                    row = (b * 2 * a.shuf_h + 2 * y + (sub >> 1)) * (2L * a.shuf_w) + 2 * x + (sub & 1);
+                }
+                a.out[row * a.ldc + co] = v;
             }
         }
 }
@@ -507,6 +541,112 @@ __global__ __launch_bounds__(256) void shyper_kernel(const float* __restrict__ u
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ AIS decoder pieces
+// InstanceNorm2d (no affine; torch.nn.InstanceNorm2d of torch_em's ConvBlock2d) on channels-last x [B, HW, C]: statistics per (b, c) over the
+// HW pixels.  Pass 1: per chunk of pixels the mean and the centred sum of squares (two sweeps over the chunk: no E[x^2] - mean^2
+// cancellation), pass 2: Chan's merge of the chunk statistics in double -> mean, 1 / sqrt(var + eps), pass 3: (x - mean) * rstd.
+constexpr int IN_CHUNK = 2048;
+__global__ __launch_bounds__(256) void sinorm_chunk_kernel(const float* __restrict__ x, long ldx, int HW, int C, float* __restrict__ part) {
+    __shared__ float red[256 * 4];
+    const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int CW = C < 256 ? C : 256, SUB = 256 / CW;
+    const int c0 = tid % CW, sub = tid / CW;
+    const bool act = sub < SUB;
+    const int p0 = chunk * IN_CHUNK, p1 = p0 + IN_CHUNK < HW ? p0 + IN_CHUNK : HW, n = p1 - p0;
+    const float* xb = x + ((long)b * HW) * ldx;
+    float mean[4];
+    for (int pass = 0; pass < 2; ++pass) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act)
+            for (int p = p0 + sub; p < p1; p += SUB)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + i * CW;
+                    if (c < C) { const float v = xb[(long)p * ldx + c]; acc[i] += pass ? (v - mean[i]) * (v - mean[i]) : v; }
+                }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[tid * 4 + i] = act ? acc[i] : 0.f;
+        __syncthreads();
+        float tot[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < SUB; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tot[i] += red[(s2 * CW + c0) * 4 + i];
+        __syncthreads();
+        if (pass == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mean[i] = tot[i] / (float)n;
+        } else if (act && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + i * CW;
+                if (c < C) { float* o = part + (((long)b * nchunk + chunk) * C + c) * 2; o[0] = mean[i]; o[1] = tot[i]; }
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void sinorm_merge_kernel(const float* __restrict__ part, int nchunk, int HW, int C, int B, float eps,
+                                                           float* __restrict__ stats) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx % C;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const float* o = part + (((long)b * nchunk + k) * C + c) * 2;
+        const int p0 = k * IN_CHUNK;
+        const double nk = (double)((p0 + IN_CHUNK < HW ? p0 + IN_CHUNK : HW) - p0), d = (double)o[0] - mean, nt = n + nk;
+        mean += d * nk / nt;
+        m2 += (double)o[1] + d * d * n * nk / nt;
+        n = nt;
+    }
+    stats[2 * idx] = (float)mean;
+    stats[2 * idx + 1] = 1.0f / sqrtf((float)(m2 / n) + eps);
+}
+__global__ __launch_bounds__(256) void sinorm_apply_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ stats, long HW, int C,
+                                                           long total4, float* __restrict__ out) {
+    const int c4n = C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        const long row = i / c4n, b = row / HW;
+        const float4 v = ld4(x + row * ldx + c);
+        const float* st = stats + (b * C + c) * 2;
+        *(float4*)(out + row * C + c) = make_float4((v.x - st[0]) * st[1], (v.y - st[2]) * st[3], (v.z - st[4]) * st[5], (v.w - st[6]) * st[7]);
+    }
+}
+// torch.nn.functional.interpolate(mode="bilinear", align_corners=False) on channels-last data: in [B, h (pitch_h rows), w (pitch_w pixels), C]
+// (the logical h x w window of a larger image: the crop of postprocess_masks) -> out [B, H2, W2, C] or NCHW [B, C, H2, W2].
+// source index = max(0, scale * (dst + 0.5) - 0.5), separately rounded (area_pixel_compute_source_index); weights 1 - l, l.
+__global__ __launch_bounds__(256) void sresize_kernel(const float* __restrict__ in, int B, int h, int w, int pitch_h, int pitch_w, long pix, int C,
+                                                      int H2, int W2, float sh, float sw, int nchw, float* __restrict__ out) {
+    const int c4n = C / 4;
+    const long total = (long)B * H2 * W2 * c4n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        long r = i / c4n;
+        const int x2 = (int)(r % W2); r /= W2;
+        const int y2 = (int)(r % H2);
+        const long b = r / H2;
+        float fy = __fsub_rn(__fmul_rn(sh, (float)y2 + 0.5f), 0.5f), fx = __fsub_rn(__fmul_rn(sw, (float)x2 + 0.5f), 0.5f);
+        fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = in + (b * pitch_h) * (long)pitch_w * pix + c;
+        const float4 p00 = ld4(base + ((long)y0 * pitch_w + x0) * pix), p01 = ld4(base + ((long)y0 * pitch_w + x1) * pix);
+        const float4 p10 = ld4(base + ((long)y1 * pitch_w + x0) * pix), p11 = ld4(base + ((long)y1 * pitch_w + x1) * pix);
+        float o[4];
+        const float a00[4] = {p00.x, p00.y, p00.z, p00.w}, a01[4] = {p01.x, p01.y, p01.z, p01.w};
+        const float a10[4] = {p10.x, p10.y, p10.z, p10.w}, a11[4] = {p11.x, p11.y, p11.z, p11.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t0 = fmaf(hx, a00[k], __fmul_rn(lx, a01[k])), t1 = fmaf(hx, a10[k], __fmul_rn(lx, a11[k]));
+            o[k] = fmaf(hy, t0, __fmul_rn(ly, t1));
+        }
+        if (nchw) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[((b * C + c + k) * H2 + y2) * (long)W2 + x2] = o[k];
+        } else *(float4*)(out + ((b * H2 + y2) * (long)W2 + x2) * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 int grid1d(long n, int per_block) {
     const long g = (n + per_block - 1) / per_block;
     return (int)(g < 1 ? 1 : (g > 0x7fffffffL ? 0x7fffffffL : g));
@@ -516,18 +656,32 @@ int grid1d(long n, int per_block) {
 
 extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
     if (!p || !p->A || !p->W || !p->out || p->M <= 0 || p->N <= 0 || p->K <= 0) { msam_set_error("msam_strict_gemm: null argument or empty shape"); return 1; }
-    if (p->K % 4 || p->lda % 4 || p->ldw % 4 || ((uintptr_t)p->A | (uintptr_t)p->W) % 16 || (p->A2 && (p->lda2 % 4 || (uintptr_t)p->A2 % 16))) {
+    const bool conv = p->conv_c > 0;
+    if (p->K % 4 || p->ldw % 4 || ((uintptr_t)p->A | (uintptr_t)p->W) % 16 || p->lda % 4 || (conv && p->lda < p->conv_c) || (p->A2 && (p->lda2 % 4 || (uintptr_t)p->A2 % 16))) {
         msam_set_error("msam_strict_gemm: K, lda, ldw (, lda2) must be multiples of 4 and the operands 16-byte aligned");
         return 1;
     }
-    if (p->act != MSAM_ACT_NONE && p->act != MSAM_ACT_GELU && p->act != MSAM_ACT_RELU) { msam_set_error("msam_strict_gemm: unknown activation"); return 1; }
+    if (p->act < MSAM_ACT_NONE || p->act > MSAM_ACT_SIGMOID) { msam_set_error("msam_strict_gemm: unknown activation"); return 1; }
+    if (conv && (p->conv_h <= 0 || p->conv_w <= 0 || p->conv_c % 4 || p->K != 9 * p->conv_c || p->M % ((int64_t)p->conv_h * p->conv_w) || p->A2)) {
+        msam_set_error("msam_strict_gemm: 3 x 3 mode needs A = [B, H, W, C] with C % 4 == 0, K == 9 C, M == B H W and no A2");
+        return 1;
+    }
+    if (p->shuffle_c > 0 && (p->shuffle_h <= 0 || p->shuffle_w <= 0 || p->N != 4 * p->shuffle_c || p->M % ((int64_t)p->shuffle_h * p->shuffle_w) || p->res)) {
+        msam_set_error("msam_strict_gemm: 2 x 2 transposed-convolution store needs N == 4 shuffle_c, M == B shuffle_h shuffle_w and no residual");
+        return 1;
+    }
+    if ((p->col_scale == nullptr) != (p->col_shift == nullptr)) { msam_set_error("msam_strict_gemm: col_scale and col_shift come together"); return 1; }
     SGemmArgs a{};
     a.A = p->A; a.lda = p->lda; a.A2 = p->A2; a.lda2 = p->lda2; a.a2_rows = p->a2_rows > 0 ? p->a2_rows : p->M;
     a.W = p->W; a.ldw = p->ldw; a.M = p->M; a.N = p->N; a.K = p->K; a.bias = p->bias; a.act = p->act;
     a.res = p->res; a.ldr = p->ldr; a.res_rows = p->res_rows > 0 ? p->res_rows : p->M; a.out = p->out; a.ldc = p->ldc;
+    a.col_scale = p->col_scale; a.col_shift = p->col_shift;
+    a.conv_h = p->conv_h; a.conv_w = p->conv_w; a.conv_c = p->conv_c;
+    a.shuf_h = p->shuffle_h; a.shuf_w = p->shuffle_w; a.shuf_c = p->shuffle_c;
     const long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
     if (blocks > 0x7fffffffL) { msam_set_error("msam_strict_gemm: too many tiles for one launch"); return 1; }
-    hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (conv) hipLaunchKernelGGL(sgemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(sgemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return msam_check_launch("strict_gemm");
 }
 
@@ -620,4 +774,34 @@ extern "C" int msam_strict_hyper_masks(const float* up, const float* hyper, int3
     }
     hipLaunchKernelGGL(shyper_kernel, dim3((unsigned)(P * 256)), dim3(256), 0, (hipStream_t)stream, up, hyper, hyper_ld, mask0, nmask, (long)P, low_res);
     return msam_check_launch("strict_hyper_masks");
+}
+
+extern "C" int msam_strict_instance_norm(const float* x, int64_t ldx, int32_t B, int64_t HW, int32_t C, float eps, float* out, float* workspace,
+                                         int64_t workspace_floats, void* stream) {
+    const long nchunk = (HW + IN_CHUNK - 1) / IN_CHUNK;
+    const long need = 2L * B * nchunk * C + 2L * B * C;
+    if (!x || !out || !workspace || B <= 0 || HW <= 0 || C <= 0 || C % 4 || C > 1024 || ldx < C || ldx % 4 || B > 65535 || HW > 0x7fffffffL) {
+        msam_set_error("msam_strict_instance_norm: null argument, C % 4 != 0, C > 1024 or ldx < C");
+        return 1;
+    }
+    if (workspace_floats < need) { msam_set_error("msam_strict_instance_norm: workspace too small (2 B ceil(HW / 2048) C + 2 B C floats)"); return 1; }
+    float* part = workspace; float* stats = workspace + 2L * B * nchunk * C;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sinorm_chunk_kernel, dim3((unsigned)nchunk, B), dim3(256), 0, s, x, (long)ldx, (int)HW, C, part);
+    hipLaunchKernelGGL(sinorm_merge_kernel, dim3(grid1d((long)B * C, 256)), dim3(256), 0, s, part, (int)nchunk, (int)HW, C, B, eps, stats);
+    const long total4 = (long)B * HW * (C / 4);
+    hipLaunchKernelGGL(sinorm_apply_kernel, dim3(grid1d(total4, 256 * 4)), dim3(256), 0, s, x, (long)ldx, stats, (long)HW, C, total4, out);
+    return msam_check_launch("strict_instance_norm");
+}
+
+extern "C" int msam_strict_resize_bilinear(const float* in, int32_t B, int32_t h, int32_t w, int32_t pitch_h, int32_t pitch_w, int64_t pixel_pitch,
+                                           int32_t C, int32_t H2, int32_t W2, float scale_h, float scale_w, int32_t out_nchw, float* out, void* stream) {
+    if (!in || !out || B <= 0 || h <= 0 || w <= 0 || h > pitch_h || w > pitch_w || C <= 0 || C % 4 || pixel_pitch < C || pixel_pitch % 4 || H2 <= 0 ||
+        W2 <= 0 || ((uintptr_t)in | (uintptr_t)out) % 16) {
+        msam_set_error("msam_strict_resize_bilinear: null argument, C % 4 != 0, pixel pitch < C or window larger than the image");
+        return 1;
+    }
+    hipLaunchKernelGGL(sresize_kernel, dim3(grid1d((long)B * H2 * W2 * (C / 4), 256 * 2)), dim3(256), 0, (hipStream_t)stream, in, B, h, w, pitch_h,
+                       pitch_w, (long)pixel_pitch, C, H2, W2, scale_h, scale_w, out_nchw, out);
+    return msam_check_launch("strict_resize_bilinear");
 }

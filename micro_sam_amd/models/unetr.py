@@ -14,8 +14,9 @@ and from torch_em's block definitions (``ConvBlock2d``: InstanceNorm, 3 x 3 conv
 at 1 and 4; ``Deconv2DBlock.block`` = Sequential(up-sampler, ``SingleConv2DBlock`` 3 x 3, BatchNorm2d, ReLU); ``Decoder.blocks / .samplers``).
 What could NOT be restated with confidence is the channel width of every layer, so **the widths are read from the checkpoint**: given a
 ``decoder_state`` the module tree is built to the shapes of its tensors (a state with other key names fails loudly, naming them); without one
-(a fresh decoder for training) the self-consistent default below is used.  Every operator here is a torch operator - like TinyViT
-(models/tiny_vit.py) this module is outside the hand-written HIP path; its input, the image embedding, comes from the HIP encoder."""
+(a fresh decoder for training) the self-consistent default below is used.  The module tree here owns the parameters and is the taped
+(training) form; INFERENCE on a GPU runs the library's fp32 kernels through ``models/unetr_hip.py`` (round 5; checked against
+``oracle/unetr_ref.py``), its input, the image embedding, comes from the HIP encoder."""
 from __future__ import annotations
 
 import warnings
@@ -240,9 +241,21 @@ class DecoderAdapter(nn.Module):
             x = self.final_activation(x)
         return x
 
+    def _hip(self):
+        if getattr(self, "_hip_decoder", None) is None:
+            from .unetr_hip import HipUnetrDecoder
+            object.__setattr__(self, "_hip_decoder", HipUnetrDecoder(self))
+        return self._hip_decoder
+
     @torch.no_grad()
     def forward(self, input_, input_shape, original_shape):
+        """Inference on a GPU runs the library's fp32 kernels (``models/unetr_hip.py``: implicit-GEMM convolutions, InstanceNorm, the
+        fused ``postprocess_masks``); ``_forward_impl`` above - the same graph as torch operators - is what trains and what a CPU-only
+        caller (the reference's own CPU path) gets.  MSAM_UNETR_TORCH=1 forces the operator form (A/B)."""
+        import os
         dev = self.out_conv.weight.device
+        if dev.type == "cuda" and os.environ.get("MSAM_UNETR_TORCH", "0") != "1":
+            return self._hip().forward(input_.to(device=dev, dtype=torch.float32), input_shape, original_shape)
         x = self._forward_impl(input_.to(device=dev, dtype=torch.float32))
         return self.postprocess_masks(x, input_shape, original_shape)
 
