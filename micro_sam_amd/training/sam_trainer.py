@@ -63,6 +63,101 @@ def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], bucket_bytes:
     return total
 
 
+class GradientBuckets:
+    """Data-parallel gradient exchange overlapped with the backward pass (the reference trains under torch DDP,
+    ``finetuning/specialists/training/light_microscopy/livecell_multi_gpu_finetuning.py:56-82``: bucketed all-reduce from autograd hooks).
+
+    The parameters' ``.grad`` tensors ARE slices of flat fp32 buckets (``bucket_bytes`` each; parameters in reverse registration order =
+    roughly the order in which backward finishes them): no ``cat`` before the all-reduce and no copy back after it (the two extra passes
+    over the gradients of the round-4 form).  A post-accumulate hook counts a bucket's finished gradients; the last one starts that
+    bucket's asynchronous all-reduce - on a communication stream that waits for the producing stream at that point - while backward
+    continues with the layers in front of it.  ``finish()`` starts whatever is left (parameters that got no gradient in this step),
+    waits, and divides by the world size.  ``zero()`` replaces ``optimizer.zero_grad()`` (which would drop the views)."""
+
+    def __init__(self, parameters: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20) -> None:
+        self.params = [p for p in parameters if p.requires_grad]
+        self.world = dist.get_world_size()
+        self.buckets: List[dict] = []
+        cur, size = [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self._make_bucket(cur)
+                cur, size = [], 0
+        if cur:
+            self._make_bucket(cur)
+        self._comm = None
+        self._handles = []
+        for b in self.buckets:
+            for q in b["params"]:
+                b["hooks"].append(q.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b)))
+
+    def _make_bucket(self, params) -> None:
+        dev = params[0].device
+        flat = torch.zeros(sum(q.numel() for q in params), dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for q in params:
+            views.append(flat[off:off + q.numel()].view(q.shape))
+            off += q.numel()
+        self.buckets.append({"flat": flat, "params": list(params), "views": views, "ready": 0, "launched": False, "hooks": []})
+        self._attach(self.buckets[-1])
+
+    @staticmethod
+    def _attach(b) -> None:
+        for q, v in zip(b["params"], b["views"]):
+            if q.grad is not v:
+                q.grad = v
+
+    def zero(self) -> None:
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["ready"], b["launched"] = 0, False
+            self._attach(b)
+        self._handles = []
+
+    def _launch(self, b) -> None:
+        b["launched"] = True
+        for q, v in zip(b["params"], b["views"]):                     # (autograd replaced a gradient it found undefined / of another layout)
+            if q.grad is not None and q.grad is not v:
+                v.copy_(q.grad)
+                q.grad = v
+        flat = b["flat"]
+        if flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=flat.device)
+            self._comm.wait_stream(torch.cuda.current_stream(flat.device))   # the bucket's gradients are complete on the producing stream
+            with torch.cuda.stream(self._comm):
+                self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), b))
+        else:
+            self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), b))
+
+    def _ready(self, b) -> None:
+        b["ready"] += 1
+        if b["ready"] == len(b["params"]) and not b["launched"]:
+            self._launch(b)
+
+    def finish(self) -> int:
+        """Start the buckets backward did not complete, wait for all of them, average.  Returns the bytes reduced."""
+        total = 0
+        for b in self.buckets:
+            if not b["launched"]:
+                self._launch(b)
+        for work, b in self._handles:
+            work.wait()
+            if b["flat"].is_cuda:
+                torch.cuda.current_stream(b["flat"].device).wait_stream(self._comm)
+            b["flat"].div_(self.world)
+            total += b["flat"].numel() * 4
+        self._handles = []
+        return total
+
+    def remove(self) -> None:
+        for b in self.buckets:
+            for h in b["hooks"]:
+                h.remove()
+
+
 class SamTrainer:
     def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, convert_inputs: Callable, n_sub_iteration: int,
                  n_objects_per_batch: Optional[int] = None, mse_loss: Callable = torch.nn.MSELoss(),
@@ -80,6 +175,9 @@ class SamTrainer:
         self.device = device if device is not None else getattr(getattr(model, "sam", None), "device", "cpu")
         self._iteration = 0
         self.history: List[dict] = []
+        # data parallel: gradients live in flat buckets that are all-reduced from autograd hooks while backward runs (GradientBuckets);
+        # MSAM_DP_OVERLAP=0 keeps the round-4 form (all_reduce_gradients after backward)
+        self._buckets = None
 
     # ---- reference :70-128
     def _get_prompt_and_multimasking_choices(self, current_iteration):
@@ -207,12 +305,20 @@ class SamTrainer:
 
     # ---- the train step of reference :384-418 (optimizer.zero_grad - forward - backward - step) + gradient all-reduce
     def train_iteration(self, x, y) -> dict:
+        import os
+        from ..parallel import collectives_active
         self.model.train()
-        self.optimizer.zero_grad()
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        overlap = collectives_active() and os.environ.get("MSAM_DP_OVERLAP", "1") != "0"
+        if overlap:
+            if self._buckets is None:
+                self._buckets = GradientBuckets(params)
+            self._buckets.zero()
+        else:
+            self.optimizer.zero_grad()
         loss, mask_loss, iou_loss, model_iou, _ = self._interactive_train_iteration(x, y)
         loss.backward()
-        params = [p for g in self.optimizer.param_groups for p in g["params"]]
-        reduced = all_reduce_gradients(params)
+        reduced = self._buckets.finish() if overlap else all_reduce_gradients(params)
         self.optimizer.step()
         rec = {"iteration": self._iteration, "loss": float(loss.detach()), "mask_loss": float(mask_loss.detach()),
                "iou_regression_loss": float(iou_loss.detach()), "model_iou": float(model_iou), "allreduce_bytes": reduced}

@@ -16,7 +16,7 @@ SCRIPT = r"""
 import os, sys, socket, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from micro_sam_amd import parallel
-from micro_sam_amd.training.sam_trainer import all_reduce_gradients
+from micro_sam_amd.training.sam_trainer import GradientBuckets, all_reduce_gradients
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MSAM_FORCE_COLLECTIVES="1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -36,6 +36,22 @@ lin.weight.grad = torch.randn(500, 300, generator=g).to(dev); lin.bias.grad = to
 w0, b0 = lin.weight.grad.clone(), lin.bias.grad.clone()
 nbytes = all_reduce_gradients(lin.parameters(), bucket_bytes=256 << 10)              # several buckets
 assert nbytes == (500 * 300 + 500) * 4 and torch.equal(lin.weight.grad, w0) and torch.equal(lin.bias.grad, b0)
+# round 5: the overlapped form - gradients written by autograd into flat buckets, every bucket all-reduced (RCCL, communication stream)
+# from the hook of its last gradient while backward runs; with one rank the averaged gradients are the plain ones
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(64, 512), torch.nn.ReLU(), torch.nn.Linear(512, 512), torch.nn.ReLU(), torch.nn.Linear(512, 8)).to(dev)
+x, t = torch.randn(256, 64, device=dev), torch.randn(256, 8, device=dev)
+((net(x) - t) ** 2).mean().backward()
+want = [p.grad.clone() for p in net.parameters()]
+net.zero_grad()
+buckets = GradientBuckets(net.parameters(), bucket_bytes=256 << 10)
+for step in range(2):
+    buckets.zero()
+    ((net(x) - t) ** 2).mean().backward()
+    nb = buckets.finish()
+    torch.cuda.synchronize()
+    assert nb == sum(p.numel() for p in net.parameters()) * 4 and len(buckets.buckets) >= 2
+    assert all(torch.allclose(p.grad, w, atol=1e-6) for p, w in zip(net.parameters(), want))
 dist.barrier(); torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RCCL_WORLD1_OK", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else "")

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -207,6 +208,60 @@ def test_gradient_all_reduce_and_mask_decision_broadcast_gloo():
         assert np.allclose(g[0], np.full((5, 7), 1.5)) and np.allclose(g[1], np.full((300,), 3.0)) and g[2] is None
         assert nbytes == (35 + 300) * 4                                   # grads all-reduce bytes = 4 * N_trainable
     assert res[0][2] == res[1][2] and any(res[0][2]) and not all(res[0][2])      # rank 0's decision everywhere
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from micro_sam_amd.training.sam_trainer import GradientBuckets
+    torch.manual_seed(0)                                                  # the same model on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 40), torch.nn.ReLU(), torch.nn.Linear(40, 3))
+    unused = torch.nn.Parameter(torch.ones(5))                           # a parameter that gets no gradient
+    buckets = GradientBuckets(list(net.parameters()) + [unused], bucket_bytes=1024)      # several buckets
+    out = []
+    for step in range(2):                                                 # two steps: zero() re-arms the hooks, the views survive
+        buckets.zero()
+        g = torch.Generator().manual_seed(100 * step + rank)             # every rank its own batch
+        x, t = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)
+        ((net(x) - t) ** 2).mean().backward()
+        nbytes = buckets.finish()
+        out.append([p.grad.numpy().copy() for p in net.parameters()] + [unused.grad.numpy().copy()])
+        assert all(p.grad.data_ptr() == v.data_ptr() for b in buckets.buckets for p, v in zip(b["params"], b["views"]))
+    q.put((rank, out, nbytes, len(buckets.buckets)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_buckets_all_reduce_from_hooks_gloo(world):
+    """GradientBuckets (round 5): gradients written by autograd straight into flat buckets, each bucket's all-reduce
+    started by the hook of its last gradient - the averaged gradients equal the mean of the per-rank gradients computed here serially."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (o, n, nb) for r, o, n, nb in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.ReLU(), torch.nn.Linear(40, 40), torch.nn.ReLU(), torch.nn.Linear(40, 3))
+    n_param = sum(p.numel() for p in net.parameters()) + 5
+    for step in range(2):
+        want = None
+        for r in range(world):
+            net.zero_grad()
+            g = torch.Generator().manual_seed(100 * step + r)
+            x, t = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)
+            ((net(x) - t) ** 2).mean().backward()
+            grads = [p.grad.clone() for p in net.parameters()]
+            want = grads if want is None else [a + b for a, b in zip(want, grads)]
+        want = [w / world for w in want]
+        for r in range(world):
+            got = res[r][0][step]
+            assert all(np.allclose(g, w.numpy(), atol=1e-6) for g, w in zip(got[:-1], want)) and np.all(got[-1] == 0)
+    assert res[0][1] == n_param * 4 and res[0][2] >= 2
 
 
 def test_weight16_cache_follows_the_parameter_version():

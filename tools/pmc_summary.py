@@ -10,8 +10,20 @@ KEEP = ("tok_layer", "up_fused", "fold_i2t", "fold_attn", "postprocess", "gemm25
         "t2i_shared4", "cc_hook", "nms_sweep", "fused_i2t", "i2t0_t2i", "i2t01", "i2t_tok")
 
 
+def measured_sha(dirs):
+    """csrc_sha16 recorded next to the passes (tools/final_measure.sh writes <gpurun_out>/final_csrc_sha.txt before them)."""
+    for d in dirs:
+        p = os.path.join(os.path.dirname(os.path.abspath(d.rstrip("/"))), "final_csrc_sha.txt")
+        if os.path.exists(p):
+            return open(p).read().strip()
+    return None
+
+
 def main():
     vals = defaultdict(lambda: defaultdict(list))
+    sha = measured_sha(sys.argv[1:])
+    # every table under profiles/ names the code it was measured on (VERDICT r4 item 9): the SQ file of round 4 carried no hash
+    print(f"csrc_sha16 of the measured code: `{sha}` (tools/csrc_sha.py at measurement time; a table quoted for other code is stale)\n")
     for d in sys.argv[1:]:
         for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(path)):

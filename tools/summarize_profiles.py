@@ -14,7 +14,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = next((a for a in sys.argv[1:] if not a.startswith("--")), "r01")
 OUT = os.path.join(ROOT, "profiles")
 GO = os.path.join(ROOT, "gpurun_out")
 
@@ -48,6 +48,16 @@ def one(pattern):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    # every table names the code it was measured on, and a measurement of OTHER code is refused (round 4's kernel
+    # summary and SQ table described the build before the last csrc commit)
+    sys.path.insert(0, ROOT)
+    import bench
+    sha_path = os.path.join(GO, "final_csrc_sha.txt")
+    measured = open(sha_path).read().strip() if os.path.exists(sha_path) else None
+    if measured != bench.csrc_sha16() and "--force" not in sys.argv:
+        raise SystemExit(f"gpurun_out/final_* was measured on csrc_sha16 {measured}, the working tree is {bench.csrc_sha16()}: re-run "
+                         "tools/final_measure.sh on this code (or pass --force to summarise the old measurement under its own hash)")
+    stamp = f"csrc_sha16 of the measured code: `{measured}`\n\n"
     line = open(os.path.join(GO, "final_bench.log")).read().strip().splitlines()[-1]
     bench = json.loads(line)
     with open(os.path.join(OUT, f"{TAG}_bench_line.json"), "w") as f:
@@ -64,6 +74,7 @@ def main():
     tiles = per_tile[0] if per_tile else pb["config"]["tiles_per_step_per_gpu"] * (pb["steps"] + pb["warmup"] + 2)
     with open(os.path.join(OUT, f"{TAG}_bench_kernel_summary.md"), "w") as f:
         f.write(f"# {TAG}: rocprofv3 kernel summary of `python bench.py --no-cpu-baseline --no-side --lanes 1` on one MI355X\n\n")
+        f.write(stamp)
         f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_prof -- python bench.py "
                 "--no-cpu-baseline --no-side --lanes 1` (no side measurements: every launch belongs to the hot path; one decode lane: kernels of different tiles do not overlap, the same order as the "
                 "serial roofline pass of bench.py)\n")
@@ -117,6 +128,7 @@ def main():
     with open(os.path.join(OUT, f"{TAG}_pmc_traffic.md"), "w") as f:
         f.write(f"# {TAG}: HBM traffic from PMC counters (separate rocprofv3 passes of `python bench.py --steps 1 --warmup 1 "
                 "--no-cpu-baseline --no-side`)\n\n")
+        f.write(stamp)
         f.write("Commands: `rocprofv3 --kernel-trace --pmc FETCH_SIZE ...` and `rocprofv3 --kernel-trace --pmc WRITE_SIZE ...` "
                 "(one counter per pass, no other trace domain).\n\n")
         f.write("Units: counter values are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports 1/2 of "
