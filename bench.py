@@ -275,7 +275,7 @@ def config_sides(timeout_s: float = 420.0):
     sides = {}
     sides["fp8_side"] = run(["bench.py", "--encoder-dtype", "fp8", "--no-cpu-baseline", "--no-side", "--steps", "3", "--warmup", "1"],
                             ("metric", "value", "unit", "ms_per_step", "dtype"))
-    sides["config3_side"] = run(["bench.py", "--workload", "config3", "--steps", "1", "--warmup", "1", "--slices", "4"],
+    sides["config3_side"] = run(["bench.py", "--workload", "config3", "--steps", "3", "--warmup", "1", "--slices", "8"],
                                 ("metric", "value", "unit", "ms_per_step", "dtype", "config"))
     # parity on weights that are not hand-designed (tools/trained_parity.py: the "cells" checkpoint after 100 AdamW steps of this package's
     # trainer), default and strict precision mode against the fp32 CPU oracle of the same run
@@ -309,11 +309,12 @@ def bench_config3(args, rank, world, dev):
     sd = synthetic_state_dict("vit_l", 0, variant=args.weights)
     predictor = util.get_sam_model("vit_l", device=dev, state_dict=sd)
     predictor.model.image_encoder.set_precision(args.encoder_dtype)
+    segmentor = TiledAutomaticMaskGenerator(predictor)          # (one generator for all steps: its decode lanes keep their workspaces)
 
     def step():
-        # batch_size = all tiles of the share: tiles are batched by shape, a slice alone has 4 + 1 + 2 + 2 tiles of four shapes
-        seg, _ = mds.segment_slices(vol, predictor, TiledAutomaticMaskGenerator(predictor), tile_shape=(768, 768), halo=(128, 128),
-                                    batch_size=9 * Z)
+        # batch_size = the tiles of TWO slices: tiles are batched by shape (a slice has 4 + 1 + 2 + 2 tiles of four shapes) and the encoder of
+        # the next pair of slices runs underneath the decode lanes of the current pair (round 5: _segment_slices_tiled_overlapped)
+        seg, _ = mds.segment_slices(vol, predictor, segmentor, tile_shape=(768, 768), halo=(128, 128), batch_size=18)
         return seg
     for _ in range(args.warmup):
         seg = step()

@@ -143,6 +143,115 @@ def _segment_slices_pipelined(data, predictor, segmentor, batch_size: int, n_lan
     return (labels if return_device else out), emb
 
 
+def _can_overlap_tiled(data, predictor, segmentor, embedding_path, tile_shape, halo) -> bool:
+    from .instance_segmentation import TiledAutomaticMaskGenerator
+    return (type(segmentor) is TiledAutomaticMaskGenerator and embedding_path is None and tile_shape is not None and halo is not None
+            and data.shape[0] > 1 and str(predictor.device).startswith("cuda") and torch.cuda.is_available()
+            and hasattr(predictor.model.image_encoder, "forward_u8") and segmentor._predictor is predictor
+            and isinstance(data, np.ndarray) and util._device_to_image_ok([data[0]]))
+
+
+@torch.no_grad()
+def _segment_slices_tiled_overlapped(data, predictor, segmentor, tile_shape, halo, batch_size: int, kwargs):
+    """The tiled slice loop (BASELINE configs[2]: 2048^2 slices, tile 768 + halo 128) with the image encoder of the NEXT group of slices
+    running on its own HIP stream underneath the decode lanes of the current one (the reference - and rounds 1 - 4 here -
+    encode every tile of every slice first, then decode slice by slice: encoder and decoder kernels never shared the GPU).
+
+      encoder stream   slices in groups of max(1, batch_size // tiles per slice): raw tiles up, ``_to_image`` (+ resize) + encoder, tiles
+                       batched by shape; results go straight into the volume's tiled feature store ([Z, 1, 256, 64, 64] per tile), an
+                       event per group
+      caller's stream  waits for the group's event, then per slice ``TiledAutomaticMaskGenerator.initialize(i=z)`` (tiles on the
+                       generator's decode lanes) + ``generate`` - the same calls as the loop, so the same labels
+
+    The next group is enqueued BEFORE the current group's slices are decoded; the host synchronisations inside ``generate`` only wait for
+    the decode streams.  Returns (segmentation, image_embeddings) as the loop does (the embeddings: the same in-memory tiled store as
+    ``precompute_image_embeddings(ndim=3, tile_shape=...)``)."""
+    from .tiling import Blocking, TileArray, TiledFeatures
+    Z, shape = data.shape[0], tuple(data.shape[1:3])
+    dev = predictor.device
+    tiling = Blocking([0, 0], shape, tile_shape)
+    n_tiles = tiling.number_of_blocks
+    features = TiledFeatures(shape, tile_shape, halo)
+    enc = getattr(predictor, "_encoder_stream", None)
+    if enc is None or enc.device != torch.device(dev):
+        enc = predictor._encoder_stream = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    step = max(1, int(batch_size) // n_tiles)
+    groups = [(z0, min(z0 + step, Z)) for z0 in range(0, Z, step)]
+    outer = []
+    for tile_id in range(n_tiles):
+        tile = tiling.get_block_with_halo(tile_id, list(halo))
+        outer.append(tuple(slice(beg, end) for beg, end in zip(tile.outer_block.begin, tile.outer_block.end)))
+
+    # the volume's feature store, allocated on the CALLER's stream (it outlives this call in the returned embeddings; memory of the encoder
+    # stream's pool handed to the caller could be recycled under the caller's later reads)
+    stores = [torch.zeros((Z, 1, modeling.PROMPT_DIM, modeling.GRID, modeling.GRID), dtype=torch.float32, device=dev) for _ in range(n_tiles)]
+
+    # page-locked staging per (group parity, tile shape): ALL uploads of a group are queued before its first encoder launch, and a buffer
+    # is reused two groups later, when its copy has long completed - the shared two-slot ring of util._upload_raw_tiles would make the
+    # host wait for a copy that sits on the encoder stream behind the encoder kernels of the same group
+    pins = getattr(predictor, "_slice_pins", None)
+    if pins is None:
+        pins = predictor._slice_pins = {}
+    uploaded = {}
+
+    def encode(g, z0, z1):
+        if g - 2 in uploaded:
+            uploaded.pop(g - 2).synchronize()
+        enc.wait_stream(main)                         # (first use: the zero fill above; later: a no-op in practice)
+        with torch.cuda.stream(enc):
+            by_shape = {}
+            for z in range(z0, z1):
+                for tile_id in range(n_tiles):
+                    image = np.asarray(data[(z,) + outer[tile_id]])
+                    by_shape.setdefault(image.shape, []).append((z, tile_id, image))
+            batches = []
+            for shp, members in by_shape.items():
+                host = np.stack([im for _, _, im in members])
+                if host.dtype != np.uint8:
+                    host = host.astype(np.float32)
+                key = (g & 1, shp, host.dtype.str)
+                pin = pins.get(key)
+                if pin is None or pin.numel() < host.size:
+                    pin = pins[key] = torch.empty(host.size, dtype=torch.from_numpy(host[:0]).dtype).pin_memory()
+                view = pin[: host.size].view(host.shape)
+                view.copy_(torch.from_numpy(host))
+                batches.append((members, view.to(dev, non_blocking=True)))
+            up = torch.cuda.Event()
+            up.record(enc)
+            uploaded[g] = up
+            predictor.reset_image()
+            for members, dev_raw in batches:
+                emb, osz, isz = util._embeddings_from_uploaded_raw(predictor, dev_raw)
+                for k, (z, tile_id, _) in enumerate(members):
+                    if tile_id not in features:
+                        features[tile_id] = TileArray(stores[tile_id], osz[k], isz[k])
+                    stores[tile_id][z, 0] = emb[k]
+            ev = torch.cuda.Event()
+            ev.record(enc)
+        return ev
+    emb = {"features": features, "input_size": None, "original_size": None}
+    segmentation = np.zeros(data.shape, dtype="uint32")
+    offset = 0
+    pending = encode(0, *groups[0])
+    for g, (z0, z1) in enumerate(groups):
+        ready = pending
+        if g + 1 < len(groups):
+            pending = encode(g + 1, *groups[g + 1])   # queued now: runs on the encoder stream while the slices below are decoded
+        main.wait_event(ready)
+        for z in range(z0, z1):
+            segmentor.initialize(data[z], image_embeddings=emb, verbose=False, i=z)
+            seg = segmentor.generate(**kwargs)
+            max_z = int(seg.max())
+            if max_z == 0:
+                continue
+            seg[seg != 0] += offset
+            offset = max_z + offset
+            segmentation[z] = seg
+    main.wait_stream(enc)
+    return segmentation, emb
+
+
 def segment_slices(data: np.ndarray, predictor, segmentor, embedding_path=None, verbose: bool = False,
                    tile_shape: Optional[Tuple[int, int]] = None, halo: Optional[Tuple[int, int]] = None,
                    batch_size: int = 1, decode_lanes: int = 3, **kwargs):
@@ -157,6 +266,8 @@ def segment_slices(data: np.ndarray, predictor, segmentor, embedding_path=None, 
         res = _segment_slices_pipelined(data, predictor, segmentor, batch_size, decode_lanes, False, kwargs)
         if res is not None:
             return res
+    if decode_lanes > 0 and _can_overlap_tiled(data, predictor, segmentor, embedding_path, tile_shape, halo):
+        return _segment_slices_tiled_overlapped(data, predictor, segmentor, tile_shape, halo, batch_size, kwargs)
     image_embeddings = util.precompute_image_embeddings(predictor=predictor, input_=data, save_path=embedding_path, ndim=3,
                                                         tile_shape=tile_shape, halo=halo, verbose=verbose,
                                                         batch_size=batch_size, keep_on_device=tile_shape is None)

@@ -255,8 +255,16 @@ def _compute_embeddings_batched_raw(predictor, raw_images):
         return _compute_embeddings_batched(predictor, [_to_image(im) for im in raw_images])
     predictor.reset_image()
     dev = _upload_raw_tiles(predictor, raw_images)
+    return _embeddings_from_uploaded_raw(predictor, dev)
+
+
+@torch.no_grad()
+def _embeddings_from_uploaded_raw(predictor, dev: torch.Tensor):
+    """The device part of ``_compute_embeddings_batched_raw``: raw tiles [B,H,W(,C)] already in HBM -> ``_to_image`` (+ the Pillow resize)
+    + encoder, on the current stream."""
     batch = torch.stack([to_image_device(dev[b]) for b in range(dev.shape[0])])
-    size = tuple(raw_images[0].shape[:2])
+    raw_images = [dev[b] for b in range(dev.shape[0])]
+    size = tuple(dev.shape[1:3])
     input_size = tuple(predictor.transform.get_preprocess_shape(size[0], size[1], modeling.IMG_SIZE))
     if input_size != size:                   # ResizeLongestSide.apply_image: Pillow's bilinear resize, on the device
         from . import ops

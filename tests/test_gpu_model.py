@@ -802,3 +802,31 @@ def test_config1_vit_t_plumbing():
     assert np.array_equal(seg, amg2.generate(pred_iou_thresh=0.5, stability_score_thresh=0.5))       # state round trip ==
     with pytest.raises(ValueError):
         util.get_sam_model("vit_t", device="cuda", state_dict=sd, peft_kwargs={"rank": 4})
+
+
+def test_tiled_segment_slices_with_the_encoder_overlapped_equals_the_loop(vit_b_sd):
+    """multi_dimensional_segmentation.segment_slices with a TiledAutomaticMaskGenerator (BASELINE configs[2]'s per-slice path): round 5 runs
+    the image encoder of the next group of slices on its own stream underneath the current group's decode lanes - the labels, the running
+    id offsets and the returned tiled embeddings are those of the reference's loop (decode_lanes=0: all embeddings first, then the slices)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import multi_dimensional_segmentation as mds
+    from micro_sam_amd import util
+    from micro_sam_amd.instance_segmentation import TiledAutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_tile
+    predictor = util.get_sam_model("vit_b", device="cuda", state_dict=vit_b_sd)
+    vol = np.stack([synthetic_tile(60 + z, (1100, 1300)) for z in range(5)])
+    kw = dict(tile_shape=(512, 512), halo=(64, 64))
+    gen_kw = dict(pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    seg_gen = TiledAutomaticMaskGenerator(predictor, points_per_side=8)
+    assert mds._can_overlap_tiled(vol, predictor, seg_gen, None, kw["tile_shape"], kw["halo"])
+    for batch_size in (9, 18):                                  # one and two slices per encoder group (the last group is ragged)
+        seg, emb = mds.segment_slices(vol, predictor, seg_gen, batch_size=batch_size, **kw, **gen_kw)
+        ref, emb_ref = mds.segment_slices(vol, predictor, TiledAutomaticMaskGenerator(predictor, points_per_side=8), batch_size=batch_size,
+                                          decode_lanes=0, **kw, **gen_kw)
+        assert seg.dtype == np.uint32 and seg.shape == vol.shape and seg.max() > 20
+        assert np.array_equal(seg, ref)
+        f, fr = emb["features"], emb_ref["features"]
+        assert set(f.keys()) == set(fr.keys()) and f.attrs["tile_shape"] == fr.attrs["tile_shape"]
+        for k in f.keys():
+            assert torch.equal(f[k].data, fr[k].data) and f[k].attrs == fr[k].attrs

@@ -150,3 +150,30 @@ def test_strict_is_a_mode_of_the_same_predictor(model):
     with pytest.raises(ValueError):
         predictor.set_precision("fp64")
     predictor.set_precision("strict")
+
+
+def test_strict_vit_h_embedding_vs_the_committed_fp32_golden():
+    """vit_h (32 blocks, 16 heads of 80 channels: the HD = 80 instantiations of the strict attention kernel, 14 x 14 windows and the global
+    grid) in strict mode against the committed fp32 oracle embedding of tile 22 (tests/golden/vit_h_embedding_tile22.npz: every 8th
+    channel; the 16-bit path's mean |error| on it is 4e-3)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import util
+    from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "vit_h_embedding_tile22.npz"))
+    p = util.get_sam_model("vit_h", device="cuda", state_dict=synthetic_state_dict("vit_h", 2))
+    p.set_precision("strict")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb = util.precompute_image_embeddings(p, synthetic_tile(22), verbose=False, keep_on_device=True)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    out = emb["features"].float().cpu()
+    ref = torch.as_tensor(gold["sub_fp32"].astype(np.float32))
+    d = (out[0, ::8] - ref).abs()
+    rec = {"max_abs_err": float(d.max()), "mean_abs_err": float(d.mean()), "seconds_first_call": round(sec, 3)}
+    print("\nstrict vit_h embedding vs fp32 golden:", json.dumps(rec))
+    _record("embedding_vit_h_tile22", rec)
+    # (the golden stores float16 samples of the fp32 embedding: 2^-11 relative = 5e-4 at unit scale is the golden's own resolution)
+    assert rec["max_abs_err"] <= 3e-3 and rec["mean_abs_err"] <= 3e-4, rec
+    assert abs(out.double().abs().sum().item() - float(gold["abs_sum_fp32"])) / float(gold["abs_sum_fp32"]) < 2e-5
