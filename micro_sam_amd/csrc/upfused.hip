@@ -25,6 +25,7 @@ constexpr int T = 4096, C = 256, TK = 16, NTHR = 256;
 int g_uf_prio = 1;                    // tuning hook msam_upscale_set_prio
 }
 int g_tune_up_gelu16 = 1;             // msam_tune_set "up_gelu16": GELUs in packed fp16 arithmetic (fp16 decoder build; 0 = packed fp32)
+int g_tune_up_ln_two_pass = 0;        // msam_tune_set "up_ln_two_pass": 1 = centred two-pass LayerNorm2d variance (default: one pass, E[u^2] - mean^2)
 namespace {
 constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;     // k-step sub-tiles [32 tokens][64 B] (+ pad), see decfold.hip
 constexpr int W2_BYTES = 128 * 128;
@@ -140,7 +141,7 @@ MSAM_DEVINL void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g0
 // LDS: tile q + 1 is read from one staging buffer while tile q + 2 is written into the other (free since the previous barrier).
 // The second half of the grid starts ~700 cycles late: co-resident workgroups (i, i + grid / 2) then run a quarter tile period out of
 // phase instead of competing for the same pipe in the same stage.
-template <int UF_PRIO, int G16>
+template <int UF_PRIO, int G16, int LN2P = 0>
 __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
     __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
@@ -286,8 +287,19 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) uc[rt][r] -= mean;
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LN2P) {
+            // msam_tune_set("up_ln_two_pass", 1): the centred two-pass variance of rounds 1 - 3 (and of the reference's LayerNorm2d) - a second
+            // exchange after the centring.  The one-pass form loses ~2^-23 E[u^2] / var of relative accuracy: negligible while |mean| is of
+            // the order of the standard deviation (SAM's up-scaling activations), not when |mean| >> std
+            float s2 = 0.f;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s2 += uc[rt][r] * uc[rt][r];
+            ss = wave_rows_sum(s2);
+        }
         UF_S1(2, ss);
-        float rstd = rsqrtf(fmaxf(ss * (1.f / 64.f) - mean * mean, 0.f) + a.eps);
+        float rstd = LN2P ? rsqrtf(ss * (1.f / 64.f) + a.eps) : rsqrtf(fmaxf(ss * (1.f / 64.f) - mean * mean, 0.f) + a.eps);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t g1w[4][2];
 #pragma unroll
@@ -434,11 +446,13 @@ extern "C" int msam_upscale_fused_out(const void* keys, int32_t keys_blocked, in
     if (g_tune_up_gelu16 == 2) hipLaunchKernelGGL((up_fused_kernel<1, 2>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     else if (g_tune_up_gelu16 == 3) hipLaunchKernelGGL((up_fused_kernel<1, 3>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     else if (g_tune_up_gelu16) {
-        if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+        if (g_tune_up_ln_two_pass) hipLaunchKernelGGL((up_fused_kernel<1, 1, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+        else if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((up_fused_kernel<0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     } else
 #endif
-    if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    if (g_tune_up_ln_two_pass) hipLaunchKernelGGL((up_fused_kernel<1, 0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((up_fused_kernel<0, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     msam_profile_mark2(stream, 0, flops, bytes, 4);
     return msam_check_launch("up_fused");
