@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-rm -rf $O/final_prof $O/final_fetch $O/final_write $O/final_sq1 $O/final_sq2
+rm -rf $O/final_prof $O/final_fetch $O/final_write $O/final_sq1 $O/final_sq2 $O/final_strict_prof
 python $R/tools/csrc_sha.py > $O/final_csrc_sha.txt
 python $R/bench.py > $O/final_bench.log 2> $O/final_bench.err
 # rocprof passes: hot path only (--no-side), one decode lane (kernels of different tiles do not overlap)
@@ -20,6 +20,9 @@ if [ "$1" != "quick" ]; then
 python $R/bench.py --encoder-dtype fp16 --no-cpu-baseline --no-side > $O/final_fp16.log 2> $O/final_fp16.err
 python $R/bench.py --lanes 1 --no-cpu-baseline --no-side > $O/final_lanes1.log 2> $O/final_lanes1.err
 fi
+# the strict precision mode: its own kernel table (two tiles through the per-tile API loop in both modes + the f32-input MFMA product on the path's shapes)
+rm -rf $O/final_strict_prof
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_strict_prof -- python $R/tools/strict_probe.py --out $O/final_strict_probe.json > $O/final_strict_prof.log 2>&1
 python $R/tools/hbm_probe.py > $O/final_hbm_probe.log 2>&1
 cd $R && python -c "import __graft_entry__ as g; g.smoke()" > $O/final_smoke.log 2>&1
 tail -1 $O/final_smoke.log

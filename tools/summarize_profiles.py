@@ -143,6 +143,24 @@ def main():
             ratio = "-" if alg is None else f"{r['hbm_bytes_per_launch'] / alg:.2f}"
             f.write(f"| `{short}` | {r['launches']} | {r['fetch_kib']:.0f} | {r['write_kib']:.0f} | {r['hbm_bytes_per_launch'] / 1e9:.3f} GB | "
                     f"{'-' if alg is None else f'{alg / 1e9:.3f} GB'} | {ratio} | {r['algorithmic']} |\n")
+    # ---- the strict precision mode's kernel table (tools/strict_probe.py under rocprofv3: both modes' per-tile API loop + product timings)
+    sp = glob.glob(os.path.join(GO, "final_strict_prof", "*", "*_kernel_stats.csv"))
+    if sp:
+        rows = list(csv.DictReader(open(max(sp, key=os.path.getmtime))))
+        probe = os.path.join(GO, "final_strict_probe.json")
+        with open(os.path.join(OUT, f"{TAG}_strict_kernel_summary.md"), "w") as f:
+            f.write(f"# {TAG}: rocprofv3 kernel summary of `python tools/strict_probe.py` (the strict precision mode next to the default one)\n\n")
+            f.write(stamp)
+            f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_strict_prof -- python tools/strict_probe.py`: per mode "
+                    "(default, strict) 4 passes of the per-tile API loop over 2 tiles + 4 encoder-only passes, then the f32-input MFMA product on seven shapes "
+                    "of the path (6 launches each).  Kernels of `csrc/strict.hip`: `sgemm_kernel`, `srelpos_kernel`, `sattn_*`, `sln*`, `shyper_kernel`, "
+                    "`spatchify / sim2col / ssrc`.\n\n")
+            if os.path.exists(probe):
+                f.write("Probe line of the same run: `" + open(probe).read().strip() + "`\n\n")
+            f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+            for r in rows[:30]:
+                f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | "
+                        f"{float(r['Percentage']):.1f} |\n")
     print("wrote", sorted(os.listdir(OUT)))
 
 
