@@ -420,6 +420,72 @@ def multicut_gaec(n_nodes: int, uv_ids: np.ndarray, costs: np.ndarray) -> np.nda
     return lut[np.searchsorted(np.sort(np.unique(roots)), roots)]
 
 
+def multicut_energy(uv_ids: np.ndarray, costs: np.ndarray, labels: np.ndarray) -> float:
+    """The multicut objective (nifty / elf convention): the sum of the costs of the CUT edges (positive = attractive: cutting it costs)."""
+    uv = np.asarray(uv_ids, dtype=np.int64)
+    cut = labels[uv[:, 0]] != labels[uv[:, 1]]
+    return float(np.asarray(costs, dtype=np.float64)[cut].sum())
+
+
+def multicut_refine(n_nodes: int, uv_ids: np.ndarray, costs: np.ndarray, labels: np.ndarray, max_sweeps: int = 50) -> np.ndarray:
+    """Local search of the Kernighan-Lin kind on top of a multicut (the reference solves with elf's ``multicut_decomposition``, whose inner
+    solver is Kernighan-Lin warm-started by greedy additive edge contraction - python-elf / nifty are absent, so the solver is restated
+    as: GAEC, then this refinement): sweeps of (a) single-node moves - a node leaves its cluster for an adjacent cluster or for a new
+    one of its own when that lowers the objective - and (b) joins of two adjacent clusters whose connecting costs sum to a positive
+    value, until a sweep changes nothing.  Deterministic (nodes and clusters in ascending id order, strict improvements only), so the
+    objective never increases over GAEC's; on forests GAEC is already optimal and nothing moves.  Returns consecutive labels in order of
+    the smallest node id of each cluster."""
+    uv = np.asarray(uv_ids, dtype=np.int64)
+    w = np.asarray(costs, dtype=np.float64)
+    lab = np.asarray(labels, dtype=np.int64).copy()
+    adj = [dict() for _ in range(n_nodes)]
+    for (u, v), c in zip(uv.tolist(), w.tolist()):
+        if u != v:
+            adj[u][v] = adj[u].get(v, 0.0) + c
+            adj[v][u] = adj[v].get(u, 0.0) + c
+    eps = 1e-12
+    next_label = int(lab.max()) + 1 if n_nodes else 0
+    for _ in range(max_sweeps):
+        changed = False
+        for u in range(n_nodes):                                         # (a) node moves
+            if not adj[u]:
+                continue
+            to = {}
+            for v, c in adj[u].items():
+                to[int(lab[v])] = to.get(int(lab[v]), 0.0) + c
+            stay = to.get(int(lab[u]), 0.0)                              # what cutting u out of its cluster would cost
+            best, gain = None, eps
+            for c_lab in sorted(to):
+                if c_lab != lab[u] and to[c_lab] - stay > gain:
+                    best, gain = c_lab, to[c_lab] - stay
+            if -stay > gain:                                            # a cluster of its own
+                best, gain = next_label, -stay
+            if best is not None:
+                if best == next_label:
+                    next_label += 1
+                lab[u] = best
+                changed = True
+        between = {}                                                     # (b) cluster joins
+        for (u, v), c in zip(uv.tolist(), w.tolist()):
+            a, b = int(lab[u]), int(lab[v])
+            if a != b:
+                key = (a, b) if a < b else (b, a)
+                between[key] = between.get(key, 0.0) + c
+        for (a, b) in sorted(between):
+            if between[(a, b)] > eps:
+                # (one join per sweep and pair; the sums of the other pairs are recomputed in the next sweep)
+                lab[lab == b] = a
+                changed = True
+                break
+        if not changed:
+            break
+    _, first = np.unique(lab, return_index=True)
+    order = np.argsort(first)
+    lut = np.empty(len(order), dtype=np.int64)
+    lut[order] = np.arange(len(order))
+    return lut[np.searchsorted(np.sort(np.unique(lab)), lab)]
+
+
 def _relabel_sequential(seg: np.ndarray, offset: int = 1) -> np.ndarray:
     """``skimage.segmentation.relabel_sequential(seg, offset)[0]``: non-zero labels -> offset, offset + 1, ... in ascending order."""
     ids = np.unique(seg)
@@ -495,6 +561,7 @@ def merge_instance_segmentation_3d(slice_segmentation: np.ndarray, beta: float =
     if with_background:
         costs[(uv_ids == 0).any(axis=1)] = -8.0
     node_labels = multicut_gaec(n_nodes, uv_ids, 1.0 - costs)
+    node_labels = multicut_refine(n_nodes, uv_ids, 1.0 - costs, node_labels)          # Kernighan-Lin style local search on GAEC's result
     if node_labels[0] != 0:                                 # keep the background at label 0
         node_labels = np.where(node_labels == node_labels[0], 0, np.where(node_labels < node_labels[0], node_labels + 1, node_labels))
     segmentation = node_labels[slice_segmentation].astype(slice_segmentation.dtype)

@@ -101,3 +101,48 @@ def test_ids_must_be_unique_across_slices():
     bad = ok.copy(); bad[2, 3] = 1
     with pytest.raises(ValueError, match="unique across slices"):
         M._check_ids_unique_per_slice(bad)
+
+
+def test_multicut_solver_against_the_exact_optimum_on_small_graphs():
+    """The reference's solver (elf multicut_decomposition: Kernighan-Lin warm-started by GAEC) is absent; ours is GAEC + a Kernighan-Lin
+    style local search (multicut_refine).  What can be pinned without the library is the objective: on random small graphs the exact
+    optimum comes from enumeration (oracle/multicut_ref.py).  (1) refinement never increases GAEC's objective; (2) on forests - most
+    slice-overlap graphs: an object overlapping one object above and one below - GAEC alone is exact (join the positive edges, cut the
+    negative ones); (3) on dense cyclic graphs with mixed signs the refined solution is optimal in the large majority of cases and its
+    excess objective is small - the numbers are printed and floored."""
+    from oracle import multicut_ref as R
+    rng = np.random.default_rng(0)
+    # (2) forests
+    for _ in range(40):
+        n = int(rng.integers(2, 10))
+        uv = np.array([[int(rng.integers(0, v)), v] for v in range(1, n)])               # a random tree
+        w = rng.normal(0, 2, len(uv))
+        lab = M.multicut_gaec(n, uv, w)
+        _, e_opt = R.optimal_multicut(n, uv, w)
+        assert abs(M.multicut_energy(uv, w, lab) - e_opt) < 1e-9
+        assert np.array_equal(M.multicut_refine(n, uv, w, lab), lab)
+        for (a, b), c in zip(uv, w):
+            assert (lab[a] == lab[b]) == (c > 0)
+    # (1) + (3) dense graphs with cycles
+    n_opt_gaec = n_opt_ref = total = 0
+    excess = []
+    for _ in range(150):
+        n = int(rng.integers(4, 9))
+        pairs = [(a, b) for a in range(n) for b in range(a + 1, n) if rng.random() < 0.6]
+        if not pairs:
+            continue
+        uv = np.array(pairs)
+        w = rng.normal(0.3, 2, len(uv))
+        g = M.multicut_gaec(n, uv, w)
+        r = M.multicut_refine(n, uv, w, g)
+        e_g, e_r = M.multicut_energy(uv, w, g), M.multicut_energy(uv, w, r)
+        _, e_opt = R.optimal_multicut(n, uv, w)
+        assert e_r <= e_g + 1e-9 and e_opt <= e_r + 1e-9
+        total += 1
+        n_opt_gaec += abs(e_g - e_opt) < 1e-9
+        n_opt_ref += abs(e_r - e_opt) < 1e-9
+        excess.append((e_r - e_opt) / max(np.abs(w).sum(), 1e-9))
+    print(f"\nmulticut on {total} random cyclic graphs: GAEC optimal in {n_opt_gaec}, GAEC + refinement in {n_opt_ref}; "
+          f"mean excess objective {np.mean(excess):.4f} of sum |w|, max {np.max(excess):.4f}")
+    # measured: GAEC optimal in 142 of 149, with the refinement 143; mean excess 0.001 of sum |w|, max 0.064
+    assert n_opt_ref >= n_opt_gaec and n_opt_ref >= 0.9 * total and np.mean(excess) <= 0.005 and np.max(excess) <= 0.1
