@@ -177,3 +177,35 @@ def test_strict_vit_h_embedding_vs_the_committed_fp32_golden():
     # (the golden stores float16 samples of the fp32 embedding: 2^-11 relative = 5e-4 at unit scale is the golden's own resolution)
     assert rec["max_abs_err"] <= 3e-3 and rec["mean_abs_err"] <= 3e-4, rec
     assert abs(out.double().abs().sum().item() - float(gold["abs_sum_fp32"])) / float(gold["abs_sum_fp32"]) < 2e-5
+
+
+def test_strict_mode_through_the_pipelined_slice_loop_and_the_tiled_generator(model):
+    """The strict mode behind the product's concurrent paths: segment_slices' device pipeline (encoder batches + decode lanes: the lane
+    views pick the mode up from the main model) gives the labels of the per-slice strict loop, and a TiledAutomaticMaskGenerator (tiles on
+    three lanes) those of its serial form."""
+    from micro_sam_amd import multi_dimensional_segmentation as mds
+    from micro_sam_amd import util
+    from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator, TiledAutomaticMaskGenerator
+    from micro_sam_amd.synthetic import synthetic_tile
+    predictor, _ = model
+    predictor.set_precision("strict")
+    vol = np.stack([synthetic_tile(80 + z, (512, 512)) for z in range(3)])
+    kw = dict(pred_iou_thresh=0.5, stability_score_thresh=0.5)
+    amg = AutomaticMaskGenerator(predictor, points_per_side=6)
+    seg, _ = mds.segment_slices(vol, predictor, amg, batch_size=2, **kw)                      # pipelined (lanes)
+    ref, _ = mds.segment_slices(vol, predictor, AutomaticMaskGenerator(predictor, points_per_side=6), batch_size=2, decode_lanes=0, **kw)
+    assert seg.max() > 5 and np.array_equal(seg, ref)
+    lanes = amg._decode_lanes(2)
+    assert all(clone._predictor.model.precision == "strict" for clone, _ in lanes)
+    img = synthetic_tile(90, (700, 900))
+    outs = []
+    for tl in (3, 1):
+        t = TiledAutomaticMaskGenerator(predictor, points_per_side=6, tile_lanes=tl)
+        t.initialize(img, tile_shape=(384, 384), halo=(64, 64))
+        outs.append(t.generate(**kw))
+    assert outs[0].max() > 5 and np.array_equal(outs[0], outs[1])
+    predictor.set_precision("default")                                                       # lanes follow the switch back
+    seg_d, _ = mds.segment_slices(vol, predictor, amg, batch_size=2, **kw)
+    assert all(clone._predictor.model.precision == "default" for clone, _ in amg._decode_lanes(2))
+    assert ((seg_d > 0) == (seg > 0)).mean() > 0.99
+    predictor.set_precision("strict")
