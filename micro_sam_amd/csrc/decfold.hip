@@ -789,6 +789,7 @@ void msam_gemm_set_g3(int delay);
 void msam_gemm_set_g3_epi(int v);
 extern int g_tune_tok_fuse;
 extern int g_tune_mlp_split_fused;
+extern int g_tune_sgemm_bufs, g_tune_srel_mfma, g_tune_sgemm_small_below;
 int g_tune_dec_chain = 1, g_tune_dec_chain_min_p = 128;
 extern "C" int msam_tune_set(const char* key, int32_t value) {
     const std::string k = key ? key : "";
@@ -807,6 +808,9 @@ extern "C" int msam_tune_set(const char* key, int32_t value) {
     else if (k == "tok_fuse") g_tune_tok_fuse = value;
     else if (k == "mlp_split_fused") g_tune_mlp_split_fused = value;
     else if (k == "dec_chain_min_p") g_tune_dec_chain_min_p = value;
+    else if (k == "sgemm_bufs") g_tune_sgemm_bufs = value;
+    else if (k == "srel_mfma") g_tune_srel_mfma = value;
+    else if (k == "sgemm_small_below") g_tune_sgemm_small_below = value;
     else { msam_set_error("msam_tune_set: unknown key"); return 1; }
     return 0;
 }

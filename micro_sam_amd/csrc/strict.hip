@@ -19,6 +19,9 @@
 
 void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
+int g_tune_sgemm_bufs = 1;               // msam_tune_set("sgemm_bufs", 1 | 2): LDS stages of sgemm_kernel (1: three workgroups per CU, +9 % on the encoder's shapes)
+int g_tune_sgemm_small_below = 512;      // msam_tune_set("sgemm_small_below", n): launches of fewer than n 128 x 128 tiles run on 64 x 64 tiles
+int g_tune_srel_mfma = 1;                // msam_tune_set("srel_mfma", 0 | 1): global attention on srelpos_mfma_kernel (0: the vector-unit kernel)
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 MSAM_DEVINL f32x16_t mfma32f(float a, float b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -46,39 +49,121 @@ struct SGemmArgs {
     int shuf_h, shuf_w, shuf_c;                          // 2 x 2 / stride 2 transposed convolution: column (ky*2+kx)*shuf_c + co of input pixel
 };                                                       // (b, y, x) is stored at output pixel (b, 2y+ky, 2x+kx), channel co
 
+// The epilogue of one wave's 64 x 64 block.  D of a 32 x 32 MFMA tile: lane (col = l & 31, half = l >> 5), register r -> row
+// (r & 3) + 8 (r >> 2) + 4 half.  Everything that depends on the row only (bounds, the residual's row, the pixel a transposed convolution
+// scatters to) is computed once per row, everything that depends on the column only once per column; the activation is a template
+// parameter.  (The first version decided all of it per element - 64 copies of erff, expf and four 64-bit divisions in the instruction
+// stream, about 50 000 cycles per wave whatever the shape: profiles/r05_experiments.md section 7.)
+template <int ACT>
+MSAM_DEVINL float sg_act(float v) {
+    if (ACT == MSAM_ACT_GELU) return gelu_exact(v);
+    if (ACT == MSAM_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == MSAM_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+// MODE 0: bias + activation only; 1: + residual; 2: + BatchNorm scale / shift and the transposed convolution's scatter
+template <int ACT, int MODE, int IT>
+MSAM_DEVINL void sg_store(const SGemmArgs& a, const f32x16_t (&acc)[IT][IT], long m0, int n0, int wm, int wn, int li, int lh) {
+    int n[IT], co[IT];
+    long coff[IT];
+    float bs[IT], cs[IT], ct[IT];
+    const bool scaled = MODE == 2 && a.col_scale != nullptr, shuf = MODE == 2 && a.shuf_c > 0;
+    const float* const resp = MODE >= 1 ? a.res : nullptr;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        n[j] = n0 + wn * (32 * IT) + j * 32 + li;
+        const int nn = n[j] < a.N ? n[j] : a.N - 1;
+        bs[j] = a.bias ? a.bias[nn] : 0.f;
+        cs[j] = scaled ? a.col_scale[nn] : 1.f;
+        ct[j] = scaled ? a.col_shift[nn] : 0.f;
+        const int sub = shuf ? nn / a.shuf_c : 0;
+        co[j] = shuf ? nn - sub * a.shuf_c : nn;
+        coff[j] = shuf ? ((long)(sub >> 1) * (2L * a.shuf_w) + (sub & 1)) * a.ldc + co[j] : (long)co[j];
+    }
+    const bool wrap = resp && a.res_rows < a.M;
+    const long res0 = wrap ? m0 % a.res_rows : m0;
+    const long shw = shuf ? (long)a.shuf_h * a.shuf_w : 1;
+    const long sb0 = shuf ? m0 / shw : 0, sp0 = shuf ? m0 - sb0 * shw : 0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int loc = wm * (32 * IT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const long m = m0 + loc;
+            if (m >= a.M) continue;
+            long rr = res0 + loc;
+            if (wrap) while (rr >= a.res_rows) rr -= a.res_rows;
+            long row = m;
+            if (shuf) {
+                long pix = sp0 + loc, b = sb0;
+                while (pix >= shw) { pix -= shw; ++b; }
+                const int y = (int)pix / a.shuf_w, x = (int)pix - y * a.shuf_w;
+                row = (b * 2 * a.shuf_h + 2 * y) * (2L * a.shuf_w) + 2 * x;
+            }
+            const float* rp = resp ? resp + rr * a.ldr : nullptr;
+            float* op = a.out + row * a.ldc;
+#pragma unroll
+            for (int j = 0; j < IT; ++j) {
+                if (n[j] >= a.N) continue;
+                float v = acc[i][j][r] + bs[j];
+                if (scaled) v = v * cs[j] + ct[j];
+                v = sg_act<ACT>(v);
+                if (rp) v += rp[n[j]];
+                op[coff[j]] = v;
+            }
+        }
+}
+
 // CONV: the 3 x 3 gather is done by the tile loader (implicit GEMM): row m = pixel (b, y, x), k = (tap, c) -> x[b][y + tap/3 - 1][x + tap%3 - 1][c],
 // zero outside the image (the reference's padding=1) - no im2col matrix in HBM (4.8 GB for the 1024^2 x 128-channel head of the UNETR decoder).
-template <bool CONV>
-__global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[2][128 * SG_PITCH];
-    __shared__ __attribute__((aligned(16))) float Ws[2][128 * SG_PITCH];
+// NBUF 2: two LDS stages, one barrier per k-tile, two workgroups per CU; NBUF 1: one stage, two barriers, three workgroups per CU.
+// IT 2: 128 x 128 tile (a wave: 2 x 2 MFMA tiles); IT 1: 64 x 64 tile (a wave: one MFMA tile) for the launches that would not fill the
+// chip with 128 x 128 tiles - the token side of the two-way transformer (M = 7 tokens x 128 prompts), the heads, the encoder at batch 1:
+// a quarter of the serial MFMA chain per wave, four times the workgroups.  An element's k order is the same in every variant.
+template <bool CONV, int NBUF, int IT>
+__global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_kernel(SGemmArgs a) {
+    constexpr int TM = 64 * IT, NJ = TM / 32;
+    __shared__ __attribute__((aligned(16))) float As[NBUF][TM * SG_PITCH];
+    __shared__ __attribute__((aligned(16))) float Ws[NBUF][TM * SG_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ntn = (a.N + 127) / 128;
+    const int ntn = (a.N + TM - 1) / TM;
     const long bid = blockIdx.x;
     const int tn = (int)(bid % ntn);
-    const long m0 = (bid / ntn) * 128;
-    const int n0 = tn * 128;
+    const long m0 = (bid / ntn) * TM;
+    const int n0 = tn * TM;
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
-    const float* ap[4]; const float* a2p[4]; const float* wp[4];
-    int py[4], px[4];
+    const float* ap[NJ]; const float* a2p[NJ]; const float* wp[NJ];
+    int py[NJ], px[NJ];
+    // 64-bit remainders once per block (m0 is uniform), the block's 128 consecutive rows by add-and-wrap
+    const long conv_hw = CONV ? (long)a.conv_h * a.conv_w : 1;
+    const long pix0 = CONV ? m0 % conv_hw : 0;
+    const long a2r0 = (!CONV && a.A2) ? m0 % a.a2_rows : 0;
+    const long mlast = a.M - 1 - m0;                    // rows past M re-read the last row (their results are not stored)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        long m = m0 + srow + 32 * j;
-        if (m >= a.M) m = a.M - 1;
+    for (int j = 0; j < NJ; ++j) {
+        long loc = srow + 32 * j;
+        if (loc > mlast) loc = mlast;
+        const long m = m0 + loc;
         if (CONV) {
-            const long pix = m % ((long)a.conv_h * a.conv_w);
-            py[j] = (int)(pix / a.conv_w); px[j] = (int)(pix % a.conv_w);
+            long pix = pix0 + loc;
+            while (pix >= conv_hw) pix -= conv_hw;
+            py[j] = (int)pix / a.conv_w; px[j] = (int)pix - py[j] * a.conv_w;
             ap[j] = a.A + m * a.lda;                     // lda = pixel pitch (>= conv_c: the input may be a column slice of a wider buffer)
         } else {
             py[j] = px[j] = 0;
             ap[j] = a.A + m * a.lda + sc4;
         }
-        a2p[j] = (!CONV && a.A2) ? a.A2 + (m % a.a2_rows) * a.lda2 + sc4 : nullptr;
+        a2p[j] = nullptr;
+        if (!CONV && a.A2) {
+            long r2 = a2r0 + loc;
+            while (r2 >= a.a2_rows) r2 -= a.a2_rows;
+            a2p[j] = a.A2 + r2 * a.lda2 + sc4;
+        }
         int n = n0 + srow + 32 * j;
         if (n >= a.N) n = a.N - 1;
         wp[j] = a.W + (long)n * a.ldw + sc4;
     }
-    float4 ra[4], rw[4];
+    float4 ra[NJ], rw[NJ];
     auto gload = [&](int k0) {
         const bool in = k0 + sc4 < a.K;
         int dy = 0, dx = 0, coff = 0;
@@ -88,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
             coff = (dy * a.conv_w + dx) * (int)a.lda + (k - tap * a.conv_c);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float4 v = zero4(), u = zero4();
             if (in) {
                 if (CONV) {
@@ -104,16 +189,16 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             *(float4*)&As[buf][(srow + 32 * j) * SG_PITCH + sc4] = ra[j];
             *(float4*)&Ws[buf][(srow + 32 * j) * SG_PITCH + sc4] = rw[j];
         }
     };
-    f32x16_t acc[2][2];
+    f32x16_t acc[IT][IT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < IT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int wm = w >> 1, wn = w & 1, li = lane & 31, lh = lane >> 5;
@@ -123,54 +208,42 @@ __global__ __launch_bounds__(256, 2) void sgemm_kernel(SGemmArgs a) {
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload((kt + 1) * 32);
-        const float* pa = &As[kt & 1][(wm * 64 + li) * SG_PITCH + lh * 16];
-        const float* pw = &Ws[kt & 1][(wn * 64 + li) * SG_PITCH + lh * 16];
+        const float* pa = &As[kt & (NBUF - 1)][(wm * (TM / 2) + li) * SG_PITCH + lh * 16];
+        const float* pw = &Ws[kt & (NBUF - 1)][(wn * (TM / 2) + li) * SG_PITCH + lh * 16];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const float4 a0 = ld4(pa + s4 * 4), a1 = ld4(pa + 32 * SG_PITCH + s4 * 4);
-            const float4 b0 = ld4(pw + s4 * 4), b1 = ld4(pw + 32 * SG_PITCH + s4 * 4);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            float av[IT][4], bv[IT][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = mfma32f(av0[e], bv0[e], acc[0][0]);
-                acc[0][1] = mfma32f(av0[e], bv1[e], acc[0][1]);
-                acc[1][0] = mfma32f(av1[e], bv0[e], acc[1][0]);
-                acc[1][1] = mfma32f(av1[e], bv1[e], acc[1][1]);
+            for (int i = 0; i < IT; ++i) {
+                const float4 t = ld4(pa + i * 32 * SG_PITCH + s4 * 4), u = ld4(pw + i * 32 * SG_PITCH + s4 * 4);
+                av[i][0] = t.x; av[i][1] = t.y; av[i][2] = t.z; av[i][3] = t.w;
+                bv[i][0] = u.x; bv[i][1] = u.y; bv[i][2] = u.z; bv[i][3] = u.w;
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+#pragma unroll
+                    for (int j = 0; j < IT; ++j) acc[i][j] = mfma32f(av[i][e], bv[j][e], acc[i][j]);
         }
-        if (kt + 1 < nk) sstore((kt + 1) & 1);
+        if (NBUF == 1) __syncthreads();
+        if (kt + 1 < nk) sstore((kt + 1) & (NBUF - 1));
         __syncthreads();
     }
-    // D of the 32 x 32 tile: lane (col = l & 31, half = l >> 5), register r -> row (r & 3) + 8 (r >> 2) + 4 half
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + li;
-            if (n >= a.N) continue;
-            const float bs = a.bias ? a.bias[n] : 0.f;
-            const float cs = a.col_scale ? a.col_scale[n] : 1.f, ct = a.col_scale ? a.col_shift[n] : 0.f;
-            const int sub = a.shuf_c > 0 ? n / a.shuf_c : 0, co = a.shuf_c > 0 ? n - sub * a.shuf_c : n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= a.M) continue;
-                float v = acc[i][j][r] + bs;
-                if (a.col_scale) v = v * cs + ct;
-                if (a.act == MSAM_ACT_GELU) v = gelu_exact(v);
-                else if (a.act == MSAM_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (a.act == MSAM_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-                if (a.res) v += a.res[(a.res_rows >= a.M ? m : m % a.res_rows) * a.ldr + n];
-                long row = m;
-                if (a.shuf_c > 0) {
-                    const long hw = (long)a.shuf_h * a.shuf_w, b = m / hw, pix = m - b * hw;
-                    const int y = (int)(pix / a.shuf_w), x = (int)(pix - (long)y * a.shuf_w);
-                    row = (b * 2 * a.shuf_h + 2 * y + (sub >> 1)) * (2L * a.shuf_w) + 2 * x + (sub & 1);
-                }
-                a.out[row * a.ldc + co] = v;
-            }
-        }
+    const int mode = (a.col_scale || a.shuf_c > 0) ? 2 : a.res ? 1 : 0;
+#define MSAM_SG_STORE(ACT_)                                                                                                           \
+    do {                                                                                                                              \
+        if (mode == 0) sg_store<ACT_, 0, IT>(a, acc, m0, n0, wm, wn, li, lh);                                                             \
+        else if (mode == 1) sg_store<ACT_, 1, IT>(a, acc, m0, n0, wm, wn, li, lh);                                                        \
+        else sg_store<ACT_, 2, IT>(a, acc, m0, n0, wm, wn, li, lh);                                                                       \
+    } while (0)
+    switch (a.act) {
+        case MSAM_ACT_GELU: MSAM_SG_STORE(MSAM_ACT_GELU); break;
+        case MSAM_ACT_RELU: MSAM_SG_STORE(MSAM_ACT_RELU); break;
+        case MSAM_ACT_SIGMOID: MSAM_SG_STORE(MSAM_ACT_SIGMOID); break;
+        default: MSAM_SG_STORE(MSAM_ACT_NONE); break;
+    }
+#undef MSAM_SG_STORE
 }
 
 // ------------------------------------------------------------------------------------------------------------------ LayerNorm
@@ -338,6 +411,181 @@ __global__ __launch_bounds__(256) void srelpos_kernel(SRelArgs a) {
     float* op = a.out + ((long)b * T + ty * a.G + tx) * a.Dm + h * HD;
 #pragma unroll
     for (int d = 0; d < HD; d += 4) *(float4*)(op + d) = make_float4(acc[d] / l, acc[d + 1] / l, acc[d + 2] / l, acc[d + 3] / l);
+}
+
+// ------------------------------------------------------------------------------------------------------------------ global attention, MFMA
+// The 64 x 64 grid's attention (4096 keys per query, 51.5 GFLOP per block of vit_b and image) on v_mfma_f32_32x32x2_f32 in the
+// TRANSPOSED orientation: S^T = K Qs^T and O^T = V^T P^T, so that in both D layouts a LANE is a QUERY (column = lane & 31) and the
+// registers run over keys (S^T) or head channels (O^T):
+//   * the softmax of a query is register-local - one exchange with lane ^ 32 per tile for the common running maximum; each half keeps
+//     the partial sum of its own 16 keys per tile, added once at the end;
+//   * the exponentials ARE the B operand of the second product: step s of v_mfma_32x32x2 contracts the key pair {key(s, 0), key(s, 1)}
+//     with key(s, h) = (s & 3) + 8 (s >> 2) + 4 h - exactly the key that register s of lane (q, h) holds in the D layout of S^T.  Any
+//     pairing is a valid contraction as long as the A operand agrees: lane (d, h) reads V^T[d][key(s, h)], four consecutive keys per
+//     ds_read_b128 from the tile stored channel-major.
+// One workgroup = 128 queries (two grid rows) of one (image, head), one wave = 32 queries of one grid row; K / V tiles of 32 keys
+// (one half grid row) pass through LDS once per workgroup.  Decomposed relative positions (upstream add_decomposed_rel_pos, UNSCALED
+// query): the column term q . R_w[qw - kw + 63] of the wave's queries against the 95 table rows they can meet is three MFMA tiles
+// before the loop, scattered to LDS as bw[query][kw]; the row term q . R_h[qh - kh + 63] is one value per query and key tile, recomputed
+// on the vector unit whenever kh changes (every second tile) from the table row, which is wave-uniform.
+// score = ((q * scale) . k + rel_h) + rel_w as upstream; expf; IEEE division by the sum.
+constexpr int SM_BWP = 68;                      // bw row pitch (floats)
+constexpr int SM_VP = 36;                       // V^T row pitch: 32 keys + 4
+template <int HD>
+__global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
+    constexpr int S = 64, T = S * S, HH = HD / 2, DT = (HD + 31) / 32, KP = HD + 4, V4 = HD / 4;
+    extern __shared__ __attribute__((aligned(16))) float sm_lds[];
+    float* const bw = sm_lds;                           // [128][SM_BWP]
+    float* const Ks = bw + 128 * SM_BWP;                // [32][KP]
+    float* const Vt = Ks + 32 * KP;                     // [DT * 32][SM_VP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    // workgroups of one (image, head) run on one XCD (round-robin dispatch): they share that head's K / V in its L2
+    const int nb = gridDim.x, per = nb >> 3;
+    const int bid = (nb & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    const int qblk = bid & 31;
+    const int h = (bid >> 5) % a.heads, b = (bid >> 5) / a.heads;
+    const long ld = 3L * a.Dm;
+    const float* const base = a.qkv + (long)b * T * ld + h * HD;
+    const int qh = qblk * 2 + (w >> 1), qw0 = (w & 1) * 32, tq = qh * S + qw0 + li;
+    // the lane's half of its query: channels lh * HH + s
+    float qu[HH], qs[HH];
+    {
+        const float* qp = base + (long)tq * ld + lh * HH;
+#pragma unroll
+        for (int d = 0; d < HH; d += 4) { const float4 t = ld4(qp + d); qu[d] = t.x; qu[d + 1] = t.y; qu[d + 2] = t.z; qu[d + 3] = t.w; }
+    }
+    // column term: G^T[jj][q] = R_w[qw0 + jj] . q for jj < 96, kept at bw[q][kw = li + 63 - jj]
+#pragma unroll 1
+    for (int jt = 0; jt < 3; ++jt) {
+        int j = qw0 + jt * 32 + li;
+        if (j > 2 * S - 2) j = 2 * S - 2;
+        const float* rp = a.rel_w + (long)j * HD + lh * HH;
+        f32x16_t g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+        for (int d = 0; d < HH; d += 4) {
+            const float4 t = ld4(rp + d);
+            g = mfma32f(t.x, qu[d], g); g = mfma32f(t.y, qu[d + 1], g); g = mfma32f(t.z, qu[d + 2], g); g = mfma32f(t.w, qu[d + 3], g);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kw = li + 63 - (jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+            if (kw >= 0 && kw < S) bw[(w * 32 + li) * SM_BWP + kw] = g[r];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HH; ++d) qs[d] = qu[d] * a.scale;
+    for (int i = tid; i < DT * 32 * SM_VP; i += 256) Vt[i] = 0.f;       // HD = 80: channels 80..95 of the third channel tile stay zero
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m = -3.0e38f, l = 0.f, bhv = 0.f;
+    // tile loader: K rows as they are, V transposed
+    constexpr int NLD = (32 * V4 + 255) / 256;
+    float4 rk[NLD], rv[NLD];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 32 * V4) {
+                const float* kp = base + (long)(t * 32 + idx / V4) * ld + a.Dm + (idx % V4) * 4;
+                rk[i] = ld4(kp); rv[i] = ld4(kp + a.Dm);
+            }
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 32 * V4) {
+                const int row = idx / V4, c = (idx % V4) * 4;
+                *(float4*)&Ks[row * KP + c] = rk[i];
+                Vt[(c + 0) * SM_VP + row] = rv[i].x; Vt[(c + 1) * SM_VP + row] = rv[i].y;
+                Vt[(c + 2) * SM_VP + row] = rv[i].z; Vt[(c + 3) * SM_VP + row] = rv[i].w;
+            }
+        }
+    };
+    gload(0);
+    __syncthreads();                                    // the zero fill of Vt
+    sstore();
+    __syncthreads();
+    const float* const bwq = bw + (w * 32 + li) * SM_BWP + 4 * lh;
+#pragma unroll 1
+    for (int t = 0; t < T / 32; ++t) {
+        if (t + 1 < T / 32) gload(t + 1);
+        // S^T tile: 32 keys x the wave's 32 queries
+        f32x16_t sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        const float* kp = Ks + li * KP + lh * HH;
+        if ((t & 1) == 0) {                             // new key row kh = t / 2: the row term, under the MFMAs of this tile
+            const float* rp = a.rel_h + (long)(qh - (t >> 1) + S - 1) * HD + lh * HH;
+            float part = 0.f;
+#pragma unroll
+            for (int d = 0; d < HH; d += 4) {
+                const float4 u = ld4(rp + d);
+                const float4 kk = ld4(kp + d);
+                sc = mfma32f(kk.x, qs[d], sc); sc = mfma32f(kk.y, qs[d + 1], sc); sc = mfma32f(kk.z, qs[d + 2], sc); sc = mfma32f(kk.w, qs[d + 3], sc);
+                part = fmaf(qu[d], u.x, part); part = fmaf(qu[d + 1], u.y, part); part = fmaf(qu[d + 2], u.z, part); part = fmaf(qu[d + 3], u.w, part);
+            }
+            bhv = part + __shfl_xor(part, 32);
+        } else {
+#pragma unroll
+            for (int d = 0; d < HH; d += 4) {
+                const float4 kk = ld4(kp + d);
+                sc = mfma32f(kk.x, qs[d], sc); sc = mfma32f(kk.y, qs[d + 1], sc); sc = mfma32f(kk.z, qs[d + 2], sc); sc = mfma32f(kk.w, qs[d + 3], sc);
+            }
+        }
+        // + rel_h + rel_w, running maximum (register r of lane (q, lh) = key (r & 3) + 8 (r >> 2) + 4 lh of the tile)
+        const float* bp = bwq + (t & 1) * 32;
+        float cm = -3.0e38f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 u = ld4(bp + 8 * g4);
+            sc[4 * g4] = (sc[4 * g4] + bhv) + u.x; sc[4 * g4 + 1] = (sc[4 * g4 + 1] + bhv) + u.y;
+            sc[4 * g4 + 2] = (sc[4 * g4 + 2] + bhv) + u.z; sc[4 * g4 + 3] = (sc[4 * g4 + 3] + bhv) + u.w;
+            cm = fmaxf(fmaxf(cm, fmaxf(sc[4 * g4], sc[4 * g4 + 1])), fmaxf(sc[4 * g4 + 2], sc[4 * g4 + 3]));
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        if (__ballot(mn > m)) {
+            const float alpha = expf(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m = mn;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = expf(sc[r] - m); l += sc[r]; }
+        // O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float* vp = Vt + (dt * 32 + li) * SM_VP + 4 * lh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = ld4(vp + 8 * g4);
+                oacc[dt] = mfma32f(v.x, sc[4 * g4], oacc[dt]); oacc[dt] = mfma32f(v.y, sc[4 * g4 + 1], oacc[dt]);
+                oacc[dt] = mfma32f(v.z, sc[4 * g4 + 2], oacc[dt]); oacc[dt] = mfma32f(v.w, sc[4 * g4 + 3], oacc[dt]);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < T / 32) sstore();
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32);
+    float* op = a.out + ((long)b * T + tq) * a.Dm + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = dt * 32 + 8 * g4 + 4 * lh;
+            if (d < HD) *(float4*)(op + d) = make_float4(oacc[dt][4 * g4] / l, oacc[dt][4 * g4 + 1] / l, oacc[dt][4 * g4 + 2] / l, oacc[dt][4 * g4 + 3] / l);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------------------------ decoder attention
@@ -678,10 +926,22 @@ extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
     a.col_scale = p->col_scale; a.col_shift = p->col_shift;
     a.conv_h = p->conv_h; a.conv_w = p->conv_w; a.conv_c = p->conv_c;
     a.shuf_h = p->shuffle_h; a.shuf_w = p->shuffle_w; a.shuf_c = p->shuffle_c;
-    const long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
+    long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
     if (blocks > 0x7fffffffL) { msam_set_error("msam_strict_gemm: too many tiles for one launch"); return 1; }
-    if (conv) hipLaunchKernelGGL(sgemm_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(sgemm_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    const bool small = blocks < g_tune_sgemm_small_below;        // fewer 128 x 128 tiles than fill the chip: 64 x 64 tiles
+    if (small) blocks = ((p->M + 63) / 64) * (long)((p->N + 63) / 64);
+    const dim3 grid((unsigned)blocks), wg(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (small) {
+        if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 1, 1>), grid, wg, 0, st, a);
+        else hipLaunchKernelGGL((sgemm_kernel<false, 1, 1>), grid, wg, 0, st, a);
+    } else if (g_tune_sgemm_bufs == 1) {
+        if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 1, 2>), grid, wg, 0, st, a);
+        else hipLaunchKernelGGL((sgemm_kernel<false, 1, 2>), grid, wg, 0, st, a);
+    } else {
+        if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 2, 2>), grid, wg, 0, st, a);
+        else hipLaunchKernelGGL((sgemm_kernel<false, 2, 2>), grid, wg, 0, st, a);
+    }
     return msam_check_launch("strict_gemm");
 }
 
@@ -715,6 +975,18 @@ extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_b
         (void)hipFuncSetAttribute((const void*)srelpos_kernel<HD_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((srelpos_kernel<HD_, S_>), dim3((unsigned)blocks), dim3(256), lds, s, a);                                 \
     } while (0)
+    if (!window && g_tune_srel_mfma) {                  // the 64 x 64 grid on the f32-input MFMA
+        const size_t lm = (size_t)(128 * SM_BWP + 32 * (head_dim + 4) + ((head_dim + 31) / 32) * 32 * SM_VP) * sizeof(float);
+        const unsigned gm = (unsigned)(B * heads * 32);
+        if (head_dim == 64) {
+            (void)hipFuncSetAttribute((const void*)srelpos_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+            hipLaunchKernelGGL((srelpos_mfma_kernel<64>), dim3(gm), dim3(256), lm, s, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)srelpos_mfma_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+            hipLaunchKernelGGL((srelpos_mfma_kernel<80>), dim3(gm), dim3(256), lm, s, a);
+        }
+        return msam_check_launch("strict_relpos_attention");
+    }
     if (head_dim == 64) { if (window) MSAM_SREL(64, 14); else MSAM_SREL(64, 64); }
     else { if (window) MSAM_SREL(80, 14); else MSAM_SREL(80, 64); }
 #undef MSAM_SREL

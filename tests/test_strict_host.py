@@ -49,10 +49,19 @@ def _gemm(lib, a, w, bias=None, act=0, a2=None, a2_rows=0, res=None, res_rows=0)
 
 
 @pytest.mark.parametrize("M,N,K", [(150, 200, 36), (5, 4, 256), (260, 32, 4), (128, 128, 64)])
-def test_strict_gemm_every_epilogue(lib, M, N, K):
+@pytest.mark.parametrize("small_below", [0, 512])
+def test_strict_gemm_every_epilogue(lib, M, N, K, small_below):
     g = torch.Generator().manual_seed(M + N + K)
     a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
     bias, a2, res = torch.randn(N, generator=g), torch.randn(7, K, generator=g), torch.randn(11, N, generator=g)
+    assert lib.msam_tune_set(b"sgemm_small_below", small_below) == 0          # 0: the 128 x 128 tile, 512: the 64 x 64 tile at these sizes
+    try:
+        _every_epilogue(lib, M, N, K, a, w, bias, a2, res)
+    finally:
+        assert lib.msam_tune_set(b"sgemm_small_below", 512) == 0
+
+
+def _every_epilogue(lib, M, N, K, a, w, bias, a2, res):
     y = a.double() @ w.double().t()
     tol = 3e-6 * max(1.0, y.abs().max().item())
     assert (_gemm(lib, a, w) - y).abs().max().item() <= tol
@@ -147,7 +156,7 @@ def _relpos_ref(qkv, bqkv, rel_h, rel_w, B, heads, hd, G, window, scale):
     return o.reshape(B * G * G, D)
 
 
-@pytest.mark.parametrize("B,heads,hd,G,window", [(2, 2, 64, 20, 14), (1, 1, 80, 30, 14), (1, 1, 64, 64, 0)])
+@pytest.mark.parametrize("B,heads,hd,G,window", [(2, 2, 64, 20, 14), (1, 1, 80, 30, 14), (1, 1, 64, 64, 0), (1, 1, 80, 64, 0)])
 def test_strict_relpos_attention(lib, B, heads, hd, G, window):
     """Windowed attention on a grid that is not a multiple of the window (the border windows see the qkv bias as their padding tokens,
     exactly as zero-padding AFTER norm1 does in the reference) and the global 64 x 64 form; head_dim 64 and 80 (vit_h)."""
@@ -163,6 +172,35 @@ def test_strict_relpos_attention(lib, B, heads, hd, G, window):
                                             scale, out.data_ptr(), None) == 0, lib.msam_last_error()
     ref = _relpos_ref(qkv, bqkv, rel_h, rel_w, B, heads, hd, G, window, scale)
     assert torch.isfinite(out).all() and (out - ref).abs().max().item() <= 2e-5
+    if not window:
+        # the global form has two kernels: srelpos_mfma_kernel (default; the transposed f32-MFMA formulation) and the vector-unit one
+        out_v = torch.full((B * G * G, D), float("nan"))
+        assert lib.msam_tune_set(b"srel_mfma", 0) == 0
+        try:
+            assert lib.msam_strict_relpos_attention(qkv.data_ptr(), bqkv.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(), B, heads, hd, G, window,
+                                                    scale, out_v.data_ptr(), None) == 0, lib.msam_last_error()
+        finally:
+            assert lib.msam_tune_set(b"srel_mfma", 1) == 0
+        assert (out_v - ref).abs().max().item() <= 2e-5
+        assert not torch.equal(out, out_v) and (out - out_v).abs().max().item() <= 3e-5      # two kernels, two summation orders
+
+
+def test_strict_gemm_tile_variants_give_the_same_bits(lib):
+    """sgemm_kernel<., 1, 2> (128 x 128 tile, one LDS stage, three workgroups per CU: the default of the large launches), <., 2, 2> (two
+    stages) and <., 1, 1> (64 x 64 tiles: launches that would not fill the chip) walk k in the same order."""
+    g = torch.Generator().manual_seed(11)
+    a, w, b = torch.randn(300, 200, generator=g), torch.randn(150, 200, generator=g), torch.randn(150, generator=g)
+    res = torch.randn(100, 150, generator=g)
+    outs = []
+    for bufs, small in ((1, 0), (2, 0), (1, 512)):
+        assert lib.msam_tune_set(b"sgemm_bufs", bufs) == 0 and lib.msam_tune_set(b"sgemm_small_below", small) == 0
+        try:
+            outs.append(_gemm(lib, a, w, b, act=1, res=res, res_rows=100))
+        finally:
+            assert lib.msam_tune_set(b"sgemm_bufs", 1) == 0 and lib.msam_tune_set(b"sgemm_small_below", 512) == 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = torch.nn.functional.gelu(a.double() @ w.double().T + b.double()) + res.double().repeat(3, 1)
+    assert (outs[0] - ref).abs().max().item() <= 1e-4
 
 
 def test_strict_gathers_and_hyper_product(lib):

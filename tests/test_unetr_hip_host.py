@@ -39,8 +39,19 @@ def _nchw(rows, B, H, W):
     return rows.reshape(B, H, W, -1).permute(0, 3, 1, 2)
 
 
-def test_layer_primitives(host):
+@pytest.mark.parametrize("small_below", [512, 0])
+def test_layer_primitives(host, small_below):
+    """(small_below: the implicit-GEMM convolution on the 64 x 64 tile these sizes get by default, and on the 128 x 128 tile of the
+    1024^2 feature maps)"""
     from micro_sam_amd.models import unetr_hip as UH
+    assert host.msam_tune_set(b"sgemm_small_below", small_below) == 0
+    try:
+        _layer_primitives(UH)
+    finally:
+        assert host.msam_tune_set(b"sgemm_small_below", 512) == 0
+
+
+def _layer_primitives(UH):
     g = torch.Generator().manual_seed(0)
     B, H, W, Cin, Cout = 2, 9, 13, 8, 12
     x = torch.randn(B, Cin, H, W, generator=g)

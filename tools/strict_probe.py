@@ -17,6 +17,7 @@ if ROOT not in sys.path:
 
 def timed(fn, reps=3):
     fn()
+    fn()                                  # (the first strict pass also grows torch's caching allocator)
     torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
@@ -31,6 +32,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--tiles", type=int, default=2)
+    ap.add_argument("--modes", default="default,strict")
+    ap.add_argument("--sgemm-bufs", default="", help="comma list of msam_tune_set('sgemm_bufs') values to A/B (strict tile + the product shapes)")
+    ap.add_argument("--srel-mfma", default="", help="comma list of msam_tune_set('srel_mfma') values to A/B (strict encoder time)")
+    ap.add_argument("--ab", default="", help="key=v1,v2,...: msam_tune_set(key, v) for each v, strict tile + encoder time under each (last v stays set)")
     a = ap.parse_args()
     from micro_sam_amd import strict, util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
@@ -46,7 +51,7 @@ def main():
         amg.initialize(tile, emb)
         return amg.generate()
 
-    for mode in ("default", "strict"):
+    for mode in a.modes.split(","):
         predictor.set_precision(mode)
         t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
         t_enc = timed(lambda: [util.precompute_image_embeddings(predictor, t, verbose=False) for t in tiles]) / len(tiles)
@@ -57,15 +62,41 @@ def main():
     shapes = {"enc_qkv": (4096 * 4, 2304, 768), "enc_lin1": (4096 * 4, 3072, 768), "enc_lin2": (4096 * 4, 768, 3072),
               "dec_t2i_kv": (128 * 4096, 128, 256), "dec_up1": (128 * 4096, 256, 256), "dec_up2": (128 * 16384, 128, 64),
               "dec_i2t_out": (128 * 4096, 256, 128)}
-    g = {}
-    for name, (M, N, K) in shapes.items():
-        A = torch.randn(M, K, device=dev)
-        W = torch.randn(N, K, device=dev) / K ** 0.5
-        out = torch.empty(M, N, device=dev)
-        t = timed(lambda: strict.gemm(A, W, out=out), reps=5)
-        g[name] = {"M": M, "N": N, "K": K, "us": round(t * 1e6, 1), "tflops": round(2.0 * M * N * K / t / 1e12, 1),
-                   "gbytes_per_s": round((M * K + M * N) * 4 / t / 1e9, 0)}
-    rec["strict_gemm"] = g
+    from micro_sam_amd import _lib
+
+    def products():
+        g = {}
+        for name, (M, N, K) in shapes.items():
+            A = torch.randn(M, K, device=dev)
+            W = torch.randn(N, K, device=dev) / K ** 0.5
+            out = torch.empty(M, N, device=dev)
+            t = timed(lambda: strict.gemm(A, W, out=out), reps=5)
+            g[name] = {"M": M, "N": N, "K": K, "us": round(t * 1e6, 1), "tflops": round(2.0 * M * N * K / t / 1e12, 1),
+                       "gbytes_per_s": round((M * K + M * N) * 4 / t / 1e9, 0)}
+        return g
+    rec["strict_gemm"] = products()
+    for v in filter(None, a.sgemm_bufs.split(",")):
+        _lib.check(_lib.load().msam_tune_set(b"sgemm_bufs", int(v)), "msam_tune_set")
+        predictor.set_precision("strict")
+        t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
+        rec[f"sgemm_bufs_{v}"] = {"strict_seconds_per_tile_api_loop": round(t_tile, 4), "strict_gemm": products()}
+    if a.sgemm_bufs:
+        _lib.check(_lib.load().msam_tune_set(b"sgemm_bufs", 1), "msam_tune_set")
+    for v in filter(None, a.srel_mfma.split(",")):
+        _lib.check(_lib.load().msam_tune_set(b"srel_mfma", int(v)), "msam_tune_set")
+        predictor.set_precision("strict")
+        t_enc = timed(lambda: [util.precompute_image_embeddings(predictor, t, verbose=False) for t in tiles]) / len(tiles)
+        rec[f"srel_mfma_{v}"] = {"strict_encoder_seconds_per_tile": round(t_enc, 5)}
+    if a.srel_mfma:
+        _lib.check(_lib.load().msam_tune_set(b"srel_mfma", 1), "msam_tune_set")
+    if a.ab:
+        key, vals = a.ab.split("=")
+        for v in vals.split(","):
+            _lib.check(_lib.load().msam_tune_set(key.encode(), int(v)), "msam_tune_set")
+            predictor.set_precision("strict")
+            t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
+            t_enc = timed(lambda: [util.precompute_image_embeddings(predictor, t, verbose=False) for t in tiles]) / len(tiles)
+            rec[f"{key}_{v}"] = {"strict_seconds_per_tile_api_loop": round(t_tile, 5), "strict_encoder_seconds_per_tile": round(t_enc, 5)}
     rec["fp32_mfma_peak_tflops"] = 157.3
     line = json.dumps(rec)
     print(line)
