@@ -665,6 +665,24 @@ int msam_strict_layernorm(const float* x, const float* weight, const float* bias
  * [B * grid^2, heads * head_dim]. */
 int msam_strict_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
                                  int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream);
+/* The "image attends to the tokens" step of one TwoWayAttentionBlock on the per-prompt image stream in ONE launch (segment_anything
+ * modeling/transformer.py TwoWayAttentionBlock.forward: q = keys + key_pe; attn_out = cross_attn_image_to_token(q, k, v);
+ * keys = norm4(keys + attn_out)), 4096 image tokens x 256 channels per prompt, 8 heads x 16 channels in the attention:
+ *   out[b] = LayerNorm(keys[b] + softmax(((keys[b] + pos) Wq^T + bq) . tok_k[b] / denom) tok_v[b] Wo^T + bo)
+ * keys fp32 [B][4096][256] (key_batch_stride 0: one [4096][256] stream shared by every prompt - layer 0 without mask prompts; then out must
+ * be another buffer), pos [4096][256], wq [128][256], wo [256][128], tok_k / tok_v [B][Tk <= 16][128] (row stride ld_tok, batch stride
+ * tok_batch_stride; the token side's k / v projections, computed by msam_strict_gemm), out [B][4096][256] (may be keys when per prompt). */
+typedef struct msam_si2t {
+    const float* keys; int64_t key_batch_stride;
+    const float* pos;
+    const float* wq; const float* bq;
+    const float* tok_k; const float* tok_v; int64_t ld_tok, tok_batch_stride;
+    const float* wo; const float* bo;
+    const float* ln_weight; const float* ln_bias; float ln_eps; float denom;
+    float* out;
+    int32_t B, Tk;
+} msam_si2t_t;
+int msam_strict_i2t_block(const msam_si2t_t* p, void* stream);
 /* Attention of the two-way transformer: q fp32 [B, Nq, H * D] (row stride ldq, batch stride in floats; 0 = one tensor shared by every
  * batch entry), k / v [B, Nk, H * D], out [B, Nq, H * D]; softmax((q . k) / denom) @ v; D = 16 or 32, Nq <= 16 or Nk <= 16. */
 int msam_strict_attention(const float* q, int64_t ldq, int64_t q_batch_stride, const float* k, int64_t ldk, int64_t k_batch_stride,

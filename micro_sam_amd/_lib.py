@@ -102,6 +102,13 @@ class SGemmParams(C.Structure):
                 ("shuffle_h", _i32), ("shuffle_w", _i32), ("shuffle_c", _i32)]
 
 
+class SI2TParams(C.Structure):
+    """include/msam_hip.h msam_si2t_t (the strict mode's fused image -> token block)."""
+    _fields_ = [("keys", _vp), ("key_batch_stride", _i64), ("pos", _vp), ("wq", _vp), ("bq", _vp), ("tok_k", _vp), ("tok_v", _vp),
+                ("ld_tok", _i64), ("tok_batch_stride", _i64), ("wo", _vp), ("bo", _vp), ("ln_weight", _vp), ("ln_bias", _vp),
+                ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32)]
+
+
 class MaskPromptParams(C.Structure):
     """include/msam_hip.h msam_mask_prompt_t: fp32 weights of prompt_encoder.mask_downscaling."""
     _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "ln1_w", "ln1_b", "c2_w", "c2_b", "ln2_w", "ln2_b", "c3_w", "c3_b")] + [("exact_gelu", _i32)]
@@ -211,6 +218,7 @@ _PROTOS = {
     "msam_paint_label_image": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "msam_label_components": (_i32, [_vp, _i32, _i32, _vp, _vp, _i32, C.POINTER(_i32), _vp]),
     "msam_strict_gemm": (_i32, [C.POINTER(SGemmParams), _vp]),
+    "msam_strict_i2t_block": (_i32, [C.POINTER(SI2TParams), _vp]),
     "msam_strict_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _vp]),
     "msam_strict_relpos_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "msam_strict_attention": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64,

@@ -588,6 +588,237 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ image -> token block
+// One launch for the whole "image attends to the tokens" step of a TwoWayAttentionBlock (upstream transformer.py: q = keys + key_pe;
+// attn_out = cross_attn_image_to_token(q, k = queries + query_pe, v = queries); keys = norm4(keys + attn_out)) over the per-prompt image
+// stream - as separate launches (q projection, sattn_short, out projection + residual, LayerNorm) the 0.5 GB stream of a 128-prompt
+// chunk crosses HBM seven times, here twice.  Both projections run in the TRANSPOSED orientation (the weights are the A operand, the
+// image rows the B operand), so a lane is an image row in every D layout and the lane pair (row, half 0 / 1) holds the row's channels:
+//   Q^T [128 ch x 32 rows per wave]: k pairing h * 16 + s as sgemm_kernel - the projection's bits are those of the separate launch;
+//   attention: 8 heads x Tk <= 16 tokens, a head's 16 channels are 8 registers in each lane of the pair (one exchange per score);
+//   out^T = W_o att^T: the attention's registers ARE the B operand (step s contracts the channel pair the two lanes hold in register s);
+//   + bias + residual, LayerNorm over the row's 256 channels (two passes, one exchange each), all in registers;
+//   residual tiles in and result tiles out pass a wave-private LDS tile so that HBM sees whole 128-byte rows.
+struct SI2TArgs {
+    const float* keys; long key_bs;                     // [B or 1][4096][256]; batch stride 0: one stream shared by every prompt (layer 0)
+    const float* pos;                                   // [4096][256] dense positional encoding
+    const float* wq; const float* bq;                   // [128][256], [128]
+    const float* tk; const float* tv; long ldt, tok_bs; // token-side k / v projections [B][Tk][128]
+    const float* wo; const float* bo;                   // [256][128], [256]
+    const float* lnw; const float* lnb; float eps, denom;
+    float* out;                                         // [B][4096][256] (may be `keys` when that is per prompt)
+    int B, Tk;
+};
+
+__global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
+    constexpr int C = 256, CI = 128, P = SG_PITCH;
+    __shared__ __attribute__((aligned(16))) float Xs[128 * P];     // projection 1: the (keys + pos) k-tile; epilogue: four wave-private [32][P] tiles
+    __shared__ __attribute__((aligned(16))) float Wt[256 * P];     // weight k-tile: W_q (128 rows), then W_o (256 rows)
+    __shared__ __attribute__((aligned(16))) float tks[16 * CI];
+    __shared__ __attribute__((aligned(16))) float tvs[16 * CI];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int b = (int)(blockIdx.x >> 5), rb = (int)(blockIdx.x & 31);
+    const float* const kin = a.keys + (long)b * a.key_bs + (long)rb * 128 * C;
+    const float* const pin = a.pos + (long)rb * 128 * C;
+    float* const outp = a.out + ((long)b * 4096 + rb * 128) * C;
+    for (int i = tid; i < a.Tk * 32; i += 256) {
+        const int t = i >> 5, c4 = (i & 31) * 4;
+        *(float4*)&tks[t * CI + c4] = ld4(a.tk + (long)b * a.tok_bs + (long)t * a.ldt + c4);
+        *(float4*)&tvs[t * CI + c4] = ld4(a.tv + (long)b * a.tok_bs + (long)t * a.ldt + c4);
+    }
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+    float4 rx[4], rw[8];
+    auto load1 = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long o = (long)(srow + 32 * j) * C + kt * 32 + sc4;
+            const float4 x = ld4(kin + o), pe = ld4(pin + o);
+            rx[j] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, x.w + pe.w);
+            rw[j] = ld4(a.wq + o);
+        }
+    };
+    auto store1 = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(float4*)&Xs[(srow + 32 * j) * P + sc4] = rx[j];
+            *(float4*)&Wt[(srow + 32 * j) * P + sc4] = rw[j];
+        }
+    };
+    // W_o k-tile: thread = output channel, its 32 k values are 128 contiguous bytes (one pointer, immediate offsets: the registers
+    // of this phase go to the 64 + 128 accumulators)
+    const float* const wop = a.wo + (long)tid * CI;
+    auto load3 = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rw[j] = ld4(wop + kt * 32 + 4 * j);
+    };
+    auto store3 = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(float4*)&Wt[tid * P + 4 * j] = rw[j];
+    };
+    // ---- Q^T = W_q (keys + pos)^T
+    f32x16_t q[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[nt][r] = 0.f;
+    load1(0);
+    store1();
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < C / 32; ++kt) {
+        if (kt + 1 < C / 32) load1(kt + 1);
+        const float* px = &Xs[(w * 32 + li) * P + lh * 16];
+        const float* pw = &Wt[li * P + lh * 16];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 xb = ld4(px + s4 * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float4 wa = ld4(pw + nt * 32 * P + s4 * 4);
+                q[nt] = mfma32f(wa.x, xb.x, q[nt]); q[nt] = mfma32f(wa.y, xb.y, q[nt]);
+                q[nt] = mfma32f(wa.z, xb.z, q[nt]); q[nt] = mfma32f(wa.w, xb.w, q[nt]);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < C / 32) store1();
+        __syncthreads();
+    }
+    load3(0);                                           // W_o's first k-tile arrives under the attention
+    // register r of tile nt = channel nt * 32 + (r & 3) + 8 (r >> 2) + 4 lh: registers 0..7 belong to head 2 nt, 8..15 to head 2 nt + 1
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 bb = ld4(a.bq + nt * 32 + 8 * g4 + 4 * lh);
+            q[nt][4 * g4] += bb.x; q[nt][4 * g4 + 1] += bb.y; q[nt][4 * g4 + 2] += bb.z; q[nt][4 * g4 + 3] += bb.w;
+        }
+    // ---- softmax((q . k) / denom) v per head, in place over q
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int c0 = nt * 32 + 16 * g + 4 * lh;   // the lane's channels of this head: c0 .. c0 + 3 and c0 + 8 .. c0 + 11
+            float sc[16];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                sc[t] = -3.0e38f;
+                if (t < a.Tk) {
+                    const float4 k0 = ld4(&tks[t * CI + c0]), k1 = ld4(&tks[t * CI + c0 + 8]);
+                    float part = q[nt][8 * g] * k0.x;
+                    part = fmaf(q[nt][8 * g + 1], k0.y, part); part = fmaf(q[nt][8 * g + 2], k0.z, part); part = fmaf(q[nt][8 * g + 3], k0.w, part);
+                    part = fmaf(q[nt][8 * g + 4], k1.x, part); part = fmaf(q[nt][8 * g + 5], k1.y, part);
+                    part = fmaf(q[nt][8 * g + 6], k1.z, part); part = fmaf(q[nt][8 * g + 7], k1.w, part);
+                    const float other = __shfl_xor(part, 32);
+                    sc[t] = (lh ? other + part : part + other) / a.denom;        // the same sum in both lanes of the pair
+                    mx = fmaxf(mx, sc[t]);
+                }
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { sc[t] = t < a.Tk ? expf(sc[t] - mx) : 0.f; l += sc[t]; }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < a.Tk) {
+                    const float pr = sc[t] / l;
+                    const float4 v0 = ld4(&tvs[t * CI + c0]), v1 = ld4(&tvs[t * CI + c0 + 8]);
+                    o[0] = fmaf(pr, v0.x, o[0]); o[1] = fmaf(pr, v0.y, o[1]); o[2] = fmaf(pr, v0.z, o[2]); o[3] = fmaf(pr, v0.w, o[3]);
+                    o[4] = fmaf(pr, v1.x, o[4]); o[5] = fmaf(pr, v1.y, o[5]); o[6] = fmaf(pr, v1.z, o[6]); o[7] = fmaf(pr, v1.w, o[7]);
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[nt][8 * g + e] = o[e];
+        }
+    // ---- out^T = W_o att^T
+    f32x16_t oa[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oa[ot][r] = 0.f;
+    store3();
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < CI / 32; ++kt) {
+        const float* pw = &Wt[li * P + 4 * lh];
+        // one W_o fragment ahead of the MFMAs, no further (sched_barrier): 192 accumulator registers are live here
+        float4 wa = ld4(pw);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) {
+                const int nx = g4 * 8 + ot + 1;
+                const float4 wn = nx < 32 ? ld4(pw + (nx & 7) * 32 * P + 8 * (nx >> 3)) : wa;
+                oa[ot] = mfma32f(wa.x, q[kt][4 * g4], oa[ot]); oa[ot] = mfma32f(wa.y, q[kt][4 * g4 + 1], oa[ot]);
+                oa[ot] = mfma32f(wa.z, q[kt][4 * g4 + 2], oa[ot]); oa[ot] = mfma32f(wa.w, q[kt][4 * g4 + 3], oa[ot]);
+                __builtin_amdgcn_sched_barrier(0);
+                wa = wn;
+            }
+        // (the next k-tile is fetched only now: 64 + 128 accumulator registers leave no room for a prefetch across the MFMAs - the other
+        //  workgroup of the CU runs under this latency)
+        if (kt + 1 < CI / 32) load3(kt + 1);
+        __syncthreads();
+        if (kt + 1 < CI / 32) store3();
+        __syncthreads();
+    }
+    // ---- (+ bias) + residual, LayerNorm, store
+    float* const st = &Xs[w * 32 * P];
+    float sum = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        __builtin_amdgcn_sched_barrier(0);              // (keeps the eight tiles' loads from being hoisted above one another: 128 live accumulators)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+            *(float4*)&st[row * P + c4] = ld4(kin + (long)(w * 32 + row) * C + ot * 32 + c4);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 rv = ld4(&st[li * P + 8 * g4 + 4 * lh]), bb = ld4(a.bo + ot * 32 + 8 * g4 + 4 * lh);
+            oa[ot][4 * g4] = (oa[ot][4 * g4] + bb.x) + rv.x; oa[ot][4 * g4 + 1] = (oa[ot][4 * g4 + 1] + bb.y) + rv.y;
+            oa[ot][4 * g4 + 2] = (oa[ot][4 * g4 + 2] + bb.z) + rv.z; oa[ot][4 * g4 + 3] = (oa[ot][4 * g4 + 3] + bb.w) + rv.w;
+            sum += (oa[ot][4 * g4] + oa[ot][4 * g4 + 1]) + (oa[ot][4 * g4 + 2] + oa[ot][4 * g4 + 3]);
+        }
+        __syncthreads();
+    }
+    {
+        const float other = __shfl_xor(sum, 32);
+        sum = lh ? other + sum : sum + other;
+    }
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float d = oa[ot][r] - mean; sq = fmaf(d, d, sq); }
+    {
+        const float other = __shfl_xor(sq, 32);
+        sq = lh ? other + sq : sq + other;
+    }
+    const float rstd = 1.0f / sqrtf(sq / (float)C + a.eps);
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int c = ot * 32 + 8 * g4 + 4 * lh;
+            const float4 ww = ld4(a.lnw + c), bb = ld4(a.lnb + c);
+            *(float4*)&st[li * P + 8 * g4 + 4 * lh] =
+                make_float4((oa[ot][4 * g4] - mean) * rstd * ww.x + bb.x, (oa[ot][4 * g4 + 1] - mean) * rstd * ww.y + bb.y,
+                            (oa[ot][4 * g4 + 2] - mean) * rstd * ww.z + bb.z, (oa[ot][4 * g4 + 3] - mean) * rstd * ww.w + bb.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+            *(float4*)(outp + (long)(w * 32 + row) * C + ot * 32 + c4) = ld4(&st[row * P + c4]);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ decoder attention
 // q [B, Nq, H*D] (row stride ldq, batch stride sqb; 0 = shared by every batch entry), k / v [B, Nk, H*D], out [B, Nq, H*D] rows ldo.
 // scores = (q . k) / denom (upstream: attn / sqrt(c_per_head)), softmax, @ v.
@@ -991,6 +1222,22 @@ extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_b
     else { if (window) MSAM_SREL(80, 14); else MSAM_SREL(80, 64); }
 #undef MSAM_SREL
     return msam_check_launch("strict_relpos_attention");
+}
+
+extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
+    if (!p || !p->keys || !p->pos || !p->wq || !p->bq || !p->tok_k || !p->tok_v || !p->wo || !p->bo || !p->ln_weight || !p->ln_bias || !p->out) {
+        msam_set_error("msam_strict_i2t_block: null argument"); return 1;
+    }
+    if (p->B <= 0 || p->Tk <= 0 || p->Tk > 16 || p->ld_tok < 128 || p->ld_tok % 4 || p->tok_batch_stride % 4 || p->key_batch_stride % 4 ||
+        ((uintptr_t)p->keys | (uintptr_t)p->pos | (uintptr_t)p->wq | (uintptr_t)p->bq | (uintptr_t)p->tok_k | (uintptr_t)p->tok_v |
+         (uintptr_t)p->wo | (uintptr_t)p->bo | (uintptr_t)p->ln_weight | (uintptr_t)p->ln_bias | (uintptr_t)p->out) % 16) {
+        msam_set_error("msam_strict_i2t_block: 1..16 tokens, strides in multiples of 4 floats, 16-byte aligned pointers"); return 1;
+    }
+    if (p->key_batch_stride == 0 && p->out == p->keys) { msam_set_error("msam_strict_i2t_block: a shared stream cannot be updated in place"); return 1; }
+    SI2TArgs a{p->keys, p->key_batch_stride, p->pos, p->wq, p->bq, p->tok_k, p->tok_v, p->ld_tok, p->tok_batch_stride, p->wo, p->bo,
+               p->ln_weight, p->ln_bias, p->ln_eps, p->denom, p->out, p->B, p->Tk};
+    hipLaunchKernelGGL(si2t_kernel, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
+    return msam_check_launch("strict_i2t_block");
 }
 
 extern "C" int msam_strict_attention(const float* q, int64_t ldq, int64_t q_batch_stride, const float* k, int64_t ldk, int64_t k_batch_stride,

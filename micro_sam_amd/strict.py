@@ -29,6 +29,9 @@ ACT_NONE, ACT_GELU, ACT_RELU = _lib.ACT_NONE, _lib.ACT_GELU, _lib.ACT_RELU
 # prompts per pass of the strict decoder: ~30 MiB of fp32 intermediates per prompt (image-token stream, its projections, the two
 # up-scaling stages)
 DECODE_CHUNK = 128
+# the "image attends to the tokens" step as one launch (msam_strict_i2t_block) instead of four (projection, attention, projection +
+# residual, LayerNorm): the same arithmetic, the 0.5 GB per-chunk stream crosses HBM twice instead of seven times.  Tokens <= 16.
+FUSED_I2T = True
 
 
 def _f32(t: torch.Tensor, dev) -> torch.Tensor:
@@ -80,6 +83,22 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, B: int, H: int,
         q.data_ptr(), q.stride(0), 0 if q_shared else Nq * q.stride(0), k.data_ptr(), k.stride(0), 0 if kv_shared else Nk * k.stride(0),
         v.data_ptr(), v.stride(0), 0 if kv_shared else Nk * v.stride(0), B, H, Nq, Nk, D, float(denom), out.data_ptr(), out.stride(0),
         Nq * out.stride(0), _lib.stream_ptr()), "msam_strict_attention")
+    return out
+
+
+def i2t_block(keys: torch.Tensor, shared: bool, pos: torch.Tensor, wq, tok_k: torch.Tensor, tok_v: torch.Tensor, wo, norm, B: int, Tk: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``norm4(keys + cross_attn_image_to_token(q=keys + pos, k, v))`` in one launch (``msam_strict_i2t_block``): keys [B*T, 256] rows
+    (``shared``: [T, 256] for every prompt), tok_k / tok_v [B*Tk, 128] the token side's projections, wq / wo (weight, bias)."""
+    if out is None:
+        out = torch.empty((B * T, PROMPT_DIM), dtype=torch.float32, device=pos.device) if shared else keys
+    p = _lib.SI2TParams()
+    p.keys, p.key_batch_stride, p.pos = keys.data_ptr(), (0 if shared else T * PROMPT_DIM), pos.data_ptr()
+    p.wq, p.bq, p.wo, p.bo = wq[0].data_ptr(), wq[1].data_ptr(), wo[0].data_ptr(), wo[1].data_ptr()
+    p.tok_k, p.tok_v, p.ld_tok, p.tok_batch_stride = tok_k.data_ptr(), tok_v.data_ptr(), tok_k.stride(0), Tk * tok_k.stride(0)
+    p.ln_weight, p.ln_bias, p.ln_eps, p.denom = norm[0].data_ptr(), norm[1].data_ptr(), float(norm[2]), 4.0
+    p.out, p.B, p.Tk = out.data_ptr(), B, Tk
+    _lib.check(_lib.load().msam_strict_i2t_block(C.byref(p), _lib.stream_ptr()), "msam_strict_i2t_block")
     return out
 
 
@@ -275,6 +294,13 @@ class StrictDecoder:
                 queries = gemm(hid, *L["lin2"], res=queries)
                 layer_norm(queries, *L["n3"], out=queries)
                 ia = L["i2t"]                                                                # image attending to the tokens
+                if FUSED_I2T and Tk <= 16 and ia["q"][0].shape[0] == 128:
+                    tok_k = gemm(queries, *ia["k"], a2=qpe)
+                    tok_v = gemm(queries, *ia["v"])
+                    keys = i2t_block(keys, ks, pos, ia["q"], tok_k, tok_v, ia["out"], L["n4"], pc, Tk)
+                    ks = False
+                    del tok_k, tok_v, hid
+                    continue
                 att = self._attn_block(ia, keys, queries, queries, pc, T, Tk, q_pe=pos, q_pe_rows=T, k_pe=qpe, q_shared=ks)
                 # keys + attention: per prompt from here on (in place once the stream is per prompt)
                 keys = gemm(att, *ia["out"], res=keys, res_rows=T if ks else 0, out=None if ks else keys)

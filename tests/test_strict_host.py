@@ -308,6 +308,34 @@ def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind):
     assert (iou - iou_r).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("shared,Tk", [(True, 7), (False, 9), (False, 16)])
+def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk):
+    """msam_strict_i2t_block (projection, 8-head attention over <= 16 tokens, projection + residual, LayerNorm in one launch, transposed
+    MFMA orientation) against the same step as four launches; layer 0's shared stream and the in-place per-prompt stream."""
+    from micro_sam_amd import strict
+    g = torch.Generator().manual_seed(Tk)
+    B = 2
+    keys = torch.randn(4096 if shared else B * 4096, 256, generator=g)
+    pos = torch.randn(4096, 256, generator=g)
+    wq, wo = (torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1), (torch.randn(256, 128, generator=g) / 11, torch.randn(256, generator=g) * 0.1)
+    tok_k, tok_v = torch.randn(B * Tk, 128, generator=g), torch.randn(B * Tk, 128, generator=g)
+    norm = (torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2, 1e-5)
+    q = strict.gemm(keys, *wq, a2=pos, a2_rows=4096)
+    att = strict.attention(q, tok_k, tok_v, B, 8, 4096, Tk, 16, 4.0, q_shared=shared)
+    want = strict.gemm(att, *wo, res=keys, res_rows=4096 if shared else 0)
+    strict.layer_norm(want, *norm, out=want)
+    got = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= 2e-5, (got - want).abs().max().item()
+    # fp64 statement of the step
+    kd = keys.double().reshape(-1, 4096, 256).expand(B, -1, -1)
+    qd = ((kd + pos.double()) @ wq[0].double().T + wq[1].double()).reshape(B, 4096, 8, 16).transpose(1, 2)
+    kk, vv = (t.double().reshape(B, Tk, 8, 16).transpose(1, 2) for t in (tok_k, tok_v))
+    ad = (torch.softmax(qd @ kk.transpose(-1, -2) / 4.0, dim=-1) @ vv).transpose(1, 2).reshape(B, 4096, 128)
+    ref = torch.nn.functional.layer_norm(kd + ad @ wo[0].double().T + wo[1].double(), (256,), norm[0].double(), norm[1].double(), 1e-5)
+    assert (got.double() - ref.reshape(-1, 256)).abs().max().item() <= 2e-5
+
+
 def test_strict_module_call_and_single_mask(host_sam):
     """``sam.mask_decoder(...)`` (the stand-alone module call of trainable_sam.py:100-106) in strict mode, multimask_output=False."""
     from oracle import sam_ref as S

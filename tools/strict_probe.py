@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--sgemm-bufs", default="", help="comma list of msam_tune_set('sgemm_bufs') values to A/B (strict tile + the product shapes)")
     ap.add_argument("--srel-mfma", default="", help="comma list of msam_tune_set('srel_mfma') values to A/B (strict encoder time)")
     ap.add_argument("--ab", default="", help="key=v1,v2,...: msam_tune_set(key, v) for each v, strict tile + encoder time under each (last v stays set)")
+    ap.add_argument("--ab-py", default="", help="NAME=0,1: a module flag of micro_sam_amd.strict (FUSED_I2T, ...) to A/B on the strict tile")
     a = ap.parse_args()
     from micro_sam_amd import strict, util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
@@ -97,6 +98,13 @@ def main():
             t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
             t_enc = timed(lambda: [util.precompute_image_embeddings(predictor, t, verbose=False) for t in tiles]) / len(tiles)
             rec[f"{key}_{v}"] = {"strict_seconds_per_tile_api_loop": round(t_tile, 5), "strict_encoder_seconds_per_tile": round(t_enc, 5)}
+    if a.ab_py:
+        key, vals = a.ab_py.split("=")
+        for v in vals.split(","):
+            setattr(strict, key, bool(int(v)))
+            predictor.set_precision("strict")
+            t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
+            rec[f"{key}_{v}"] = {"strict_seconds_per_tile_api_loop": round(t_tile, 5)}
     rec["fp32_mfma_peak_tflops"] = 157.3
     line = json.dumps(rec)
     print(line)
