@@ -789,7 +789,7 @@ void msam_gemm_set_g3(int delay);
 void msam_gemm_set_g3_epi(int v);
 extern int g_tune_tok_fuse;
 extern int g_tune_mlp_split_fused;
-extern int g_tune_sgemm_bufs, g_tune_srel_mfma, g_tune_sgemm_small_below;
+extern int g_tune_sgemm_bufs, g_tune_srel_mfma, g_tune_sgemm_small_below, g_tune_si2t_dbg, g_tune_si2t_late_us;
 int g_tune_dec_chain = 1, g_tune_dec_chain_min_p = 128;
 extern "C" int msam_tune_set(const char* key, int32_t value) {
     const std::string k = key ? key : "";
@@ -811,6 +811,8 @@ extern "C" int msam_tune_set(const char* key, int32_t value) {
     else if (k == "sgemm_bufs") g_tune_sgemm_bufs = value;
     else if (k == "srel_mfma") g_tune_srel_mfma = value;
     else if (k == "sgemm_small_below") g_tune_sgemm_small_below = value;
+    else if (k == "si2t_dbg") g_tune_si2t_dbg = value;
+    else if (k == "si2t_late_us") g_tune_si2t_late_us = value;
     else { msam_set_error("msam_tune_set: unknown key"); return 1; }
     return 0;
 }

@@ -21,6 +21,8 @@ void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
 int g_tune_sgemm_bufs = 1;               // msam_tune_set("sgemm_bufs", 1 | 2): LDS stages of sgemm_kernel (1: three workgroups per CU, +9 % on the encoder's shapes)
 int g_tune_sgemm_small_below = 512;      // msam_tune_set("sgemm_small_below", n): launches of fewer than n 128 x 128 tiles run on 64 x 64 tiles
+int g_tune_si2t_late_us = 0;             // msam_tune_set("si2t_late_us", n): start delay of the second workgroup per CU (0: none; measured: no effect)
+int g_tune_si2t_dbg = 0;                 // msam_tune_set("si2t_dbg", bits): timing experiments of si2t_kernel (WRONG results when != 0)
 int g_tune_srel_mfma = 1;                // msam_tune_set("srel_mfma", 0 | 1): global attention on srelpos_mfma_kernel (0: the vector-unit kernel)
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
@@ -599,6 +601,11 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
 //   out^T = W_o att^T: the attention's registers ARE the B operand (step s contracts the channel pair the two lanes hold in register s);
 //   + bias + residual, LayerNorm over the row's 256 channels (two passes, one exchange each), all in registers;
 //   residual tiles in and result tiles out pass a wave-private LDS tile so that HBM sees whole 128-byte rows.
+MSAM_DEVINL void si_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 struct SI2TArgs {
     const float* keys; long key_bs;                     // [B or 1][4096][256]; batch stride 0: one stream shared by every prompt (layer 0)
     const float* pos;                                   // [4096][256] dense positional encoding
@@ -608,23 +615,45 @@ struct SI2TArgs {
     const float* lnw; const float* lnb; float eps, denom;
     float* out;                                         // [B][4096][256] (may be `keys` when that is per prompt)
     int B, Tk;
-};
+    int dbg;                                            // timing experiments (msam_tune_set "si2t_dbg"; WRONG results): 1 no projection 1, 2 no attention,
+                                                        // 4 no projection 2, 8 no residual / LayerNorm
+    int late_lo, late_hi, late_ticks;                   // workgroups [late_lo, late_hi) - the second one of every CU in the first dispatch round -
+};                                                      // start late_ticks x 10 ns late (de-phasing, see the kernel)
 
 __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     constexpr int C = 256, CI = 128, P = SG_PITCH;
-    __shared__ __attribute__((aligned(16))) float Xs[128 * P];     // projection 1: the (keys + pos) k-tile; epilogue: four wave-private [32][P] tiles
-    __shared__ __attribute__((aligned(16))) float Wt[256 * P];     // weight k-tile: W_q (128 rows), then W_o (256 rows)
-    __shared__ __attribute__((aligned(16))) float tks[16 * CI];
-    __shared__ __attribute__((aligned(16))) float tvs[16 * CI];
+    // one LDS block, the small broadcast tables first (ds offsets are 16-bit immediates: an array placed above 64 KB costs an address
+    // register per access)
+    // (59 KB: two workgroups per CU.  With the token tables in their own 16 KB the block was 76 KB and only ONE workgroup was resident
+    //  per CU - 814 us per 128 prompts, exactly 16 serial workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float si_lds[4 * 256 + 128 * P + 256 * P];
+    float* const par = si_lds;                          // bq (128, padded) | bo | LayerNorm weight | bias
+    float* const Xs = par + 4 * 256;                    // projection 1: the (keys + pos) k-tile; attention: the token tables; epilogue: four wave-private [32][P] tiles
+    float* const tks = Xs;                              // token k [16][128] (after projection 1)
+    float* const tvs = Xs + 16 * CI;                    // token v
+    float* const Wt = Xs + 128 * P;                     // weight k-tile: W_q (128 rows), then W_o (256 rows)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
     const int b = (int)(blockIdx.x >> 5), rb = (int)(blockIdx.x & 31);
+    par[tid] = tid < CI ? a.bq[tid] : 0.f; par[256 + tid] = a.bo[tid]; par[512 + tid] = a.lnw[tid]; par[768 + tid] = a.lnb[tid];
+    // Two workgroups share a CU (one wave of each per SIMD).  Measured, the launch takes exactly the SUM of its phases (tools/si2t_probe.py:
+    // projection 1 286 us, attention 120, projection 2 216 - the MFMA rate of the chip -, residual + LayerNorm 81, loads / stores 121 of
+    // 818 us per 128 prompts), and starting the second workgroup of every CU late (this experiment knob, 5 - 50 us) changes nothing:
+    // on this chip the matrix pipe and the vector ALU of a SIMD do not run at the same time, whichever waves the instructions come
+    // from (tools/mfma_valu_overlap_probe.hip; profiles/r05_experiments.md section 8).
+    if (a.late_ticks > 0 && (int)blockIdx.x >= a.late_lo && (int)blockIdx.x < a.late_hi) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.late_ticks) __builtin_amdgcn_s_sleep(16);
+    }
     const float* const kin = a.keys + (long)b * a.key_bs + (long)rb * 128 * C;
     const float* const pin = a.pos + (long)rb * 128 * C;
     float* const outp = a.out + ((long)b * 4096 + rb * 128) * C;
-    for (int i = tid; i < a.Tk * 32; i += 256) {
-        const int t = i >> 5, c4 = (i & 31) * 4;
-        *(float4*)&tks[t * CI + c4] = ld4(a.tk + (long)b * a.tok_bs + (long)t * a.ldt + c4);
-        *(float4*)&tvs[t * CI + c4] = ld4(a.tv + (long)b * a.tok_bs + (long)t * a.ldt + c4);
+    // the prompt's token k / v rows wait in registers until projection 1 releases its LDS tile (thread -> rows tid / 32 and 8 + tid / 32)
+    float4 tkr[2], tvr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+        tkr[i] = tvr[i] = zero4();
+        if (t < a.Tk) { tkr[i] = ld4(a.tk + (long)b * a.tok_bs + (long)t * a.ldt + c4); tvr[i] = ld4(a.tv + (long)b * a.tok_bs + (long)t * a.ldt + c4); }
     }
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
     float4 rx[4], rw[8];
@@ -665,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     store1();
     __syncthreads();
 #pragma unroll 1
-    for (int kt = 0; kt < C / 32; ++kt) {
+    for (int kt = 0; kt < ((a.dbg & 1) ? 0 : C / 32); ++kt) {
         if (kt + 1 < C / 32) load1(kt + 1);
         const float* px = &Xs[(w * 32 + li) * P + lh * 16];
         const float* pw = &Wt[li * P + lh * 16];
@@ -684,15 +713,23 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
         __syncthreads();
     }
     load3(0);                                           // W_o's first k-tile arrives under the attention
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int t = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+        *(float4*)&tks[t * CI + c4] = tkr[i];
+        *(float4*)&tvs[t * CI + c4] = tvr[i];
+    }
+    __syncthreads();
     // register r of tile nt = channel nt * 32 + (r & 3) + 8 (r >> 2) + 4 lh: registers 0..7 belong to head 2 nt, 8..15 to head 2 nt + 1
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 bb = ld4(a.bq + nt * 32 + 8 * g4 + 4 * lh);
+            const float4 bb = ld4(&par[nt * 32 + 8 * g4 + 4 * lh]);
             q[nt][4 * g4] += bb.x; q[nt][4 * g4 + 1] += bb.y; q[nt][4 * g4 + 2] += bb.z; q[nt][4 * g4 + 3] += bb.w;
         }
     // ---- softmax((q . k) / denom) v per head, in place over q
+    if (!(a.dbg & 2))
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -739,6 +776,7 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
         for (int r = 0; r < 16; ++r) oa[ot][r] = 0.f;
     store3();
     __syncthreads();
+    if (!(a.dbg & 4))
 #pragma unroll
     for (int kt = 0; kt < CI / 32; ++kt) {
         const float* pw = &Wt[li * P + 4 * lh];
@@ -762,26 +800,41 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
         if (kt + 1 < CI / 32) store3();
         __syncthreads();
     }
-    // ---- (+ bias) + residual, LayerNorm, store
+    // ---- (+ bias) + residual, LayerNorm, store.  The staging tile is wave-private: LDS instructions of one wave execute in issue
+    // order, so a wave-level fence (no workgroup barrier: the four waves drift apart here) orders its writes before its reads.
     float* const st = &Xs[w * 32 * P];
     float sum = 0.f;
+    // residual tiles two at a time: their 8 loads are in flight together
+    if (!(a.dbg & 8))
 #pragma unroll
-    for (int ot = 0; ot < 8; ++ot) {
-        __builtin_amdgcn_sched_barrier(0);              // (keeps the eight tiles' loads from being hoisted above one another: 128 live accumulators)
+    for (int ob = 0; ob < 8; ob += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        float4 rr[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
-            *(float4*)&st[row * P + c4] = ld4(kin + (long)(w * 32 + row) * C + ot * 32 + c4);
+        for (int o4 = 0; o4 < 2; ++o4)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+                rr[o4][i] = ld4(kin + (long)(w * 32 + row) * C + (ob + o4) * 32 + c4);
+            }
+#pragma unroll
+        for (int o4 = 0; o4 < 2; ++o4) {
+            const int ot = ob + o4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+                *(float4*)&st[row * P + c4] = rr[o4][i];
+            }
+            si_wave_sync();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 rv = ld4(&st[li * P + 8 * g4 + 4 * lh]), bb = ld4(&par[256 + ot * 32 + 8 * g4 + 4 * lh]);
+                oa[ot][4 * g4] = (oa[ot][4 * g4] + bb.x) + rv.x; oa[ot][4 * g4 + 1] = (oa[ot][4 * g4 + 1] + bb.y) + rv.y;
+                oa[ot][4 * g4 + 2] = (oa[ot][4 * g4 + 2] + bb.z) + rv.z; oa[ot][4 * g4 + 3] = (oa[ot][4 * g4 + 3] + bb.w) + rv.w;
+                sum += (oa[ot][4 * g4] + oa[ot][4 * g4 + 1]) + (oa[ot][4 * g4 + 2] + oa[ot][4 * g4 + 3]);
+            }
+            si_wave_sync();
         }
-        __syncthreads();
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 rv = ld4(&st[li * P + 8 * g4 + 4 * lh]), bb = ld4(a.bo + ot * 32 + 8 * g4 + 4 * lh);
-            oa[ot][4 * g4] = (oa[ot][4 * g4] + bb.x) + rv.x; oa[ot][4 * g4 + 1] = (oa[ot][4 * g4 + 1] + bb.y) + rv.y;
-            oa[ot][4 * g4 + 2] = (oa[ot][4 * g4 + 2] + bb.z) + rv.z; oa[ot][4 * g4 + 3] = (oa[ot][4 * g4 + 3] + bb.w) + rv.w;
-            sum += (oa[ot][4 * g4] + oa[ot][4 * g4 + 1]) + (oa[ot][4 * g4 + 2] + oa[ot][4 * g4 + 3]);
-        }
-        __syncthreads();
     }
     {
         const float other = __shfl_xor(sum, 32);
@@ -804,18 +857,18 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const int c = ot * 32 + 8 * g4 + 4 * lh;
-            const float4 ww = ld4(a.lnw + c), bb = ld4(a.lnb + c);
+            const float4 ww = ld4(&par[512 + c]), bb = ld4(&par[768 + c]);
             *(float4*)&st[li * P + 8 * g4 + 4 * lh] =
                 make_float4((oa[ot][4 * g4] - mean) * rstd * ww.x + bb.x, (oa[ot][4 * g4 + 1] - mean) * rstd * ww.y + bb.y,
                             (oa[ot][4 * g4 + 2] - mean) * rstd * ww.z + bb.z, (oa[ot][4 * g4 + 3] - mean) * rstd * ww.w + bb.w);
         }
-        __syncthreads();
+        si_wave_sync();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
             *(float4*)(outp + (long)(w * 32 + row) * C + ot * 32 + c4) = ld4(&st[row * P + c4]);
         }
-        __syncthreads();
+        si_wave_sync();
     }
 }
 
@@ -1224,6 +1277,16 @@ extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_b
     return msam_check_launch("strict_relpos_attention");
 }
 
+static int strict_num_cus() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
     if (!p || !p->keys || !p->pos || !p->wq || !p->bq || !p->tok_k || !p->tok_v || !p->wo || !p->bo || !p->ln_weight || !p->ln_bias || !p->out) {
         msam_set_error("msam_strict_i2t_block: null argument"); return 1;
@@ -1235,7 +1298,8 @@ extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
     }
     if (p->key_batch_stride == 0 && p->out == p->keys) { msam_set_error("msam_strict_i2t_block: a shared stream cannot be updated in place"); return 1; }
     SI2TArgs a{p->keys, p->key_batch_stride, p->pos, p->wq, p->bq, p->tok_k, p->tok_v, p->ld_tok, p->tok_batch_stride, p->wo, p->bo,
-               p->ln_weight, p->ln_bias, p->ln_eps, p->denom, p->out, p->B, p->Tk};
+               p->ln_weight, p->ln_bias, p->ln_eps, p->denom, p->out, p->B, p->Tk, g_tune_si2t_dbg,
+               strict_num_cus(), 2 * strict_num_cus(), g_tune_si2t_late_us * 100};
     hipLaunchKernelGGL(si2t_kernel, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     return msam_check_launch("strict_i2t_block");
 }

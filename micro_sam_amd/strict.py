@@ -27,8 +27,10 @@ GRID, PROMPT_DIM, WINDOW = 64, 256, 14
 T = GRID * GRID
 ACT_NONE, ACT_GELU, ACT_RELU = _lib.ACT_NONE, _lib.ACT_GELU, _lib.ACT_RELU
 # prompts per pass of the strict decoder: ~30 MiB of fp32 intermediates per prompt (image-token stream, its projections, the two
-# up-scaling stages)
-DECODE_CHUNK = 128
+# up-scaling stages) = 15 GiB per pass of 512 - sized for the 288 GB of one MI355X (three decode lanes: 45 GiB).  Measured on the bench
+# tile (1024 prompts): 128 -> 65.5 ms, 256 -> 61.5, 512 -> 59.3, 1024 -> 58.9 ms per tile (the token side's small products fill the chip
+# better; profiles/r05_experiments.md section 7).  Element counts stay below 2^31 up to 1023 prompts per pass.
+DECODE_CHUNK = 512
 # the "image attends to the tokens" step as one launch (msam_strict_i2t_block) instead of four (projection, attention, projection +
 # residual, LayerNorm): the same arithmetic, the 0.5 GB per-chunk stream crosses HBM twice instead of seven times.  Tokens <= 16.
 FUSED_I2T = True

@@ -20,6 +20,7 @@ PRELUDE = r"""
 #include <algorithm>
 #include <condition_variable>
 #include <cstdio>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -170,6 +171,7 @@ static inline uint2 ds_read_tr16_b64_emu(const unsigned char* p) {
     return uint2{(uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16)};
 }
 static inline void __builtin_amdgcn_wave_barrier() { wave_sync(); }
+#define __builtin_amdgcn_fence(order_, scope_) ((void)0)     /* memory-model fence: the emulation's wave_sync() is already sequentially consistent */
 static inline float elem16(const uint4& v, int j, bool f16) {
     const uint32_t wd = (&v.x)[j >> 1];
     const u16 b = (u16)((j & 1) ? (wd >> 16) : (wd & 0xffffu));
@@ -348,7 +350,9 @@ static inline int __clz(uint32_t x) { return x ? __builtin_clz(x) : 32; }
 static inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }
-static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return 0; }
+static inline unsigned long long __builtin_amdgcn_s_memrealtime() {      /* the 100 MHz constant clock */
+    return (unsigned long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() / 10);
+}
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}

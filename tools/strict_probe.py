@@ -101,7 +101,7 @@ def main():
     if a.ab_py:
         key, vals = a.ab_py.split("=")
         for v in vals.split(","):
-            setattr(strict, key, bool(int(v)))
+            setattr(strict, key, type(getattr(strict, key))(int(v)))
             predictor.set_precision("strict")
             t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
             rec[f"{key}_{v}"] = {"strict_seconds_per_tile_api_loop": round(t_tile, 5)}
