@@ -167,7 +167,7 @@ def _reference(low, in_hw, out_hw):
     if exact_scale:
         assert np.array_equal(y, t)
     else:
-        assert np.abs(y - t).max() <= 1e-4 and (y != t).mean() < 0.02
+        assert np.abs(y - t).max() <= 2e-5 * max(1.0, float(np.abs(y).max())) and (y != t).mean() < 0.02      # (one rounding of a weight x the logit scale)
     return torch.from_numpy(y)
 
 
@@ -225,9 +225,7 @@ def test_x4_path_source_on_the_cpu(emu, low_res):
     _check(emu, low_res[:1], (1024, 1024), (1024, 1024), want_logits=True)
 
 
-def test_x4_path_decided_words_source_on_the_cpu(emu):
-    """Object-like logits: most 32-row words are decided from the range of their ten low-res rows; a plateau inside the +-1 band and a
-    region within 0.01 of a threshold must take the exact path - bits and counts equal the per-pixel reference either way."""
+def _object_like_logits():
     g = torch.Generator().manual_seed(16)
     yy, xx = torch.meshgrid(torch.arange(256.0), torch.arange(256.0), indexing="ij")
     low = torch.empty(3, 256, 256)
@@ -239,4 +237,17 @@ def test_x4_path_decided_words_source_on_the_cpu(emu):
         low[i] = f * 45.0 - 14.0 + torch.randn(256, 256, generator=g) * 0.3
     low[1] = low[1].clamp(-0.995, 0.995)
     low[2, :128] = 1.005
-    _check(emu, low, (1024, 1024), (1024, 1024), want_logits=False)
+    return low
+
+
+def test_x4_path_decided_words_source_on_the_cpu(emu):
+    """Object-like logits: most 32-row words are decided from the range of their ten low-res rows; a plateau inside the +-1 band and a
+    region within 0.01 of a threshold must take the exact path - bits and counts equal the per-pixel reference either way."""
+    _check(emu, _object_like_logits(), (1024, 1024), (1024, 1024), want_logits=False)
+
+
+@pytest.mark.parametrize("in_hw,out_hw", [((1024, 1024), (896, 896)), ((731, 1024), (640, 896)), ((1024, 683), (300, 200))])
+def test_general_path_decided_words_source_on_the_cpu(emu, in_hw, out_hw):
+    """The same for the two-stage path (round 5: a word is decided from the range of the low-res rows / columns under it): the border
+    tiles of a tiled volume (896, 640 pixels long) and a reduction whose last word is partial and whose last workgroup has idle lanes."""
+    _check(emu, _object_like_logits(), in_hw, out_hw, want_logits=False)

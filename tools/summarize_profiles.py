@@ -152,8 +152,8 @@ def main():
             f.write(f"# {TAG}: rocprofv3 kernel summary of `python tools/strict_probe.py` (the strict precision mode next to the default one)\n\n")
             f.write(stamp)
             f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_strict_prof -- python tools/strict_probe.py`: per mode "
-                    "(default, strict) 4 passes of the per-tile API loop over 2 tiles + 4 encoder-only passes, then the f32-input MFMA product on seven shapes "
-                    "of the path (6 launches each).  Kernels of `csrc/strict.hip`: `sgemm_kernel`, `srelpos_kernel`, `sattn_*`, `sln*`, `shyper_kernel`, "
+                    "(default, strict) 5 passes of the per-tile API loop over 2 tiles + 5 encoder-only passes, then the f32-input MFMA product on seven shapes "
+                    "of the path (7 launches each).  Kernels of `csrc/strict.hip`: `sgemm_kernel<CONV, stages, tile>`, `srelpos_mfma_kernel`, `srelpos_kernel`, `si2t_kernel`, `sattn_*`, `sln*`, `shyper_kernel`, "
                     "`spatchify / sim2col / ssrc`.\n\n")
             if os.path.exists(probe):
                 f.write("Probe line of the same run: `" + open(probe).read().strip() + "`\n\n")
