@@ -222,6 +222,13 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const TL* __restrict__
             vb = lerp_torch(ay.w0, b0, ay.w1, b1);
             ir[inext] = Y; ia[inext] = va; ib[inext] = vb; inext ^= 1;
         };
+        // low-res columns under the workgroup's output columns (monotone in x): first thread's left one .. last thread's right one
+        int gclo, gchi;
+        {
+            const int xf = min((int)blockIdx.x * 256, out_w - 1), xl = min((int)blockIdx.x * 256 + 255, out_w - 1);
+            const Axis f2 = axis_weights(xf, sx, in_w), l2 = axis_weights(xl, sx, in_w);
+            gclo = axis_weights(f2.i0, 0.25f, 256).i0; gchi = axis_weights(l2.i1, 0.25f, 256).i1;
+        }
         for (int yw = 0; yw < wpc; ++yw) {
             uint32_t word = 0;
             // Decided words (as in the x4 path): every pixel of the word is a convex combination (three nested lerps, weights w0 + w1 = 1)
@@ -234,10 +241,19 @@ __global__ __launch_bounds__(256) void postprocess_kernel(const TL* __restrict__
                 const int y0 = yw * 32, nb = min(32, out_h - y0);
                 const int Ylo = axis_weights(y0, sy, in_h).i0, Yhi = axis_weights(y0 + nb - 1, sy, in_h).i1;
                 const int rlo = axis_weights(Ylo, 0.25f, 256).i0, rhi = axis_weights(Yhi, 0.25f, 256).i1;
+                // the rows are the same for the whole workgroup: every thread reduces ONE low-res column over them into LDS (the
+                // columns under the workgroup's 256 output columns), then reads the two to four columns of its own pixel
+                float* cm = &tile[yw & 1][0];                         // [2][<= 256]: min | max (the x4 path's LDS, unused here)
+                if ((int)threadIdx.x <= gchi - gclo) {
+                    const int c = gclo + threadIdx.x;
+                    float a = 3.0e38f, b = -3.0e38f;
+                    for (int r = rlo; r <= rhi; ++r) { const float v = lowf(low[r * 256 + c]); a = fminf(a, v); b = fmaxf(b, v); }
+                    cm[threadIdx.x] = a; cm[256 + threadIdx.x] = b;
+                }
+                __syncthreads();
                 const int clo = min(axa.i0, axb.i0), chi = max(axa.i1, axb.i1);
                 float mn = 3.0e38f, mx = -3.0e38f;
-                for (int r = rlo; r <= rhi; ++r)
-                    for (int c = clo; c <= chi; ++c) { const float v = lowf(low[r * 256 + c]); mn = fminf(mn, v); mx = fmaxf(mx, v); }
+                for (int c = clo; c <= chi; ++c) { mn = fminf(mn, cm[c - gclo]); mx = fmaxf(mx, cm[256 + c - gclo]); }
                 const bool one = mn > hi_t + 0.01f && mx < 8192.f, zero = mx < lo_t - 0.01f && mn > -8192.f;
                 if (__ballot(!(one || zero)) == 0) {
                     if (!live) continue;
