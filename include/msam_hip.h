@@ -652,6 +652,8 @@ typedef struct {
                                           * GEMM (the loader gathers the taps): M == B conv_h conv_w, K == 9 conv_c, weight columns (ky, kx, c); lda / A2 unused */
     int32_t shuffle_h, shuffle_w, shuffle_c;   /* shuffle_c > 0: ConvTranspose2d(kernel 2, stride 2) store - N == 4 shuffle_c columns (ky*2+kx)*shuffle_c + co of input
                                                 * pixel (b, y, x) (M == B shuffle_h shuffle_w) go to out[((b*2H + 2y+ky)*2W + 2x+kx) * ldc + co]; no residual */
+    int32_t a2_cols;                     /* > 0 (a multiple of 128): A2 is added for the output columns n < a2_cols only - two projections of one input
+                                          * in one launch, `k = (x + pe) Wk^T` | `v = x Wv^T` with W = [Wk; Wv] (the input crosses HBM once); 0: every column */
 } msam_sgemm_t;
 int msam_strict_gemm(const msam_sgemm_t* p, void* stream);
 /* torch.nn.LayerNorm / LayerNorm2d rows: x fp32 [rows, dim <= 1280] -> out fp32 (may be x), optional exact GELU afterwards;

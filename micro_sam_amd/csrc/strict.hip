@@ -49,6 +49,7 @@ struct SGemmArgs {
     const float* col_scale; const float* col_shift;      // v = v * scale[n] + shift[n] after the bias (BatchNorm2d on running statistics)
     int conv_h, conv_w, conv_c;                          // CONV: A = [B, H, W, C] channels-last, K = 9 C, columns (ky, kx, c): 3 x 3 / pad 1
     int shuf_h, shuf_w, shuf_c;                          // 2 x 2 / stride 2 transposed convolution: column (ky*2+kx)*shuf_c + co of input pixel
+    int a2_cols;                                         // A2 only for column tiles n0 < a2_cols (0: all)
 };                                                       // (b, y, x) is stored at output pixel (b, 2y+ky, 2x+kx), channel co
 
 // The epilogue of one wave's 64 x 64 block.  D of a 32 x 32 MFMA tile: lane (col = l & 31, half = l >> 5), register r -> row
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
     // 64-bit remainders once per block (m0 is uniform), the block's 128 consecutive rows by add-and-wrap
     const long conv_hw = CONV ? (long)a.conv_h * a.conv_w : 1;
     const long pix0 = CONV ? m0 % conv_hw : 0;
-    const long a2r0 = (!CONV && a.A2) ? m0 % a.a2_rows : 0;
+    const float* const A2 = (!CONV && a.A2 && (a.a2_cols <= 0 || n0 < a.a2_cols)) ? a.A2 : nullptr;      // block-uniform
+    const long a2r0 = A2 ? m0 % a.a2_rows : 0;
     const long mlast = a.M - 1 - m0;                    // rows past M re-read the last row (their results are not stored)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -156,10 +158,10 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
             ap[j] = a.A + m * a.lda + sc4;
         }
         a2p[j] = nullptr;
-        if (!CONV && a.A2) {
+        if (A2) {
             long r2 = a2r0 + loc;
             while (r2 >= a.a2_rows) r2 -= a.a2_rows;
-            a2p[j] = a.A2 + r2 * a.lda2 + sc4;
+            a2p[j] = A2 + r2 * a.lda2 + sc4;
         }
         int n = n0 + srow + 32 * j;
         if (n >= a.N) n = a.N - 1;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
                     if ((unsigned)(py[j] + dy) < (unsigned)a.conv_h && (unsigned)(px[j] + dx) < (unsigned)a.conv_w) v = ld4(ap[j] + coff);
                 } else {
                     v = ld4(ap[j] + k0);
-                    if (a.A2) { const float4 t = ld4(a2p[j] + k0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                    if (A2) { const float4 t = ld4(a2p[j] + k0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
                 }
                 u = ld4(wp[j] + k0);
             }
@@ -1203,6 +1205,7 @@ extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
         return 1;
     }
     if ((p->col_scale == nullptr) != (p->col_shift == nullptr)) { msam_set_error("msam_strict_gemm: col_scale and col_shift come together"); return 1; }
+    if (p->a2_cols < 0 || p->a2_cols % 128) { msam_set_error("msam_strict_gemm: a2_cols is a multiple of 128 (the column tile)"); return 1; }
     SGemmArgs a{};
     a.A = p->A; a.lda = p->lda; a.A2 = p->A2; a.lda2 = p->lda2; a.a2_rows = p->a2_rows > 0 ? p->a2_rows : p->M;
     a.W = p->W; a.ldw = p->ldw; a.M = p->M; a.N = p->N; a.K = p->K; a.bias = p->bias; a.act = p->act;
@@ -1210,6 +1213,7 @@ extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
     a.col_scale = p->col_scale; a.col_shift = p->col_shift;
     a.conv_h = p->conv_h; a.conv_w = p->conv_w; a.conv_c = p->conv_c;
     a.shuf_h = p->shuffle_h; a.shuf_w = p->shuffle_w; a.shuf_c = p->shuffle_c;
+    a.a2_cols = p->a2_cols;
     long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
     if (blocks > 0x7fffffffL) { msam_set_error("msam_strict_gemm: too many tiles for one launch"); return 1; }
     const bool small = blocks < g_tune_sgemm_small_below;        // fewer 128 x 128 tiles than fill the chip: 64 x 64 tiles

@@ -34,6 +34,10 @@ DECODE_CHUNK = 512
 # the "image attends to the tokens" step as one launch (msam_strict_i2t_block) instead of four (projection, attention, projection +
 # residual, LayerNorm): the same arithmetic, the 0.5 GB per-chunk stream crosses HBM twice instead of seven times.  Tokens <= 16.
 FUSED_I2T = True
+# the token -> image attentions' k and v projections of the image stream as one product over [Wk; Wv] (msam_sgemm_t.a2_cols: the
+# stream crosses HBM once).  Measured: 59.4 ms per tile against 58.5 with two launches - these products are bound by the f32 MFMA,
+# not by HBM; off.
+FUSED_KV = False
 
 
 def _f32(t: torch.Tensor, dev) -> torch.Tensor:
@@ -44,9 +48,11 @@ def _f32(t: torch.Tensor, dev) -> torch.Tensor:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
          a2: Optional[torch.Tensor] = None, a2_rows: int = 0, res: Optional[torch.Tensor] = None, res_rows: int = 0,
-         out: Optional[torch.Tensor] = None, rows: Optional[int] = None, lda: Optional[int] = None, a_offset: int = 0) -> torch.Tensor:
+         out: Optional[torch.Tensor] = None, rows: Optional[int] = None, lda: Optional[int] = None, a_offset: int = 0,
+         a2_cols: int = 0) -> torch.Tensor:
     """``act((a + a2[row % a2_rows]) @ w.T + bias) + res[row % res_rows]`` (fp32).  ``a``: [M, K] rows (``rows`` / ``lda`` /
-    ``a_offset`` address a strided row set inside a larger buffer: the output tokens of the two-way transformer)."""
+    ``a_offset`` address a strided row set inside a larger buffer: the output tokens of the two-way transformer); ``a2_cols``: ``a2``
+    is added for the first ``a2_cols`` output columns only (two projections of one input in one launch)."""
     K = w.shape[1]
     M = a.shape[0] if rows is None else rows
     N = w.shape[0]
@@ -55,7 +61,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p = _lib.SGemmParams()
     p.A, p.lda = a.data_ptr() + 4 * a_offset, (a.stride(0) if lda is None else lda)
     if a2 is not None:
-        p.A2, p.lda2, p.a2_rows = a2.data_ptr(), a2.stride(0), a2_rows
+        p.A2, p.lda2, p.a2_rows, p.a2_cols = a2.data_ptr(), a2.stride(0), a2_rows, a2_cols
     p.W, p.ldw, p.M, p.N, p.K = w.data_ptr(), w.stride(0), M, N, K
     p.bias = None if bias is None else bias.data_ptr()
     p.act = act
@@ -212,7 +218,10 @@ class StrictDecoder:
         md, tr = sam.mask_decoder, sam.mask_decoder.transformer
 
         def attn(m):
-            return {n: (_f32(getattr(m, n + "_proj").weight, dev), _f32(getattr(m, n + "_proj").bias, dev)) for n in ("q", "k", "v", "out")}
+            d = {n: (_f32(getattr(m, n + "_proj").weight, dev), _f32(getattr(m, n + "_proj").bias, dev)) for n in ("q", "k", "v", "out")}
+            # [Wk; Wv]: the k and v projections of one input as ONE product (msam_sgemm_t.a2_cols: the positional encoding goes to k only)
+            d["kv"] = (torch.cat([d["k"][0], d["v"][0]], dim=0).contiguous(), torch.cat([d["k"][1], d["v"][1]], dim=0).contiguous())
+            return d
 
         def norm(m):
             return (_f32(m.weight, dev), _f32(m.bias, dev), m.eps)
@@ -241,9 +250,14 @@ class StrictDecoder:
                     kv_shared=False):
         """upstream ``Attention.forward``: projections, heads, softmax, (out_proj is left to the caller: it carries the residual)."""
         q = gemm(q_in, *aw["q"], a2=q_pe, a2_rows=q_pe_rows)
-        k = gemm(k_in, *aw["k"], a2=k_pe, a2_rows=k_pe_rows)
-        v = gemm(v_in, *aw["v"])
         inner = aw["q"][0].shape[0]
+        if FUSED_KV and k_in is v_in and k_pe is not None and inner % 128 == 0 and k_in.shape[0] >= 4096:
+            # the image side's k | v: one pass over the per-prompt stream instead of two
+            kv = gemm(k_in, *aw["kv"], a2=k_pe, a2_rows=k_pe_rows, a2_cols=inner)
+            k, v = kv[:, :inner], kv[:, inner:]
+        else:
+            k = gemm(k_in, *aw["k"], a2=k_pe, a2_rows=k_pe_rows)
+            v = gemm(v_in, *aw["v"])
         D = inner // 8
         return attention(q, k, v, B, 8, Nq, Nk, D, math.sqrt(D), q_shared=q_shared, kv_shared=kv_shared)
 

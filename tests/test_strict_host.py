@@ -294,11 +294,14 @@ def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind):
         mask_in = torch.randn(P, 1, 256, 256, generator=g) * 6
     with torch.no_grad():
         _, iou_r, low_r = S.predict_torch(sd, feats, (1024, 1024), (1024, 1024), pts, lbl, boxes, mask_in, return_logits=True, precision="fp32")
+    from micro_sam_amd import strict
     sam.set_precision("strict")
+    strict.FUSED_KV = kind == "box+points"              # (one case through the one-launch k | v projection, off by default)
     try:
         low, iou = sam.decode(feats, pts, lbl, boxes, mask_in)
     finally:
         sam.set_precision("default")
+        strict.FUSED_KV = False
     scale = low_r.abs().max().item()
     d = (low - low_r).abs()
     # fp32 rounding through ~40 dependent products (logits of +-130: one ulp is 1.5e-5): max <= 1e-4, mean <= 2e-6 of the scale
@@ -306,6 +309,18 @@ def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind):
     assert torch.isfinite(low).all() and d.max().item() <= tol * scale and d.mean().item() <= tol_mean * scale, \
         (d.max().item() / scale, d.mean().item() / scale)
     assert (iou - iou_r).abs().max().item() <= 2e-5
+
+
+def test_strict_gemm_a2_cols_is_two_products(host_sam):
+    """msam_sgemm_t.a2_cols: `(x + pe) Wk^T | x Wv^T` over [Wk; Wv] in one launch = the two launches, bit for bit; bad values are refused."""
+    from micro_sam_amd import _lib, strict
+    g = torch.Generator().manual_seed(4)
+    x, pe = torch.randn(700, 96, generator=g), torch.randn(100, 96, generator=g)
+    wk, wv, bk, bv = torch.randn(128, 96, generator=g), torch.randn(256, 96, generator=g), torch.randn(128, generator=g), torch.randn(256, generator=g)
+    kv = strict.gemm(x, torch.cat([wk, wv]), torch.cat([bk, bv]), a2=pe, a2_rows=100, a2_cols=128)
+    assert torch.equal(kv[:, :128], strict.gemm(x, wk, bk, a2=pe, a2_rows=100)) and torch.equal(kv[:, 128:], strict.gemm(x, wv, bv))
+    with pytest.raises(ValueError, match="a2_cols"):
+        strict.gemm(x, torch.cat([wk, wv]), torch.cat([bk, bv]), a2=pe, a2_rows=100, a2_cols=100)
 
 
 @pytest.mark.parametrize("shared,Tk", [(True, 7), (False, 9), (False, 16)])
