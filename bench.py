@@ -713,7 +713,13 @@ def main():
                                      f"({n_tiles * prof_steps / serial_elapsed:.1f} tiles/s): in the timed region {len(lanes)} lanes "
                                      "overlap the kernels of different tiles, so a HIP-event bracket there also counts queueing; "
                                      "profiles/ holds the rocprofv3 summary of the same one-lane command (--lanes 1)"),
-                "other_kernels": fams[1:]}
+                "other_kernels": fams[1:],
+                # why frac stops where it does on this chip (measured, not assumed): profiles/r05_mfma_valu_overlap.md
+                "pipes": ("MI355X, measured (tools/mfma_valu_overlap_probe.hip): the matrix pipe and the vector ALU of a SIMD do not overlap - MFMA-only waves + "
+                          "vector-only waves on the same SIMDs take the SUM of their times (0.251 + 0.351 -> 0.596 ms), inside one wave 3.45 cycles per vector "
+                          "instruction added next to its MFMAs.  SQ counters of the dominant kernel on this code (profiles/r05_pmc_sq_counters.md): two waves "
+                          "per SIMD x 35 % vector-busy + 32 % matrix-busy = 101 % of the launch: `frac` is the matrix share of a budget its vector "
+                          "instructions (LayerNorm2d, two GELUs, packing) fill")}
         out = {
             "metric": {"bf16": "1024^2 tiles/s embed+AMG (vit_b bf16)",
                        "fp16": "1024^2 tiles/s embed+AMG (vit_b, fp16 instead of bf16 operands in the image encoder: side measurement)",
