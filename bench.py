@@ -719,7 +719,8 @@ def main():
                           "vector-only waves on the same SIMDs take the SUM of their times (0.251 + 0.351 -> 0.596 ms), inside one wave 3.45 cycles per vector "
                           "instruction added next to its MFMAs.  SQ counters of the dominant kernel on this code (profiles/r05_pmc_sq_counters.md): two waves "
                           "per SIMD x 35 % vector-busy + 32 % matrix-busy = 101 % of the launch: `frac` is the matrix share of a budget its vector "
-                          "instructions (LayerNorm2d, two GELUs, packing) fill")}
+                          "instructions (LayerNorm2d, two GELUs, packing) fill.  Clock under this load (GRBM_GUI_ACTIVE / duration, profiles/r05_clock_under_load.md): "
+                          "2.00 GHz for the hot kernels, not the 2.4 GHz of the nominal peak (strict mode's f32 kernels: 2.43)")}
         out = {
             "metric": {"bf16": "1024^2 tiles/s embed+AMG (vit_b bf16)",
                        "fp16": "1024^2 tiles/s embed+AMG (vit_b, fp16 instead of bf16 operands in the image encoder: side measurement)",

@@ -22,7 +22,8 @@ def main():
                 continue
             name, ns = dur[r["Dispatch_Id"]]
             if ns > 20000:                          # >= 20 us: the counter's start / stop skew is below 1 %
-                per[name.split("(")[0][-60:]].append((float(r["Counter_Value"]), ns))
+                short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+                per[short].append((float(r["Counter_Value"]), ns))
     print("| kernel | dispatches | mean us | GRBM_GUI_ACTIVE / ns | / 8 |")
     print("|---|---|---|---|---|")
     for name, v in sorted(per.items(), key=lambda kv: -sum(x[1] for x in kv[1]))[:24]:
