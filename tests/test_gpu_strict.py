@@ -209,3 +209,77 @@ def test_strict_mode_through_the_pipelined_slice_loop_and_the_tiled_generator(mo
     assert all(clone._predictor.model.precision == "default" for clone, _ in amg._decode_lanes(2))
     assert ((seg_d > 0) == (seg > 0)).mean() > 0.99
     predictor.set_precision("strict")
+
+
+# ------------------------------------------------------------------------------------------------ the kernels of the round's second pass
+
+def test_strict_kernel_variants_on_the_device():
+    """What tests/test_strict_host.py checks on the host build of csrc/strict.hip, on the device: sgemm_kernel's tile / stage variants and
+    `a2_cols` give the same bits, the MFMA global attention and the vector-unit one agree to fp32 rounding and with an fp64 statement, and
+    msam_strict_i2t_block is the four launches it replaces (shared and per-prompt stream)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from micro_sam_amd import _lib, strict
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(12)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+
+    def tune(key, v):
+        _lib.check(lib.msam_tune_set(key, v), "msam_tune_set")
+    # products: M large enough for the 128 x 128 tile by default (>= 512 tiles) and a token-side shape on the 64 x 64 tile
+    for (M, N, K) in ((8192, 1024, 256), (896, 256, 2048)):
+        a, w, b, res, a2 = r(M, K), r(N, K) / K ** 0.5, r(N), r(4096 if M % 4096 == 0 else M, N), r(128, K)
+        outs = []
+        for bufs, small in ((1, 512), (2, 512), (1, 0), (1, 1 << 30)):
+            tune(b"sgemm_bufs", bufs); tune(b"sgemm_small_below", small)
+            try:
+                outs.append(strict.gemm(a, w, b, act=strict.ACT_GELU, a2=a2, a2_rows=128, res=res, res_rows=res.shape[0] if res.shape[0] != M else 0))
+            finally:
+                tune(b"sgemm_bufs", 1); tune(b"sgemm_small_below", 512)
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        rows = torch.arange(M, device=dev)
+        want = torch.nn.functional.gelu((a.double() + a2.double()[rows % 128]) @ w.double().T + b.double()) + res.double()[rows % res.shape[0]]
+        assert (outs[0] - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    x, pe = r(8192, 256), r(4096, 256)
+    wk, wv, bk, bv = r(128, 256) / 16, r(128, 256) / 16, r(128), r(128)
+    kv = strict.gemm(x, torch.cat([wk, wv]), torch.cat([bk, bv]), a2=pe, a2_rows=4096, a2_cols=128)
+    assert torch.equal(kv[:, :128], strict.gemm(x, wk, bk, a2=pe, a2_rows=4096)) and torch.equal(kv[:, 128:], strict.gemm(x, wv, bv))
+    # global attention: two kernels
+    for heads, hd in ((2, 64), (1, 80)):
+        D = heads * hd
+        qkv, bq = r(4096, 3 * D), r(3 * D) * 0.5
+        rel_h, rel_w = r(127, hd) * 0.2, r(127, hd) * 0.2
+        outs = []
+        for mfma in (1, 0):
+            tune(b"srel_mfma", mfma)
+            try:
+                o = torch.full((4096, D), float("nan"), device=dev)
+                _lib.check(lib.msam_strict_relpos_attention(qkv.data_ptr(), bq.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(), 1, heads, hd, 64, 0,
+                                                            hd ** -0.5, o.data_ptr(), _lib.stream_ptr()), "relpos")
+                outs.append(o)
+            finally:
+                tune(b"srel_mfma", 1)
+        assert torch.isfinite(outs[0]).all() and (outs[0] - outs[1]).abs().max().item() <= 3e-5 and not torch.equal(outs[0], outs[1])
+        t = qkv.double().reshape(4096, 3, heads, hd).permute(1, 2, 0, 3)
+        q, k, v = t[0], t[1], t[2]
+        idx = torch.arange(64, device=dev)[:, None] - torch.arange(64, device=dev)[None, :] + 63
+        Rh, Rw = rel_h.double()[idx], rel_w.double()[idx]                                   # [q, k, hd]
+        qg = q.reshape(heads, 64, 64, hd)
+        bias = torch.einsum("nhwc,hkc->nhwk", qg, Rh)[:, :, :, :, None] + torch.einsum("nhwc,wkc->nhwk", qg, Rw)[:, :, :, None, :]
+        attn = ((q * hd ** -0.5) @ k.transpose(-1, -2)).reshape(heads, 64, 64, 64, 64) + bias
+        ref = (attn.reshape(heads, 4096, 4096).softmax(-1) @ v).permute(1, 0, 2).reshape(4096, D)
+        assert (outs[0].double() - ref).abs().max().item() <= 2e-5
+    # the image -> token step in one launch
+    for shared, Tk, B in ((True, 7, 5), (False, 9, 3)):
+        keys = r(4096 if shared else B * 4096, 256)
+        pos = r(4096, 256)
+        wq, wo = (r(128, 256) / 16, r(128) * 0.1), (r(256, 128) / 11, r(256) * 0.1)
+        tok_k, tok_v = r(B * Tk, 128), r(B * Tk, 128)
+        norm = (torch.rand(256, generator=g).to(dev) + 0.5, r(256) * 0.2, 1e-5)
+        q = strict.gemm(keys, *wq, a2=pos, a2_rows=4096)
+        att = strict.attention(q, tok_k, tok_v, B, 8, 4096, Tk, 16, 4.0, q_shared=shared)
+        want = strict.gemm(att, *wo, res=keys, res_rows=4096 if shared else 0)
+        strict.layer_norm(want, *norm, out=want)
+        got = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
+        assert torch.isfinite(got).all() and (got - want).abs().max().item() <= 2e-5, (got - want).abs().max().item()
