@@ -23,7 +23,7 @@ int g_tune_sgemm_bufs = 1;               // msam_tune_set("sgemm_bufs", 1 | 2): 
 int g_tune_sgemm_small_below = 512;      // msam_tune_set("sgemm_small_below", n): launches of fewer than n 128 x 128 tiles run on 64 x 64 tiles
 int g_tune_si2t_late_us = 0;             // msam_tune_set("si2t_late_us", n): start delay of the second workgroup per CU (0: none; measured: no effect)
 int g_tune_si2t_dbg = 0;                 // msam_tune_set("si2t_dbg", bits): timing experiments of si2t_kernel (WRONG results when != 0)
-int g_tune_srel_mfma = 1;                // msam_tune_set("srel_mfma", 0 | 1): global attention on srelpos_mfma_kernel (0: the vector-unit kernel)
+int g_tune_srel_mfma = 2;                // msam_tune_set("srel_mfma", 0 | 1 | 2): 1 = global attention on srelpos_mfma_kernel, 2 = the windows on srelpos_win_mfma_kernel as well, 0 = the vector-unit kernel for both
 
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 MSAM_DEVINL f32x16_t mfma32f(float a, float b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
@@ -583,6 +583,165 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
     }
     l += __shfl_xor(l, 32);
     float* op = a.out + ((long)b * T + tq) * a.Dm + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = dt * 32 + 8 * g4 + 4 * lh;
+            if (d < HD) *(float4*)(op + d) = make_float4(oacc[dt][4 * g4] / l, oacc[dt][4 * g4 + 1] / l, oacc[dt][4 * g4 + 2] / l, oacc[dt][4 * g4 + 3] / l);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------ window attention, MFMA
+// The same transposed formulation for the 14 x 14 windows (196 tokens; windows of the zero-padded grid: tokens outside the grid are the
+// qkv bias, as in srelpos_kernel).  One workgroup of 7 waves = one (image, window, head): wave w owns queries 32 w .. 32 w + 31 (the last
+// wave: 4 of them), the 196 keys pass LDS in 7 tiles of 32 (the last one masked from key 196 on).  Decomposed relative positions: a
+// query meets 14 row and 14 column offsets, so both terms are ONE MFMA tile each before the loop (the 27 table rows against the wave's
+// queries), scattered to LDS as bh[query][kh] | bw[query][kw]; a score reads its two entries by the key's (kh, kw).
+constexpr int SW_S = 14, SW_T = SW_S * SW_S, SW_KT = (SW_T + 31) / 32;      // 196 tokens, 7 tiles
+template <int HD>
+__global__ __launch_bounds__(448, 2) void srelpos_win_mfma_kernel(SRelArgs a) {
+    constexpr int HH = HD / 2, DT = (HD + 31) / 32, KP = HD + 4, V4 = HD / 4;
+    extern __shared__ __attribute__((aligned(16))) float sw_lds[];
+    float* const bt = sw_lds;                           // [224][32]: bh (16) | bw (16) per query
+    float* const Ks = bt + 224 * 32;                    // [32][KP]
+    float* const Vt = Ks + 32 * KP;                     // [DT * 32][SM_VP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int nW = (a.G + SW_S - 1) / SW_S, nwin = nW * nW;
+    int bid = blockIdx.x;
+    const int h = bid % a.heads; bid /= a.heads;
+    const int win = bid % nwin, b = bid / nwin;
+    const int wy = win / nW, wx = win % nW;
+    const int T = a.G * a.G;
+    const long ld = 3L * a.Dm;
+    auto row_ptr = [&](int gi, int which) -> const float* {        // token index inside the window -> its q / k / v slice (or the bias: padding)
+        const int ty = wy * SW_S + gi / SW_S, tx = wx * SW_S + gi % SW_S;
+        if (ty >= a.G || tx >= a.G) return a.bqkv + (long)which * a.Dm + h * HD;
+        return a.qkv + ((long)b * T + ty * a.G + tx) * ld + (long)which * a.Dm + h * HD;
+    };
+    const int qi = w * 32 + li, qic = qi < SW_T ? qi : SW_T - 1;
+    const int qh = qic / SW_S, qw = qic % SW_S;
+    float qu[HH], qs[HH];
+    {
+        const float* qp = row_ptr(qic, 0) + lh * HH;
+#pragma unroll
+        for (int d = 0; d < HH; d += 4) { const float4 t = ld4(qp + d); qu[d] = t.x; qu[d + 1] = t.y; qu[d + 2] = t.z; qu[d + 3] = t.w; }
+    }
+    // G^T[j][q] = R[j] . q for the 27 table rows (one tile), kept at bh[q][kh = qh + 13 - j] / bw[q][kw = qw + 13 - j]
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        const float* tab = which ? a.rel_w : a.rel_h;
+        const float* rp = tab + (long)(li < 2 * SW_S - 1 ? li : 2 * SW_S - 2) * HD + lh * HH;
+        f32x16_t g;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = 0.f;
+#pragma unroll
+        for (int d = 0; d < HH; d += 4) {
+            const float4 t = ld4(rp + d);
+            g = mfma32f(t.x, qu[d], g); g = mfma32f(t.y, qu[d + 1], g); g = mfma32f(t.z, qu[d + 2], g); g = mfma32f(t.w, qu[d + 3], g);
+        }
+        const int q0 = which ? qw : qh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = q0 + (SW_S - 1) - ((r & 3) + 8 * (r >> 2) + 4 * lh);
+            if (kk >= 0 && kk < SW_S) bt[qi * 32 + which * 16 + kk] = g[r];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HH; ++d) qs[d] = qu[d] * a.scale;
+    for (int i = tid; i < DT * 32 * SM_VP; i += 448) Vt[i] = 0.f;
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m = -3.0e38f, l = 0.f;
+    constexpr int NLD = (32 * V4 + 447) / 448;
+    float4 rk[NLD], rv[NLD];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 448 * i;
+            if (idx < 32 * V4) {
+                const int key = t * 32 + idx / V4;
+                rk[i] = rv[i] = zero4();
+                if (key < SW_T) { const float* kp = row_ptr(key, 1) + (idx % V4) * 4; rk[i] = ld4(kp); rv[i] = ld4(kp + a.Dm); }
+            }
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + 448 * i;
+            if (idx < 32 * V4) {
+                const int row = idx / V4, c = (idx % V4) * 4;
+                *(float4*)&Ks[row * KP + c] = rk[i];
+                Vt[(c + 0) * SM_VP + row] = rv[i].x; Vt[(c + 1) * SM_VP + row] = rv[i].y;
+                Vt[(c + 2) * SM_VP + row] = rv[i].z; Vt[(c + 3) * SM_VP + row] = rv[i].w;
+            }
+        }
+    };
+    gload(0);
+    __syncthreads();                                    // the zero fill of Vt, the bias tables
+    sstore();
+    __syncthreads();
+    const float* const bq = bt + qi * 32;
+#pragma unroll 1
+    for (int t = 0; t < SW_KT; ++t) {
+        if (t + 1 < SW_KT) gload(t + 1);
+        f32x16_t sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+        const float* kp = Ks + li * KP + lh * HH;
+#pragma unroll
+        for (int d = 0; d < HH; d += 4) {
+            const float4 kk = ld4(kp + d);
+            sc = mfma32f(kk.x, qs[d], sc); sc = mfma32f(kk.y, qs[d + 1], sc); sc = mfma32f(kk.z, qs[d + 2], sc); sc = mfma32f(kk.w, qs[d + 3], sc);
+        }
+        float cm = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int kh = key / SW_S, kw = key - kh * SW_S;
+            sc[r] = key < SW_T ? (sc[r] + bq[kh]) + bq[16 + kw] : -3.0e38f;
+            cm = fmaxf(cm, sc[r]);
+        }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        if (__ballot(mn > m)) {
+            const float alpha = expf(m - mn);
+            l *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m = mn;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sc[r] = key < SW_T ? expf(sc[r] - m) : 0.f;
+            l += sc[r];
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float* vp = Vt + (dt * 32 + li) * SM_VP + 4 * lh;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 v = ld4(vp + 8 * g4);
+                oacc[dt] = mfma32f(v.x, sc[4 * g4], oacc[dt]); oacc[dt] = mfma32f(v.y, sc[4 * g4 + 1], oacc[dt]);
+                oacc[dt] = mfma32f(v.z, sc[4 * g4 + 2], oacc[dt]); oacc[dt] = mfma32f(v.w, sc[4 * g4 + 3], oacc[dt]);
+            }
+        }
+        __syncthreads();
+        if (t + 1 < SW_KT) sstore();
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32);
+    if (qi >= SW_T) return;
+    const int ty = wy * SW_S + qh, tx = wx * SW_S + qw;
+    if (ty >= a.G || tx >= a.G) return;                              // padded query rows are dropped by window_unpartition
+    float* op = a.out + ((long)b * T + ty * a.G + tx) * a.Dm + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -1263,6 +1422,19 @@ extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_b
         (void)hipFuncSetAttribute((const void*)srelpos_kernel<HD_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((srelpos_kernel<HD_, S_>), dim3((unsigned)blocks), dim3(256), lds, s, a);                                 \
     } while (0)
+    if (window && g_tune_srel_mfma >= 2) {              // the 14 x 14 windows on the f32-input MFMA
+        const size_t lw = (size_t)(224 * 32 + 32 * (head_dim + 4) + ((head_dim + 31) / 32) * 32 * SM_VP) * sizeof(float);
+        const int nWw = (grid + SW_S - 1) / SW_S;
+        const unsigned gw = (unsigned)(B * nWw * nWw * heads);
+        if (head_dim == 64) {
+            (void)hipFuncSetAttribute((const void*)srelpos_win_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+            hipLaunchKernelGGL((srelpos_win_mfma_kernel<64>), dim3(gw), dim3(448), lw, s, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)srelpos_win_mfma_kernel<80>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+            hipLaunchKernelGGL((srelpos_win_mfma_kernel<80>), dim3(gw), dim3(448), lw, s, a);
+        }
+        return msam_check_launch("strict_relpos_attention");
+    }
     if (!window && g_tune_srel_mfma) {                  // the 64 x 64 grid on the f32-input MFMA
         const size_t lm = (size_t)(128 * SM_BWP + 32 * (head_dim + 4) + ((head_dim + 31) / 32) * 32 * SM_VP) * sizeof(float);
         const unsigned gm = (unsigned)(B * heads * 32);

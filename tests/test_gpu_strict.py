@@ -259,7 +259,7 @@ def test_strict_kernel_variants_on_the_device():
                                                             hd ** -0.5, o.data_ptr(), _lib.stream_ptr()), "relpos")
                 outs.append(o)
             finally:
-                tune(b"srel_mfma", 1)
+                tune(b"srel_mfma", 2)
         assert torch.isfinite(outs[0]).all() and (outs[0] - outs[1]).abs().max().item() <= 3e-5 and not torch.equal(outs[0], outs[1])
         t = qkv.double().reshape(4096, 3, heads, hd).permute(1, 2, 0, 3)
         q, k, v = t[0], t[1], t[2]
@@ -270,6 +270,22 @@ def test_strict_kernel_variants_on_the_device():
         attn = ((q * hd ** -0.5) @ k.transpose(-1, -2)).reshape(heads, 64, 64, 64, 64) + bias
         ref = (attn.reshape(heads, 4096, 4096).softmax(-1) @ v).permute(1, 0, 2).reshape(4096, D)
         assert (outs[0].double() - ref).abs().max().item() <= 2e-5
+    # the 14 x 14 windows of the zero-padded 64 x 64 grid: MFMA kernel against the vector-unit kernel
+    for heads, hd in ((2, 64), (1, 80)):
+        D = heads * hd
+        qkv, bq = r(2 * 4096, 3 * D), r(3 * D) * 0.5
+        rel_h, rel_w = r(27, hd) * 0.2, r(27, hd) * 0.2
+        outs = []
+        for mode in (2, 0):
+            tune(b"srel_mfma", mode)
+            try:
+                o = torch.full((2 * 4096, D), float("nan"), device=dev)
+                _lib.check(lib.msam_strict_relpos_attention(qkv.data_ptr(), bq.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(), 2, heads, hd, 64, 14,
+                                                            hd ** -0.5, o.data_ptr(), _lib.stream_ptr()), "relpos")
+                outs.append(o)
+            finally:
+                tune(b"srel_mfma", 2)
+        assert torch.isfinite(outs[0]).all() and (outs[0] - outs[1]).abs().max().item() <= 3e-5 and not torch.equal(outs[0], outs[1])
     # the image -> token step in one launch
     for shared, Tk, B in ((True, 7, 5), (False, 9, 3)):
         keys = r(4096 if shared else B * 4096, 256)

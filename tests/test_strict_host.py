@@ -172,17 +172,17 @@ def test_strict_relpos_attention(lib, B, heads, hd, G, window):
                                             scale, out.data_ptr(), None) == 0, lib.msam_last_error()
     ref = _relpos_ref(qkv, bqkv, rel_h, rel_w, B, heads, hd, G, window, scale)
     assert torch.isfinite(out).all() and (out - ref).abs().max().item() <= 2e-5
-    if not window:
-        # the global form has two kernels: srelpos_mfma_kernel (default; the transposed f32-MFMA formulation) and the vector-unit one
-        out_v = torch.full((B * G * G, D), float("nan"))
-        assert lib.msam_tune_set(b"srel_mfma", 0) == 0
-        try:
-            assert lib.msam_strict_relpos_attention(qkv.data_ptr(), bqkv.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(), B, heads, hd, G, window,
-                                                    scale, out_v.data_ptr(), None) == 0, lib.msam_last_error()
-        finally:
-            assert lib.msam_tune_set(b"srel_mfma", 1) == 0
-        assert (out_v - ref).abs().max().item() <= 2e-5
-        assert not torch.equal(out, out_v) and (out - out_v).abs().max().item() <= 3e-5      # two kernels, two summation orders
+    # both forms have two kernels: the transposed f32-MFMA formulation (srelpos_mfma_kernel / srelpos_win_mfma_kernel; the default) and the
+    # vector-unit one
+    out_v = torch.full((B * G * G, D), float("nan"))
+    assert lib.msam_tune_set(b"srel_mfma", 0) == 0
+    try:
+        assert lib.msam_strict_relpos_attention(qkv.data_ptr(), bqkv.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(), B, heads, hd, G, window,
+                                                scale, out_v.data_ptr(), None) == 0, lib.msam_last_error()
+    finally:
+        assert lib.msam_tune_set(b"srel_mfma", 2) == 0
+    assert (out_v - ref).abs().max().item() <= 2e-5
+    assert not torch.equal(out, out_v) and (out - out_v).abs().max().item() <= 3e-5      # two kernels, two summation orders
 
 
 def test_strict_gemm_tile_variants_give_the_same_bits(lib):
