@@ -664,8 +664,8 @@ int msam_strict_layernorm(const float* x, const float* weight, const float* bias
  * (q | k | v, heads inside), qkv_bias fp32 [3 * heads * head_dim] (= the q / k / v of the zero-padded window border), rel_h / rel_w fp32
  * [2 S - 1, head_dim] with S = window or grid (already resized to that length), window 14 (any grid <= 64: windows of the zero-padded
  * grid) or 0 (global, grid 64), head_dim 64 or 80; scores = (scale q) . k + q . R_h + q . R_w, softmax, @ v -> out fp32
- * [B * grid^2, heads * head_dim].  The global form runs both products on the f32-input MFMA (srelpos_mfma_kernel), the windows on the
- * vector unit; msam_tune_set("srel_mfma", 0) sends the global form to the vector-unit kernel as well. */
+ * [B * grid^2, heads * head_dim].  Both forms run their two products on the f32-input MFMA (srelpos_mfma_kernel, srelpos_win_mfma_kernel);
+ * msam_tune_set("srel_mfma", 1) sends the windows, 0 both forms to the vector-unit kernel (srelpos_kernel). */
 int msam_strict_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
                                  int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream);
 /* The "image attends to the tokens" step of one TwoWayAttentionBlock on the per-prompt image stream in ONE launch (segment_anything

@@ -25,6 +25,12 @@ int g_tune_si2t_late_us = 0;             // msam_tune_set("si2t_late_us", n): st
 int g_tune_si2t_dbg = 0;                 // msam_tune_set("si2t_dbg", bits): timing experiments of si2t_kernel (WRONG results when != 0)
 int g_tune_srel_mfma = 2;                // msam_tune_set("srel_mfma", 0 | 1 | 2): 1 = global attention on srelpos_mfma_kernel, 2 = the windows on srelpos_win_mfma_kernel as well, 0 = the vector-unit kernel for both
 
+// register budget of a kernel as waves per SIMD (the tests' host build of this file - tests/hip_host_shim.py, g++ - has no such attribute)
+#if defined(__HIPCC__)
+#define MSAM_WAVES_PER_EU(n_) __attribute__((amdgpu_waves_per_eu(n_, n_)))
+#else
+#define MSAM_WAVES_PER_EU(n_)
+#endif
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 MSAM_DEVINL f32x16_t mfma32f(float a, float b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 
@@ -600,7 +606,8 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
 // queries), scattered to LDS as bh[query][kh] | bw[query][kw]; a score reads its two entries by the key's (kh, kw).
 constexpr int SW_S = 14, SW_T = SW_S * SW_S, SW_KT = (SW_T + 31) / 32;      // 196 tokens, 7 tiles
 template <int HD>
-__global__ __launch_bounds__(448, 2) void srelpos_win_mfma_kernel(SRelArgs a) {
+// (head_dim 64: 128 registers = four waves per SIMD = two of these 7-wave workgroups per CU, at the price of 5 spilled dwords in the prologue)
+__global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelpos_win_mfma_kernel(SRelArgs a) {
     constexpr int HH = HD / 2, DT = (HD + 31) / 32, KP = HD + 4, V4 = HD / 4;
     extern __shared__ __attribute__((aligned(16))) float sw_lds[];
     float* const bt = sw_lds;                           // [224][32]: bh (16) | bw (16) per query
