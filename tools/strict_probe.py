@@ -32,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--tiles", type=int, default=2)
+    ap.add_argument("--model", default="vit_b")
+    ap.add_argument("--no-products", action="store_true", help="skip the product shapes (they are vit_b's)")
     ap.add_argument("--modes", default="default,strict")
     ap.add_argument("--sgemm-bufs", default="", help="comma list of msam_tune_set('sgemm_bufs') values to A/B (strict tile + the product shapes)")
     ap.add_argument("--srel-mfma", default="", help="comma list of msam_tune_set('srel_mfma') values to A/B (strict encoder time)")
@@ -41,8 +43,8 @@ def main():
     from micro_sam_amd import strict, util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
     from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
-    sd = synthetic_state_dict("vit_b", 0, variant="cells")
-    predictor = util.get_sam_model("vit_b", device="cuda", state_dict=sd)
+    sd = synthetic_state_dict(a.model, 0, variant="cells")
+    predictor = util.get_sam_model(a.model, device="cuda", state_dict=sd)
     tiles = [synthetic_tile(1000 + i) for i in range(a.tiles)]
     amg = AutomaticMaskGenerator(predictor, device_chunk=1024)
     rec = {}
@@ -75,7 +77,8 @@ def main():
             g[name] = {"M": M, "N": N, "K": K, "us": round(t * 1e6, 1), "tflops": round(2.0 * M * N * K / t / 1e12, 1),
                        "gbytes_per_s": round((M * K + M * N) * 4 / t / 1e9, 0)}
         return g
-    rec["strict_gemm"] = products()
+    if not a.no_products:
+        rec["strict_gemm"] = products()
     for v in filter(None, a.sgemm_bufs.split(",")):
         _lib.check(_lib.load().msam_tune_set(b"sgemm_bufs", int(v)), "msam_tune_set")
         predictor.set_precision("strict")
