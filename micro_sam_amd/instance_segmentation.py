@@ -181,6 +181,32 @@ class AMGBase(ABC):
             pass
         return data
 
+    def _postprocess_batch_prepare(self, data, crop_box, original_size, pred_iou_thresh, stability_score_thresh, box_nms_thresh):
+        """The tests of ``_postprocess_batch`` for a device state WITHOUT a host synchronisation: returns (order, count) - the rows that
+        survive the three filters and the box NMS are ``order[:count]``, in the order ``_postprocess_batch`` leaves them (descending
+        predicted IoU, ties by row).  ``generate`` prepares every crop / tile first and reads all counts in one transfer (round 5: a
+        2048^2 slice has 9 tiles, two synchronisations each were 6 of its generate()'s 9 ms)."""
+        orig_h, orig_w = original_size
+        keep = ~amg_utils.is_box_near_crop_edge(data["boxes"], crop_box, [0, 0, orig_w, orig_h])
+        if pred_iou_thresh > 0.0:
+            keep = keep & (data["iou_preds"] > pred_iou_thresh)
+        if stability_score_thresh > 0.0:
+            keep = keep & (data["stability_score"] >= stability_score_thresh)
+        scores = data["iou_preds"].float()
+        flags = ops.box_nms_flags(data["boxes"], scores, keep, box_nms_thresh)
+        order = torch.sort(torch.where(flags, scores, torch.full_like(scores, float("-inf"))), descending=True, stable=True).indices
+        return order, flags.sum()
+
+    def _postprocess_batch_finish(self, data, crop_box, order, count: int):
+        data.filter(order[:count])
+        data["boxes"] = amg_utils.uncrop_boxes_xyxy(data["boxes"], crop_box)
+        data["crop_boxes"] = torch.tensor([crop_box for _ in range(int(data["iou_preds"].shape[0]))])
+        try:
+            data["points"] = amg_utils.uncrop_points(data["points"], crop_box)
+        except KeyError:
+            pass
+        return data
+
     def _postprocess_small_regions(self, mask_data, min_area, nms_thresh):
         """Reference :146-186: remove small islands / fill small holes of every kept mask (host step, like the reference's
         cv2 loop), recompute boxes, NMS that prefers unchanged masks, re-encode the changed ones."""
@@ -502,14 +528,25 @@ class AutomaticMaskGenerator(AMGBase):
                 return out[:-1].reshape(self.original_size).view(np.uint32)
             # (two union passes did not converge: the general path below iterates until they do)
         data = DeviceMaskData()
-        for data_, crop_box in zip(self.crop_list, self.crop_boxes):
-            # filter() re-binds columns and never mutates them in place: a shallow copy protects the state
-            crop_data = self._postprocess_batch(
-                data=data_.shallow_copy() if isinstance(data_, DeviceMaskData) else deepcopy(data_),
-                crop_box=crop_box, original_size=self.original_size,
-                pred_iou_thresh=pred_iou_thresh, stability_score_thresh=stability_score_thresh,
-                box_nms_thresh=box_nms_thresh)
-            data.cat(crop_data)
+        on_device = len(self.crop_list) > 1 and all(
+            isinstance(d, DeviceMaskData) and len(d) > 0 and all(torch.is_tensor(d[k]) and d[k].is_cuda for k in ("boxes", "iou_preds", "stability_score"))
+            for d in self.crop_list)
+        if on_device:
+            # every crop's filters + box NMS are enqueued first, their survivor counts come back in ONE transfer
+            prepared = [self._postprocess_batch_prepare(d, cb, self.original_size, pred_iou_thresh, stability_score_thresh, box_nms_thresh)
+                        for d, cb in zip(self.crop_list, self.crop_boxes)]
+            counts = torch.stack([c for _, c in prepared]).tolist()
+            for data_, crop_box, (order, _), n in zip(self.crop_list, self.crop_boxes, prepared, counts):
+                data.cat(self._postprocess_batch_finish(data_.shallow_copy(), crop_box, order, int(n)))
+        else:
+            for data_, crop_box in zip(self.crop_list, self.crop_boxes):
+                # filter() re-binds columns and never mutates them in place: a shallow copy protects the state
+                crop_data = self._postprocess_batch(
+                    data=data_.shallow_copy() if isinstance(data_, DeviceMaskData) else deepcopy(data_),
+                    crop_box=crop_box, original_size=self.original_size,
+                    pred_iou_thresh=pred_iou_thresh, stability_score_thresh=stability_score_thresh,
+                    box_nms_thresh=box_nms_thresh)
+                data.cat(crop_data)
         if len(self.crop_boxes) > 1 and len(data["crop_boxes"]) > 0:
             scores = 1 / amg_utils.box_area(data["crop_boxes"])
             scores = scores.to(data["boxes"].device)
