@@ -103,3 +103,20 @@ def test_integer_stages_are_the_oracles_on_the_products_own_state(run):
                                       boxes=d["boxes"].long(), points=torch.as_tensor(d["points"]), rles=A.mask_to_rle(masks))],
              "crop_boxes": amg.crop_boxes, "original_size": amg.original_size}
     assert np.array_equal(np.asarray(PR.amg_generate(state)).astype(np.uint32), np.asarray(run["seg"]).astype(np.uint32))
+
+
+@pytest.mark.parametrize("thr", [(0.88, 0.95, 0.7), (0.0, 0.0, 0.7), (0.5, 0.9, 0.3)])
+def test_one_synchronisation_form_of_postprocess_batch(run, thr):
+    """generate() of tiled / cropped device states enqueues every crop's filters + NMS first (_postprocess_batch_prepare: no host
+    synchronisation) and reads the survivor counts once; per crop it must leave the rows _postprocess_batch leaves, in its order."""
+    amg, data = run["amg"], run["data"]
+    a = data.shallow_copy()
+    a["cand"] = torch.arange(len(data))
+    b = data.shallow_copy()
+    b["cand"] = torch.arange(len(data))
+    want = amg._postprocess_batch(a, amg.crop_boxes[0], amg.original_size, *thr)
+    order, count = amg._postprocess_batch_prepare(b, amg.crop_boxes[0], amg.original_size, *thr)
+    got = amg._postprocess_batch_finish(b, amg.crop_boxes[0], order, int(count))
+    assert torch.equal(got["cand"], want["cand"]) and len(want["cand"]) > 0
+    assert torch.equal(got["boxes"], want["boxes"]) and torch.equal(got["iou_preds"], want["iou_preds"])
+    assert torch.equal(torch.as_tensor(got["crop_boxes"]), torch.as_tensor(want["crop_boxes"]))
