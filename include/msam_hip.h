@@ -654,6 +654,13 @@ typedef struct {
                                                 * pixel (b, y, x) (M == B shuffle_h shuffle_w) go to out[((b*2H + 2y+ky)*2W + 2x+kx) * ldc + co]; no residual */
     int32_t a2_cols;                     /* > 0 (a multiple of 128): A2 is added for the output columns n < a2_cols only - two projections of one input
                                           * in one launch, `k = (x + pe) Wk^T` | `v = x Wv^T` with W = [Wk; Wv] (the input crosses HBM once); 0: every column */
+    int32_t split16;                     /* 0: exact fp32 products on the f32-input MFMA (the strict mode).  1: the "split16" mode - both operands
+                                          * enter the 16-bit matrix pipe as fp16 pairs (hi = fp16(x), lo = fp16(x - hi)) and a product is a_hi w_hi + a_hi w_lo
+                                          * + a_lo w_hi (fp32 accumulation): fp32-level accuracy (the dropped term is 2^-22 of a product) at 5.3 x the
+                                          * f32-input MFMA rate.  Same tiles, loaders and epilogues; everything outside the product stays fp32. */
+    float a_scale, w_scale;              /* split16: powers of two (0 = 1.0) applied to A (+ A2) and W before the split so that the values sit inside
+                                          * fp16's range (|x| < 65504, subnormals below 6e-5): W scaled to max |w| ~ 2^13, activations usually 1; undone exactly
+                                          * in the epilogue */
 } msam_sgemm_t;
 int msam_strict_gemm(const msam_sgemm_t* p, void* stream);
 /* torch.nn.LayerNorm / LayerNorm2d rows: x fp32 [rows, dim <= 1280] -> out fp32 (may be x), optional exact GELU afterwards;

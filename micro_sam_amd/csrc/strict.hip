@@ -33,6 +33,29 @@ int g_tune_srel_mfma = 2;                // msam_tune_set("srel_mfma", 0 | 1 | 2
 #endif
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 MSAM_DEVINL f32x16_t mfma32f(float a, float b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+// ---- the "split16" precision mode: an fp32 value x is carried into the 16-bit matrix pipe as the fp16 PAIR hi = fp16(x), lo = fp16(x - hi)
+// (x - hi is exact in fp32; hi + lo holds 21 - 22 bits of x) and a product a . w is formed as a_hi w_hi + a_hi w_lo + a_lo w_hi on
+// v_mfma_f32_32x32x16_f16 (exact fp16 x fp16 products, fp32 accumulation): the dropped a_lo w_lo term is 2^-22 of the product.  Three MFMAs
+// at 16 x the f32-input rate = 5.3 x the strict mode's matrix throughput at fp32-level accuracy (measured against fp64 on the CPU: mean
+// relative error 7e-8 against 3e-7 of an fp32 GEMM; DESIGN.md "precision modes").  Range: fp16 holds |x| < 65504 and its subnormals stop at
+// 2^-24, so weights are pre-scaled by a power of two (SGemmArgs.w_scale, undone exactly in the epilogue) and activations are taken as they
+// are (|x| >= 2^-3 keeps 21 bits; smaller values carry an absolute error of 2^-25).
+#if defined(__HIPCC__)
+MSAM_DEVINL f32x16_t mfma32h(const uint4& a, const uint4& b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+MSAM_DEVINL float sp_h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (u16)bits16); }
+#else
+static inline f32x16_t mfma32h(const uint4& a, const uint4& b, f32x16_t c) { return mfma32<true>(a, b, c); }
+static inline float sp_h2f(uint32_t bits16) { return h16_to_f((u16)bits16); }
+#endif
+// four consecutive values -> their hi and lo halves (4 x fp16 = 8 bytes each)
+MSAM_DEVINL void sp_split4(const float4& v, float scale, uint2& hi, uint2& lo) {
+    const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
+    hi.x = pack2h(x0, x1); hi.y = pack2h(x2, x3);
+    lo.x = pack2h(x0 - sp_h2f(hi.x & 0xffffu), x1 - sp_h2f(hi.x >> 16));
+    lo.y = pack2h(x2 - sp_h2f(hi.y & 0xffffu), x3 - sp_h2f(hi.y >> 16));
+}
 
 namespace {
 
@@ -56,6 +79,7 @@ struct SGemmArgs {
     int conv_h, conv_w, conv_c;                          // CONV: A = [B, H, W, C] channels-last, K = 9 C, columns (ky, kx, c): 3 x 3 / pad 1
     int shuf_h, shuf_w, shuf_c;                          // 2 x 2 / stride 2 transposed convolution: column (ky*2+kx)*shuf_c + co of input pixel
     int a2_cols;                                         // A2 only for column tiles n0 < a2_cols (0: all)
+    float a_scale, w_scale, out_scale;                   // SPLIT: powers of two applied to A / W before the fp16 split; out_scale = 1 / (a_scale w_scale)
 };                                                       // (b, y, x) is stored at output pixel (b, 2y+ky, 2x+kx), channel co
 
 // The epilogue of one wave's 64 x 64 block.  D of a 32 x 32 MFMA tile: lane (col = l & 31, half = l >> 5), register r -> row
@@ -71,7 +95,7 @@ MSAM_DEVINL float sg_act(float v) {
     return v;
 }
 // MODE 0: bias + activation only; 1: + residual; 2: + BatchNorm scale / shift and the transposed convolution's scatter
-template <int ACT, int MODE, int IT>
+template <int ACT, int MODE, int IT, bool SPLIT = false>
 MSAM_DEVINL void sg_store(const SGemmArgs& a, const f32x16_t (&acc)[IT][IT], long m0, int n0, int wm, int wn, int li, int lh) {
     int n[IT], co[IT];
     long coff[IT];
@@ -114,7 +138,7 @@ MSAM_DEVINL void sg_store(const SGemmArgs& a, const f32x16_t (&acc)[IT][IT], lon
 #pragma unroll
             for (int j = 0; j < IT; ++j) {
                 if (n[j] >= a.N) continue;
-                float v = acc[i][j][r] + bs[j];
+                float v = (SPLIT ? acc[i][j][r] * a.out_scale : acc[i][j][r]) + bs[j];
                 if (scaled) v = v * cs[j] + ct[j];
                 v = sg_act<ACT>(v);
                 if (rp) v += rp[n[j]];
@@ -129,7 +153,9 @@ MSAM_DEVINL void sg_store(const SGemmArgs& a, const f32x16_t (&acc)[IT][IT], lon
 // IT 2: 128 x 128 tile (a wave: 2 x 2 MFMA tiles); IT 1: 64 x 64 tile (a wave: one MFMA tile) for the launches that would not fill the
 // chip with 128 x 128 tiles - the token side of the two-way transformer (M = 7 tokens x 128 prompts), the heads, the encoder at batch 1:
 // a quarter of the serial MFMA chain per wave, four times the workgroups.  An element's k order is the same in every variant.
-template <bool CONV, int NBUF, int IT>
+// SPLIT: the split16 mode - the same tiles, loaders and epilogues; a row of an LDS k-tile holds 32 hi halves | 32 lo halves (128 of its 144
+// bytes) instead of 32 floats, and a 32 x 32 tile's k-tile is 2 k-steps x 3 v_mfma_f32_32x32x16_f16 instead of 16 v_mfma_f32_32x32x2_f32.
+template <bool CONV, int NBUF, int IT, bool SPLIT = false>
 __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_kernel(SGemmArgs a) {
     constexpr int TM = 64 * IT, NJ = TM / 32;
     __shared__ __attribute__((aligned(16))) float As[NBUF][TM * SG_PITCH];
@@ -200,8 +226,18 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            *(float4*)&As[buf][(srow + 32 * j) * SG_PITCH + sc4] = ra[j];
-            *(float4*)&Ws[buf][(srow + 32 * j) * SG_PITCH + sc4] = rw[j];
+            if constexpr (SPLIT) {
+                uint2 h, l;
+                char* const pa_ = (char*)&As[buf][(srow + 32 * j) * SG_PITCH] + sc4 * 2;
+                char* const pw_ = (char*)&Ws[buf][(srow + 32 * j) * SG_PITCH] + sc4 * 2;
+                sp_split4(ra[j], a.a_scale, h, l);
+                *(uint2*)pa_ = h; *(uint2*)(pa_ + 64) = l;
+                sp_split4(rw[j], a.w_scale, h, l);
+                *(uint2*)pw_ = h; *(uint2*)(pw_ + 64) = l;
+            } else {
+                *(float4*)&As[buf][(srow + 32 * j) * SG_PITCH + sc4] = ra[j];
+                *(float4*)&Ws[buf][(srow + 32 * j) * SG_PITCH + sc4] = rw[j];
+            }
         }
     };
     f32x16_t acc[IT][IT];
@@ -218,8 +254,30 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload((kt + 1) * 32);
-        const float* pa = &As[kt & (NBUF - 1)][(wm * (TM / 2) + li) * SG_PITCH + lh * 16];
-        const float* pw = &Ws[kt & (NBUF - 1)][(wn * (TM / 2) + li) * SG_PITCH + lh * 16];
+        const float* pa = &As[kt & (NBUF - 1)][(wm * (TM / 2) + li) * SG_PITCH + lh * (SPLIT ? 4 : 16)];
+        const float* pw = &Ws[kt & (NBUF - 1)][(wn * (TM / 2) + li) * SG_PITCH + lh * (SPLIT ? 4 : 16)];
+        if constexpr (SPLIT) {
+            // lane (row li, half lh) of a 32 x 32 x 16 step ks: k = 16 ks + 8 lh .. + 7 = 16 bytes at 32 ks + 16 lh of the row's hi (lo: + 64) block
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 ah[IT], al[IT], wh[IT], wl[IT];
+#pragma unroll
+                for (int i = 0; i < IT; ++i) {
+                    const char* qa = (const char*)(pa + i * 32 * SG_PITCH) + ks * 32;
+                    const char* qw = (const char*)(pw + i * 32 * SG_PITCH) + ks * 32;
+                    ah[i] = *(const uint4*)qa; al[i] = *(const uint4*)(qa + 64);
+                    wh[i] = *(const uint4*)qw; wl[i] = *(const uint4*)(qw + 64);
+                }
+#pragma unroll
+                for (int i = 0; i < IT; ++i)
+#pragma unroll
+                    for (int j = 0; j < IT; ++j) {
+                        acc[i][j] = mfma32h(al[i], wh[j], acc[i][j]);
+                        acc[i][j] = mfma32h(ah[i], wl[j], acc[i][j]);
+                        acc[i][j] = mfma32h(ah[i], wh[j], acc[i][j]);
+                    }
+            }
+        } else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             float av[IT][4], bv[IT][4];
@@ -243,9 +301,9 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
     const int mode = (a.col_scale || a.shuf_c > 0) ? 2 : a.res ? 1 : 0;
 #define MSAM_SG_STORE(ACT_)                                                                                                           \
     do {                                                                                                                              \
-        if (mode == 0) sg_store<ACT_, 0, IT>(a, acc, m0, n0, wm, wn, li, lh);                                                             \
-        else if (mode == 1) sg_store<ACT_, 1, IT>(a, acc, m0, n0, wm, wn, li, lh);                                                        \
-        else sg_store<ACT_, 2, IT>(a, acc, m0, n0, wm, wn, li, lh);                                                                       \
+        if (mode == 0) sg_store<ACT_, 0, IT, SPLIT>(a, acc, m0, n0, wm, wn, li, lh);                                                      \
+        else if (mode == 1) sg_store<ACT_, 1, IT, SPLIT>(a, acc, m0, n0, wm, wn, li, lh);                                                 \
+        else sg_store<ACT_, 2, IT, SPLIT>(a, acc, m0, n0, wm, wn, li, lh);                                                                \
     } while (0)
     switch (a.act) {
         case MSAM_ACT_GELU: MSAM_SG_STORE(MSAM_ACT_GELU); break;
@@ -1380,13 +1438,28 @@ extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
     a.conv_h = p->conv_h; a.conv_w = p->conv_w; a.conv_c = p->conv_c;
     a.shuf_h = p->shuffle_h; a.shuf_w = p->shuffle_w; a.shuf_c = p->shuffle_c;
     a.a2_cols = p->a2_cols;
+    const bool split = p->split16 != 0;
+    if (p->split16 < 0 || p->split16 > 1 || p->a_scale < 0.f || p->w_scale < 0.f) { msam_set_error("msam_strict_gemm: split16 is 0 or 1, the scales are powers of two > 0 (0 = 1)"); return 1; }
+    a.a_scale = p->a_scale > 0.f ? p->a_scale : 1.f; a.w_scale = p->w_scale > 0.f ? p->w_scale : 1.f;
+    a.out_scale = 1.0f / (a.a_scale * a.w_scale);
     long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
     if (blocks > 0x7fffffffL) { msam_set_error("msam_strict_gemm: too many tiles for one launch"); return 1; }
     const bool small = blocks < g_tune_sgemm_small_below;        // fewer 128 x 128 tiles than fill the chip: 64 x 64 tiles
     if (small) blocks = ((p->M + 63) / 64) * (long)((p->N + 63) / 64);
     const dim3 grid((unsigned)blocks), wg(256);
     hipStream_t st = (hipStream_t)stream;
-    if (small) {
+    if (split) {
+        if (small) {
+            if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 1, 1, true>), grid, wg, 0, st, a);
+            else hipLaunchKernelGGL((sgemm_kernel<false, 1, 1, true>), grid, wg, 0, st, a);
+        } else if (g_tune_sgemm_bufs == 1) {
+            if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 1, 2, true>), grid, wg, 0, st, a);
+            else hipLaunchKernelGGL((sgemm_kernel<false, 1, 2, true>), grid, wg, 0, st, a);
+        } else {
+            if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 2, 2, true>), grid, wg, 0, st, a);
+            else hipLaunchKernelGGL((sgemm_kernel<false, 2, 2, true>), grid, wg, 0, st, a);
+        }
+    } else if (small) {
         if (conv) hipLaunchKernelGGL((sgemm_kernel<true, 1, 1>), grid, wg, 0, st, a);
         else hipLaunchKernelGGL((sgemm_kernel<false, 1, 1>), grid, wg, 0, st, a);
     } else if (g_tune_sgemm_bufs == 1) {

@@ -166,9 +166,10 @@ class ImageEncoderViT(nn.Module):
         fp32); "fp8": the four large projections of every block take OCP e4m3 operands on the MX-scaled MFMA (per-token
         activation scales, per-output-channel weight scales; fp32 accumulation, scales applied in the GEMM epilogue);
         attention, patch embedding and neck stay bf16; "fp32": the strict mode (micro_sam_amd/strict.py) - the reference's formulation
-        on fp32 kernels (f32-input MFMA products, erf GELU, expf softmax), ~1/16 of the MFMA rate, results to fp32 rounding."""
-        if precision not in ("bf16", "fp16", "fp8", "fp32"):
-            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16', 'fp16', 'fp8' or 'fp32'")
+        on fp32 kernels (f32-input MFMA products, erf GELU, expf softmax), ~1/16 of the MFMA rate, results to fp32 rounding;
+        "split16": that formulation with every product on fp16 operand pairs (3 MFMAs of the 16-bit pipe per product, fp32-level accuracy)."""
+        if precision not in ("bf16", "fp16", "fp8", "fp32", "split16"):
+            raise ValueError(f"Invalid encoder precision {precision!r}: expect 'bf16', 'fp16', 'fp8', 'fp32' or 'split16'")
         if precision != self.precision:
             self.precision = precision
             self.invalidate()
@@ -277,7 +278,7 @@ class ImageEncoderViT(nn.Module):
     @torch.no_grad()
     def forward(self, x: torch.Tensor, tap_block: Optional[int] = None):
         assert x.dim() == 4 and x.shape[1:] == (3, IMG_SIZE, IMG_SIZE), x.shape
-        if self.precision == "fp32":
+        if self.precision in ("fp32", "split16"):
             if tap_block is not None:
                 raise NotImplementedError("micro_sam_amd: tap_block is a test hook of the 16-bit encoder")
             return self._strict().forward(x=x)
@@ -298,7 +299,7 @@ class ImageEncoderViT(nn.Module):
     def forward_u8(self, images: torch.Tensor) -> torch.Tensor:
         """uint8 HWC batch [B,h,w,3] (after ``ResizeLongestSide.apply_image``): ``Sam.preprocess`` fused on device."""
         assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] == 3, images.shape
-        if self.precision == "fp32":
+        if self.precision in ("fp32", "split16"):
             return self._strict().forward(images_u8=images)
         params, _ = self._prepare()
         images = images.to(self.pos_embed.device).contiguous()
@@ -479,14 +480,24 @@ class Sam(nn.Module):
         "strict": the reference's formulation on fp32 kernels for the image encoder, the prompt encoder and the mask decoder
         (micro_sam_amd/strict.py): results equal to the reference CPU path up to fp32 rounding, at ~1/30 of the default throughput.
         The integer post-processing is the same (bit-exact) code in both modes."""
-        if mode not in ("default", "strict"):
-            raise ValueError(f"Invalid precision mode {mode!r}: expect 'default' or 'strict'")
+        if mode not in ("default", "strict", "split16"):
+            raise ValueError(f"Invalid precision mode {mode!r}: expect 'default', 'split16' or 'strict'")
         if mode == getattr(self, "precision", "default"):
             return
+        enc_now = getattr(self.image_encoder, "precision", None)
+        if getattr(self, "precision", "default") == "default" and enc_now in ("bf16", "fp16", "fp8"):
+            self._default_encoder_precision = enc_now                    # (a caller's fp16 / fp8 choice survives a round trip; ADVICE r5)
         self.precision = mode
-        if hasattr(self.image_encoder, "set_precision"):                 # (vit_t: TinyViT runs fp32 torch operators in both modes)
-            self.image_encoder.set_precision("fp32" if mode == "strict" else "bf16")
+        if hasattr(self.image_encoder, "set_precision"):                 # (vit_t: TinyViT runs fp32 torch operators in every mode)
+            self.image_encoder.set_precision({"strict": "fp32", "split16": "split16"}.get(mode, getattr(self, "_default_encoder_precision", "bf16")))
+        if getattr(self, "_mask_params", None) is not None:
+            self._mask_params.exact_gelu = 0 if mode == "default" else 1 # (a field of a struct shared with the lane views: set where the mode is set)
         self._img_state = None
+
+    @property
+    def reference_formulation(self) -> bool:
+        """True in the strict and the split16 mode: the reference's un-folded formulation (micro_sam_amd/strict.py) is the one that runs."""
+        return self.precision in ("strict", "split16")
 
     def _strict_decoder(self):
         if getattr(self, "_strict_dec", None) is None:
@@ -612,6 +623,7 @@ class Sam(nn.Module):
         mp.c2_w, mp.c2_b = k(_f32(ds[3].weight.reshape(-1))), k(_f32(ds[3].bias))
         mp.ln2_w, mp.ln2_b = k(_f32(ds[4].weight)), k(_f32(ds[4].bias))
         mp.c3_w, mp.c3_b = k(_f32(ds[6].weight.reshape(PROMPT_DIM, 16))), k(_f32(ds[6].bias))
+        mp.exact_gelu = 1 if self.reference_formulation else 0
         self._mask_params = mp
         lib = _lib.load()
         consts = torch.empty(lib.msam_decoder_const_bytes(), dtype=torch.uint8, device=dev)
@@ -672,7 +684,7 @@ class Sam(nn.Module):
         sparse = torch.empty((B, Ns, PROMPT_DIM), dtype=torch.float32, device=dev)
         dense = torch.empty((B, PROMPT_DIM, GRID, GRID), dtype=torch.float32, device=dev) if msk is not None else None
         if Ns > 0 or msk is not None:
-            self._mask_params.exact_gelu = 1 if self.precision == "strict" else 0       # (read by this call only)
+            self._mask_params.exact_gelu = 1 if self.reference_formulation else 0
             _lib.check(_lib.load().msam_prompt_encode(
                 C.byref(p), C.byref(self._mask_params), _lib.ptr(pts), _lib.ptr(lbl), Np, _lib.ptr(bx), _lib.ptr(msk), B,
                 _lib.ptr(sparse) if Ns > 0 else None, _lib.ptr(dense), _lib.stream_ptr()), "msam_prompt_encode")
@@ -688,7 +700,7 @@ class Sam(nn.Module):
                                       f"(got {tuple(image_embeddings.shape)})")
         p, _, consts = self._prepare_decoder()
         dev = self.device
-        if self.precision == "strict":
+        if self.reference_formulation:
             nm = self.prompt_encoder.no_mask_embed.weight.detach().to(dev).reshape(1, -1, 1, 1)
             dn = dense.to(device=dev, dtype=torch.float32)
             no_mask = (dn.stride(-1) == 0 and dn.stride(-2) == 0 and torch.equal(dn[:, :, :1, :1], nm.expand(dn.shape[0], -1, 1, 1))) \
@@ -742,7 +754,7 @@ class Sam(nn.Module):
             raise ValueError("low_res_dtype is torch.float32 or torch.float16")
         if features.numel() != PROMPT_DIM * GRID * GRID:
             raise ValueError(f"expected one image embedding [1,256,64,64], got {tuple(features.shape)}")
-        if self.precision == "strict":
+        if self.reference_formulation:
             if point_coords is None and boxes is None and mask_input is None:
                 raise ValueError("micro_sam_amd: a prompt needs points, a box and / or a mask input")
             pts = None if point_coords is None else (point_coords, point_labels)

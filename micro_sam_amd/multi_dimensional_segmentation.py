@@ -479,6 +479,21 @@ def multicut_refine(n_nodes: int, uv_ids: np.ndarray, costs: np.ndarray, labels:
                 break
         if not changed:
             break
+    # a node move can take an articulation node out of a cluster: the rest keeps one label without being connected any more.  A multicut
+    # is a partition into CONNECTED components, so clusters are re-cut by the connected components of the edges they keep.
+    parent = list(range(n_nodes))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for u, v in uv.tolist():
+        if u != v and lab[u] == lab[v]:
+            ru, rv = find(u), find(v)
+            if ru != rv:
+                parent[max(ru, rv)] = min(ru, rv)
+    lab = np.array([find(u) for u in range(n_nodes)], dtype=np.int64) if n_nodes else lab
     _, first = np.unique(lab, return_index=True)
     order = np.argsort(first)
     lut = np.empty(len(order), dtype=np.int64)

@@ -26,8 +26,9 @@ class SamPredictor:
         return self.model.device
 
     def set_precision(self, mode: str) -> None:
-        """"default" (16-bit throughput path) or "strict" (the reference's formulation in fp32: ``Sam.set_precision``).  Embeddings
-        computed before the switch stay what they are: call ``set_image`` / ``precompute_image_embeddings`` again for strict ones."""
+        """"default" (16-bit throughput path), "split16" (the reference's formulation, every product on fp16 operand pairs: fp32-level
+        accuracy on the 16-bit MFMA) or "strict" (the reference's formulation on fp32 kernels): ``Sam.set_precision``.  Embeddings
+        computed before the switch stay what they are: call ``set_image`` / ``precompute_image_embeddings`` again after it."""
         self.model.set_precision(mode)
 
     def reset_image(self) -> None:

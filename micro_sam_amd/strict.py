@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -45,6 +46,53 @@ def _f32(t: torch.Tensor, dev) -> torch.Tensor:
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
 
+# ---------------------------------------------------------------------------------------------------- the split16 mode
+# ``Sam.set_precision("split16")``: the same formulation and the same sequence of library calls as the strict mode, with every
+# matrix product on fp16 operand PAIRS (hi = fp16(x), lo = fp16(x - hi); a . w = a_hi w_hi + a_hi w_lo + a_lo w_hi on the 16-bit MFMA,
+# fp32 accumulation; include/msam_hip.h msam_sgemm_t.split16).  Everything outside the products (LayerNorm, softmax, GELU, residuals,
+# the tensors in HBM) stays fp32.  fp16's range is handled by power-of-two scales that are undone exactly in the epilogue: weights are
+# scaled so that max |w| lies in (2^12, 2^13] (cached per weight tensor), activations enter as they are.
+_MODE = threading.local()
+_WSCALE = {}
+
+
+class split_mode:
+    """Context: products of this thread run in the split16 mode (entered by StrictEncoder.forward / StrictDecoder.decode)."""
+
+    def __init__(self, on: bool) -> None:
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = getattr(_MODE, "split", False)
+        _MODE.split = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _MODE.split = self.prev
+        return False
+
+
+def split_active() -> bool:
+    return getattr(_MODE, "split", False)
+
+
+def weight_scale(w: torch.Tensor) -> float:
+    """Power of two that brings max |w| into (2^12, 2^13] (fp16: 10 bits of lo below 11 bits of hi stay normal numbers down to 2^-22 of
+    the largest weight).  One device synchronisation per weight tensor, cached until the weights are rebuilt (``forget_scales``)."""
+    key = (w.data_ptr(), w.numel())
+    sc = _WSCALE.get(key)
+    if sc is None:
+        m = float(w.abs().max())
+        sc = 1.0 if not (m > 0.0 and math.isfinite(m)) else 2.0 ** (13 - math.ceil(math.log2(m)))
+        sc = min(max(sc, 2.0 ** -40), 2.0 ** 40)
+        _WSCALE[key] = sc
+    return sc
+
+
+def forget_scales() -> None:
+    _WSCALE.clear()
+
+
 # ---------------------------------------------------------------------------------------------------- library calls
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
@@ -69,6 +117,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if res is not None:
         p.res, p.ldr, p.res_rows = res.data_ptr(), res.stride(0), res_rows
     p.out, p.ldc = out.data_ptr(), out.stride(0)
+    if split_active():
+        p.split16, p.a_scale, p.w_scale = 1, 1.0, weight_scale(w)
     _lib.check(_lib.load().msam_strict_gemm(C.byref(p), _lib.stream_ptr()), "msam_strict_gemm")
     return out
 
@@ -129,6 +179,7 @@ class StrictEncoder:
             return self._w
         dev = enc.pos_embed.device
         _lib.require_gpu(dev)
+        forget_scales()
         D = enc.embed_dim
         w = {"patch_w": _f32(enc.patch_embed.proj.weight.reshape(D, -1), dev), "patch_b": _f32(enc.patch_embed.proj.bias, dev),
              "pos": _f32(enc.pos_embed.reshape(T, D), dev), "blocks": []}
@@ -154,6 +205,10 @@ class StrictEncoder:
     @torch.no_grad()
     def forward(self, x: Optional[torch.Tensor] = None, images_u8: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x fp32 [B,3,1024,1024] (after ``Sam.preprocess``) or uint8 HWC [B,h,w,3] (``Sam.preprocess`` fused) -> [B,256,64,64]."""
+        with split_mode(self.enc.precision == "split16"):
+            return self._forward(x, images_u8)
+
+    def _forward(self, x, images_u8):
         enc = self.enc
         w = self._weights()
         dev = enc.pos_embed.device
@@ -216,6 +271,7 @@ class StrictDecoder:
         if self._w is not None and key == self._key:
             return self._w
         dev = sam.device
+        forget_scales()
         md, tr = sam.mask_decoder, sam.mask_decoder.transformer
 
         def attn(m):
@@ -267,6 +323,10 @@ class StrictDecoder:
                multimask_output: bool) -> Tuple[torch.Tensor, torch.Tensor]:
         """features [1,256,64,64], sparse fp32 [P, Ns, 256], dense fp32 [P,256,64,64] or None (= the broadcast no_mask_embed),
         pos fp32 [4096, 256] (token-major dense positional encoding) -> (low_res [P, C, 256, 256], iou [P, C])."""
+        with split_mode(self.sam.precision == "split16"):
+            return self._decode(features, sparse, dense, pos, multimask_output)
+
+    def _decode(self, features, sparse, dense, pos, multimask_output):
         w = self._weights()
         dev = self.sam.device
         lib = _lib.load()

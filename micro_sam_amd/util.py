@@ -639,8 +639,10 @@ def load_image_data(path: Union[str, os.PathLike], key: Optional[str] = None, la
             import h5py
         except ImportError as exc:
             raise RuntimeError("load_image_data: reading hdf5 needs h5py, which is not installed here") from exc
+        if lazy_loading:                          # the dataset handle is only valid while its file is open: the file stays open (as the
+            return h5py.File(path, "r")[key]      # reference's lazy path does; the handle keeps the file object alive) - ADVICE r5
         with h5py.File(path, "r") as f:
-            return f[key] if lazy_loading else f[key][:]
+            return f[key][:]
     if os.path.isdir(path):                       # zarr (v2 / v3) directory store
         from . import zarr_store
         arr = zarr_store.open(path, mode="r")[key]
