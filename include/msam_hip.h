@@ -691,6 +691,8 @@ typedef struct msam_si2t {
     const float* ln_weight; const float* ln_bias; float ln_eps; float denom;
     float* out;
     int32_t B, Tk;
+    int32_t split16;                     /* 1: both projections on fp16 operand pairs (msam_sgemm_t.split16); attention, residual, LayerNorm stay fp32 */
+    float wq_scale, wo_scale;            /* split16: powers of two for wq / wo (0 = 1), undone on the accumulators */
 } msam_si2t_t;
 int msam_strict_i2t_block(const msam_si2t_t* p, void* stream);
 /* Attention of the two-way transformer: q fp32 [B, Nq, H * D] (row stride ldq, batch stride in floats; 0 = one tensor shared by every

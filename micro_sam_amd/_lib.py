@@ -106,7 +106,7 @@ class SI2TParams(C.Structure):
     """include/msam_hip.h msam_si2t_t (the strict mode's fused image -> token block)."""
     _fields_ = [("keys", _vp), ("key_batch_stride", _i64), ("pos", _vp), ("wq", _vp), ("bq", _vp), ("tok_k", _vp), ("tok_v", _vp),
                 ("ld_tok", _i64), ("tok_batch_stride", _i64), ("wo", _vp), ("bo", _vp), ("ln_weight", _vp), ("ln_bias", _vp),
-                ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32)]
+                ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32), ("split16", _i32), ("wq_scale", _f32), ("wo_scale", _f32)]
 
 
 class MaskPromptParams(C.Structure):

@@ -844,8 +844,15 @@ struct SI2TArgs {
     int dbg;                                            // timing experiments (msam_tune_set "si2t_dbg"; WRONG results): 1 no projection 1, 2 no attention,
                                                         // 4 no projection 2, 8 no residual / LayerNorm
     int late_lo, late_hi, late_ticks;                   // workgroups [late_lo, late_hi) - the second one of every CU in the first dispatch round -
-};                                                      // start late_ticks x 10 ns late (de-phasing, see the kernel)
+                                                        // start late_ticks x 10 ns late (de-phasing, see the kernel)
+    float wq_scale, wo_scale;                           // SPLIT: powers of two applied to W_q / W_o before the fp16 split (undone on the accumulators)
+};
 
+// SPLIT: the split16 mode - both projections on fp16 operand pairs (3 x v_mfma_f32_32x32x16_f16 per product and 16-deep k-step); LDS rows hold
+// 32 hi | 32 lo halves as in sgemm_kernel<SPLIT>.  In projection 2 the attention's registers are still the B operand: k-step s of channel tile kt
+// takes a lane's registers 8 s .. 8 s + 7 = channels 16 s + 4 lh + {0..3, 8..11}, so W_o's k-tile is stored with that permutation
+// (any assignment of k that is the same on both operands is a valid contraction).  Attention, residual and LayerNorm: the same fp32 code.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     constexpr int C = 256, CI = 128, P = SG_PITCH;
     // one LDS block, the small broadcast tables first (ds offsets are 16-bit immediates: an array placed above 64 KB costs an address
@@ -895,8 +902,18 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     auto store1 = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *(float4*)&Xs[(srow + 32 * j) * P + sc4] = rx[j];
-            *(float4*)&Wt[(srow + 32 * j) * P + sc4] = rw[j];
+            if constexpr (SPLIT) {
+                uint2 h, l;
+                char* const px_ = (char*)&Xs[(srow + 32 * j) * P] + sc4 * 2;
+                char* const pw_ = (char*)&Wt[(srow + 32 * j) * P] + sc4 * 2;
+                sp_split4(rx[j], 1.0f, h, l);
+                *(uint2*)px_ = h; *(uint2*)(px_ + 64) = l;
+                sp_split4(rw[j], a.wq_scale, h, l);
+                *(uint2*)pw_ = h; *(uint2*)(pw_ + 64) = l;
+            } else {
+                *(float4*)&Xs[(srow + 32 * j) * P + sc4] = rx[j];
+                *(float4*)&Wt[(srow + 32 * j) * P + sc4] = rw[j];
+            }
         }
     };
     // W_o k-tile: thread = output channel, its 32 k values are 128 contiguous bytes (one pointer, immediate offsets: the registers
@@ -908,7 +925,15 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     };
     auto store3 = [&]() {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *(float4*)&Wt[tid * P + 4 * j] = rw[j];
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (SPLIT) {
+                // channels 4 j .. 4 j + 3 of the k-tile: k-step j >> 2, lane half j & 1, first / second group of four (j >> 1) & 1
+                uint2 h, l;
+                char* const pw_ = (char*)&Wt[tid * P] + ((j >> 2) * 16 + (j & 1) * 8 + ((j >> 1) & 1) * 4) * 2;
+                sp_split4(rw[j], a.wo_scale, h, l);
+                *(uint2*)pw_ = h; *(uint2*)(pw_ + 64) = l;
+            } else *(float4*)&Wt[tid * P + 4 * j] = rw[j];
+        }
     };
     // ---- Q^T = W_q (keys + pos)^T
     f32x16_t q[4];
@@ -922,8 +947,20 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
 #pragma unroll 1
     for (int kt = 0; kt < ((a.dbg & 1) ? 0 : C / 32); ++kt) {
         if (kt + 1 < C / 32) load1(kt + 1);
-        const float* px = &Xs[(w * 32 + li) * P + lh * 16];
-        const float* pw = &Wt[li * P + lh * 16];
+        const float* px = &Xs[(w * 32 + li) * P + lh * (SPLIT ? 4 : 16)];
+        const float* pw = &Wt[li * P + lh * (SPLIT ? 4 : 16)];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint4 xh = *(const uint4*)((const char*)px + ks * 32), xl = *(const uint4*)((const char*)px + ks * 32 + 64);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const char* qw = (const char*)(pw + nt * 32 * P) + ks * 32;
+                    const uint4 wh = *(const uint4*)qw, wl = *(const uint4*)(qw + 64);
+                    q[nt] = mfma32h(wl, xh, q[nt]); q[nt] = mfma32h(wh, xl, q[nt]); q[nt] = mfma32h(wh, xh, q[nt]);
+                }
+            }
+        } else
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const float4 xb = ld4(px + s4 * 4);
@@ -952,7 +989,13 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const float4 bb = ld4(&par[nt * 32 + 8 * g4 + 4 * lh]);
-            q[nt][4 * g4] += bb.x; q[nt][4 * g4 + 1] += bb.y; q[nt][4 * g4 + 2] += bb.z; q[nt][4 * g4 + 3] += bb.w;
+            if constexpr (SPLIT) {
+                const float iq = 1.0f / a.wq_scale;
+                q[nt][4 * g4] = q[nt][4 * g4] * iq + bb.x; q[nt][4 * g4 + 1] = q[nt][4 * g4 + 1] * iq + bb.y;
+                q[nt][4 * g4 + 2] = q[nt][4 * g4 + 2] * iq + bb.z; q[nt][4 * g4 + 3] = q[nt][4 * g4 + 3] * iq + bb.w;
+            } else {
+                q[nt][4 * g4] += bb.x; q[nt][4 * g4 + 1] += bb.y; q[nt][4 * g4 + 2] += bb.z; q[nt][4 * g4 + 3] += bb.w;
+            }
         }
     // ---- softmax((q . k) / denom) v per head, in place over q
     if (!(a.dbg & 2))
@@ -1006,6 +1049,25 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
 #pragma unroll
     for (int kt = 0; kt < CI / 32; ++kt) {
         const float* pw = &Wt[li * P + 4 * lh];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                // the lane's eight attention values of this k-step as an fp16 pair
+                uint4 bh, bl;
+                {
+                    uint2 h0, l0, h1, l1;
+                    sp_split4(make_float4(q[kt][8 * ks], q[kt][8 * ks + 1], q[kt][8 * ks + 2], q[kt][8 * ks + 3]), 1.0f, h0, l0);
+                    sp_split4(make_float4(q[kt][8 * ks + 4], q[kt][8 * ks + 5], q[kt][8 * ks + 6], q[kt][8 * ks + 7]), 1.0f, h1, l1);
+                    bh = uint4{h0.x, h0.y, h1.x, h1.y}; bl = uint4{l0.x, l0.y, l1.x, l1.y};
+                }
+#pragma unroll
+                for (int ot = 0; ot < 8; ++ot) {
+                    const char* qw = (const char*)(pw + ot * 32 * P) + ks * 32;
+                    const uint4 wh = *(const uint4*)qw, wl = *(const uint4*)(qw + 64);
+                    oa[ot] = mfma32h(wl, bh, oa[ot]); oa[ot] = mfma32h(wh, bl, oa[ot]); oa[ot] = mfma32h(wh, bh, oa[ot]);
+                }
+            }
+        } else {
         // one W_o fragment ahead of the MFMAs, no further (sched_barrier): 192 accumulator registers are live here
         float4 wa = ld4(pw);
 #pragma unroll
@@ -1019,6 +1081,7 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 wa = wn;
             }
+        }
         // (the next k-tile is fetched only now: 64 + 128 accumulator registers leave no room for a prefetch across the MFMAs - the other
         //  workgroup of the CU runs under this latency)
         if (kt + 1 < CI / 32) load3(kt + 1);
@@ -1055,6 +1118,10 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const float4 rv = ld4(&st[li * P + 8 * g4 + 4 * lh]), bb = ld4(&par[256 + ot * 32 + 8 * g4 + 4 * lh]);
+                if constexpr (SPLIT) {
+                    const float io = 1.0f / a.wo_scale;
+                    oa[ot][4 * g4] *= io; oa[ot][4 * g4 + 1] *= io; oa[ot][4 * g4 + 2] *= io; oa[ot][4 * g4 + 3] *= io;
+                }
                 oa[ot][4 * g4] = (oa[ot][4 * g4] + bb.x) + rv.x; oa[ot][4 * g4 + 1] = (oa[ot][4 * g4 + 1] + bb.y) + rv.y;
                 oa[ot][4 * g4 + 2] = (oa[ot][4 * g4 + 2] + bb.z) + rv.z; oa[ot][4 * g4 + 3] = (oa[ot][4 * g4 + 3] + bb.w) + rv.w;
                 sum += (oa[ot][4 * g4] + oa[ot][4 * g4 + 1]) + (oa[ot][4 * g4 + 2] + oa[ot][4 * g4 + 3]);
@@ -1555,8 +1622,11 @@ extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
     if (p->key_batch_stride == 0 && p->out == p->keys) { msam_set_error("msam_strict_i2t_block: a shared stream cannot be updated in place"); return 1; }
     SI2TArgs a{p->keys, p->key_batch_stride, p->pos, p->wq, p->bq, p->tok_k, p->tok_v, p->ld_tok, p->tok_batch_stride, p->wo, p->bo,
                p->ln_weight, p->ln_bias, p->ln_eps, p->denom, p->out, p->B, p->Tk, g_tune_si2t_dbg,
-               strict_num_cus(), 2 * strict_num_cus(), g_tune_si2t_late_us * 100};
-    hipLaunchKernelGGL(si2t_kernel, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
+               strict_num_cus(), 2 * strict_num_cus(), g_tune_si2t_late_us * 100,
+               p->wq_scale > 0.f ? p->wq_scale : 1.f, p->wo_scale > 0.f ? p->wo_scale : 1.f};
+    if (p->split16 < 0 || p->split16 > 1) { msam_set_error("msam_strict_i2t_block: split16 is 0 or 1"); return 1; }
+    if (p->split16) hipLaunchKernelGGL(si2t_kernel<true>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(si2t_kernel<false>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     return msam_check_launch("strict_i2t_block");
 }
 

@@ -157,6 +157,8 @@ def i2t_block(keys: torch.Tensor, shared: bool, pos: torch.Tensor, wq, tok_k: to
     p.tok_k, p.tok_v, p.ld_tok, p.tok_batch_stride = tok_k.data_ptr(), tok_v.data_ptr(), tok_k.stride(0), Tk * tok_k.stride(0)
     p.ln_weight, p.ln_bias, p.ln_eps, p.denom = norm[0].data_ptr(), norm[1].data_ptr(), float(norm[2]), 4.0
     p.out, p.B, p.Tk = out.data_ptr(), B, Tk
+    if split_active():
+        p.split16, p.wq_scale, p.wo_scale = 1, weight_scale(wq[0]), weight_scale(wo[0])
     _lib.check(_lib.load().msam_strict_i2t_block(C.byref(p), _lib.stream_ptr()), "msam_strict_i2t_block")
     return out
 

@@ -31,7 +31,7 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-def _gemm(lib, a, w, bias=None, act=0, a2=None, a2_rows=0, res=None, res_rows=0):
+def _gemm(lib, a, w, bias=None, act=0, a2=None, a2_rows=0, res=None, res_rows=0, split=False):
     from micro_sam_amd import _lib as L
     M, K = a.shape
     N = w.shape[0]
@@ -44,33 +44,39 @@ def _gemm(lib, a, w, bias=None, act=0, a2=None, a2_rows=0, res=None, res_rows=0)
     if res is not None:
         p.res, p.ldr, p.res_rows = res.data_ptr(), res.stride(0), res_rows
     p.out, p.ldc = out.data_ptr(), out.stride(0)
+    if split:
+        from micro_sam_amd import strict
+        strict.forget_scales()
+        p.split16, p.a_scale, p.w_scale = 1, 1.0, strict.weight_scale(w)
     assert lib.msam_strict_gemm(C.byref(p), None) == 0, lib.msam_last_error()
     return out
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("M,N,K", [(150, 200, 36), (5, 4, 256), (260, 32, 4), (128, 128, 64)])
 @pytest.mark.parametrize("small_below", [0, 512])
-def test_strict_gemm_every_epilogue(lib, M, N, K, small_below):
+def test_strict_gemm_every_epilogue(lib, M, N, K, small_below, split):
     g = torch.Generator().manual_seed(M + N + K)
     a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
     bias, a2, res = torch.randn(N, generator=g), torch.randn(7, K, generator=g), torch.randn(11, N, generator=g)
     assert lib.msam_tune_set(b"sgemm_small_below", small_below) == 0          # 0: the 128 x 128 tile, 512: the 64 x 64 tile at these sizes
     try:
-        _every_epilogue(lib, M, N, K, a, w, bias, a2, res)
+        _every_epilogue(lib, M, N, K, a, w, bias, a2, res, split)
     finally:
         assert lib.msam_tune_set(b"sgemm_small_below", 512) == 0
 
 
-def _every_epilogue(lib, M, N, K, a, w, bias, a2, res):
+def _every_epilogue(lib, M, N, K, a, w, bias, a2, res, split=False):
+    """split: the split16 form of the product (fp16 operand pairs, msam_sgemm_t.split16) - held to the SAME tolerance as the fp32 product."""
     y = a.double() @ w.double().t()
     tol = 3e-6 * max(1.0, y.abs().max().item())
-    assert (_gemm(lib, a, w) - y).abs().max().item() <= tol
+    assert (_gemm(lib, a, w, split=split) - y).abs().max().item() <= tol
     rows = torch.arange(M)
     y2 = (a.double() + a2.double()[rows % 7]) @ w.double().t() + bias.double()
-    out = _gemm(lib, a, w, bias, act=1, a2=a2, a2_rows=7, res=res, res_rows=11)
+    out = _gemm(lib, a, w, bias, act=1, a2=a2, a2_rows=7, res=res, res_rows=11, split=split)
     want = torch.nn.functional.gelu(y2) + res.double()[rows % 11]
     assert (out - want).abs().max().item() <= 3e-6 * max(1.0, want.abs().max().item())
-    out = _gemm(lib, a, w, bias, act=2, res=a.new_ones(M, N), res_rows=0)
+    out = _gemm(lib, a, w, bias, act=2, res=a.new_ones(M, N), res_rows=0, split=split)
     assert (out - (torch.relu(y + bias.double()) + 1)).abs().max().item() <= tol
 
 
@@ -275,8 +281,9 @@ def host_sam(lib):
         os.environ.pop("MSAM_EMU_CUS", None)
 
 
+@pytest.mark.parametrize("mode", ["strict", "split16"])
 @pytest.mark.parametrize("kind", ["points", "box+points", "mask"])
-def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind):
+def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind, mode):
     """Sam.set_precision("strict") -> Sam.decode = the reference's un-folded two-way transformer + up-scaling in fp32: low-res logits and
     IoU predictions equal the oracle's fp32 path to fp32 rounding (the default 16-bit path: 3e-2 of the logit scale)."""
     from oracle import sam_ref as S
@@ -295,7 +302,7 @@ def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind):
     with torch.no_grad():
         _, iou_r, low_r = S.predict_torch(sd, feats, (1024, 1024), (1024, 1024), pts, lbl, boxes, mask_in, return_logits=True, precision="fp32")
     from micro_sam_amd import strict
-    sam.set_precision("strict")
+    sam.set_precision(mode)                             # split16: every product on fp16 operand pairs - the same tolerances hold
     strict.FUSED_KV = kind == "box+points"              # (one case through the one-launch k | v projection, off by default)
     try:
         low, iou = sam.decode(feats, pts, lbl, boxes, mask_in)
@@ -323,8 +330,9 @@ def test_strict_gemm_a2_cols_is_two_products(host_sam):
         strict.gemm(x, torch.cat([wk, wv]), torch.cat([bk, bv]), a2=pe, a2_rows=100, a2_cols=100)
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("shared,Tk", [(True, 7), (False, 9), (False, 16)])
-def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk):
+def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk, split):
     """msam_strict_i2t_block (projection, 8-head attention over <= 16 tokens, projection + residual, LayerNorm in one launch, transposed
     MFMA orientation) against the same step as four launches; layer 0's shared stream and the in-place per-prompt stream."""
     from micro_sam_amd import strict
@@ -335,11 +343,13 @@ def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk):
     wq, wo = (torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1), (torch.randn(256, 128, generator=g) / 11, torch.randn(256, generator=g) * 0.1)
     tok_k, tok_v = torch.randn(B * Tk, 128, generator=g), torch.randn(B * Tk, 128, generator=g)
     norm = (torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2, 1e-5)
-    q = strict.gemm(keys, *wq, a2=pos, a2_rows=4096)
-    att = strict.attention(q, tok_k, tok_v, B, 8, 4096, Tk, 16, 4.0, q_shared=shared)
-    want = strict.gemm(att, *wo, res=keys, res_rows=4096 if shared else 0)
-    strict.layer_norm(want, *norm, out=want)
-    got = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
+    strict.forget_scales()
+    with strict.split_mode(split):                      # split: the split16 form of both (fp16 operand pairs; same tolerance: fp32-level accuracy)
+        q = strict.gemm(keys, *wq, a2=pos, a2_rows=4096)
+        att = strict.attention(q, tok_k, tok_v, B, 8, 4096, Tk, 16, 4.0, q_shared=shared)
+        want = strict.gemm(att, *wo, res=keys, res_rows=4096 if shared else 0)
+        strict.layer_norm(want, *norm, out=want)
+        got = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
     assert got.shape == want.shape and torch.isfinite(got).all()
     assert (got - want).abs().max().item() <= 2e-5, (got - want).abs().max().item()
     # fp64 statement of the step
