@@ -830,13 +830,14 @@ def main():
                                      "overlap the kernels of different tiles, so a HIP-event bracket there also counts queueing; "
                                      "profiles/ holds the rocprofv3 summary of the same one-lane command (--lanes 1)"),
                 "other_kernels": fams[1:],
-                # why frac stops where it does on this chip (measured, not assumed): profiles/r05_mfma_valu_overlap.md
-                "pipes": ("MI355X, measured (tools/mfma_valu_overlap_probe.hip): the matrix pipe and the vector ALU of a SIMD do not overlap - MFMA-only waves + "
-                          "vector-only waves on the same SIMDs take the SUM of their times (0.251 + 0.351 -> 0.596 ms), inside one wave 3.45 cycles per vector "
-                          "instruction added next to its MFMAs.  SQ counters of the dominant kernel on this code (profiles/r05_pmc_sq_counters.md): two waves "
-                          "per SIMD x 35 % vector-busy + 32 % matrix-busy = 101 % of the launch: `frac` is the matrix share of a budget its vector "
-                          "instructions (LayerNorm2d, two GELUs, packing) fill.  Clock under this load (GRBM_GUI_ACTIVE / duration, profiles/r05_clock_under_load.md): "
-                          "2.00 GHz for the hot kernels, not the 2.4 GHz of the nominal peak (strict mode's f32 kernels: 2.43)")}
+                # why frac stops where it does (measured: profiles/r06_mfma_valu_overlap.md - the matrix pipe and the vector ALU of a SIMD DO overlap,
+                # round 5's "additive" reading came from a probe whose vector stream was dependent v_pk_fma_f32)
+                "pipes": ("MI355X, measured (tools/mfma_valu_overlap_probe2.hip, inline-asm streams): an MFMA-only and a VALU-only wave of one SIMD take 1.09 - 1.12 x the longer "
+                          "of the two in both age orders; two waves per SIMD hide up to 5 plain vector instructions per 32-cycle MFMA at 91 - 94 % matrix-pipe "
+                          "occupancy, beyond that the SIMD's vector ISSUE (~one instruction per 5.5 cycles between two waves) is the limit.  The dominant kernel "
+                          "carries 372 vector : 57 (16-cycle) matrix instructions per tile and wave: it is vector-issue-bound (profiles/r05_pmc_sq_counters.md: "
+                          "2 x 35 % VALU-active, 31 % MFMA-busy); `frac` is what its vector stream leaves of the matrix pipe.  Clock under this load: ~2.0 GHz "
+                          "(GRBM_GUI_ACTIVE / duration), not the 2.4 GHz of the nominal peak")}
         out = {
             "metric": {"bf16": "1024^2 tiles/s embed+AMG (vit_b bf16)",
                        "fp16": "1024^2 tiles/s embed+AMG (vit_b, fp16 instead of bf16 operands in the image encoder: side measurement)",

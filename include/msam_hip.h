@@ -712,6 +712,21 @@ int msam_strict_source(const float* embedding, const float* dense, int64_t dense
  * second sub-pixel * 32 + channel), hyper fp32 [P, 4, hyper_ld] -> low_res fp32 [P, nmask, 256, 256] of masks mask0 .. mask0 + nmask - 1. */
 int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, int64_t P, float* low_res,
                             void* stream);
+/* The second half of MaskDecoder.predict_masks' up-scaling + the hyper product in ONE launch, split16 products (segment_anything
+ * modeling/mask_decoder.py: output_upscaling[1:] = LayerNorm2d, GELU, ConvTranspose2d(64 -> 32, k 2, s 2), GELU; masks = hyper_in @ upscaled):
+ *   low_res[p][m][4 ty + 2 ky + ky2][4 tx + 2 kx + kx2] = sum_c hyper[p][mask0 + m][c] * GELU(W2 GELU(LayerNorm(u1[row])) + b2)[(ky2, kx2), c]
+ * u1 fp32 [P * 4096 * 4, 64]: row (prompt, token (ty, tx), first sub-pixel ky * 2 + kx) of the first transposed convolution (msam_strict_gemm
+ * over its [256, 256] weight, BEFORE the LayerNorm); w2 fp32 [128, 64] rows (ky2, kx2, c2), b2 [128]; hyper fp32 [P, 4, hyper_ld].
+ * The stream is read once; nothing but the masks is written.  Products on fp16 operand pairs (w_scale: power of two for w2, 0 = 1). */
+typedef struct {
+    const float* u1;
+    const float* ln_weight; const float* ln_bias; float ln_eps;
+    const float* w2; const float* b2; float w_scale;
+    const float* hyper; int32_t hyper_ld, mask0, nmask;
+    float* low_res;
+    int64_t P;
+} msam_sup2_t;
+int msam_strict_upscale2(const msam_sup2_t* p, void* stream);
 /* torch.nn.InstanceNorm2d (no affine; torch_em ConvBlock2d) on channels-last data: x fp32 [B, HW, C] with pixel pitch ldx (>= C: a column
  * slice of a wider buffer) -> out fp32 [B, HW, C] dense; C % 4 == 0, C <= 1024.  workspace: 2 B ceil(HW / 2048) C + 2 B C floats. */
 int msam_strict_instance_norm(const float* x, int64_t ldx, int32_t B, int64_t HW, int32_t C, float eps, float* out, float* workspace,

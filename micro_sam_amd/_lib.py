@@ -109,6 +109,12 @@ class SI2TParams(C.Structure):
                 ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32), ("split16", _i32), ("wq_scale", _f32), ("wo_scale", _f32)]
 
 
+class SUp2Params(C.Structure):
+    """include/msam_hip.h msam_sup2_t (split16: LayerNorm2d + GELU + ConvT2 + GELU + hyper product in one launch)."""
+    _fields_ = [("u1", _vp), ("ln_weight", _vp), ("ln_bias", _vp), ("ln_eps", _f32), ("w2", _vp), ("b2", _vp), ("w_scale", _f32),
+                ("hyper", _vp), ("hyper_ld", _i32), ("mask0", _i32), ("nmask", _i32), ("low_res", _vp), ("P", _i64)]
+
+
 class MaskPromptParams(C.Structure):
     """include/msam_hip.h msam_mask_prompt_t: fp32 weights of prompt_encoder.mask_downscaling."""
     _fields_ = [(n, _vp) for n in ("c1_w", "c1_b", "ln1_w", "ln1_b", "c2_w", "c2_b", "ln2_w", "ln2_b", "c3_w", "c3_b")] + [("exact_gelu", _i32)]
@@ -227,6 +233,7 @@ _PROTOS = {
     "msam_strict_im2col3x3": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "msam_strict_source": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "msam_strict_hyper_masks": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "msam_strict_upscale2": (_i32, [C.POINTER(SUp2Params), _vp]),
     "msam_strict_instance_norm": (_i32, [_vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _i64, _vp]),
     "msam_strict_resize_bilinear": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp]),
 }

@@ -49,6 +49,17 @@ MSAM_DEVINL float sp_h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Fl
 static inline f32x16_t mfma32h(const uint4& a, const uint4& b, f32x16_t c) { return mfma32<true>(a, b, c); }
 static inline float sp_h2f(uint32_t bits16) { return h16_to_f((u16)bits16); }
 #endif
+// erf GELU to fp32 rounding without erff's branches: gelu(x) = max(x, 0) - |x| Psi(|x|), Psi(t) = erfc(t / sqrt 2) / 2, with log2 Psi as a degree-8
+// minimax polynomial on [0, 9] (weighted by t Psi(t), the resulting GELU error; beyond 9 the term is < 1e-18).  Evaluated in fp32 against fp64:
+// max |error| 2.5e-7 (half an ulp of the result at x = 4.5), mean 1.8e-8 - torch's own fp32 GELU: 1.2e-6.  12 instructions instead of ~40.
+MSAM_DEVINL float gelu_p8(float x) {
+    const float t = fminf(fabsf(x), 9.0f);
+    float q = fmaf(-1.6902803281482193e-06f, t, 2.5081630155909806e-05f);
+    q = fmaf(q, t, -0.00011445332347648218f); q = fmaf(q, t, -0.000323369400575757f); q = fmaf(q, t, 0.0073334285989403725f);
+    q = fmaf(q, t, -0.05271423980593681f); q = fmaf(q, t, -0.4591154158115387f); q = fmaf(q, t, -1.151123285293579f);
+    q = fmaf(q, t, -0.9999988675117493f);
+    return fmaf(-t, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+}
 // four consecutive values -> their hi and lo halves (4 x fp16 = 8 bytes each)
 MSAM_DEVINL void sp_split4(const float4& v, float scale, uint2& hi, uint2& lo) {
     const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
@@ -1366,6 +1377,137 @@ __global__ __launch_bounds__(256) void shyper_kernel(const float* __restrict__ u
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ up-scaling, second half (split16)
+// LayerNorm2d -> GELU -> ConvTranspose2d(64 -> 32, 2 x 2, stride 2) -> GELU -> hyper_in @ upscaled -> the un-shuffled low-res masks in ONE launch
+// (upstream MaskDecoder.predict_masks: output_upscaling[1:] and `masks = (hyper_in @ upscaled_embedding.view(b, c, h * w))`).  As separate launches
+// (sln64, sgemm, shyper) the 4.3 GB first-stage stream of a 1024-prompt tile is read and written by the LayerNorm, read by the product, whose 8.6 GB
+// result is written and read again by the hyper product: 34 GB per tile; here the stream is read once and 0.8 GB of masks are written.
+// Row = (prompt, token, s1): one of the four 64-channel pixels the first transposed convolution makes of a token.  TRANSPOSED product as in
+// si2t_kernel: the weights are the A operand (row n = s2 * 32 + c2), the rows are the B operand, so a LANE is a ROW in the D layout and the lane
+// pair (row, half 0 / 1) holds the row's 128 outputs: the hyper product is register-local (one exchange per mask).  The B operand comes straight
+// from global memory: lane (row, half) needs channels 16 ks + 8 half .. + 7 of its row for k-step ks - 32 of the row's 64 values, the pair holds
+// the row (LayerNorm statistics: one exchange each).  No LDS traffic for the stream, no workgroup barrier in the loop; W2 (fp16 pair, 34 KB)
+// and the small vectors are staged once per workgroup.  Products on fp16 operand pairs (split16); LayerNorm, both erf GELUs (gelu_p8: the erf
+// form to fp32 rounding) and the hyper product in fp32.
+struct SUp2Args {
+    const float* u1;                                    // [P * 16384, 64] first-stage rows (before the LayerNorm)
+    const float* lnw; const float* lnb; float eps;
+    const float* w2; const float* b2; float w_scale;    // [128, 64] rows (ky2, kx2, c2), [128]
+    const float* hyper; int hyper_ld, mask0, nmask;     // [P, 4, hyper_ld]
+    float* low;                                         // [P, nmask, 256, 256]
+    long P;
+};
+constexpr int SU_WP = 272;                              // W2 row pitch in bytes: 64 hi | 64 lo halves + 16
+constexpr int SU_TILES = 4;                             // 32-row tiles per wave and workgroup (a workgroup: 512 rows of one prompt)
+
+__global__ __launch_bounds__(256, 2) void s16_up2_kernel(SUp2Args a) {
+    __shared__ __attribute__((aligned(16))) unsigned char w2s[128 * SU_WP];
+    __shared__ __attribute__((aligned(16))) float vec[64 + 64 + 128 + 128];      // LayerNorm weight | bias | b2 | hyper [4][32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const long p = blockIdx.x >> 5;                     // 32 workgroups of 512 rows per prompt
+    const int blk = (int)(blockIdx.x & 31);
+    // W2 -> fp16 pairs: thread = (row n = tid / 2, 32 columns)
+    {
+        const int n = tid >> 1, c0 = (tid & 1) * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint2 h, l;
+            sp_split4(ld4(a.w2 + n * 64 + c0 + 4 * j), a.w_scale, h, l);
+            *(uint2*)(w2s + n * SU_WP + (c0 + 4 * j) * 2) = h;
+            *(uint2*)(w2s + n * SU_WP + 128 + (c0 + 4 * j) * 2) = l;
+        }
+        if (tid < 64) { vec[tid] = a.lnw[tid]; vec[64 + tid] = a.lnb[tid]; }
+        if (tid < 128) {
+            vec[128 + tid] = a.b2[tid];
+            const int m = tid >> 5;
+            vec[256 + tid] = m < a.nmask ? a.hyper[(p * 4 + a.mask0 + m) * a.hyper_ld + (tid & 31)] : 0.f;
+        }
+    }
+    __syncthreads();
+    const float inv = 1.0f / a.w_scale;
+#pragma unroll 1
+    for (int t = 0; t < SU_TILES; ++t) {
+        const int r0 = blk * 512 + (t * 4 + w) * 32;    // row of lane 0 inside the prompt (16384 rows)
+        const float* xr = a.u1 + ((long)p * 16384 + r0 + li) * 64 + lh * 8;
+        float x[32];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 u = ld4(xr + ks * 16), v = ld4(xr + ks * 16 + 4);
+            x[8 * ks] = u.x; x[8 * ks + 1] = u.y; x[8 * ks + 2] = u.z; x[8 * ks + 3] = u.w;
+            x[8 * ks + 4] = v.x; x[8 * ks + 5] = v.y; x[8 * ks + 6] = v.z; x[8 * ks + 7] = v.w;
+        }
+        // LayerNorm2d over the pixel's 64 channels (two-pass statistics as sln64_kernel), exact GELU
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) sm += x[i];
+        { const float o = __shfl_xor(sm, 32); sm = lh ? o + sm : sm + o; }
+        const float mean = sm * (1.0f / 64.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { x[i] -= mean; sq = fmaf(x[i], x[i], sq); }
+        { const float o = __shfl_xor(sq, 32); sq = lh ? o + sq : sq + o; }
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + a.eps);
+        uint4 bh[4], bl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ks * 16 + lh * 8;
+            const float4 w0 = ld4(&vec[c]), w1 = ld4(&vec[c + 4]), b0 = ld4(&vec[64 + c]), b1 = ld4(&vec[64 + c + 4]);
+            const float4 g0 = make_float4(gelu_p8(x[8 * ks] * rstd * w0.x + b0.x), gelu_p8(x[8 * ks + 1] * rstd * w0.y + b0.y),
+                                          gelu_p8(x[8 * ks + 2] * rstd * w0.z + b0.z), gelu_p8(x[8 * ks + 3] * rstd * w0.w + b0.w));
+            const float4 g1 = make_float4(gelu_p8(x[8 * ks + 4] * rstd * w1.x + b1.x), gelu_p8(x[8 * ks + 5] * rstd * w1.y + b1.y),
+                                          gelu_p8(x[8 * ks + 6] * rstd * w1.z + b1.z), gelu_p8(x[8 * ks + 7] * rstd * w1.w + b1.w));
+            uint2 h0, l0, h1, l1;
+            sp_split4(g0, 1.0f, h0, l0); sp_split4(g1, 1.0f, h1, l1);
+            bh[ks] = uint4{h0.x, h0.y, h1.x, h1.y}; bl[ks] = uint4{l0.x, l0.y, l1.x, l1.y};
+            __builtin_amdgcn_sched_barrier(0);          // (one k-step's eight GELUs at a time: the unrolled form spilled 180 registers)
+        }
+        // the second transposed convolution: D[n = s2 * 32 + c2][row]
+        f32x16_t acc[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s2][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const unsigned char* qw = w2s + (s2 * 32 + li) * SU_WP + ks * 32 + lh * 16;
+                const uint4 wh = *(const uint4*)qw, wl = *(const uint4*)(qw + 128);
+                acc[s2] = mfma32h(wl, bh[ks], acc[s2]); acc[s2] = mfma32h(wh, bl[ks], acc[s2]); acc[s2] = mfma32h(wh, bh[ks], acc[s2]);
+            }
+        // + bias, GELU, hyper product over the lane pair's 32 channels of every sub-pixel; register r = channel (r & 3) + 8 (r >> 2) + 4 lh
+        const int row = r0 + li, tok = row >> 2, s1 = row & 3;
+        const int y0 = 4 * (tok >> 6) + 2 * (s1 >> 1), x0 = 4 * (tok & 63) + 2 * (s1 & 1);
+        float res[4][4];                                 // [mask][s2]
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = 8 * g4 + 4 * lh;
+                const float4 bb = ld4(&vec[128 + s2 * 32 + c]);
+                const float v0 = gelu_p8(acc[s2][4 * g4] * inv + bb.x), v1 = gelu_p8(acc[s2][4 * g4 + 1] * inv + bb.y),
+                            v2 = gelu_p8(acc[s2][4 * g4 + 2] * inv + bb.z), v3 = gelu_p8(acc[s2][4 * g4 + 3] * inv + bb.w);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 hh = ld4(&vec[256 + m * 32 + c]);
+                    part[m] = fmaf(hh.x, v0, part[m]); part[m] = fmaf(hh.y, v1, part[m]); part[m] = fmaf(hh.z, v2, part[m]); part[m] = fmaf(hh.w, v3, part[m]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { const float o = __shfl_xor(part[m], 32); res[m][s2] = lh ? o + part[m] : part[m] + o; }
+        }
+        // lane half 0 stores the sub-pixel row ky2 = 0, half 1 the row ky2 = 1: two adjacent pixels (kx2 = 0, 1) per store
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m < a.nmask) {
+                float* o = a.low + (((long)p * a.nmask + m) * 256 + y0 + lh) * 256 + x0;
+                *(float2*)o = make_float2(lh ? res[m][2] : res[m][0], lh ? res[m][3] : res[m][1]);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ AIS decoder pieces
 // InstanceNorm2d (no affine; torch.nn.InstanceNorm2d of torch_em's ConvBlock2d) on channels-last x [B, HW, C]: statistics per (b, c) over the
 // HW pixels.  Pass 1: per chunk of pixels the mean and the centred sum of squares (two sweeps over the chunk: no E[x^2] - mean^2
@@ -1683,6 +1825,16 @@ extern "C" int msam_strict_hyper_masks(const float* up, const float* hyper, int3
     }
     hipLaunchKernelGGL(shyper_kernel, dim3((unsigned)(P * 256)), dim3(256), 0, (hipStream_t)stream, up, hyper, hyper_ld, mask0, nmask, (long)P, low_res);
     return msam_check_launch("strict_hyper_masks");
+}
+
+extern "C" int msam_strict_upscale2(const msam_sup2_t* p, void* stream) {
+    if (!p || !p->u1 || !p->ln_weight || !p->ln_bias || !p->w2 || !p->b2 || !p->hyper || !p->low_res || p->P <= 0) { msam_set_error("msam_strict_upscale2: null argument"); return 1; }
+    if (p->nmask < 1 || p->mask0 < 0 || p->mask0 + p->nmask > 4 || p->hyper_ld < 32 || ((uintptr_t)p->u1 | (uintptr_t)p->w2 | (uintptr_t)p->low_res) % 16 || p->P > (1L << 26)) {
+        msam_set_error("msam_strict_upscale2: 1 <= nmask masks out of 4, hyper_ld >= 32, 16-byte aligned pointers"); return 1;
+    }
+    SUp2Args a{p->u1, p->ln_weight, p->ln_bias, p->ln_eps, p->w2, p->b2, p->w_scale > 0.f ? p->w_scale : 1.f, p->hyper, p->hyper_ld, p->mask0, p->nmask, p->low_res, (long)p->P};
+    hipLaunchKernelGGL(s16_up2_kernel, dim3((unsigned)(p->P * 32)), dim3(256), 0, (hipStream_t)stream, a);
+    return msam_check_launch("strict_upscale2");
 }
 
 extern "C" int msam_strict_instance_norm(const float* x, int64_t ldx, int32_t B, int64_t HW, int32_t C, float eps, float* out, float* workspace,

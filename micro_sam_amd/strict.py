@@ -40,6 +40,11 @@ FUSED_I2T = True
 # stream crosses HBM once).  Measured: 59.4 ms per tile against 58.5 with two launches - these products are bound by the f32 MFMA,
 # not by HBM; off.
 FUSED_KV = False
+# ... but in the split16 mode the same products are bound by HBM (4.1 TB/s on the k / v shape), so there the one-launch form is the default
+FUSED_KV_SPLIT = True
+# split16 only: the up-scaling's LayerNorm2d, GELU, second transposed convolution, GELU and hyper product as one launch
+# (msam_strict_upscale2: the 4.3 GB first-stage stream of a tile is read once; as four launches 34 GB cross HBM)
+FUSED_UP2 = True
 
 
 def _f32(t: torch.Tensor, dev) -> torch.Tensor:
@@ -310,7 +315,7 @@ class StrictDecoder:
         """upstream ``Attention.forward``: projections, heads, softmax, (out_proj is left to the caller: it carries the residual)."""
         q = gemm(q_in, *aw["q"], a2=q_pe, a2_rows=q_pe_rows)
         inner = aw["q"][0].shape[0]
-        if FUSED_KV and k_in is v_in and k_pe is not None and inner % 128 == 0 and k_in.shape[0] >= 4096:
+        if (FUSED_KV or (split_active() and FUSED_KV_SPLIT)) and k_in is v_in and k_pe is not None and inner % 128 == 0 and k_in.shape[0] >= 4096:
             # the image side's k | v: one pass over the per-prompt stream instead of two
             kv = gemm(k_in, *aw["kv"], a2=k_pe, a2_rows=k_pe_rows, a2_cols=inner)
             k, v = kv[:, :inner], kv[:, inner:]
@@ -403,6 +408,16 @@ class StrictDecoder:
             iou[p0:p0 + pc] = iou4[:, mask0:mask0 + nc]
             # output_upscaling: ConvT 2x2 - LayerNorm2d - GELU - ConvT 2x2 - GELU on token-major rows, then hyper_in @ upscaled
             up1 = gemm(keys, *w["up1"])                                                      # [pc*4096, 4*64] = [(pc*4096*4), 64]
+            if split_active() and FUSED_UP2:
+                # LayerNorm2d + GELU + the second transposed convolution + GELU + the hyper product: one pass over the first-stage stream
+                del keys
+                q = _lib.SUp2Params()
+                q.u1, q.ln_weight, q.ln_bias, q.ln_eps = up1.data_ptr(), w["up_ln"][0].data_ptr(), w["up_ln"][1].data_ptr(), float(w["up_ln"][2])
+                q.w2, q.b2, q.w_scale = w["up2"][0].data_ptr(), w["up2"][1].data_ptr(), weight_scale(w["up2"][0])
+                q.hyper, q.hyper_ld, q.mask0, q.nmask, q.low_res, q.P = hyper.data_ptr(), 32, mask0, nc, low[p0:p0 + pc].data_ptr(), pc
+                _lib.check(lib.msam_strict_upscale2(C.byref(q), _lib.stream_ptr()), "msam_strict_upscale2")
+                del up1
+                continue
             layer_norm(up1, *w["up_ln"], out=up1, gelu=True, rows=pc * T * 4, dim=64)
             up2 = gemm(up1.view(pc * T * 4, 64), *w["up2"], act=ACT_GELU)                    # [(pc*4096*4), 4*32]
             del up1, keys

@@ -91,6 +91,8 @@ struct float4 { float x, y, z, w; };
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
 static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct float2 { float x, y; };
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline float bf2f(u16 h) { uint32_t u = (uint32_t)h << 16; float f; std::memcpy(&f, &u, 4); return f; }
 static inline u16 f2bf(float f) {
     uint32_t u; std::memcpy(&u, &f, 4);

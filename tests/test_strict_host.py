@@ -361,6 +361,43 @@ def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk, split):
     assert (got.double() - ref.reshape(-1, 256)).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("mask0,nmask", [(1, 3), (0, 1)])
+def test_split16_upscale2_is_the_three_launches(host_sam, mask0, nmask):
+    """msam_strict_upscale2 (LayerNorm2d, GELU, second transposed convolution, GELU, hyper product, un-shuffle in one launch; transposed
+    split16 product, the stream read straight from global memory) against the same steps as three launches and against fp64."""
+    from micro_sam_amd import _lib as L
+    from micro_sam_amd import strict
+    lib, _, _ = host_sam
+    g = torch.Generator().manual_seed(mask0 + 10 * nmask)
+    P = 1
+    u1 = torch.randn(P * 16384, 64, generator=g) * torch.exp(0.5 * torch.randn(P * 16384, 1, generator=g))
+    lnw, lnb = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    w2, b2 = torch.randn(128, 64, generator=g) / 8, torch.randn(128, generator=g) * 0.1
+    hyper = torch.randn(P, 4, 32, generator=g)
+    low = torch.full((P, nmask, 256, 256), float("nan"))
+    strict.forget_scales()
+    q = L.SUp2Params()
+    q.u1, q.ln_weight, q.ln_bias, q.ln_eps = u1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), 1e-6
+    q.w2, q.b2, q.w_scale = w2.data_ptr(), b2.data_ptr(), strict.weight_scale(w2)
+    q.hyper, q.hyper_ld, q.mask0, q.nmask, q.low_res, q.P = hyper.data_ptr(), 32, mask0, nmask, low.data_ptr(), P
+    assert lib.msam_strict_upscale2(C.byref(q), None) == 0, lib.msam_last_error()
+    with strict.split_mode(True):
+        t = strict.layer_norm(u1.clone(), lnw, lnb, 1e-6, gelu=True)
+        t = strict.gemm(t, w2, b2, act=strict.ACT_GELU)
+    want = torch.full((P, nmask, 256, 256), float("nan"))
+    assert lib.msam_strict_hyper_masks(t.data_ptr(), hyper.data_ptr(), 32, mask0, nmask, P, want.data_ptr(), None) == 0
+    assert torch.isfinite(low).all()
+    scale = want.abs().max().item()
+    assert (low - want).abs().max().item() <= 2e-6 * scale, (low - want).abs().max().item() / scale
+    # fp64 statement
+    xd = torch.nn.functional.gelu(torch.nn.functional.layer_norm(u1.double(), (64,), lnw.double(), lnb.double(), 1e-6))
+    up = torch.nn.functional.gelu(xd @ w2.double().T + b2.double()).reshape(P, 64, 64, 2, 2, 2, 2, 32)      # p, ty, tx, ky, kx, ky2, kx2, c
+    ref = torch.einsum("pmc,pyxabdec->pmyadxbe", hyper.double()[:, mask0:mask0 + nmask], up).reshape(P, nmask, 256, 256)
+    assert (low.double() - ref).abs().max().item() <= 3e-6 * scale
+    q.nmask = 5
+    assert lib.msam_strict_upscale2(C.byref(q), None) == 1
+
+
 def test_strict_module_call_and_single_mask(host_sam):
     """``sam.mask_decoder(...)`` (the stand-alone module call of trainable_sam.py:100-106) in strict mode, multimask_output=False."""
     from oracle import sam_ref as S
