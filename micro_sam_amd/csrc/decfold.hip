@@ -789,7 +789,7 @@ void msam_gemm_set_g3(int delay);
 void msam_gemm_set_g3_epi(int v);
 extern int g_tune_tok_fuse;
 extern int g_tune_mlp_split_fused;
-extern int g_tune_sgemm_bufs, g_tune_srel_mfma, g_tune_sgemm_small_below, g_tune_si2t_dbg, g_tune_si2t_late_us;
+extern int g_tune_sgemm_bufs, g_tune_srel_mfma, g_tune_sgemm_small_below, g_tune_si2t_dbg, g_tune_si2t_late_us, g_tune_sattn_allh;
 int g_tune_dec_chain = 1, g_tune_dec_chain_min_p = 128;
 extern "C" int msam_tune_set(const char* key, int32_t value) {
     const std::string k = key ? key : "";
@@ -810,6 +810,7 @@ extern "C" int msam_tune_set(const char* key, int32_t value) {
     else if (k == "dec_chain_min_p") g_tune_dec_chain_min_p = value;
     else if (k == "sgemm_bufs") g_tune_sgemm_bufs = value;
     else if (k == "srel_mfma") g_tune_srel_mfma = value;
+    else if (k == "sattn_allh") g_tune_sattn_allh = value;
     else if (k == "sgemm_small_below") g_tune_sgemm_small_below = value;
     else if (k == "si2t_dbg") g_tune_si2t_dbg = value;
     else if (k == "si2t_late_us") g_tune_si2t_late_us = value;

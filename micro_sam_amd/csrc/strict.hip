@@ -23,6 +23,7 @@ int g_tune_sgemm_bufs = 1;               // msam_tune_set("sgemm_bufs", 1 | 2): 
 int g_tune_sgemm_small_below = 512;      // msam_tune_set("sgemm_small_below", n): launches of fewer than n 128 x 128 tiles run on 64 x 64 tiles
 int g_tune_si2t_late_us = 0;             // msam_tune_set("si2t_late_us", n): start delay of the second workgroup per CU (0: none; measured: no effect)
 int g_tune_si2t_dbg = 0;                 // msam_tune_set("si2t_dbg", bits): timing experiments of si2t_kernel (WRONG results when != 0)
+int g_tune_sattn_allh = 1;               // msam_tune_set("sattn_allh", 0 | 1): token -> image attention with one workgroup per prompt (all heads) instead of one per (prompt, head)
 int g_tune_srel_mfma = 2;                // msam_tune_set("srel_mfma", 0 | 1 | 2): 1 = global attention on srelpos_mfma_kernel, 2 = the windows on srelpos_win_mfma_kernel as well, 0 = the vector-unit kernel for both
 
 // register budget of a kernel as waves per SIMD (the tests' host build of this file - tests/hip_host_shim.py, g++ - has no such attribute)
@@ -59,6 +60,19 @@ MSAM_DEVINL float gelu_p8(float x) {
     q = fmaf(q, t, -0.05271423980593681f); q = fmaf(q, t, -0.4591154158115387f); q = fmaf(q, t, -1.151123285293579f);
     q = fmaf(q, t, -0.9999988675117493f);
     return fmaf(-t, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+}
+// two values at once on packed fp32 arithmetic (v_pk_fma_f32: the vector ALU issues one instruction per 4 cycles and SIMD whatever its width,
+// so a VALU-bound kernel wants the packed forms - profiles/r06_mfma_valu_overlap.md)
+MSAM_DEVINL f32x2_t gelu_p8x2(f32x2_t x) {
+    const f32x2_t r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    f32x2_t t = r * 2.0f - x;                       // |x|
+    t.x = fminf(t.x, 9.0f); t.y = fminf(t.y, 9.0f);
+    f32x2_t q = t * -1.6902803281482193e-06f + 2.5081630155909806e-05f;
+    q = q * t + -0.00011445332347648218f; q = q * t + -0.000323369400575757f; q = q * t + 0.0073334285989403725f;
+    q = q * t + -0.05271423980593681f; q = q * t + -0.4591154158115387f; q = q * t + -1.151123285293579f;
+    q = q * t + -0.9999988675117493f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    return r - t * e;
 }
 // four consecutive values -> their hi and lo halves (4 x fp16 = 8 bytes each)
 MSAM_DEVINL void sp_split4(const float4& v, float scale, uint2& hi, uint2& lo) {
@@ -1239,14 +1253,17 @@ __global__ __launch_bounds__(256) void sattn_short_kernel(SAttnArgs a) {
 
 // Nq <= 16, long key side (token -> image attention over the 4096 image tokens): one workgroup per (batch, head); thread (t, slice) walks
 // the keys slice, slice + NS, ... for query t with an online softmax; the NS partial (m, l, acc) of a query are merged through LDS.
-template <int D, int NQP>
+// ALLH (H == 8, head dim 16, <= 8 queries): one workgroup per batch entry - thread = (query t, head h, slice of 4) - so that the workgroup reads
+// whole 512-byte k / v rows (8 heads x 64 bytes) instead of one 64-byte piece of every row (2.0 -> ~1 ms per 1024-prompt layer: the kernel is
+// a stream over the prompt's k and v, 4.3 GB per layer).
+template <int D, int NQP, bool ALLH = false>
 __global__ __launch_bounds__(256) void sattn_long_kernel(SAttnArgs a) {
-    constexpr int NS = 256 / NQP;
+    constexpr int NS = ALLH ? 256 / (NQP * 8) : 256 / NQP;
     __shared__ float red_m[256], red_l[256];
     __shared__ __attribute__((aligned(16))) float red_o[256 * D];
-    const int tid = threadIdx.x, t = tid % NQP, sl = tid / NQP;
-    const int h = blockIdx.x % a.H;
-    const long b = blockIdx.x / a.H;
+    const int tid = threadIdx.x, t = tid % NQP, sl = ALLH ? tid / (NQP * 8) : tid / NQP;
+    const int h = ALLH ? (tid / NQP) & 7 : blockIdx.x % a.H;
+    const long b = ALLH ? blockIdx.x : blockIdx.x / a.H;
     const bool act = t < a.Nq;
     float q[D], o[D];
     {
@@ -1282,6 +1299,23 @@ __global__ __launch_bounds__(256) void sattn_long_kernel(SAttnArgs a) {
 #pragma unroll
     for (int d = 0; d < D; ++d) red_o[tid * D + d] = o[d];
     __syncthreads();
+    if constexpr (ALLH) {
+        // thread index = (sl * 8 + h) * NQP + t: the NS partial results of (t, h) sit NQP * 8 apart
+        for (int idx = tid; idx < a.Nq * 8 * D; idx += 256) {
+            const int d = idx % D, hh = (idx / D) & 7, tt = idx / (D * 8);
+            const int base = hh * NQP + tt;
+            float M = -3.0e38f;
+            for (int s2 = 0; s2 < NS; ++s2) M = fmaxf(M, red_m[s2 * NQP * 8 + base]);
+            float L = 0.f, O = 0.f;
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float wgt = expf(red_m[s2 * NQP * 8 + base] - M);
+                L = fmaf(red_l[s2 * NQP * 8 + base], wgt, L);
+                O = fmaf(red_o[(s2 * NQP * 8 + base) * D + d], wgt, O);
+            }
+            a.out[b * a.sob + (long)tt * a.ldo + hh * D + d] = O / L;
+        }
+        return;
+    }
     for (int idx = tid; idx < a.Nq * D; idx += 256) {
         const int tt = idx / D, d = idx % D;
         float M = -3.0e38f;
@@ -1400,7 +1434,7 @@ struct SUp2Args {
 constexpr int SU_WP = 272;                              // W2 row pitch in bytes: 64 hi | 64 lo halves + 16
 constexpr int SU_TILES = 4;                             // 32-row tiles per wave and workgroup (a workgroup: 512 rows of one prompt)
 
-__global__ __launch_bounds__(256, 2) void s16_up2_kernel(SUp2Args a) {
+__global__ __launch_bounds__(256, 4) void s16_up2_kernel(SUp2Args a) {
     __shared__ __attribute__((aligned(16))) unsigned char w2s[128 * SU_WP];
     __shared__ __attribute__((aligned(16))) float vec[64 + 64 + 128 + 128];      // LayerNorm weight | bias | b2 | hyper [4][32]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -1429,22 +1463,23 @@ __global__ __launch_bounds__(256, 2) void s16_up2_kernel(SUp2Args a) {
     for (int t = 0; t < SU_TILES; ++t) {
         const int r0 = blk * 512 + (t * 4 + w) * 32;    // row of lane 0 inside the prompt (16384 rows)
         const float* xr = a.u1 + ((long)p * 16384 + r0 + li) * 64 + lh * 8;
-        float x[32];
+        f32x2_t x[16];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const float4 u = ld4(xr + ks * 16), v = ld4(xr + ks * 16 + 4);
-            x[8 * ks] = u.x; x[8 * ks + 1] = u.y; x[8 * ks + 2] = u.z; x[8 * ks + 3] = u.w;
-            x[8 * ks + 4] = v.x; x[8 * ks + 5] = v.y; x[8 * ks + 6] = v.z; x[8 * ks + 7] = v.w;
+            x[4 * ks] = f32x2_t{u.x, u.y}; x[4 * ks + 1] = f32x2_t{u.z, u.w}; x[4 * ks + 2] = f32x2_t{v.x, v.y}; x[4 * ks + 3] = f32x2_t{v.z, v.w};
         }
-        // LayerNorm2d over the pixel's 64 channels (two-pass statistics as sln64_kernel), exact GELU
-        float sm = 0.f;
+        // LayerNorm2d over the pixel's 64 channels (two-pass statistics as sln64_kernel), erf GELU
+        f32x2_t s2v = x[0];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) sm += x[i];
+        for (int i = 1; i < 16; ++i) s2v += x[i];
+        float sm = s2v.x + s2v.y;
         { const float o = __shfl_xor(sm, 32); sm = lh ? o + sm : sm + o; }
         const float mean = sm * (1.0f / 64.0f);
-        float sq = 0.f;
+        f32x2_t sqv = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { x[i] -= mean; sq = fmaf(x[i], x[i], sq); }
+        for (int i = 0; i < 16; ++i) { x[i] -= mean; sqv += x[i] * x[i]; }
+        float sq = sqv.x + sqv.y;
         { const float o = __shfl_xor(sq, 32); sq = lh ? o + sq : sq + o; }
         const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + a.eps);
         uint4 bh[4], bl[4];
@@ -1452,59 +1487,68 @@ __global__ __launch_bounds__(256, 2) void s16_up2_kernel(SUp2Args a) {
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ks * 16 + lh * 8;
             const float4 w0 = ld4(&vec[c]), w1 = ld4(&vec[c + 4]), b0 = ld4(&vec[64 + c]), b1 = ld4(&vec[64 + c + 4]);
-            const float4 g0 = make_float4(gelu_p8(x[8 * ks] * rstd * w0.x + b0.x), gelu_p8(x[8 * ks + 1] * rstd * w0.y + b0.y),
-                                          gelu_p8(x[8 * ks + 2] * rstd * w0.z + b0.z), gelu_p8(x[8 * ks + 3] * rstd * w0.w + b0.w));
-            const float4 g1 = make_float4(gelu_p8(x[8 * ks + 4] * rstd * w1.x + b1.x), gelu_p8(x[8 * ks + 5] * rstd * w1.y + b1.y),
-                                          gelu_p8(x[8 * ks + 6] * rstd * w1.z + b1.z), gelu_p8(x[8 * ks + 7] * rstd * w1.w + b1.w));
+            const f32x2_t g0 = gelu_p8x2(x[4 * ks] * rstd * f32x2_t{w0.x, w0.y} + f32x2_t{b0.x, b0.y});
+            const f32x2_t g1 = gelu_p8x2(x[4 * ks + 1] * rstd * f32x2_t{w0.z, w0.w} + f32x2_t{b0.z, b0.w});
+            const f32x2_t g2 = gelu_p8x2(x[4 * ks + 2] * rstd * f32x2_t{w1.x, w1.y} + f32x2_t{b1.x, b1.y});
+            const f32x2_t g3 = gelu_p8x2(x[4 * ks + 3] * rstd * f32x2_t{w1.z, w1.w} + f32x2_t{b1.z, b1.w});
             uint2 h0, l0, h1, l1;
-            sp_split4(g0, 1.0f, h0, l0); sp_split4(g1, 1.0f, h1, l1);
+            sp_split4(make_float4(g0.x, g0.y, g1.x, g1.y), 1.0f, h0, l0); sp_split4(make_float4(g2.x, g2.y, g3.x, g3.y), 1.0f, h1, l1);
             bh[ks] = uint4{h0.x, h0.y, h1.x, h1.y}; bl[ks] = uint4{l0.x, l0.y, l1.x, l1.y};
-            __builtin_amdgcn_sched_barrier(0);          // (one k-step's eight GELUs at a time: the unrolled form spilled 180 registers)
+            __builtin_amdgcn_sched_barrier(0);          // (one k-step's eight GELUs at a time: the fully interleaved form spilled 180 registers)
         }
-        // the second transposed convolution: D[n = s2 * 32 + c2][row]
-        f32x16_t acc[4];
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[s2][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const unsigned char* qw = w2s + (s2 * 32 + li) * SU_WP + ks * 32 + lh * 16;
-                const uint4 wh = *(const uint4*)qw, wl = *(const uint4*)(qw + 128);
-                acc[s2] = mfma32h(wl, bh[ks], acc[s2]); acc[s2] = mfma32h(wh, bl[ks], acc[s2]); acc[s2] = mfma32h(wh, bh[ks], acc[s2]);
-            }
-        // + bias, GELU, hyper product over the lane pair's 32 channels of every sub-pixel; register r = channel (r & 3) + 8 (r >> 2) + 4 lh
         const int row = r0 + li, tok = row >> 2, s1 = row & 3;
         const int y0 = 4 * (tok >> 6) + 2 * (s1 >> 1), x0 = 4 * (tok & 63) + 2 * (s1 & 1);
-        float res[4][4];                                 // [mask][s2]
+        // the second transposed convolution, one sub-pixel row (ky2 = hp: s2 = 2 hp, 2 hp + 1) at a time: D[n = s2 * 32 + c2][row]; 32 instead of 64
+        // accumulator registers live -> three waves per SIMD (the kernel is bound by its vector instructions: more waves, more issue slots used)
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int hp = 0; hp < 2; ++hp) {
+            f32x16_t acc[2];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int c = 8 * g4 + 4 * lh;
-                const float4 bb = ld4(&vec[128 + s2 * 32 + c]);
-                const float v0 = gelu_p8(acc[s2][4 * g4] * inv + bb.x), v1 = gelu_p8(acc[s2][4 * g4 + 1] * inv + bb.y),
-                            v2 = gelu_p8(acc[s2][4 * g4 + 2] * inv + bb.z), v3 = gelu_p8(acc[s2][4 * g4 + 3] * inv + bb.w);
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q2][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const unsigned char* qw = w2s + ((2 * hp + q2) * 32 + li) * SU_WP + ks * 32 + lh * 16;
+                    const uint4 wh = *(const uint4*)qw, wl = *(const uint4*)(qw + 128);
+                    acc[q2] = mfma32h(wl, bh[ks], acc[q2]); acc[q2] = mfma32h(wh, bl[ks], acc[q2]); acc[q2] = mfma32h(wh, bh[ks], acc[q2]);
+                }
+            // + bias, GELU, hyper product over the lane pair's 32 channels of the sub-pixel; register r = channel (r & 3) + 8 (r >> 2) + 4 lh
+            float res[4][2];                             // [mask][kx2]
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                f32x2_t part[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int c = 8 * g4 + 4 * lh;
+                    const float4 bb = ld4(&vec[128 + (2 * hp + q2) * 32 + c]);
+                    const f32x2_t v01 = gelu_p8x2(f32x2_t{acc[q2][4 * g4], acc[q2][4 * g4 + 1]} * inv + f32x2_t{bb.x, bb.y});
+                    const f32x2_t v23 = gelu_p8x2(f32x2_t{acc[q2][4 * g4 + 2], acc[q2][4 * g4 + 3]} * inv + f32x2_t{bb.z, bb.w});
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float4 hh = ld4(&vec[256 + m * 32 + c]);
+                        part[m] += f32x2_t{hh.x, hh.y} * v01; part[m] += f32x2_t{hh.z, hh.w} * v23;
+                    }
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const float4 hh = ld4(&vec[256 + m * 32 + c]);
-                    part[m] = fmaf(hh.x, v0, part[m]); part[m] = fmaf(hh.y, v1, part[m]); part[m] = fmaf(hh.z, v2, part[m]); part[m] = fmaf(hh.w, v3, part[m]);
+                    const float pm = part[m].x + part[m].y;
+                    const float o = __shfl_xor(pm, 32);
+                    res[m][q2] = lh ? o + pm : pm + o;
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            // the lane pair splits the masks: half 0 stores masks 0 and 2, half 1 masks 1 and 3 (two adjacent pixels kx2 = 0, 1 per store)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { const float o = __shfl_xor(part[m], 32); res[m][s2] = lh ? o + part[m] : part[m] + o; }
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = 2 * mm + lh;
+                if (m < a.nmask) {
+                    float* o = a.low + (((long)p * a.nmask + m) * 256 + y0 + hp) * 256 + x0;
+                    *(float2*)o = make_float2(lh ? res[2 * mm + 1][0] : res[2 * mm][0], lh ? res[2 * mm + 1][1] : res[2 * mm][1]);
+                }
+            }
         }
-        // lane half 0 stores the sub-pixel row ky2 = 0, half 1 the row ky2 = 1: two adjacent pixels (kx2 = 0, 1) per store
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (m < a.nmask) {
-                float* o = a.low + (((long)p * a.nmask + m) * 256 + y0 + lh) * 256 + x0;
-                *(float2*)o = make_float2(lh ? res[m][2] : res[m][0], lh ? res[m][3] : res[m][1]);
-            }
     }
 }
 
@@ -1790,7 +1834,8 @@ extern "C" int msam_strict_attention(const float* q, int64_t ldq, int64_t q_batc
         else hipLaunchKernelGGL(sattn_short_kernel<32>, dim3(g), dim3(256), 0, s, a);
     } else {
         const dim3 g((unsigned)((long)B * H));
-        if (D == 16) { if (Nq <= 8) hipLaunchKernelGGL((sattn_long_kernel<16, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((sattn_long_kernel<16, 16>), g, dim3(256), 0, s, a); }
+        if (D == 16 && Nq <= 8 && H == 8 && g_tune_sattn_allh) hipLaunchKernelGGL((sattn_long_kernel<16, 8, true>), dim3((unsigned)B), dim3(256), 0, s, a);
+        else if (D == 16) { if (Nq <= 8) hipLaunchKernelGGL((sattn_long_kernel<16, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((sattn_long_kernel<16, 16>), g, dim3(256), 0, s, a); }
         else { if (Nq <= 8) hipLaunchKernelGGL((sattn_long_kernel<32, 8>), g, dim3(256), 0, s, a); else hipLaunchKernelGGL((sattn_long_kernel<32, 16>), g, dim3(256), 0, s, a); }
     }
     return msam_check_launch("strict_attention");

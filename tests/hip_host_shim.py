@@ -82,6 +82,8 @@ struct f32x2_t {                                             // clang's ext_vect
     f32x2_t operator*(float s) const { return {x * s, y * s}; }
     f32x2_t operator+(float s) const { return {x + s, y + s}; }
     f32x2_t& operator+=(const f32x2_t& o) { x += o.x; y += o.y; return *this; }
+    f32x2_t operator-(float s) const { return {x - s, y - s}; }
+    f32x2_t& operator-=(float s) { x -= s; y -= s; return *this; }
 };
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 typedef float f32x16_t __attribute__((vector_size(64)));

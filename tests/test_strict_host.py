@@ -114,7 +114,7 @@ def test_strict_layernorm_nchw_output(lib):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D,shared", [(3, 8, 4096 // 64, 7, 16, False), (2, 8, 7, 7, 32, False), (2, 8, 7, 300, 16, True),
-                                               (2, 2, 12, 520, 16, False), (1, 8, 16, 16, 32, False), (2, 8, 64, 13, 16, True)])
+                                               (2, 2, 12, 520, 16, False), (2, 8, 5, 520, 16, False), (1, 8, 16, 16, 32, False), (2, 8, 64, 13, 16, True)])
 def test_strict_attention(lib, B, H, Nq, Nk, D, shared):
     """Both kernels (short key side: one thread per query and head; long key side: a workgroup per (batch, head)), with the shared
     (batch stride 0) operands of the first decoder layer."""
