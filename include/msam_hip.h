@@ -675,6 +675,10 @@ int msam_strict_layernorm(const float* x, const float* weight, const float* bias
  * msam_tune_set("srel_mfma", 1) sends the windows, 0 both forms to the vector-unit kernel (srelpos_kernel). */
 int msam_strict_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
                                  int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream);
+/* The same attention in the split16 mode: q . k and p @ v on fp16 operand pairs (msam_sgemm_t.split16; the exponentials are scaled by 2^12 into
+ * fp16's normal range before the split), scores / softmax / relative-position terms / the division in fp32 as above. */
+int msam_split16_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
+                                  int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream);
 /* The "image attends to the tokens" step of one TwoWayAttentionBlock on the per-prompt image stream in ONE launch (segment_anything
  * modeling/transformer.py TwoWayAttentionBlock.forward: q = keys + key_pe; attn_out = cross_attn_image_to_token(q, k, v);
  * keys = norm4(keys + attn_out)), 4096 image tokens x 256 channels per prompt, 8 heads x 16 channels in the attention:

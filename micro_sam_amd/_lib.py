@@ -227,6 +227,7 @@ _PROTOS = {
     "msam_strict_i2t_block": (_i32, [C.POINTER(SI2TParams), _vp]),
     "msam_strict_layernorm": (_i32, [_vp, _vp, _vp, _f32, _i64, _i32, _vp, _i32, _i32, _vp]),
     "msam_strict_relpos_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "msam_split16_relpos_attention": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "msam_strict_attention": (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _i64,
                                      _i64, _vp]),
     "msam_strict_patchify": (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp]),

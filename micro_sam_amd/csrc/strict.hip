@@ -23,7 +23,7 @@ int g_tune_sgemm_bufs = 1;               // msam_tune_set("sgemm_bufs", 1 | 2): 
 int g_tune_sgemm_small_below = 512;      // msam_tune_set("sgemm_small_below", n): launches of fewer than n 128 x 128 tiles run on 64 x 64 tiles
 int g_tune_si2t_late_us = 0;             // msam_tune_set("si2t_late_us", n): start delay of the second workgroup per CU (0: none; measured: no effect)
 int g_tune_si2t_dbg = 0;                 // msam_tune_set("si2t_dbg", bits): timing experiments of si2t_kernel (WRONG results when != 0)
-int g_tune_sattn_allh = 1;               // msam_tune_set("sattn_allh", 0 | 1): token -> image attention with one workgroup per prompt (all heads) instead of one per (prompt, head)
+int g_tune_sattn_allh = 0;               // msam_tune_set("sattn_allh", 0 | 1): token -> image attention with one workgroup per prompt (all heads) instead of one per (prompt, head); measured 1221 vs 691 us per 512 prompts: off
 int g_tune_srel_mfma = 2;                // msam_tune_set("srel_mfma", 0 | 1 | 2): 1 = global attention on srelpos_mfma_kernel, 2 = the windows on srelpos_win_mfma_kernel as well, 0 = the vector-unit kernel for both
 
 // register budget of a kernel as waves per SIMD (the tests' host build of this file - tests/hip_host_shim.py, g++ - has no such attribute)
@@ -81,12 +81,24 @@ MSAM_DEVINL void sp_split4(const float4& v, float scale, uint2& hi, uint2& lo) {
     lo.x = pack2h(x0 - sp_h2f(hi.x & 0xffffu), x1 - sp_h2f(hi.x >> 16));
     lo.y = pack2h(x2 - sp_h2f(hi.y & 0xffffu), x3 - sp_h2f(hi.y >> 16));
 }
+// eight values -> one MFMA operand pair (hi, lo)
+MSAM_DEVINL void sp_split8(const float* v, float scale, uint4& hi, uint4& lo) {
+    uint2 h0, l0, h1, l1;
+    sp_split4(make_float4(v[0], v[1], v[2], v[3]), scale, h0, l0);
+    sp_split4(make_float4(v[4], v[5], v[6], v[7]), scale, h1, l1);
+    hi = uint4{h0.x, h0.y, h1.x, h1.y}; lo = uint4{l0.x, l0.y, l1.x, l1.y};
+}
 
 namespace {
 
 MSAM_DEVINL float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 MSAM_DEVINL float4 ld4(const float* p) { return *(const float4*)p; }
 MSAM_DEVINL float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// position of key (0..31) inside a V^T row of the split16 attention kernels: k-step s = key >> 4 takes, from lane half b, the keys
+// 16 s + 4 b + {0..3, 8..11} - the keys whose probabilities that lane half holds in registers 8 s .. 8 s + 7 of the S^T accumulator
+MSAM_DEVINL int sp_vpos(int key) { return (key & 16) | ((key & 4) << 1) | ((key & 8) >> 1) | (key & 3); }
+constexpr float SP_PSCALE = 4096.0f;     // probabilities (<= 1) are scaled into fp16's normal range before the split, undone with the 1 / l
 
 // ------------------------------------------------------------------------------------------------------------------ sgemm
 // 128 x 128 output tile, k-tiles of 32, 4 waves x (64 x 64 = 2 x 2 MFMA tiles of 32 x 32), register-staged double buffer, one barrier
@@ -524,7 +536,10 @@ __global__ __launch_bounds__(256) void srelpos_kernel(SRelArgs a) {
 // score = ((q * scale) . k + rel_h) + rel_w as upstream; expf; IEEE division by the sum.
 constexpr int SM_BWP = 68;                      // bw row pitch (floats)
 constexpr int SM_VP = 36;                       // V^T row pitch: 32 keys + 4
-template <int HD>
+// SPLIT (the split16 mode): both products on fp16 operand pairs - K rows and V^T rows sit in LDS as hi | lo halves (same pitches), the
+// query's halves and the exponentials (scaled by 2^12) are split in registers; 12 + 12 MFMAs of the 16-bit pipe per key tile and head-dim 64
+// instead of 32 + 32 f32-input ones.  Scores, softmax, relative-position terms and the final division: the same fp32 code.
+template <int HD, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
     constexpr int S = 64, T = S * S, HH = HD / 2, DT = (HD + 31) / 32, KP = HD + 4, V4 = HD / 4;
     extern __shared__ __attribute__((aligned(16))) float sm_lds[];
@@ -569,6 +584,12 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
     }
 #pragma unroll
     for (int d = 0; d < HH; ++d) qs[d] = qu[d] * a.scale;
+    constexpr int NKS = HH / 8;                          // SPLIT: k-steps of the S^T product (a lane half's HH channels, eight at a time)
+    uint4 qsh[SPLIT ? NKS : 1], qsl[SPLIT ? NKS : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int s8 = 0; s8 < NKS; ++s8) sp_split8(&qs[8 * s8], 1.0f, qsh[s8], qsl[s8]);
+    }
     for (int i = tid; i < DT * 32 * SM_VP; i += 256) Vt[i] = 0.f;       // HD = 80: channels 80..95 of the third channel tile stay zero
     f32x16_t oacc[DT];
 #pragma unroll
@@ -595,9 +616,22 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
             const int idx = tid + 256 * i;
             if (idx < 32 * V4) {
                 const int row = idx / V4, c = (idx % V4) * 4;
-                *(float4*)&Ks[row * KP + c] = rk[i];
-                Vt[(c + 0) * SM_VP + row] = rv[i].x; Vt[(c + 1) * SM_VP + row] = rv[i].y;
-                Vt[(c + 2) * SM_VP + row] = rv[i].z; Vt[(c + 3) * SM_VP + row] = rv[i].w;
+                if constexpr (SPLIT) {
+                    uint2 h, l;
+                    sp_split4(rk[i], 1.0f, h, l);
+                    char* const pk = (char*)Ks + row * (KP * 4) + c * 2;
+                    *(uint2*)pk = h; *(uint2*)(pk + HD * 2) = l;
+                    sp_split4(rv[i], 1.0f, h, l);
+                    u16* const pv = (u16*)((char*)Vt + c * (SM_VP * 4)) + sp_vpos(row);
+                    pv[0] = (u16)(h.x & 0xffffu); pv[32] = (u16)(l.x & 0xffffu);
+                    pv[SM_VP * 2] = (u16)(h.x >> 16); pv[SM_VP * 2 + 32] = (u16)(l.x >> 16);
+                    pv[SM_VP * 4] = (u16)(h.y & 0xffffu); pv[SM_VP * 4 + 32] = (u16)(l.y & 0xffffu);
+                    pv[SM_VP * 6] = (u16)(h.y >> 16); pv[SM_VP * 6 + 32] = (u16)(l.y >> 16);
+                } else {
+                    *(float4*)&Ks[row * KP + c] = rk[i];
+                    Vt[(c + 0) * SM_VP + row] = rv[i].x; Vt[(c + 1) * SM_VP + row] = rv[i].y;
+                    Vt[(c + 2) * SM_VP + row] = rv[i].z; Vt[(c + 3) * SM_VP + row] = rv[i].w;
+                }
             }
         }
     };
@@ -614,6 +648,24 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
         const float* kp = Ks + li * KP + lh * HH;
+        if constexpr (SPLIT) {
+            const char* kb = (const char*)Ks + li * (KP * 4) + lh * (HH * 2);
+#pragma unroll
+            for (int s8 = 0; s8 < NKS; ++s8) {
+                const uint4 kh = *(const uint4*)(kb + 16 * s8), kl = *(const uint4*)(kb + HD * 2 + 16 * s8);
+                sc = mfma32h(kl, qsh[s8], sc); sc = mfma32h(kh, qsl[s8], sc); sc = mfma32h(kh, qsh[s8], sc);
+            }
+            if ((t & 1) == 0) {
+                const float* rp = a.rel_h + (long)(qh - (t >> 1) + S - 1) * HD + lh * HH;
+                float part = 0.f;
+#pragma unroll
+                for (int d = 0; d < HH; d += 4) {
+                    const float4 u = ld4(rp + d);
+                    part = fmaf(qu[d], u.x, part); part = fmaf(qu[d + 1], u.y, part); part = fmaf(qu[d + 2], u.z, part); part = fmaf(qu[d + 3], u.w, part);
+                }
+                bhv = part + __shfl_xor(part, 32);
+            }
+        } else
         if ((t & 1) == 0) {                             // new key row kh = t / 2: the row term, under the MFMAs of this tile
             const float* rp = a.rel_h + (long)(qh - (t >> 1) + S - 1) * HD + lh * HH;
             float part = 0.f;
@@ -656,6 +708,24 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sc[r] = expf(sc[r] - m); l += sc[r]; }
         // O^T += V^T P^T
+        if constexpr (SPLIT) {
+            uint4 ph[2], pl[2];
+            {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = sc[r];
+                sp_split8(&pv[0], SP_PSCALE, ph[0], pl[0]); sp_split8(&pv[8], SP_PSCALE, ph[1], pl[1]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* vb = (const char*)Vt + (dt * 32 + li) * (SM_VP * 4) + 16 * lh;
+#pragma unroll
+                for (int s8 = 0; s8 < 2; ++s8) {
+                    const uint4 vh = *(const uint4*)(vb + 32 * s8), vl = *(const uint4*)(vb + 64 + 32 * s8);
+                    oacc[dt] = mfma32h(vl, ph[s8], oacc[dt]); oacc[dt] = mfma32h(vh, pl[s8], oacc[dt]); oacc[dt] = mfma32h(vh, ph[s8], oacc[dt]);
+                }
+            }
+        } else
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const float* vp = Vt + (dt * 32 + li) * SM_VP + 4 * lh;
@@ -671,6 +741,7 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
         __syncthreads();
     }
     l += __shfl_xor(l, 32);
+    if constexpr (SPLIT) l *= SP_PSCALE;
     float* op = a.out + ((long)b * T + tq) * a.Dm + h * HD;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -688,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
 // query meets 14 row and 14 column offsets, so both terms are ONE MFMA tile each before the loop (the 27 table rows against the wave's
 // queries), scattered to LDS as bh[query][kh] | bw[query][kw]; a score reads its two entries by the key's (kh, kw).
 constexpr int SW_S = 14, SW_T = SW_S * SW_S, SW_KT = (SW_T + 31) / 32;      // 196 tokens, 7 tiles
-template <int HD>
+template <int HD, bool SPLIT = false>
 // (head_dim 64: 128 registers = four waves per SIMD = two of these 7-wave workgroups per CU, at the price of 5 spilled dwords in the prologue)
 __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelpos_win_mfma_kernel(SRelArgs a) {
     constexpr int HH = HD / 2, DT = (HD + 31) / 32, KP = HD + 4, V4 = HD / 4;
@@ -739,6 +810,12 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
     }
 #pragma unroll
     for (int d = 0; d < HH; ++d) qs[d] = qu[d] * a.scale;
+    constexpr int NKS = HH / 8;
+    uint4 qsh[SPLIT ? NKS : 1], qsl[SPLIT ? NKS : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int s8 = 0; s8 < NKS; ++s8) sp_split8(&qs[8 * s8], 1.0f, qsh[s8], qsl[s8]);
+    }
     for (int i = tid; i < DT * 32 * SM_VP; i += 448) Vt[i] = 0.f;
     f32x16_t oacc[DT];
 #pragma unroll
@@ -765,9 +842,22 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
             const int idx = tid + 448 * i;
             if (idx < 32 * V4) {
                 const int row = idx / V4, c = (idx % V4) * 4;
+                if constexpr (SPLIT) {
+                    uint2 h, l;
+                    sp_split4(rk[i], 1.0f, h, l);
+                    char* const pk = (char*)Ks + row * (KP * 4) + c * 2;
+                    *(uint2*)pk = h; *(uint2*)(pk + HD * 2) = l;
+                    sp_split4(rv[i], 1.0f, h, l);
+                    u16* const pv = (u16*)((char*)Vt + c * (SM_VP * 4)) + sp_vpos(row);
+                    pv[0] = (u16)(h.x & 0xffffu); pv[32] = (u16)(l.x & 0xffffu);
+                    pv[SM_VP * 2] = (u16)(h.x >> 16); pv[SM_VP * 2 + 32] = (u16)(l.x >> 16);
+                    pv[SM_VP * 4] = (u16)(h.y & 0xffffu); pv[SM_VP * 4 + 32] = (u16)(l.y & 0xffffu);
+                    pv[SM_VP * 6] = (u16)(h.y >> 16); pv[SM_VP * 6 + 32] = (u16)(l.y >> 16);
+                } else {
                 *(float4*)&Ks[row * KP + c] = rk[i];
                 Vt[(c + 0) * SM_VP + row] = rv[i].x; Vt[(c + 1) * SM_VP + row] = rv[i].y;
                 Vt[(c + 2) * SM_VP + row] = rv[i].z; Vt[(c + 3) * SM_VP + row] = rv[i].w;
+                }
             }
         }
     };
@@ -783,6 +873,14 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
         const float* kp = Ks + li * KP + lh * HH;
+        if constexpr (SPLIT) {
+            const char* kb = (const char*)Ks + li * (KP * 4) + lh * (HH * 2);
+#pragma unroll
+            for (int s8 = 0; s8 < NKS; ++s8) {
+                const uint4 kh = *(const uint4*)(kb + 16 * s8), kl = *(const uint4*)(kb + HD * 2 + 16 * s8);
+                sc = mfma32h(kl, qsh[s8], sc); sc = mfma32h(kh, qsl[s8], sc); sc = mfma32h(kh, qsh[s8], sc);
+            }
+        } else
 #pragma unroll
         for (int d = 0; d < HH; d += 4) {
             const float4 kk = ld4(kp + d);
@@ -813,6 +911,24 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
             sc[r] = key < SW_T ? expf(sc[r] - m) : 0.f;
             l += sc[r];
         }
+        if constexpr (SPLIT) {
+            uint4 ph[2], pl[2];
+            {
+                float pv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pv[r] = sc[r];
+                sp_split8(&pv[0], SP_PSCALE, ph[0], pl[0]); sp_split8(&pv[8], SP_PSCALE, ph[1], pl[1]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const char* vb = (const char*)Vt + (dt * 32 + li) * (SM_VP * 4) + 16 * lh;
+#pragma unroll
+                for (int s8 = 0; s8 < 2; ++s8) {
+                    const uint4 vh = *(const uint4*)(vb + 32 * s8), vl = *(const uint4*)(vb + 64 + 32 * s8);
+                    oacc[dt] = mfma32h(vl, ph[s8], oacc[dt]); oacc[dt] = mfma32h(vh, pl[s8], oacc[dt]); oacc[dt] = mfma32h(vh, ph[s8], oacc[dt]);
+                }
+            }
+        } else
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const float* vp = Vt + (dt * 32 + li) * SM_VP + 4 * lh;
@@ -828,6 +944,7 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
         __syncthreads();
     }
     l += __shfl_xor(l, 32);
+    if constexpr (SPLIT) l *= SP_PSCALE;
     if (qi >= SW_T) return;
     const int ty = wy * SW_S + qh, tx = wx * SW_S + qw;
     if (ty >= a.G || tx >= a.G) return;                              // padded query rows are dropped by window_unpartition
@@ -1254,8 +1371,8 @@ __global__ __launch_bounds__(256) void sattn_short_kernel(SAttnArgs a) {
 // Nq <= 16, long key side (token -> image attention over the 4096 image tokens): one workgroup per (batch, head); thread (t, slice) walks
 // the keys slice, slice + NS, ... for query t with an online softmax; the NS partial (m, l, acc) of a query are merged through LDS.
 // ALLH (H == 8, head dim 16, <= 8 queries): one workgroup per batch entry - thread = (query t, head h, slice of 4) - so that the workgroup reads
-// whole 512-byte k / v rows (8 heads x 64 bytes) instead of one 64-byte piece of every row (2.0 -> ~1 ms per 1024-prompt layer: the kernel is
-// a stream over the prompt's k and v, 4.3 GB per layer).
+// whole 512-byte k / v rows (8 heads x 64 bytes) instead of one 64-byte piece of every row.  MEASURED SLOWER (1221 vs 691 us per 512 prompts: a
+// thread's serial chain of 1024 keys with two expf each outweighs the better access pattern); kept behind msam_tune_set("sattn_allh", 1).
 template <int D, int NQP, bool ALLH = false>
 __global__ __launch_bounds__(256) void sattn_long_kernel(SAttnArgs a) {
     constexpr int NS = ALLH ? 256 / (NQP * 8) : 256 / NQP;
@@ -1736,9 +1853,20 @@ extern "C" int msam_strict_layernorm(const float* x, const float* weight, const 
     return msam_check_launch("strict_layernorm");
 }
 
+static int relpos_attention_impl(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
+                                 int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream, bool split);
 extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B,
                                             int32_t heads, int32_t head_dim, int32_t grid, int32_t window, float scale, float* out,
                                             void* stream) {
+    return relpos_attention_impl(qkv, qkv_bias, rel_h, rel_w, B, heads, head_dim, grid, window, scale, out, stream, false);
+}
+extern "C" int msam_split16_relpos_attention(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B,
+                                             int32_t heads, int32_t head_dim, int32_t grid, int32_t window, float scale, float* out,
+                                             void* stream) {
+    return relpos_attention_impl(qkv, qkv_bias, rel_h, rel_w, B, heads, head_dim, grid, window, scale, out, stream, true);
+}
+static int relpos_attention_impl(const float* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, int32_t B, int32_t heads,
+                                 int32_t head_dim, int32_t grid, int32_t window, float scale, float* out, void* stream, bool split) {
     if (!qkv || !qkv_bias || !rel_h || !rel_w || !out || B <= 0 || heads <= 0) { msam_set_error("msam_strict_relpos_attention: null argument"); return 1; }
     if ((head_dim != 64 && head_dim != 80) || (window != 0 && window != 14) || (window == 0 && grid != 64) || grid < 1 || grid > 64) {
         msam_set_error("msam_strict_relpos_attention: head_dim 64 / 80; window 14 (any grid <= 64) or 0 = global on the 64 x 64 grid");
@@ -1755,6 +1883,25 @@ extern "C" int msam_strict_relpos_attention(const float* qkv, const float* qkv_b
         (void)hipFuncSetAttribute((const void*)srelpos_kernel<HD_, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((srelpos_kernel<HD_, S_>), dim3((unsigned)blocks), dim3(256), lds, s, a);                                 \
     } while (0)
+    if (split) {                                        // both products on fp16 operand pairs (the split16 mode)
+        const size_t lw = (size_t)(224 * 32 + 32 * (head_dim + 4) + ((head_dim + 31) / 32) * 32 * SM_VP) * sizeof(float);
+        const size_t lm = (size_t)(128 * SM_BWP + 32 * (head_dim + 4) + ((head_dim + 31) / 32) * 32 * SM_VP) * sizeof(float);
+        const int nWw = (grid + SW_S - 1) / SW_S;
+        const unsigned gw = (unsigned)(B * nWw * nWw * heads), gm = (unsigned)(B * heads * 32);
+#define MSAM_SPLIT_ATT(HD_)                                                                                                                         \
+        do {                                                                                                                                        \
+            if (window) {                                                                                                                           \
+                (void)hipFuncSetAttribute((const void*)srelpos_win_mfma_kernel<HD_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);  \
+                hipLaunchKernelGGL((srelpos_win_mfma_kernel<HD_, true>), dim3(gw), dim3(448), lw, s, a);                                            \
+            } else {                                                                                                                                \
+                (void)hipFuncSetAttribute((const void*)srelpos_mfma_kernel<HD_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);       \
+                hipLaunchKernelGGL((srelpos_mfma_kernel<HD_, true>), dim3(gm), dim3(256), lm, s, a);                                                \
+            }                                                                                                                                       \
+        } while (0)
+        if (head_dim == 64) MSAM_SPLIT_ATT(64); else MSAM_SPLIT_ATT(80);
+#undef MSAM_SPLIT_ATT
+        return msam_check_launch("split16_relpos_attention");
+    }
     if (window && g_tune_srel_mfma >= 2) {              // the 14 x 14 windows on the f32-input MFMA
         const size_t lw = (size_t)(224 * 32 + 32 * (head_dim + 4) + ((head_dim + 31) / 32) * 32 * SM_VP) * sizeof(float);
         const int nWw = (grid + SW_S - 1) / SW_S;

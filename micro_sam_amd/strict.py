@@ -33,6 +33,7 @@ ACT_NONE, ACT_GELU, ACT_RELU = _lib.ACT_NONE, _lib.ACT_GELU, _lib.ACT_RELU
 # tile (1024 prompts): 128 -> 65.5 ms, 256 -> 61.5, 512 -> 59.3, 1024 -> 58.9 ms per tile (the token side's small products fill the chip
 # better; profiles/r05_experiments.md section 7).  Element counts stay below 2^31 up to 1023 prompts per pass.
 DECODE_CHUNK = 512
+DECODE_CHUNK_SPLIT = 1024
 # the "image attends to the tokens" step as one launch (msam_strict_i2t_block) instead of four (projection, attention, projection +
 # residual, LayerNorm): the same arithmetic, the 0.5 GB per-chunk stream crosses HBM twice instead of seven times.  Tokens <= 16.
 FUSED_I2T = True
@@ -243,7 +244,7 @@ class StrictEncoder:
                 y = layer_norm(xs, *blk["ln1"])
                 qkv = gemm(y, *blk["qkv"])
                 att = torch.empty((nb * T, D), dtype=torch.float32, device=dev)
-                _lib.check(lib.msam_strict_relpos_attention(qkv.data_ptr(), blk["qkv"][1].data_ptr(), blk["rel_h"].data_ptr(),
+                _lib.check((lib.msam_split16_relpos_attention if split_active() else lib.msam_strict_relpos_attention)(qkv.data_ptr(), blk["qkv"][1].data_ptr(), blk["rel_h"].data_ptr(),
                                                             blk["rel_w"].data_ptr(), nb, heads, hd, GRID, blk["window"], blk["scale"],
                                                             att.data_ptr(), _lib.stream_ptr()), "msam_strict_relpos_attention")
                 del qkv
@@ -349,8 +350,10 @@ class StrictDecoder:
             _lib.check(lib.msam_strict_source(emb.data_ptr(), w["no_mask"].data_ptr(), 0, 1, src_all.data_ptr(), _lib.stream_ptr()),
                        "msam_strict_source")
         tokens_all = torch.cat([w["out_tokens"].unsqueeze(0).expand(P, -1, -1), sparse.to(device=dev, dtype=torch.float32)], dim=1).contiguous()
-        for p0 in range(0, P, DECODE_CHUNK):
-            pc = min(DECODE_CHUNK, P - p0)
+        # (split16: the second up-scaling stage is never materialised, so a whole 1024-prompt grid fits one pass - half the token-side launches)
+        chunk = DECODE_CHUNK_SPLIT if (split_active() and FUSED_UP2) else DECODE_CHUNK
+        for p0 in range(0, P, chunk):
+            pc = min(chunk, P - p0)
             qpe = tokens_all[p0:p0 + pc].reshape(pc * Tk, PROMPT_DIM)                       # query_pe = the prompt tokens themselves
             queries = qpe.clone()
             if shared:

@@ -189,6 +189,11 @@ def test_strict_relpos_attention(lib, B, heads, hd, G, window):
         assert lib.msam_tune_set(b"srel_mfma", 2) == 0
     assert (out_v - ref).abs().max().item() <= 2e-5
     assert not torch.equal(out, out_v) and (out - out_v).abs().max().item() <= 3e-5      # two kernels, two summation orders
+    # the split16 form of the MFMA kernels (q . k and p @ v on fp16 operand pairs): the same tolerance against fp64
+    out_s = torch.full((B * G * G, D), float("nan"))
+    assert lib.msam_split16_relpos_attention(qkv.data_ptr(), bqkv.data_ptr(), rel_h.data_ptr(), rel_w.data_ptr(), B, heads, hd, G, window,
+                                             scale, out_s.data_ptr(), None) == 0, lib.msam_last_error()
+    assert torch.isfinite(out_s).all() and (out_s - ref).abs().max().item() <= 2e-5, (out_s - ref).abs().max().item()
 
 
 def test_strict_gemm_tile_variants_give_the_same_bits(lib):

@@ -35,7 +35,9 @@ def main():
     ap.add_argument("--modes", default="default,split16,strict")
     ap.add_argument("--no-products", action="store_true")
     ap.add_argument("--weights", default="cells")
+    ap.add_argument("--slice-tiles", type=int, default=16, help="tiles of the segment_slices timing (0: skip)")
     a = ap.parse_args()
+    from micro_sam_amd import multi_dimensional_segmentation as mds
     from micro_sam_amd import ops, strict, util
     from micro_sam_amd.instance_segmentation import AutomaticMaskGenerator
     from micro_sam_amd.synthetic import synthetic_state_dict, synthetic_tile
@@ -66,7 +68,13 @@ def main():
         results[mode] = [snapshot(t) for t in tiles]
         t_tile = timed(lambda: [whole_tile(t) for t in tiles]) / len(tiles)
         t_enc = timed(lambda: [util.precompute_image_embeddings(predictor, t, verbose=False) for t in tiles]) / len(tiles)
+        # the product's own slice loop (encoder batches of 8, decode lanes): multi_dimensional_segmentation.segment_slices, host arrays in and out
+        stack = np.stack([synthetic_tile(1000 + i) for i in range(a.slice_tiles)])
+        t_pipe = None
+        if a.slice_tiles:
+            t_pipe = timed(lambda: mds.segment_slices(stack, predictor, amg, batch_size=8), reps=2) / a.slice_tiles
         rec[mode] = {"seconds_per_tile_api_loop": round(t_tile, 4), "tiles_per_s_api_loop": round(1.0 / t_tile, 2),
+                     "tiles_per_s_segment_slices": None if t_pipe is None else round(1.0 / t_pipe, 2),
                      "encoder_seconds_per_tile": round(t_enc, 4), "decode_and_generate_seconds_per_tile": round(t_tile - t_enc, 4)}
     if "strict" in results:
         for mode in results:
