@@ -395,7 +395,7 @@ def config_sides(timeout_s: float = 420.0, fp8: bool = False):
     # parity on weights that are not hand-designed (tools/trained_parity.py: the "cells" checkpoint after 100 AdamW steps of this package's
     # trainer), default and strict precision mode against the fp32 CPU oracle of the same run
     tp = run([os.path.join("tools", "trained_parity.py"), "--steps", "100", "--strict", "--quartile", "--stability-thresh", "0.8"],
-             ("steps", "train_seconds", "weight_distance_from_designed", "iou", "labels", "strict", "pred_iou_thresh", "stability_score_thresh",
+             ("steps", "train_seconds", "checkpoint_digest", "weight_distance_from_designed", "iou", "labels", "split16", "strict", "pred_iou_thresh", "stability_score_thresh",
               "embedding_mean_abs_err", "oracle_seconds"))
     if "iou" in tp:
         tp["default"] = {"iou": tp.pop("iou"), "labels": tp.pop("labels")}

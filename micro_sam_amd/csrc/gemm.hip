@@ -10,6 +10,9 @@
 #include "common.h"
 #include "../../include/msam_hip.h"
 
+float* msam_det_workspace(size_t floats, int slot);                                           // train.hip: library-owned workspaces of the fixed-order reductions
+void msam_det_reduce(const float* parts, int nparts, long n, float* out, int accumulate, void* stream);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -23,8 +26,8 @@ struct Epi {
     int out_mode; u16* q; u16* k; u16* v; int heads, head_dim, tokens;
     const float* row_scale; const float* col_scale;      // fp8 operands: C = acc * row_scale[m] * col_scale[n]
     int splitk_len = 0;                                  // > 0: split-K launch (msam_gemm_t.split_k): workgroup blockIdx.y contracts over
-                                                         // k in [y * splitk_len, (y + 1) * splitk_len) and ADDS its fp32 tile to `out`
-                                                         // (atomics; plain fp32 output, zeroed by the launcher; no bias / epilogue)
+                                                         // k in [y * splitk_len, (y + 1) * splitk_len) and stores its fp32 tile to part y of a
+                                                         // workspace; the launcher adds the parts in order (no atomics: reproducible)
     unsigned long long* trace = nullptr;                 // gemm2w_kernel debug timeline (msam_gemm_set_trace): 64 words per workgroup
     int direct_epi = 0;                                  // gemm256_kernel: epilogue from the accumulators (epi_direct) instead of the LDS transposition
     int gw_delay = 0, gw_class = 0;                      // gemm2w_kernel: start delay of the second workgroup class (units of s_sleep 100), class rule
@@ -257,8 +260,9 @@ __device__ __forceinline__ void gemm_body(const u16* __restrict__ A, long lda, c
         }
         if (e.out_mode == 0) {
             if (e.splitk_len > 0) {
-                float* o = (float*)e.out + (long)row * e.ldc + col;
-                atomicAdd(o, v[0]); atomicAdd(o + 1, v[1]); atomicAdd(o + 2, v[2]); atomicAdd(o + 3, v[3]);
+                // split-K: this slice's tile goes to ITS part of the workspace (e.out = parts [split_k][M][N]); the launcher adds the parts in
+                // slice order (train.hip msam_det_reduce) - no atomics: the weight gradients are the same bits on every run
+                *(float4*)((float*)e.out + ((long)blockIdx.y * M + row) * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
             } else if (e.out_dtype == MSAM_F32) {
                 *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
@@ -1404,12 +1408,15 @@ extern "C" int msam_gemm_bf16(const msam_gemm_t* p, void* stream) {
             msam_set_error("msam_gemm_bf16(split_k): plain fp32 output with ldc == N, no bias / table / residual / activation, K % (split_k * 64) == 0");
             return 1;
         }
-        if (hipMemsetAsync(p->out, 0, (size_t)p->M * p->N * sizeof(float), s) != hipSuccess) { msam_set_error("msam_gemm_bf16(split_k): memset failed"); return 2; }
+        float* parts = msam_det_workspace((size_t)p->split_k * p->M * p->N, 2);
+        if (!parts) { msam_set_error("msam_gemm_bf16(split_k): cannot allocate the partial-tile workspace"); return 2; }
+        e.out = parts;
         e.splitk_len = p->K / p->split_k;
         if (f16) hipLaunchKernelGGL((gemm_kernel<false, true>), dim3(tiles, p->split_k), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
                                     (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
         else hipLaunchKernelGGL(gemm_kernel<false>, dim3(tiles, p->split_k), dim3(256), 0, s, (const u16*)p->A, (long)p->lda,
                                 (const u16*)p->W, (long)p->ldw, p->M, p->N, p->K, e);
+        msam_det_reduce(parts, p->split_k, (long)p->M * p->N, (float*)p->out, 0, stream);       // out = slice 0 + slice 1 + ... in that order
         return msam_check_launch("msam_gemm_bf16(split_k)");
     }
     if (prof) {

@@ -9,6 +9,37 @@
 void msam_set_error(const char* msg);
 int msam_check_launch(const char* what);
 
+// ---- reproducible parameter gradients (split-K and the column sums added their partial results with atomicAdd, so every
+// fine-tuning run produced a different checkpoint).  Every reduction over workgroups now writes its partial results to a workspace and a
+// second launch adds them in a FIXED order (one thread per output element walks the parts 0, 1, 2, ...): the same bits on every run.
+// The workspaces are library-owned, one per call site ("slot"), grown on demand (hipMalloc / hipFree synchronise; steady state: no
+// allocation); a slot is used by one stream at a time - the trainer's compute stream.
+float* msam_det_workspace(size_t floats, int slot) {
+    static float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    static size_t cap[4] = {0, 0, 0, 0};
+    if (slot < 0 || slot > 3) return nullptr;
+    if (cap[slot] < floats) {
+        if (buf[slot]) (void)hipFree(buf[slot]);
+        buf[slot] = nullptr; cap[slot] = 0;
+        const size_t n = floats + floats / 4 + 1024;
+        void* pnew = nullptr;
+        if (hipMalloc(&pnew, n * sizeof(float)) != hipSuccess) return nullptr;
+        buf[slot] = (float*)pnew; cap[slot] = n;
+    }
+    return buf[slot];
+}
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ parts, int nparts, long n, float* __restrict__ out, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int p = 0; p < nparts; ++p) s += parts[(long)p * n + i];
+    out[i] = s;
+}
+// out[i] (+)= parts[0][i] + parts[1][i] + ... in that order
+void msam_det_reduce(const float* parts, int nparts, long n, float* out, int accumulate, void* stream) {
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, nparts, n, out, accumulate);
+}
+
 namespace {
 
 // ---- LayerNorm backward over rows of `dim` <= 256 channels (one wave per row):
@@ -16,7 +47,8 @@ namespace {
 template <int V>   // V = dim / 64 values per lane (dim in {64, 128, 256})
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ dy, float eps, long rows,
-                                                            float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db) {
+                                                            float* __restrict__ dx, float* __restrict__ part) {
+    // part [gridDim.x][2][DIM]: this workgroup's sums of dy * xhat and dy (added across workgroups in a fixed order by msam_det_reduce)
     constexpr int DIM = V * 64;
     __shared__ float sdw[4][DIM], sdb[4][DIM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,9 +79,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < V; ++i) { sdw[wave][i * 64 + lane] = aw[i]; sdb[wave][i * 64 + lane] = ab[i]; }
     __syncthreads();
+    float* const mine = part + (long)blockIdx.x * 2 * DIM;
     for (int c = threadIdx.x; c < DIM; c += 256) {
-        atomicAdd(dw + c, sdw[0][c] + sdw[1][c] + sdw[2][c] + sdw[3][c]);
-        atomicAdd(db + c, sdb[0][c] + sdb[1][c] + sdb[2][c] + sdb[3][c]);
+        mine[c] = sdw[0][c] + sdw[1][c] + sdw[2][c] + sdw[3][c];
+        mine[DIM + c] = sdb[0][c] + sdb[1][c] + sdb[2][c] + sdb[3][c];
     }
 }
 
@@ -380,19 +413,19 @@ __global__ __launch_bounds__(128) void relpos_bwd_kv_kernel(const float* __restr
 // x [M, K] fp32 (SRC16 = false) or bf16 (SRC16 = true), row stride ldx.  One workgroup per 64 x 64 tile:
 //   out16 [M, K]  bf16 copy (optional)            - coalesced 8-byte writes,
 //   outT  [K, M]  bf16 transpose (optional)       - through a padded LDS tile, 8-byte writes along M,
-//   colsum [K]    fp32 column sums (optional)     - per-workgroup partial sums in LDS, one atomicAdd per column (the caller zeroes it).
+//   colsum        fp32 column sums (optional)     - per-workgroup partial sums (fixed order inside the workgroup) to part [gridDim.y][K]; the
+//                                                   launcher adds the row blocks in order (msam_det_reduce) INTO the caller's zeroed vector.
 // The unfused form was three to four torch launches per operand (cast, strided transpose copy at 0.5 TB/s, sum): 30 % of a fine-tuning
 // step's device time (profiles/r03_experiments.md section 8).  K % 4 == 0, ldx % 4 == 0; M arbitrary.
 template <bool SRC16>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const void* __restrict__ xin, long M, int K, long ldx, unsigned short* __restrict__ out16,
                                                              unsigned short* __restrict__ outT, float* __restrict__ colsum) {
     __shared__ unsigned short tile[64][68];          // [m][k], rows padded to 136 B
-    __shared__ float csum[64];
+    __shared__ float csum[16][64];                   // [row group r0][column]
     const int tid = threadIdx.x;
     const int k0 = blockIdx.x * 64;
     const long m0 = (long)blockIdx.y * 64;
     const int c4 = (tid & 15) * 4, r0 = tid >> 4;     // 4 consecutive columns, rows r0 + 16 p
-    if (tid < 64) csum[tid] = 0.f;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -417,8 +450,8 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const void* __restr
             *(uint2*)(out16 + m * (long)K + k0 + c4) = pk;
         }
     }
+    if (colsum) { csum[r0][c4] = s0; csum[r0][c4 + 1] = s1; csum[r0][c4 + 2] = s2; csum[r0][c4 + 3] = s3; }
     __syncthreads();
-    if (colsum) { atomicAdd(&csum[c4], s0); atomicAdd(&csum[c4 + 1], s1); atomicAdd(&csum[c4 + 2], s2); atomicAdd(&csum[c4 + 3], s3); }
     if (outT) {
         const int mq = (tid & 15) * 4, kr0 = tid >> 4;   // 4 consecutive rows m of the source = 4 consecutive columns of outT
 #pragma unroll
@@ -438,10 +471,21 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const void* __restr
             }
         }
     }
-    if (colsum) {
-        __syncthreads();
-        if (tid < 64 && k0 + tid < K) atomicAdd(colsum + k0 + tid, csum[tid]);
+    if (colsum && tid < 64 && k0 + tid < K) {       // colsum here = the partial-sum workspace [gridDim.y][K]
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += csum[r][tid];
+        colsum[(long)blockIdx.y * K + k0 + tid] = t;
     }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int dim, float* __restrict__ dw, float* __restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * dim) return;
+    float* const dst = i < dim ? dw + i : db + (i - dim);
+    float s = *dst;                                  // (the reference accumulates parameter gradients: `+=` as the atomic form did)
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * 2 * dim + i];
+    *dst = s;
 }
 
 }  // namespace
@@ -451,14 +495,18 @@ extern "C" int msam_layernorm_backward(const float* x, const float* weight, cons
     if (!x || !weight || !dy || !dx || !dweight || !dbias || rows <= 0) { msam_set_error("msam_layernorm_backward: bad argument"); return 1; }
     hipStream_t s = (hipStream_t)stream;
     const int grid = (int)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048);
-    if (dim == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
-    else if (dim == 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
-    else if (dim == 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
+    if (dim != 64 && dim != 128 && dim != 256 && dim != 768 && dim != 1024 && dim != 1280) { msam_set_error("msam_layernorm_backward: dim must be 64, 128, 256, 768, 1024 or 1280"); return 1; }
+    float* part = msam_det_workspace((size_t)grid * 2 * dim, 0);
+    if (!part) { msam_set_error("msam_layernorm_backward: cannot allocate the partial-sum workspace"); return 2; }
+    if (dim == 256) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
+    else if (dim == 128) hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
+    else if (dim == 64) hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
     // the image encoder's widths (vit_b / vit_l / vit_h), for un-frozen fine-tuning
-    else if (dim == 768) hipLaunchKernelGGL(layernorm_bwd_kernel<12>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
-    else if (dim == 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
-    else if (dim == 1280) hipLaunchKernelGGL(layernorm_bwd_kernel<20>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, dweight, dbias);
-    else { msam_set_error("msam_layernorm_backward: dim must be 64, 128, 256, 768, 1024 or 1280"); return 1; }
+    else if (dim == 768) hipLaunchKernelGGL(layernorm_bwd_kernel<12>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
+    else if (dim == 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<20>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
+    // dweight / dbias += the workgroups' sums, in workgroup order (the pair [dw | db] of a workgroup is 2 dim contiguous floats)
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, s, (const float*)part, grid, dim, dweight, dbias);
     return msam_check_launch("msam_layernorm_backward");
 }
 
@@ -549,11 +597,17 @@ extern "C" int msam_cast_transpose(const void* x, int32_t x_dtype, int64_t M, in
     if (x_dtype != MSAM_F32 && x_dtype != MSAM_BF16) { msam_set_error("msam_cast_transpose: source fp32 or bf16"); return 1; }
     if ((M + 63) / 64 > 65535) { msam_set_error("msam_cast_transpose: M <= 4 194 240"); return 1; }
     const dim3 grid((K + 63) / 64, (unsigned)((M + 63) / 64));
+    float* part = nullptr;
+    if (colsum) {
+        part = msam_det_workspace((size_t)grid.y * K, 1);
+        if (!part) { msam_set_error("msam_cast_transpose: cannot allocate the partial-sum workspace"); return 2; }
+    }
     if (x_dtype == MSAM_F32)
         hipLaunchKernelGGL(cast_transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, K, (long)ldx, (unsigned short*)out16,
-                           (unsigned short*)outT, colsum);
+                           (unsigned short*)outT, part);
     else
         hipLaunchKernelGGL(cast_transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, K, (long)ldx, (unsigned short*)out16,
-                           (unsigned short*)outT, colsum);
+                           (unsigned short*)outT, part);
+    if (colsum) msam_det_reduce(part, (int)grid.y, K, colsum, 1, stream);       // colsum += row block 0 + row block 1 + ... (the caller zeroes it)
     return msam_check_launch("msam_cast_transpose");
 }

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -33,7 +34,7 @@ ACT_NONE, ACT_GELU, ACT_RELU = _lib.ACT_NONE, _lib.ACT_GELU, _lib.ACT_RELU
 # tile (1024 prompts): 128 -> 65.5 ms, 256 -> 61.5, 512 -> 59.3, 1024 -> 58.9 ms per tile (the token side's small products fill the chip
 # better; profiles/r05_experiments.md section 7).  Element counts stay below 2^31 up to 1023 prompts per pass.
 DECODE_CHUNK = 512
-DECODE_CHUNK_SPLIT = 1024
+DECODE_CHUNK_SPLIT = int(os.environ.get("MSAM_SPLIT16_CHUNK", "1024"))
 # the "image attends to the tokens" step as one launch (msam_strict_i2t_block) instead of four (projection, attention, projection +
 # residual, LayerNorm): the same arithmetic, the 0.5 GB per-chunk stream crosses HBM twice instead of seven times.  Tokens <= 16.
 FUSED_I2T = True

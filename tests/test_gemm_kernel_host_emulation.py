@@ -216,14 +216,19 @@ def test_gemm_kernel_qkv_split_and_split_k_on_the_cpu(emu):
     ref = (a.double() @ w.double().t() + bias.double()).reshape(Bn, tokens, 3, heads, hd).permute(2, 0, 3, 1, 4)
     for got, want in zip((q, k, v), ref):
         assert (_from_bits(got) - want).abs().max().item() <= 1.2e-2 * want.abs().max().item()
-    # split-K: 4 slices of the contraction accumulate into the zeroed fp32 output
+    # split-K: the 4 slices of the contraction store their fp32 tiles to THEIR part of a workspace [4][M][N] (round 6: no atomics - the launcher
+    # adds the parts in slice order, train.hip msam_det_reduce, so that weight gradients are the same bits on every run)
     M, N, K = 128, 128, 1024
     a, w = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) / K ** 0.5)
     A, W = _bits(a), _bits(w)
-    out = np.zeros((M, N), np.float32)
-    emu.emu_gemm(0, _ptr(A), K, _ptr(W), K, M, N, K, None, None, 0, 0, 0, None, 0, 0, 0, 0, _ptr(out), MSAM_F32, N, 0, None, None, None, 0, 0, 0, 4)
+    parts = np.full((4, M, N), np.nan, np.float32)
+    emu.emu_gemm(0, _ptr(A), K, _ptr(W), K, M, N, K, None, None, 0, 0, 0, None, 0, 0, 0, 0, _ptr(parts), MSAM_F32, N, 0, None, None, None, 0, 0, 0, 4)
+    out = ((parts[0] + parts[1]) + parts[2]) + parts[3]
     ref = a.double() @ w.double().t()
-    assert np.abs(out - ref.numpy()).max() <= 3e-5 * ref.abs().max().item()
+    assert np.isfinite(parts).all() and np.abs(out - ref.numpy()).max() <= 3e-5 * ref.abs().max().item()
+    for sl in range(4):                                   # every part is the product over its own quarter of K
+        want = a[:, sl * 256:(sl + 1) * 256].double() @ w[:, sl * 256:(sl + 1) * 256].double().t()
+        assert np.abs(parts[sl] - want.numpy()).max() <= 3e-5 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("staging", [3, 0, 1, 2])

@@ -144,14 +144,19 @@ static void atomicAdd(float* p, float v) { std::lock_guard<std::mutex> g(atomic_
 template <int V> static void run(const float* x, const float* w, const float* dy, float eps, long rows, float* dx, float* dw, float* db,
                                  int grid) {
     gridDim = {grid, 1, 1};
+    constexpr int DIM = V * 64;
+    std::vector<float> part((size_t)grid * 2 * DIM, NAN);          // the kernel's per-workgroup sums (round 6: no atomics)
+    float* pp = part.data();
     for (int bx = 0; bx < grid; ++bx) {
         std::barrier<> b0(64), b1(64), b2(64), b3(64), bb(256);
         wave_bar[0] = &b0; wave_bar[1] = &b1; wave_bar[2] = &b2; wave_bar[3] = &b3; block_bar = &bb;
         std::vector<std::thread> ts;
         for (int tx = 0; tx < 256; ++tx)
-            ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, 0, 0}; layernorm_bwd_kernel<V>(x, w, dy, eps, rows, dx, dw, db); });
+            ts.emplace_back([=] { threadIdx = {tx, 0, 0}; blockIdx = {bx, 0, 0}; layernorm_bwd_kernel<V>(x, w, dy, eps, rows, dx, pp); });
         for (auto& t : ts) t.join();
     }
+    for (int c = 0; c < DIM; ++c)                                    // ln_bwd_reduce_kernel: workgroup order
+        for (int bx = 0; bx < grid; ++bx) { dw[c] += part[((size_t)bx * 2) * DIM + c]; db[c] += part[((size_t)bx * 2 + 1) * DIM + c]; }
 }
 extern "C" int emu_ln_bwd(int dim, const float* x, const float* w, const float* dy, float eps, long rows, float* dx, float* dw, float* db,
                           int grid) {

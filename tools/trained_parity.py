@@ -3,9 +3,10 @@ package's own trainer (training.SamTrainer: iterative prompting, AdamW - the ref
 synthetic cell tiles with their instance labels, everything trainable, and the per-instance mask IoU of the HIP inference path against
 the fp32 CPU oracle is measured on the TRAINED weights on an unseen tile.
 
-The checkpoint "generator + seed" is this file: `train_checkpoint(steps, seed, lr)`.  Fine-tuning on the GPU is not bit-reproducible
-(split-K weight gradients meet in fp32 atomics), so no golden can be committed for the trained weights: both sides of the comparison
-are computed on the spot from the same state_dict (tests/test_gpu_parity_trained.py; `python tools/trained_parity.py` prints the report).
+The checkpoint "generator + seed" is this file: `train_checkpoint(steps, seed, lr)`.  Since round 6 the library's reductions run in a
+fixed order (csrc/train.hip msam_det_reduce: no atomics in split-K, the column sums or the LayerNorm parameter gradients), so the same
+seed gives the same checkpoint on a given box (`checkpoint_digest`); both sides of the comparison are still computed on the spot from the
+same state_dict (tests/test_gpu_parity_trained.py; `python tools/trained_parity.py` prints the report).
 The oracle is the checker here (test infrastructure), never the measured path."""
 import json
 import os
@@ -105,18 +106,20 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
              "embedding_mean_abs": float(feats.abs().mean())}
     def short(r):
         return {k: (round(r[k], 4) if isinstance(r[k], float) else r[k]) for k in ("n_instances", "frac_ge_0.999", "frac_ge_0.99", "min", "median", "keep_set")}
-    if strict:
-        # the strict precision mode (micro_sam_amd/strict.py: the reference's formulation on fp32 kernels) on the same weights and tile
-        predictor.set_precision("strict")
+    for mode in (("split16", "strict") if strict else ()):
+        # the reference's formulation on the same weights and tile (micro_sam_amd/strict.py): "split16" = every product on fp16 operand pairs
+        # (3 MFMAs of the 16-bit pipe), "strict" = fp32 kernels
+        predictor.set_precision(mode)
+        emb_s = util.precompute_image_embeddings(predictor, tile, verbose=False)     # (first pass of a mode: weight preparation)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         emb_s = util.precompute_image_embeddings(predictor, tile, verbose=False)
         rs_, labs_, sc_ = product_report(emb_s)
         torch.cuda.synchronize()
-        extra["strict"] = dict(short(rs_), labels=labs_, seconds=round(time.perf_counter() - t0, 2),
-                               iou_pred_max_abs_diff=float(np.abs(rs["iou_pred"] - sc_["iou_pred"]).max()),
-                               embedding_mean_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().mean()),
-                               embedding_max_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().max()))
+        extra[mode] = dict(short(rs_), labels=labs_, seconds=round(time.perf_counter() - t0, 2),
+                           iou_pred_max_abs_diff=float(np.abs(rs["iou_pred"] - sc_["iou_pred"]).max()),
+                           embedding_mean_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().mean()),
+                           embedding_max_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().max()))
         predictor.set_precision("default")
     if ablations:
         abl = {}
@@ -139,6 +142,16 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
         predictor.model.set_split_token_mlp(True)
         extra["ablations"] = abl
     return rep, lab, extra
+
+
+def checkpoint_digest(sd) -> str:
+    """sha256 (16 hex digits) over the tensors of a state_dict in key order: names the checkpoint a parity number was measured on (round 6:
+    fine-tuning is reproducible - fixed-order reductions instead of atomics - so the same seed gives the same digest on every run)."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode()); h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()[:16]
 
 
 def weight_distance(sd_a, sd_b):
@@ -179,6 +192,7 @@ def main():
         pub.pop("worst", None)
         print(json.dumps({"steps": steps, "lr": a.lr, "train_seconds": round(t_train, 1),
                           "loss_first_last": [round(float(np.mean(losses[:5])), 4), round(float(np.mean(losses[-5:])), 4)] if losses else None,
+                          "checkpoint_digest": checkpoint_digest(sd),
                           "weight_distance_from_designed": weight_distance(sd, base), "iou": pub, "labels": lab, **extra}), flush=True)
 
 
