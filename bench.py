@@ -83,8 +83,9 @@ def _parity_summary(rep):
     r4 = lambda v: round(v, 4) if isinstance(v, float) else v                     # noqa: E731
     out = {"n_instances": iou.get("n_instances"), "frac_ge_0.999": r4(iou.get("frac_ge_0.999")), "min": r4(iou.get("min")),
            "keep_set": iou.get("keep_set"), "identical_id_frac_foreground": r4(labels.get("identical_id_frac_foreground"))}
-    if "tiles_per_s" in rep:
-        out["tiles_per_s"] = rep["tiles_per_s"]
+    for k in ("tiles_per_s", "tiles_per_s_segment_slices"):
+        if k in rep:
+            out[k] = rep[k]
     return out
 
 
@@ -248,12 +249,15 @@ def mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs):
     return out
 
 
-def strict_leg(predictor, amg, tiles_np, ref_states, ref_segs, cpu_tiles_per_s):
-    """mask_iou_vs_ref in the strict precision mode + that mode's throughput through the literal API sequence (per tile
-    precompute_image_embeddings -> AutomaticMaskGenerator.initialize -> generate, host arrays in and out)."""
+def strict_leg(predictor, amg, tiles_np, ref_states, ref_segs, cpu_tiles_per_s, mode="strict", slice_tiles=16):
+    """mask_iou_vs_ref in a reference-formulation precision mode ("strict": fp32 kernels; "split16": every product on fp16 operand pairs) + that
+    mode's throughput two ways: the literal per-tile API loop (precompute_image_embeddings -> AutomaticMaskGenerator.initialize -> generate,
+    host arrays in and out, one lane) and the product's own slice loop (multi_dimensional_segmentation.segment_slices: encoder batches of 8,
+    decode lanes)."""
+    from micro_sam_amd import multi_dimensional_segmentation as mds
     from micro_sam_amd import util
-    predictor.set_precision("strict")
-    rep = mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs)        # (also the warm-up of the strict kernels)
+    predictor.set_precision(mode)
+    rep = mask_iou_vs_ref(predictor, amg, tiles_np, ref_states, ref_segs)        # (also the warm-up of the mode's kernels)
 
     def whole(tile):
         emb = util.precompute_image_embeddings(predictor, tile, verbose=False)
@@ -268,8 +272,23 @@ def strict_leg(predictor, amg, tiles_np, ref_states, ref_segs, cpu_tiles_per_s):
     tps = n / (time.perf_counter() - t0)
     rep["tiles_per_s"] = round(tps, 2)
     rep["times_cpu_baseline"] = round(tps / cpu_tiles_per_s, 1) if cpu_tiles_per_s else None
-    rep["mode"] = ("predictor.set_precision('strict'): image encoder, prompt encoder and mask decoder in the reference's formulation on fp32 "
-                   "kernels (f32-input MFMA products, erf GELU, expf softmax); tiles_per_s = the literal per-tile API loop, one lane")
+    try:
+        stack = np.stack([tiles_np[k % len(tiles_np)] for k in range(slice_tiles)])
+        mds.segment_slices(stack[:8], predictor, amg, batch_size=8)              # warm-up: lane streams and their workspaces
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mds.segment_slices(stack, predictor, amg, batch_size=8)
+        torch.cuda.synchronize()
+        rep["tiles_per_s_segment_slices"] = round(slice_tiles / (time.perf_counter() - t0), 2)
+    except Exception as exc:                # a side measurement must not cost the parity report
+        rep["tiles_per_s_segment_slices"] = None
+        rep["segment_slices_error"] = repr(exc)[:200]
+    rep["mode"] = {"strict": "predictor.set_precision('strict'): image encoder, prompt encoder and mask decoder in the reference's formulation on fp32 "
+                             "kernels (f32-input MFMA products, erf GELU, expf softmax)",
+                   "split16": "predictor.set_precision('split16'): the same formulation, every product on fp16 operand pairs (hi + lo of each fp32 "
+                              "operand, 3 MFMAs of the 16-bit pipe, fp32 accumulation; LayerNorm / softmax / GELU in fp32) with the up-scaling's second half, "
+                              "the image->token block and the k|v projections fused"}[mode] + \
+                  "; tiles_per_s = the literal per-tile API loop on one lane, tiles_per_s_segment_slices = one segment_slices call over 16 tiles"
     return rep
 
 
@@ -909,13 +928,15 @@ def main():
             out["mask_iou_vs_ref"] = mask_iou_vs_ref(predictor, amg, ref_tiles, ref_states, ref_segs)
             # the strict precision mode (predictor.set_precision("strict"): the reference's formulation on fp32 kernels, micro_sam_amd/strict.py)
             # on the same tiles against the same reference: the point of the speed / parity curve that meets the north-star statement
-            try:
-                out["mask_iou_vs_ref_strict"] = strict_leg(predictor, amg, ref_tiles, ref_states, ref_segs, out["cpu_baseline"]["value"])
-            except Exception as exc:            # a side measurement must not cost the bench line
-                out["mask_iou_vs_ref_strict"] = {"error": repr(exc)}
-            finally:
-                predictor.set_precision("default")
-                predictor.model.image_encoder.set_precision(args.encoder_dtype)
+            for mode in ("split16", "strict"):
+                try:
+                    out[f"mask_iou_vs_ref_{mode}"] = strict_leg(predictor, amg, ref_tiles, ref_states, ref_segs, out["cpu_baseline"]["value"], mode=mode)
+                except Exception as exc:            # a side measurement must not cost the bench line
+                    out[f"mask_iou_vs_ref_{mode}"] = {"error": repr(exc)}
+                finally:
+                    predictor.set_precision("default")
+                    predictor.model.image_encoder.set_precision(args.encoder_dtype)
+                    torch.cuda.empty_cache()    # (the modes' multi-GiB fp32 streams go back to the driver before the next leg)
             if args.encoder_dtype == "bf16":
                 # what the bf16 rounding of the encoder's operands costs: the same comparison with IEEE fp16 operands in the encoder
                 # (same kernels and MFMA rate; throughput of that mode: python bench.py --encoder-dtype fp16)

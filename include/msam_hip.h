@@ -716,6 +716,25 @@ int msam_strict_source(const float* embedding, const float* dense, int64_t dense
  * second sub-pixel * 32 + channel), hyper fp32 [P, 4, hyper_ld] -> low_res fp32 [P, nmask, 256, 256] of masks mask0 .. mask0 + nmask - 1. */
 int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, int64_t P, float* low_res,
                             void* stream);
+/* "The tokens attend to the image" on a PER-PROMPT image stream in the split16 mode, without materialising the stream's k and v projections
+ * (segment_anything modeling/transformer.py Attention.forward with q = the tokens' projection, k = k_proj(keys + key_pe), v = v_proj(keys);
+ * TwoWayAttentionBlock.cross_attn_token_to_image of layers >= 1 and final_attn_token_to_image):
+ *   out[b, j, h] = softmax_t(q[b, j, h] . ((keys[b, t] + pos[t]) Wk_h^T + bk_h) / denom) ((keys[b, t]) Wv_h^T + bv_h)
+ * computed as S = (keys + pos) G^T with G = Wk_h^T q / denom folded on the token side (q . bk is constant over t and cancels), an online
+ * softmax over the 4096 image tokens, U = P^T keys and out = Wv_h U + bv_h (sum_t p = 1) - exact algebra; the 4096 x 256 stream of a prompt is
+ * read once.  keys fp32 [B][4096][256], pos [4096][256], q fp32 rows (b, j) [B * Tk][>= 128] (8 heads x 16 channels, ALREADY projected: q_proj
+ * and its bias applied), wk / wv fp32 [128][256], bv [128]; Tk <= 8; out fp32 rows (b, j) [B * Tk][ldo]; workspace: B x 131072 bytes. */
+typedef struct {
+    const float* keys; int64_t key_batch_stride;
+    const float* pos;
+    const float* q; int64_t ldq;
+    const float* wk; const float* wv; const float* bv;
+    float denom;
+    float* out; int64_t ldo;
+    int32_t B, Tk;
+    void* workspace; int64_t workspace_bytes;
+} msam_st2i_t;
+int msam_split16_t2i_attention(const msam_st2i_t* p, void* stream);
 /* The second half of MaskDecoder.predict_masks' up-scaling + the hyper product in ONE launch, split16 products (segment_anything
  * modeling/mask_decoder.py: output_upscaling[1:] = LayerNorm2d, GELU, ConvTranspose2d(64 -> 32, k 2, s 2), GELU; masks = hyper_in @ upscaled):
  *   low_res[p][m][4 ty + 2 ky + ky2][4 tx + 2 kx + kx2] = sum_c hyper[p][mask0 + m][c] * GELU(W2 GELU(LayerNorm(u1[row])) + b2)[(ky2, kx2), c]

@@ -109,6 +109,12 @@ class SI2TParams(C.Structure):
                 ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32), ("split16", _i32), ("wq_scale", _f32), ("wo_scale", _f32)]
 
 
+class ST2IParams(C.Structure):
+    """include/msam_hip.h msam_st2i_t (split16: token -> image attention with the k / v projections folded into the token side)."""
+    _fields_ = [("keys", _vp), ("key_batch_stride", _i64), ("pos", _vp), ("q", _vp), ("ldq", _i64), ("wk", _vp), ("wv", _vp), ("bv", _vp),
+                ("denom", _f32), ("out", _vp), ("ldo", _i64), ("B", _i32), ("Tk", _i32), ("workspace", _vp), ("workspace_bytes", _i64)]
+
+
 class SUp2Params(C.Structure):
     """include/msam_hip.h msam_sup2_t (split16: LayerNorm2d + GELU + ConvT2 + GELU + hyper product in one launch)."""
     _fields_ = [("u1", _vp), ("ln_weight", _vp), ("ln_bias", _vp), ("ln_eps", _f32), ("w2", _vp), ("b2", _vp), ("w_scale", _f32),
@@ -235,6 +241,7 @@ _PROTOS = {
     "msam_strict_source": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "msam_strict_hyper_masks": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "msam_strict_upscale2": (_i32, [C.POINTER(SUp2Params), _vp]),
+    "msam_split16_t2i_attention": (_i32, [C.POINTER(ST2IParams), _vp]),
     "msam_strict_instance_norm": (_i32, [_vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _i64, _vp]),
     "msam_strict_resize_bilinear": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp]),
 }

@@ -1307,6 +1307,229 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ token -> image attention (split16)
+// "The tokens attend to the image" of a TwoWayAttentionBlock / the final attention on a PER-PROMPT image stream, without the k and v projections
+// of the stream ever existing (upstream transformer.py Attention.forward: k = k_proj(keys + key_pe), v = v_proj(keys); as launches - one
+// product over [Wk; Wv] writing k | v, then sattn_long_kernel reading them - 17 GB cross HBM per layer and 1024 prompts; here the 4.3 GB stream
+// is read once).  The projections are folded into the token side, which is exact algebra:
+//   score[j, h, t] = (q[j, h] . k[t, h]) / sqrt(d) = (X[t] + pos[t]) . G[j h] + const(j, h),   G[j h] = Wk_h^T q[j, h] / sqrt(d)   (the constant
+//                                                                                                 q . bk cancels in the softmax over t)
+//   out[j, h]      = sum_t p[j h, t] v[t, h]     = Wv_h U[j h] + bv_h,                          U[j h] = sum_t p[j h, t] X[t]
+// so per prompt the kernel forms S = (X + pos) G^T [4096 x 64] and U = P^T X [64 x 256] (64 = 8 heads x 8 token slots, Tk <= 8) with an online
+// softmax over the 4096 image tokens in between; two small launches do the folds (s16_t2i_fold_kernel before, s16_t2i_out_kernel after, fp32).
+// One workgroup = one prompt, 4 waves = (jt: heads 0-3 / 4-7) x (ih: channels 0-127 / 128-255), one wave per SIMD (G lives in 128 registers):
+//   S tile [32 rows x 32 jh]: A = the (X + pos) tile's rows from LDS (row-major fp16 pairs), B = G from registers; D: a LANE is a (token, head)
+//     pair jh, its registers are image rows -> the running maximum / sum of the softmax are per lane (one exchange with lane ^ 32 per tile);
+//   U tile [32 jh x 128 ch] += P^T X: A = the lane's OWN exponentials (registers 8 s .. 8 s + 7 are k-step s: rows 16 s + 4 lh + {0..3, 8..11}),
+//     B = the X tile stored TRANSPOSED in LDS with its rows in that order (sp_vpos); the rare rescale of U when a maximum grows goes through
+//     a wave-private LDS vector (U's registers run over jh).
+// Both waves of a jt compute the same S tile (the price of not exchanging P through LDS): 72 MFMAs per wave and 32-row tile, 0.6 ms of matrix
+// time per 1024-prompt layer against 0.9 ms of HBM time for the stream.
+struct ST2IArgs {
+    const float* keys; long key_bs;                     // [B][4096][256]
+    const float* pos;                                   // [4096][256]
+    const unsigned short* g;                            // [B][64][512]: G as fp16 pairs (256 hi | 256 lo), scaled by T2I_GSCALE
+    float* u;                                           // [B][64][256]: U, normalised by the softmax denominator
+    int B;
+};
+constexpr float T2I_GSCALE = 64.0f;
+constexpr int T2I_RP = 1040;                            // (X + pos) row pitch in bytes: 256 hi | 256 lo halves + 16
+constexpr int T2I_TP = 144;                             // X^T row pitch: 32 hi | 32 lo halves + 16
+constexpr int T2I_BUF = 32 * T2I_RP + 256 * T2I_TP;     // one stage: 70 144 bytes
+constexpr int T2I_LDS = 2 * T2I_BUF + 4 * 32 * 4;       // + one 32-float vector per wave
+
+// G[p][h * 8 + j][i] = sum_{c in head h} q[p, j, c] Wk[c, i] / denom as fp16 pairs (thread = (p, jh, four columns))
+__global__ __launch_bounds__(256) void s16_t2i_fold_kernel(const float* __restrict__ q, long ldq, int Tk, const float* __restrict__ wk, float denom,
+                                                           long total, unsigned short* __restrict__ g) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int i4 = (int)(gid & 63) * 4, jh = (int)((gid >> 6) & 63);
+    const long p = gid >> 12;
+    const int h = jh >> 3, j = jh & 7;
+    float4 acc = zero4();
+    if (j < Tk) {
+        const float* qp = q + (p * Tk + j) * ldq + h * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float qc = qp[c];
+            const float4 wv = ld4(wk + (long)(h * 16 + c) * 256 + i4);
+            acc.x = fmaf(qc, wv.x, acc.x); acc.y = fmaf(qc, wv.y, acc.y); acc.z = fmaf(qc, wv.z, acc.z); acc.w = fmaf(qc, wv.w, acc.w);
+        }
+        acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
+    }
+    uint2 hi, lo;
+    sp_split4(acc, T2I_GSCALE, hi, lo);
+    unsigned short* dst = g + (p * 64 + jh) * 512 + i4;
+    *(uint2*)dst = hi; *(uint2*)(dst + 256) = lo;
+}
+// att[p, j, c] = Wv[c] . U[p][h(c) * 8 + j] + bv[c]  (thread = one output)
+__global__ __launch_bounds__(256) void s16_t2i_out_kernel(const float* __restrict__ u, const float* __restrict__ wv, const float* __restrict__ bv, int Tk,
+                                                          long total, float* __restrict__ out, long ldo) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid & 127);
+    const long pj = gid >> 7;
+    const long p = pj / Tk;
+    const int j = (int)(pj - p * Tk);
+    const float* up = u + (p * 64 + (c >> 4) * 8 + j) * 256;
+    const float* wp = wv + (long)c * 256;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 256; i += 4) {
+        const float4 a = ld4(up + i), b = ld4(wp + i);
+        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+    }
+    out[pj * ldo + c] = acc + bv[c];
+}
+
+__global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t2_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int jt = w >> 1, ih = w & 1;
+    const long p = blockIdx.x;
+    float* const av = (float*)(t2_lds + 2 * T2I_BUF) + w * 32;      // wave-private vector (rescale factors / final 1 / l)
+    const float* const xin = a.keys + p * a.key_bs;
+    // G of the lane's jh = jt * 32 + li: 16 k-steps x (hi, lo) of eight channels
+    uint4 gh[16], gl[16];
+    {
+        const unsigned short* gp = a.g + (p * 64 + jt * 32 + li) * 512 + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) { gh[ks] = *(const uint4*)(gp + ks * 16); gl[ks] = *(const uint4*)(gp + 256 + ks * 16); }
+    }
+    // staging: thread -> two 4 x 4 blocks (rows 4 rg .. + 3, channels 4 cg .. + 3) of the 32 x 256 tile
+    float4 rx[2][4], rp[2][4];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = tid + 256 * k, rg = b >> 6, cg = b & 63;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long o = (long)(t * 32 + rg * 4 + r) * 256 + cg * 4;
+                rx[k][r] = ld4(xin + o); rp[k][r] = ld4(a.pos + o);
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+        unsigned char* const xr = t2_lds + buf * T2I_BUF;
+        unsigned char* const xt = xr + 32 * T2I_RP;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = tid + 256 * k, rg = b >> 6, cg = b & 63;
+            uint2 xh[4], xl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint2 h, l;
+                sp_split4(make_float4(rx[k][r].x + rp[k][r].x, rx[k][r].y + rp[k][r].y, rx[k][r].z + rp[k][r].z, rx[k][r].w + rp[k][r].w), 1.0f, h, l);
+                unsigned char* q = xr + (rg * 4 + r) * T2I_RP + cg * 8;
+                *(uint2*)q = h; *(uint2*)(q + 512) = l;
+                sp_split4(rx[k][r], 1.0f, xh[r], xl[r]);
+            }
+            // transposed: channel 4 cg + c, rows 4 rg .. 4 rg + 3 (consecutive positions sp_vpos(4 rg) ..)
+            const int tp = sp_vpos(rg * 4) * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int sh = (c & 1) * 16;
+                uint2 th, tl;
+                if (c < 2) {
+                    th.x = ((xh[0].x >> sh) & 0xffffu) | (((xh[1].x >> sh) & 0xffffu) << 16); th.y = ((xh[2].x >> sh) & 0xffffu) | (((xh[3].x >> sh) & 0xffffu) << 16);
+                    tl.x = ((xl[0].x >> sh) & 0xffffu) | (((xl[1].x >> sh) & 0xffffu) << 16); tl.y = ((xl[2].x >> sh) & 0xffffu) | (((xl[3].x >> sh) & 0xffffu) << 16);
+                } else {
+                    th.x = ((xh[0].y >> sh) & 0xffffu) | (((xh[1].y >> sh) & 0xffffu) << 16); th.y = ((xh[2].y >> sh) & 0xffffu) | (((xh[3].y >> sh) & 0xffffu) << 16);
+                    tl.x = ((xl[0].y >> sh) & 0xffffu) | (((xl[1].y >> sh) & 0xffffu) << 16); tl.y = ((xl[2].y >> sh) & 0xffffu) | (((xl[3].y >> sh) & 0xffffu) << 16);
+                }
+                unsigned char* q = xt + (cg * 4 + c) * T2I_TP + tp;
+                *(uint2*)q = th; *(uint2*)(q + 64) = tl;
+            }
+        }
+    };
+    f32x16_t uacc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) uacc[it][r] = 0.f;
+    float m = -3.0e38f, l = 0.f, lc = 0.f;              // l: compensated (Kahan) sum - one exponential of 1.0 and 2047 tiny ones per lane otherwise
+    gload(0);                                           // lose 1e-5 of the small ones' mass to the 6e-8 grid of a sum near 1
+    sstore(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < 128; ++t) {
+        if (t + 1 < 128) gload(t + 1);
+        const unsigned char* const xr = t2_lds + (t & 1) * T2I_BUF;
+        const unsigned char* const xt = xr + 32 * T2I_RP;
+        // S tile: rows x jh
+        // (two accumulators: the hi x hi terms - 16 roundings at the score's magnitude, as a 16-step fp32 chain has - and the small cross terms,
+        //  whose 32 roundings happen at 2^-11 of it; one accumulator rounded the +-20 score 48 times: 5e-5 instead of 5e-6 on the attention output)
+        f32x16_t sc, scl;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; scl[r] = 0.f; }
+        const unsigned char* xa = xr + li * T2I_RP + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const uint4 xh = *(const uint4*)(xa + ks * 32), xl = *(const uint4*)(xa + 512 + ks * 32);
+            scl = mfma32h(xl, gh[ks], scl); scl = mfma32h(xh, gl[ks], scl); sc = mfma32h(xh, gh[ks], sc);
+        }
+        float cm = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = (sc[r] + scl[r]) * (1.0f / T2I_GSCALE); cm = fmaxf(cm, sc[r]); }
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m, cm);
+        if (__ballot(mn > m)) {
+            // a maximum grew: U's rows jh are rescaled (U's registers run over jh: the factors travel through the wave-private vector)
+            const float alpha = expf(m - mn);
+            l *= alpha; lc *= alpha;
+            if (lh == 0) av[li] = alpha;
+            si_wave_sync();
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 f = ld4(&av[8 * g4 + 4 * lh]);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { uacc[it][4 * g4] *= f.x; uacc[it][4 * g4 + 1] *= f.y; uacc[it][4 * g4 + 2] *= f.z; uacc[it][4 * g4 + 3] *= f.w; }
+            }
+            si_wave_sync();
+            m = mn;
+        }
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[r] = expf(sc[r] - m);
+        {
+            const float ts = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
+                             (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));
+            const float y = ts - lc, tn = l + y;
+            lc = (tn - l) - y; l = tn;
+        }
+        uint4 ph[2], pl[2];
+        sp_split8(&pv[0], SP_PSCALE, ph[0], pl[0]); sp_split8(&pv[8], SP_PSCALE, ph[1], pl[1]);
+        // U tile: jh x channels of this wave's half
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const unsigned char* xb = xt + (ih * 128 + it * 32 + li) * T2I_TP + lh * 16;
+#pragma unroll
+            for (int s8 = 0; s8 < 2; ++s8) {
+                const uint4 xh = *(const uint4*)(xb + 32 * s8), xl = *(const uint4*)(xb + 64 + 32 * s8);
+                uacc[it] = mfma32h(pl[s8], xh, uacc[it]); uacc[it] = mfma32h(ph[s8], xl, uacc[it]); uacc[it] = mfma32h(ph[s8], xh, uacc[it]);
+            }
+        }
+        if (t + 1 < 128) sstore((t + 1) & 1);
+        __syncthreads();
+    }
+    // 1 / (sum of the exponentials): both halves of a lane pair hold partial sums of the same jh
+    l -= lc;
+    l += __shfl_xor(l, 32);
+    if (lh == 0) av[li] = 1.0f / (l * SP_PSCALE);
+    si_wave_sync();
+    float* const up = a.u + (p * 64 + jt * 32) * 256 + ih * 128 + li;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 f = ld4(&av[8 * g4 + 4 * lh]);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r0 = 8 * g4 + 4 * lh;
+            up[(long)(r0 + 0) * 256 + it * 32] = uacc[it][4 * g4] * f.x; up[(long)(r0 + 1) * 256 + it * 32] = uacc[it][4 * g4 + 1] * f.y;
+            up[(long)(r0 + 2) * 256 + it * 32] = uacc[it][4 * g4 + 2] * f.z; up[(long)(r0 + 3) * 256 + it * 32] = uacc[it][4 * g4 + 3] * f.w;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ decoder attention
 // q [B, Nq, H*D] (row stride ldq, batch stride sqb; 0 = shared by every batch entry), k / v [B, Nk, H*D], out [B, Nq, H*D] rows ldo.
 // scores = (q . k) / denom (upstream: attn / sqrt(c_per_head)), softmax, @ v.
@@ -1961,6 +2184,32 @@ extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
     if (p->split16) hipLaunchKernelGGL(si2t_kernel<true>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(si2t_kernel<false>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     return msam_check_launch("strict_i2t_block");
+}
+
+extern "C" int msam_split16_t2i_attention(const msam_st2i_t* p, void* stream) {
+    if (!p || !p->keys || !p->pos || !p->q || !p->wk || !p->wv || !p->bv || !p->out || !p->workspace || p->B <= 0) { msam_set_error("msam_split16_t2i_attention: null argument"); return 1; }
+    if (p->Tk < 1 || p->Tk > 8 || p->ldq < 128 || p->ldq % 4 || p->ldo < 128 || p->key_batch_stride % 4 || p->denom <= 0.f ||
+        ((uintptr_t)p->keys | (uintptr_t)p->pos | (uintptr_t)p->q | (uintptr_t)p->wk | (uintptr_t)p->wv | (uintptr_t)p->workspace) % 16) {
+        msam_set_error("msam_split16_t2i_attention: 1..8 tokens, 8 heads x 16 channels, strides in multiples of 4 floats, 16-byte aligned pointers"); return 1;
+    }
+    if (p->workspace_bytes < (int64_t)p->B * 64 * (512 * 2 + 256 * 4)) { msam_set_error("msam_split16_t2i_attention: workspace of B x 131072 bytes needed"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* g = (unsigned short*)p->workspace;
+    float* u = (float*)((char*)p->workspace + (size_t)p->B * 64 * 512 * 2);
+    const long nf = (long)p->B * 64 * 64;
+    hipLaunchKernelGGL(s16_t2i_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, p->q, (long)p->ldq, p->Tk, p->wk, p->denom, nf, g);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)s16_t2i_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T2I_LDS) != hipSuccess) {
+            msam_set_error("msam_split16_t2i_attention: cannot raise the dynamic LDS limit"); return 2;
+        }
+        attr = true;
+    }
+    ST2IArgs a{p->keys, (long)p->key_batch_stride, p->pos, g, u, p->B};
+    hipLaunchKernelGGL(s16_t2i_kernel, dim3((unsigned)p->B), dim3(256), T2I_LDS, s, a);
+    const long no = (long)p->B * p->Tk * 128;
+    hipLaunchKernelGGL(s16_t2i_out_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, s, (const float*)u, p->wv, p->bv, p->Tk, no, p->out, (long)p->ldo);
+    return msam_check_launch("split16_t2i_attention");
 }
 
 extern "C" int msam_strict_attention(const float* q, int64_t ldq, int64_t q_batch_stride, const float* k, int64_t ldk, int64_t k_batch_stride,

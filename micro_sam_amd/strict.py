@@ -44,6 +44,9 @@ FUSED_I2T = True
 FUSED_KV = False
 # ... but in the split16 mode the same products are bound by HBM (4.1 TB/s on the k / v shape), so there the one-launch form is the default
 FUSED_KV_SPLIT = True
+# split16 only: "tokens attend to the image" on a per-prompt stream (layer >= 1 and the final attention) as msam_split16_t2i_attention - the k / v
+# projections folded into the token side, online softmax, the stream read once (17 GB -> 4.3 GB per 1024-prompt layer); Tk <= 8
+FUSED_T2I = True
 # split16 only: the up-scaling's LayerNorm2d, GELU, second transposed convolution, GELU and hyper product as one launch
 # (msam_strict_upscale2: the 4.3 GB first-stage stream of a tile is read once; as four launches 34 GB cross HBM)
 FUSED_UP2 = True
@@ -317,6 +320,17 @@ class StrictDecoder:
         """upstream ``Attention.forward``: projections, heads, softmax, (out_proj is left to the caller: it carries the residual)."""
         q = gemm(q_in, *aw["q"], a2=q_pe, a2_rows=q_pe_rows)
         inner = aw["q"][0].shape[0]
+        if (split_active() and FUSED_T2I and k_in is v_in and k_pe is not None and not kv_shared and not q_shared and Nk == T and Nq <= 8
+                and inner == 128 and k_pe_rows == T):
+            # tokens attending to a per-prompt image stream: k / v projections folded into the token side, one pass over the stream
+            out = torch.empty((B * Nq, inner), dtype=torch.float32, device=q.device)
+            ws = torch.empty(B * 131072, dtype=torch.uint8, device=q.device)
+            p = _lib.ST2IParams()
+            p.keys, p.key_batch_stride, p.pos, p.q, p.ldq = k_in.data_ptr(), T * PROMPT_DIM, k_pe.data_ptr(), q.data_ptr(), q.stride(0)
+            p.wk, p.wv, p.bv, p.denom = aw["k"][0].data_ptr(), aw["v"][0].data_ptr(), aw["v"][1].data_ptr(), math.sqrt(inner // 8)
+            p.out, p.ldo, p.B, p.Tk, p.workspace, p.workspace_bytes = out.data_ptr(), out.stride(0), B, Nq, ws.data_ptr(), ws.numel()
+            _lib.check(_lib.load().msam_split16_t2i_attention(C.byref(p), _lib.stream_ptr()), "msam_split16_t2i_attention")
+            return out
         if (FUSED_KV or (split_active() and FUSED_KV_SPLIT)) and k_in is v_in and k_pe is not None and inner % 128 == 0 and k_in.shape[0] >= 4096:
             # the image side's k | v: one pass over the per-prompt stream instead of two
             kv = gemm(k_in, *aw["kv"], a2=k_pe, a2_rows=k_pe_rows, a2_cols=inner)

@@ -449,3 +449,47 @@ def test_strict_encoder_is_the_oracles_fp32_encoder(host_sam):
     assert (out - ref).abs().max().item() <= 3e-5 * max(1.0, ref.abs().max().item()), (out - ref).abs().max().item()
     out2 = enc(S.preprocess(u8.permute(0, 3, 1, 2).float()))
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("Tk", [7, 8, 3])
+def test_split16_t2i_attention_is_the_projections_and_the_attention(host_sam, Tk):
+    """msam_split16_t2i_attention (k / v projections folded into the token side, one pass over the per-prompt image stream with an online
+    softmax, MFMA products on fp16 pairs) against the unfused strict steps (k | v projection, sattn_long) and an fp64 statement."""
+    from micro_sam_amd import _lib as L
+    from micro_sam_amd import strict
+    lib, _, _ = host_sam
+    g = torch.Generator().manual_seed(30 + Tk)
+    B = 2
+    keys = torch.randn(B * 4096, 256, generator=g) * torch.exp(0.3 * torch.randn(B * 4096, 1, generator=g))
+    pos = torch.randn(4096, 256, generator=g)
+    q = torch.randn(B * Tk, 128, generator=g) * 1.5
+    wk, bk = torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1
+    wv, bv = torch.randn(128, 256, generator=g) / 16, torch.randn(128, generator=g) * 0.1
+    out = torch.full((B * Tk, 128), float("nan"))
+    ws = torch.zeros(B * 131072, dtype=torch.uint8)
+    p = L.ST2IParams()
+    p.keys, p.key_batch_stride, p.pos, p.q, p.ldq = keys.data_ptr(), 4096 * 256, pos.data_ptr(), q.data_ptr(), 128
+    p.wk, p.wv, p.bv, p.denom, p.out, p.ldo, p.B, p.Tk = wk.data_ptr(), wv.data_ptr(), bv.data_ptr(), 4.0, out.data_ptr(), 128, B, Tk
+    p.workspace, p.workspace_bytes = ws.data_ptr(), ws.numel()
+    assert lib.msam_split16_t2i_attention(C.byref(p), None) == 0, lib.msam_last_error()
+    assert torch.isfinite(out).all()
+    # fp64 statement of upstream Attention.forward (q already projected)
+    kd = ((keys.double().reshape(B, 4096, 256) + pos.double()) @ wk.double().T + bk.double()).reshape(B, 4096, 8, 16).transpose(1, 2)
+    vd = (keys.double().reshape(B, 4096, 256) @ wv.double().T + bv.double()).reshape(B, 4096, 8, 16).transpose(1, 2)
+    qd = q.double().reshape(B, Tk, 8, 16).transpose(1, 2)
+    ref = (torch.softmax(qd @ kd.transpose(-1, -2) / 4.0, dim=-1) @ vd).transpose(1, 2).reshape(B * Tk, 128)
+    # the unfused strict steps (fp32 products)
+    k = strict.gemm(keys, wk, bk, a2=pos, a2_rows=4096)
+    v = strict.gemm(keys, wv, bv)
+    want = strict.attention(q, k, v, B, 8, Tk, 4096, 16, 4.0)
+    strict.forget_scales()
+    with strict.split_mode(True):                       # the unfused steps with split16 products: the error class the fused kernel belongs to
+        want16 = strict.attention(q, strict.gemm(keys, wk, bk, a2=pos, a2_rows=4096), strict.gemm(keys, wv, bv), B, 8, Tk, 4096, 16, 4.0)
+    err, err_unfused = (out.double() - ref).abs().max().item(), (want.double() - ref).abs().max().item()
+    err16 = (want16.double() - ref).abs().max().item()
+    print(f"\nt2i Tk={Tk}: fused split16 vs fp64 {err:.2e}, unfused fp32 steps vs fp64 {err_unfused:.2e}, unfused split16 steps {err16:.2e}")
+    # scores of +-20 with these operands, some rows with one probability of 0.99: the fused kernel sums the softmax denominator with
+    # compensation (without it the 2047 tiny exponentials a lane adds to a sum near 1 lost 1e-5 of their mass: 5e-5 on the output)
+    assert err <= 2e-5 and err <= 2 * max(err_unfused, err16) and (out - want).abs().max().item() <= 3e-5
+    p.Tk = 9
+    assert lib.msam_split16_t2i_attention(C.byref(p), None) == 1
