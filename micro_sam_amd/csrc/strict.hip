@@ -74,6 +74,18 @@ MSAM_DEVINL f32x2_t gelu_p8x2(f32x2_t x) {
     const f32x2_t e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
     return r - t * e;
 }
+// split16 kernels: exponentials as ONE v_exp_f32 on scores that already carry log2(e) (the factor is folded into a scale the kernel applies
+// anyway).  The argument's fp32 rounding (|score| log2 e <= ~30: 2e-6) is the error of the result, the size of the score's own error in this
+// mode; expf (the strict kernels) is ~15 instructions, and these kernels are bound by their vector instruction count.
+constexpr float SP_LOG2E = 1.4426950408889634f;
+// (a.lo16 << 16) | b.lo16 and (a.hi16 << 16) | b.hi16 in one instruction
+#if defined(__HIPCC__)
+MSAM_DEVINL uint32_t sp_pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(a, b, 0x05040100u); }
+MSAM_DEVINL uint32_t sp_pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(a, b, 0x07060302u); }
+#else
+static inline uint32_t sp_pack_lo(uint32_t a, uint32_t b) { return (a << 16) | (b & 0xffffu); }
+static inline uint32_t sp_pack_hi(uint32_t a, uint32_t b) { return (a & 0xffff0000u) | (b >> 16); }
+#endif
 // four consecutive values -> their hi and lo halves (4 x fp16 = 8 bytes each)
 MSAM_DEVINL void sp_split4(const float4& v, float scale, uint2& hi, uint2& lo) {
     const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
@@ -1140,6 +1152,7 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
             }
         }
     // ---- softmax((q . k) / denom) v per head, in place over q
+    const float inv_denom = 1.0f / a.denom;
     if (!(a.dbg & 2))
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -1158,20 +1171,23 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
                     part = fmaf(q[nt][8 * g + 4], k1.x, part); part = fmaf(q[nt][8 * g + 5], k1.y, part);
                     part = fmaf(q[nt][8 * g + 6], k1.z, part); part = fmaf(q[nt][8 * g + 7], k1.w, part);
                     const float other = __shfl_xor(part, 32);
-                    sc[t] = (lh ? other + part : part + other) / a.denom;        // the same sum in both lanes of the pair
+                    // (split16: one multiplication by the reciprocal instead of an IEEE division per score - 1 / denom is exact for upstream's
+                    //  sqrt(16) - and one division per head instead of one per probability below: ~130 of a head's ~360 vector instructions)
+                    sc[t] = SPLIT ? (lh ? other + part : part + other) * (inv_denom * SP_LOG2E) : (lh ? other + part : part + other) / a.denom;
                     mx = fmaxf(mx, sc[t]);
                 }
             }
             float l = 0.f;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { sc[t] = t < a.Tk ? expf(sc[t] - mx) : 0.f; l += sc[t]; }
+            for (int t = 0; t < 16; ++t) { sc[t] = t < a.Tk ? (SPLIT ? __builtin_amdgcn_exp2f(sc[t] - mx) : expf(sc[t] - mx)) : 0.f; l += sc[t]; }
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = 0.f;
+            const float inv_l = 1.0f / l;
 #pragma unroll
             for (int t = 0; t < 16; ++t)
                 if (t < a.Tk) {
-                    const float pr = sc[t] / l;
+                    const float pr = SPLIT ? sc[t] * inv_l : sc[t] / l;
                     const float4 v0 = ld4(&tvs[t * CI + c0]), v1 = ld4(&tvs[t * CI + c0 + 8]);
                     o[0] = fmaf(pr, v0.x, o[0]); o[1] = fmaf(pr, v0.y, o[1]); o[2] = fmaf(pr, v0.z, o[2]); o[3] = fmaf(pr, v0.w, o[3]);
                     o[4] = fmaf(pr, v1.x, o[4]); o[5] = fmaf(pr, v1.y, o[5]); o[6] = fmaf(pr, v1.z, o[6]); o[7] = fmaf(pr, v1.w, o[7]);
@@ -1428,15 +1444,12 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
             const int tp = sp_vpos(rg * 4) * 2;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int sh = (c & 1) * 16;
+                // channel c of rows 0..3: the low / high half of word c >> 1 of each row's pair
                 uint2 th, tl;
-                if (c < 2) {
-                    th.x = ((xh[0].x >> sh) & 0xffffu) | (((xh[1].x >> sh) & 0xffffu) << 16); th.y = ((xh[2].x >> sh) & 0xffffu) | (((xh[3].x >> sh) & 0xffffu) << 16);
-                    tl.x = ((xl[0].x >> sh) & 0xffffu) | (((xl[1].x >> sh) & 0xffffu) << 16); tl.y = ((xl[2].x >> sh) & 0xffffu) | (((xl[3].x >> sh) & 0xffffu) << 16);
-                } else {
-                    th.x = ((xh[0].y >> sh) & 0xffffu) | (((xh[1].y >> sh) & 0xffffu) << 16); th.y = ((xh[2].y >> sh) & 0xffffu) | (((xh[3].y >> sh) & 0xffffu) << 16);
-                    tl.x = ((xl[0].y >> sh) & 0xffffu) | (((xl[1].y >> sh) & 0xffffu) << 16); tl.y = ((xl[2].y >> sh) & 0xffffu) | (((xl[3].y >> sh) & 0xffffu) << 16);
-                }
+                const uint32_t h0 = c < 2 ? xh[0].x : xh[0].y, h1 = c < 2 ? xh[1].x : xh[1].y, h2 = c < 2 ? xh[2].x : xh[2].y, h3 = c < 2 ? xh[3].x : xh[3].y;
+                const uint32_t l0 = c < 2 ? xl[0].x : xl[0].y, l1 = c < 2 ? xl[1].x : xl[1].y, l2 = c < 2 ? xl[2].x : xl[2].y, l3 = c < 2 ? xl[3].x : xl[3].y;
+                if (c & 1) { th.x = sp_pack_hi(h1, h0); th.y = sp_pack_hi(h3, h2); tl.x = sp_pack_hi(l1, l0); tl.y = sp_pack_hi(l3, l2); }
+                else { th.x = sp_pack_lo(h1, h0); th.y = sp_pack_lo(h3, h2); tl.x = sp_pack_lo(l1, l0); tl.y = sp_pack_lo(l3, l2); }
                 unsigned char* q = xt + (cg * 4 + c) * T2I_TP + tp;
                 *(uint2*)q = th; *(uint2*)(q + 64) = tl;
             }
@@ -1470,12 +1483,12 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
         }
         float cm = -3.0e38f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] = (sc[r] + scl[r]) * (1.0f / T2I_GSCALE); cm = fmaxf(cm, sc[r]); }
+        for (int r = 0; r < 16; ++r) { sc[r] = (sc[r] + scl[r]) * (SP_LOG2E / T2I_GSCALE); cm = fmaxf(cm, sc[r]); }     // scores in units of ln 2
         cm = fmaxf(cm, __shfl_xor(cm, 32));
         const float mn = fmaxf(m, cm);
         if (__ballot(mn > m)) {
             // a maximum grew: U's rows jh are rescaled (U's registers run over jh: the factors travel through the wave-private vector)
-            const float alpha = expf(m - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
             l *= alpha; lc *= alpha;
             if (lh == 0) av[li] = alpha;
             si_wave_sync();
@@ -1490,7 +1503,7 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
         }
         float pv[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pv[r] = expf(sc[r] - m);
+        for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(sc[r] - m);
         {
             const float ts = (((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]))) +
                              (((pv[8] + pv[9]) + (pv[10] + pv[11])) + ((pv[12] + pv[13]) + (pv[14] + pv[15])));

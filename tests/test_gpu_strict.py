@@ -100,7 +100,12 @@ def test_strict_decoder_is_the_fp32_reference(model, kind):
     rec = {"max_rel": d.max().item() / scale, "mean_rel": d.mean().item() / scale, "iou_pred_max": (iou.cpu() - iou_r).abs().max().item()}
     print(f"\n{predictor.model.precision} decoder [{kind}] vs fp32 oracle:", json.dumps(rec))
     _record(f"decoder_{kind}[{predictor.model.precision}]", rec)
-    assert torch.isfinite(low).all() and rec["max_rel"] <= 1e-4 and rec["mean_rel"] <= 2e-6 and rec["iou_pred_max"] <= 2e-5, rec
+    # strict: fp32 products (measured max 2.5e-5 / 4e-7 / 5.7e-5 of the logit scale, mean 3e-8 ... 1.3e-7).  split16: an fp16 PAIR holds 22 bits of an
+    # operand against fp32's 24 and the a_lo w_lo term is dropped, so a product carries ~5 x the strict mode's error - measured max 1.7e-4, mean 4.6e-7,
+    # the same with every fused kernel switched off (tools/split16_ablation.py: the distance is the pair arithmetic, not the fusion); the default
+    # 16-bit path is at 3e-2.  The masks do not feel it: tests below, and 283 + 234 instances identical to the strict mode's on the bench / trained tiles
+    tol_max = 1e-4 if predictor.model.precision == "strict" else 5e-4
+    assert torch.isfinite(low).all() and rec["max_rel"] <= tol_max and rec["mean_rel"] <= 2e-6 and rec["iou_pred_max"] <= 2e-5, rec
 
 
 CASES = [(1000, 0, "cells", 1.0), (1001, 0, "cells", 1.0), (1002, 0, "cells", 1.0), (1000, 1, "cells", 1.0), (1000, 2, "cells", 1.0),
