@@ -86,6 +86,17 @@ MSAM_DEVINL uint32_t sp_pack_hi(uint32_t a, uint32_t b) { return __builtin_amdgc
 static inline uint32_t sp_pack_lo(uint32_t a, uint32_t b) { return (a << 16) | (b & 0xffffu); }
 static inline uint32_t sp_pack_hi(uint32_t a, uint32_t b) { return (a & 0xffff0000u) | (b >> 16); }
 #endif
+// ds_read_b64_tr_b16: inside a group of 16 lanes, lane r receives element (r & 3) of the four 16-bit values read by the lanes 4 j + (r >> 2),
+// j = 0..3 - a 4 x 16 <-> 16 x 4 transpose of the block the group addressed: MFMA operands that run DOWN the columns of a row-major LDS tile
+#if defined(__HIPCC__)
+typedef short sp_s16x4_t __attribute__((ext_vector_type(4)));
+MSAM_DEVINL uint2 sp_tr16(const unsigned char* p) {
+    sp_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((sp_s16x4_t __attribute__((address_space(3)))*)p);
+    return __builtin_bit_cast(uint2, v);
+}
+#else
+static inline uint2 sp_tr16(const unsigned char* p) { return ds_read_tr16_b64_emu(p); }
+#endif
 // four consecutive values -> their hi and lo halves (4 x fp16 = 8 bytes each)
 MSAM_DEVINL void sp_split4(const float4& v, float scale, uint2& hi, uint2& lo) {
     const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
@@ -1337,8 +1348,9 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
 //   S tile [32 rows x 32 jh]: A = the (X + pos) tile's rows from LDS (row-major fp16 pairs), B = G from registers; D: a LANE is a (token, head)
 //     pair jh, its registers are image rows -> the running maximum / sum of the softmax are per lane (one exchange with lane ^ 32 per tile);
 //   U tile [32 jh x 128 ch] += P^T X: A = the lane's OWN exponentials (registers 8 s .. 8 s + 7 are k-step s: rows 16 s + 4 lh + {0..3, 8..11}),
-//     B = the X tile stored TRANSPOSED in LDS with its rows in that order (sp_vpos); the rare rescale of U when a maximum grows goes through
-//     a wave-private LDS vector (U's registers run over jh).
+//     B = columns of a second, pos-free row-major copy of the tile through the transposing LDS read (ds_read_b64_tr_b16, two per operand: rows
+//     16 s + 4 lh + 0..3 and + 8..11); the rare rescale of U when a maximum grows goes through a wave-private LDS vector (U's registers run
+//     over jh).  (First form: a transposed copy written with 8-byte stores - 8-way bank conflicts on every one of them.)
 // Both waves of a jt compute the same S tile (the price of not exchanging P through LDS): 72 MFMAs per wave and 32-row tile, 0.6 ms of matrix
 // time per 1024-prompt layer against 0.9 ms of HBM time for the stream.
 struct ST2IArgs {
@@ -1350,8 +1362,9 @@ struct ST2IArgs {
 };
 constexpr float T2I_GSCALE = 64.0f;
 constexpr int T2I_RP = 1040;                            // (X + pos) row pitch in bytes: 256 hi | 256 lo halves + 16
-constexpr int T2I_TP = 144;                             // X^T row pitch: 32 hi | 32 lo halves + 16
-constexpr int T2I_BUF = 32 * T2I_RP + 256 * T2I_TP;     // one stage: 70 144 bytes
+constexpr int T2I_NP = 1088;                            // X row pitch (the second, pos-free copy): 272 dwords = 16 mod 64 - the transposing reads of a
+                                                        // 32-lane group (4 rows x 8 column blocks) then touch 64 different banks
+constexpr int T2I_BUF = 32 * T2I_RP + 32 * T2I_NP;      // one stage: 68 096 bytes
 constexpr int T2I_LDS = 2 * T2I_BUF + 4 * 32 * 4;       // + one 32-float vector per wave
 
 // G[p][h * 8 + j][i] = sum_{c in head h} q[p, j, c] Wk[c, i] / denom as fp16 pairs (thread = (p, jh, four columns))
@@ -1427,31 +1440,19 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
     };
     auto sstore = [&](int buf) {
         unsigned char* const xr = t2_lds + buf * T2I_BUF;
-        unsigned char* const xt = xr + 32 * T2I_RP;
+        unsigned char* const xn = xr + 32 * T2I_RP;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int b = tid + 256 * k, rg = b >> 6, cg = b & 63;
-            uint2 xh[4], xl[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 uint2 h, l;
                 sp_split4(make_float4(rx[k][r].x + rp[k][r].x, rx[k][r].y + rp[k][r].y, rx[k][r].z + rp[k][r].z, rx[k][r].w + rp[k][r].w), 1.0f, h, l);
                 unsigned char* q = xr + (rg * 4 + r) * T2I_RP + cg * 8;
                 *(uint2*)q = h; *(uint2*)(q + 512) = l;
-                sp_split4(rx[k][r], 1.0f, xh[r], xl[r]);
-            }
-            // transposed: channel 4 cg + c, rows 4 rg .. 4 rg + 3 (consecutive positions sp_vpos(4 rg) ..)
-            const int tp = sp_vpos(rg * 4) * 2;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                // channel c of rows 0..3: the low / high half of word c >> 1 of each row's pair
-                uint2 th, tl;
-                const uint32_t h0 = c < 2 ? xh[0].x : xh[0].y, h1 = c < 2 ? xh[1].x : xh[1].y, h2 = c < 2 ? xh[2].x : xh[2].y, h3 = c < 2 ? xh[3].x : xh[3].y;
-                const uint32_t l0 = c < 2 ? xl[0].x : xl[0].y, l1 = c < 2 ? xl[1].x : xl[1].y, l2 = c < 2 ? xl[2].x : xl[2].y, l3 = c < 2 ? xl[3].x : xl[3].y;
-                if (c & 1) { th.x = sp_pack_hi(h1, h0); th.y = sp_pack_hi(h3, h2); tl.x = sp_pack_hi(l1, l0); tl.y = sp_pack_hi(l3, l2); }
-                else { th.x = sp_pack_lo(h1, h0); th.y = sp_pack_lo(h3, h2); tl.x = sp_pack_lo(l1, l0); tl.y = sp_pack_lo(l3, l2); }
-                unsigned char* q = xt + (cg * 4 + c) * T2I_TP + tp;
-                *(uint2*)q = th; *(uint2*)(q + 64) = tl;
+                sp_split4(rx[k][r], 1.0f, h, l);
+                q = xn + (rg * 4 + r) * T2I_NP + cg * 8;
+                *(uint2*)q = h; *(uint2*)(q + 512) = l;
             }
         }
     };
@@ -1468,7 +1469,7 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
     for (int t = 0; t < 128; ++t) {
         if (t + 1 < 128) gload(t + 1);
         const unsigned char* const xr = t2_lds + (t & 1) * T2I_BUF;
-        const unsigned char* const xt = xr + 32 * T2I_RP;
+        const unsigned char* const xn = xr + 32 * T2I_RP;
         // S tile: rows x jh
         // (two accumulators: the hi x hi terms - 16 roundings at the score's magnitude, as a 16-step fp32 chain has - and the small cross terms,
         //  whose 32 roundings happen at 2^-11 of it; one accumulator rounded the +-20 score 48 times: 5e-5 instead of 5e-6 on the attention output)
@@ -1513,12 +1514,16 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
         uint4 ph[2], pl[2];
         sp_split8(&pv[0], SP_PSCALE, ph[0], pl[0]); sp_split8(&pv[8], SP_PSCALE, ph[1], pl[1]);
         // U tile: jh x channels of this wave's half
+        // (as a SOURCE lane of the transposing read, lane r of a 16-lane group addresses row 4 lh + (r >> 2) [+ 8, + 16 s] and the four channels
+        //  4 (r & 3) .. + 3 of the group's 16)
+        const unsigned char* xb = xn + (4 * lh + ((li & 15) >> 2)) * T2I_NP + (ih * 128 + (li >> 4) * 16 + (li & 3) * 4) * 2;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const unsigned char* xb = xt + (ih * 128 + it * 32 + li) * T2I_TP + lh * 16;
 #pragma unroll
             for (int s8 = 0; s8 < 2; ++s8) {
-                const uint4 xh = *(const uint4*)(xb + 32 * s8), xl = *(const uint4*)(xb + 64 + 32 * s8);
+                const unsigned char* q0 = xb + it * 64 + s8 * 16 * T2I_NP;
+                const uint2 h0 = sp_tr16(q0), h1 = sp_tr16(q0 + 8 * T2I_NP), l0 = sp_tr16(q0 + 512), l1 = sp_tr16(q0 + 8 * T2I_NP + 512);
+                const uint4 xh = uint4{h0.x, h0.y, h1.x, h1.y}, xl = uint4{l0.x, l0.y, l1.x, l1.y};
                 uacc[it] = mfma32h(pl[s8], xh, uacc[it]); uacc[it] = mfma32h(ph[s8], xl, uacc[it]); uacc[it] = mfma32h(ph[s8], xh, uacc[it]);
             }
         }
