@@ -697,6 +697,8 @@ typedef struct msam_si2t {
     int32_t B, Tk;
     int32_t split16;                     /* 1: both projections on fp16 operand pairs (msam_sgemm_t.split16); attention, residual, LayerNorm stay fp32 */
     float wq_scale, wo_scale;            /* split16: powers of two for wq / wo (0 = 1), undone on the accumulators */
+    const void* wq_pairs; const void* wo_pairs;   /* split16, optional: wq / wo already as fp16 pairs (msam_split16_prepare_pairs with the same scales;
+                                                   * wo with permute = 1) - every workgroup then copies the weights' k-tiles instead of re-splitting them */
 } msam_si2t_t;
 int msam_strict_i2t_block(const msam_si2t_t* p, void* stream);
 /* Attention of the two-way transformer: q fp32 [B, Nq, H * D] (row stride ldq, batch stride in floats; 0 = one tensor shared by every
@@ -724,6 +726,10 @@ int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_l
  * softmax over the 4096 image tokens, U = P^T keys and out = Wv_h U + bv_h (sum_t p = 1) - exact algebra; the 4096 x 256 stream of a prompt is
  * read once.  keys fp32 [B][4096][256], pos [4096][256], q fp32 rows (b, j) [B * Tk][>= 128] (8 heads x 16 channels, ALREADY projected: q_proj
  * and its bias applied), wk / wv fp32 [128][256], bv [128]; Tk <= 8; out fp32 rows (b, j) [B * Tk][ldo]; workspace: B x 131072 bytes. */
+/* A weight matrix as fp16 pairs in the LDS tile layout of the split16 kernels: w fp32 [N][K] (K % 32 == 0), each value times `scale` (a power of two),
+ * hi = fp16(x), lo = fp16(x - hi); out: N rows of K / 32 k-tiles of [32 hi | 32 lo] halves (2 K halves per row).  permute = 1: the k order of
+ * msam_strict_i2t_block's second projection inside a k-tile. */
+int msam_split16_prepare_pairs(const float* w, int64_t N, int32_t K, float scale, int32_t permute, void* out, void* stream);
 typedef struct {
     const float* keys; int64_t key_batch_stride;
     const float* pos;

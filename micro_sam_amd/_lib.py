@@ -106,7 +106,7 @@ class SI2TParams(C.Structure):
     """include/msam_hip.h msam_si2t_t (the strict mode's fused image -> token block)."""
     _fields_ = [("keys", _vp), ("key_batch_stride", _i64), ("pos", _vp), ("wq", _vp), ("bq", _vp), ("tok_k", _vp), ("tok_v", _vp),
                 ("ld_tok", _i64), ("tok_batch_stride", _i64), ("wo", _vp), ("bo", _vp), ("ln_weight", _vp), ("ln_bias", _vp),
-                ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32), ("split16", _i32), ("wq_scale", _f32), ("wo_scale", _f32)]
+                ("ln_eps", _f32), ("denom", _f32), ("out", _vp), ("B", _i32), ("Tk", _i32), ("split16", _i32), ("wq_scale", _f32), ("wo_scale", _f32), ("wq_pairs", _vp), ("wo_pairs", _vp)]
 
 
 class ST2IParams(C.Structure):
@@ -242,6 +242,7 @@ _PROTOS = {
     "msam_strict_hyper_masks": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "msam_strict_upscale2": (_i32, [C.POINTER(SUp2Params), _vp]),
     "msam_split16_t2i_attention": (_i32, [C.POINTER(ST2IParams), _vp]),
+    "msam_split16_prepare_pairs": (_i32, [_vp, _i64, _i32, _f32, _i32, _vp, _vp]),
     "msam_strict_instance_norm": (_i32, [_vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _i64, _vp]),
     "msam_strict_resize_bilinear": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp]),
 }

@@ -1011,7 +1011,8 @@ struct SI2TArgs {
     int late_lo, late_hi, late_ticks;                   // workgroups [late_lo, late_hi) - the second one of every CU in the first dispatch round -
                                                         // start late_ticks x 10 ns late (de-phasing, see the kernel)
     float wq_scale, wo_scale;                           // SPLIT: powers of two applied to W_q / W_o before the fp16 split (undone on the accumulators)
-};
+    const unsigned short* wq16; const unsigned short* wo16;   // SPLIT, optional: the weights ALREADY as fp16 pairs in the kernel's LDS tile layout
+};                                                      // (msam_split16_prepare_pairs: row n = per k-tile of 32 [32 hi | 32 lo]; W_o with the permuted k order)
 
 // SPLIT: the split16 mode - both projections on fp16 operand pairs (3 x v_mfma_f32_32x32x16_f16 per product and 16-deep k-step); LDS rows hold
 // 32 hi | 32 lo halves as in sgemm_kernel<SPLIT>.  In projection 2 the attention's registers are still the B operand: k-step s of channel tile kt
@@ -1061,7 +1062,10 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
             const long o = (long)(srow + 32 * j) * C + kt * 32 + sc4;
             const float4 x = ld4(kin + o), pe = ld4(pin + o);
             rx[j] = make_float4(x.x + pe.x, x.y + pe.y, x.z + pe.z, x.w + pe.w);
-            rw[j] = ld4(a.wq + o);
+            if (SPLIT && a.wq16) {                      // prepared pairs: 16-byte pieces of the tile's 128-byte rows, copied as they are
+                const int idx = tid + 256 * j;
+                rw[j] = ld4((const float*)((const char*)a.wq16 + (long)(idx >> 3) * 1024 + kt * 128 + (idx & 7) * 16));
+            } else rw[j] = ld4(a.wq + o);
         }
     };
     auto store1 = [&]() {
@@ -1073,8 +1077,13 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
                 char* const pw_ = (char*)&Wt[(srow + 32 * j) * P] + sc4 * 2;
                 sp_split4(rx[j], 1.0f, h, l);
                 *(uint2*)px_ = h; *(uint2*)(px_ + 64) = l;
-                sp_split4(rw[j], a.wq_scale, h, l);
-                *(uint2*)pw_ = h; *(uint2*)(pw_ + 64) = l;
+                if (a.wq16) {
+                    const int idx = tid + 256 * j;
+                    *(float4*)((char*)Wt + (idx >> 3) * (P * 4) + (idx & 7) * 16) = rw[j];
+                } else {
+                    sp_split4(rw[j], a.wq_scale, h, l);
+                    *(uint2*)pw_ = h; *(uint2*)(pw_ + 64) = l;
+                }
             } else {
                 *(float4*)&Xs[(srow + 32 * j) * P + sc4] = rx[j];
                 *(float4*)&Wt[(srow + 32 * j) * P + sc4] = rw[j];
@@ -1086,12 +1095,20 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
     const float* const wop = a.wo + (long)tid * CI;
     auto load3 = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) rw[j] = ld4(wop + kt * 32 + 4 * j);
+        for (int j = 0; j < 8; ++j) {
+            if (SPLIT && a.wo16) {
+                const int idx = tid + 256 * j;
+                rw[j] = ld4((const float*)((const char*)a.wo16 + (long)(idx >> 3) * 512 + kt * 128 + (idx & 7) * 16));
+            } else rw[j] = ld4(wop + kt * 32 + 4 * j);
+        }
     };
     auto store3 = [&]() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if constexpr (SPLIT) {
+            if (SPLIT && a.wo16) {
+                const int idx = tid + 256 * j;
+                *(float4*)((char*)Wt + (idx >> 3) * (P * 4) + (idx & 7) * 16) = rw[j];
+            } else if constexpr (SPLIT) {
                 // channels 4 j .. 4 j + 3 of the k-tile: k-step j >> 2, lane half j & 1, first / second group of four (j >> 1) & 1
                 uint2 h, l;
                 char* const pw_ = (char*)&Wt[tid * P] + ((j >> 2) * 16 + (j & 1) * 8 + ((j >> 1) & 1) * 4) * 2;
@@ -1332,6 +1349,21 @@ __global__ __launch_bounds__(256, 2) void si2t_kernel(SI2TArgs a) {
         }
         si_wave_sync();
     }
+}
+
+// fp32 weight [N][K] (K % 32 == 0) -> fp16 pairs in the LDS tile layout of the split16 kernels: row n = K / 32 k-tiles of [32 hi | 32 lo] halves;
+// perm: the k order of si2t_kernel's second projection inside a k-tile (channels 4 j .. 4 j + 3 at (j >> 2) * 16 + (j & 1) * 8 + ((j >> 1) & 1) * 4)
+__global__ __launch_bounds__(256) void s16_prepare_pairs_kernel(const float* __restrict__ w, long N, int K, float scale, int perm, unsigned short* __restrict__ out) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int k4 = K / 4;
+    if (gid >= N * k4) return;
+    const long n = gid / k4;
+    const int c4 = (int)(gid - n * k4), kt = c4 >> 3, j = c4 & 7;
+    uint2 h, l;
+    sp_split4(ld4(w + n * K + c4 * 4), scale, h, l);
+    const int pos = perm ? (j >> 2) * 16 + (j & 1) * 8 + ((j >> 1) & 1) * 4 : j * 4;
+    unsigned short* dst = out + n * (2L * K) + kt * 64 + pos;
+    *(uint2*)dst = h; *(uint2*)(dst + 32) = l;
 }
 
 // ------------------------------------------------------------------------------------------------------------------ token -> image attention (split16)
@@ -2197,11 +2229,23 @@ extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
     SI2TArgs a{p->keys, p->key_batch_stride, p->pos, p->wq, p->bq, p->tok_k, p->tok_v, p->ld_tok, p->tok_batch_stride, p->wo, p->bo,
                p->ln_weight, p->ln_bias, p->ln_eps, p->denom, p->out, p->B, p->Tk, g_tune_si2t_dbg,
                strict_num_cus(), 2 * strict_num_cus(), g_tune_si2t_late_us * 100,
-               p->wq_scale > 0.f ? p->wq_scale : 1.f, p->wo_scale > 0.f ? p->wo_scale : 1.f};
+               p->wq_scale > 0.f ? p->wq_scale : 1.f, p->wo_scale > 0.f ? p->wo_scale : 1.f, (const unsigned short*)p->wq_pairs, (const unsigned short*)p->wo_pairs};
+    if (((uintptr_t)p->wq_pairs | (uintptr_t)p->wo_pairs) % 16 || ((p->wq_pairs || p->wo_pairs) && !p->split16)) {
+        msam_set_error("msam_strict_i2t_block: prepared weight pairs are 16-byte aligned and go with split16"); return 1;
+    }
     if (p->split16 < 0 || p->split16 > 1) { msam_set_error("msam_strict_i2t_block: split16 is 0 or 1"); return 1; }
     if (p->split16) hipLaunchKernelGGL(si2t_kernel<true>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(si2t_kernel<false>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     return msam_check_launch("strict_i2t_block");
+}
+
+extern "C" int msam_split16_prepare_pairs(const float* w, int64_t N, int32_t K, float scale, int32_t permute, void* out, void* stream) {
+    if (!w || !out || N <= 0 || K <= 0 || K % 32 || scale <= 0.f || ((uintptr_t)w | (uintptr_t)out) % 16) {
+        msam_set_error("msam_split16_prepare_pairs: K % 32 == 0, scale > 0, 16-byte aligned pointers"); return 1;
+    }
+    const long n = N * (K / 4);
+    hipLaunchKernelGGL(s16_prepare_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (long)N, K, scale, permute, (unsigned short*)out);
+    return msam_check_launch("split16_prepare_pairs");
 }
 
 extern "C" int msam_split16_t2i_attention(const msam_st2i_t* p, void* stream) {

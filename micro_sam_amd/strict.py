@@ -64,6 +64,7 @@ def _f32(t: torch.Tensor, dev) -> torch.Tensor:
 # scaled so that max |w| lies in (2^12, 2^13] (cached per weight tensor), activations enter as they are.
 _MODE = threading.local()
 _WSCALE = {}
+_WPAIRS = {}
 
 
 class split_mode:
@@ -99,8 +100,24 @@ def weight_scale(w: torch.Tensor) -> float:
     return sc
 
 
+def weight_pairs(w: torch.Tensor, permute: bool) -> torch.Tensor:
+    """``w`` [N, K] as fp16 pairs in the split16 kernels' LDS tile layout (msam_split16_prepare_pairs), scaled by ``weight_scale(w)``; cached with
+    the scale (the fused image -> token block copies these k-tiles instead of splitting the fp32 weights again in every workgroup)."""
+    key = (w.data_ptr(), w.numel(), bool(permute))
+    t = _WPAIRS.get(key)
+    if t is None:
+        t = torch.empty((w.shape[0], 2 * w.shape[1]), dtype=torch.float16, device=w.device)
+        _lib.check(_lib.load().msam_split16_prepare_pairs(w.data_ptr(), w.shape[0], w.shape[1], weight_scale(w), 1 if permute else 0, t.data_ptr(),
+                                                          _lib.stream_ptr()), "msam_split16_prepare_pairs")
+        if w.is_cuda:
+            torch.cuda.current_stream(w.device).synchronize()      # (once per weight: decode lanes on other streams read it too)
+        _WPAIRS[key] = t
+    return t
+
+
 def forget_scales() -> None:
     _WSCALE.clear()
+    _WPAIRS.clear()
 
 
 # ---------------------------------------------------------------------------------------------------- library calls
@@ -169,6 +186,7 @@ def i2t_block(keys: torch.Tensor, shared: bool, pos: torch.Tensor, wq, tok_k: to
     p.out, p.B, p.Tk = out.data_ptr(), B, Tk
     if split_active():
         p.split16, p.wq_scale, p.wo_scale = 1, weight_scale(wq[0]), weight_scale(wo[0])
+        p.wq_pairs, p.wo_pairs = weight_pairs(wq[0], False).data_ptr(), weight_pairs(wo[0], True).data_ptr()
     _lib.check(_lib.load().msam_strict_i2t_block(C.byref(p), _lib.stream_ptr()), "msam_strict_i2t_block")
     return out
 

@@ -116,7 +116,28 @@ def compare(sd, tile_seed: int = 1000, points_per_side: int = 16, device="cuda",
         emb_s = util.precompute_image_embeddings(predictor, tile, verbose=False)
         rs_, labs_, sc_ = product_report(emb_s)
         torch.cuda.synchronize()
-        extra[mode] = dict(short(rs_), labels=labs_, seconds=round(time.perf_counter() - t0, 2),
+        # the instance furthest from the reference: which pixels differ and how far from the threshold the REFERENCE's own logits are there
+        # ("fp32 against fp32 should not lose an instance by 0.5 % of its area unless ... sits on a threshold - say which")
+        worst = None
+        if rs_.get("worst"):
+            from micro_sam_amd import util as _u
+            from oracle import sam_ref as S
+            c = int(rs_["worst"][0]["candidate"])
+            pt = torch.as_tensor(ref["crop_list"][0]["points"][c]).float().reshape(1, 1, 2)
+            pt_in = torch.as_tensor(S.apply_coords(pt[0].numpy(), osz[0]), dtype=torch.float)[None]
+            lab1 = torch.ones(1, 1, dtype=torch.int)
+            m_ref, _, low_ref = S.predict_torch(sd, feats, isz[0], osz[0], pt_in, lab1, multimask_output=True, return_logits=True, precision="fp32")
+            _u.set_precomputed(predictor, emb_s)
+            m_own, _, low_own = predictor.predict_torch(pt_in.to(device), lab1.to(device), multimask_output=True, return_logits=True)
+            k = c % 3
+            a, b = m_ref[0, k].float(), m_own[0, k].float().cpu()
+            diff = (a > 0) != (b > 0)
+            worst = {"candidate": c, "iou": round(float(rs_["worst"][0]["iou"]), 5), "area": int(rs_["worst"][0]["area"]),
+                     "differing_px": int(diff.sum()), "max_abs_ref_logit_at_differing_px": float(a[diff].abs().max()) if bool(diff.any()) else 0.0,
+                     "max_abs_logit_diff_full_res": float((a - b).abs().max()), "max_abs_low_res_logit_diff": float((low_ref[0, k] - low_own[0, k].float().cpu()).abs().max()),
+                     "logit_scale": float(a.abs().max()),
+                     "px_within_1e-4_of_threshold_in_ref": int((a.abs() < 1e-4).sum())}
+        extra[mode] = dict(short(rs_), labels=labs_, seconds=round(time.perf_counter() - t0, 2), worst_instance=worst,
                            iou_pred_max_abs_diff=float(np.abs(rs["iou_pred"] - sc_["iou_pred"]).max()),
                            embedding_mean_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().mean()),
                            embedding_max_abs_err=float((torch.as_tensor(emb_s["features"]).float().cpu() - feats).abs().max()))
