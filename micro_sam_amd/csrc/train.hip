@@ -35,8 +35,36 @@ __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict
     for (int p = 0; p < nparts; ++p) s += parts[(long)p * n + i];
     out[i] = s;
 }
-// out[i] (+)= parts[0][i] + parts[1][i] + ... in that order
+// one level of the fixed-order tree: out[g][i] = parts[32 g][i] + parts[32 g + 1][i] + ... (32 consecutive parts, in that order)
+__global__ __launch_bounds__(256) void det_reduce_stage_kernel(const float* __restrict__ parts, int nparts, long n, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= n) return;
+    const int p0 = g * 32, p1 = p0 + 32 < nparts ? p0 + 32 : nparts;
+    float s = 0.f;
+    for (int p = p0; p < p1; ++p) s += parts[(long)p * n + i];
+    out[(long)g * n + i] = s;
+}
+// Groups of 32 parts are summed level by level (every level in a fixed order, every element by one thread: the same bits on every run) until at
+// most 32 parts are left; returns them.  (One thread per element walking 8192 parts - the bias column sums of a 524288-row product - took
+// milliseconds: the first form of round 6 cost fine-tuning 25 % of its step rate.)
+const float* msam_det_reduce_tree(const float* parts, int* nparts, long n, void* stream) {
+    if (*nparts <= 32) return parts;
+    const size_t half = (size_t)((*nparts + 31) / 32) * n;          // the first level's output is the largest
+    float* ws = msam_det_workspace(2 * half, 3);
+    if (!ws) return nullptr;
+    for (int level = 0; *nparts > 32; ++level) {
+        const int groups = (*nparts + 31) / 32;
+        float* dst = ws + (level & 1) * half;                       // levels alternate between the two halves: a level never writes where it reads
+        hipLaunchKernelGGL(det_reduce_stage_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)groups), dim3(256), 0, (hipStream_t)stream, parts, *nparts, n, dst);
+        parts = dst; *nparts = groups;
+    }
+    return parts;
+}
+// out[i] (+)= the sum of the parts, in a fixed order
 void msam_det_reduce(const float* parts, int nparts, long n, float* out, int accumulate, void* stream) {
+    parts = msam_det_reduce_tree(parts, &nparts, n, stream);
+    if (!parts) return;
     hipLaunchKernelGGL(det_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, nparts, n, out, accumulate);
 }
 
@@ -505,8 +533,11 @@ extern "C" int msam_layernorm_backward(const float* x, const float* weight, cons
     else if (dim == 768) hipLaunchKernelGGL(layernorm_bwd_kernel<12>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
     else if (dim == 1024) hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
     else hipLaunchKernelGGL(layernorm_bwd_kernel<20>, dim3(grid), dim3(256), 0, s, x, weight, dy, eps, (long)rows, dx, part);
-    // dweight / dbias += the workgroups' sums, in workgroup order (the pair [dw | db] of a workgroup is 2 dim contiguous floats)
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, s, (const float*)part, grid, dim, dweight, dbias);
+    // dweight / dbias += the workgroups' sums, in a fixed order (the pair [dw | db] of a workgroup is 2 dim contiguous floats)
+    int nparts = grid;
+    const float* red = msam_det_reduce_tree(part, &nparts, 2L * dim, stream);
+    if (!red) { msam_set_error("msam_layernorm_backward: cannot allocate the reduction workspace"); return 2; }
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, s, red, nparts, dim, dweight, dbias);
     return msam_check_launch("msam_layernorm_backward");
 }
 
