@@ -99,7 +99,7 @@ class SGemmParams(C.Structure):
     _fields_ = [("A", _vp), ("lda", _i64), ("A2", _vp), ("lda2", _i64), ("a2_rows", _i64), ("W", _vp), ("ldw", _i64),
                 ("M", _i64), ("N", _i32), ("K", _i32), ("bias", _vp), ("act", _i32), ("res", _vp), ("ldr", _i64), ("res_rows", _i64),
                 ("out", _vp), ("ldc", _i64), ("col_scale", _vp), ("col_shift", _vp), ("conv_h", _i32), ("conv_w", _i32), ("conv_c", _i32),
-                ("shuffle_h", _i32), ("shuffle_w", _i32), ("shuffle_c", _i32), ("a2_cols", _i32), ("split16", _i32), ("a_scale", _f32), ("w_scale", _f32)]
+                ("shuffle_h", _i32), ("shuffle_w", _i32), ("shuffle_c", _i32), ("a2_cols", _i32), ("split16", _i32), ("a_scale", _f32), ("w_scale", _f32), ("w_pairs", _vp)]
 
 
 class SI2TParams(C.Structure):

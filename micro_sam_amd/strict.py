@@ -47,6 +47,8 @@ FUSED_KV_SPLIT = True
 # split16 only: "tokens attend to the image" on a per-prompt stream (layer >= 1 and the final attention) as msam_split16_t2i_attention - the k / v
 # projections folded into the token side, online softmax, the stream read once (17 GB -> 4.3 GB per 1024-prompt layer); Tk <= 8
 FUSED_T2I = True
+# split16: weights handed to the product kernel as prepared fp16 pairs (cached per weight tensor) instead of being split again by every workgroup
+PREPARED_WEIGHTS = True
 # split16 only: the up-scaling's LayerNorm2d, GELU, second transposed convolution, GELU and hyper product as one launch
 # (msam_strict_upscale2: the 4.3 GB first-stage stream of a tile is read once; as four launches 34 GB cross HBM)
 FUSED_UP2 = True
@@ -146,6 +148,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.out, p.ldc = out.data_ptr(), out.stride(0)
     if split_active():
         p.split16, p.a_scale, p.w_scale = 1, 1.0, weight_scale(w)
+        if PREPARED_WEIGHTS and K % 32 == 0 and w.stride(0) == K and w.shape[0] * K >= 4096:
+            p.w_pairs = weight_pairs(w, False).data_ptr()
     _lib.check(_lib.load().msam_strict_gemm(C.byref(p), _lib.stream_ptr()), "msam_strict_gemm")
     return out
 
