@@ -20,6 +20,7 @@ import ctypes as C
 import math
 import os
 import threading
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -47,8 +48,11 @@ FUSED_KV_SPLIT = True
 # split16 only: "tokens attend to the image" on a per-prompt stream (layer >= 1 and the final attention) as msam_split16_t2i_attention - the k / v
 # projections folded into the token side, online softmax, the stream read once (17 GB -> 4.3 GB per 1024-prompt layer); Tk <= 8
 FUSED_T2I = True
-# split16: weights handed to the product kernel as prepared fp16 pairs (cached per weight tensor) instead of being split again by every workgroup
-PREPARED_WEIGHTS = True
+# split16: weights handed to the kernels as prepared fp16 pairs (cached per weight tensor) instead of being split again by every workgroup.
+# MEASURED SLOWER and therefore off: the product 221 -> 233 us (encoder qkv), 323 -> 448 us (second up-scaling shape: two 8-byte loads per
+# thread and k-tile instead of one 16-byte load), the fused image -> token block 3.50 -> 3.64 ms - these kernels are not bound by the
+# conversion's vector instructions (profiles/r06_experiments.md)
+PREPARED_WEIGHTS = False
 # split16 only: the up-scaling's LayerNorm2d, GELU, second transposed convolution, GELU and hyper product as one launch
 # (msam_strict_upscale2: the 4.3 GB first-stage stream of a tile is read once; as four launches 34 GB cross HBM)
 FUSED_UP2 = True
@@ -89,32 +93,39 @@ def split_active() -> bool:
     return getattr(_MODE, "split", False)
 
 
+def _cached(cache: dict, w: torch.Tensor, extra, make):
+    """Per-tensor cache keyed by the tensor OBJECT (a weak reference guards against another tensor that later lives at the same address:
+    a probe that allocates one random weight after another got the previous weight's pairs back - measured, round 6)."""
+    key = (id(w), extra)
+    hit = cache.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == (w.data_ptr(), w._version):
+        return hit[2]
+    val = make()
+    cache[key] = (weakref.ref(w), (w.data_ptr(), w._version), val)
+    return val
+
+
 def weight_scale(w: torch.Tensor) -> float:
     """Power of two that brings max |w| into (2^12, 2^13] (fp16: 10 bits of lo below 11 bits of hi stay normal numbers down to 2^-22 of
     the largest weight).  One device synchronisation per weight tensor, cached until the weights are rebuilt (``forget_scales``)."""
-    key = (w.data_ptr(), w.numel())
-    sc = _WSCALE.get(key)
-    if sc is None:
+    def make():
         m = float(w.abs().max())
         sc = 1.0 if not (m > 0.0 and math.isfinite(m)) else 2.0 ** (13 - math.ceil(math.log2(m)))
-        sc = min(max(sc, 2.0 ** -40), 2.0 ** 40)
-        _WSCALE[key] = sc
-    return sc
+        return min(max(sc, 2.0 ** -40), 2.0 ** 40)
+    return _cached(_WSCALE, w, None, make)
 
 
 def weight_pairs(w: torch.Tensor, permute: bool) -> torch.Tensor:
     """``w`` [N, K] as fp16 pairs in the split16 kernels' LDS tile layout (msam_split16_prepare_pairs), scaled by ``weight_scale(w)``; cached with
-    the scale (the fused image -> token block copies these k-tiles instead of splitting the fp32 weights again in every workgroup)."""
-    key = (w.data_ptr(), w.numel(), bool(permute))
-    t = _WPAIRS.get(key)
-    if t is None:
+    the scale."""
+    def make():
         t = torch.empty((w.shape[0], 2 * w.shape[1]), dtype=torch.float16, device=w.device)
         _lib.check(_lib.load().msam_split16_prepare_pairs(w.data_ptr(), w.shape[0], w.shape[1], weight_scale(w), 1 if permute else 0, t.data_ptr(),
                                                           _lib.stream_ptr()), "msam_split16_prepare_pairs")
         if w.is_cuda:
             torch.cuda.current_stream(w.device).synchronize()      # (once per weight: decode lanes on other streams read it too)
-        _WPAIRS[key] = t
-    return t
+        return t
+    return _cached(_WPAIRS, w, bool(permute), make)
 
 
 def forget_scales() -> None:
@@ -190,7 +201,8 @@ def i2t_block(keys: torch.Tensor, shared: bool, pos: torch.Tensor, wq, tok_k: to
     p.out, p.B, p.Tk = out.data_ptr(), B, Tk
     if split_active():
         p.split16, p.wq_scale, p.wo_scale = 1, weight_scale(wq[0]), weight_scale(wo[0])
-        p.wq_pairs, p.wo_pairs = weight_pairs(wq[0], False).data_ptr(), weight_pairs(wo[0], True).data_ptr()
+        if PREPARED_WEIGHTS:
+            p.wq_pairs, p.wo_pairs = weight_pairs(wq[0], False).data_ptr(), weight_pairs(wo[0], True).data_ptr()
     _lib.check(_lib.load().msam_strict_i2t_block(C.byref(p), _lib.stream_ptr()), "msam_strict_i2t_block")
     return out
 

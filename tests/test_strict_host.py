@@ -349,12 +349,15 @@ def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk, split):
     tok_k, tok_v = torch.randn(B * Tk, 128, generator=g), torch.randn(B * Tk, 128, generator=g)
     norm = (torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.2, 1e-5)
     strict.forget_scales()
+    prepared = strict.PREPARED_WEIGHTS
+    strict.PREPARED_WEIGHTS = split and Tk == 16        # one case through the prepared weight pairs (msam_split16_prepare_pairs; off by default)
     with strict.split_mode(split):                      # split: the split16 form of both (fp16 operand pairs; same tolerance: fp32-level accuracy)
         q = strict.gemm(keys, *wq, a2=pos, a2_rows=4096)
         att = strict.attention(q, tok_k, tok_v, B, 8, 4096, Tk, 16, 4.0, q_shared=shared)
         want = strict.gemm(att, *wo, res=keys, res_rows=4096 if shared else 0)
         strict.layer_norm(want, *norm, out=want)
         got = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
+    strict.PREPARED_WEIGHTS = prepared
     assert got.shape == want.shape and torch.isfinite(got).all()
     assert (got - want).abs().max().item() <= 2e-5, (got - want).abs().max().item()
     # fp64 statement of the step
