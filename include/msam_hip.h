@@ -728,6 +728,11 @@ int msam_strict_hyper_masks(const float* up, const float* hyper, int32_t hyper_l
  * softmax over the 4096 image tokens, U = P^T keys and out = Wv_h U + bv_h (sum_t p = 1) - exact algebra; the 4096 x 256 stream of a prompt is
  * read once.  keys fp32 [B][4096][256], pos [4096][256], q fp32 rows (b, j) [B * Tk][>= 128] (8 heads x 16 channels, ALREADY projected: q_proj
  * and its bias applied), wk / wv fp32 [128][256], bv [128]; Tk <= 8; out fp32 rows (b, j) [B * Tk][ldo]; workspace: B x 131072 bytes. */
+/* The same step as msam_strict_i2t_block in the split16 mode with BOTH projections folded into the prompt's <= 8 tokens (exact algebra):
+ * scores = (keys + pos) . (Wq_h^T k[j, h] / denom) + bq_h . k[j, h] / denom, out = sum_{h j} p (Wo[:, h] v[j, h]) + bo, then + residual, LayerNorm.
+ * A prompt's folded operands (128 KB of fp16 pairs) are staged once and its 4096 rows walked by one workgroup, instead of W_q / W_o streaming through
+ * LDS for every 128-row block.  Same argument struct (split16 / scales / pairs fields unused); Tk <= 8; workspace: B x 131328 bytes. */
+int msam_split16_i2t_block(const msam_si2t_t* p, void* workspace, int64_t workspace_bytes, void* stream);
 /* A weight matrix as fp16 pairs in the LDS tile layout of the split16 kernels: w fp32 [N][K] (K % 32 == 0), each value times `scale` (a power of two),
  * hi = fp16(x), lo = fp16(x - hi); out: N rows of K / 32 k-tiles of [32 hi | 32 lo] halves (2 K halves per row).  permute = 1: the k order of
  * msam_strict_i2t_block's second projection inside a k-tile. */

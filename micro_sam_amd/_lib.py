@@ -243,6 +243,7 @@ _PROTOS = {
     "msam_strict_upscale2": (_i32, [C.POINTER(SUp2Params), _vp]),
     "msam_split16_t2i_attention": (_i32, [C.POINTER(ST2IParams), _vp]),
     "msam_split16_prepare_pairs": (_i32, [_vp, _i64, _i32, _f32, _i32, _vp, _vp]),
+    "msam_split16_i2t_block": (_i32, [C.POINTER(SI2TParams), _vp, _i64, _vp]),
     "msam_strict_instance_norm": (_i32, [_vp, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _i64, _vp]),
     "msam_strict_resize_bilinear": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _i32, _f32, _f32, _i32, _vp, _vp]),
 }

@@ -1588,6 +1588,233 @@ __global__ __launch_bounds__(256, 1) void s16_t2i_kernel(ST2IArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------ image -> token block, folded (split16)
+// The same step as si2t_kernel - keys = norm4(keys + cross_attn_image_to_token(keys + pos, k, v)) - with BOTH projections folded into the <= 8 tokens
+// of a prompt (exact algebra, as the default mode's fold kernels do):
+//   score[t, h, j] = ((x_t + pos_t) Wq_h^T + bq_h) . k[j, h] / d = (x_t + pos_t) . G[h j] + beta[h j],   G[h j] = Wq_h^T k[j, h] / d,  beta = bq_h . k[j, h] / d
+//   out[t]         = sum_h (softmax_j score[t, h, :]) v[:, h] Wo[:, h]^T + bo = sum_{h j} p[t, h j] VO[h j] + bo,   VO[h j] = Wo[:, 16 h .. 16 h + 15] v[j, h]
+// si2t_kernel streams W_q and W_o (256 KB of fp32) through LDS for EVERY 128-row block - 0.77 MB of loads per block, and the launch is bound by that
+// (9 B per cycle and CU): here a prompt's two operands (G: 64 x 256, VO: 256 x 64, fp16 pairs, 128 KB) are staged ONCE per prompt and the workgroup
+// walks the prompt's 4096 rows.  One workgroup = one prompt, one wave per SIMD (512 registers), a wave owns 32-row tiles and exchanges nothing:
+//   S^T [64 hj x 32 rows] = G (A, LDS) x (x + pos)^T (B, straight from global memory: lane (row, half) loads the channels 16 s + 4 half + {0..3, 8..11} of
+//     k-step s - the SAME channels its accumulators of the second product hold, so the fp32 values stay in registers as the residual);
+//   the hj order puts the 8 tokens of a head into one lane's registers (rows {0-3, 8-11} | {16-19, 24-27} of a tile and lane half): softmax lane-local;
+//   out^T [256 ch x 32 rows] = VO^T (A, LDS) x P (B = the lane's own probabilities, registers 8 s .. 8 s + 7 of k-step s);
+//   + bias + residual, LayerNorm over the lane pair's 256 channels, rows leave through a wave-private LDS tile as whole 128-byte pieces.
+struct SI2FArgs {
+    const float* keys; long key_bs;                     // [B or 1][4096][256]
+    const float* pos;                                   // [4096][256]
+    const unsigned short* g;                            // [B][64 rho][512]: G as fp16 pairs in operand order ([s][half][e] hi | the same lo), scaled by I2F_GSCALE
+    const float* beta;                                  // [B][64 rho]: score constants (-3e38 for the unused token slots)
+    const unsigned short* vo;                           // [B][256 c][128]: VO^T as fp16 pairs in operand order ([s][half][j] hi | lo), scaled by I2F_VSCALE
+    const float* bo; const float* lnw; const float* lnb; float eps;
+    float* out;                                         // [B][4096][256] (may be keys when that is per prompt)
+    int B;
+};
+constexpr float I2F_GSCALE = 64.0f, I2F_VSCALE = 64.0f;
+constexpr int I2F_GP = 1040;                            // G row pitch in bytes (512 hi + 512 lo + 16)
+constexpr int I2F_VP = 272;                             // VO^T row pitch (128 hi + 128 lo + 16)
+constexpr int I2F_SP = 144;                             // staging tile row pitch (32 floats + 4)
+constexpr int I2F_LDS = 64 * I2F_GP + 256 * I2F_VP + 4 * 32 * I2F_SP + 4 * 256 * 4;     // 66 560 + 69 632 + 18 432 + 4 096 = 158 720 bytes
+
+// thread = (prompt, rho, four channel slots) for G / beta; (prompt, c_out, four hj slots) for VO
+__global__ __launch_bounds__(256) void s16_i2t_fold_kernel(const float* __restrict__ tk, const float* __restrict__ tv, long ldt, long tok_bs, int Tk,
+                                                           const float* __restrict__ wq, const float* __restrict__ bq, const float* __restrict__ wo, float denom,
+                                                           long B, unsigned short* __restrict__ g, float* __restrict__ beta, unsigned short* __restrict__ vo) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long ng = B * 64 * 64;
+    if (gid < ng) {
+        // G row rho of tile T: lane half (rho >> 2) & 1, register r = (rho & 3) + 4 (rho >> 3): head 4 T + 2 half + (r >> 3), token r & 7
+        const int q4 = (int)(gid & 63), row = (int)((gid >> 6) & 63);
+        const long p = gid >> 12;
+        const int T = row >> 5, rho = row & 31, half = (rho >> 2) & 1, r = (rho & 3) + 4 * (rho >> 3);
+        const int h = 4 * T + 2 * half + (r >> 3), j = r & 7;
+        // slot q4 of the row's 64: k-step s = q4 >> 2, lane half (q4 >> 1) & 1, first / second group: channels 16 s + 4 lh + 8 (q4 & 1) + 0..3
+        const int ks = q4 >> 2, lh = (q4 >> 1) & 1, c0 = 16 * ks + 4 * lh + 8 * (q4 & 1);
+        float4 acc = zero4();
+        if (j < Tk) {
+            const float* kp = tk + p * tok_bs + (long)j * ldt + h * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float kc = kp[c];
+                const float4 wv = ld4(wq + (long)(h * 16 + c) * 256 + c0);
+                acc.x = fmaf(kc, wv.x, acc.x); acc.y = fmaf(kc, wv.y, acc.y); acc.z = fmaf(kc, wv.z, acc.z); acc.w = fmaf(kc, wv.w, acc.w);
+            }
+            acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
+        }
+        uint2 hi, lo;
+        sp_split4(acc, I2F_GSCALE, hi, lo);
+        unsigned short* dst = g + (p * 64 + row) * 512 + ks * 16 + lh * 8 + (q4 & 1) * 4;
+        *(uint2*)dst = hi; *(uint2*)(dst + 256) = lo;
+        if (q4 == 0) {
+            float b = -3.0e38f;
+            if (j < Tk) {
+                const float* kp = tk + p * tok_bs + (long)j * ldt + h * 16;
+                b = 0.f;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) b = fmaf(kp[c], bq[h * 16 + c], b);
+                b /= denom;
+            }
+            beta[p * 64 + row] = b;
+        }
+        return;
+    }
+    const long gv = gid - ng;
+    if (gv >= B * 256 * 16) return;
+    // VO^T row c_out, slots [s][half][j]: head 4 (s >> 1) + 2 half + (s & 1); this thread: four consecutive j of one (s, half)
+    const int q4 = (int)(gv & 15), co = (int)((gv >> 4) & 255);
+    const long p = gv >> 12;
+    const int ks = q4 >> 2, lh = (q4 >> 1) & 1, j0 = (q4 & 1) * 4;
+    const int h = 4 * (ks >> 1) + 2 * lh + (ks & 1);
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = j0 + jj;
+        if (j < Tk) {
+            const float* vp = tv + p * tok_bs + (long)j * ldt + h * 16;
+            const float* wp = wo + (long)co * 128 + h * 16;
+            float a0 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a0 = fmaf(wp[c], vp[c], a0);
+            v4[jj] = a0;
+        }
+    }
+    uint2 hi, lo;
+    sp_split4(make_float4(v4[0], v4[1], v4[2], v4[3]), I2F_VSCALE, hi, lo);
+    unsigned short* dst = vo + (p * 256 + co) * 128 + ks * 16 + lh * 8 + j0;
+    *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
+}
+
+__global__ __launch_bounds__(256, 1) void s16_i2t_kernel(SI2FArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char i2_lds[];
+    unsigned char* const gs = i2_lds;                                   // G   [64][I2F_GP]
+    unsigned char* const vs = gs + 64 * I2F_GP;                         // VO^T [256][I2F_VP]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 31, lh = lane >> 5;
+    float* const st = (float*)(vs + 256 * I2F_VP + w * 32 * I2F_SP);    // wave-private [32][36] floats
+    float* const par = (float*)(vs + 256 * I2F_VP + 4 * 32 * I2F_SP);   // beta (64) | bo (256) | ln weight (256) | ln bias (256) (+ pad)
+    const long p = blockIdx.x;
+    // stage the prompt's operands: 16-byte pieces
+    {
+        const unsigned char* gsrc = (const unsigned char*)(a.g + p * 64 * 512);
+        for (int i = tid; i < 64 * 64; i += 256) *(uint4*)(gs + (i >> 6) * I2F_GP + (i & 63) * 16) = *(const uint4*)(gsrc + (long)i * 16);
+        const unsigned char* vsrc = (const unsigned char*)(a.vo + p * 256 * 128);
+        for (int i = tid; i < 256 * 16; i += 256) *(uint4*)(vs + (i >> 4) * I2F_VP + (i & 15) * 16) = *(const uint4*)(vsrc + (long)i * 16);
+        if (tid < 64) par[tid] = a.beta[p * 64 + tid];
+        par[64 + tid] = a.bo[tid]; par[320 + tid] = a.lnw[tid]; par[576 + tid] = a.lnb[tid];
+    }
+    __syncthreads();
+    const float* const xin = a.keys + p * a.key_bs;
+    float* const outp = a.out + p * 4096L * 256;
+#pragma unroll 1
+    for (int tile = w; tile < 128; tile += 4) {
+        const int t0 = tile * 32;
+        // the lane's half of its row: x[s][e] = channel 16 s + 4 lh + (e & 3) + 8 (e >> 2), kept for the residual
+        float x[16][8];
+        const float* xr = xin + (long)(t0 + li) * 256 + 4 * lh;
+        const float* pr = a.pos + (long)(t0 + li) * 256 + 4 * lh;
+#pragma unroll
+        for (int s8 = 0; s8 < 16; ++s8) {
+            const float4 u = ld4(xr + 16 * s8), v = ld4(xr + 16 * s8 + 8);
+            x[s8][0] = u.x; x[s8][1] = u.y; x[s8][2] = u.z; x[s8][3] = u.w; x[s8][4] = v.x; x[s8][5] = v.y; x[s8][6] = v.z; x[s8][7] = v.w;
+        }
+        // ---- S^T = G (x + pos)^T, two tiles of 32 hj; hi x hi and the cross terms in separate accumulators (s16_t2i_kernel)
+        f32x16_t sc[2], scl[2];
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[T][r] = 0.f; scl[T][r] = 0.f; }
+#pragma unroll
+        for (int s8 = 0; s8 < 16; ++s8) {
+            const float4 pu = ld4(pr + 16 * s8), pv = ld4(pr + 16 * s8 + 8);
+            float xp[8] = {x[s8][0] + pu.x, x[s8][1] + pu.y, x[s8][2] + pu.z, x[s8][3] + pu.w, x[s8][4] + pv.x, x[s8][5] + pv.y, x[s8][6] + pv.z, x[s8][7] + pv.w};
+            uint4 bh, bl;
+            sp_split8(xp, 1.0f, bh, bl);
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                const unsigned char* ga = gs + (T * 32 + li) * I2F_GP + s8 * 32 + lh * 16;
+                const uint4 ah = *(const uint4*)ga, al = *(const uint4*)(ga + 512);
+                scl[T] = mfma32h(al, bh, scl[T]); scl[T] = mfma32h(ah, bl, scl[T]); sc[T] = mfma32h(ah, bh, sc[T]);
+            }
+        }
+        // ---- softmax over the 8 tokens of each head (registers 8 g .. 8 g + 7 of a tile), in units of ln 2; probabilities -> B operands
+        uint4 ph[4], pl[4];
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float v[8];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * g + e, rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    v[e] = ((sc[T][r] + scl[T][r]) * (1.0f / I2F_GSCALE) + par[T * 32 + rho]) * SP_LOG2E;
+                    mx = fmaxf(mx, v[e]);
+                }
+                float l = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[e] = __builtin_amdgcn_exp2f(v[e] - mx); l += v[e]; }
+                const float il = SP_PSCALE / l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= il;
+                sp_split8(v, 1.0f, ph[2 * T + g], pl[2 * T + g]);
+            }
+        // ---- out^T = VO^T P
+        f32x16_t oa[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oa[ct][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const unsigned char* va = vs + (ct * 32 + li) * I2F_VP + ks * 32 + lh * 16;
+                const uint4 ah = *(const uint4*)va, al = *(const uint4*)(va + 128);
+                oa[ct] = mfma32h(al, ph[ks], oa[ct]); oa[ct] = mfma32h(ah, pl[ks], oa[ct]); oa[ct] = mfma32h(ah, ph[ks], oa[ct]);
+            }
+        // ---- (+ bias) + residual (the x registers: channel 32 ct + (r & 3) + 8 (r >> 2) + 4 lh = x[2 ct + (r >> 3)][(r & 3) + 4 ((r >> 2) & 1)]), LayerNorm
+        const float io = 1.0f / (I2F_VSCALE * SP_PSCALE);
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 bb = ld4(&par[64 + ct * 32 + 8 * g4 + 4 * lh]);
+                const int s8 = 2 * ct + (g4 >> 1), e0 = 4 * (g4 & 1);
+                oa[ct][4 * g4] = (oa[ct][4 * g4] * io + bb.x) + x[s8][e0]; oa[ct][4 * g4 + 1] = (oa[ct][4 * g4 + 1] * io + bb.y) + x[s8][e0 + 1];
+                oa[ct][4 * g4 + 2] = (oa[ct][4 * g4 + 2] * io + bb.z) + x[s8][e0 + 2]; oa[ct][4 * g4 + 3] = (oa[ct][4 * g4 + 3] * io + bb.w) + x[s8][e0 + 3];
+                sum += (oa[ct][4 * g4] + oa[ct][4 * g4 + 1]) + (oa[ct][4 * g4 + 2] + oa[ct][4 * g4 + 3]);
+            }
+        { const float o = __shfl_xor(sum, 32); sum = lh ? o + sum : sum + o; }
+        const float mean = sum * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = oa[ct][r] - mean; sq = fmaf(d, d, sq); }
+        { const float o = __shfl_xor(sq, 32); sq = lh ? o + sq : sq + o; }
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 256.0f) + a.eps);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int c = ct * 32 + 8 * g4 + 4 * lh;
+                const float4 ww = ld4(&par[320 + c]), bb = ld4(&par[576 + c]);
+                *(float4*)&st[li * (I2F_SP / 4) + 8 * g4 + 4 * lh] =
+                    make_float4((oa[ct][4 * g4] - mean) * rstd * ww.x + bb.x, (oa[ct][4 * g4 + 1] - mean) * rstd * ww.y + bb.y,
+                                (oa[ct][4 * g4 + 2] - mean) * rstd * ww.z + bb.z, (oa[ct][4 * g4 + 3] - mean) * rstd * ww.w + bb.w);
+            }
+            si_wave_sync();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lane + 64 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+                *(float4*)(outp + (long)(t0 + row) * 256 + ct * 32 + c4) = ld4(&st[row * (I2F_SP / 4) + c4]);
+            }
+            si_wave_sync();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ decoder attention
 // q [B, Nq, H*D] (row stride ldq, batch stride sqb; 0 = shared by every batch entry), k / v [B, Nk, H*D], out [B, Nq, H*D] rows ldo.
 // scores = (q . k) / denom (upstream: attn / sqrt(c_per_head)), softmax, @ v.
@@ -2250,6 +2477,36 @@ extern "C" int msam_strict_i2t_block(const msam_si2t_t* p, void* stream) {
     if (p->split16) hipLaunchKernelGGL(si2t_kernel<true>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(si2t_kernel<false>, dim3((unsigned)p->B * 32u), dim3(256), 0, (hipStream_t)stream, a);
     return msam_check_launch("strict_i2t_block");
+}
+
+extern "C" int msam_split16_i2t_block(const msam_si2t_t* p, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!p || !p->keys || !p->pos || !p->wq || !p->bq || !p->tok_k || !p->tok_v || !p->wo || !p->bo || !p->ln_weight || !p->ln_bias || !p->out || !workspace) {
+        msam_set_error("msam_split16_i2t_block: null argument"); return 1;
+    }
+    if (p->B <= 0 || p->Tk <= 0 || p->Tk > 8 || p->ld_tok < 128 || p->ld_tok % 4 || p->tok_batch_stride % 4 || p->key_batch_stride % 4 || p->denom <= 0.f ||
+        ((uintptr_t)p->keys | (uintptr_t)p->pos | (uintptr_t)p->wq | (uintptr_t)p->wo | (uintptr_t)p->out | (uintptr_t)workspace) % 16) {
+        msam_set_error("msam_split16_i2t_block: 1..8 tokens, strides in multiples of 4 floats, 16-byte aligned pointers"); return 1;
+    }
+    if (p->key_batch_stride == 0 && p->out == p->keys) { msam_set_error("msam_split16_i2t_block: a shared stream cannot be updated in place"); return 1; }
+    const size_t gb = (size_t)p->B * 64 * 512 * 2, vb = (size_t)p->B * 256 * 128 * 2, bb = (size_t)p->B * 64 * 4;
+    if ((size_t)workspace_bytes < gb + vb + bb) { msam_set_error("msam_split16_i2t_block: workspace of B x 131328 bytes needed"); return 1; }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* g = (unsigned short*)workspace;
+    unsigned short* vo = (unsigned short*)((char*)workspace + gb);
+    float* beta = (float*)((char*)workspace + gb + vb);
+    const long nf = (long)p->B * 64 * 64 + (long)p->B * 256 * 16;
+    hipLaunchKernelGGL(s16_i2t_fold_kernel, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, s, p->tok_k, p->tok_v, (long)p->ld_tok, (long)p->tok_batch_stride, p->Tk,
+                       p->wq, p->bq, p->wo, p->denom, (long)p->B, g, beta, vo);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)s16_i2t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I2F_LDS) != hipSuccess) {
+            msam_set_error("msam_split16_i2t_block: cannot raise the dynamic LDS limit"); return 2;
+        }
+        attr = true;
+    }
+    SI2FArgs a{p->keys, (long)p->key_batch_stride, p->pos, g, beta, vo, p->bo, p->ln_weight, p->ln_bias, p->ln_eps, p->out, p->B};
+    hipLaunchKernelGGL(s16_i2t_kernel, dim3((unsigned)p->B), dim3(256), I2F_LDS, s, a);
+    return msam_check_launch("split16_i2t_block");
 }
 
 extern "C" int msam_split16_prepare_pairs(const float* w, int64_t N, int32_t K, float scale, int32_t permute, void* out, void* stream) {

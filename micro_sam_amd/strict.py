@@ -48,6 +48,9 @@ FUSED_KV_SPLIT = True
 # split16 only: "tokens attend to the image" on a per-prompt stream (layer >= 1 and the final attention) as msam_split16_t2i_attention - the k / v
 # projections folded into the token side, online softmax, the stream read once (17 GB -> 4.3 GB per 1024-prompt layer); Tk <= 8
 FUSED_T2I = True
+# split16 only: the image -> token block with BOTH projections folded into the prompt's tokens (msam_split16_i2t_block: a prompt's operands staged once,
+# its 4096 rows walked by one workgroup) instead of si2t_kernel<SPLIT> (W_q / W_o streamed through LDS for every 128-row block); Tk <= 8
+FOLDED_I2T = True
 # split16: weights handed to the kernels as prepared fp16 pairs (cached per weight tensor) instead of being split again by every workgroup.
 # MEASURED SLOWER and therefore off: the product 221 -> 233 us (encoder qkv), 323 -> 448 us (second up-scaling shape: two 8-byte loads per
 # thread and k-tile instead of one 16-byte load), the fused image -> token block 3.50 -> 3.64 ms - these kernels are not bound by the
@@ -199,6 +202,10 @@ def i2t_block(keys: torch.Tensor, shared: bool, pos: torch.Tensor, wq, tok_k: to
     p.tok_k, p.tok_v, p.ld_tok, p.tok_batch_stride = tok_k.data_ptr(), tok_v.data_ptr(), tok_k.stride(0), Tk * tok_k.stride(0)
     p.ln_weight, p.ln_bias, p.ln_eps, p.denom = norm[0].data_ptr(), norm[1].data_ptr(), float(norm[2]), 4.0
     p.out, p.B, p.Tk = out.data_ptr(), B, Tk
+    if split_active() and FOLDED_I2T and Tk <= 8:
+        ws = torch.empty(B * 131328, dtype=torch.uint8, device=pos.device)
+        _lib.check(_lib.load().msam_split16_i2t_block(C.byref(p), ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "msam_split16_i2t_block")
+        return out
     if split_active():
         p.split16, p.wq_scale, p.wo_scale = 1, weight_scale(wq[0]), weight_scale(wo[0])
         if PREPARED_WEIGHTS:

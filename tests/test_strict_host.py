@@ -336,7 +336,7 @@ def test_strict_gemm_a2_cols_is_two_products(host_sam):
 
 
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("shared,Tk", [(True, 7), (False, 9), (False, 16)])
+@pytest.mark.parametrize("shared,Tk", [(True, 7), (False, 9), (False, 16), (False, 5)])
 def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk, split):
     """msam_strict_i2t_block (projection, 8-head attention over <= 16 tokens, projection + residual, LayerNorm in one launch, transposed
     MFMA orientation) against the same step as four launches; layer 0's shared stream and the in-place per-prompt stream."""
@@ -357,6 +357,14 @@ def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk, split):
         want = strict.gemm(att, *wo, res=keys, res_rows=4096 if shared else 0)
         strict.layer_norm(want, *norm, out=want)
         got = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
+        if split and Tk <= 8:
+            # Tk <= 8 went through the folded kernel (msam_split16_i2t_block); the un-folded one-launch form must agree with it
+            strict.FOLDED_I2T = False
+            try:
+                got_unfolded = strict.i2t_block(keys.clone(), shared, pos, wq, tok_k, tok_v, wo, norm, B, Tk)
+            finally:
+                strict.FOLDED_I2T = True
+            assert (got - got_unfolded).abs().max().item() <= 2e-5
     strict.PREPARED_WEIGHTS = prepared
     assert got.shape == want.shape and torch.isfinite(got).all()
     assert (got - want).abs().max().item() <= 2e-5, (got - want).abs().max().item()
