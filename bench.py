@@ -553,6 +553,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     if args.dry_run:
+        # launcher / rendezvous check without a GPU (gloo).  --workload config3 additionally walks the sharded bench path of BASELINE configs[2]:
+        # every rank's share of the 64-slice volume (slice seeds as bench_config3 draws them), the barrier, the MAX over ranks of the step time and
+        # rank 0's line - so that the config-3 launch is exercised before hardware sees it
+        shares = None
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -560,10 +564,30 @@ def main():
             dist.all_reduce(t)
             assert int(t.item()) == world
             dist.barrier()
+        if args.workload == "config3":
+            Z = args.slices
+            mine = torch.tensor([3000 + rank * Z + z for z in range(Z)], dtype=torch.int64)
+            elapsed = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)          # a stand-in step time: rank r "takes" r + 1 ms
+            if world > 1:
+                gathered = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(gathered, mine)
+                dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+                dist.barrier()
+            else:
+                gathered = [mine]
+            shares = [g.tolist() for g in gathered]
+            flat = [s_ for sh in shares for s_ in sh]
+            assert len(set(flat)) == world * Z and flat == list(range(3000, 3000 + world * Z)), flat       # disjoint, contiguous, in rank order
+            assert abs(float(elapsed.item()) - 0.001 * world) < 1e-12                                       # the slowest rank's time is the step's
+        if world > 1:
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "1024^2 tiles/s embed+AMG (vit_b bf16)", "value": 0.0, "unit": "tiles/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "dry_run": True}), flush=True)
+            rec = {"metric": "1024^2 tiles/s embed+AMG (vit_b bf16)", "value": 0.0, "unit": "tiles/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "dry_run": True}
+            if shares is not None:
+                rec.update({"metric": "2048^2 slices/s tiled embed+AMG (vit_l bf16), BASELINE configs[2] per-slice path", "unit": "slices/s",
+                            "config": {"workload": "config3", "slices_per_gpu": args.slices, "slice_seeds_per_rank": shares}})
+            print(json.dumps(rec), flush=True)
         return
 
     # distinct synthetic tiles per rank (seed = global tile index), generated before CUDA is initialised (fork pool)

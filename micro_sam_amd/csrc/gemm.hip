@@ -741,13 +741,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
             const int D = e.heads * e.head_dim;
             which = col / D; const int rem = col - which * D; head = rem / e.head_dim; d = rem - head * e.head_dim;
         }
+        // per-thread row bookkeeping ONCE per column half (round 6): a pass advances 16 rows - pointers advance by 16 rows' pitch, the q / k / v
+        // store's (image, token) pair by 16 tokens with a wrap - instead of a 64-bit multiplication and a division per pass (the epilogue was
+        // 30 - 45 % on top of a K = 768 k-loop, much of it this index arithmetic; full tiles only: the ragged last tile takes the clamped form)
+        const bool full_tile = m0 + G2 <= M;
+        const long step_r = 16L * e.ldr, step_c = 16L * e.ldc;
+        const float* rptr = e.resid_dtype == MSAM_F32 ? (const float*)e.resid + (long)(m0 + rg) * e.ldr + col : nullptr;
+        char* optr = e.out_mode == 0 ? (char*)e.out + ((long)(m0 + rg) * e.ldc + col) * (e.out_dtype == MSAM_F32 ? 4 : 2) : nullptr;
+        const long step_o = step_c * (e.out_dtype == MSAM_F32 ? 4 : 2);
+        int tb = 0, tt = 0;
+        if (e.out_mode != 0) { tb = (m0 + rg) / e.tokens; tt = (m0 + rg) - tb * e.tokens; }
         for (int grp = 0; grp < 2; ++grp) {              // residual rows of 8 passes at a time (register budget)
         float4 rt[8];
         if (e.resid_dtype == MSAM_F32) {
 #pragma unroll
             for (int ps = 0; ps < 8; ++ps) {
-                const int row = min(m0 + (grp * 8 + ps) * 16 + rg, M - 1);
-                rt[ps] = *(const float4*)((const float*)e.resid + (long)row * e.ldr + col);
+                if (full_tile) rt[ps] = *(const float4*)(rptr + (grp * 8 + ps) * step_r);
+                else {
+                    const int row = min(m0 + (grp * 8 + ps) * 16 + rg, M - 1);
+                    rt[ps] = *(const float4*)((const float*)e.resid + (long)row * e.ldr + col);
+                }
             }
         }
 #pragma unroll
@@ -773,22 +786,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const u16* __restrict__
             }
             if (row < M && !(e.dbg & 1)) {
                 if (e.out_mode == 0) {
+                    char* const op = optr + pass * step_o;          // == out + (row * ldc + col) elements
                     if (e.out_dtype == MSAM_F32) {
-                        *(float4*)((float*)e.out + (long)row * e.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
                         uint2 pk;
                         if constexpr (F16) { pk.x = pack2h(v[0], v[1]); pk.y = pack2h(v[2], v[3]); }
                         else { pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); }
-                        *(uint2*)((u16*)e.out + (long)row * e.ldc + col) = pk;
+                        *(uint2*)op = pk;
                     }
                 } else {
                     u16* dst = which == 0 ? e.q : (which == 1 ? e.k : e.v);
-                    const int b = row / e.tokens, t = row - b * e.tokens;
                     uint2 pk;
                     if constexpr (F16) { pk.x = pack2h(v[0], v[1]); pk.y = pack2h(v[2], v[3]); }
                     else { pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); }
-                    *(uint2*)(dst + ((long)(b * e.heads + head) * e.tokens + t) * e.head_dim + d) = pk;
+                    *(uint2*)(dst + ((long)(tb * e.heads + head) * e.tokens + tt) * e.head_dim + d) = pk;
                 }
+            }
+            if (e.out_mode != 0) {                                  // the next pass: 16 tokens further (a tile may straddle several images)
+                tt += 16;
+                while (tt >= e.tokens) { tt -= e.tokens; ++tb; }
             }
         }
         }

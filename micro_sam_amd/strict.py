@@ -61,6 +61,30 @@ PREPARED_WEIGHTS = False
 FUSED_UP2 = True
 
 
+# fp32 intermediates of one prompt in a decode pass: strict - the image-token stream, its k | v projections and the two up-scaling stages (30 MiB);
+# split16 - the stream, the first up-scaling stage and the fused kernels' workspaces (13 MiB live at the peak: keys + up1 + a k | v projection of layer 0)
+BYTES_PER_PROMPT = {False: 30 << 20, True: 13 << 20}
+
+
+def decode_chunk(dev, split: bool) -> int:
+    """Prompts per decode pass: the configured chunk (DECODE_CHUNK / DECODE_CHUNK_SPLIT), reduced to what fits HALF of the device memory that is free
+    or cached by torch right now (several decode lanes and the AMG state share the device) - a 1024-prompt pass needs 13 GiB (split16) / a 512-prompt
+    pass 15 GiB (strict), which a 288 GB MI355X holds many times over but a smaller or busier device may not (the chunk was a constant)."""
+    want = DECODE_CHUNK_SPLIT if split else DECODE_CHUNK
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        return want
+    free, _ = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)          # blocks torch holds but does not use
+    fit = int(free // 2 // BYTES_PER_PROMPT[bool(split)])
+    if fit >= want:
+        return want
+    if fit < 16:
+        raise RuntimeError(f"micro_sam_amd: {free / 2 ** 30:.1f} GiB of free device memory is not enough for a reference-formulation decode pass "
+                           f"(16 prompts need {16 * BYTES_PER_PROMPT[bool(split)] / 2 ** 30:.1f} GiB)")
+    return 1 << (fit.bit_length() - 1)                   # a power of two below the fit
+
+
 def _f32(t: torch.Tensor, dev) -> torch.Tensor:
     return t.detach().to(device=dev, dtype=torch.float32).contiguous()
 
@@ -407,7 +431,7 @@ class StrictDecoder:
                        "msam_strict_source")
         tokens_all = torch.cat([w["out_tokens"].unsqueeze(0).expand(P, -1, -1), sparse.to(device=dev, dtype=torch.float32)], dim=1).contiguous()
         # (split16: the second up-scaling stage is never materialised, so a whole 1024-prompt grid fits one pass - half the token-side launches)
-        chunk = DECODE_CHUNK_SPLIT if (split_active() and FUSED_UP2) else DECODE_CHUNK
+        chunk = decode_chunk(dev, split_active() and FUSED_UP2)
         for p0 in range(0, P, chunk):
             pc = min(chunk, P - p0)
             qpe = tokens_all[p0:p0 + pc].reshape(pc * Tk, PROMPT_DIM)                       # query_pe = the prompt tokens themselves

@@ -23,6 +23,18 @@ def test_gpus_2_spawns_two_ranks_dry_run():
     assert rec["n_gpus"] == 2 and rec["dry_run"] is True
 
 
+def test_config3_dry_run_shards_the_volume_over_two_ranks():
+    """bench.py --workload config3 --gpus 2 --dry-run (gloo): the sharded bench path of BASELINE configs[2] - disjoint contiguous slice shares in rank
+    order, barrier, MAX over ranks - before hardware sees it."""
+    r = _run(["--gpus", "2", "--dry-run", "--workload", "config3", "--slices", "4", "--steps", "1", "--warmup", "0"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["unit"] == "slices/s"
+    assert rec["config"]["slice_seeds_per_rank"] == [[3000, 3001, 3002, 3003], [3004, 3005, 3006, 3007]]
+
+
 def test_world_size_mismatch_fails_loudly():
     r = _run(["--gpus", "2", "--dry-run"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
