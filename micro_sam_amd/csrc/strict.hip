@@ -78,6 +78,7 @@ MSAM_DEVINL f32x2_t gelu_p8x2(f32x2_t x) {
 // anyway).  The argument's fp32 rounding (|score| log2 e <= ~30: 2e-6) is the error of the result, the size of the score's own error in this
 // mode; expf (the strict kernels) is ~15 instructions, and these kernels are bound by their vector instruction count.
 constexpr float SP_LOG2E = 1.4426950408889634f;
+template <bool FAST> MSAM_DEVINL float sp_exp(float x) { return FAST ? __builtin_amdgcn_exp2f(x) : expf(x); }      // FAST: x is in units of ln 2
 // (a.lo16 << 16) | b.lo16 and (a.hi16 << 16) | b.hi16 in one instruction
 #if defined(__HIPCC__)
 MSAM_DEVINL uint32_t sp_pack_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(a, b, 0x05040100u); }
@@ -610,11 +611,11 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kw = li + 63 - (jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-            if (kw >= 0 && kw < S) bw[(w * 32 + li) * SM_BWP + kw] = g[r];
+            if (kw >= 0 && kw < S) bw[(w * 32 + li) * SM_BWP + kw] = SPLIT ? g[r] * SP_LOG2E : g[r];      // (split16: every score term in units of ln 2)
         }
     }
 #pragma unroll
-    for (int d = 0; d < HH; ++d) qs[d] = qu[d] * a.scale;
+    for (int d = 0; d < HH; ++d) qs[d] = qu[d] * (SPLIT ? a.scale * SP_LOG2E : a.scale);
     constexpr int NKS = HH / 8;                          // SPLIT: k-steps of the S^T product (a lane half's HH channels, eight at a time)
     uint4 qsh[SPLIT ? NKS : 1], qsl[SPLIT ? NKS : 1];
     if constexpr (SPLIT) {
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
                     const float4 u = ld4(rp + d);
                     part = fmaf(qu[d], u.x, part); part = fmaf(qu[d + 1], u.y, part); part = fmaf(qu[d + 2], u.z, part); part = fmaf(qu[d + 3], u.w, part);
                 }
-                bhv = part + __shfl_xor(part, 32);
+                bhv = (part + __shfl_xor(part, 32)) * SP_LOG2E;
             }
         } else
         if ((t & 1) == 0) {                             // new key row kh = t / 2: the row term, under the MFMAs of this tile
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
         cm = fmaxf(cm, __shfl_xor(cm, 32));
         const float mn = fmaxf(m, cm);
         if (__ballot(mn > m)) {
-            const float alpha = expf(m - mn);
+            const float alpha = sp_exp<SPLIT>(m - mn);
             l *= alpha;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(256, 2) void srelpos_mfma_kernel(SRelArgs a) {
             m = mn;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sc[r] = expf(sc[r] - m); l += sc[r]; }
+        for (int r = 0; r < 16; ++r) { sc[r] = sp_exp<SPLIT>(sc[r] - m); l += sc[r]; }
         // O^T += V^T P^T
         if constexpr (SPLIT) {
             uint4 ph[2], pl[2];
@@ -836,11 +837,11 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kk = q0 + (SW_S - 1) - ((r & 3) + 8 * (r >> 2) + 4 * lh);
-            if (kk >= 0 && kk < SW_S) bt[qi * 32 + which * 16 + kk] = g[r];
+            if (kk >= 0 && kk < SW_S) bt[qi * 32 + which * 16 + kk] = SPLIT ? g[r] * SP_LOG2E : g[r];
         }
     }
 #pragma unroll
-    for (int d = 0; d < HH; ++d) qs[d] = qu[d] * a.scale;
+    for (int d = 0; d < HH; ++d) qs[d] = qu[d] * (SPLIT ? a.scale * SP_LOG2E : a.scale);
     constexpr int NKS = HH / 8;
     uint4 qsh[SPLIT ? NKS : 1], qsl[SPLIT ? NKS : 1];
     if constexpr (SPLIT) {
@@ -928,7 +929,7 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
         cm = fmaxf(cm, __shfl_xor(cm, 32));
         const float mn = fmaxf(m, cm);
         if (__ballot(mn > m)) {
-            const float alpha = expf(m - mn);
+            const float alpha = sp_exp<SPLIT>(m - mn);
             l *= alpha;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
@@ -939,7 +940,7 @@ __global__ __launch_bounds__(448) MSAM_WAVES_PER_EU(HD == 64 ? 4 : 3) void srelp
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            sc[r] = key < SW_T ? expf(sc[r] - m) : 0.f;
+            sc[r] = key < SW_T ? sp_exp<SPLIT>(sc[r] - m) : 0.f;
             l += sc[r];
         }
         if constexpr (SPLIT) {

@@ -398,10 +398,14 @@ def test_cast_transpose_kernel_source_on_the_cpu(emu_ct, M, K, ldx, src16):
     ref16 = x[:, :K].to(torch.bfloat16)
     out16 = np.full((M, K), 0x7fc0, np.uint16)
     outT = np.full((K, M), 0x7fc0, np.uint16)
+    # round 6: the kernel writes per-row-block column sums [ceil(M / 64)][K] (no atomics); the launcher adds the blocks in order (msam_det_reduce)
+    parts = np.full(((M + 63) // 64, K), np.nan, np.float32)
+    emu_ct.emu_cast_transpose(int(src16), _ptr(src), M, K, ldx, _ptr(out16), _ptr(outT), _ptr(parts))
     cs = np.zeros(K, np.float32)
-    emu_ct.emu_cast_transpose(int(src16), _ptr(src), M, K, ldx, _ptr(out16), _ptr(outT), _ptr(cs))
+    for blk in parts:
+        cs += blk
     want = ref16.view(torch.int16).numpy().view(np.uint16)
-    assert (out16 == want).all() and (outT == want.T).all()
+    assert np.isfinite(parts).all() and (out16 == want).all() and (outT == want.T).all()
     assert np.abs(cs - x[:, :K].float().sum(0).numpy()).max() <= 1e-4 * max(1.0, float(x.float().abs().sum(0).max()))
     # outputs are optional
     outT2 = np.zeros((K, M), np.uint16)

@@ -89,6 +89,9 @@ def main():
             f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {t / 1e6:.2f} | {t / 1e6 / tiles:.3f} | {float(r['AverageNs']) / 1e3:.1f} | "
                     f"{float(r['Percentage']):.1f} |\n")
         rf = bench["roofline"]
+        extras = os.path.join(GO, "final_bench_extras.json")          # round 6: the final line carries the dominant kernel only; the families are in the full tree
+        if os.path.exists(extras):
+            rf = json.load(open(extras)).get("roofline", rf)
         f.write("\nLive HIP-event measurement of the same kernels inside bench.py (timed region, unprofiled run):\n\n")
         f.write("| kernel family | bound | achieved | peak | frac | avg launch us |\n|---|---|---|---|---|---|\n")
         for k in [rf] + rf.get("other_kernels", []):
@@ -161,6 +164,28 @@ def main():
             for r in rows[:30]:
                 f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | "
                         f"{float(r['Percentage']):.1f} |\n")
+    # ---- the split16 precision mode's kernel table (tools/split16_probe.py under rocprofv3)
+    sp = glob.glob(os.path.join(GO, "final_split16_prof", "*", "*_kernel_stats.csv"))
+    if sp:
+        rows = list(csv.DictReader(open(max(sp, key=os.path.getmtime))))
+        probe = os.path.join(GO, "final_split16_probe.json")
+        per_tile = [int(r["Calls"]) for r in rows if "s16_up2_kernel" in r["Name"]]
+        tiles = per_tile[0] if per_tile else 12
+        total = sum(float(r["TotalDurationNs"]) for r in rows)
+        with open(os.path.join(OUT, f"{TAG}_split16_kernel_summary.md"), "w") as f:
+            f.write(f"# {TAG}: rocprofv3 kernel summary of `python tools/split16_probe.py --modes split16 --no-products --slice-tiles 0` (the split16 precision mode)\n\n")
+            f.write(stamp)
+            f.write("Command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_split16_prof -- python tools/split16_probe.py --modes split16 --no-products "
+                    f"--slice-tiles 0`: {tiles} tile decodes (1024 prompts each, one pass) and 22 tile encodes at batch 1 through the literal API loop.  GPU time {total / 1e6:.1f} ms.\n\n")
+            if os.path.exists(probe):
+                d = json.load(open(probe))
+                for k in ("split16", "strict"):
+                    if k in d:
+                        f.write(f"`{k}` (unprofiled probe of the same code): `" + json.dumps(d[k]) + "`\n\n")
+            f.write(f"| kernel | calls | total ms | ms / tile decode ({tiles}) | avg us | % |\n|---|---|---|---|---|---|\n")
+            for r in rows[:24]:
+                t = float(r["TotalDurationNs"])
+                f.write(f"| `{r['Name'][:100]}` | {r['Calls']} | {t / 1e6:.2f} | {t / 1e6 / tiles:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
     print("wrote", sorted(os.listdir(OUT)))
 
 
