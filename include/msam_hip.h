@@ -661,8 +661,8 @@ typedef struct {
     float a_scale, w_scale;              /* split16: powers of two (0 = 1.0) applied to A (+ A2) and W before the split so that the values sit inside
                                           * fp16's range (|x| < 65504, subnormals below 6e-5): W scaled to max |w| ~ 2^13, activations usually 1; undone exactly
                                           * in the epilogue */
-    const void* w_pairs;                 /* split16, optional: W already as fp16 pairs (msam_split16_prepare_pairs(W, N, K, w_scale, 0, ...); K % 32 == 0, ldw == K):
-                                          * the kernel copies the weight tiles instead of splitting them again in every workgroup */
+    const void* w_pairs;                 /* reserved, must be NULL (prepared weight pairs in the product kernel measured 5 - 40 % slower - even the unused branch
+                                          * cost the kernel 28 % - and were removed; msam_si2t_t.wq_pairs / wo_pairs remain) */
 } msam_sgemm_t;
 int msam_strict_gemm(const msam_sgemm_t* p, void* stream);
 /* torch.nn.LayerNorm / LayerNorm2d rows: x fp32 [rows, dim <= 1280] -> out fp32 (may be x), optional exact GELU afterwards;

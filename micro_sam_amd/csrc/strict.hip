@@ -141,7 +141,6 @@ struct SGemmArgs {
     int shuf_h, shuf_w, shuf_c;                          // 2 x 2 / stride 2 transposed convolution: column (ky*2+kx)*shuf_c + co of input pixel
     int a2_cols;                                         // A2 only for column tiles n0 < a2_cols (0: all)
     float a_scale, w_scale, out_scale;                   // SPLIT: powers of two applied to A / W before the fp16 split; out_scale = 1 / (a_scale w_scale)
-    const unsigned short* w16;                           // SPLIT, optional (K % 32 == 0): W already as fp16 pairs, row n = K / 32 k-tiles of [32 hi | 32 lo]
 };                                                       // (b, y, x) is stored at output pixel (b, 2y+ky, 2x+kx), channel co
 
 // The epilogue of one wave's 64 x 64 block.  D of a 32 x 32 MFMA tile: lane (col = l & 31, half = l >> 5), register r -> row
@@ -280,12 +279,7 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
                     v = ld4(ap[j] + k0);
                     if (A2) { const float4 t = ld4(a2p[j] + k0); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
                 }
-                if (SPLIT && a.w16) {
-                    // prepared pairs (msam_split16_prepare_pairs): the thread's four k values are 8 bytes of the k-tile's hi block and 8 of its lo block
-                    const unsigned short* q = a.w16 + (wp[j] - a.W - sc4) * 2 + (k0 >> 5) * 64 + sc4;      // (row n) * 2 K + k-tile * 64 + column
-                    const uint2 h = *(const uint2*)q, l = *(const uint2*)(q + 32);
-                    u = make_float4(__uint_as_float(h.x), __uint_as_float(h.y), __uint_as_float(l.x), __uint_as_float(l.y));
-                } else u = ld4(wp[j] + k0);
+                u = ld4(wp[j] + k0);
             }
             ra[j] = v; rw[j] = u;
         }
@@ -299,9 +293,7 @@ __global__ __launch_bounds__(256, IT == 1 ? 4 : NBUF == 1 ? 3 : 2) void sgemm_ke
                 char* const pw_ = (char*)&Ws[buf][(srow + 32 * j) * SG_PITCH] + sc4 * 2;
                 sp_split4(ra[j], a.a_scale, h, l);
                 *(uint2*)pa_ = h; *(uint2*)(pa_ + 64) = l;
-                if (a.w16) {
-                    h = uint2{__float_as_uint(rw[j].x), __float_as_uint(rw[j].y)}; l = uint2{__float_as_uint(rw[j].z), __float_as_uint(rw[j].w)};
-                } else sp_split4(rw[j], a.w_scale, h, l);
+                sp_split4(rw[j], a.w_scale, h, l);
                 *(uint2*)pw_ = h; *(uint2*)(pw_ + 64) = l;
             } else {
                 *(float4*)&As[buf][(srow + 32 * j) * SG_PITCH + sc4] = ra[j];
@@ -2321,11 +2313,7 @@ extern "C" int msam_strict_gemm(const msam_sgemm_t* p, void* stream) {
     if (p->split16 < 0 || p->split16 > 1 || p->a_scale < 0.f || p->w_scale < 0.f) { msam_set_error("msam_strict_gemm: split16 is 0 or 1, the scales are powers of two > 0 (0 = 1)"); return 1; }
     a.a_scale = p->a_scale > 0.f ? p->a_scale : 1.f; a.w_scale = p->w_scale > 0.f ? p->w_scale : 1.f;
     a.out_scale = 1.0f / (a.a_scale * a.w_scale);
-    a.w16 = nullptr;
-    if (p->w_pairs) {
-        if (!split || p->K % 32 || p->ldw != p->K || (uintptr_t)p->w_pairs % 16) { msam_set_error("msam_strict_gemm: w_pairs goes with split16, K % 32 == 0, ldw == K"); return 1; }
-        a.w16 = (const unsigned short*)p->w_pairs;
-    }
+    if (p->w_pairs) { msam_set_error("msam_strict_gemm: w_pairs is not supported (measured slower: profiles/r06_experiments.md); leave it NULL"); return 1; }
     long blocks = ((p->M + 127) / 128) * (long)((p->N + 127) / 128);
     if (blocks > 0x7fffffffL) { msam_set_error("msam_strict_gemm: too many tiles for one launch"); return 1; }
     const bool small = blocks < g_tune_sgemm_small_below;        // fewer 128 x 128 tiles than fill the chip: 64 x 64 tiles

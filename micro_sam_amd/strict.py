@@ -186,8 +186,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.out, p.ldc = out.data_ptr(), out.stride(0)
     if split_active():
         p.split16, p.a_scale, p.w_scale = 1, 1.0, weight_scale(w)
-        if PREPARED_WEIGHTS and K % 32 == 0 and w.stride(0) == K and w.shape[0] * K >= 4096:
-            p.w_pairs = weight_pairs(w, False).data_ptr()
     _lib.check(_lib.load().msam_strict_gemm(C.byref(p), _lib.stream_ptr()), "msam_strict_gemm")
     return out
 
