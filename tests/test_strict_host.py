@@ -286,8 +286,8 @@ def host_sam(lib):
         os.environ.pop("MSAM_EMU_CUS", None)
 
 
-@pytest.mark.parametrize("mode", ["strict", "split16"])
-@pytest.mark.parametrize("kind", ["points", "box+points", "mask"])
+# (the mask-prompt case runs in the strict mode only: the split16 mode shares its per-prompt-source path with "box+points" - CPU suite time)
+@pytest.mark.parametrize("kind,mode", [("points", "strict"), ("box+points", "strict"), ("mask", "strict"), ("points", "split16"), ("box+points", "split16")])
 def test_strict_decode_is_the_oracles_fp32_decoder(host_sam, kind, mode):
     """Sam.set_precision("strict") -> Sam.decode = the reference's un-folded two-way transformer + up-scaling in fp32: low-res logits and
     IoU predictions equal the oracle's fp32 path to fp32 rounding (the default 16-bit path: 3e-2 of the logit scale)."""
@@ -335,8 +335,7 @@ def test_strict_gemm_a2_cols_is_two_products(host_sam):
         strict.gemm(x, torch.cat([wk, wv]), torch.cat([bk, bv]), a2=pe, a2_rows=100, a2_cols=100)
 
 
-@pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("shared,Tk", [(True, 7), (False, 9), (False, 16), (False, 5)])
+@pytest.mark.parametrize("shared,Tk,split", [(True, 7, False), (False, 9, False), (False, 16, False), (True, 7, True), (False, 16, True), (False, 5, True)])
 def test_strict_i2t_block_is_the_four_launches(host_sam, shared, Tk, split):
     """msam_strict_i2t_block (projection, 8-head attention over <= 16 tokens, projection + residual, LayerNorm in one launch, transposed
     MFMA orientation) against the same step as four launches; layer 0's shared stream and the in-place per-prompt stream."""
@@ -462,7 +461,7 @@ def test_strict_encoder_is_the_oracles_fp32_encoder(host_sam):
     assert torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("Tk", [7, 8, 3])
+@pytest.mark.parametrize("Tk", [7, 3])
 def test_split16_t2i_attention_is_the_projections_and_the_attention(host_sam, Tk):
     """msam_split16_t2i_attention (k / v projections folded into the token side, one pass over the per-prompt image stream with an online
     softmax, MFMA products on fp16 pairs) against the unfused strict steps (k | v projection, sattn_long) and an fp64 statement."""
