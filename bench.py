@@ -131,7 +131,7 @@ def compact_line(out, extras_path=None):
     if isinstance(tp, dict):
         line["mask_iou_vs_ref_trained"] = ({"error": str(tp["error"])[:120]} if "error" in tp else
                                            {m: _parity_summary(tp[m]) for m in ("default", "split16", "strict") if m in tp})
-    for k in ("pcie_inclusive", "api_inclusive", "config3_side", "fp8_side"):
+    for k in ("pcie_inclusive", "api_inclusive", "config3_side", "split16_side", "fp8_side"):
         if k in out:
             line[k] = _side_summary(out[k])
     if isinstance(out.get("interactive_side"), dict):
@@ -406,6 +406,10 @@ def config_sides(timeout_s: float = 420.0, fp8: bool = False):
         except Exception as exc:
             return {"error": repr(exc)[:300]}
     sides = {}
+    # the parity-meeting precision mode in the headline's own harness: tiles resident in HBM, 3 decode lanes, label tiles in HBM (mask_iou_vs_ref_split16
+    # carries its parity; its tiles_per_s_segment_slices is the host-array-in / host-volume-out rate of the same mode)
+    sides["split16_side"] = run(["bench.py", "--precision", "split16", "--no-cpu-baseline", "--no-side", "--steps", "2", "--warmup", "1", "--tiles-per-step", "32",
+                                 "--distinct-tiles", "64", "--enc-batch", "8"], ("metric", "value", "unit", "ms_per_step"))
     if fp8:         # configs[4]: a precision mode, not a performance mode (rounds 3-5: 175 vs 170-174 tiles/s; DESIGN "fp8") - on request only
         sides["fp8_side"] = run(["bench.py", "--encoder-dtype", "fp8", "--no-cpu-baseline", "--no-side", "--steps", "3", "--warmup", "1"],
                                 ("metric", "value", "unit", "ms_per_step", "dtype"))
@@ -540,6 +544,9 @@ def main():
     ap.add_argument("--api-tiles", type=int, default=TILES_PER_STEP, help="tiles of the api_inclusive side measurement (default: one step's worth)")
     ap.add_argument("--no-config-sides", action="store_true",
                     help="skip config3_side / fp8_side / train_side (the other named configurations as short side runs, N = 1 only)")
+    ap.add_argument("--precision", choices=("default", "split16", "strict"), default="default",
+                    help="precision mode of the timed region (predictor.set_precision): default = the headline's 16-bit path; split16 / strict = the reference's "
+                         "formulation on fp16 operand pairs / fp32 kernels (side measurements: `split16_side` of the default run is this script with --precision split16)")
     ap.add_argument("--fp8-side", action="store_true", help="also run the fp8-encoder configuration (BASELINE configs[4]) as a side run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous check only: gloo, no GPU work, prints the JSON line with n_gpus = world size")
@@ -663,6 +670,9 @@ def main():
         pk = util.get_sam_model("vit_b", device=dev, state_dict=sd)
         pk.model.use_glds = args.glds
         lanes.append((pk, AutomaticMaskGenerator(pk, device_chunk=args.device_chunk), torch.cuda.Stream(device=dev)))
+    if args.precision != "default":
+        for pk_, _, _ in lanes:
+            pk_.set_precision(args.precision)
     pinned_labels = [None]
     # N > 1: the all_gather of step k's label tiles runs on a communication stream underneath step k + 1's encoder / decoder kernels
     # (8 ranks x 64 tiles: every rank receives 1.75 GiB per step - ~6 ms of a 370 ms step over xGMI - un-overlapped before round 4)
@@ -884,14 +894,18 @@ def main():
         out = {
             "metric": {"bf16": "1024^2 tiles/s embed+AMG (vit_b bf16)",
                        "fp16": "1024^2 tiles/s embed+AMG (vit_b, fp16 instead of bf16 operands in the image encoder: side measurement)",
-                       "fp8": "1024^2 tiles/s embed+AMG (vit_b fp8 encoder + bf16 decoder, BASELINE configs[4])"}[args.encoder_dtype],
+                       "fp8": "1024^2 tiles/s embed+AMG (vit_b fp8 encoder + bf16 decoder, BASELINE configs[4])"}[args.encoder_dtype] +
+                      ("" if args.precision == "default" else f" [precision mode {args.precision}: side measurement]"),
             "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp16": "fp16", "fp8": "fp8 projections + bf16"}[args.encoder_dtype] + " image encoder (patch embedding "
-                     "+ neck, 1.2 % of its flops, on hi+lo operand pairs of that type), " +
-                     ("fp16" if _lib.decoder_dtype() == torch.float16 else "bf16") + " mask decoder (16-bit MFMA operands, fp32 accumulation)",
+            "dtype": ({"bf16": "bf16", "fp16": "fp16", "fp8": "fp8 projections + bf16"}[args.encoder_dtype] + " image encoder (patch embedding "
+                      "+ neck, 1.2 % of its flops, on hi+lo operand pairs of that type), " +
+                      ("fp16" if _lib.decoder_dtype() == torch.float16 else "bf16") + " mask decoder (16-bit MFMA operands, fp32 accumulation)")
+                     if args.precision == "default" else
+                     {"split16": "fp16 operand pairs (hi + lo of every fp32 operand, 3 MFMAs of the 16-bit pipe per product, fp32 accumulation) in the reference's formulation",
+                      "strict": "f32 (f32-input MFMA) in the reference's formulation"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[1]: vit_b, 1024x1024 uint8 synthetic tiles, batched embedding precompute + "
                                    "AutomaticMaskGenerator (32x32 grid, multimask, default thresholds)",
