@@ -1,7 +1,7 @@
 """Per-instance mask parity on weights that are NOT hand-designed (VERDICT r3 item 1 ii): the "cells" checkpoint after 100 AdamW steps of
 this package's own trainer on synthetic cell tiles, everything trainable (tools/trained_parity.py = the checkpoint generator + seed).
-Fine-tuning on the GPU is not bit-reproducible, so both sides - the HIP path and the fp32 CPU oracle - are computed here from the same
-freshly trained state_dict; no golden exists for it.
+Since round 6 fine-tuning is bit-reproducible (no atomics in any gradient), so the numbers below belong to ONE checkpoint; both sides - the HIP path and
+the fp32 CPU oracle - are still computed here from the same freshly trained state_dict (a golden of the trained weights would be 360 MB).
 
 What the trained weights show (profiles/r04_experiments.md section 3): the designed checkpoint FLATTERS the 16-bit arithmetic - its weights
 are exactly representable structures, and 100 steps (0.2 % relative weight change) remove that.  With the token MLP on plain fp16 operands
@@ -42,22 +42,24 @@ def test_parity_on_a_fine_tuned_checkpoint():
             json.dump({"weights_moved": dist, "iou": pub, "labels": lab, **extra}, fh, indent=1)
     except OSError:
         pass
-    # measured (round 4).  At a FIXED predicted-IoU threshold of 0.5 (four runs, tools/trained_parity.py --thresholds 0.5 0.8): 170 - 191 instances,
-    # 70 - 75 % >= 0.999, 92 - 96 % >= 0.99, min 0.94 - 0.96, median 1.0 - and one run with 36 instances (58 %), the fine-tuned IoU head moves
-    # from run to run.  At the lower quartile of the reference's predictions (what this test uses; 0.29 in the measured run): 280 instances incl.
-    # the low-confidence ones, 49 % >= 0.999, 95 % >= 0.99, min 0.974, median 0.9989 (plain token MLP: 12 % / 39 % / min 0.68, median 0.985).
-    # Floors leave room for the run-to-run spread of the (non-reproducible) training: round 5 measured 34.6 - 64 % >= 0.999, 88.8 - 98 % >= 0.99,
-    # min 0.935 - 0.981, median 0.9979 - 0.9989 over six runs (the checkpoint differs every time: split-K atomics in the backward pass)
-    assert rep["n_instances"] >= 100
-    assert rep["frac_ge_0.999"] >= 0.25 and rep["frac_ge_0.99"] >= 0.80 and rep["median"] >= 0.995 and rep["min"] >= 0.85, pub
+    # Round 6: fine-tuning is reproducible (fixed-order reductions: csrc/train.hip msam_det_reduce), so these are the numbers of ONE checkpoint
+    # (tools/trained_parity.checkpoint_digest: cda477f0e44ce875 on every box measured) instead of floors under "six measured runs" (round 5: 0.25 / 0.80 / 0.85):
+    # default mode 234 instances at the lower quartile of the reference's predictions, 40.2 % >= 0.999, min 0.966, median 0.9985, keep set 226 / 8 / 4;
+    # split16 and strict: 233 / 234 >= 0.999 (min 0.9986), keep set 234 / 0 / 0.  Floors a few instances under the measured values (another ROCm build may
+    # round one instance across a threshold; the training itself does not move any more)
+    print("checkpoint digest:", TP.checkpoint_digest(sd))
+    assert rep["n_instances"] >= 200
+    assert rep["frac_ge_0.999"] >= 0.36 and rep["frac_ge_0.99"] >= 0.85 and rep["median"] >= 0.997 and rep["min"] >= 0.95, pub
     ks = rep["keep_set"]
     assert ks["ref_only"] + ks["test_only"] <= 0.06 * rep["n_instances"], ks
-    assert lab["foreground_agreement"] >= 0.99          # (0.9953 - 0.9999 over four runs: one kept mask more or less is its whole area)
-    # the strict precision mode on the same (trained) weights: the reference's result up to fp32 rounding
-    st = extra["strict"]
-    assert st["frac_ge_0.999"] >= 0.95 and st["min"] >= 0.99, st
-    assert st["keep_set"]["ref_only"] + st["keep_set"]["test_only"] <= 0.02 * st["n_instances"], st
-    assert st["embedding_max_abs_err"] <= 2e-3 and st["iou_pred_max_abs_diff"] <= 1e-4, st
+    assert lab["foreground_agreement"] >= 0.99
+    # the reference-formulation modes on the same (trained) weights: the north-star tolerance - split16 (fp16 operand pairs) and strict (fp32 kernels) alike
+    for mode in ("split16", "strict"):
+        st = extra[mode]
+        assert st["frac_ge_0.999"] >= 0.99 and st["min"] >= 0.995, (mode, st)
+        assert st["keep_set"]["ref_only"] + st["keep_set"]["test_only"] == 0, (mode, st)
+        assert st["embedding_max_abs_err"] <= 2e-3 and st["iou_pred_max_abs_diff"] <= 1e-4, (mode, st)
+    assert extra["split16"]["labels"]["identical_id_frac_foreground"] >= 0.999, extra["split16"]["labels"]
     abl = extra["ablations"]
     # the hi + lo token MLP is what carries it: the plain-operand decoder of rounds 1 - 3 on the same weights
     assert abl["product_with_plain_token_mlp"]["frac_ge_0.999"] <= rep["frac_ge_0.999"] - 0.15, abl
