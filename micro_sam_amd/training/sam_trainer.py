@@ -91,7 +91,7 @@ class GradientBuckets:
         self._handles = []
         for b in self.buckets:
             for q in b["params"]:
-                b["hooks"].append(q.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b)))
+                b["hooks"].append(q.register_post_accumulate_grad_hook(lambda _p, b=b: self._ready(b, _p)))
 
     def _make_bucket(self, params) -> None:
         dev = params[0].device
@@ -100,7 +100,7 @@ class GradientBuckets:
         for q in params:
             views.append(flat[off:off + q.numel()].view(q.shape))
             off += q.numel()
-        self.buckets.append({"flat": flat, "params": list(params), "views": views, "ready": 0, "launched": False, "hooks": []})
+        self.buckets.append({"flat": flat, "params": list(params), "views": views, "ready": 0, "launched": False, "hooks": [], "fired": set()})
         self._attach(self.buckets[-1])
 
     @staticmethod
@@ -113,6 +113,7 @@ class GradientBuckets:
         for b in self.buckets:
             b["flat"].zero_()
             b["ready"], b["launched"] = 0, False
+            b["fired"].clear()
             self._attach(b)
         self._handles = []
 
@@ -132,8 +133,10 @@ class GradientBuckets:
         else:
             self._handles.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True), b))
 
-    def _ready(self, b) -> None:
+    def _ready(self, b, p=None) -> None:
         b["ready"] += 1
+        if p is not None:
+            b["fired"].add(id(p))
         if b["ready"] == len(b["params"]) and not b["launched"]:
             self._launch(b)
 
@@ -150,6 +153,13 @@ class GradientBuckets:
             b["flat"].div_(self.world)
             total += b["flat"].numel() * 4
         self._handles = []
+        # a parameter that received no gradient in this step has `.grad = None` for the optimizer, as without the buckets (its zero-filled
+        # view would make AdamW decay it and move its moments: the overlapped and the plain path must produce the same update - ADVICE r5);
+        # `zero()` attaches the views again
+        for b in self.buckets:
+            for q in b["params"]:
+                if id(q) not in b["fired"]:
+                    q.grad = None
         return total
 
     def remove(self) -> None:
@@ -315,6 +325,9 @@ class SamTrainer:
                 self._buckets = GradientBuckets(params)
             self._buckets.zero()
         else:
+            if self._buckets is not None:            # overlap switched off after the buckets were made: their hooks must not reduce a second time
+                self._buckets.remove()
+                self._buckets = None
             self.optimizer.zero_grad()
         loss, mask_loss, iou_loss, model_iou, _ = self._interactive_train_iteration(x, y)
         loss.backward()

@@ -226,8 +226,11 @@ def _bucket_worker(rank, world, port, q):
         x, t = torch.randn(16, 6, generator=g), torch.randn(16, 3, generator=g)
         ((net(x) - t) ** 2).mean().backward()
         nbytes = buckets.finish()
-        out.append([p.grad.numpy().copy() for p in net.parameters()] + [unused.grad.numpy().copy()])
-        assert all(p.grad.data_ptr() == v.data_ptr() for b in buckets.buckets for p, v in zip(b["params"], b["views"]))
+        # (round 6) a parameter that got no gradient has `.grad = None` after finish() - the optimizer skips it as it does without the
+        # buckets (its zero-filled view would make AdamW decay it) - and gets its view back from zero()
+        assert unused.grad is None
+        out.append([p.grad.numpy().copy() for p in net.parameters()] + [np.zeros(5, np.float32)])
+        assert all(p.grad.data_ptr() == v.data_ptr() for b in buckets.buckets for p, v in zip(b["params"], b["views"]) if p is not unused)
     q.put((rank, out, nbytes, len(buckets.buckets)))
     dist.destroy_process_group()
 
