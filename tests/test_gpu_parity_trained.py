@@ -43,23 +43,25 @@ def test_parity_on_a_fine_tuned_checkpoint():
     except OSError:
         pass
     # Round 6: fine-tuning is reproducible (fixed-order reductions: csrc/train.hip msam_det_reduce), so these are the numbers of ONE checkpoint
-    # (tools/trained_parity.checkpoint_digest: cda477f0e44ce875 on every box measured) instead of floors under "six measured runs" (round 5: 0.25 / 0.80 / 0.85):
-    # default mode 234 instances at the lower quartile of the reference's predictions, 40.2 % >= 0.999, min 0.966, median 0.9985, keep set 226 / 8 / 4;
-    # split16 and strict: 233 / 234 >= 0.999 (min 0.9986), keep set 234 / 0 / 0.  Floors a few instances under the measured values (another ROCm build may
-    # round one instance across a threshold; the training itself does not move any more)
+    # (tools/trained_parity.checkpoint_digest: 48c4f8ff8fde61c7 with the 32-ary reduction tree; the first, sequential form of the round gave cda477f0e44ce875
+    # with 40 % / 99.6 %) instead of floors under "six measured runs" (round 5: 0.25 / 0.80 / 0.85).  Measured: default mode 265 instances at the lower quartile
+    # of the reference's predictions, 68.7 % >= 0.999, 95.1 % >= 0.99, min 0.944, median 1.0, keep set 261 / 4 / 7; split16 and strict: 265 / 265 >= 0.999
+    # (min 0.9994 / 0.9995: ONE pixel of a 1 700-pixel mask, where the reference's own logit is 0.009 / 0.021 of a scale of 113 and the two fp32 evaluations
+    # differ by 0.017 / 0.040 - `worst_instance`), keep set 265 / 0 / 0.  Floors a few instances under the measured values.
     print("checkpoint digest:", TP.checkpoint_digest(sd))
     assert rep["n_instances"] >= 200
-    assert rep["frac_ge_0.999"] >= 0.36 and rep["frac_ge_0.99"] >= 0.85 and rep["median"] >= 0.997 and rep["min"] >= 0.95, pub
+    assert rep["frac_ge_0.999"] >= 0.60 and rep["frac_ge_0.99"] >= 0.90 and rep["median"] >= 0.999 and rep["min"] >= 0.92, pub
     ks = rep["keep_set"]
     assert ks["ref_only"] + ks["test_only"] <= 0.06 * rep["n_instances"], ks
     assert lab["foreground_agreement"] >= 0.99
-    # the reference-formulation modes on the same (trained) weights: the north-star tolerance - split16 (fp16 operand pairs) and strict (fp32 kernels) alike
+    # the reference-formulation modes on the same (trained) weights: the north-star tolerance - split16 (fp16 operand pairs) and strict (fp32 kernels) alike.
+    # (Instance IDS are not asserted here: one pixel can split a component of these soft masks - 893 vs 896 components - and every later id shifts.)
     for mode in ("split16", "strict"):
         st = extra[mode]
         assert st["frac_ge_0.999"] >= 0.99 and st["min"] >= 0.995, (mode, st)
         assert st["keep_set"]["ref_only"] + st["keep_set"]["test_only"] == 0, (mode, st)
         assert st["embedding_max_abs_err"] <= 2e-3 and st["iou_pred_max_abs_diff"] <= 1e-4, (mode, st)
-    assert extra["split16"]["labels"]["identical_id_frac_foreground"] >= 0.999, extra["split16"]["labels"]
+        assert st["labels"]["foreground_agreement"] >= 0.9999, (mode, st["labels"])
     abl = extra["ablations"]
     # the hi + lo token MLP is what carries it: the plain-operand decoder of rounds 1 - 3 on the same weights
     assert abl["product_with_plain_token_mlp"]["frac_ge_0.999"] <= rep["frac_ge_0.999"] - 0.15, abl
