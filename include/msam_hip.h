@@ -485,6 +485,9 @@ typedef struct {
     int32_t use_glds;
     int32_t low_res_dtype;           /* type of the `low_res` buffer the msam_decoder_forward_* calls write: 0 / MSAM_F32 = fp32 (the
                                       * predict_torch contract), MSAM_F16 = fp16 (the AMG path: msam_postprocess_masks16 reads it back) */
+    int32_t up1_centred;             /* 1: up1_w / up1_b are CENTRED over the 64 output channels of every sub-pixel (rows sub*64 .. sub*64+63 of
+                                      * up1_w minus their mean row, up1_b minus its mean) - LayerNorm2d's mean is then zero by construction and the
+                                      * up-scaling kernel skips it (msam_upscale_fused_out, keys_blocked bit 1).  0: plain weights. */
 } msam_decoder_t;
 
 /* Per-image constants of the decoder (dense positional encoding etc.): computed once per model. */

@@ -90,7 +90,7 @@ class DecoderParams(C.Structure):
         ("layer", TwoWayLayer * 2), ("final_attn", AttnW), ("nf_w", _vp), ("nf_b", _vp),
         ("up1_w", _vp), ("up1_b", _vp), ("up_ln_w", _vp), ("up_ln_b", _vp), ("up2_w", _vp), ("up2_b", _vp),
         ("hyp_w", (_vp * 3) * 4), ("hyp_b", (_vp * 3) * 4), ("iou_w", _vp * 3), ("iou_b", _vp * 3),
-        ("use_glds", _i32), ("low_res_dtype", _i32),
+        ("use_glds", _i32), ("low_res_dtype", _i32), ("up1_centred", _i32),
     ]
 
 

@@ -782,7 +782,7 @@ extern "C" int msam_fold_attn_set_dma(int32_t on) { g_fold_attn_dma = on; return
 //   "i2t_wg_per_cu"   workgroups per CU of the token-owner kernel's persistent grid (default 2)
 //   "dec_chain"       1 = decoder_run chains layer 0 into layer 1 on a shared source (decfold_tok.hip), 0 = one kernel per stage
 //   "dec_chain_min_p" smallest number of prompts for which it does (default 128)
-extern int g_tune_i2t_wg_per_cu, g_tune_chain_variant, g_tune_chain_tmask, g_tune_up_gelu16, g_tune_up_ln_two_pass;
+extern int g_tune_i2t_wg_per_cu, g_tune_chain_variant, g_tune_chain_tmask, g_tune_up_gelu16, g_tune_up_ln_two_pass, g_tune_up_centred;
 void msam_gemm_set_dbg(int v);
 void msam_gemm_set_gw(int delay, int cls);
 void msam_gemm_set_g3(int delay);
@@ -800,6 +800,7 @@ extern "C" int msam_tune_set(const char* key, int32_t value) {
     else if (k == "chain_tmask") g_tune_chain_tmask = value;
     else if (k == "up_gelu16") g_tune_up_gelu16 = value;
     else if (k == "up_ln_two_pass") g_tune_up_ln_two_pass = value;
+    else if (k == "up_centred") g_tune_up_centred = value;
     else if (k == "gemm_dbg") msam_gemm_set_dbg(value);
     else if (k == "gw_delay") msam_gemm_set_gw(value, -1);
     else if (k == "gw_class") msam_gemm_set_gw(-2, value);

@@ -989,7 +989,7 @@ int decoder_run(const msam_decoder_t* dec, const msam_mask_prompt_t* mask_w, con
 
     // up-scaling (ConvT1 + LayerNorm2d + GELU + ConvT2 + GELU) and hyper-network product in one pass over the stream
     // (dec->low_res_dtype == MSAM_F16: `low_res` is an fp16 buffer - the AMG path, whose post-processing reads fp16 back)
-    CHECK(msam_upscale_fused_out(w.keys, chain ? 1 : 0, P, dec->up1_w, dec->up1_b, dec->up_ln_w, dec->up_ln_b, 1e-6f, dec->up2_w,
+    CHECK(msam_upscale_fused_out(w.keys, (chain ? 1 : 0) | (dec->up1_centred ? 2 : 0), P, dec->up1_w, dec->up1_b, dec->up_ln_w, dec->up_ln_b, 1e-6f, dec->up2_w,
                                  dec->up2_b, w.hyper, 128, mask0, nmask, low_res, dec->low_res_dtype == MSAM_F16 ? MSAM_F16 : MSAM_F32,
                                  cx.s));
 #undef CHECK

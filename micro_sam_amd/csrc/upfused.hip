@@ -25,6 +25,7 @@ constexpr int T = 4096, C = 256, TK = 16, NTHR = 256;
 int g_uf_prio = 1;                    // tuning hook msam_upscale_set_prio
 }
 int g_tune_up_gelu16 = 1;             // msam_tune_set "up_gelu16": GELUs in packed fp16 arithmetic (fp16 decoder build; 0 = packed fp32)
+int g_tune_up_centred = 1;            // msam_tune_set "up_centred": 0 = centred weights run through the general kernel (which computes their mean of ~0): the A/B of CEN
 int g_tune_up_ln_two_pass = 0;        // msam_tune_set "up_ln_two_pass": 1 = centred two-pass LayerNorm2d variance (default: one pass, E[u^2] - mean^2)
 namespace {
 constexpr int SUB_BYTES = TK * 64 + 64, XT_BYTES = 8 * SUB_BYTES;     // k-step sub-tiles [32 tokens][64 B] (+ pad), see decfold.hip
@@ -41,6 +42,7 @@ struct UpArgs {
     void* out;                           // fp32 or (out16) fp16 [P, nmask, 256, 256]
     int out16;
     int blocked;                         // keys in the blocked layout of decfold_tok.hip ([16-token tile][k-step][lane][8]) instead of row-major
+    int centred;                         // w1 / b1 are centred over the 64 channels of every sub-pixel (see CEN)
 };
 
 // sum over the wave's four 16-lane rows, in every lane, without the LDS crossbar: v_permlane16_swap exchanges the odd rows of its first
@@ -141,11 +143,42 @@ MSAM_DEVINL void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g0
 // LDS: tile q + 1 is read from one staging buffer while tile q + 2 is written into the other (free since the previous barrier).
 // The second half of the grid starts ~700 cycles late: co-resident workgroups (i, i + grid / 2) then run a quarter tile period out of
 // phase instead of competing for the same pipe in the same stage.
-template <int UF_PRIO, int G16, int LN2P = 0>
+// round 6: phase A's LDS operands are read AHEAD of their use - the B fragment of k-step ks + 2 behind the MFMAs of k-step ks (two register sets
+// by turns), the LayerNorm affine parameters of row tile rt + 1 in front of the GELUs of row tile rt, the next tile's first two fragments and its
+// stage-1 bias right behind the barrier.  The ISA of the round-5 form had `ds_read_b128; s_waitcnt lgkmcnt(0)` in front of every MFMA group and
+// every affine step: 16 exposed LDS round trips per tile and wave (SQ_WAIT_INST_ANY 30 % of the wave cycles).  Plain loads do not stay ahead - the
+// optimizer sinks them back to their first use, and the compiler's lgkmcnt counts cannot see an inline-assembly read next to them - so EVERY LDS read
+// of phase A is inline assembly with its own `s_waitcnt lgkmcnt(n)`: LDS operations return in order, n = the number of younger reads that may still
+// be in flight (derivation next to each wait; a compiler-issued LDS operation in between only makes a wait stricter; there is no scalar memory load
+// in the loop - those return out of order and would void the counts: tests/test_upfused_isa.py checks the ISA for it).
+// Same arithmetic in the same order: bit-identical to round 5 (tools/uf_lab.py "R_lds_behind" is the A/B).
+// 16 VGPRs for it: the stage-2 bias and the prompt's hyper weights (hi, lo) live in LDS between the tiles' phases B (4 more reads per tile).
+// CEN (round 6): the caller hands over CENTRED first-layer weights and bias (every sub-pixel's 64 rows of w1 minus their mean row, b1 minus its mean:
+// msam_upscale_fused_out, `keys_blocked` bit 1) - the 64 channels of a (token, sub-pixel) then have mean zero by construction, LayerNorm2d's mean, its
+// exchange and the centring (16 + 6 + 8 vector instructions per tile and wave) are not computed and the variance is the plain mean of squares
+// (the two-pass value).  The other instantiations accept such weights too (they compute a mean of ~0).
+template <int UF_PRIO, int G16, int LN2P = 0, int CEN = 0>
 __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
+#define UF_LDS_AHEAD 1
+#if defined(__HIP_DEVICE_COMPILE__) && UF_LDS_AHEAD
+#define UF_R16(dst_, base_, imm_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(base_), "n"(imm_))      // base_: LDS byte address (one VGPR), imm_: constant < 65536
+#define UF_LDS_ADDR(ptr_) ((uint32_t)(size_t)(ptr_))
+#define UF_ARRIVED2(n_, x0_, tok_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(x0_), "+v"(tok_))
+#define UF_ARRIVED4(n_, x0_, x1_, x2_, tok_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(x0_), "+v"(x1_), "+v"(x2_), "+v"(tok_))
+#define UF_ARRIVED6(n_, x0_, x1_, x2_, x3_, x4_, tok_) asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(x0_), "+v"(x1_), "+v"(x2_), "+v"(x3_), "+v"(x4_), "+v"(tok_))
+#else                               // (host build of the kernel source: the reads complete at once)
+#define UF_R16(dst_, base_, imm_) dst_ = *(const f32x4_t*)((base_) + (imm_))
+#define UF_LDS_ADDR(ptr_) ((const unsigned char*)(ptr_))
+#define UF_ARRIVED2(n_, x0_, tok_) (void)0
+#define UF_ARRIVED4(n_, x0_, x1_, x2_, tok_) (void)0
+#define UF_ARRIVED6(n_, x0_, x1_, x2_, x3_, x4_, tok_) (void)0
+#endif
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
     __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
     __shared__ __attribute__((aligned(16))) float prm[256 + 64 + 64 + 32];       // b1, ln_w, ln_b, b2
+#if UF_LDS_AHEAD
+    __shared__ __attribute__((aligned(16))) uint4 hyp[4][2][64];                 // per wave: hyper weights of the current prompt as MFMA A fragments (hi, lo)
+#endif
     unsigned char* const W2L = lds + 2 * XT_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fg = lane >> 4;
     const int sub = w;
@@ -201,12 +234,14 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     const int w2off = fr * 128;
     const int w2sw = (fr >> 1) & 7;
     const float* const b1p = prm + sub * 64 + fg * 4;                             // + 16 rt: the stage-1 bias of rows 16 rt + 4 fg ..
+#if !UF_LDS_AHEAD
     uint4 hh = make_uint4(0, 0, 0, 0), hl = hh;
     f32x4_t b2a, b2b;                                                             // stage-2 bias: the initial accumulator of every chain
     {
         const float4 ba = *(const float4*)(a.b2 + fg * 4), bb = *(const float4*)(a.b2 + 16 + fg * 4);
         b2a = f32x4_t{ba.x, ba.y, ba.z, ba.w}; b2b = f32x4_t{bb.x, bb.y, bb.z, bb.w};
     }
+#endif
     wait_vmem_all();
 
     // stage 1 of one tile, alone (prologue only)
@@ -232,6 +267,17 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
     __syncthreads();
     stage1(lds, ua);
     __syncthreads();                                         // every wave is done with buffer 0 before tile 2 goes there
+#if UF_LDS_AHEAD
+    f32x4_t kfa, kfb;                                        // B fragments of the even / odd k-steps (bit patterns of 8 fp16)
+#define UF_NEXT_TILE(B_, u_)                                                                       \
+    do {                                                                                           \
+        UF_R16(u_[0], b1a, 0); UF_R16(u_[1], b1a, 64); UF_R16(u_[2], b1a, 128); UF_R16(u_[3], b1a, 192); \
+        const auto bn_ = UF_LDS_ADDR((B_) + boff);                                                 \
+        UF_R16(kfa, bn_, 0); UF_R16(kfb, bn_, SUB_BYTES);                                          \
+    } while (0)
+    const auto b1a = UF_LDS_ADDR(b1p), prma = UF_LDS_ADDR(&prm[256 + fg * 4]);
+    UF_NEXT_TILE(lds + XT_BYTES, ub);
+#endif
 
     if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) __builtin_amdgcn_s_sleep(11);        // ~700 cycles: see the note above the kernel
     int q = 0;
@@ -247,45 +293,85 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
                 h8[0] = x0.x; h8[1] = x0.y; h8[2] = x0.z; h8[3] = x0.w; h8[4] = x1.x; h8[5] = x1.y; h8[6] = x1.z; h8[7] = x1.w;
             }
             wait_vmem_all();
+#if UF_LDS_AHEAD
+            uint4 hh, hl;
+#endif
             hh = make_uint4(pack2h(h8[0], h8[1]), pack2h(h8[2], h8[3]), pack2h(h8[4], h8[5]), pack2h(h8[6], h8[7]));
             const uint32_t hw_[4] = {hh.x, hh.y, hh.z, hh.w};
             float l8[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { l8[2 * i] = h8[2 * i] - h2f(hw_[i] & 0xffff); l8[2 * i + 1] = h8[2 * i + 1] - h2f(hw_[i] >> 16); }
             hl = make_uint4(pack2h(l8[0], l8[1]), pack2h(l8[2], l8[3]), pack2h(l8[4], l8[5]), pack2h(l8[6], l8[7]));
+#if UF_LDS_AHEAD
+            hyp[w][0][lane] = hh; hyp[w][1][lane] = hl;
+#endif
         }
         // ---- phase A: stage 1 of tile q + 1 (staging buffer (q + 1) & 1) under LayerNorm2d + GELU of tile q
         const unsigned char* Bn = lds + ((q + 1) & 1) * XT_BYTES;
+#if UF_LDS_AHEAD
+        const auto bna = UF_LDS_ADDR(Bn + boff);
+#endif
+#if !UF_LDS_AHEAD
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) un[rt] = *(const f32x4_t*)(b1p + rt * 16);
+#endif
         // (the empty asm makes the k-step's operand fragment depend on `tok_`, the last value of the VALU chunk in front of it: instruction
         //  selection cannot move the MFMA group above that chunk; the sched_barrier keeps the machine scheduler from undoing the placement)
-#define UF_S1(ks_, tok_)                                                                           \
+#if UF_LDS_AHEAD
+        // k-step ks_: its fragment has arrived once at most n_ younger reads are in flight; the MFMA group; the fragment of k-step ks_ + 2 into the same registers
+#define UF_MF(ks_)                                                                                 \
+        do {                                                                                       \
+            f32x4_t& kf_ = ((ks_) & 1) ? kfb : kfa;                                                \
+            const uint4 kw_ = make_uint4(__float_as_uint(kf_[0]), __float_as_uint(kf_[1]), __float_as_uint(kf_[2]), __float_as_uint(kf_[3])); \
+            _Pragma("unroll") for (int rt_ = 0; rt_ < 4; ++rt_) un[rt_] = mfma16d(w1f[rt_][ks_], kw_, un[rt_]); \
+            if ((ks_) + 2 < 8) UF_R16(kf_, bna, (((ks_) + 2) & 7) * SUB_BYTES);                    \
+        } while (0)
+#define UF_S1(ks_, tok_, n_)                                                                       \
+        do {                                                                                       \
+            if ((ks_) & 1) UF_ARRIVED2(n_, kfb, tok_); else UF_ARRIVED2(n_, kfa, tok_);            \
+            UF_MF(ks_);                                                                            \
+        } while (0)
+#else
+#define UF_MF(ks_) (void)0
+#define UF_S1(ks_, tok_, n_) UF_S1_(ks_, tok_)
+#define UF_S1_(ks_, tok_)                                                                          \
         do {                                                                                       \
             uint4 kf_ = *(const uint4*)(Bn + boff + (ks_) * SUB_BYTES);                            \
             asm volatile("" : "+v"(kf_.x), "+v"(tok_));                                            \
             _Pragma("unroll") for (int rt_ = 0; rt_ < 4; ++rt_) un[rt_] = mfma16d(w1f[rt_][ks_], kf_, un[rt_]); \
         } while (0)
+#endif
         // (sched_barrier: the MFMA group of a k-step and the VALU chunk next to it stay together - the scheduler otherwise moves the
         //  GELUs behind all 32 MFMAs, which is the shipped order again)
-        { int first_ = 0; UF_S1(0, first_); }
+#if UF_LDS_AHEAD
+        // in flight here, oldest first: bias x 4, kfa (k-step 0), kfb (1) [UF_NEXT_TILE behind the last barrier]: the bias and kfa are there with <= 1 left
+        { int first_ = 0; UF_ARRIVED6(1, un[0], un[1], un[2], un[3], kfa, first_); }
+        UF_MF(0);                                         // + kfa (2)
+        f32x4_t gq[2], bq[2];                             // affine parameters, two register sets by turns
+        UF_R16(gq[0], prma, 0); UF_R16(bq[0], prma, 256);
+#else
+        { int first_ = 0; UF_S1(0, first_, 0); }
+#endif
         // LayerNorm2d statistics in one pass: both sums before either exchange (the two exchanges are independent: one latency
         // instead of two in a row), variance = E[u^2] - mean^2 in fp32 (measured -6 % on the launch, profiles/r04_experiments.md)
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            s += (uc[rt][0] + uc[rt][1]) + (uc[rt][2] + uc[rt][3]);
+            if constexpr (!CEN) s += (uc[rt][0] + uc[rt][1]) + (uc[rt][2] + uc[rt][3]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) ss += uc[rt][r] * uc[rt][r];
         }
-        s = wave_rows_sum(s); ss = wave_rows_sum(ss);
+        if constexpr (!CEN) s = wave_rows_sum(s);
+        ss = wave_rows_sum(ss);
         float mean = s * (1.f / 64.f);
         __builtin_amdgcn_sched_barrier(0);
-        UF_S1(1, mean);
+        if constexpr (CEN) UF_S1(1, ss, 3); else UF_S1(1, mean, 3);      // in flight: kfb (1), kfa (2), g (0), b (0)  -> + kfb (3)
+        if constexpr (!CEN) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+            for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) uc[rt][r] -= mean;
+                for (int r = 0; r < 4; ++r) uc[rt][r] -= mean;
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LN2P) {
             // msam_tune_set("up_ln_two_pass", 1): the centred two-pass variance of rounds 1 - 3 (and of the reference's LayerNorm2d) - a second
@@ -298,14 +384,25 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
                 for (int r = 0; r < 4; ++r) s2 += uc[rt][r] * uc[rt][r];
             ss = wave_rows_sum(s2);
         }
-        UF_S1(2, ss);
-        float rstd = LN2P ? rsqrtf(ss * (1.f / 64.f) + a.eps) : rsqrtf(fmaxf(ss * (1.f / 64.f) - mean * mean, 0.f) + a.eps);
+        UF_S1(2, ss, 3);                                 // in flight: kfa (2), g (0), b (0), kfb (3)  -> + kfa (4)
+        float rstd = (LN2P || CEN) ? rsqrtf(ss * (1.f / 64.f) + a.eps) : rsqrtf(fmaxf(ss * (1.f / 64.f) - mean * mean, 0.f) + a.eps);
         __builtin_amdgcn_sched_barrier(0);
         uint32_t g1w[4][2];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            if (rt == 0) UF_S1(3, rstd); else UF_S1(3 + rt, g1w[rt - 1][1]);
+#if UF_LDS_AHEAD
+            // in flight, oldest first: [rt = 0] g (0), b (0), kfb (3), kfa (4); [rt > 0] kf (3 + rt), g (rt), b (rt), kf (4 + rt): this step's three with <= 1 left
+            // (tied to the previous chunk's last value, or the wait drifts above that chunk's arithmetic)
+            f32x4_t& kfr = (rt & 1) ? kfa : kfb;          // k-step 3 + rt
+            if (rt == 0) UF_ARRIVED4(1, gq[0], bq[0], kfr, rstd); else UF_ARRIVED4(1, gq[rt & 1], bq[rt & 1], kfr, g1w[rt - 1][1]);
+            const float4 g4 = make_float4(gq[rt & 1][0], gq[rt & 1][1], gq[rt & 1][2], gq[rt & 1][3]);
+            const float4 b4 = make_float4(bq[rt & 1][0], bq[rt & 1][1], bq[rt & 1][2], bq[rt & 1][3]);
+            if (rt < 3) { UF_R16(gq[(rt + 1) & 1], prma, ((rt + 1) & 3) * 64); UF_R16(bq[(rt + 1) & 1], prma, 256 + ((rt + 1) & 3) * 64); }
+            UF_MF(3 + rt);                                // + kf (5 + rt) while there is one
+#else
+            if (rt == 0) UF_S1(3, rstd, 0); else UF_S1(3 + rt, g1w[rt - 1][1], 0);
             const float4 g4 = *(const float4*)&prm[256 + rt * 16 + fg * 4], b4 = *(const float4*)&prm[320 + rt * 16 + fg * 4];
+#endif
             if (G16) {
                 gelu_pk_h2<G16>(uc[rt][0] * rstd * g4.x + b4.x, uc[rt][1] * rstd * g4.y + b4.y, uc[rt][2] * rstd * g4.z + b4.z,
                                 uc[rt][3] * rstd * g4.w + b4.w, g1w[rt][0], g1w[rt][1]);
@@ -316,8 +413,9 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        UF_S1(7, g1w[3][1]);
+        UF_S1(7, g1w[3][1], 0);                          // in flight: kfb (7)
 #undef UF_S1
+#undef UF_MF
         uint4 g1[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) g1[kk] = make_uint4(g1w[2 * kk][0], g1w[2 * kk][1], g1w[2 * kk + 1][0], g1w[2 * kk + 1][1]);
@@ -325,6 +423,10 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         float* pt = patch[q & 1];
         f32x4_t ya[4], yb[4], ov[4];
         uint4 gh[4];
+#if UF_LDS_AHEAD
+        const f32x4_t b2a = *(const f32x4_t*)&prm[384 + fg * 4], b2b = *(const f32x4_t*)&prm[400 + fg * 4];
+        const uint4 hh = hyp[w][0][lane], hl = hyp[w][1][lane];
+#endif
         auto stage2 = [&](int s2) {                                  // c2 = 4 fg + r (ya) and 16 + 4 fg + r (yb)
             f32x4_t xa = b2a, xb = b2b;
 #pragma unroll
@@ -372,6 +474,9 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         }
         UF_STORE(p0, p1, q & 1);                         // tile q + 2 into the buffer tile q was read from (free since the last barrier)
         __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete
+#if UF_LDS_AHEAD
+        UF_NEXT_TILE(lds + (q & 1) * XT_BYTES, uc);      // the next iteration's stage-1 bias (its accumulators' initial value) and first two B fragments (tile q + 2, staged above)
+#endif
         if (tid < 64 * a.nmask) {
             const int mk = tid >> 6, rem = tid & 63, yl = rem >> 4, x4 = rem & 15;
             const int ty = key0 >> 6, tx0 = key0 & 63;
@@ -436,7 +541,7 @@ extern "C" int msam_upscale_fused_out(const void* keys, int32_t keys_blocked, in
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     int ks = 1;
     while (P * ks < 2 * cus && ks < 16) ks *= 2;
-    a.KS = ks; a.nitems = P * ks; a.out = low_res; a.out16 = low_res_dtype == MSAM_F16; a.blocked = keys_blocked ? 1 : 0;
+    a.KS = ks; a.nitems = P * ks; a.out = low_res; a.out16 = low_res_dtype == MSAM_F16; a.blocked = keys_blocked & 1; a.centred = (keys_blocked >> 1) & 1;
     const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;
     const double rows = (double)P * T;
     const double flops = rows * (2.0 * 256 * 256 + 4 * 2.0 * 128 * 64 + 16 * 3 * 2.0 * 16 * 32);
@@ -447,11 +552,13 @@ extern "C" int msam_upscale_fused_out(const void* keys, int32_t keys_blocked, in
     else if (g_tune_up_gelu16 == 3) hipLaunchKernelGGL((up_fused_kernel<1, 3>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     else if (g_tune_up_gelu16) {
         if (g_tune_up_ln_two_pass) hipLaunchKernelGGL((up_fused_kernel<1, 1, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+        else if (g_uf_prio && a.centred && g_tune_up_centred) hipLaunchKernelGGL((up_fused_kernel<1, 1, 0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
         else if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((up_fused_kernel<0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     } else
 #endif
     if (g_tune_up_ln_two_pass) hipLaunchKernelGGL((up_fused_kernel<1, 0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
+    else if (g_uf_prio && a.centred && g_tune_up_centred) hipLaunchKernelGGL((up_fused_kernel<1, 0, 0, 1>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     else if (g_uf_prio) hipLaunchKernelGGL((up_fused_kernel<1, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((up_fused_kernel<0, 0>), dim3(grid), dim3(NTHR), 0, (hipStream_t)stream, a);
     msam_profile_mark2(stream, 0, flops, bytes, 4);

@@ -591,8 +591,18 @@ class Sam(nn.Module):
         p.nf_w, p.nf_b = k(_f32(md.transformer.norm_final_attn.weight)), k(_f32(md.transformer.norm_final_attn.bias))
         up = md.output_upscaling
         # ConvTranspose2d weight [ci, co, ky, kx] -> GEMM weight rows n = (ky*2+kx)*co_n + co, cols ci
-        p.up1_w = k(_d16(up[0].weight.permute(2, 3, 1, 0).reshape(4 * 64, PROMPT_DIM)))
-        p.up1_b = k(_f32(up[0].bias.repeat(4)))
+        # (round 6) handed over CENTRED over the 64 output channels: LayerNorm2d follows the layer directly, so (W - mean_co W) x + (b - mean b) IS the
+        # centred activation - the up-scaling kernel then has no mean to compute (csrc/upfused.hip CEN).  Centring happens on the fp32 weights, before
+        # their rounding to the decoder's 16-bit type.  MSAM_UP_CENTRED=0: plain weights (the kernel computes the mean itself; the round 1 - 5 form).
+        w1 = up[0].weight.detach().float().permute(2, 3, 1, 0).reshape(4, 64, PROMPT_DIM)          # [sub-pixel, co, ci]
+        b1 = up[0].bias.detach().float()
+        centred = os.environ.get("MSAM_UP_CENTRED", "1") != "0"
+        if centred:
+            w1 = w1 - w1.mean(dim=1, keepdim=True)
+            b1 = b1 - b1.mean()
+        p.up1_w = k(_d16(w1.reshape(4 * 64, PROMPT_DIM)))
+        p.up1_b = k(_f32(b1.repeat(4)))
+        p.up1_centred = 1 if centred else 0
         p.up_ln_w, p.up_ln_b = k(_f32(up[1].weight)), k(_f32(up[1].bias))
         p.up2_w = k(_d16(up[3].weight.permute(2, 3, 1, 0).reshape(4 * 32, 64)))
         p.up2_b = k(_f32(up[3].bias))

@@ -589,7 +589,7 @@ static inline u32x4_t_gw gw_rsrc(const void* base, long bytes) { return u32x4_t_
 
 """
 FILE_PATCHES = {
-    "upfused.hip": [("typedef _Float16 h16x2_t", "template <int UF_PRIO, int G16, int LN2P = 0>", _PKH)],
+    "upfused.hip": [("typedef _Float16 h16x2_t", "// CEN (round 6): the caller hands over CENTRED first-layer weights", _PKH)],
     "attention.hip": [("typedef short gs16x4_t", "template <int HD, bool F16 = false>\n__global__ __launch_bounds__(256, HD == 64 ? 3 : 2)",
                        "static inline uint2 g_tr16(const unsigned char* p) { return ds_read_tr16_b64_emu(p); }\n\n")],
     "decfold.hip": [("typedef short s16x4_t", "// Q'[p][h*8 + t][c]", "static inline uint2 lds_tr16(const unsigned char* p) { return ds_read_tr16_b64_emu(p); }\n\n")],

@@ -53,6 +53,8 @@ extern "C" void emu_up_fused(int g16, const u16* keys, int blocked, int P, const
     a.keys = keys; a.w1 = w1; a.b1 = b1; a.lnw = lnw; a.lnb = lnb; a.eps = eps; a.w2 = w2; a.b2 = b2; a.hyper = hyper; a.hyper_ld = hyper_ld;
     a.mask0 = mask0; a.nmask = nmask; a.KS = 2; a.nitems = P * 2; a.out = out; a.blocked = blocked;
     if (g16 == 3) launch_grid(3, 1, [=] { up_fused_kernel<1, 0, 1>(a); });     // fp32 GELUs, centred two-pass LayerNorm2d variance
+    else if (g16 == 4) launch_grid(3, 1, [=] { up_fused_kernel<1, 1, 0, 1>(a); });     // CEN: centred weights, no mean (round 6)
+    else if (g16 == 5) launch_grid(3, 1, [=] { up_fused_kernel<1, 0, 0, 1>(a); });     // CEN with fp32 GELUs
     else if (g16) launch_grid(3, 1, [=] { up_fused_kernel<1, 1>(a); });     // 3 workgroups over 2 P items: uneven shares
     else launch_grid(3, 1, [=] { up_fused_kernel<1, 0>(a); });
 }
@@ -67,7 +69,7 @@ def emu(tmp_path_factory):
     text = open(os.path.join(ROOT, "micro_sam_amd", "csrc", "upfused.hip")).read()
     s0 = text.index("constexpr int SUB_BYTES = TK * 64 + 64")
     s1 = text.index("// erf-GELU of two values in PACKED fp16 arithmetic")
-    k0 = text.index("template <int UF_PRIO, int G16, int LN2P = 0>")
+    k0 = text.index("template <int UF_PRIO, int G16, int LN2P = 0, int CEN = 0>")
     k1 = text.index("}  // namespace", k0)
     body = DEC + gelu + text[s0:s1] + text[k0:k1]
     assert "up_fused_kernel" in body and "_Float16" not in body
@@ -89,7 +91,15 @@ def _bits(t):
     return _h(t).contiguous().view(torch.int16).numpy().view(np.uint16).copy()
 
 
-@pytest.mark.parametrize("g16,blocked", [(1, 0), (0, 0), (1, 1)])
+def _centre(w1, b1_tiled):
+    """What modeling.py hands the decoder since round 6: every sub-pixel's 64 rows of w1 minus their mean row (on the fp32 values, rounded to fp16 afterwards),
+    the bias minus its mean."""
+    w = w1.float().view(4, 64, 256)
+    b = b1_tiled.view(4, 64)
+    return _h(w - w.mean(1, keepdim=True)).reshape(256, 256).contiguous(), (b - b.mean(1, keepdim=True)).reshape(256).contiguous()
+
+
+@pytest.mark.parametrize("g16,blocked", [(1, 0), (0, 0), (1, 1), (4, 1), (5, 0)])
 def test_up_fused_kernel_source_on_the_cpu(emu, g16, blocked):
     g = torch.Generator().manual_seed(5 + g16 + 2 * blocked)
     P, mask0, nmask = 1, 1, 3                         # two half-prompt items over three workgroups: one of them has nothing to do
@@ -104,7 +114,10 @@ def test_up_fused_kernel_source_on_the_cpu(emu, g16, blocked):
     if blocked:            # [16-token tile][k-step of 32 channels][lane = 16 (lane >> 4) + token][8]: decfold_tok.hip's stream layout
         stream = keys.reshape(P, 256, 16, 8, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
     out = np.full((P, nmask, 256, 256), np.nan, np.float32)
-    arrs = [_bits(stream), _bits(w1), cb1.repeat(4).numpy().astype(np.float32).copy(), lw.numpy().astype(np.float32).copy(),
+    b1t = cb1.repeat(4)
+    if g16 >= 4:           # the CEN instantiations read centred weights; the reference below is the function of the plain ones
+        w1, b1t = _centre(w1, b1t)
+    arrs = [_bits(stream), _bits(w1), b1t.numpy().astype(np.float32).copy(), lw.numpy().astype(np.float32).copy(),
             lb.numpy().astype(np.float32).copy(), _bits(w2), cb2.numpy().astype(np.float32).copy(), hyper.numpy().astype(np.float32).copy()]
     emu.emu_up_fused(g16, _ptr(arrs[0]), blocked, P, _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]), 1e-6, _ptr(arrs[5]),
                      _ptr(arrs[6]), _ptr(arrs[7]), 128, mask0, nmask, _ptr(out))
@@ -137,10 +150,13 @@ def test_layernorm_variance_one_pass_vs_two_pass_with_a_large_mean(emu):
     w2 = ct2.permute(2, 3, 1, 0).reshape(128, 64).contiguous()
     arrs = [_bits(keys), _bits(w1), cb1.repeat(4).numpy().astype(np.float32).copy(), lw.numpy().astype(np.float32).copy(),
             lb.numpy().astype(np.float32).copy(), _bits(w2), cb2.numpy().astype(np.float32).copy(), hyper.numpy().astype(np.float32).copy()]
+    w1c, b1c = _centre(w1, cb1.repeat(4))
+    arrs_c = [_bits(w1c), b1c.numpy().astype(np.float32).copy()]
     outs = {}
-    for mode in (0, 3):
+    for mode in (0, 3, 5):
         out = np.full((P, nmask, 256, 256), np.nan, np.float32)
-        emu.emu_up_fused(mode, _ptr(arrs[0]), 0, P, _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]), _ptr(arrs[4]), 1e-6, _ptr(arrs[5]),
+        a1, a2 = (arrs_c[0], arrs_c[1]) if mode == 5 else (arrs[1], arrs[2])
+        emu.emu_up_fused(mode, _ptr(arrs[0]), 0, P, _ptr(a1), _ptr(a2), _ptr(arrs[3]), _ptr(arrs[4]), 1e-6, _ptr(arrs[5]),
                          _ptr(arrs[6]), _ptr(arrs[7]), 128, mask0, nmask, _ptr(out))
         outs[mode] = out
     src = keys.double().transpose(1, 2).reshape(P, 256, 64, 64)
@@ -155,3 +171,7 @@ def test_layernorm_variance_one_pass_vs_two_pass_with_a_large_mean(emu):
     print(f"large-mean LayerNorm2d: one-pass max error {e1:.2e} of the scale, two-pass {e2:.2e}")
     assert np.isfinite(outs[0]).all() and np.isfinite(outs[3]).all()
     assert e2 <= 2e-2 and e2 <= e1          # the two-pass form stays at the fp16-operand level; the one-pass form is no better here
+    # round 6: centred weights (the CEN instantiation) never see the mean at all - at least as good as the two-pass form
+    e3 = np.abs(outs[5] - ref).max() / scale
+    print(f"                        centred weights (CEN) {e3:.2e}")
+    assert np.isfinite(outs[5]).all() and e3 <= 2e-2 and e3 <= 1.5 * e2 + 1e-3

@@ -86,6 +86,11 @@ _QUAD_S2 = ("                gh[s2] = make_uint4(gelu_pk_h<G16>(ya[s2][0], ya[s2
 V["R_exp_pair"] = dict(kind="exact", doc="round 3's exponential pair (plain + SDWA source select + v_pack_b32_f16), pair by pair",
                        patches=[_R_EXP_PAIR_PATCH, (_QUAD_S1_NEW, _QUAD_S1), (_QUAD_S2_NEW, _QUAD_S2)])
 V["R_exp_by_pair"] = dict(kind="exact", doc="round 4's shipped form: one GELU pair per call (two s_nop per pair)", patches=[(_QUAD_S1_NEW, _QUAD_S1), (_QUAD_S2_NEW, _QUAD_S2)])
+# round 6: the shipped form reads phase A's LDS operands ahead of their use (csrc/upfused.hip UF_LDS_AHEAD: inline-assembly reads with their own wait counts); the round-5 form is the A/B
+V["R_lds_behind"] = dict(kind="exact", doc="round 5's form: every phase-A LDS operand read right in front of its use (compiler-placed loads and waits)", patches=[("#define UF_LDS_AHEAD 1\n", "#define UF_LDS_AHEAD 0\n")])
+V["R_centred"] = dict(kind="close", host_checked=False, centred=True, doc="the CEN instantiation on centred first-layer weights (the shipped decoder path since round 6; `base` here = plain weights through the general kernel)", patches=[])
+V["R_centred_general"] = dict(kind="close", host_checked=False, centred=True, doc="centred weights through the general kernel (computes their mean of ~0): what CEN itself is worth",
+                              patches=[("int g_tune_up_centred = 1;", "int g_tune_up_centred = 0;")])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conversion",
                       patches=[(_CVT, _CVT + "    if (EXPM >= 0) return __builtin_bit_cast(uint32_t, x);\n")])
@@ -180,6 +185,10 @@ def main():
     keys = keys.repeat((P + 63) // 64, 1, 1)[:P].contiguous()                    # [P, 4096, 256] fp16, read as the blocked stream
     w1 = (torch.randn(256, 256, generator=g) / 16).to(torch.float16).to(dev)
     b1 = torch.randn(256, generator=g).to(dev)
+    # centred variants: every sub-pixel's 64 rows minus their mean row (centring on the fp32 values of the fp16 weights the other variants read - the fp64
+    # reference below is evaluated on the uncentred ones: LayerNorm2d makes them the same function)
+    w1c = (w1.float().view(4, 64, 256) - w1.float().view(4, 64, 256).mean(1, keepdim=True)).reshape(256, 256).to(torch.float16).contiguous()
+    b1c = (b1.view(4, 64) - b1.view(4, 64).mean(1, keepdim=True)).reshape(256).contiguous()
     lnw = (torch.randn(64, generator=g) * 0.2 + 1).to(dev); lnb = (torch.randn(64, generator=g) * 0.3).to(dev)
     w2_true = torch.randn(128, 64, generator=g) / 8                               # fp32: the checkpoint's weights
     w2_hi = w2_true.to(torch.float16)
@@ -215,8 +224,11 @@ def main():
         fn.argtypes = [vp, i32, i32, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, i32, i32, i32, vp, vp]
         out = torch.full((P, 3, 256, 256), float("nan"), device=dev)
 
+        cen = bool(V[n].get("centred"))
+        w1_, b1_ = (w1c, b1c) if cen else (w1, b1)
+
         def launch():
-            rc = fn(keys.data_ptr(), 1, P, w1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), 1e-6, w2.data_ptr(), b2.data_ptr(),
+            rc = fn(keys.data_ptr(), 3 if cen else 1, P, w1_.data_ptr(), b1_.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), 1e-6, w2.data_ptr(), b2.data_ptr(),
                     hyper.data_ptr(), 128, 1, 3, out.data_ptr(), stream)
             assert rc == 0, (n, rc)
         for _ in range(3):
@@ -232,7 +244,7 @@ def main():
         rec = dict(kind=V[n]["kind"], doc=V[n]["doc"], ms_per_launch=round(ms, 4), **res)
         if V[n]["kind"] != "timing":
             o2 = torch.empty((PR, 3, 256, 256), device=dev)
-            rc = fn(keys[:PR].contiguous().data_ptr(), 0, PR, w1.data_ptr(), b1.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), 1e-6, w2.data_ptr(), b2.data_ptr(),
+            rc = fn(keys[:PR].contiguous().data_ptr(), 2 if cen else 0, PR, w1_.data_ptr(), b1_.data_ptr(), lnw.data_ptr(), lnb.data_ptr(), 1e-6, w2.data_ptr(), b2.data_ptr(),
                     hyper[:PR].contiguous().data_ptr(), 128, 1, 3, o2.data_ptr(), stream)
             assert rc == 0
             torch.cuda.synchronize()
