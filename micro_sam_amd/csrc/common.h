@@ -46,6 +46,10 @@ MSAM_DEVINL uint4 buf_load16(rsrc_t r, int voff, int soff) {
 MSAM_DEVINL void buf_store16(const uint4& v, rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
 }
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+MSAM_DEVINL void buf_store8(const uint2& v, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, voff, soff, 0);
+}
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 #define UF_ARRIVED6(n_, x0_, x1_, x2_, x3_, x4_, tok_) (void)0
 #endif
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * XT_BYTES + W2_BYTES];
-    __shared__ __attribute__((aligned(16))) float patch[2][PATCH];
+    __shared__ __attribute__((aligned(16))) float patch[2][PATCH + 4 * 64];      // (+ one mask's worth: the output stage's idle lanes read a fourth mask)
     __shared__ __attribute__((aligned(16))) float prm[256 + 64 + 64 + 32];       // b1, ln_w, ln_b, b2
 #if UF_LDS_AHEAD
     __shared__ __attribute__((aligned(16))) uint4 hyp[4][2][64];                 // per wave: hyper weights of the current prompt as MFMA A fragments (hi, lo)
@@ -217,12 +217,33 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         key0 = __builtin_amdgcn_readfirstlane((item & (a.KS - 1)) * (T >> ks_sh) + (q & (TPI - 1)) * TK);
     };
     const int voff = tid * 16;
-#define UF_LOAD(r0_, r1_, q_)                                                                      \
+    // round 6: the load cursor (the tile being fetched, three ahead of the tile being computed, clamped to the last one) and the compute cursor advance
+    // INCREMENTALLY - a tile is 8 KiB further in the prompt's stream, 16 tokens further in the output - and are recomputed from the tile number only
+    // at a work item's first tile: ~20 scalar instructions less per tile (every instruction of a wave costs it an issue slot, scalar ones included)
+    int lq = 0, lsoff;                                   // load cursor: tile number, byte offset of the tile in its prompt's stream
+    const u16* lbase;                                    //              the prompt's stream
+    {
+        int p_, k0_;
+        tile_pos(0, p_, k0_);
+        lbase = a.keys + (long)p_ * T * C; lsoff = k0_ * C * 2;
+    }
+    auto load_advance = [&]() {
+        if (lq < nq - 1) {
+            ++lq;
+            if ((lq & (TPI - 1)) == 0) {
+                int p_, k0_;
+                tile_pos(lq, p_, k0_);
+                lbase = a.keys + (long)p_ * T * C; lsoff = k0_ * C * 2;
+            } else {
+                lsoff += TK * C * 2;
+            }
+        }
+    };
+#define UF_LOAD(r0_, r1_)                                                                          \
     do {                                                                                           \
-        int p_, k0_;                                                                               \
-        tile_pos(q_, p_, k0_);                                                                     \
-        const rsrc_t rx_ = make_rsrc(a.keys + (long)p_ * T * C, T * C * 2);                        \
-        r0_ = buf_load16(rx_, voff, k0_ * C * 2); r1_ = buf_load16(rx_, voff, k0_ * C * 2 + NTHR * 16); \
+        const rsrc_t rx_ = make_rsrc(lbase, T * C * 2);                                            \
+        r0_ = buf_load16(rx_, voff, lsoff); r1_ = buf_load16(rx_, voff, lsoff + NTHR * 16);        \
+        load_advance();                                                                            \
     } while (0)
 #define UF_STORE(r0_, r1_, buf_)                                                                   \
     do {                                                                                           \
@@ -258,12 +279,12 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 
     // tiles 0 and 1 staged, tile 2 in flight, stage 1 of tile 0 done
     f32x4_t ua[4], ub[4];
-    UF_LOAD(ra0, ra1, 0);
-    UF_LOAD(rb0, rb1, min(1, nq - 1));
+    UF_LOAD(ra0, ra1);                                      // tile 0
+    UF_LOAD(rb0, rb1);                                      // tile min(1, nq - 1)
     __syncthreads();                                         // prm / W2 image written
     UF_STORE(ra0, ra1, 0);
     UF_STORE(rb0, rb1, 1);
-    UF_LOAD(ra0, ra1, min(2, nq - 1));
+    UF_LOAD(ra0, ra1);                                      // tile min(2, nq - 1)
     __syncthreads();
     stage1(lds, ua);
     __syncthreads();                                         // every wave is done with buffer 0 before tile 2 goes there
@@ -280,12 +301,37 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 #endif
 
     if ((int)blockIdx.x >= ((int)gridDim.x >> 1)) __builtin_amdgcn_s_sleep(11);        // ~700 cycles: see the note above the kernel
-    int q = 0;
+    const int oesz = a.out16 ? 1 : 2;                                                  // log2 of the output element size
+    const int ptoff = ((lane >> 4) * 4 + w) * 64 + (lane & 15) * 4;                     // output stage: mask lane >> 4, patch row w, pixels 4 (lane & 15) ..
+    const int ovoff = ((((lane >> 4) * 256 + w) * 256) + (lane & 15) * 4) << oesz;
+    // output stage, one tile behind: every wave stores one patch row of all masks (lane >> 4 = mask, 4 pixels per lane: the same work in all four waves)
+    // through buffer addressing - the per-thread part of the address is loop-invariant, and lanes of a mask >= nmask fall outside the descriptor's
+    // range: the hardware drops their store (as it drops every lane's before the first tile: range 0)
+    float4 o4c = make_float4(0.f, 0.f, 0.f, 0.f);
+    const char* obase_c = (const char*)a.out;
+    uint32_t orange_c = 0;
+    int osoff_c = 0;
+    auto store_previous = [&]() {
+        // (loop-carried scalars: the compiler keeps some of them in vector registers and would wrap the store in a readfirstlane loop)
+        const int oso = __builtin_amdgcn_readfirstlane(osoff_c);
+        const unsigned long long ob_ = (unsigned long long)obase_c;
+        const char* obu = (const char*)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ob_ >> 32)) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ob_));
+        const rsrc_t ro = make_rsrc(obu, (uint32_t)__builtin_amdgcn_readfirstlane((int)orange_c));
+        // fp16 low-res logits (the AMG path: msam_postprocess_masks16 reads them back - half the round trip of 0.8 GB per tile;
+        // 2^-11 relative, i.e. <= 5e-4 where the thresholds 0, +-1 are decided, against a logit error of ~3e-2)
+        if (__builtin_amdgcn_readfirstlane(oesz) == 1) buf_store8(make_uint2(pack2h(o4c.x, o4c.y), pack2h(o4c.z, o4c.w)), ro, ovoff, oso);
+        else buf_store16(make_uint4(__float_as_uint(o4c.x), __float_as_uint(o4c.y), __float_as_uint(o4c.z), __float_as_uint(o4c.w)), ro, ovoff, oso);
+    };
+    int q = 0, p = 0, key0 = 0;                                                        // compute cursor: tile number, prompt, first token of the tile
+    const char* obase = (const char*)a.out;
     auto iteration = [&](uint4& p0, uint4& p1, uint4& f0, uint4& f1, f32x4_t (&uc)[4], f32x4_t (&un)[4]) {
-        UF_LOAD(f0, f1, min(q + 3, nq - 1));
-        int p, key0;
-        tile_pos(q, p, key0);
-        if ((q & (TPI - 1)) == 0) {                      // new work item: hyper weights, rows = masks, k-slots = c2
+        UF_LOAD(f0, f1);                                 // tile min(q + 3, nq - 1)
+        if ((q & (TPI - 1)) != 0) {
+            key0 += TK;
+        } else {                                         // new work item: position, output descriptor base, hyper weights (rows = masks, k-slots = c2)
+            tile_pos(q, p, key0);
+            obase = (const char*)a.out + (((long)p * a.nmask) << (16 + oesz));
             float h8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (fr < a.nmask) {
                 const float* hp = a.hyper + ((long)p * 4 + a.mask0 + fr) * a.hyper_ld;
@@ -319,13 +365,15 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         //  selection cannot move the MFMA group above that chunk; the sched_barrier keeps the machine scheduler from undoing the placement)
 #if UF_LDS_AHEAD
         // k-step ks_: its fragment has arrived once at most n_ younger reads are in flight; the MFMA group; the fragment of k-step ks_ + 2 into the same registers
-#define UF_MF(ks_)                                                                                 \
+#define UF_MF_(ks_, between_)                                                                      \
         do {                                                                                       \
             f32x4_t& kf_ = ((ks_) & 1) ? kfb : kfa;                                                \
             const uint4 kw_ = make_uint4(__float_as_uint(kf_[0]), __float_as_uint(kf_[1]), __float_as_uint(kf_[2]), __float_as_uint(kf_[3])); \
             _Pragma("unroll") for (int rt_ = 0; rt_ < 4; ++rt_) un[rt_] = mfma16d(w1f[rt_][ks_], kw_, un[rt_]); \
+            between_;                                                                              \
             if ((ks_) + 2 < 8) UF_R16(kf_, bna, (((ks_) + 2) & 7) * SUB_BYTES);                    \
         } while (0)
+#define UF_MF(ks_) UF_MF_(ks_, (void)0)
 #define UF_S1(ks_, tok_, n_)                                                                       \
         do {                                                                                       \
             if ((ks_) & 1) UF_ARRIVED2(n_, kfb, tok_); else UF_ARRIVED2(n_, kfa, tok_);            \
@@ -346,11 +394,14 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 #if UF_LDS_AHEAD
         // in flight here, oldest first: bias x 4, kfa (k-step 0), kfb (1) [UF_NEXT_TILE behind the last barrier]: the bias and kfa are there with <= 1 left
         { int first_ = 0; UF_ARRIVED6(1, un[0], un[1], un[2], un[3], kfa, first_); }
-        UF_MF(0);                                         // + kfa (2)
+        // (the previous tile's output store sits between this k-step's MFMAs and the next reads: its patch read - the one compiler-issued LDS read of the
+        //  phase, whose wait the compiler can only write as lgkmcnt(0) - is then the only LDS operation in flight, and a whole phase B + barrier old)
+        UF_MF_(0, store_previous());                      // + kfa (2)
         f32x4_t gq[2], bq[2];                             // affine parameters, two register sets by turns
         UF_R16(gq[0], prma, 0); UF_R16(bq[0], prma, 256);
 #else
         { int first_ = 0; UF_S1(0, first_, 0); }
+        store_previous();
 #endif
         // LayerNorm2d statistics in one pass: both sums before either exchange (the two exchanges are independent: one latency
         // instead of two in a row), variance = E[u^2] - mean^2 in fp32 (measured -6 % on the launch, profiles/r04_experiments.md)
@@ -477,16 +528,11 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
 #if UF_LDS_AHEAD
         UF_NEXT_TILE(lds + (q & 1) * XT_BYTES, uc);      // the next iteration's stage-1 bias (its accumulators' initial value) and first two B fragments (tile q + 2, staged above)
 #endif
-        if (tid < 64 * a.nmask) {
-            const int mk = tid >> 6, rem = tid & 63, yl = rem >> 4, x4 = rem & 15;
-            const int ty = key0 >> 6, tx0 = key0 & 63;
-            const float4 o4 = *(const float4*)&pt[(mk * 4 + yl) * 64 + x4 * 4];
-            const long oi = (((long)p * a.nmask + mk) * 256 + ty * 4 + yl) * 256 + tx0 * 4 + x4 * 4;
-            // fp16 low-res logits (the AMG path: msam_postprocess_masks16 reads them back - half the round trip of 0.8 GB per tile;
-            // 2^-11 relative, i.e. <= 5e-4 where the thresholds 0, +-1 are decided, against a logit error of ~3e-2)
-            if (a.out16) *(uint2*)((unsigned short*)a.out + oi) = make_uint2(pack2h(o4.x, o4.y), pack2h(o4.z, o4.w));
-            else *(float4*)((float*)a.out + oi) = o4;
-        }
+        // round 6: the tile's output leaves ONE ITERATION LATER (store_previous, in the next iteration's first k-step): here only its patch read is issued
+        // - stored right away, the read's round trip (behind the six reads above) stood between the barrier and everything else of the next iteration
+        o4c = *(const float4*)&pt[ptoff];
+        obase_c = obase; orange_c = (uint32_t)a.nmask << (16 + oesz);
+        osoff_c = (((key0 >> 6) << 10) + ((key0 & 63) << 2)) << oesz;                    // rows 4 ty .., pixels 4 tx0 ..
     };
     while (true) {
         iteration(ra0, ra1, rb0, rb1, ua, ub);
@@ -494,6 +540,7 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         iteration(rb0, rb1, ra0, ra1, ub, ua);
         if (++q >= nq) break;
     }
+    store_previous();                                        // the last tile's
 #undef UF_LOAD
 #undef UF_STORE
 }

@@ -11,6 +11,7 @@ Hyper-parameters: ``micro_sam/models/build_sam.py:40-142``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import torch

@@ -259,6 +259,10 @@ static inline void buf_store16(const uint4& v, rsrc_t r, int voff, int soff) {
     const long o = (long)voff + soff;
     if (o >= 0 && o + 16 <= (long)r.bytes) std::memcpy(r.base + o, &v, 16);
 }
+static inline void buf_store8(const uint2& v, rsrc_t r, int voff, int soff) {
+    const long o = (long)voff + soff;
+    if (o >= 0 && o + 8 <= (long)r.bytes) std::memcpy(r.base + o, &v, 8);
+}
 // v_mfma_scale_f32_32x32x64_f8f6f4 with fp8 e4m3 operands and unit block scales: lane l holds the 32 bytes k = 32 (l / 32) .. + 31 of
 // row (A) / column (B) l % 32; D as the 32x32x16 form
 static inline float e4m3_to_f(uint8_t b) {

@@ -38,7 +38,7 @@ _EXP_PAIR = "        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__b
 _BARRIER = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
 _CVT = "    const h16x2_t x = __builtin_convertvector(xf, h16x2_t);\n"
 _PATCH_WRITE = "        if (fg == 0) {                                   // rows = masks r, column = token fr\n"
-_STORE = "        if (tid < 64 * a.nmask) {\n"
+_STORE = "        const int oso = __builtin_amdgcn_readfirstlane(osoff_c);\n"
 _GRID = "    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;\n"
 
 V = collections.OrderedDict()
@@ -88,14 +88,18 @@ V["R_exp_pair"] = dict(kind="exact", doc="round 3's exponential pair (plain + SD
 V["R_exp_by_pair"] = dict(kind="exact", doc="round 4's shipped form: one GELU pair per call (two s_nop per pair)", patches=[(_QUAD_S1_NEW, _QUAD_S1), (_QUAD_S2_NEW, _QUAD_S2)])
 # round 6: the shipped form reads phase A's LDS operands ahead of their use (csrc/upfused.hip UF_LDS_AHEAD: inline-assembly reads with their own wait counts); the round-5 form is the A/B
 V["R_lds_behind"] = dict(kind="exact", doc="round 5's form: every phase-A LDS operand read right in front of its use (compiler-placed loads and waits)", patches=[("#define UF_LDS_AHEAD 1\n", "#define UF_LDS_AHEAD 0\n")])
-V["R_centred"] = dict(kind="close", host_checked=False, centred=True, doc="the CEN instantiation on centred first-layer weights (the shipped decoder path since round 6; `base` here = plain weights through the general kernel)", patches=[])
+V["R_plain"] = dict(kind="close", host_checked=False, centred=False, doc="plain (uncentred) first-layer weights through the general kernel: rounds 1 - 5 (every other variant here: centred weights, the CEN instantiation unless it says otherwise)", patches=[])
 V["R_centred_general"] = dict(kind="close", host_checked=False, centred=True, doc="centred weights through the general kernel (computes their mean of ~0): what CEN itself is worth",
                               patches=[("int g_tune_up_centred = 1;", "int g_tune_up_centred = 0;")])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
+_H2 = "    const h16x2_t ra = __builtin_elementwise_max(xa, zero), rb = __builtin_elementwise_max(xb, zero);\n"
 V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conversion",
-                      patches=[(_CVT, _CVT + "    if (EXPM >= 0) return __builtin_bit_cast(uint32_t, x);\n")])
+                      patches=[(_CVT, _CVT + "    if (EXPM >= 0) return __builtin_bit_cast(uint32_t, x);\n"),
+                               (_H2, "    if (EXPM >= 0) { g01 = __builtin_bit_cast(uint32_t, xa); g23 = __builtin_bit_cast(uint32_t, xb); return; }\n" + _H2)])
+V["T_no_exp"] = dict(kind="timing", doc="the GELUs without their exponentials (the library's up_gelu16 = 2 instantiation)", patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 2;")])
+V["R_exp_packed"] = dict(kind="close", host_checked=False, doc="2^q in packed full-rate fp16 arithmetic instead of v_exp_f16 (the library's up_gelu16 = 3 instantiation)", patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 3;")])
 V["T_no_output"] = dict(kind="timing", doc="no output patch and no global store (stage 3 results kept alive by one predicated store)",
-                        patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {\n"), (_STORE, "        if (tid < 64 * a.nmask && key0 < 0) {\n")])
+                        patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {\n"), (_STORE, "        if (osoff_c >= 0) return;\n" + _STORE)])
 V["T_one_wg_per_cu"] = dict(kind="timing", doc="grid = number of CUs: what the second co-resident workgroup buys",
                             patches=[(_GRID, "    const int grid = a.nitems < cus ? a.nitems : cus;\n")])
 
@@ -224,7 +228,7 @@ def main():
         fn.argtypes = [vp, i32, i32, vp, vp, vp, vp, ctypes.c_float, vp, vp, vp, i32, i32, i32, vp, vp]
         out = torch.full((P, 3, 256, 256), float("nan"), device=dev)
 
-        cen = bool(V[n].get("centred"))
+        cen = bool(V[n].get("centred", True))
         w1_, b1_ = (w1c, b1c) if cen else (w1, b1)
 
         def launch():
