@@ -121,6 +121,8 @@ MSAM_DEVINL void gelu_pk_h2(float x0, float x1, float x2, float x3, uint32_t& g0
     const h16x2_t ta = ra * (_Float16)2.f - xa, tb = rb * (_Float16)2.f - xb;
     h16x2_t qa = ta * (_Float16)-0.0248758f + (_Float16)-0.49884797f, qb = tb * (_Float16)-0.0248758f + (_Float16)-0.49884797f;
     qa = qa * ta + (_Float16)-1.12922424f; qb = qb * tb + (_Float16)-1.12922424f;
+    // (round 6, measured and not shipped - profiles/r06_experiments.md: the cubic's last step, the exponentials and the final multiply-adds as ONE inline-assembly
+    //  block are 10 instructions less per tile and 1 - 2 % SLOWER: nothing can be scheduled into the block)
     qa = qa * ta + (_Float16)-1.00353579f; qb = qb * tb + (_Float16)-1.00353579f;
     uint32_t ea_, eb_;
     asm("v_exp_f16_sdwa %0, %2 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0\n\t"
@@ -514,6 +516,7 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         stage3(1);
         act2(3);
         stage3(2); stage3(3);
+        // (round 6, measured: forcing 24 x (1 MFMA, 5 .. 8 vector instructions) on this phase through sched_group_barrier: +1.5 % .. -0.5 %: the compiler's order stays)
         if (fg == 0) {                                   // rows = masks r, column = token fr
 #pragma unroll
             for (int sub2 = 0; sub2 < 4; ++sub2) {

@@ -15,14 +15,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 #define MFMA(acc_) "v_mfma_f32_32x32x16_bf16 %" #acc_ ", %12, %13, %" #acc_ "\n"
-#define F0 "v_fma_f32 %4, %4, %14, %15\n"
-#define F1 "v_fma_f32 %5, %5, %14, %15\n"
-#define F2 "v_fma_f32 %6, %6, %14, %15\n"
-#define F3 "v_fma_f32 %7, %7, %14, %15\n"
-#define F4 "v_fma_f32 %8, %8, %14, %15\n"
-#define F5 "v_fma_f32 %9, %9, %14, %15\n"
-#define F6 "v_fma_f32 %10, %10, %14, %15\n"
-#define F7 "v_fma_f32 %11, %11, %14, %15\n"
+// The filler instruction (round 6, second call: WHICH vector instructions overlap with the matrix pipe): -DFILLER=0 plain v_fma_f32 (default),
+// 1 v_pk_fma_f16, 3 v_exp_f16, 4 v_cvt_pk_f16_f32, 5 v_pk_max_f16, 6 v_fma_f16, 7 v_exp_f32, 8 v_pk_mul_f16
+#ifndef FILLER
+#define FILLER 0
+#endif
+#if FILLER == 0
+#define FI(d_) "v_fma_f32 %" #d_ ", %" #d_ ", %14, %15\n"
+#elif FILLER == 1
+#define FI(d_) "v_pk_fma_f16 %" #d_ ", %" #d_ ", %14, %15\n"
+#elif FILLER == 3
+#define FI(d_) "v_exp_f16 %" #d_ ", %14\n"
+#elif FILLER == 4
+#define FI(d_) "v_cvt_pk_f16_f32 %" #d_ ", %14, %15\n"
+#elif FILLER == 5
+#define FI(d_) "v_pk_max_f16 %" #d_ ", %" #d_ ", %14\n"
+#elif FILLER == 6
+#define FI(d_) "v_fma_f16 %" #d_ ", %" #d_ ", %14, %15\n"
+#elif FILLER == 7
+#define FI(d_) "v_exp_f32 %" #d_ ", %14\n"
+#elif FILLER == 8
+#define FI(d_) "v_pk_mul_f16 %" #d_ ", %" #d_ ", %14\n"
+#endif
+#define F0 FI(4)
+#define F1 FI(5)
+#define F2 FI(6)
+#define F3 FI(7)
+#define F4 FI(8)
+#define F5 FI(9)
+#define F6 FI(10)
+#define F7 FI(11)
 #define FILL_0 ""
 #define FILL_1 F0
 #define FILL_2 F0 F1
