@@ -45,6 +45,9 @@ V = collections.OrderedDict()
 V["base"] = dict(kind="base", doc="the shipped source, unchanged", patches=[])
 V["R_no_dephase"] = dict(kind="exact", doc="no start offset for the second half of the grid", patches=[(_DEPHASE, "")])
 V["R_dephase_22"] = dict(kind="exact", doc="start offset ~1400 cycles instead of ~700", patches=[(_DEPHASE, _DEPHASE.replace("s_sleep(11)", "s_sleep(22)"))])
+V["R_dephase_33"] = dict(kind="exact", doc="start offset ~2100 cycles instead of ~700", patches=[(_DEPHASE, _DEPHASE.replace("s_sleep(11)", "s_sleep(33)"))])
+V["R_dephase_42"] = dict(kind="exact", doc="start offset ~2700 cycles instead of ~700", patches=[(_DEPHASE, _DEPHASE.replace("s_sleep(11)", "s_sleep(42)"))])
+V["R_dephase_64"] = dict(kind="exact", doc="start offset ~4100 cycles instead of ~700", patches=[(_DEPHASE, _DEPHASE.replace("s_sleep(11)", "s_sleep(64)"))])
 _R_EXP_PAIR_PATCH = (_EXP_SDWA_START, _EXP_SDWA_END, _EXP_PAIR)            # (used together with R_exp_by_pair below: the shipped kernel calls gelu_pk_h2)
 # parity candidate (profiles/r04_experiments.md section 3: the ConvT2 weights W2 are the largest remaining rounding site of the decoder on generic weights,
 # mean logit error 0.015 of 0.032): W2 as fp16 hi + lo pairs - a second LDS image (+16 KiB) and a second MFMA per (row tile, k-step) in stage 2 (+16 MFMAs per
