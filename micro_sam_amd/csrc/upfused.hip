@@ -517,6 +517,8 @@ __global__ __launch_bounds__(NTHR, 2) void up_fused_kernel(UpArgs a) {
         act2(3);
         stage3(2); stage3(3);
         // (round 6, measured: forcing 24 x (1 MFMA, 5 .. 8 vector instructions) on this phase through sched_group_barrier: +1.5 % .. -0.5 %: the compiler's order stays)
+        // (round 6, measured - profiles/r06_uf_lab_call8.txt: a further diet of 21 instructions per tile - sum of squares in packed fp32, a mask-innermost patch written
+        //  without register moves, the stage-2 bias held in registers, a loop without mid-exits - is 1.4 % SLOWER than this form: instruction count is not the whole story)
         // (round 6, measured: the outputs straight from these accumulators - six 4 / 8-byte stores of pixel pairs per wave, no patch - is 3 % SLOWER than the patch,
         //  profiles/r06_uf_lab_call6.txt; without ANY output store the launch is 9 % shorter: the stores themselves, not the path to them)
         if (fg == 0) {                                   // rows = masks r, column = token fr

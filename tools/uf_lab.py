@@ -37,7 +37,7 @@ _EXP_SDWA_START, _EXP_SDWA_END = "        // v_exp_f16 has no packed form.", "  
 _EXP_PAIR = "        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};\n"
 _BARRIER = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
 _CVT = "    const h16x2_t x = __builtin_convertvector(xf, h16x2_t);\n"
-_PATCH_WRITE = "        if (fg == 0) {                                   // rows = masks r, column = token fr\n"
+_PATCH_WRITE = "        if (fg == 0) {                                   // rows = masks r, column = token fr: the patch is [4 rows][64 pixels][4 masks] - a pixel's masks are the\n"
 _STORE = "        const int oso = __builtin_amdgcn_readfirstlane(osoff_c);\n"
 _GRID = "    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;\n"
 
@@ -102,7 +102,7 @@ V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conve
 V["T_no_exp"] = dict(kind="timing", doc="the GELUs without their exponentials (the library's up_gelu16 = 2 instantiation)", patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 2;")])
 V["R_exp_packed"] = dict(kind="close", host_checked=False, doc="2^q in packed full-rate fp16 arithmetic instead of v_exp_f16 (the library's up_gelu16 = 3 instantiation)", patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 3;")])
 V["T_no_output"] = dict(kind="timing", doc="no output patch and no global store (stage 3 results kept alive by one predicated store)",
-                        patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {\n"), (_STORE, "        if (osoff_c >= 0) return;\n" + _STORE)])
+                        patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {                       //\n"), (_STORE, "        if (osoff_c >= 0) return;\n" + _STORE)])
 V["T_one_wg_per_cu"] = dict(kind="timing", doc="grid = number of CUs: what the second co-resident workgroup buys",
                             patches=[(_GRID, "    const int grid = a.nitems < cus ? a.nitems : cus;\n")])
 
@@ -117,6 +117,8 @@ void msam_profile_mark2(void*, int, double, double, int) {}
 def variant_source(name: str) -> str:
     """The shipped source with the variant's patches applied: (old, new) - the text must occur exactly once - or (start, end, new) -
     everything from the start marker up to (not including) the end marker is replaced."""
+    if name.startswith("G_"):                     # a committed revision of the kernel (python tools/uf_lab.py --snapshot REV writes tools/lab_build/G_<REV>.src here, where git is)
+        return open(os.path.join(ROOT, "tools", "lab_build", name + ".src")).read()
     src = open(SRC).read()
     for patch in V[name]["patches"]:
         if len(patch) == 3:
@@ -170,9 +172,17 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--prompts", type=int, default=1024)
     ap.add_argument("--launches", type=int, default=20)
+    ap.add_argument("--snapshot", default="", help="git revision of csrc/upfused.hip to add as variant G_<rev> (kind exact-or-close: compared, not required to match)")
     ap.add_argument("--build-only", action="store_true", help="compile every variant (works without a GPU) and print its register use")
     ap.add_argument("--out", default=os.path.join(ROOT, "tools", "lab_build"), help="objects are cached here by source hash (git-ignored, travels with gpurun)")
     a = ap.parse_args()
+    if a.snapshot:
+        os.makedirs(a.out, exist_ok=True)
+        with open(os.path.join(a.out, "G_" + a.snapshot + ".src"), "w") as fh:
+            fh.write(subprocess.run(["git", "-C", ROOT, "show", a.snapshot + ":micro_sam_amd/csrc/upfused.hip"], capture_output=True, text=True, check=True).stdout)
+    for f in sorted(os.listdir(a.out)) if os.path.isdir(a.out) else []:
+        if f.startswith("G_") and f.endswith(".src"):
+            V[f[:-4]] = dict(kind="close", host_checked=False, doc="csrc/upfused.hip as committed at " + f[2:-4], patches=[])
     names = [n for n in V if not a.only or n in a.only.split(",")]
     if a.list:
         for n in names:
