@@ -37,7 +37,7 @@ _EXP_SDWA_START, _EXP_SDWA_END = "        // v_exp_f16 has no packed form.", "  
 _EXP_PAIR = "        e = h16x2_t{(_Float16)__builtin_exp2f16(q.x), (_Float16)__builtin_exp2f16(q.y)};\n"
 _BARRIER = "        __syncthreads();                                 // tile q + 2 staged; output patch of this tile complete\n"
 _CVT = "    const h16x2_t x = __builtin_convertvector(xf, h16x2_t);\n"
-_PATCH_WRITE = "        if (fg == 0) {                                   // rows = masks r, column = token fr: the patch is [4 rows][64 pixels][4 masks] - a pixel's masks are the\n"
+_PATCH_WRITE = "        if (fg == 0) {                                   // rows = masks r, column = token fr\n"
 _STORE = "        const int oso = __builtin_amdgcn_readfirstlane(osoff_c);\n"
 _GRID = "    const int grid = a.nitems < 2 * cus ? a.nitems : 2 * cus;\n"
 
@@ -102,7 +102,7 @@ V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conve
 V["T_no_exp"] = dict(kind="timing", doc="the GELUs without their exponentials (the library's up_gelu16 = 2 instantiation)", patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 2;")])
 V["R_exp_packed"] = dict(kind="close", host_checked=False, doc="2^q in packed full-rate fp16 arithmetic instead of v_exp_f16 (the library's up_gelu16 = 3 instantiation)", patches=[("int g_tune_up_gelu16 = 1;", "int g_tune_up_gelu16 = 3;")])
 V["T_no_output"] = dict(kind="timing", doc="no output patch and no global store (stage 3 results kept alive by one predicated store)",
-                        patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {                       //\n"), (_STORE, "        if (osoff_c >= 0) return;\n" + _STORE)])
+                        patches=[(_PATCH_WRITE, "        if (fg == 0 && key0 < 0) {\n"), (_STORE, "        if (osoff_c >= 0) return;\n" + _STORE)])
 V["T_one_wg_per_cu"] = dict(kind="timing", doc="grid = number of CUs: what the second co-resident workgroup buys",
                             patches=[(_GRID, "    const int grid = a.nitems < cus ? a.nitems : cus;\n")])
 
