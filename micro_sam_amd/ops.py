@@ -774,18 +774,30 @@ def i2t01_fused(tables, operands0, ln0_w, ln0_b, operands1, ln1_w, ln1_b, P: int
     return out
 
 
-def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: int, *, ln_eps: float = 1e-6, blocked: bool = False):
+def upscale_fused(keys, w1, b1, ln_w, ln_b, w2, b2, hyper, mask0: int, nmask: int, *, ln_eps: float = 1e-6, blocked: bool = False,
+                  centred: bool = False):
     """Fused output up-scaling + hyper-network product (include/msam_hip.h msam_upscale_fused).
-    keys [P,4096,256] (decoder 16-bit type), hyper fp32 [P,4,ld] -> fp32 [P,nmask,256,256]."""
+    keys [P,4096,256] (decoder 16-bit type), hyper fp32 [P,4,ld] -> fp32 [P,nmask,256,256].
+    centred=True: the caller states that w1 / b1 are centred over the 64 output channels of every sub-pixel (upscale_centre_weights):
+    LayerNorm2d's mean is zero by construction and the kernel does not compute it (bit 1 of the C entry point's `keys_blocked`)."""
     _lib.require_gpu()
     _dec16(keys, w1, w2)
     P = keys.shape[0]
     out = torch.empty((P, nmask, 256, 256), dtype=torch.float32, device=keys.device)
-    _lib.check(_lib.load().msam_upscale_fused_layout(keys.data_ptr(), int(blocked), P, w1.data_ptr(), b1.data_ptr(), ln_w.data_ptr(),
+    _lib.check(_lib.load().msam_upscale_fused_layout(keys.data_ptr(), int(blocked) | (2 if centred else 0), P, w1.data_ptr(), b1.data_ptr(), ln_w.data_ptr(),
                                                      ln_b.data_ptr(), ln_eps, w2.data_ptr(), b2.data_ptr(), hyper.data_ptr(),
                                                      hyper.shape[-1], mask0, nmask, out.data_ptr(), _lib.stream_ptr()),
                "msam_upscale_fused_layout")
     return out
+
+
+def upscale_centre_weights(w1_f32: torch.Tensor, b1_f32: torch.Tensor):
+    """What modeling.Sam hands the decoder (msam_decoder_t.up1_centred = 1): the first up-scaling layer's GEMM weight [4 * 64 (sub-pixel, channel), 256] minus,
+    per sub-pixel, the mean of its 64 rows - on the fp32 values, cast to the decoder's 16-bit type afterwards - and the tiled bias [256] minus its mean."""
+    w = w1_f32.float().view(4, 64, -1)
+    b = b1_f32.float().view(4, 64)
+    return ((w - w.mean(1, keepdim=True)).reshape(256, -1).to(_lib.decoder_dtype()).contiguous(),
+            (b - b.mean(1, keepdim=True)).reshape(256).contiguous())
 
 
 def uncrop_bits(bits: torch.Tensor, crop_box, height: int, width: int) -> torch.Tensor:

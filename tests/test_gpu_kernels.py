@@ -541,6 +541,19 @@ def _chained_layer0_case(env, P, Nt):
 
 
 @pytest.mark.parametrize("gelu16", [1, 0])
+@pytest.mark.parametrize("P,mask0,nmask", [(2, 1, 3), (300, 1, 3)])
+def test_upscale_fused_centred_weights(env, P, mask0, nmask, gelu16):
+    """Round 6: the CEN instantiation of up_fused_kernel (centred first-layer weights, no LayerNorm2d mean: what the decoder runs) against the same
+    torch formulation on the PLAIN weights - LayerNorm2d makes the two the same function - and next to the general kernel on the centred weights."""
+    from micro_sam_amd import _lib
+    _lib.load().msam_tune_set(b"up_gelu16", gelu16)
+    try:
+        _upscale_fused_case(env, P, mask0, nmask, centred=True)
+    finally:
+        _lib.load().msam_tune_set(b"up_gelu16", 1)
+
+
+@pytest.mark.parametrize("gelu16", [1, 0])
 @pytest.mark.parametrize("P,mask0,nmask", [(2, 1, 3), (3, 0, 1), (300, 1, 3)])
 def test_upscale_fused(env, P, mask0, nmask, gelu16):
     """Fused ConvT + LayerNorm2d + GELU + ConvT + GELU + hyper product vs torch (conv_transpose2d on the same bf16 operands), with
@@ -553,7 +566,7 @@ def test_upscale_fused(env, P, mask0, nmask, gelu16):
         _lib.load().msam_tune_set(b"up_gelu16", 1)
 
 
-def _upscale_fused_case(env, P, mask0, nmask):
+def _upscale_fused_case(env, P, mask0, nmask, centred=False):
     ops, dev = env
     g = torch.Generator().manual_seed(5 + P)
     keys = _d(torch.randn(P, 4096, 256, generator=g)).to(dev)
@@ -563,7 +576,14 @@ def _upscale_fused_case(env, P, mask0, nmask):
     hyper = torch.randn(P, 4, 128, generator=g).to(dev)
     w1 = ct1.permute(2, 3, 1, 0).reshape(256, 256).contiguous().to(_ddt())
     w2 = ct2.permute(2, 3, 1, 0).reshape(128, 64).contiguous().to(_ddt())
-    out = ops.upscale_fused(keys, w1, cb1.repeat(4).contiguous(), lw, lb, w2, cb2, hyper, mask0, nmask)
+    if centred:
+        ct1f = ct1.float().permute(2, 3, 1, 0).reshape(256, 256)
+        w1c, b1c = ops.upscale_centre_weights(ct1f, cb1.repeat(4))
+        out = ops.upscale_fused(keys, w1c, b1c, lw, lb, w2, cb2, hyper, mask0, nmask, centred=True)
+        general = ops.upscale_fused(keys, w1c, b1c, lw, lb, w2, cb2, hyper, mask0, nmask)          # the general kernel computes the (zero) mean itself
+        assert (out - general).abs().max().item() <= 6e-3 * general.abs().max().item()
+    else:
+        out = ops.upscale_fused(keys, w1, cb1.repeat(4).contiguous(), lw, lb, w2, cb2, hyper, mask0, nmask)
     sel = list(range(min(P, 2))) + ([P - 1] if P > 2 else [])
     src = keys[sel].float().transpose(1, 2).reshape(len(sel), 256, 64, 64)
     up = F.conv_transpose2d(src, ct1.float(), cb1, stride=2)
