@@ -219,7 +219,10 @@ int msam_i2t01_fused(const void* tables, const void* operands0, const float* ln0
 int msam_upscale_fused(const void* keys, int32_t P, const void* w1, const float* b1, const float* ln_w, const float* ln_b,
                        float ln_eps, const void* w2, const float* b2, const float* hyper, int32_t hyper_ld, int32_t mask0,
                        int32_t nmask, float* low_res, void* stream);
-/* the same with the stream layout stated: keys_blocked != 0 = the blocked layout msam_i2t01_fused writes */
+/* the same with the stream layout stated.  keys_blocked is a bit field: bit 0 = `keys` is in the blocked layout msam_i2t01_fused writes
+ * (0: row-major [P,4096,256]); bit 1 (round 6) = w1 / b1 are CENTRED over the 64 output channels of every sub-pixel (rows sub*64 .. sub*64+63
+ * of w1 minus their mean row, b1 minus its mean: msam_decoder_t.up1_centred) - LayerNorm2d's mean is then zero by construction and is not
+ * computed.  Plain weights with bit 1 clear run the general kernel. */
 int msam_upscale_fused_layout(const void* keys, int32_t keys_blocked, int32_t P, const void* w1, const float* b1,
                               const float* ln_w, const float* ln_b, float ln_eps, const void* w2, const float* b2,
                               const float* hyper, int32_t hyper_ld, int32_t mask0, int32_t nmask, float* low_res, void* stream);
