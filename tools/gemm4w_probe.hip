@@ -82,15 +82,20 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const u16* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int rn = wn * 128 + i * 32 + l31, rm = wm * 128 + i * 32 + l31;
-                wf[set][i] = lw[rn * 8 + ((s4 * 2 + lh) ^ swz(rn))];
-                af[set][i] = la[rm * 8 + ((s4 * 2 + lh) ^ swz(rm))];
+                if (NOLOAD == 2) {                               // timing control: 1 KiB-contiguous (certainly conflict-free) fragment reads, wrong values
+                    wf[set][i] = lw[(wn * 4 + i) * 256 + s4 * 64 + lane];
+                    af[set][i] = la[(wm * 4 + i) * 256 + s4 * 64 + lane];
+                } else {
+                    wf[set][i] = lw[rn * 8 + ((s4 * 2 + lh) ^ swz(rn))];
+                    af[set][i] = la[rm * 8 + ((s4 * 2 + lh) ^ swz(rm))];
+                }
             }
         };
         frags(0, 0);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             if (s4 < 3) frags(s4 + 1, (s4 + 1) & 1);
-            else if (!NOLOAD && kt + 1 < nk) commit((kt & 1) ^ 1);    // tile kt + 1 (in flight since the end of the previous iteration) -> the buffer every wave left at the last barrier
+            else if (NOLOAD == 0 && kt + 1 < nk) commit((kt & 1) ^ 1);    // tile kt + 1 (in flight since the end of the previous iteration) -> the buffer every wave left at the last barrier
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -104,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const u16* __restrict__ 
                 for (int g = 0; g < 16; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); }
             }
         }
-        if (!NOLOAD) load(kt + 2 < nk ? kt + 2 : nk - 1);
+        if (NOLOAD == 0) load(kt + 2 < nk ? kt + 2 : nk - 1);
         __syncthreads();
     }
     if (STORE) {
@@ -174,6 +179,13 @@ int main() {
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms2; (void)hipEventElapsedTime(&ms2, e0, e1); ms2 /= reps;
         printf("   static LDS image (no operand stream): %.3f ms = %.3f of 2500\n", ms2, 2.0 * M * N * K / (ms2 * 1e-3) / 1e12 / 2500.0);
+        (void)hipFuncSetAttribute((const void*)gemm4w_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((gemm4w_kernel<0, 2>), dim3(grid), dim3(256), LDS_BYTES, 0, dA, (long)K, dW, (long)K, M, N, K, dC);
+        (void)hipEventRecord(e0);
+        for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((gemm4w_kernel<0, 2>), dim3(grid), dim3(256), LDS_BYTES, 0, dA, (long)K, dW, (long)K, M, N, K, dC);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&ms2, e0, e1); ms2 /= reps;
+        printf("   static LDS image, 1 KiB-contiguous fragment reads (wrong values): %.3f ms = %.3f of 2500\n", ms2, 2.0 * M * N * K / (ms2 * 1e-3) / 1e12 / 2500.0);
         printf("M %d N %d K %d: k-loop only %.3f ms = %.0f TFLOP/s = %.3f of 2500; max |err| of 200 entries %.3g\n", M, N, K, ms, tf, tf / 2500.0, maxerr);
         (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC);
     }
