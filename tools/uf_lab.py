@@ -94,6 +94,11 @@ V["R_lds_behind"] = dict(kind="exact", doc="round 5's form: every phase-A LDS op
 V["R_plain"] = dict(kind="close", host_checked=False, centred=False, doc="plain (uncentred) first-layer weights through the general kernel: rounds 1 - 5 (every other variant here: centred weights, the CEN instantiation unless it says otherwise)", patches=[])
 V["R_centred_general"] = dict(kind="close", host_checked=False, centred=True, doc="centred weights through the general kernel (computes their mean of ~0): what CEN itself is worth",
                               patches=[("int g_tune_up_centred = 1;", "int g_tune_up_centred = 0;")])
+_W2A = "                const uint4 wa = *(const uint4*)(W2L + (s2 * 2) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));\n"
+_W2B = "                const uint4 wb = *(const uint4*)(W2L + (s2 * 2 + 1) * 2048 + w2off + (((kk * 4 + fg) ^ w2sw) << 4));\n"
+V["T_w2_one_fragment"] = dict(kind="timing", doc="every stage-2 MFMA on ONE W2 fragment pair made distinct by a register xor (2 LDS reads per tile instead of 16, + 16 vector instructions): how much of the tile time is LDS read volume",
+                              patches=[(_W2A, "                uint4 wa = *(const uint4*)(W2L + w2off + ((fg ^ w2sw) << 4)); wa.x ^= (uint32_t)(s2 * 4 + kk * 2 + 1);\n"),
+                                       (_W2B, "                uint4 wb = *(const uint4*)(W2L + 2048 + w2off + ((fg ^ w2sw) << 4)); wb.x ^= (uint32_t)(s2 * 4 + kk * 2 + 2);\n")])
 V["T_no_barrier"] = dict(kind="timing", doc="the per-tile workgroup barrier removed (racy)", patches=[(_BARRIER, "        (void)0;\n")])
 _H2 = "    const h16x2_t ra = __builtin_elementwise_max(xa, zero), rb = __builtin_elementwise_max(xb, zero);\n"
 V["T_no_gelu"] = dict(kind="timing", doc="both GELUs reduced to their fp16 conversion",
